@@ -1,0 +1,124 @@
+/* include/trust4_hip.h -- C ABI of libt4hip.so, the MI355X (gfx950) engine for TRUST4's stage-1
+ * k-mer seed -> hit chaining -> banded-DP scoring hot path.
+ *
+ * The reference has no plugin / FFI interface: its algorithms are member functions of the
+ * header-only classes SeqSet / KmerIndex / AlignAlgo that main.cpp includes (main.cpp:11-13).
+ * This header therefore defines the boundary a host driver binds instead of calling those
+ * members; each entry point names the reference interface it replaces. All arguments are plain
+ * pointers and sizes, no C++ or torch types. Calls on one t4_ctx are not re-entrant (as
+ * SeqSet's Add path, SeqSet.hpp:206); use one ctx per GPU / host thread.
+ * Every function returns 0 (T4_OK) or a negative error code; t4_last_error() gives the text.
+ * Nothing here ever calls exit() or throws (the reference exit(1)s, e.g. main.cpp:887-891).
+ */
+#ifndef TRUST4_HIP_H
+#define TRUST4_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T4_OK 0
+#define T4_ERR_ARG (-1)         /* bad argument */
+#define T4_ERR_HIP (-2)         /* HIP runtime error (no device, OOM, launch failure) */
+#define T4_ERR_IO (-3)          /* cannot read a file */
+#define T4_ERR_UNSUPPORTED (-4) /* input outside the engine's limits */
+#define T4_ERR_STATE (-5)       /* call order violated (e.g. index not committed) */
+
+typedef struct t4_ctx t4_ctx;     /* one GPU + one HIP stream + scratch */
+typedef struct t4_index t4_index; /* device image of one SeqSet: sequences + k-mer index */
+typedef struct t4_batch t4_batch; /* 2-bit packed reads resident in HBM */
+
+/* struct _overlap (SeqSet.hpp:76-136) without its heap members. 40 bytes. */
+typedef struct {
+  int32_t seqIdx, readStart, readEnd, seqStart, seqEnd, strand, matchCnt, indelCnt;
+  double similarity;
+} t4_overlap;
+
+/* struct _hit (SeqSet.hpp:53-74). 20 bytes. */
+typedef struct {
+  int32_t idx, offset, readOffset, strand, repeats;
+} t4_hit;
+
+/* ---- context --------------------------------------------------------------------------------- */
+/* device_ordinal: HIP device index. Fails with T4_ERR_HIP when no GPU is present: there is no CPU
+ * fallback in this library. */
+int t4_init(int device_ordinal, t4_ctx **out);
+void t4_destroy(t4_ctx *ctx);
+int t4_sync(t4_ctx *ctx);
+const char *t4_last_error(t4_ctx *ctx);
+/* number of compute units of the device (for sizing persistent grids / reporting) */
+int t4_device_cus(t4_ctx *ctx);
+
+/* ---- sequence set + k-mer index  (replaces SeqSet::SeqSet, InputRefFa, InputNovelRead and
+ *      KmerIndex::BuildIndexFromRead; SeqSet.hpp:2557-2576, 2673-2865, 3028-3073;
+ *      KmerIndex.hpp:118-141) ----------------------------------------------------------------- */
+int t4_index_create(t4_ctx *ctx, int kmer_length, int consider_barcode, t4_index **out);
+void t4_index_destroy(t4_index *ix);
+/* SeqSet::SetHitLenRequired / SetRadius / SetNovelSeqSimilarity (SeqSet.hpp:2600-2614) */
+int t4_index_set_params(t4_index *ix, int hit_len_required, int radius, double novel_seq_similarity);
+/* SeqSet::InputRefFa(path) for a gene FASTA (plain or .gz): '/OR' filter, '.' removal, non-ACGT
+ * -> N, de-duplication with name merging, then index every sequence. */
+int t4_index_load_ref_fasta(t4_index *ix, const char *path);
+/* The same, one record at a time (id = FASTA name token, seq = raw sequence line(s)). Returns the
+ * sequence id through *seq_id (-1 when the record was filtered or merged). */
+int t4_index_add_ref_record(t4_index *ix, const char *id, const char *seq, int *seq_id);
+/* SeqSet::InputNovelRead semantics for a contig: consensus (forward strand), barcode (-1: none),
+ * posweight = 4 int32 counts per base (NULL: count 1 on the consensus base). */
+int t4_index_add_contig(t4_index *ix, const char *name, const char *consensus, int barcode,
+                        const int32_t *posweight, int *seq_id);
+/* Build the device image (CSR postings + lookup table + sequence table). Must be called after the
+ * last add and before any query. */
+int t4_index_commit(t4_index *ix);
+int t4_index_size(const t4_index *ix);
+int t4_index_seq_len(const t4_index *ix, int seq_id);
+const char *t4_index_seq_name(const t4_index *ix, int seq_id);
+const char *t4_index_seq_consensus(const t4_index *ix, int seq_id);
+
+/* ---- reads (replaces the strdup'ed char* reads of main.cpp:845-878) -------------------------- */
+/* bases: concatenated read sequences (alphabet ACGTN, upper case); offsets[n+1]: start of each read
+ * in `bases`; barcode: per-read transformed barcode or NULL (= -1 for all). The reads are 2-bit
+ * packed (+1 bit/base N mask) on the host and copied to HBM. */
+int t4_reads_upload(t4_ctx *ctx, const char *bases, const int64_t *offsets, const int32_t *barcode,
+                    int64_t n_reads, t4_batch **out);
+void t4_batch_destroy(t4_batch *b);
+int64_t t4_batch_size(const t4_batch *b);
+
+/* ---- queries --------------------------------------------------------------------------------- */
+/* SeqSet::GetHitsFromRead + SortHits (SeqSet.hpp:1341-1501, 1306-1339) for every read: hits are
+ * returned ordered by (strand, idx, readOffset, offset). Parity/debug entry point.
+ * hit_offsets[n+1] receives the CSR offsets. If hits == NULL only hit_offsets is filled (size
+ * query). hits_cap = capacity of `hits` in records. */
+int t4_hits(t4_index *ix, t4_batch *b, int strand, int allow_total_skip, int64_t *hit_offsets,
+            t4_hit *hits, int64_t hits_cap);
+
+/* SeqSet::GetOverlapsFromRead(read, strand, barcode, readType 0, skipRepeats) (SeqSet.hpp:1508-2124)
+ * for every read. counts[i] receives the function's return value for read i (-1: shorter than k);
+ * out receives at most max_per_read overlaps per read at out[i*max_per_read ...], in the order
+ * of the reference's result vector. */
+int t4_overlaps(t4_index *ix, t4_batch *b, int strand, int skip_repeats, int max_per_read,
+                int32_t *counts, t4_overlap *out);
+
+/* SeqSet::AnnotateRead(read, 0, geneOverlap, NULL, NULL) (SeqSet.hpp:6016-6321) against a reference
+ * gene set: out[4*i + g] is geneOverlap[g] of read i (g: 0 V, 1 D (always -1), 2 J, 3 C). Fields of
+ * entries with seqIdx == -1 are unspecified (the reference leaves stale data there). This is the
+ * rough-annotation pass of main.cpp:1084-1120. */
+int t4_annotate_rough(t4_index *ref, t4_batch *b, t4_overlap *out);
+
+/* ---- measurement ----------------------------------------------------------------------------- */
+/* Per-call statistics of the last query on this ctx: kernel time measured with HIP events on the
+ * ctx's stream, number of _hit records the seed stage emitted (H of SURVEY.md 8d), number of reads
+ * that went through each capacity tier. */
+typedef struct {
+  double kernel_ms;       /* all kernels of the call, event-timed on the ctx stream */
+  double chain_kernel_ms; /* the dominant probe->sort->chain->score kernels only */
+  int64_t total_hits;     /* sum over reads and passes of emitted _hit records */
+  int64_t reads;          /* reads processed */
+  int64_t tier_reads[4];  /* reads per capacity tier (LDS small / mid / large / global scratch) */
+  int64_t launches;       /* kernel launches in the call */
+} t4_stats;
+int t4_last_stats(t4_ctx *ctx, t4_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,143 @@
+// tests/hipemu/hip/hip_runtime.h -- TEST INFRASTRUCTURE ONLY.
+//
+// A tiny single-threaded emulator of the subset of HIP that trust4_amd/csrc uses, so that the very
+// same kernel sources can be compiled with g++ and executed (slowly) on the CPU inside the
+// `-m "not gpu"` test-suite: every lane of a workgroup is a ucontext fiber, wave intrinsics and
+// __syncthreads() are rendezvous points. It exists because the development container has no GPU;
+// it is NOT a fallback: the product library (trust4_amd/libt4hip.so) is built by hipcc from the
+// same sources and never links this header. Built only by tests/hipemu/build_emu.py.
+#pragma once
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+
+#include <chrono>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __restrict__
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint2 { unsigned x, y; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+static inline int2 make_int2(int x, int y) { int2 r = {x, y}; return r; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { uint2 r = {x, y}; return r; }
+static inline int4 make_int4(int x, int y, int z, int w) { int4 r = {x, y, z, w}; return r; }
+
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorUnknown = 999 };
+typedef struct hipemu_stream *hipStream_t;
+typedef struct hipemu_event { std::chrono::steady_clock::time_point t; } *hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+struct hipDeviceProp_t { int multiProcessorCount; char name[64]; char gcnArchName[64]; size_t totalGlobalMem; };
+
+namespace hipemu {
+struct Tid { unsigned x, y, z; };
+extern Tid cur_tid, cur_bid;
+extern dim3 cur_bdim, cur_gdim;
+extern uint64_t xchg[1024];
+extern int nthreads, nalive;
+void yield_lane();
+void run_grid(dim3 grid, dim3 block, const std::function<void()> &body);
+}  // namespace hipemu
+
+#define threadIdx (hipemu::cur_tid)
+#define blockIdx (hipemu::cur_bid)
+#define blockDim (hipemu::cur_bdim)
+#define gridDim (hipemu::cur_gdim)
+#define warpSize 64
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+  hipemu::run_grid(dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); })
+
+static inline void __syncthreads() { hipemu::yield_lane(); }
+
+// ---- wave intrinsics (wave == the 64 consecutive threads the caller belongs to)
+static inline int hipemu_lane() { return hipemu::cur_tid.x & 63; }
+static inline int hipemu_wbase() { return hipemu::cur_tid.x & ~63u; }
+template <class T> static inline T hipemu_shfl_any(T v, int src) {
+  static_assert(sizeof(T) <= 8, "shfl size");
+  uint64_t raw = 0; memcpy(&raw, &v, sizeof(T));
+  hipemu::xchg[hipemu::cur_tid.x] = raw;
+  hipemu::yield_lane();
+  uint64_t got = hipemu::xchg[hipemu_wbase() + (src & 63)];
+  hipemu::yield_lane();
+  T r; memcpy(&r, &got, sizeof(T));
+  return r;
+}
+template <class T> static inline T __shfl(T v, int src, int width = 64) { (void)width; return hipemu_shfl_any(v, src); }
+template <class T> static inline T __shfl_up(T v, unsigned d, int width = 64) {
+  (void)width; int l = hipemu_lane(); return hipemu_shfl_any(v, l >= (int)d ? l - (int)d : l);
+}
+template <class T> static inline T __shfl_down(T v, unsigned d, int width = 64) {
+  (void)width; int l = hipemu_lane(); return hipemu_shfl_any(v, l + (int)d < 64 ? l + (int)d : l);
+}
+template <class T> static inline T __shfl_xor(T v, int m, int width = 64) { (void)width; return hipemu_shfl_any(v, hipemu_lane() ^ m); }
+static inline unsigned long long __ballot(int pred) {
+  hipemu::xchg[hipemu::cur_tid.x] = pred ? 1 : 0;
+  hipemu::yield_lane();
+  unsigned long long m = 0; int b = hipemu_wbase();
+  for (int i = 0; i < 64 && b + i < hipemu::nthreads; ++i) if (hipemu::xchg[b + i]) m |= 1ull << i;
+  hipemu::yield_lane();
+  return m;
+}
+static inline int __any(int p) { return __ballot(p) != 0; }
+static inline int __all(int p) { return __ballot(!p) == 0; }
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __popc(unsigned x) { return __builtin_popcount(x); }
+static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+static inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz((unsigned)x); }
+static inline int __clzll(long long x) { return x == 0 ? 64 : __builtin_clzll((unsigned long long)x); }
+
+template <class T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> static inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <class T> static inline T atomicMin(T *p, T v) { T o = *p; if (v < o) *p = v; return o; }
+template <class T> static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
+template <class T> static inline T atomicExch(T *p, T v) { T o = *p; *p = v; return o; }
+static inline void __threadfence() {}
+static inline void __threadfence_block() {}
+
+// ---- host API
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
+  memset(p, 0, sizeof(*p)); p->multiProcessorCount = 2; strcpy(p->name, "hipemu"); strcpy(p->gcnArchName, "emu");
+  p->totalGlobalMem = 1ull << 34; return hipSuccess;
+}
+template <class T> static inline hipError_t hipMalloc(T **p, size_t n) { *p = (T *)calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorUnknown; }
+static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+template <class T> static inline hipError_t hipHostMalloc(T **p, size_t n, unsigned = 0) { *p = (T *)calloc(1, n ? n : 1); return hipSuccess; }
+static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = 0) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = 0) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = 0; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = 0; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+static inline const char *hipGetErrorString(hipError_t) { return "hipemu"; }
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new hipemu_event; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = 0) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
+  *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess;
+}
+#define hipStreamNonBlocking 1
+#define hipHostMallocDefault 0

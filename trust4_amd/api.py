@@ -1,0 +1,226 @@
+"""ctypes mirror of include/trust4_hip.h (same names, argument meaning and error behaviour)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+OV_DTYPE = np.dtype([("seqIdx", "<i4"), ("readStart", "<i4"), ("readEnd", "<i4"), ("seqStart", "<i4"),
+                     ("seqEnd", "<i4"), ("strand", "<i4"), ("matchCnt", "<i4"), ("indelCnt", "<i4"),
+                     ("similarity", "<f8")])
+HIT_DTYPE = np.dtype([("idx", "<i4"), ("offset", "<i4"), ("readOffset", "<i4"), ("strand", "<i4"),
+                      ("repeats", "<i4")])
+
+
+class Stats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("chain_kernel_ms", C.c_double), ("total_hits", C.c_int64),
+                ("reads", C.c_int64), ("tier_reads", C.c_int64 * 4), ("launches", C.c_int64)]
+
+
+class T4Error(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("t4 error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib_path():
+    """The product library. T4_LIB overrides it (the CPU test-suite points it at the emulator build)."""
+    return os.environ.get("T4_LIB", os.path.join(HERE, "libt4hip.so"))
+
+
+def _load():
+    path = lib_path()
+    if not os.path.exists(path):
+        raise T4Error(-2, "%s not found: build it with `python -m trust4_amd.build` (there is no CPU fallback)" % path)
+    lib = C.CDLL(path)
+    P, I, L = C.c_void_p, C.c_int, C.c_int64
+    sig = {
+        "t4_init": (I, [I, C.POINTER(P)]), "t4_destroy": (None, [P]), "t4_sync": (I, [P]),
+        "t4_last_error": (C.c_char_p, [P]), "t4_device_cus": (I, [P]), "t4_last_stats": (I, [P, C.POINTER(Stats)]),
+        "t4_index_create": (I, [P, I, I, C.POINTER(P)]), "t4_index_destroy": (None, [P]),
+        "t4_index_set_params": (I, [P, I, I, C.c_double]), "t4_index_load_ref_fasta": (I, [P, C.c_char_p]),
+        "t4_index_add_ref_record": (I, [P, C.c_char_p, C.c_char_p, C.POINTER(I)]),
+        "t4_index_add_contig": (I, [P, C.c_char_p, C.c_char_p, I, P, C.POINTER(I)]),
+        "t4_index_commit": (I, [P]), "t4_index_size": (I, [P]), "t4_index_seq_len": (I, [P, I]),
+        "t4_index_seq_name": (C.c_char_p, [P, I]), "t4_index_seq_consensus": (C.c_char_p, [P, I]),
+        "t4_reads_upload": (I, [P, P, P, P, L, C.POINTER(P)]), "t4_batch_destroy": (None, [P]),
+        "t4_batch_size": (L, [P]),
+        "t4_hits": (I, [P, P, I, I, P, P, L]), "t4_overlaps": (I, [P, P, I, I, I, P, P]),
+        "t4_annotate_rough": (I, [P, P, P]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+class Engine:
+    """t4_ctx: one GPU, one stream."""
+
+    def __init__(self, device=0):
+        self.lib = _load()
+        h = C.c_void_p()
+        rc = self.lib.t4_init(device, C.byref(h))
+        if rc != 0:
+            raise T4Error(rc, "t4_init failed (no MI355X visible?)")
+        self.h = h
+
+    def check(self, rc):
+        if rc != 0:
+            raise T4Error(rc, self.lib.t4_last_error(self.h).decode())
+
+    def cus(self):
+        return self.lib.t4_device_cus(self.h)
+
+    def stats(self):
+        s = Stats()
+        self.check(self.lib.t4_last_stats(self.h, C.byref(s)))
+        return {"kernel_ms": s.kernel_ms, "chain_kernel_ms": s.chain_kernel_ms, "total_hits": s.total_hits,
+                "reads": s.reads, "tier_reads": list(s.tier_reads), "launches": s.launches}
+
+    def index(self, k, consider_barcode=False):
+        return Index(self, k, consider_barcode)
+
+    def upload(self, reads, barcodes=None):
+        return Batch(self, reads, barcodes)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.t4_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Index:
+    """t4_index: the device image of one SeqSet."""
+
+    def __init__(self, eng, k, consider_barcode=False):
+        self.eng = eng
+        h = C.c_void_p()
+        eng.check(eng.lib.t4_index_create(eng.h, k, 1 if consider_barcode else 0, C.byref(h)))
+        self.h = h
+
+    def set_params(self, hit_len_required=31, radius=10, novel_seq_similarity=0.9):
+        self.eng.check(self.eng.lib.t4_index_set_params(self.h, hit_len_required, radius, novel_seq_similarity))
+        return self
+
+    def load_ref_fasta(self, path):
+        self.eng.check(self.eng.lib.t4_index_load_ref_fasta(self.h, path.encode()))
+        return self
+
+    def add_ref_record(self, name, seq):
+        sid = C.c_int(-1)
+        self.eng.check(self.eng.lib.t4_index_add_ref_record(self.h, name.encode(), seq.encode(), C.byref(sid)))
+        return sid.value
+
+    def add_contig(self, name, consensus, barcode=-1, posweight=None):
+        sid = C.c_int(-1)
+        pw = None
+        if posweight is not None:
+            posweight = np.ascontiguousarray(posweight, dtype=np.int32)
+            pw = posweight.ctypes.data_as(C.c_void_p)
+        self.eng.check(self.eng.lib.t4_index_add_contig(self.h, name.encode(), consensus.encode(), barcode, pw, C.byref(sid)))
+        return sid.value
+
+    def commit(self):
+        self.eng.check(self.eng.lib.t4_index_commit(self.h))
+        return self
+
+    def size(self):
+        return self.eng.lib.t4_index_size(self.h)
+
+    def name(self, i):
+        return self.eng.lib.t4_index_seq_name(self.h, i).decode()
+
+    def consensus(self, i):
+        return self.eng.lib.t4_index_seq_consensus(self.h, i).decode()
+
+    def hits(self, batch, strand=0, allow_total_skip=0):
+        n = batch.n
+        off = np.zeros(n + 1, dtype=np.int64)
+        self.eng.check(self.eng.lib.t4_hits(self.h, batch.h, strand, allow_total_skip, off.ctypes.data_as(C.c_void_p), None, 0))
+        hits = np.zeros(int(off[-1]), dtype=HIT_DTYPE)
+        self.eng.check(self.eng.lib.t4_hits(self.h, batch.h, strand, allow_total_skip, off.ctypes.data_as(C.c_void_p),
+                                            hits.ctypes.data_as(C.c_void_p), len(hits)))
+        return off, hits
+
+    def overlaps(self, batch, strand=0, skip_repeats=0, max_per_read=64, fetch=True):
+        n = batch.n
+        counts = np.zeros(n, dtype=np.int32)
+        out = np.zeros((n, max_per_read), dtype=OV_DTYPE) if fetch else None
+        self.eng.check(self.eng.lib.t4_overlaps(self.h, batch.h, strand, skip_repeats, max_per_read,
+                                                counts.ctypes.data_as(C.c_void_p),
+                                                out.ctypes.data_as(C.c_void_p) if fetch else None))
+        return counts, out
+
+    def annotate_rough(self, batch, fetch=True):
+        out = np.zeros((batch.n, 4), dtype=OV_DTYPE) if fetch else None
+        self.eng.check(self.eng.lib.t4_annotate_rough(self.h, batch.h, out.ctypes.data_as(C.c_void_p) if fetch else None))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.eng.lib.t4_index_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """t4_batch: 2-bit packed reads in HBM. `reads`: list of str/bytes, or a uint8 [n, stride] array of
+    NUL-terminated fixed-stride records (as produced by the synthetic generator)."""
+
+    def __init__(self, eng, reads, barcodes=None):
+        self.eng = eng
+        if isinstance(reads, np.ndarray):
+            arr = np.ascontiguousarray(reads, dtype=np.uint8)
+            n, stride = arr.shape
+            lens = np.where((arr == 0).any(axis=1), (arr == 0).argmax(axis=1), stride).astype(np.int64)
+            offs = np.arange(n + 1, dtype=np.int64) * stride
+            if (lens == lens[0]).all() if n else True:
+                # offsets[i+1]-offsets[i] must equal the length: repack only when lengths are ragged
+                L = int(lens[0]) if n else 0
+                buf = np.ascontiguousarray(arr[:, :L]).reshape(-1)
+                offs = np.arange(n + 1, dtype=np.int64) * L
+            else:
+                buf = np.concatenate([arr[i, :lens[i]] for i in range(n)]) if n else np.zeros(0, np.uint8)
+                offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        else:
+            bs = [r if isinstance(r, bytes) else r.encode() for r in reads]
+            n = len(bs)
+            buf = np.frombuffer(b"".join(bs), dtype=np.uint8) if n else np.zeros(0, np.uint8)
+            offs = np.zeros(n + 1, dtype=np.int64)
+            if n:
+                offs[1:] = np.cumsum([len(b) for b in bs])
+        if len(buf) == 0:
+            buf = np.zeros(1, np.uint8)
+        self.n = n
+        bc = None
+        if barcodes is not None:
+            barcodes = np.ascontiguousarray(barcodes, dtype=np.int32)
+            bc = barcodes.ctypes.data_as(C.c_void_p)
+        h = C.c_void_p()
+        eng.check(eng.lib.t4_reads_upload(eng.h, buf.ctypes.data_as(C.c_void_p), offs.ctypes.data_as(C.c_void_p), bc, n, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.eng.lib.t4_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

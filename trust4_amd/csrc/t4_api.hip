@@ -1,0 +1,657 @@
+// trust4_amd/csrc/t4_api.hip -- C ABI of libt4hip.so (include/trust4_hip.h): host side of the engine.
+// Sequence-set construction follows SeqSet::InputRefFa / InputNovelRead and
+// KmerIndex::BuildIndexFromRead (SeqSet.hpp:2673-2865, 3028-3073; KmerIndex.hpp:118-141); the k-mer
+// index is flattened into CSR postings + a direct-addressed (k <= 12) or open-addressing table that
+// stays resident in HBM/L2. Queries run as: bin reads by hit count -> one persistent-grid launch per
+// capacity tier (reads that outgrow a tier are re-queued on the next one).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/trust4_hip.h"
+#include "t4_kernels.h"
+
+static_assert(sizeof(t4_overlap) == sizeof(T4OverlapOut), "overlap layout");
+static_assert(sizeof(t4_hit) == sizeof(T4HitOut), "hit layout");
+static_assert(sizeof(t4k::OvRec) == 40, "OvRec layout");
+
+namespace {
+
+const int TIER_CAP[3] = {1024, 4096, 8192};
+const int TIER_MAXOV[3] = {128, 256, 512};
+const int TIER_BLOCKS_PER_CU[4] = {6, 2, 1, 2};
+const int G_CAP = 32768, G_MAXOV = 4096;
+
+struct HostSeq {
+  std::string name, cons;
+  std::vector<int32_t> pw;  // 4 per base, novel only
+  int barcode;
+  bool isRef;
+};
+
+}  // namespace
+
+struct t4_ctx {
+  int device = 0, cus = 0;
+  hipStream_t stream = 0;
+  hipEvent_t ev[4] = {0, 0, 0, 0};
+  std::string err;
+  t4_stats stats;
+  // scratch
+  int maxGrid = 0;
+  int *dpRows = nullptr;
+  unsigned char *dpDir = nullptr;
+  unsigned long long *gKeys = nullptr;
+  unsigned *gPairs = nullptr, *gCand = nullptr;
+  int *gOv = nullptr, *gFin = nullptr;
+  unsigned short *gOrd = nullptr;
+  int gGrid = 0;
+  unsigned long long *hitsKeys = nullptr;
+  int hitsGrid = 0;
+  // per-call buffers (grown on demand)
+  int *lists = nullptr, *listCounts = nullptr, *status = nullptr, *counts = nullptr;
+  long long listCap = 0;
+  unsigned long long *hitCounter = nullptr;
+  T4OverlapOut *result = nullptr;
+  size_t resultCap = 0, resultBytes = 0;
+};
+
+struct t4_index {
+  t4_ctx *ctx;
+  int k, considerBarcode;
+  int hitLenRequired = 31, radius = 10;
+  double novelSim = 0.9, refSim = 0.75, repeatSim = 0.95;
+  int nomatchGapLimit;
+  std::vector<HostSeq> seqs;
+  std::unordered_map<std::string, int> dedup;
+  bool committed = false;
+  // device image
+  uint2 *dTable = nullptr;
+  T4HashEnt *dHtab = nullptr;
+  int2 *dPost = nullptr;
+  T4SeqInfo *dSeqs = nullptr;
+  char *dCons = nullptr;
+  int4 *dPw = nullptr;
+  T4IndexView view;
+};
+
+struct t4_batch {
+  t4_ctx *ctx;
+  long long n = 0;
+  int wpk = 0, wnm = 0, maxLen = 0;
+  unsigned *dPk = nullptr, *dNm = nullptr;
+  int *dLen = nullptr, *dBarcode = nullptr;
+  T4BatchView view;
+};
+
+namespace {
+
+int fail(t4_ctx *c, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+  return code;
+}
+
+#define HIPCHK(ctx, call)                                                                   \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess) return fail((ctx), T4_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+  } while (0)
+
+template <class T> int devAlloc(t4_ctx *c, T **p, size_t count) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  HIPCHK(c, hipMalloc(p, sizeof(T) * (count ? count : 1)));
+  return T4_OK;
+}
+
+// SeqSet::GetChainType / GetGeneType (SeqSet.hpp:5132-5155, 5076-5100)
+int chainType(const char *n) {
+  if (n[0] == 'I') { if (n[2] == 'H') return 0; if (n[2] == 'K') return 1; if (n[2] == 'L') return 2; }
+  else if (n[0] == 'T') { if (n[2] == 'A') return 3; if (n[2] == 'B') return 4; if (n[2] == 'G') return 5; if (n[2] == 'D') return 6; }
+  return 8;
+}
+int geneType(const char *n) {
+  if (n[0] == 'N' && n[1] == 'o') return -1;
+  switch (n[3]) {
+    case 'V': return 0;
+    case 'D': return (n[4] >= '0' && n[4] <= '9') ? 1 : 3;
+    case 'J': return 2;
+    case 'L': if (chainType(n) == 2) return -1; return 3;
+    default: return 3;
+  }
+}
+inline int nucNum(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
+
+int ensureScratch(t4_ctx *c, int grid) {
+  if (grid <= c->maxGrid) return T4_OK;
+  int r;
+  if ((r = devAlloc(c, &c->dpRows, (size_t)grid * 6 * T4_ROWW * 64))) return r;
+  if ((r = devAlloc(c, &c->dpDir, (size_t)grid * 64 * T4_DIR_BYTES))) return r;
+  c->maxGrid = grid;
+  return T4_OK;
+}
+int ensureGlobalTier(t4_ctx *c, int grid) {
+  if (grid <= c->gGrid) return T4_OK;
+  int r;
+  if ((r = devAlloc(c, &c->gKeys, (size_t)grid * G_CAP))) return r;
+  if ((r = devAlloc(c, &c->gPairs, (size_t)grid * G_CAP))) return r;
+  if ((r = devAlloc(c, &c->gCand, (size_t)grid * G_CAP))) return r;
+  if ((r = devAlloc(c, &c->gOv, (size_t)grid * G_MAXOV * 10))) return r;
+  if ((r = devAlloc(c, &c->gFin, (size_t)grid * G_MAXOV * 10))) return r;
+  if ((r = devAlloc(c, &c->gOrd, (size_t)grid * G_MAXOV))) return r;
+  c->gGrid = grid;
+  return T4_OK;
+}
+int ensurePerCall(t4_ctx *c, long long n) {
+  if (n <= c->listCap) return T4_OK;
+  int r;
+  if ((r = devAlloc(c, &c->lists, (size_t)n * T4_NTIER))) return r;
+  if ((r = devAlloc(c, &c->status, (size_t)n))) return r;
+  if ((r = devAlloc(c, &c->counts, (size_t)n))) return r;
+  c->listCap = n;
+  return T4_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int t4_init(int device_ordinal, t4_ctx **out) {
+  if (!out) return T4_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_ordinal < 0 || device_ordinal >= ndev) return T4_ERR_HIP;
+  if (hipSetDevice(device_ordinal) != hipSuccess) return T4_ERR_HIP;
+  t4_ctx *c = new t4_ctx();
+  c->device = device_ordinal;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) { delete c; return T4_ERR_HIP; }
+  c->cus = prop.multiProcessorCount;
+  if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return T4_ERR_HIP; }
+  for (int i = 0; i < 4; ++i) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return T4_ERR_HIP; }
+  memset(&c->stats, 0, sizeof c->stats);
+  if (hipMalloc(&c->listCounts, sizeof(int) * 8) != hipSuccess || hipMalloc(&c->hitCounter, sizeof(unsigned long long)) != hipSuccess) { delete c; return T4_ERR_HIP; }
+  *out = c;
+  return T4_OK;
+}
+
+void t4_destroy(t4_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  void *ptrs[] = {c->dpRows, c->dpDir, c->gKeys, c->gPairs, c->gCand, c->gOv, c->gFin, c->gOrd, c->hitsKeys, c->lists,
+                  c->listCounts, c->status, c->counts, c->hitCounter, c->result};
+  for (void *p : ptrs) if (p) (void)hipFree(p);
+  for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int t4_sync(t4_ctx *c) {
+  if (!c) return T4_ERR_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return T4_OK;
+}
+const char *t4_last_error(t4_ctx *c) { return c ? c->err.c_str() : "null ctx"; }
+int t4_device_cus(t4_ctx *c) { return c ? c->cus : 0; }
+int t4_last_stats(t4_ctx *c, t4_stats *out) {
+  if (!c || !out) return T4_ERR_ARG;
+  *out = c->stats;
+  return T4_OK;
+}
+
+// ---- index -------------------------------------------------------------------------------------
+int t4_index_create(t4_ctx *c, int k, int consider_barcode, t4_index **out) {
+  if (!c || !out) return T4_ERR_ARG;
+  if (k < 2 || k > 31) return fail(c, T4_ERR_ARG, "kmer_length %d outside [2,31]", k);
+  t4_index *ix = new t4_index();
+  ix->ctx = c; ix->k = k; ix->considerBarcode = consider_barcode ? 1 : 0;
+  double kmerHitProb = pow(0.8, k);  // SeqSet::ComputeNomatchGapLimit (SeqSet.hpp:2476-2482)
+  ix->nomatchGapLimit = int(k * (log(0.01) / log(1 - kmerHitProb))) + 1;
+  *out = ix;
+  return T4_OK;
+}
+
+void t4_index_destroy(t4_index *ix) {
+  if (!ix) return;
+  void *ptrs[] = {ix->dTable, ix->dHtab, ix->dPost, ix->dSeqs, ix->dCons, ix->dPw};
+  for (void *p : ptrs) if (p) (void)hipFree(p);
+  delete ix;
+}
+
+int t4_index_set_params(t4_index *ix, int hit_len_required, int radius, double novel_sim) {
+  if (!ix) return T4_ERR_ARG;
+  ix->hitLenRequired = hit_len_required; ix->radius = radius; ix->novelSim = novel_sim;
+  if (ix->committed) { ix->view.hitLenRequired = hit_len_required; ix->view.radius = radius; ix->view.novelSim = novel_sim; }
+  return T4_OK;
+}
+
+int t4_index_add_ref_record(t4_index *ix, const char *id, const char *seq, int *seq_id) {
+  if (!ix || !id || !seq) return T4_ERR_ARG;
+  if (ix->committed) return fail(ix->ctx, T4_ERR_STATE, "index already committed");
+  if (seq_id) *seq_id = -1;
+  if (strlen(id) < 4) return fail(ix->ctx, T4_ERR_ARG, "gene name '%s' shorter than 4 characters", id);
+  if (geneType(id) != 1) {  // drop "/OR" orphon genes unless they are D genes
+    for (const char *p = id; *p; ++p)
+      if (p[0] == '/' && p[1] == 'O' && p[2] == 'R') return T4_OK;
+  }
+  std::string cons;
+  for (const char *p = seq; *p; ++p) {
+    if (*p == '.') continue;
+    int c = (signed char)*p;
+    if (c >= 'a' && c <= 'z') c = (signed char)(c - ('a' + 'A'));  // reference arithmetic: lower case becomes N
+    if (c >= 'A' && c <= 'Z') { if (nucNum((char)c) == -1 && c != 'N') c = 'N'; }
+    else c = 'N';
+    cons.push_back((char)c);
+  }
+  auto it = ix->dedup.find(cons);
+  if (it != ix->dedup.end()) {
+    HostSeq &e = ix->seqs[it->second];
+    if (e.name.find(id) == std::string::npos) e.name += std::string("|") + id;
+    return T4_OK;
+  }
+  if ((int)ix->seqs.size() >= T4_MAX_SEQS || (int)cons.size() >= T4_MAX_SEQLEN) return fail(ix->ctx, T4_ERR_UNSUPPORTED, "sequence set too large");
+  HostSeq hs;
+  hs.name = id; hs.cons = cons; hs.barcode = -1; hs.isRef = true;
+  ix->dedup[cons] = (int)ix->seqs.size();
+  if (seq_id) *seq_id = (int)ix->seqs.size();
+  ix->seqs.push_back(hs);
+  return T4_OK;
+}
+
+int t4_index_load_ref_fasta(t4_index *ix, const char *path) {
+  if (!ix || !path) return T4_ERR_ARG;
+  gzFile fp = gzopen(path, "rb");
+  if (!fp) return fail(ix->ctx, T4_ERR_IO, "cannot open %s", path);
+  std::string id, seq;
+  bool have = false;
+  std::vector<char> line(1 << 20);
+  int rc = T4_OK;
+  auto flush = [&]() { if (have && rc == T4_OK) rc = t4_index_add_ref_record(ix, id.c_str(), seq.c_str(), nullptr); };
+  while (gzgets(fp, line.data(), (int)line.size())) {
+    size_t l = strlen(line.data());
+    while (l > 0 && (line[l - 1] == '\n' || line[l - 1] == '\r')) line[--l] = 0;
+    if (line[0] == '>') {
+      flush();
+      size_t i = 1;
+      while (line[i] && line[i] != ' ' && line[i] != '\t') ++i;
+      id.assign(line.data() + 1, i - 1);
+      size_t n = id.size();  // ReadFiles.hpp:180-185 strips a trailing /1 or /2
+      if (n >= 2 && (id[n - 1] == '1' || id[n - 1] == '2') && id[n - 2] == '/') id.resize(n - 2);
+      seq.clear(); have = true;
+    } else if (have) seq.append(line.data(), l);
+  }
+  flush();
+  gzclose(fp);
+  return rc;
+}
+
+int t4_index_add_contig(t4_index *ix, const char *name, const char *consensus, int barcode, const int32_t *posweight, int *seq_id) {
+  if (!ix || !name || !consensus) return T4_ERR_ARG;
+  if (ix->committed) return fail(ix->ctx, T4_ERR_STATE, "index already committed");
+  HostSeq hs;
+  hs.name = name; hs.cons = consensus; hs.barcode = barcode; hs.isRef = false;
+  size_t len = hs.cons.size();
+  if ((int)ix->seqs.size() >= T4_MAX_SEQS || (int)len >= T4_MAX_SEQLEN) return fail(ix->ctx, T4_ERR_UNSUPPORTED, "sequence set too large");
+  for (char ch : hs.cons) if (nucNum(ch) < 0 && ch != 'N') return fail(ix->ctx, T4_ERR_UNSUPPORTED, "contig alphabet must be ACGTN");
+  hs.pw.assign(4 * len, 0);
+  if (posweight) memcpy(hs.pw.data(), posweight, sizeof(int32_t) * 4 * len);
+  else for (size_t i = 0; i < len; ++i) if (hs.cons[i] != 'N') hs.pw[4 * i + nucNum(hs.cons[i])] = 1;
+  if (seq_id) *seq_id = (int)ix->seqs.size();
+  ix->seqs.push_back(std::move(hs));
+  return T4_OK;
+}
+
+int t4_index_commit(t4_index *ix) {
+  if (!ix) return T4_ERR_ARG;
+  t4_ctx *c = ix->ctx;
+  (void)hipSetDevice(c->device);
+  const int K = ix->k;
+  const unsigned long long mask = K < 32 ? ((1ull << (2 * K)) - 1ull) : ~0ull;
+  // postings in BuildIndexFromRead order (KmerIndex.hpp:118-141), keyed by (code, bucket)
+  struct Rec { unsigned long long code; int h; int idx, off; };
+  std::vector<Rec> recs;
+  for (size_t id = 0; id < ix->seqs.size(); ++id) {
+    const HostSeq &s = ix->seqs[id];
+    int len = (int)s.cons.size();
+    if (len < K) continue;
+    unsigned long long code = 0, prev = 0;
+    int invalidPos = -1;
+    for (int i = 0; i < len; ++i) {
+      char ch = s.cons[i];
+      if (invalidPos != -1) ++invalidPos;
+      code = ((code << 2) & mask) | (unsigned long long)(nucNum(ch) & 3);
+      if (ch == 'N') invalidPos = 0;
+      if (invalidPos >= K) invalidPos = -1;
+      if (i < K - 1) continue;
+      if (invalidPos == -1 && (i == K || code != prev)) {
+        int h = (int)((code + (unsigned long long)(long long)(ix->considerBarcode ? s.barcode + 1 : 0)) % 1000003ull);
+        recs.push_back({code, h, (int)id, i - K + 1});
+      }
+      prev = code;
+    }
+  }
+  std::stable_sort(recs.begin(), recs.end(), [](const Rec &a, const Rec &b) { return a.code != b.code ? a.code < b.code : a.h < b.h; });
+  std::vector<int2> post(recs.size());
+  for (size_t i = 0; i < recs.size(); ++i) post[i] = make_int2(recs[i].idx, recs[i].off);
+  const bool direct = (K <= 12 && !ix->considerBarcode);
+  std::vector<uint2> table;
+  std::vector<T4HashEnt> htab;
+  unsigned long long hashMask = 0;
+  if (direct) {
+    table.assign((size_t)1 << (2 * K), make_uint2(0, 0));
+    for (size_t i = 0; i < recs.size();) {
+      size_t j = i;
+      while (j < recs.size() && recs[j].code == recs[i].code) ++j;
+      table[recs[i].code] = make_uint2((unsigned)i, (unsigned)(j - i));
+      i = j;
+    }
+  } else {
+    size_t nkeys = 0;
+    for (size_t i = 0; i < recs.size();) { size_t j = i; while (j < recs.size() && recs[j].code == recs[i].code && recs[j].h == recs[i].h) ++j; ++nkeys; i = j; }
+    size_t sz = 1024;
+    while (sz < 2 * nkeys + 2) sz <<= 1;
+    hashMask = sz - 1;
+    T4HashEnt empty; empty.code = 0; empty.h = -1; empty.start = 0; empty.cnt = 0; empty.pad = 0;
+    htab.assign(sz, empty);
+    for (size_t i = 0; i < recs.size();) {
+      size_t j = i;
+      while (j < recs.size() && recs[j].code == recs[i].code && recs[j].h == recs[i].h) ++j;
+      unsigned long long s = t4k::mix64(recs[i].code * 1000003ull + (unsigned long long)recs[i].h) & hashMask;
+      while (htab[s].h >= 0) s = (s + 1) & hashMask;
+      htab[s].code = recs[i].code; htab[s].h = recs[i].h; htab[s].start = (unsigned)i; htab[s].cnt = (unsigned)(j - i);
+      i = j;
+    }
+  }
+  // sequence table
+  std::vector<T4SeqInfo> infos(ix->seqs.size());
+  std::string cons;
+  std::vector<int4> pw;
+  bool hasNovel = false;
+  for (size_t id = 0; id < ix->seqs.size(); ++id) {
+    const HostSeq &s = ix->seqs[id];
+    T4SeqInfo &f = infos[id];
+    memset(&f, 0, sizeof f);
+    f.consOff = (int)cons.size(); f.len = (int)s.cons.size(); f.barcode = s.barcode; f.isRef = s.isRef ? 1 : 0;
+    cons += s.cons; cons.push_back('\0');
+    char nm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    strncpy(nm, s.name.c_str(), 7);
+    int gt = geneType(nm);
+    f.geneType = gt < 0 ? 255 : (unsigned char)gt;
+    f.name0 = (unsigned char)nm[0]; f.name1 = (unsigned char)nm[1]; f.name2 = (unsigned char)nm[2]; f.name3 = (unsigned char)nm[3];
+    f.pwOff = -1;
+    if (!s.isRef) {
+      hasNovel = true;
+      f.pwOff = (int)pw.size();
+      for (int i = 0; i < f.len; ++i) pw.push_back(make_int4(s.pw[4 * i], s.pw[4 * i + 1], s.pw[4 * i + 2], s.pw[4 * i + 3]));
+      pw.push_back(make_int4(0, 0, 0, 0));
+    }
+  }
+  int r;
+  void *old[] = {ix->dTable, ix->dHtab, ix->dPost, ix->dSeqs, ix->dCons, ix->dPw};
+  for (void *p : old) if (p) (void)hipFree(p);
+  ix->dTable = nullptr; ix->dHtab = nullptr; ix->dPost = nullptr; ix->dSeqs = nullptr; ix->dCons = nullptr; ix->dPw = nullptr;
+  if ((r = devAlloc(c, &ix->dPost, post.size()))) return r;
+  if ((r = devAlloc(c, &ix->dSeqs, infos.size()))) return r;
+  if ((r = devAlloc(c, &ix->dCons, cons.size() + 16))) return r;
+  if ((r = devAlloc(c, &ix->dPw, pw.size()))) return r;
+  if (direct) { if ((r = devAlloc(c, &ix->dTable, table.size()))) return r; }
+  else { if ((r = devAlloc(c, &ix->dHtab, htab.size()))) return r; }
+  if (!post.empty()) HIPCHK(c, hipMemcpy(ix->dPost, post.data(), sizeof(int2) * post.size(), hipMemcpyHostToDevice));
+  if (!infos.empty()) HIPCHK(c, hipMemcpy(ix->dSeqs, infos.data(), sizeof(T4SeqInfo) * infos.size(), hipMemcpyHostToDevice));
+  if (!cons.empty()) HIPCHK(c, hipMemcpy(ix->dCons, cons.data(), cons.size(), hipMemcpyHostToDevice));
+  if (!pw.empty()) HIPCHK(c, hipMemcpy(ix->dPw, pw.data(), sizeof(int4) * pw.size(), hipMemcpyHostToDevice));
+  if (direct) HIPCHK(c, hipMemcpy(ix->dTable, table.data(), sizeof(uint2) * table.size(), hipMemcpyHostToDevice));
+  else HIPCHK(c, hipMemcpy(ix->dHtab, htab.data(), sizeof(T4HashEnt) * htab.size(), hipMemcpyHostToDevice));
+  T4IndexView &v = ix->view;
+  memset(&v, 0, sizeof v);
+  v.k = K; v.nseq = (int)ix->seqs.size(); v.direct = direct ? 1 : 0; v.considerBarcode = ix->considerBarcode;
+  v.hashMask = hashMask; v.table = ix->dTable; v.htab = ix->dHtab; v.post = ix->dPost; v.seqs = ix->dSeqs;
+  v.cons = ix->dCons; v.pw = ix->dPw;
+  v.radius = ix->radius; v.hitLenRequired = ix->hitLenRequired; v.nomatchGapLimit = ix->nomatchGapLimit;
+  v.firstIsRef = (!ix->seqs.empty() && ix->seqs[0].isRef) ? 1 : 0;
+  v.hasNovel = hasNovel ? 1 : 0;
+  v.novelSim = ix->novelSim; v.refSim = ix->refSim; v.repeatSim = ix->repeatSim;
+  ix->committed = true;
+  return T4_OK;
+}
+
+int t4_index_size(const t4_index *ix) { return ix ? (int)ix->seqs.size() : 0; }
+int t4_index_seq_len(const t4_index *ix, int i) { return (ix && i >= 0 && i < (int)ix->seqs.size()) ? (int)ix->seqs[i].cons.size() : -1; }
+const char *t4_index_seq_name(const t4_index *ix, int i) { return (ix && i >= 0 && i < (int)ix->seqs.size()) ? ix->seqs[i].name.c_str() : nullptr; }
+const char *t4_index_seq_consensus(const t4_index *ix, int i) { return (ix && i >= 0 && i < (int)ix->seqs.size()) ? ix->seqs[i].cons.c_str() : nullptr; }
+
+// ---- reads -------------------------------------------------------------------------------------
+int t4_reads_upload(t4_ctx *c, const char *bases, const int64_t *offsets, const int32_t *barcode, int64_t n, t4_batch **out) {
+  if (!c || !out || n < 0 || (n > 0 && (!bases || !offsets))) return T4_ERR_ARG;
+  *out = nullptr;
+  (void)hipSetDevice(c->device);
+  int maxLen = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    int64_t l = offsets[i + 1] - offsets[i];
+    if (l < 0) return fail(c, T4_ERR_ARG, "offsets not monotone at read %lld", (long long)i);
+    if (l > T4_MAXL) return fail(c, T4_ERR_UNSUPPORTED, "read %lld is %lld bp; this engine takes reads up to %d bp", (long long)i, (long long)l, T4_MAXL);
+    if (l > maxLen) maxLen = (int)l;
+  }
+  t4_batch *b = new t4_batch();
+  b->ctx = c; b->n = n; b->maxLen = maxLen;
+  b->wpk = (maxLen + 15) / 16; b->wnm = (maxLen + 31) / 32;
+  if (b->wpk == 0) b->wpk = 1;
+  if (b->wnm == 0) b->wnm = 1;
+  std::vector<unsigned> pk((size_t)n * b->wpk, 0u), nm((size_t)n * b->wnm, 0u);
+  std::vector<int> len((size_t)n);
+  for (int64_t i = 0; i < n; ++i) {
+    const char *s = bases + offsets[i];
+    int l = (int)(offsets[i + 1] - offsets[i]);
+    len[i] = l;
+    unsigned *p = pk.data() + (size_t)i * b->wpk, *m = nm.data() + (size_t)i * b->wnm;
+    for (int j = 0; j < l; ++j) {
+      int v = nucNum(s[j]);
+      if (v < 0) {
+        if (s[j] != 'N') { delete b; return fail(c, T4_ERR_UNSUPPORTED, "read %lld has base '%c' (alphabet is ACGTN)", (long long)i, s[j]); }
+        m[j >> 5] |= 1u << (j & 31);
+        v = 0;
+      }
+      p[j >> 4] |= (unsigned)v << ((j & 15) * 2);
+    }
+  }
+  int r;
+  if ((r = devAlloc(c, &b->dPk, pk.size())) || (r = devAlloc(c, &b->dNm, nm.size())) || (r = devAlloc(c, &b->dLen, len.size()))) { t4_batch_destroy(b); return r; }
+  if (n > 0) {
+    HIPCHK(c, hipMemcpy(b->dPk, pk.data(), sizeof(unsigned) * pk.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(b->dNm, nm.data(), sizeof(unsigned) * nm.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(b->dLen, len.data(), sizeof(int) * len.size(), hipMemcpyHostToDevice));
+  }
+  if (barcode) {
+    if ((r = devAlloc(c, &b->dBarcode, (size_t)n))) { t4_batch_destroy(b); return r; }
+    if (n > 0) HIPCHK(c, hipMemcpy(b->dBarcode, barcode, sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+  }
+  b->view.pk = b->dPk; b->view.nm = b->dNm; b->view.len = b->dLen; b->view.barcode = b->dBarcode;
+  b->view.wpk = b->wpk; b->view.wnm = b->wnm; b->view.n = n;
+  *out = b;
+  return T4_OK;
+}
+
+void t4_batch_destroy(t4_batch *b) {
+  if (!b) return;
+  void *ptrs[] = {b->dPk, b->dNm, b->dLen, b->dBarcode};
+  for (void *p : ptrs) if (p) (void)hipFree(p);
+  delete b;
+}
+int64_t t4_batch_size(const t4_batch *b) { return b ? b->n : 0; }
+
+}  // extern "C"
+
+namespace {
+
+template <int CAP, int MAXOV>
+void launchTier(int grid, hipStream_t st, const T4IndexView &iv, const T4BatchView &bv, const T4Work &wk, const T4QueryArgs &qa) {
+  hipLaunchKernelGGL((t4k::queryKernel<CAP, MAXOV>), dim3(grid), dim3(64), 0, st, iv, bv, wk, qa);
+}
+
+// Shared driver of t4_overlaps / t4_annotate_rough.
+int runQuery(t4_index *ix, t4_batch *b, T4QueryArgs qa, bool useBarcode) {
+  t4_ctx *c = ix->ctx;
+  if (!ix->committed) return fail(c, T4_ERR_STATE, "index not committed");
+  if (b->ctx != c) return fail(c, T4_ERR_ARG, "batch belongs to another ctx");
+  (void)hipSetDevice(c->device);
+  const long long n = b->n;
+  memset(&c->stats, 0, sizeof c->stats);
+  c->stats.reads = n;
+  if (n == 0) return T4_OK;
+  int r;
+  int grids[T4_NTIER];
+  int maxGrid = 1;
+  for (int t = 0; t < T4_NTIER; ++t) { grids[t] = c->cus * TIER_BLOCKS_PER_CU[t]; if (grids[t] > maxGrid) maxGrid = grids[t]; }
+  if ((r = ensureScratch(c, maxGrid))) return r;
+  if ((r = ensurePerCall(c, n))) return r;
+  HIPCHK(c, hipMemsetAsync(c->listCounts, 0, sizeof(int) * 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(int) * (size_t)n, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->hitCounter, 0, sizeof(unsigned long long), c->stream));
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  int binGrid = c->cus * 8;
+  if ((long long)binGrid > n) binGrid = (int)n;
+  hipLaunchKernelGGL(t4k::binKernel, dim3(binGrid), dim3(64), 0, c->stream, ix->view, b->view, useBarcode ? 1 : 0,
+                     TIER_CAP[0], TIER_CAP[1], TIER_CAP[2], c->lists, c->listCounts, (long long)n);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  c->stats.launches = 1;
+  int hostCounts[8];
+  for (int t = 0; t < T4_NTIER; ++t) {
+    HIPCHK(c, hipMemcpyAsync(hostCounts, c->listCounts, sizeof(int) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int cnt = hostCounts[t];
+    c->stats.tier_reads[t] = cnt;
+    if (cnt == 0) continue;
+    T4Work wk;
+    memset(&wk, 0, sizeof wk);
+    wk.list = c->lists + (size_t)t * n; wk.nList = cnt;
+    wk.nextList = t + 1 < T4_NTIER ? c->lists + (size_t)(t + 1) * n : nullptr;
+    wk.nextCount = t + 1 < T4_NTIER ? c->listCounts + (t + 1) : nullptr;
+    wk.status = c->status; wk.hitCounter = c->hitCounter;
+    wk.dpRows = c->dpRows; wk.dpDir = c->dpDir;
+    int grid = grids[t] < cnt ? grids[t] : cnt;
+    if (t == 3) {
+      if ((r = ensureGlobalTier(c, grids[3]))) return r;
+      wk.gKeys = c->gKeys; wk.gPairs = c->gPairs; wk.gCand = c->gCand; wk.gOv = c->gOv; wk.gFin = c->gFin; wk.gOrd = c->gOrd;
+      wk.gCap = G_CAP; wk.gMaxOv = G_MAXOV;
+      launchTier<0, 0>(grid, c->stream, ix->view, b->view, wk, qa);
+    } else if (t == 0) launchTier<1024, 128>(grid, c->stream, ix->view, b->view, wk, qa);
+    else if (t == 1) launchTier<4096, 256>(grid, c->stream, ix->view, b->view, wk, qa);
+    else launchTier<8192, 512>(grid, c->stream, ix->view, b->view, wk, qa);
+    HIPCHK(c, hipGetLastError());
+    ++c->stats.launches;
+  }
+  HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+  std::vector<int> status((size_t)n);
+  unsigned long long hits = 0;
+  HIPCHK(c, hipMemcpyAsync(status.data(), c->status, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&hits, c->hitCounter, sizeof hits, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  float msAll = 0, msChain = 0;
+  HIPCHK(c, hipEventElapsedTime(&msAll, c->ev[0], c->ev[2]));
+  HIPCHK(c, hipEventElapsedTime(&msChain, c->ev[1], c->ev[2]));
+  c->stats.kernel_ms = msAll; c->stats.chain_kernel_ms = msChain; c->stats.total_hits = (int64_t)hits;
+  for (long long i = 0; i < n; ++i)
+    if (status[i] != 0)
+      return fail(c, T4_ERR_UNSUPPORTED, "read %lld exceeds the engine limits (status %d: %s)", i, status[i],
+                  status[i] == 2 ? "more than 32768 k-mer hits or 4096 overlaps" : "gap DP or contig count beyond scratch");
+  return T4_OK;
+}
+
+int ensureResult(t4_ctx *c, size_t records) {
+  if (records <= c->resultCap) return T4_OK;
+  int r = devAlloc(c, &c->result, records);
+  if (r) return r;
+  c->resultCap = records;
+  return T4_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int t4_overlaps(t4_index *ix, t4_batch *b, int strand, int skip_repeats, int max_per_read, int32_t *counts, t4_overlap *out) {
+  if (!ix || !b || max_per_read <= 0) return T4_ERR_ARG;
+  t4_ctx *c = ix->ctx;
+  int r;
+  if ((r = ensurePerCall(c, b->n))) return r;
+  if ((r = ensureResult(c, (size_t)b->n * max_per_read))) return r;
+  T4QueryArgs qa;
+  qa.mode = 0; qa.strand = strand; qa.skipRepeats = skip_repeats; qa.maxPerRead = max_per_read;
+  qa.counts = c->counts; qa.out = c->result;
+  if ((r = runQuery(ix, b, qa, true))) return r;
+  if (counts && b->n) HIPCHK(c, hipMemcpy(counts, c->counts, sizeof(int) * (size_t)b->n, hipMemcpyDeviceToHost));
+  if (out && b->n) HIPCHK(c, hipMemcpy(out, c->result, sizeof(t4_overlap) * (size_t)b->n * max_per_read, hipMemcpyDeviceToHost));
+  return T4_OK;
+}
+
+int t4_annotate_rough(t4_index *ref, t4_batch *b, t4_overlap *out) {
+  if (!ref || !b) return T4_ERR_ARG;
+  t4_ctx *c = ref->ctx;
+  int r;
+  if ((r = ensureResult(c, (size_t)b->n * 4))) return r;
+  T4QueryArgs qa;
+  qa.mode = 1; qa.strand = 0; qa.skipRepeats = 0; qa.maxPerRead = 4; qa.counts = nullptr; qa.out = c->result;
+  if ((r = runQuery(ref, b, qa, false))) return r;
+  if (out && b->n) HIPCHK(c, hipMemcpy(out, c->result, sizeof(t4_overlap) * (size_t)b->n * 4, hipMemcpyDeviceToHost));
+  return T4_OK;
+}
+
+int t4_hits(t4_index *ix, t4_batch *b, int strand, int allow_total_skip, int64_t *hit_offsets, t4_hit *hits, int64_t hits_cap) {
+  if (!ix || !b || !hit_offsets) return T4_ERR_ARG;
+  t4_ctx *c = ix->ctx;
+  if (!ix->committed) return fail(c, T4_ERR_STATE, "index not committed");
+  (void)hipSetDevice(c->device);
+  const long long n = b->n;
+  hit_offsets[0] = 0;
+  if (n == 0) return T4_OK;
+  int r;
+  int grid = c->cus * 2;
+  if ((long long)grid > n) grid = (int)n;
+  const int HCAP = 65536;
+  if (grid > c->hitsGrid) { if ((r = devAlloc(c, &c->hitsKeys, (size_t)grid * HCAP))) return r; c->hitsGrid = grid; }
+  if ((r = ensurePerCall(c, n))) return r;
+  long long *dOff = nullptr;
+  T4HitOut *dHits = nullptr;
+  if ((r = devAlloc(c, &dOff, (size_t)n + 1))) return r;
+  HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(int) * (size_t)n, c->stream));
+  hipLaunchKernelGGL(t4k::hitsKernel, dim3(grid), dim3(64), 0, c->stream, ix->view, b->view, strand, allow_total_skip, 0, dOff,
+                     (T4HitOut *)nullptr, c->hitsKeys, HCAP, c->status);
+  HIPCHK(c, hipGetLastError());
+  std::vector<long long> off((size_t)n + 1);
+  HIPCHK(c, hipMemcpyAsync(off.data(), dOff, sizeof(long long) * ((size_t)n + 1), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  off[0] = 0;
+  for (long long i = 0; i < n; ++i) off[i + 1] += off[i];
+  for (long long i = 0; i <= n; ++i) hit_offsets[i] = off[i];
+  std::vector<int> status((size_t)n);
+  HIPCHK(c, hipMemcpy(status.data(), c->status, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+  for (long long i = 0; i < n; ++i) if (status[i]) { (void)hipFree(dOff); return fail(c, T4_ERR_UNSUPPORTED, "read %lld has more than %d hits", i, HCAP); }
+  if (hits) {
+    if (hits_cap < off[n]) { (void)hipFree(dOff); return fail(c, T4_ERR_ARG, "hits_cap %lld < %lld", (long long)hits_cap, off[n]); }
+    if ((r = devAlloc(c, &dHits, (size_t)off[n]))) { (void)hipFree(dOff); return r; }
+    HIPCHK(c, hipMemcpyAsync(dOff, off.data(), sizeof(long long) * ((size_t)n + 1), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(t4k::hitsKernel, dim3(grid), dim3(64), 0, c->stream, ix->view, b->view, strand, allow_total_skip, 1, dOff,
+                       dHits, c->hitsKeys, HCAP, c->status);
+    HIPCHK(c, hipGetLastError());
+    if (off[n]) HIPCHK(c, hipMemcpyAsync(hits, dHits, sizeof(t4_hit) * (size_t)off[n], hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(dHits);
+  }
+  (void)hipFree(dOff);
+  return T4_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+// trust4_amd/csrc/t4_device.h -- POD views shared by the host side (t4_api.hip) and the kernels.
+#pragma once
+#include <stdint.h>
+
+#define T4_MAXL 384          // longest read the kernels take (150 bp mates merge to <= ~290 bp)
+#define T4_MAXPOS (2 * T4_MAXL)
+#define T4_MAXGAP 320        // longest side of one gap DP (nomatchGapLimit is 288 at k = 9)
+#define T4_DIR_BYTES 49152   // per-lane traceback bytes of one gap DP
+#define T4_NTIER 4
+
+// key of a k-mer hit, sortable as (strand, seq idx, diagonal, seq offset)
+#define T4_IDX_BITS 22
+#define T4_C_BITS 21
+#define T4_B_BITS 20
+#define T4_C_BIAS (1 << 20)
+#define T4_MAX_SEQS (1 << T4_IDX_BITS)
+#define T4_MAX_SEQLEN (1 << T4_B_BITS)
+
+struct T4SeqInfo {           // 24 bytes per sequence of the set
+  int consOff;               // start in the consensus char array
+  int len;
+  int pwOff;                 // start (in bases) in the posWeight array, -1 for reference genes
+  int barcode;
+  unsigned char isRef, geneType /* 0 V 1 D 2 J 3 C 255 none */, name0, name1, name2, name3;
+  unsigned short pad1;
+};
+
+struct T4HashEnt {           // open-addressing slot of the (code, bucket) -> postings map
+  unsigned long long code;
+  int h;                     // KmerIndex bucket id; -1 = empty slot
+  unsigned start, cnt;
+  unsigned pad;
+};
+
+struct T4IndexView {
+  int k, nseq, direct, considerBarcode;
+  unsigned long long hashMask;
+  const uint2 *table;        // direct-addressed [4^k] {start,cnt} (k <= 12, no barcode)
+  const T4HashEnt *htab;
+  const int2 *post;          // postings (idx, offset) -- sizeof(_indexInfo) = 8
+  const T4SeqInfo *seqs;
+  const char *cons;
+  const int4 *pw;            // posWeight counts (A,C,G,T) of novel contigs
+  int radius, hitLenRequired, nomatchGapLimit, firstIsRef, hasNovel;
+  double novelSim, refSim, repeatSim;
+};
+
+struct T4BatchView {
+  const unsigned *pk;        // 2-bit bases, 16 per word, wpk words per read
+  const unsigned *nm;        // N mask, 32 bases per word, wnm words per read
+  const int *len;
+  const int *barcode;        // may be null
+  int wpk, wnm;
+  long long n;
+};
+
+struct T4Work {              // per-launch work description
+  const int *list;           // read ids of this tier
+  int nList;
+  int *nextList;             // overflow -> next tier
+  int *nextCount;
+  int *status;               // per read: 0 ok, 1 unsupported
+  unsigned long long *hitCounter;
+  // scratch (per persistent block)
+  int *dpRows;               // [grid][6 * (T4_MAXGAP + 2) * 64]
+  unsigned char *dpDir;      // [grid][64 * T4_DIR_BYTES]
+  // global-tier working arrays (per block), null for LDS tiers
+  unsigned long long *gKeys; // [grid][cap]
+  unsigned *gPairs;          // [grid][cap]
+  unsigned *gCand;           // [grid][cap]
+  int *gOv;                  // [grid][maxov * 10]
+  int *gFin;                 // [grid][maxov * 10]
+  unsigned short *gOrd;      // [grid][maxov]
+  int gCap, gMaxOv;
+};
+
+struct T4OverlapOut {        // == t4_overlap of include/trust4_hip.h
+  int seqIdx, readStart, readEnd, seqStart, seqEnd, strand, matchCnt, indelCnt;
+  double similarity;
+};
+
+struct T4HitOut { int idx, offset, readOffset, strand, repeats; };  // == t4_hit
+
+struct T4QueryArgs {
+  int mode;                  // 0: overlaps (GetOverlapsFromRead), 1: annotate level 0
+  int strand;                // strand argument of GetOverlapsFromRead
+  int skipRepeats;
+  int maxPerRead;            // mode 0 output stride
+  int *counts;               // mode 0
+  T4OverlapOut *out;
+};

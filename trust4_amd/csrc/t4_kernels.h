@@ -1,0 +1,1269 @@
+// trust4_amd/csrc/t4_kernels.h -- hand-written gfx950 kernels of the stage-1 hot path.
+//
+// One 64-lane wavefront owns one read from its 2-bit image in HBM to its scored overlaps:
+//   unpack -> roll k-mers (fwd + rc) -> probe the index -> expand postings into 64-bit hit keys in LDS
+//   -> wave bitonic sort by (strand, seq, diagonal, seq offset) -> runs of concordant hits
+//   -> one lane per run: LIS chaining -> overlap records -> rank sort -> one lane per overlap:
+//   anchor walk + banded integer gap DPs -> similarity filters -> (annotate) V/J/C selection.
+// Nothing here is GEMM shaped: it is integer scan / gather / sort work, so there is no MFMA.
+// Reference semantics followed (file:line in /root/reference):
+//   k-mer roll + probe   KmerCode.hpp:94-109, KmerIndex.hpp:29-33,104-116, SeqSet.hpp:1341-1501
+//   hit order            SeqSet.hpp:1306-1339 (only the (strand, idx) grouping is observable)
+//   runs + chaining      SeqSet.hpp:763-1063, LIS 342-499, VJ rescue 1066-1161
+//   overlap scoring      SeqSet.hpp:1508-2124, low complexity 590-617
+//   gap DPs              AlignAlgo.hpp:57-216 (posWeight, linear gap), 218-424 (affine)
+//   rough annotation     SeqSet.hpp:6016-6066, 6167-6321, contig split 5289-5321
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "t4_device.h"
+
+namespace t4k {
+
+// ------------------------------------------------------------------------------------------------
+// wave helpers (a workgroup is exactly one wavefront: blockDim.x == 64)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int laneId() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ int waveInclScan(int v) {
+  int lane = laneId();
+  for (int d = 1; d < 64; d <<= 1) {
+    int t = __shfl_up(v, d);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ int waveSum(int v) {
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+  return v;
+}
+__device__ __forceinline__ int waveMax(int v) {
+  for (int d = 32; d > 0; d >>= 1) { int t = __shfl_xor(v, d); v = t > v ? t : v; }
+  return v;
+}
+
+__host__ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+// KmerIndex::Search (KmerIndex.hpp:104-116): (start, cnt) of the posting list of a valid k-mer.
+__device__ __forceinline__ void indexLookup(const T4IndexView &ix, unsigned long long code, int barcode,
+                                            unsigned &start, unsigned &cnt) {
+  if (ix.direct) {
+    uint2 e = ix.table[code];
+    start = e.x; cnt = e.y;
+    return;
+  }
+  int h = (int)((code + (unsigned long long)(long long)(ix.considerBarcode ? barcode + 1 : 0)) % 1000003ull);
+  unsigned long long i = mix64(code * 1000003ull + (unsigned long long)h) & ix.hashMask;
+  for (;;) {
+    T4HashEnt e = ix.htab[i];
+    if (e.h < 0) { start = 0; cnt = 0; return; }
+    if (e.code == code && e.h == h) { start = e.start; cnt = e.cnt; return; }
+    i = (i + 1) & ix.hashMask;
+  }
+}
+
+__device__ __forceinline__ int nuc2(char c) { // nucToNum[c-'A'] & 3 for the packed alphabet
+  return c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gap DPs. One alignment per lane; score rows live in a lane-interleaved scratch, traceback
+// decisions (1 byte / band cell) in a per-lane scratch. Results are the GetAlignStats counts.
+// ------------------------------------------------------------------------------------------------
+struct DPScratch {
+  int *rows;            // [(arr * ROWW + col) * 64 + lane]
+  unsigned char *dir;   // this lane's T4_DIR_BYTES
+};
+#define T4_ROWW (T4_MAXGAP + 2)
+#define T4_ROW(arr, col) sc.rows[(((arr) * T4_ROWW) + (col)) * 64 + lane]
+
+// AlignAlgo::GlobalAlignment (AlignAlgo.hpp:218-424) + GetAlignStats. t: consensus chars (global),
+// p: read chars (LDS). Returns false when the problem exceeds the scratch (caller flags the read).
+__device__ bool dpAffine(const char *t, int lent, const char *p, int lenp, DPScratch sc, int lane,
+                         int &nMatch, int &nMis, int &nIndel) {
+  nMatch = nMis = nIndel = 0;
+  if (lent == 0 || lenp == 0) return true;
+  if (lent == 1 && lenp == 1) {
+    char a = t[0], b = p[0];
+    if (a == b || a == 'N' || b == 'N') nMatch = 1; else nMis = 1;
+    return true;
+  }
+  if (lent > T4_MAXGAP || lenp > T4_MAXGAP) return false;
+  int leftBand = 5, rightBand = 5;
+  if (lent > lenp) rightBand += lent - lenp; else if (lent < lenp) leftBand += lenp - lent;
+  int DW = leftBand + rightBand + 1;
+  if (DW > lent) DW = lent;
+  if ((long long)(lenp + 1) * DW > T4_DIR_BYTES) return false;
+  const int negInf = (lent + 1) * (lenp + 1) * (-4);
+  // row 0 (prev = arrays 0..2 : m,e,f)
+  int pr = 0, cu = 3;
+  int end1 = (1 + rightBand > lent) ? lent : (1 + rightBand);
+  T4_ROW(pr + 0, 0) = 0; T4_ROW(pr + 1, 0) = 0; T4_ROW(pr + 2, 0) = 0;
+  for (int j = 1; j <= end1; ++j) {
+    T4_ROW(pr + 0, j) = -4 - 4 * j;
+    T4_ROW(pr + 1, j) = -4 + (lenp + 1) * (-4);  // the reference's stale loop variable (line 271)
+    T4_ROW(pr + 2, j) = -4 - j;
+  }
+  if (end1 < lent) { T4_ROW(pr + 0, end1 + 1) = -4 - 4 * (end1 + 1); T4_ROW(pr + 1, end1 + 1) = -4 + (lenp + 1) * (-4); T4_ROW(pr + 2, end1 + 1) = -4 - (end1 + 1); }
+  for (int i = 1; i <= lenp; ++i) {
+    int start = (i - leftBand < 1) ? 1 : (i - leftBand);
+    int end = (i + rightBand > lent) ? lent : (i + rightBand);
+    if (start > 1) { T4_ROW(cu + 0, start - 1) = negInf; T4_ROW(cu + 1, start - 1) = negInf; T4_ROW(cu + 2, start - 1) = negInf; }
+    else { T4_ROW(cu + 0, 0) = -4 - 4 * i; T4_ROW(cu + 1, 0) = -4 - i; T4_ROW(cu + 2, 0) = -4 - 4 * i; }
+    if (end < lent) { T4_ROW(cu + 0, end + 1) = negInf; T4_ROW(cu + 1, end + 1) = negInf; T4_ROW(cu + 2, end + 1) = negInf; }
+    char pc = p[i - 1];
+    int mLeft = T4_ROW(cu + 0, start - 1), fLeft = T4_ROW(cu + 2, start - 1);
+    int mDiag = T4_ROW(pr + 0, start - 1);
+    unsigned char *drow = sc.dir + (size_t)i * DW;
+    for (int j = start; j <= end; ++j) {
+      int mUp = T4_ROW(pr + 0, j), eUp = T4_ROW(pr + 1, j);
+      int e = eUp - 1;
+      int eo = mUp - 5;
+      if (eo > e) e = eo;
+      int f = fLeft - 1;
+      int fo = mLeft - 5;
+      if (fo > f) f = fo;
+      char tc = t[j - 1];
+      bool eq = (tc == pc || tc == 'N' || pc == 'N');
+      int dsc = mDiag + (eq ? 2 : -2);
+      int m = dsc;
+      if (e > m) m = e;
+      if (f > m) m = f;
+      T4_ROW(cu + 0, j) = m; T4_ROW(cu + 1, j) = e; T4_ROW(cu + 2, j) = f;
+      unsigned char bits = (unsigned char)((f >= e ? 1 : 0) | (dsc == m ? 2 : 0) | (eq ? 4 : 0) | (eo == e ? 8 : 0) | (fo == f ? 16 : 0));
+      drow[j - start] = bits;
+      mDiag = mUp; mLeft = m; fLeft = f;
+    }
+    int tsw = pr; pr = cu; cu = tsw;
+  }
+  // traceback (border cells are evaluated from their closed forms)
+  int tagi = lenp, tagj = lent, mat = 0;
+  while (tagi > 0 || tagj > 0) {
+    bool interior = tagi > 0 && tagj > 0;
+    unsigned char bits = 0;
+    if (interior) {
+      int start = (tagi - leftBand < 1) ? 1 : (tagi - leftBand);
+      bits = sc.dir[(size_t)tagi * DW + (tagj - start)];
+    }
+    if (mat == 0) {
+      int a;  // 2 insert, 3 delete, 0 match, 1 mismatch
+      if (interior) {
+        a = (bits & 1) ? 3 : 2;
+        if (bits & 2) a = (bits & 4) ? 0 : 1;
+      } else if (tagi == 0) {
+        // e[0][j] = -4-4(lenp+1), f[0][j] = -4-j
+        a = (-4 - tagj >= -4 + (lenp + 1) * (-4)) ? 3 : 2;
+      } else {
+        // e[i][0] = -4-i, f[i][0] = -4-4i  => f >= e only for i <= 0
+        a = 2;
+      }
+      if (a == 0) { ++nMatch; --tagi; --tagj; }
+      else if (a == 1) { ++nMis; --tagi; --tagj; }
+      else if (a == 2) mat = 1;
+      else mat = 2;
+    } else if (mat == 1) {
+      ++nIndel;
+      if (tagi > 0) {
+        bool open;
+        if (interior) open = (bits & 8) != 0;
+        else { // column 0: m[i-1][0] - 5 == e[i][0] = -4 - i
+          int mUp = (tagi - 1 == 0) ? 0 : (-4 - 4 * (tagi - 1));
+          open = (mUp - 5 == -4 - tagi);
+        }
+        --tagi;
+        mat = open ? 0 : 1;
+      } else mat = 2;
+    } else {
+      ++nIndel;
+      if (tagj > 0) {
+        bool open;
+        if (interior) open = (bits & 16) != 0;
+        else { // row 0: m[0][j-1] - 5 == f[0][j] = -4 - j
+          int mL = (tagj - 1 == 0) ? 0 : (-4 - 4 * (tagj - 1));
+          open = (mL - 5 == -4 - tagj);
+        }
+        --tagj;
+        mat = open ? 0 : 2;
+      } else mat = 1;
+    }
+  }
+  return true;
+}
+
+// AlignAlgo::IsBaseEqual (AlignAlgo.hpp:49-55)
+__device__ __forceinline__ bool baseEqualW(int4 w, char c) {
+  int sum = w.x + w.y + w.z + w.w;
+  if (sum == 0 || c == 'N') return true;
+  int n = nuc2(c);
+  int wc = n == 0 ? w.x : n == 1 ? w.y : n == 2 ? w.z : w.w;
+  return sum < 3 * wc;
+}
+
+// AlignAlgo::GlobalAlignment_PosWeight (AlignAlgo.hpp:57-216). When `align` is non-null the edit
+// string (terminated by -1) is written there (lane-private global memory, needs lent+lenp+2 bytes).
+__device__ bool dpPosWeight(const int4 *w, int lent, const char *p, int lenp, DPScratch sc, int lane,
+                            int &nMatch, int &nMis, int &nIndel, signed char *align) {
+  nMatch = nMis = nIndel = 0;
+  if (lent == 0 || lenp == 0) { if (align) align[0] = -1; return true; }
+  if (lent == 1 && lenp == 1) {
+    bool eq = baseEqualW(w[0], p[0]);
+    if (eq) nMatch = 1; else nMis = 1;
+    if (align) { align[0] = eq ? 0 : 1; align[1] = -1; }
+    return true;
+  }
+  if (lent == lenp) {
+    int score = 0, mm = 0;
+    for (int i = 0; i < lent; ++i) {
+      bool eq = baseEqualW(w[i], p[i]);
+      score += eq ? 2 : -2;
+      mm += eq ? 0 : 1;
+      if (align) align[i] = eq ? 0 : 1;
+    }
+    if (score >= lent * 2 - 8) {
+      if (align) align[lent] = -1;
+      nMatch = lent - mm; nMis = mm;
+      return true;
+    }
+  }
+  if (lent > T4_MAXGAP || lenp > T4_MAXGAP) return false;
+  int leftBand = 5, rightBand = 5;
+  if (lent > lenp) rightBand += lent - lenp; else if (lent < lenp) leftBand += lenp - lent;
+  int DW = leftBand + rightBand + 1;
+  if (DW > lent) DW = lent;
+  if ((long long)(lenp + 1) * DW > T4_DIR_BYTES) return false;
+  const int negInf = (lent + 1) * (lenp + 1) * (-4);
+  int pr = 0, cu = 3;
+  int end1 = (1 + rightBand > lent) ? lent : (1 + rightBand);
+  T4_ROW(pr, 0) = 0;
+  for (int j = 1; j <= end1; ++j) T4_ROW(pr, j) = -4 - 4 * j;
+  if (end1 < lent) T4_ROW(pr, end1 + 1) = -4 - 4 * (end1 + 1);
+  for (int i = 1; i <= lenp; ++i) {
+    int start = (i - leftBand < 1) ? 1 : (i - leftBand);
+    int end = (i + rightBand > lent) ? lent : (i + rightBand);
+    if (start > 1) T4_ROW(cu, start - 1) = negInf; else T4_ROW(cu, 0) = -4 - 4 * i;
+    if (end < lent) T4_ROW(cu, end + 1) = negInf;
+    char pc = p[i - 1];
+    int mLeft = T4_ROW(cu, start - 1), mDiag = T4_ROW(pr, start - 1);
+    unsigned char *drow = sc.dir + (size_t)i * DW;
+    for (int j = start; j <= end; ++j) {
+      int mUp = T4_ROW(pr, j);
+      bool eq = baseEqualW(w[j - 1], pc);
+      int dsc = mDiag + (eq ? 2 : -2);
+      int m = dsc;
+      if (mLeft - 4 > m) m = mLeft - 4;
+      if (mUp - 4 > m) m = mUp - 4;
+      T4_ROW(cu, j) = m;
+      drow[j - start] = (unsigned char)((mLeft - 4 == m ? 1 : 0) | (mUp - 4 == m ? 2 : 0) | (dsc == m ? 4 : 0) | (eq ? 8 : 0));
+      mDiag = mUp; mLeft = m;
+    }
+    int tsw = pr; pr = cu; cu = tsw;
+  }
+  int tagi = lenp, tagj = lent, tag = 0;
+  while (tagi > 0 || tagj > 0) {
+    int a = 0;
+    if (tagi > 0 && tagj > 0) {
+      int start = (tagi - leftBand < 1) ? 1 : (tagi - leftBand);
+      unsigned char bits = sc.dir[(size_t)tagi * DW + (tagj - start)];
+      if (bits & 1) a = 3;
+      if (bits & 2) a = 2;
+      if (bits & 4) a = (bits & 8) ? 0 : 1;
+    } else if (tagi == 0) { // row 0: m[0][j] = -4-4j, m[0][0] = 0
+      int mL = (tagj - 1 == 0) ? 0 : (-4 - 4 * (tagj - 1));
+      if (mL - 4 == -4 - 4 * tagj) a = 3;
+    } else {                // column 0
+      int mU = (tagi - 1 == 0) ? 0 : (-4 - 4 * (tagi - 1));
+      if (mU - 4 == -4 - 4 * tagi) a = 2;
+    }
+    if (align) align[tag] = (signed char)a;
+    ++tag;
+    if (a == 0) ++nMatch; else if (a == 1) ++nMis; else ++nIndel;
+    if (a == 3) --tagj; else if (a == 2) --tagi; else { --tagi; --tagj; }
+  }
+  if (align) {
+    align[tag] = -1;
+    for (int i = 0, j = tag - 1; i < j; ++i, --j) { signed char x = align[i]; align[i] = align[j]; align[j] = x; }
+  }
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LIS of one run (SeqSet::LongestIncreasingSubsequence, SeqSet.hpp:342-499), executed by one lane.
+// hits: (b << 12 | a) sorted by (b, a). Returns the chain length; chain written to lisOut.
+// ------------------------------------------------------------------------------------------------
+#define PA(v) ((int)((v) & 0xFFFu))
+#define PB(v) ((int)((v) >> 12))
+__device__ __forceinline__ double dabs(double x) { return x < 0 ? -x : x; }
+
+__device__ int lisLane(const unsigned *hits, int size, unsigned *LIS, unsigned short *top, unsigned short *link) {
+  double avgDiff = 0;
+  for (int i = 1; i < size; ++i) avgDiff += (PA(hits[i]) - PB(hits[i]));
+  avgDiff /= size;
+  int ret = 1;
+  top[0] = 0; link[0] = 0xFFFF;
+  for (int i = 1; i < size; ++i) {
+    int ai = PA(hits[i]);
+    int tag;
+    if (PA(hits[top[ret - 1]]) <= ai) tag = ret - 1;
+    else {
+      int l = 0, r = ret - 1; tag = -2;
+      while (l <= r) {
+        int m = (l + r) / 2;
+        int am = PA(hits[top[m]]);
+        if (ai == am) { tag = m; break; }
+        else if (ai < am) r = m - 1; else l = m + 1;
+      }
+      if (tag == -2) tag = l - 1;
+    }
+    if (tag == -1) { top[0] = (unsigned short)i; link[i] = 0xFFFF; }
+    else {
+      int at = PA(hits[top[tag]]);
+      if (ai > at) {
+        if (tag == ret - 1) { top[ret] = (unsigned short)i; ++ret; link[i] = top[tag]; }
+        else if (ai < PA(hits[top[tag + 1]])) { top[tag + 1] = (unsigned short)i; link[i] = top[tag]; }
+      } else if (ai == at) {
+        unsigned ht = hits[top[tag]];
+        if (dabs(ai - PB(hits[i]) - avgDiff) < dabs(PA(ht) - PB(ht) - avgDiff)) {
+          top[tag] = (unsigned short)i;
+          link[i] = tag > 0 ? top[tag - 1] : (unsigned short)0xFFFF;
+        }
+      }
+    }
+  }
+  int k = top[ret - 1];
+  for (int i = ret - 1; i >= 0; --i) { LIS[i] = hits[k]; k = link[k]; }
+  // collapse equal-b runs (keep the least divergent, first on ties)
+  k = 0;
+  for (int i = 0; i < ret;) {
+    int j;
+    for (j = i + 1; j < ret; ++j) if (PB(LIS[i]) != PB(LIS[j])) break;
+    if (j == i + 1) LIS[k] = LIS[i];
+    else {
+      int mintag = i; double minDiff = dabs(PA(LIS[i]) - PB(LIS[i]) - avgDiff);
+      for (int l = i + 1; l < j; ++l) {
+        double d = dabs(PA(LIS[l]) - PB(LIS[l]) - avgDiff);
+        if (d < minDiff) { minDiff = d; mintag = l; }
+      }
+      LIS[k] = LIS[mintag];
+    }
+    i = j; ++k;
+  }
+  ret = k;
+  // replacement sweep
+  int i = 0, j = 0;
+  while (i < ret && j < size) {
+    unsigned hj = hits[j], li = LIS[i];
+    if (PB(hj) < PB(li)) ++j;
+    else if (i + 1 < ret && PB(LIS[i + 1]) <= PB(hj)) ++i;
+    else if (li == hj) ++j;
+    else {
+      if (PA(li) <= PA(hj) && (i == ret - 1 || PA(hj) < PA(LIS[i + 1])) &&
+          dabs(PA(hj) - PB(hj) - avgDiff) < dabs(PA(li) - PB(li) - avgDiff))
+        LIS[i] = hj;
+      ++j;
+    }
+  }
+  return ret;
+}
+
+// GetTotalHitLengthOnRead / OnSeq (SeqSet.hpp:3330-3367) over a chain
+__device__ __forceinline__ int totalHitLen(const unsigned *c, int n, int K, bool onSeq) {
+  int ret = 0;
+  for (int i = 0; i < n;) {
+    int j;
+    for (j = i + 1; j < n; ++j) {
+      int cur = onSeq ? PB(c[j]) : PA(c[j]), prv = onSeq ? PB(c[j - 1]) : PA(c[j - 1]);
+      if (cur > prv + K - 1) break;
+    }
+    ret += (onSeq ? PB(c[j - 1]) - PB(c[i]) : PA(c[j - 1]) - PA(c[i])) + K;
+    i = j;
+  }
+  return ret;
+}
+
+// overlap record while a read is being processed (10 ints)
+struct OvRec {
+  int seqIdx, rs, re, ss, se;
+  int matchCnt;      // final matchCnt
+  int indelCnt;
+  int chainPos;      // run start index (chain = u32 view of the key array at 2*chainPos)
+  int chainLen;
+  int flags;         // bit0: strand == 1, bit1: similarity forced to 0, bit2: isRef
+};
+#define OV_PLUS 1
+#define OV_SIMZERO 2
+#define OV_ISREF 4
+
+__device__ __forceinline__ double ovSim(const OvRec &o) {
+  if (o.flags & OV_SIMZERO) return 0.0;
+  return (double)o.matchCnt / (double)(o.se - o.ss + 1 + o.re - o.rs + 1);
+}
+// _overlap::operator< (SeqSet.hpp:104-128); `scored` = similarity is meaningful
+__device__ __forceinline__ bool ovLess(const OvRec &a, const OvRec &b, bool scored) {
+  if (a.matchCnt != b.matchCnt) return a.matchCnt > b.matchCnt;
+  if (scored) {
+    double sa = ovSim(a), sb = ovSim(b);
+    if (sa != sb) return sa > sb;
+  }
+  if (a.re - a.rs != b.re - b.rs) return a.re - a.rs > b.re - b.rs;
+  if (a.seqIdx != b.seqIdx) return a.seqIdx < b.seqIdx;
+  int sta = (a.flags & OV_PLUS) ? 1 : -1, stb = (b.flags & OV_PLUS) ? 1 : -1;
+  if (sta != stb) return sta < stb;
+  if (a.rs != b.rs) return a.rs < b.rs;
+  if (a.re != b.re) return a.re < b.re;
+  if (a.ss != b.ss) return a.ss < b.ss;
+  return a.se < b.se;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-wave working set. CAP = hit capacity, MAXOV = overlap capacity. LDS tiers use static
+// __shared__ arrays; the last tier (CAP == 0) works out of per-block global scratch.
+// ------------------------------------------------------------------------------------------------
+struct WaveMem {
+  unsigned long long *keys;  // [cap]   hit keys; later per-run {chain u32[n], top u16[n], link u16[n]}
+  unsigned *pairs;           // [cap]   (b << 12 | a) of candidate runs; first: posPref
+  OvRec *ov;                 // [maxOv] overlaps of the current pass; first: posStart
+  OvRec *fin;                // [maxFin] accumulated final overlaps (annotate) / result (overlaps)
+  unsigned short *ord;       // [maxOv] sort order
+  unsigned *cand;            // [cap / 3 + 1] candidate runs: start | len << 16
+  char *seg, *rc;            // [T4_MAXL + 8] current segment, forward and reverse complement
+  int cap, maxOv, maxFin, candCap;
+};
+
+struct WaveState { // wave-uniform scalars kept in LDS
+  int ovCount, candCount, overflow, unsupported, finCount, nContig;
+  int novelMin[2];
+  short contigA[64], contigB[64];
+};
+
+// Build segment chars (forward + reverse complement of the segment) from the packed read.
+__device__ void loadSegment(const T4BatchView &bv, long long r, int segStart, int segLen, WaveMem &wm) {
+  const unsigned *pk = bv.pk + r * bv.wpk;
+  const unsigned *nm = bv.nm + r * bv.wnm;
+  for (int i = laneId(); i < segLen; i += 64) {
+    int g = segStart + i;
+    unsigned w = pk[g >> 4], m = nm[g >> 5];
+    int code = (w >> ((g & 15) * 2)) & 3;
+    bool isN = (m >> (g & 31)) & 1;
+    char c = isN ? 'N' : (code == 0 ? 'A' : code == 1 ? 'C' : code == 2 ? 'G' : 'T');
+    wm.seg[i] = c;
+    wm.rc[segLen - 1 - i] = isN ? 'N' : (code == 0 ? 'T' : code == 1 ? 'G' : code == 2 ? 'C' : 'A');
+  }
+  if (laneId() == 0) { wm.seg[segLen] = 0; wm.rc[segLen] = 0; }
+  __syncthreads();
+}
+
+// k-mer code at position p of chars S (N -> 0), and whether the window holds an N
+__device__ __forceinline__ unsigned long long kmerAt(const char *S, int p, int K, bool &valid) {
+  unsigned long long code = 0;
+  valid = true;
+  for (int j = 0; j < K; ++j) {
+    char c = S[p + j];
+    if (c == 'N') valid = false;
+    code = (code << 2) | (unsigned long long)nuc2(c);
+  }
+  return code;
+}
+
+// Seed stage of one pass: fills posStart/posPref (aliased on wm.ov / wm.pairs) and returns the number
+// of hit records H that GetHitsFromRead would emit (before the barcode filter). Wave-uniform result.
+// vjOnly only changes the later expansion.
+__device__ int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int strandArg, int barcode,
+                             bool allowTotalSkip, unsigned *posStart, unsigned *posPref) {
+  const int K = ix.k, lane = laneId();
+  const int nk = segLen - K + 1;           // k-mers per strand
+  const unsigned long long mask = K < 32 ? ((1ull << (2 * K)) - 1ull) : ~0ull;
+  int skipLimit = ix.firstIsRef ? 0 : K / 2;
+  // raw list sizes (0 for invalid k-mers) and starts, for both strands
+  int big = 0;
+  for (int q = lane; q < 2 * nk; q += 64) {
+    int st = q >= nk, p = st ? q - nk : q;
+    bool active = st ? (strandArg != 1) : (strandArg != -1);
+    unsigned start = 0, cnt = 0;
+    if (active) {
+      bool valid;
+      unsigned long long code = kmerAt(st ? wm.rc : wm.seg, p, K, valid) & mask;
+      if (valid) indexLookup(ix, code, barcode, start, cnt);
+    }
+    posStart[q] = start; posPref[q] = cnt;
+    if (cnt >= 100) big = 1;
+  }
+  big = __any(big);
+  __syncthreads();
+  if ((skipLimit == 0 && !allowTotalSkip) || !big) {
+    // no `continue` can fire: prevKmerCode is always the code of the previous position
+    for (int q = lane; q < 2 * nk; q += 64) {
+      int st = q >= nk, p = st ? q - nk : q;
+      const char *S = st ? wm.rc : wm.seg;
+      bool emit = true;
+      if (p > 0) {
+        bool v0, v1;
+        unsigned long long c0 = kmerAt(S, p - 1, K, v0) & mask, c1 = kmerAt(S, p, K, v1) & mask;
+        emit = (c0 != c1);
+      }
+      if (!emit) posPref[q] = 0;
+    }
+  } else if (lane == 0) {
+    // sequential replay of the skip state machine (SeqSet.hpp:1370-1425, 1437-1498)
+    unsigned long long prev = 0;
+    for (int st = 0; st < 2; ++st) {
+      bool active = st ? (strandArg != 1) : (strandArg != -1);
+      if (!active) continue;
+      const char *S = st ? wm.rc : wm.seg;
+      unsigned long long code = 0;
+      int skipCnt = 0;
+      for (int i = 0; i < K - 1; ++i) code = ((code << 2) & mask) | (unsigned long long)nuc2(S[i]);
+      for (int i = K - 1; i < segLen; ++i) {
+        code = ((code << 2) & mask) | (unsigned long long)nuc2(S[i]);
+        int p = i - K + 1, q = st * nk + p;
+        unsigned size = posPref[q];
+        bool emit = false;
+        if (p == 0 || prev != code) {
+          if (size >= 100 && p != 0 && i != segLen - 1 && skipCnt < skipLimit) { ++skipCnt; posPref[q] = 0; continue; }
+          if (size >= 100 && allowTotalSkip) { posPref[q] = 0; continue; }
+          skipCnt = 0;
+          emit = true;
+        }
+        if (!emit) posPref[q] = 0;
+        prev = code;
+      }
+    }
+  }
+  __syncthreads();
+  // exclusive prefix sums over the 2*nk positions
+  int carry = 0;
+  for (int q0 = 0; q0 < 2 * nk; q0 += 64) {
+    int q = q0 + lane;
+    int v = q < 2 * nk ? (int)posPref[q] : 0;
+    int inc = waveInclScan(v);
+    if (q < 2 * nk) posPref[q] = (unsigned)(carry + inc - v);
+    carry += __shfl(inc, 63);
+  }
+  if (lane == 0) posPref[2 * nk] = (unsigned)carry;
+  __syncthreads();
+  return carry;
+}
+
+// Expand postings into sortable keys. Returns the number of valid keys (after barcode / VJ filters);
+// invalid slots get the all-ones key and sort to the end.
+__device__ int expandHits(const T4IndexView &ix, WaveMem &wm, int nk, int H, int barcode, bool vjOnly,
+                          const unsigned *posStart, const unsigned *posPref) {
+  const int lane = laneId();
+  int dropped = 0;
+  for (int s = lane; s < H; s += 64) {
+    int lo = 0, hi = 2 * nk - 1;   // last q with posPref[q] <= s
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (posPref[mid] <= (unsigned)s) lo = mid; else hi = mid - 1;
+    }
+    int q = lo;
+    int2 po = ix.post[posStart[q] + ((unsigned)s - posPref[q])];
+    int st = q >= nk, a = st ? q - nk : q;
+    bool keep = true;
+    T4SeqInfo si = ix.seqs[po.x];
+    if (barcode != -1 && si.barcode != barcode) keep = false;
+    if (vjOnly) { // GetVJOverlapsFromHits (SeqSet.hpp:1075-1089)
+      if (!si.isRef) keep = false;
+      else if (si.name3 == 'V') { if (!(po.y >= si.len - 31)) keep = false; }
+      else if (si.name3 == 'J') { if (!(po.y < 31)) keep = false; }
+      else keep = false;
+    }
+    unsigned long long key = ~0ull;
+    if (keep) {
+      unsigned long long sb = st ? 0ull : 1ull;  // minus strand sorts first
+      key = (sb << 63) | ((unsigned long long)po.x << (T4_C_BITS + T4_B_BITS)) |
+            ((unsigned long long)(a - po.y + T4_C_BIAS) << T4_B_BITS) | (unsigned long long)po.y;
+    } else ++dropped;
+    wm.keys[s] = key;
+  }
+  dropped = waveSum(dropped);
+  return H - dropped;
+}
+
+// wave-cooperative bitonic sort of n2 (power of two) 64-bit keys
+__device__ void bitonicSort(unsigned long long *keys, int n2) {
+  const int lane = laneId();
+  for (int k = 2; k <= n2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = lane; t < (n2 >> 1); t += 64) {
+        int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        int p = i | j;
+        bool up = (i & k) == 0;
+        unsigned long long a = keys[i], b = keys[p];
+        if ((a > b) == up) { keys[i] = b; keys[p] = a; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+#define KEY_G(k) ((unsigned)((k) >> (T4_C_BITS + T4_B_BITS)))
+#define KEY_IDX(k) ((int)(((k) >> (T4_C_BITS + T4_B_BITS)) & ((1u << T4_IDX_BITS) - 1)))
+#define KEY_PLUS(k) ((int)((k) >> 63))
+#define KEY_C(k) ((int)(((k) >> T4_B_BITS) & ((1u << T4_C_BITS) - 1)))
+#define KEY_B(k) ((int)((k) & ((1u << T4_B_BITS) - 1)))
+
+// Chain one run [s, s+n) whose pairs are already in wm.pairs sorted by (b, a); append the overlap.
+__device__ void chainRun(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int s, int n, int seqIdx, int plus,
+                         bool isRef, int hitLenRequired) {
+  const int K = ix.k;
+  unsigned *lisOut = (unsigned *)(wm.keys + s);
+  unsigned short *top = (unsigned short *)(lisOut + n);
+  unsigned short *link = top + n;
+  int lisSize = lisLane(wm.pairs + s, n, lisOut, top, link);
+  if (lisSize * K < hitLenRequired) return;
+  int hitLen = totalHitLen(lisOut, lisSize, K, false);
+  if (hitLen < hitLenRequired) return;
+  if (totalHitLen(lisOut, lisSize, K, true) < hitLenRequired) return;
+  OvRec o;
+  o.seqIdx = seqIdx;
+  o.rs = PA(lisOut[0]); o.re = PA(lisOut[lisSize - 1]) + K - 1;
+  o.ss = PB(lisOut[0]); o.se = PB(lisOut[lisSize - 1]) + K - 1;
+  o.matchCnt = 2 * hitLen; o.indelCnt = 0;
+  o.chainPos = s; o.chainLen = lisSize;
+  o.flags = (plus ? OV_PLUS : 0) | (isRef ? OV_ISREF : 0) | OV_SIMZERO;
+  if (!isRef && hitLen * 2 < o.se - o.ss + 1) return;
+  int slot = atomicAdd(&ws->ovCount, 1);
+  if (slot < wm.maxOv) wm.ov[slot] = o; else ws->overflow = 1;
+}
+
+
+// GetOverlapsFromHits (SeqSet.hpp:763-1063) on the sorted keys [0, Hv). Overlaps land in wm.ov.
+// `filter` is the reference's filter argument. removeOnlyRepeats needs a hit with repeats > 10000,
+// impossible while H <= 65535 only if ... it is handled by the caller refusing such reads (status).
+__device__ void overlapsFromKeys(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int Hv, int hitLenRequired, int filter) {
+  const int lane = laneId(), K = ix.k;
+  if (lane == 0) {
+    ws->novelMin[0] = ws->novelMin[1] = 3;
+    ws->candCount = 0;
+    if (filter == 1 && ix.hasNovel) {
+      // group statistics with the reference's `i = j` + `++i` stepping (SeqSet.hpp:784-811)
+      int possible[2] = {0, 0}, longest[2] = {0, 0};
+      for (int i = 0; i < Hv; ++i) {
+        unsigned g = KEY_G(wm.keys[i]);
+        int j;
+        for (j = i + 1; j < Hv; ++j) if (KEY_G(wm.keys[j]) != g) break;
+        int plus = KEY_PLUS(wm.keys[i]);
+        if (!ix.seqs[KEY_IDX(wm.keys[i])].isRef) {
+          if (j - i > 3) ++possible[plus];
+          if (j - i > longest[plus]) longest[plus] = j - i;
+        }
+        i = j;
+      }
+      for (int t = 0; t <= 1; ++t) {
+        if (possible[t] > 100000) ws->novelMin[t] = (int)(longest[t] * 0.75);
+        else if (possible[t] > 10000) ws->novelMin[t] = longest[t] / 2;
+        else if (possible[t] > 1000) ws->novelMin[t] = longest[t] / 3;
+        else if (possible[t] > 100) ws->novelMin[t] = longest[t] / 4;
+      }
+    }
+  }
+  __syncthreads();
+  // R1: every hit that starts a run measures it; qualifying runs become candidates
+  for (int i0 = 0; i0 < Hv; i0 += 64) {
+    int i = i0 + lane;
+    if (i < Hv) {
+      unsigned long long ki = wm.keys[i];
+      int idx = KEY_IDX(ki), plus = KEY_PLUS(ki);
+      bool isRef = ix.seqs[idx].isRef != 0;
+      int adjustRadius = isRef ? ix.radius : 0;
+      bool runStart = true;
+      if (i > 0) {
+        unsigned long long kp = wm.keys[i - 1];
+        if (KEY_G(kp) == KEY_G(ki) && KEY_C(ki) - KEY_C(kp) <= adjustRadius) runStart = false;
+      }
+      if (runStart) {
+        int e = i + 1, cprev = KEY_C(ki);
+        while (e < Hv) {
+          unsigned long long ke = wm.keys[e];
+          if (KEY_G(ke) != KEY_G(ki)) break;
+          int ce = KEY_C(ke);
+          if (ce - cprev > adjustRadius) break;
+          cprev = ce; ++e;
+        }
+        int n = e - i;
+        int minHit = isRef ? 3 : ws->novelMin[plus];
+        if (n >= minHit && n * K >= hitLenRequired) {
+          int slot = atomicAdd(&ws->candCount, 1);
+          if (slot < wm.candCap) wm.cand[slot] = (unsigned)i | ((unsigned)n << 16);
+          else ws->overflow = 1;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int nCand = ws->candCount < wm.candCap ? ws->candCount : wm.candCap;
+  // R2: one lane per candidate run: extract (b << 12 | a), order by (b, a), chain
+  for (int c = lane; c < nCand; c += 64) {
+    int s = wm.cand[c] & 0xFFFF, n = wm.cand[c] >> 16;
+    unsigned long long ks = wm.keys[s];
+    int idx = KEY_IDX(ks), plus = KEY_PLUS(ks);
+    bool isRef = ix.seqs[idx].isRef != 0;
+    int adjustRadius = isRef ? ix.radius : 0;
+    if (adjustRadius > 0 && n > 48) continue;  // long multi-diagonal run: cooperative path below
+    for (int t = s; t < s + n; ++t) {
+      unsigned long long kt = wm.keys[t];
+      int b = KEY_B(kt), a = KEY_C(kt) - T4_C_BIAS + b;
+      wm.pairs[t] = ((unsigned)b << 12) | (unsigned)a;
+    }
+    if (adjustRadius > 0) { // insertion sort by (b, a): a run is a union of a few diagonals
+      for (int t = s + 1; t < s + n; ++t) {
+        unsigned v = wm.pairs[t];
+        int u = t - 1;
+        while (u >= s && wm.pairs[u] > v) { wm.pairs[u + 1] = wm.pairs[u]; --u; }
+        wm.pairs[u + 1] = v;
+      }
+    }
+    chainRun(ix, wm, ws, s, n, idx, plus, isRef, hitLenRequired);
+  }
+  __syncthreads();
+  // R3: long runs, rank-sorted by the whole wave, then chained by one lane each
+  if (ix.radius > 0) {
+    for (int c = 0; c < nCand; ++c) {
+      int s = wm.cand[c] & 0xFFFF, n = wm.cand[c] >> 16;
+      if (n <= 48) continue;                                  // wave-uniform
+      unsigned long long ks = wm.keys[s];
+      if (!ix.seqs[KEY_IDX(ks)].isRef) continue;              // wave-uniform
+      unsigned *tmp = (unsigned *)(wm.keys + s) + n;          // upper half of the run's own key area
+      for (int t = lane; t < n; t += 64) {
+        unsigned long long kt = wm.keys[s + t];
+        int b = KEY_B(kt), a = KEY_C(kt) - T4_C_BIAS + b;
+        wm.pairs[s + t] = ((unsigned)b << 12) | (unsigned)a;
+      }
+      __syncthreads();
+      // keys[s] still carries the group id in its low half only if tmp does not touch it: tmp starts
+      // at u32 index n >= 49 of the run area, keys[s] is u32 index 0..1 -> untouched.
+      for (int t = lane; t < n; t += 64) {
+        unsigned v = wm.pairs[s + t];
+        int rank = 0;
+        for (int u = 0; u < n; ++u) { unsigned x = wm.pairs[s + u]; rank += (x < v) ? 1 : 0; }
+        tmp[rank] = v;                                        // pairs of one run are distinct
+      }
+      __syncthreads();
+      for (int t = lane; t < n; t += 64) wm.pairs[s + t] = tmp[t];
+      __syncthreads();
+    }
+    for (int c = lane; c < nCand; c += 64) {
+      int s = wm.cand[c] & 0xFFFF, n = wm.cand[c] >> 16;
+      if (n <= 48) continue;
+      unsigned long long ks = wm.keys[s];
+      int idx = KEY_IDX(ks), plus = KEY_PLUS(ks);
+      if (!ix.seqs[idx].isRef) continue;
+      chainRun(ix, wm, ws, s, n, idx, plus, true, hitLenRequired);
+    }
+    __syncthreads();
+  }
+}
+
+// IsOverlapLowComplex (SeqSet.hpp:590-617)
+__device__ __forceinline__ bool lowComplex(const char *r, int rs, int re) {
+  int cnt[4] = {0, 0, 0, 0};
+  for (int i = rs; i <= re; ++i) {
+    char c = r[i];
+    if (c == 'N') continue;
+    int n = nuc2(c);
+    cnt[0] += n == 0; cnt[1] += n == 1; cnt[2] += n == 2; cnt[3] += n == 3;
+  }
+  int lowCnt = 0, lowTotal = 0;
+  for (int i = 0; i < 4; ++i) if (cnt[i] <= 2) { ++lowCnt; lowTotal += cnt[i]; }
+  if (lowTotal * 7 >= re - rs + 1) return false;
+  return lowCnt >= 2;
+}
+
+// Anchor walk + gap DPs of one overlap (SeqSet.hpp:1829-2019). One lane.
+__device__ void scoreOverlap(const T4IndexView &ix, WaveMem &wm, WaveState *ws, OvRec &o, DPScratch sc, int lane) {
+  const int K = ix.k;
+  const char *r = (o.flags & OV_PLUS) ? wm.seg : wm.rc;
+  const T4SeqInfo si = ix.seqs[o.seqIdx];
+  const bool isRef = si.isRef != 0;
+  const unsigned *hc = (const unsigned *)(wm.keys + o.chainPos);
+  int matchCnt = 2 * K, indelCnt = 0;
+  bool simOne = true;
+  for (int j = 1; j < o.chainLen; ++j) {
+    int pa = PA(hc[j - 1]), pb = PB(hc[j - 1]), qa = PA(hc[j]), qb = PB(hc[j]);
+    int doDP = 0;
+    if (pb - pa == qb - qa) {
+      if (pa + K - 1 >= qa) matchCnt += 2 * (qa - pa);
+      else { matchCnt += 2 * K; doDP = 1; }
+    } else {
+      if (ix.radius == 0 || !isRef) { simOne = false; break; }
+      if (pa + K - 1 >= qa && pb + K - 1 < qb) { matchCnt += 2 * (qa - pa); indelCnt += (qb - (pb + K) + (qa + K - pa)); }
+      else if (pa + K - 1 < qa && pb + K - 1 >= qb) { matchCnt += 2 * (qb - pb); indelCnt += (qa - (pa + K) + (qb + K - pb)); }
+      else if (pa + K - 1 >= qa && pb + K - 1 >= qb) {
+        int da = qa - pa, db = qb - pb;
+        matchCnt += 2 * (da < db ? da : db);
+        int d = (qa - qb) - (pa - pb);
+        indelCnt += d < 0 ? -d : d;
+      } else { matchCnt += 2 * K; doDP = 2; }
+    }
+    if (doDP) {
+      int lent = qb - (pb + K), lenp = qa - (pa + K);
+      if (lent > ix.nomatchGapLimit || lenp > ix.nomatchGapLimit) { simOne = false; break; }
+      int c0, c1, c2;
+      bool ok;
+      if (isRef) ok = dpAffine(ix.cons + si.consOff + pb + K, lent, r + pa + K, lenp, sc, lane, c0, c1, c2);
+      else ok = dpPosWeight(ix.pw + si.pwOff + pb + K, lent, r + pa + K, lenp, sc, lane, c0, c1, c2, (signed char *)0);
+      if (!ok) { ws->unsupported = 1; simOne = false; break; }
+      matchCnt += 2 * c0; indelCnt += c2;
+      if (doDP == 1) { if ((ix.radius == 0 || !isRef) && indelCnt > 0) { simOne = false; break; } }
+      else { if (!isRef && indelCnt > 0) { simOne = false; break; } }
+    }
+  }
+  o.matchCnt = matchCnt; o.indelCnt = indelCnt;
+  if (simOne) o.flags &= ~OV_SIMZERO; else o.flags |= OV_SIMZERO;
+  if (lowComplex(r, o.rs, o.re)) o.flags |= OV_SIMZERO;
+}
+
+// GetVJOverlapsFromHits' pair selection (SeqSet.hpp:1093-1160) on wm.ov[0..n). One lane. Returns 0 or 2
+// and leaves the chosen pair in wm.ov[0], wm.ov[1].
+__device__ int selectVJPair(const T4IndexView &ix, WaveMem &wm, int n) {
+  int maxMatch = 0, tagi = 0, tagj = 0;
+  for (int i = 0; i < n; ++i)
+    for (int j = i + 1; j < n; ++j) {
+      T4SeqInfo a = ix.seqs[wm.ov[i].seqIdx], b = ix.seqs[wm.ov[j].seqIdx];
+      if (a.name0 != b.name0 || a.name1 != b.name1 || a.name2 != b.name2 || a.name3 == b.name3) continue;
+      if (a.name3 == 'V') { if (wm.ov[i].rs > wm.ov[j].rs) continue; }
+      else { if (wm.ov[i].rs < wm.ov[j].rs) continue; }
+      if (wm.ov[i].matchCnt + wm.ov[j].matchCnt > maxMatch) { maxMatch = wm.ov[i].matchCnt + wm.ov[j].matchCnt; tagi = i; tagj = j; }
+    }
+  if (maxMatch == 0) return 0;
+  OvRec a = wm.ov[tagi], b = wm.ov[tagj];
+  wm.ov[0] = a; wm.ov[1] = b;
+  return 2;
+}
+
+// One GetHitsFromRead + GetOverlapsFromHits pass over the current segment. Returns H (hit records
+// emitted by the seed stage) or -1 on capacity overflow. Overlaps are left in wm.ov / ws->ovCount.
+__device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int segLen, int strandArg, int barcode,
+                             bool allowTotalSkip, bool vjOnly, int hitLenRequired, int filter) {
+  const int lane = laneId();
+  unsigned *posStart = (unsigned *)wm.ov;   // dead before the first overlap record is written
+  unsigned *posPref = wm.pairs;             // dead before the first pair is written
+  const int nk = segLen - ix.k + 1;
+  if (lane == 0) ws->ovCount = 0;
+  int H = seedPositions(ix, wm, segLen, strandArg, barcode, allowTotalSkip, posStart, posPref);
+  if (H > wm.cap) return -1;
+  int Hv = expandHits(ix, wm, nk, H, barcode, vjOnly, posStart, posPref);
+  int n2 = 1;
+  while (n2 < H) n2 <<= 1;
+  for (int s = H + lane; s < n2; s += 64) wm.keys[s] = ~0ull;   // n2 <= cap: caps are powers of two
+  __syncthreads();
+  if (H > 1) bitonicSort(wm.keys, n2);
+  overlapsFromKeys(ix, wm, ws, Hv, hitLenRequired, filter);
+  return H;
+}
+
+// SeqSet::GetOverlapsFromRead (SeqSet.hpp:1508-2124, readType 0) for the segment in wm.seg / wm.rc.
+// Scored and filtered overlaps are appended to wm.fin (coordinates shifted by `shift`).
+// Returns the reference's return value (-1, 0 or the overlap count); -2 on capacity overflow.
+__device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int segLen, int strandArg, int barcode,
+                                   bool skipRepeats, int shift, DPScratch sc, unsigned long long &hitTotal) {
+  const int lane = laneId();
+  if (segLen < ix.k) return -1;
+  int overlapCnt = 0;
+  if (skipRepeats) {
+    int H = seedChainPass(ix, wm, ws, segLen, strandArg, barcode, true, false, ix.hitLenRequired, 0);
+    if (H < 0) return -2;
+    hitTotal += (unsigned long long)H;
+    __syncthreads();
+    overlapCnt = ws->ovCount;
+  }
+  if (overlapCnt == 0) {
+    __syncthreads();
+    int H = seedChainPass(ix, wm, ws, segLen, strandArg, barcode, false, false, ix.hitLenRequired, 1);
+    if (H < 0) return -2;
+    hitTotal += (unsigned long long)H;
+    __syncthreads();
+    overlapCnt = ws->ovCount;
+    if (overlapCnt == 0) {
+      // VJ junction rescue on the hits of this pass (SeqSet.hpp:1570-1575)
+      __syncthreads();
+      int H2 = seedChainPass(ix, wm, ws, segLen, strandArg, barcode, false, true, 17, 0);
+      if (H2 < 0) return -2;
+      __syncthreads();
+      int n = ws->ovCount;
+      if (n > wm.maxOv) return -2;
+      if (lane == 0) ws->ovCount = selectVJPair(ix, wm, n);
+      __syncthreads();
+      overlapCnt = ws->ovCount;
+      if (overlapCnt == 0) return 0;
+    }
+  }
+  if (ws->overflow || overlapCnt > wm.maxOv) return -2;
+  // std::sort(overlaps) by operator< : rank sort (the order is total on distinct overlaps)
+  for (int i = lane; i < overlapCnt; i += 64) {
+    OvRec me = wm.ov[i];
+    int rank = 0;
+    for (int j = 0; j < overlapCnt; ++j) {
+      if (j == i) continue;
+      OvRec ot = wm.ov[j];
+      if (ovLess(ot, me, false) || (!ovLess(me, ot, false) && j < i)) ++rank;
+    }
+    wm.ord[rank] = (unsigned short)i;
+  }
+  __syncthreads();
+  // keep the overlaps on the strand of the best one (SeqSet.hpp:1601-1616), order preserved
+  int strand0 = wm.ov[wm.ord[0]].flags & OV_PLUS;
+  int kept = 0;
+  for (int i0 = 0; i0 < overlapCnt; i0 += 64) {
+    int i = i0 + lane;
+    int o = i < overlapCnt ? wm.ord[i] : 0;
+    bool keep = i < overlapCnt && ((wm.ov[o].flags & OV_PLUS) == strand0);
+    unsigned long long m = __ballot(keep);
+    int pos = kept + __popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();
+    if (keep) wm.ord[pos] = (unsigned short)o;   // pos <= i: compaction in place, chunk by chunk
+    kept += __popcll(m);
+    __syncthreads();
+  }
+  overlapCnt = kept;
+  // score every kept overlap (one lane each)
+  for (int i = lane; i < overlapCnt; i += 64) {
+    OvRec o = wm.ov[wm.ord[i]];
+    int m0 = o.matchCnt;
+    scoreOverlap(ix, wm, ws, o, sc, lane);
+    o.chainLen = m0;                       // chain no longer needed: keep the pre-score matchCnt here
+    wm.ov[wm.ord[i]] = o;
+  }
+  __syncthreads();
+  if (ix.hasNovel && overlapCnt > 50) {
+    // the fast pre-filters against the best novel overlap (SeqSet.hpp:1705-1794) are order dependent:
+    // replay them sequentially over the already scored list
+    if (lane == 0) {
+      int best = -1;
+      const int len = segLen;
+      for (int i = 0; i < overlapCnt; ++i) {
+        OvRec &o = wm.ov[wm.ord[i]];
+        bool isRef = (o.flags & OV_ISREF) != 0;
+        if (!isRef && best != -1) {
+          const OvRec &bn = wm.ov[wm.ord[best]];
+          double bs = ovSim(bn);
+          int m0 = o.chainLen;
+          bool cut = false;
+          if (bn.rs == 0 && bn.re == len - 1) {
+            if (bs == 1) cut = true;
+            else if (bs > ix.repeatSim && m0 < 0.9 * bn.matchCnt) cut = true;
+          }
+          if (!cut && bn.rs + len - 1 - bn.re < ix.radius) {
+            if (bs == 1 && m0 < 0.9 * bn.matchCnt) cut = true;
+            else if (bs > ix.repeatSim && m0 < 0.8 * bn.matchCnt) cut = true;
+          }
+          if (!cut && o.ss - o.rs >= ix.radius && o.se + (len - 1 - o.re) + ix.radius < ix.seqs[o.seqIdx].len &&
+              bn.matchCnt > 0.97 * (2 * len) && bs > ix.repeatSim && m0 < 0.9 * bn.matchCnt) cut = true;
+          if (!cut && m0 < 0.4 * bn.matchCnt) cut = true;
+          if (!cut && overlapCnt > 1000 && m0 < 0.9 * bn.matchCnt) cut = true;
+          if (cut) { o.matchCnt = m0; o.indelCnt = 0; o.flags |= OV_SIMZERO; continue; }
+        }
+        if (!isRef && !(o.flags & OV_SIMZERO) && ovSim(o) > 0) {
+          if (best == -1 || ovLess(o, wm.ov[wm.ord[best]], true)) best = i;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // similarity thresholds (SeqSet.hpp:2105-2119), order preserved; append to fin
+  int base = ws->finCount;
+  int outCnt = 0;
+  for (int i0 = 0; i0 < overlapCnt; i0 += 64) {
+    int i = i0 + lane;
+    bool keep = false;
+    OvRec o;
+    if (i < overlapCnt) {
+      o = wm.ov[wm.ord[i]];
+      double sim = ovSim(o);
+      keep = (o.flags & OV_ISREF) ? !(sim < ix.refSim) : !(sim < ix.novelSim);
+    }
+    unsigned long long m = __ballot(keep);
+    int pos = base + outCnt + __popcll(m & ((1ull << lane) - 1ull));
+    if (keep) {
+      if (pos < wm.maxFin) { o.rs += shift; o.re += shift; o.chainLen = 0; wm.fin[pos] = o; }
+      else ws->overflow = 1;
+    }
+    outCnt += __popcll(m);
+  }
+  __syncthreads();
+  if (lane == 0) ws->finCount = base + outCnt;
+  __syncthreads();
+  if (ws->overflow) return -2;
+  return outCnt;
+}
+
+
+__device__ __forceinline__ void storeOverlap(T4OverlapOut *dst, const OvRec &o) {
+  T4OverlapOut t;
+  t.seqIdx = o.seqIdx; t.readStart = o.rs; t.readEnd = o.re; t.seqStart = o.ss; t.seqEnd = o.se;
+  t.strand = (o.flags & OV_PLUS) ? 1 : -1; t.matchCnt = o.matchCnt; t.indelCnt = o.indelCnt;
+  t.similarity = ovSim(o);
+  *dst = t;
+}
+
+// GetContigIntervals (SeqSet.hpp:5289-5321) on the whole read in wm.seg. One lane.
+__device__ void contigIntervals(const char *read, int gapN, WaveState *ws) {
+  int n = 0;
+  for (int i = 0; read[i];) {
+    int NCnt = 0, j;
+    for (j = i + 1; read[j]; ++j) {
+      if (j >= i + gapN && read[j - gapN] == 'N') --NCnt;
+      if (read[j] == 'N') ++NCnt;
+      if (NCnt >= gapN) break;
+    }
+    if (n < 64) { ws->contigA[n] = (short)i; ws->contigB[n] = (short)(read[j] ? j - gapN : j - 1); }
+    ++n;
+    if (!read[j]) break;
+    i = j + 1;
+  }
+  ws->nContig = n;
+}
+
+// The level-0 part of SeqSet::AnnotateRead after the per-contig overlaps are known
+// (SeqSet.hpp:6167-6321). fin[0..n) holds all contigs' overlaps; ord = their sorted order.
+// `kept` is scratch for n ints. One lane. Writes the four gene overlaps.
+__device__ void annotateSelect(const T4IndexView &ix, WaveMem &wm, int n, int readLen, int *kept, T4OverlapOut *out) {
+  int g[4] = {-1, -1, -1, -1};
+  int k = 0;
+  for (int i = 0; i < n; ++i) {
+    int oi = wm.ord[i];
+    const OvRec &o = wm.fin[oi];
+    T4SeqInfo si = ix.seqs[o.seqIdx];
+    int gt = si.geneType == 255 ? -1 : si.geneType;
+    if (gt < 0 || gt == 1) continue;
+    int used = -1;
+    for (int j = 0; j < k; ++j) if (wm.fin[kept[j]].seqIdx == o.seqIdx) { used = j; break; }
+    double sim = ovSim(o);
+    if (used == -1 && sim >= 0.8) { kept[k++] = oi; }
+    else if (used != -1 && gt == 2) {
+      const OvRec &base = wm.fin[kept[used]];
+      if (o.matchCnt == base.matchCnt && sim == ovSim(base)) {
+        int j;
+        for (j = 0; j < k; ++j) if (ix.seqs[wm.fin[kept[j]].seqIdx].geneType == 3) break;
+        if (j < k) {
+          const OvRec &c = wm.fin[kept[j]];
+          if (o.re <= c.rs + 3) {
+            int d1 = o.re - c.rs, d2 = base.re - c.rs;
+            if (d1 < 0) d1 = -d1;
+            if (d2 < 0) d2 = -d2;
+            if (base.re > c.rs + 3 || d1 < d2) kept[used] = oi;
+          }
+        }
+      }
+    }
+  }
+  if (k > 0) {
+    char BT = 0, chain = 0;
+    for (int i = 0; i < k; ++i) {
+      const OvRec &o = wm.fin[kept[i]];
+      T4SeqInfo si = ix.seqs[o.seqIdx];
+      char n0 = (char)si.name0, n2 = (char)si.name2;
+      if (BT && n0 != BT) continue;
+      BT = n0;
+      if (chain && !(n2 == chain || (n2 == 'D' && chain == 'A') || (n2 == 'A' && chain == 'D'))) continue;
+      chain = n2;
+      int gt = si.geneType == 255 ? -1 : si.geneType;
+      if (gt >= 0 && g[gt] == -1) g[gt] = kept[i];
+    }
+    if (g[3] != -1) {
+      const OvRec &c = wm.fin[g[3]];
+      if (c.re - c.rs + 1 <= readLen / 2 && c.re - c.rs + 1 <= 50) {
+        for (int i = 0; i < 3; ++i) {
+          if (g[i] < 0) continue;
+          const OvRec &x = wm.fin[g[i]];
+          if ((x.re - 17 > c.rs || c.re < x.re) && c.ss >= 100) { g[3] = -1; break; }
+        }
+      }
+    }
+  }
+  for (int t = 0; t < 4; ++t) {
+    if (g[t] >= 0) storeOverlap(out + t, wm.fin[g[t]]);
+    else {
+      T4OverlapOut z;
+      z.seqIdx = -1; z.readStart = z.readEnd = z.seqStart = z.seqEnd = -1; z.strand = 1; z.matchCnt = 0; z.indelCnt = 0; z.similarity = 0;
+      out[t] = z;
+    }
+  }
+}
+
+// Process one read in one wavefront. Returns false when the read has to move to a larger tier.
+__device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const T4Work &wk, const T4QueryArgs &qa,
+                            WaveMem &wm, WaveState *ws, long long r, DPScratch sc) {
+  const int lane = laneId();
+  const int len = bv.len[r];
+  unsigned long long hitTotal = 0;
+  if (lane == 0) { ws->overflow = 0; ws->unsupported = 0; ws->finCount = 0; ws->nContig = 0; ws->ovCount = 0; }
+  __syncthreads();
+  if (qa.mode == 0) {
+    int barcode = bv.barcode ? bv.barcode[r] : -1;
+    loadSegment(bv, r, 0, len, wm);
+    int ret = overlapsFromSegment(ix, wm, ws, len, qa.strand, barcode, qa.skipRepeats != 0, 0, sc, hitTotal);
+    if (ret == -2) return false;
+    int n = ret > 0 ? ret : 0;
+    if (lane == 0) qa.counts[r] = ret;
+    for (int i = lane; i < n && i < qa.maxPerRead; i += 64) storeOverlap(qa.out + r * qa.maxPerRead + i, wm.fin[i]);
+  } else {
+    loadSegment(bv, r, 0, len, wm);
+    if (lane == 0) contigIntervals(wm.seg, 7, ws);
+    __syncthreads();
+    int nContig = ws->nContig;
+    if (nContig > 64) { if (lane == 0) wk.status[r] = 1; return true; }
+    for (int c = 0; c < nContig; ++c) {
+      int a = ws->contigA[c], b = ws->contigB[c];
+      if (nContig > 1 || a != 0 || b != len - 1) { __syncthreads(); loadSegment(bv, r, a, b - a + 1, wm); }
+      int ret = overlapsFromSegment(ix, wm, ws, b - a + 1, 0, -1, false, a, sc, hitTotal);
+      if (ret == -2) return false;
+      __syncthreads();
+    }
+    int n = ws->finCount;
+    for (int i = lane; i < n; i += 64) {
+      OvRec me = wm.fin[i];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) {
+        if (j == i) continue;
+        OvRec ot = wm.fin[j];
+        if (ovLess(ot, me, true) || (!ovLess(me, ot, true) && j < i)) ++rank;
+      }
+      wm.ord[rank] = (unsigned short)i;
+    }
+    __syncthreads();
+    if (lane == 0) annotateSelect(ix, wm, n, len, (int *)wm.cand, qa.out + r * 4);
+  }
+  __syncthreads();
+  if (lane == 0) {
+    if (ws->unsupported) wk.status[r] = 1;
+    atomicAdd(wk.hitCounter, hitTotal);
+  }
+  return true;
+}
+
+// The query kernel. CAP > 0: LDS tier; CAP == 0: global-scratch tier. Persistent grid, one wave/block.
+template <int CAP, int MAXOV>
+__global__ __launch_bounds__(64) void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
+  constexpr int C = CAP > 0 ? CAP : 1;
+  constexpr int M = CAP > 0 ? MAXOV : 1;
+  __shared__ unsigned long long s_keys[C];
+  __shared__ unsigned s_pairs[C];
+  __shared__ unsigned s_cand[C / 3 + 2];
+  __shared__ OvRec s_ov[M];
+  __shared__ OvRec s_fin[M];
+  __shared__ unsigned short s_ord[M];
+  __shared__ char s_seg[T4_MAXL + 8];
+  __shared__ char s_rc[T4_MAXL + 8];
+  __shared__ WaveState s_ws;
+  WaveMem wm;
+  if (CAP > 0) {
+    wm.keys = s_keys; wm.pairs = s_pairs; wm.cand = s_cand; wm.ov = s_ov; wm.fin = s_fin; wm.ord = s_ord;
+    wm.cap = CAP; wm.maxOv = MAXOV; wm.maxFin = MAXOV; wm.candCap = C / 3 + 2;
+  } else {
+    size_t b = blockIdx.x;
+    wm.keys = wk.gKeys + b * (size_t)wk.gCap;
+    wm.pairs = wk.gPairs + b * (size_t)wk.gCap;
+    wm.cand = wk.gCand + b * (size_t)wk.gCap;
+    wm.ov = (OvRec *)(wk.gOv + b * (size_t)wk.gMaxOv * 10);
+    wm.fin = (OvRec *)(wk.gFin + b * (size_t)wk.gMaxOv * 10);
+    wm.ord = wk.gOrd + b * (size_t)wk.gMaxOv;
+    wm.cap = wk.gCap; wm.maxOv = wk.gMaxOv; wm.maxFin = wk.gMaxOv; wm.candCap = wk.gCap;
+  }
+  wm.seg = s_seg; wm.rc = s_rc;
+  DPScratch sc;
+  sc.rows = wk.dpRows + (size_t)blockIdx.x * (6 * T4_ROWW * 64);
+  sc.dir = wk.dpDir + ((size_t)blockIdx.x * 64 + laneId()) * T4_DIR_BYTES;
+  for (int w = blockIdx.x; w < wk.nList; w += gridDim.x) {
+    long long r = wk.list[w];
+    bool done = processRead(ix, bv, wk, qa, wm, &s_ws, r, sc);
+    if (!done && laneId() == 0) {
+      if (wk.nextList) { int slot = atomicAdd(wk.nextCount, 1); wk.nextList[slot] = (int)r; }
+      else wk.status[r] = 2;
+    }
+    __syncthreads();
+  }
+}
+
+// Tiering: estimate H of every read (whole read, both strands) and bin the reads by capacity.
+__global__ __launch_bounds__(64) void binKernel(T4IndexView ix, T4BatchView bv, int useBarcode, int cap0, int cap1, int cap2,
+                                               int *lists, int *counts, long long listStride) {
+  __shared__ unsigned s_posStart[T4_MAXPOS + 8];
+  __shared__ unsigned s_posPref[T4_MAXPOS + 8];
+  __shared__ char s_seg[T4_MAXL + 8];
+  __shared__ char s_rc[T4_MAXL + 8];
+  WaveMem wm;
+  wm.seg = s_seg; wm.rc = s_rc;
+  for (long long r = blockIdx.x; r < bv.n; r += gridDim.x) {
+    int len = bv.len[r];
+    int H = 0;
+    if (len >= ix.k) {
+      loadSegment(bv, r, 0, len, wm);
+      int barcode = (useBarcode && bv.barcode) ? bv.barcode[r] : -1;
+      H = seedPositions(ix, wm, len, 0, barcode, false, s_posStart, s_posPref);
+    }
+    if (laneId() == 0) {
+      int t = H <= cap0 ? 0 : H <= cap1 ? 1 : H <= cap2 ? 2 : 3;
+      int slot = atomicAdd(&counts[t], 1);
+      lists[t * listStride + slot] = (int)r;
+    }
+    __syncthreads();
+  }
+}
+
+// t4_hits: GetHitsFromRead + SortHits. pass 0 counts the hits per read, pass 1 writes them.
+__global__ __launch_bounds__(64) void hitsKernel(T4IndexView ix, T4BatchView bv, int strandArg, int allowTotalSkip, int pass,
+                                                long long *offsets, T4HitOut *out, unsigned long long *gKeys, int gCap, int *status) {
+  __shared__ unsigned s_posStart[T4_MAXPOS + 8];
+  __shared__ unsigned s_posPref[T4_MAXPOS + 8];
+  __shared__ char s_seg[T4_MAXL + 8];
+  __shared__ char s_rc[T4_MAXL + 8];
+  WaveMem wm;
+  wm.seg = s_seg; wm.rc = s_rc;
+  wm.keys = gKeys + (size_t)blockIdx.x * gCap;
+  const int lane = laneId();
+  for (long long r = blockIdx.x; r < bv.n; r += gridDim.x) {
+    int len = bv.len[r];
+    int barcode = bv.barcode ? bv.barcode[r] : -1;
+    int Hv = 0;
+    if (len >= 1 && len >= ix.k) {
+      loadSegment(bv, r, 0, len, wm);
+      int nk = len - ix.k + 1;
+      int H = seedPositions(ix, wm, len, strandArg, barcode, allowTotalSkip != 0, s_posStart, s_posPref);
+      if (H > gCap) { if (lane == 0) status[r] = 2; H = 0; }
+      // keys ordered as _hit::operator< : (strand, idx, readOffset, offset)
+      int dropped = 0;
+      for (int s = lane; s < H; s += 64) {
+        int lo = 0, hi = 2 * nk - 1;
+        while (lo < hi) { int mid = (lo + hi + 1) >> 1; if (s_posPref[mid] <= (unsigned)s) lo = mid; else hi = mid - 1; }
+        int q = lo;
+        int2 po = ix.post[s_posStart[q] + ((unsigned)s - s_posPref[q])];
+        int st = q >= nk, a = st ? q - nk : q;
+        unsigned long long key = ~0ull;
+        if (barcode != -1 && ix.seqs[po.x].barcode != barcode) ++dropped;
+        else key = ((st ? 0ull : 1ull) << 63) | ((unsigned long long)po.x << 32) | ((unsigned long long)a << 20) | (unsigned long long)po.y;
+        wm.keys[s] = key;
+      }
+      dropped = waveSum(dropped);
+      Hv = H - dropped;
+      if (pass == 1 && H > 0) {
+        int n2 = 1;
+        while (n2 < H) n2 <<= 1;
+        for (int s = H + lane; s < n2; s += 64) wm.keys[s] = ~0ull;
+        __syncthreads();
+        if (H > 1) bitonicSort(wm.keys, n2);
+        __syncthreads();
+        long long base = offsets[r];
+        for (int s = lane; s < Hv; s += 64) {
+          unsigned long long key = wm.keys[s];
+          T4HitOut h;
+          h.idx = (int)((key >> 32) & 0x3FFFFFull);
+          h.readOffset = (int)((key >> 20) & 0xFFF);
+          h.offset = (int)(key & 0xFFFFF);
+          h.strand = (key >> 63) ? 1 : -1;
+          int q = (h.strand == 1 ? 0 : nk) + h.readOffset;
+          h.repeats = barcode != -1 ? 1 : (int)(s_posPref[q + 1] - s_posPref[q]);
+          out[base + s] = h;
+        }
+      }
+    }
+    if (pass == 0 && lane == 0) offsets[r + 1] = Hv;
+    __syncthreads();
+  }
+}
+
+}  // namespace t4k
