@@ -49,7 +49,7 @@ extern Tid cur_tid, cur_bid;
 extern dim3 cur_bdim, cur_gdim;
 extern uint64_t xchg[1024];
 extern int nthreads, nalive;
-void yield_lane();
+void yield_lane(void *site = nullptr);
 void run_grid(dim3 grid, dim3 block, const std::function<void()> &body);
 }  // namespace hipemu
 
@@ -62,7 +62,7 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()> &body);
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
   hipemu::run_grid(dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); })
 
-static inline void __syncthreads() { hipemu::yield_lane(); }
+static inline void __syncthreads() { hipemu::yield_lane(__builtin_return_address(0)); }
 
 // ---- wave intrinsics (wave == the 64 consecutive threads the caller belongs to)
 static inline int hipemu_lane() { return hipemu::cur_tid.x & 63; }
@@ -87,7 +87,7 @@ template <class T> static inline T __shfl_down(T v, unsigned d, int width = 64) 
 template <class T> static inline T __shfl_xor(T v, int m, int width = 64) { (void)width; return hipemu_shfl_any(v, hipemu_lane() ^ m); }
 static inline unsigned long long __ballot(int pred) {
   hipemu::xchg[hipemu::cur_tid.x] = pred ? 1 : 0;
-  hipemu::yield_lane();
+  hipemu::yield_lane(__builtin_return_address(0));
   unsigned long long m = 0; int b = hipemu_wbase();
   for (int i = 0; i < 64 && b + i < hipemu::nthreads; ++i) if (hipemu::xchg[b + i]) m |= 1ull << i;
   hipemu::yield_lane();

@@ -579,7 +579,13 @@ __device__ int expandHits(const T4IndexView &ix, WaveMem &wm, int nk, int H, int
     } else ++dropped;
     wm.keys[s] = key;
   }
+#ifdef T4_DEBUG
+  int mydrop = dropped;
+#endif
   dropped = waveSum(dropped);
+#ifdef T4_DEBUG
+  if (vjOnly) printf("DBG expand lane %d H %d mydrop %d dropped %d\n", lane, H, mydrop, dropped);
+#endif
   return H - dropped;
 }
 
@@ -668,6 +674,9 @@ __device__ void overlapsFromKeys(const T4IndexView &ix, WaveMem &wm, WaveState *
     if (i < Hv) {
       unsigned long long ki = wm.keys[i];
       int idx = KEY_IDX(ki), plus = KEY_PLUS(ki);
+#ifdef T4_DEBUG
+      if (idx >= ix.nseq) { printf("DBG bad key i %d Hv %d key %llx filter %d hlr %d\n", i, Hv, ki, filter, hitLenRequired); }
+#endif
       bool isRef = ix.seqs[idx].isRef != 0;
       int adjustRadius = isRef ? ix.radius : 0;
       bool runStart = true;
@@ -696,46 +705,21 @@ __device__ void overlapsFromKeys(const T4IndexView &ix, WaveMem &wm, WaveState *
   }
   __syncthreads();
   const int nCand = ws->candCount < wm.candCap ? ws->candCount : wm.candCap;
-  // R2: one lane per candidate run: extract (b << 12 | a), order by (b, a), chain
-  for (int c = lane; c < nCand; c += 64) {
-    int s = wm.cand[c] & 0xFFFF, n = wm.cand[c] >> 16;
-    unsigned long long ks = wm.keys[s];
-    int idx = KEY_IDX(ks), plus = KEY_PLUS(ks);
-    bool isRef = ix.seqs[idx].isRef != 0;
-    int adjustRadius = isRef ? ix.radius : 0;
-    if (adjustRadius > 0 && n > 48) continue;  // long multi-diagonal run: cooperative path below
-    for (int t = s; t < s + n; ++t) {
-      unsigned long long kt = wm.keys[t];
-      int b = KEY_B(kt), a = KEY_C(kt) - T4_C_BIAS + b;
-      wm.pairs[t] = ((unsigned)b << 12) | (unsigned)a;
-    }
-    if (adjustRadius > 0) { // insertion sort by (b, a): a run is a union of a few diagonals
-      for (int t = s + 1; t < s + n; ++t) {
-        unsigned v = wm.pairs[t];
-        int u = t - 1;
-        while (u >= s && wm.pairs[u] > v) { wm.pairs[u + 1] = wm.pairs[u]; --u; }
-        wm.pairs[u + 1] = v;
-      }
-    }
-    chainRun(ix, wm, ws, s, n, idx, plus, isRef, hitLenRequired);
-  }
-  __syncthreads();
-  // R3: long runs, rank-sorted by the whole wave, then chained by one lane each
+  // R2: long multi-diagonal runs (reference genes only) are ordered by (b, a) by the whole wave
   if (ix.radius > 0) {
     for (int c = 0; c < nCand; ++c) {
       int s = wm.cand[c] & 0xFFFF, n = wm.cand[c] >> 16;
       if (n <= 48) continue;                                  // wave-uniform
       unsigned long long ks = wm.keys[s];
       if (!ix.seqs[KEY_IDX(ks)].isRef) continue;              // wave-uniform
-      unsigned *tmp = (unsigned *)(wm.keys + s) + n;          // upper half of the run's own key area
+      // upper half of the run's own key area; keys[s] itself (u32 words 0,1) stays intact for R3
+      unsigned *tmp = (unsigned *)(wm.keys + s) + n;
       for (int t = lane; t < n; t += 64) {
         unsigned long long kt = wm.keys[s + t];
         int b = KEY_B(kt), a = KEY_C(kt) - T4_C_BIAS + b;
         wm.pairs[s + t] = ((unsigned)b << 12) | (unsigned)a;
       }
       __syncthreads();
-      // keys[s] still carries the group id in its low half only if tmp does not touch it: tmp starts
-      // at u32 index n >= 49 of the run area, keys[s] is u32 index 0..1 -> untouched.
       for (int t = lane; t < n; t += 64) {
         unsigned v = wm.pairs[s + t];
         int rank = 0;
@@ -746,16 +730,33 @@ __device__ void overlapsFromKeys(const T4IndexView &ix, WaveMem &wm, WaveState *
       for (int t = lane; t < n; t += 64) wm.pairs[s + t] = tmp[t];
       __syncthreads();
     }
-    for (int c = lane; c < nCand; c += 64) {
-      int s = wm.cand[c] & 0xFFFF, n = wm.cand[c] >> 16;
-      if (n <= 48) continue;
-      unsigned long long ks = wm.keys[s];
-      int idx = KEY_IDX(ks), plus = KEY_PLUS(ks);
-      if (!ix.seqs[idx].isRef) continue;
-      chainRun(ix, wm, ws, s, n, idx, plus, true, hitLenRequired);
-    }
-    __syncthreads();
   }
+  __syncthreads();   // R3 overwrites key areas that R2's wave-uniform tests read
+  // R3: one lane per candidate run: extract (b << 12 | a), order by (b, a), chain
+  for (int c = lane; c < nCand; c += 64) {
+    int s = wm.cand[c] & 0xFFFF, n = wm.cand[c] >> 16;
+    unsigned long long ks = wm.keys[s];
+    int idx = KEY_IDX(ks), plus = KEY_PLUS(ks);
+    bool isRef = ix.seqs[idx].isRef != 0;
+    int adjustRadius = isRef ? ix.radius : 0;
+    if (!(adjustRadius > 0 && n > 48)) {
+      for (int t = s; t < s + n; ++t) {
+        unsigned long long kt = wm.keys[t];
+        int b = KEY_B(kt), a = KEY_C(kt) - T4_C_BIAS + b;
+        wm.pairs[t] = ((unsigned)b << 12) | (unsigned)a;
+      }
+      if (adjustRadius > 0) { // insertion sort by (b, a): a run is a union of a few diagonals
+        for (int t = s + 1; t < s + n; ++t) {
+          unsigned v = wm.pairs[t];
+          int u = t - 1;
+          while (u >= s && wm.pairs[u] > v) { wm.pairs[u + 1] = wm.pairs[u]; --u; }
+          wm.pairs[u + 1] = v;
+        }
+      }
+    }
+    chainRun(ix, wm, ws, s, n, idx, plus, isRef, hitLenRequired);
+  }
+  __syncthreads();
 }
 
 // IsOverlapLowComplex (SeqSet.hpp:590-617)
@@ -886,12 +887,16 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
       __syncthreads();
       int n = ws->ovCount;
       if (n > wm.maxOv) return -2;
+      __syncthreads();
       if (lane == 0) ws->ovCount = selectVJPair(ix, wm, n);
       __syncthreads();
       overlapCnt = ws->ovCount;
       if (overlapCnt == 0) return 0;
     }
   }
+#ifdef T4_DEBUG
+  if (lane == 0) printf("DBG seg len %d overlapCnt %d overflow %d\n", segLen, overlapCnt, ws->overflow);
+#endif
   if (ws->overflow || overlapCnt > wm.maxOv) return -2;
   // std::sort(overlaps) by operator< : rank sort (the order is total on distinct overlaps)
   for (int i = lane; i < overlapCnt; i += 64) {
@@ -964,6 +969,9 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
     }
     __syncthreads();
   }
+#ifdef T4_DEBUG
+  if (lane == 0) for (int i = 0; i < overlapCnt; ++i) { OvRec o = wm.ov[wm.ord[i]]; printf("DBG ov %d seq %d %d-%d %d-%d m %d ind %d fl %d sim %f\n", i, o.seqIdx, o.rs, o.re, o.ss, o.se, o.matchCnt, o.indelCnt, o.flags, ovSim(o)); }
+#endif
   // similarity thresholds (SeqSet.hpp:2105-2119), order preserved; append to fin
   int base = ws->finCount;
   int outCnt = 0;
