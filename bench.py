@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""bench.py -- stage-1 hot path throughput on N MI355X of one node (driver contract in the task brief).
+
+A "step" is one pass of the GPU hot path over one resident batch of synthetic 150 bp paired-end reads
+(SURVEY.md 8d recipe, config C2: 1 M pairs, 20 k clones, seed 1, -f hg38_bcrtcr.fa, k = 9). The pass
+measured this round is the stage-1 rough-annotation pass of every read (main.cpp:1084-1120:
+GetHitsFromRead -> SortHits -> GetOverlapsFromHits -> GetOverlapsFromRead scoring -> AnnotateRead
+level 0); the order-dependent AddRead loop is not on the GPU yet and is NOT part of this number.
+Inputs are 2-bit packed and resident in HBM before the timed region; results stay on the device.
+Read batches shard across ranks with no data-path collective (weak scaling: every rank owns its own
+C2-sized batch, seeded by rank).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes(n_reads, read_len, total_hits):
+    """ceil(L/4) + ceil(L/8) + 8*H + 4*32 per read."""
+    return n_reads * ((read_len + 3) // 4 + (read_len + 7) // 8 + 128) + 8 * total_hits
+
+
+def cpu_baseline(reads_arr, sample_reads):
+    """Time the CPU path on this box's host cores over a bounded sample of the same workload.
+    Uses the compiled reference (oracle/_ref/libt4ref.so) when it travelled with the repo, else the C oracle."""
+    import ctypes as C
+    import t4libs
+    n = min(sample_reads, len(reads_arr))
+    sample = np.ascontiguousarray(reads_arr[:n])
+    stride = sample.shape[1]
+    if t4libs.Ref.available():
+        r = t4libs.Ref(9, t4libs.REF_FA, 17)
+        fn = r.lib.ref_annotate_batch
+        fn.restype = C.c_long
+        fn.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_long, C.c_void_p]
+        t0 = time.perf_counter()
+        fn(r.h, sample.ctypes.data_as(C.c_char_p), stride, n, None)
+        dt = time.perf_counter() - t0
+        kind = "reference"
+    else:
+        o = t4libs.Oracle(9, t4libs.REF_FA, 17)
+        t0 = time.perf_counter()
+        o.annotate_batch(sample, stride, n)
+        dt = time.perf_counter() - t0
+        kind = "port"
+    return {"value": n / dt, "unit": "reads/s", "cores": 1, "kind": kind,
+            "sample": "first %d reads of the rank-0 batch, same rough-annotation pass, 1 thread, %.1f s" % (n, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=1000000, help="read pairs per GPU per step (C2 = 1M)")
+    ap.add_argument("--clones", type=int, default=20000)
+    ap.add_argument("--cpu-sample", type=int, default=100000, help="reads timed on the CPU baseline (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import trust4_amd
+    import trust4_amd.build
+    import t4libs
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the measured path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    if rank == 0:
+        trust4_amd.build.build()
+        t4libs.build_checkers()
+    if dist:
+        dist.barrier()
+
+    eng = trust4_amd.Engine(local_rank)
+    ref = eng.index(9).set_params(17, 10, 0.9).load_ref_fasta(t4libs.REF_FA).commit()
+    # synthetic batch of this rank (seed 1 on rank 0 == config C2), resident in HBM
+    synth = t4libs.Synth(args.clones, 1 + rank)
+    reads = synth.next_reads(args.pairs)  # [2*pairs, 151] uint8, mates interleaved
+    n_reads = reads.shape[0]
+    batch = eng.upload(reads)
+
+    def step():
+        ref.annotate_rough(batch, fetch=False)
+
+    def sync_all():
+        eng.check(eng.lib.t4_sync(eng.h))
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    hits = 0
+    for _ in range(args.steps):
+        step()
+        st = eng.stats()
+        kernel_ms.append(st["chain_kernel_ms"])
+        hits = st["total_hits"]
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_reads = n_reads * world * args.steps
+        st = eng.stats()
+        # dominant kernels = the per-tier probe->sort->chain->score launches, event-timed on the engine's stream
+        k_ms = float(np.mean(kernel_ms))
+        alg = algorithmic_bytes(n_reads, 150, hits)
+        achieved = alg / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "stage-1 assembly reads/sec (150 bp PE)",
+            "value": total_reads / dt,
+            "unit": "reads/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32/u64", "data": "synthetic",
+            "config": {"workload": "C2: %d synthetic 150 bp PE pairs per GPU (%d reads), %d clones, seed 1+rank, -f hg38_bcrtcr.fa, k=9; "
+                                   "pass = stage-1 rough annotation of every read (seed->sort->chain->score->V/J/C select); "
+                                   "AddRead loop not included" % (args.pairs, n_reads, args.clones),
+                       "pairs_per_gpu": args.pairs, "reads_per_gpu": n_reads, "hits_per_read": hits / n_reads,
+                       "tier_reads": st["tier_reads"], "sharding": "reads sharded by rank, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "t4k::queryKernel (all tiers of one pass)", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_launch": alg},
+        }
+        if args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(reads, args.cpu_sample)
+        print(json.dumps(out))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -104,6 +104,15 @@ int t4_overlaps(t4_index *ix, t4_batch *b, int strand, int skip_repeats, int max
  * rough-annotation pass of main.cpp:1084-1120. */
 int t4_annotate_rough(t4_index *ref, t4_batch *b, t4_overlap *out);
 
+/* AlignAlgo::GlobalAlignment (kind 0; AlignAlgo.hpp:218-424; t_data = chars) or
+ * AlignAlgo::GlobalAlignment_PosWeight (kind 1; AlignAlgo.hpp:57-216; t_data = 4 int32 weights per base)
+ * for n independent (target, pattern) pairs given as CSR offsets; out4[4*i..] = GetAlignStats of
+ * the reference's alignment (matches, mismatches, indels) and a status word (0 ok, 1 beyond the
+ * engine's gap limits). impl 0 = the forward-only LDS formulation the overlap scorer uses (falls back
+ * to the traceback formulation for wide bands), impl 1 = traceback formulation only. */
+int t4_gap_dp(t4_ctx *ctx, int kind, int impl, int n, const int64_t *t_off, const int64_t *p_off,
+              const void *t_data, const char *p_chars, int32_t *out4);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* Per-call statistics of the last query on this ctx: kernel time measured with HIP events on the
  * ctx's stream, number of _hit records the seed stage emitted (H of SURVEY.md 8d), number of reads
@@ -113,7 +122,7 @@ typedef struct {
   double chain_kernel_ms; /* the dominant probe->sort->chain->score kernels only */
   int64_t total_hits;     /* sum over reads and passes of emitted _hit records */
   int64_t reads;          /* reads processed */
-  int64_t tier_reads[4];  /* reads per capacity tier (LDS small / mid / large / global scratch) */
+  int64_t tier_reads[5];  /* reads per capacity tier (LDS 1k / 2k / 4k / 8k hits, global scratch) */
   int64_t launches;       /* kernel launches in the call */
 } t4_stats;
 int t4_last_stats(t4_ctx *ctx, t4_stats *out);

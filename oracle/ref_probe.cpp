@@ -249,3 +249,15 @@ int ref_lis(void *h, const int *pairs, int n, int *out) {
 }
 
 }  // extern "C"
+
+// Batch form of AnnotateRead(level 0) for bench.py's cpu_baseline leg ("reference" kind): reads are
+// fixed-stride NUL-terminated records; returns the number of reads annotated.
+extern "C" long ref_annotate_batch(void *h, const char *reads, int stride, long n, ref_overlap_t *out4) {
+  SeqSet *s = (SeqSet *)h;
+  struct _overlap g[4];
+  for (long i = 0; i < n; ++i) {
+    s->AnnotateRead((char *)(reads + i * stride), 0, g, NULL, NULL);
+    if (out4) for (int t = 0; t < 4; ++t) copy_overlap(out4 + 4 * i + t, g[t]);
+  }
+  return n;
+}

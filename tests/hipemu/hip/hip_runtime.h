@@ -2,7 +2,7 @@
 //
 // A tiny single-threaded emulator of the subset of HIP that trust4_amd/csrc uses, so that the very
 // same kernel sources can be compiled with g++ and executed (slowly) on the CPU inside the
-// `-m "not gpu"` test-suite: every lane of a workgroup is a ucontext fiber, wave intrinsics and
+// `-m "not gpu"` test-suite: every lane of a workgroup is a fiber (hand-rolled x86-64 context switch), wave intrinsics and
 // __syncthreads() are rendezvous points. It exists because the development container has no GPU;
 // it is NOT a fallback: the product library (trust4_amd/libt4hip.so) is built by hipcc from the
 // same sources and never links this header. Built only by tests/hipemu/build_emu.py.
@@ -50,6 +50,8 @@ extern dim3 cur_bdim, cur_gdim;
 extern uint64_t xchg[1024];
 extern int nthreads, nalive;
 void yield_lane(void *site = nullptr);
+void block_barrier(void *site);
+void wave_rendezvous(void *site);
 void run_grid(dim3 grid, dim3 block, const std::function<void()> &body);
 }  // namespace hipemu
 
@@ -62,7 +64,7 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()> &body);
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
   hipemu::run_grid(dim3(grid), dim3(block), [=]() { kernel(__VA_ARGS__); })
 
-static inline void __syncthreads() { hipemu::yield_lane(__builtin_return_address(0)); }
+static inline void __syncthreads() { hipemu::block_barrier(__builtin_return_address(0)); }
 
 // ---- wave intrinsics (wave == the 64 consecutive threads the caller belongs to)
 static inline int hipemu_lane() { return hipemu::cur_tid.x & 63; }
@@ -71,9 +73,9 @@ template <class T> static inline T hipemu_shfl_any(T v, int src) {
   static_assert(sizeof(T) <= 8, "shfl size");
   uint64_t raw = 0; memcpy(&raw, &v, sizeof(T));
   hipemu::xchg[hipemu::cur_tid.x] = raw;
-  hipemu::yield_lane();
+  hipemu::wave_rendezvous(nullptr);
   uint64_t got = hipemu::xchg[hipemu_wbase() + (src & 63)];
-  hipemu::yield_lane();
+  hipemu::wave_rendezvous(nullptr);
   T r; memcpy(&r, &got, sizeof(T));
   return r;
 }
@@ -87,10 +89,10 @@ template <class T> static inline T __shfl_down(T v, unsigned d, int width = 64) 
 template <class T> static inline T __shfl_xor(T v, int m, int width = 64) { (void)width; return hipemu_shfl_any(v, hipemu_lane() ^ m); }
 static inline unsigned long long __ballot(int pred) {
   hipemu::xchg[hipemu::cur_tid.x] = pred ? 1 : 0;
-  hipemu::yield_lane(__builtin_return_address(0));
+  hipemu::wave_rendezvous(__builtin_return_address(0));
   unsigned long long m = 0; int b = hipemu_wbase();
   for (int i = 0; i < 64 && b + i < hipemu::nthreads; ++i) if (hipemu::xchg[b + i]) m |= 1ull << i;
-  hipemu::yield_lane();
+  hipemu::wave_rendezvous(nullptr);
   return m;
 }
 static inline int __any(int p) { return __ballot(p) != 0; }

@@ -11,8 +11,33 @@ uint64_t xchg[1024];
 int nthreads = 0, nalive = 0;
 
 static const size_t STACK = 512 * 1024;
-static ucontext_t sched_ctx;
-static std::vector<ucontext_t> lane_ctx;
+// minimal x86-64 SysV context switch (glibc's swapcontext makes a sigprocmask syscall per switch)
+struct Ctx { void *rsp; };
+extern "C" void hipemu_switch(Ctx *from, Ctx *to);
+asm(R"(
+.text
+.globl hipemu_switch
+.type hipemu_switch,@function
+hipemu_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq (%rsi), %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size hipemu_switch,.-hipemu_switch
+)");
+static Ctx sched_ctx;
+static std::vector<Ctx> lane_ctx;
 static std::vector<char *> stacks;
 static std::vector<char> done;
 static int cur = 0;
@@ -30,14 +55,40 @@ static bool handler_set = false;
 static void *pending[1024];
 void yield_lane(void *site) {
   pending[cur] = site ? site : __builtin_return_address(0);
-  swapcontext(&lane_ctx[cur], &sched_ctx);
+  hipemu_switch(&lane_ctx[cur], &sched_ctx);
+}
+
+// real rendezvous semantics: a workgroup barrier releases when every live thread of the block has arrived,
+// a wave rendezvous when every live lane of that wavefront has (waves may run different trip counts in between)
+static int bar_count = 0, bar_gen = 0;
+static int wave_count[16], wave_gen[16], wave_alive[16];
+static int wait_kind[1024], wait_gen[1024];   // 0 runnable, 1 parked at a block barrier, 2 parked at a wave rendezvous
+void block_barrier(void *site) {
+  int gen = bar_gen;
+  if (++bar_count >= nalive) { bar_count = 0; ++bar_gen; return; }
+  wait_kind[cur] = 1; wait_gen[cur] = gen;
+  while (bar_gen == gen) yield_lane(site);
+  wait_kind[cur] = 0;
+}
+void wave_rendezvous(void *site) {
+  int w = cur / 64;
+  int gen = wave_gen[w];
+  if (++wave_count[w] >= wave_alive[w]) { wave_count[w] = 0; ++wave_gen[w]; return; }
+  wait_kind[cur] = 2; wait_gen[cur] = gen;
+  while (wave_gen[w] == gen) yield_lane(site);
+  wait_kind[cur] = 0;
 }
 
 static void lane_entry() {
   (*cur_body)();
   done[cur] = 1;
   --nalive;
-  swapcontext(&lane_ctx[cur], &sched_ctx);
+  --wave_alive[cur / 64];
+  // a thread that exits releases rendezvous points the others are parked at
+  if (nalive > 0 && bar_count >= nalive) { bar_count = 0; ++bar_gen; }
+  { int w = cur / 64; if (wave_alive[w] > 0 && wave_count[w] >= wave_alive[w]) { wave_count[w] = 0; ++wave_gen[w]; } }
+  hipemu_switch(&lane_ctx[cur], &sched_ctx);
+  abort();
 }
 
 void run_grid(dim3 grid, dim3 block, const std::function<void()> &body) {
@@ -50,18 +101,24 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()> &body) {
   for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned bx = 0; bx < grid.x; ++bx) {
     cur_bid.x = bx; cur_bid.y = by; cur_bid.z = bz;
     for (int i = 0; i < nt; ++i) {
-      getcontext(&lane_ctx[i]);
-      lane_ctx[i].uc_stack.ss_sp = stacks[i]; lane_ctx[i].uc_stack.ss_size = STACK; lane_ctx[i].uc_link = &sched_ctx;
-      makecontext(&lane_ctx[i], lane_entry, 0);
-      done[i] = 0;
+      // fresh stack: six zeroed callee-saved slots, then lane_entry as the return address (16-byte ABI alignment)
+      uintptr_t top = ((uintptr_t)stacks[i] + STACK) & ~(uintptr_t)15;
+      void **sp = (void **)(top - 8);
+      *--sp = (void *)lane_entry;
+      for (int k = 0; k < 6; ++k) *--sp = nullptr;
+      lane_ctx[i].rsp = sp;
+      done[i] = 0; wait_kind[i] = 0;
     }
-    nalive = nt;
+    nalive = nt; bar_count = 0;
+    for (int w = 0; w < 16; ++w) { wave_count[w] = 0; int lo = w * 64, hi = lo + 64 < nt ? lo + 64 : nt; wave_alive[w] = hi > lo ? hi - lo : 0; }
     while (nalive > 0) {
       for (int i = 0; i < nt; ++i) {
         if (done[i]) continue;
+        if (wait_kind[i] == 1 && bar_gen == wait_gen[i]) continue;          // still parked
+        if (wait_kind[i] == 2 && wave_gen[i / 64] == wait_gen[i]) continue;
         cur = i;
         cur_tid.x = i % block.x; cur_tid.y = (i / block.x) % block.y; cur_tid.z = i / (block.x * block.y);
-        swapcontext(&sched_ctx, &lane_ctx[i]);
+        hipemu_switch(&sched_ctx, &lane_ctx[i]);
       }
       // divergence check (HIPEMU_CHECK=1, build with -O0: optimisers duplicate call sites): every live
       // lane of a wave must be parked at the same rendezvous

@@ -127,3 +127,114 @@ def test_novel_sets(emu_engine, k):
 
 def test_novel_sets_barcoded(emu_engine):
     run_novel_case(emu_engine, 77, 9, barcodes=True, hit_len=13)
+
+
+def make_dp_cases(seed, n, posweight):
+    rnd = random.Random(seed)
+    nprnd = np.random.RandomState(seed)
+    T, P = [], []
+    for it in range(n):
+        lt = rnd.randint(0, 40)
+        if it % 25 == 0:
+            lt = rnd.randint(60, 300)
+        base = [rnd.randrange(4) for _ in range(lt)]
+        p = ["ACGT"[b] for b in base]
+        nedit = rnd.randint(0, 5) if it % 3 else rnd.randint(3, 14)
+        for _ in range(nedit):
+            c = rnd.random()
+            if p and c < 0.35:
+                del p[rnd.randrange(len(p))]
+            elif c < 0.7:
+                p.insert(rnd.randint(0, len(p)), rnd.choice("ACGT"))
+            elif p:
+                p[rnd.randrange(len(p))] = rnd.choice("ACGTN")
+        if it % 11 == 0:
+            p = [rnd.choice("ACGT") for _ in range(rnd.randint(0, 40))]
+        p = "".join(p)[:300]
+        if posweight:
+            w = np.zeros((lt, 4), dtype=np.int32)
+            for i, b in enumerate(base):
+                mode = rnd.random()
+                if mode < 0.6:
+                    w[i, b] = rnd.randint(1, 30)
+                elif mode < 0.8:
+                    w[i] = nprnd.randint(0, 10, 4)
+                elif mode < 0.9:
+                    w[i, b] = 3
+                    w[i, (b + 1) % 4] = 2
+            T.append(w)
+        else:
+            t = "".join("ACGT"[b] for b in base)
+            if it % 7 == 0 and lt:
+                t = list(t)
+                t[rnd.randrange(lt)] = "N"
+                t = "".join(t)
+            T.append(t)
+        P.append(p)
+    return T, P
+
+
+def check_gap_dp(eng, seed, n):
+    o = Oracle(9)
+    for kind in (0, 1):
+        T, P = make_dp_cases(seed + kind, n, kind == 1)
+        exp = []
+        for t, p in zip(T, P):
+            sc, al = o.global_alignment(t, p) if kind == 0 else o.global_alignment_posweight(t, p)
+            exp.append((al.count(0), al.count(1), al.count(2) + al.count(3)))
+        for impl in (0, 1, 2):
+            got = eng.gap_dp(kind, T, P, impl)
+            wide = got[:, 3] == 2     # impl 2 only: band wider than one wavefront (the scorer falls back to impl 1)
+            assert impl == 2 or not wide.any()
+            assert ((got[:, 3] == 0) | wide).all() and wide.sum() < n // 10
+            bad = [i for i in range(n) if not wide[i] and tuple(got[i, :3]) != exp[i]]
+            assert not bad, (kind, impl, bad[:5], [(T[i] if kind == 0 else T[i].tolist(), P[i], exp[i], got[i].tolist()) for i in bad[:2]])
+
+
+def test_gap_dp_vs_oracle(emu_engine):
+    check_gap_dp(emu_engine, 5, 600)
+
+
+def equal_length_cases(seed, n_random):
+    """Equal-length targets with 0..4 substitutions at every placement: the affine shortcut's domain."""
+    import itertools
+    rnd = random.Random(seed)
+    T, P = [], []
+    for L in range(2, 11):
+        for mmc in range(0, 5):
+            for pos in itertools.islice(itertools.combinations(range(L), mmc), 40):
+                for rep in range(3):
+                    t = [rnd.choice("ACGT") for _ in range(L)]
+                    if rep == 1:
+                        t = [rnd.choice("AC") for _ in range(L)]
+                    if rep == 2:
+                        t = ["A"] * L
+                    p = list(t)
+                    for q in pos:
+                        p[q] = rnd.choice([c for c in "ACGT" if c != t[q]])
+                    T.append("".join(t))
+                    P.append("".join(p))
+    for _ in range(n_random):
+        L = rnd.randint(2, 40)
+        t = [rnd.choice("ACGT" if rnd.random() < .7 else "AC") for _ in range(L)]
+        p = list(t)
+        for q in rnd.sample(range(L), min(L, rnd.randint(0, 5))):
+            p[q] = rnd.choice("ACGTN")
+        if rnd.random() < .2:
+            t[rnd.randrange(L)] = "N"
+        T.append("".join(t))
+        P.append("".join(p))
+    return T, P
+
+
+def check_equal_length_shortcut(eng, n_random):
+    o = Oracle(9)
+    T, P = equal_length_cases(3, n_random)
+    got = eng.gap_dp(0, T, P, 0)
+    for i, (t, p) in enumerate(zip(T, P)):
+        sc, al = o.global_alignment(t, p)
+        assert tuple(got[i, :3]) == (al.count(0), al.count(1), al.count(2) + al.count(3)), (t, p)
+
+
+def test_affine_equal_length_shortcut(emu_engine):
+    check_equal_length_shortcut(emu_engine, 3000)

@@ -1,0 +1,120 @@
+"""-m gpu: the hipcc-built library (through the C ABI) against the golden vectors, the C oracle and,
+when it travelled with the repo, the compiled reference itself."""
+import os
+
+import numpy as np
+import pytest
+
+import t4check
+from t4libs import REF_FA, ROOT, Oracle, Ref, Synth, rows_to_strs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    os.environ.pop("T4_LIB", None)
+    import trust4_amd
+    import trust4_amd.build
+    trust4_amd.build.build()
+    assert trust4_amd.lib_path().endswith("trust4_amd/libt4hip.so")
+    return trust4_amd.Engine(0)
+
+
+@pytest.fixture(scope="module")
+def ref_index(eng):
+    return eng.index(9).set_params(17, 10, 0.9).load_ref_fasta(REF_FA).commit()
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return Oracle(9, REF_FA, 17)
+
+
+def test_golden_all(eng, ref_index):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_query_k9.npz"))
+    reads = [str(x) for x in g["reads"]]
+    b = eng.upload(reads)
+    ann = ref_index.annotate_rough(b)
+    cnt, ov = ref_index.overlaps(b, 0, 0, 128)
+    off, hits = ref_index.hits(b)
+    for i in range(len(reads)):
+        for t in range(4):
+            assert t4check.ann_equal(ann[i, t], tuple(g["annotate"][i, t].tolist())), (i, t)
+        exp = g["overlaps"][g["overlap_off"][i]:g["overlap_off"][i + 1]]
+        assert cnt[i] == len(exp) or (cnt[i] == -1 and len(exp) == 0)
+        assert [tuple(x) for x in ov[i, :len(exp)].tolist()] == [tuple(x) for x in exp.tolist()], i
+        if i % 8 == 0:
+            m = t4check.hits_as_sorted_rows(off, hits, i)
+            assert (m == g["hits"][g["hit_off"][i]:g["hit_off"][i + 1]]).all(), i
+
+
+def test_synthetic_20k_vs_oracle(eng, ref_index, oracle):
+    arr = Synth(2000, 21).next_reads(10000)
+    b = eng.upload(arr)
+    ann = ref_index.annotate_rough(b)
+    exp, hp, tot = oracle.annotate_batch(arr, arr.shape[1], arr.shape[0])
+    assert eng.stats()["total_hits"] == tot           # H_r of SURVEY 8(d) is a parity quantity
+    ok = (ann["seqIdx"] == exp["seqIdx"])
+    assert ok.all()
+    m = exp["seqIdx"] != -1
+    for f in ("readStart", "readEnd", "seqStart", "seqEnd", "strand", "matchCnt", "indelCnt", "similarity"):
+        assert (ann[f][m] == exp[f][m]).all(), f
+
+
+@pytest.mark.skipif(not Ref.available(), reason="oracle/_ref not shipped")
+def test_vs_compiled_reference(eng, ref_index):
+    r = Ref(9, REF_FA, 17)
+    reads = rows_to_strs(Synth(500, 33).next_reads(500))
+    b = eng.upload(reads)
+    ann = ref_index.annotate_rough(b)
+    assert t4check.check_annotate(ann, reads, r) == []
+
+
+def test_hits_overlaps_skip_repeats(eng, ref_index, oracle):
+    reads = rows_to_strs(Synth(400, 5).next_reads(300)) + ["A" * 150, "ACGTACGTA", "", "N" * 30]
+    b = eng.upload(reads)
+    for sk in (0, 1):
+        off, hits = ref_index.hits(b, 0, sk)
+        assert t4check.check_hits(off, hits, reads, oracle, allow_total_skip=sk) == []
+        cnt, ov = ref_index.overlaps(b, 0, sk, 128)
+        assert t4check.check_overlaps(cnt, ov, reads, oracle, skip_repeats=sk) == []
+    for strand in (1, -1):
+        off, hits = ref_index.hits(b, strand, 0)
+        assert t4check.check_hits(off, hits, reads, oracle, strand=strand) == []
+
+
+@pytest.mark.parametrize("k", [9, 11, 17])
+def test_novel_sets(eng, k):
+    from test_engine_emu import run_novel_case
+    run_novel_case(eng, 100 + k, k)
+
+
+def test_novel_sets_barcoded(eng):
+    from test_engine_emu import run_novel_case
+    run_novel_case(eng, 77, 9, barcodes=True, hit_len=13)
+
+
+def test_full_size_properties(eng, ref_index):
+    """C2-scale (200k pairs here to bound time) size-independent properties: determinism across runs and
+    invariance to batch composition (a read's result does not depend on its neighbours)."""
+    arr = Synth(20000, 1).next_reads(200000)
+    b = eng.upload(arr)
+    a1 = ref_index.annotate_rough(b)
+    h1 = eng.stats()["total_hits"]
+    a2 = ref_index.annotate_rough(b)
+    assert eng.stats()["total_hits"] == h1
+    assert (a1["seqIdx"] == a2["seqIdx"]).all() and (a1["matchCnt"] == a2["matchCnt"]).all()
+    perm = np.random.RandomState(0).permutation(arr.shape[0])[:50000]
+    b2 = eng.upload(arr[perm])
+    a3 = ref_index.annotate_rough(b2)
+    assert (a3["seqIdx"] == a1["seqIdx"][perm]).all()
+    m = a3["seqIdx"] != -1
+    assert (a3["matchCnt"][m] == a1["matchCnt"][perm][m]).all()
+    assert (a3["readStart"][m] == a1["readStart"][perm][m]).all()
+
+
+def test_gap_dp_vs_oracle(eng):
+    from test_engine_emu import check_equal_length_shortcut, check_gap_dp
+    check_gap_dp(eng, 5, 20000)
+    check_equal_length_shortcut(eng, 50000)

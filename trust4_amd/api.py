@@ -15,7 +15,7 @@ HIT_DTYPE = np.dtype([("idx", "<i4"), ("offset", "<i4"), ("readOffset", "<i4"), 
 
 class Stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("chain_kernel_ms", C.c_double), ("total_hits", C.c_int64),
-                ("reads", C.c_int64), ("tier_reads", C.c_int64 * 4), ("launches", C.c_int64)]
+                ("reads", C.c_int64), ("tier_reads", C.c_int64 * 5), ("launches", C.c_int64)]
 
 
 class T4Error(RuntimeError):
@@ -48,6 +48,7 @@ def _load():
         "t4_batch_size": (L, [P]),
         "t4_hits": (I, [P, P, I, I, P, P, L]), "t4_overlaps": (I, [P, P, I, I, I, P, P]),
         "t4_annotate_rough": (I, [P, P, P]),
+        "t4_gap_dp": (I, [P, I, I, I, P, P, P, P, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -79,6 +80,24 @@ class Engine:
         self.check(self.lib.t4_last_stats(self.h, C.byref(s)))
         return {"kernel_ms": s.kernel_ms, "chain_kernel_ms": s.chain_kernel_ms, "total_hits": s.total_hits,
                 "reads": s.reads, "tier_reads": list(s.tier_reads), "launches": s.launches}
+
+    def gap_dp(self, kind, targets, patterns, impl=0):
+        """targets: list of str (kind 0) or list of [len,4] int32 arrays (kind 1); patterns: list of str.
+        -> int32 [n, 4] (matches, mismatches, indels, status)."""
+        n = len(patterns)
+        toff = np.zeros(n + 1, dtype=np.int64)
+        poff = np.zeros(n + 1, dtype=np.int64)
+        toff[1:] = np.cumsum([len(t) for t in targets])
+        poff[1:] = np.cumsum([len(p) for p in patterns])
+        pbuf = np.frombuffer(("".join(patterns) + "\0").encode(), dtype=np.uint8)
+        if kind == 0:
+            tbuf = np.frombuffer(("".join(targets) + "\0").encode(), dtype=np.uint8)
+        else:
+            tbuf = np.ascontiguousarray(np.concatenate([np.asarray(t, dtype=np.int32).reshape(-1, 4) for t in targets] + [np.zeros((1, 4), np.int32)]))
+        out = np.zeros((n, 4), dtype=np.int32)
+        self.check(self.lib.t4_gap_dp(self.h, kind, impl, n, toff.ctypes.data_as(C.c_void_p), poff.ctypes.data_as(C.c_void_p),
+                                      tbuf.ctypes.data_as(C.c_void_p), pbuf.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def index(self, k, consider_barcode=False):
         return Index(self, k, consider_barcode)

@@ -25,9 +25,9 @@ static_assert(sizeof(t4k::OvRec) == 40, "OvRec layout");
 
 namespace {
 
-const int TIER_CAP[3] = {1024, 4096, 8192};
-const int TIER_MAXOV[3] = {128, 256, 512};
-const int TIER_BLOCKS_PER_CU[4] = {6, 2, 1, 2};
+const int QUERY_THREADS = 256;                 // threads (4 wavefronts) cooperating on one read
+const int TIER_CAP[4] = {1024, 2048, 4096, 8192};
+const int TIER_BLOCKS_PER_CU[T4_NTIER] = {6, 3, 2, 1, 2};
 const int G_CAP = 32768, G_MAXOV = 4096;
 
 struct HostSeq {
@@ -137,8 +137,8 @@ inline int nucNum(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 
 int ensureScratch(t4_ctx *c, int grid) {
   if (grid <= c->maxGrid) return T4_OK;
   int r;
-  if ((r = devAlloc(c, &c->dpRows, (size_t)grid * 6 * T4_ROWW * 64))) return r;
-  if ((r = devAlloc(c, &c->dpDir, (size_t)grid * 64 * T4_DIR_BYTES))) return r;
+  if ((r = devAlloc(c, &c->dpRows, (size_t)grid * (QUERY_THREADS / 64) * 6 * T4_ROWW * 64))) return r;
+  if ((r = devAlloc(c, &c->dpDir, (size_t)grid * QUERY_THREADS * T4_DIR_BYTES))) return r;
   c->maxGrid = grid;
   return T4_OK;
 }
@@ -146,8 +146,7 @@ int ensureGlobalTier(t4_ctx *c, int grid) {
   if (grid <= c->gGrid) return T4_OK;
   int r;
   if ((r = devAlloc(c, &c->gKeys, (size_t)grid * G_CAP))) return r;
-  if ((r = devAlloc(c, &c->gPairs, (size_t)grid * G_CAP))) return r;
-  if ((r = devAlloc(c, &c->gCand, (size_t)grid * G_CAP))) return r;
+  if ((r = devAlloc(c, &c->gPairs, (size_t)grid * G_CAP * 2))) return r;   // pairs + cand, contiguous per block
   if ((r = devAlloc(c, &c->gOv, (size_t)grid * G_MAXOV * 10))) return r;
   if ((r = devAlloc(c, &c->gFin, (size_t)grid * G_MAXOV * 10))) return r;
   if ((r = devAlloc(c, &c->gOrd, (size_t)grid * G_MAXOV))) return r;
@@ -205,6 +204,15 @@ int t4_sync(t4_ctx *c) {
 }
 const char *t4_last_error(t4_ctx *c) { return c ? c->err.c_str() : "null ctx"; }
 int t4_device_cus(t4_ctx *c) { return c ? c->cus : 0; }
+#ifdef T4_PHASE_TIMING
+// development aid: cycles spent per kernel phase (summed over workgroups) since the last call
+int t4_debug_phase_cycles(unsigned long long *out16) {
+  unsigned long long zero[T4_NPHASE] = {0};
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(t4k::g_phaseCycles), sizeof(zero)) != hipSuccess) return T4_ERR_HIP;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(t4k::g_phaseCycles), zero, sizeof(zero)) != hipSuccess) return T4_ERR_HIP;
+  return T4_OK;
+}
+#endif
 int t4_last_stats(t4_ctx *c, t4_stats *out) {
   if (!c || !out) return T4_ERR_ARG;
   *out = c->stats;
@@ -497,7 +505,7 @@ namespace {
 
 template <int CAP, int MAXOV>
 void launchTier(int grid, hipStream_t st, const T4IndexView &iv, const T4BatchView &bv, const T4Work &wk, const T4QueryArgs &qa) {
-  hipLaunchKernelGGL((t4k::queryKernel<CAP, MAXOV>), dim3(grid), dim3(64), 0, st, iv, bv, wk, qa);
+  hipLaunchKernelGGL((t4k::queryKernel<CAP, MAXOV>), dim3(grid), dim3(QUERY_THREADS), 0, st, iv, bv, wk, qa);
 }
 
 // Shared driver of t4_overlaps / t4_annotate_rough.
@@ -523,7 +531,7 @@ int runQuery(t4_index *ix, t4_batch *b, T4QueryArgs qa, bool useBarcode) {
   int binGrid = c->cus * 8;
   if ((long long)binGrid > n) binGrid = (int)n;
   hipLaunchKernelGGL(t4k::binKernel, dim3(binGrid), dim3(64), 0, c->stream, ix->view, b->view, useBarcode ? 1 : 0,
-                     TIER_CAP[0], TIER_CAP[1], TIER_CAP[2], c->lists, c->listCounts, (long long)n);
+                     TIER_CAP[0], TIER_CAP[1], TIER_CAP[2], TIER_CAP[3], c->lists, c->listCounts, (long long)n);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   c->stats.launches = 1;
@@ -542,13 +550,14 @@ int runQuery(t4_index *ix, t4_batch *b, T4QueryArgs qa, bool useBarcode) {
     wk.status = c->status; wk.hitCounter = c->hitCounter;
     wk.dpRows = c->dpRows; wk.dpDir = c->dpDir;
     int grid = grids[t] < cnt ? grids[t] : cnt;
-    if (t == 3) {
-      if ((r = ensureGlobalTier(c, grids[3]))) return r;
+    if (t == T4_NTIER - 1) {
+      if ((r = ensureGlobalTier(c, grids[T4_NTIER - 1]))) return r;
       wk.gKeys = c->gKeys; wk.gPairs = c->gPairs; wk.gCand = c->gCand; wk.gOv = c->gOv; wk.gFin = c->gFin; wk.gOrd = c->gOrd;
       wk.gCap = G_CAP; wk.gMaxOv = G_MAXOV;
       launchTier<0, 0>(grid, c->stream, ix->view, b->view, wk, qa);
     } else if (t == 0) launchTier<1024, 128>(grid, c->stream, ix->view, b->view, wk, qa);
-    else if (t == 1) launchTier<4096, 256>(grid, c->stream, ix->view, b->view, wk, qa);
+    else if (t == 1) launchTier<2048, 128>(grid, c->stream, ix->view, b->view, wk, qa);
+    else if (t == 2) launchTier<4096, 256>(grid, c->stream, ix->view, b->view, wk, qa);
     else launchTier<8192, 512>(grid, c->stream, ix->view, b->view, wk, qa);
     HIPCHK(c, hipGetLastError());
     ++c->stats.launches;
@@ -651,6 +660,36 @@ int t4_hits(t4_index *ix, t4_batch *b, int strand, int allow_total_skip, int64_t
     (void)hipFree(dHits);
   }
   (void)hipFree(dOff);
+  return T4_OK;
+}
+
+
+int t4_gap_dp(t4_ctx *c, int kind, int impl, int n, const int64_t *t_off, const int64_t *p_off, const void *t_data,
+              const char *p_chars, int32_t *out4) {
+  if (!c || n < 0 || (n > 0 && (!t_off || !p_off || !t_data || !p_chars || !out4)) || (kind != 0 && kind != 1)) return T4_ERR_ARG;
+  if (n == 0) return T4_OK;
+  (void)hipSetDevice(c->device);
+  int grid = (n + 63) / 64;
+  if (grid > c->cus * 4) grid = c->cus * 4;
+  int r;
+  if ((r = ensureScratch(c, grid))) return r;
+  long long *dT = nullptr, *dP = nullptr;
+  char *dTc = nullptr, *dPc = nullptr;
+  int4 *dTw = nullptr;
+  int *dOut = nullptr;
+  size_t tn = (size_t)t_off[n], pn = (size_t)p_off[n];
+  if ((r = devAlloc(c, &dT, (size_t)n + 1)) || (r = devAlloc(c, &dP, (size_t)n + 1)) || (r = devAlloc(c, &dPc, pn + 16)) || (r = devAlloc(c, &dOut, (size_t)n * 4))) return r;
+  if (kind == 0) { if ((r = devAlloc(c, &dTc, tn + 16))) return r; HIPCHK(c, hipMemcpy(dTc, t_data, tn, hipMemcpyHostToDevice)); }
+  else { if ((r = devAlloc(c, &dTw, tn + 1))) return r; HIPCHK(c, hipMemcpy(dTw, t_data, tn * sizeof(int4), hipMemcpyHostToDevice)); }
+  HIPCHK(c, hipMemcpy(dT, t_off, sizeof(long long) * ((size_t)n + 1), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(dP, p_off, sizeof(long long) * ((size_t)n + 1), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(dPc, p_chars, pn, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(t4k::gapDpKernel, dim3(grid), dim3(64), 0, c->stream, kind, impl, n, dT, dP, dTc, dTw, dPc, dOut, c->dpRows, c->dpDir);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(out4, dOut, sizeof(int) * (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  void *ptrs[] = {dT, dP, dTc, dPc, dTw, dOut};
+  for (void *q : ptrs) if (q) (void)hipFree(q);
   return T4_OK;
 }
 

@@ -6,7 +6,7 @@
 #define T4_MAXPOS (2 * T4_MAXL)
 #define T4_MAXGAP 320        // longest side of one gap DP (nomatchGapLimit is 288 at k = 9)
 #define T4_DIR_BYTES 49152   // per-lane traceback bytes of one gap DP
-#define T4_NTIER 4
+#define T4_NTIER 5
 
 // key of a k-mer hit, sortable as (strand, seq idx, diagonal, seq offset)
 #define T4_IDX_BITS 22

@@ -23,7 +23,11 @@ namespace t4k {
 // ------------------------------------------------------------------------------------------------
 // wave helpers (a workgroup is exactly one wavefront: blockDim.x == 64)
 // ------------------------------------------------------------------------------------------------
+// A workgroup (NT = blockDim.x threads, a multiple of 64) owns one read; wave-level helpers below are
+// combined through a few LDS words into workgroup-level scans / reductions.
 __device__ __forceinline__ int laneId() { return threadIdx.x & 63; }
+__device__ __forceinline__ int tid() { return threadIdx.x; }
+__device__ __forceinline__ int nthr() { return blockDim.x; }
 
 __device__ __forceinline__ int waveInclScan(int v) {
   int lane = laneId();
@@ -40,6 +44,29 @@ __device__ __forceinline__ int waveSum(int v) {
 __device__ __forceinline__ int waveMax(int v) {
   for (int d = 32; d > 0; d >>= 1) { int t = __shfl_xor(v, d); v = t > v ? t : v; }
   return v;
+}
+
+// workgroup inclusive scan / sum / any; `red` points at >= 16 ints of LDS. Two barriers each.
+__device__ __forceinline__ int blockInclScan(int v, int *red, int &total) {
+  int inc = waveInclScan(v);
+  int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if (laneId() == 63) red[wave] = inc;
+  __syncthreads();
+  int off = 0, tot = 0;
+  for (int w = 0; w < nw; ++w) { int x = red[w]; if (w < wave) off += x; tot += x; }
+  __syncthreads();
+  total = tot;
+  return inc + off;
+}
+__device__ __forceinline__ int blockSum(int v, int *red) {
+  v = waveSum(v);
+  int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if (laneId() == 0) red[wave] = v;
+  __syncthreads();
+  int tot = 0;
+  for (int w = 0; w < nw; ++w) tot += red[w];
+  __syncthreads();
+  return tot;
 }
 
 __host__ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
@@ -291,6 +318,157 @@ __device__ bool dpPosWeight(const int4 *w, int lent, const char *p, int lenp, DP
 }
 
 // ------------------------------------------------------------------------------------------------
+// Forward-only gap DPs for overlap scoring. GetOverlapsFromRead only consumes GetAlignStats of the
+// alignment (matches, mismatches, indels), and the reference's traceback is a deterministic function
+// of the DP cell it stands on, so the statistics of "the traceback path from this cell" obey the same
+// recurrences as the scores and can be carried forward: no direction matrix, no traceback, and a
+// single band-wide row per alignment (T4_DPW columns, updated in place) that lives in LDS.
+// Row storage: slotBase[(arr * T4_DPW + d) * slotStride], arr in {M, E, C0, C1} (affine) / {M, C}.
+// Counts are packed match | mismatch << 10 | indel << 20 (each < 1024 because gaps are <= T4_MAXGAP).
+// Returns false when the band is wider than T4_DPW (caller falls back to the scratch version).
+// ------------------------------------------------------------------------------------------------
+#define T4_DPW 32
+#define DP_PENDING 0xFFFFFFFFu
+#define DP_FAIL 0xFFFFFFFEu
+#define CNT_MATCH 1u
+#define CNT_MIS (1u << 10)
+#define CNT_INDEL (1u << 20)
+#define T4_SLOT(arr, d) slot[((arr) * T4_DPW + (d)) * slotStride]
+
+__device__ bool dpAffineFwd(const char *t, int lent, const char *p, int lenp, int *slot, int slotStride,
+                            int &nMatch, int &nMis, int &nIndel) {
+  nMatch = nMis = nIndel = 0;
+  if (lent == 0 || lenp == 0) return true;
+  if (lent == 1 && lenp == 1) {
+    char a = t[0], b = p[0];
+    if (a == b || a == 'N' || b == 'N') nMatch = 1; else nMis = 1;
+    return true;
+  }
+  if (lent == lenp) {
+    // Substitution-only shortcut. With equal lengths every alignment that leaves the main diagonal opens at
+    // least one insertion and one deletion (2 x -5) and so scores <= 2*len - 12 on every prefix, while the
+    // diagonal prefix scores 2*i - 4*mm_i; for mm <= 3 the diagonal is therefore optimal on every prefix and
+    // the reference's traceback (which tests the diagonal move first, AlignAlgo.hpp:338-349) walks it.
+    int mm = 0;
+    for (int i = 0; i < lent; ++i) { char a = t[i], b = p[i]; mm += (a == b || a == 'N' || b == 'N') ? 0 : 1; }
+    if (mm <= 3) { nMatch = lent - mm; nMis = mm; return true; }
+  }
+  int leftBand = 5, rightBand = 5;
+  if (lent > lenp) rightBand += lent - lenp; else if (lent < lenp) leftBand += lenp - lent;
+  const int W = leftBand + rightBand + 1;
+  if (W > T4_DPW || lent > T4_MAXGAP || lenp > T4_MAXGAP) return false;
+  const int negInf = (lent + 1) * (lenp + 1) * (-4);
+  const int e0 = -4 + (lenp + 1) * (-4);   // e[0][j], j >= 1 (the reference's stale loop variable)
+  // row 0 in the band coordinates of row 0: d' <-> j' = d' - leftBand
+  for (int d = 0; d < W; ++d) {
+    int j = d - leftBand;
+    if (j < 0 || j > lent) continue;
+    if (j == 0) { T4_SLOT(0, d) = 0; T4_SLOT(1, d) = 0; T4_SLOT(2, d) = 0; T4_SLOT(3, d) = 0; }
+    else {
+      T4_SLOT(0, d) = -4 - 4 * j; T4_SLOT(1, d) = e0;
+      T4_SLOT(2, d) = (int)(CNT_INDEL * (unsigned)(j + (j > 4 * (lenp + 1) ? 1 : 0)));  // state 0 at (0, j)
+      T4_SLOT(3, d) = (int)(CNT_INDEL * (unsigned)(1 + j));                               // state 1 at (0, j)
+    }
+  }
+  for (int i = 1; i <= lenp; ++i) {
+    const int start = (i - leftBand < 1) ? 1 : (i - leftBand);
+    const int end = (i + rightBand > lent) ? lent : (i + rightBand);
+    const char pc = p[i - 1];
+    int mLeft, fLeft; unsigned c0Left, c2Left;
+    if (start > 1) { mLeft = negInf; fLeft = negInf; c0Left = 0; c2Left = 0; }
+    else { mLeft = -4 - 4 * i; fLeft = -4 - 4 * i; c0Left = CNT_INDEL * (unsigned)i; c2Left = CNT_INDEL * (unsigned)(1 + i); }
+    for (int j = start; j <= end; ++j) {
+      const int d = j - i + leftBand;          // band column in row i; row i-1 keeps (i-1, j-1) at d, (i-1, j) at d+1
+      int mDiag = T4_SLOT(0, d); unsigned c0Diag = (unsigned)T4_SLOT(2, d);
+      int mUp, eUp; unsigned c0Up, c1Up;
+      if (d + 1 < W) { mUp = T4_SLOT(0, d + 1); eUp = T4_SLOT(1, d + 1); c0Up = (unsigned)T4_SLOT(2, d + 1); c1Up = (unsigned)T4_SLOT(3, d + 1); }
+      else { mUp = negInf; eUp = negInf; c0Up = 0; c1Up = 0; }
+      int e = eUp - 1, eo = mUp - 5;
+      if (eo > e) e = eo;
+      int f = fLeft - 1, fo = mLeft - 5;
+      if (fo > f) f = fo;
+      const char tc = t[j - 1];
+      const bool eq = (tc == pc || tc == 'N' || pc == 'N');
+      const int dsc = mDiag + (eq ? 2 : -2);
+      int m = dsc;
+      if (e > m) m = e;
+      if (f > m) m = f;
+      const unsigned c1 = CNT_INDEL + ((eo == e) ? c0Up : c1Up);
+      const unsigned c2 = CNT_INDEL + ((fo == f) ? c0Left : c2Left);
+      unsigned c0;
+      if (dsc == m) c0 = c0Diag + (eq ? CNT_MATCH : CNT_MIS);
+      else c0 = (f >= e) ? c2 : c1;
+      T4_SLOT(0, d) = m; T4_SLOT(1, d) = e; T4_SLOT(2, d) = (int)c0; T4_SLOT(3, d) = (int)c1;
+      mLeft = m; fLeft = f; c0Left = c0; c2Left = c2;
+    }
+    // column 0 of this row, read as (i, 0) by cell (i + 1, 1)
+    const int d0 = leftBand - i;
+    if (d0 >= 0) { T4_SLOT(0, d0) = -4 - 4 * i; T4_SLOT(1, d0) = -4 - i; T4_SLOT(2, d0) = (int)(CNT_INDEL * (unsigned)i); T4_SLOT(3, d0) = (int)(CNT_INDEL * (unsigned)i); }
+    // sentinel right of the band, read as (i, end + 1) by cell (i + 1, end + 1): its band column in row i is W
+    // (handled by the d + 1 < W test); a sentinel left of the band is the `start > 1` case above.
+  }
+  const unsigned c = (unsigned)T4_SLOT(2, lent - lenp + leftBand);
+  nMatch = (int)(c & 1023u); nMis = (int)((c >> 10) & 1023u); nIndel = (int)(c >> 20);
+  return true;
+}
+
+__device__ bool dpPosWeightFwd(const int4 *w, int lent, const char *p, int lenp, int *slot, int slotStride,
+                               int &nMatch, int &nMis, int &nIndel) {
+  nMatch = nMis = nIndel = 0;
+  if (lent == 0 || lenp == 0) return true;
+  if (lent == 1 && lenp == 1) {
+    if (baseEqualW(w[0], p[0])) nMatch = 1; else nMis = 1;
+    return true;
+  }
+  if (lent == lenp) {
+    int mm = 0;
+    for (int i = 0; i < lent; ++i) mm += baseEqualW(w[i], p[i]) ? 0 : 1;
+    if ((lent - mm) * 2 - mm * 2 >= lent * 2 - 8) { nMatch = lent - mm; nMis = mm; return true; }
+  }
+  int leftBand = 5, rightBand = 5;
+  if (lent > lenp) rightBand += lent - lenp; else if (lent < lenp) leftBand += lenp - lent;
+  const int W = leftBand + rightBand + 1;
+  if (W > T4_DPW || lent > T4_MAXGAP || lenp > T4_MAXGAP) return false;
+  const int negInf = (lent + 1) * (lenp + 1) * (-4);
+  for (int d = 0; d < W; ++d) {
+    int j = d - leftBand;
+    if (j < 0 || j > lent) continue;
+    if (j == 0) { T4_SLOT(0, d) = 0; T4_SLOT(1, d) = 0; }
+    else { T4_SLOT(0, d) = -4 - 4 * j; T4_SLOT(1, d) = (int)(CNT_MATCH + CNT_INDEL * (unsigned)(j - 1)); }
+  }
+  for (int i = 1; i <= lenp; ++i) {
+    const int start = (i - leftBand < 1) ? 1 : (i - leftBand);
+    const int end = (i + rightBand > lent) ? lent : (i + rightBand);
+    const char pc = p[i - 1];
+    int mLeft; unsigned cLeft;
+    if (start > 1) { mLeft = negInf; cLeft = 0; }
+    else { mLeft = -4 - 4 * i; cLeft = CNT_MATCH + CNT_INDEL * (unsigned)(i - 1); }
+    for (int j = start; j <= end; ++j) {
+      const int d = j - i + leftBand;
+      int mDiag = T4_SLOT(0, d); unsigned cDiag = (unsigned)T4_SLOT(1, d);
+      int mUp; unsigned cUp;
+      if (d + 1 < W) { mUp = T4_SLOT(0, d + 1); cUp = (unsigned)T4_SLOT(1, d + 1); } else { mUp = negInf; cUp = 0; }
+      const bool eq = baseEqualW(w[j - 1], pc);
+      const int dsc = mDiag + (eq ? 2 : -2);
+      int m = dsc;
+      if (mLeft - 4 > m) m = mLeft - 4;
+      if (mUp - 4 > m) m = mUp - 4;
+      unsigned c;
+      if (dsc == m) c = cDiag + (eq ? CNT_MATCH : CNT_MIS);
+      else if (mUp - 4 == m) c = cUp + CNT_INDEL;
+      else c = cLeft + CNT_INDEL;
+      T4_SLOT(0, d) = m; T4_SLOT(1, d) = (int)c;
+      mLeft = m; cLeft = c;
+    }
+    const int d0 = leftBand - i;
+    if (d0 >= 0) { T4_SLOT(0, d0) = -4 - 4 * i; T4_SLOT(1, d0) = (int)(CNT_MATCH + CNT_INDEL * (unsigned)(i - 1)); }
+  }
+  const unsigned c = (unsigned)T4_SLOT(1, lent - lenp + leftBand);
+  nMatch = (int)(c & 1023u); nMis = (int)((c >> 10) & 1023u); nIndel = (int)(c >> 20);
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
 // LIS of one run (SeqSet::LongestIncreasingSubsequence, SeqSet.hpp:342-499), executed by one lane.
 // hits: (b << 12 | a) sorted by (b, a). Returns the chain length; chain written to lisOut.
 // ------------------------------------------------------------------------------------------------
@@ -396,6 +574,9 @@ struct OvRec {
 #define OV_PLUS 1
 #define OV_SIMZERO 2
 #define OV_ISREF 4
+#define OV_GENETYPE(f) (((f) >> 8) & 255)
+#define OV_NAME0(f) ((char)(((f) >> 16) & 255))
+#define OV_NAME2(f) ((char)(((unsigned)(f)) >> 24))
 
 __device__ __forceinline__ double ovSim(const OvRec &o) {
   if (o.flags & OV_SIMZERO) return 0.0;
@@ -422,6 +603,16 @@ __device__ __forceinline__ bool ovLess(const OvRec &a, const OvRec &b, bool scor
 // per-wave working set. CAP = hit capacity, MAXOV = overlap capacity. LDS tiers use static
 // __shared__ arrays; the last tier (CAP == 0) works out of per-block global scratch.
 // ------------------------------------------------------------------------------------------------
+// optional per-phase cycle accounting (build with -DT4_PHASE_TIMING; read back through T4Work.phase)
+#ifdef T4_PHASE_TIMING
+#define T4_NPHASE 16
+__device__ unsigned long long g_phaseCycles[T4_NPHASE];
+#define PHASE_MARK(ws, id)                                                                  \
+  do { if (threadIdx.x == 0) { long long now_ = clock64(); atomicAdd(&g_phaseCycles[(ws)->curPhase], (unsigned long long)(now_ - (ws)->phaseT0)); (ws)->phaseT0 = now_; (ws)->curPhase = (id); } } while (0)
+#else
+#define PHASE_MARK(ws, id) do { } while (0)
+#endif
+
 struct WaveMem {
   unsigned long long *keys;  // [cap]   hit keys; later per-run {chain u32[n], top u16[n], link u16[n]}
   unsigned *pairs;           // [cap]   (b << 12 | a) of candidate runs; first: posPref
@@ -434,16 +625,18 @@ struct WaveMem {
 };
 
 struct WaveState { // wave-uniform scalars kept in LDS
-  int ovCount, candCount, overflow, unsupported, finCount, nContig;
+  int ovCount, candCount, jobCount, overflow, unsupported, finCount, nContig;
   int novelMin[2];
+  int red[16];
   short contigA[64], contigB[64];
+  long long phaseT0; int curPhase;
 };
 
 // Build segment chars (forward + reverse complement of the segment) from the packed read.
 __device__ void loadSegment(const T4BatchView &bv, long long r, int segStart, int segLen, WaveMem &wm) {
   const unsigned *pk = bv.pk + r * bv.wpk;
   const unsigned *nm = bv.nm + r * bv.wnm;
-  for (int i = laneId(); i < segLen; i += 64) {
+  for (int i = tid(); i < segLen; i += nthr()) {
     int g = segStart + i;
     unsigned w = pk[g >> 4], m = nm[g >> 5];
     int code = (w >> ((g & 15) * 2)) & 3;
@@ -452,7 +645,7 @@ __device__ void loadSegment(const T4BatchView &bv, long long r, int segStart, in
     wm.seg[i] = c;
     wm.rc[segLen - 1 - i] = isN ? 'N' : (code == 0 ? 'T' : code == 1 ? 'G' : code == 2 ? 'C' : 'A');
   }
-  if (laneId() == 0) { wm.seg[segLen] = 0; wm.rc[segLen] = 0; }
+  if (tid() == 0) { wm.seg[segLen] = 0; wm.rc[segLen] = 0; }
   __syncthreads();
 }
 
@@ -472,14 +665,14 @@ __device__ __forceinline__ unsigned long long kmerAt(const char *S, int p, int K
 // of hit records H that GetHitsFromRead would emit (before the barcode filter). Wave-uniform result.
 // vjOnly only changes the later expansion.
 __device__ int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int strandArg, int barcode,
-                             bool allowTotalSkip, unsigned *posStart, unsigned *posPref) {
-  const int K = ix.k, lane = laneId();
+                             bool allowTotalSkip, unsigned *posStart, unsigned *posPref, int *red) {
+  const int K = ix.k, lane = tid(), NT = nthr();
   const int nk = segLen - K + 1;           // k-mers per strand
   const unsigned long long mask = K < 32 ? ((1ull << (2 * K)) - 1ull) : ~0ull;
   int skipLimit = ix.firstIsRef ? 0 : K / 2;
   // raw list sizes (0 for invalid k-mers) and starts, for both strands
   int big = 0;
-  for (int q = lane; q < 2 * nk; q += 64) {
+  for (int q = lane; q < 2 * nk; q += NT) {
     int st = q >= nk, p = st ? q - nk : q;
     bool active = st ? (strandArg != 1) : (strandArg != -1);
     unsigned start = 0, cnt = 0;
@@ -491,11 +684,10 @@ __device__ int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int
     posStart[q] = start; posPref[q] = cnt;
     if (cnt >= 100) big = 1;
   }
-  big = __any(big);
-  __syncthreads();
+  big = blockSum(big, red) != 0;
   if ((skipLimit == 0 && !allowTotalSkip) || !big) {
     // no `continue` can fire: prevKmerCode is always the code of the previous position
-    for (int q = lane; q < 2 * nk; q += 64) {
+    for (int q = lane; q < 2 * nk; q += NT) {
       int st = q >= nk, p = st ? q - nk : q;
       const char *S = st ? wm.rc : wm.seg;
       bool emit = true;
@@ -535,12 +727,13 @@ __device__ int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int
   __syncthreads();
   // exclusive prefix sums over the 2*nk positions
   int carry = 0;
-  for (int q0 = 0; q0 < 2 * nk; q0 += 64) {
+  for (int q0 = 0; q0 < 2 * nk; q0 += NT) {
     int q = q0 + lane;
     int v = q < 2 * nk ? (int)posPref[q] : 0;
-    int inc = waveInclScan(v);
+    int tot;
+    int inc = blockInclScan(v, red, tot);
     if (q < 2 * nk) posPref[q] = (unsigned)(carry + inc - v);
-    carry += __shfl(inc, 63);
+    carry += tot;
   }
   if (lane == 0) posPref[2 * nk] = (unsigned)carry;
   __syncthreads();
@@ -550,10 +743,10 @@ __device__ int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int
 // Expand postings into sortable keys. Returns the number of valid keys (after barcode / VJ filters);
 // invalid slots get the all-ones key and sort to the end.
 __device__ int expandHits(const T4IndexView &ix, WaveMem &wm, int nk, int H, int barcode, bool vjOnly,
-                          const unsigned *posStart, const unsigned *posPref) {
-  const int lane = laneId();
+                          const unsigned *posStart, const unsigned *posPref, int *red) {
+  const int lane = tid(), NT = nthr();
   int dropped = 0;
-  for (int s = lane; s < H; s += 64) {
+  for (int s = lane; s < H; s += NT) {
     int lo = 0, hi = 2 * nk - 1;   // last q with posPref[q] <= s
     while (lo < hi) {
       int mid = (lo + hi + 1) >> 1;
@@ -579,22 +772,16 @@ __device__ int expandHits(const T4IndexView &ix, WaveMem &wm, int nk, int H, int
     } else ++dropped;
     wm.keys[s] = key;
   }
-#ifdef T4_DEBUG
-  int mydrop = dropped;
-#endif
-  dropped = waveSum(dropped);
-#ifdef T4_DEBUG
-  if (vjOnly) printf("DBG expand lane %d H %d mydrop %d dropped %d\n", lane, H, mydrop, dropped);
-#endif
+  dropped = blockSum(dropped, red);
   return H - dropped;
 }
 
 // wave-cooperative bitonic sort of n2 (power of two) 64-bit keys
 __device__ void bitonicSort(unsigned long long *keys, int n2) {
-  const int lane = laneId();
+  const int lane = tid(), NT = nthr();
   for (int k = 2; k <= n2; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = lane; t < (n2 >> 1); t += 64) {
+      for (int t = lane; t < (n2 >> 1); t += NT) {
         int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
         int p = i | j;
         bool up = (i & k) == 0;
@@ -619,7 +806,20 @@ __device__ void chainRun(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int 
   unsigned *lisOut = (unsigned *)(wm.keys + s);
   unsigned short *top = (unsigned short *)(lisOut + n);
   unsigned short *link = top + n;
-  int lisSize = lisLane(wm.pairs + s, n, lisOut, top, link);
+  // A run whose (b, a)-sorted hits are strictly increasing in both coordinates is its own LIS: the
+  // equal-b collapse and the replacement sweep of LongestIncreasingSubsequence are then identities.
+  bool mono = true;
+  {
+    unsigned prev = wm.pairs[s];
+    for (int t = 1; t < n; ++t) {
+      unsigned cur = wm.pairs[s + t];
+      mono = mono && (PA(cur) > PA(prev)) && (PB(cur) > PB(prev));
+      prev = cur;
+    }
+  }
+  int lisSize;
+  if (mono) { for (int t = 0; t < n; ++t) lisOut[t] = wm.pairs[s + t]; lisSize = n; }
+  else lisSize = lisLane(wm.pairs + s, n, lisOut, top, link);
   if (lisSize * K < hitLenRequired) return;
   int hitLen = totalHitLen(lisOut, lisSize, K, false);
   if (hitLen < hitLenRequired) return;
@@ -630,7 +830,10 @@ __device__ void chainRun(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int 
   o.ss = PB(lisOut[0]); o.se = PB(lisOut[lisSize - 1]) + K - 1;
   o.matchCnt = 2 * hitLen; o.indelCnt = 0;
   o.chainPos = s; o.chainLen = lisSize;
-  o.flags = (plus ? OV_PLUS : 0) | (isRef ? OV_ISREF : 0) | OV_SIMZERO;
+  {
+    const T4SeqInfo si = ix.seqs[seqIdx];   // gene class + chain letters ride along for the V/J/C selection
+    o.flags = (plus ? OV_PLUS : 0) | (isRef ? OV_ISREF : 0) | OV_SIMZERO | ((int)si.geneType << 8) | ((int)si.name0 << 16) | ((int)si.name2 << 24);
+  }
   if (!isRef && hitLen * 2 < o.se - o.ss + 1) return;
   int slot = atomicAdd(&ws->ovCount, 1);
   if (slot < wm.maxOv) wm.ov[slot] = o; else ws->overflow = 1;
@@ -641,7 +844,7 @@ __device__ void chainRun(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int 
 // `filter` is the reference's filter argument. removeOnlyRepeats needs a hit with repeats > 10000,
 // impossible while H <= 65535 only if ... it is handled by the caller refusing such reads (status).
 __device__ void overlapsFromKeys(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int Hv, int hitLenRequired, int filter) {
-  const int lane = laneId(), K = ix.k;
+  const int lane = tid(), NT = nthr(), K = ix.k;
   if (lane == 0) {
     ws->novelMin[0] = ws->novelMin[1] = 3;
     ws->candCount = 0;
@@ -668,8 +871,9 @@ __device__ void overlapsFromKeys(const T4IndexView &ix, WaveMem &wm, WaveState *
     }
   }
   __syncthreads();
+  PHASE_MARK(ws, 5);
   // R1: every hit that starts a run measures it; qualifying runs become candidates
-  for (int i0 = 0; i0 < Hv; i0 += 64) {
+  for (int i0 = 0; i0 < Hv; i0 += NT) {
     int i = i0 + lane;
     if (i < Hv) {
       unsigned long long ki = wm.keys[i];
@@ -705,6 +909,7 @@ __device__ void overlapsFromKeys(const T4IndexView &ix, WaveMem &wm, WaveState *
   }
   __syncthreads();
   const int nCand = ws->candCount < wm.candCap ? ws->candCount : wm.candCap;
+  PHASE_MARK(ws, 6);
   // R2: long multi-diagonal runs (reference genes only) are ordered by (b, a) by the whole wave
   if (ix.radius > 0) {
     for (int c = 0; c < nCand; ++c) {
@@ -714,26 +919,27 @@ __device__ void overlapsFromKeys(const T4IndexView &ix, WaveMem &wm, WaveState *
       if (!ix.seqs[KEY_IDX(ks)].isRef) continue;              // wave-uniform
       // upper half of the run's own key area; keys[s] itself (u32 words 0,1) stays intact for R3
       unsigned *tmp = (unsigned *)(wm.keys + s) + n;
-      for (int t = lane; t < n; t += 64) {
+      for (int t = lane; t < n; t += NT) {
         unsigned long long kt = wm.keys[s + t];
         int b = KEY_B(kt), a = KEY_C(kt) - T4_C_BIAS + b;
         wm.pairs[s + t] = ((unsigned)b << 12) | (unsigned)a;
       }
       __syncthreads();
-      for (int t = lane; t < n; t += 64) {
+      for (int t = lane; t < n; t += NT) {
         unsigned v = wm.pairs[s + t];
         int rank = 0;
         for (int u = 0; u < n; ++u) { unsigned x = wm.pairs[s + u]; rank += (x < v) ? 1 : 0; }
         tmp[rank] = v;                                        // pairs of one run are distinct
       }
       __syncthreads();
-      for (int t = lane; t < n; t += 64) wm.pairs[s + t] = tmp[t];
+      for (int t = lane; t < n; t += NT) wm.pairs[s + t] = tmp[t];
       __syncthreads();
     }
   }
   __syncthreads();   // R3 overwrites key areas that R2's wave-uniform tests read
+  PHASE_MARK(ws, 7);
   // R3: one lane per candidate run: extract (b << 12 | a), order by (b, a), chain
-  for (int c = lane; c < nCand; c += 64) {
+  for (int c = lane; c < nCand; c += NT) {
     int s = wm.cand[c] & 0xFFFF, n = wm.cand[c] >> 16;
     unsigned long long ks = wm.keys[s];
     int idx = KEY_IDX(ks), plus = KEY_PLUS(ks);
@@ -774,13 +980,149 @@ __device__ __forceinline__ bool lowComplex(const char *r, int rs, int re) {
   return lowCnt >= 2;
 }
 
-// Anchor walk + gap DPs of one overlap (SeqSet.hpp:1829-2019). One lane.
-__device__ void scoreOverlap(const T4IndexView &ix, WaveMem &wm, WaveState *ws, OvRec &o, DPScratch sc, int lane) {
+// Quick exits of the two gap aligners: empty side, 1 x 1, and the equal-length cases that provably (affine) or
+// by the reference's own early return (posWeight, AlignAlgo.hpp:81-103) stay on the main diagonal.
+// Returns true when the packed GetAlignStats counts could be produced without a banded DP.
+__device__ bool dpAffineQuick(const char *t, int lent, const char *p, int lenp, unsigned &cnt) {
+  cnt = 0;
+  if (lent == 0 || lenp == 0) return true;
+  if (lent != lenp) return false;
+  // Equal lengths: every alignment leaving the diagonal opens an insertion and a deletion (2 x -5), so it
+  // scores <= 2*i - 12 on a prefix of length i while the diagonal scores 2*i - 4*mm_i: for mm <= 3 the diagonal
+  // is optimal on every prefix and the traceback, which tests the diagonal move first (AlignAlgo.hpp:338-349),
+  // walks it. (1 x 1 is the reference's own special case and gives the same counts.)
+  int mm = 0;
+  for (int i = 0; i < lent; ++i) { char a = t[i], b = p[i]; mm += (a == b || a == 'N' || b == 'N') ? 0 : 1; }
+  if (lent > 1 && mm > 3) return false;
+  cnt = CNT_MATCH * (unsigned)(lent - mm) + CNT_MIS * (unsigned)mm;
+  return true;
+}
+__device__ bool dpPosWeightQuick(const int4 *w, int lent, const char *p, int lenp, unsigned &cnt) {
+  cnt = 0;
+  if (lent == 0 || lenp == 0) return true;
+  if (lent != lenp) return false;
+  int mm = 0;
+  for (int i = 0; i < lent; ++i) mm += baseEqualW(w[i], p[i]) ? 0 : 1;
+  if (lent > 1 && !((lent - mm) * 2 - mm * 2 >= lent * 2 - 8)) return false;
+  cnt = CNT_MATCH * (unsigned)(lent - mm) + CNT_MIS * (unsigned)mm;
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wave-cooperative banded gap DP: lane d owns band column d (W = 11 + |lent - lenp| <= 64 columns) and the
+// cells are swept in the skewed order s = 2*i + d, in which the left neighbour (i, d-1) and the upper
+// neighbour (i-1, d+1) were both produced at step s-1 by the adjacent lanes and the diagonal neighbour
+// (i-1, d) is the lane's own previous cell: one alignment costs 2*lenp + W shuffle rounds instead of
+// lenp * W serial cell updates. Scores, borders, sentinels and tie-breaks are those of
+// AlignAlgo::GlobalAlignment (PW == false) / GlobalAlignment_PosWeight (PW == true); the result is the packed
+// GetAlignStats of the reference's traceback (see the forward-count recurrences above dpAffineFwd).
+// Every lane of the wave must call it with the same arguments. tbuf: >= lent bytes of LDS (affine only).
+// ------------------------------------------------------------------------------------------------
+template <bool PW>
+__device__ unsigned dpWave(const char *t, const int4 *w, int lent, const char *p, int lenp, char *tbuf) {
+  const int d = laneId();
+  if (lent == 0 || lenp == 0) return 0u;
+  if (lent == 1 && lenp == 1) {
+    bool eq = PW ? baseEqualW(w[0], p[0]) : (t[0] == p[0] || t[0] == 'N' || p[0] == 'N');
+    return eq ? CNT_MATCH : CNT_MIS;
+  }
+  if (PW && lent == lenp) {   // the reference's ungapped early return (AlignAlgo.hpp:81-103)
+    int mm = 0;
+    for (int i = d; i < lent; i += 64) mm += baseEqualW(w[i], p[i]) ? 0 : 1;
+    mm = waveSum(mm);
+    if ((lent - mm) * 2 - mm * 2 >= lent * 2 - 8) return CNT_MATCH * (unsigned)(lent - mm) + CNT_MIS * (unsigned)mm;
+  }
+  int leftBand = 5, rightBand = 5;
+  if (lent > lenp) rightBand += lent - lenp; else if (lent < lenp) leftBand += lenp - lent;
+  const int W = leftBand + rightBand + 1;
+  if (W > 64 || lent > T4_MAXGAP || lenp > T4_MAXGAP) return DP_FAIL;
+  if (!PW) { for (int i = d; i < lent; i += 64) tbuf[i] = t[i]; }
+  const int negInf = (lent + 1) * (lenp + 1) * (-4);
+  const int e0 = -4 + (lenp + 1) * (-4);
+  const int q4 = 4 * (lenp + 1);
+  // the lane's cell of row 0
+  int M = negInf, E = negInf, F = negInf;
+  unsigned C0 = 0, C1 = 0, C2 = 0;
+  {
+    int j0 = d - leftBand;
+    if (d < W && j0 >= 0 && j0 <= lent) {
+      if (j0 == 0) { M = 0; E = 0; F = 0; }
+      else if (PW) { M = -4 - 4 * j0; C0 = CNT_MATCH + CNT_INDEL * (unsigned)(j0 - 1); }
+      else { M = -4 - 4 * j0; E = e0; F = -4 - j0; C0 = CNT_INDEL * (unsigned)(j0 + (j0 > q4 ? 1 : 0)); C1 = CNT_INDEL * (unsigned)(1 + j0); C2 = CNT_INDEL * (unsigned)j0; }
+    }
+  }
+  const int lastStep = 2 * lenp + W - 1;
+  for (int s = 2; s <= lastStep; ++s) {
+    int lM = __shfl_up(M, 1), uM = __shfl_down(M, 1);
+    unsigned lC0 = __shfl_up(C0, 1), uC0 = __shfl_down(C0, 1);
+    int lF = 0, uE = 0; unsigned lC2 = 0, uC1 = 0;
+    if (!PW) { lF = __shfl_up(F, 1); lC2 = __shfl_up(C2, 1); uE = __shfl_down(E, 1); uC1 = __shfl_down(C1, 1); }
+    const int i2 = s - d, i = i2 >> 1, j = i - leftBand + d;
+    if (d < W && (i2 & 1) == 0 && i >= 1 && i <= lenp && j >= 1 && j <= lent) {
+      if (j == 1) {             // left neighbour is column 0
+        lM = -4 - 4 * i;
+        if (PW) lC0 = CNT_MATCH + CNT_INDEL * (unsigned)(i - 1);
+        else { lF = -4 - 4 * i; lC0 = CNT_INDEL * (unsigned)i; lC2 = CNT_INDEL * (unsigned)(1 + i); }
+      } else if (d == 0) { lM = negInf; lF = negInf; lC0 = 0; lC2 = 0; }
+      if (i == 1) {             // upper neighbour is row 0
+        uM = -4 - 4 * j;
+        if (PW) uC0 = CNT_MATCH + CNT_INDEL * (unsigned)(j - 1);
+        else { uE = e0; uC0 = CNT_INDEL * (unsigned)(j + (j > q4 ? 1 : 0)); uC1 = CNT_INDEL * (unsigned)(1 + j); }
+      } else if (d + 1 >= W) { uM = negInf; uE = negInf; uC0 = 0; uC1 = 0; }
+      int dM; unsigned dC0;     // diagonal neighbour
+      if (i == 1) {
+        int jj = j - 1;
+        dM = jj == 0 ? 0 : -4 - 4 * jj;
+        dC0 = jj == 0 ? 0u : (PW ? CNT_MATCH + CNT_INDEL * (unsigned)(jj - 1) : CNT_INDEL * (unsigned)(jj + (jj > q4 ? 1 : 0)));
+      } else if (j == 1) {
+        dM = -4 - 4 * (i - 1);
+        dC0 = PW ? CNT_MATCH + CNT_INDEL * (unsigned)(i - 2) : CNT_INDEL * (unsigned)(i - 1);
+      } else { dM = M; dC0 = C0; }
+      const char pc = p[i - 1];
+      if (PW) {
+        const bool eq = baseEqualW(w[j - 1], pc);
+        const int dsc = dM + (eq ? 2 : -2);
+        int m = dsc;
+        if (lM - 4 > m) m = lM - 4;
+        if (uM - 4 > m) m = uM - 4;
+        unsigned c;
+        if (dsc == m) c = dC0 + (eq ? CNT_MATCH : CNT_MIS);
+        else if (uM - 4 == m) c = uC0 + CNT_INDEL;
+        else c = lC0 + CNT_INDEL;
+        M = m; C0 = c;
+      } else {
+        const char tc = tbuf[j - 1];
+        const bool eq = (tc == pc || tc == 'N' || pc == 'N');
+        int e = uE - 1, eo = uM - 5;
+        if (eo > e) e = eo;
+        int f = lF - 1, fo = lM - 5;
+        if (fo > f) f = fo;
+        const int dsc = dM + (eq ? 2 : -2);
+        int m = dsc;
+        if (e > m) m = e;
+        if (f > m) m = f;
+        const unsigned c1 = CNT_INDEL + ((eo == e) ? uC0 : uC1);
+        const unsigned c2 = CNT_INDEL + ((fo == f) ? lC0 : lC2);
+        unsigned c0;
+        if (dsc == m) c0 = dC0 + (eq ? CNT_MATCH : CNT_MIS);
+        else c0 = (f >= e) ? c2 : c1;
+        M = m; E = e; F = f; C0 = c0; C1 = c1; C2 = c2;
+      }
+    }
+  }
+  return __shfl(C0, lent - lenp + leftBand);
+}
+
+
+// Anchor walk of one overlap (SeqSet.hpp:1829-2019). One lane. The gap alignments themselves are hoisted out
+// of this data-dependent loop (a wavefront would otherwise execute them one lane at a time):
+//   collect == true : append one job (ordIdx | j << 16) per gap that needs an alignment
+//   collect == false: consume the job results stored behind the chain and finish the overlap
+__device__ void walkOverlap(const T4IndexView &ix, WaveMem &wm, WaveState *ws, OvRec &o, int ordIdx, bool collect) {
   const int K = ix.k;
-  const char *r = (o.flags & OV_PLUS) ? wm.seg : wm.rc;
-  const T4SeqInfo si = ix.seqs[o.seqIdx];
-  const bool isRef = si.isRef != 0;
+  const bool isRef = (o.flags & OV_ISREF) != 0;
   const unsigned *hc = (const unsigned *)(wm.keys + o.chainPos);
+  const unsigned *res = hc + o.chainLen;
   int matchCnt = 2 * K, indelCnt = 0;
   bool simOne = true;
   for (int j = 1; j < o.chainLen; ++j) {
@@ -803,19 +1145,38 @@ __device__ void scoreOverlap(const T4IndexView &ix, WaveMem &wm, WaveState *ws, 
     if (doDP) {
       int lent = qb - (pb + K), lenp = qa - (pa + K);
       if (lent > ix.nomatchGapLimit || lenp > ix.nomatchGapLimit) { simOne = false; break; }
-      int c0, c1, c2;
-      bool ok;
-      if (isRef) ok = dpAffine(ix.cons + si.consOff + pb + K, lent, r + pa + K, lenp, sc, lane, c0, c1, c2);
-      else ok = dpPosWeight(ix.pw + si.pwOff + pb + K, lent, r + pa + K, lenp, sc, lane, c0, c1, c2, (signed char *)0);
-      if (!ok) { ws->unsupported = 1; simOne = false; break; }
-      matchCnt += 2 * c0; indelCnt += c2;
+      if (collect) {
+        int slot = atomicAdd(&ws->jobCount, 1);
+        if (slot < wm.candCap) wm.cand[slot] = (unsigned)ordIdx | ((unsigned)j << 16); else ws->overflow = 1;
+        continue;
+      }
+      unsigned c = res[j];
+      if (c == DP_FAIL) { ws->unsupported = 1; simOne = false; break; }
+      matchCnt += 2 * (int)(c & 1023u); indelCnt += (int)(c >> 20);
       if (doDP == 1) { if ((ix.radius == 0 || !isRef) && indelCnt > 0) { simOne = false; break; } }
       else { if (!isRef && indelCnt > 0) { simOne = false; break; } }
     }
   }
+  if (collect) return;
   o.matchCnt = matchCnt; o.indelCnt = indelCnt;
   if (simOne) o.flags &= ~OV_SIMZERO; else o.flags |= OV_SIMZERO;
-  if (lowComplex(r, o.rs, o.re)) o.flags |= OV_SIMZERO;
+  if (lowComplex((o.flags & OV_PLUS) ? wm.seg : wm.rc, o.rs, o.re)) o.flags |= OV_SIMZERO;
+}
+
+// Quick exits of one gap job (any lane); jobs that need the banded DP are marked DP_PENDING.
+__device__ void runGapJobQuick(const T4IndexView &ix, WaveMem &wm, unsigned job) {
+  const int K = ix.k;
+  const OvRec &o = wm.ov[wm.ord[job & 0xFFFF]];
+  const int j = (int)(job >> 16);
+  unsigned *hc = (unsigned *)(wm.keys + o.chainPos);
+  const int pa = PA(hc[j - 1]), pb = PB(hc[j - 1]), qa = PA(hc[j]), qb = PB(hc[j]);
+  const int lent = qb - (pb + K), lenp = qa - (pa + K);
+  const char *r = ((o.flags & OV_PLUS) ? wm.seg : wm.rc) + pa + K;
+  const T4SeqInfo si = ix.seqs[o.seqIdx];
+  unsigned cnt;
+  bool done = si.isRef ? dpAffineQuick(ix.cons + si.consOff + pb + K, lent, r, lenp, cnt)
+                       : dpPosWeightQuick(ix.pw + si.pwOff + pb + K, lent, r, lenp, cnt);
+  hc[o.chainLen + j] = done ? cnt : DP_PENDING;
 }
 
 // GetVJOverlapsFromHits' pair selection (SeqSet.hpp:1093-1160) on wm.ov[0..n). One lane. Returns 0 or 2
@@ -840,20 +1201,25 @@ __device__ int selectVJPair(const T4IndexView &ix, WaveMem &wm, int n) {
 // emitted by the seed stage) or -1 on capacity overflow. Overlaps are left in wm.ov / ws->ovCount.
 __device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int segLen, int strandArg, int barcode,
                              bool allowTotalSkip, bool vjOnly, int hitLenRequired, int filter) {
-  const int lane = laneId();
+  const int lane = tid(), NT = nthr();
   unsigned *posStart = (unsigned *)wm.ov;   // dead before the first overlap record is written
   unsigned *posPref = wm.pairs;             // dead before the first pair is written
   const int nk = segLen - ix.k + 1;
   if (lane == 0) ws->ovCount = 0;
-  int H = seedPositions(ix, wm, segLen, strandArg, barcode, allowTotalSkip, posStart, posPref);
+  PHASE_MARK(ws, 1);
+  int H = seedPositions(ix, wm, segLen, strandArg, barcode, allowTotalSkip, posStart, posPref, ws->red);
   if (H > wm.cap) return -1;
-  int Hv = expandHits(ix, wm, nk, H, barcode, vjOnly, posStart, posPref);
+  PHASE_MARK(ws, 2);
+  int Hv = expandHits(ix, wm, nk, H, barcode, vjOnly, posStart, posPref, ws->red);
   int n2 = 1;
   while (n2 < H) n2 <<= 1;
-  for (int s = H + lane; s < n2; s += 64) wm.keys[s] = ~0ull;   // n2 <= cap: caps are powers of two
+  for (int s = H + lane; s < n2; s += NT) wm.keys[s] = ~0ull;   // n2 <= cap: caps are powers of two
   __syncthreads();
+  PHASE_MARK(ws, 3);
   if (H > 1) bitonicSort(wm.keys, n2);
+  PHASE_MARK(ws, 4);
   overlapsFromKeys(ix, wm, ws, Hv, hitLenRequired, filter);
+  PHASE_MARK(ws, 0);
   return H;
 }
 
@@ -862,7 +1228,7 @@ __device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, 
 // Returns the reference's return value (-1, 0 or the overlap count); -2 on capacity overflow.
 __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int segLen, int strandArg, int barcode,
                                    bool skipRepeats, int shift, DPScratch sc, unsigned long long &hitTotal) {
-  const int lane = laneId();
+  const int lane = tid(), NT = nthr();
   if (segLen < ix.k) return -1;
   int overlapCnt = 0;
   if (skipRepeats) {
@@ -898,8 +1264,9 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
   if (lane == 0) printf("DBG seg len %d overlapCnt %d overflow %d\n", segLen, overlapCnt, ws->overflow);
 #endif
   if (ws->overflow || overlapCnt > wm.maxOv) return -2;
+  PHASE_MARK(ws, 8);
   // std::sort(overlaps) by operator< : rank sort (the order is total on distinct overlaps)
-  for (int i = lane; i < overlapCnt; i += 64) {
+  for (int i = lane; i < overlapCnt; i += NT) {
     OvRec me = wm.ov[i];
     int rank = 0;
     for (int j = 0; j < overlapCnt; ++j) {
@@ -913,27 +1280,86 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
   // keep the overlaps on the strand of the best one (SeqSet.hpp:1601-1616), order preserved
   int strand0 = wm.ov[wm.ord[0]].flags & OV_PLUS;
   int kept = 0;
-  for (int i0 = 0; i0 < overlapCnt; i0 += 64) {
+  for (int i0 = 0; i0 < overlapCnt; i0 += NT) {
     int i = i0 + lane;
     int o = i < overlapCnt ? wm.ord[i] : 0;
     bool keep = i < overlapCnt && ((wm.ov[o].flags & OV_PLUS) == strand0);
-    unsigned long long m = __ballot(keep);
-    int pos = kept + __popcll(m & ((1ull << lane) - 1ull));
-    __syncthreads();
-    if (keep) wm.ord[pos] = (unsigned short)o;   // pos <= i: compaction in place, chunk by chunk
-    kept += __popcll(m);
+    int tot;
+    int inc = blockInclScan(keep ? 1 : 0, ws->red, tot);   // barriers inside: every ord[i] of the chunk is read
+    if (keep) wm.ord[kept + inc - 1] = (unsigned short)o;   // target <= i: compaction in place, chunk by chunk
+    kept += tot;
     __syncthreads();
   }
   overlapCnt = kept;
+  PHASE_MARK(ws, 9);
   // score every kept overlap (one lane each)
-  for (int i = lane; i < overlapCnt; i += 64) {
+  // (1) collect the gap-alignment jobs of every kept overlap (job list = the dead cand array)
+  if (lane == 0) ws->jobCount = 0;
+  __syncthreads();
+  for (int i = lane; i < overlapCnt; i += NT) {
+    OvRec o = wm.ov[wm.ord[i]];
+    walkOverlap(ix, wm, ws, o, i, true);
+  }
+  __syncthreads();
+  if (ws->overflow) return -2;
+  const int nJobs = ws->jobCount;
+  // (2) quick exits, one job per lane
+  PHASE_MARK(ws, 13);
+  for (int q = lane; q < nJobs; q += NT) runGapJobQuick(ix, wm, wm.cand[q]);
+  __syncthreads();
+  // (3) banded DPs: compact the pending jobs, then one wavefront per alignment
+  PHASE_MARK(ws, 14);
+  int nPend = 0;
+  for (int q0 = 0; q0 < nJobs; q0 += NT) {
+    int q = q0 + lane;
+    unsigned job = q < nJobs ? wm.cand[q] : 0u;
+    bool pend = false;
+    if (q < nJobs) {
+      const OvRec &o = wm.ov[wm.ord[job & 0xFFFF]];
+      pend = ((const unsigned *)(wm.keys + o.chainPos))[o.chainLen + (job >> 16)] == DP_PENDING;
+    }
+    int tot;
+    int inc = blockInclScan(pend ? 1 : 0, ws->red, tot);   // barriers inside: the chunk's jobs are all read
+    if (pend) wm.cand[nPend + inc - 1] = job;               // target <= q: in-place, chunk by chunk
+    nPend += tot;
+    __syncthreads();
+  }
+  {
+    const int wave = lane >> 6, nw = NT >> 6;
+    char *tbuf = (char *)wm.pairs + wave * (T4_MAXGAP + 16);   // pairs is dead here (cap >= 1024 ints)
+    for (int q = wave; q < nPend; q += nw) {
+      const unsigned job = wm.cand[q];
+
+      const OvRec &o = wm.ov[wm.ord[job & 0xFFFF]];
+      const int jj = (int)(job >> 16);
+      unsigned *hc = (unsigned *)(wm.keys + o.chainPos);
+      const int pa = PA(hc[jj - 1]), pb = PB(hc[jj - 1]), qa = PA(hc[jj]), qb = PB(hc[jj]);
+      const int lent = qb - (pb + ix.k), lenp = qa - (pa + ix.k);
+      const char *r = ((o.flags & OV_PLUS) ? wm.seg : wm.rc) + pa + ix.k;
+      const T4SeqInfo si = ix.seqs[o.seqIdx];
+      unsigned c = si.isRef ? dpWave<false>(ix.cons + si.consOff + pb + ix.k, (const int4 *)0, lent, r, lenp, tbuf)
+                            : dpWave<true>((const char *)0, ix.pw + si.pwOff + pb + ix.k, lent, r, lenp, tbuf);
+      if (c == DP_FAIL && laneId() == 0) {   // band wider than a wavefront: lane-serial scratch version
+        int c0, c1, c2;
+        bool ok = si.isRef ? dpAffine(ix.cons + si.consOff + pb + ix.k, lent, r, lenp, sc, laneId(), c0, c1, c2)
+                           : dpPosWeight(ix.pw + si.pwOff + pb + ix.k, lent, r, lenp, sc, laneId(), c0, c1, c2, (signed char *)0);
+        if (ok) c = CNT_MATCH * (unsigned)c0 + CNT_MIS * (unsigned)c1 + CNT_INDEL * (unsigned)c2;
+      }
+      if (laneId() == 0) hc[o.chainLen + jj] = c;
+    }
+  }
+  __syncthreads();
+  // (4) finish the overlaps
+  PHASE_MARK(ws, 15);
+  for (int i = lane; i < overlapCnt; i += NT) {
     OvRec o = wm.ov[wm.ord[i]];
     int m0 = o.matchCnt;
-    scoreOverlap(ix, wm, ws, o, sc, lane);
+    walkOverlap(ix, wm, ws, o, i, false);
     o.chainLen = m0;                       // chain no longer needed: keep the pre-score matchCnt here
     wm.ov[wm.ord[i]] = o;
   }
   __syncthreads();
+  PHASE_MARK(ws, 10);
   if (ix.hasNovel && overlapCnt > 50) {
     // the fast pre-filters against the best novel overlap (SeqSet.hpp:1705-1794) are order dependent:
     // replay them sequentially over the already scored list
@@ -972,10 +1398,11 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
 #ifdef T4_DEBUG
   if (lane == 0) for (int i = 0; i < overlapCnt; ++i) { OvRec o = wm.ov[wm.ord[i]]; printf("DBG ov %d seq %d %d-%d %d-%d m %d ind %d fl %d sim %f\n", i, o.seqIdx, o.rs, o.re, o.ss, o.se, o.matchCnt, o.indelCnt, o.flags, ovSim(o)); }
 #endif
+  PHASE_MARK(ws, 11);
   // similarity thresholds (SeqSet.hpp:2105-2119), order preserved; append to fin
   int base = ws->finCount;
   int outCnt = 0;
-  for (int i0 = 0; i0 < overlapCnt; i0 += 64) {
+  for (int i0 = 0; i0 < overlapCnt; i0 += NT) {
     int i = i0 + lane;
     bool keep = false;
     OvRec o;
@@ -984,17 +1411,19 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
       double sim = ovSim(o);
       keep = (o.flags & OV_ISREF) ? !(sim < ix.refSim) : !(sim < ix.novelSim);
     }
-    unsigned long long m = __ballot(keep);
-    int pos = base + outCnt + __popcll(m & ((1ull << lane) - 1ull));
+    int tot;
+    int inc = blockInclScan(keep ? 1 : 0, ws->red, tot);
+    int pos = base + outCnt + inc - 1;
     if (keep) {
       if (pos < wm.maxFin) { o.rs += shift; o.re += shift; o.chainLen = 0; wm.fin[pos] = o; }
       else ws->overflow = 1;
     }
-    outCnt += __popcll(m);
+    outCnt += tot;
   }
   __syncthreads();
   if (lane == 0) ws->finCount = base + outCnt;
   __syncthreads();
+  PHASE_MARK(ws, 0);
   if (ws->overflow) return -2;
   return outCnt;
 }
@@ -1035,8 +1464,7 @@ __device__ void annotateSelect(const T4IndexView &ix, WaveMem &wm, int n, int re
   for (int i = 0; i < n; ++i) {
     int oi = wm.ord[i];
     const OvRec &o = wm.fin[oi];
-    T4SeqInfo si = ix.seqs[o.seqIdx];
-    int gt = si.geneType == 255 ? -1 : si.geneType;
+    int gt = OV_GENETYPE(o.flags) == 255 ? -1 : OV_GENETYPE(o.flags);
     if (gt < 0 || gt == 1) continue;
     int used = -1;
     for (int j = 0; j < k; ++j) if (wm.fin[kept[j]].seqIdx == o.seqIdx) { used = j; break; }
@@ -1046,7 +1474,7 @@ __device__ void annotateSelect(const T4IndexView &ix, WaveMem &wm, int n, int re
       const OvRec &base = wm.fin[kept[used]];
       if (o.matchCnt == base.matchCnt && sim == ovSim(base)) {
         int j;
-        for (j = 0; j < k; ++j) if (ix.seqs[wm.fin[kept[j]].seqIdx].geneType == 3) break;
+        for (j = 0; j < k; ++j) if (OV_GENETYPE(wm.fin[kept[j]].flags) == 3) break;
         if (j < k) {
           const OvRec &c = wm.fin[kept[j]];
           if (o.re <= c.rs + 3) {
@@ -1063,13 +1491,12 @@ __device__ void annotateSelect(const T4IndexView &ix, WaveMem &wm, int n, int re
     char BT = 0, chain = 0;
     for (int i = 0; i < k; ++i) {
       const OvRec &o = wm.fin[kept[i]];
-      T4SeqInfo si = ix.seqs[o.seqIdx];
-      char n0 = (char)si.name0, n2 = (char)si.name2;
+      char n0 = OV_NAME0(o.flags), n2 = OV_NAME2(o.flags);
       if (BT && n0 != BT) continue;
       BT = n0;
       if (chain && !(n2 == chain || (n2 == 'D' && chain == 'A') || (n2 == 'A' && chain == 'D'))) continue;
       chain = n2;
-      int gt = si.geneType == 255 ? -1 : si.geneType;
+      int gt = OV_GENETYPE(o.flags) == 255 ? -1 : OV_GENETYPE(o.flags);
       if (gt >= 0 && g[gt] == -1) g[gt] = kept[i];
     }
     if (g[3] != -1) {
@@ -1096,10 +1523,13 @@ __device__ void annotateSelect(const T4IndexView &ix, WaveMem &wm, int n, int re
 // Process one read in one wavefront. Returns false when the read has to move to a larger tier.
 __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const T4Work &wk, const T4QueryArgs &qa,
                             WaveMem &wm, WaveState *ws, long long r, DPScratch sc) {
-  const int lane = laneId();
+  const int lane = tid(), NT = nthr();
   const int len = bv.len[r];
   unsigned long long hitTotal = 0;
   if (lane == 0) { ws->overflow = 0; ws->unsupported = 0; ws->finCount = 0; ws->nContig = 0; ws->ovCount = 0; }
+#ifdef T4_PHASE_TIMING
+  if (lane == 0) { ws->phaseT0 = clock64(); ws->curPhase = 0; }
+#endif
   __syncthreads();
   if (qa.mode == 0) {
     int barcode = bv.barcode ? bv.barcode[r] : -1;
@@ -1108,7 +1538,7 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
     if (ret == -2) return false;
     int n = ret > 0 ? ret : 0;
     if (lane == 0) qa.counts[r] = ret;
-    for (int i = lane; i < n && i < qa.maxPerRead; i += 64) storeOverlap(qa.out + r * qa.maxPerRead + i, wm.fin[i]);
+    for (int i = lane; i < n && i < qa.maxPerRead; i += NT) storeOverlap(qa.out + r * qa.maxPerRead + i, wm.fin[i]);
   } else {
     loadSegment(bv, r, 0, len, wm);
     if (lane == 0) contigIntervals(wm.seg, 7, ws);
@@ -1123,7 +1553,8 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
       __syncthreads();
     }
     int n = ws->finCount;
-    for (int i = lane; i < n; i += 64) {
+    PHASE_MARK(ws, 12);
+    for (int i = lane; i < n; i += NT) {
       OvRec me = wm.fin[i];
       int rank = 0;
       for (int j = 0; j < n; ++j) {
@@ -1137,6 +1568,7 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
     if (lane == 0) annotateSelect(ix, wm, n, len, (int *)wm.cand, qa.out + r * 4);
   }
   __syncthreads();
+  PHASE_MARK(ws, 0);
   if (lane == 0) {
     if (ws->unsupported) wk.status[r] = 1;
     atomicAdd(wk.hitCounter, hitTotal);
@@ -1146,12 +1578,11 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
 
 // The query kernel. CAP > 0: LDS tier; CAP == 0: global-scratch tier. Persistent grid, one wave/block.
 template <int CAP, int MAXOV>
-__global__ __launch_bounds__(64) void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
+__global__ __launch_bounds__(256) void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
   constexpr int C = CAP > 0 ? CAP : 1;
   constexpr int M = CAP > 0 ? MAXOV : 1;
   __shared__ unsigned long long s_keys[C];
-  __shared__ unsigned s_pairs[C];
-  __shared__ unsigned s_cand[C / 3 + 2];
+  __shared__ unsigned s_pairs[C + C / 3 + 2];   // pairs[C] followed by cand[C / 3 + 2]
   __shared__ OvRec s_ov[M];
   __shared__ OvRec s_fin[M];
   __shared__ unsigned short s_ord[M];
@@ -1160,13 +1591,13 @@ __global__ __launch_bounds__(64) void queryKernel(T4IndexView ix, T4BatchView bv
   __shared__ WaveState s_ws;
   WaveMem wm;
   if (CAP > 0) {
-    wm.keys = s_keys; wm.pairs = s_pairs; wm.cand = s_cand; wm.ov = s_ov; wm.fin = s_fin; wm.ord = s_ord;
+    wm.keys = s_keys; wm.pairs = s_pairs; wm.cand = s_pairs + C; wm.ov = s_ov; wm.fin = s_fin; wm.ord = s_ord;
     wm.cap = CAP; wm.maxOv = MAXOV; wm.maxFin = MAXOV; wm.candCap = C / 3 + 2;
   } else {
     size_t b = blockIdx.x;
     wm.keys = wk.gKeys + b * (size_t)wk.gCap;
-    wm.pairs = wk.gPairs + b * (size_t)wk.gCap;
-    wm.cand = wk.gCand + b * (size_t)wk.gCap;
+    wm.pairs = wk.gPairs + b * (size_t)wk.gCap * 2;
+    wm.cand = wm.pairs + wk.gCap;
     wm.ov = (OvRec *)(wk.gOv + b * (size_t)wk.gMaxOv * 10);
     wm.fin = (OvRec *)(wk.gFin + b * (size_t)wk.gMaxOv * 10);
     wm.ord = wk.gOrd + b * (size_t)wk.gMaxOv;
@@ -1174,12 +1605,12 @@ __global__ __launch_bounds__(64) void queryKernel(T4IndexView ix, T4BatchView bv
   }
   wm.seg = s_seg; wm.rc = s_rc;
   DPScratch sc;
-  sc.rows = wk.dpRows + (size_t)blockIdx.x * (6 * T4_ROWW * 64);
-  sc.dir = wk.dpDir + ((size_t)blockIdx.x * 64 + laneId()) * T4_DIR_BYTES;
+  sc.rows = wk.dpRows + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (6 * T4_ROWW * 64);
+  sc.dir = wk.dpDir + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * T4_DIR_BYTES;
   for (int w = blockIdx.x; w < wk.nList; w += gridDim.x) {
     long long r = wk.list[w];
     bool done = processRead(ix, bv, wk, qa, wm, &s_ws, r, sc);
-    if (!done && laneId() == 0) {
+    if (!done && tid() == 0) {
       if (wk.nextList) { int slot = atomicAdd(wk.nextCount, 1); wk.nextList[slot] = (int)r; }
       else wk.status[r] = 2;
     }
@@ -1188,12 +1619,13 @@ __global__ __launch_bounds__(64) void queryKernel(T4IndexView ix, T4BatchView bv
 }
 
 // Tiering: estimate H of every read (whole read, both strands) and bin the reads by capacity.
-__global__ __launch_bounds__(64) void binKernel(T4IndexView ix, T4BatchView bv, int useBarcode, int cap0, int cap1, int cap2,
+__global__ __launch_bounds__(64) void binKernel(T4IndexView ix, T4BatchView bv, int useBarcode, int cap0, int cap1, int cap2, int cap3,
                                                int *lists, int *counts, long long listStride) {
   __shared__ unsigned s_posStart[T4_MAXPOS + 8];
   __shared__ unsigned s_posPref[T4_MAXPOS + 8];
   __shared__ char s_seg[T4_MAXL + 8];
   __shared__ char s_rc[T4_MAXL + 8];
+  __shared__ int s_red[16];
   WaveMem wm;
   wm.seg = s_seg; wm.rc = s_rc;
   for (long long r = blockIdx.x; r < bv.n; r += gridDim.x) {
@@ -1202,10 +1634,10 @@ __global__ __launch_bounds__(64) void binKernel(T4IndexView ix, T4BatchView bv, 
     if (len >= ix.k) {
       loadSegment(bv, r, 0, len, wm);
       int barcode = (useBarcode && bv.barcode) ? bv.barcode[r] : -1;
-      H = seedPositions(ix, wm, len, 0, barcode, false, s_posStart, s_posPref);
+      H = seedPositions(ix, wm, len, 0, barcode, false, s_posStart, s_posPref, s_red);
     }
     if (laneId() == 0) {
-      int t = H <= cap0 ? 0 : H <= cap1 ? 1 : H <= cap2 ? 2 : 3;
+      int t = H <= cap0 ? 0 : H <= cap1 ? 1 : H <= cap2 ? 2 : H <= cap3 ? 3 : 4;
       int slot = atomicAdd(&counts[t], 1);
       lists[t * listStride + slot] = (int)r;
     }
@@ -1220,6 +1652,7 @@ __global__ __launch_bounds__(64) void hitsKernel(T4IndexView ix, T4BatchView bv,
   __shared__ unsigned s_posPref[T4_MAXPOS + 8];
   __shared__ char s_seg[T4_MAXL + 8];
   __shared__ char s_rc[T4_MAXL + 8];
+  __shared__ int s_red[16];
   WaveMem wm;
   wm.seg = s_seg; wm.rc = s_rc;
   wm.keys = gKeys + (size_t)blockIdx.x * gCap;
@@ -1231,7 +1664,7 @@ __global__ __launch_bounds__(64) void hitsKernel(T4IndexView ix, T4BatchView bv,
     if (len >= 1 && len >= ix.k) {
       loadSegment(bv, r, 0, len, wm);
       int nk = len - ix.k + 1;
-      int H = seedPositions(ix, wm, len, strandArg, barcode, allowTotalSkip != 0, s_posStart, s_posPref);
+      int H = seedPositions(ix, wm, len, strandArg, barcode, allowTotalSkip != 0, s_posStart, s_posPref, s_red);
       if (H > gCap) { if (lane == 0) status[r] = 2; H = 0; }
       // keys ordered as _hit::operator< : (strand, idx, readOffset, offset)
       int dropped = 0;
@@ -1246,7 +1679,7 @@ __global__ __launch_bounds__(64) void hitsKernel(T4IndexView ix, T4BatchView bv,
         else key = ((st ? 0ull : 1ull) << 63) | ((unsigned long long)po.x << 32) | ((unsigned long long)a << 20) | (unsigned long long)po.y;
         wm.keys[s] = key;
       }
-      dropped = waveSum(dropped);
+      dropped = blockSum(dropped, s_red);
       Hv = H - dropped;
       if (pass == 1 && H > 0) {
         int n2 = 1;
@@ -1271,6 +1704,56 @@ __global__ __launch_bounds__(64) void hitsKernel(T4IndexView ix, T4BatchView bv,
     }
     if (pass == 0 && lane == 0) offsets[r + 1] = Hv;
     __syncthreads();
+  }
+}
+
+
+// t4_gap_dp: a batch of independent gap alignments, one per lane. kind 0: AlignAlgo::GlobalAlignment on
+// chars, kind 1: GlobalAlignment_PosWeight on weights. impl 0: forward LDS version with scratch fallback
+// (what overlap scoring uses), impl 1: scratch + traceback version only. out: 3 ints per problem.
+__global__ __launch_bounds__(64) void gapDpKernel(int kind, int impl, int n, const long long *tOff, const long long *pOff,
+                                                 const char *tChars, const int4 *tW, const char *pChars, int *out,
+                                                 int *dpRows, unsigned char *dpDir) {
+  __shared__ int s_slots[4 * T4_DPW * 64];   // 32 KiB
+  __shared__ char s_p[64][T4_MAXGAP + 8];
+  const int lane = laneId();
+  DPScratch sc;
+  sc.rows = dpRows + (size_t)blockIdx.x * (6 * T4_ROWW * 64);
+  sc.dir = dpDir + ((size_t)blockIdx.x * 64 + lane) * T4_DIR_BYTES;
+  if (impl == 2) {   // the wave-cooperative formulation: one alignment per wavefront
+    for (int i = blockIdx.x; i < n; i += gridDim.x) {
+      int lent = (int)(tOff[i + 1] - tOff[i]), lenp = (int)(pOff[i + 1] - pOff[i]);
+      unsigned c = DP_FAIL;
+      if (lenp <= T4_MAXGAP) {
+        for (int j = lane; j < lenp; j += 64) s_p[0][j] = pChars[pOff[i] + j];
+        __syncthreads();
+        c = kind == 0 ? dpWave<false>(tChars + tOff[i], (const int4 *)0, lent, s_p[0], lenp, s_p[1])
+                      : dpWave<true>((const char *)0, tW + tOff[i], lent, s_p[0], lenp, s_p[1]);
+        __syncthreads();
+      }
+      if (lane == 0) {
+        if (c == DP_FAIL) { out[4 * i] = out[4 * i + 1] = out[4 * i + 2] = 0; out[4 * i + 3] = 2; }   // 2: band wider than a wavefront
+        else { out[4 * i] = (int)(c & 1023u); out[4 * i + 1] = (int)((c >> 10) & 1023u); out[4 * i + 2] = (int)(c >> 20); out[4 * i + 3] = 0; }
+      }
+    }
+    return;
+  }
+  for (int i0 = blockIdx.x * 64; i0 < n; i0 += gridDim.x * 64) {
+    int i = i0 + lane;
+    if (i < n) {
+      int lent = (int)(tOff[i + 1] - tOff[i]), lenp = (int)(pOff[i + 1] - pOff[i]);
+      int c0 = 0, c1 = 0, c2 = 0;
+      bool ok = lenp <= T4_MAXGAP;
+      if (ok) {
+        for (int j = 0; j < lenp; ++j) s_p[lane][j] = pChars[pOff[i] + j];   // the read side lives in LDS in the real path
+        bool done = false;
+        if (impl == 0) done = kind == 0 ? dpAffineFwd(tChars + tOff[i], lent, s_p[lane], lenp, s_slots + lane, 64, c0, c1, c2)
+                                        : dpPosWeightFwd(tW + tOff[i], lent, s_p[lane], lenp, s_slots + lane, 64, c0, c1, c2);
+        if (!done) ok = kind == 0 ? dpAffine(tChars + tOff[i], lent, s_p[lane], lenp, sc, lane, c0, c1, c2)
+                                  : dpPosWeight(tW + tOff[i], lent, s_p[lane], lenp, sc, lane, c0, c1, c2, (signed char *)0);
+      }
+      out[4 * i] = c0; out[4 * i + 1] = c1; out[4 * i + 2] = c2; out[4 * i + 3] = ok ? 0 : 1;
+    }
   }
 }
 
