@@ -25,8 +25,9 @@ static_assert(sizeof(t4k::OvRec) == 40, "OvRec layout");
 
 namespace {
 
-const int QUERY_THREADS = 256;                 // threads (4 wavefronts) cooperating on one read
+// per capacity tier: LDS hit capacity, threads cooperating on one read, resident workgroups per CU
 const int TIER_CAP[4] = {1024, 2048, 4096, 8192};
+const int TIER_THREADS[T4_NTIER] = {256, 256, 256, 256, 256};   // 512/1024 threads in the upper tiers measured slower (barriers)
 const int TIER_BLOCKS_PER_CU[T4_NTIER] = {6, 3, 2, 1, 2};
 const int G_CAP = 32768, G_MAXOV = 4096;
 
@@ -134,12 +135,13 @@ int geneType(const char *n) {
 }
 inline int nucNum(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
 
-int ensureScratch(t4_ctx *c, int grid) {
-  if (grid <= c->maxGrid) return T4_OK;
+// gap-DP scratch for `threads` resident threads (fallback path of bands wider than a wavefront)
+int ensureScratch(t4_ctx *c, int threads) {
+  if (threads <= c->maxGrid) return T4_OK;
   int r;
-  if ((r = devAlloc(c, &c->dpRows, (size_t)grid * (QUERY_THREADS / 64) * 6 * T4_ROWW * 64))) return r;
-  if ((r = devAlloc(c, &c->dpDir, (size_t)grid * QUERY_THREADS * T4_DIR_BYTES))) return r;
-  c->maxGrid = grid;
+  if ((r = devAlloc(c, &c->dpRows, (size_t)(threads / 64 + 1) * 6 * T4_ROWW * 64))) return r;
+  if ((r = devAlloc(c, &c->dpDir, (size_t)threads * T4_DIR_BYTES))) return r;
+  c->maxGrid = threads;
   return T4_OK;
 }
 int ensureGlobalTier(t4_ctx *c, int grid) {
@@ -503,9 +505,9 @@ int64_t t4_batch_size(const t4_batch *b) { return b ? b->n : 0; }
 
 namespace {
 
-template <int CAP, int MAXOV>
+template <int CAP, int MAXOV, int NT>
 void launchTier(int grid, hipStream_t st, const T4IndexView &iv, const T4BatchView &bv, const T4Work &wk, const T4QueryArgs &qa) {
-  hipLaunchKernelGGL((t4k::queryKernel<CAP, MAXOV>), dim3(grid), dim3(QUERY_THREADS), 0, st, iv, bv, wk, qa);
+  hipLaunchKernelGGL((t4k::queryKernel<CAP, MAXOV, NT>), dim3(grid), dim3(NT), 0, st, iv, bv, wk, qa);
 }
 
 // Shared driver of t4_overlaps / t4_annotate_rough.
@@ -521,7 +523,7 @@ int runQuery(t4_index *ix, t4_batch *b, T4QueryArgs qa, bool useBarcode) {
   int r;
   int grids[T4_NTIER];
   int maxGrid = 1;
-  for (int t = 0; t < T4_NTIER; ++t) { grids[t] = c->cus * TIER_BLOCKS_PER_CU[t]; if (grids[t] > maxGrid) maxGrid = grids[t]; }
+  for (int t = 0; t < T4_NTIER; ++t) { grids[t] = c->cus * TIER_BLOCKS_PER_CU[t]; if (grids[t] * TIER_THREADS[t] > maxGrid) maxGrid = grids[t] * TIER_THREADS[t]; }
   if ((r = ensureScratch(c, maxGrid))) return r;
   if ((r = ensurePerCall(c, n))) return r;
   HIPCHK(c, hipMemsetAsync(c->listCounts, 0, sizeof(int) * 8, c->stream));
@@ -554,11 +556,11 @@ int runQuery(t4_index *ix, t4_batch *b, T4QueryArgs qa, bool useBarcode) {
       if ((r = ensureGlobalTier(c, grids[T4_NTIER - 1]))) return r;
       wk.gKeys = c->gKeys; wk.gPairs = c->gPairs; wk.gCand = c->gCand; wk.gOv = c->gOv; wk.gFin = c->gFin; wk.gOrd = c->gOrd;
       wk.gCap = G_CAP; wk.gMaxOv = G_MAXOV;
-      launchTier<0, 0>(grid, c->stream, ix->view, b->view, wk, qa);
-    } else if (t == 0) launchTier<1024, 128>(grid, c->stream, ix->view, b->view, wk, qa);
-    else if (t == 1) launchTier<2048, 128>(grid, c->stream, ix->view, b->view, wk, qa);
-    else if (t == 2) launchTier<4096, 256>(grid, c->stream, ix->view, b->view, wk, qa);
-    else launchTier<8192, 512>(grid, c->stream, ix->view, b->view, wk, qa);
+      launchTier<0, 0, 256>(grid, c->stream, ix->view, b->view, wk, qa);
+    } else if (t == 0) launchTier<1024, 128, 256>(grid, c->stream, ix->view, b->view, wk, qa);
+    else if (t == 1) launchTier<2048, 128, 256>(grid, c->stream, ix->view, b->view, wk, qa);
+    else if (t == 2) launchTier<4096, 256, 256>(grid, c->stream, ix->view, b->view, wk, qa);
+    else launchTier<8192, 512, 256>(grid, c->stream, ix->view, b->view, wk, qa);
     HIPCHK(c, hipGetLastError());
     ++c->stats.launches;
   }
@@ -672,7 +674,7 @@ int t4_gap_dp(t4_ctx *c, int kind, int impl, int n, const int64_t *t_off, const 
   int grid = (n + 63) / 64;
   if (grid > c->cus * 4) grid = c->cus * 4;
   int r;
-  if ((r = ensureScratch(c, grid))) return r;
+  if ((r = ensureScratch(c, grid * 64))) return r;
   long long *dT = nullptr, *dP = nullptr;
   char *dTc = nullptr, *dPc = nullptr;
   int4 *dTw = nullptr;

@@ -1577,8 +1577,8 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
 }
 
 // The query kernel. CAP > 0: LDS tier; CAP == 0: global-scratch tier. Persistent grid, one wave/block.
-template <int CAP, int MAXOV>
-__global__ __launch_bounds__(256) void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
+template <int CAP, int MAXOV, int NTHREADS>
+__global__ __launch_bounds__(NTHREADS) void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
   constexpr int C = CAP > 0 ? CAP : 1;
   constexpr int M = CAP > 0 ? MAXOV : 1;
   __shared__ unsigned long long s_keys[C];
