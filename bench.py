@@ -72,19 +72,14 @@ def main():
     import trust4_amd.build
     import t4libs
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import trust4_amd.dist as t4dist
+    rank, local_rank, world = t4dist.env_rank()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the measured path")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    dist = t4dist.init("nccl")   # RCCL; used for the barrier + max-reduce only (no data-path collective)
 
     if rank == 0:
         trust4_amd.build.build()
@@ -95,7 +90,7 @@ def main():
     eng = trust4_amd.Engine(local_rank)
     ref = eng.index(9).set_params(17, 10, 0.9).load_ref_fasta(t4libs.REF_FA).commit()
     # synthetic batch of this rank (seed 1 on rank 0 == config C2), resident in HBM
-    synth = t4libs.Synth(args.clones, 1 + rank)
+    synth = t4libs.Synth(args.clones, t4dist.shard_seed(1, rank))
     reads = synth.next_reads(args.pairs)  # [2*pairs, 151] uint8, mates interleaved
     n_reads = reads.shape[0]
     batch = eng.upload(reads)
@@ -122,10 +117,8 @@ def main():
         hits = st["total_hits"]
     sync_all()
     dt = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = t4dist.max_over_ranks(dist, dt, "cuda")
+    total_hits_all = t4dist.sum_over_ranks(dist, float(hits), "cuda")
 
     if rank == 0:
         total_reads = n_reads * world * args.steps
@@ -145,7 +138,7 @@ def main():
             "config": {"workload": "C2: %d synthetic 150 bp PE pairs per GPU (%d reads), %d clones, seed 1+rank, -f hg38_bcrtcr.fa, k=9; "
                                    "pass = stage-1 rough annotation of every read (seed->sort->chain->score->V/J/C select); "
                                    "AddRead loop not included" % (args.pairs, n_reads, args.clones),
-                       "pairs_per_gpu": args.pairs, "reads_per_gpu": n_reads, "hits_per_read": hits / n_reads,
+                       "pairs_per_gpu": args.pairs, "reads_per_gpu": n_reads, "hits_per_read": hits / n_reads, "hits_all_ranks": total_hits_all,
                        "tier_reads": st["tier_reads"], "sharding": "reads sharded by rank, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
