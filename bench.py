@@ -30,6 +30,16 @@ def algorithmic_bytes(n_reads, read_len, total_hits):
     return n_reads * ((read_len + 3) // 4 + (read_len + 7) // 8 + 128) + 8 * total_hits
 
 
+def pmc_traffic(pairs):
+    """HBM-side traffic per pass from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE
+    need separate profiler runs, so they cannot be collected inside this process). Only valid for the workload
+    they were collected on (C2, 1 M pairs); otherwise null."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if pairs != 1000000 or not os.path.exists(path):
+        return None
+    return json.load(open(path)).get("traffic_bytes")
+
+
 def cpu_baseline(reads_arr, sample_reads):
     """Time the CPU path on this box's host cores over a bounded sample of the same workload.
     Uses the compiled reference (oracle/_ref/libt4ref.so) when it travelled with the repo, else the C oracle."""
@@ -141,7 +151,7 @@ def main():
                        "pairs_per_gpu": args.pairs, "reads_per_gpu": n_reads, "hits_per_read": hits / n_reads, "hits_all_ranks": total_hits_all,
                        "tier_reads": st["tier_reads"], "sharding": "reads sharded by rank, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.pairs),
                          "kernel": "t4k::queryKernel (all tiers of one pass)", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg},
         }
