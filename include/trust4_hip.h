@@ -104,6 +104,17 @@ int t4_overlaps(t4_index *ix, t4_batch *b, int strand, int skip_repeats, int max
  * rough-annotation pass of main.cpp:1084-1120. */
 int t4_annotate_rough(t4_index *ref, t4_batch *b, t4_overlap *out);
 
+/* SeqSet::ExtendOverlap(r, len, seq, mismatch_factor, align, overlap, extendedOverlap) (SeqSet.hpp:1165-1277) for
+ * caller-supplied overlaps of every read (layout of t4_overlaps: counts[i] overlaps at in[i*max_per_read ...]); every
+ * overlap is aligned against the read strand it names. ret receives the function's return value (0 / 1) and out the
+ * extendedOverlap of a call that starts from a default-constructed _overlap. Contig sets only (posWeight). */
+int t4_extend(t4_index *ix, t4_batch *b, int max_per_read, const int32_t *counts, const t4_overlap *in,
+              double mismatch_factor, int32_t *ret, t4_overlap *out);
+
+/* SeqSet::AssignRead(read, strand, barcode, assign) (SeqSet.hpp:4632-4701): ret[i] = its return value (seq id or
+ * -1), out[i] = `assign` (seqIdx -1 when no overlap extends over the whole read). Contig sets only. */
+int t4_assign(t4_index *ix, t4_batch *b, int strand, int32_t *ret, t4_overlap *out);
+
 /* AlignAlgo::GlobalAlignment (kind 0; AlignAlgo.hpp:218-424; t_data = chars) or
  * AlignAlgo::GlobalAlignment_PosWeight (kind 1; AlignAlgo.hpp:57-216; t_data = 4 int32 weights per base)
  * for n independent (target, pattern) pairs given as CSR offsets; out4[4*i..] = GetAlignStats of

@@ -118,6 +118,29 @@ def run_novel_case(eng, seed, k, barcodes=False, hit_len=31):
         cnt, ov = ix.overlaps(b, 0, sk, 128)
         assert t4check.check_overlaps(cnt, ov, reads, o, skip_repeats=sk, barcodes=bcs) == []
         assert (cnt > 0).sum() > len(reads) // 3
+    # ExtendOverlap of every returned overlap, and AssignRead
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    cnt, ov = ix.overlaps(b, 0, 0, 32)
+    for factor in (1.0, 2.0):
+        ret, ext = ix.extend(b, cnt, ov, factor)
+        n_ext = 0
+        for i, rd in enumerate(reads):
+            rc = "".join(comp[x] for x in reversed(rd))
+            for t in range(max(int(cnt[i]), 0)):
+                o_in = tuple(ov[i, t].tolist())
+                eret, eout = o.extend_overlap(rd if o_in[5] == 1 else rc, factor, o_in)
+                assert int(ret[i, t]) == eret and tuple(ext[i, t].tolist()) == tuple(eout), (i, t, o_in, eout, tuple(ext[i, t].tolist()))
+                n_ext += 1
+        assert n_ext > 30
+    aret, aout = ix.assign(b, 0)
+    n_asg = 0
+    for i, rd in enumerate(reads):
+        eret, eout = o.assign_read(rd, 0, -1 if bcs is None else int(bcs[i]))
+        assert int(aret[i]) == eret, (i, eret, int(aret[i]))
+        if eret != -1:
+            assert tuple(aout[i].tolist()) == tuple(eout), (i, eout, tuple(aout[i].tolist()))
+            n_asg += 1
+    assert n_asg > 5
 
 
 @pytest.mark.parametrize("k", [9, 11, 17])

@@ -49,6 +49,7 @@ def _load():
         "t4_hits": (I, [P, P, I, I, P, P, L]), "t4_overlaps": (I, [P, P, I, I, I, P, P]),
         "t4_annotate_rough": (I, [P, P, P]),
         "t4_gap_dp": (I, [P, I, I, I, P, P, P, P, P]),
+        "t4_extend": (I, [P, P, I, P, P, C.c_double, P, P]), "t4_assign": (I, [P, P, I, P, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -178,6 +179,24 @@ class Index:
                                                 counts.ctypes.data_as(C.c_void_p),
                                                 out.ctypes.data_as(C.c_void_p) if fetch else None))
         return counts, out
+
+    def extend(self, batch, counts, overlaps, mismatch_factor=1.0):
+        """overlaps: OV_DTYPE [n, max_per_read] (as returned by overlaps()). -> (ret int32 [n, m], out OV_DTYPE [n, m])."""
+        n, m = overlaps.shape
+        counts = np.ascontiguousarray(counts, dtype=np.int32)
+        overlaps = np.ascontiguousarray(overlaps)
+        ret = np.zeros((n, m), dtype=np.int32)
+        out = np.zeros((n, m), dtype=OV_DTYPE)
+        self.eng.check(self.eng.lib.t4_extend(self.h, batch.h, m, counts.ctypes.data_as(C.c_void_p), overlaps.ctypes.data_as(C.c_void_p),
+                                              mismatch_factor, ret.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+        return ret, out
+
+    def assign(self, batch, strand=0, fetch=True):
+        ret = np.zeros(batch.n, dtype=np.int32)
+        out = np.zeros(batch.n, dtype=OV_DTYPE) if fetch else None
+        self.eng.check(self.eng.lib.t4_assign(self.h, batch.h, strand, ret.ctypes.data_as(C.c_void_p),
+                                              out.ctypes.data_as(C.c_void_p) if fetch else None))
+        return ret, out
 
     def annotate_rough(self, batch, fetch=True):
         out = np.zeros((batch.n, 4), dtype=OV_DTYPE) if fetch else None

@@ -511,7 +511,7 @@ void launchTier(int grid, hipStream_t st, const T4IndexView &iv, const T4BatchVi
 }
 
 // Shared driver of t4_overlaps / t4_annotate_rough.
-int runQuery(t4_index *ix, t4_batch *b, T4QueryArgs qa, bool useBarcode) {
+int runQuery(t4_index *ix, t4_batch *b, T4QueryArgs qa, bool useBarcode, bool noHits = false) {
   t4_ctx *c = ix->ctx;
   if (!ix->committed) return fail(c, T4_ERR_STATE, "index not committed");
   if (b->ctx != c) return fail(c, T4_ERR_ARG, "batch belongs to another ctx");
@@ -533,7 +533,7 @@ int runQuery(t4_index *ix, t4_batch *b, T4QueryArgs qa, bool useBarcode) {
   int binGrid = c->cus * 8;
   if ((long long)binGrid > n) binGrid = (int)n;
   hipLaunchKernelGGL(t4k::binKernel, dim3(binGrid), dim3(64), 0, c->stream, ix->view, b->view, useBarcode ? 1 : 0,
-                     TIER_CAP[0], TIER_CAP[1], TIER_CAP[2], TIER_CAP[3], c->lists, c->listCounts, (long long)n);
+                     noHits ? (1 << 30) : TIER_CAP[0], TIER_CAP[1], TIER_CAP[2], TIER_CAP[3], c->lists, c->listCounts, (long long)n);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   c->stats.launches = 1;
@@ -693,6 +693,53 @@ int t4_gap_dp(t4_ctx *c, int kind, int impl, int n, const int64_t *t_off, const 
   void *ptrs[] = {dT, dP, dTc, dPc, dTw, dOut};
   for (void *q : ptrs) if (q) (void)hipFree(q);
   return T4_OK;
+}
+
+
+int t4_assign(t4_index *ix, t4_batch *b, int strand, int32_t *ret, t4_overlap *out) {
+  if (!ix || !b) return T4_ERR_ARG;
+  t4_ctx *c = ix->ctx;
+  if (ix->committed && ix->view.firstIsRef) return fail(c, T4_ERR_UNSUPPORTED, "t4_assign needs a contig set (ExtendOverlap aligns against posWeight)");
+  int r;
+  if ((r = ensurePerCall(c, b->n))) return r;
+  if ((r = ensureResult(c, (size_t)b->n))) return r;
+  T4QueryArgs qa;
+  memset(&qa, 0, sizeof qa);
+  qa.mode = 2; qa.strand = strand; qa.skipRepeats = 0; qa.maxPerRead = 1; qa.counts = nullptr; qa.out = c->result; qa.ret = c->counts;
+  if ((r = runQuery(ix, b, qa, true))) return r;
+  if (ret && b->n) HIPCHK(c, hipMemcpy(ret, c->counts, sizeof(int) * (size_t)b->n, hipMemcpyDeviceToHost));
+  if (out && b->n) HIPCHK(c, hipMemcpy(out, c->result, sizeof(t4_overlap) * (size_t)b->n, hipMemcpyDeviceToHost));
+  return T4_OK;
+}
+
+int t4_extend(t4_index *ix, t4_batch *b, int max_per_read, const int32_t *counts, const t4_overlap *in, double mismatch_factor,
+              int32_t *ret, t4_overlap *out) {
+  if (!ix || !b || max_per_read <= 0 || (b->n > 0 && (!counts || !in))) return T4_ERR_ARG;
+  t4_ctx *c = ix->ctx;
+  if (ix->committed && ix->view.firstIsRef) return fail(c, T4_ERR_UNSUPPORTED, "t4_extend needs a contig set (ExtendOverlap aligns against posWeight)");
+  if (max_per_read > 128) return fail(c, T4_ERR_UNSUPPORTED, "t4_extend takes at most 128 overlaps per read");
+  const size_t n = (size_t)b->n, m = n * max_per_read;
+  if (n == 0) return T4_OK;
+  (void)hipSetDevice(c->device);
+  int r;
+  if ((r = ensurePerCall(c, b->n))) return r;
+  if ((r = ensureResult(c, m))) return r;
+  T4OverlapOut *dIn = nullptr;
+  int *dCnt = nullptr, *dRet = nullptr;
+  if ((r = devAlloc(c, &dIn, m)) || (r = devAlloc(c, &dCnt, n)) || (r = devAlloc(c, &dRet, m))) return r;
+  HIPCHK(c, hipMemcpy(dIn, in, sizeof(t4_overlap) * m, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(dCnt, counts, sizeof(int) * n, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemset(dRet, 0, sizeof(int) * m));
+  T4QueryArgs qa;
+  memset(&qa, 0, sizeof qa);
+  qa.mode = 3; qa.maxPerRead = max_per_read; qa.out = c->result; qa.in = dIn; qa.inCounts = dCnt; qa.ret = dRet; qa.mismatchFactor = mismatch_factor;
+  r = runQuery(ix, b, qa, true, true);
+  if (r == T4_OK) {
+    if (ret) HIPCHK(c, hipMemcpy(ret, dRet, sizeof(int) * m, hipMemcpyDeviceToHost));
+    if (out) HIPCHK(c, hipMemcpy(out, c->result, sizeof(t4_overlap) * m, hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(dIn); (void)hipFree(dCnt); (void)hipFree(dRet);
+  return r;
 }
 
 }  // extern "C"

@@ -1520,6 +1520,160 @@ __device__ void annotateSelect(const T4IndexView &ix, WaveMem &wm, int n, int re
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// SeqSet::ExtendOverlap (SeqSet.hpp:1165-1277) for a list of overlaps of the current read.
+// Both overhang alignments are GlobalAlignment_PosWeight calls with lent == lenp, so the reference's
+// ungapped early return (<= 2 mismatches) is the common case and is evaluated one (overlap, side) per lane;
+// the others run the wave-cooperative banded DP with one direction byte per cell in LDS and a lane-0
+// traceback that reproduces the reference's edit string (needed for the "good overhang" scans).
+// ------------------------------------------------------------------------------------------------
+struct ExtSide { short size, good, match, mis, indel, pending; };
+struct ExtOut { int ret, rs, re, ss, se, matchCnt, simFail, den; };   // similarity = matchCnt / den unless simFail
+
+// banded posWeight DP of an L x L problem (W = 11) by one wavefront; dir bytes -> dirbuf[i * 11 + d]
+__device__ void dpWaveTracePW(const int4 *w, int L, const char *p, unsigned char *dirbuf) {
+  const int d = laneId(), W = 11, leftBand = 5;
+  const int negInf = (L + 1) * (L + 1) * (-4);
+  int M = negInf;
+  { int j0 = d - leftBand; if (d < W && j0 >= 0 && j0 <= L) M = j0 == 0 ? 0 : -4 - 4 * j0; }
+  const int lastStep = 2 * L + W - 1;
+  for (int s = 2; s <= lastStep; ++s) {
+    int lM = __shfl_up(M, 1), uM = __shfl_down(M, 1);
+    const int i2 = s - d, i = i2 >> 1, j = i - leftBand + d;
+    if (d < W && (i2 & 1) == 0 && i >= 1 && i <= L && j >= 1 && j <= L) {
+      if (j == 1) lM = -4 - 4 * i; else if (d == 0) lM = negInf;
+      if (i == 1) uM = -4 - 4 * j; else if (d + 1 >= W) uM = negInf;
+      int dM;
+      if (i == 1) dM = (j - 1 == 0) ? 0 : -4 - 4 * (j - 1);
+      else if (j == 1) dM = -4 - 4 * (i - 1);
+      else dM = M;
+      const bool eq = baseEqualW(w[j - 1], p[i - 1]);
+      const int dsc = dM + (eq ? 2 : -2);
+      int m = dsc;
+      if (lM - 4 > m) m = lM - 4;
+      if (uM - 4 > m) m = uM - 4;
+      dirbuf[i * W + d] = (unsigned char)((lM - 4 == m ? 1 : 0) | (uM - 4 == m ? 2 : 0) | (dsc == m ? 4 : 0) | (eq ? 8 : 0));
+      M = m;
+    }
+  }
+}
+// traceback of the above (AlignAlgo.hpp:160-205); align[] receives the edit string, returns its length. One lane.
+__device__ int tracebackPW(const unsigned char *dirbuf, int L, signed char *align) {
+  const int W = 11, leftBand = 5;
+  int tagi = L, tagj = L, tag = 0;
+  while (tagi > 0 || tagj > 0) {
+    int a = 0;
+    if (tagi > 0 && tagj > 0) {
+      unsigned char bits = dirbuf[tagi * W + (tagj - tagi + leftBand)];
+      if (bits & 1) a = 3;
+      if (bits & 2) a = 2;
+      if (bits & 4) a = (bits & 8) ? 0 : 1;
+    } else if (tagi == 0) {
+      int mL = (tagj - 1 == 0) ? 0 : (-4 - 4 * (tagj - 1));
+      if (mL - 4 == -4 - 4 * tagj) a = 3;
+    } else {
+      int mU = (tagi - 1 == 0) ? 0 : (-4 - 4 * (tagi - 1));
+      if (mU - 4 == -4 - 4 * tagi) a = 2;
+    }
+    align[tag++] = (signed char)a;
+    if (a == 3) --tagj; else if (a == 2) --tagi; else { --tagi; --tagj; }
+  }
+  for (int i = 0, j = tag - 1; i < j; ++i, --j) { signed char x = align[i]; align[i] = align[j]; align[j] = x; }
+  return tag;
+}
+
+// Extend the n overlaps wm.fin[ord[0..n)] of the read in wm.seg / wm.rc (length len). Results in `res[i]`.
+// useFirstStrand: AssignRead aligns every overlap against the strand of overlaps[0] (SeqSet.hpp:4657-4659).
+// Scratch: sides = 2 * n ExtSide records, dirbuf >= (len + 1) * 11 + 2 * len + 8 bytes. All LDS.
+__device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int n, int len, bool useFirstStrand,
+                               double factor, ExtSide *sides, unsigned char *dirbuf, ExtOut *res) {
+  const int lane = tid(), NT = nthr();
+  const int plus0 = n > 0 ? (wm.fin[wm.ord[0]].flags & OV_PLUS) : 1;
+  // E1: ungapped evaluation of every (overlap, side)
+  for (int q = lane; q < 2 * n; q += NT) {
+    const OvRec &o = wm.fin[wm.ord[q >> 1]];
+    const int side = q & 1;
+    const T4SeqInfo si = ix.seqs[o.seqIdx];
+    const char *r = (useFirstStrand ? plus0 : (o.flags & OV_PLUS)) ? wm.seg : wm.rc;
+    ExtSide e;
+    int size, t0, p0;   // overhang length; first target / read position of the overhang
+    if (side == 0) { size = o.rs < o.ss ? o.rs : o.ss; t0 = o.ss - size; p0 = o.rs - size; }
+    else { int a = len - 1 - o.re, b = si.len - 1 - o.se; size = a < b ? a : b; t0 = o.se + 1; p0 = o.re + 1; }
+    const int4 *w = ix.pw + si.pwOff + t0;
+    int mm = 0, good = 0, tmp = 0;
+    for (int k = 0; k < size; ++k) mm += baseEqualW(w[k], r[p0 + k]) ? 0 : 1;
+    e.size = (short)size; e.match = (short)(size - mm); e.mis = (short)mm; e.indel = 0; e.pending = 0;
+    if (size > 1 && !((size - mm) * 2 - mm * 2 >= size * 2 - 8)) e.pending = 1;   // needs the banded DP
+    else {
+      if (side == 0) { for (int k = 1; k <= size; ++k) if (baseEqualW(w[size - k], r[p0 + size - k])) { ++tmp; if (tmp > 0.75 * k) good = k; } }
+      else { for (int k = 0; k < size; ++k) if (baseEqualW(w[k], r[p0 + k])) { ++tmp; if (tmp > 0.75 * (k + 1)) good = k + 1; } }
+    }
+    e.good = (short)good;
+    sides[q] = e;
+  }
+  __syncthreads();
+  // E2: gapped sides, one at a time on wavefront 0
+  if (lane < 64) {
+    for (int q = 0; q < 2 * n; ++q) {
+      if (!sides[q].pending) continue;           // wave-uniform
+      const OvRec &o = wm.fin[wm.ord[q >> 1]];
+      const int side = q & 1, size = sides[q].size;
+      const T4SeqInfo si = ix.seqs[o.seqIdx];
+      const char *r = (useFirstStrand ? plus0 : (o.flags & OV_PLUS)) ? wm.seg : wm.rc;
+      const int t0 = side == 0 ? o.ss - size : o.se + 1, p0 = side == 0 ? o.rs - size : o.re + 1;
+      dpWaveTracePW(ix.pw + si.pwOff + t0, size, r + p0, dirbuf);
+      if (lane == 0) {
+        signed char *align = (signed char *)(dirbuf + (size + 1) * 11);
+        int alen = tracebackPW(dirbuf, size, align);
+        int m = 0, mm = 0, ind = 0, good = 0, tmp = 0;
+        for (int k = 0; k < alen; ++k) { if (align[k] == 0) ++m; else if (align[k] == 1) ++mm; else ++ind; }
+        if (side == 0) {
+          for (int i = alen - 1, k = 1; i >= 0; --i, ++k) {
+            if (align[i] == 0) { ++tmp; if (tmp > 0.75 * k) good = k; }
+            else if (align[i] != 1) break;
+          }
+        } else {
+          for (int i = 0; i < alen; ++i) {
+            if (align[i] == 0) { ++tmp; if (tmp > 0.75 * (i + 1)) good = i + 1; }
+            else if (align[i] != 1) break;
+          }
+        }
+        ExtSide e = sides[q];
+        e.match = (short)m; e.mis = (short)mm; e.indel = (short)ind; e.good = (short)good; e.pending = 0;
+        sides[q] = e;
+      }
+    }
+  }
+  __syncthreads();
+  // E3: combine (SeqSet.hpp:1179-1266)
+  for (int i = lane; i < n; i += NT) {
+    const OvRec &o = wm.fin[wm.ord[i]];
+    const ExtSide L = sides[2 * i], R = sides[2 * i + 1];
+    int ret = 1;
+    int left = L.size, right = R.size;
+    int matchCnt = L.match + R.match, mismatchCnt = L.mis + R.mis;
+    if (L.indel > 0) { left = 0; ret = 0; }
+    if (R.indel > 0) { right = 0; ret = 0; }
+    int thr = 2;
+    if (left >= 2) ++thr;
+    if (right >= 2) ++thr;
+    const double density = 1.5 / ix.k;
+    thr = (int)(thr * factor);
+    if (mismatchCnt > thr && (double)mismatchCnt / (left + right) > density) ret = 0;
+    ExtOut e;
+    e.rs = o.rs - left; e.re = o.re + right; e.ss = o.ss - left; e.se = o.se + right;
+    e.matchCnt = 2 * matchCnt + o.matchCnt; e.simFail = 0;
+    e.den = e.re - e.rs + 1 + e.se - e.ss + 1;
+    double sim = (double)e.matchCnt / (double)e.den;
+    bool isRef = (o.flags & OV_ISREF) != 0;
+    if ((isRef && sim < ix.refSim) || (!isRef && sim < ix.novelSim)) { e.simFail = 1; e.matchCnt = o.matchCnt; ret = 0; }
+    if (ret == 0) { e.rs = o.rs - L.good; e.re = o.re + R.good; e.ss = o.ss - L.good; e.se = o.se + R.good; }
+    e.ret = ret;
+    res[i] = e;
+  }
+  __syncthreads();
+}
+
 // Process one read in one wavefront. Returns false when the read has to move to a larger tier.
 __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const T4Work &wk, const T4QueryArgs &qa,
                             WaveMem &wm, WaveState *ws, long long r, DPScratch sc) {
@@ -1531,7 +1685,79 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
   if (lane == 0) { ws->phaseT0 = clock64(); ws->curPhase = 0; }
 #endif
   __syncthreads();
-  if (qa.mode == 0) {
+  if (qa.mode == 2 || qa.mode == 3) {
+    // scratch carved from the arrays that are dead after overlapsFromSegment: pairs (+cand) and the key area
+    ExtSide *sides = (ExtSide *)wm.pairs;                 // 2 * maxFin * 12 B  <= cap * 4 B
+    ExtOut *res = (ExtOut *)wm.ov;                         // maxFin * 32 B      <= maxOv * 40 B
+    unsigned char *dirbuf = (unsigned char *)wm.keys;      // (len + 1) * 11 + 2 * len + 8 <= cap * 8 B
+    int barcode = bv.barcode ? bv.barcode[r] : -1;
+    loadSegment(bv, r, 0, len, wm);
+    int n;
+    if (qa.mode == 2) {
+      // SeqSet::AssignRead (SeqSet.hpp:4632-4701)
+      int ret = overlapsFromSegment(ix, wm, ws, len, qa.strand, barcode, false, 0, sc, hitTotal);
+      if (ret == -2) return false;
+      n = ret > 0 ? ret : 0;
+      __syncthreads();
+      for (int i = lane; i < n; i += NT) {   // std::sort(overlaps) with the scored similarity
+        OvRec me = wm.fin[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+          if (j == i) continue;
+          OvRec ot = wm.fin[j];
+          if (ovLess(ot, me, true) || (!ovLess(me, ot, true) && j < i)) ++rank;
+        }
+        wm.ord[rank] = (unsigned short)i;
+      }
+      __syncthreads();
+      extendOverlaps(ix, wm, ws, n, len, true, barcode == -1 ? 1.0 : 2.0, sides, dirbuf, res);
+      if (lane == 0) {
+        int hit = -1, staleIndel = 0;
+        for (int i = 0; i < n; ++i) {
+          if (res[i].ret == 1 && res[i].rs == 0 && res[i].re == len - 1) { hit = i; break; }
+          if (res[i].simFail) staleIndel = wm.fin[wm.ord[i]].indelCnt;   // `extendedOverlap = overlap` leaves its fields behind
+        }
+        T4OverlapOut t;
+        if (hit >= 0) {
+          const OvRec &o = wm.fin[wm.ord[hit]];
+          t.seqIdx = o.seqIdx; t.readStart = res[hit].rs; t.readEnd = res[hit].re; t.seqStart = res[hit].ss; t.seqEnd = res[hit].se;
+          t.strand = (o.flags & OV_PLUS) ? 1 : -1; t.matchCnt = res[hit].matchCnt; t.indelCnt = staleIndel;
+          t.similarity = (double)t.matchCnt / (double)res[hit].den;
+          qa.ret[r] = o.seqIdx;
+        } else {
+          t.seqIdx = -1; t.readStart = t.readEnd = t.seqStart = t.seqEnd = -1; t.strand = 1; t.matchCnt = 0; t.indelCnt = 0; t.similarity = 0;
+          qa.ret[r] = -1;
+        }
+        qa.out[r] = t;
+      }
+    } else {
+      // ExtendOverlap of caller-supplied overlaps, each against the strand it names
+      n = qa.inCounts[r];
+      if (n < 0) n = 0;
+      if (n > qa.maxPerRead) n = qa.maxPerRead;
+      if (n > wm.maxFin) return false;
+      for (int i = lane; i < n; i += NT) {
+        T4OverlapOut in = qa.in[r * qa.maxPerRead + i];
+        OvRec o;
+        o.seqIdx = in.seqIdx; o.rs = in.readStart; o.re = in.readEnd; o.ss = in.seqStart; o.se = in.seqEnd;
+        o.matchCnt = in.matchCnt; o.indelCnt = in.indelCnt; o.chainPos = 0; o.chainLen = 0;
+        o.flags = (in.strand == 1 ? OV_PLUS : 0) | (ix.seqs[in.seqIdx].isRef ? OV_ISREF : 0) | (in.similarity == 0 ? OV_SIMZERO : 0);
+        wm.fin[i] = o; wm.ord[i] = (unsigned short)i;
+      }
+      __syncthreads();
+      extendOverlaps(ix, wm, ws, n, len, false, qa.mismatchFactor, sides, dirbuf, res);
+      for (int i = lane; i < n; i += NT) {
+        const OvRec &o = wm.fin[i];
+        T4OverlapOut t;
+        t.seqIdx = o.seqIdx; t.readStart = res[i].rs; t.readEnd = res[i].re; t.seqStart = res[i].ss; t.seqEnd = res[i].se;
+        t.strand = (o.flags & OV_PLUS) ? 1 : -1; t.matchCnt = res[i].matchCnt;
+        if (res[i].simFail) { t.indelCnt = o.indelCnt; t.similarity = qa.in[r * qa.maxPerRead + i].similarity; }
+        else { t.indelCnt = 0; t.similarity = (double)t.matchCnt / (double)res[i].den; }
+        qa.out[r * qa.maxPerRead + i] = t;
+        qa.ret[r * qa.maxPerRead + i] = res[i].ret;
+      }
+    }
+  } else if (qa.mode == 0) {
     int barcode = bv.barcode ? bv.barcode[r] : -1;
     loadSegment(bv, r, 0, len, wm);
     int ret = overlapsFromSegment(ix, wm, ws, len, qa.strand, barcode, qa.skipRepeats != 0, 0, sc, hitTotal);
