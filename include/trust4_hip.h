@@ -69,6 +69,13 @@ int t4_index_add_contig(t4_index *ix, const char *name, const char *consensus, i
 /* Build the device image (CSR postings + lookup table + sequence table). Must be called after the
  * last add and before any query. */
 int t4_index_commit(t4_index *ix);
+/* Device image of a MUTATED contig set: the sequences added so far plus an explicit posting multiset
+ * (k-mer code, KmerIndex bucket, seq id, offset), i.e. the state KmerIndex::Insert / Remove /
+ * UpdateIndexFromRead (KmerIndex.hpp:66-181) left behind, which is not a function of the sequences alone. */
+int t4_index_commit_postings(t4_index *ix, int64_t n, const uint64_t *code, const int32_t *bucket,
+                             const int32_t *idx, const int32_t *offset);
+/* Forget every sequence (keeps k, barcode mode and parameters) so the handle can be re-filled. */
+int t4_index_clear(t4_index *ix);
 int t4_index_size(const t4_index *ix);
 int t4_index_seq_len(const t4_index *ix, int seq_id);
 const char *t4_index_seq_name(const t4_index *ix, int seq_id);
@@ -123,6 +130,30 @@ int t4_assign(t4_index *ix, t4_batch *b, int strand, int32_t *ret, t4_overlap *o
  * to the traceback formulation for wide bands), impl 1 = traceback formulation only. */
 int t4_gap_dp(t4_ctx *ctx, int kind, int impl, int n, const int64_t *t_off, const int64_t *p_off,
               const void *t_data, const char *p_chars, int32_t *out4);
+
+/* ---- ordered contig builder (host-side commit logic + GPU queries) ----------------------------------
+ * t4_assembler owns a mutable set of novel contigs (the reference's `SeqSet seqSet`, main.cpp:642) and exposes
+ * the members stage 1 calls on it, with the same arguments and return values:
+ *   t4_assembler_input_novel_read   SeqSet::InputNovelRead      (SeqSet.hpp:3028-3073)
+ *   t4_assembler_add_read           SeqSet::AddRead             (SeqSet.hpp:3426-4473)  >= 0 contig id, -1, -2
+ *   t4_assembler_repeat_add_read    SeqSet::RepeatAddRead       (SeqSet.hpp:4477-4507)
+ *   t4_assembler_update_all_consensus SeqSet::UpdateAllConsensus (SeqSet.hpp:4525-4535)
+ *   t4_assembler_output             SeqSet::Output(fp, NULL)    (SeqSet.hpp:10939-10994)  the _raw.out records
+ * GetOverlapsFromRead and every ExtendOverlap of an AddRead run on the GPU (t4_overlaps + t4_extend against a
+ * device image of the set); the order-dependent bookkeeping runs on the host. Return values below -50 are
+ * -100 + (a T4_ERR_* code). */
+typedef struct t4_assembler t4_assembler;
+int t4_assembler_create(t4_ctx *ctx, int kmer_length, int consider_barcode, t4_assembler **out);
+void t4_assembler_destroy(t4_assembler *a);
+int t4_assembler_set_params(t4_assembler *a, int hit_len_required, int radius, double novel_seq_similarity);
+int t4_assembler_input_novel_read(t4_assembler *a, const char *id, const char *read, int strand, int barcode);
+int t4_assembler_add_read(t4_assembler *a, const char *read, const char *gene_name, int *strand, int barcode,
+                          int min_kmer_count, int repetitive_data, double similarity_threshold);
+int t4_assembler_repeat_add_read(t4_assembler *a, const char *read);
+int t4_assembler_update_all_consensus(t4_assembler *a);
+int t4_assembler_output(t4_assembler *a, const char *path);
+int t4_assembler_size(const t4_assembler *a);
+int64_t t4_assembler_index_postings(const t4_assembler *a);
 
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* Per-call statistics of the last query on this ctx: kernel time measured with HIP events on the

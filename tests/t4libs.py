@@ -306,3 +306,41 @@ class Synth:
 
 def rows_to_strs(arr):
     return [bytes(r[:-1]).split(b"\0")[0].decode() for r in arr]
+
+
+class RefSeqSet:
+    """A mutable reference SeqSet (novel contigs) driven through oracle/_ref: the checker of the Add path."""
+
+    def __init__(self, k, hit_len_required=31):
+        self.lib = C.CDLL(Ref.PATH)
+        self.lib.ref_seqset_new.restype = C.c_void_p
+        self.h = C.c_void_p(self.lib.ref_seqset_new(k))
+        I, P = C.c_int, C.c_void_p
+        self.lib.ref_set_hit_len_required.argtypes = [P, I]
+        self.lib.ref_input_novel_read.argtypes = [P, C.c_char_p, C.c_char_p, I, I]
+        self.lib.ref_add_read.argtypes = [P, C.c_char_p, C.c_char_p, C.POINTER(I), I, I, I, C.c_double]
+        self.lib.ref_repeat_add_read.argtypes = [P, C.c_char_p]
+        self.lib.ref_update_all_consensus.argtypes = [P]
+        self.lib.ref_output.argtypes = [P, C.c_char_p]
+        self.lib.ref_size.argtypes = [P]
+        self.lib.ref_set_hit_len_required(self.h, hit_len_required)
+
+    def input_novel_read(self, name, read, strand, barcode=-1):
+        return self.lib.ref_input_novel_read(self.h, _b(name), _b(read), strand, barcode)
+
+    def add_read(self, read, gene_name, strand, barcode=-1, min_kmer_count=1, repetitive_data=0, similarity_threshold=0.9):
+        st = C.c_int(strand)
+        r = self.lib.ref_add_read(self.h, _b(read), _b(gene_name), C.byref(st), barcode, min_kmer_count, repetitive_data, similarity_threshold)
+        return r, st.value
+
+    def repeat_add_read(self, read):
+        return self.lib.ref_repeat_add_read(self.h, _b(read))
+
+    def update_all_consensus(self):
+        self.lib.ref_update_all_consensus(self.h)
+
+    def output(self, path):
+        self.lib.ref_output(self.h, _b(path))
+
+    def size(self):
+        return self.lib.ref_size(self.h)

@@ -1,0 +1,93 @@
+"""The ordered contig builder (trust4_amd/csrc/t4_assembler.cpp + GPU queries, here through the emulator build)
+against the UNMODIFIED reference SeqSet driven with the same call sequence (oracle/_ref). The driver below
+follows the policy of main.cpp:1583-1880: AddRead every distinct read in order, RepeatAddRead duplicates,
+seed a new contig with InputNovelRead when AddRead fails, UpdateAllConsensus periodically."""
+import filecmp
+import os
+import random
+
+import pytest
+
+import t4check
+from t4libs import REF_FA, Oracle, Ref, RefSeqSet, Synth, rows_to_strs
+
+pytestmark = pytest.mark.skipif(not Ref.available(), reason="oracle/_ref/libt4ref.so not built")
+
+
+def make_reads(seed, n_pairs, n_clones):
+    rnd = random.Random(seed)
+    reads = rows_to_strs(Synth(n_clones, seed).next_reads(n_pairs))
+    extra = []
+    for r in reads[: n_pairs // 3]:
+        x = list(r)
+        x[rnd.randrange(len(x))] = "N"
+        extra.append("".join(x))
+    reads += extra + reads[: n_pairs // 2]          # N-containing reads and exact duplicates
+    reads.sort(key=lambda s: (-len(s), s))          # duplicates become adjacent, as after main.cpp's sort
+    return reads
+
+
+def drive(asm, reads, names, thresholds, update_every=150):
+    log = []
+    prev_ret, n_ok = -1, 0
+    for i, rd in enumerate(reads):
+        if i > 0 and rd == reads[i - 1]:
+            ret = asm.repeat_add_read(rd) if prev_ret not in (-1, -3) else prev_ret
+            log.append(("rep", ret))
+        else:
+            ret, strand = asm.add_read(rd, names[i], 0, -1, 1 + (i % 7), 0, thresholds[i])
+            log.append(("add", ret, strand))
+            if ret < 0 and i % 3 != 2:
+                ret = asm.input_novel_read(names[i] if names[i] else "Novel", rd, 1 if i % 5 else -1, -1)
+                log.append(("new", ret))
+        prev_ret = ret
+        if ret >= 0:
+            n_ok += 1
+            if n_ok % update_every == 0:
+                asm.update_all_consensus()
+    asm.update_all_consensus()
+    return log
+
+
+def run_case(eng, tmp_path, seed, n_pairs, n_clones, k=9):
+    import trust4_amd
+    reads = make_reads(seed, n_pairs, n_clones)
+    # gene names come from the rough annotation, as in main.cpp:1609-1620 (first 4 letters of the last annotated gene)
+    o = Oracle(9, REF_FA, 17)
+    names, thr = [], []
+    rnd = random.Random(seed)
+    for rd in reads:
+        _, g = o.annotate_read0(rd)
+        nm = ""
+        for t in range(4):
+            if g[t][0] != -1:
+                nm = o.name(g[t][0])[:4]
+        names.append(nm)
+        thr.append(rnd.choice([0.9, 0.95, 0.97]))
+    ref = RefSeqSet(k)
+    mine = trust4_amd.Assembler(eng, k)
+    log_ref = drive(ref, reads, names, thr)
+    log_mine = drive(mine, reads, names, thr)
+    first_diff = next((i for i, (a, b) in enumerate(zip(log_ref, log_mine)) if a != b), None)
+    assert first_diff is None, (first_diff, log_ref[first_diff], log_mine[first_diff])
+    pa, pb = str(tmp_path / "ref_raw.out"), str(tmp_path / "mine_raw.out")
+    ref.output(pa)
+    mine.output(pb)
+    assert filecmp.cmp(pa, pb, shallow=False)
+    n_add = sum(1 for x in log_ref if x[0] == "add" and x[1] >= 0)
+    assert n_add > len(reads) // 10
+    return log_ref
+
+
+@pytest.fixture(scope="module")
+def emu_engine():
+    os.environ["T4_LIB"] = t4check.build_emulator_lib()
+    import trust4_amd
+    eng = trust4_amd.Engine(0)
+    yield eng
+    os.environ.pop("T4_LIB", None)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_add_path_matches_reference(emu_engine, tmp_path, seed):
+    run_case(emu_engine, tmp_path, seed, 150, 12)

@@ -118,3 +118,12 @@ def test_gap_dp_vs_oracle(eng):
     from test_engine_emu import check_equal_length_shortcut, check_gap_dp
     check_gap_dp(eng, 5, 20000)
     check_equal_length_shortcut(eng, 50000)
+
+
+@pytest.mark.skipif(not Ref.available(), reason="oracle/_ref not shipped")
+@pytest.mark.parametrize("seed,n_pairs,n_clones", [(1, 150, 12), (3, 500, 30), (4, 400, 6)])
+def test_add_path_matches_reference(eng, tmp_path, seed, n_pairs, n_clones):
+    """Ordered contig builder: every AddRead / RepeatAddRead / InputNovelRead return value and the final _raw.out
+    records equal the unmodified reference SeqSet driven with the same calls."""
+    from test_assembler_emu import run_case
+    run_case(eng, tmp_path, seed, n_pairs, n_clones)

@@ -50,6 +50,12 @@ def _load():
         "t4_annotate_rough": (I, [P, P, P]),
         "t4_gap_dp": (I, [P, I, I, I, P, P, P, P, P]),
         "t4_extend": (I, [P, P, I, P, P, C.c_double, P, P]), "t4_assign": (I, [P, P, I, P, P]),
+        "t4_assembler_create": (I, [P, I, I, C.POINTER(P)]), "t4_assembler_destroy": (None, [P]),
+        "t4_assembler_set_params": (I, [P, I, I, C.c_double]),
+        "t4_assembler_input_novel_read": (I, [P, C.c_char_p, C.c_char_p, I, I]),
+        "t4_assembler_add_read": (I, [P, C.c_char_p, C.c_char_p, C.POINTER(I), I, I, I, C.c_double]),
+        "t4_assembler_repeat_add_read": (I, [P, C.c_char_p]), "t4_assembler_update_all_consensus": (I, [P]),
+        "t4_assembler_output": (I, [P, C.c_char_p]), "t4_assembler_size": (I, [P]), "t4_assembler_index_postings": (L, [P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -109,6 +115,54 @@ class Engine:
     def close(self):
         if getattr(self, "h", None):
             self.lib.t4_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Assembler:
+    """t4_assembler: the reference's `SeqSet seqSet` of novel contigs with its Add path (same call signatures)."""
+
+    def __init__(self, eng, k, consider_barcode=False, hit_len_required=31, radius=10, novel_seq_similarity=0.9):
+        self.eng = eng
+        h = C.c_void_p()
+        eng.check(eng.lib.t4_assembler_create(eng.h, k, 1 if consider_barcode else 0, C.byref(h)))
+        self.h = h
+        eng.check(eng.lib.t4_assembler_set_params(h, hit_len_required, radius, novel_seq_similarity))
+
+    def _ret(self, r):
+        if r < -50:
+            raise T4Error(r + 100, self.eng.lib.t4_last_error(self.eng.h).decode())
+        return r
+
+    def input_novel_read(self, name, read, strand, barcode=-1):
+        return self._ret(self.eng.lib.t4_assembler_input_novel_read(self.h, name.encode(), read.encode(), strand, barcode))
+
+    def add_read(self, read, gene_name, strand, barcode=-1, min_kmer_count=1, repetitive_data=0, similarity_threshold=0.9):
+        st = C.c_int(strand)
+        r = self._ret(self.eng.lib.t4_assembler_add_read(self.h, read.encode(), gene_name.encode(), C.byref(st), barcode, min_kmer_count,
+                                                        repetitive_data, similarity_threshold))
+        return r, st.value
+
+    def repeat_add_read(self, read):
+        return self._ret(self.eng.lib.t4_assembler_repeat_add_read(self.h, read.encode()))
+
+    def update_all_consensus(self):
+        self.eng.check(self.eng.lib.t4_assembler_update_all_consensus(self.h))
+
+    def output(self, path):
+        self.eng.check(self.eng.lib.t4_assembler_output(self.h, path.encode()))
+
+    def size(self):
+        return self.eng.lib.t4_assembler_size(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.eng.lib.t4_assembler_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -5,8 +5,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "t4_api.hip")
+SRC_HOST = os.path.join(HERE, "csrc", "t4_assembler.cpp")
 OUT = os.path.join(HERE, "libt4hip.so")
-DEPS = [SRC, os.path.join(HERE, "csrc", "t4_kernels.h"), os.path.join(HERE, "csrc", "t4_device.h"),
+DEPS = [SRC, SRC_HOST, os.path.join(HERE, "csrc", "t4_kernels.h"), os.path.join(HERE, "csrc", "t4_device.h"),
         os.path.join(os.path.dirname(HERE), "include", "trust4_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
@@ -15,7 +16,7 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", OUT, SRC, "-lz"]
+    cmd = [hipcc] + FLAGS + ["-o", OUT, SRC, SRC_HOST, "-lz"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

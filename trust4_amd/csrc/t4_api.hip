@@ -323,14 +323,36 @@ int t4_index_add_contig(t4_index *ix, const char *name, const char *consensus, i
   return T4_OK;
 }
 
+}  // extern "C"
+
+namespace {
+struct Rec { unsigned long long code; int h; int idx, off; };
+int commitWithPostings(t4_index *ix, std::vector<Rec> &recs);
+}  // namespace
+
+extern "C" {
+
+int t4_index_clear(t4_index *ix) {
+  if (!ix) return T4_ERR_ARG;
+  ix->seqs.clear(); ix->dedup.clear(); ix->committed = false;
+  return T4_OK;
+}
+
+int t4_index_commit_postings(t4_index *ix, int64_t n, const uint64_t *code, const int32_t *bucket, const int32_t *idx, const int32_t *offset) {
+  if (!ix || n < 0 || (n > 0 && (!code || !bucket || !idx || !offset))) return T4_ERR_ARG;
+  std::vector<Rec> recs((size_t)n);
+  for (int64_t i = 0; i < n; ++i) {
+    if (idx[i] < 0 || idx[i] >= (int)ix->seqs.size()) return fail(ix->ctx, T4_ERR_ARG, "posting %lld names sequence %d", (long long)i, idx[i]);
+    recs[(size_t)i] = {code[i], bucket[i], idx[i], offset[i]};
+  }
+  return commitWithPostings(ix, recs);
+}
+
 int t4_index_commit(t4_index *ix) {
   if (!ix) return T4_ERR_ARG;
-  t4_ctx *c = ix->ctx;
-  (void)hipSetDevice(c->device);
   const int K = ix->k;
   const unsigned long long mask = K < 32 ? ((1ull << (2 * K)) - 1ull) : ~0ull;
   // postings in BuildIndexFromRead order (KmerIndex.hpp:118-141), keyed by (code, bucket)
-  struct Rec { unsigned long long code; int h; int idx, off; };
   std::vector<Rec> recs;
   for (size_t id = 0; id < ix->seqs.size(); ++id) {
     const HostSeq &s = ix->seqs[id];
@@ -352,6 +374,16 @@ int t4_index_commit(t4_index *ix) {
       prev = code;
     }
   }
+  return commitWithPostings(ix, recs);
+}
+
+}  // extern "C"
+
+namespace {
+int commitWithPostings(t4_index *ix, std::vector<Rec> &recs) {
+  t4_ctx *c = ix->ctx;
+  (void)hipSetDevice(c->device);
+  const int K = ix->k;
   std::stable_sort(recs.begin(), recs.end(), [](const Rec &a, const Rec &b) { return a.code != b.code ? a.code < b.code : a.h < b.h; });
   std::vector<int2> post(recs.size());
   for (size_t i = 0; i < recs.size(); ++i) post[i] = make_int2(recs[i].idx, recs[i].off);
@@ -436,6 +468,9 @@ int t4_index_commit(t4_index *ix) {
   ix->committed = true;
   return T4_OK;
 }
+}  // namespace
+
+extern "C" {
 
 int t4_index_size(const t4_index *ix) { return ix ? (int)ix->seqs.size() : 0; }
 int t4_index_seq_len(const t4_index *ix, int i) { return (ix && i >= 0 && i < (int)ix->seqs.size()) ? (int)ix->seqs[i].cons.size() : -1; }

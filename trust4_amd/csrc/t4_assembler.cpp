@@ -1,0 +1,652 @@
+// trust4_amd/csrc/t4_assembler.cpp -- host side of the order-dependent contig builder.
+//
+// The greedy assembly loop of stage 1 (main.cpp:1583-1880) is inherently sequential: every successful
+// SeqSet::AddRead mutates the contig set the next read is matched against (hard part 1).
+// This file is the ordered-commit half of that design: it owns the mutable contig set and its k-mer
+// index on the host and replays the reference's bookkeeping exactly, while everything that is
+// expensive and read-only per read -- GetOverlapsFromRead and the ExtendOverlap alignments -- is
+// obtained from the GPU through the C ABI of include/trust4_hip.h (t4_overlaps, t4_extend) against a
+// device image of the set. Round 1 refreshes that image whenever the set changed (commit window of
+// one read: exact, not yet fast); the windowed speculation described in DESIGN.md builds on this.
+//
+// Reference semantics followed: SeqSet::AddRead (SeqSet.hpp:3426-4473), RepeatAddRead (4477-4507),
+// InputNovelRead (3028-3073), UpdateConsensus / UpdateAllConsensus (4525-4588), SubstituteConsensusPos
+// (11058-11080), IsNameCompatible (3370-3419), Output (10939-10994), and KmerIndex::Insert / Remove /
+// BuildIndexFromRead / UpdateIndexFromRead / RemoveIndexFromRead (KmerIndex.hpp:66-201).
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/trust4_hip.h"
+
+namespace {
+
+inline int nucNum(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
+const char NUM2NUC[4] = {'A', 'C', 'G', 'T'};
+
+struct KCode {  // KmerCode.hpp
+  int k, invalidPos;
+  uint64_t code, mask;
+  explicit KCode(int kl) : k(kl), invalidPos(-1), code(0), mask(kl < 32 ? ((1ull << (2 * kl)) - 1ull) : ~0ull) {}
+  void restart() { code = 0; invalidPos = -1; }
+  void append(char c) {
+    if (invalidPos != -1) ++invalidPos;
+    code = ((code << 2) & mask) | (uint64_t)(nucNum(c) & 3);
+    if (c == 'N') invalidPos = 0;
+    if (invalidPos >= k) invalidPos = -1;
+  }
+  bool valid() const { return invalidPos == -1; }
+};
+
+struct Post { int idx, offset; };
+struct Key {
+  uint64_t code; int h;
+  bool operator==(const Key &o) const { return code == o.code && h == o.h; }
+};
+struct KeyHash {
+  size_t operator()(const Key &k) const {
+    uint64_t z = k.code * 1000003ull + (uint64_t)k.h;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return (size_t)(z ^ (z >> 31));
+  }
+};
+
+// The mutable KmerIndex: a posting multiset per (code, bucket) with the reference's edit operations.
+struct HostIndex {
+  int k; bool considerBarcode = false;
+  std::unordered_map<Key, std::vector<Post>, KeyHash> map;
+  size_t total = 0;
+  explicit HostIndex(int kl) : k(kl) {}
+  int bucket(uint64_t code, int barcode) const { return (int)((code + (uint64_t)(int64_t)(considerBarcode ? barcode + 1 : 0)) % 1000003ull); }
+  void insert(const KCode &kc, int idx, int off, int barcode) {
+    if (!kc.valid()) return;
+    map[Key{kc.code, bucket(kc.code, barcode)}].push_back(Post{idx, off});
+    ++total;
+  }
+  void remove(const KCode &kc, int idx, int off, int barcode) {  // first posting equal to (idx, off)
+    if (!kc.valid()) return;
+    auto it = map.find(Key{kc.code, bucket(kc.code, barcode)});
+    if (it == map.end()) return;
+    auto &l = it->second;
+    for (size_t i = 0; i < l.size(); ++i)
+      if (l[i].idx == idx && l[i].offset == off) { l.erase(l.begin() + i); --total; break; }
+    if (l.empty()) map.erase(it);
+  }
+  void build(const char *s, int len, int id, int barcode, int shift = 0) {  // BuildIndexFromRead
+    if (len < k) return;
+    KCode kc(k), prev(k);
+    int i;
+    for (i = 0; i < k - 1; ++i) kc.append(s[i]);
+    for (; i < len; ++i) {
+      kc.append(s[i]);
+      if (kc.valid() && (i == k || kc.code != prev.code)) insert(kc, id, i - k + 1 + shift, barcode);
+      prev = kc;
+    }
+  }
+  void update(const char *s, int len, int barcode, int shift, int oldId, int id) {  // UpdateIndexFromRead
+    if (len < k) return;
+    KCode kc(k);
+    int i;
+    for (i = 0; i < k - 1; ++i) kc.append(s[i]);
+    for (; i < len; ++i) {
+      kc.append(s[i]);
+      if (!kc.valid()) continue;
+      auto it = map.find(Key{kc.code, bucket(kc.code, barcode)});
+      if (it == map.end()) continue;
+      for (auto &p : it->second)
+        if (p.idx == oldId && p.offset == i - k + 1) { p.idx = id; p.offset += shift; break; }
+    }
+  }
+  void removeSeq(const char *s, int len, int id, int barcode, int offset) {  // RemoveIndexFromRead
+    if (len < k) return;
+    KCode kc(k);
+    int i;
+    for (i = 0; i < k - 1; ++i) kc.append(s[i]);
+    for (; i < len; ++i) { kc.append(s[i]); if (kc.valid()) remove(kc, id, i - k + 1 + offset, barcode); }
+  }
+};
+
+struct PosWeight { int c[4]; };
+struct Seq {
+  std::string name, cons;
+  std::vector<PosWeight> pw;
+  bool released = false;
+  int minLeftExtAnchor = 0, minRightExtAnchor = 0, barcode = -1, numRead = 0;
+};
+
+struct Ov {  // struct _overlap fields that the Add path reads or writes
+  int seqIdx = -1, readStart = -1, readEnd = -1, seqStart = -1, seqEnd = -1, strand = 1, matchCnt = 0, indelCnt = 0;
+  double similarity = 0;
+};
+bool ovLess(const Ov &a, const Ov &b) {  // _overlap::operator< (SeqSet.hpp:104-128)
+  if (a.matchCnt != b.matchCnt) return a.matchCnt > b.matchCnt;
+  if (a.similarity != b.similarity) return a.similarity > b.similarity;
+  if (a.readEnd - a.readStart != b.readEnd - b.readStart) return a.readEnd - a.readStart > b.readEnd - b.readStart;
+  if (a.seqIdx != b.seqIdx) return a.seqIdx < b.seqIdx;
+  if (a.strand != b.strand) return a.strand < b.strand;
+  if (a.readStart != b.readStart) return a.readStart < b.readStart;
+  if (a.readEnd != b.readEnd) return a.readEnd < b.readEnd;
+  if (a.seqStart != b.seqStart) return a.seqStart < b.seqStart;
+  return a.seqEnd < b.seqEnd;
+}
+Ov fromT4(const t4_overlap &o) {
+  Ov v; v.seqIdx = o.seqIdx; v.readStart = o.readStart; v.readEnd = o.readEnd; v.seqStart = o.seqStart; v.seqEnd = o.seqEnd;
+  v.strand = o.strand; v.matchCnt = o.matchCnt; v.indelCnt = o.indelCnt; v.similarity = o.similarity;
+  return v;
+}
+
+// SeqSet::GetChainType / GetGeneType (SeqSet.hpp:5132-5155, 5076-5100)
+int chainType(const char *n) {
+  if (n[0] == 'I') { if (n[2] == 'H') return 0; if (n[2] == 'K') return 1; if (n[2] == 'L') return 2; }
+  else if (n[0] == 'T') { if (n[2] == 'A') return 3; if (n[2] == 'B') return 4; if (n[2] == 'G') return 5; if (n[2] == 'D') return 6; }
+  return 8;
+}
+int geneType(const char *n) {
+  if (n[0] == 'N' && n[1] == 'o') return -1;
+  switch (n[3]) {
+    case 'V': return 0;
+    case 'D': return (n[4] >= '0' && n[4] <= '9') ? 1 : 3;
+    case 'J': return 2;
+    case 'L': if (chainType(n) == 2) return -1; return 3;
+    default: return 3;
+  }
+}
+// IsNameCompatible (SeqSet.hpp:3370-3419): b comes after a
+bool nameCompatible(const std::string &a, const std::string &b) {
+  int maxA = -1, minB = 10;
+  auto each = [](const std::string &s, auto fn) {
+    size_t i = 0;
+    while (i < s.size()) {
+      if (s[i] == '+') { ++i; continue; }
+      size_t j = i;
+      while (j < s.size() && s[j] != '+') ++j;
+      std::string part = s.substr(i, j - i);
+      part.append(8, '\0');
+      fn(geneType(part.c_str()));
+      i = j;
+    }
+  };
+  each(a, [&](int gt) { if (gt > maxA) maxA = gt; });
+  each(b, [&](int gt) { if (gt < minB && gt != -1) minB = gt; });
+  return maxA <= minB;
+}
+
+void reverseComplement(std::string &rc, const std::string &s) {
+  size_t n = s.size();
+  rc.resize(n);
+  for (size_t i = 0; i < n; ++i) { char c = s[n - 1 - i]; rc[i] = c != 'N' ? NUM2NUC[3 - nucNum(c)] : 'N'; }
+}
+
+}  // namespace
+
+struct t4_assembler {
+  t4_ctx *ctx;
+  t4_index *dev = nullptr;   // device image of the current set
+  bool dirty = true;
+  int k, radius = 10, hitLenRequired = 31;
+  double novelSim = 0.9;
+  std::vector<Seq> seqs;
+  HostIndex index;
+  Ov prevAdd;
+  std::string err;
+  int64_t queries = 0, refreshes = 0;
+  t4_assembler(t4_ctx *c, int kl) : ctx(c), k(kl), index(kl) { prevAdd.readStart = -1; }
+
+  void setPrev(int seqIdx, int rs, int re, int ss, int se, int strand) {
+    prevAdd.seqIdx = seqIdx; prevAdd.readStart = rs; prevAdd.readEnd = re; prevAdd.seqStart = ss; prevAdd.seqEnd = se; prevAdd.strand = strand;
+  }
+
+  int refreshDevice() {
+    if (!dirty) return T4_OK;
+    int r;
+    if (!dev) { if ((r = t4_index_create(ctx, k, index.considerBarcode ? 1 : 0, &dev))) return r; }
+    if ((r = t4_index_clear(dev))) return r;
+    if ((r = t4_index_set_params(dev, hitLenRequired, radius, novelSim))) return r;
+    for (const Seq &s : seqs) {
+      int id;
+      const char *cons = s.released ? "" : s.cons.c_str();
+      if ((r = t4_index_add_contig(dev, s.released ? "" : s.name.c_str(), cons, s.barcode,
+                                   s.released || s.pw.empty() ? nullptr : (const int32_t *)s.pw.data(), &id))) return r;
+    }
+    std::vector<uint64_t> code; std::vector<int32_t> bucket, idx, off;
+    code.reserve(index.total); bucket.reserve(index.total); idx.reserve(index.total); off.reserve(index.total);
+    for (const auto &kv : index.map)
+      for (const Post &p : kv.second) { code.push_back(kv.first.code); bucket.push_back(kv.first.h); idx.push_back(p.idx); off.push_back(p.offset); }
+    if ((r = t4_index_commit_postings(dev, (int64_t)code.size(), code.data(), bucket.data(), idx.data(), off.data()))) return r;
+    dirty = false; ++refreshes;
+    return T4_OK;
+  }
+
+  // SeqSet::InputNovelRead (SeqSet.hpp:3028-3073)
+  int inputNovelRead(const char *id, const char *read, int strand, int barcode) {
+    Seq ns;
+    ns.name = id; ns.cons = read;
+    if (strand == -1) reverseComplement(ns.cons, std::string(read));
+    ns.barcode = barcode; ns.numRead = 1;
+    int len = (int)ns.cons.size();
+    ns.pw.assign(len, PosWeight{{0, 0, 0, 0}});
+    for (int i = 0; i < len; ++i) if (ns.cons[i] != 'N') ns.pw[i].c[nucNum(ns.cons[i])] = 1;
+    int seqIdx = (int)seqs.size();
+    seqs.push_back(ns);
+    index.build(seqs[seqIdx].cons.c_str(), len, seqIdx, barcode);
+    setPrev(seqIdx, 0, len - 1, 0, len - 1, strand);
+    dirty = true;
+    return seqIdx;
+  }
+
+  // UpdateConsensus (SeqSet.hpp:4537-4588)
+  void updateConsensus(int seqIdx, bool updateIndex) {
+    Seq &s = seqs[seqIdx];
+    std::vector<std::pair<int, int>> changes;
+    for (int i = 0; i < (int)s.cons.size(); ++i) {
+      int mx = 0, tag = 0;
+      for (int j = 0; j < 4; ++j) if (s.pw[i].c[j] > mx) { mx = s.pw[i].c[j]; tag = j; }
+      if (mx == 0) continue;
+      int cur = s.cons[i] == 'N' ? 0 : nucNum(s.cons[i]);   // nucToNum['N' - 'A'] is 0 in the reference's table (main.cpp:39-44)
+      if (cur != tag && s.pw[i].c[cur] < mx) changes.push_back({i, tag});
+    }
+    if (changes.empty()) return;
+    if (updateIndex) index.removeSeq(s.cons.c_str(), (int)s.cons.size(), seqIdx, s.barcode, 0);
+    for (auto &c : changes) s.cons[c.first] = NUM2NUC[c.second];
+    if (updateIndex) index.build(s.cons.c_str(), (int)s.cons.size(), seqIdx, s.barcode, 0);
+    dirty = true;
+  }
+  void updateAllConsensus() { for (int i = 0; i < (int)seqs.size(); ++i) if (!seqs[i].released) updateConsensus(i, true); }
+
+  // SubstituteConsensusPos (SeqSet.hpp:11058-11080), updateIndex == true
+  void substituteConsensusPos(int seqIdx, int pos, char c) {
+    Seq &s = seqs[seqIdx];
+    int clen = (int)s.cons.size();
+    if (pos >= clen || s.cons[pos] == c) return;
+    int start = pos - k + 1, end = pos + k - 1;
+    if (start < 0) start = 0;
+    if (end >= clen) end = clen - 1;
+    index.removeSeq(s.cons.c_str() + start, end - start + 1, seqIdx, s.barcode, start);
+    s.cons[pos] = c;
+    index.build(s.cons.c_str() + start, end - start + 1, seqIdx, s.barcode, start);
+    dirty = true;
+  }
+
+  // RepeatAddRead (SeqSet.hpp:4477-4507)
+  int repeatAddRead(const char *read) {
+    if (prevAdd.seqIdx < 0) return prevAdd.seqIdx;
+    std::string r = read;
+    if (prevAdd.strand == -1) reverseComplement(r, std::string(read));
+    Seq &s = seqs[prevAdd.seqIdx];
+    for (int i = prevAdd.readStart; i <= prevAdd.readEnd; ++i) {
+      if (r[i] == 'N') continue;
+      ++s.pw[i + prevAdd.seqStart].c[nucNum(r[i])];
+    }
+    ++s.numRead;
+    dirty = true;
+    return prevAdd.seqIdx;
+  }
+
+  int addRead(const char *read, const char *geneName, int *strandIO, int barcode, int minKmerCount, bool repetitiveData, double similarityThreshold);
+  int output(const char *path) const;
+};
+
+// SeqSet::AddRead (SeqSet.hpp:3426-4473) for a set that holds novel contigs only (stage 1 keeps the reference genes
+// in a separate SeqSet, main.cpp:642, so the isRef branches of the reference are unreachable there).
+int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO, int barcode, int minKmerCount,
+                          bool repetitiveData, double similarityThreshold) {
+  const std::string read = readC;
+  const int len = (int)read.size();
+  const int K = this->k;   // k-mer length
+  setPrev(-1, -1, -1, -1, -1, 0);
+  int rc;
+  if ((rc = refreshDevice())) return -100 + rc;
+  // GetOverlapsFromRead + the ExtendOverlap of every overlap, from the GPU
+  const int MAXOV = 128;
+  t4_batch *batch = nullptr;
+  int64_t offs[2] = {0, len};
+  int32_t bc = barcode;
+  if ((rc = t4_reads_upload(ctx, read.c_str(), offs, &bc, 1, &batch))) return -100 + rc;
+  std::vector<t4_overlap> ovBuf(MAXOV), extBuf(MAXOV);
+  std::vector<int32_t> extRet(MAXOV);
+  int32_t cnt = 0;
+  rc = t4_overlaps(dev, batch, *strandIO, repetitiveData ? 1 : 0, MAXOV, &cnt, ovBuf.data());
+  ++queries;
+  if (rc == T4_OK && cnt > MAXOV) rc = T4_ERR_UNSUPPORTED;
+  if (rc == T4_OK && cnt > 0)
+    rc = t4_extend(dev, batch, MAXOV, &cnt, ovBuf.data(), (barcode == -1 && !repetitiveData) ? 1.0 : 2.0, extRet.data(), extBuf.data());
+  t4_batch_destroy(batch);
+  if (rc) return -100 + rc;
+  int overlapCnt = cnt;
+  if (overlapCnt <= 0) return -1;
+
+  struct Cand { Ov ov; Ov ext; int extRet; };
+  std::vector<Cand> cands;
+  for (int i = 0; i < overlapCnt; ++i) cands.push_back(Cand{fromT4(ovBuf[i]), fromT4(extBuf[i]), extRet[i]});
+  if (geneName[0] != '\0') {
+    std::vector<Cand> kept;
+    for (auto &c : cands) {
+      const std::string &nm = seqs[c.ov.seqIdx].name;
+      int j = 3;
+      if (!nm.empty() && nm[0] >= 'A' && nm[0] <= 'Z') {
+        for (j = 0; j < 3; ++j) if ((j < (int)nm.size() ? nm[j] : '\0') != geneName[j]) break;
+      }
+      if (j == 3 || nm == "Novel") kept.push_back(c);
+    }
+    cands.swap(kept);
+    overlapCnt = (int)cands.size();
+    if (overlapCnt <= 0) return -1;
+  }
+  std::stable_sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return ovLess(a.ov, b.ov); });
+  std::vector<Ov> overlaps(overlapCnt);
+  for (int i = 0; i < overlapCnt; ++i) overlaps[i] = cands[i].ov;
+
+  std::vector<Ov> ext(overlapCnt), failed(overlapCnt);
+  std::vector<std::pair<int, int>> oldMinExtAnchor(overlapCnt);
+  int ne = 0, ret = -1, failedCnt = 0, tag = 0, jMerge = 0;
+  bool sortExtended = true;
+  Ov good;
+  std::string rcRead;
+  reverseComplement(rcRead, read);
+  const std::string &r = overlaps[0].strand == 1 ? read : rcRead;
+  int readInConsensusOffset = 0, seqIdx = -1;
+  bool addNew = true;
+  int i, j;
+
+  auto clen = [&](int s) { return (int)seqs[s].cons.size(); };
+  for (i = 0; i < overlapCnt; ++i) {
+    oldMinExtAnchor[i] = {seqs[overlaps[i].seqIdx].minLeftExtAnchor, seqs[overlaps[i].seqIdx].minRightExtAnchor};
+    for (j = 0; j < ne; ++j) {
+      int leftRadius = radius, rightRadius = radius;
+      if (ext[j].seqStart == 0) leftRadius = 0;
+      if (ext[j].seqEnd == clen(ext[j].seqIdx) - 1) rightRadius = 0;
+      if (overlaps[i].readStart >= ext[j].readStart - leftRadius && overlaps[i].readEnd <= ext[j].readEnd + rightRadius &&
+          (overlaps[i].seqStart >= radius || overlaps[i].seqEnd <= clen(overlaps[i].seqIdx) - radius - 1)) break;
+      leftRadius = radius; rightRadius = radius;
+      if (overlaps[i].seqStart == 0) leftRadius = 0;
+      if (overlaps[i].seqEnd == clen(overlaps[i].seqIdx) - 1) rightRadius = 0;
+      if (ext[j].readStart >= overlaps[i].readStart - leftRadius && ext[j].readEnd <= overlaps[i].readEnd + rightRadius) break;
+    }
+    if (j < ne) continue;
+    ext[ne] = cands[i].ext;                       // what ExtendOverlap leaves in extendedOverlaps[ne]
+    if (cands[i].extRet == 1) {
+      Seq &es = seqs[ext[ne].seqIdx];
+      if (ext[ne].similarity < similarityThreshold) {
+        if ((minKmerCount <= 1 || ext[ne].similarity + 0.01 >= similarityThreshold) && ext[ne].readStart == 0 && ext[ne].readEnd == len - 1) good = ext[ne];
+        continue;
+      }
+      for (j = 0; j < ne; ++j) {
+        int leftRadius = radius, rightRadius = radius;
+        if (ext[j].seqStart == 0) leftRadius = 0;
+        if (ext[j].seqEnd == clen(ext[j].seqIdx) - 1) rightRadius = 0;
+        if (ext[ne].readStart >= ext[j].readStart - leftRadius && ext[ne].readEnd <= ext[j].readEnd + rightRadius &&
+            (overlaps[i].seqStart > 0 || overlaps[i].seqEnd < clen(overlaps[i].seqIdx) - 1)) break;
+        if (ext[j].readStart >= ext[ne].readStart - radius && ext[j].readEnd <= ext[ne].readEnd + radius) break;
+      }
+      if (j < ne) continue;
+      const int span = ext[ne].readEnd - ext[ne].readStart + 1;
+      auto raiseAnchors = [&]() {
+        if (ext[ne].readStart > 0 && es.minLeftExtAnchor < span) es.minLeftExtAnchor = span;
+        if (ext[ne].readEnd < len - 1 && es.minRightExtAnchor < span) es.minRightExtAnchor = span;
+      };
+      for (j = 0; j < i; ++j) {
+        if (ext[ne].seqStart == 0 && ext[ne].seqEnd == clen(ext[ne].seqIdx) - 1) continue;
+        if (ext[ne].readStart >= overlaps[j].readStart && ext[ne].readEnd <= overlaps[j].readEnd &&
+            (overlaps[j].readEnd - overlaps[j].readStart >= ext[ne].readEnd - ext[ne].readStart + 10 ||
+             overlaps[j].similarity + 0.02 >= ext[ne].similarity)) { raiseAnchors(); break; }
+      }
+      if (j < i) continue;
+      for (j = 0; j < failedCnt; ++j) {
+        if (ext[ne].seqStart == 0 && ext[ne].seqEnd == clen(ext[ne].seqIdx) - 1) continue;
+        if (ext[ne].readStart >= failed[j].readStart && ext[ne].readEnd <= failed[j].readEnd) { raiseAnchors(); break; }
+      }
+      if (j < failedCnt) continue;
+      if (ext[ne].readStart > 0 && es.minLeftExtAnchor >= span) continue;
+      if (ext[ne].readEnd < len - 1 && es.minRightExtAnchor >= span) continue;
+      tag = i;
+      ++ne;
+    } else failed[failedCnt++] = ext[ne];
+  }
+
+  if (ne == 1 && ext[0].readStart <= radius && ext[0].readEnd >= len - radius) {
+    // could the read bridge two contigs?
+    for (i = 0; i < overlapCnt; ++i) {
+      if (tag == i) continue;
+      ext[ne] = cands[i].ext;
+      if (cands[i].extRet == 1) { jMerge = i; ++ne; }
+    }
+    if (ne > 2) ne = 1;
+    else if (ne == 2) {
+      const int span1 = ext[1].readEnd - ext[1].readStart + 1;
+      if (ext[1].readStart > 0 && oldMinExtAnchor[jMerge].first >= span1) ne = 1;
+      if (ext[1].readEnd < len - 1 && oldMinExtAnchor[jMerge].second >= span1) ne = 1;
+      if (ne == 2) {
+        if (ext[0].seqEnd == clen(ext[0].seqIdx) - 1 && ext[1].seqStart == 0) sortExtended = false;
+        else if (ext[0].seqStart == 0 && ext[1].seqEnd == clen(ext[1].seqIdx) - 1) { sortExtended = false; std::swap(ext[0], ext[1]); }
+        else ne = 1;
+      }
+    }
+  }
+  if (similarityThreshold > novelSim) {
+    int c = 0;
+    for (i = 0; i < ne; ++i) if (ext[i].similarity >= similarityThreshold) ext[c++] = ext[i];
+    ne = c;
+  }
+  if (ne == 0 && good.seqIdx != -1) { ext[0] = good; ne = 1; }
+  if (ne > 1) {
+    for (i = 0; i < ne; ++i) if (ext[i].similarity >= 0.95) break;
+    if (i >= ne) {
+      int maxtag = 0;
+      for (i = 1; i < ne; ++i) if (ovLess(ext[i], ext[maxtag])) maxtag = i;
+      ext[0] = ext[maxtag];
+      ne = 1;
+    }
+  }
+  if (ne > 1) {
+    bool dup = false;
+    for (i = 0; i < ne - 1 && !dup; ++i) for (j = i + 1; j < ne; ++j) if (ext[i].seqIdx == ext[j].seqIdx) { dup = true; break; }
+    if (dup) ne = 0;
+  }
+
+  if (ne > 1) {
+    // ---- merge contigs through the read (SeqSet.hpp:3878-4130)
+    const int eCnt = ne;
+    addNew = false;
+    if (sortExtended) std::stable_sort(ext.begin(), ext.begin() + eCnt, [](const Ov &a, const Ov &b) { return a.readStart < b.readStart; });
+    for (i = 0; i < eCnt; ++i) for (j = i + 1; j < eCnt; ++j) if (!nameCompatible(seqs[ext[i].seqIdx].name, seqs[ext[j].seqIdx].name)) return -1;
+    int sum = 0;
+    for (i = 0; i < eCnt; ++i) sum += clen(ext[i].seqIdx);
+    std::string newCons(sum + len + 1, '\0');
+    std::vector<int> seqOffset(eCnt);
+    if (ext[0].readStart > 0) { for (i = 0; i < eCnt; ++i) seqOffset[i] = ext[i].readStart; }
+    else {
+      seqOffset[0] = 0;
+      for (i = 1; i < eCnt; ++i) seqOffset[i] = seqOffset[i - 1] + clen(ext[i - 1].seqIdx) - 1 + (ext[i].readStart - ext[i - 1].readEnd);
+    }
+    if (ext[0].readStart > 0) memcpy(&newCons[0], r.data(), len); else memcpy(&newCons[ext[0].seqStart], r.data(), len);
+    for (i = eCnt - 1; i >= 0; --i) memcpy(&newCons[seqOffset[i]], seqs[ext[i].seqIdx].cons.data(), clen(ext[i].seqIdx));
+    int newLen = 0, lastEnd = eCnt - 1, kk = 0;
+    for (i = 0; i < eCnt; ++i) if (seqOffset[i] + clen(ext[i].seqIdx) > kk) { kk = seqOffset[i] + clen(ext[i].seqIdx); lastEnd = i; }
+    if (ext[lastEnd].readEnd < len) newLen = kk + (len - ext[lastEnd].readEnd - 1); else newLen = kk;
+    newCons.resize(newLen);
+    int newSeqIdx = ext[0].seqIdx, kmin = 0;
+    for (i = 1; i < eCnt; ++i) if (ext[i].seqIdx < newSeqIdx) { newSeqIdx = ext[i].seqIdx; kmin = i; }
+    {
+      std::vector<PosWeight> &pw = seqs[newSeqIdx].pw;
+      int oldLen = clen(newSeqIdx);
+      std::vector<PosWeight> npw(newLen, PosWeight{{0, 0, 0, 0}});
+      for (int t = 0; t < oldLen && seqOffset[kmin] + t < newLen; ++t) npw[seqOffset[kmin] + t] = pw[t];
+      pw.swap(npw);
+    }
+    for (i = 0; i < eCnt; ++i) {
+      int sIdx = ext[i].seqIdx;
+      if (sIdx == newSeqIdx) continue;
+      seqs[newSeqIdx].numRead += seqs[sIdx].numRead;
+      for (j = 0; j < clen(sIdx); ++j) for (int c = 0; c < 4; ++c) seqs[newSeqIdx].pw[seqOffset[i] + j].c[c] += seqs[sIdx].pw[j].c[c];
+    }
+    for (i = 0; i < eCnt; ++i) index.removeSeq(seqs[ext[i].seqIdx].cons.c_str(), clen(ext[i].seqIdx), ext[i].seqIdx, barcode, 0);
+    {
+      int nameIdx;
+      for (nameIdx = 0; nameIdx < eCnt; ++nameIdx) if (seqs[ext[nameIdx].seqIdx].name != "Novel") break;
+      if (nameIdx >= eCnt) nameIdx = 0;
+      std::string nb = seqs[ext[nameIdx].seqIdx].name;
+      for (i = 0; i < eCnt; ++i) {
+        if (i == nameIdx) continue;
+        if (i > 0 && seqs[ext[i].seqIdx].name != seqs[ext[i - 1].seqIdx].name) nb += "+" + seqs[ext[i].seqIdx].name;
+      }
+      // the reference frees/overwrites name strings in place; names of merged-away seqs are read before release
+      seqs[newSeqIdx].name = nb;
+    }
+    // anchors are read from the (pre-merge) owners before they are released
+    const int newMinLeft = seqs[ext[0].seqIdx].minLeftExtAnchor, newMinRight = seqs[ext[lastEnd].seqIdx].minRightExtAnchor;
+    for (i = 0; i < eCnt; ++i) {
+      int sIdx = ext[i].seqIdx;
+      if (sIdx == newSeqIdx) continue;
+      Seq &d = seqs[sIdx];
+      d.released = true; d.name.clear(); d.cons.clear(); d.pw.clear();
+    }
+    seqs[newSeqIdx].cons = newCons;
+    updateConsensus(newSeqIdx, false);
+    index.build(seqs[newSeqIdx].cons.c_str(), newLen, newSeqIdx, barcode);
+    seqs[newSeqIdx].minLeftExtAnchor = newMinLeft;
+    seqs[newSeqIdx].minRightExtAnchor = newMinRight;
+    readInConsensusOffset = ext[0].seqStart > 0 ? ext[0].seqStart : 0;
+    seqIdx = newSeqIdx;
+  } else if (ne == 1) {
+    // ---- extend one contig, or place the read inside it (SeqSet.hpp:4131-4316)
+    addNew = false;
+    seqIdx = ext[0].seqIdx;
+    Seq &seq = seqs[seqIdx];
+    ++seq.numRead;
+    if (ext[0].readStart > 0 || ext[0].readEnd < len - 1) {
+      std::vector<std::pair<int, int>> replacement;
+      const int oldLen = clen(seqIdx);
+      std::string newCons;
+      if (ext[0].readStart > 0) newCons.assign(r.data(), ext[0].readStart);
+      newCons += seq.cons;
+      if (ext[0].readEnd < len - 1) newCons.append(r.data() + ext[0].readEnd + 1, len - 1 - ext[0].readEnd);
+      const int newLen = (int)newCons.size();
+      const int shift = ext[0].readStart;
+      if (shift > 0) {
+        index.build(newCons.c_str(), ext[0].readStart + K - 1, seqIdx, barcode);
+        index.update(seq.cons.c_str(), oldLen, barcode, shift, seqIdx, seqIdx);
+      }
+      if (ext[0].readEnd < len - 1) {
+        int start = ext[0].readStart + ext[0].seqEnd - K + 2;
+        index.build(newCons.c_str() + start, newLen - start, seqIdx, barcode, start);
+      }
+      const int expandSize = ext[0].readStart + (len - 1 - ext[0].readEnd);
+      seq.pw.resize(oldLen + expandSize, PosWeight{{0, 0, 0, 0}});
+      if (shift > 0) {
+        for (i = oldLen - 1; i >= 0; --i) seq.pw[i + shift] = seq.pw[i];
+        if (barcode == -1 || minKmerCount > 1) {
+          for (i = 0; i < 2; ++i) {
+            if (i + shift >= len || r[i + shift] == 'N') continue;
+            if (r[i + shift] != newCons[i + shift] && newCons[i + shift] != 'N' && seq.pw[i + shift].c[nucNum(newCons[i + shift])] == 1)
+              replacement.push_back({i + shift, (int)r[i + shift]});
+            for (j = 0; j < 4; ++j) if (r[i + shift] != NUM2NUC[j] && seq.pw[i + shift].c[j] > 1) --seq.pw[i + shift].c[j];
+          }
+        }
+        for (i = 0; i < shift; ++i) seq.pw[i] = PosWeight{{0, 0, 0, 0}};
+      }
+      if (ext[0].readEnd < len - 1) {
+        int start = ext[0].readStart + oldLen;
+        for (i = 0; i < len - ext[0].readEnd - 1; ++i) seq.pw[start + i] = PosWeight{{0, 0, 0, 0}};
+        if (barcode == -1 || minKmerCount > 1) {
+          for (i = oldLen - 2; i < oldLen; ++i) {
+            int pos = i - ext[0].seqStart, seqPos = i + shift;
+            if (pos < 0 || r[pos] == 'N') continue;
+            if (r[pos] != newCons[seqPos] && newCons[seqPos] != 'N' && seq.pw[seqPos].c[nucNum(newCons[seqPos])] == 1)
+              replacement.push_back({seqPos, (int)r[pos]});
+            for (j = 0; j < 4; ++j) if (r[pos] != NUM2NUC[j] && seq.pw[seqPos].c[j] > 1) --seq.pw[seqPos].c[j];
+          }
+        }
+      }
+      if (shift > 0) seq.minLeftExtAnchor = 0;
+      if (ext[0].readEnd < len - 1) seq.minRightExtAnchor = 0;
+      readInConsensusOffset = ext[0].seqStart > 0 ? ext[0].seqStart : 0;
+      seq.cons = newCons;
+      for (auto &p : replacement) substituteConsensusPos(seqIdx, p.first, (char)p.second);
+    } else readInConsensusOffset = ext[0].seqStart;
+  }
+
+  if (!addNew) {
+    Seq &seq = seqs[seqIdx];
+    std::vector<int> nPos;
+    for (i = 0; i < len; ++i) {
+      if (r[i] == 'N') continue;
+      ++seq.pw[i + readInConsensusOffset].c[nucNum(r[i])];
+      if (seq.cons[i + readInConsensusOffset] == 'N') nPos.push_back(i);
+    }
+    setPrev(seqIdx, 0, len - 1, readInConsensusOffset, readInConsensusOffset + len - 1, overlaps[0].strand);
+    int size = (int)nPos.size();
+    for (i = 0; i < size;) {
+      for (j = i + 1; j < size; ++j) if (nPos[j] > nPos[j - 1] + K - 1) break;
+      for (int l = i; l < j; ++l) seq.cons[nPos[l] + readInConsensusOffset] = r[nPos[l]];
+      int start = nPos[i] - K + 1 + readInConsensusOffset;
+      if (start < 0) start = 0;
+      int end = nPos[j - 1] + K - 1 + readInConsensusOffset;
+      if (end >= (int)seq.cons.size()) end = (int)seq.cons.size() - 1;
+      index.build(seq.cons.c_str() + start, end - start + 1, seqIdx, barcode, start);
+      i = j;
+    }
+    ret = seqIdx;
+    dirty = true;
+  }
+  // a set of novel contigs has no reference sequence to anchor a new contig on (SeqSet.hpp:4373-4384)
+  if (ret == -1) { setPrev(-2, -1, -1, -1, -1, 0); ret = -2; }
+  if (ret >= 0 && *strandIO == 0) *strandIO = overlaps[0].strand;
+  return ret;
+}
+
+// SeqSet::Output (SeqSet.hpp:10939-10994) without barcode names
+int t4_assembler::output(const char *path) const {
+  FILE *fp = fopen(path, "w");
+  if (!fp) return T4_ERR_IO;
+  for (int i = 0; i < (int)seqs.size(); ++i) {
+    const Seq &s = seqs[i];
+    if (s.released) continue;
+    fprintf(fp, ">assemble%d %s\n%s\n", i, s.name.c_str(), s.cons.c_str());
+    for (int c = 0; c < 4; ++c) {
+      for (size_t j = 0; j < s.cons.size(); ++j) fprintf(fp, "%d ", s.pw[j].c[c]);
+      fprintf(fp, "\n");
+    }
+  }
+  fclose(fp);
+  return T4_OK;
+}
+
+extern "C" {
+
+int t4_assembler_create(t4_ctx *ctx, int kmer_length, int consider_barcode, t4_assembler **out) {
+  if (!ctx || !out || kmer_length < 2 || kmer_length > 31) return T4_ERR_ARG;
+  t4_assembler *a = new t4_assembler(ctx, kmer_length);
+  a->index.considerBarcode = consider_barcode != 0;
+  *out = a;
+  return T4_OK;
+}
+void t4_assembler_destroy(t4_assembler *a) {
+  if (!a) return;
+  if (a->dev) t4_index_destroy(a->dev);
+  delete a;
+}
+int t4_assembler_set_params(t4_assembler *a, int hit_len_required, int radius, double novel_seq_similarity) {
+  if (!a) return T4_ERR_ARG;
+  a->hitLenRequired = hit_len_required; a->radius = radius; a->novelSim = novel_seq_similarity; a->dirty = true;
+  return T4_OK;
+}
+int t4_assembler_input_novel_read(t4_assembler *a, const char *id, const char *read, int strand, int barcode) {
+  if (!a || !id || !read) return T4_ERR_ARG - 100;
+  return a->inputNovelRead(id, read, strand, barcode);
+}
+int t4_assembler_add_read(t4_assembler *a, const char *read, const char *gene_name, int *strand, int barcode, int min_kmer_count,
+                          int repetitive_data, double similarity_threshold) {
+  if (!a || !read || !gene_name || !strand) return T4_ERR_ARG - 100;
+  return a->addRead(read, gene_name, strand, barcode, min_kmer_count, repetitive_data != 0, similarity_threshold);
+}
+int t4_assembler_repeat_add_read(t4_assembler *a, const char *read) { return a ? a->repeatAddRead(read) : T4_ERR_ARG - 100; }
+int t4_assembler_update_all_consensus(t4_assembler *a) { if (!a) return T4_ERR_ARG; a->updateAllConsensus(); return T4_OK; }
+int t4_assembler_output(t4_assembler *a, const char *path) { return a ? a->output(path) : T4_ERR_ARG; }
+int t4_assembler_size(const t4_assembler *a) { return a ? (int)a->seqs.size() : 0; }
+int64_t t4_assembler_index_postings(const t4_assembler *a) { return a ? (int64_t)a->index.total : 0; }
+
+}  // extern "C"
