@@ -150,6 +150,15 @@ int t4_assembler_input_novel_read(t4_assembler *a, const char *id, const char *r
 int t4_assembler_add_read(t4_assembler *a, const char *read, const char *gene_name, int *strand, int barcode,
                           int min_kmer_count, int repetitive_data, double similarity_threshold);
 int t4_assembler_repeat_add_read(t4_assembler *a, const char *read);
+/* Speculation window: query the GPU once for the next n reads (in the order they will be offered to
+ * t4_assembler_add_read, with the strand / barcode / repetitive_data arguments they will be offered with). The
+ * results are consumed by the following add_read calls for as long as no commit changed anything a query can
+ * observe (index, consensus, contig creation, an IsBaseEqual state flip); after that add_read falls back to a
+ * fresh query and t4_assembler_window_valid returns 0 so that the caller can prefetch again. Never changes results. */
+int t4_assembler_prefetch(t4_assembler *a, int n, const char *const *reads, const int *strands, const int *barcodes,
+                          int repetitive_data);
+int t4_assembler_window_valid(const t4_assembler *a);
+int t4_assembler_counters(const t4_assembler *a, int64_t *queries, int64_t *refreshes, int64_t *window_hits);
 int t4_assembler_update_all_consensus(t4_assembler *a);
 int t4_assembler_output(t4_assembler *a, const char *path);
 int t4_assembler_size(const t4_assembler *a);

@@ -27,10 +27,13 @@ def make_reads(seed, n_pairs, n_clones):
     return reads
 
 
-def drive(asm, reads, names, thresholds, update_every=150):
+def drive(asm, reads, names, thresholds, update_every=150, window=0):
     log = []
     prev_ret, n_ok = -1, 0
     for i, rd in enumerate(reads):
+        if window and not (i > 0 and rd == reads[i - 1]) and not asm.window_valid():
+            nxt = [reads[j] for j in range(i, len(reads)) if j == 0 or reads[j] != reads[j - 1]][:window]
+            asm.prefetch(nxt, [0] * len(nxt))
         if i > 0 and rd == reads[i - 1]:
             ret = asm.repeat_add_read(rd) if prev_ret not in (-1, -3) else prev_ret
             log.append(("rep", ret))
@@ -49,7 +52,7 @@ def drive(asm, reads, names, thresholds, update_every=150):
     return log
 
 
-def run_case(eng, tmp_path, seed, n_pairs, n_clones, k=9):
+def run_case(eng, tmp_path, seed, n_pairs, n_clones, k=9, window=0):
     import trust4_amd
     reads = make_reads(seed, n_pairs, n_clones)
     # gene names come from the rough annotation, as in main.cpp:1609-1620 (first 4 letters of the last annotated gene)
@@ -67,7 +70,10 @@ def run_case(eng, tmp_path, seed, n_pairs, n_clones, k=9):
     ref = RefSeqSet(k)
     mine = trust4_amd.Assembler(eng, k)
     log_ref = drive(ref, reads, names, thr)
-    log_mine = drive(mine, reads, names, thr)
+    log_mine = drive(mine, reads, names, thr, window=window)
+    if window:
+        c = mine.counters()
+        assert c["window_hits"] > 0 and c["queries"] < sum(1 for x in log_mine if x[0] == "add")
     first_diff = next((i for i, (a, b) in enumerate(zip(log_ref, log_mine)) if a != b), None)
     assert first_diff is None, (first_diff, log_ref[first_diff], log_mine[first_diff])
     pa, pb = str(tmp_path / "ref_raw.out"), str(tmp_path / "mine_raw.out")
@@ -91,3 +97,7 @@ def emu_engine():
 @pytest.mark.parametrize("seed", [1, 2])
 def test_add_path_matches_reference(emu_engine, tmp_path, seed):
     run_case(emu_engine, tmp_path, seed, 150, 12)
+
+
+def test_speculation_window_is_exact(emu_engine, tmp_path):
+    run_case(emu_engine, tmp_path, 5, 200, 10, window=32)

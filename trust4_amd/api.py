@@ -54,6 +54,8 @@ def _load():
         "t4_assembler_set_params": (I, [P, I, I, C.c_double]),
         "t4_assembler_input_novel_read": (I, [P, C.c_char_p, C.c_char_p, I, I]),
         "t4_assembler_add_read": (I, [P, C.c_char_p, C.c_char_p, C.POINTER(I), I, I, I, C.c_double]),
+        "t4_assembler_prefetch": (I, [P, I, P, P, P, I]), "t4_assembler_window_valid": (I, [P]),
+        "t4_assembler_counters": (I, [P, P, P, P]),
         "t4_assembler_repeat_add_read": (I, [P, C.c_char_p]), "t4_assembler_update_all_consensus": (I, [P]),
         "t4_assembler_output": (I, [P, C.c_char_p]), "t4_assembler_size": (I, [P]), "t4_assembler_index_postings": (L, [P]),
     }
@@ -150,6 +152,22 @@ class Assembler:
 
     def repeat_add_read(self, read):
         return self._ret(self.eng.lib.t4_assembler_repeat_add_read(self.h, read.encode()))
+
+    def prefetch(self, reads, strands, barcodes=None, repetitive_data=0):
+        n = len(reads)
+        arr = (C.c_char_p * n)(*[r.encode() for r in reads])
+        st = np.ascontiguousarray(strands, dtype=np.int32)
+        bc = None if barcodes is None else np.ascontiguousarray(barcodes, dtype=np.int32)
+        self.eng.check(self.eng.lib.t4_assembler_prefetch(self.h, n, C.cast(arr, C.c_void_p), st.ctypes.data_as(C.c_void_p),
+                                                          None if bc is None else bc.ctypes.data_as(C.c_void_p), repetitive_data))
+
+    def window_valid(self):
+        return bool(self.eng.lib.t4_assembler_window_valid(self.h))
+
+    def counters(self):
+        q, r, h = C.c_int64(), C.c_int64(), C.c_int64()
+        self.eng.check(self.eng.lib.t4_assembler_counters(self.h, C.byref(q), C.byref(r), C.byref(h)))
+        return {"queries": q.value, "refreshes": r.value, "window_hits": h.value}
 
     def update_all_consensus(self):
         self.eng.check(self.eng.lib.t4_assembler_update_all_consensus(self.h))

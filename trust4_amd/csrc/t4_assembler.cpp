@@ -193,8 +193,26 @@ struct t4_assembler {
   HostIndex index;
   Ov prevAdd;
   std::string err;
-  int64_t queries = 0, refreshes = 0;
+  int64_t queries = 0, refreshes = 0, cacheHits = 0;
+  // speculation window: query results of upcoming reads, valid while `epoch` (bumped by every change a query can
+  // observe: index, consensus, contig creation/release, a flip of a posWeight column's IsBaseEqual state) stands
+  struct Cached { std::string read; int strand, barcode, skip; int32_t cnt; std::vector<t4_overlap> ov, ext; std::vector<int32_t> extRet; };
+  std::vector<Cached> cache;
+  size_t cacheHead = 0;
+  uint64_t epoch = 0, cacheEpoch = ~0ull;
   t4_assembler(t4_ctx *c, int kl) : ctx(c), k(kl), index(kl) { prevAdd.readStart = -1; }
+  void structuralChange() { dirty = true; ++epoch; }
+  // ++count[base] of one posWeight column; reports whether AlignAlgo::IsBaseEqual (AlignAlgo.hpp:49-55) can now answer differently
+  void bumpWeight(PosWeight &w, int base) {
+    int sum = w.c[0] + w.c[1] + w.c[2] + w.c[3];
+    unsigned before = sum == 0 ? 16u : 0u, after = 0;
+    for (int x = 0; x < 4; ++x) before |= (sum < 3 * w.c[x]) ? (1u << x) : 0u;
+    ++w.c[base]; ++sum;
+    for (int x = 0; x < 4; ++x) after |= (sum < 3 * w.c[x]) ? (1u << x) : 0u;
+    dirty = true;
+    if (before != after) ++epoch;
+  }
+  int prefetch(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive);
 
   void setPrev(int seqIdx, int rs, int re, int ss, int se, int strand) {
     prevAdd.seqIdx = seqIdx; prevAdd.readStart = rs; prevAdd.readEnd = re; prevAdd.seqStart = ss; prevAdd.seqEnd = se; prevAdd.strand = strand;
@@ -234,7 +252,7 @@ struct t4_assembler {
     seqs.push_back(ns);
     index.build(seqs[seqIdx].cons.c_str(), len, seqIdx, barcode);
     setPrev(seqIdx, 0, len - 1, 0, len - 1, strand);
-    dirty = true;
+    structuralChange();
     return seqIdx;
   }
 
@@ -253,7 +271,7 @@ struct t4_assembler {
     if (updateIndex) index.removeSeq(s.cons.c_str(), (int)s.cons.size(), seqIdx, s.barcode, 0);
     for (auto &c : changes) s.cons[c.first] = NUM2NUC[c.second];
     if (updateIndex) index.build(s.cons.c_str(), (int)s.cons.size(), seqIdx, s.barcode, 0);
-    dirty = true;
+    structuralChange();
   }
   void updateAllConsensus() { for (int i = 0; i < (int)seqs.size(); ++i) if (!seqs[i].released) updateConsensus(i, true); }
 
@@ -268,7 +286,7 @@ struct t4_assembler {
     index.removeSeq(s.cons.c_str() + start, end - start + 1, seqIdx, s.barcode, start);
     s.cons[pos] = c;
     index.build(s.cons.c_str() + start, end - start + 1, seqIdx, s.barcode, start);
-    dirty = true;
+    structuralChange();
   }
 
   // RepeatAddRead (SeqSet.hpp:4477-4507)
@@ -279,10 +297,9 @@ struct t4_assembler {
     Seq &s = seqs[prevAdd.seqIdx];
     for (int i = prevAdd.readStart; i <= prevAdd.readEnd; ++i) {
       if (r[i] == 'N') continue;
-      ++s.pw[i + prevAdd.seqStart].c[nucNum(r[i])];
+      bumpWeight(s.pw[i + prevAdd.seqStart], nucNum(r[i]));
     }
     ++s.numRead;
-    dirty = true;
     return prevAdd.seqIdx;
   }
 
@@ -298,24 +315,30 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
   const int len = (int)read.size();
   const int K = this->k;   // k-mer length
   setPrev(-1, -1, -1, -1, -1, 0);
-  int rc;
-  if ((rc = refreshDevice())) return -100 + rc;
-  // GetOverlapsFromRead + the ExtendOverlap of every overlap, from the GPU
+  // GetOverlapsFromRead + the ExtendOverlap of every overlap: from the speculation window when it is still valid,
+  // else from a fresh GPU query of this read
   const int MAXOV = 128;
-  t4_batch *batch = nullptr;
-  int64_t offs[2] = {0, len};
-  int32_t bc = barcode;
-  if ((rc = t4_reads_upload(ctx, read.c_str(), offs, &bc, 1, &batch))) return -100 + rc;
-  std::vector<t4_overlap> ovBuf(MAXOV), extBuf(MAXOV);
-  std::vector<int32_t> extRet(MAXOV);
+  std::vector<t4_overlap> ovBuf, extBuf;
+  std::vector<int32_t> extRet;
   int32_t cnt = 0;
-  rc = t4_overlaps(dev, batch, *strandIO, repetitiveData ? 1 : 0, MAXOV, &cnt, ovBuf.data());
-  ++queries;
-  if (rc == T4_OK && cnt > MAXOV) rc = T4_ERR_UNSUPPORTED;
-  if (rc == T4_OK && cnt > 0)
-    rc = t4_extend(dev, batch, MAXOV, &cnt, ovBuf.data(), (barcode == -1 && !repetitiveData) ? 1.0 : 2.0, extRet.data(), extBuf.data());
-  t4_batch_destroy(batch);
-  if (rc) return -100 + rc;
+  bool served = false;
+  if (cacheEpoch == epoch && cacheHead < cache.size()) {
+    Cached &c = cache[cacheHead];
+    if (c.read == read && c.strand == *strandIO && c.barcode == barcode && c.skip == (repetitiveData ? 1 : 0)) {
+      cnt = c.cnt; ovBuf.swap(c.ov); extBuf.swap(c.ext); extRet.swap(c.extRet);
+      ++cacheHead; ++cacheHits; served = true;
+    }
+  }
+  if (!served) {
+    cache.clear(); cacheHead = 0; cacheEpoch = ~0ull;
+    const char *one = read.c_str();
+    int st = *strandIO, bcOne = barcode;
+    int rc = prefetch(1, &one, &st, &bcOne, repetitiveData ? 1 : 0);
+    if (rc) return -100 + rc;
+    Cached &c = cache[0];
+    cnt = c.cnt; ovBuf.swap(c.ov); extBuf.swap(c.ext); extRet.swap(c.extRet);
+    cacheHead = 1;
+  }
   int overlapCnt = cnt;
   if (overlapCnt <= 0) return -1;
 
@@ -511,6 +534,7 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
     seqs[newSeqIdx].minRightExtAnchor = newMinRight;
     readInConsensusOffset = ext[0].seqStart > 0 ? ext[0].seqStart : 0;
     seqIdx = newSeqIdx;
+    structuralChange();
   } else if (ne == 1) {
     // ---- extend one contig, or place the read inside it (SeqSet.hpp:4131-4316)
     addNew = false;
@@ -565,6 +589,7 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
       if (ext[0].readEnd < len - 1) seq.minRightExtAnchor = 0;
       readInConsensusOffset = ext[0].seqStart > 0 ? ext[0].seqStart : 0;
       seq.cons = newCons;
+      structuralChange();
       for (auto &p : replacement) substituteConsensusPos(seqIdx, p.first, (char)p.second);
     } else readInConsensusOffset = ext[0].seqStart;
   }
@@ -574,7 +599,7 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
     std::vector<int> nPos;
     for (i = 0; i < len; ++i) {
       if (r[i] == 'N') continue;
-      ++seq.pw[i + readInConsensusOffset].c[nucNum(r[i])];
+      bumpWeight(seq.pw[i + readInConsensusOffset], nucNum(r[i]));
       if (seq.cons[i + readInConsensusOffset] == 'N') nPos.push_back(i);
     }
     setPrev(seqIdx, 0, len - 1, readInConsensusOffset, readInConsensusOffset + len - 1, overlaps[0].strand);
@@ -587,15 +612,71 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
       int end = nPos[j - 1] + K - 1 + readInConsensusOffset;
       if (end >= (int)seq.cons.size()) end = (int)seq.cons.size() - 1;
       index.build(seq.cons.c_str() + start, end - start + 1, seqIdx, barcode, start);
+      structuralChange();
       i = j;
     }
     ret = seqIdx;
-    dirty = true;
   }
   // a set of novel contigs has no reference sequence to anchor a new contig on (SeqSet.hpp:4373-4384)
   if (ret == -1) { setPrev(-2, -1, -1, -1, -1, 0); ret = -2; }
   if (ret >= 0 && *strandIO == 0) *strandIO = overlaps[0].strand;
   return ret;
+}
+
+// Query the GPU for n upcoming reads against the current set (one batch) and keep the results as the speculation window.
+int t4_assembler::prefetch(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive) {
+  const int MAXOV = 128;
+  int rc;
+  if ((rc = refreshDevice())) return rc;
+  cache.clear(); cacheHead = 0;
+  // t4_overlaps takes one strand argument per call: group the window by strand value (-1 / 0 / 1)
+  cache.resize(n);
+  for (int i = 0; i < n; ++i) { cache[i].read = reads[i]; cache[i].strand = strands[i]; cache[i].barcode = barcodes ? barcodes[i] : -1; cache[i].skip = repetitive; cache[i].cnt = 0; }
+  for (int sv = -1; sv <= 1; ++sv) {
+    std::vector<int> ids;
+    for (int i = 0; i < n; ++i) if (strands[i] == sv) ids.push_back(i);
+    if (ids.empty()) continue;
+    std::string bases; std::vector<int64_t> offs(1, 0); std::vector<int32_t> bcs;
+    for (int i : ids) { bases += cache[i].read; offs.push_back((int64_t)bases.size()); bcs.push_back(cache[i].barcode); }
+    t4_batch *batch = nullptr;
+    if (bases.empty()) bases.push_back('A');
+    if ((rc = t4_reads_upload(ctx, bases.data(), offs.data(), bcs.data(), (int64_t)ids.size(), &batch))) return rc;
+    const size_t m = ids.size();
+    std::vector<t4_overlap> ov(m * MAXOV), ex(m * MAXOV);
+    std::vector<int32_t> cnts(m), rets(m * MAXOV);
+    rc = t4_overlaps(dev, batch, sv, repetitive, MAXOV, cnts.data(), ov.data());
+    ++queries;
+    for (size_t q = 0; rc == T4_OK && q < m; ++q) if (cnts[q] > MAXOV) rc = T4_ERR_UNSUPPORTED;
+    if (rc == T4_OK) {
+      // ExtendOverlap's mismatch factor depends on the read's barcode (SeqSet.hpp:3597-3598): one call per factor
+      for (int pass = 0; pass < 2 && rc == T4_OK; ++pass) {
+        std::vector<int32_t> c2(m, 0);
+        bool any = false;
+        for (size_t q = 0; q < m; ++q) {
+          bool f1 = (bcs[q] == -1 && !repetitive);
+          if ((pass == 0) == f1 && cnts[q] > 0) { c2[q] = cnts[q]; any = true; }
+        }
+        if (!any) continue;
+        std::vector<t4_overlap> ex2(m * MAXOV);
+        std::vector<int32_t> r2(m * MAXOV);
+        rc = t4_extend(dev, batch, MAXOV, c2.data(), ov.data(), pass == 0 ? 1.0 : 2.0, r2.data(), ex2.data());
+        for (size_t q = 0; rc == T4_OK && q < m; ++q)
+          for (int t = 0; t < c2[q]; ++t) { ex[q * MAXOV + t] = ex2[q * MAXOV + t]; rets[q * MAXOV + t] = r2[q * MAXOV + t]; }
+      }
+    }
+    t4_batch_destroy(batch);
+    if (rc) { cache.clear(); return rc; }
+    for (size_t q = 0; q < m; ++q) {
+      Cached &c = cache[ids[q]];
+      c.cnt = cnts[q];
+      int k2 = c.cnt > 0 ? c.cnt : 0;
+      c.ov.assign(ov.begin() + q * MAXOV, ov.begin() + q * MAXOV + k2);
+      c.ext.assign(ex.begin() + q * MAXOV, ex.begin() + q * MAXOV + k2);
+      c.extRet.assign(rets.begin() + q * MAXOV, rets.begin() + q * MAXOV + k2);
+    }
+  }
+  cacheEpoch = epoch;
+  return T4_OK;
 }
 
 // SeqSet::Output (SeqSet.hpp:10939-10994) without barcode names
@@ -642,6 +723,18 @@ int t4_assembler_add_read(t4_assembler *a, const char *read, const char *gene_na
                           int repetitive_data, double similarity_threshold) {
   if (!a || !read || !gene_name || !strand) return T4_ERR_ARG - 100;
   return a->addRead(read, gene_name, strand, barcode, min_kmer_count, repetitive_data != 0, similarity_threshold);
+}
+int t4_assembler_prefetch(t4_assembler *a, int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive_data) {
+  if (!a || n < 0 || (n > 0 && (!reads || !strands))) return T4_ERR_ARG;
+  return a->prefetch(n, reads, strands, barcodes, repetitive_data ? 1 : 0);
+}
+int t4_assembler_window_valid(const t4_assembler *a) { return a && a->cacheEpoch == a->epoch && a->cacheHead < a->cache.size(); }
+int t4_assembler_counters(const t4_assembler *a, int64_t *queries, int64_t *refreshes, int64_t *window_hits) {
+  if (!a) return T4_ERR_ARG;
+  if (queries) *queries = a->queries;
+  if (refreshes) *refreshes = a->refreshes;
+  if (window_hits) *window_hits = a->cacheHits;
+  return T4_OK;
 }
 int t4_assembler_repeat_add_read(t4_assembler *a, const char *read) { return a ? a->repeatAddRead(read) : T4_ERR_ARG - 100; }
 int t4_assembler_update_all_consensus(t4_assembler *a) { if (!a) return T4_ERR_ARG; a->updateAllConsensus(); return T4_OK; }
