@@ -162,6 +162,8 @@ int t4_assembler_counters(const t4_assembler *a, int64_t *queries, int64_t *refr
 int t4_assembler_update_all_consensus(t4_assembler *a);
 int t4_assembler_output(t4_assembler *a, const char *path);
 int t4_assembler_size(const t4_assembler *a);
+/* SeqSet::ChangeKmerLength (SeqSet.hpp:4624-4629): compacts the set (ids are renumbered) and re-indexes with the new k. */
+int t4_assembler_change_kmer_length(t4_assembler *a, int kmer_length);
 int64_t t4_assembler_index_postings(const t4_assembler *a);
 
 /* ---- measurement ----------------------------------------------------------------------------- */

@@ -303,6 +303,23 @@ struct t4_assembler {
     return prevAdd.seqIdx;
   }
 
+  // SeqSet::ChangeKmerLength -> Clean(false) (SeqSet.hpp:4591-4629): drop released slots (contig ids are renumbered),
+  // rebuild the whole index with the new k
+  int changeKmerLength(int kl) {
+    k = kl;
+    bool cb = index.considerBarcode;
+    index = HostIndex(kl);
+    index.considerBarcode = cb;
+    std::vector<Seq> kept;
+    for (Seq &s : seqs) if (!s.released) kept.push_back(std::move(s));
+    seqs.swap(kept);
+    for (int i = 0; i < (int)seqs.size(); ++i) index.build(seqs[i].cons.c_str(), (int)seqs[i].cons.size(), i, seqs[i].barcode, 0);
+    setPrev(-1, -1, -1, -1, -1, 0);
+    if (dev) { t4_index_destroy(dev); dev = nullptr; }   // nomatchGapLimit and the lookup layout depend on k
+    cache.clear(); cacheHead = 0; cacheEpoch = ~0ull;
+    structuralChange();
+    return T4_OK;
+  }
   int addRead(const char *read, const char *geneName, int *strandIO, int barcode, int minKmerCount, bool repetitiveData, double similarityThreshold);
   int output(const char *path) const;
 };
@@ -740,6 +757,10 @@ int t4_assembler_repeat_add_read(t4_assembler *a, const char *read) { return a ?
 int t4_assembler_update_all_consensus(t4_assembler *a) { if (!a) return T4_ERR_ARG; a->updateAllConsensus(); return T4_OK; }
 int t4_assembler_output(t4_assembler *a, const char *path) { return a ? a->output(path) : T4_ERR_ARG; }
 int t4_assembler_size(const t4_assembler *a) { return a ? (int)a->seqs.size() : 0; }
+int t4_assembler_change_kmer_length(t4_assembler *a, int kmer_length) {
+  if (!a || kmer_length < 2 || kmer_length > 31) return T4_ERR_ARG;
+  return a->changeKmerLength(kmer_length);
+}
 int64_t t4_assembler_index_postings(const t4_assembler *a) { return a ? (int64_t)a->index.total : 0; }
 
 }  // extern "C"

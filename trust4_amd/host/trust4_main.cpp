@@ -1,0 +1,677 @@
+// trust4_amd/host/trust4_main.cpp -- `trust4-hip`: stage-1 driver with the command line and the on-disk
+// inputs/outputs of the reference's `trust4` (main.cpp), running the hot path on the MI355X through the C ABI
+// of include/trust4_hip.h:
+//   * rough annotation of every distinct read            -> t4_annotate_rough        (main.cpp:1084-1120)
+//   * greedy assembly (AddRead / RepeatAddRead / ...)    -> t4_assembler_*           (main.cpp:1583-1940)
+// Everything else here is the reference's host-side read handling restated: FASTA/FASTQ input, mate
+// read-through / merge (ProcessRead, main.cpp:224-449, AlignAlgo::IsMateOverlap), canonical 21-mer counting and
+// quality trimming (KmerCount.hpp:64-97, 177-288), the read order (main.cpp:103-125), V/C trimming
+// (main.cpp:1262-1464), the per-read AddRead parameters and good-candidate propagation (main.cpp:1583-1880),
+// the rescue pass and the three output files. Written from the behaviour of those functions, not copied.
+//
+// Limits of this round: no --barcode/--UMI/-c/--debug-ns; `_final.out` is written as a copy of `_raw.out`
+// (the reference does the same under --skipMateExtension; its mate-graph extension tail is out of scope).
+#include <getopt.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/trust4_hip.h"
+
+namespace {
+
+const char *USAGE =
+    "./trust4-hip [OPTIONS]:\n"
+    "Required:\n"
+    "\t-f STRING: fasta file containing the receptor genome sequence\n"
+    "\t-u STRING: path to single-end read file\n"
+    "\t\tor\n"
+    "\t-1 STRING -2 STRING: path to paried-end read files\n"
+    "Optional:\n"
+    "\t-o STRING: prefix of the output file (default: trust)\n"
+    "\t-t INT: accepted for compatibility (the GPU engine does not use host threads)\n"
+    "\t-k INT: the starting k-mer size for indexing contigs (default: 9)\n"
+    "\t--minHitLen INT: the minimal hit length for a valid overlap (default: auto)\n"
+    "\t--skipMateExtension: accepted; _final.out is always the raw assembly in this build\n"
+    "\t--trimLevel INT: 0: no trim; 1: trim low quality; 2: trim unmatched (default: 1)\n"
+    "\t--cgeneEnd INT: skipping reads mapped to C gene coordinate greater than INT (default: 200)\n";
+
+void PrintLog(const char *fmt, ...) {
+  char buf[2048], stime[256];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  time_t t = time(NULL);
+  strftime(stime, sizeof stime, "%c", localtime(&t));
+  fprintf(stderr, "[%s] %s\n", stime, buf);
+}
+
+inline int nucNum(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
+const char NUM2NUC[4] = {'A', 'C', 'G', 'T'};
+
+void revCompInPlace(std::string &s) {
+  std::reverse(s.begin(), s.end());
+  for (char &c : s) if (c != 'N') { int n = nucNum(c); c = n >= 0 ? NUM2NUC[3 - n] : 'N'; }
+}
+
+// ---- FASTA / FASTQ (optionally gzip) reader with kseq's record model ---------------------------------
+struct SeqReader {
+  std::vector<std::string> files;
+  size_t cur = 0;
+  gzFile fp = nullptr;
+  std::string pending;   // look-ahead line
+  bool havePending = false;
+  std::string id, seq, qual;
+  bool hasQual = false;
+  bool getLine(std::string &out) {
+    if (havePending) { out.swap(pending); havePending = false; return true; }
+    out.clear();
+    char buf[1 << 16];
+    bool any = false;
+    while (gzgets(fp, buf, sizeof buf)) {
+      any = true;
+      size_t l = strlen(buf);
+      bool eol = l > 0 && buf[l - 1] == '\n';
+      while (l > 0 && (buf[l - 1] == '\n' || buf[l - 1] == '\r')) buf[--l] = 0;
+      out.append(buf, l);
+      if (eol) break;
+    }
+    return any;
+  }
+  bool next() {
+    for (;;) {
+      if (!fp) {
+        if (cur >= files.size()) return false;
+        fp = gzopen(files[cur].c_str(), "rb");
+        if (!fp) { fprintf(stderr, "Could not open %s\n", files[cur].c_str()); exit(EXIT_FAILURE); }
+      }
+      std::string line;
+      bool got = false;
+      while (getLine(line)) if (!line.empty() && (line[0] == '>' || line[0] == '@')) { got = true; break; }
+      if (!got) { gzclose(fp); fp = nullptr; ++cur; havePending = false; continue; }
+      size_t e = 1;
+      while (e < line.size() && line[e] != ' ' && line[e] != '\t') ++e;
+      id.assign(line, 1, e - 1);
+      size_t n = id.size();   // ReadFiles.hpp:180-185
+      if (n >= 2 && (id[n - 1] == '1' || id[n - 1] == '2') && id[n - 2] == '/') id.resize(n - 2);
+      seq.clear(); qual.clear(); hasQual = false;
+      bool plus = false;
+      while (getLine(line)) {
+        if (!line.empty() && (line[0] == '>' || line[0] == '@')) { pending.swap(line); havePending = true; break; }
+        if (!line.empty() && line[0] == '+') { plus = true; break; }
+        for (char c : line) if (c > ' ' && c < 127) seq.push_back(c);
+      }
+      if (plus) {
+        hasQual = true;
+        while (qual.size() < seq.size() && getLine(line)) qual += line;
+      }
+      return true;
+    }
+  }
+};
+
+// ---- AlignAlgo::IsMateOverlap (AlignAlgo.hpp:1027-1096) ---------------------------------------------
+int isMateOverlap(const std::string &fr, const std::string &sr, int minOverlap, int &offset, int &bestMatchCnt, bool checkTandem) {
+  const int flen = (int)fr.size(), slen = (int)sr.size();
+  int offsetCnt = 0, overlapSize = -1;
+  bestMatchCnt = -1;
+  for (int j = 0; j < flen - minOverlap; ++j) {
+    int matchCnt = 0, k;
+    bool ok = true;
+    double thr = 0.95;
+    if (flen - j >= 100) thr = 0.85;
+    else if (flen - j >= 50) thr = 0.85 + (flen - j - 50) / 50.0 * 0.1;
+    const int need = int((flen - j) * thr);
+    for (k = 0; j + k < flen && k < slen; ++k) {
+      if (fr[j + k] == sr[k]) ++matchCnt;
+      if (matchCnt + (flen - (j + k) - 1) < need) { ok = false; break; }
+    }
+    if (ok) { offset = j; ++offsetCnt; overlapSize = k; bestMatchCnt = matchCnt; }
+  }
+  if (offsetCnt != 1) return -1;
+  if (checkTandem && overlapSize <= minOverlap * 2) {
+    for (int i = 1; i <= overlapSize / 2; ++i) {
+      bool tandem = true;
+      for (int j = i; j + i - 1 < overlapSize; j += i) {
+        int k;
+        for (k = j; k <= j + i - 1; ++k) if (sr[k - j] != sr[k]) break;
+        if (k <= j + i - 1) { tandem = false; break; }
+      }
+      if (tandem) return -1;
+    }
+  }
+  return overlapSize;
+}
+
+// ---- canonical 21-mer counts (KmerCount.hpp) ---------------------------------------------------------
+struct KmerCounter {
+  int k;
+  std::unordered_map<uint64_t, int> cnt;
+  int maxReadLen = -1;
+  std::vector<int> c;
+  explicit KmerCounter(int kl) : k(kl) {}
+  template <class F> void eachValid(const std::string &r, F f) const {
+    const int len = (int)r.size();
+    const uint64_t mask = k < 32 ? ((1ull << (2 * k)) - 1ull) : ~0ull;
+    uint64_t code = 0;
+    int invalidPos = -1;
+    for (int i = 0; i < len; ++i) {
+      if (invalidPos != -1) ++invalidPos;
+      code = ((code << 2) & mask) | (uint64_t)(nucNum(r[i]) & 3);
+      if (r[i] == 'N') invalidPos = 0;
+      if (invalidPos >= k) invalidPos = -1;
+      if (i < k - 1 || invalidPos != -1) continue;
+      uint64_t rc = 0;
+      for (int t = 0; t < k; ++t) rc = (rc << 2) | (3ull - ((code >> (2 * t)) & 3ull));
+      f(rc < code ? rc : code);
+    }
+  }
+  void addCount(const std::string &r) {
+    if ((int)r.size() < k) return;
+    eachValid(r, [&](uint64_t kc) { ++cnt[kc]; });
+    if ((int)r.size() > maxReadLen) maxReadLen = (int)r.size();
+  }
+  // GetCountStatsAndTrim (KmerCount.hpp:177-288); read/qual are trimmed in place. qual == nullptr: no trimming.
+  void statsAndTrim(std::string &read, std::string *qual, int &minCount, int &medianCount, float &avgCount) {
+    if (maxReadLen == -1) return;
+    if ((int)c.size() < maxReadLen + 1) c.assign(maxReadLen + 1, 0);
+    const int len = (int)read.size();
+    if (len < k) { minCount = medianCount = -1; avgCount = -1; return; }
+    int n = 0, sum = 0;
+    eachValid(read, [&](uint64_t kc) {
+      auto it = cnt.find(kc);
+      int v = it == cnt.end() ? 0 : it->second;
+      if (v <= 0) v = 1;
+      c[n++] = v; sum += v;
+    });
+    if (n == 0) { minCount = medianCount = -len; avgCount = (float)-len; if (qual) read.clear(); return; }
+    const std::string orig = read;   // the reference truncates with a NUL but keeps scanning the old buffer below
+    int nul0 = -1, nul1 = -1;
+    if (qual) {
+      int i;
+      for (i = n - 1; i >= 0; --i) if (c[i] > 1) break;
+      ++i;
+      int badCnt = 0, trimStart = -1;
+      for (int j = len - 1; j >= i + k - 1; --j)
+        if ((*qual)[j] - 32 <= 15) { ++badCnt; if (badCnt >= 0.1 * (len - j)) trimStart = j; }
+      if (trimStart > 0) { n = trimStart - k + 1; read.resize(trimStart); qual->resize(trimStart); nul0 = trimStart; }
+      if (trimStart > 0 && trimStart < k) { n = 0; read.clear(); qual->clear(); nul1 = 0; }
+    }
+    if (n > 0) std::sort(c.begin(), c.begin() + n);
+    minCount = c[0]; medianCount = c[n > 0 ? n / 2 : 0]; avgCount = (float)(sum / (double)n);
+    for (int i = 0; i < len; ++i)
+      if (i != nul0 && i != nul1 && orig[i] == 'N') { if (minCount >= 0) minCount = 0; else if (minCount <= 0) --minCount; }
+  }
+};
+
+struct SortRead {
+  std::string id, read, qual;
+  bool hasQual = false, dead = false;
+  int minCnt = 0, medianCnt = 0;
+  float avgCnt = 0;
+  int len = 0, strand = 0, mateIdx = -1, info = -1;
+  t4_overlap g[4];
+  bool operator<(const SortRead &b) const {   // main.cpp:103-125
+    if (minCnt != b.minCnt) return minCnt > b.minCnt;
+    if (medianCnt != b.medianCnt) return medianCnt > b.medianCnt;
+    if (avgCnt != b.avgCnt) return avgCnt > b.avgCnt;
+    if (len != b.len) return len > b.len;
+    int t = strcmp(read.c_str(), b.read.c_str());
+    if (t != 0) return t < 0;
+    return strcmp(id.c_str(), b.id.c_str()) < 0;
+  }
+};
+
+bool isLowComplexity(const std::string &s) {   // main.cpp:183-205
+  int cnt[5] = {0, 0, 0, 0, 0};
+  const int n = (int)s.size();
+  for (char ch : s) { if (ch == 'N') ++cnt[4]; else ++cnt[nucNum(ch) < 0 ? 0 : nucNum(ch)]; }
+  if (cnt[0] >= n / 2 || cnt[1] >= n / 2 || cnt[2] >= n / 2 || cnt[3] >= n / 2 || cnt[4] >= n / 10) return true;
+  int low = 0;
+  for (int i = 0; i < 4; ++i) if (cnt[i] <= 2) ++low;
+  return low >= 2;
+}
+
+// ProcessRead (main.cpp:224-449): read-through clipping, mate merging, low-complexity filter, 21-mer counting
+void processRead(SortRead r1, SortRead r2, bool hasMate2, KmerCounter &kc, std::vector<SortRead> &out) {
+  int rWeight = 1;
+  bool r2Alive = hasMate2;
+  if (hasMate2) {
+    const int flen = (int)r2.read.size(), slen = (int)r1.read.size();
+    revCompInPlace(r2.read);
+    if (r2.hasQual) std::reverse(r2.qual.begin(), r2.qual.end());
+    int minOverlap = (flen + slen) / 10, minOverlap2 = (flen + slen) / 20;
+    if (minOverlap > 31) minOverlap = 31;
+    if (minOverlap2 > 31) minOverlap2 = 31;
+    int offset = -1, best = -1;
+    int ov = isMateOverlap(r2.read, r1.read, minOverlap, offset, best, false);
+    if (ov >= 0) {   // read-through: keep the overlapped part of read 1
+      r1.read.resize(ov);
+      if (r1.hasQual) {
+        r1.qual.resize(ov);
+        for (int j = 0; j < ov; ++j)
+          if (r2.qual[j + offset] > r1.qual[j] || r1.read[j] == 'N') { r1.read[j] = r2.read[j + offset]; r1.qual[j] = r2.qual[j + offset]; }
+      }
+      r2Alive = false;
+    } else if ((ov = isMateOverlap(r1.read, r2.read, minOverlap2, offset, best, true)) >= 0) {
+      if (best >= 0.95 * ov) {   // merge the mates
+        std::string r(slen + flen + 1, '\0'), q(slen + flen + 1, '\0');
+        for (int j = 0; j < flen; ++j) { r[offset + j] = r2.read[j]; q[offset + j] = r2.hasQual ? r2.qual[j] : 0; }
+        const int len = offset + flen;
+        for (int j = 0; j < slen && j < len; ++j)
+          if (j < offset || (r1.hasQual ? r1.qual[j] : 0) >= q[j] - 14 || r[j] == 'N') { r[j] = r1.read[j]; q[j] = r1.hasQual ? r1.qual[j] : 0; }
+        r.resize(len); q.resize(len);
+        r1.read = r; r1.qual = q;
+        r2Alive = false;
+        ++rWeight;
+      } else {
+        bool useFirst = true;
+        if (r1.hasQual) {
+          double a = 0, b = 0;
+          for (int j = offset; j < slen; ++j) a += r1.qual[j] - 32;
+          for (int j = flen - 1; j >= flen - ov; --j) b += r2.qual[j] - 32;
+          a /= ov; b /= ov;
+          if (a + 10 < b) useFirst = false;
+        }
+        if (!useFirst) { r1.read = r2.read; revCompInPlace(r1.read); r1.qual = r2.qual; r1.hasQual = r2.hasQual; }
+        r2Alive = false;
+      }
+    } else {
+      revCompInPlace(r2.read);
+      if (r2.hasQual) std::reverse(r2.qual.begin(), r2.qual.end());
+    }
+  }
+  if (!isLowComplexity(r1.read)) {
+    out.push_back(r1);
+    kc.addCount(r1.read);
+    if (rWeight == 2) { SortRead w = r1; w.id += ".1"; out.push_back(w); kc.addCount(w.read); }
+  }
+  if (r2Alive && !isLowComplexity(r2.read)) { out.push_back(r2); kc.addCount(r2.read); }
+}
+
+// SeqSet::DnaToAa / HasMotif (SeqSet.hpp:638-749, 5029-5074); note that the reference translates `read`, not its
+// reverse complement, whatever the strand
+char dnaToAa(char a, char b, char c) {
+  if (a == 'N' || b == 'N' || c == 'N' || a == 'M' || b == 'M' || c == 'M') return '?';
+  const bool cAG = (c == 'A' || c == 'G');
+  if (a == 'A') {
+    if (b == 'A') return cAG ? 'K' : 'N';
+    if (b == 'C') return 'T';
+    if (b == 'G') return cAG ? 'R' : 'S';
+    return c == 'G' ? 'M' : 'I';
+  } else if (a == 'C') {
+    if (b == 'A') return cAG ? 'Q' : 'H';
+    if (b == 'C') return 'P';
+    if (b == 'G') return 'R';
+    return 'L';
+  } else if (a == 'G') {
+    if (b == 'A') return cAG ? 'E' : 'D';
+    if (b == 'C') return 'A';
+    if (b == 'G') return 'G';
+    return 'V';
+  }
+  if (b == 'A') return cAG ? '_' : 'Y';
+  if (b == 'C') return 'S';
+  if (b == 'G') return c == 'A' ? '_' : c == 'G' ? 'W' : 'C';
+  return cAG ? 'L' : 'F';
+}
+int hasMotif(const std::string &read, int strand) {
+  if (strand == 0) return 0;
+  const int len = (int)read.size();
+  std::string aa(len + 1, '\0');
+  int ret = 0;
+  for (int k = 0; k <= 2; ++k) {
+    int j = 0;
+    for (int i = k; i + 2 < len; i += 3, ++j) aa[j] = dnaToAa(read[i], read[i + 1], read[i + 2]);
+    for (int i = 0; i + 2 < j; ++i) if (aa[i] == 'Y' && aa[i + 1] == 'Y' && aa[i + 2] == 'C') { ret |= 2; break; }
+    for (int i = 0; i + 3 < j; ++i) if ((aa[i] == 'F' || aa[i] == 'W') && aa[i + 1] == 'G' && aa[i + 3] == 'G') { ret |= 1; break; }
+  }
+  return ret;
+}
+
+void die(t4_ctx *ctx, const char *what, int rc) {
+  fprintf(stderr, "%s failed (%d): %s\n", what, rc, ctx ? t4_last_error(ctx) : "");
+  exit(EXIT_FAILURE);
+}
+
+}  // namespace
+
+int main(int argc, char *argv[]) {
+  if (argc <= 1) { fprintf(stderr, "%s", USAGE); return 0; }
+  static struct option long_options[] = {{"trimLevel", required_argument, 0, 10001}, {"skipMateExtension", no_argument, 0, 10005},
+                                         {"minHitLen", required_argument, 0, 10006}, {"cgeneEnd", required_argument, 0, 10008},
+                                         {"barcode", required_argument, 0, 10002}, {"UMI", required_argument, 0, 10004},
+                                         {"keepNoBarcode", no_argument, 0, 10003}, {"contigMinCov", required_argument, 0, 10007},
+                                         {(char *)0, 0, 0, 0}};
+  int indexKmerLength = 9, changeKmerLengthThreshold = 4096, trimLevel = 1, minHitLen = -1, constantGeneEnd = 200;
+  std::string refFa, outputPrefix = "trust";
+  SeqReader reads, mateReads;
+  bool hasMate = false;
+  int c, oi = 0;
+  while ((c = getopt_long(argc, argv, "f:u:1:2:o:t:k:", long_options, &oi)) != -1) {
+    if (c == 'f') refFa = optarg;
+    else if (c == 'u') reads.files.push_back(optarg);
+    else if (c == '1') { reads.files.push_back(optarg); hasMate = true; }
+    else if (c == '2') { mateReads.files.push_back(optarg); hasMate = true; }
+    else if (c == 'o') outputPrefix = optarg;
+    else if (c == 't') { /* no host threads */ }
+    else if (c == 'k') indexKmerLength = atoi(optarg);
+    else if (c == 10001) trimLevel = atoi(optarg);
+    else if (c == 10005) { /* always */ }
+    else if (c == 10006) minHitLen = atoi(optarg);
+    else if (c == 10008) constantGeneEnd = atoi(optarg);
+    else if (c == 10002 || c == 10003 || c == 10004 || c == 10007) { fprintf(stderr, "trust4-hip: barcode / UMI / contigMinCov modes are not built yet.\n"); return EXIT_FAILURE; }
+    else { fprintf(stderr, "%s", USAGE); return EXIT_FAILURE; }
+  }
+  if (refFa.empty()) { fprintf(stderr, "Need to use -f to specify the receptor genome sequence.\n"); return EXIT_FAILURE; }
+
+  t4_ctx *ctx = nullptr;
+  int rc = t4_init(getenv("T4_DEVICE") ? atoi(getenv("T4_DEVICE")) : 0, &ctx);
+  if (rc) { fprintf(stderr, "trust4-hip needs an MI355X (t4_init failed: %d); there is no CPU path.\n", rc); return EXIT_FAILURE; }
+  t4_index *refSet = nullptr;
+  if ((rc = t4_index_create(ctx, trimLevel > 1 ? 7 : 9, 0, &refSet))) die(ctx, "t4_index_create", rc);
+  if ((rc = t4_index_set_params(refSet, 17, trimLevel > 1 ? 0 : 10, 0.9))) die(ctx, "t4_index_set_params", rc);
+  if ((rc = t4_index_load_ref_fasta(refSet, refFa.c_str()))) die(ctx, "t4_index_load_ref_fasta", rc);
+  if (t4_index_size(refSet) == 0) { fprintf(stderr, "Need to use -f to specify the receptor genome sequence.\n"); return EXIT_FAILURE; }
+  if ((rc = t4_index_commit(refSet))) die(ctx, "t4_index_commit", rc);
+  PrintLog("Start to assemble reads.");
+
+  // ---- read input, mate processing, 21-mer counting (main.cpp:787-915)
+  KmerCounter kmerCount(21);
+  std::vector<SortRead> sortedReads;
+  int firstReadLen = -1, nIn = 0;
+  while (reads.next()) {
+    SortRead nr, mate;
+    nr.id = reads.id; nr.read = reads.seq; nr.qual = reads.qual; nr.hasQual = reads.hasQual;
+    ++nIn;
+    if (nIn % 100000 == 0) PrintLog("Read in and count kmers for %d reads.", nIn);
+    if (firstReadLen == -1) firstReadLen = (int)reads.seq.size();
+    bool haveMate = false;
+    if (mateReads.next()) {
+      haveMate = true;
+      mate.id = mateReads.id; mate.read = mateReads.seq; mate.qual = mateReads.qual; mate.hasQual = mateReads.hasQual;
+      ++nIn;
+      if (nIn % 100000 == 0) PrintLog("Read in and count kmers for %d reads.", nIn);
+    } else if (hasMate) { fprintf(stderr, "The two mate-pair read files have different number of reads.\n"); exit(1); }
+    processRead(nr, mate, haveMate, kmerCount, sortedReads);
+  }
+  int readCnt = (int)sortedReads.size();
+  auto writeEmpty = [&](const char *suffix) { FILE *fp = fopen((outputPrefix + suffix).c_str(), "w"); if (fp) fclose(fp); };
+  if (readCnt <= 0) { writeEmpty("_raw.out"); writeEmpty("_assembled_reads.fa"); writeEmpty("_final.out"); return 0; }
+
+  // ---- count statistics + quality trimming (main.cpp:980-1061)
+  for (SortRead &r : sortedReads) {
+    kmerCount.statsAndTrim(r.read, (trimLevel == 0 || !r.hasQual) ? nullptr : &r.qual, r.minCnt, r.medianCnt, r.avgCnt);
+    r.qual.clear(); r.hasQual = false;
+    if (r.read.empty()) r.dead = true;
+  }
+  {
+    std::vector<SortRead> kept;
+    for (SortRead &r : sortedReads) if (!r.dead) { r.len = (int)r.read.size(); kept.push_back(std::move(r)); }
+    sortedReads.swap(kept);
+    readCnt = (int)sortedReads.size();
+  }
+  PrintLog("Found %i reads.", readCnt);
+  kmerCount.cnt.clear();
+  for (int i = 0; i < readCnt; ++i) { sortedReads[i].info = i; sortedReads[i].mateIdx = -1; }
+  for (int i = 0; i < readCnt - 1; ++i)
+    if (sortedReads[i].id == sortedReads[i + 1].id) { sortedReads[i].mateIdx = i + 1; sortedReads[i + 1].mateIdx = i; ++i; }
+  std::sort(sortedReads.begin(), sortedReads.end());
+  PrintLog("Finish sorting the reads.");
+
+  // ---- rough annotation on the GPU (main.cpp:1084-1120)
+  {
+    std::string bases; std::vector<int64_t> off(1, 0); std::vector<int> firstOf;
+    for (int i = 0; i < readCnt; ++i)
+      if (i == 0 || sortedReads[i].read != sortedReads[i - 1].read) { bases += sortedReads[i].read; off.push_back((int64_t)bases.size()); firstOf.push_back(i); }
+    const int n = (int)firstOf.size();
+    t4_batch *batch = nullptr;
+    if ((rc = t4_reads_upload(ctx, bases.data(), off.data(), nullptr, n, &batch))) die(ctx, "t4_reads_upload", rc);
+    std::vector<t4_overlap> out(4 * (size_t)n);
+    if ((rc = t4_annotate_rough(refSet, batch, out.data()))) die(ctx, "t4_annotate_rough", rc);
+    t4_batch_destroy(batch);
+    for (int k = -1, i = 0; i < readCnt; ++i) {
+      if (k + 1 < n && firstOf[k + 1] == i) ++k;
+      for (int j = 0; j < 4; ++j) sortedReads[i].g[j] = out[4 * (size_t)k + j];
+    }
+  }
+  PrintLog("Finish rough annotations.");
+
+  // ---- mate links in sorted order, V / C trimming (main.cpp:1208-1526)
+  std::vector<int> originToSorted(readCnt);
+  std::vector<char> goodCandidate(readCnt, 0);
+  for (int i = 0; i < readCnt; ++i) originToSorted[sortedReads[i].info] = i;
+  for (int i = 0; i < readCnt; ++i) if (sortedReads[i].mateIdx != -1) sortedReads[i].mateIdx = originToSorted[sortedReads[i].mateIdx];
+  auto refName = [&](int idx) { return t4_index_seq_name(refSet, idx); };
+  auto eraseFront = [](std::string &s, int n) { s.erase(0, n); };
+  for (int i = 0; i < readCnt; ++i) {   // bases before the V gene
+    SortRead &sr = sortedReads[i];
+    t4_overlap *g = sr.g;
+    if (sr.dead || g[0].seqIdx == -1) continue;
+    bool mayTrim = false;
+    if (g[0].seqStart < 31 && g[0].similarity > 0.9) mayTrim = true;
+    if (g[0].similarity > 0.95 && g[0].seqStart <= t4_index_seq_len(refSet, g[0].seqIdx) / 3) mayTrim = true;
+    if (trimLevel > 1) mayTrim = true;
+    if (!mayTrim) continue;
+    int trimBase = g[0].readStart;
+    if (trimLevel > 1 && refName(g[0].seqIdx)[0] == 'T' && g[0].similarity < 0.97) trimBase = (g[0].readStart + g[0].readEnd) / 2;
+    if (trimBase <= 0) continue;
+    if (g[2].seqIdx != -1 && g[2].readStart < trimBase && trimLevel <= 1) continue;
+    if (g[3].seqIdx != -1 && g[3].readStart < trimBase && trimLevel <= 1) continue;
+    if (sr.len - trimBase < 31) { sr.dead = true; continue; }
+    if (g[0].strand >= 0) eraseFront(sr.read, trimBase); else sr.read.resize(sr.len - trimBase);
+    for (int j = 0; j < 4; ++j) {
+      if (g[j].seqIdx == -1) continue;
+      g[j].readStart -= trimBase; g[j].readEnd -= trimBase;
+      if (g[j].readStart < 0) g[j].readStart = 0;
+      if (g[j].readEnd < 0) { g[j].readEnd = 0; g[j].seqIdx = -1; }
+    }
+    sr.len -= trimBase;
+  }
+  for (int i = 0; i < readCnt; ++i) {   // bases after the C gene
+    SortRead &sr = sortedReads[i];
+    t4_overlap *g = sr.g;
+    const int len = sr.len;
+    if (sr.dead) continue;
+    int gidx;
+    for (gidx = 2; gidx <= 3; ++gidx) if (g[gidx].seqIdx != -1) break;
+    if (gidx > 3) continue;
+    if (gidx == 2 && refName(g[gidx].seqIdx)[2] == 'H') { gidx = 3; if (g[gidx].seqIdx == -1) continue; }
+    bool mayTrim = false;
+    if (gidx == 3 && g[3].seqStart < 9 && g[3].similarity > 0.95) mayTrim = true;
+    if (trimLevel > 1) mayTrim = true;
+    if (!mayTrim) continue;
+    int trimBase = len - g[gidx].readEnd - 1;
+    if (trimLevel > 1 && refName(g[gidx].seqIdx)[0] == 'T' && g[gidx].similarity < 0.97) trimBase = len - ((g[gidx].readStart + g[gidx].readEnd) / 2) - 1;
+    if (trimBase <= 0) continue;
+    if (gidx == 3 && g[2].seqIdx != -1 && g[2].readStart + trimBase >= sr.len && trimLevel <= 1) continue;
+    if (g[0].seqIdx != -1 && g[0].readStart + trimBase >= sr.len && trimLevel <= 1) continue;
+    if (sr.len - trimBase < 31) { sr.dead = true; continue; }
+    if (g[gidx].strand < 0) eraseFront(sr.read, trimBase); else sr.read.resize(len - trimBase);
+    g[3].seqIdx = -1;
+    for (int j = 0; j < 4; ++j) {
+      if (g[j].seqIdx == -1) continue;
+      if (g[j].readStart + trimBase >= len) { g[j].readStart = len - 1; g[j].seqIdx = -1; }
+      if (g[j].readEnd + trimBase >= len) g[j].readEnd = len - 1;
+    }
+    sr.len -= trimBase;
+  }
+  if (firstReadLen > 200) { fprintf(stderr, "trust4-hip: long-read mode (first read > 200 bp) is not built.\n"); return EXIT_FAILURE; }
+  {
+    std::vector<int> remap(readCnt, -1);
+    std::vector<SortRead> kept;
+    for (int i = 0; i < readCnt; ++i) if (!sortedReads[i].dead) { remap[i] = (int)kept.size(); kept.push_back(std::move(sortedReads[i])); }
+    for (SortRead &r : kept) if (r.mateIdx != -1) r.mateIdx = remap[r.mateIdx];
+    std::vector<char> gc(kept.size(), 0);
+    sortedReads.swap(kept); goodCandidate.swap(gc);
+    readCnt = (int)sortedReads.size();
+  }
+
+  // ---- the assembly loop (main.cpp:1528-1880)
+  t4_assembler *seqSet = nullptr;
+  if ((rc = t4_assembler_create(ctx, indexKmerLength, 0, &seqSet))) die(ctx, "t4_assembler_create", rc);
+  int hitLenRequired = 31;
+  if (firstReadLen / 2 < 31) { int l = firstReadLen / 2; if (l < 21) l = 21; hitLenRequired = l; }
+  if (minHitLen != -1) hitLenRequired = minHitLen;
+  t4_assembler_set_params(seqSet, hitLenRequired, 10, 0.9);
+  if (trimLevel > 1) changeKmerLengthThreshold /= 2;
+  std::vector<int> rescueReadIdx, assembledReadIdx;
+  int assembledReadCnt = 0, prevAddRet = -1;
+  const int WINDOW = getenv("T4_WINDOW") ? atoi(getenv("T4_WINDOW")) : 16;
+
+  // AddRead arguments of read i that do not depend on the loop state (main.cpp:1609-1701)
+  struct AddArgs { bool filter; char name[5]; int strand; double thr; };
+  auto addArgs = [&](int i) {
+    AddArgs a; a.filter = false; a.name[0] = 0; a.strand = 0;
+    const t4_overlap *g = sortedReads[i].g;
+    for (int j = 0; j < 4 && !a.filter; ++j) {
+      if (g[j].seqIdx == -1) continue;
+      for (int l = j + 1; l < 4; ++l) { if (g[l].seqIdx == -1) continue; if (g[j].readEnd - 10 > g[l].readStart) { a.filter = true; break; } }
+    }
+    if (g[3].seqIdx != -1 && g[0].seqIdx == -1 && g[2].seqIdx == -1) {
+      if (g[3].seqStart >= constantGeneEnd) a.filter = true;
+      else if (constantGeneEnd <= 200 && g[3].seqStart >= 100 && (g[3].strand == 1 || g[3].readEnd - g[3].readStart + 1 < sortedReads[i].len)) a.filter = true;
+    }
+    int ambiguous = 0;
+    for (int j = 0; j < 4; ++j)
+      if (g[j].seqIdx != -1) {
+        const char *s = refName(g[j].seqIdx);
+        a.name[0] = s[0]; a.name[1] = s[1]; a.name[2] = s[2]; a.name[3] = s[3]; a.name[4] = 0;
+        if (a.strand != 0 && a.strand != g[j].strand) ambiguous = 1;
+        a.strand = g[j].strand;
+      }
+    if (ambiguous) a.strand = 0;
+    a.thr = 0.9;
+    if (sortedReads[i].minCnt >= 20) a.thr = 0.97; else if (sortedReads[i].minCnt >= 2) a.thr = 0.95;
+    if (a.name[0] == 'T' && a.thr < 0.95) a.thr = 0.95;
+    if (trimLevel > 1) a.thr = 0.9;
+    return a;
+  };
+  auto isNewRead = [&](int i) { return i == 0 || sortedReads[i].read != sortedReads[i - 1].read; };
+
+  const t4_overlap *g = nullptr;   // the reference's `static geneOverlap[4]`: refreshed for new sequences only
+  for (int i = 0; i < readCnt; ++i) {
+    int addRet = -1;
+    if (isNewRead(i)) {
+      g = sortedReads[i].g;
+      AddArgs a = addArgs(i);
+      if (!a.filter) {
+        if (WINDOW > 1 && !t4_assembler_window_valid(seqSet)) {   // speculate on the next distinct, unfiltered reads
+          std::vector<const char *> rs; std::vector<int> st;
+          for (int j = i; j < readCnt && (int)rs.size() < WINDOW; ++j) {
+            if (!isNewRead(j)) continue;
+            AddArgs b = addArgs(j);
+            if (b.filter) continue;
+            rs.push_back(sortedReads[j].read.c_str()); st.push_back(b.strand);
+          }
+          if ((rc = t4_assembler_prefetch(seqSet, (int)rs.size(), rs.data(), st.data(), nullptr, trimLevel > 1))) die(ctx, "t4_assembler_prefetch", rc);
+        }
+        int strand = a.strand;
+        addRet = t4_assembler_add_read(seqSet, sortedReads[i].read.c_str(), a.name, &strand, -1, sortedReads[i].minCnt, trimLevel > 1, a.thr);
+        if (addRet < -50) die(ctx, "t4_assembler_add_read", addRet + 100);
+        if (addRet < 0) {
+          int matchCnt = 0;
+          for (int j = 0; j < 4; ++j) if (g[j].seqIdx != -1) matchCnt += g[j].matchCnt / 2;
+          bool filter = true;
+          if (matchCnt >= 31) filter = false;
+          else if (g[0].seqIdx != -1 && g[2].seqIdx != -1 && g[0].readEnd < g[2].readStart) filter = false;
+          else if (g[0].seqIdx != -1) { if (g[0].seqEnd >= t4_index_seq_len(refSet, g[0].seqIdx) - 17) filter = false; }
+          else if (g[2].seqIdx != -1) { if (g[2].seqStart <= 17) filter = false; }
+          int j;
+          for (j = 0; j < 4; ++j) if (g[j].seqIdx != -1) break;
+          if (!filter) addRet = t4_assembler_input_novel_read(seqSet, refName(g[j].seqIdx), sortedReads[i].read.c_str(), g[j].strand, -1);
+          else if (goodCandidate[i]) {
+            int ms = -sortedReads[sortedReads[i].info].strand;
+            if (hasMotif(sortedReads[i].read, ms)) addRet = t4_assembler_input_novel_read(seqSet, "Novel", sortedReads[i].read.c_str(), ms, -1);
+          }
+        }
+        sortedReads[i].strand = strand;
+      }
+    } else {
+      if (prevAddRet != -1 && prevAddRet != -3) addRet = t4_assembler_repeat_add_read(seqSet, sortedReads[i].read.c_str());
+      else if (prevAddRet == -3) addRet = -3;
+      sortedReads[i].strand = sortedReads[i - 1].strand;
+    }
+    if (addRet == -2) rescueReadIdx.push_back(i);
+    else if (addRet >= 0) {
+      ++assembledReadCnt;
+      assembledReadIdx.push_back(i);
+      if (sortedReads[i].mateIdx > i) {   // good-candidate propagation to the mate (main.cpp:1781-1843)
+        bool good = false, maySpan = false;
+        if (g[0].seqIdx != -1 && g[0].similarity >= 0.9 && sortedReads[i].strand == 1) {
+          good = true;
+          if (g[2].seqIdx != -1 && g[2].readStart > g[0].readEnd) maySpan = true;
+          if (g[3].seqIdx != -1 && g[3].readStart > g[0].readEnd) maySpan = true;
+        }
+        for (int j = 2; j <= 3; ++j)
+          if (g[j].seqIdx != -1 && g[j].similarity >= 0.9 && sortedReads[i].strand == -1) {
+            good = true;
+            if (g[0].seqIdx != -1 && g[j].readStart > g[0].readEnd) maySpan = true;
+          }
+        if (maySpan) good = false;
+        const int tag = sortedReads[i].mateIdx;
+        if (good && !goodCandidate[tag]) {
+          for (int j = tag - 1; j > 0; --j) { if (sortedReads[j].read == sortedReads[tag].read) { goodCandidate[j] = 1; sortedReads[j].info = i; } else break; }
+          for (int j = tag + 1; j < readCnt; ++j) { if (sortedReads[j].read == sortedReads[tag].read) { goodCandidate[j] = 1; sortedReads[j].info = i; } else break; }
+        }
+        if (good) { goodCandidate[tag] = 1; sortedReads[tag].info = i; }
+      }
+    }
+    if (assembledReadCnt > 0 && assembledReadCnt % 10000 == 0) t4_assembler_update_all_consensus(seqSet);
+    if ((i + 1) % 100000 == 0) PrintLog("Processed %d reads (%d are used for assembly).", i + 1, assembledReadCnt);
+    prevAddRet = addRet;
+    if (t4_assembler_size(seqSet) > changeKmerLengthThreshold && indexKmerLength < 16) {
+      changeKmerLengthThreshold *= 4;
+      indexKmerLength += 2;
+      t4_assembler_change_kmer_length(seqSet, indexKmerLength);
+    }
+  }
+  t4_assembler_update_all_consensus(seqSet);
+  PrintLog("Assembled %d reads.", assembledReadCnt);
+
+  // ---- rescue pass (main.cpp:1897-1940)
+  const int rescueReadCnt = (int)rescueReadIdx.size();
+  PrintLog("Try to rescue %d reads for assembly.", rescueReadCnt);
+  assembledReadCnt = 0;
+  for (int i = 0; i < rescueReadCnt; ++i) {
+    SortRead &sr = sortedReads[rescueReadIdx[i]];
+    double thr = 0.9;
+    if (sr.minCnt >= 20) thr = 0.97; else if (sr.minCnt >= 2) thr = 0.95;
+    int strand = 0;
+    int addRet = t4_assembler_add_read(seqSet, sr.read.c_str(), "", &strand, -1, 1, trimLevel > 1, thr);
+    if (addRet < -50) die(ctx, "t4_assembler_add_read", addRet + 100);
+    sr.strand = strand;
+    if (addRet >= 0) { ++assembledReadCnt; assembledReadIdx.push_back(rescueReadIdx[i]); }
+  }
+  t4_assembler_update_all_consensus(seqSet);
+  PrintLog("Rescued %d reads.", assembledReadCnt);
+
+  // ---- outputs (main.cpp:1959-2036)
+  if ((rc = t4_assembler_output(seqSet, (outputPrefix + "_raw.out").c_str()))) die(ctx, "t4_assembler_output", rc);
+  {
+    FILE *fp = fopen((outputPrefix + "_assembled_reads.fa").c_str(), "w");
+    for (int idx : assembledReadIdx) {
+      const SortRead &sr = sortedReads[idx];
+      fprintf(fp, ">%s %d %d %d\n%s\n", sr.id.c_str(), sr.strand, sr.minCnt, sr.medianCnt, sr.read.c_str());
+    }
+    fclose(fp);
+  }
+  if ((rc = t4_assembler_output(seqSet, (outputPrefix + "_final.out").c_str()))) die(ctx, "t4_assembler_output", rc);
+  int64_t q = 0, rf = 0, wh = 0;
+  t4_assembler_counters(seqSet, &q, &rf, &wh);
+  PrintLog("Finish assembly. (GPU query batches %lld, device image refreshes %lld, reads served from the speculation window %lld)", (long long)q, (long long)rf, (long long)wh);
+  t4_assembler_destroy(seqSet);
+  t4_index_destroy(refSet);
+  t4_destroy(ctx);
+  return 0;
+}
