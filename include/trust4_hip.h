@@ -131,6 +131,14 @@ int t4_assign(t4_index *ix, t4_batch *b, int strand, int32_t *ret, t4_overlap *o
 int t4_gap_dp(t4_ctx *ctx, int kind, int impl, int n, const int64_t *t_off, const int64_t *p_off,
               const void *t_data, const char *p_chars, int32_t *out4);
 
+/* The query half of SeqSet::AddRead for a (small) batch of reads in ONE launch and one host round trip:
+ * GetOverlapsFromRead(read, strands[i], barcode, 0, skip_repeats) (SeqSet.hpp:3437) and the ExtendOverlap
+ * (SeqSet.hpp:3597 / 3746, mismatch factor factors[i]) of every overlap it returns. Layout as t4_overlaps /
+ * t4_extend. Used by t4_assembler for its speculation windows. Contig sets only. */
+int t4_add_query(t4_index *ix, int n, const char *bases, const int64_t *offsets, const int32_t *barcodes,
+                 const int32_t *strands, int skip_repeats, const double *factors, int max_per_read, int32_t *counts,
+                 t4_overlap *ov, t4_overlap *ext, int32_t *ext_ret);
+
 /* ---- ordered contig builder (host-side commit logic + GPU queries) ----------------------------------
  * t4_assembler owns a mutable set of novel contigs (the reference's `SeqSet seqSet`, main.cpp:642) and exposes
  * the members stage 1 calls on it, with the same arguments and return values:
@@ -159,6 +167,8 @@ int t4_assembler_prefetch(t4_assembler *a, int n, const char *const *reads, cons
                           int repetitive_data);
 int t4_assembler_window_valid(const t4_assembler *a);
 int t4_assembler_counters(const t4_assembler *a, int64_t *queries, int64_t *refreshes, int64_t *window_hits);
+/* host seconds spent refreshing the device image / in GPU query batches (upload + kernels + download) */
+int t4_assembler_timers(const t4_assembler *a, double *sec_refresh, double *sec_query);
 int t4_assembler_update_all_consensus(t4_assembler *a);
 int t4_assembler_output(t4_assembler *a, const char *path);
 int t4_assembler_size(const t4_assembler *a);

@@ -63,6 +63,11 @@ struct t4_ctx {
   unsigned long long *hitCounter = nullptr;
   T4OverlapOut *result = nullptr;
   size_t resultCap = 0, resultBytes = 0;
+  // lean path of t4_add_query (small batches, one launch, one round trip)
+  int aqCap = 0, aqWpk = 0, aqWnm = 0, aqMax = 0;
+  unsigned char *aqIn = nullptr, *aqOut = nullptr;      // device blobs
+  unsigned char *aqInHost = nullptr, *aqOutHost = nullptr;   // pinned staging
+  size_t aqInBytes = 0, aqOutBytes = 0;
 };
 
 struct t4_index {
@@ -192,7 +197,9 @@ void t4_destroy(t4_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   void *ptrs[] = {c->dpRows, c->dpDir, c->gKeys, c->gPairs, c->gCand, c->gOv, c->gFin, c->gOrd, c->hitsKeys, c->lists,
-                  c->listCounts, c->status, c->counts, c->hitCounter, c->result};
+                  c->listCounts, c->status, c->counts, c->hitCounter, c->result, c->aqIn, c->aqOut};
+  if (c->aqInHost) (void)hipHostFree(c->aqInHost);
+  if (c->aqOutHost) (void)hipHostFree(c->aqOutHost);
   for (void *p : ptrs) if (p) (void)hipFree(p);
   for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -775,6 +782,111 @@ int t4_extend(t4_index *ix, t4_batch *b, int max_per_read, const int32_t *counts
   }
   (void)hipFree(dIn); (void)hipFree(dCnt); (void)hipFree(dRet);
   return r;
+}
+
+
+// The query half of SeqSet::AddRead for a small batch of reads, in one launch and one host round trip.
+int t4_add_query(t4_index *ix, int n, const char *bases, const int64_t *offsets, const int32_t *barcodes, const int32_t *strands,
+                 int skip_repeats, const double *factors, int max_per_read, int32_t *counts, t4_overlap *ov, t4_overlap *ext, int32_t *ext_ret) {
+  if (!ix || n < 0 || max_per_read <= 0 || max_per_read > 128 || (n > 0 && (!bases || !offsets || !strands || !factors || !counts || !ov || !ext || !ext_ret))) return T4_ERR_ARG;
+  t4_ctx *c = ix->ctx;
+  if (!ix->committed) return fail(c, T4_ERR_STATE, "index not committed");
+  if (ix->view.firstIsRef) return fail(c, T4_ERR_UNSUPPORTED, "t4_add_query needs a contig set");
+  if (n == 0) return T4_OK;
+  (void)hipSetDevice(c->device);
+  int maxLen = 1;
+  for (int i = 0; i < n; ++i) {
+    int64_t l = offsets[i + 1] - offsets[i];
+    if (l < 0 || l > T4_MAXL) return fail(c, T4_ERR_UNSUPPORTED, "read %d is %lld bp; this engine takes reads up to %d bp", i, (long long)l, T4_MAXL);
+    if (l > maxLen) maxLen = (int)l;
+  }
+  const int wpk = (maxLen + 15) / 16, wnm = (maxLen + 31) / 32;
+  // input blob: pk | nm | len | barcode | strand | list(iota) | factor ; output blob: counts | status | ov | ext | ret | tail{overflowCount, hits}
+  auto al8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
+  const size_t oPk = 0, oNm = al8(oPk + sizeof(unsigned) * (size_t)n * wpk), oLen = al8(oNm + sizeof(unsigned) * (size_t)n * wnm),
+               oBc = al8(oLen + sizeof(int) * (size_t)n), oSt = al8(oBc + sizeof(int) * (size_t)n), oLs = al8(oSt + sizeof(int) * (size_t)n),
+               oFa = al8(oLs + sizeof(int) * (size_t)n), inBytes = al8(oFa + sizeof(double) * (size_t)n);
+  const size_t m = (size_t)n * max_per_read;
+  const size_t pCnt = 0, pSta = al8(pCnt + sizeof(int) * (size_t)n), pNext = al8(pSta + sizeof(int) * (size_t)n), pOv = al8(pNext + sizeof(int) * (size_t)n),
+               pEx = al8(pOv + sizeof(t4_overlap) * m), pRet = al8(pEx + sizeof(t4_overlap) * m), pTail = al8(pRet + sizeof(int) * m), outBytes = pTail + 16;
+  int r;
+  if (inBytes > c->aqInBytes) {
+    if (c->aqIn) (void)hipFree(c->aqIn);
+    if (c->aqInHost) (void)hipHostFree(c->aqInHost);
+    c->aqIn = nullptr; c->aqInHost = nullptr;
+    HIPCHK(c, hipMalloc(&c->aqIn, inBytes * 2));
+    HIPCHK(c, hipHostMalloc(&c->aqInHost, inBytes * 2, hipHostMallocDefault));
+    c->aqInBytes = inBytes * 2;
+  }
+  if (outBytes > c->aqOutBytes) {
+    if (c->aqOut) (void)hipFree(c->aqOut);
+    if (c->aqOutHost) (void)hipHostFree(c->aqOutHost);
+    c->aqOut = nullptr; c->aqOutHost = nullptr;
+    HIPCHK(c, hipMalloc(&c->aqOut, outBytes * 2));
+    HIPCHK(c, hipHostMalloc(&c->aqOutHost, outBytes * 2, hipHostMallocDefault));
+    c->aqOutBytes = outBytes * 2;
+  }
+  unsigned char *h = c->aqInHost;
+  memset(h, 0, inBytes);
+  unsigned *pk = (unsigned *)(h + oPk), *nm = (unsigned *)(h + oNm);
+  int *len = (int *)(h + oLen), *bc = (int *)(h + oBc), *st = (int *)(h + oSt), *ls = (int *)(h + oLs);
+  double *fa = (double *)(h + oFa);
+  for (int i = 0; i < n; ++i) {
+    const char *s = bases + offsets[i];
+    int l = (int)(offsets[i + 1] - offsets[i]);
+    len[i] = l; bc[i] = barcodes ? barcodes[i] : -1; st[i] = strands[i]; ls[i] = i; fa[i] = factors[i];
+    unsigned *p = pk + (size_t)i * wpk, *q = nm + (size_t)i * wnm;
+    for (int j = 0; j < l; ++j) {
+      int v = nucNum(s[j]);
+      if (v < 0) {
+        if (s[j] != 'N') return fail(c, T4_ERR_UNSUPPORTED, "read %d has base '%c' (alphabet is ACGTN)", i, s[j]);
+        q[j >> 5] |= 1u << (j & 31); v = 0;
+      }
+      p[j >> 4] |= (unsigned)v << ((j & 15) * 2);
+    }
+  }
+  HIPCHK(c, hipMemcpyAsync(c->aqIn, h, inBytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->aqOut, 0, outBytes, c->stream));
+  T4BatchView bv;
+  bv.pk = (const unsigned *)(c->aqIn + oPk); bv.nm = (const unsigned *)(c->aqIn + oNm); bv.len = (const int *)(c->aqIn + oLen);
+  bv.barcode = (const int *)(c->aqIn + oBc); bv.wpk = wpk; bv.wnm = wnm; bv.n = n;
+  T4QueryArgs qa;
+  memset(&qa, 0, sizeof qa);
+  qa.mode = 4; qa.skipRepeats = skip_repeats; qa.maxPerRead = max_per_read;
+  qa.counts = (int *)(c->aqOut + pCnt); qa.out = (T4OverlapOut *)(c->aqOut + pOv); qa.outExt = (T4OverlapOut *)(c->aqOut + pEx);
+  qa.ret = (int *)(c->aqOut + pRet); qa.strandPerRead = (const int *)(c->aqIn + oSt); qa.factorPerRead = (const double *)(c->aqIn + oFa);
+  const int threads = TIER_THREADS[3];
+  if ((r = ensureScratch(c, (n > c->cus * 2 ? n : c->cus * 2) * threads))) return r;
+  T4Work wk;
+  memset(&wk, 0, sizeof wk);
+  wk.list = (const int *)(c->aqIn + oLs); wk.nList = n;
+  wk.nextList = (int *)(c->aqOut + pNext); wk.nextCount = (int *)(c->aqOut + pTail);
+  wk.status = (int *)(c->aqOut + pSta); wk.hitCounter = (unsigned long long *)(c->aqOut + pTail + 8);
+  wk.dpRows = c->dpRows; wk.dpDir = c->dpDir;
+  launchTier<8192, 512, 256>(n, c->stream, ix->view, bv, wk, qa);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->aqOutHost, c->aqOut, outBytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int overflow = *(int *)(c->aqOutHost + pTail);
+  if (overflow > 0) {   // reads beyond the LDS tier: global-scratch tier
+    if ((r = ensureGlobalTier(c, overflow))) return r;
+    T4Work w2 = wk;
+    w2.list = (const int *)(c->aqOut + pNext); w2.nList = overflow; w2.nextList = nullptr; w2.nextCount = nullptr;
+    w2.gKeys = c->gKeys; w2.gPairs = c->gPairs; w2.gCand = c->gCand; w2.gOv = c->gOv; w2.gFin = c->gFin; w2.gOrd = c->gOrd;
+    w2.gCap = G_CAP; w2.gMaxOv = G_MAXOV;
+    launchTier<0, 0, 256>(overflow, c->stream, ix->view, bv, w2, qa);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->aqOutHost, c->aqOut, outBytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  const unsigned char *o = c->aqOutHost;
+  const int *status = (const int *)(o + pSta);
+  for (int i = 0; i < n; ++i) if (status[i]) return fail(c, T4_ERR_UNSUPPORTED, "read %d exceeds the engine limits (status %d)", i, status[i]);
+  memcpy(counts, o + pCnt, sizeof(int) * (size_t)n);
+  memcpy(ov, o + pOv, sizeof(t4_overlap) * m);
+  memcpy(ext, o + pEx, sizeof(t4_overlap) * m);
+  memcpy(ext_ret, o + pRet, sizeof(int) * m);
+  return T4_OK;
 }
 
 }  // extern "C"

@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -194,6 +195,7 @@ struct t4_assembler {
   Ov prevAdd;
   std::string err;
   int64_t queries = 0, refreshes = 0, cacheHits = 0;
+  double secRefresh = 0, secQuery = 0;
   // speculation window: query results of upcoming reads, valid while `epoch` (bumped by every change a query can
   // observe: index, consensus, contig creation/release, a flip of a posWeight column's IsBaseEqual state) stands
   struct Cached { std::string read; int strand, barcode, skip; int32_t cnt; std::vector<t4_overlap> ov, ext; std::vector<int32_t> extRet; };
@@ -220,6 +222,8 @@ struct t4_assembler {
 
   int refreshDevice() {
     if (!dirty) return T4_OK;
+    auto t0_ = std::chrono::steady_clock::now();
+    struct Tm { double &acc; std::chrono::steady_clock::time_point t0; ~Tm() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tm_{secRefresh, t0_};
     int r;
     if (!dev) { if ((r = t4_index_create(ctx, k, index.considerBarcode ? 1 : 0, &dev))) return r; }
     if ((r = t4_index_clear(dev))) return r;
@@ -646,51 +650,30 @@ int t4_assembler::prefetch(int n, const char *const *reads, const int *strands, 
   int rc;
   if ((rc = refreshDevice())) return rc;
   cache.clear(); cacheHead = 0;
-  // t4_overlaps takes one strand argument per call: group the window by strand value (-1 / 0 / 1)
+  auto tq0_ = std::chrono::steady_clock::now();
+  struct Tq { double &acc; std::chrono::steady_clock::time_point t0; ~Tq() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tq_{secQuery, tq0_};
   cache.resize(n);
-  for (int i = 0; i < n; ++i) { cache[i].read = reads[i]; cache[i].strand = strands[i]; cache[i].barcode = barcodes ? barcodes[i] : -1; cache[i].skip = repetitive; cache[i].cnt = 0; }
-  for (int sv = -1; sv <= 1; ++sv) {
-    std::vector<int> ids;
-    for (int i = 0; i < n; ++i) if (strands[i] == sv) ids.push_back(i);
-    if (ids.empty()) continue;
-    std::string bases; std::vector<int64_t> offs(1, 0); std::vector<int32_t> bcs;
-    for (int i : ids) { bases += cache[i].read; offs.push_back((int64_t)bases.size()); bcs.push_back(cache[i].barcode); }
-    t4_batch *batch = nullptr;
-    if (bases.empty()) bases.push_back('A');
-    if ((rc = t4_reads_upload(ctx, bases.data(), offs.data(), bcs.data(), (int64_t)ids.size(), &batch))) return rc;
-    const size_t m = ids.size();
-    std::vector<t4_overlap> ov(m * MAXOV), ex(m * MAXOV);
-    std::vector<int32_t> cnts(m), rets(m * MAXOV);
-    rc = t4_overlaps(dev, batch, sv, repetitive, MAXOV, cnts.data(), ov.data());
-    ++queries;
-    for (size_t q = 0; rc == T4_OK && q < m; ++q) if (cnts[q] > MAXOV) rc = T4_ERR_UNSUPPORTED;
-    if (rc == T4_OK) {
-      // ExtendOverlap's mismatch factor depends on the read's barcode (SeqSet.hpp:3597-3598): one call per factor
-      for (int pass = 0; pass < 2 && rc == T4_OK; ++pass) {
-        std::vector<int32_t> c2(m, 0);
-        bool any = false;
-        for (size_t q = 0; q < m; ++q) {
-          bool f1 = (bcs[q] == -1 && !repetitive);
-          if ((pass == 0) == f1 && cnts[q] > 0) { c2[q] = cnts[q]; any = true; }
-        }
-        if (!any) continue;
-        std::vector<t4_overlap> ex2(m * MAXOV);
-        std::vector<int32_t> r2(m * MAXOV);
-        rc = t4_extend(dev, batch, MAXOV, c2.data(), ov.data(), pass == 0 ? 1.0 : 2.0, r2.data(), ex2.data());
-        for (size_t q = 0; rc == T4_OK && q < m; ++q)
-          for (int t = 0; t < c2[q]; ++t) { ex[q * MAXOV + t] = ex2[q * MAXOV + t]; rets[q * MAXOV + t] = r2[q * MAXOV + t]; }
-      }
-    }
-    t4_batch_destroy(batch);
-    if (rc) { cache.clear(); return rc; }
-    for (size_t q = 0; q < m; ++q) {
-      Cached &c = cache[ids[q]];
-      c.cnt = cnts[q];
-      int k2 = c.cnt > 0 ? c.cnt : 0;
-      c.ov.assign(ov.begin() + q * MAXOV, ov.begin() + q * MAXOV + k2);
-      c.ext.assign(ex.begin() + q * MAXOV, ex.begin() + q * MAXOV + k2);
-      c.extRet.assign(rets.begin() + q * MAXOV, rets.begin() + q * MAXOV + k2);
-    }
+  std::string bases; std::vector<int64_t> offs(1, 0); std::vector<int32_t> bcs(n), sts(n); std::vector<double> fac(n);
+  for (int i = 0; i < n; ++i) {
+    Cached &c = cache[i];
+    c.read = reads[i]; c.strand = strands[i]; c.barcode = barcodes ? barcodes[i] : -1; c.skip = repetitive; c.cnt = 0;
+    bases += c.read; offs.push_back((int64_t)bases.size()); bcs[i] = c.barcode; sts[i] = c.strand;
+    fac[i] = (c.barcode == -1 && !repetitive) ? 1.0 : 2.0;   // ExtendOverlap's mismatch factor (SeqSet.hpp:3597-3598)
+  }
+  if (bases.empty()) bases.push_back('A');
+  const size_t m = (size_t)n * MAXOV;
+  std::vector<t4_overlap> ov(m), ex(m);
+  std::vector<int32_t> cnts(n), rets(m);
+  rc = t4_add_query(dev, n, bases.data(), offs.data(), bcs.data(), sts.data(), repetitive, fac.data(), MAXOV, cnts.data(), ov.data(), ex.data(), rets.data());
+  ++queries;
+  if (rc) { cache.clear(); return rc; }
+  for (int q = 0; q < n; ++q) {
+    Cached &c = cache[q];
+    c.cnt = cnts[q];
+    int k2 = c.cnt > 0 ? c.cnt : 0;
+    c.ov.assign(ov.begin() + (size_t)q * MAXOV, ov.begin() + (size_t)q * MAXOV + k2);
+    c.ext.assign(ex.begin() + (size_t)q * MAXOV, ex.begin() + (size_t)q * MAXOV + k2);
+    c.extRet.assign(rets.begin() + (size_t)q * MAXOV, rets.begin() + (size_t)q * MAXOV + k2);
   }
   cacheEpoch = epoch;
   return T4_OK;
@@ -751,6 +734,12 @@ int t4_assembler_counters(const t4_assembler *a, int64_t *queries, int64_t *refr
   if (queries) *queries = a->queries;
   if (refreshes) *refreshes = a->refreshes;
   if (window_hits) *window_hits = a->cacheHits;
+  return T4_OK;
+}
+int t4_assembler_timers(const t4_assembler *a, double *sec_refresh, double *sec_query) {
+  if (!a) return T4_ERR_ARG;
+  if (sec_refresh) *sec_refresh = a->secRefresh;
+  if (sec_query) *sec_query = a->secQuery;
   return T4_OK;
 }
 int t4_assembler_repeat_add_read(t4_assembler *a, const char *read) { return a ? a->repeatAddRead(read) : T4_ERR_ARG - 100; }

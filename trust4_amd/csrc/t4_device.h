@@ -82,7 +82,7 @@ struct T4OverlapOut {        // == t4_overlap of include/trust4_hip.h
 struct T4HitOut { int idx, offset, readOffset, strand, repeats; };  // == t4_hit
 
 struct T4QueryArgs {
-  int mode;                  // 0: overlaps (GetOverlapsFromRead), 1: annotate level 0, 2: AssignRead, 3: ExtendOverlap of given overlaps
+  int mode;                  // 0: overlaps (GetOverlapsFromRead), 1: annotate level 0, 2: AssignRead, 3: ExtendOverlap of given overlaps, 4: AddRead query
   int strand;                // strand argument of GetOverlapsFromRead
   int skipRepeats;
   int maxPerRead;            // mode 0 output stride
@@ -93,4 +93,8 @@ struct T4QueryArgs {
   const int *inCounts;       // mode 3
   int *ret;                  // mode 2: AssignRead return value per read; mode 3: ExtendOverlap return value per overlap
   double mismatchFactor;     // mode 3 (mode 2 uses 1.0 / 2.0 by barcode as AssignRead does)
+  // mode 4: GetOverlapsFromRead + ExtendOverlap of every returned overlap, per-read strand argument and factor
+  const int *strandPerRead;
+  const double *factorPerRead;
+  T4OverlapOut *outExt;
 };

@@ -1685,7 +1685,34 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
   if (lane == 0) { ws->phaseT0 = clock64(); ws->curPhase = 0; }
 #endif
   __syncthreads();
-  if (qa.mode == 2 || qa.mode == 3) {
+  if (qa.mode == 4) {
+    // the query half of SeqSet::AddRead (SeqSet.hpp:3437 + every ExtendOverlap of 3597 / 3746): one launch, results
+    // consumed by the host-side ordered commit (t4_assembler)
+    ExtSide *sides = (ExtSide *)wm.pairs;
+    ExtOut *res = (ExtOut *)wm.ov;
+    unsigned char *dirbuf = (unsigned char *)wm.keys;
+    int barcode = bv.barcode ? bv.barcode[r] : -1;
+    loadSegment(bv, r, 0, len, wm);
+    int ret = overlapsFromSegment(ix, wm, ws, len, qa.strandPerRead[r], barcode, qa.skipRepeats != 0, 0, sc, hitTotal);
+    if (ret == -2) return false;
+    int n = ret > 0 ? ret : 0;
+    if (n > qa.maxPerRead) { if (lane == 0) wk.status[r] = 2; n = 0; ret = 0; }
+    __syncthreads();
+    for (int i = lane; i < n; i += NT) { storeOverlap(qa.out + r * qa.maxPerRead + i, wm.fin[i]); wm.ord[i] = (unsigned short)i; }
+    __syncthreads();
+    extendOverlaps(ix, wm, ws, n, len, false, qa.factorPerRead[r], sides, dirbuf, res);
+    for (int i = lane; i < n; i += NT) {
+      const OvRec &o = wm.fin[i];
+      T4OverlapOut t;
+      t.seqIdx = o.seqIdx; t.readStart = res[i].rs; t.readEnd = res[i].re; t.seqStart = res[i].ss; t.seqEnd = res[i].se;
+      t.strand = (o.flags & OV_PLUS) ? 1 : -1; t.matchCnt = res[i].matchCnt;
+      if (res[i].simFail) { t.indelCnt = o.indelCnt; t.similarity = ovSim(o); }
+      else { t.indelCnt = 0; t.similarity = (double)t.matchCnt / (double)res[i].den; }
+      qa.outExt[r * qa.maxPerRead + i] = t;
+      qa.ret[r * qa.maxPerRead + i] = res[i].ret;
+    }
+    if (lane == 0) qa.counts[r] = ret;
+  } else if (qa.mode == 2 || qa.mode == 3) {
     // scratch carved from the arrays that are dead after overlapsFromSegment: pairs (+cand) and the key area
     ExtSide *sides = (ExtSide *)wm.pairs;                 // 2 * maxFin * 12 B  <= cap * 4 B
     ExtOut *res = (ExtOut *)wm.ov;                         // maxFin * 32 B      <= maxOv * 40 B

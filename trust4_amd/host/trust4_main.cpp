@@ -669,7 +669,9 @@ int main(int argc, char *argv[]) {
   if ((rc = t4_assembler_output(seqSet, (outputPrefix + "_final.out").c_str()))) die(ctx, "t4_assembler_output", rc);
   int64_t q = 0, rf = 0, wh = 0;
   t4_assembler_counters(seqSet, &q, &rf, &wh);
-  PrintLog("Finish assembly. (GPU query batches %lld, device image refreshes %lld, reads served from the speculation window %lld)", (long long)q, (long long)rf, (long long)wh);
+  double sr = 0, sq = 0;
+  t4_assembler_timers(seqSet, &sr, &sq);
+  PrintLog("Finish assembly. (GPU query batches %lld in %.2f s, device image refreshes %lld in %.2f s, reads served from the speculation window %lld)", (long long)q, sq, (long long)rf, sr, (long long)wh);
   t4_assembler_destroy(seqSet);
   t4_index_destroy(refSet);
   t4_destroy(ctx);
