@@ -57,16 +57,20 @@ struct KeyHash {
 };
 
 // The mutable KmerIndex: a posting multiset per (code, bucket) with the reference's edit operations.
+struct InsertHook { virtual void onInsert(uint64_t code, int h) = 0; virtual ~InsertHook() {} };
 struct HostIndex {
   int k; bool considerBarcode = false;
+  InsertHook *hook = nullptr;
   std::unordered_map<Key, std::vector<Post>, KeyHash> map;
   size_t total = 0;
   explicit HostIndex(int kl) : k(kl) {}
   int bucket(uint64_t code, int barcode) const { return (int)((code + (uint64_t)(int64_t)(considerBarcode ? barcode + 1 : 0)) % 1000003ull); }
   void insert(const KCode &kc, int idx, int off, int barcode) {
     if (!kc.valid()) return;
-    map[Key{kc.code, bucket(kc.code, barcode)}].push_back(Post{idx, off});
+    const int h = bucket(kc.code, barcode);
+    map[Key{kc.code, h}].push_back(Post{idx, off});
     ++total;
+    if (hook) hook->onInsert(kc.code, h);
   }
   void remove(const KCode &kc, int idx, int off, int barcode) {  // first posting equal to (idx, off)
     if (!kc.valid()) return;
@@ -184,7 +188,7 @@ void reverseComplement(std::string &rc, const std::string &s) {
 
 }  // namespace
 
-struct t4_assembler {
+struct t4_assembler : InsertHook {
   t4_ctx *ctx;
   t4_index *dev = nullptr;   // device image of the current set
   bool dirty = true;
@@ -198,21 +202,38 @@ struct t4_assembler {
   double secRefresh = 0, secQuery = 0;
   // speculation window: query results of upcoming reads, valid while `epoch` (bumped by every change a query can
   // observe: index, consensus, contig creation/release, a flip of a posWeight column's IsBaseEqual state) stands
-  struct Cached { std::string read; int strand, barcode, skip; int32_t cnt; std::vector<t4_overlap> ov, ext; std::vector<int32_t> extRet; };
+  struct Cached { std::string read; int strand, barcode, skip; int32_t cnt; bool valid; std::vector<t4_overlap> ov, ext; std::vector<int32_t> extRet; };
   std::vector<Cached> cache;
   size_t cacheHead = 0;
-  uint64_t epoch = 0, cacheEpoch = ~0ull;
-  t4_assembler(t4_ctx *c, int kl) : ctx(c), k(kl), index(kl) { prevAdd.readStart = -1; }
-  void structuralChange() { dirty = true; ++epoch; }
+  // What a cached query result depends on ("speculation window"): the contigs the read has any k-mer hit with,
+  // and the absence of its k-mers among the postings inserted since the snapshot. Both are tracked exactly:
+  std::unordered_map<Key, std::vector<int>, KeyHash> winKmers;   // (code, bucket) of every window read k-mer -> window slots
+  std::unordered_map<int, std::vector<int>> winContigs;          // contig id -> window slots whose hit set contains it
+  int64_t invalidations = 0;
+  t4_assembler(t4_ctx *c, int kl) : ctx(c), k(kl), index(kl) { prevAdd.readStart = -1; index.hook = this; }
+  void dropWindow() { cache.clear(); cacheHead = 0; winKmers.clear(); winContigs.clear(); }
+  void invalidateSlot(int slot) { if (slot >= (int)cacheHead && slot < (int)cache.size() && cache[slot].valid) { cache[slot].valid = false; ++invalidations; } }
+  void onInsert(uint64_t code, int h) override {
+    if (winKmers.empty()) return;
+    auto it = winKmers.find(Key{code, h});
+    if (it != winKmers.end()) for (int slot : it->second) invalidateSlot(slot);
+  }
+  // contig c changed in a way a query can observe (consensus, length, postings, an IsBaseEqual state of a column)
+  void structuralChange(int c) {
+    dirty = true;
+    if (winContigs.empty()) return;
+    auto it = winContigs.find(c);
+    if (it != winContigs.end()) for (int slot : it->second) invalidateSlot(slot);
+  }
   // ++count[base] of one posWeight column; reports whether AlignAlgo::IsBaseEqual (AlignAlgo.hpp:49-55) can now answer differently
-  void bumpWeight(PosWeight &w, int base) {
+  void bumpWeight(int seqIdx, PosWeight &w, int base) {
     int sum = w.c[0] + w.c[1] + w.c[2] + w.c[3];
     unsigned before = sum == 0 ? 16u : 0u, after = 0;
     for (int x = 0; x < 4; ++x) before |= (sum < 3 * w.c[x]) ? (1u << x) : 0u;
     ++w.c[base]; ++sum;
     for (int x = 0; x < 4; ++x) after |= (sum < 3 * w.c[x]) ? (1u << x) : 0u;
     dirty = true;
-    if (before != after) ++epoch;
+    if (before != after) structuralChange(seqIdx);
   }
   int prefetch(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive);
 
@@ -256,7 +277,7 @@ struct t4_assembler {
     seqs.push_back(ns);
     index.build(seqs[seqIdx].cons.c_str(), len, seqIdx, barcode);
     setPrev(seqIdx, 0, len - 1, 0, len - 1, strand);
-    structuralChange();
+    structuralChange(seqIdx);
     return seqIdx;
   }
 
@@ -275,7 +296,7 @@ struct t4_assembler {
     if (updateIndex) index.removeSeq(s.cons.c_str(), (int)s.cons.size(), seqIdx, s.barcode, 0);
     for (auto &c : changes) s.cons[c.first] = NUM2NUC[c.second];
     if (updateIndex) index.build(s.cons.c_str(), (int)s.cons.size(), seqIdx, s.barcode, 0);
-    structuralChange();
+    structuralChange(seqIdx);
   }
   void updateAllConsensus() { for (int i = 0; i < (int)seqs.size(); ++i) if (!seqs[i].released) updateConsensus(i, true); }
 
@@ -290,7 +311,7 @@ struct t4_assembler {
     index.removeSeq(s.cons.c_str() + start, end - start + 1, seqIdx, s.barcode, start);
     s.cons[pos] = c;
     index.build(s.cons.c_str() + start, end - start + 1, seqIdx, s.barcode, start);
-    structuralChange();
+    structuralChange(seqIdx);
   }
 
   // RepeatAddRead (SeqSet.hpp:4477-4507)
@@ -301,7 +322,7 @@ struct t4_assembler {
     Seq &s = seqs[prevAdd.seqIdx];
     for (int i = prevAdd.readStart; i <= prevAdd.readEnd; ++i) {
       if (r[i] == 'N') continue;
-      bumpWeight(s.pw[i + prevAdd.seqStart], nucNum(r[i]));
+      bumpWeight(prevAdd.seqIdx, s.pw[i + prevAdd.seqStart], nucNum(r[i]));
     }
     ++s.numRead;
     return prevAdd.seqIdx;
@@ -320,8 +341,8 @@ struct t4_assembler {
     for (int i = 0; i < (int)seqs.size(); ++i) index.build(seqs[i].cons.c_str(), (int)seqs[i].cons.size(), i, seqs[i].barcode, 0);
     setPrev(-1, -1, -1, -1, -1, 0);
     if (dev) { t4_index_destroy(dev); dev = nullptr; }   // nomatchGapLimit and the lookup layout depend on k
-    cache.clear(); cacheHead = 0; cacheEpoch = ~0ull;
-    structuralChange();
+    dropWindow();
+    dirty = true;
     return T4_OK;
   }
   int addRead(const char *read, const char *geneName, int *strandIO, int barcode, int minKmerCount, bool repetitiveData, double similarityThreshold);
@@ -343,15 +364,15 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
   std::vector<int32_t> extRet;
   int32_t cnt = 0;
   bool served = false;
-  if (cacheEpoch == epoch && cacheHead < cache.size()) {
+  if (cacheHead < cache.size()) {
     Cached &c = cache[cacheHead];
-    if (c.read == read && c.strand == *strandIO && c.barcode == barcode && c.skip == (repetitiveData ? 1 : 0)) {
+    if (c.valid && c.read == read && c.strand == *strandIO && c.barcode == barcode && c.skip == (repetitiveData ? 1 : 0)) {
       cnt = c.cnt; ovBuf.swap(c.ov); extBuf.swap(c.ext); extRet.swap(c.extRet);
       ++cacheHead; ++cacheHits; served = true;
     }
   }
   if (!served) {
-    cache.clear(); cacheHead = 0; cacheEpoch = ~0ull;
+    dropWindow();
     const char *one = read.c_str();
     int st = *strandIO, bcOne = barcode;
     int rc = prefetch(1, &one, &st, &bcOne, repetitiveData ? 1 : 0);
@@ -555,7 +576,7 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
     seqs[newSeqIdx].minRightExtAnchor = newMinRight;
     readInConsensusOffset = ext[0].seqStart > 0 ? ext[0].seqStart : 0;
     seqIdx = newSeqIdx;
-    structuralChange();
+    for (i = 0; i < eCnt; ++i) structuralChange(ext[i].seqIdx);
   } else if (ne == 1) {
     // ---- extend one contig, or place the read inside it (SeqSet.hpp:4131-4316)
     addNew = false;
@@ -610,7 +631,7 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
       if (ext[0].readEnd < len - 1) seq.minRightExtAnchor = 0;
       readInConsensusOffset = ext[0].seqStart > 0 ? ext[0].seqStart : 0;
       seq.cons = newCons;
-      structuralChange();
+      structuralChange(seqIdx);
       for (auto &p : replacement) substituteConsensusPos(seqIdx, p.first, (char)p.second);
     } else readInConsensusOffset = ext[0].seqStart;
   }
@@ -620,7 +641,7 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
     std::vector<int> nPos;
     for (i = 0; i < len; ++i) {
       if (r[i] == 'N') continue;
-      bumpWeight(seq.pw[i + readInConsensusOffset], nucNum(r[i]));
+      bumpWeight(seqIdx, seq.pw[i + readInConsensusOffset], nucNum(r[i]));
       if (seq.cons[i + readInConsensusOffset] == 'N') nPos.push_back(i);
     }
     setPrev(seqIdx, 0, len - 1, readInConsensusOffset, readInConsensusOffset + len - 1, overlaps[0].strand);
@@ -633,7 +654,7 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
       int end = nPos[j - 1] + K - 1 + readInConsensusOffset;
       if (end >= (int)seq.cons.size()) end = (int)seq.cons.size() - 1;
       index.build(seq.cons.c_str() + start, end - start + 1, seqIdx, barcode, start);
-      structuralChange();
+      structuralChange(seqIdx);
       i = j;
     }
     ret = seqIdx;
@@ -649,14 +670,14 @@ int t4_assembler::prefetch(int n, const char *const *reads, const int *strands, 
   const int MAXOV = 128;
   int rc;
   if ((rc = refreshDevice())) return rc;
-  cache.clear(); cacheHead = 0;
+  dropWindow();
   auto tq0_ = std::chrono::steady_clock::now();
   struct Tq { double &acc; std::chrono::steady_clock::time_point t0; ~Tq() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tq_{secQuery, tq0_};
   cache.resize(n);
   std::string bases; std::vector<int64_t> offs(1, 0); std::vector<int32_t> bcs(n), sts(n); std::vector<double> fac(n);
   for (int i = 0; i < n; ++i) {
     Cached &c = cache[i];
-    c.read = reads[i]; c.strand = strands[i]; c.barcode = barcodes ? barcodes[i] : -1; c.skip = repetitive; c.cnt = 0;
+    c.read = reads[i]; c.strand = strands[i]; c.barcode = barcodes ? barcodes[i] : -1; c.skip = repetitive; c.cnt = 0; c.valid = true;
     bases += c.read; offs.push_back((int64_t)bases.size()); bcs[i] = c.barcode; sts[i] = c.strand;
     fac[i] = (c.barcode == -1 && !repetitive) ? 1.0 : 2.0;   // ExtendOverlap's mismatch factor (SeqSet.hpp:3597-3598)
   }
@@ -666,7 +687,33 @@ int t4_assembler::prefetch(int n, const char *const *reads, const int *strands, 
   std::vector<int32_t> cnts(n), rets(m);
   rc = t4_add_query(dev, n, bases.data(), offs.data(), bcs.data(), sts.data(), repetitive, fac.data(), MAXOV, cnts.data(), ov.data(), ex.data(), rets.data());
   ++queries;
-  if (rc) { cache.clear(); return rc; }
+  if (rc) { dropWindow(); return rc; }
+  // dependency sets of every window read, from the host copy of the index (both strands, every valid k-mer)
+  if (n > 1) {
+    std::string rcs;
+    for (int q = 0; q < n; ++q) {
+      const Cached &c = cache[q];
+      reverseComplement(rcs, c.read);
+      std::vector<int> contigs;
+      for (int st = 0; st < 2; ++st) {
+        const std::string &r = st ? rcs : c.read;
+        if ((int)r.size() < k) continue;
+        KCode kc(k);
+        for (int i = 0; i < (int)r.size(); ++i) {
+          kc.append(r[i]);
+          if (i < k - 1 || !kc.valid()) continue;
+          Key key{kc.code, index.bucket(kc.code, c.barcode)};
+          auto &slots = winKmers[key];
+          if (slots.empty() || slots.back() != q) slots.push_back(q);
+          auto it = index.map.find(key);
+          if (it != index.map.end()) for (const Post &p : it->second) contigs.push_back(p.idx);
+        }
+      }
+      std::sort(contigs.begin(), contigs.end());
+      contigs.erase(std::unique(contigs.begin(), contigs.end()), contigs.end());
+      for (int cid : contigs) winContigs[cid].push_back(q);
+    }
+  }
   for (int q = 0; q < n; ++q) {
     Cached &c = cache[q];
     c.cnt = cnts[q];
@@ -675,7 +722,6 @@ int t4_assembler::prefetch(int n, const char *const *reads, const int *strands, 
     c.ext.assign(ex.begin() + (size_t)q * MAXOV, ex.begin() + (size_t)q * MAXOV + k2);
     c.extRet.assign(rets.begin() + (size_t)q * MAXOV, rets.begin() + (size_t)q * MAXOV + k2);
   }
-  cacheEpoch = epoch;
   return T4_OK;
 }
 
@@ -728,7 +774,7 @@ int t4_assembler_prefetch(t4_assembler *a, int n, const char *const *reads, cons
   if (!a || n < 0 || (n > 0 && (!reads || !strands))) return T4_ERR_ARG;
   return a->prefetch(n, reads, strands, barcodes, repetitive_data ? 1 : 0);
 }
-int t4_assembler_window_valid(const t4_assembler *a) { return a && a->cacheEpoch == a->epoch && a->cacheHead < a->cache.size(); }
+int t4_assembler_window_valid(const t4_assembler *a) { return a && a->cacheHead < a->cache.size() && a->cache[a->cacheHead].valid; }
 int t4_assembler_counters(const t4_assembler *a, int64_t *queries, int64_t *refreshes, int64_t *window_hits) {
   if (!a) return T4_ERR_ARG;
   if (queries) *queries = a->queries;
