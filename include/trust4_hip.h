@@ -175,6 +175,36 @@ int t4_assembler_size(const t4_assembler *a);
 /* SeqSet::ChangeKmerLength (SeqSet.hpp:4624-4629): compacts the set (ids are renumbered) and re-indexes with the new k. */
 int t4_assembler_change_kmer_length(t4_assembler *a, int kmer_length);
 int64_t t4_assembler_index_postings(const t4_assembler *a);
+/* SeqSet::ReleaseFinishedBarcodeSeq({barcode}, removeFromIndex = true, contigMinCov = 0, earlyStop = true)
+ * (SeqSet.hpp:10815-10935; main.cpp:1846-1859): the trailing contigs of that barcode leave the index and are final. */
+int t4_assembler_release_finished_barcode(t4_assembler *a, int barcode);
+
+/* ---- per-barcode contig sets (barcode mode, main.cpp:1549-1559) ---------------------------------------
+ * With --barcode the reference keys the k-mer index by barcode (SetConsiderBarcodeInIndexHash, KmerIndex.hpp:29-33)
+ * and filters every hit to the read's barcode (SeqSet.hpp:1418, 1485): contigs of different cells never meet, so its
+ * one `SeqSet seqSet` is a disjoint union of per-cell sets processed one after the other (main.cpp:1126, 1183-1192).
+ * t4_cellset exposes that structure: t4_cellset_cell returns the t4_assembler of one barcode (contig ids local to the
+ * cell; every t4_assembler_* call above works on it, with that barcode as the `barcode` argument), and
+ * t4_cellset_prefetch runs the AddRead queries of the next reads of MANY cells in one launch against per-cell device
+ * images, which is what lets the order-dependent Add path batch without conflicts. The results are what
+ * the reference's sequential pass over the cells produces; t4_cellset_output numbers the contigs as that pass would
+ * (cells in ascending barcode id, creation order inside a cell) and prints SeqSet::Output(fp, &barcodeIntToStr)
+ * (SeqSet.hpp:10939-10994). Barcode ids must be < 1000003 (beyond that the reference lets two barcodes share lists). */
+typedef struct t4_cellset t4_cellset;
+int t4_cellset_create(t4_ctx *ctx, int kmer_length, t4_cellset **out);
+void t4_cellset_destroy(t4_cellset *cs);   /* also destroys its cells */
+int t4_cellset_set_params(t4_cellset *cs, int hit_len_required, int radius, double novel_seq_similarity);
+int t4_cellset_cell(t4_cellset *cs, int barcode, t4_assembler **cell);   /* get or create */
+int t4_cellset_close_cell(t4_cellset *cs, t4_assembler *cell);           /* no more queries: recycle its device slot */
+/* read i is the next read cells[i] will be offered by t4_assembler_add_read (strand argument strands[i]); a cell may
+ * appear several times, in the order its reads will come (its speculation window, validity tracked as above). */
+int t4_cellset_prefetch(t4_cellset *cs, int n, t4_assembler *const *cells, const char *const *reads, const int *strands,
+                        int repetitive_data);
+int t4_cellset_update_all_consensus(t4_cellset *cs);
+int t4_cellset_size(const t4_cellset *cs);   /* contig slots over all cells == seqSet.Size() */
+int t4_cellset_output(t4_cellset *cs, const char *path, const char *const *barcode_names, int n_names);
+int t4_cellset_counters(const t4_cellset *cs, int64_t *query_batches, int64_t *reads_queried, int64_t *images_staged,
+                        int64_t *bytes_staged, double *sec_query, double *sec_stage);
 
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* Per-call statistics of the last query on this ctx: kernel time measured with HIP events on the

@@ -207,6 +207,20 @@ int ref_repeat_add_read(void *h, const char *read) {
   return ret;
 }
 void ref_update_all_consensus(void *h) { ((SeqSet *)h)->UpdateAllConsensus(); }
+// barcode mode (main.cpp:1549-1559, 1846-1859, 1968-1969)
+void ref_set_consider_barcode(void *h, int on) { ((SeqSet *)h)->SetConsiderBarcodeInIndexHash(on != 0); }
+void ref_release_finished_barcode(void *h, int barcode, int total) {
+  std::map<int, int> fin;
+  fin[barcode] = total;
+  ((SeqSet *)h)->ReleaseFinishedBarcodeSeq(fin, true, 0, true);
+}
+void ref_output_barcodes(void *h, const char *path, const char *const *names, int n) {
+  std::vector<std::string> v;
+  for (int i = 0; i < n; ++i) v.push_back(names[i]);
+  FILE *fp = fopen(path, "w");
+  ((SeqSet *)h)->Output(fp, &v);
+  fclose(fp);
+}
 void ref_output(void *h, const char *path) {
   FILE *fp = fopen(path, "w");
   ((SeqSet *)h)->Output(fp);

@@ -32,6 +32,7 @@ struct dim3 {
 struct uint2 { unsigned x, y; };
 struct int2 { int x, y; };
 struct int4 { int x, y, z, w; };
+struct uint4 { unsigned x, y, z, w; };
 static inline int2 make_int2(int x, int y) { int2 r = {x, y}; return r; }
 static inline uint2 make_uint2(unsigned x, unsigned y) { uint2 r = {x, y}; return r; }
 static inline int4 make_int4(int x, int y, int z, int w) { int4 r = {x, y, z, w}; return r; }

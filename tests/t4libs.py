@@ -311,7 +311,7 @@ def rows_to_strs(arr):
 class RefSeqSet:
     """A mutable reference SeqSet (novel contigs) driven through oracle/_ref: the checker of the Add path."""
 
-    def __init__(self, k, hit_len_required=31):
+    def __init__(self, k, hit_len_required=31, consider_barcode=False):
         self.lib = C.CDLL(Ref.PATH)
         self.lib.ref_seqset_new.restype = C.c_void_p
         self.h = C.c_void_p(self.lib.ref_seqset_new(k))
@@ -323,7 +323,19 @@ class RefSeqSet:
         self.lib.ref_update_all_consensus.argtypes = [P]
         self.lib.ref_output.argtypes = [P, C.c_char_p]
         self.lib.ref_size.argtypes = [P]
+        self.lib.ref_set_consider_barcode.argtypes = [P, I]
+        self.lib.ref_release_finished_barcode.argtypes = [P, I, I]
+        self.lib.ref_output_barcodes.argtypes = [P, C.c_char_p, P, I]
         self.lib.ref_set_hit_len_required(self.h, hit_len_required)
+        if consider_barcode:
+            self.lib.ref_set_consider_barcode(self.h, 1)
+
+    def release_finished_barcode(self, barcode, total=1):
+        self.lib.ref_release_finished_barcode(self.h, barcode, total)
+
+    def output_barcodes(self, path, names):
+        arr = (C.c_char_p * len(names))(*[_b(x) for x in names])
+        self.lib.ref_output_barcodes(self.h, _b(path), C.cast(arr, C.c_void_p), len(names))
 
     def input_novel_read(self, name, read, strand, barcode=-1):
         return self.lib.ref_input_novel_read(self.h, _b(name), _b(read), strand, barcode)

@@ -5,4 +5,4 @@ The product is the C-ABI library ``trust4_amd/libt4hip.so`` (include/trust4_hip.
 ABI used by tests and bench.py. There is NO CPU fallback: importing works anywhere, but creating an
 ``Engine`` raises if the HIP library is missing or no GPU is present.
 """
-from .api import Engine, Index, Batch, Assembler, T4Error, OV_DTYPE, HIT_DTYPE, lib_path  # noqa: F401
+from .api import Engine, Index, Batch, Assembler, CellSet, T4Error, OV_DTYPE, HIT_DTYPE, lib_path  # noqa: F401

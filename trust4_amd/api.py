@@ -58,6 +58,12 @@ def _load():
         "t4_assembler_counters": (I, [P, P, P, P]),
         "t4_assembler_repeat_add_read": (I, [P, C.c_char_p]), "t4_assembler_update_all_consensus": (I, [P]),
         "t4_assembler_output": (I, [P, C.c_char_p]), "t4_assembler_size": (I, [P]), "t4_assembler_index_postings": (L, [P]),
+        "t4_assembler_release_finished_barcode": (I, [P, I]),
+        "t4_cellset_create": (I, [P, I, C.POINTER(P)]), "t4_cellset_destroy": (None, [P]),
+        "t4_cellset_set_params": (I, [P, I, I, C.c_double]), "t4_cellset_cell": (I, [P, I, C.POINTER(P)]),
+        "t4_cellset_close_cell": (I, [P, P]), "t4_cellset_prefetch": (I, [P, I, P, P, P, I]),
+        "t4_cellset_update_all_consensus": (I, [P]), "t4_cellset_size": (I, [P]),
+        "t4_cellset_output": (I, [P, C.c_char_p, P, I]), "t4_cellset_counters": (I, [P, P, P, P, P, P, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -129,12 +135,19 @@ class Engine:
 class Assembler:
     """t4_assembler: the reference's `SeqSet seqSet` of novel contigs with its Add path (same call signatures)."""
 
-    def __init__(self, eng, k, consider_barcode=False, hit_len_required=31, radius=10, novel_seq_similarity=0.9):
+    def __init__(self, eng, k, consider_barcode=False, hit_len_required=31, radius=10, novel_seq_similarity=0.9, _cell=None):
         self.eng = eng
+        self.owned = _cell is None
+        if _cell is not None:      # a cell of a CellSet: the handle belongs to the set
+            self.h = _cell
+            return
         h = C.c_void_p()
         eng.check(eng.lib.t4_assembler_create(eng.h, k, 1 if consider_barcode else 0, C.byref(h)))
         self.h = h
         eng.check(eng.lib.t4_assembler_set_params(h, hit_len_required, radius, novel_seq_similarity))
+
+    def release_finished_barcode(self, barcode):
+        self.eng.check(self.eng.lib.t4_assembler_release_finished_barcode(self.h, barcode))
 
     def _ret(self, r):
         if r < -50:
@@ -180,7 +193,68 @@ class Assembler:
 
     def close(self):
         if getattr(self, "h", None):
-            self.eng.lib.t4_assembler_destroy(self.h)
+            if self.owned:
+                self.eng.lib.t4_assembler_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CellSet:
+    """t4_cellset: the reference's barcode-mode `SeqSet seqSet` as a disjoint union of per-barcode sets."""
+
+    def __init__(self, eng, k, hit_len_required=13, radius=10, novel_seq_similarity=0.9):
+        self.eng = eng
+        h = C.c_void_p()
+        eng.check(eng.lib.t4_cellset_create(eng.h, k, C.byref(h)))
+        self.h = h
+        eng.check(eng.lib.t4_cellset_set_params(h, hit_len_required, radius, novel_seq_similarity))
+        self.cells = {}
+
+    def cell(self, barcode):
+        if barcode not in self.cells:
+            c = C.c_void_p()
+            self.eng.check(self.eng.lib.t4_cellset_cell(self.h, barcode, C.byref(c)))
+            self.cells[barcode] = Assembler(self.eng, 0, _cell=c)
+        return self.cells[barcode]
+
+    def close_cell(self, barcode):
+        self.eng.check(self.eng.lib.t4_cellset_close_cell(self.h, self.cell(barcode).h))
+
+    def prefetch(self, barcodes, reads, strands, repetitive_data=0):
+        n = len(reads)
+        cells = (C.c_void_p * n)(*[self.cell(b).h.value for b in barcodes])
+        arr = (C.c_char_p * n)(*[r.encode() for r in reads])
+        st = np.ascontiguousarray(strands, dtype=np.int32)
+        self.eng.check(self.eng.lib.t4_cellset_prefetch(self.h, n, C.cast(cells, C.c_void_p), C.cast(arr, C.c_void_p),
+                                                        st.ctypes.data_as(C.c_void_p), repetitive_data))
+
+    def update_all_consensus(self):
+        self.eng.check(self.eng.lib.t4_cellset_update_all_consensus(self.h))
+
+    def size(self):
+        return self.eng.lib.t4_cellset_size(self.h)
+
+    def output(self, path, names):
+        arr = (C.c_char_p * len(names))(*[x.encode() for x in names])
+        self.eng.check(self.eng.lib.t4_cellset_output(self.h, path.encode(), C.cast(arr, C.c_void_p), len(names)))
+
+    def counters(self):
+        q, r, i, b = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        sq, ss = C.c_double(), C.c_double()
+        self.eng.check(self.eng.lib.t4_cellset_counters(self.h, C.byref(q), C.byref(r), C.byref(i), C.byref(b), C.byref(sq), C.byref(ss)))
+        return {"query_batches": q.value, "reads_queried": r.value, "images_staged": i.value, "bytes_staged": b.value,
+                "sec_query": sq.value, "sec_stage": ss.value}
+
+    def close(self):
+        if getattr(self, "h", None):
+            for c in self.cells.values():
+                c.h = None
+            self.eng.lib.t4_cellset_destroy(self.h)
             self.h = None
 
     def __del__(self):

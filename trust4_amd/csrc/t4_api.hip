@@ -12,16 +12,19 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <map>
 #include <string>
 #include <unordered_map>
 #include <vector>
 
 #include "../../include/trust4_hip.h"
 #include "t4_kernels.h"
+#include "t4_internal.h"
 
 static_assert(sizeof(t4_overlap) == sizeof(T4OverlapOut), "overlap layout");
 static_assert(sizeof(t4_hit) == sizeof(T4HitOut), "hit layout");
 static_assert(sizeof(t4k::OvRec) == 40, "OvRec layout");
+static_assert(sizeof(T4IndexView) % 16 == 0, "view stride");
 
 namespace {
 
@@ -784,15 +787,15 @@ int t4_extend(t4_index *ix, t4_batch *b, int max_per_read, const int32_t *counts
   return r;
 }
 
+}  // extern "C"
 
-// The query half of SeqSet::AddRead for a small batch of reads, in one launch and one host round trip.
-int t4_add_query(t4_index *ix, int n, const char *bases, const int64_t *offsets, const int32_t *barcodes, const int32_t *strands,
-                 int skip_repeats, const double *factors, int max_per_read, int32_t *counts, t4_overlap *ov, t4_overlap *ext, int32_t *ext_ret) {
-  if (!ix || n < 0 || max_per_read <= 0 || max_per_read > 128 || (n > 0 && (!bases || !offsets || !strands || !factors || !counts || !ov || !ext || !ext_ret))) return T4_ERR_ARG;
-  t4_ctx *c = ix->ctx;
-  if (!ix->committed) return fail(c, T4_ERR_STATE, "index not committed");
-  if (ix->view.firstIsRef) return fail(c, T4_ERR_UNSUPPORTED, "t4_add_query needs a contig set");
-  if (n == 0) return T4_OK;
+namespace {
+// The query half of SeqSet::AddRead for a batch of reads, lean path: one blob in, one blob out. Either every read is
+// matched against `base` (viewOf == nullptr; first launch on the 8192-hit LDS tier) or read i against views[viewOf[i]]
+// (per-barcode images: reads meet a handful of contigs, so the first launch is the 1024-hit tier at 6 groups / CU).
+int addQueryImpl(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const int32_t *viewOf, int n, const char *bases,
+                 const int64_t *offsets, const int32_t *barcodes, const int32_t *strands, int skip_repeats, const double *factors,
+                 int max_per_read, int32_t *counts, t4_overlap *ov, t4_overlap *ext, int32_t *ext_ret) {
   (void)hipSetDevice(c->device);
   int maxLen = 1;
   for (int i = 0; i < n; ++i) {
@@ -801,14 +804,16 @@ int t4_add_query(t4_index *ix, int n, const char *bases, const int64_t *offsets,
     if (l > maxLen) maxLen = (int)l;
   }
   const int wpk = (maxLen + 15) / 16, wnm = (maxLen + 31) / 32;
-  // input blob: pk | nm | len | barcode | strand | list(iota) | factor ; output blob: counts | status | ov | ext | ret | tail{overflowCount, hits}
+  // input blob: pk | nm | len | barcode | strand | list(iota) | viewOf | factor
+  // output blob: counts | status | next1 | next2 | ov | ext | ret | tail{overflow1, overflow2, hits}
   auto al8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
   const size_t oPk = 0, oNm = al8(oPk + sizeof(unsigned) * (size_t)n * wpk), oLen = al8(oNm + sizeof(unsigned) * (size_t)n * wnm),
                oBc = al8(oLen + sizeof(int) * (size_t)n), oSt = al8(oBc + sizeof(int) * (size_t)n), oLs = al8(oSt + sizeof(int) * (size_t)n),
-               oFa = al8(oLs + sizeof(int) * (size_t)n), inBytes = al8(oFa + sizeof(double) * (size_t)n);
+               oVw = al8(oLs + sizeof(int) * (size_t)n), oFa = al8(oVw + sizeof(int) * (size_t)n), inBytes = al8(oFa + sizeof(double) * (size_t)n);
   const size_t m = (size_t)n * max_per_read;
-  const size_t pCnt = 0, pSta = al8(pCnt + sizeof(int) * (size_t)n), pNext = al8(pSta + sizeof(int) * (size_t)n), pOv = al8(pNext + sizeof(int) * (size_t)n),
-               pEx = al8(pOv + sizeof(t4_overlap) * m), pRet = al8(pEx + sizeof(t4_overlap) * m), pTail = al8(pRet + sizeof(int) * m), outBytes = pTail + 16;
+  const size_t pCnt = 0, pSta = al8(pCnt + sizeof(int) * (size_t)n), pNext = al8(pSta + sizeof(int) * (size_t)n),
+               pNext2 = al8(pNext + sizeof(int) * (size_t)n), pOv = al8(pNext2 + sizeof(int) * (size_t)n),
+               pEx = al8(pOv + sizeof(t4_overlap) * m), pRet = al8(pEx + sizeof(t4_overlap) * m), pTail = al8(pRet + sizeof(int) * m), outBytes = pTail + 24;
   int r;
   if (inBytes > c->aqInBytes) {
     if (c->aqIn) (void)hipFree(c->aqIn);
@@ -829,12 +834,12 @@ int t4_add_query(t4_index *ix, int n, const char *bases, const int64_t *offsets,
   unsigned char *h = c->aqInHost;
   memset(h, 0, inBytes);
   unsigned *pk = (unsigned *)(h + oPk), *nm = (unsigned *)(h + oNm);
-  int *len = (int *)(h + oLen), *bc = (int *)(h + oBc), *st = (int *)(h + oSt), *ls = (int *)(h + oLs);
+  int *len = (int *)(h + oLen), *bc = (int *)(h + oBc), *st = (int *)(h + oSt), *ls = (int *)(h + oLs), *vw = (int *)(h + oVw);
   double *fa = (double *)(h + oFa);
   for (int i = 0; i < n; ++i) {
     const char *s = bases + offsets[i];
     int l = (int)(offsets[i + 1] - offsets[i]);
-    len[i] = l; bc[i] = barcodes ? barcodes[i] : -1; st[i] = strands[i]; ls[i] = i; fa[i] = factors[i];
+    len[i] = l; bc[i] = barcodes ? barcodes[i] : -1; st[i] = strands[i]; ls[i] = i; fa[i] = factors[i]; vw[i] = viewOf ? viewOf[i] : 0;
     unsigned *p = pk + (size_t)i * wpk, *q = nm + (size_t)i * wnm;
     for (int j = 0; j < l; ++j) {
       int v = nucNum(s[j]);
@@ -846,7 +851,8 @@ int t4_add_query(t4_index *ix, int n, const char *bases, const int64_t *offsets,
     }
   }
   HIPCHK(c, hipMemcpyAsync(c->aqIn, h, inBytes, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->aqOut, 0, outBytes, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->aqOut, 0, pOv, c->stream));          // counts, status, overflow lists
+  HIPCHK(c, hipMemsetAsync(c->aqOut + pTail, 0, 24, c->stream));
   T4BatchView bv;
   bv.pk = (const unsigned *)(c->aqIn + oPk); bv.nm = (const unsigned *)(c->aqIn + oNm); bv.len = (const int *)(c->aqIn + oLen);
   bv.barcode = (const int *)(c->aqIn + oBc); bv.wpk = wpk; bv.wnm = wnm; bv.n = n;
@@ -855,26 +861,43 @@ int t4_add_query(t4_index *ix, int n, const char *bases, const int64_t *offsets,
   qa.mode = 4; qa.skipRepeats = skip_repeats; qa.maxPerRead = max_per_read;
   qa.counts = (int *)(c->aqOut + pCnt); qa.out = (T4OverlapOut *)(c->aqOut + pOv); qa.outExt = (T4OverlapOut *)(c->aqOut + pEx);
   qa.ret = (int *)(c->aqOut + pRet); qa.strandPerRead = (const int *)(c->aqIn + oSt); qa.factorPerRead = (const double *)(c->aqIn + oFa);
-  const int threads = TIER_THREADS[3];
-  if ((r = ensureScratch(c, (n > c->cus * 2 ? n : c->cus * 2) * threads))) return r;
+  if (views) { qa.views = views; qa.viewOf = (const int *)(c->aqIn + oVw); }
+  const int threads = 256;
+  const int grid0 = views ? (n < c->cus * TIER_BLOCKS_PER_CU[0] ? n : c->cus * TIER_BLOCKS_PER_CU[0]) : n;
+  if ((r = ensureScratch(c, (grid0 > c->cus * 2 ? grid0 : c->cus * 2) * threads))) return r;
   T4Work wk;
   memset(&wk, 0, sizeof wk);
   wk.list = (const int *)(c->aqIn + oLs); wk.nList = n;
   wk.nextList = (int *)(c->aqOut + pNext); wk.nextCount = (int *)(c->aqOut + pTail);
-  wk.status = (int *)(c->aqOut + pSta); wk.hitCounter = (unsigned long long *)(c->aqOut + pTail + 8);
+  wk.status = (int *)(c->aqOut + pSta); wk.hitCounter = (unsigned long long *)(c->aqOut + pTail + 16);
   wk.dpRows = c->dpRows; wk.dpDir = c->dpDir;
-  launchTier<8192, 512, 256>(n, c->stream, ix->view, bv, wk, qa);
+  if (views) launchTier<1024, 128, 256>(grid0, c->stream, base, bv, wk, qa);
+  else launchTier<8192, 512, 256>(grid0, c->stream, base, bv, wk, qa);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(c->aqOutHost, c->aqOut, outBytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   int overflow = *(int *)(c->aqOutHost + pTail);
-  if (overflow > 0) {   // reads beyond the LDS tier: global-scratch tier
+  if (overflow > 0 && views) {   // reads beyond the 1024-hit tier: 8192-hit LDS tier
+    T4Work w1 = wk;
+    w1.list = (const int *)(c->aqOut + pNext); w1.nList = overflow;
+    w1.nextList = (int *)(c->aqOut + pNext2); w1.nextCount = (int *)(c->aqOut + pTail + 8);
+    if ((r = ensureScratch(c, (overflow > c->cus * 2 ? overflow : c->cus * 2) * threads))) return r;
+    w1.dpRows = c->dpRows; w1.dpDir = c->dpDir;
+    launchTier<8192, 512, 256>(overflow, c->stream, base, bv, w1, qa);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->aqOutHost, c->aqOut, outBytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    overflow = *(int *)(c->aqOutHost + pTail + 8);
+    wk.nextList = (int *)(c->aqOut + pNext2);
+  }
+  if (overflow > 0) {   // reads beyond the LDS tiers: global-scratch tier
     if ((r = ensureGlobalTier(c, overflow))) return r;
     T4Work w2 = wk;
-    w2.list = (const int *)(c->aqOut + pNext); w2.nList = overflow; w2.nextList = nullptr; w2.nextCount = nullptr;
+    w2.list = wk.nextList; w2.nList = overflow; w2.nextList = nullptr; w2.nextCount = nullptr;
     w2.gKeys = c->gKeys; w2.gPairs = c->gPairs; w2.gCand = c->gCand; w2.gOv = c->gOv; w2.gFin = c->gFin; w2.gOrd = c->gOrd;
     w2.gCap = G_CAP; w2.gMaxOv = G_MAXOV;
-    launchTier<0, 0, 256>(overflow, c->stream, ix->view, bv, w2, qa);
+    w2.dpRows = c->dpRows; w2.dpDir = c->dpDir;
+    launchTier<0, 0, 256>(overflow, c->stream, base, bv, w2, qa);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->aqOutHost, c->aqOut, outBytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -883,10 +906,273 @@ int t4_add_query(t4_index *ix, int n, const char *bases, const int64_t *offsets,
   const int *status = (const int *)(o + pSta);
   for (int i = 0; i < n; ++i) if (status[i]) return fail(c, T4_ERR_UNSUPPORTED, "read %d exceeds the engine limits (status %d)", i, status[i]);
   memcpy(counts, o + pCnt, sizeof(int) * (size_t)n);
-  memcpy(ov, o + pOv, sizeof(t4_overlap) * m);
-  memcpy(ext, o + pEx, sizeof(t4_overlap) * m);
-  memcpy(ext_ret, o + pRet, sizeof(int) * m);
+  const int *cn = (const int *)(o + pCnt);
+  for (int i = 0; i < n; ++i) {   // only the records that exist
+    const int k2 = cn[i] > 0 ? (cn[i] < max_per_read ? cn[i] : max_per_read) : 0;
+    if (!k2) continue;
+    const size_t at = (size_t)i * max_per_read;
+    memcpy(ov + at, o + pOv + sizeof(t4_overlap) * at, sizeof(t4_overlap) * k2);
+    memcpy(ext + at, o + pEx + sizeof(t4_overlap) * at, sizeof(t4_overlap) * k2);
+    memcpy(ext_ret + at, o + pRet + sizeof(int) * at, sizeof(int) * k2);
+  }
   return T4_OK;
 }
+}  // namespace
+
+extern "C" {
+
+int t4_add_query(t4_index *ix, int n, const char *bases, const int64_t *offsets, const int32_t *barcodes, const int32_t *strands,
+                 int skip_repeats, const double *factors, int max_per_read, int32_t *counts, t4_overlap *ov, t4_overlap *ext, int32_t *ext_ret) {
+  if (!ix || n < 0 || max_per_read <= 0 || max_per_read > 128 || (n > 0 && (!bases || !offsets || !strands || !factors || !counts || !ov || !ext || !ext_ret))) return T4_ERR_ARG;
+  t4_ctx *c = ix->ctx;
+  if (!ix->committed) return fail(c, T4_ERR_STATE, "index not committed");
+  if (ix->view.firstIsRef) return fail(c, T4_ERR_UNSUPPORTED, "t4_add_query needs a contig set");
+  if (n == 0) return T4_OK;
+  return addQueryImpl(c, ix->view, nullptr, nullptr, n, bases, offsets, barcodes, strands, skip_repeats, factors, max_per_read, counts, ov, ext, ext_ret);
+}
+
+}  // extern "C"
+
+// ---- device arena of per-barcode set images ------------------------------------------------------------------
+struct t4_cellstore {
+  t4_ctx *ctx = nullptr;
+  int k = 9, hitLenRequired = 31, radius = 10, nomatchGapLimit = 0;
+  double novelSim = 0.9;
+  struct Slot { unsigned char *base = nullptr; size_t cap = 0; bool live = false; };
+  std::vector<Slot> slots;
+  std::vector<int> freeIds;
+  std::vector<unsigned char *> chunks;
+  size_t chunkUsed = 0;
+  std::map<size_t, std::vector<unsigned char *>> freeBySize;
+  T4IndexView *dViews = nullptr;
+  int viewCap = 0;
+  unsigned char *stHost = nullptr, *stDev = nullptr;   // staging of the images rebuilt since the last flush
+  size_t stCap = 0, stUsed = 0;
+  std::vector<T4CopyDesc> descs;
+  T4CopyDesc *dDescs = nullptr;
+  size_t descCap = 0;
+  int64_t bytesStaged = 0;
+  static constexpr size_t CHUNK = (size_t)256 << 20;
+};
+
+namespace {
+int cellAlloc(t4_cellstore *cs, size_t cap, unsigned char **out) {
+  auto it = cs->freeBySize.find(cap);
+  if (it != cs->freeBySize.end() && !it->second.empty()) { *out = it->second.back(); it->second.pop_back(); return T4_OK; }
+  if (cap > t4_cellstore::CHUNK) return fail(cs->ctx, T4_ERR_UNSUPPORTED, "a per-barcode set image of %zu bytes exceeds the arena chunk", cap);
+  if (cs->chunks.empty() || cs->chunkUsed + cap > t4_cellstore::CHUNK) {
+    unsigned char *p = nullptr;
+    HIPCHK(cs->ctx, hipMalloc(&p, t4_cellstore::CHUNK));
+    cs->chunks.push_back(p); cs->chunkUsed = 0;
+  }
+  *out = cs->chunks.back() + cs->chunkUsed;
+  cs->chunkUsed += cap;
+  return T4_OK;
+}
+int cellStagingReserve(t4_cellstore *cs, size_t more) {
+  if (cs->stUsed + more <= cs->stCap) return T4_OK;
+  size_t ncap = cs->stCap ? cs->stCap : ((size_t)4 << 20);
+  while (ncap < cs->stUsed + more) ncap *= 2;
+  unsigned char *nh = nullptr, *nd = nullptr;
+  HIPCHK(cs->ctx, hipHostMalloc(&nh, ncap, hipHostMallocDefault));
+  HIPCHK(cs->ctx, hipMalloc(&nd, ncap));
+  if (cs->stUsed) memcpy(nh, cs->stHost, cs->stUsed);
+  if (cs->stHost) (void)hipHostFree(cs->stHost);
+  if (cs->stDev) { (void)hipStreamSynchronize(cs->ctx->stream); (void)hipFree(cs->stDev); }
+  cs->stHost = nh; cs->stDev = nd; cs->stCap = ncap;
+  return T4_OK;
+}
+int cellFlush(t4_cellstore *cs) {
+  if (cs->descs.empty()) return T4_OK;
+  t4_ctx *c = cs->ctx;
+  if (cs->descs.size() > cs->descCap) {
+    if (cs->dDescs) { (void)hipStreamSynchronize(c->stream); (void)hipFree(cs->dDescs); cs->dDescs = nullptr; }
+    cs->descCap = cs->descs.size() * 2;
+    HIPCHK(c, hipMalloc(&cs->dDescs, sizeof(T4CopyDesc) * cs->descCap));
+  }
+  HIPCHK(c, hipMemcpyAsync(cs->stDev, cs->stHost, cs->stUsed, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(cs->dDescs, cs->descs.data(), sizeof(T4CopyDesc) * cs->descs.size(), hipMemcpyHostToDevice, c->stream));
+  int grid = (int)cs->descs.size();
+  if (grid > c->cus * 8) grid = c->cus * 8;
+  hipLaunchKernelGGL(t4k::scatterKernel, dim3(grid), dim3(256), 0, c->stream, (const unsigned char *)cs->stDev, (const T4CopyDesc *)cs->dDescs, (int)cs->descs.size());
+  HIPCHK(c, hipGetLastError());
+  // the pageable descriptor vector and the pinned staging are reused by the next stage() calls
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  cs->bytesStaged += (int64_t)cs->stUsed;
+  cs->descs.clear(); cs->stUsed = 0;
+  return T4_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int t4_cellstore_create(t4_ctx *c, int k, t4_cellstore **out) {
+  if (!c || !out) return T4_ERR_ARG;
+  if (k < 2 || k > 31) return fail(c, T4_ERR_ARG, "kmer_length %d outside [2,31]", k);
+  t4_cellstore *cs = new t4_cellstore();
+  cs->ctx = c; cs->k = k;
+  double kmerHitProb = pow(0.8, k);  // SeqSet::ComputeNomatchGapLimit (SeqSet.hpp:2476-2482)
+  cs->nomatchGapLimit = int(k * (log(0.01) / log(1 - kmerHitProb))) + 1;
+  *out = cs;
+  return T4_OK;
+}
+void t4_cellstore_destroy(t4_cellstore *cs) {
+  if (!cs) return;
+  (void)hipSetDevice(cs->ctx->device);
+  (void)hipStreamSynchronize(cs->ctx->stream);
+  for (unsigned char *p : cs->chunks) (void)hipFree(p);
+  if (cs->dViews) (void)hipFree(cs->dViews);
+  if (cs->stDev) (void)hipFree(cs->stDev);
+  if (cs->stHost) (void)hipHostFree(cs->stHost);
+  if (cs->dDescs) (void)hipFree(cs->dDescs);
+  delete cs;
+}
+int t4_cellstore_set_params(t4_cellstore *cs, int hit_len_required, int radius, double novel_sim) {
+  if (!cs) return T4_ERR_ARG;
+  cs->hitLenRequired = hit_len_required; cs->radius = radius; cs->novelSim = novel_sim;
+  return T4_OK;
+}
+int t4_cellstore_open(t4_cellstore *cs, int *slot) {
+  if (!cs || !slot) return T4_ERR_ARG;
+  if (!cs->freeIds.empty()) { *slot = cs->freeIds.back(); cs->freeIds.pop_back(); }
+  else { *slot = (int)cs->slots.size(); cs->slots.push_back(t4_cellstore::Slot()); }
+  cs->slots[*slot].live = true;
+  return T4_OK;
+}
+int t4_cellstore_close(t4_cellstore *cs, int slot) {
+  if (!cs || slot < 0 || slot >= (int)cs->slots.size() || !cs->slots[slot].live) return T4_ERR_ARG;
+  t4_cellstore::Slot &s = cs->slots[slot];
+  if (s.base) cs->freeBySize[s.cap].push_back(s.base);
+  s = t4_cellstore::Slot();
+  cs->freeIds.push_back(slot);
+  return T4_OK;
+}
+
+int t4_cellstore_stage(t4_cellstore *cs, int slot, int barcode, int nseq, const char *const *names, const char *const *cons,
+                       const int32_t *const *pw, int64_t npost, const uint64_t *code, const int32_t *bucket, const int32_t *idx,
+                       const int32_t *offset) {
+  if (!cs || slot < 0 || slot >= (int)cs->slots.size() || !cs->slots[slot].live || nseq < 0 || npost < 0) return T4_ERR_ARG;
+  t4_ctx *c = cs->ctx;
+  (void)hipSetDevice(c->device);
+  if (nseq > T4_MAX_SEQS) return fail(c, T4_ERR_UNSUPPORTED, "more than %d sequences in one barcode", T4_MAX_SEQS);
+  // order of the postings inside a list is the host replica's; lists are grouped by a stable sort on (code, bucket)
+  std::vector<int> order((size_t)npost);
+  for (int64_t i = 0; i < npost; ++i) order[(size_t)i] = (int)i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return code[a] != code[b] ? code[a] < code[b] : bucket[a] < bucket[b]; });
+  size_t nkeys = 0;
+  for (size_t i = 0; i < order.size();) {
+    size_t j = i;
+    while (j < order.size() && code[order[j]] == code[order[i]] && bucket[order[j]] == bucket[order[i]]) ++j;
+    ++nkeys; i = j;
+  }
+  size_t sz = 64;
+  while (sz < 2 * nkeys + 2) sz <<= 1;
+  size_t consBytes = 0, pwCount = 0;
+  for (int i = 0; i < nseq; ++i) {
+    size_t l = strlen(cons[i]);
+    if (l > T4_MAX_SEQLEN) return fail(c, T4_ERR_UNSUPPORTED, "contig longer than %d", T4_MAX_SEQLEN);
+    consBytes += l + 1; pwCount += l + 1;
+  }
+  auto al16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const size_t oHt = 0, oPost = al16(oHt + sizeof(T4HashEnt) * sz), oSeq = al16(oPost + sizeof(int2) * (size_t)npost),
+               oPw = al16(oSeq + sizeof(T4SeqInfo) * (size_t)nseq), oCons = al16(oPw + sizeof(int4) * pwCount),
+               blobBytes = al16(oCons + consBytes + 16);
+  int r;
+  t4_cellstore::Slot &sl = cs->slots[slot];
+  if (blobBytes > sl.cap) {
+    if (sl.base) cs->freeBySize[sl.cap].push_back(sl.base);
+    size_t cap = (size_t)64 << 10;
+    while (cap < blobBytes + blobBytes / 2) cap <<= 1;
+    sl.base = nullptr; sl.cap = 0;
+    unsigned char *p = nullptr;
+    if ((r = cellAlloc(cs, cap, &p))) return r;
+    sl.base = p; sl.cap = cap;
+  }
+  if (slot >= cs->viewCap) {
+    int ncap = cs->viewCap ? cs->viewCap : 1024;
+    while (ncap <= slot) ncap *= 2;
+    T4IndexView *nv = nullptr;
+    HIPCHK(c, hipMalloc(&nv, sizeof(T4IndexView) * (size_t)ncap));
+    if ((r = cellFlush(cs))) return r;   // pending descriptors may point into the old array
+    if (cs->dViews) {
+      HIPCHK(c, hipMemcpyAsync(nv, cs->dViews, sizeof(T4IndexView) * (size_t)cs->viewCap, hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      (void)hipFree(cs->dViews);
+    }
+    cs->dViews = nv; cs->viewCap = ncap;
+  }
+  const size_t viewBytes = al16(sizeof(T4IndexView));
+  if ((r = cellStagingReserve(cs, blobBytes + viewBytes))) return r;
+  unsigned char *b = cs->stHost + cs->stUsed;
+  memset(b, 0, blobBytes + viewBytes);
+  T4HashEnt *ht = (T4HashEnt *)(b + oHt);
+  for (size_t i = 0; i < sz; ++i) ht[i].h = -1;
+  int2 *post = (int2 *)(b + oPost);
+  const unsigned long long hashMask = sz - 1;
+  for (size_t i = 0; i < order.size();) {
+    size_t j = i;
+    const unsigned long long cd = code[order[i]];
+    const int hb = bucket[order[i]];
+    while (j < order.size() && code[order[j]] == cd && bucket[order[j]] == hb) {
+      const int o = order[j];
+      if (idx[o] < 0 || idx[o] >= nseq) return fail(c, T4_ERR_ARG, "posting names sequence %d of %d", idx[o], nseq);
+      post[j] = make_int2(idx[o], offset[o]);
+      ++j;
+    }
+    unsigned long long s = t4k::mix64(cd * 1000003ull + (unsigned long long)hb) & hashMask;
+    while (ht[s].h >= 0) s = (s + 1) & hashMask;
+    ht[s].code = cd; ht[s].h = hb; ht[s].start = (unsigned)i; ht[s].cnt = (unsigned)(j - i);
+    i = j;
+  }
+  T4SeqInfo *infos = (T4SeqInfo *)(b + oSeq);
+  int4 *pwOut = (int4 *)(b + oPw);
+  char *consOut = (char *)(b + oCons);
+  size_t consAt = 0, pwAt = 0;
+  for (int i = 0; i < nseq; ++i) {
+    T4SeqInfo &f = infos[i];
+    const int l = (int)strlen(cons[i]);
+    f.consOff = (int)consAt; f.len = l; f.barcode = barcode; f.isRef = 0;
+    memcpy(consOut + consAt, cons[i], (size_t)l + 1);
+    consAt += (size_t)l + 1;
+    char nm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    strncpy(nm, names[i], 7);
+    int gt = geneType(nm);
+    f.geneType = gt < 0 ? 255 : (unsigned char)gt;
+    f.name0 = (unsigned char)nm[0]; f.name1 = (unsigned char)nm[1]; f.name2 = (unsigned char)nm[2]; f.name3 = (unsigned char)nm[3];
+    f.pwOff = (int)pwAt;
+    if (l > 0 && pw[i]) memcpy(pwOut + pwAt, pw[i], sizeof(int4) * (size_t)l);
+    pwAt += (size_t)l + 1;
+  }
+  T4IndexView &v = *(T4IndexView *)(b + blobBytes);
+  v.k = cs->k; v.nseq = nseq; v.direct = 0; v.considerBarcode = 1;
+  v.hashMask = hashMask; v.table = nullptr; v.htab = (const T4HashEnt *)(sl.base + oHt); v.post = (const int2 *)(sl.base + oPost);
+  v.seqs = (const T4SeqInfo *)(sl.base + oSeq); v.cons = (const char *)(sl.base + oCons); v.pw = (const int4 *)(sl.base + oPw);
+  v.radius = cs->radius; v.hitLenRequired = cs->hitLenRequired; v.nomatchGapLimit = cs->nomatchGapLimit;
+  v.firstIsRef = 0; v.hasNovel = 1;
+  v.novelSim = cs->novelSim; v.refSim = 0.75; v.repeatSim = 0.95;
+  T4CopyDesc d0; d0.srcOff = cs->stUsed; d0.dst = sl.base; d0.bytes = blobBytes;
+  T4CopyDesc d1; d1.srcOff = cs->stUsed + blobBytes; d1.dst = (unsigned char *)(cs->dViews + slot); d1.bytes = viewBytes;
+  cs->descs.push_back(d0); cs->descs.push_back(d1);
+  cs->stUsed += blobBytes + viewBytes;
+  return T4_OK;
+}
+
+int t4_cellstore_query(t4_cellstore *cs, int n, const int32_t *slots, const char *bases, const int64_t *offsets, const int32_t *barcodes,
+                       const int32_t *strands, int skip_repeats, const double *factors, int max_per_read, int32_t *counts,
+                       t4_overlap *ov, t4_overlap *ext, int32_t *ext_ret) {
+  if (!cs || n < 0 || max_per_read <= 0 || max_per_read > 128 || (n > 0 && (!slots || !bases || !offsets || !strands || !factors || !counts || !ov || !ext || !ext_ret))) return T4_ERR_ARG;
+  t4_ctx *c = cs->ctx;
+  (void)hipSetDevice(c->device);
+  int r;
+  if ((r = cellFlush(cs))) return r;
+  if (n == 0) return T4_OK;
+  for (int i = 0; i < n; ++i)
+    if (slots[i] < 0 || slots[i] >= (int)cs->slots.size() || !cs->slots[slots[i]].base) return fail(c, T4_ERR_STATE, "read %d names cell slot %d which has no image", i, slots[i]);
+  T4IndexView base;
+  memset(&base, 0, sizeof base);
+  base.k = cs->k;
+  return addQueryImpl(c, base, cs->dViews, slots, n, bases, offsets, barcodes, strands, skip_repeats, factors, max_per_read, counts, ov, ext, ext_ret);
+}
+int64_t t4_cellstore_bytes_staged(const t4_cellstore *cs) { return cs ? cs->bytesStaged : 0; }
 
 }  // extern "C"

@@ -18,11 +18,13 @@
 
 #include <algorithm>
 #include <chrono>
+#include <map>
 #include <string>
 #include <unordered_map>
 #include <vector>
 
 #include "../../include/trust4_hip.h"
+#include "t4_internal.h"
 
 namespace {
 
@@ -120,6 +122,7 @@ struct Seq {
   std::string name, cons;
   std::vector<PosWeight> pw;
   bool released = false;
+  bool frozen = false;   // ReleaseFinishedBarcodeSeq: out of the index, posWeight final (SeqSet.hpp:10847-10935)
   int minLeftExtAnchor = 0, minRightExtAnchor = 0, barcode = -1, numRead = 0;
 };
 
@@ -188,9 +191,12 @@ void reverseComplement(std::string &rc, const std::string &s) {
 
 }  // namespace
 
+struct t4_cellset;
 struct t4_assembler : InsertHook {
   t4_ctx *ctx;
   t4_index *dev = nullptr;   // device image of the current set
+  t4_cellset *owner = nullptr;   // cell of a per-barcode set: the image lives in the owner's arena slot
+  int slot = -1, cellBarcode = -1;
   bool dirty = true;
   int k, radius = 10, hitLenRequired = 31;
   double novelSim = 0.9;
@@ -232,10 +238,13 @@ struct t4_assembler : InsertHook {
     for (int x = 0; x < 4; ++x) before |= (sum < 3 * w.c[x]) ? (1u << x) : 0u;
     ++w.c[base]; ++sum;
     for (int x = 0; x < 4; ++x) after |= (sum < 3 * w.c[x]) ? (1u << x) : 0u;
-    dirty = true;
-    if (before != after) structuralChange(seqIdx);
+    if (before != after) structuralChange(seqIdx);   // other increments cannot be observed by a query: the image stays as it is
   }
   int prefetch(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive);
+  void beginWindow(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive);
+  void endWindow(const int32_t *cnts, const t4_overlap *ov, const t4_overlap *ex, const int32_t *rets, int stride);
+  int stageImage();   // cell mode: queue this cell's image in the owner's arena
+  int releaseFinishedBarcode(int barcode);
 
   void setPrev(int seqIdx, int rs, int re, int ss, int se, int strand) {
     prevAdd.seqIdx = seqIdx; prevAdd.readStart = rs; prevAdd.readEnd = re; prevAdd.seqStart = ss; prevAdd.seqEnd = se; prevAdd.strand = strand;
@@ -284,6 +293,7 @@ struct t4_assembler : InsertHook {
   // UpdateConsensus (SeqSet.hpp:4537-4588)
   void updateConsensus(int seqIdx, bool updateIndex) {
     Seq &s = seqs[seqIdx];
+    if (s.frozen) return;   // posWeightCompressed (SeqSet.hpp:4542-4543)
     std::vector<std::pair<int, int>> changes;
     for (int i = 0; i < (int)s.cons.size(); ++i) {
       int mx = 0, tag = 0;
@@ -665,30 +675,62 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
   return ret;
 }
 
-// Query the GPU for n upcoming reads against the current set (one batch) and keep the results as the speculation window.
-int t4_assembler::prefetch(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive) {
-  const int MAXOV = 128;
-  int rc;
-  if ((rc = refreshDevice())) return rc;
+// ---- per-barcode sets -------------------------------------------------------------------------------
+// With barcodes the index key carries the barcode and hits are filtered to the read's barcode (main.cpp:1556-1559,
+// SeqSet.hpp:1418): the contigs of different cells never interact, a cell is an independent SeqSet. t4_cellset keeps one
+// t4_assembler per barcode (contig ids local to the cell) and serves the AddRead queries of many cells in one launch.
+struct t4_cellset {
+  t4_ctx *ctx = nullptr;
+  t4_cellstore *store = nullptr;
+  int k = 9, hitLenRequired = 31, radius = 10;
+  double novelSim = 0.9;
+  std::map<int, t4_assembler *> cells;   // by barcode id == the reference's processing order of the cells
+  int64_t queries = 0, stagedImages = 0, readsQueried = 0;
+  double secQuery = 0, secStage = 0;
+  std::string err;
+};
+
+int t4_assembler::stageImage() {
+  if (!dirty) return T4_OK;
+  auto t0 = std::chrono::steady_clock::now();
+  int r;
+  if (slot < 0 && (r = t4_cellstore_open(owner->store, &slot))) return r;
+  const int n = (int)seqs.size();
+  std::vector<const char *> names(n), cons(n);
+  std::vector<const int32_t *> pw(n);
+  for (int i = 0; i < n; ++i) {
+    const Seq &q = seqs[i];
+    const bool gone = q.released;
+    names[i] = gone ? "" : q.name.c_str();
+    cons[i] = gone ? "" : q.cons.c_str();
+    pw[i] = (gone || q.pw.empty()) ? nullptr : (const int32_t *)q.pw.data();
+  }
+  std::vector<uint64_t> code; std::vector<int32_t> bucket, idx, off;
+  code.reserve(index.total); bucket.reserve(index.total); idx.reserve(index.total); off.reserve(index.total);
+  for (const auto &kv : index.map)
+    for (const Post &p : kv.second) { code.push_back(kv.first.code); bucket.push_back(kv.first.h); idx.push_back(p.idx); off.push_back(p.offset); }
+  r = t4_cellstore_stage(owner->store, slot, cellBarcode, n, names.data(), cons.data(), pw.data(), (int64_t)code.size(), code.data(),
+                         bucket.data(), idx.data(), off.data());
+  owner->secStage += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (r) return r;
+  dirty = false; ++refreshes; ++owner->stagedImages;
+  return T4_OK;
+}
+
+void t4_assembler::beginWindow(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive) {
   dropWindow();
-  auto tq0_ = std::chrono::steady_clock::now();
-  struct Tq { double &acc; std::chrono::steady_clock::time_point t0; ~Tq() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tq_{secQuery, tq0_};
   cache.resize(n);
-  std::string bases; std::vector<int64_t> offs(1, 0); std::vector<int32_t> bcs(n), sts(n); std::vector<double> fac(n);
   for (int i = 0; i < n; ++i) {
     Cached &c = cache[i];
     c.read = reads[i]; c.strand = strands[i]; c.barcode = barcodes ? barcodes[i] : -1; c.skip = repetitive; c.cnt = 0; c.valid = true;
-    bases += c.read; offs.push_back((int64_t)bases.size()); bcs[i] = c.barcode; sts[i] = c.strand;
-    fac[i] = (c.barcode == -1 && !repetitive) ? 1.0 : 2.0;   // ExtendOverlap's mismatch factor (SeqSet.hpp:3597-3598)
+    c.ov.clear(); c.ext.clear(); c.extRet.clear();
   }
-  if (bases.empty()) bases.push_back('A');
-  const size_t m = (size_t)n * MAXOV;
-  std::vector<t4_overlap> ov(m), ex(m);
-  std::vector<int32_t> cnts(n), rets(m);
-  rc = t4_add_query(dev, n, bases.data(), offs.data(), bcs.data(), sts.data(), repetitive, fac.data(), MAXOV, cnts.data(), ov.data(), ex.data(), rets.data());
-  ++queries;
-  if (rc) { dropWindow(); return rc; }
-  // dependency sets of every window read, from the host copy of the index (both strands, every valid k-mer)
+}
+
+// results of the window's query (stride records per read) + the dependency sets of every window read, from the host
+// copy of the index (both strands, every valid k-mer)
+void t4_assembler::endWindow(const int32_t *cnts, const t4_overlap *ov, const t4_overlap *ex, const int32_t *rets, int stride) {
+  const int n = (int)cache.size();
   if (n > 1) {
     std::string rcs;
     for (int q = 0; q < n; ++q) {
@@ -716,28 +758,80 @@ int t4_assembler::prefetch(int n, const char *const *reads, const int *strands, 
   }
   for (int q = 0; q < n; ++q) {
     Cached &c = cache[q];
-    c.cnt = cnts[q];
+    c.cnt = cnts ? cnts[q] : 0;
     int k2 = c.cnt > 0 ? c.cnt : 0;
-    c.ov.assign(ov.begin() + (size_t)q * MAXOV, ov.begin() + (size_t)q * MAXOV + k2);
-    c.ext.assign(ex.begin() + (size_t)q * MAXOV, ex.begin() + (size_t)q * MAXOV + k2);
-    c.extRet.assign(rets.begin() + (size_t)q * MAXOV, rets.begin() + (size_t)q * MAXOV + k2);
+    if (k2 > stride) k2 = stride;
+    if (k2 > 0) {
+      c.ov.assign(ov + (size_t)q * stride, ov + (size_t)q * stride + k2);
+      c.ext.assign(ex + (size_t)q * stride, ex + (size_t)q * stride + k2);
+      c.extRet.assign(rets + (size_t)q * stride, rets + (size_t)q * stride + k2);
+    }
+  }
+}
+
+// Query the GPU for n upcoming reads against the current set (one batch) and keep the results as the speculation window.
+int t4_assembler::prefetch(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive) {
+  const int MAXOV = 128;
+  int rc;
+  if (owner) {   // a cell: its own reads only, through the owner's arena
+    std::vector<t4_assembler *> who(n, this);
+    return t4_cellset_prefetch(owner, n, who.data(), reads, strands, repetitive);
+  }
+  if ((rc = refreshDevice())) return rc;
+  auto tq0_ = std::chrono::steady_clock::now();
+  struct Tq { double &acc; std::chrono::steady_clock::time_point t0; ~Tq() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tq_{secQuery, tq0_};
+  beginWindow(n, reads, strands, barcodes, repetitive);
+  std::string bases; std::vector<int64_t> offs(1, 0); std::vector<int32_t> bcs(n), sts(n); std::vector<double> fac(n);
+  for (int i = 0; i < n; ++i) {
+    const Cached &c = cache[i];
+    bases += c.read; offs.push_back((int64_t)bases.size()); bcs[i] = c.barcode; sts[i] = c.strand;
+    fac[i] = (c.barcode == -1 && !repetitive) ? 1.0 : 2.0;   // ExtendOverlap's mismatch factor (SeqSet.hpp:3597-3598)
+  }
+  if (bases.empty()) bases.push_back('A');
+  const size_t m = (size_t)n * MAXOV;
+  std::vector<t4_overlap> ov(m), ex(m);
+  std::vector<int32_t> cnts(n), rets(m);
+  rc = t4_add_query(dev, n, bases.data(), offs.data(), bcs.data(), sts.data(), repetitive, fac.data(), MAXOV, cnts.data(), ov.data(), ex.data(), rets.data());
+  ++queries;
+  if (rc) { dropWindow(); return rc; }
+  endWindow(cnts.data(), ov.data(), ex.data(), rets.data(), MAXOV);
+  return T4_OK;
+}
+
+// SeqSet::ReleaseFinishedBarcodeSeq({barcode}, removeFromIndex = true, contigMinCov = 0, earlyStop = true)
+// (SeqSet.hpp:10815-10935). The posWeight "compression" there is lossless for Output, so the counts are kept as they are.
+int t4_assembler::releaseFinishedBarcode(int barcode) {
+  for (int i = (int)seqs.size() - 1; i >= 0; --i) {
+    Seq &s = seqs[i];
+    if (s.released) continue;
+    if (s.frozen || s.pw.empty()) break;
+    if (s.barcode != barcode) break;
+    s.frozen = true;   // before UpdateConsensus as in the reference: index = false, then the consensus is settled without re-indexing
+    index.removeSeq(s.cons.c_str(), (int)s.cons.size(), i, s.barcode, 0);
+    s.frozen = false; updateConsensus(i, false); s.frozen = true;
+    structuralChange(i);
   }
   return T4_OK;
 }
 
-// SeqSet::Output (SeqSet.hpp:10939-10994) without barcode names
-int t4_assembler::output(const char *path) const {
-  FILE *fp = fopen(path, "w");
-  if (!fp) return T4_ERR_IO;
+// SeqSet::Output (SeqSet.hpp:10939-10994): records of this set with ids shifted by idBase; barcodeName == nullptr prints
+// the `>assemble<id>` form
+static void writeRecords(FILE *fp, const std::vector<Seq> &seqs, int idBase, const char *barcodeName) {
   for (int i = 0; i < (int)seqs.size(); ++i) {
     const Seq &s = seqs[i];
     if (s.released) continue;
-    fprintf(fp, ">assemble%d %s\n%s\n", i, s.name.c_str(), s.cons.c_str());
+    if (barcodeName) fprintf(fp, ">%s_%d %s\n%s\n", barcodeName, idBase + i, s.name.c_str(), s.cons.c_str());
+    else fprintf(fp, ">assemble%d %s\n%s\n", idBase + i, s.name.c_str(), s.cons.c_str());
     for (int c = 0; c < 4; ++c) {
       for (size_t j = 0; j < s.cons.size(); ++j) fprintf(fp, "%d ", s.pw[j].c[c]);
       fprintf(fp, "\n");
     }
   }
+}
+int t4_assembler::output(const char *path) const {
+  FILE *fp = fopen(path, "w");
+  if (!fp) return T4_ERR_IO;
+  writeRecords(fp, seqs, 0, nullptr);
   fclose(fp);
   return T4_OK;
 }
@@ -754,6 +848,7 @@ int t4_assembler_create(t4_ctx *ctx, int kmer_length, int consider_barcode, t4_a
 void t4_assembler_destroy(t4_assembler *a) {
   if (!a) return;
   if (a->dev) t4_index_destroy(a->dev);
+  if (a->owner) return;   // cells belong to their t4_cellset
   delete a;
 }
 int t4_assembler_set_params(t4_assembler *a, int hit_len_required, int radius, double novel_seq_similarity) {
@@ -797,5 +892,138 @@ int t4_assembler_change_kmer_length(t4_assembler *a, int kmer_length) {
   return a->changeKmerLength(kmer_length);
 }
 int64_t t4_assembler_index_postings(const t4_assembler *a) { return a ? (int64_t)a->index.total : 0; }
+int t4_assembler_release_finished_barcode(t4_assembler *a, int barcode) { return a ? a->releaseFinishedBarcode(barcode) : T4_ERR_ARG; }
+
+// ---- t4_cellset ----------------------------------------------------------------------------------------------
+int t4_cellset_create(t4_ctx *ctx, int kmer_length, t4_cellset **out) {
+  if (!ctx || !out || kmer_length < 2 || kmer_length > 31) return T4_ERR_ARG;
+  t4_cellset *cs = new t4_cellset();
+  cs->ctx = ctx; cs->k = kmer_length;
+  int r = t4_cellstore_create(ctx, kmer_length, &cs->store);
+  if (r) { delete cs; return r; }
+  *out = cs;
+  return T4_OK;
+}
+void t4_cellset_destroy(t4_cellset *cs) {
+  if (!cs) return;
+  for (auto &kv : cs->cells) delete kv.second;
+  t4_cellstore_destroy(cs->store);
+  delete cs;
+}
+int t4_cellset_set_params(t4_cellset *cs, int hit_len_required, int radius, double novel_seq_similarity) {
+  if (!cs) return T4_ERR_ARG;
+  cs->hitLenRequired = hit_len_required; cs->radius = radius; cs->novelSim = novel_seq_similarity;
+  for (auto &kv : cs->cells) { kv.second->hitLenRequired = hit_len_required; kv.second->radius = radius; kv.second->novelSim = novel_seq_similarity; kv.second->dirty = true; }
+  return t4_cellstore_set_params(cs->store, hit_len_required, radius, novel_seq_similarity);
+}
+int t4_cellset_cell(t4_cellset *cs, int barcode, t4_assembler **cell) {
+  if (!cs || !cell || barcode < 0 || barcode >= 1000003) return T4_ERR_ARG;   // beyond that, barcodes share index lists (KmerIndex.hpp:29-33)
+  auto it = cs->cells.find(barcode);
+  if (it == cs->cells.end()) {
+    t4_assembler *a = new t4_assembler(cs->ctx, cs->k);
+    a->index.considerBarcode = true;
+    a->owner = cs; a->cellBarcode = barcode;
+    a->hitLenRequired = cs->hitLenRequired; a->radius = cs->radius; a->novelSim = cs->novelSim;
+    it = cs->cells.emplace(barcode, a).first;
+  }
+  *cell = it->second;
+  return T4_OK;
+}
+int t4_cellset_close_cell(t4_cellset *cs, t4_assembler *cell) {   // no further queries for this cell: its arena slot is recycled
+  if (!cs || !cell || cell->owner != cs) return T4_ERR_ARG;
+  cell->dropWindow();
+  if (cell->slot >= 0) { int r = t4_cellstore_close(cs->store, cell->slot); cell->slot = -1; cell->dirty = true; return r; }
+  return T4_OK;
+}
+
+// One query batch for reads of many cells: read i is the next read cells[i] will be offered (a cell may appear several
+// times, in the order its reads will come: that is the cell's speculation window).
+int t4_cellset_prefetch(t4_cellset *cs, int n, t4_assembler *const *cells, const char *const *reads, const int *strands, int repetitive_data) {
+  if (!cs || n < 0 || (n > 0 && (!cells || !reads || !strands))) return T4_ERR_ARG;
+  const int MAXOV = 128;
+  const int rep = repetitive_data ? 1 : 0;
+  // group by cell, keeping the order within a cell
+  std::vector<t4_assembler *> order;
+  std::unordered_map<t4_assembler *, std::vector<int>> byCell;
+  for (int i = 0; i < n; ++i) {
+    if (!cells[i] || cells[i]->owner != cs) return T4_ERR_ARG;
+    auto &v = byCell[cells[i]];
+    if (v.empty()) order.push_back(cells[i]);
+    v.push_back(i);
+  }
+  int rc;
+  std::string bases; std::vector<int64_t> offs(1, 0); std::vector<int32_t> bcs, sts, slots; std::vector<double> fac;
+  struct Span { t4_assembler *cell; int first, count; bool queried; };
+  std::vector<Span> spans;
+  for (t4_assembler *cell : order) {
+    const std::vector<int> &ids = byCell[cell];
+    std::vector<const char *> rs; std::vector<int> st, bc;
+    for (int i : ids) { rs.push_back(reads[i]); st.push_back(strands[i]); bc.push_back(cell->cellBarcode); }
+    cell->beginWindow((int)ids.size(), rs.data(), st.data(), bc.data(), rep);
+    Span sp{cell, (int)sts.size(), (int)ids.size(), cell->index.total > 0};
+    if (sp.queried) {   // an empty index has no hit for anybody: GetOverlapsFromRead returns 0 without a launch
+      if ((rc = cell->stageImage())) { cs->err = t4_last_error(cs->ctx); return rc; }
+      for (int i : ids) {
+        bases += reads[i]; offs.push_back((int64_t)bases.size()); bcs.push_back(cell->cellBarcode); sts.push_back(strands[i]);
+        slots.push_back(cell->slot); fac.push_back(2.0);   // ExtendOverlap's mismatch factor with a barcode (SeqSet.hpp:3597-3598)
+      }
+    }
+    spans.push_back(sp);
+  }
+  const int m = (int)sts.size();
+  std::vector<t4_overlap> ov((size_t)m * MAXOV), ex((size_t)m * MAXOV);
+  std::vector<int32_t> cnts(m), rets((size_t)m * MAXOV);
+  if (m > 0) {
+    auto t0 = std::chrono::steady_clock::now();
+    rc = t4_cellstore_query(cs->store, m, slots.data(), bases.data(), offs.data(), bcs.data(), sts.data(), rep, fac.data(), MAXOV,
+                            cnts.data(), ov.data(), ex.data(), rets.data());
+    cs->secQuery += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    ++cs->queries; cs->readsQueried += m;
+    if (rc) { for (Span &sp : spans) sp.cell->dropWindow(); return rc; }
+  }
+  for (Span &sp : spans) {
+    if (sp.queried) { sp.cell->endWindow(cnts.data() + sp.first, ov.data() + (size_t)sp.first * MAXOV, ex.data() + (size_t)sp.first * MAXOV, rets.data() + (size_t)sp.first * MAXOV, MAXOV); ++sp.cell->queries; }
+    else sp.cell->endWindow(nullptr, nullptr, nullptr, nullptr, MAXOV);
+  }
+  return T4_OK;
+}
+
+// SeqSet::Output(fp, &barcodeIntToStr) of the set the reference would hold: cells in barcode order, contig ids numbered in
+// creation order across the cells (contig slots are only ever created by InputNovelRead; merges reuse a slot)
+int t4_cellset_output(t4_cellset *cs, const char *path, const char *const *barcode_names, int n_names) {
+  if (!cs || !path) return T4_ERR_ARG;
+  FILE *fp = fopen(path, "w");
+  if (!fp) return T4_ERR_IO;
+  int base = 0;
+  for (auto &kv : cs->cells) {
+    const char *nm = (barcode_names && kv.first >= 0 && kv.first < n_names) ? barcode_names[kv.first] : nullptr;
+    writeRecords(fp, kv.second->seqs, base, nm);
+    base += (int)kv.second->seqs.size();
+  }
+  fclose(fp);
+  return T4_OK;
+}
+int t4_cellset_size(const t4_cellset *cs) {
+  if (!cs) return 0;
+  int n = 0;
+  for (auto &kv : cs->cells) n += (int)kv.second->seqs.size();
+  return n;
+}
+int t4_cellset_update_all_consensus(t4_cellset *cs) {
+  if (!cs) return T4_ERR_ARG;
+  for (auto &kv : cs->cells) kv.second->updateAllConsensus();
+  return T4_OK;
+}
+int t4_cellset_counters(const t4_cellset *cs, int64_t *query_batches, int64_t *reads_queried, int64_t *images_staged, int64_t *bytes_staged,
+                        double *sec_query, double *sec_stage) {
+  if (!cs) return T4_ERR_ARG;
+  if (query_batches) *query_batches = cs->queries;
+  if (reads_queried) *reads_queried = cs->readsQueried;
+  if (images_staged) *images_staged = cs->stagedImages;
+  if (bytes_staged) *bytes_staged = t4_cellstore_bytes_staged(cs->store);
+  if (sec_query) *sec_query = cs->secQuery;
+  if (sec_stage) *sec_stage = cs->secStage;
+  return T4_OK;
+}
 
 }  // extern "C"

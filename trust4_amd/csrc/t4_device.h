@@ -32,7 +32,7 @@ struct T4HashEnt {           // open-addressing slot of the (code, bucket) -> po
   unsigned pad;
 };
 
-struct T4IndexView {
+struct alignas(16) T4IndexView {   // 128 bytes: per-barcode views are scattered in 16-byte units
   int k, nseq, direct, considerBarcode;
   unsigned long long hashMask;
   const uint2 *table;        // direct-addressed [4^k] {start,cnt} (k <= 12, no barcode)
@@ -97,4 +97,9 @@ struct T4QueryArgs {
   const int *strandPerRead;
   const double *factorPerRead;
   T4OverlapOut *outExt;
+  // per-read set images (per-barcode contig sets): read r is matched against views[viewOf[r]]
+  const T4IndexView *views;
+  const int *viewOf;
 };
+
+struct T4CopyDesc { unsigned long long srcOff; unsigned char *dst; unsigned long long bytes; };  // scatter of staged set images

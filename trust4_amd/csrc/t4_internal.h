@@ -1,0 +1,30 @@
+// trust4_amd/csrc/t4_internal.h -- library-internal interface between the host-side contig builder
+// (t4_assembler.cpp) and the device side (t4_api.hip). Not part of the public C ABI.
+#pragma once
+#include <stdint.h>
+#include "../../include/trust4_hip.h"
+
+extern "C" {
+
+// Device arena of per-barcode set images (in barcode mode every cell is an independent SeqSet,
+// main.cpp:1556-1559 + SeqSet.hpp:1418). One slot per open cell; a slot's image is rebuilt from the host replica of
+// the cell (sequences, posWeight, explicit postings) and uploaded with all other rebuilt images of a window in one
+// host-to-device copy + one scatter kernel.
+typedef struct t4_cellstore t4_cellstore;
+int t4_cellstore_create(t4_ctx *ctx, int kmer_length, t4_cellstore **out);
+void t4_cellstore_destroy(t4_cellstore *cs);
+int t4_cellstore_set_params(t4_cellstore *cs, int hit_len_required, int radius, double novel_seq_similarity);
+int t4_cellstore_open(t4_cellstore *cs, int *slot);
+int t4_cellstore_close(t4_cellstore *cs, int slot);
+// Queue the new image of one cell. names/cons: nseq C strings ("" for released slots), pw: 4 counts per base
+// concatenated over the sequences; postings as (code, bucket, idx, offset) with idx local to the cell.
+int t4_cellstore_stage(t4_cellstore *cs, int slot, int barcode, int nseq, const char *const *names, const char *const *cons,
+                       const int32_t *const *pw, int64_t npost, const uint64_t *code, const int32_t *bucket,
+                       const int32_t *idx, const int32_t *offset);
+// Flush the staged images, then run the AddRead query (== t4_add_query) of read i against the image of slot[i].
+int t4_cellstore_query(t4_cellstore *cs, int n, const int32_t *slots, const char *bases, const int64_t *offsets,
+                       const int32_t *barcodes, const int32_t *strands, int skip_repeats, const double *factors,
+                       int max_per_read, int32_t *counts, t4_overlap *ov, t4_overlap *ext, int32_t *ext_ret);
+int64_t t4_cellstore_bytes_staged(const t4_cellstore *cs);
+
+}  // extern "C"

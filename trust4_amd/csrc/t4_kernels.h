@@ -1862,12 +1862,27 @@ __global__ __launch_bounds__(NTHREADS) void queryKernel(T4IndexView ix, T4BatchV
   sc.dir = wk.dpDir + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * T4_DIR_BYTES;
   for (int w = blockIdx.x; w < wk.nList; w += gridDim.x) {
     long long r = wk.list[w];
-    bool done = processRead(ix, bv, wk, qa, wm, &s_ws, r, sc);
+    bool done;
+    if (qa.views) {
+      const T4IndexView cell = qa.views[qa.viewOf[r]];   // uniform address: scalar loads
+      done = processRead(cell, bv, wk, qa, wm, &s_ws, r, sc);
+    } else done = processRead(ix, bv, wk, qa, wm, &s_ws, r, sc);
     if (!done && tid() == 0) {
       if (wk.nextList) { int slot = atomicAdd(wk.nextCount, 1); wk.nextList[slot] = (int)r; }
       else wk.status[r] = 2;
     }
     __syncthreads();
+  }
+}
+
+// Scatter of freshly built per-barcode set images from the staging buffer to their slots (16-byte units).
+__global__ __launch_bounds__(256) void scatterKernel(const unsigned char *staging, const T4CopyDesc *desc, int nDesc) {
+  for (int d = blockIdx.x; d < nDesc; d += gridDim.x) {
+    const T4CopyDesc cd = desc[d];
+    const uint4 *src = (const uint4 *)(staging + cd.srcOff);
+    uint4 *dst = (uint4 *)cd.dst;
+    const unsigned long long n16 = cd.bytes >> 4;
+    for (unsigned long long i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
   }
 }
 
