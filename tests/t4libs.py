@@ -41,6 +41,9 @@ def build_checkers():
     src = os.path.join(ROOT, "tools", "t4synth.c")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         subprocess.run(["gcc", "-O2", "-std=gnu99", "-fPIC", "-shared", "-o", so, src, "-lz"], check=True)
+    cli = os.path.join(ROOT, "tools", "t4synth")
+    if not os.path.exists(cli) or os.path.getmtime(cli) < os.path.getmtime(src):
+        subprocess.run(["gcc", "-O2", "-std=gnu99", "-DT4SYNTH_MAIN", "-o", cli, src, "-lz"], check=True)
 
 
 class _SetAPI:

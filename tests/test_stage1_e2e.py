@@ -61,3 +61,41 @@ def test_synthetic_matches_reference_binary(tmp_path, pairs, clones, seed):
     for suffix in ("_raw.out", "_assembled_reads.fa", "_final.out"):
         assert filecmp.cmp(ref_out + suffix, my_out + suffix, shallow=False), suffix
     assert open(ref_out + "_raw.out").read().count(">") > 5
+
+
+def _barcode_case(tmp_path, driver, pairs, cells, seed, env=None):
+    """10x-style input (tools/t4synth --cells: barcode + UMI FASTA files parallel to the reads) through `driver` and through
+    the reference binary; all three outputs must be byte-identical (with barcodes the reference writes _final.out = raw)."""
+    fa = str(tmp_path / "ref.fa")
+    _gunzip(REF_FA, fa)
+    pre = str(tmp_path / "c5")
+    subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, str(pairs), "0", str(seed), pre, "--cells", str(cells)], check=True)
+    args = ["-f", fa, "-1", pre + "_1.fq", "-2", pre + "_2.fq", "--barcode", pre + "_bc.fa", "--UMI", pre + "_umi.fa"]
+    ref_out, my_out = str(tmp_path / "ref"), str(tmp_path / "mine")
+    subprocess.run([REF_BIN, "-t", "1"] + args + ["-o", ref_out], check=True, stderr=subprocess.DEVNULL)
+    e = dict(os.environ)
+    e.update(env or {})
+    subprocess.run([driver] + args + ["-o", my_out], check=True, env=e)
+    for suffix in ("_raw.out", "_assembled_reads.fa", "_final.out"):
+        assert filecmp.cmp(ref_out + suffix, my_out + suffix, shallow=False), suffix
+    assert open(ref_out + "_raw.out").read().count(">") >= cells
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not shipped")
+@pytest.mark.parametrize("pairs,cells,seed,lanes,window", [(3000, 60, 4, 4096, 4), (3000, 60, 5, 7, 1)])
+def test_barcode_mode_matches_reference_binary(tmp_path, pairs, cells, seed, lanes, window):
+    _barcode_case(tmp_path, _driver(), pairs, cells, seed, {"T4_LANES": str(lanes), "T4_WINDOW": str(window)})
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
+def test_barcode_mode_emulated(tmp_path):
+    """the same driver source linked against the emulator build of the kernels (test infrastructure): tiny case for the CPU suite"""
+    import t4check
+    lib = t4check.build_emulator_lib()
+    exe = os.path.join(ROOT, "tests", "hipemu", "trust4-hip-emu")
+    src = os.path.join(ROOT, "trust4_amd", "host", "trust4_main.cpp")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(lib)):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, src, "-L" + os.path.dirname(lib), "-lt4hip_emu",
+                        "-Wl,-rpath," + os.path.dirname(lib), "-lz"], check=True)
+    _barcode_case(tmp_path, exe, 160, 8, 6, {"T4_LANES": "5", "T4_WINDOW": "3"})

@@ -8,6 +8,9 @@
  *                + first 350 bp of C
  *   abundance  = Zipf(1) over clones; fragment length U[200,420]; read_len bases from each end,
  *                mate 2 reverse-complemented; 50 % strand flip; 0.3 % substitutions; quality 'I'.
+ * Cell mode: n_cells cells x 2 clones (IGH + IGK/IGL, or TRB + TRA), every pair drawn from a
+ * uniformly chosen cell and one of its two clones; 16-nt barcode per cell, 10-nt random UMI per pair, written as
+ * FASTA files parallel to the reads (`--cells N` -> out_prefix_bc.fa / _umi.fa).
  * Built both as a shared library (ctypes: fills fixed-stride read buffers) and as a CLI
  * (`t4synth ref.fa[.gz] n_pairs n_clones seed out_prefix` -> out_prefix_1.fq / _2.fq).
  */
@@ -83,7 +86,7 @@ typedef struct {
   clone_t *clones; int nclones; double *cdf; rng_t rng; int read_len;
 } synth_t;
 
-void *t4synth_open(const char *fasta, int nclones, uint64_t seed, int read_len) {
+static void *synth_open(const char *fasta, int nclones, uint64_t seed, int read_len, int cells) {
   recs_t recs;
   if (load_fasta(fasta, &recs) <= 0) return NULL;
   synth_t *s = (synth_t *)calloc(1, sizeof(synth_t));
@@ -102,6 +105,11 @@ void *t4synth_open(const char *fasta, int nclones, uint64_t seed, int read_len) 
   static const char ACGT[4] = {'A', 'C', 'G', 'T'};
   for (int k = 0; k < nclones; ++k) {
     int c = rng_int(&s->rng, 0, 4);
+    if (cells) {   /* clone 2i: heavy / beta chain of cell i, clone 2i+1: its light / alpha chain */
+      static int isB;
+      if ((k & 1) == 0) { isB = (int)(rng_next(&s->rng) & 1); c = isB ? 0 : 4; }
+      else c = isB ? rng_int(&s->rng, 1, 2) : 3;
+    }
     rec_t *v = &recs.r[lst[c][0][rng_int(&s->rng, 0, cnt[c][0] - 1)]];
     rec_t *j = &recs.r[lst[c][1][rng_int(&s->rng, 0, cnt[c][1] - 1)]];
     rec_t *cg = &recs.r[lst[c][2][rng_int(&s->rng, 0, cnt[c][2] - 1)]];
@@ -121,13 +129,16 @@ void *t4synth_open(const char *fasta, int nclones, uint64_t seed, int read_len) 
   }
   s->cdf = (double *)malloc(sizeof(double) * nclones);
   double tot = 0;
-  for (int k = 0; k < nclones; ++k) { tot += 1.0 / (k + 1); s->cdf[k] = tot; }
+  for (int k = 0; k < nclones; ++k) { tot += cells ? 1.0 : 1.0 / (k + 1); s->cdf[k] = tot; }
   for (int k = 0; k < nclones; ++k) s->cdf[k] /= tot;
   for (int c = 0; c < 5; ++c) for (int g = 0; g < 3; ++g) free(lst[c][g]);
   for (int i = 0; i < recs.n; ++i) free(recs.r[i].seq);
   free(recs.r);
   return s;
 }
+
+void *t4synth_open(const char *fasta, int nclones, uint64_t seed, int read_len) { return synth_open(fasta, nclones, seed, read_len, 0); }
+void *t4synth_open_cells(const char *fasta, int ncells, uint64_t seed, int read_len) { return synth_open(fasta, 2 * ncells, seed, read_len, 1); }
 
 void t4synth_close(void *h) {
   synth_t *s = (synth_t *)h;
@@ -137,7 +148,10 @@ void t4synth_close(void *h) {
 
 /* Fill n_pairs pairs. r1/r2: n_pairs * (read_len+1) bytes, NUL-terminated fixed-stride records.
  * The generator is stateful: successive calls continue the same stream. */
-void t4synth_next(void *h, int64_t n_pairs, char *r1, char *r2) {
+void t4synth_next_ex(void *h, int64_t n_pairs, char *r1, char *r2, int *clone_of);
+void t4synth_next(void *h, int64_t n_pairs, char *r1, char *r2) { t4synth_next_ex(h, n_pairs, r1, r2, NULL); }
+/* clone_of (optional): index of the clone every pair was drawn from (cell mode: cell = clone / 2) */
+void t4synth_next_ex(void *h, int64_t n_pairs, char *r1, char *r2, int *clone_of) {
   synth_t *s = (synth_t *)h;
   int L = s->read_len, stride = L + 1;
   char frag[512], tmp[512];
@@ -147,6 +161,7 @@ void t4synth_next(void *h, int64_t n_pairs, char *r1, char *r2) {
     int lo = 0, hi = s->nclones - 1;
     while (lo < hi) { int m = (lo + hi) / 2; if (s->cdf[m] < u) lo = m + 1; else hi = m; }
     clone_t *c = &s->clones[lo];
+    if (clone_of) clone_of[n] = lo;
     int flen = rng_int(&s->rng, 200, 420);
     if (flen > c->len) flen = c->len;
     if (flen < L) flen = L; /* transcripts are always > 150 bp for this reference */
@@ -165,24 +180,44 @@ void t4synth_next(void *h, int64_t n_pairs, char *r1, char *r2) {
 
 #ifdef T4SYNTH_MAIN
 int main(int argc, char **argv) {
-  if (argc < 6) { fprintf(stderr, "usage: %s ref.fa[.gz] n_pairs n_clones seed out_prefix [first_id]\n", argv[0]); return 1; }
+  if (argc < 6) { fprintf(stderr, "usage: %s ref.fa[.gz] n_pairs n_clones seed out_prefix [--cells N]\n", argv[0]); return 1; }
   int64_t n = atoll(argv[2]); int nclones = atoi(argv[3]); uint64_t seed = strtoull(argv[4], 0, 10);
-  void *h = t4synth_open(argv[1], nclones, seed, 150);
+  int ncells = (argc >= 8 && !strcmp(argv[6], "--cells")) ? atoi(argv[7]) : 0;
+  void *h = ncells ? t4synth_open_cells(argv[1], ncells, seed, 150) : t4synth_open(argv[1], nclones, seed, 150);
   if (!h) { fprintf(stderr, "cannot read %s\n", argv[1]); return 1; }
   char p1[1024], p2[1024];
   snprintf(p1, sizeof p1, "%s_1.fq", argv[5]); snprintf(p2, sizeof p2, "%s_2.fq", argv[5]);
-  FILE *f1 = fopen(p1, "w"), *f2 = fopen(p2, "w");
+  FILE *f1 = fopen(p1, "w"), *f2 = fopen(p2, "w"), *fb = NULL, *fu = NULL;
+  static const char ACGT[4] = {'A', 'C', 'G', 'T'};
+  rng_t urng; urng.s = seed * 77 + 5;
+  if (ncells) {
+    char pb[1024], pu[1024];
+    snprintf(pb, sizeof pb, "%s_bc.fa", argv[5]); snprintf(pu, sizeof pu, "%s_umi.fa", argv[5]);
+    fb = fopen(pb, "w"); fu = fopen(pu, "w");
+  }
   char q[151]; memset(q, 'I', 150); q[150] = 0;
   const int64_t B = 65536; char *r1 = (char *)malloc(B * 151), *r2 = (char *)malloc(B * 151);
+  int *cl = (int *)malloc(sizeof(int) * B);
   for (int64_t done = 0; done < n; done += B) {
     int64_t m = n - done < B ? n - done : B;
-    t4synth_next(h, m, r1, r2);
+    t4synth_next_ex(h, m, r1, r2, cl);
     for (int64_t i = 0; i < m; ++i) {
       fprintf(f1, "@r%lld\n%s\n+\n%s\n", (long long)(done + i), r1 + i * 151, q);
       fprintf(f2, "@r%lld\n%s\n+\n%s\n", (long long)(done + i), r2 + i * 151, q);
+      if (ncells) {
+        char bc[17], umi[11];
+        rng_t b; b.s = (uint64_t)(cl[i] / 2) * 0x9E3779B97F4A7C15ULL + seed;   /* the barcode is a function of the cell */
+        uint64_t x = rng_next(&b);
+        for (int t = 0; t < 16; ++t) bc[t] = ACGT[(x >> (2 * t)) & 3];
+        bc[16] = 0;
+        for (int t = 0; t < 10; ++t) umi[t] = ACGT[rng_int(&urng, 0, 3)];
+        umi[10] = 0;
+        fprintf(fb, ">r%lld\n%s\n", (long long)(done + i), bc);
+        fprintf(fu, ">r%lld\n%s\n", (long long)(done + i), umi);
+      }
     }
   }
-  fclose(f1); fclose(f2); t4synth_close(h);
+  fclose(f1); fclose(f2); if (fb) fclose(fb); if (fu) fclose(fu); t4synth_close(h);
   return 0;
 }
 #endif

@@ -645,6 +645,7 @@ int t4_overlaps(t4_index *ix, t4_batch *b, int strand, int skip_repeats, int max
   if ((r = ensurePerCall(c, b->n))) return r;
   if ((r = ensureResult(c, (size_t)b->n * max_per_read))) return r;
   T4QueryArgs qa;
+  memset(&qa, 0, sizeof qa);
   qa.mode = 0; qa.strand = strand; qa.skipRepeats = skip_repeats; qa.maxPerRead = max_per_read;
   qa.counts = c->counts; qa.out = c->result;
   if ((r = runQuery(ix, b, qa, true))) return r;
@@ -659,6 +660,7 @@ int t4_annotate_rough(t4_index *ref, t4_batch *b, t4_overlap *out) {
   int r;
   if ((r = ensureResult(c, (size_t)b->n * 4))) return r;
   T4QueryArgs qa;
+  memset(&qa, 0, sizeof qa);
   qa.mode = 1; qa.strand = 0; qa.skipRepeats = 0; qa.maxPerRead = 4; qa.counts = nullptr; qa.out = c->result;
   if ((r = runQuery(ref, b, qa, false))) return r;
   if (out && b->n) HIPCHK(c, hipMemcpy(out, c->result, sizeof(t4_overlap) * (size_t)b->n * 4, hipMemcpyDeviceToHost));
@@ -750,6 +752,7 @@ int t4_assign(t4_index *ix, t4_batch *b, int strand, int32_t *ret, t4_overlap *o
   if ((r = ensureResult(c, (size_t)b->n))) return r;
   T4QueryArgs qa;
   memset(&qa, 0, sizeof qa);
+  memset(&qa, 0, sizeof qa);
   qa.mode = 2; qa.strand = strand; qa.skipRepeats = 0; qa.maxPerRead = 1; qa.counts = nullptr; qa.out = c->result; qa.ret = c->counts;
   if ((r = runQuery(ix, b, qa, true))) return r;
   if (ret && b->n) HIPCHK(c, hipMemcpy(ret, c->counts, sizeof(int) * (size_t)b->n, hipMemcpyDeviceToHost));
@@ -776,6 +779,7 @@ int t4_extend(t4_index *ix, t4_batch *b, int max_per_read, const int32_t *counts
   HIPCHK(c, hipMemcpy(dCnt, counts, sizeof(int) * n, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemset(dRet, 0, sizeof(int) * m));
   T4QueryArgs qa;
+  memset(&qa, 0, sizeof qa);
   memset(&qa, 0, sizeof qa);
   qa.mode = 3; qa.maxPerRead = max_per_read; qa.out = c->result; qa.in = dIn; qa.inCounts = dCnt; qa.ret = dRet; qa.mismatchFactor = mismatch_factor;
   r = runQuery(ix, b, qa, true, true);
@@ -857,6 +861,7 @@ int addQueryImpl(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
   bv.pk = (const unsigned *)(c->aqIn + oPk); bv.nm = (const unsigned *)(c->aqIn + oNm); bv.len = (const int *)(c->aqIn + oLen);
   bv.barcode = (const int *)(c->aqIn + oBc); bv.wpk = wpk; bv.wnm = wnm; bv.n = n;
   T4QueryArgs qa;
+  memset(&qa, 0, sizeof qa);
   memset(&qa, 0, sizeof qa);
   qa.mode = 4; qa.skipRepeats = skip_repeats; qa.maxPerRead = max_per_read;
   qa.counts = (int *)(c->aqOut + pCnt); qa.out = (T4OverlapOut *)(c->aqOut + pOv); qa.outExt = (T4OverlapOut *)(c->aqOut + pEx);

@@ -9,8 +9,12 @@
 // (main.cpp:1262-1464), the per-read AddRead parameters and good-candidate propagation (main.cpp:1583-1880),
 // the rescue pass and the three output files. Written from the behaviour of those functions, not copied.
 //
-// Limits of this round: no --barcode/--UMI/-c/--debug-ns; `_final.out` is written as a copy of `_raw.out`
-// (the reference does the same under --skipMateExtension; its mate-graph extension tail is out of scope).
+// Barcode mode (--barcode [--UMI]; main.cpp:797-842, 1123-1193, 1549-1559, 1846-1859): every cell is an independent
+// contig set (t4_cellset), so the Add queries of many cells run in one launch ("lanes") while each cell's reads are
+// committed in the reference's order; outputs are those of the reference's cell-after-cell pass.
+// Limits of this round: no --keepNoBarcode/--contigMinCov/-c/--debug-ns; without barcodes `_final.out` is written as a
+// copy of `_raw.out` (the reference does the same under --skipMateExtension and always with barcodes; its mate-graph
+// extension tail is out of scope).
 #include <getopt.h>
 #include <math.h>
 #include <stdarg.h>
@@ -43,7 +47,9 @@ const char *USAGE =
     "\t--minHitLen INT: the minimal hit length for a valid overlap (default: auto)\n"
     "\t--skipMateExtension: accepted; _final.out is always the raw assembly in this build\n"
     "\t--trimLevel INT: 0: no trim; 1: trim low quality; 2: trim unmatched (default: 1)\n"
-    "\t--cgeneEnd INT: skipping reads mapped to C gene coordinate greater than INT (default: 200)\n";
+    "\t--cgeneEnd INT: skipping reads mapped to C gene coordinate greater than INT (default: 200)\n"
+    "\t--barcode STRING: the path to the barcode file (default: not used)\n"
+    "\t--UMI STRING: the path to the UMI file (default: not used)\n";
 
 void PrintLog(const char *fmt, ...) {
   char buf[2048], stime[256];
@@ -220,6 +226,8 @@ struct SortRead {
   int minCnt = 0, medianCnt = 0;
   float avgCnt = 0;
   int len = 0, strand = 0, mateIdx = -1, info = -1;
+  int barcode = -1, umi = -1, barcodeMinCnt = 0, barcodeMedianCnt = 0;
+  float barcodeAvgCnt = 0;
   t4_overlap g[4];
   bool operator<(const SortRead &b) const {   // main.cpp:103-125
     if (minCnt != b.minCnt) return minCnt > b.minCnt;
@@ -231,6 +239,12 @@ struct SortRead {
     return strcmp(id.c_str(), b.id.c_str()) < 0;
   }
 };
+
+bool compReadWithBarcode(const SortRead &a, const SortRead &b) {   // main.cpp:128-136
+  if (a.barcode != -1 && a.barcode != b.barcode) return a.barcode < b.barcode;
+  if (a.barcode != -1 && b.barcode != -1 && a.barcodeMinCnt != b.barcodeMinCnt) return a.barcodeMinCnt > b.barcodeMinCnt;
+  return a < b;
+}
 
 bool isLowComplexity(const std::string &s) {   // main.cpp:183-205
   int cnt[5] = {0, 0, 0, 0, 0};
@@ -355,8 +369,8 @@ int main(int argc, char *argv[]) {
                                          {(char *)0, 0, 0, 0}};
   int indexKmerLength = 9, changeKmerLengthThreshold = 4096, trimLevel = 1, minHitLen = -1, constantGeneEnd = 200;
   std::string refFa, outputPrefix = "trust";
-  SeqReader reads, mateReads;
-  bool hasMate = false;
+  SeqReader reads, mateReads, barcodeFile, umiFile;
+  bool hasMate = false, hasBarcode = false, hasUmi = false;
   int c, oi = 0;
   while ((c = getopt_long(argc, argv, "f:u:1:2:o:t:k:", long_options, &oi)) != -1) {
     if (c == 'f') refFa = optarg;
@@ -370,7 +384,9 @@ int main(int argc, char *argv[]) {
     else if (c == 10005) { /* always */ }
     else if (c == 10006) minHitLen = atoi(optarg);
     else if (c == 10008) constantGeneEnd = atoi(optarg);
-    else if (c == 10002 || c == 10003 || c == 10004 || c == 10007) { fprintf(stderr, "trust4-hip: barcode / UMI / contigMinCov modes are not built yet.\n"); return EXIT_FAILURE; }
+    else if (c == 10002) { barcodeFile.files.push_back(optarg); hasBarcode = true; }
+    else if (c == 10004) { umiFile.files.push_back(optarg); hasUmi = true; }
+    else if (c == 10003 || c == 10007) { fprintf(stderr, "trust4-hip: --keepNoBarcode / --contigMinCov are not built yet.\n"); return EXIT_FAILURE; }
     else { fprintf(stderr, "%s", USAGE); return EXIT_FAILURE; }
   }
   if (refFa.empty()) { fprintf(stderr, "Need to use -f to specify the receptor genome sequence.\n"); return EXIT_FAILURE; }
@@ -390,8 +406,29 @@ int main(int argc, char *argv[]) {
   KmerCounter kmerCount(21);
   std::vector<SortRead> sortedReads;
   int firstReadLen = -1, nIn = 0;
+  std::unordered_map<std::string, int> barcodeStrToInt, umiStrToInt;
+  std::vector<std::string> barcodeIntToStr;
   while (reads.next()) {
+    int barcode = -1, umi = -1;
+    if (hasBarcode) {   // main.cpp:799-828
+      barcodeFile.next();
+      if (barcodeFile.seq == "missing_barcode") {
+        if (hasMate) mateReads.next();
+        if (hasUmi) umiFile.next();
+        continue;
+      }
+      auto it = barcodeStrToInt.find(barcodeFile.seq);
+      if (it != barcodeStrToInt.end()) barcode = it->second;
+      else { barcode = (int)barcodeIntToStr.size(); barcodeStrToInt[barcodeFile.seq] = barcode; barcodeIntToStr.push_back(barcodeFile.seq); }
+    }
+    if (hasUmi) {       // main.cpp:831-842
+      umiFile.next();
+      auto it = umiStrToInt.find(umiFile.seq);
+      if (it != umiStrToInt.end()) umi = it->second;
+      else { umi = (int)umiStrToInt.size(); umiStrToInt[umiFile.seq] = umi; }
+    }
     SortRead nr, mate;
+    nr.barcode = mate.barcode = barcode; nr.umi = mate.umi = umi;
     nr.id = reads.id; nr.read = reads.seq; nr.qual = reads.qual; nr.hasQual = reads.hasQual;
     ++nIn;
     if (nIn % 100000 == 0) PrintLog("Read in and count kmers for %d reads.", nIn);
@@ -406,6 +443,9 @@ int main(int argc, char *argv[]) {
     processRead(nr, mate, haveMate, kmerCount, sortedReads);
   }
   int readCnt = (int)sortedReads.size();
+  int maxReadLen = 0;
+  for (const SortRead &r : sortedReads) if ((int)r.read.size() > maxReadLen) maxReadLen = (int)r.read.size();
+  kmerCount.maxReadLen = maxReadLen;   // KmerCount::SetBuffer (main.cpp:979)
   auto writeEmpty = [&](const char *suffix) { FILE *fp = fopen((outputPrefix + suffix).c_str(), "w"); if (fp) fclose(fp); };
   if (readCnt <= 0) { writeEmpty("_raw.out"); writeEmpty("_assembled_reads.fa"); writeEmpty("_final.out"); return 0; }
 
@@ -446,6 +486,30 @@ int main(int argc, char *argv[]) {
     }
   }
   PrintLog("Finish rough annotations.");
+
+  // ---- barcode order: by barcode, then by the barcode-wise 21-mer support (main.cpp:1123-1193)
+  if (hasBarcode) {
+    std::sort(sortedReads.begin(), sortedReads.end(), compReadWithBarcode);
+    PrintLog("Get barcode-wise kmer count.");
+    for (int i = 0; i < readCnt;) {
+      int j = i + 1;
+      while (j < readCnt && sortedReads[j].barcode == sortedReads[i].barcode) ++j;
+      KmerCounter bkc(21);
+      bkc.maxReadLen = maxReadLen;
+      for (int t = i; t < j; ++t) bkc.addCount(sortedReads[t].read);
+      for (int t = i; t < j; ++t)
+        bkc.statsAndTrim(sortedReads[t].read, nullptr, sortedReads[t].barcodeMinCnt, sortedReads[t].barcodeMedianCnt, sortedReads[t].barcodeAvgCnt);
+      i = j;
+    }
+    PrintLog("Finish barcode-wise kmer count.");
+    for (int i = 0; i < readCnt;) {
+      int j = i + 1;
+      while (j < readCnt && sortedReads[j].barcode == sortedReads[i].barcode) ++j;
+      if (j - i > 1) std::sort(sortedReads.begin() + i, sortedReads.begin() + j, compReadWithBarcode);
+      i = j;
+    }
+    PrintLog("Finish re-sorting the reads based on barcode.");
+  }
 
   // ---- mate links in sorted order, V / C trimming (main.cpp:1208-1526)
   std::vector<int> originToSorted(readCnt);
@@ -518,16 +582,26 @@ int main(int argc, char *argv[]) {
   }
 
   // ---- the assembly loop (main.cpp:1528-1880)
-  t4_assembler *seqSet = nullptr;
-  if ((rc = t4_assembler_create(ctx, indexKmerLength, 0, &seqSet))) die(ctx, "t4_assembler_create", rc);
+  t4_assembler *seqSet = nullptr;     // bulk mode: the one contig set
+  t4_cellset *cellSet = nullptr;      // barcode mode: one contig set per cell
   int hitLenRequired = 31;
   if (firstReadLen / 2 < 31) { int l = firstReadLen / 2; if (l < 21) l = 21; hitLenRequired = l; }
+  if (hasBarcode) hitLenRequired = 13;
   if (minHitLen != -1) hitLenRequired = minHitLen;
-  t4_assembler_set_params(seqSet, hitLenRequired, 10, 0.9);
+  if (hasBarcode) {
+    if (barcodeIntToStr.size() >= 1000003) { fprintf(stderr, "trust4-hip: more than 1000002 barcodes are not supported.\n"); return EXIT_FAILURE; }
+    if ((rc = t4_cellset_create(ctx, indexKmerLength, &cellSet))) die(ctx, "t4_cellset_create", rc);
+    t4_cellset_set_params(cellSet, hitLenRequired, 10, 0.9);
+  } else {
+    if ((rc = t4_assembler_create(ctx, indexKmerLength, 0, &seqSet))) die(ctx, "t4_assembler_create", rc);
+    t4_assembler_set_params(seqSet, hitLenRequired, 10, 0.9);
+  }
   if (trimLevel > 1) changeKmerLengthThreshold /= 2;
-  std::vector<int> rescueReadIdx, assembledReadIdx;
-  int assembledReadCnt = 0, prevAddRet = -1;
-  const int WINDOW = getenv("T4_WINDOW") ? atoi(getenv("T4_WINDOW")) : 16;
+  std::vector<int> barcodeTotalReadCount(barcodeIntToStr.size(), 0), barcodeReadCount(barcodeIntToStr.size(), 0);
+  if (hasBarcode) for (int i = 0; i < readCnt; ++i) if (sortedReads[i].barcode != -1) ++barcodeTotalReadCount[sortedReads[i].barcode];
+  int assembledReadCnt = 0;
+  const int WINDOW = getenv("T4_WINDOW") ? atoi(getenv("T4_WINDOW")) : (hasBarcode ? 4 : 16);
+  const int LANES = getenv("T4_LANES") ? atoi(getenv("T4_LANES")) : 4096;
 
   // AddRead arguments of read i that do not depend on the loop state (main.cpp:1609-1701)
   struct AddArgs { bool filter; char name[5]; int strand; double thr; };
@@ -554,30 +628,42 @@ int main(int argc, char *argv[]) {
     a.thr = 0.9;
     if (sortedReads[i].minCnt >= 20) a.thr = 0.97; else if (sortedReads[i].minCnt >= 2) a.thr = 0.95;
     if (a.name[0] == 'T' && a.thr < 0.95) a.thr = 0.95;
-    if (trimLevel > 1) a.thr = 0.9;
+    if (hasBarcode || trimLevel > 1) a.thr = 0.9;
     return a;
   };
-  auto isNewRead = [&](int i) { return i == 0 || sortedReads[i].read != sortedReads[i - 1].read; };
+  auto isNewRead = [&](int i) { return i == 0 || sortedReads[i].read != sortedReads[i - 1].read || sortedReads[i].barcode != sortedReads[i - 1].barcode; };
+  std::vector<t4_assembler *> cellOf;   // barcode mode: the cell of every read
+  if (hasBarcode) {
+    cellOf.resize(readCnt);
+    for (int i = 0; i < readCnt; ++i) if ((rc = t4_cellset_cell(cellSet, sortedReads[i].barcode, &cellOf[i]))) die(ctx, "t4_cellset_cell", rc);
+  }
+  auto setOf = [&](int i) { return hasBarcode ? cellOf[i] : seqSet; };
 
-  const t4_overlap *g = nullptr;   // the reference's `static geneOverlap[4]`: refreshed for new sequences only
-  for (int i = 0; i < readCnt; ++i) {
+  // One walk = a run of consecutive reads processed in order: the whole input in bulk mode, one cell (or a chain of
+  // cells whose boundary reads are identical, see below) in barcode mode.
+  struct Walk {
+    int begin = 0, end = 0, cur = 0, prevAddRet = -1;
+    const t4_overlap *g = nullptr;   // the reference's `static geneOverlap[4]`: refreshed for new sequences only
+    std::vector<int> rescue, assembledMain, assembledRescue;
+    size_t rcur = 0;
+    int phase = 0;   // 0 main pass, 1 rescue pass, 2 done
+  };
+  auto needsQuery = [&](int i) { return isNewRead(i) && !addArgs(i).filter; };
+
+  // main.cpp:1585-1870 for read w.cur
+  auto stepMain = [&](Walk &w) {
+    const int i = w.cur;
+    t4_assembler *set = setOf(i);
+    const int barcode = sortedReads[i].barcode;
     int addRet = -1;
     if (isNewRead(i)) {
-      g = sortedReads[i].g;
+      w.g = sortedReads[i].g;
+      const t4_overlap *g = w.g;
       AddArgs a = addArgs(i);
       if (!a.filter) {
-        if (WINDOW > 1 && !t4_assembler_window_valid(seqSet)) {   // speculate on the next distinct, unfiltered reads
-          std::vector<const char *> rs; std::vector<int> st;
-          for (int j = i; j < readCnt && (int)rs.size() < WINDOW; ++j) {
-            if (!isNewRead(j)) continue;
-            AddArgs b = addArgs(j);
-            if (b.filter) continue;
-            rs.push_back(sortedReads[j].read.c_str()); st.push_back(b.strand);
-          }
-          if ((rc = t4_assembler_prefetch(seqSet, (int)rs.size(), rs.data(), st.data(), nullptr, trimLevel > 1))) die(ctx, "t4_assembler_prefetch", rc);
-        }
         int strand = a.strand;
-        addRet = t4_assembler_add_read(seqSet, sortedReads[i].read.c_str(), a.name, &strand, -1, sortedReads[i].minCnt, trimLevel > 1, a.thr);
+        const int minKmerCount = hasBarcode ? (sortedReads[i].minCnt + sortedReads[i].barcodeMinCnt + 1) / 2 : sortedReads[i].minCnt;
+        addRet = t4_assembler_add_read(set, sortedReads[i].read.c_str(), a.name, &strand, barcode, minKmerCount, trimLevel > 1, a.thr);
         if (addRet < -50) die(ctx, "t4_assembler_add_read", addRet + 100);
         if (addRet < 0) {
           int matchCnt = 0;
@@ -589,23 +675,24 @@ int main(int argc, char *argv[]) {
           else if (g[2].seqIdx != -1) { if (g[2].seqStart <= 17) filter = false; }
           int j;
           for (j = 0; j < 4; ++j) if (g[j].seqIdx != -1) break;
-          if (!filter) addRet = t4_assembler_input_novel_read(seqSet, refName(g[j].seqIdx), sortedReads[i].read.c_str(), g[j].strand, -1);
+          if (!filter) addRet = t4_assembler_input_novel_read(set, refName(g[j].seqIdx), sortedReads[i].read.c_str(), g[j].strand, barcode);
           else if (goodCandidate[i]) {
             int ms = -sortedReads[sortedReads[i].info].strand;
-            if (hasMotif(sortedReads[i].read, ms)) addRet = t4_assembler_input_novel_read(seqSet, "Novel", sortedReads[i].read.c_str(), ms, -1);
+            if (hasMotif(sortedReads[i].read, ms)) addRet = t4_assembler_input_novel_read(set, "Novel", sortedReads[i].read.c_str(), ms, barcode);
           }
         }
         sortedReads[i].strand = strand;
       }
     } else {
-      if (prevAddRet != -1 && prevAddRet != -3) addRet = t4_assembler_repeat_add_read(seqSet, sortedReads[i].read.c_str());
-      else if (prevAddRet == -3) addRet = -3;
+      if (w.prevAddRet != -1 && w.prevAddRet != -3) addRet = t4_assembler_repeat_add_read(set, sortedReads[i].read.c_str());
+      else if (w.prevAddRet == -3) addRet = -3;
       sortedReads[i].strand = sortedReads[i - 1].strand;
     }
-    if (addRet == -2) rescueReadIdx.push_back(i);
+    const t4_overlap *g = w.g;
+    if (addRet == -2) w.rescue.push_back(i);
     else if (addRet >= 0) {
       ++assembledReadCnt;
-      assembledReadIdx.push_back(i);
+      w.assembledMain.push_back(i);
       if (sortedReads[i].mateIdx > i) {   // good-candidate propagation to the mate (main.cpp:1781-1843)
         bool good = false, maySpan = false;
         if (g[0].seqIdx != -1 && g[0].similarity >= 0.9 && sortedReads[i].strand == 1) {
@@ -620,53 +707,183 @@ int main(int argc, char *argv[]) {
           }
         if (maySpan) good = false;
         const int tag = sortedReads[i].mateIdx;
-        if (good && !goodCandidate[tag]) {
+        if (good && !goodCandidate[tag]) {   // the loops only compare sequences: they may run into the neighbouring cells
           for (int j = tag - 1; j > 0; --j) { if (sortedReads[j].read == sortedReads[tag].read) { goodCandidate[j] = 1; sortedReads[j].info = i; } else break; }
           for (int j = tag + 1; j < readCnt; ++j) { if (sortedReads[j].read == sortedReads[tag].read) { goodCandidate[j] = 1; sortedReads[j].info = i; } else break; }
         }
         if (good) { goodCandidate[tag] = 1; sortedReads[tag].info = i; }
       }
+      if (hasBarcode && barcode != -1) {   // a barcode whose every read was assembled leaves the index (main.cpp:1846-1859)
+        if (++barcodeReadCount[barcode] >= barcodeTotalReadCount[barcode]) t4_assembler_release_finished_barcode(set, barcode);
+      }
     }
-    if (assembledReadCnt > 0 && assembledReadCnt % 10000 == 0) t4_assembler_update_all_consensus(seqSet);
-    if ((i + 1) % 100000 == 0) PrintLog("Processed %d reads (%d are used for assembly).", i + 1, assembledReadCnt);
-    prevAddRet = addRet;
-    if (t4_assembler_size(seqSet) > changeKmerLengthThreshold && indexKmerLength < 16) {
-      changeKmerLengthThreshold *= 4;
-      indexKmerLength += 2;
-      t4_assembler_change_kmer_length(seqSet, indexKmerLength);
-    }
-  }
-  t4_assembler_update_all_consensus(seqSet);
-  PrintLog("Assembled %d reads.", assembledReadCnt);
-
-  // ---- rescue pass (main.cpp:1897-1940)
-  const int rescueReadCnt = (int)rescueReadIdx.size();
-  PrintLog("Try to rescue %d reads for assembly.", rescueReadCnt);
-  assembledReadCnt = 0;
-  for (int i = 0; i < rescueReadCnt; ++i) {
-    SortRead &sr = sortedReads[rescueReadIdx[i]];
+    w.prevAddRet = addRet;
+    ++w.cur;
+  };
+  // main.cpp:1904-1937 for rescue read w.rescue[w.rcur]
+  auto stepRescue = [&](Walk &w) {
+    const int idx = w.rescue[w.rcur++];
+    SortRead &sr = sortedReads[idx];
     double thr = 0.9;
     if (sr.minCnt >= 20) thr = 0.97; else if (sr.minCnt >= 2) thr = 0.95;
     int strand = 0;
-    int addRet = t4_assembler_add_read(seqSet, sr.read.c_str(), "", &strand, -1, 1, trimLevel > 1, thr);
+    int addRet = t4_assembler_add_read(setOf(idx), sr.read.c_str(), "", &strand, sr.barcode, 1, trimLevel > 1, thr);
     if (addRet < -50) die(ctx, "t4_assembler_add_read", addRet + 100);
     sr.strand = strand;
-    if (addRet >= 0) { ++assembledReadCnt; assembledReadIdx.push_back(rescueReadIdx[i]); }
+    if (addRet >= 0) { ++assembledReadCnt; w.assembledRescue.push_back(idx); }
+  };
+
+  std::vector<int> assembledReadIdx;
+  int rescueReadCnt = 0, rescuedCnt = 0;
+  int64_t laneBatches = 0, fallbackQueries = 0;
+  if (!hasBarcode) {
+    Walk w;
+    w.begin = 0; w.end = readCnt;
+    while (w.cur < w.end) {
+      const int i = w.cur;
+      if (WINDOW > 1 && needsQuery(i) && !t4_assembler_window_valid(seqSet)) {   // speculate on the next distinct, unfiltered reads
+        std::vector<const char *> rs; std::vector<int> st;
+        for (int j = i; j < readCnt && (int)rs.size() < WINDOW; ++j) {
+          if (!isNewRead(j)) continue;
+          AddArgs b = addArgs(j);
+          if (b.filter) continue;
+          rs.push_back(sortedReads[j].read.c_str()); st.push_back(b.strand);
+        }
+        if ((rc = t4_assembler_prefetch(seqSet, (int)rs.size(), rs.data(), st.data(), nullptr, trimLevel > 1))) die(ctx, "t4_assembler_prefetch", rc);
+      }
+      stepMain(w);
+      if (assembledReadCnt > 0 && assembledReadCnt % 10000 == 0) t4_assembler_update_all_consensus(seqSet);
+      if ((i + 1) % 100000 == 0) PrintLog("Processed %d reads (%d are used for assembly).", i + 1, assembledReadCnt);
+      if (t4_assembler_size(seqSet) > changeKmerLengthThreshold && indexKmerLength < 16) {
+        changeKmerLengthThreshold *= 4;
+        indexKmerLength += 2;
+        t4_assembler_change_kmer_length(seqSet, indexKmerLength);
+      }
+    }
+    t4_assembler_update_all_consensus(seqSet);
+    PrintLog("Assembled %d reads.", assembledReadCnt);
+    rescueReadCnt = (int)w.rescue.size();
+    PrintLog("Try to rescue %d reads for assembly.", rescueReadCnt);
+    const int before = assembledReadCnt;
+    while (w.rcur < w.rescue.size()) stepRescue(w);
+    rescuedCnt = assembledReadCnt - before;
+    t4_assembler_update_all_consensus(seqSet);
+    PrintLog("Rescued %d reads.", rescuedCnt);
+    assembledReadIdx = w.assembledMain;
+    assembledReadIdx.insert(assembledReadIdx.end(), w.assembledRescue.begin(), w.assembledRescue.end());
+  } else {
+    // Cells are independent contig sets (see t4_cellset in trust4_hip.h), so the reference's cell-after-cell pass can be
+    // replayed with many cells in flight: every round takes up to WINDOW upcoming AddRead reads of each active walk, queries
+    // them all in one launch, then lets every walk commit its reads in order. Per cell the sequence of calls is the
+    // reference's: main pass, UpdateAllConsensus, rescue reads, UpdateAllConsensus (main.cpp:1583-1940 with the passes of
+    // different cells interleaved, which they cannot observe). One coupling exists: the good-candidate propagation compares
+    // read sequences only and can cross into the next cell when the boundary reads are identical; such cells form one walk.
+    std::vector<Walk> walks;
+    for (int i = 0; i < readCnt;) {
+      int j = i + 1;
+      while (j < readCnt && (sortedReads[j].barcode == sortedReads[j - 1].barcode || sortedReads[j].read == sortedReads[j - 1].read)) ++j;
+      Walk w; w.begin = w.cur = i; w.end = j;
+      walks.push_back(w);
+      i = j;
+    }
+    size_t nextWalk = 0;
+    std::vector<int> active;
+    auto cellsOfWalkDone = [&](Walk &w) {   // its cells will not be queried again
+      for (int i = w.begin; i < w.end; ++i) if (i == w.begin || cellOf[i] != cellOf[i - 1]) t4_cellset_close_cell(cellSet, cellOf[i]);
+    };
+    auto finishMain = [&](Walk &w) {
+      for (int i = w.begin; i < w.end; ++i) if (i == w.begin || cellOf[i] != cellOf[i - 1]) t4_assembler_update_all_consensus(cellOf[i]);
+      w.phase = w.rescue.empty() ? 2 : 1;
+      if (w.phase == 2) cellsOfWalkDone(w);
+    };
+    while (nextWalk < walks.size() || !active.empty()) {
+      while (nextWalk < walks.size() && (int)active.size() < LANES) active.push_back((int)nextWalk++);
+      // the upcoming AddRead reads of every active walk
+      std::vector<t4_assembler *> qc; std::vector<const char *> qr; std::vector<int> qs;
+      std::vector<int> quota(active.size(), 0);
+      for (size_t a = 0; a < active.size(); ++a) {
+        Walk &w = walks[active[a]];
+        if (w.phase == 0) {
+          for (int j = w.cur; j < w.end && quota[a] < WINDOW; ++j) {
+            if (!isNewRead(j)) continue;
+            AddArgs b = addArgs(j);
+            if (b.filter) continue;
+            qc.push_back(cellOf[j]); qr.push_back(sortedReads[j].read.c_str()); qs.push_back(b.strand); ++quota[a];
+          }
+        } else {
+          for (size_t j = w.rcur; j < w.rescue.size() && quota[a] < WINDOW; ++j) {
+            qc.push_back(cellOf[w.rescue[j]]); qr.push_back(sortedReads[w.rescue[j]].read.c_str()); qs.push_back(0); ++quota[a];
+          }
+        }
+      }
+      if (!qc.empty()) {
+        if ((rc = t4_cellset_prefetch(cellSet, (int)qc.size(), qc.data(), qr.data(), qs.data(), trimLevel > 1))) die(ctx, "t4_cellset_prefetch", rc);
+        ++laneBatches;
+      }
+      // commit, walk by walk, what was queried (reads that need no query ride along)
+      std::vector<int> still;
+      for (size_t a = 0; a < active.size(); ++a) {
+        Walk &w = walks[active[a]];
+        int left = quota[a];
+        if (w.phase == 0) {
+          while (w.cur < w.end) {
+            if (needsQuery(w.cur)) {   // never fall back to a one-read launch: a read whose cached query a commit invalidated waits for the next round
+              if (left == 0 || !t4_assembler_window_valid(cellOf[w.cur])) break;
+              --left;
+            }
+            stepMain(w);
+          }
+          if (w.cur >= w.end) finishMain(w);
+        } else if (w.phase == 1) {
+          while (w.rcur < w.rescue.size() && left > 0 && t4_assembler_window_valid(cellOf[w.rescue[w.rcur]])) { stepRescue(w); --left; }
+          if (w.rcur >= w.rescue.size()) {
+            for (int i = w.begin; i < w.end; ++i) if (i == w.begin || cellOf[i] != cellOf[i - 1]) t4_assembler_update_all_consensus(cellOf[i]);
+            w.phase = 2;
+            cellsOfWalkDone(w);
+          }
+        }
+        if (w.phase != 2) still.push_back(active[a]);
+      }
+      active.swap(still);
+    }
+    int mainCnt = 0;
+    for (Walk &w : walks) { assembledReadIdx.insert(assembledReadIdx.end(), w.assembledMain.begin(), w.assembledMain.end()); mainCnt += (int)w.assembledMain.size(); rescueReadCnt += (int)w.rescue.size(); }
+    for (Walk &w : walks) { assembledReadIdx.insert(assembledReadIdx.end(), w.assembledRescue.begin(), w.assembledRescue.end()); rescuedCnt += (int)w.assembledRescue.size(); }
+    PrintLog("Assembled %d reads.", mainCnt);
+    PrintLog("Try to rescue %d reads for assembly.", rescueReadCnt);
+    PrintLog("Rescued %d reads.", rescuedCnt);
   }
-  t4_assembler_update_all_consensus(seqSet);
-  PrintLog("Rescued %d reads.", assembledReadCnt);
 
   // ---- outputs (main.cpp:1959-2036)
-  if ((rc = t4_assembler_output(seqSet, (outputPrefix + "_raw.out").c_str()))) die(ctx, "t4_assembler_output", rc);
+  std::vector<const char *> bnames;
+  for (const std::string &b : barcodeIntToStr) bnames.push_back(b.c_str());
+  auto writeSet = [&](const std::string &path) {
+    if (hasBarcode) { if ((rc = t4_cellset_output(cellSet, path.c_str(), bnames.data(), (int)bnames.size()))) die(ctx, "t4_cellset_output", rc); }
+    else if ((rc = t4_assembler_output(seqSet, path.c_str()))) die(ctx, "t4_assembler_output", rc);
+  };
+  writeSet(outputPrefix + "_raw.out");
   {
     FILE *fp = fopen((outputPrefix + "_assembled_reads.fa").c_str(), "w");
     for (int idx : assembledReadIdx) {
       const SortRead &sr = sortedReads[idx];
-      fprintf(fp, ">%s %d %d %d\n%s\n", sr.id.c_str(), sr.strand, sr.minCnt, sr.medianCnt, sr.read.c_str());
+      std::string extra;
+      if (hasBarcode) extra += " barcode:" + barcodeIntToStr[sr.barcode];
+      if (hasUmi) extra += " umi:" + std::to_string(sr.umi);
+      fprintf(fp, ">%s %d %d %d%s\n%s\n", sr.id.c_str(), sr.strand, sr.minCnt, sr.medianCnt, extra.c_str(), sr.read.c_str());
     }
     fclose(fp);
   }
-  if ((rc = t4_assembler_output(seqSet, (outputPrefix + "_final.out").c_str()))) die(ctx, "t4_assembler_output", rc);
+  writeSet(outputPrefix + "_final.out");
+  if (hasBarcode) {
+    int64_t qb = 0, rq = 0, im = 0, by = 0; double sq = 0, ss = 0;
+    t4_cellset_counters(cellSet, &qb, &rq, &im, &by, &sq, &ss);
+    PrintLog("Finish assembly. (%lld cells; GPU query batches %lld with %lld reads in %.2f s; %lld cell images, %.1f MB, staged in %.2f s)",
+             (long long)barcodeIntToStr.size(), (long long)qb, (long long)rq, sq, (long long)im, by / 1e6, ss);
+    t4_cellset_destroy(cellSet);
+    t4_index_destroy(refSet);
+    t4_destroy(ctx);
+    return 0;
+  }
   int64_t q = 0, rf = 0, wh = 0;
   t4_assembler_counters(seqSet, &q, &rf, &wh);
   double sr = 0, sq = 0;
