@@ -197,7 +197,8 @@ int t4_cellset_set_params(t4_cellset *cs, int hit_len_required, int radius, doub
 int t4_cellset_cell(t4_cellset *cs, int barcode, t4_assembler **cell);   /* get or create */
 int t4_cellset_close_cell(t4_cellset *cs, t4_assembler *cell);           /* no more queries: recycle its device slot */
 /* read i is the next read cells[i] will be offered by t4_assembler_add_read (strand argument strands[i]); a cell may
- * appear several times, in the order its reads will come (its speculation window, validity tracked as above). */
+ * contribute several CONSECUTIVE entries, in the order its reads will come (its speculation window: it stands until a
+ * commit changes anything a query of that cell can observe). */
 int t4_cellset_prefetch(t4_cellset *cs, int n, t4_assembler *const *cells, const char *const *reads, const int *strands,
                         int repetitive_data);
 int t4_cellset_update_all_consensus(t4_cellset *cs);

@@ -1054,22 +1054,15 @@ int t4_cellstore_close(t4_cellstore *cs, int slot) {
 }
 
 int t4_cellstore_stage(t4_cellstore *cs, int slot, int barcode, int nseq, const char *const *names, const char *const *cons,
-                       const int32_t *const *pw, int64_t npost, const uint64_t *code, const int32_t *bucket, const int32_t *idx,
-                       const int32_t *offset) {
-  if (!cs || slot < 0 || slot >= (int)cs->slots.size() || !cs->slots[slot].live || nseq < 0 || npost < 0) return T4_ERR_ARG;
+                       const int32_t *const *pw, int64_t nkeys64, const uint64_t *keyCode, const int32_t *keyBucket, const int32_t *keyCnt,
+                       const int32_t *postIn) {
+  if (!cs || slot < 0 || slot >= (int)cs->slots.size() || !cs->slots[slot].live || nseq < 0 || nkeys64 < 0) return T4_ERR_ARG;
   t4_ctx *c = cs->ctx;
   (void)hipSetDevice(c->device);
   if (nseq > T4_MAX_SEQS) return fail(c, T4_ERR_UNSUPPORTED, "more than %d sequences in one barcode", T4_MAX_SEQS);
-  // order of the postings inside a list is the host replica's; lists are grouped by a stable sort on (code, bucket)
-  std::vector<int> order((size_t)npost);
-  for (int64_t i = 0; i < npost; ++i) order[(size_t)i] = (int)i;
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return code[a] != code[b] ? code[a] < code[b] : bucket[a] < bucket[b]; });
-  size_t nkeys = 0;
-  for (size_t i = 0; i < order.size();) {
-    size_t j = i;
-    while (j < order.size() && code[order[j]] == code[order[i]] && bucket[order[j]] == bucket[order[i]]) ++j;
-    ++nkeys; i = j;
-  }
+  const size_t nkeys = (size_t)nkeys64;
+  int64_t npost = 0;
+  for (size_t i = 0; i < nkeys; ++i) npost += keyCnt[i];
   size_t sz = 64;
   while (sz < 2 * nkeys + 2) sz <<= 1;
   size_t consBytes = 0, pwCount = 0;
@@ -1114,20 +1107,19 @@ int t4_cellstore_stage(t4_cellstore *cs, int slot, int barcode, int nseq, const 
   for (size_t i = 0; i < sz; ++i) ht[i].h = -1;
   int2 *post = (int2 *)(b + oPost);
   const unsigned long long hashMask = sz - 1;
-  for (size_t i = 0; i < order.size();) {
-    size_t j = i;
-    const unsigned long long cd = code[order[i]];
-    const int hb = bucket[order[i]];
-    while (j < order.size() && code[order[j]] == cd && bucket[order[j]] == hb) {
-      const int o = order[j];
-      if (idx[o] < 0 || idx[o] >= nseq) return fail(c, T4_ERR_ARG, "posting names sequence %d of %d", idx[o], nseq);
-      post[j] = make_int2(idx[o], offset[o]);
-      ++j;
+  size_t at = 0;
+  for (size_t i = 0; i < nkeys; ++i) {
+    const unsigned long long cd = keyCode[i];
+    const int hb = keyBucket[i], cnt = keyCnt[i];
+    for (int j = 0; j < cnt; ++j) {
+      const int id = postIn[2 * (at + j)];
+      if (id < 0 || id >= nseq) return fail(c, T4_ERR_ARG, "posting names sequence %d of %d", id, nseq);
+      post[at + j] = make_int2(id, postIn[2 * (at + j) + 1]);
     }
     unsigned long long s = t4k::mix64(cd * 1000003ull + (unsigned long long)hb) & hashMask;
     while (ht[s].h >= 0) s = (s + 1) & hashMask;
-    ht[s].code = cd; ht[s].h = hb; ht[s].start = (unsigned)i; ht[s].cnt = (unsigned)(j - i);
-    i = j;
+    ht[s].code = cd; ht[s].h = hb; ht[s].start = (unsigned)at; ht[s].cnt = (unsigned)cnt;
+    at += (size_t)cnt;
   }
   T4SeqInfo *infos = (T4SeqInfo *)(b + oSeq);
   int4 *pwOut = (int4 *)(b + oPw);

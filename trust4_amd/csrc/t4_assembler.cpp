@@ -197,6 +197,7 @@ struct t4_assembler : InsertHook {
   t4_index *dev = nullptr;   // device image of the current set
   t4_cellset *owner = nullptr;   // cell of a per-barcode set: the image lives in the owner's arena slot
   int slot = -1, cellBarcode = -1;
+  int64_t windowStamp = -1;
   bool dirty = true;
   int k, radius = 10, hitLenRequired = 31;
   double novelSim = 0.9;
@@ -220,6 +221,7 @@ struct t4_assembler : InsertHook {
   void dropWindow() { cache.clear(); cacheHead = 0; winKmers.clear(); winContigs.clear(); }
   void invalidateSlot(int slot) { if (slot >= (int)cacheHead && slot < (int)cache.size() && cache[slot].valid) { cache[slot].valid = false; ++invalidations; } }
   void onInsert(uint64_t code, int h) override {
+    if (owner) { for (size_t q = cacheHead; q < cache.size(); ++q) invalidateSlot((int)q); return; }
     if (winKmers.empty()) return;
     auto it = winKmers.find(Key{code, h});
     if (it != winKmers.end()) for (int slot : it->second) invalidateSlot(slot);
@@ -227,6 +229,8 @@ struct t4_assembler : InsertHook {
   // contig c changed in a way a query can observe (consensus, length, postings, an IsBaseEqual state of a column)
   void structuralChange(int c) {
     dirty = true;
+    // a cell holds a handful of contigs which almost every read of the cell hits: any observable change ends its window
+    if (owner) { for (size_t q = cacheHead; q < cache.size(); ++q) invalidateSlot((int)q); return; }
     if (winContigs.empty()) return;
     auto it = winContigs.find(c);
     if (it != winContigs.end()) for (int slot : it->second) invalidateSlot(slot);
@@ -685,7 +689,7 @@ struct t4_cellset {
   int k = 9, hitLenRequired = 31, radius = 10;
   double novelSim = 0.9;
   std::map<int, t4_assembler *> cells;   // by barcode id == the reference's processing order of the cells
-  int64_t queries = 0, stagedImages = 0, readsQueried = 0;
+  int64_t queries = 0, stagedImages = 0, readsQueried = 0, batchSeq = 0;
   double secQuery = 0, secStage = 0;
   std::string err;
 };
@@ -705,12 +709,15 @@ int t4_assembler::stageImage() {
     cons[i] = gone ? "" : q.cons.c_str();
     pw[i] = (gone || q.pw.empty()) ? nullptr : (const int32_t *)q.pw.data();
   }
-  std::vector<uint64_t> code; std::vector<int32_t> bucket, idx, off;
-  code.reserve(index.total); bucket.reserve(index.total); idx.reserve(index.total); off.reserve(index.total);
-  for (const auto &kv : index.map)
-    for (const Post &p : kv.second) { code.push_back(kv.first.code); bucket.push_back(kv.first.h); idx.push_back(p.idx); off.push_back(p.offset); }
-  r = t4_cellstore_stage(owner->store, slot, cellBarcode, n, names.data(), cons.data(), pw.data(), (int64_t)code.size(), code.data(),
-                         bucket.data(), idx.data(), off.data());
+  // one list per (code, bucket) key, postings in the replica's order; the order of the keys does not matter to a hash table
+  static thread_local std::vector<uint64_t> keyCode; static thread_local std::vector<int32_t> keyBucket, keyCnt, post;
+  keyCode.clear(); keyBucket.clear(); keyCnt.clear(); post.clear();
+  for (const auto &kv : index.map) {
+    keyCode.push_back(kv.first.code); keyBucket.push_back(kv.first.h); keyCnt.push_back((int32_t)kv.second.size());
+    for (const Post &p : kv.second) { post.push_back(p.idx); post.push_back(p.offset); }
+  }
+  r = t4_cellstore_stage(owner->store, slot, cellBarcode, n, names.data(), cons.data(), pw.data(), (int64_t)keyCode.size(), keyCode.data(),
+                         keyBucket.data(), keyCnt.data(), post.data());
   owner->secStage += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (r) return r;
   dirty = false; ++refreshes; ++owner->stagedImages;
@@ -731,7 +738,7 @@ void t4_assembler::beginWindow(int n, const char *const *reads, const int *stran
 // copy of the index (both strands, every valid k-mer)
 void t4_assembler::endWindow(const int32_t *cnts, const t4_overlap *ov, const t4_overlap *ex, const int32_t *rets, int stride) {
   const int n = (int)cache.size();
-  if (n > 1) {
+  if (n > 1 && !owner) {
     std::string rcs;
     for (int q = 0; q < n; ++q) {
       const Cached &c = cache[q];
@@ -936,39 +943,38 @@ int t4_cellset_close_cell(t4_cellset *cs, t4_assembler *cell) {   // no further 
   return T4_OK;
 }
 
-// One query batch for reads of many cells: read i is the next read cells[i] will be offered (a cell may appear several
-// times, in the order its reads will come: that is the cell's speculation window).
+// One query batch for reads of many cells: read i is the next read cells[i] will be offered (a cell may contribute several
+// consecutive reads, in the order they will come: that is the cell's speculation window).
 int t4_cellset_prefetch(t4_cellset *cs, int n, t4_assembler *const *cells, const char *const *reads, const int *strands, int repetitive_data) {
   if (!cs || n < 0 || (n > 0 && (!cells || !reads || !strands))) return T4_ERR_ARG;
   const int MAXOV = 128;
   const int rep = repetitive_data ? 1 : 0;
-  // group by cell, keeping the order within a cell
-  std::vector<t4_assembler *> order;
-  std::unordered_map<t4_assembler *, std::vector<int>> byCell;
-  for (int i = 0; i < n; ++i) {
-    if (!cells[i] || cells[i]->owner != cs) return T4_ERR_ARG;
-    auto &v = byCell[cells[i]];
-    if (v.empty()) order.push_back(cells[i]);
-    v.push_back(i);
-  }
+  ++cs->batchSeq;
+  // the reads of one cell must be consecutive (its speculation window, in the order they will be offered)
   int rc;
   std::string bases; std::vector<int64_t> offs(1, 0); std::vector<int32_t> bcs, sts, slots; std::vector<double> fac;
   struct Span { t4_assembler *cell; int first, count; bool queried; };
   std::vector<Span> spans;
-  for (t4_assembler *cell : order) {
-    const std::vector<int> &ids = byCell[cell];
-    std::vector<const char *> rs; std::vector<int> st, bc;
-    for (int i : ids) { rs.push_back(reads[i]); st.push_back(strands[i]); bc.push_back(cell->cellBarcode); }
-    cell->beginWindow((int)ids.size(), rs.data(), st.data(), bc.data(), rep);
-    Span sp{cell, (int)sts.size(), (int)ids.size(), cell->index.total > 0};
+  std::vector<const char *> rs; std::vector<int> st, bc;
+  for (int i = 0; i < n;) {
+    t4_assembler *cell = cells[i];
+    if (!cell || cell->owner != cs) return T4_ERR_ARG;
+    int j = i;
+    rs.clear(); st.clear(); bc.clear();
+    while (j < n && cells[j] == cell) { rs.push_back(reads[j]); st.push_back(strands[j]); bc.push_back(cell->cellBarcode); ++j; }
+    if (cell->windowStamp == cs->batchSeq) return T4_ERR_ARG;   // the cell appeared earlier in this batch
+    cell->windowStamp = cs->batchSeq;
+    cell->beginWindow(j - i, rs.data(), st.data(), bc.data(), rep);
+    Span sp{cell, (int)sts.size(), j - i, cell->index.total > 0};
     if (sp.queried) {   // an empty index has no hit for anybody: GetOverlapsFromRead returns 0 without a launch
       if ((rc = cell->stageImage())) { cs->err = t4_last_error(cs->ctx); return rc; }
-      for (int i : ids) {
-        bases += reads[i]; offs.push_back((int64_t)bases.size()); bcs.push_back(cell->cellBarcode); sts.push_back(strands[i]);
+      for (int t = i; t < j; ++t) {
+        bases += reads[t]; offs.push_back((int64_t)bases.size()); bcs.push_back(cell->cellBarcode); sts.push_back(strands[t]);
         slots.push_back(cell->slot); fac.push_back(2.0);   // ExtendOverlap's mismatch factor with a barcode (SeqSet.hpp:3597-3598)
       }
     }
     spans.push_back(sp);
+    i = j;
   }
   const int m = (int)sts.size();
   std::vector<t4_overlap> ov((size_t)m * MAXOV), ex((size_t)m * MAXOV);
@@ -978,9 +984,10 @@ int t4_cellset_prefetch(t4_cellset *cs, int n, t4_assembler *const *cells, const
     rc = t4_cellstore_query(cs->store, m, slots.data(), bases.data(), offs.data(), bcs.data(), sts.data(), rep, fac.data(), MAXOV,
                             cnts.data(), ov.data(), ex.data(), rets.data());
     cs->secQuery += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    ++cs->queries; cs->readsQueried += m;
+    cs->readsQueried += m;
     if (rc) { for (Span &sp : spans) sp.cell->dropWindow(); return rc; }
   }
+  ++cs->queries;
   for (Span &sp : spans) {
     if (sp.queried) { sp.cell->endWindow(cnts.data() + sp.first, ov.data() + (size_t)sp.first * MAXOV, ex.data() + (size_t)sp.first * MAXOV, rets.data() + (size_t)sp.first * MAXOV, MAXOV); ++sp.cell->queries; }
     else sp.cell->endWindow(nullptr, nullptr, nullptr, nullptr, MAXOV);

@@ -16,11 +16,12 @@ void t4_cellstore_destroy(t4_cellstore *cs);
 int t4_cellstore_set_params(t4_cellstore *cs, int hit_len_required, int radius, double novel_seq_similarity);
 int t4_cellstore_open(t4_cellstore *cs, int *slot);
 int t4_cellstore_close(t4_cellstore *cs, int slot);
-// Queue the new image of one cell. names/cons: nseq C strings ("" for released slots), pw: 4 counts per base
-// concatenated over the sequences; postings as (code, bucket, idx, offset) with idx local to the cell.
+// Queue the new image of one cell. names/cons: nseq C strings ("" for released slots), pw[i]: 4 counts per base of
+// sequence i; the index as nkeys lists: key (key_code, key_bucket) owns the next key_cnt (idx, offset) pairs of `post`
+// (idx local to the cell, list order = the order KmerIndex holds them in).
 int t4_cellstore_stage(t4_cellstore *cs, int slot, int barcode, int nseq, const char *const *names, const char *const *cons,
-                       const int32_t *const *pw, int64_t npost, const uint64_t *code, const int32_t *bucket,
-                       const int32_t *idx, const int32_t *offset);
+                       const int32_t *const *pw, int64_t nkeys, const uint64_t *key_code, const int32_t *key_bucket,
+                       const int32_t *key_cnt, const int32_t *post);
 // Flush the staged images, then run the AddRead query (== t4_add_query) of read i against the image of slot[i].
 int t4_cellstore_query(t4_cellstore *cs, int n, const int32_t *slots, const char *bases, const int64_t *offsets,
                        const int32_t *barcodes, const int32_t *strands, int skip_repeats, const double *factors,

@@ -25,6 +25,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -788,6 +789,9 @@ int main(int argc, char *argv[]) {
     }
     size_t nextWalk = 0;
     std::vector<int> active;
+    double secCollect = 0, secPrefetch = 0, secCommit = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
     auto cellsOfWalkDone = [&](Walk &w) {   // its cells will not be queried again
       for (int i = w.begin; i < w.end; ++i) if (i == w.begin || cellOf[i] != cellOf[i - 1]) t4_cellset_close_cell(cellSet, cellOf[i]);
     };
@@ -799,6 +803,7 @@ int main(int argc, char *argv[]) {
     while (nextWalk < walks.size() || !active.empty()) {
       while (nextWalk < walks.size() && (int)active.size() < LANES) active.push_back((int)nextWalk++);
       // the upcoming AddRead reads of every active walk
+      auto tc0 = now();
       std::vector<t4_assembler *> qc; std::vector<const char *> qr; std::vector<int> qs;
       std::vector<int> quota(active.size(), 0);
       for (size_t a = 0; a < active.size(); ++a) {
@@ -816,11 +821,15 @@ int main(int argc, char *argv[]) {
           }
         }
       }
+      secCollect += since(tc0);
+      auto tp0 = now();
       if (!qc.empty()) {
         if ((rc = t4_cellset_prefetch(cellSet, (int)qc.size(), qc.data(), qr.data(), qs.data(), trimLevel > 1))) die(ctx, "t4_cellset_prefetch", rc);
         ++laneBatches;
       }
+      secPrefetch += since(tp0);
       // commit, walk by walk, what was queried (reads that need no query ride along)
+      auto tm0 = now();
       std::vector<int> still;
       for (size_t a = 0; a < active.size(); ++a) {
         Walk &w = walks[active[a]];
@@ -845,7 +854,9 @@ int main(int argc, char *argv[]) {
         if (w.phase != 2) still.push_back(active[a]);
       }
       active.swap(still);
+      secCommit += since(tm0);
     }
+    PrintLog("Assembly rounds: %lld (collect %.2f s, query batches incl. image staging %.2f s, ordered commits %.2f s).", (long long)laneBatches, secCollect, secPrefetch, secCommit);
     int mainCnt = 0;
     for (Walk &w : walks) { assembledReadIdx.insert(assembledReadIdx.end(), w.assembledMain.begin(), w.assembledMain.end()); mainCnt += (int)w.assembledMain.size(); rescueReadCnt += (int)w.rescue.size(); }
     for (Walk &w : walks) { assembledReadIdx.insert(assembledReadIdx.end(), w.assembledRescue.begin(), w.assembledRescue.end()); rescuedCnt += (int)w.assembledRescue.size(); }
