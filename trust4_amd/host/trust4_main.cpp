@@ -50,7 +50,9 @@ const char *USAGE =
     "\t--trimLevel INT: 0: no trim; 1: trim low quality; 2: trim unmatched (default: 1)\n"
     "\t--cgeneEnd INT: skipping reads mapped to C gene coordinate greater than INT (default: 200)\n"
     "\t--barcode STRING: the path to the barcode file (default: not used)\n"
-    "\t--UMI STRING: the path to the UMI file (default: not used)\n";
+    "\t--UMI STRING: the path to the UMI file (default: not used)\n"
+    "Extension (multi-GPU, see trust4_amd/stage1_dist.py):\n"
+    "\t--cellShard R/N: barcode mode only; assemble the R-th of N contiguous ranges of cells, write shard outputs\n";
 
 void PrintLog(const char *fmt, ...) {
   char buf[2048], stime[256];
@@ -367,8 +369,10 @@ int main(int argc, char *argv[]) {
                                          {"minHitLen", required_argument, 0, 10006}, {"cgeneEnd", required_argument, 0, 10008},
                                          {"barcode", required_argument, 0, 10002}, {"UMI", required_argument, 0, 10004},
                                          {"keepNoBarcode", no_argument, 0, 10003}, {"contigMinCov", required_argument, 0, 10007},
+                                         {"cellShard", required_argument, 0, 10100},
                                          {(char *)0, 0, 0, 0}};
   int indexKmerLength = 9, changeKmerLengthThreshold = 4096, trimLevel = 1, minHitLen = -1, constantGeneEnd = 200;
+  int shardRank = 0, shardCount = 1;
   std::string refFa, outputPrefix = "trust";
   SeqReader reads, mateReads, barcodeFile, umiFile;
   bool hasMate = false, hasBarcode = false, hasUmi = false;
@@ -387,10 +391,12 @@ int main(int argc, char *argv[]) {
     else if (c == 10008) constantGeneEnd = atoi(optarg);
     else if (c == 10002) { barcodeFile.files.push_back(optarg); hasBarcode = true; }
     else if (c == 10004) { umiFile.files.push_back(optarg); hasUmi = true; }
+    else if (c == 10100) { if (sscanf(optarg, "%d/%d", &shardRank, &shardCount) != 2 || shardCount < 1 || shardRank < 0 || shardRank >= shardCount) { fprintf(stderr, "--cellShard takes R/N with 0 <= R < N\n"); return EXIT_FAILURE; } }
     else if (c == 10003 || c == 10007) { fprintf(stderr, "trust4-hip: --keepNoBarcode / --contigMinCov are not built yet.\n"); return EXIT_FAILURE; }
     else { fprintf(stderr, "%s", USAGE); return EXIT_FAILURE; }
   }
   if (refFa.empty()) { fprintf(stderr, "Need to use -f to specify the receptor genome sequence.\n"); return EXIT_FAILURE; }
+  if (shardCount > 1 && !hasBarcode) { fprintf(stderr, "--cellShard needs --barcode: without barcodes the Add pass does not shard (DESIGN.md 6).\n"); return EXIT_FAILURE; }
 
   t4_ctx *ctx = nullptr;
   int rc = t4_init(getenv("T4_DEVICE") ? atoi(getenv("T4_DEVICE")) : 0, &ctx);
@@ -633,11 +639,7 @@ int main(int argc, char *argv[]) {
     return a;
   };
   auto isNewRead = [&](int i) { return i == 0 || sortedReads[i].read != sortedReads[i - 1].read || sortedReads[i].barcode != sortedReads[i - 1].barcode; };
-  std::vector<t4_assembler *> cellOf;   // barcode mode: the cell of every read
-  if (hasBarcode) {
-    cellOf.resize(readCnt);
-    for (int i = 0; i < readCnt; ++i) if ((rc = t4_cellset_cell(cellSet, sortedReads[i].barcode, &cellOf[i]))) die(ctx, "t4_cellset_cell", rc);
-  }
+  std::vector<t4_assembler *> cellOf;   // barcode mode: the cell of every read this process assembles
   auto setOf = [&](int i) { return hasBarcode ? cellOf[i] : seqSet; };
 
   // One walk = a run of consecutive reads processed in order: the whole input in bulk mode, one cell (or a chain of
@@ -787,7 +789,20 @@ int main(int argc, char *argv[]) {
       walks.push_back(w);
       i = j;
     }
-    size_t nextWalk = 0;
+    size_t nextWalk = 0, endWalk = walks.size();
+    if (shardCount > 1) {   // contiguous ranges of walks with about the same number of reads
+      auto bound = [&](int r) {
+        const long long target = (long long)readCnt * r / shardCount;
+        size_t wI = 0;
+        while (wI < walks.size() && walks[wI].begin < target) ++wI;
+        return wI;
+      };
+      nextWalk = bound(shardRank); endWalk = bound(shardRank + 1);
+    }
+    const size_t firstWalk = nextWalk;
+    cellOf.assign(readCnt, nullptr);
+    for (size_t wI = firstWalk; wI < endWalk; ++wI)
+      for (int i = walks[wI].begin; i < walks[wI].end; ++i) if ((rc = t4_cellset_cell(cellSet, sortedReads[i].barcode, &cellOf[i]))) die(ctx, "t4_cellset_cell", rc);
     std::vector<int> active;
     double secCollect = 0, secPrefetch = 0, secCommit = 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -800,8 +815,8 @@ int main(int argc, char *argv[]) {
       w.phase = w.rescue.empty() ? 2 : 1;
       if (w.phase == 2) cellsOfWalkDone(w);
     };
-    while (nextWalk < walks.size() || !active.empty()) {
-      while (nextWalk < walks.size() && (int)active.size() < LANES) active.push_back((int)nextWalk++);
+    while (nextWalk < endWalk || !active.empty()) {
+      while (nextWalk < endWalk && (int)active.size() < LANES) active.push_back((int)nextWalk++);
       // the upcoming AddRead reads of every active walk
       auto tc0 = now();
       std::vector<t4_assembler *> qc; std::vector<const char *> qr; std::vector<int> qs;
@@ -873,9 +888,16 @@ int main(int argc, char *argv[]) {
     else if ((rc = t4_assembler_output(seqSet, path.c_str()))) die(ctx, "t4_assembler_output", rc);
   };
   writeSet(outputPrefix + "_raw.out");
+  size_t nMainAssembled = assembledReadIdx.size();
+  if (shardCount > 1) nMainAssembled -= (size_t)rescuedCnt;
   {
     FILE *fp = fopen((outputPrefix + "_assembled_reads.fa").c_str(), "w");
+    size_t nWritten = 0;
     for (int idx : assembledReadIdx) {
+      if (shardCount > 1 && nWritten++ == nMainAssembled) {   // a shard keeps the rescue-pass reads apart: the merged file lists them after every shard's main pass
+        fclose(fp);
+        fp = fopen((outputPrefix + "_assembled_reads_rescue.fa").c_str(), "w");
+      }
       const SortRead &sr = sortedReads[idx];
       std::string extra;
       if (hasBarcode) extra += " barcode:" + barcodeIntToStr[sr.barcode];
@@ -884,7 +906,12 @@ int main(int argc, char *argv[]) {
     }
     fclose(fp);
   }
-  writeSet(outputPrefix + "_final.out");
+  if (shardCount > 1) {   // contig ids above are local to the shard; stage1_dist.py shifts them by the slots of the earlier shards
+    if (nMainAssembled == assembledReadIdx.size()) { FILE *fp = fopen((outputPrefix + "_assembled_reads_rescue.fa").c_str(), "w"); if (fp) fclose(fp); }
+    FILE *fp = fopen((outputPrefix + "_shard.meta").c_str(), "w");
+    fprintf(fp, "shard %d %d\ncontig_slots %d\nreads %d\n", shardRank, shardCount, t4_cellset_size(cellSet), readCnt);
+    fclose(fp);
+  } else writeSet(outputPrefix + "_final.out");
   if (hasBarcode) {
     int64_t qb = 0, rq = 0, im = 0, by = 0; double sq = 0, ss = 0;
     t4_cellset_counters(cellSet, &qb, &rq, &im, &by, &sq, &ss);
