@@ -5,7 +5,10 @@ A "step" is one pass of the GPU hot path over one resident batch of synthetic 15
 (SURVEY.md 8d recipe, config C2: 1 M pairs, 20 k clones, seed 1, -f hg38_bcrtcr.fa, k = 9). The pass
 measured this round is the stage-1 rough-annotation pass of every read (main.cpp:1084-1120:
 GetHitsFromRead -> SortHits -> GetOverlapsFromHits -> GetOverlapsFromRead scoring -> AnnotateRead
-level 0); the order-dependent AddRead loop is not on the GPU yet and is NOT part of this number.
+level 0), the data-parallel pass; the order-dependent AddRead loop is NOT part of `value`. Rank 0 at N=1 also
+reports, as the extra object `stage1_e2e`, the wall-clock of WHOLE stage 1 (FASTQ in -> _raw.out/_final.out out) of the
+`trust4-hip` driver on a bounded 10x-style sample (SURVEY 8d C5 recipe), next to the reference binary on the same files
+and with the outputs compared byte for byte.
 Inputs are 2-bit packed and resident in HBM before the timed region; results stay on the device.
 Read batches shard across ranks with no data-path collective (weak scaling: every rank owns its own
 C2-sized batch, seeded by rank).
@@ -67,6 +70,41 @@ def cpu_baseline(reads_arr, sample_reads):
             "sample": "first %d reads of the rank-0 batch, same rough-annotation pass, 1 thread, %.1f s" % (n, dt)}
 
 
+def stage1_e2e(pairs, cells):
+    """Whole stage 1 in barcode mode through trust4-hip vs oracle/_ref/trust4 (when it travelled) on the same files."""
+    import filecmp
+    import gzip
+    import shutil
+    import subprocess
+    import tempfile
+    import t4libs
+    tmp = tempfile.mkdtemp()
+    try:
+        fa = os.path.join(tmp, "ref.fa")
+        with gzip.open(t4libs.REF_FA, "rb") as f, open(fa, "wb") as g:
+            shutil.copyfileobj(f, g)
+        pre = os.path.join(tmp, "c5")
+        subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, str(pairs), "0", "4", pre, "--cells", str(cells)], check=True)
+        argv = ["-f", fa, "-1", pre + "_1.fq", "-2", pre + "_2.fq", "--barcode", pre + "_bc.fa", "--UMI", pre + "_umi.fa"]
+        t0 = time.perf_counter()
+        subprocess.run([os.path.join(ROOT, "trust4_amd", "bin", "trust4-hip")] + argv + ["-o", os.path.join(tmp, "mine")], check=True, stderr=subprocess.DEVNULL)
+        t_mine = time.perf_counter() - t0
+        out = {"workload": "C5 recipe sample: %d synthetic 150 bp PE pairs, %d cells x 2 clones, barcode + UMI files; FASTQ in -> _raw.out/_final.out/_assembled_reads.fa out" % (pairs, cells),
+               "pairs_per_s": pairs / t_mine, "seconds": t_mine, "host_threads": 1}
+        ref_bin = os.path.join(ROOT, "oracle", "_ref", "trust4")
+        if os.path.exists(ref_bin):
+            cores = os.cpu_count() or 1
+            t0 = time.perf_counter()
+            subprocess.run([ref_bin, "-t", str(cores)] + argv + ["-o", os.path.join(tmp, "ref")], check=True, stderr=subprocess.DEVNULL)
+            t_ref = time.perf_counter() - t0
+            out.update({"reference_pairs_per_s": pairs / t_ref, "reference_seconds": t_ref, "reference_threads": cores,
+                        "identical": all(filecmp.cmp(os.path.join(tmp, "ref" + x), os.path.join(tmp, "mine" + x), shallow=False)
+                                         for x in ("_raw.out", "_final.out", "_assembled_reads.fa"))})
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,6 +113,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=1000000, help="read pairs per GPU per step (C2 = 1M)")
     ap.add_argument("--clones", type=int, default=20000)
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--e2e-pairs", type=int, default=50000, help="pairs of the whole-stage-1 leg (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -147,7 +186,7 @@ def main():
             "dtype": "int32/u64", "data": "synthetic",
             "config": {"workload": "C2: %d synthetic 150 bp PE pairs per GPU (%d reads), %d clones, seed 1+rank, -f hg38_bcrtcr.fa, k=9; "
                                    "pass = stage-1 rough annotation of every read (seed->sort->chain->score->V/J/C select); "
-                                   "AddRead loop not included" % (args.pairs, n_reads, args.clones),
+                                   "AddRead loop not included (see stage1_e2e)" % (args.pairs, n_reads, args.clones),
                        "pairs_per_gpu": args.pairs, "reads_per_gpu": n_reads, "hits_per_read": hits / n_reads, "hits_all_ranks": total_hits_all,
                        "tier_reads": st["tier_reads"], "sharding": "reads sharded by rank, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -157,6 +196,8 @@ def main():
         }
         if args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(reads, args.cpu_sample)
+        if args.e2e_pairs > 0 and world == 1:
+            out["stage1_e2e"] = stage1_e2e(args.e2e_pairs, max(1, args.e2e_pairs // 100))
         print(json.dumps(out))
     if dist:
         dist.barrier()
