@@ -201,6 +201,10 @@ int t4_cellset_close_cell(t4_cellset *cs, t4_assembler *cell);           /* no m
  * commit changes anything a query of that cell can observe). */
 int t4_cellset_prefetch(t4_cellset *cs, int n, t4_assembler *const *cells, const char *const *reads, const int *strands,
                         int repetitive_data);
+/* Host threads used inside t4_cellset_prefetch for the per-cell image builds and window bookkeeping (default 1).
+ * Different cells may also be driven from different caller threads between two prefetch calls (t4_assembler_* on a cell
+ * touches that cell only, provided every AddRead it is offered was prefetched); one cell is never re-entrant. */
+int t4_cellset_set_threads(t4_cellset *cs, int host_threads);
 int t4_cellset_update_all_consensus(t4_cellset *cs);
 int t4_cellset_size(const t4_cellset *cs);   /* contig slots over all cells == seqSet.Size() */
 int t4_cellset_output(t4_cellset *cs, const char *path, const char *const *barcode_names, int n_names);

@@ -17,7 +17,7 @@ def build_emulator_lib():
     if os.path.exists(EMU_LIB) and all(os.path.getmtime(EMU_LIB) >= os.path.getmtime(s) for s in srcs):
         return EMU_LIB
     subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-I",
-                    os.path.join(ROOT, "tests", "hipemu"), "-o", EMU_LIB, "-x", "c++", srcs[0], srcs[3], srcs[4], "-lz"], check=True)
+                    os.path.join(ROOT, "tests", "hipemu"), "-o", EMU_LIB, "-x", "c++", srcs[0], srcs[3], srcs[4], "-lz", "-lpthread"], check=True)
     return EMU_LIB
 
 

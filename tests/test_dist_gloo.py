@@ -105,7 +105,7 @@ def test_two_rank_barcode_stage1(tmp_path):
     src = os.path.join(ROOT, "trust4_amd", "host", "trust4_main.cpp")
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(lib)):
         subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, src, "-L" + os.path.dirname(lib), "-lt4hip_emu",
-                        "-Wl,-rpath," + os.path.dirname(lib), "-lz"], check=True)
+                        "-Wl,-rpath," + os.path.dirname(lib), "-lz", "-lpthread"], check=True)
     run_stage1_two_ranks(tmp_path, exe, 120, 7, 9)
 
 

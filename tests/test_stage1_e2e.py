@@ -83,9 +83,9 @@ def _barcode_case(tmp_path, driver, pairs, cells, seed, env=None):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not shipped")
-@pytest.mark.parametrize("pairs,cells,seed,lanes,window", [(3000, 60, 4, 4096, 4), (3000, 60, 5, 7, 1)])
-def test_barcode_mode_matches_reference_binary(tmp_path, pairs, cells, seed, lanes, window):
-    _barcode_case(tmp_path, _driver(), pairs, cells, seed, {"T4_LANES": str(lanes), "T4_WINDOW": str(window)})
+@pytest.mark.parametrize("pairs,cells,seed,lanes,window,threads", [(3000, 60, 4, 4096, 4, 8), (3000, 60, 5, 7, 1, 1)])
+def test_barcode_mode_matches_reference_binary(tmp_path, pairs, cells, seed, lanes, window, threads):
+    _barcode_case(tmp_path, _driver(), pairs, cells, seed, {"T4_LANES": str(lanes), "T4_WINDOW": str(window), "T4_THREADS": str(threads)})
 
 
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
@@ -97,5 +97,5 @@ def test_barcode_mode_emulated(tmp_path):
     src = os.path.join(ROOT, "trust4_amd", "host", "trust4_main.cpp")
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(lib)):
         subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, src, "-L" + os.path.dirname(lib), "-lt4hip_emu",
-                        "-Wl,-rpath," + os.path.dirname(lib), "-lz"], check=True)
-    _barcode_case(tmp_path, exe, 160, 8, 6, {"T4_LANES": "5", "T4_WINDOW": "3"})
+                        "-Wl,-rpath," + os.path.dirname(lib), "-lz", "-lpthread"], check=True)
+    _barcode_case(tmp_path, exe, 160, 8, 6, {"T4_LANES": "8", "T4_WINDOW": "3", "T4_THREADS": "2"})

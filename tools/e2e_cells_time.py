@@ -16,7 +16,7 @@ subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, str(pairs), "0", str
 args = ["-f", fa, "-1", pre + "_1.fq", "-2", pre + "_2.fq", "--barcode", pre + "_bc.fa", "--UMI", pre + "_umi.fa"]
 ref_bin = os.path.join(ROOT, "oracle", "_ref", "trust4")
 t0 = time.time(); pr = subprocess.run([ref_bin, "-t", threads] + args + ["-o", os.path.join(tmp, "ref")], check=True, stderr=subprocess.PIPE, text=True); t_ref = time.time() - t0
-t0 = time.time(); p = subprocess.run([os.path.join(ROOT, "trust4_amd", "bin", "trust4-hip")] + args + ["-o", os.path.join(tmp, "mine")], check=True, stderr=subprocess.PIPE, text=True); t_mine = time.time() - t0
+t0 = time.time(); p = subprocess.run([os.path.join(ROOT, "trust4_amd", "bin", "trust4-hip"), "-t", threads] + args + ["-o", os.path.join(tmp, "mine")], check=True, stderr=subprocess.PIPE, text=True); t_mine = time.time() - t0
 same = all(filecmp.cmp(os.path.join(tmp, "ref" + s), os.path.join(tmp, "mine" + s), shallow=False) for s in ("_raw.out", "_assembled_reads.fa", "_final.out"))
 print("pairs %d cells %d: reference -t %s %.1f s (%.0f pairs/s) | trust4-hip %.1f s (%.0f pairs/s) | identical=%s | contigs %d" % (
     pairs, cells, threads, t_ref, pairs / t_ref, t_mine, pairs / t_mine, same, open(os.path.join(tmp, "ref_raw.out")).read().count(">")))

@@ -62,7 +62,7 @@ def _load():
         "t4_cellset_create": (I, [P, I, C.POINTER(P)]), "t4_cellset_destroy": (None, [P]),
         "t4_cellset_set_params": (I, [P, I, I, C.c_double]), "t4_cellset_cell": (I, [P, I, C.POINTER(P)]),
         "t4_cellset_close_cell": (I, [P, P]), "t4_cellset_prefetch": (I, [P, I, P, P, P, I]),
-        "t4_cellset_update_all_consensus": (I, [P]), "t4_cellset_size": (I, [P]),
+        "t4_cellset_update_all_consensus": (I, [P]), "t4_cellset_set_threads": (I, [P, I]), "t4_cellset_size": (I, [P]),
         "t4_cellset_output": (I, [P, C.c_char_p, P, I]), "t4_cellset_counters": (I, [P, P, P, P, P, P, P]),
     }
     for name, (res, args) in sig.items():

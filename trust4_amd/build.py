@@ -16,7 +16,7 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", OUT, SRC, SRC_HOST, "-lz"]
+    cmd = [hipcc] + FLAGS + ["-o", OUT, SRC, SRC_HOST, "-lz", "-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
@@ -30,7 +30,7 @@ def build_driver(verbose=False):
     out_dir = os.path.join(HERE, "bin")
     os.makedirs(out_dir, exist_ok=True)
     out = os.path.join(out_dir, "trust4-hip")
-    cmd = ["g++", "-O2", "-std=c++17", "-o", out, src, "-L" + HERE, "-lt4hip", "-Wl,-rpath," + HERE, "-Wl,-rpath,$ORIGIN/..", "-lz"]
+    cmd = ["g++", "-O2", "-std=c++17", "-o", out, src, "-L" + HERE, "-lt4hip", "-Wl,-rpath," + HERE, "-Wl,-rpath,$ORIGIN/..", "-lz", "-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

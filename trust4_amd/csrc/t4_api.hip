@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -957,6 +958,7 @@ struct t4_cellstore {
   T4CopyDesc *dDescs = nullptr;
   size_t descCap = 0;
   int64_t bytesStaged = 0;
+  std::mutex mu;   // t4_cellstore_stage may run on several host threads after t4_cellstore_prepare
   static constexpr size_t CHUNK = (size_t)256 << 20;
 };
 
@@ -1053,6 +1055,39 @@ int t4_cellstore_close(t4_cellstore *cs, int slot) {
   return T4_OK;
 }
 
+size_t t4_cellstore_image_bytes(int nseq, int64_t nkeys, int64_t npost, int64_t cons_bytes) {
+  auto al16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  size_t sz = 64;
+  while (sz < 2 * (size_t)nkeys + 2) sz <<= 1;
+  const size_t pwCount = (size_t)cons_bytes;   // one int4 per consensus byte incl. the terminators
+  const size_t oPost = al16(sizeof(T4HashEnt) * sz), oSeq = al16(oPost + sizeof(int2) * (size_t)npost),
+               oPw = al16(oSeq + sizeof(T4SeqInfo) * (size_t)nseq), oCons = al16(oPw + sizeof(int4) * pwCount);
+  return al16(oCons + (size_t)cons_bytes + 16) + al16(sizeof(T4IndexView));
+}
+
+// Serial step before a group of (possibly concurrent) t4_cellstore_stage calls: room for `bytes` more staged bytes and a
+// view entry for every slot id up to max_slot, so that no buffer moves while images are being written.
+int t4_cellstore_prepare(t4_cellstore *cs, int max_slot, size_t bytes) {
+  if (!cs) return T4_ERR_ARG;
+  t4_ctx *c = cs->ctx;
+  (void)hipSetDevice(c->device);
+  int r;
+  if (max_slot >= cs->viewCap) {
+    int ncap = cs->viewCap ? cs->viewCap : 1024;
+    while (ncap <= max_slot) ncap *= 2;
+    T4IndexView *nv = nullptr;
+    HIPCHK(c, hipMalloc(&nv, sizeof(T4IndexView) * (size_t)ncap));
+    if ((r = cellFlush(cs))) return r;   // pending descriptors may point into the old array
+    if (cs->dViews) {
+      HIPCHK(c, hipMemcpyAsync(nv, cs->dViews, sizeof(T4IndexView) * (size_t)cs->viewCap, hipMemcpyDeviceToDevice, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      (void)hipFree(cs->dViews);
+    }
+    cs->dViews = nv; cs->viewCap = ncap;
+  }
+  return cellStagingReserve(cs, bytes);
+}
+
 int t4_cellstore_stage(t4_cellstore *cs, int slot, int barcode, int nseq, const char *const *names, const char *const *cons,
                        const int32_t *const *pw, int64_t nkeys64, const uint64_t *keyCode, const int32_t *keyBucket, const int32_t *keyCnt,
                        const int32_t *postIn) {
@@ -1076,35 +1111,34 @@ int t4_cellstore_stage(t4_cellstore *cs, int slot, int barcode, int nseq, const 
                oPw = al16(oSeq + sizeof(T4SeqInfo) * (size_t)nseq), oCons = al16(oPw + sizeof(int4) * pwCount),
                blobBytes = al16(oCons + consBytes + 16);
   int r;
-  t4_cellstore::Slot &sl = cs->slots[slot];
-  if (blobBytes > sl.cap) {
-    if (sl.base) cs->freeBySize[sl.cap].push_back(sl.base);
-    size_t cap = (size_t)64 << 10;
-    while (cap < blobBytes + blobBytes / 2) cap <<= 1;
-    sl.base = nullptr; sl.cap = 0;
-    unsigned char *p = nullptr;
-    if ((r = cellAlloc(cs, cap, &p))) return r;
-    sl.base = p; sl.cap = cap;
-  }
-  if (slot >= cs->viewCap) {
-    int ncap = cs->viewCap ? cs->viewCap : 1024;
-    while (ncap <= slot) ncap *= 2;
-    T4IndexView *nv = nullptr;
-    HIPCHK(c, hipMalloc(&nv, sizeof(T4IndexView) * (size_t)ncap));
-    if ((r = cellFlush(cs))) return r;   // pending descriptors may point into the old array
-    if (cs->dViews) {
-      HIPCHK(c, hipMemcpyAsync(nv, cs->dViews, sizeof(T4IndexView) * (size_t)cs->viewCap, hipMemcpyDeviceToDevice, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      (void)hipFree(cs->dViews);
-    }
-    cs->dViews = nv; cs->viewCap = ncap;
-  }
   const size_t viewBytes = al16(sizeof(T4IndexView));
-  if ((r = cellStagingReserve(cs, blobBytes + viewBytes))) return r;
-  unsigned char *b = cs->stHost + cs->stUsed;
-  memset(b, 0, blobBytes + viewBytes);
+  unsigned char *b = nullptr, *slotBase = nullptr;
+  size_t stOff = 0;
+  {
+    std::lock_guard<std::mutex> lock(cs->mu);
+    t4_cellstore::Slot &sl = cs->slots[slot];
+    if (blobBytes > sl.cap) {
+      if (sl.base) cs->freeBySize[sl.cap].push_back(sl.base);
+      size_t cap = (size_t)64 << 10;
+      while (cap < blobBytes + blobBytes / 2) cap <<= 1;
+      sl.base = nullptr; sl.cap = 0;
+      unsigned char *p = nullptr;
+      if ((r = cellAlloc(cs, cap, &p))) return r;
+      sl.base = p; sl.cap = cap;
+    }
+    slotBase = sl.base;
+    if (slot >= cs->viewCap || cs->stUsed + blobBytes + viewBytes > cs->stCap)
+      return fail(c, T4_ERR_STATE, "t4_cellstore_stage without a sufficient t4_cellstore_prepare (slot %d, %zu bytes)", slot, blobBytes + viewBytes);
+    stOff = cs->stUsed;
+    b = cs->stHost + stOff;
+    T4CopyDesc d0; d0.srcOff = stOff; d0.dst = slotBase; d0.bytes = blobBytes;
+    T4CopyDesc d1; d1.srcOff = stOff + blobBytes; d1.dst = (unsigned char *)(cs->dViews + slot); d1.bytes = viewBytes;
+    cs->descs.push_back(d0); cs->descs.push_back(d1);
+    cs->stUsed += blobBytes + viewBytes;
+  }
+  memset(b + oPost, 0, blobBytes + viewBytes - oPost);
   T4HashEnt *ht = (T4HashEnt *)(b + oHt);
-  for (size_t i = 0; i < sz; ++i) ht[i].h = -1;
+  for (size_t i = 0; i < sz; ++i) { ht[i].code = 0; ht[i].h = -1; ht[i].start = 0; ht[i].cnt = 0; ht[i].pad = 0; }
   int2 *post = (int2 *)(b + oPost);
   const unsigned long long hashMask = sz - 1;
   size_t at = 0;
@@ -1142,15 +1176,11 @@ int t4_cellstore_stage(t4_cellstore *cs, int slot, int barcode, int nseq, const 
   }
   T4IndexView &v = *(T4IndexView *)(b + blobBytes);
   v.k = cs->k; v.nseq = nseq; v.direct = 0; v.considerBarcode = 1;
-  v.hashMask = hashMask; v.table = nullptr; v.htab = (const T4HashEnt *)(sl.base + oHt); v.post = (const int2 *)(sl.base + oPost);
-  v.seqs = (const T4SeqInfo *)(sl.base + oSeq); v.cons = (const char *)(sl.base + oCons); v.pw = (const int4 *)(sl.base + oPw);
+  v.hashMask = hashMask; v.table = nullptr; v.htab = (const T4HashEnt *)(slotBase + oHt); v.post = (const int2 *)(slotBase + oPost);
+  v.seqs = (const T4SeqInfo *)(slotBase + oSeq); v.cons = (const char *)(slotBase + oCons); v.pw = (const int4 *)(slotBase + oPw);
   v.radius = cs->radius; v.hitLenRequired = cs->hitLenRequired; v.nomatchGapLimit = cs->nomatchGapLimit;
   v.firstIsRef = 0; v.hasNovel = 1;
   v.novelSim = cs->novelSim; v.refSim = 0.75; v.repeatSim = 0.95;
-  T4CopyDesc d0; d0.srcOff = cs->stUsed; d0.dst = sl.base; d0.bytes = blobBytes;
-  T4CopyDesc d1; d1.srcOff = cs->stUsed + blobBytes; d1.dst = (unsigned char *)(cs->dViews + slot); d1.bytes = viewBytes;
-  cs->descs.push_back(d0); cs->descs.push_back(d1);
-  cs->stUsed += blobBytes + viewBytes;
   return T4_OK;
 }
 

@@ -17,7 +17,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -181,6 +183,18 @@ bool nameCompatible(const std::string &a, const std::string &b) {
   each(a, [&](int gt) { if (gt > maxA) maxA = gt; });
   each(b, [&](int gt) { if (gt < minB && gt != -1) minB = gt; });
   return maxA <= minB;
+}
+
+// fn(i) for i in [0, n) on up to `threads` host threads (dynamic chunks); fn must only touch data owned by item i
+template <class F> void parallelFor(int n, int threads, F fn) {
+  if (threads <= 1 || n < 2 * threads) { for (int i = 0; i < n; ++i) fn(i); return; }
+  std::atomic<int> next(0);
+  const int chunk = n / (threads * 8) > 0 ? n / (threads * 8) : 1;
+  auto body = [&]() { for (;;) { int b = next.fetch_add(chunk); if (b >= n) break; int e = b + chunk < n ? b + chunk : n; for (int i = b; i < e; ++i) fn(i); } };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; ++t) pool.emplace_back(body);
+  body();
+  for (auto &th : pool) th.join();
 }
 
 void reverseComplement(std::string &rc, const std::string &s) {
@@ -689,16 +703,17 @@ struct t4_cellset {
   int k = 9, hitLenRequired = 31, radius = 10;
   double novelSim = 0.9;
   std::map<int, t4_assembler *> cells;   // by barcode id == the reference's processing order of the cells
-  int64_t queries = 0, stagedImages = 0, readsQueried = 0, batchSeq = 0;
+  int64_t queries = 0, readsQueried = 0, batchSeq = 0;
+  std::atomic<int64_t> stagedImages{0};
   double secQuery = 0, secStage = 0;
+  int threads = 1;   // host threads for image builds and window bookkeeping (cells are independent)
   std::string err;
 };
 
-int t4_assembler::stageImage() {
+int t4_assembler::stageImage() {   // thread-safe across cells once the owner has run t4_cellstore_prepare
   if (!dirty) return T4_OK;
-  auto t0 = std::chrono::steady_clock::now();
   int r;
-  if (slot < 0 && (r = t4_cellstore_open(owner->store, &slot))) return r;
+  if (slot < 0) return T4_ERR_STATE;
   const int n = (int)seqs.size();
   std::vector<const char *> names(n), cons(n);
   std::vector<const int32_t *> pw(n);
@@ -718,7 +733,6 @@ int t4_assembler::stageImage() {
   }
   r = t4_cellstore_stage(owner->store, slot, cellBarcode, n, names.data(), cons.data(), pw.data(), (int64_t)keyCode.size(), keyCode.data(),
                          keyBucket.data(), keyCnt.data(), post.data());
-  owner->secStage += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (r) return r;
   dirty = false; ++refreshes; ++owner->stagedImages;
   return T4_OK;
@@ -952,46 +966,71 @@ int t4_cellset_prefetch(t4_cellset *cs, int n, t4_assembler *const *cells, const
   ++cs->batchSeq;
   // the reads of one cell must be consecutive (its speculation window, in the order they will be offered)
   int rc;
-  std::string bases; std::vector<int64_t> offs(1, 0); std::vector<int32_t> bcs, sts, slots; std::vector<double> fac;
-  struct Span { t4_assembler *cell; int first, count; bool queried; };
+  struct Span { t4_assembler *cell; int begin, end, first; bool queried; int err; };
   std::vector<Span> spans;
-  std::vector<const char *> rs; std::vector<int> st, bc;
   for (int i = 0; i < n;) {
     t4_assembler *cell = cells[i];
     if (!cell || cell->owner != cs) return T4_ERR_ARG;
     int j = i;
-    rs.clear(); st.clear(); bc.clear();
-    while (j < n && cells[j] == cell) { rs.push_back(reads[j]); st.push_back(strands[j]); bc.push_back(cell->cellBarcode); ++j; }
+    while (j < n && cells[j] == cell) ++j;
     if (cell->windowStamp == cs->batchSeq) return T4_ERR_ARG;   // the cell appeared earlier in this batch
     cell->windowStamp = cs->batchSeq;
-    cell->beginWindow(j - i, rs.data(), st.data(), bc.data(), rep);
-    Span sp{cell, (int)sts.size(), j - i, cell->index.total > 0};
-    if (sp.queried) {   // an empty index has no hit for anybody: GetOverlapsFromRead returns 0 without a launch
-      if ((rc = cell->stageImage())) { cs->err = t4_last_error(cs->ctx); return rc; }
-      for (int t = i; t < j; ++t) {
-        bases += reads[t]; offs.push_back((int64_t)bases.size()); bcs.push_back(cell->cellBarcode); sts.push_back(strands[t]);
-        slots.push_back(cell->slot); fac.push_back(2.0);   // ExtendOverlap's mismatch factor with a barcode (SeqSet.hpp:3597-3598)
-      }
-    }
-    spans.push_back(sp);
+    spans.push_back(Span{cell, i, j, 0, cell->index.total > 0, 0});   // an empty index has no hit for anybody: no launch needed
     i = j;
   }
-  const int m = (int)sts.size();
+  // serial: slots, batch positions and the staging reservation of every image that has to be rebuilt
+  auto t0 = std::chrono::steady_clock::now();
+  int m = 0, maxSlot = -1;
+  size_t stageBytes = 0;
+  for (Span &sp : spans) {
+    if (!sp.queried) continue;
+    sp.first = m; m += sp.end - sp.begin;
+    t4_assembler *cell = sp.cell;
+    if (cell->slot < 0 && (rc = t4_cellstore_open(cs->store, &cell->slot))) return rc;
+    if (cell->slot > maxSlot) maxSlot = cell->slot;
+    if (cell->dirty) {
+      int64_t consBytes = 0;
+      for (const Seq &q : cell->seqs) consBytes += (q.released ? 0 : (int64_t)q.cons.size()) + 1;
+      stageBytes += t4_cellstore_image_bytes((int)cell->seqs.size(), (int64_t)cell->index.map.size(), (int64_t)cell->index.total, consBytes);
+    }
+  }
+  if ((rc = t4_cellstore_prepare(cs->store, maxSlot, stageBytes))) return rc;
+  // parallel over cells: window slots + image builds
+  parallelFor((int)spans.size(), cs->threads, [&](int si) {
+    Span &sp = spans[si];
+    t4_assembler *cell = sp.cell;
+    const int cnt = sp.end - sp.begin;
+    std::vector<int> bc(cnt, cell->cellBarcode);
+    cell->beginWindow(cnt, reads + sp.begin, strands + sp.begin, bc.data(), rep);
+    if (sp.queried) sp.err = cell->stageImage();
+  });
+  for (Span &sp : spans) if (sp.err) { cs->err = t4_last_error(cs->ctx); for (Span &q : spans) q.cell->dropWindow(); return sp.err; }
+  cs->secStage += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  std::string bases; std::vector<int64_t> offs(1, 0); std::vector<int32_t> bcs, sts, slots; std::vector<double> fac;
+  bcs.reserve(m); sts.reserve(m); slots.reserve(m); fac.reserve(m); offs.reserve(m + 1);
+  for (Span &sp : spans) {
+    if (!sp.queried) continue;
+    for (int t = sp.begin; t < sp.end; ++t) {
+      bases += reads[t]; offs.push_back((int64_t)bases.size()); bcs.push_back(sp.cell->cellBarcode); sts.push_back(strands[t]);
+      slots.push_back(sp.cell->slot); fac.push_back(2.0);   // ExtendOverlap's mismatch factor with a barcode (SeqSet.hpp:3597-3598)
+    }
+  }
   std::vector<t4_overlap> ov((size_t)m * MAXOV), ex((size_t)m * MAXOV);
   std::vector<int32_t> cnts(m), rets((size_t)m * MAXOV);
   if (m > 0) {
-    auto t0 = std::chrono::steady_clock::now();
+    auto tq = std::chrono::steady_clock::now();
     rc = t4_cellstore_query(cs->store, m, slots.data(), bases.data(), offs.data(), bcs.data(), sts.data(), rep, fac.data(), MAXOV,
                             cnts.data(), ov.data(), ex.data(), rets.data());
-    cs->secQuery += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    cs->secQuery += std::chrono::duration<double>(std::chrono::steady_clock::now() - tq).count();
     cs->readsQueried += m;
     if (rc) { for (Span &sp : spans) sp.cell->dropWindow(); return rc; }
   }
   ++cs->queries;
-  for (Span &sp : spans) {
+  parallelFor((int)spans.size(), cs->threads, [&](int si) {
+    Span &sp = spans[si];
     if (sp.queried) { sp.cell->endWindow(cnts.data() + sp.first, ov.data() + (size_t)sp.first * MAXOV, ex.data() + (size_t)sp.first * MAXOV, rets.data() + (size_t)sp.first * MAXOV, MAXOV); ++sp.cell->queries; }
     else sp.cell->endWindow(nullptr, nullptr, nullptr, nullptr, MAXOV);
-  }
+  });
   return T4_OK;
 }
 
@@ -1010,6 +1049,11 @@ int t4_cellset_output(t4_cellset *cs, const char *path, const char *const *barco
   fclose(fp);
   return T4_OK;
 }
+int t4_cellset_set_threads(t4_cellset *cs, int host_threads) {
+  if (!cs || host_threads < 1) return T4_ERR_ARG;
+  cs->threads = host_threads > 64 ? 64 : host_threads;
+  return T4_OK;
+}
 int t4_cellset_size(const t4_cellset *cs) {
   if (!cs) return 0;
   int n = 0;
@@ -1026,7 +1070,7 @@ int t4_cellset_counters(const t4_cellset *cs, int64_t *query_batches, int64_t *r
   if (!cs) return T4_ERR_ARG;
   if (query_batches) *query_batches = cs->queries;
   if (reads_queried) *reads_queried = cs->readsQueried;
-  if (images_staged) *images_staged = cs->stagedImages;
+  if (images_staged) *images_staged = cs->stagedImages.load();
   if (bytes_staged) *bytes_staged = t4_cellstore_bytes_staged(cs->store);
   if (sec_query) *sec_query = cs->secQuery;
   if (sec_stage) *sec_stage = cs->secStage;

@@ -1,6 +1,7 @@
 // trust4_amd/csrc/t4_internal.h -- library-internal interface between the host-side contig builder
 // (t4_assembler.cpp) and the device side (t4_api.hip). Not part of the public C ABI.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 #include "../../include/trust4_hip.h"
 
@@ -22,6 +23,10 @@ int t4_cellstore_close(t4_cellstore *cs, int slot);
 int t4_cellstore_stage(t4_cellstore *cs, int slot, int barcode, int nseq, const char *const *names, const char *const *cons,
                        const int32_t *const *pw, int64_t nkeys, const uint64_t *key_code, const int32_t *key_bucket,
                        const int32_t *key_cnt, const int32_t *post);
+// Exact staged size of one image, and the serial reservation that must precede a group of t4_cellstore_stage calls
+// (which may then run concurrently on several host threads: nothing moves while they write).
+size_t t4_cellstore_image_bytes(int nseq, int64_t nkeys, int64_t npost, int64_t cons_bytes);
+int t4_cellstore_prepare(t4_cellstore *cs, int max_slot, size_t bytes);
 // Flush the staged images, then run the AddRead query (== t4_add_query) of read i against the image of slot[i].
 int t4_cellstore_query(t4_cellstore *cs, int n, const int32_t *slots, const char *bases, const int64_t *offsets,
                        const int32_t *barcodes, const int32_t *strands, int skip_repeats, const double *factors,

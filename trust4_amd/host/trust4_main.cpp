@@ -25,7 +25,9 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -43,7 +45,7 @@ const char *USAGE =
     "\t-1 STRING -2 STRING: path to paried-end read files\n"
     "Optional:\n"
     "\t-o STRING: prefix of the output file (default: trust)\n"
-    "\t-t INT: accepted for compatibility (the GPU engine does not use host threads)\n"
+    "\t-t INT: number of host threads (default: 1); used by the barcode-mode Add pass (cells are independent)\n"
     "\t-k INT: the starting k-mer size for indexing contigs (default: 9)\n"
     "\t--minHitLen INT: the minimal hit length for a valid overlap (default: auto)\n"
     "\t--skipMateExtension: accepted; _final.out is always the raw assembly in this build\n"
@@ -372,7 +374,7 @@ int main(int argc, char *argv[]) {
                                          {"cellShard", required_argument, 0, 10100},
                                          {(char *)0, 0, 0, 0}};
   int indexKmerLength = 9, changeKmerLengthThreshold = 4096, trimLevel = 1, minHitLen = -1, constantGeneEnd = 200;
-  int shardRank = 0, shardCount = 1;
+  int shardRank = 0, shardCount = 1, threadCnt = 1;
   std::string refFa, outputPrefix = "trust";
   SeqReader reads, mateReads, barcodeFile, umiFile;
   bool hasMate = false, hasBarcode = false, hasUmi = false;
@@ -383,7 +385,7 @@ int main(int argc, char *argv[]) {
     else if (c == '1') { reads.files.push_back(optarg); hasMate = true; }
     else if (c == '2') { mateReads.files.push_back(optarg); hasMate = true; }
     else if (c == 'o') outputPrefix = optarg;
-    else if (c == 't') { /* no host threads */ }
+    else if (c == 't') threadCnt = atoi(optarg) > 0 ? atoi(optarg) : 1;
     else if (c == 'k') indexKmerLength = atoi(optarg);
     else if (c == 10001) trimLevel = atoi(optarg);
     else if (c == 10005) { /* always */ }
@@ -599,6 +601,7 @@ int main(int argc, char *argv[]) {
     if (barcodeIntToStr.size() >= 1000003) { fprintf(stderr, "trust4-hip: more than 1000002 barcodes are not supported.\n"); return EXIT_FAILURE; }
     if ((rc = t4_cellset_create(ctx, indexKmerLength, &cellSet))) die(ctx, "t4_cellset_create", rc);
     t4_cellset_set_params(cellSet, hitLenRequired, 10, 0.9);
+    t4_cellset_set_threads(cellSet, threadCnt);
   } else {
     if ((rc = t4_assembler_create(ctx, indexKmerLength, 0, &seqSet))) die(ctx, "t4_assembler_create", rc);
     t4_assembler_set_params(seqSet, hitLenRequired, 10, 0.9);
@@ -606,7 +609,8 @@ int main(int argc, char *argv[]) {
   if (trimLevel > 1) changeKmerLengthThreshold /= 2;
   std::vector<int> barcodeTotalReadCount(barcodeIntToStr.size(), 0), barcodeReadCount(barcodeIntToStr.size(), 0);
   if (hasBarcode) for (int i = 0; i < readCnt; ++i) if (sortedReads[i].barcode != -1) ++barcodeTotalReadCount[sortedReads[i].barcode];
-  int assembledReadCnt = 0;
+  std::atomic<int> assembledReadCnt(0);
+  if (getenv("T4_THREADS")) threadCnt = atoi(getenv("T4_THREADS")) > 0 ? atoi(getenv("T4_THREADS")) : 1;
   const int WINDOW = getenv("T4_WINDOW") ? atoi(getenv("T4_WINDOW")) : (hasBarcode ? 4 : 16);
   const int LANES = getenv("T4_LANES") ? atoi(getenv("T4_LANES")) : 4096;
 
@@ -756,7 +760,7 @@ int main(int argc, char *argv[]) {
       }
       stepMain(w);
       if (assembledReadCnt > 0 && assembledReadCnt % 10000 == 0) t4_assembler_update_all_consensus(seqSet);
-      if ((i + 1) % 100000 == 0) PrintLog("Processed %d reads (%d are used for assembly).", i + 1, assembledReadCnt);
+      if ((i + 1) % 100000 == 0) PrintLog("Processed %d reads (%d are used for assembly).", i + 1, assembledReadCnt.load());
       if (t4_assembler_size(seqSet) > changeKmerLengthThreshold && indexKmerLength < 16) {
         changeKmerLengthThreshold *= 4;
         indexKmerLength += 2;
@@ -764,7 +768,7 @@ int main(int argc, char *argv[]) {
       }
     }
     t4_assembler_update_all_consensus(seqSet);
-    PrintLog("Assembled %d reads.", assembledReadCnt);
+    PrintLog("Assembled %d reads.", assembledReadCnt.load());
     rescueReadCnt = (int)w.rescue.size();
     PrintLog("Try to rescue %d reads for assembly.", rescueReadCnt);
     const int before = assembledReadCnt;
@@ -813,7 +817,6 @@ int main(int argc, char *argv[]) {
     auto finishMain = [&](Walk &w) {
       for (int i = w.begin; i < w.end; ++i) if (i == w.begin || cellOf[i] != cellOf[i - 1]) t4_assembler_update_all_consensus(cellOf[i]);
       w.phase = w.rescue.empty() ? 2 : 1;
-      if (w.phase == 2) cellsOfWalkDone(w);
     };
     while (nextWalk < endWalk || !active.empty()) {
       while (nextWalk < endWalk && (int)active.size() < LANES) active.push_back((int)nextWalk++);
@@ -845,8 +848,8 @@ int main(int argc, char *argv[]) {
       secPrefetch += since(tp0);
       // commit, walk by walk, what was queried (reads that need no query ride along)
       auto tm0 = now();
-      std::vector<int> still;
-      for (size_t a = 0; a < active.size(); ++a) {
+      // walks own disjoint cells and disjoint ranges of sortedReads / goodCandidate / barcodeReadCount: they commit concurrently
+      auto commitWalk = [&](size_t a) {
         Walk &w = walks[active[a]];
         int left = quota[a];
         if (w.phase == 0) {
@@ -863,10 +866,24 @@ int main(int argc, char *argv[]) {
           if (w.rcur >= w.rescue.size()) {
             for (int i = w.begin; i < w.end; ++i) if (i == w.begin || cellOf[i] != cellOf[i - 1]) t4_assembler_update_all_consensus(cellOf[i]);
             w.phase = 2;
-            cellsOfWalkDone(w);
           }
         }
-        if (w.phase != 2) still.push_back(active[a]);
+      };
+      {
+        const int nA = (int)active.size();
+        const int nT = threadCnt < nA / 4 ? threadCnt : (nA / 4 > 0 ? nA / 4 : 1);
+        std::atomic<int> nextA(0);
+        auto worker = [&]() { for (;;) { int b = nextA.fetch_add(8); if (b >= nA) break; for (int a = b; a < b + 8 && a < nA; ++a) commitWalk((size_t)a); } };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nT; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto &th : pool) th.join();
+      }
+      std::vector<int> still;
+      for (size_t a = 0; a < active.size(); ++a) {
+        Walk &w = walks[active[a]];
+        if (w.phase == 2) cellsOfWalkDone(w);   // arena bookkeeping: serial
+        else still.push_back(active[a]);
       }
       active.swap(still);
       secCommit += since(tm0);
