@@ -21,6 +21,7 @@
 #include <chrono>
 #include <thread>
 #include <map>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -187,7 +188,8 @@ bool nameCompatible(const std::string &a, const std::string &b) {
 
 // fn(i) for i in [0, n) on up to `threads` host threads (dynamic chunks); fn must only touch data owned by item i
 template <class F> void parallelFor(int n, int threads, F fn) {
-  if (threads <= 1 || n < 2 * threads) { for (int i = 0; i < n; ++i) fn(i); return; }
+  if (threads <= 1 || n <= 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+  if (threads > n) threads = n;
   std::atomic<int> next(0);
   const int chunk = n / (threads * 8) > 0 ? n / (threads * 8) : 1;
   auto body = [&]() { for (;;) { int b = next.fetch_add(chunk); if (b >= n) break; int e = b + chunk < n ? b + chunk : n; for (int i = b; i < e; ++i) fn(i); } };
@@ -707,6 +709,9 @@ struct t4_cellset {
   std::atomic<int64_t> stagedImages{0};
   double secQuery = 0, secStage = 0;
   int threads = 1;   // host threads for image builds and window bookkeeping (cells are independent)
+  std::unique_ptr<t4_overlap[]> resOv, resEx;
+  std::unique_ptr<int32_t[]> resRet;
+  size_t resCap = 0;
   std::string err;
 };
 
@@ -1015,12 +1020,18 @@ int t4_cellset_prefetch(t4_cellset *cs, int n, t4_assembler *const *cells, const
       slots.push_back(sp.cell->slot); fac.push_back(2.0);   // ExtendOverlap's mismatch factor with a barcode (SeqSet.hpp:3597-3598)
     }
   }
-  std::vector<t4_overlap> ov((size_t)m * MAXOV), ex((size_t)m * MAXOV);
-  std::vector<int32_t> cnts(m), rets((size_t)m * MAXOV);
+  // result buffers persist across batches and are never value-initialised (only the records that exist are written and read)
+  if ((size_t)m * MAXOV > cs->resCap) {
+    cs->resCap = (size_t)m * MAXOV * 2;
+    cs->resOv.reset(new t4_overlap[cs->resCap]); cs->resEx.reset(new t4_overlap[cs->resCap]); cs->resRet.reset(new int32_t[cs->resCap]);
+  }
+  t4_overlap *ovp = cs->resOv.get(), *exp = cs->resEx.get();
+  int32_t *retp = cs->resRet.get();
+  std::vector<int32_t> cnts(m);
   if (m > 0) {
     auto tq = std::chrono::steady_clock::now();
     rc = t4_cellstore_query(cs->store, m, slots.data(), bases.data(), offs.data(), bcs.data(), sts.data(), rep, fac.data(), MAXOV,
-                            cnts.data(), ov.data(), ex.data(), rets.data());
+                            cnts.data(), ovp, exp, retp);
     cs->secQuery += std::chrono::duration<double>(std::chrono::steady_clock::now() - tq).count();
     cs->readsQueried += m;
     if (rc) { for (Span &sp : spans) sp.cell->dropWindow(); return rc; }
@@ -1028,7 +1039,7 @@ int t4_cellset_prefetch(t4_cellset *cs, int n, t4_assembler *const *cells, const
   ++cs->queries;
   parallelFor((int)spans.size(), cs->threads, [&](int si) {
     Span &sp = spans[si];
-    if (sp.queried) { sp.cell->endWindow(cnts.data() + sp.first, ov.data() + (size_t)sp.first * MAXOV, ex.data() + (size_t)sp.first * MAXOV, rets.data() + (size_t)sp.first * MAXOV, MAXOV); ++sp.cell->queries; }
+    if (sp.queried) { sp.cell->endWindow(cnts.data() + sp.first, ovp + (size_t)sp.first * MAXOV, exp + (size_t)sp.first * MAXOV, retp + (size_t)sp.first * MAXOV, MAXOV); ++sp.cell->queries; }
     else sp.cell->endWindow(nullptr, nullptr, nullptr, nullptr, MAXOV);
   });
   return T4_OK;

@@ -165,43 +165,71 @@ int isMateOverlap(const std::string &fr, const std::string &sr, int minOverlap, 
 }
 
 // ---- canonical 21-mer counts (KmerCount.hpp) ---------------------------------------------------------
+// fn(i) for i in [0, n) on up to `threads` host threads (dynamic chunks); fn must only touch data owned by item i
+template <class F> void parallelFor(long long n, int threads, F fn) {
+  if (threads <= 1 || n <= 1) { for (long long i = 0; i < n; ++i) fn(i); return; }
+  if (threads > n) threads = (int)n;
+  std::atomic<long long> next(0);
+  const long long chunk = n / (threads * 16LL) > 0 ? n / (threads * 16LL) : 1;
+  auto body = [&]() { for (;;) { long long b = next.fetch_add(chunk); if (b >= n) break; long long e = b + chunk < n ? b + chunk : n; for (long long i = b; i < e; ++i) fn(i); } };
+  std::vector<std::thread> pool;
+  for (int t = 1; t < threads; ++t) pool.emplace_back(body);
+  body();
+  for (auto &th : pool) th.join();
+}
+
 struct KmerCounter {
   int k;
-  std::unordered_map<uint64_t, int> cnt;
+  // counts of canonical k-mers, split by a hash of the k-mer so that every shard can be filled by its own thread
+  std::vector<std::unordered_map<uint64_t, int>> shards;
   int maxReadLen = -1;
-  std::vector<int> c;
-  explicit KmerCounter(int kl) : k(kl) {}
+  explicit KmerCounter(int kl, int nShards = 1) : k(kl), shards(nShards > 0 ? nShards : 1) {}
+  static uint64_t mix(uint64_t z) { z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31); }
+  size_t shardOf(uint64_t kc) const { return shards.size() == 1 ? 0 : (size_t)(mix(kc) % shards.size()); }
   template <class F> void eachValid(const std::string &r, F f) const {
     const int len = (int)r.size();
     const uint64_t mask = k < 32 ? ((1ull << (2 * k)) - 1ull) : ~0ull;
-    uint64_t code = 0;
+    uint64_t code = 0, rc = 0;
+    const int hi = 2 * (k - 1);
     int invalidPos = -1;
     for (int i = 0; i < len; ++i) {
       if (invalidPos != -1) ++invalidPos;
-      code = ((code << 2) & mask) | (uint64_t)(nucNum(r[i]) & 3);
+      const uint64_t b = (uint64_t)(nucNum(r[i]) & 3);
+      code = ((code << 2) & mask) | b;
+      rc = (rc >> 2) | ((3ull - b) << hi);
       if (r[i] == 'N') invalidPos = 0;
       if (invalidPos >= k) invalidPos = -1;
       if (i < k - 1 || invalidPos != -1) continue;
-      uint64_t rc = 0;
-      for (int t = 0; t < k; ++t) rc = (rc << 2) | (3ull - ((code >> (2 * t)) & 3ull));
       f(rc < code ? rc : code);
     }
   }
-  void addCount(const std::string &r) {
+  void addCount(const std::string &r) {   // KmerCount::AddCount (KmerCount.hpp:64-97)
     if ((int)r.size() < k) return;
-    eachValid(r, [&](uint64_t kc) { ++cnt[kc]; });
-    if ((int)r.size() > maxReadLen) maxReadLen = (int)r.size();
+    eachValid(r, [&](uint64_t kc) { ++shards[shardOf(kc)][kc]; });
   }
+  // the same counts for a whole read set, shard s filled by one thread
+  template <class GetRead> void addCountAll(long long nReads, int threads, GetRead getRead) {
+    const int S = (int)shards.size();
+    parallelFor(S, threads < S ? threads : S, [&](long long s) {
+      auto &m = shards[(size_t)s];
+      for (long long i = 0; i < nReads; ++i) {
+        const std::string &r = getRead(i);
+        if ((int)r.size() < k) continue;
+        eachValid(r, [&](uint64_t kc) { if (S == 1 || (long long)(mix(kc) % (uint64_t)S) == s) ++m[kc]; });
+      }
+    });
+  }
+  int count(uint64_t kc) const { const auto &m = shards[shardOf(kc)]; auto it = m.find(kc); return it == m.end() ? 0 : it->second; }
   // GetCountStatsAndTrim (KmerCount.hpp:177-288); read/qual are trimmed in place. qual == nullptr: no trimming.
-  void statsAndTrim(std::string &read, std::string *qual, int &minCount, int &medianCount, float &avgCount) {
+  void statsAndTrim(std::string &read, std::string *qual, int &minCount, int &medianCount, float &avgCount) const {
     if (maxReadLen == -1) return;
+    static thread_local std::vector<int> c;
     if ((int)c.size() < maxReadLen + 1) c.assign(maxReadLen + 1, 0);
     const int len = (int)read.size();
     if (len < k) { minCount = medianCount = -1; avgCount = -1; return; }
     int n = 0, sum = 0;
     eachValid(read, [&](uint64_t kc) {
-      auto it = cnt.find(kc);
-      int v = it == cnt.end() ? 0 : it->second;
+      int v = count(kc);
       if (v <= 0) v = 1;
       c[n++] = v; sum += v;
     });
@@ -261,8 +289,9 @@ bool isLowComplexity(const std::string &s) {   // main.cpp:183-205
   return low >= 2;
 }
 
-// ProcessRead (main.cpp:224-449): read-through clipping, mate merging, low-complexity filter, 21-mer counting
-void processRead(SortRead r1, SortRead r2, bool hasMate2, KmerCounter &kc, std::vector<SortRead> &out) {
+// ProcessRead (main.cpp:224-449): read-through clipping, mate merging, low-complexity filter; the 21-mer counting of the
+// surviving reads (same multiset of AddCount calls) is done afterwards over the whole read list
+void processRead(SortRead r1, SortRead r2, bool hasMate2, std::vector<SortRead> &out) {
   int rWeight = 1;
   bool r2Alive = hasMate2;
   if (hasMate2) {
@@ -312,10 +341,9 @@ void processRead(SortRead r1, SortRead r2, bool hasMate2, KmerCounter &kc, std::
   }
   if (!isLowComplexity(r1.read)) {
     out.push_back(r1);
-    kc.addCount(r1.read);
-    if (rWeight == 2) { SortRead w = r1; w.id += ".1"; out.push_back(w); kc.addCount(w.read); }
+    if (rWeight == 2) { SortRead w = r1; w.id += ".1"; out.push_back(w); }
   }
-  if (r2Alive && !isLowComplexity(r2.read)) { out.push_back(r2); kc.addCount(r2.read); }
+  if (r2Alive && !isLowComplexity(r2.read)) out.push_back(r2);
 }
 
 // SeqSet::DnaToAa / HasMotif (SeqSet.hpp:638-749, 5029-5074); note that the reference translates `read`, not its
@@ -398,6 +426,7 @@ int main(int argc, char *argv[]) {
     else { fprintf(stderr, "%s", USAGE); return EXIT_FAILURE; }
   }
   if (refFa.empty()) { fprintf(stderr, "Need to use -f to specify the receptor genome sequence.\n"); return EXIT_FAILURE; }
+  if (getenv("T4_THREADS")) threadCnt = atoi(getenv("T4_THREADS")) > 0 ? atoi(getenv("T4_THREADS")) : 1;
   if (shardCount > 1 && !hasBarcode) { fprintf(stderr, "--cellShard needs --barcode: without barcodes the Add pass does not shard (DESIGN.md 6).\n"); return EXIT_FAILURE; }
 
   t4_ctx *ctx = nullptr;
@@ -412,8 +441,17 @@ int main(int argc, char *argv[]) {
   PrintLog("Start to assemble reads.");
 
   // ---- read input, mate processing, 21-mer counting (main.cpp:787-915)
-  KmerCounter kmerCount(21);
+  KmerCounter kmerCount(21, threadCnt);
   std::vector<SortRead> sortedReads;
+  struct InPair { SortRead a, b; bool haveMate; };
+  std::vector<InPair> block;
+  const size_t BLOCK = 262144;
+  auto flushBlock = [&]() {   // ProcessRead of every pair of the block on the host threads, results appended in input order
+    std::vector<std::vector<SortRead>> outs(block.size());
+    parallelFor((long long)block.size(), threadCnt, [&](long long i) { processRead(std::move(block[(size_t)i].a), std::move(block[(size_t)i].b), block[(size_t)i].haveMate, outs[(size_t)i]); });
+    for (auto &v : outs) for (SortRead &r : v) sortedReads.push_back(std::move(r));
+    block.clear();
+  };
   int firstReadLen = -1, nIn = 0;
   std::unordered_map<std::string, int> barcodeStrToInt, umiStrToInt;
   std::vector<std::string> barcodeIntToStr;
@@ -449,21 +487,27 @@ int main(int argc, char *argv[]) {
       ++nIn;
       if (nIn % 100000 == 0) PrintLog("Read in and count kmers for %d reads.", nIn);
     } else if (hasMate) { fprintf(stderr, "The two mate-pair read files have different number of reads.\n"); exit(1); }
-    processRead(nr, mate, haveMate, kmerCount, sortedReads);
+    block.push_back(InPair{std::move(nr), std::move(mate), haveMate});
+    if (block.size() >= BLOCK) flushBlock();
   }
+  flushBlock();
+  if (getenv("T4_TIMING")) PrintLog("timing: input parsed and mates processed");
   int readCnt = (int)sortedReads.size();
   int maxReadLen = 0;
   for (const SortRead &r : sortedReads) if ((int)r.read.size() > maxReadLen) maxReadLen = (int)r.read.size();
   kmerCount.maxReadLen = maxReadLen;   // KmerCount::SetBuffer (main.cpp:979)
+  kmerCount.addCountAll((long long)sortedReads.size(), threadCnt, [&](long long i) -> const std::string & { return sortedReads[(size_t)i].read; });
+  if (getenv("T4_TIMING")) PrintLog("timing: 21-mers counted");
   auto writeEmpty = [&](const char *suffix) { FILE *fp = fopen((outputPrefix + suffix).c_str(), "w"); if (fp) fclose(fp); };
   if (readCnt <= 0) { writeEmpty("_raw.out"); writeEmpty("_assembled_reads.fa"); writeEmpty("_final.out"); return 0; }
 
   // ---- count statistics + quality trimming (main.cpp:980-1061)
-  for (SortRead &r : sortedReads) {
+  parallelFor((long long)sortedReads.size(), threadCnt, [&](long long i) {
+    SortRead &r = sortedReads[(size_t)i];
     kmerCount.statsAndTrim(r.read, (trimLevel == 0 || !r.hasQual) ? nullptr : &r.qual, r.minCnt, r.medianCnt, r.avgCnt);
-    r.qual.clear(); r.hasQual = false;
+    r.qual.clear(); r.qual.shrink_to_fit(); r.hasQual = false;
     if (r.read.empty()) r.dead = true;
-  }
+  });
   {
     std::vector<SortRead> kept;
     for (SortRead &r : sortedReads) if (!r.dead) { r.len = (int)r.read.size(); kept.push_back(std::move(r)); }
@@ -471,7 +515,7 @@ int main(int argc, char *argv[]) {
     readCnt = (int)sortedReads.size();
   }
   PrintLog("Found %i reads.", readCnt);
-  kmerCount.cnt.clear();
+  kmerCount.shards.clear();
   for (int i = 0; i < readCnt; ++i) { sortedReads[i].info = i; sortedReads[i].mateIdx = -1; }
   for (int i = 0; i < readCnt - 1; ++i)
     if (sortedReads[i].id == sortedReads[i + 1].id) { sortedReads[i].mateIdx = i + 1; sortedReads[i + 1].mateIdx = i; ++i; }
@@ -500,23 +544,26 @@ int main(int argc, char *argv[]) {
   if (hasBarcode) {
     std::sort(sortedReads.begin(), sortedReads.end(), compReadWithBarcode);
     PrintLog("Get barcode-wise kmer count.");
+    std::vector<std::pair<int, int>> groups;
     for (int i = 0; i < readCnt;) {
       int j = i + 1;
       while (j < readCnt && sortedReads[j].barcode == sortedReads[i].barcode) ++j;
+      groups.push_back({i, j});
+      i = j;
+    }
+    parallelFor((long long)groups.size(), threadCnt, [&](long long gI) {   // one private counter per barcode
+      const int i = groups[(size_t)gI].first, j = groups[(size_t)gI].second;
       KmerCounter bkc(21);
       bkc.maxReadLen = maxReadLen;
       for (int t = i; t < j; ++t) bkc.addCount(sortedReads[t].read);
       for (int t = i; t < j; ++t)
         bkc.statsAndTrim(sortedReads[t].read, nullptr, sortedReads[t].barcodeMinCnt, sortedReads[t].barcodeMedianCnt, sortedReads[t].barcodeAvgCnt);
-      i = j;
-    }
+    });
     PrintLog("Finish barcode-wise kmer count.");
-    for (int i = 0; i < readCnt;) {
-      int j = i + 1;
-      while (j < readCnt && sortedReads[j].barcode == sortedReads[i].barcode) ++j;
+    parallelFor((long long)groups.size(), threadCnt, [&](long long gI) {
+      const int i = groups[(size_t)gI].first, j = groups[(size_t)gI].second;
       if (j - i > 1) std::sort(sortedReads.begin() + i, sortedReads.begin() + j, compReadWithBarcode);
-      i = j;
-    }
+    });
     PrintLog("Finish re-sorting the reads based on barcode.");
   }
 
@@ -610,7 +657,6 @@ int main(int argc, char *argv[]) {
   std::vector<int> barcodeTotalReadCount(barcodeIntToStr.size(), 0), barcodeReadCount(barcodeIntToStr.size(), 0);
   if (hasBarcode) for (int i = 0; i < readCnt; ++i) if (sortedReads[i].barcode != -1) ++barcodeTotalReadCount[sortedReads[i].barcode];
   std::atomic<int> assembledReadCnt(0);
-  if (getenv("T4_THREADS")) threadCnt = atoi(getenv("T4_THREADS")) > 0 ? atoi(getenv("T4_THREADS")) : 1;
   const int WINDOW = getenv("T4_WINDOW") ? atoi(getenv("T4_WINDOW")) : (hasBarcode ? 4 : 16);
   const int LANES = getenv("T4_LANES") ? atoi(getenv("T4_LANES")) : 4096;
 
