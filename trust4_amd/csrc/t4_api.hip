@@ -89,7 +89,7 @@ struct t4_index {
   int2 *dPost = nullptr;
   T4SeqInfo *dSeqs = nullptr;
   char *dCons = nullptr;
-  int4 *dPw = nullptr;
+  T4PW *dPw = nullptr;
   T4IndexView view;
 };
 
@@ -430,7 +430,7 @@ int commitWithPostings(t4_index *ix, std::vector<Rec> &recs) {
   // sequence table
   std::vector<T4SeqInfo> infos(ix->seqs.size());
   std::string cons;
-  std::vector<int4> pw;
+  std::vector<T4PW> pw;
   bool hasNovel = false;
   for (size_t id = 0; id < ix->seqs.size(); ++id) {
     const HostSeq &s = ix->seqs[id];
@@ -447,8 +447,8 @@ int commitWithPostings(t4_index *ix, std::vector<Rec> &recs) {
     if (!s.isRef) {
       hasNovel = true;
       f.pwOff = (int)pw.size();
-      for (int i = 0; i < f.len; ++i) pw.push_back(make_int4(s.pw[4 * i], s.pw[4 * i + 1], s.pw[4 * i + 2], s.pw[4 * i + 3]));
-      pw.push_back(make_int4(0, 0, 0, 0));
+      for (int i = 0; i < f.len; ++i) pw.push_back(t4PwByte(s.pw[4 * i], s.pw[4 * i + 1], s.pw[4 * i + 2], s.pw[4 * i + 3]));
+      pw.push_back(t4PwByte(0, 0, 0, 0));
     }
   }
   int r;
@@ -464,7 +464,7 @@ int commitWithPostings(t4_index *ix, std::vector<Rec> &recs) {
   if (!post.empty()) HIPCHK(c, hipMemcpy(ix->dPost, post.data(), sizeof(int2) * post.size(), hipMemcpyHostToDevice));
   if (!infos.empty()) HIPCHK(c, hipMemcpy(ix->dSeqs, infos.data(), sizeof(T4SeqInfo) * infos.size(), hipMemcpyHostToDevice));
   if (!cons.empty()) HIPCHK(c, hipMemcpy(ix->dCons, cons.data(), cons.size(), hipMemcpyHostToDevice));
-  if (!pw.empty()) HIPCHK(c, hipMemcpy(ix->dPw, pw.data(), sizeof(int4) * pw.size(), hipMemcpyHostToDevice));
+  if (!pw.empty()) HIPCHK(c, hipMemcpy(ix->dPw, pw.data(), sizeof(T4PW) * pw.size(), hipMemcpyHostToDevice));
   if (direct) HIPCHK(c, hipMemcpy(ix->dTable, table.data(), sizeof(uint2) * table.size(), hipMemcpyHostToDevice));
   else HIPCHK(c, hipMemcpy(ix->dHtab, htab.data(), sizeof(T4HashEnt) * htab.size(), hipMemcpyHostToDevice));
   T4IndexView &v = ix->view;
@@ -725,12 +725,18 @@ int t4_gap_dp(t4_ctx *c, int kind, int impl, int n, const int64_t *t_off, const 
   if ((r = ensureScratch(c, grid * 64))) return r;
   long long *dT = nullptr, *dP = nullptr;
   char *dTc = nullptr, *dPc = nullptr;
-  int4 *dTw = nullptr;
+  T4PW *dTw = nullptr;
   int *dOut = nullptr;
   size_t tn = (size_t)t_off[n], pn = (size_t)p_off[n];
   if ((r = devAlloc(c, &dT, (size_t)n + 1)) || (r = devAlloc(c, &dP, (size_t)n + 1)) || (r = devAlloc(c, &dPc, pn + 16)) || (r = devAlloc(c, &dOut, (size_t)n * 4))) return r;
   if (kind == 0) { if ((r = devAlloc(c, &dTc, tn + 16))) return r; HIPCHK(c, hipMemcpy(dTc, t_data, tn, hipMemcpyHostToDevice)); }
-  else { if ((r = devAlloc(c, &dTw, tn + 1))) return r; HIPCHK(c, hipMemcpy(dTw, t_data, tn * sizeof(int4), hipMemcpyHostToDevice)); }
+  else {   // _posWeight columns (4 x int32) -> predicate bytes
+    std::vector<T4PW> wb(tn + 1, t4PwByte(0, 0, 0, 0));
+    const int32_t *w4 = (const int32_t *)t_data;
+    for (size_t i = 0; i < tn; ++i) wb[i] = t4PwByte(w4[4 * i], w4[4 * i + 1], w4[4 * i + 2], w4[4 * i + 3]);
+    if ((r = devAlloc(c, &dTw, tn + 16))) return r;
+    HIPCHK(c, hipMemcpy(dTw, wb.data(), tn + 1, hipMemcpyHostToDevice));
+  }
   HIPCHK(c, hipMemcpy(dT, t_off, sizeof(long long) * ((size_t)n + 1), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(dP, p_off, sizeof(long long) * ((size_t)n + 1), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(dPc, p_chars, pn, hipMemcpyHostToDevice));
@@ -1058,10 +1064,10 @@ int t4_cellstore_close(t4_cellstore *cs, int slot) {
 size_t t4_cellstore_image_bytes(int nseq, int64_t nkeys, int64_t npost, int64_t cons_bytes) {
   auto al16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
   size_t sz = 64;
-  while (sz < 2 * (size_t)nkeys + 2) sz <<= 1;
-  const size_t pwCount = (size_t)cons_bytes;   // one int4 per consensus byte incl. the terminators
-  const size_t oPost = al16(sizeof(T4HashEnt) * sz), oSeq = al16(oPost + sizeof(int2) * (size_t)npost),
-               oPw = al16(oSeq + sizeof(T4SeqInfo) * (size_t)nseq), oCons = al16(oPw + sizeof(int4) * pwCount);
+  while (2 * sz < 3 * (size_t)nkeys + 2) sz <<= 1;   // load factor <= 2/3
+  const size_t pwCount = (size_t)cons_bytes;   // one predicate byte per consensus byte incl. the terminators
+  const size_t oPost = al16(sizeof(T4HashEntC) * sz), oSeq = al16(oPost + sizeof(int2) * (size_t)npost),
+               oPw = al16(oSeq + sizeof(T4SeqInfo) * (size_t)nseq), oCons = al16(oPw + sizeof(T4PW) * pwCount);
   return al16(oCons + (size_t)cons_bytes + 16) + al16(sizeof(T4IndexView));
 }
 
@@ -1099,7 +1105,7 @@ int t4_cellstore_stage(t4_cellstore *cs, int slot, int barcode, int nseq, const 
   int64_t npost = 0;
   for (size_t i = 0; i < nkeys; ++i) npost += keyCnt[i];
   size_t sz = 64;
-  while (sz < 2 * nkeys + 2) sz <<= 1;
+  while (2 * sz < 3 * nkeys + 2) sz <<= 1;   // load factor <= 2/3
   size_t consBytes = 0, pwCount = 0;
   for (int i = 0; i < nseq; ++i) {
     size_t l = strlen(cons[i]);
@@ -1107,8 +1113,8 @@ int t4_cellstore_stage(t4_cellstore *cs, int slot, int barcode, int nseq, const 
     consBytes += l + 1; pwCount += l + 1;
   }
   auto al16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
-  const size_t oHt = 0, oPost = al16(oHt + sizeof(T4HashEnt) * sz), oSeq = al16(oPost + sizeof(int2) * (size_t)npost),
-               oPw = al16(oSeq + sizeof(T4SeqInfo) * (size_t)nseq), oCons = al16(oPw + sizeof(int4) * pwCount),
+  const size_t oHt = 0, oPost = al16(oHt + sizeof(T4HashEntC) * sz), oSeq = al16(oPost + sizeof(int2) * (size_t)npost),
+               oPw = al16(oSeq + sizeof(T4SeqInfo) * (size_t)nseq), oCons = al16(oPw + sizeof(T4PW) * pwCount),
                blobBytes = al16(oCons + consBytes + 16);
   int r;
   const size_t viewBytes = al16(sizeof(T4IndexView));
@@ -1136,9 +1142,8 @@ int t4_cellstore_stage(t4_cellstore *cs, int slot, int barcode, int nseq, const 
     cs->descs.push_back(d0); cs->descs.push_back(d1);
     cs->stUsed += blobBytes + viewBytes;
   }
-  memset(b + oPost, 0, blobBytes + viewBytes - oPost);
-  T4HashEnt *ht = (T4HashEnt *)(b + oHt);
-  for (size_t i = 0; i < sz; ++i) { ht[i].code = 0; ht[i].h = -1; ht[i].start = 0; ht[i].cnt = 0; ht[i].pad = 0; }
+  memset(b, 0, blobBytes + viewBytes);
+  T4HashEntC *ht = (T4HashEntC *)(b + oHt);
   int2 *post = (int2 *)(b + oPost);
   const unsigned long long hashMask = sz - 1;
   size_t at = 0;
@@ -1150,13 +1155,15 @@ int t4_cellstore_stage(t4_cellstore *cs, int slot, int barcode, int nseq, const 
       if (id < 0 || id >= nseq) return fail(c, T4_ERR_ARG, "posting names sequence %d of %d", id, nseq);
       post[at + j] = make_int2(id, postIn[2 * (at + j) + 1]);
     }
-    unsigned long long s = t4k::mix64(cd * 1000003ull + (unsigned long long)hb) & hashMask;
-    while (ht[s].h >= 0) s = (s + 1) & hashMask;
-    ht[s].code = cd; ht[s].h = hb; ht[s].start = (unsigned)at; ht[s].cnt = (unsigned)cnt;
+    if (cnt <= 0) continue;
+    if (hb != (int)((cd + (unsigned long long)(long long)(barcode + 1)) % 1000003ull)) return fail(c, T4_ERR_ARG, "key of another barcode in the image of barcode %d", barcode);
+    unsigned long long s = t4k::mix64(cd) & hashMask;
+    while (ht[s].cnt != 0) s = (s + 1) & hashMask;
+    ht[s].code = cd; ht[s].start = (unsigned)at; ht[s].cnt = (unsigned)cnt;
     at += (size_t)cnt;
   }
   T4SeqInfo *infos = (T4SeqInfo *)(b + oSeq);
-  int4 *pwOut = (int4 *)(b + oPw);
+  T4PW *pwOut = (T4PW *)(b + oPw);
   char *consOut = (char *)(b + oCons);
   size_t consAt = 0, pwAt = 0;
   for (int i = 0; i < nseq; ++i) {
@@ -1171,13 +1178,14 @@ int t4_cellstore_stage(t4_cellstore *cs, int slot, int barcode, int nseq, const 
     f.geneType = gt < 0 ? 255 : (unsigned char)gt;
     f.name0 = (unsigned char)nm[0]; f.name1 = (unsigned char)nm[1]; f.name2 = (unsigned char)nm[2]; f.name3 = (unsigned char)nm[3];
     f.pwOff = (int)pwAt;
-    if (l > 0 && pw[i]) memcpy(pwOut + pwAt, pw[i], sizeof(int4) * (size_t)l);
+    if (l > 0 && pw[i]) for (int t = 0; t < l; ++t) pwOut[pwAt + t] = t4PwByte(pw[i][4 * t], pw[i][4 * t + 1], pw[i][4 * t + 2], pw[i][4 * t + 3]);
+    for (size_t t = (l > 0 && pw[i]) ? (size_t)l : 0; t <= (size_t)l; ++t) pwOut[pwAt + t] = t4PwByte(0, 0, 0, 0);
     pwAt += (size_t)l + 1;
   }
   T4IndexView &v = *(T4IndexView *)(b + blobBytes);
-  v.k = cs->k; v.nseq = nseq; v.direct = 0; v.considerBarcode = 1;
-  v.hashMask = hashMask; v.table = nullptr; v.htab = (const T4HashEnt *)(slotBase + oHt); v.post = (const int2 *)(slotBase + oPost);
-  v.seqs = (const T4SeqInfo *)(slotBase + oSeq); v.cons = (const char *)(slotBase + oCons); v.pw = (const int4 *)(slotBase + oPw);
+  v.k = cs->k; v.nseq = nseq; v.direct = 2; v.considerBarcode = 1;
+  v.hashMask = hashMask; v.table = nullptr; v.htab = nullptr; v.ctab = (const T4HashEntC *)(slotBase + oHt); v.post = (const int2 *)(slotBase + oPost);
+  v.seqs = (const T4SeqInfo *)(slotBase + oSeq); v.cons = (const char *)(slotBase + oCons); v.pw = (const T4PW *)(slotBase + oPw);
   v.radius = cs->radius; v.hitLenRequired = cs->hitLenRequired; v.nomatchGapLimit = cs->nomatchGapLimit;
   v.firstIsRef = 0; v.hasNovel = 1;
   v.novelSim = cs->novelSim; v.refSim = 0.75; v.repeatSim = 0.95;

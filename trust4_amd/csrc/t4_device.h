@@ -25,6 +25,24 @@ struct T4SeqInfo {           // 24 bytes per sequence of the set
   unsigned short pad1;
 };
 
+// A posWeight column as the kernels see it. Every consumer of _posWeight on this path goes through
+// AlignAlgo::IsBaseEqual (AlignAlgo.hpp:49-55): sum == 0 || c == 'N' || sum < 3 * count[c]. So a column is stored as its
+// five predicate bits: bit x (0..3) = (sum < 3 * count[x]), bit 4 = (sum == 0). 1 byte / base instead of 16.
+typedef unsigned char T4PW;
+static inline
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+T4PW t4PwByte(int a, int c, int g, int t) {
+  const int sum = a + c + g + t;
+  return (T4PW)((sum == 0 ? 16 : 0) | (sum < 3 * a ? 1 : 0) | (sum < 3 * c ? 2 : 0) | (sum < 3 * g ? 4 : 0) | (sum < 3 * t ? 8 : 0));
+}
+
+struct T4HashEntC {          // slot of a per-barcode image: one barcode, so the bucket is implied by the code; cnt == 0 = empty
+  unsigned long long code;
+  unsigned start, cnt;
+};
+
 struct T4HashEnt {           // open-addressing slot of the (code, bucket) -> postings map
   unsigned long long code;
   int h;                     // KmerIndex bucket id; -1 = empty slot
@@ -33,14 +51,15 @@ struct T4HashEnt {           // open-addressing slot of the (code, bucket) -> po
 };
 
 struct alignas(16) T4IndexView {   // 128 bytes: per-barcode views are scattered in 16-byte units
-  int k, nseq, direct, considerBarcode;
+  int k, nseq, direct /* 0 htab, 1 table, 2 ctab */, considerBarcode;
   unsigned long long hashMask;
   const uint2 *table;        // direct-addressed [4^k] {start,cnt} (k <= 12, no barcode)
   const T4HashEnt *htab;
   const int2 *post;          // postings (idx, offset) -- sizeof(_indexInfo) = 8
   const T4SeqInfo *seqs;
   const char *cons;
-  const int4 *pw;            // posWeight counts (A,C,G,T) of novel contigs
+  const T4PW *pw;            // posWeight predicate bytes of novel contigs
+  const T4HashEntC *ctab;    // direct == 2
   int radius, hitLenRequired, nomatchGapLimit, firstIsRef, hasNovel;
   double novelSim, refSim, repeatSim;
 };

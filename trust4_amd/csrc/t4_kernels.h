@@ -78,10 +78,19 @@ __host__ __device__ __forceinline__ unsigned long long mix64(unsigned long long 
 // KmerIndex::Search (KmerIndex.hpp:104-116): (start, cnt) of the posting list of a valid k-mer.
 __device__ __forceinline__ void indexLookup(const T4IndexView &ix, unsigned long long code, int barcode,
                                             unsigned &start, unsigned &cnt) {
-  if (ix.direct) {
+  if (ix.direct == 1) {
     uint2 e = ix.table[code];
     start = e.x; cnt = e.y;
     return;
+  }
+  if (ix.direct == 2) {   // per-barcode image
+    unsigned long long i = mix64(code) & ix.hashMask;
+    for (;;) {
+      T4HashEntC e = ix.ctab[i];
+      if (e.cnt == 0) { start = 0; cnt = 0; return; }
+      if (e.code == code) { start = e.start; cnt = e.cnt; return; }
+      i = (i + 1) & ix.hashMask;
+    }
   }
   int h = (int)((code + (unsigned long long)(long long)(ix.considerBarcode ? barcode + 1 : 0)) % 1000003ull);
   unsigned long long i = mix64(code * 1000003ull + (unsigned long long)h) & ix.hashMask;
@@ -222,17 +231,14 @@ __device__ bool dpAffine(const char *t, int lent, const char *p, int lenp, DPScr
 }
 
 // AlignAlgo::IsBaseEqual (AlignAlgo.hpp:49-55)
-__device__ __forceinline__ bool baseEqualW(int4 w, char c) {
-  int sum = w.x + w.y + w.z + w.w;
-  if (sum == 0 || c == 'N') return true;
-  int n = nuc2(c);
-  int wc = n == 0 ? w.x : n == 1 ? w.y : n == 2 ? w.z : w.w;
-  return sum < 3 * wc;
+__device__ __forceinline__ bool baseEqualW(T4PW w, char c) {
+  if ((w & 16) || c == 'N') return true;
+  return (w >> nuc2(c)) & 1;
 }
 
 // AlignAlgo::GlobalAlignment_PosWeight (AlignAlgo.hpp:57-216). When `align` is non-null the edit
 // string (terminated by -1) is written there (lane-private global memory, needs lent+lenp+2 bytes).
-__device__ bool dpPosWeight(const int4 *w, int lent, const char *p, int lenp, DPScratch sc, int lane,
+__device__ bool dpPosWeight(const T4PW *w, int lent, const char *p, int lenp, DPScratch sc, int lane,
                             int &nMatch, int &nMis, int &nIndel, signed char *align) {
   nMatch = nMis = nIndel = 0;
   if (lent == 0 || lenp == 0) { if (align) align[0] = -1; return true; }
@@ -412,7 +418,7 @@ __device__ bool dpAffineFwd(const char *t, int lent, const char *p, int lenp, in
   return true;
 }
 
-__device__ bool dpPosWeightFwd(const int4 *w, int lent, const char *p, int lenp, int *slot, int slotStride,
+__device__ bool dpPosWeightFwd(const T4PW *w, int lent, const char *p, int lenp, int *slot, int slotStride,
                                int &nMatch, int &nMis, int &nIndel) {
   nMatch = nMis = nIndel = 0;
   if (lent == 0 || lenp == 0) return true;
@@ -997,7 +1003,7 @@ __device__ bool dpAffineQuick(const char *t, int lent, const char *p, int lenp, 
   cnt = CNT_MATCH * (unsigned)(lent - mm) + CNT_MIS * (unsigned)mm;
   return true;
 }
-__device__ bool dpPosWeightQuick(const int4 *w, int lent, const char *p, int lenp, unsigned &cnt) {
+__device__ bool dpPosWeightQuick(const T4PW *w, int lent, const char *p, int lenp, unsigned &cnt) {
   cnt = 0;
   if (lent == 0 || lenp == 0) return true;
   if (lent != lenp) return false;
@@ -1019,7 +1025,7 @@ __device__ bool dpPosWeightQuick(const int4 *w, int lent, const char *p, int len
 // Every lane of the wave must call it with the same arguments. tbuf: >= lent bytes of LDS (affine only).
 // ------------------------------------------------------------------------------------------------
 template <bool PW>
-__device__ unsigned dpWave(const char *t, const int4 *w, int lent, const char *p, int lenp, char *tbuf) {
+__device__ unsigned dpWave(const char *t, const T4PW *w, int lent, const char *p, int lenp, char *tbuf) {
   const int d = laneId();
   if (lent == 0 || lenp == 0) return 0u;
   if (lent == 1 && lenp == 1) {
@@ -1337,7 +1343,7 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
       const int lent = qb - (pb + ix.k), lenp = qa - (pa + ix.k);
       const char *r = ((o.flags & OV_PLUS) ? wm.seg : wm.rc) + pa + ix.k;
       const T4SeqInfo si = ix.seqs[o.seqIdx];
-      unsigned c = si.isRef ? dpWave<false>(ix.cons + si.consOff + pb + ix.k, (const int4 *)0, lent, r, lenp, tbuf)
+      unsigned c = si.isRef ? dpWave<false>(ix.cons + si.consOff + pb + ix.k, (const T4PW *)0, lent, r, lenp, tbuf)
                             : dpWave<true>((const char *)0, ix.pw + si.pwOff + pb + ix.k, lent, r, lenp, tbuf);
       if (c == DP_FAIL && laneId() == 0) {   // band wider than a wavefront: lane-serial scratch version
         int c0, c1, c2;
@@ -1531,7 +1537,7 @@ struct ExtSide { short size, good, match, mis, indel, pending; };
 struct ExtOut { int ret, rs, re, ss, se, matchCnt, simFail, den; };   // similarity = matchCnt / den unless simFail
 
 // banded posWeight DP of an L x L problem (W = 11) by one wavefront; dir bytes -> dirbuf[i * 11 + d]
-__device__ void dpWaveTracePW(const int4 *w, int L, const char *p, unsigned char *dirbuf) {
+__device__ void dpWaveTracePW(const T4PW *w, int L, const char *p, unsigned char *dirbuf) {
   const int d = laneId(), W = 11, leftBand = 5;
   const int negInf = (L + 1) * (L + 1) * (-4);
   int M = negInf;
@@ -1599,7 +1605,7 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
     int size, t0, p0;   // overhang length; first target / read position of the overhang
     if (side == 0) { size = o.rs < o.ss ? o.rs : o.ss; t0 = o.ss - size; p0 = o.rs - size; }
     else { int a = len - 1 - o.re, b = si.len - 1 - o.se; size = a < b ? a : b; t0 = o.se + 1; p0 = o.re + 1; }
-    const int4 *w = ix.pw + si.pwOff + t0;
+    const T4PW *w = ix.pw + si.pwOff + t0;
     int mm = 0, good = 0, tmp = 0;
     for (int k = 0; k < size; ++k) mm += baseEqualW(w[k], r[p0 + k]) ? 0 : 1;
     e.size = (short)size; e.match = (short)(size - mm); e.mis = (short)mm; e.indel = 0; e.pending = 0;
@@ -1980,7 +1986,7 @@ __global__ __launch_bounds__(64) void hitsKernel(T4IndexView ix, T4BatchView bv,
 // chars, kind 1: GlobalAlignment_PosWeight on weights. impl 0: forward LDS version with scratch fallback
 // (what overlap scoring uses), impl 1: scratch + traceback version only. out: 3 ints per problem.
 __global__ __launch_bounds__(64) void gapDpKernel(int kind, int impl, int n, const long long *tOff, const long long *pOff,
-                                                 const char *tChars, const int4 *tW, const char *pChars, int *out,
+                                                 const char *tChars, const T4PW *tW, const char *pChars, int *out,
                                                  int *dpRows, unsigned char *dpDir) {
   __shared__ int s_slots[4 * T4_DPW * 64];   // 32 KiB
   __shared__ char s_p[64][T4_MAXGAP + 8];
@@ -1995,7 +2001,7 @@ __global__ __launch_bounds__(64) void gapDpKernel(int kind, int impl, int n, con
       if (lenp <= T4_MAXGAP) {
         for (int j = lane; j < lenp; j += 64) s_p[0][j] = pChars[pOff[i] + j];
         __syncthreads();
-        c = kind == 0 ? dpWave<false>(tChars + tOff[i], (const int4 *)0, lent, s_p[0], lenp, s_p[1])
+        c = kind == 0 ? dpWave<false>(tChars + tOff[i], (const T4PW *)0, lent, s_p[0], lenp, s_p[1])
                       : dpWave<true>((const char *)0, tW + tOff[i], lent, s_p[0], lenp, s_p[1]);
         __syncthreads();
       }
