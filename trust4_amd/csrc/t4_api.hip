@@ -963,6 +963,10 @@ struct t4_cellstore {
   std::vector<T4CopyDesc> descs;
   T4CopyDesc *dDescs = nullptr;
   size_t descCap = 0;
+  std::vector<T4BytePatch> patches;
+  T4BytePatch *dPatches = nullptr;
+  size_t patchCap = 0;
+  int64_t bytesPatched = 0;
   int64_t bytesStaged = 0;
   std::mutex mu;   // t4_cellstore_stage may run on several host threads after t4_cellstore_prepare
   static constexpr size_t CHUNK = (size_t)256 << 20;
@@ -995,8 +999,27 @@ int cellStagingReserve(t4_cellstore *cs, size_t more) {
   cs->stHost = nh; cs->stDev = nd; cs->stCap = ncap;
   return T4_OK;
 }
+int cellFlushPatches(t4_cellstore *cs) {
+  if (cs->patches.empty()) return T4_OK;
+  t4_ctx *c = cs->ctx;
+  if (cs->patches.size() > cs->patchCap) {
+    if (cs->dPatches) { (void)hipStreamSynchronize(c->stream); (void)hipFree(cs->dPatches); cs->dPatches = nullptr; }
+    cs->patchCap = cs->patches.size() * 2;
+    HIPCHK(c, hipMalloc(&cs->dPatches, sizeof(T4BytePatch) * cs->patchCap));
+  }
+  HIPCHK(c, hipMemcpyAsync(cs->dPatches, cs->patches.data(), sizeof(T4BytePatch) * cs->patches.size(), hipMemcpyHostToDevice, c->stream));
+  const int n = (int)cs->patches.size();
+  int grid = (n + 255) / 256;
+  if (grid > c->cus * 4) grid = c->cus * 4;
+  hipLaunchKernelGGL(t4k::patchKernel, dim3(grid), dim3(256), 0, c->stream, (const T4BytePatch *)cs->dPatches, n);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // the host vector is reused
+  cs->bytesPatched += n;
+  cs->patches.clear();
+  return T4_OK;
+}
 int cellFlush(t4_cellstore *cs) {
-  if (cs->descs.empty()) return T4_OK;
+  if (cs->descs.empty()) return cellFlushPatches(cs);
   t4_ctx *c = cs->ctx;
   if (cs->descs.size() > cs->descCap) {
     if (cs->dDescs) { (void)hipStreamSynchronize(c->stream); (void)hipFree(cs->dDescs); cs->dDescs = nullptr; }
@@ -1013,7 +1036,7 @@ int cellFlush(t4_cellstore *cs) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   cs->bytesStaged += (int64_t)cs->stUsed;
   cs->descs.clear(); cs->stUsed = 0;
-  return T4_OK;
+  return cellFlushPatches(cs);
 }
 }  // namespace
 
@@ -1038,6 +1061,7 @@ void t4_cellstore_destroy(t4_cellstore *cs) {
   if (cs->stDev) (void)hipFree(cs->stDev);
   if (cs->stHost) (void)hipHostFree(cs->stHost);
   if (cs->dDescs) (void)hipFree(cs->dDescs);
+  if (cs->dPatches) (void)hipFree(cs->dPatches);
   delete cs;
 }
 int t4_cellstore_set_params(t4_cellstore *cs, int hit_len_required, int radius, double novel_sim) {
@@ -1096,7 +1120,7 @@ int t4_cellstore_prepare(t4_cellstore *cs, int max_slot, size_t bytes) {
 
 int t4_cellstore_stage(t4_cellstore *cs, int slot, int barcode, int nseq, const char *const *names, const char *const *cons,
                        const int32_t *const *pw, int64_t nkeys64, const uint64_t *keyCode, const int32_t *keyBucket, const int32_t *keyCnt,
-                       const int32_t *postIn) {
+                       const int32_t *postIn, int64_t *pwOffsetInImage) {
   if (!cs || slot < 0 || slot >= (int)cs->slots.size() || !cs->slots[slot].live || nseq < 0 || nkeys64 < 0) return T4_ERR_ARG;
   t4_ctx *c = cs->ctx;
   (void)hipSetDevice(c->device);
@@ -1182,6 +1206,7 @@ int t4_cellstore_stage(t4_cellstore *cs, int slot, int barcode, int nseq, const 
     for (size_t t = (l > 0 && pw[i]) ? (size_t)l : 0; t <= (size_t)l; ++t) pwOut[pwAt + t] = t4PwByte(0, 0, 0, 0);
     pwAt += (size_t)l + 1;
   }
+  if (pwOffsetInImage) *pwOffsetInImage = (int64_t)oPw;
   T4IndexView &v = *(T4IndexView *)(b + blobBytes);
   v.k = cs->k; v.nseq = nseq; v.direct = 2; v.considerBarcode = 1;
   v.hashMask = hashMask; v.table = nullptr; v.htab = nullptr; v.ctab = (const T4HashEntC *)(slotBase + oHt); v.post = (const int2 *)(slotBase + oPost);
@@ -1189,6 +1214,17 @@ int t4_cellstore_stage(t4_cellstore *cs, int slot, int barcode, int nseq, const 
   v.radius = cs->radius; v.hitLenRequired = cs->hitLenRequired; v.nomatchGapLimit = cs->nomatchGapLimit;
   v.firstIsRef = 0; v.hasNovel = 1;
   v.novelSim = cs->novelSim; v.refSim = 0.75; v.repeatSim = 0.95;
+  return T4_OK;
+}
+
+int t4_cellstore_patch(t4_cellstore *cs, int slot, int n, const int64_t *byteOffsets, const unsigned char *values) {
+  if (!cs || slot < 0 || slot >= (int)cs->slots.size() || !cs->slots[slot].base || n < 0 || (n > 0 && (!byteOffsets || !values))) return T4_ERR_ARG;
+  const t4_cellstore::Slot &sl = cs->slots[slot];
+  for (int i = 0; i < n; ++i) {
+    if (byteOffsets[i] < 0 || (size_t)byteOffsets[i] >= sl.cap) return fail(cs->ctx, T4_ERR_ARG, "patch outside the image of slot %d", slot);
+    T4BytePatch p; p.dst = sl.base + byteOffsets[i]; p.val = values[i];
+    cs->patches.push_back(p);
+  }
   return T4_OK;
 }
 
@@ -1208,6 +1244,6 @@ int t4_cellstore_query(t4_cellstore *cs, int n, const int32_t *slots, const char
   base.k = cs->k;
   return addQueryImpl(c, base, cs->dViews, slots, n, bases, offsets, barcodes, strands, skip_repeats, factors, max_per_read, counts, ov, ext, ext_ret);
 }
-int64_t t4_cellstore_bytes_staged(const t4_cellstore *cs) { return cs ? cs->bytesStaged : 0; }
+int64_t t4_cellstore_bytes_staged(const t4_cellstore *cs) { return cs ? cs->bytesStaged + cs->bytesPatched : 0; }
 
 }  // extern "C"

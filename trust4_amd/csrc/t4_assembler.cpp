@@ -213,6 +213,10 @@ struct t4_assembler : InsertHook {
   t4_index *dev = nullptr;   // device image of the current set
   t4_cellset *owner = nullptr;   // cell of a per-barcode set: the image lives in the owner's arena slot
   int slot = -1, cellBarcode = -1;
+  // cell mode: IsBaseEqual flips since the image was staged (most changes between two queries of a cell are single columns)
+  struct PwPatch { int seq, pos; unsigned char val; };
+  std::vector<PwPatch> patches;
+  std::vector<int64_t> imgPwOff;   // byte offset of every contig's posWeight bytes inside the staged image
   int64_t windowStamp = -1;
   bool dirty = true;
   int k, radius = 10, hitLenRequired = 31;
@@ -244,7 +248,7 @@ struct t4_assembler : InsertHook {
   }
   // contig c changed in a way a query can observe (consensus, length, postings, an IsBaseEqual state of a column)
   void structuralChange(int c) {
-    dirty = true;
+    dirty = true; patches.clear();
     // a cell holds a handful of contigs which almost every read of the cell hits: any observable change ends its window
     if (owner) { for (size_t q = cacheHead; q < cache.size(); ++q) invalidateSlot((int)q); return; }
     if (winContigs.empty()) return;
@@ -258,7 +262,13 @@ struct t4_assembler : InsertHook {
     for (int x = 0; x < 4; ++x) before |= (sum < 3 * w.c[x]) ? (1u << x) : 0u;
     ++w.c[base]; ++sum;
     for (int x = 0; x < 4; ++x) after |= (sum < 3 * w.c[x]) ? (1u << x) : 0u;
-    if (before != after) structuralChange(seqIdx);   // other increments cannot be observed by a query: the image stays as it is
+    if (before == after) return;   // cannot be observed by a query: the image stays as it is
+    if (owner && !dirty && slot >= 0) {   // the resident image only needs this byte
+      for (size_t q = cacheHead; q < cache.size(); ++q) invalidateSlot((int)q);
+      patches.push_back(PwPatch{seqIdx, (int)(&w - seqs[seqIdx].pw.data()), (unsigned char)after});
+      return;
+    }
+    structuralChange(seqIdx);
   }
   int prefetch(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive);
   void beginWindow(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive);
@@ -736,9 +746,13 @@ int t4_assembler::stageImage() {   // thread-safe across cells once the owner ha
     keyCode.push_back(kv.first.code); keyBucket.push_back(kv.first.h); keyCnt.push_back((int32_t)kv.second.size());
     for (const Post &p : kv.second) { post.push_back(p.idx); post.push_back(p.offset); }
   }
+  int64_t oPw = 0;
   r = t4_cellstore_stage(owner->store, slot, cellBarcode, n, names.data(), cons.data(), pw.data(), (int64_t)keyCode.size(), keyCode.data(),
-                         keyBucket.data(), keyCnt.data(), post.data());
+                         keyBucket.data(), keyCnt.data(), post.data(), &oPw);
   if (r) return r;
+  imgPwOff.resize(n);
+  for (int i = 0; i < n; ++i) { imgPwOff[i] = oPw; oPw += (int64_t)strlen(cons[i]) + 1; }
+  patches.clear();
   dirty = false; ++refreshes; ++owner->stagedImages;
   return T4_OK;
 }
@@ -993,6 +1007,12 @@ int t4_cellset_prefetch(t4_cellset *cs, int n, t4_assembler *const *cells, const
     t4_assembler *cell = sp.cell;
     if (cell->slot < 0 && (rc = t4_cellstore_open(cs->store, &cell->slot))) return rc;
     if (cell->slot > maxSlot) maxSlot = cell->slot;
+    if (!cell->dirty && !cell->patches.empty()) {
+      std::vector<int64_t> offs; std::vector<unsigned char> vals;
+      for (const t4_assembler::PwPatch &pp : cell->patches) { offs.push_back(cell->imgPwOff[pp.seq] + pp.pos); vals.push_back(pp.val); }
+      if ((rc = t4_cellstore_patch(cs->store, cell->slot, (int)offs.size(), offs.data(), vals.data()))) return rc;
+      cell->patches.clear();
+    }
     if (cell->dirty) {
       int64_t consBytes = 0;
       for (const Seq &q : cell->seqs) consBytes += (q.released ? 0 : (int64_t)q.cons.size()) + 1;

@@ -121,4 +121,5 @@ struct T4QueryArgs {
   const int *viewOf;
 };
 
+struct T4BytePatch { unsigned char *dst; unsigned long long val; };   // one posWeight predicate byte of a resident image
 struct T4CopyDesc { unsigned long long srcOff; unsigned char *dst; unsigned long long bytes; };  // scatter of staged set images

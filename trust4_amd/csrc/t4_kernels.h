@@ -1892,6 +1892,11 @@ __global__ __launch_bounds__(256) void scatterKernel(const unsigned char *stagin
   }
 }
 
+// IsBaseEqual flips of resident per-barcode images (the common change between two queries of a cell): single bytes
+__global__ __launch_bounds__(256) void patchKernel(const T4BytePatch *patches, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) *patches[i].dst = (unsigned char)patches[i].val;
+}
+
 // Tiering: estimate H of every read (whole read, both strands) and bin the reads by capacity.
 __global__ __launch_bounds__(64) void binKernel(T4IndexView ix, T4BatchView bv, int useBarcode, int cap0, int cap1, int cap2, int cap3,
                                                int *lists, int *counts, long long listStride) {
