@@ -86,14 +86,14 @@ def stage1_e2e(pairs, cells):
         pre = os.path.join(tmp, "c5")
         subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, str(pairs), "0", "4", pre, "--cells", str(cells)], check=True)
         argv = ["-f", fa, "-1", pre + "_1.fq", "-2", pre + "_2.fq", "--barcode", pre + "_bc.fa", "--UMI", pre + "_umi.fa"]
+        cores = min(8, os.cpu_count() or 1)   # same host-thread budget for both programs
         t0 = time.perf_counter()
-        subprocess.run([os.path.join(ROOT, "trust4_amd", "bin", "trust4-hip")] + argv + ["-o", os.path.join(tmp, "mine")], check=True, stderr=subprocess.DEVNULL)
+        subprocess.run([os.path.join(ROOT, "trust4_amd", "bin", "trust4-hip"), "-t", str(cores)] + argv + ["-o", os.path.join(tmp, "mine")], check=True, stderr=subprocess.DEVNULL)
         t_mine = time.perf_counter() - t0
         out = {"workload": "C5 recipe sample: %d synthetic 150 bp PE pairs, %d cells x 2 clones, barcode + UMI files; FASTQ in -> _raw.out/_final.out/_assembled_reads.fa out" % (pairs, cells),
-               "pairs_per_s": pairs / t_mine, "seconds": t_mine, "host_threads": 1}
+               "pairs_per_s": pairs / t_mine, "seconds": t_mine, "host_threads": cores}
         ref_bin = os.path.join(ROOT, "oracle", "_ref", "trust4")
         if os.path.exists(ref_bin):
-            cores = os.cpu_count() or 1
             t0 = time.perf_counter()
             subprocess.run([ref_bin, "-t", str(cores)] + argv + ["-o", os.path.join(tmp, "ref")], check=True, stderr=subprocess.DEVNULL)
             t_ref = time.perf_counter() - t0
@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=1000000, help="read pairs per GPU per step (C2 = 1M)")
     ap.add_argument("--clones", type=int, default=20000)
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads timed on the CPU baseline (0 = skip)")
-    ap.add_argument("--e2e-pairs", type=int, default=50000, help="pairs of the whole-stage-1 leg (0 = skip)")
+    ap.add_argument("--e2e-pairs", type=int, default=100000, help="pairs of the whole-stage-1 leg (0 = skip)")
     args = ap.parse_args()
 
     import torch
