@@ -553,7 +553,9 @@ namespace {
 
 template <int CAP, int MAXOV, int NT>
 void launchTier(int grid, hipStream_t st, const T4IndexView &iv, const T4BatchView &bv, const T4Work &wk, const T4QueryArgs &qa) {
-  hipLaunchKernelGGL((t4k::queryKernel<CAP, MAXOV, NT>), dim3(grid), dim3(NT), 0, st, iv, bv, wk, qa);
+  if (qa.views) hipLaunchKernelGGL((t4k::queryKernel<CAP, MAXOV, NT, 2>), dim3(grid), dim3(NT), 0, st, iv, bv, wk, qa);
+  else if (qa.mode >= 2) hipLaunchKernelGGL((t4k::queryKernel<CAP, MAXOV, NT, 1>), dim3(grid), dim3(NT), 0, st, iv, bv, wk, qa);
+  else hipLaunchKernelGGL((t4k::queryKernel<CAP, MAXOV, NT, 0>), dim3(grid), dim3(NT), 0, st, iv, bv, wk, qa);
 }
 
 // Shared driver of t4_overlaps / t4_annotate_rough.

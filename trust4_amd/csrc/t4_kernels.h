@@ -1681,6 +1681,9 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
 }
 
 // Process one read in one wavefront. Returns false when the read has to move to a larger tier.
+// VARIANT 0: GetOverlapsFromRead / AnnotateRead level 0 (modes 0, 1); VARIANT 1: the modes that also run ExtendOverlap
+// (2, 3, 4). Separate instantiations: the extension code must not cost the rough-annotation kernels registers.
+template <int VARIANT>
 __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const T4Work &wk, const T4QueryArgs &qa,
                             WaveMem &wm, WaveState *ws, long long r, DPScratch sc) {
   const int lane = tid(), NT = nthr();
@@ -1691,7 +1694,7 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
   if (lane == 0) { ws->phaseT0 = clock64(); ws->curPhase = 0; }
 #endif
   __syncthreads();
-  if (qa.mode == 4) {
+  if (VARIANT == 1 && qa.mode == 4) {
     // the query half of SeqSet::AddRead (SeqSet.hpp:3437 + every ExtendOverlap of 3597 / 3746): one launch, results
     // consumed by the host-side ordered commit (t4_assembler)
     ExtSide *sides = (ExtSide *)wm.pairs;
@@ -1718,7 +1721,7 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
       qa.ret[r * qa.maxPerRead + i] = res[i].ret;
     }
     if (lane == 0) qa.counts[r] = ret;
-  } else if (qa.mode == 2 || qa.mode == 3) {
+  } else if (VARIANT == 1 && (qa.mode == 2 || qa.mode == 3)) {
     // scratch carved from the arrays that are dead after overlapsFromSegment: pairs (+cand) and the key area
     ExtSide *sides = (ExtSide *)wm.pairs;                 // 2 * maxFin * 12 B  <= cap * 4 B
     ExtOut *res = (ExtOut *)wm.ov;                         // maxFin * 32 B      <= maxOv * 40 B
@@ -1790,7 +1793,7 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
         qa.ret[r * qa.maxPerRead + i] = res[i].ret;
       }
     }
-  } else if (qa.mode == 0) {
+  } else if (VARIANT == 0 && qa.mode == 0) {
     int barcode = bv.barcode ? bv.barcode[r] : -1;
     loadSegment(bv, r, 0, len, wm);
     int ret = overlapsFromSegment(ix, wm, ws, len, qa.strand, barcode, qa.skipRepeats != 0, 0, sc, hitTotal);
@@ -1798,7 +1801,7 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
     int n = ret > 0 ? ret : 0;
     if (lane == 0) qa.counts[r] = ret;
     for (int i = lane; i < n && i < qa.maxPerRead; i += NT) storeOverlap(qa.out + r * qa.maxPerRead + i, wm.fin[i]);
-  } else {
+  } else if (VARIANT == 0) {
     loadSegment(bv, r, 0, len, wm);
     if (lane == 0) contigIntervals(wm.seg, 7, ws);
     __syncthreads();
@@ -1836,7 +1839,9 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
 }
 
 // The query kernel. CAP > 0: LDS tier; CAP == 0: global-scratch tier. Persistent grid, one wave/block.
-template <int CAP, int MAXOV, int NTHREADS>
+// VARIANT 0 / 1: see processRead; VARIANT 2: mode 4 with every read matched against its own per-barcode image
+// (qa.views[qa.viewOf[read]]).
+template <int CAP, int MAXOV, int NTHREADS, int VARIANT>
 __global__ __launch_bounds__(NTHREADS) void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
   constexpr int C = CAP > 0 ? CAP : 1;
   constexpr int M = CAP > 0 ? MAXOV : 1;
@@ -1868,11 +1873,8 @@ __global__ __launch_bounds__(NTHREADS) void queryKernel(T4IndexView ix, T4BatchV
   sc.dir = wk.dpDir + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * T4_DIR_BYTES;
   for (int w = blockIdx.x; w < wk.nList; w += gridDim.x) {
     long long r = wk.list[w];
-    bool done;
-    if (qa.views) {
-      const T4IndexView cell = qa.views[qa.viewOf[r]];   // uniform address: scalar loads
-      done = processRead(cell, bv, wk, qa, wm, &s_ws, r, sc);
-    } else done = processRead(ix, bv, wk, qa, wm, &s_ws, r, sc);
+    if (VARIANT == 2) ix = qa.views[qa.viewOf[r]];   // uniform address: scalar loads
+    bool done = processRead<(VARIANT == 0 ? 0 : 1)>(ix, bv, wk, qa, wm, &s_ws, r, sc);
     if (!done && tid() == 0) {
       if (wk.nextList) { int slot = atomicAdd(wk.nextCount, 1); wk.nextList[slot] = (int)r; }
       else wk.status[r] = 2;
