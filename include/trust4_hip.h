@@ -220,7 +220,7 @@ typedef struct {
   double chain_kernel_ms; /* the dominant probe->sort->chain->score kernels only */
   int64_t total_hits;     /* sum over reads and passes of emitted _hit records */
   int64_t reads;          /* reads processed */
-  int64_t tier_reads[5];  /* reads per capacity tier (LDS 1k / 2k / 4k / 8k hits, global scratch) */
+  int64_t tier_reads[6];  /* reads per capacity tier (LDS 1k / 2k / 3k / 4k / 8k hits, global scratch) */
   int64_t launches;       /* kernel launches in the call */
 } t4_stats;
 int t4_last_stats(t4_ctx *ctx, t4_stats *out);

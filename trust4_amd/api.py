@@ -15,7 +15,7 @@ HIT_DTYPE = np.dtype([("idx", "<i4"), ("offset", "<i4"), ("readOffset", "<i4"), 
 
 class Stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("chain_kernel_ms", C.c_double), ("total_hits", C.c_int64),
-                ("reads", C.c_int64), ("tier_reads", C.c_int64 * 5), ("launches", C.c_int64)]
+                ("reads", C.c_int64), ("tier_reads", C.c_int64 * 6), ("launches", C.c_int64)]
 
 
 class T4Error(RuntimeError):

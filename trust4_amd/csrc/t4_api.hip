@@ -30,9 +30,13 @@ static_assert(sizeof(T4IndexView) % 16 == 0, "view stride");
 namespace {
 
 // per capacity tier: LDS hit capacity, threads cooperating on one read, resident workgroups per CU
-const int TIER_CAP[4] = {1024, 2048, 4096, 8192};
-const int TIER_THREADS[T4_NTIER] = {256, 256, 256, 256, 256};   // 512/1024 threads in the upper tiers measured slower (barriers)
-const int TIER_BLOCKS_PER_CU[T4_NTIER] = {6, 3, 2, 1, 2};
+const int TIER_CAP[T4_NTIER - 1] = {1024, 2048, 3072, 4096, 8192};
+// Reads in flight per CU are what counts (most phases of a read are latency bound): tier 0 runs 8 groups of 2 waves in
+// 8 x 20 KB of LDS, tier 1 4 groups of 4 waves in 4 x 39 KB, both at 128 VGPRs (4 waves / SIMD); the 3072-hit tier exists
+// because 3 of its groups fit a CU where only 2 of the 4096-hit tier do. 512/1024 threads per read in the upper tiers
+// measured slower (barriers).
+const int TIER_THREADS[T4_NTIER] = {128, 256, 256, 256, 256, 256};
+const int TIER_BLOCKS_PER_CU[T4_NTIER] = {8, 4, 3, 2, 1, 2};
 const int G_CAP = 32768, G_MAXOV = 4096;
 
 struct HostSeq {
@@ -578,10 +582,13 @@ int runQuery(t4_index *ix, t4_batch *b, T4QueryArgs qa, bool useBarcode, bool no
   HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(int) * (size_t)n, c->stream));
   HIPCHK(c, hipMemsetAsync(c->hitCounter, 0, sizeof(unsigned long long), c->stream));
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  T4TierCaps caps;
+  for (int t = 0; t < T4_NTIER - 1; ++t) caps.cap[t] = TIER_CAP[t];
+  if (noHits) caps.cap[0] = 1 << 30;
   int binGrid = c->cus * 8;
   if ((long long)binGrid > n) binGrid = (int)n;
   hipLaunchKernelGGL(t4k::binKernel, dim3(binGrid), dim3(64), 0, c->stream, ix->view, b->view, useBarcode ? 1 : 0,
-                     noHits ? (1 << 30) : TIER_CAP[0], TIER_CAP[1], TIER_CAP[2], TIER_CAP[3], c->lists, c->listCounts, (long long)n);
+                     caps, c->lists, c->listCounts, (long long)n);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
   c->stats.launches = 1;
@@ -605,9 +612,24 @@ int runQuery(t4_index *ix, t4_batch *b, T4QueryArgs qa, bool useBarcode, bool no
       wk.gKeys = c->gKeys; wk.gPairs = c->gPairs; wk.gCand = c->gCand; wk.gOv = c->gOv; wk.gFin = c->gFin; wk.gOrd = c->gOrd;
       wk.gCap = G_CAP; wk.gMaxOv = G_MAXOV;
       launchTier<0, 0, 256>(grid, c->stream, ix->view, b->view, wk, qa);
-    } else if (t == 0) launchTier<1024, 128, 256>(grid, c->stream, ix->view, b->view, wk, qa);
-    else if (t == 1) launchTier<2048, 128, 256>(grid, c->stream, ix->view, b->view, wk, qa);
-    else if (t == 2) launchTier<4096, 256, 256>(grid, c->stream, ix->view, b->view, wk, qa);
+    } else if (t == 0) {
+      static const int nt0 = getenv("T4_T0_THREADS") ? atoi(getenv("T4_T0_THREADS")) : TIER_THREADS[0];
+      static const int bl0 = getenv("T4_T0_BLOCKS") ? atoi(getenv("T4_T0_BLOCKS")) : TIER_BLOCKS_PER_CU[0];
+      static const int mo0 = getenv("T4_T0_MAXOV") ? atoi(getenv("T4_T0_MAXOV")) : 64;
+      int g0 = c->cus * bl0 < cnt ? c->cus * bl0 : cnt;
+      if (nt0 == 128 && mo0 == 64) launchTier<1024, 64, 128>(g0, c->stream, ix->view, b->view, wk, qa);
+      else if (nt0 == 128) launchTier<1024, 128, 128>(g0, c->stream, ix->view, b->view, wk, qa);
+      else if (mo0 == 64) launchTier<1024, 64, 256>(g0, c->stream, ix->view, b->view, wk, qa);
+      else launchTier<1024, 128, 256>(g0, c->stream, ix->view, b->view, wk, qa);
+    } else if (t == 1) {
+      static const int bl1 = getenv("T4_T1_BLOCKS") ? atoi(getenv("T4_T1_BLOCKS")) : TIER_BLOCKS_PER_CU[1];
+      static const int mo1 = getenv("T4_T1_MAXOV") ? atoi(getenv("T4_T1_MAXOV")) : 128;
+      int g1 = c->cus * bl1 < cnt ? c->cus * bl1 : cnt;
+      if (mo1 == 64) launchTier<2048, 64, 256>(g1, c->stream, ix->view, b->view, wk, qa);
+      else launchTier<2048, 128, 256>(g1, c->stream, ix->view, b->view, wk, qa);
+    }
+    else if (t == 2) launchTier<3072, 128, 256>(grid, c->stream, ix->view, b->view, wk, qa);
+    else if (t == 3) launchTier<4096, 256, 256>(grid, c->stream, ix->view, b->view, wk, qa);
     else launchTier<8192, 512, 256>(grid, c->stream, ix->view, b->view, wk, qa);
     HIPCHK(c, hipGetLastError());
     ++c->stats.launches;

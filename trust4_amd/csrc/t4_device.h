@@ -6,7 +6,7 @@
 #define T4_MAXPOS (2 * T4_MAXL)
 #define T4_MAXGAP 320        // longest side of one gap DP (nomatchGapLimit is 288 at k = 9)
 #define T4_DIR_BYTES 49152   // per-lane traceback bytes of one gap DP
-#define T4_NTIER 5
+#define T4_NTIER 6
 
 // key of a k-mer hit, sortable as (strand, seq idx, diagonal, seq offset)
 #define T4_IDX_BITS 22
@@ -72,6 +72,8 @@ struct T4BatchView {
   int wpk, wnm;
   long long n;
 };
+
+struct T4TierCaps { int cap[T4_NTIER - 1]; };   // hit capacity of the LDS tiers, ascending
 
 struct T4Work {              // per-launch work description
   const int *list;           // read ids of this tier

@@ -1842,7 +1842,10 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
 // VARIANT 0 / 1: see processRead; VARIANT 2: mode 4 with every read matched against its own per-barcode image
 // (qa.views[qa.viewOf[read]]).
 template <int CAP, int MAXOV, int NTHREADS, int VARIANT>
-__global__ __launch_bounds__(NTHREADS) void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
+__global__ __launch_bounds__(NTHREADS)
+// rough-annotation kernels of the two small tiers: register budget for 4 waves / SIMD (LDS lets that many groups in)
+__attribute__((amdgpu_waves_per_eu((VARIANT == 0 && CAP > 0 && CAP <= 2048) ? 4 : 1)))
+void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
   constexpr int C = CAP > 0 ? CAP : 1;
   constexpr int M = CAP > 0 ? MAXOV : 1;
   __shared__ unsigned long long s_keys[C];
@@ -1900,7 +1903,7 @@ __global__ __launch_bounds__(256) void patchKernel(const T4BytePatch *patches, i
 }
 
 // Tiering: estimate H of every read (whole read, both strands) and bin the reads by capacity.
-__global__ __launch_bounds__(64) void binKernel(T4IndexView ix, T4BatchView bv, int useBarcode, int cap0, int cap1, int cap2, int cap3,
+__global__ __launch_bounds__(64) void binKernel(T4IndexView ix, T4BatchView bv, int useBarcode, T4TierCaps caps,
                                                int *lists, int *counts, long long listStride) {
   __shared__ unsigned s_posStart[T4_MAXPOS + 8];
   __shared__ unsigned s_posPref[T4_MAXPOS + 8];
@@ -1918,7 +1921,8 @@ __global__ __launch_bounds__(64) void binKernel(T4IndexView ix, T4BatchView bv, 
       H = seedPositions(ix, wm, len, 0, barcode, false, s_posStart, s_posPref, s_red);
     }
     if (laneId() == 0) {
-      int t = H <= cap0 ? 0 : H <= cap1 ? 1 : H <= cap2 ? 2 : H <= cap3 ? 3 : 4;
+      int t = 0;
+      while (t < T4_NTIER - 1 && H > caps.cap[t]) ++t;
       int slot = atomicAdd(&counts[t], 1);
       lists[t * listStride + slot] = (int)r;
     }
