@@ -88,6 +88,15 @@ template <class T> static inline T __shfl_down(T v, unsigned d, int width = 64) 
   (void)width; int l = hipemu_lane(); return hipemu_shfl_any(v, l + (int)d < 64 ? l + (int)d : l);
 }
 template <class T> static inline T __shfl_xor(T v, int m, int width = 64) { (void)width; return hipemu_shfl_any(v, hipemu_lane() ^ m); }
+// DPP wave shifts by one lane (the only dpp_ctrl values the kernels use)
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) {
+  (void)old;
+  if (ctrl == 0x138) return __shfl_up(src, 1);
+  if (ctrl == 0x130) return __shfl_down(src, 1);
+  if (ctrl == 0x111) { int l = hipemu_lane(); return hipemu_shfl_any(src, (l & 15) ? l - 1 : l); }        // row_shr:1
+  if (ctrl == 0x101) { int l = hipemu_lane(); return hipemu_shfl_any(src, (l & 15) != 15 ? l + 1 : l); }  // row_shl:1
+  fprintf(stderr, "hipemu: dpp_ctrl 0x%x not emulated\n", ctrl); abort();
+}
 static inline unsigned long long __ballot(int pred) {
   hipemu::xchg[hipemu::cur_tid.x] = pred ? 1 : 0;
   hipemu::wave_rendezvous(__builtin_return_address(0));

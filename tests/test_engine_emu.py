@@ -205,11 +205,13 @@ def check_gap_dp(eng, seed, n):
         for t, p in zip(T, P):
             sc, al = o.global_alignment(t, p) if kind == 0 else o.global_alignment_posweight(t, p)
             exp.append((al.count(0), al.count(1), al.count(2) + al.count(3)))
-        for impl in (0, 1, 2):
+        for impl in (0, 1, 2, 3):
             got = eng.gap_dp(kind, T, P, impl)
-            wide = got[:, 3] == 2     # impl 2 only: band wider than one wavefront (the scorer falls back to impl 1)
-            assert impl == 2 or not wide.any()
-            assert ((got[:, 3] == 0) | wide).all() and wide.sum() < n // 10
+            wide = got[:, 3] == 2     # impl 2 / 3 only: band wider than one wavefront / one 16-lane row (the scorer falls back)
+            assert impl >= 2 or not wide.any()
+            assert ((got[:, 3] == 0) | wide).all() and wide.sum() < (n // 10 if impl == 2 else n // 2)
+            if impl == 3:
+                assert (~wide).sum() > n // 3
             bad = [i for i in range(n) if not wide[i] and tuple(got[i, :3]) != exp[i]]
             assert not bad, (kind, impl, bad[:5], [(T[i] if kind == 0 else T[i].tolist(), P[i], exp[i], got[i].tolist()) for i in bad[:2]])
 

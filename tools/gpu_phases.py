@@ -11,9 +11,14 @@ arr = t4libs.Synth(20000, 1).next_reads(n // 2)
 b = eng.upload(arr)
 ref.annotate_rough(b, fetch=False)
 buf = (C.c_ulonglong * 16)()
+dbg = (C.c_ulonglong * 8)()
 eng.lib.t4_debug_phase_cycles(buf)
+eng.lib.t4_debug_counters(dbg)
 ref.annotate_rough(b, fetch=False)
 eng.lib.t4_debug_phase_cycles(buf)
+eng.lib.t4_debug_counters(dbg)
+print("gap jobs %d (%.1f/read), banded %d (%.2f/read), wave-DP steps %d (%.0f/DP), scratch fallbacks %d, fallback cells %d, fallback cycles %.3e" % (
+    dbg[0], dbg[0] / n, dbg[1], dbg[1] / n, dbg[2], dbg[2] / max(1, dbg[1] - dbg[3]), dbg[3], dbg[4], dbg[5]))
 names = ["other", "seed", "expand", "sort", "stats", "runs", "bigsort", "chain", "ovsort", "score", "prefilter", "final", "annotate", "score:quick", "score:banded", "score:finish"]
 tot = sum(buf[:16])
 print(eng.stats())

@@ -229,6 +229,12 @@ int t4_debug_phase_cycles(unsigned long long *out16) {
   if (hipMemcpyToSymbol(HIP_SYMBOL(t4k::g_phaseCycles), zero, sizeof(zero)) != hipSuccess) return T4_ERR_HIP;
   return T4_OK;
 }
+int t4_debug_counters(unsigned long long *out8) {
+  unsigned long long zero[8] = {0};
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(t4k::g_dbgCount), sizeof(zero)) != hipSuccess) return T4_ERR_HIP;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(t4k::g_dbgCount), zero, sizeof(zero)) != hipSuccess) return T4_ERR_HIP;
+  return T4_OK;
+}
 #endif
 int t4_last_stats(t4_ctx *c, t4_stats *out) {
   if (!c || !out) return T4_ERR_ARG;

@@ -102,6 +102,20 @@ __device__ __forceinline__ void indexLookup(const T4IndexView &ix, unsigned long
   }
 }
 
+// Neighbour exchange by one lane as a DPP wave shift (a v_mov with a few cycles of latency instead of a ds_bpermute round
+// trip through the LDS crossbar): lane i receives lane i-1 (waveUp1; lane 0 keeps its value) or lane i+1 (waveDown1; lane 63
+// keeps its value) -- the __shfl_up / __shfl_down(v, 1) semantics. All 64 lanes must be active.
+__device__ __forceinline__ int waveUp1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
+__device__ __forceinline__ int waveDown1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false); }
+__device__ __forceinline__ unsigned waveUp1(unsigned v) { return (unsigned)waveUp1((int)v); }
+// the same inside each row of 16 lanes (lane 0 / 15 of a row keeps its value)
+__device__ __forceinline__ int rowUp1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false); }
+__device__ __forceinline__ int rowDown1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x101 /* row_shl:1 */, 0xf, 0xf, false); }
+__device__ __forceinline__ unsigned rowUp1(unsigned v) { return (unsigned)rowUp1((int)v); }
+__device__ __forceinline__ unsigned rowDown1(unsigned v) { return (unsigned)rowDown1((int)v); }
+__device__ __forceinline__ int rowSum16(int v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); return v; }
+__device__ __forceinline__ unsigned waveDown1(unsigned v) { return (unsigned)waveDown1((int)v); }
+
 __device__ __forceinline__ int nuc2(char c) { // nucToNum[c-'A'] & 3 for the packed alphabet
   return c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 0;
 }
@@ -613,10 +627,13 @@ __device__ __forceinline__ bool ovLess(const OvRec &a, const OvRec &b, bool scor
 #ifdef T4_PHASE_TIMING
 #define T4_NPHASE 16
 __device__ unsigned long long g_phaseCycles[T4_NPHASE];
+__device__ unsigned long long g_dbgCount[8];   // 0 jobs, 1 pending (banded) jobs, 2 wave-DP steps, 3 scratch fallbacks, 4 fallback cells, 5 fallback cycles
+#define DBG_ADD(i, v) do { atomicAdd(&g_dbgCount[i], (unsigned long long)(v)); } while (0)
 #define PHASE_MARK(ws, id)                                                                  \
   do { if (threadIdx.x == 0) { long long now_ = clock64(); atomicAdd(&g_phaseCycles[(ws)->curPhase], (unsigned long long)(now_ - (ws)->phaseT0)); (ws)->phaseT0 = now_; (ws)->curPhase = (id); } } while (0)
 #else
 #define PHASE_MARK(ws, id) do { } while (0)
+#define DBG_ADD(i, v) do { } while (0)
 #endif
 
 struct WaveMem {
@@ -1059,10 +1076,10 @@ __device__ unsigned dpWave(const char *t, const T4PW *w, int lent, const char *p
   }
   const int lastStep = 2 * lenp + W - 1;
   for (int s = 2; s <= lastStep; ++s) {
-    int lM = __shfl_up(M, 1), uM = __shfl_down(M, 1);
-    unsigned lC0 = __shfl_up(C0, 1), uC0 = __shfl_down(C0, 1);
+    int lM = waveUp1(M), uM = waveDown1(M);
+    unsigned lC0 = waveUp1(C0), uC0 = waveDown1(C0);
     int lF = 0, uE = 0; unsigned lC2 = 0, uC1 = 0;
-    if (!PW) { lF = __shfl_up(F, 1); lC2 = __shfl_up(C2, 1); uE = __shfl_down(E, 1); uC1 = __shfl_down(C1, 1); }
+    if (!PW) { lF = waveUp1(F); lC2 = waveUp1(C2); uE = waveDown1(E); uC1 = waveDown1(C1); }
     const int i2 = s - d, i = i2 >> 1, j = i - leftBand + d;
     if (d < W && (i2 & 1) == 0 && i >= 1 && i <= lenp && j >= 1 && j <= lent) {
       if (j == 1) {             // left neighbour is column 0
@@ -1117,6 +1134,114 @@ __device__ unsigned dpWave(const char *t, const T4PW *w, int lent, const char *p
     }
   }
   return __shfl(C0, lent - lenp + leftBand);
+}
+
+
+// The same recurrences with FOUR alignments per wavefront, one per row of 16 lanes (DPP row shifts): most bands are
+// 11 + |lent - lenp| <= 16 columns wide, so a whole wavefront per alignment leaves 3/4 of the lanes without a cell.
+// Every lane passes the job of its row (has == false: no job); rows whose band is wider than 16 columns, or whose sides
+// exceed T4_MAXGAP (or the row's tcap bytes of LDS at tbuf, affine only), get DP_FAIL and are left to dpWave.
+// All 64 lanes must call it.
+template <bool PW>
+__device__ __attribute__((noinline)) unsigned dpRow16(bool has, const char *t, const T4PW *w, int lent, const char *p, int lenp, char *tbuf, int tcap) {
+  const int d = laneId() & 15, rowBase = laneId() & 48;
+  unsigned result = 0u;
+  bool run = has;
+  if (run && (lent == 0 || lenp == 0)) { result = 0u; run = false; }
+  if (run && lent == 1 && lenp == 1) {
+    bool eq = PW ? baseEqualW(w[0], p[0]) : (t[0] == p[0] || t[0] == 'N' || p[0] == 'N');
+    result = eq ? CNT_MATCH : CNT_MIS; run = false;
+  }
+  if (PW) {   // the reference's ungapped early return (AlignAlgo.hpp:81-103)
+    const bool chk = run && lent == lenp;
+    int mm = 0;
+    if (chk) for (int i = d; i < lent; i += 16) mm += baseEqualW(w[i], p[i]) ? 0 : 1;
+    mm = rowSum16(mm);
+    if (chk && (lent - mm) * 2 - mm * 2 >= lent * 2 - 8) { result = CNT_MATCH * (unsigned)(lent - mm) + CNT_MIS * (unsigned)mm; run = false; }
+  }
+  int leftBand = 5, rightBand = 5;
+  if (lent > lenp) rightBand += lent - lenp; else if (lent < lenp) leftBand += lenp - lent;
+  const int W = leftBand + rightBand + 1;
+  if (run && (W > 16 || lent > T4_MAXGAP || lenp > T4_MAXGAP || (!PW && lent > tcap))) { result = DP_FAIL; run = false; }
+  if (!PW && run) { for (int i = d; i < lent; i += 16) tbuf[i] = t[i]; }
+  const int negInf = (lent + 1) * (lenp + 1) * (-4);
+  const int e0 = -4 + (lenp + 1) * (-4);
+  const int q4 = 4 * (lenp + 1);
+  int M = negInf, E = negInf, F = negInf;
+  unsigned C0 = 0, C1 = 0, C2 = 0;
+  if (run) {
+    int j0 = d - leftBand;
+    if (d < W && j0 >= 0 && j0 <= lent) {
+      if (j0 == 0) { M = 0; E = 0; F = 0; }
+      else if (PW) { M = -4 - 4 * j0; C0 = CNT_MATCH + CNT_INDEL * (unsigned)(j0 - 1); }
+      else { M = -4 - 4 * j0; E = e0; F = -4 - j0; C0 = CNT_INDEL * (unsigned)(j0 + (j0 > q4 ? 1 : 0)); C1 = CNT_INDEL * (unsigned)(1 + j0); C2 = CNT_INDEL * (unsigned)j0; }
+    }
+  }
+  const int lastStep = run ? 2 * lenp + W - 1 : 0;
+  int maxStep = lastStep;
+  for (int o = 16; o < 64; o <<= 1) { int v = __shfl_xor(maxStep, o); if (v > maxStep) maxStep = v; }
+  for (int s = 2; s <= maxStep; ++s) {
+    int lM = rowUp1(M), uM = rowDown1(M);
+    unsigned lC0 = rowUp1(C0), uC0 = rowDown1(C0);
+    int lF = 0, uE = 0; unsigned lC2 = 0, uC1 = 0;
+    if (!PW) { lF = rowUp1(F); lC2 = rowUp1(C2); uE = rowDown1(E); uC1 = rowDown1(C1); }
+    const int i2 = s - d, i = i2 >> 1, j = i - leftBand + d;
+    if (run && s <= lastStep && d < W && (i2 & 1) == 0 && i >= 1 && i <= lenp && j >= 1 && j <= lent) {
+      if (j == 1) {             // left neighbour is column 0
+        lM = -4 - 4 * i;
+        if (PW) lC0 = CNT_MATCH + CNT_INDEL * (unsigned)(i - 1);
+        else { lF = -4 - 4 * i; lC0 = CNT_INDEL * (unsigned)i; lC2 = CNT_INDEL * (unsigned)(1 + i); }
+      } else if (d == 0) { lM = negInf; lF = negInf; lC0 = 0; lC2 = 0; }
+      if (i == 1) {             // upper neighbour is row 0
+        uM = -4 - 4 * j;
+        if (PW) uC0 = CNT_MATCH + CNT_INDEL * (unsigned)(j - 1);
+        else { uE = e0; uC0 = CNT_INDEL * (unsigned)(j + (j > q4 ? 1 : 0)); uC1 = CNT_INDEL * (unsigned)(1 + j); }
+      } else if (d + 1 >= W) { uM = negInf; uE = negInf; uC0 = 0; uC1 = 0; }
+      int dM; unsigned dC0;     // diagonal neighbour
+      if (i == 1) {
+        int jj = j - 1;
+        dM = jj == 0 ? 0 : -4 - 4 * jj;
+        dC0 = jj == 0 ? 0u : (PW ? CNT_MATCH + CNT_INDEL * (unsigned)(jj - 1) : CNT_INDEL * (unsigned)(jj + (jj > q4 ? 1 : 0)));
+      } else if (j == 1) {
+        dM = -4 - 4 * (i - 1);
+        dC0 = PW ? CNT_MATCH + CNT_INDEL * (unsigned)(i - 2) : CNT_INDEL * (unsigned)(i - 1);
+      } else { dM = M; dC0 = C0; }
+      const char pc = p[i - 1];
+      if (PW) {
+        const bool eq = baseEqualW(w[j - 1], pc);
+        const int dsc = dM + (eq ? 2 : -2);
+        int m = dsc;
+        if (lM - 4 > m) m = lM - 4;
+        if (uM - 4 > m) m = uM - 4;
+        unsigned c;
+        if (dsc == m) c = dC0 + (eq ? CNT_MATCH : CNT_MIS);
+        else if (uM - 4 == m) c = uC0 + CNT_INDEL;
+        else c = lC0 + CNT_INDEL;
+        M = m; C0 = c;
+      } else {
+        const char tc = tbuf[j - 1];
+        const bool eq = (tc == pc || tc == 'N' || pc == 'N');
+        int e = uE - 1, eo = uM - 5;
+        if (eo > e) e = eo;
+        int f = lF - 1, fo = lM - 5;
+        if (fo > f) f = fo;
+        const int dsc = dM + (eq ? 2 : -2);
+        int m = dsc;
+        if (e > m) m = e;
+        if (f > m) m = f;
+        const unsigned c1 = CNT_INDEL + ((eo == e) ? uC0 : uC1);
+        const unsigned c2 = CNT_INDEL + ((fo == f) ? lC0 : lC2);
+        unsigned c0;
+        if (dsc == m) c0 = dC0 + (eq ? CNT_MATCH : CNT_MIS);
+        else c0 = (f >= e) ? c2 : c1;
+        M = m; E = e; F = f; C0 = c0; C1 = c1; C2 = c2;
+      }
+    }
+  }
+  int src = lent - lenp + leftBand;
+  if (src < 0 || src > 15) src = 0;
+  const unsigned fin = __shfl(C0, rowBase + src);
+  return run ? fin : result;
 }
 
 
@@ -1309,6 +1434,7 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
   __syncthreads();
   if (ws->overflow) return -2;
   const int nJobs = ws->jobCount;
+  if (lane == 0) DBG_ADD(0, nJobs);
   // (2) quick exits, one job per lane
   PHASE_MARK(ws, 13);
   for (int q = lane; q < nJobs; q += NT) runGapJobQuick(ix, wm, wm.cand[q]);
@@ -1331,21 +1457,54 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
     __syncthreads();
   }
   {
-    const int wave = lane >> 6, nw = NT >> 6;
-    char *tbuf = (char *)wm.pairs + wave * (T4_MAXGAP + 16);   // pairs is dead here (cap >= 1024 ints)
+    const int wave = lane >> 6, nw = NT >> 6, row = (lane >> 4) & 3;
+    // pairs is dead here (cap >= 1024 ints): one slice per wave, cut into the four rows' target buffers
+    const int rowCap = ((wm.cap * 4) / (nw * 4)) & ~15;
+    char *tbufWave = (char *)wm.pairs + wave * 4 * rowCap;
+    // (3a) four alignments per wavefront, one per row of 16 lanes (bands of <= 16 columns: almost all of them)
+    for (int q0 = wave * 4; q0 < nPend; q0 += nw * 4) {
+      const int q = q0 + row;
+      const bool has = q < nPend;
+      const unsigned job = has ? wm.cand[q] : 0u;
+      const OvRec o = wm.ov[wm.ord[job & 0xFFFF]];
+      const int jj = has ? (int)(job >> 16) : 1;
+      unsigned *hc = (unsigned *)(wm.keys + o.chainPos);
+      int lent = 0, lenp = 0, pa = 0, pb = 0;
+      if (has) {
+        pa = PA(hc[jj - 1]); pb = PB(hc[jj - 1]);
+        const int qa = PA(hc[jj]), qb = PB(hc[jj]);
+        lent = qb - (pb + ix.k); lenp = qa - (pa + ix.k);
+      }
+      const char *r = ((o.flags & OV_PLUS) ? wm.seg : wm.rc) + pa + ix.k;
+      const T4SeqInfo si = ix.seqs[o.seqIdx];
+      const bool asRef = has && si.isRef, asPw = has && !si.isRef;
+      unsigned c = DP_FAIL;
+      if (__any(asRef)) { unsigned v = dpRow16<false>(asRef, ix.cons + si.consOff + pb + ix.k, (const T4PW *)0, lent, r, lenp, tbufWave + row * rowCap, rowCap); if (asRef) c = v; }
+      if (__any(asPw)) { unsigned v = dpRow16<true>(asPw, (const char *)0, ix.pw + si.pwOff + pb + ix.k, lent, r, lenp, tbufWave + row * rowCap, rowCap); if (asPw) c = v; }
+      if (has && (lane & 15) == 0) {
+        DBG_ADD(1, 1);
+        if (c != DP_FAIL) { hc[o.chainLen + jj] = c; DBG_ADD(2, 2 * lenp + 11 + (lent > lenp ? lent - lenp : lenp - lent)); }
+      }
+    }
+    __syncthreads();
+    // (3b) the wider bands: one wavefront per alignment
+    char *tbuf = tbufWave;
     for (int q = wave; q < nPend; q += nw) {
       const unsigned job = wm.cand[q];
-
       const OvRec &o = wm.ov[wm.ord[job & 0xFFFF]];
       const int jj = (int)(job >> 16);
       unsigned *hc = (unsigned *)(wm.keys + o.chainPos);
+      if (hc[o.chainLen + jj] != DP_PENDING) continue;   // wave-uniform
       const int pa = PA(hc[jj - 1]), pb = PB(hc[jj - 1]), qa = PA(hc[jj]), qb = PB(hc[jj]);
       const int lent = qb - (pb + ix.k), lenp = qa - (pa + ix.k);
       const char *r = ((o.flags & OV_PLUS) ? wm.seg : wm.rc) + pa + ix.k;
       const T4SeqInfo si = ix.seqs[o.seqIdx];
-      unsigned c = si.isRef ? dpWave<false>(ix.cons + si.consOff + pb + ix.k, (const T4PW *)0, lent, r, lenp, tbuf)
-                            : dpWave<true>((const char *)0, ix.pw + si.pwOff + pb + ix.k, lent, r, lenp, tbuf);
+      unsigned c = DP_FAIL;
+      if (lent <= 4 * rowCap || !si.isRef)
+        c = si.isRef ? dpWave<false>(ix.cons + si.consOff + pb + ix.k, (const T4PW *)0, lent, r, lenp, tbuf)
+                     : dpWave<true>((const char *)0, ix.pw + si.pwOff + pb + ix.k, lent, r, lenp, tbuf);
       if (c == DP_FAIL && laneId() == 0) {   // band wider than a wavefront: lane-serial scratch version
+        DBG_ADD(3, 1); DBG_ADD(4, (long long)lent * lenp);
         int c0, c1, c2;
         bool ok = si.isRef ? dpAffine(ix.cons + si.consOff + pb + ix.k, lent, r, lenp, sc, laneId(), c0, c1, c2)
                            : dpPosWeight(ix.pw + si.pwOff + pb + ix.k, lent, r, lenp, sc, laneId(), c0, c1, c2, (signed char *)0);
@@ -1544,7 +1703,7 @@ __device__ void dpWaveTracePW(const T4PW *w, int L, const char *p, unsigned char
   { int j0 = d - leftBand; if (d < W && j0 >= 0 && j0 <= L) M = j0 == 0 ? 0 : -4 - 4 * j0; }
   const int lastStep = 2 * L + W - 1;
   for (int s = 2; s <= lastStep; ++s) {
-    int lM = __shfl_up(M, 1), uM = __shfl_down(M, 1);
+    int lM = waveUp1(M), uM = waveDown1(M);
     const int i2 = s - d, i = i2 >> 1, j = i - leftBand + d;
     if (d < W && (i2 & 1) == 0 && i >= 1 && i <= L && j >= 1 && j <= L) {
       if (j == 1) lM = -4 - 4 * i; else if (d == 0) lM = negInf;
@@ -2005,6 +2164,27 @@ __global__ __launch_bounds__(64) void gapDpKernel(int kind, int impl, int n, con
   DPScratch sc;
   sc.rows = dpRows + (size_t)blockIdx.x * (6 * T4_ROWW * 64);
   sc.dir = dpDir + ((size_t)blockIdx.x * 64 + lane) * T4_DIR_BYTES;
+  if (impl == 3) {   // four alignments per wavefront, one per 16-lane row; bands wider than 16 columns report status 2
+    const int row = lane >> 4;
+    for (int i0 = blockIdx.x * 4; i0 < n; i0 += gridDim.x * 4) {
+      const int i = i0 + row;
+      const bool has = i < n;
+      int lent = 0, lenp = 0;
+      if (has) { lent = (int)(tOff[i + 1] - tOff[i]); lenp = (int)(pOff[i + 1] - pOff[i]); }
+      const bool fits = has && lenp <= T4_MAXGAP && lent <= T4_MAXGAP;
+      if (fits) for (int j = lane & 15; j < lenp; j += 16) s_p[row][j] = pChars[pOff[i] + j];
+      __syncthreads();
+      unsigned c = kind == 0 ? dpRow16<false>(fits, tChars + (has ? tOff[i] : 0), (const T4PW *)0, lent, s_p[row], lenp, s_p[4 + row], T4_MAXGAP)
+                             : dpRow16<true>(fits, (const char *)0, tW + (has ? tOff[i] : 0), lent, s_p[row], lenp, s_p[4 + row], T4_MAXGAP);
+      if (!fits) c = DP_FAIL;
+      __syncthreads();
+      if (has && (lane & 15) == 0) {
+        if (c == DP_FAIL) { out[4 * i] = out[4 * i + 1] = out[4 * i + 2] = 0; out[4 * i + 3] = 2; }
+        else { out[4 * i] = (int)(c & 1023u); out[4 * i + 1] = (int)((c >> 10) & 1023u); out[4 * i + 2] = (int)(c >> 20); out[4 * i + 3] = 0; }
+      }
+    }
+    return;
+  }
   if (impl == 2) {   // the wave-cooperative formulation: one alignment per wavefront
     for (int i = blockIdx.x; i < n; i += gridDim.x) {
       int lent = (int)(tOff[i + 1] - tOff[i]), lenp = (int)(pOff[i + 1] - pOff[i]);
