@@ -602,22 +602,30 @@ __device__ __forceinline__ double ovSim(const OvRec &o) {
   if (o.flags & OV_SIMZERO) return 0.0;
   return (double)o.matchCnt / (double)(o.se - o.ss + 1 + o.re - o.rs + 1);
 }
-// _overlap::operator< (SeqSet.hpp:104-128); `scored` = similarity is meaningful
-__device__ __forceinline__ bool ovLess(const OvRec &a, const OvRec &b, bool scored) {
-  if (a.matchCnt != b.matchCnt) return a.matchCnt > b.matchCnt;
-  if (scored) {
-    double sa = ovSim(a), sb = ovSim(b);
-    if (sa != sb) return sa > sb;
-  }
-  if (a.re - a.rs != b.re - b.rs) return a.re - a.rs > b.re - b.rs;
-  if (a.seqIdx != b.seqIdx) return a.seqIdx < b.seqIdx;
-  int sta = (a.flags & OV_PLUS) ? 1 : -1, stb = (b.flags & OV_PLUS) ? 1 : -1;
-  if (sta != stb) return sta < stb;
-  if (a.rs != b.rs) return a.rs < b.rs;
-  if (a.re != b.re) return a.re < b.re;
-  if (a.ss != b.ss) return a.ss < b.ss;
-  return a.se < b.se;
+// _overlap::operator< (SeqSet.hpp:104-128) as a three-way comparison (< 0: a sorts first); `scored` = similarity is
+// meaningful. The similarity test only runs between records of EQUAL matchCnt m, where the doubles m / den_a and m / den_b
+// (den < 2^12) differ exactly when the denominators do and order inversely to them; a zero similarity (m == 0 or the
+// SIMZERO flag) is the largest denominator. No floating point, identical order.
+__device__ __forceinline__ unsigned ovSimDen(const OvRec &o) {
+  return ((o.flags & OV_SIMZERO) || o.matchCnt == 0) ? 0xFFFFFFFFu : (unsigned)(o.se - o.ss + 1 + o.re - o.rs + 1);
 }
+__device__ __forceinline__ int ovCmp(const OvRec &a, const OvRec &b, bool scored) {
+  if (a.matchCnt != b.matchCnt) return a.matchCnt > b.matchCnt ? -1 : 1;
+  if (scored) {
+    const unsigned da = ovSimDen(a), db = ovSimDen(b);
+    if (da != db) return da < db ? -1 : 1;
+  }
+  if (a.re - a.rs != b.re - b.rs) return a.re - a.rs > b.re - b.rs ? -1 : 1;
+  if (a.seqIdx != b.seqIdx) return a.seqIdx < b.seqIdx ? -1 : 1;
+  const int sta = (a.flags & OV_PLUS) ? 1 : -1, stb = (b.flags & OV_PLUS) ? 1 : -1;
+  if (sta != stb) return sta < stb ? -1 : 1;
+  if (a.rs != b.rs) return a.rs < b.rs ? -1 : 1;
+  if (a.re != b.re) return a.re < b.re ? -1 : 1;
+  if (a.ss != b.ss) return a.ss < b.ss ? -1 : 1;
+  if (a.se != b.se) return a.se < b.se ? -1 : 1;
+  return 0;
+}
+__device__ __forceinline__ bool ovLess(const OvRec &a, const OvRec &b, bool scored) { return ovCmp(a, b, scored) < 0; }
 
 // ------------------------------------------------------------------------------------------------
 // per-wave working set. CAP = hit capacity, MAXOV = overlap capacity. LDS tiers use static
@@ -1403,7 +1411,8 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
     for (int j = 0; j < overlapCnt; ++j) {
       if (j == i) continue;
       OvRec ot = wm.ov[j];
-      if (ovLess(ot, me, false) || (!ovLess(me, ot, false) && j < i)) ++rank;
+      const int cm = ovCmp(ot, me, false);
+      if (cm < 0 || (cm == 0 && j < i)) ++rank;
     }
     wm.ord[rank] = (unsigned short)i;
   }
@@ -1900,7 +1909,8 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
         for (int j = 0; j < n; ++j) {
           if (j == i) continue;
           OvRec ot = wm.fin[j];
-          if (ovLess(ot, me, true) || (!ovLess(me, ot, true) && j < i)) ++rank;
+          const int cm = ovCmp(ot, me, true);
+          if (cm < 0 || (cm == 0 && j < i)) ++rank;
         }
         wm.ord[rank] = (unsigned short)i;
       }
@@ -1981,7 +1991,8 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
       for (int j = 0; j < n; ++j) {
         if (j == i) continue;
         OvRec ot = wm.fin[j];
-        if (ovLess(ot, me, true) || (!ovLess(me, ot, true) && j < i)) ++rank;
+        const int cm = ovCmp(ot, me, true);
+        if (cm < 0 || (cm == 0 && j < i)) ++rank;
       }
       wm.ord[rank] = (unsigned short)i;
     }
