@@ -88,6 +88,9 @@ template <class T> static inline T __shfl_down(T v, unsigned d, int width = 64) 
   (void)width; int l = hipemu_lane(); return hipemu_shfl_any(v, l + (int)d < 64 ? l + (int)d : l);
 }
 template <class T> static inline T __shfl_xor(T v, int m, int width = 64) { (void)width; return hipemu_shfl_any(v, hipemu_lane() ^ m); }
+// wave-level ordering of LDS traffic: a rendezvous of the wave's fibers
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+static inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_rendezvous(__builtin_return_address(0)); }
 // DPP wave shifts by one lane (the only dpp_ctrl values the kernels use)
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) {
   (void)old;

@@ -807,20 +807,52 @@ __device__ int expandHits(const T4IndexView &ix, WaveMem &wm, int nk, int H, int
   return H - dropped;
 }
 
-// wave-cooperative bitonic sort of n2 (power of two) 64-bit keys
-__device__ void bitonicSort(unsigned long long *keys, int n2) {
+// Workgroup bitonic sort of keys[0, n) (any n): the all-ascending network on the next power of two with VIRTUAL +inf
+// padding -- every compare-exchange moves the minimum to the lower index, so padding never moves and pairs that touch it
+// are skipped (no element >= n is ever read or written; up to 2x less work than a padded sort). The compare-exchanges of
+// the sub-steps with j <= 64 stay inside aligned chunks of 128 elements: each wavefront owns whole chunks through those
+// sub-steps and only needs its own LDS ordering (wave barrier), so a stage costs log2(k) - 6 workgroup barriers, not log2(k).
+__device__ __forceinline__ void waveLdsSync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ void bitonicSort(unsigned long long *keys, int n) {
   const int lane = tid(), NT = nthr();
+  int n2 = 1;
+  while (n2 < n) n2 <<= 1;
+  const int half = n2 >> 1;
+  const int nChunk = (half + 63) >> 6;        // chunks of 64 pairs = 128 elements
+  const int wave = lane >> 6, nw = NT >> 6, wl = lane & 63;
   for (int k = 2; k <= n2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = lane; t < (n2 >> 1); t += NT) {
-        int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        int p = i | j;
-        bool up = (i & k) == 0;
-        unsigned long long a = keys[i], b = keys[p];
-        if ((a > b) == up) { keys[i] = b; keys[p] = a; }
+    // first sub-step of the stage: partner mirrored inside the k-block (i ^ (k - 1))
+    int j = k >> 1;
+    if (j > 64) {
+      for (int t = lane; t < half; t += NT) {
+        const int low = t & (j - 1), i = ((t & ~(j - 1)) << 1) | low, p = (i & ~(k - 1)) + (k - 1 - low);
+        if (p < n) { unsigned long long a = keys[i], b = keys[p]; if (a > b) { keys[i] = b; keys[p] = a; } }
       }
       __syncthreads();
+      for (j >>= 1; j > 64; j >>= 1) {
+        for (int t = lane; t < half; t += NT) {
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
+          if (p < n) { unsigned long long a = keys[i], b = keys[p]; if (a > b) { keys[i] = b; keys[p] = a; } }
+        }
+        __syncthreads();
+      }
     }
+    // chunk-local sub-steps (j <= 64): wave w owns chunks w, w + nw, ...
+    for (int c = wave; c < nChunk; c += nw) {
+      const int t = (c << 6) + wl;
+      for (int jj = j; jj > 0; jj >>= 1) {
+        if (t < half) {
+          const int low = t & (jj - 1), i = ((t & ~(jj - 1)) << 1) | low;
+          const int p = (jj == (k >> 1)) ? (i & ~(k - 1)) + (k - 1 - low) : (i | jj);
+          if (p < n) { unsigned long long a = keys[i], b = keys[p]; if (a > b) { keys[i] = b; keys[p] = a; } }
+        }
+        waveLdsSync();
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -1350,12 +1382,9 @@ __device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, 
   if (H > wm.cap) return -1;
   PHASE_MARK(ws, 2);
   int Hv = expandHits(ix, wm, nk, H, barcode, vjOnly, posStart, posPref, ws->red);
-  int n2 = 1;
-  while (n2 < H) n2 <<= 1;
-  for (int s = H + lane; s < n2; s += NT) wm.keys[s] = ~0ull;   // n2 <= cap: caps are powers of two
   __syncthreads();
   PHASE_MARK(ws, 3);
-  if (H > 1) bitonicSort(wm.keys, n2);
+  if (H > 1) bitonicSort(wm.keys, H);
   PHASE_MARK(ws, 4);
   overlapsFromKeys(ix, wm, ws, Hv, hitLenRequired, filter);
   PHASE_MARK(ws, 0);
@@ -2137,11 +2166,8 @@ __global__ __launch_bounds__(64) void hitsKernel(T4IndexView ix, T4BatchView bv,
       dropped = blockSum(dropped, s_red);
       Hv = H - dropped;
       if (pass == 1 && H > 0) {
-        int n2 = 1;
-        while (n2 < H) n2 <<= 1;
-        for (int s = H + lane; s < n2; s += 64) wm.keys[s] = ~0ull;
         __syncthreads();
-        if (H > 1) bitonicSort(wm.keys, n2);
+        if (H > 1) bitonicSort(wm.keys, H);
         __syncthreads();
         long long base = offsets[r];
         for (int s = lane; s < Hv; s += 64) {
