@@ -441,7 +441,7 @@ int commitWithPostings(t4_index *ix, std::vector<Rec> &recs) {
   std::vector<T4SeqInfo> infos(ix->seqs.size());
   std::string cons;
   std::vector<T4PW> pw;
-  bool hasNovel = false;
+  bool hasNovel = false, hasRef = false;
   for (size_t id = 0; id < ix->seqs.size(); ++id) {
     const HostSeq &s = ix->seqs[id];
     T4SeqInfo &f = infos[id];
@@ -484,7 +484,8 @@ int commitWithPostings(t4_index *ix, std::vector<Rec> &recs) {
   v.cons = ix->dCons; v.pw = ix->dPw;
   v.radius = ix->radius; v.hitLenRequired = ix->hitLenRequired; v.nomatchGapLimit = ix->nomatchGapLimit;
   v.firstIsRef = (!ix->seqs.empty() && ix->seqs[0].isRef) ? 1 : 0;
-  v.hasNovel = hasNovel ? 1 : 0;
+  for (const HostSeq &q : ix->seqs) if (q.isRef) { hasRef = true; break; }
+  v.hasNovel = hasNovel ? (hasRef ? 1 : 2) : 0;
   v.novelSim = ix->novelSim; v.refSim = ix->refSim; v.repeatSim = ix->repeatSim;
   ix->committed = true;
   return T4_OK;
@@ -1242,7 +1243,7 @@ int t4_cellstore_stage(t4_cellstore *cs, int slot, int barcode, int nseq, const 
   v.hashMask = hashMask; v.table = nullptr; v.htab = nullptr; v.ctab = (const T4HashEntC *)(slotBase + oHt); v.post = (const int2 *)(slotBase + oPost);
   v.seqs = (const T4SeqInfo *)(slotBase + oSeq); v.cons = (const char *)(slotBase + oCons); v.pw = (const T4PW *)(slotBase + oPw);
   v.radius = cs->radius; v.hitLenRequired = cs->hitLenRequired; v.nomatchGapLimit = cs->nomatchGapLimit;
-  v.firstIsRef = 0; v.hasNovel = 1;
+  v.firstIsRef = 0; v.hasNovel = 2;
   v.novelSim = cs->novelSim; v.refSim = 0.75; v.repeatSim = 0.95;
   return T4_OK;
 }

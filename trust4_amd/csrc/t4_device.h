@@ -60,7 +60,7 @@ struct alignas(16) T4IndexView {   // 128 bytes: per-barcode views are scattered
   const char *cons;
   const T4PW *pw;            // posWeight predicate bytes of novel contigs
   const T4HashEntC *ctab;    // direct == 2
-  int radius, hitLenRequired, nomatchGapLimit, firstIsRef, hasNovel;
+  int radius, hitLenRequired, nomatchGapLimit, firstIsRef, hasNovel /* 0 no novel contig, 1 mixed set, 2 novel contigs only */;
   double novelSim, refSim, repeatSim;
 };
 

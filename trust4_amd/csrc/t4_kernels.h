@@ -116,6 +116,14 @@ __device__ __forceinline__ unsigned rowDown1(unsigned v) { return (unsigned)rowD
 __device__ __forceinline__ int rowSum16(int v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); return v; }
 __device__ __forceinline__ unsigned waveDown1(unsigned v) { return (unsigned)waveDown1((int)v); }
 
+// isRef of a sequence without touching the sequence table when the set is homogeneous (reference genes only, or novel
+// contigs only -- the two kinds of set stage 1 builds)
+__device__ __forceinline__ bool seqIsRef(const T4IndexView &ix, int idx) {
+  if (ix.hasNovel == 0) return true;    // reference genes only
+  if (ix.hasNovel == 2) return false;   // novel contigs only
+  return ix.seqs[idx].isRef != 0;
+}
+
 __device__ __forceinline__ int nuc2(char c) { // nucToNum[c-'A'] & 3 for the packed alphabet
   return c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 0;
 }
@@ -787,7 +795,8 @@ __device__ int expandHits(const T4IndexView &ix, WaveMem &wm, int nk, int H, int
     int2 po = ix.post[posStart[q] + ((unsigned)s - posPref[q])];
     int st = q >= nk, a = st ? q - nk : q;
     bool keep = true;
-    T4SeqInfo si = ix.seqs[po.x];
+    T4SeqInfo si;
+    if (barcode != -1 || vjOnly) si = ix.seqs[po.x];   // the plain pass needs nothing from the sequence table here
     if (barcode != -1 && si.barcode != barcode) keep = false;
     if (vjOnly) { // GetVJOverlapsFromHits (SeqSet.hpp:1075-1089)
       if (!si.isRef) keep = false;
@@ -919,7 +928,7 @@ __device__ void overlapsFromKeys(const T4IndexView &ix, WaveMem &wm, WaveState *
         int j;
         for (j = i + 1; j < Hv; ++j) if (KEY_G(wm.keys[j]) != g) break;
         int plus = KEY_PLUS(wm.keys[i]);
-        if (!ix.seqs[KEY_IDX(wm.keys[i])].isRef) {
+        if (!seqIsRef(ix, KEY_IDX(wm.keys[i]))) {
           if (j - i > 3) ++possible[plus];
           if (j - i > longest[plus]) longest[plus] = j - i;
         }
@@ -935,39 +944,38 @@ __device__ void overlapsFromKeys(const T4IndexView &ix, WaveMem &wm, WaveState *
   }
   __syncthreads();
   PHASE_MARK(ws, 5);
-  // R1: every hit that starts a run measures it; qualifying runs become candidates
+  // R1: run starts are compacted (wm.pairs is dead here); a run is the stretch up to the next start, so nobody walks a
+  // run hit by hit. Qualifying runs become candidates.
+  unsigned *starts = wm.pairs;
+  int nRuns = 0;
   for (int i0 = 0; i0 < Hv; i0 += NT) {
-    int i = i0 + lane;
+    const int i = i0 + lane;
+    bool runStart = false;
     if (i < Hv) {
-      unsigned long long ki = wm.keys[i];
-      int idx = KEY_IDX(ki), plus = KEY_PLUS(ki);
-#ifdef T4_DEBUG
-      if (idx >= ix.nseq) { printf("DBG bad key i %d Hv %d key %llx filter %d hlr %d\n", i, Hv, ki, filter, hitLenRequired); }
-#endif
-      bool isRef = ix.seqs[idx].isRef != 0;
-      int adjustRadius = isRef ? ix.radius : 0;
-      bool runStart = true;
+      const unsigned long long ki = wm.keys[i];
+      runStart = true;
       if (i > 0) {
-        unsigned long long kp = wm.keys[i - 1];
+        const unsigned long long kp = wm.keys[i - 1];
+        const int adjustRadius = seqIsRef(ix, KEY_IDX(ki)) ? ix.radius : 0;
         if (KEY_G(kp) == KEY_G(ki) && KEY_C(ki) - KEY_C(kp) <= adjustRadius) runStart = false;
       }
-      if (runStart) {
-        int e = i + 1, cprev = KEY_C(ki);
-        while (e < Hv) {
-          unsigned long long ke = wm.keys[e];
-          if (KEY_G(ke) != KEY_G(ki)) break;
-          int ce = KEY_C(ke);
-          if (ce - cprev > adjustRadius) break;
-          cprev = ce; ++e;
-        }
-        int n = e - i;
-        int minHit = isRef ? 3 : ws->novelMin[plus];
-        if (n >= minHit && n * K >= hitLenRequired) {
-          int slot = atomicAdd(&ws->candCount, 1);
-          if (slot < wm.candCap) wm.cand[slot] = (unsigned)i | ((unsigned)n << 16);
-          else ws->overflow = 1;
-        }
-      }
+    }
+    int tot;
+    const int inc = blockInclScan(runStart ? 1 : 0, ws->red, tot);
+    if (runStart) starts[nRuns + inc - 1] = (unsigned)i;
+    nRuns += tot;
+  }
+  __syncthreads();
+  for (int r = lane; r < nRuns; r += NT) {
+    const int i = (int)starts[r], e = r + 1 < nRuns ? (int)starts[r + 1] : Hv;
+    const int n = e - i;
+    const unsigned long long ki = wm.keys[i];
+    const bool isRef = seqIsRef(ix, KEY_IDX(ki));
+    const int minHit = isRef ? 3 : ws->novelMin[KEY_PLUS(ki)];
+    if (n >= minHit && n * K >= hitLenRequired) {
+      int slot = atomicAdd(&ws->candCount, 1);
+      if (slot < wm.candCap) wm.cand[slot] = (unsigned)i | ((unsigned)n << 16);
+      else ws->overflow = 1;
     }
   }
   __syncthreads();
@@ -979,7 +987,7 @@ __device__ void overlapsFromKeys(const T4IndexView &ix, WaveMem &wm, WaveState *
       int s = wm.cand[c] & 0xFFFF, n = wm.cand[c] >> 16;
       if (n <= 48) continue;                                  // wave-uniform
       unsigned long long ks = wm.keys[s];
-      if (!ix.seqs[KEY_IDX(ks)].isRef) continue;              // wave-uniform
+      if (!seqIsRef(ix, KEY_IDX(ks))) continue;               // wave-uniform
       // upper half of the run's own key area; keys[s] itself (u32 words 0,1) stays intact for R3
       unsigned *tmp = (unsigned *)(wm.keys + s) + n;
       for (int t = lane; t < n; t += NT) {
@@ -1006,7 +1014,7 @@ __device__ void overlapsFromKeys(const T4IndexView &ix, WaveMem &wm, WaveState *
     int s = wm.cand[c] & 0xFFFF, n = wm.cand[c] >> 16;
     unsigned long long ks = wm.keys[s];
     int idx = KEY_IDX(ks), plus = KEY_PLUS(ks);
-    bool isRef = ix.seqs[idx].isRef != 0;
+    bool isRef = seqIsRef(ix, idx);
     int adjustRadius = isRef ? ix.radius : 0;
     if (!(adjustRadius > 0 && n > 48)) {
       for (int t = s; t < s + n; ++t) {
@@ -1661,31 +1669,36 @@ __device__ void contigIntervals(const char *read, int gapN, WaveState *ws) {
 // The level-0 part of SeqSet::AnnotateRead after the per-contig overlaps are known
 // (SeqSet.hpp:6167-6321). fin[0..n) holds all contigs' overlaps; ord = their sorted order.
 // `kept` is scratch for n ints. One lane. Writes the four gene overlaps.
+// `first[i]` (precomputed by all lanes, see annotatePrepare): sorted position of the first overlap of the same sequence that
+// qualifies for the list (V/J/C gene, similarity >= 0.8), or -1. The reference's linear searches over the kept list
+// (SeqSet.hpp:6160-6215) then cost O(1) per overlap: the list slot of a sequence is slotOf[first], and the first kept C
+// gene is remembered when it is appended.
 __device__ void annotateSelect(const T4IndexView &ix, WaveMem &wm, int n, int readLen, int *kept, T4OverlapOut *out) {
   int g[4] = {-1, -1, -1, -1};
-  int k = 0;
+  int k = 0, cSlot = -1;
+  const int *first = kept + n;
+  int *slotOf = kept + 2 * n;
   for (int i = 0; i < n; ++i) {
-    int oi = wm.ord[i];
+    const int f = first[i];
+    if (f < 0) continue;                       // no overlap of this sequence is ever kept
+    const int oi = wm.ord[i];
     const OvRec &o = wm.fin[oi];
-    int gt = OV_GENETYPE(o.flags) == 255 ? -1 : OV_GENETYPE(o.flags);
+    const int gt = OV_GENETYPE(o.flags) == 255 ? -1 : OV_GENETYPE(o.flags);
     if (gt < 0 || gt == 1) continue;
-    int used = -1;
-    for (int j = 0; j < k; ++j) if (wm.fin[kept[j]].seqIdx == o.seqIdx) { used = j; break; }
-    double sim = ovSim(o);
-    if (used == -1 && sim >= 0.8) { kept[k++] = oi; }
-    else if (used != -1 && gt == 2) {
+    if (f == i) {                              // used == -1 && sim >= 0.8
+      slotOf[i] = k;
+      if (gt == 3 && cSlot < 0) cSlot = k;
+      kept[k++] = oi;
+    } else if (f < i && gt == 2) {             // used != -1: a J gene may replace the kept overlap of its sequence
+      const int used = slotOf[f];
       const OvRec &base = wm.fin[kept[used]];
-      if (o.matchCnt == base.matchCnt && sim == ovSim(base)) {
-        int j;
-        for (j = 0; j < k; ++j) if (OV_GENETYPE(wm.fin[kept[j]].flags) == 3) break;
-        if (j < k) {
-          const OvRec &c = wm.fin[kept[j]];
-          if (o.re <= c.rs + 3) {
-            int d1 = o.re - c.rs, d2 = base.re - c.rs;
-            if (d1 < 0) d1 = -d1;
-            if (d2 < 0) d2 = -d2;
-            if (base.re > c.rs + 3 || d1 < d2) kept[used] = oi;
-          }
+      if (o.matchCnt == base.matchCnt && ovSimDen(o) == ovSimDen(base) && cSlot >= 0) {
+        const OvRec &c = wm.fin[kept[cSlot]];
+        if (o.re <= c.rs + 3) {
+          int d1 = o.re - c.rs, d2 = base.re - c.rs;
+          if (d1 < 0) d1 = -d1;
+          if (d2 < 0) d2 = -d2;
+          if (base.re > c.rs + 3 || d1 < d2) kept[used] = oi;
         }
       }
     }
@@ -2024,6 +2037,22 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
         if (cm < 0 || (cm == 0 && j < i)) ++rank;
       }
       wm.ord[rank] = (unsigned short)i;
+    }
+    __syncthreads();
+    {   // first[i] for annotateSelect: all lanes, one sorted position each
+      int *first = (int *)wm.cand + n;
+      for (int i = lane; i < n; i += NT) {
+        const int seq = wm.fin[wm.ord[i]].seqIdx;
+        int f = -1;
+        for (int j = 0; j <= i; ++j) {
+          const OvRec &x = wm.fin[wm.ord[j]];
+          if (x.seqIdx != seq) continue;
+          const int gt = OV_GENETYPE(x.flags);
+          if (gt == 255 || gt == 1) continue;
+          if (ovSim(x) >= 0.8) { f = j; break; }
+        }
+        first[i] = f;
+      }
     }
     __syncthreads();
     if (lane == 0) annotateSelect(ix, wm, n, len, (int *)wm.cand, qa.out + r * 4);
