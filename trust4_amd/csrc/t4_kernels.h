@@ -661,6 +661,8 @@ struct WaveMem {
   unsigned *cand;            // [cap / 3 + 1] candidate runs: start | len << 16
   char *seg, *rc;            // [T4_MAXL + 8] current segment, forward and reverse complement
   int cap, maxOv, maxFin, candCap;
+  const unsigned *pkRow, *nmRow;   // the read's packed words (global), set by loadSegment
+  int segAbs, segLen;              // position of the current segment inside the read
 };
 
 struct WaveState { // wave-uniform scalars kept in LDS
@@ -685,6 +687,7 @@ __device__ void loadSegment(const T4BatchView &bv, long long r, int segStart, in
     wm.rc[segLen - 1 - i] = isN ? 'N' : (code == 0 ? 'T' : code == 1 ? 'G' : code == 2 ? 'C' : 'A');
   }
   if (tid() == 0) { wm.seg[segLen] = 0; wm.rc[segLen] = 0; }
+  wm.pkRow = pk; wm.nmRow = nm; wm.segAbs = segStart; wm.segLen = segLen;
   __syncthreads();
 }
 
@@ -880,22 +883,33 @@ __device__ void chainRun(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int 
   unsigned short *link = top + n;
   // A run whose (b, a)-sorted hits are strictly increasing in both coordinates is its own LIS: the
   // equal-b collapse and the replacement sweep of LongestIncreasingSubsequence are then identities.
+  // One pass for the common case: copy the run, test monotonicity and accumulate both GetTotalHitLength sums (for an
+  // increasing chain, sum over segments of (last - first + K) == K + sum over neighbours of min(step, K)).
   bool mono = true;
+  int hitLen = K, hitLenSeq = K;
   {
     unsigned prev = wm.pairs[s];
+    lisOut[0] = prev;
     for (int t = 1; t < n; ++t) {
-      unsigned cur = wm.pairs[s + t];
-      mono = mono && (PA(cur) > PA(prev)) && (PB(cur) > PB(prev));
+      const unsigned cur = wm.pairs[s + t];
+      const int da = PA(cur) - PA(prev), db = PB(cur) - PB(prev);
+      mono = mono && da > 0 && db > 0;
+      hitLen += da < K ? da : K;
+      hitLenSeq += db < K ? db : K;
+      lisOut[t] = cur;
       prev = cur;
     }
   }
-  int lisSize;
-  if (mono) { for (int t = 0; t < n; ++t) lisOut[t] = wm.pairs[s + t]; lisSize = n; }
-  else lisSize = lisLane(wm.pairs + s, n, lisOut, top, link);
+  int lisSize = n;
+  if (!mono) {
+    lisSize = lisLane(wm.pairs + s, n, lisOut, top, link);
+    if (lisSize * K < hitLenRequired) return;
+    hitLen = totalHitLen(lisOut, lisSize, K, false);
+    hitLenSeq = totalHitLen(lisOut, lisSize, K, true);
+  }
   if (lisSize * K < hitLenRequired) return;
-  int hitLen = totalHitLen(lisOut, lisSize, K, false);
   if (hitLen < hitLenRequired) return;
-  if (totalHitLen(lisOut, lisSize, K, true) < hitLenRequired) return;
+  if (hitLenSeq < hitLenRequired) return;
   OvRec o;
   o.seqIdx = seqIdx;
   o.rs = PA(lisOut[0]); o.re = PA(lisOut[lisSize - 1]) + K - 1;
@@ -1037,14 +1051,27 @@ __device__ void overlapsFromKeys(const T4IndexView &ix, WaveMem &wm, WaveState *
 }
 
 // IsOverlapLowComplex (SeqSet.hpp:590-617)
-__device__ __forceinline__ bool lowComplex(const char *r, int rs, int re) {
-  int cnt[4] = {0, 0, 0, 0};
-  for (int i = rs; i <= re; ++i) {
-    char c = r[i];
-    if (c == 'N') continue;
-    int n = nuc2(c);
-    cnt[0] += n == 0; cnt[1] += n == 1; cnt[2] += n == 2; cnt[3] += n == 3;
+// SeqSet::IsLowComplexity-style test of GetOverlapsFromRead (SeqSet.hpp:2036-2062) on segment positions [rs, re] of the
+// strand the overlap is on. Only the multiset of the four base counts matters, and the reverse complement permutes the
+// counts of the mirrored forward interval, so both strands count on the read's 2-bit packed words: 16 bases per popcount
+// round instead of one LDS byte at a time.
+__device__ __forceinline__ bool lowComplex(const WaveMem &wm, bool plus, int rs, int re) {
+  int lo = plus ? rs : wm.segLen - 1 - re, hi = plus ? re : wm.segLen - 1 - rs;
+  lo += wm.segAbs; hi += wm.segAbs;
+  int cA = 0, cC = 0, cG = 0, cT = 0;
+  for (int w = lo >> 4; w <= (hi >> 4); ++w) {
+    const unsigned x = wm.pkRow[w];
+    unsigned nb = (wm.nmRow[w >> 1] >> ((w & 1) * 16)) & 0xFFFFu;   // N flags of these 16 bases -> even bit positions
+    nb = (nb | (nb << 8)) & 0x00FF00FFu; nb = (nb | (nb << 4)) & 0x0F0F0F0Fu;
+    nb = (nb | (nb << 2)) & 0x33333333u; nb = (nb | (nb << 1)) & 0x55555555u;
+    unsigned v = 0x55555555u & ~nb;
+    const int b0 = w << 4;
+    if (lo > b0) v &= ~0u << ((lo - b0) * 2);
+    if (hi < b0 + 15) v &= ~0u >> ((b0 + 15 - hi) * 2);
+    const unsigned l = x & 0x55555555u, h = (x >> 1) & 0x55555555u;
+    cA += __popc(~h & ~l & v); cC += __popc(~h & l & v); cG += __popc(h & ~l & v); cT += __popc(h & l & v);
   }
+  const int cnt[4] = {cA, cC, cG, cT};
   int lowCnt = 0, lowTotal = 0;
   for (int i = 0; i < 4; ++i) if (cnt[i] <= 2) { ++lowCnt; lowTotal += cnt[i]; }
   if (lowTotal * 7 >= re - rs + 1) return false;
@@ -1339,7 +1366,7 @@ __device__ void walkOverlap(const T4IndexView &ix, WaveMem &wm, WaveState *ws, O
   if (collect) return;
   o.matchCnt = matchCnt; o.indelCnt = indelCnt;
   if (simOne) o.flags &= ~OV_SIMZERO; else o.flags |= OV_SIMZERO;
-  if (lowComplex((o.flags & OV_PLUS) ? wm.seg : wm.rc, o.rs, o.re)) o.flags |= OV_SIMZERO;
+  if (lowComplex(wm, (o.flags & OV_PLUS) != 0, o.rs, o.re)) o.flags |= OV_SIMZERO;
 }
 
 // Quick exits of one gap job (any lane); jobs that need the banded DP are marked DP_PENDING.
