@@ -93,7 +93,13 @@ template <class T> static inline T __shfl_xor(T v, int m, int width = 64) { (voi
 static inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_rendezvous(__builtin_return_address(0)); }
 // DPP wave shifts by one lane (the only dpp_ctrl values the kernels use)
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) {
-  (void)old;
+  if (old != src) {   // edge lanes receive `old`
+    const int l = hipemu_lane();
+    if (ctrl == 0x111) { int v = hipemu_shfl_any(src, (l & 15) ? l - 1 : l); return (l & 15) ? v : old; }
+    if (ctrl == 0x101) { int v = hipemu_shfl_any(src, (l & 15) != 15 ? l + 1 : l); return (l & 15) != 15 ? v : old; }
+    if (ctrl == 0x138) { int v = __shfl_up(src, 1); return l ? v : old; }
+    if (ctrl == 0x130) { int v = __shfl_down(src, 1); return l != 63 ? v : old; }
+  }
   if (ctrl == 0x138) return __shfl_up(src, 1);
   if (ctrl == 0x130) return __shfl_down(src, 1);
   if (ctrl == 0x111) { int l = hipemu_lane(); return hipemu_shfl_any(src, (l & 15) ? l - 1 : l); }        // row_shr:1

@@ -113,6 +113,11 @@ __device__ __forceinline__ int rowUp1(int v) { return __builtin_amdgcn_update_dp
 __device__ __forceinline__ int rowDown1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x101 /* row_shl:1 */, 0xf, 0xf, false); }
 __device__ __forceinline__ unsigned rowUp1(unsigned v) { return (unsigned)rowUp1((int)v); }
 __device__ __forceinline__ unsigned rowDown1(unsigned v) { return (unsigned)rowDown1((int)v); }
+// row shifts whose edge lane (lane 0 of the row for Up, lane 15 for Down) receives `edge` instead of keeping its own value
+__device__ __forceinline__ int rowUp1E(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x111, 0xf, 0xf, false); }
+__device__ __forceinline__ int rowDown1E(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x101, 0xf, 0xf, false); }
+__device__ __forceinline__ unsigned rowUp1E(unsigned v, unsigned edge) { return (unsigned)rowUp1E((int)v, (int)edge); }
+__device__ __forceinline__ unsigned rowDown1E(unsigned v, unsigned edge) { return (unsigned)rowDown1E((int)v, (int)edge); }
 __device__ __forceinline__ int rowSum16(int v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); return v; }
 __device__ __forceinline__ unsigned waveDown1(unsigned v) { return (unsigned)waveDown1((int)v); }
 
@@ -1255,32 +1260,34 @@ __device__ __attribute__((noinline)) unsigned dpRow16(bool has, const char *t, c
   const int lastStep = run ? 2 * lenp + W - 1 : 0;
   int maxStep = lastStep;
   for (int o = 16; o < 64; o <<= 1) { int v = __shfl_xor(maxStep, o); if (v > maxStep) maxStep = v; }
+  // Band edges cost nothing inside the loop: a lane outside the band (d >= W) never updates its cell, which stays at
+  // (negInf, 0) as initialised, and the row's edge lanes receive (negInf, 0) from the DPP shift itself.
   for (int s = 2; s <= maxStep; ++s) {
-    int lM = rowUp1(M), uM = rowDown1(M);
-    unsigned lC0 = rowUp1(C0), uC0 = rowDown1(C0);
+    int lM = rowUp1E(M, negInf), uM = rowDown1E(M, negInf);
+    unsigned lC0 = rowUp1E(C0, 0u), uC0 = rowDown1E(C0, 0u);
     int lF = 0, uE = 0; unsigned lC2 = 0, uC1 = 0;
-    if (!PW) { lF = rowUp1(F); lC2 = rowUp1(C2); uE = rowDown1(E); uC1 = rowDown1(C1); }
+    if (!PW) { lF = rowUp1E(F, negInf); lC2 = rowUp1E(C2, 0u); uE = rowDown1E(E, negInf); uC1 = rowDown1E(C1, 0u); }
     const int i2 = s - d, i = i2 >> 1, j = i - leftBand + d;
     if (run && s <= lastStep && d < W && (i2 & 1) == 0 && i >= 1 && i <= lenp && j >= 1 && j <= lent) {
-      if (j == 1) {             // left neighbour is column 0
-        lM = -4 - 4 * i;
-        if (PW) lC0 = CNT_MATCH + CNT_INDEL * (unsigned)(i - 1);
-        else { lF = -4 - 4 * i; lC0 = CNT_INDEL * (unsigned)i; lC2 = CNT_INDEL * (unsigned)(1 + i); }
-      } else if (d == 0) { lM = negInf; lF = negInf; lC0 = 0; lC2 = 0; }
-      if (i == 1) {             // upper neighbour is row 0
-        uM = -4 - 4 * j;
-        if (PW) uC0 = CNT_MATCH + CNT_INDEL * (unsigned)(j - 1);
-        else { uE = e0; uC0 = CNT_INDEL * (unsigned)(j + (j > q4 ? 1 : 0)); uC1 = CNT_INDEL * (unsigned)(1 + j); }
-      } else if (d + 1 >= W) { uM = negInf; uE = negInf; uC0 = 0; uC1 = 0; }
-      int dM; unsigned dC0;     // diagonal neighbour
-      if (i == 1) {
-        int jj = j - 1;
-        dM = jj == 0 ? 0 : -4 - 4 * jj;
-        dC0 = jj == 0 ? 0u : (PW ? CNT_MATCH + CNT_INDEL * (unsigned)(jj - 1) : CNT_INDEL * (unsigned)(jj + (jj > q4 ? 1 : 0)));
-      } else if (j == 1) {
-        dM = -4 - 4 * (i - 1);
-        dC0 = PW ? CNT_MATCH + CNT_INDEL * (unsigned)(i - 2) : CNT_INDEL * (unsigned)(i - 1);
-      } else { dM = M; dC0 = C0; }
+      int dM = M; unsigned dC0 = C0;     // diagonal neighbour: the lane's own previous cell
+      if (i == 1 || j == 1) {            // first row / first column: closed forms of the reference's borders
+        if (j == 1) {             // left neighbour is column 0
+          lM = -4 - 4 * i;
+          if (PW) lC0 = CNT_MATCH + CNT_INDEL * (unsigned)(i - 1);
+          else { lF = -4 - 4 * i; lC0 = CNT_INDEL * (unsigned)i; lC2 = CNT_INDEL * (unsigned)(1 + i); }
+        }
+        if (i == 1) {             // upper neighbour is row 0
+          uM = -4 - 4 * j;
+          if (PW) uC0 = CNT_MATCH + CNT_INDEL * (unsigned)(j - 1);
+          else { uE = e0; uC0 = CNT_INDEL * (unsigned)(j + (j > q4 ? 1 : 0)); uC1 = CNT_INDEL * (unsigned)(1 + j); }
+          int jj = j - 1;
+          dM = jj == 0 ? 0 : -4 - 4 * jj;
+          dC0 = jj == 0 ? 0u : (PW ? CNT_MATCH + CNT_INDEL * (unsigned)(jj - 1) : CNT_INDEL * (unsigned)(jj + (jj > q4 ? 1 : 0)));
+        } else {                  // j == 1, i > 1
+          dM = -4 - 4 * (i - 1);
+          dC0 = PW ? CNT_MATCH + CNT_INDEL * (unsigned)(i - 2) : CNT_INDEL * (unsigned)(i - 1);
+        }
+      }
       const char pc = p[i - 1];
       if (PW) {
         const bool eq = baseEqualW(w[j - 1], pc);
