@@ -1000,30 +1000,32 @@ __device__ void overlapsFromKeys(const T4IndexView &ix, WaveMem &wm, WaveState *
   __syncthreads();
   const int nCand = ws->candCount < wm.candCap ? ws->candCount : wm.candCap;
   PHASE_MARK(ws, 6);
-  // R2: long multi-diagonal runs (reference genes only) are ordered by (b, a) by the whole wave
+  // R2: long multi-diagonal runs (reference genes only) are ordered by (b, a), one run per wavefront (runs own disjoint
+  // slices of pairs / keys, so the wavefronts need no workgroup barrier between them, only their own LDS ordering)
   if (ix.radius > 0) {
-    for (int c = 0; c < nCand; ++c) {
+    const int wave = lane >> 6, nw = NT >> 6, wl = lane & 63;
+    for (int c = wave; c < nCand; c += nw) {
       int s = wm.cand[c] & 0xFFFF, n = wm.cand[c] >> 16;
       if (n <= 48) continue;                                  // wave-uniform
       unsigned long long ks = wm.keys[s];
       if (!seqIsRef(ix, KEY_IDX(ks))) continue;               // wave-uniform
       // upper half of the run's own key area; keys[s] itself (u32 words 0,1) stays intact for R3
       unsigned *tmp = (unsigned *)(wm.keys + s) + n;
-      for (int t = lane; t < n; t += NT) {
+      for (int t = wl; t < n; t += 64) {
         unsigned long long kt = wm.keys[s + t];
         int b = KEY_B(kt), a = KEY_C(kt) - T4_C_BIAS + b;
         wm.pairs[s + t] = ((unsigned)b << 12) | (unsigned)a;
       }
-      __syncthreads();
-      for (int t = lane; t < n; t += NT) {
+      waveLdsSync();
+      for (int t = wl; t < n; t += 64) {
         unsigned v = wm.pairs[s + t];
         int rank = 0;
         for (int u = 0; u < n; ++u) { unsigned x = wm.pairs[s + u]; rank += (x < v) ? 1 : 0; }
         tmp[rank] = v;                                        // pairs of one run are distinct
       }
-      __syncthreads();
-      for (int t = lane; t < n; t += NT) wm.pairs[s + t] = tmp[t];
-      __syncthreads();
+      waveLdsSync();
+      for (int t = wl; t < n; t += 64) wm.pairs[s + t] = tmp[t];
+      waveLdsSync();
     }
   }
   __syncthreads();   // R3 overwrites key areas that R2's wave-uniform tests read
