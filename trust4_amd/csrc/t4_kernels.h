@@ -717,35 +717,35 @@ __device__ int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int
   const int nk = segLen - K + 1;           // k-mers per strand
   const unsigned long long mask = K < 32 ? ((1ull << (2 * K)) - 1ull) : ~0ull;
   int skipLimit = ix.firstIsRef ? 0 : K / 2;
-  // raw list sizes (0 for invalid k-mers) and starts, for both strands
+  // raw list sizes (0 for invalid k-mers) and starts, for both strands; bit 31 of the size marks a k-mer whose code
+  // equals the code of the previous position (K + 1 equal bases): the repeat test of SeqSet.hpp:1380 without a second
+  // and third pass over the characters
+  const unsigned SAME = 0x80000000u;
   int big = 0;
   for (int q = lane; q < 2 * nk; q += NT) {
     int st = q >= nk, p = st ? q - nk : q;
     bool active = st ? (strandArg != 1) : (strandArg != -1);
+    const char *S = st ? wm.rc : wm.seg;
     unsigned start = 0, cnt = 0;
-    if (active) {
-      bool valid;
-      unsigned long long code = kmerAt(st ? wm.rc : wm.seg, p, K, valid) & mask;
-      if (valid) indexLookup(ix, code, barcode, start, cnt);
-    }
-    posStart[q] = start; posPref[q] = cnt;
+    bool valid;
+    const unsigned long long code = kmerAt(S, p, K, valid) & mask;
+    if (active && valid) indexLookup(ix, code, barcode, start, cnt);
+    bool same = false;
+    if (p > 0) same = (((code >> 2) | ((unsigned long long)nuc2(S[p - 1]) << (2 * (K - 1)))) == code);
+    posStart[q] = start; posPref[q] = cnt | (same ? SAME : 0u);
     if (cnt >= 100) big = 1;
   }
   big = blockSum(big, red) != 0;
   if ((skipLimit == 0 && !allowTotalSkip) || !big) {
     // no `continue` can fire: prevKmerCode is always the code of the previous position
     for (int q = lane; q < 2 * nk; q += NT) {
-      int st = q >= nk, p = st ? q - nk : q;
-      const char *S = st ? wm.rc : wm.seg;
-      bool emit = true;
-      if (p > 0) {
-        bool v0, v1;
-        unsigned long long c0 = kmerAt(S, p - 1, K, v0) & mask, c1 = kmerAt(S, p, K, v1) & mask;
-        emit = (c0 != c1);
-      }
-      if (!emit) posPref[q] = 0;
+      const unsigned v = posPref[q];
+      posPref[q] = (v & SAME) ? 0u : v;
     }
-  } else if (lane == 0) {
+  } else {
+    for (int q = lane; q < 2 * nk; q += NT) posPref[q] &= ~SAME;
+    __syncthreads();
+    if (lane == 0) {
     // sequential replay of the skip state machine (SeqSet.hpp:1370-1425, 1437-1498)
     unsigned long long prev = 0;
     for (int st = 0; st < 2; ++st) {
@@ -769,6 +769,7 @@ __device__ int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int
         if (!emit) posPref[q] = 0;
         prev = code;
       }
+    }
     }
   }
   __syncthreads();
