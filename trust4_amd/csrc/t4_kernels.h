@@ -1373,14 +1373,34 @@ __device__ void walkOverlap(const T4IndexView &ix, WaveMem &wm, WaveState *ws, O
       else { if (!isRef && indelCnt > 0) { simOne = false; break; } }
     }
   }
-  if (collect) return;
+  if (collect) {
+    // Reference-gene overlaps under radius > 0 never break on an alignment result (only on geometry, which this pass sees):
+    // their matchCnt / indelCnt are plain sums, so the alignment results are ADDED by whoever computes them (res[0], which no
+    // gap uses, and o.indelCnt) and the finishing pass does not walk the chain again.
+    if (isRef && ix.radius > 0) {
+      ((unsigned *)res)[0] = (unsigned)matchCnt;
+      OvRec &dst = wm.ov[wm.ord[ordIdx]];
+      dst.indelCnt = indelCnt;
+      if (simOne) dst.flags &= ~OV_SIMZERO; else dst.flags |= OV_SIMZERO;
+    }
+    return;
+  }
   o.matchCnt = matchCnt; o.indelCnt = indelCnt;
   if (simOne) o.flags &= ~OV_SIMZERO; else o.flags |= OV_SIMZERO;
   if (lowComplex(wm, (o.flags & OV_PLUS) != 0, o.rs, o.re)) o.flags |= OV_SIMZERO;
 }
 
+// result of one gap alignment of overlap slot `ovSlot` (fast class of walkOverlap): add it where the finishing pass expects it
+__device__ __forceinline__ void addGapResult(WaveMem &wm, WaveState *ws, int ovSlot, unsigned c) {
+  OvRec &o = wm.ov[ovSlot];
+  if (c == DP_FAIL) { ws->unsupported = 1; return; }
+  unsigned *res0 = (unsigned *)(wm.keys + o.chainPos) + o.chainLen;
+  atomicAdd(res0, 2u * (c & 1023u));
+  if (c >> 20) atomicAdd(&o.indelCnt, (int)(c >> 20));
+}
+
 // Quick exits of one gap job (any lane); jobs that need the banded DP are marked DP_PENDING.
-__device__ void runGapJobQuick(const T4IndexView &ix, WaveMem &wm, unsigned job) {
+__device__ void runGapJobQuick(const T4IndexView &ix, WaveMem &wm, WaveState *ws, unsigned job) {
   const int K = ix.k;
   const OvRec &o = wm.ov[wm.ord[job & 0xFFFF]];
   const int j = (int)(job >> 16);
@@ -1393,6 +1413,7 @@ __device__ void runGapJobQuick(const T4IndexView &ix, WaveMem &wm, unsigned job)
   bool done = si.isRef ? dpAffineQuick(ix.cons + si.consOff + pb + K, lent, r, lenp, cnt)
                        : dpPosWeightQuick(ix.pw + si.pwOff + pb + K, lent, r, lenp, cnt);
   hc[o.chainLen + j] = done ? cnt : DP_PENDING;
+  if (done && si.isRef && ix.radius > 0) addGapResult(wm, ws, wm.ord[job & 0xFFFF], cnt);
 }
 
 // GetVJOverlapsFromHits' pair selection (SeqSet.hpp:1093-1160) on wm.ov[0..n). One lane. Returns 0 or 2
@@ -1520,7 +1541,7 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
   if (lane == 0) DBG_ADD(0, nJobs);
   // (2) quick exits, one job per lane
   PHASE_MARK(ws, 13);
-  for (int q = lane; q < nJobs; q += NT) runGapJobQuick(ix, wm, wm.cand[q]);
+  for (int q = lane; q < nJobs; q += NT) runGapJobQuick(ix, wm, ws, wm.cand[q]);
   __syncthreads();
   // (3) banded DPs: compact the pending jobs, then one wavefront per alignment
   PHASE_MARK(ws, 14);
@@ -1566,7 +1587,11 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
       if (__any(asPw)) { unsigned v = dpRow16<true>(asPw, (const char *)0, ix.pw + si.pwOff + pb + ix.k, lent, r, lenp, tbufWave + row * rowCap, rowCap); if (asPw) c = v; }
       if (has && (lane & 15) == 0) {
         DBG_ADD(1, 1);
-        if (c != DP_FAIL) { hc[o.chainLen + jj] = c; DBG_ADD(2, 2 * lenp + 11 + (lent > lenp ? lent - lenp : lenp - lent)); }
+        if (c != DP_FAIL) {
+          hc[o.chainLen + jj] = c;
+          if (si.isRef && ix.radius > 0) addGapResult(wm, ws, wm.ord[job & 0xFFFF], c);
+          DBG_ADD(2, 2 * lenp + 11 + (lent > lenp ? lent - lenp : lenp - lent));
+        }
       }
     }
     __syncthreads();
@@ -1593,7 +1618,10 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
                            : dpPosWeight(ix.pw + si.pwOff + pb + ix.k, lent, r, lenp, sc, laneId(), c0, c1, c2, (signed char *)0);
         if (ok) c = CNT_MATCH * (unsigned)c0 + CNT_MIS * (unsigned)c1 + CNT_INDEL * (unsigned)c2;
       }
-      if (laneId() == 0) hc[o.chainLen + jj] = c;
+      if (laneId() == 0) {
+        hc[o.chainLen + jj] = c;
+        if (si.isRef && ix.radius > 0) addGapResult(wm, ws, wm.ord[job & 0xFFFF], c);
+      }
     }
   }
   __syncthreads();
@@ -1602,7 +1630,10 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
   for (int i = lane; i < overlapCnt; i += NT) {
     OvRec o = wm.ov[wm.ord[i]];
     int m0 = o.matchCnt;
-    walkOverlap(ix, wm, ws, o, i, false);
+    if ((o.flags & OV_ISREF) && ix.radius > 0) {   // sums are complete (see walkOverlap): no second walk
+      o.matchCnt = (int)((const unsigned *)(wm.keys + o.chainPos))[o.chainLen];
+      if (lowComplex(wm, (o.flags & OV_PLUS) != 0, o.rs, o.re)) o.flags |= OV_SIMZERO;
+    } else walkOverlap(ix, wm, ws, o, i, false);
     o.chainLen = m0;                       // chain no longer needed: keep the pre-score matchCnt here
     wm.ov[wm.ord[i]] = o;
   }
