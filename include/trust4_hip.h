@@ -128,7 +128,7 @@ int t4_assign(t4_index *ix, t4_batch *b, int strand, int32_t *ret, t4_overlap *o
  * the reference's alignment (matches, mismatches, indels) and a status word (0 ok, 1 beyond the
  * engine's gap limits). impl 0 = the forward-only LDS formulation the overlap scorer uses (falls back
  * to the traceback formulation for wide bands), impl 1 = traceback formulation only, impl 2 = one alignment per
- * wavefront (status 2 in out4[3] for bands wider than 64 columns), impl 3 = four alignments per wavefront, one per
+ * wavefront (status 2 in out4[3] for bands wider than 64 columns), impl 3 = eight alignments per wavefront, two per
  * 16-lane DPP row (status 2 for bands wider than 16 columns): the two formulations overlap scoring runs on the GPU. */
 int t4_gap_dp(t4_ctx *ctx, int kind, int impl, int n, const int64_t *t_off, const int64_t *p_off,
               const void *t_data, const char *p_chars, int32_t *out4);

@@ -1220,14 +1220,17 @@ __device__ unsigned dpWave(const char *t, const T4PW *w, int lent, const char *p
 }
 
 
-// The same recurrences with FOUR alignments per wavefront, one per row of 16 lanes (DPP row shifts): most bands are
-// 11 + |lent - lenp| <= 16 columns wide, so a whole wavefront per alignment leaves 3/4 of the lanes without a cell.
-// Every lane passes the job of its row (has == false: no job); rows whose band is wider than 16 columns, or whose sides
-// exceed T4_MAXGAP (or the row's tcap bytes of LDS at tbuf, affine only), get DP_FAIL and are left to dpWave.
-// All 64 lanes must call it.
+// The same recurrences with EIGHT alignments per wavefront and no idle cell slot. A band is 11 + |lent - lenp| columns,
+// almost always <= 16; in the skewed order s = 2i + d a lane that owns ONE column has a cell only every other step. So
+// lane L of a group of 8 owns the column pair (2L, 2L+1): in step pair u it computes row i = u - L of both columns,
+//   A = (i, 2L):   left (i, 2L-1) = lane L-1's B of the previous pair (one DPP row shift), upper = own old B, diagonal = own old A
+//   B = (i, 2L+1): left = own new A, upper (i-1, 2L+2) = lane L+1's new A (one DPP row shift), diagonal = own old B
+// i.e. 8 DPP moves and two full cell updates per pair, every lane busy, two alignments per 16-lane DPP row. Every lane
+// passes the job of its group of 8 (has == false: none); jobs whose band is wider than 16 columns or whose sides exceed
+// T4_MAXGAP (or the group's tcap bytes of LDS at tbuf, affine only) get DP_FAIL and are left to dpWave. All 64 lanes call it.
 template <bool PW>
-__device__ __attribute__((noinline)) unsigned dpRow16(bool has, const char *t, const T4PW *w, int lent, const char *p, int lenp, char *tbuf, int tcap) {
-  const int d = laneId() & 15, rowBase = laneId() & 48;
+__device__ __attribute__((noinline)) unsigned dpOct(bool has, const char *t, const T4PW *w, int lent, const char *p, int lenp, char *tbuf, int tcap) {
+  const int L = laneId() & 7, grpBase = laneId() & 56;
   unsigned result = 0u;
   bool run = has;
   if (run && (lent == 0 || lenp == 0)) { result = 0u; run = false; }
@@ -1238,97 +1241,166 @@ __device__ __attribute__((noinline)) unsigned dpRow16(bool has, const char *t, c
   if (PW) {   // the reference's ungapped early return (AlignAlgo.hpp:81-103)
     const bool chk = run && lent == lenp;
     int mm = 0;
-    if (chk) for (int i = d; i < lent; i += 16) mm += baseEqualW(w[i], p[i]) ? 0 : 1;
-    mm = rowSum16(mm);
+    if (chk) for (int i = L; i < lent; i += 8) mm += baseEqualW(w[i], p[i]) ? 0 : 1;
+    mm += __shfl_xor(mm, 1); mm += __shfl_xor(mm, 2); mm += __shfl_xor(mm, 4);
     if (chk && (lent - mm) * 2 - mm * 2 >= lent * 2 - 8) { result = CNT_MATCH * (unsigned)(lent - mm) + CNT_MIS * (unsigned)mm; run = false; }
   }
   int leftBand = 5, rightBand = 5;
   if (lent > lenp) rightBand += lent - lenp; else if (lent < lenp) leftBand += lenp - lent;
   const int W = leftBand + rightBand + 1;
   if (run && (W > 16 || lent > T4_MAXGAP || lenp > T4_MAXGAP || (!PW && lent > tcap))) { result = DP_FAIL; run = false; }
-  if (!PW && run) { for (int i = d; i < lent; i += 16) tbuf[i] = t[i]; }
+  if (!PW && run) { for (int i = L; i < lent; i += 8) tbuf[i] = t[i]; }
   const int negInf = (lent + 1) * (lenp + 1) * (-4);
   const int e0 = -4 + (lenp + 1) * (-4);
   const int q4 = 4 * (lenp + 1);
-  int M = negInf, E = negInf, F = negInf;
-  unsigned C0 = 0, C1 = 0, C2 = 0;
+  // row 0 of the lane's two columns
+  int MA = negInf, EA = negInf, FA = negInf, MB = negInf, EB = negInf, FB = negInf;
+  unsigned C0A = 0, C1A = 0, C2A = 0, C0B = 0, C1B = 0, C2B = 0;
   if (run) {
-    int j0 = d - leftBand;
-    if (d < W && j0 >= 0 && j0 <= lent) {
-      if (j0 == 0) { M = 0; E = 0; F = 0; }
-      else if (PW) { M = -4 - 4 * j0; C0 = CNT_MATCH + CNT_INDEL * (unsigned)(j0 - 1); }
-      else { M = -4 - 4 * j0; E = e0; F = -4 - j0; C0 = CNT_INDEL * (unsigned)(j0 + (j0 > q4 ? 1 : 0)); C1 = CNT_INDEL * (unsigned)(1 + j0); C2 = CNT_INDEL * (unsigned)j0; }
+    for (int c = 0; c < 2; ++c) {
+      const int dcol = 2 * L + c, j0 = dcol - leftBand;
+      int m = negInf, e = negInf, f = negInf; unsigned c0 = 0, c1 = 0, c2 = 0;
+      if (dcol < W && j0 >= 0 && j0 <= lent) {
+        if (j0 == 0) { m = 0; e = 0; f = 0; }
+        else if (PW) { m = -4 - 4 * j0; c0 = CNT_MATCH + CNT_INDEL * (unsigned)(j0 - 1); }
+        else { m = -4 - 4 * j0; e = e0; f = -4 - j0; c0 = CNT_INDEL * (unsigned)(j0 + (j0 > q4 ? 1 : 0)); c1 = CNT_INDEL * (unsigned)(1 + j0); c2 = CNT_INDEL * (unsigned)j0; }
+      }
+      if (c == 0) { MA = m; EA = e; FA = f; C0A = c0; C1A = c1; C2A = c2; } else { MB = m; EB = e; FB = f; C0B = c0; C1B = c1; C2B = c2; }
     }
   }
-  const int lastStep = run ? 2 * lenp + W - 1 : 0;
-  int maxStep = lastStep;
-  for (int o = 16; o < 64; o <<= 1) { int v = __shfl_xor(maxStep, o); if (v > maxStep) maxStep = v; }
-  // Band edges cost nothing inside the loop: a lane outside the band (d >= W) never updates its cell, which stays at
-  // (negInf, 0) as initialised, and the row's edge lanes receive (negInf, 0) from the DPP shift itself.
-  for (int s = 2; s <= maxStep; ++s) {
-    int lM = rowUp1E(M, negInf), uM = rowDown1E(M, negInf);
-    unsigned lC0 = rowUp1E(C0, 0u), uC0 = rowDown1E(C0, 0u);
-    int lF = 0, uE = 0; unsigned lC2 = 0, uC1 = 0;
-    if (!PW) { lF = rowUp1E(F, negInf); lC2 = rowUp1E(C2, 0u); uE = rowDown1E(E, negInf); uC1 = rowDown1E(C1, 0u); }
-    const int i2 = s - d, i = i2 >> 1, j = i - leftBand + d;
-    if (run && s <= lastStep && d < W && (i2 & 1) == 0 && i >= 1 && i <= lenp && j >= 1 && j <= lent) {
-      int dM = M; unsigned dC0 = C0;     // diagonal neighbour: the lane's own previous cell
-      if (i == 1 || j == 1) {            // first row / first column: closed forms of the reference's borders
-        if (j == 1) {             // left neighbour is column 0
-          lM = -4 - 4 * i;
-          if (PW) lC0 = CNT_MATCH + CNT_INDEL * (unsigned)(i - 1);
-          else { lF = -4 - 4 * i; lC0 = CNT_INDEL * (unsigned)i; lC2 = CNT_INDEL * (unsigned)(1 + i); }
+  const int lastPair = run ? lenp + ((W - 1) >> 1) : 0;
+  int maxPair = lastPair;
+  for (int o = 8; o < 64; o <<= 1) { int v = __shfl_xor(maxPair, o); if (v > maxPair) maxPair = v; }
+  for (int u = 1; u <= maxPair; ++u) {
+    const int i = u - L;
+    const bool rowOk = run && u <= lastPair && i >= 1 && i <= lenp;
+    const char pc = rowOk ? p[i - 1] : 'A';
+    // ---- column A = 2L: left neighbour from lane L-1's B (previous pair)
+    int lM = rowUp1E(MB, negInf); unsigned lC0 = rowUp1E(C0B, 0u);
+    int lF = 0; unsigned lC2 = 0;
+    if (!PW) { lF = rowUp1E(FB, negInf); lC2 = rowUp1E(C2B, 0u); }
+    if (L == 0) { lM = negInf; lC0 = 0; lF = negInf; lC2 = 0; }   // the group's first lane: column -1 (the DPP edge only covers the row's)
+    const int oMA = MA; const unsigned oC0A = C0A;                 // A's diagonal neighbour (i-1, 2L): own A of the previous pair
+    const int oMB = MB, oEB = EB; const unsigned oC0B = C0B, oC1B = C1B;   // A's upper and B's diagonal neighbour: own B of the previous pair
+    {
+      const int dcol = 2 * L, j = i - leftBand + dcol;
+      if (rowOk && dcol < W && j >= 1 && j <= lent) {
+        int uM = oMB, uE = oEB; unsigned uC0 = oC0B, uC1 = oC1B;   // upper neighbour (i-1, 2L+1): own B of the previous pair
+        int dM = oMA; unsigned dC0 = oC0A;
+        if (i == 1 || j == 1) {
+          if (j == 1) {
+            lM = -4 - 4 * i;
+            if (PW) lC0 = CNT_MATCH + CNT_INDEL * (unsigned)(i - 1);
+            else { lF = -4 - 4 * i; lC0 = CNT_INDEL * (unsigned)i; lC2 = CNT_INDEL * (unsigned)(1 + i); }
+          }
+          if (i == 1) {
+            uM = -4 - 4 * j;
+            if (PW) uC0 = CNT_MATCH + CNT_INDEL * (unsigned)(j - 1);
+            else { uE = e0; uC0 = CNT_INDEL * (unsigned)(j + (j > q4 ? 1 : 0)); uC1 = CNT_INDEL * (unsigned)(1 + j); }
+            const int jj = j - 1;
+            dM = jj == 0 ? 0 : -4 - 4 * jj;
+            dC0 = jj == 0 ? 0u : (PW ? CNT_MATCH + CNT_INDEL * (unsigned)(jj - 1) : CNT_INDEL * (unsigned)(jj + (jj > q4 ? 1 : 0)));
+          } else {
+            dM = -4 - 4 * (i - 1);
+            dC0 = PW ? CNT_MATCH + CNT_INDEL * (unsigned)(i - 2) : CNT_INDEL * (unsigned)(i - 1);
+          }
         }
-        if (i == 1) {             // upper neighbour is row 0
-          uM = -4 - 4 * j;
-          if (PW) uC0 = CNT_MATCH + CNT_INDEL * (unsigned)(j - 1);
-          else { uE = e0; uC0 = CNT_INDEL * (unsigned)(j + (j > q4 ? 1 : 0)); uC1 = CNT_INDEL * (unsigned)(1 + j); }
-          int jj = j - 1;
-          dM = jj == 0 ? 0 : -4 - 4 * jj;
-          dC0 = jj == 0 ? 0u : (PW ? CNT_MATCH + CNT_INDEL * (unsigned)(jj - 1) : CNT_INDEL * (unsigned)(jj + (jj > q4 ? 1 : 0)));
-        } else {                  // j == 1, i > 1
-          dM = -4 - 4 * (i - 1);
-          dC0 = PW ? CNT_MATCH + CNT_INDEL * (unsigned)(i - 2) : CNT_INDEL * (unsigned)(i - 1);
+        if (PW) {
+          const bool eq = baseEqualW(w[j - 1], pc);
+          const int dsc = dM + (eq ? 2 : -2);
+          int m = dsc;
+          if (lM - 4 > m) m = lM - 4;
+          if (uM - 4 > m) m = uM - 4;
+          unsigned c;
+          if (dsc == m) c = dC0 + (eq ? CNT_MATCH : CNT_MIS);
+          else if (uM - 4 == m) c = uC0 + CNT_INDEL;
+          else c = lC0 + CNT_INDEL;
+          MA = m; C0A = c;
+        } else {
+          const char tc = tbuf[j - 1];
+          const bool eq = (tc == pc || tc == 'N' || pc == 'N');
+          int e = uE - 1, eo = uM - 5;
+          if (eo > e) e = eo;
+          int f = lF - 1, fo = lM - 5;
+          if (fo > f) f = fo;
+          const int dsc = dM + (eq ? 2 : -2);
+          int m = dsc;
+          if (e > m) m = e;
+          if (f > m) m = f;
+          const unsigned c1 = CNT_INDEL + ((eo == e) ? uC0 : uC1);
+          const unsigned c2 = CNT_INDEL + ((fo == f) ? lC0 : lC2);
+          unsigned c0;
+          if (dsc == m) c0 = dC0 + (eq ? CNT_MATCH : CNT_MIS);
+          else c0 = (f >= e) ? c2 : c1;
+          MA = m; EA = e; FA = f; C0A = c0; C1A = c1; C2A = c2;
         }
       }
-      const char pc = p[i - 1];
-      if (PW) {
-        const bool eq = baseEqualW(w[j - 1], pc);
-        const int dsc = dM + (eq ? 2 : -2);
-        int m = dsc;
-        if (lM - 4 > m) m = lM - 4;
-        if (uM - 4 > m) m = uM - 4;
-        unsigned c;
-        if (dsc == m) c = dC0 + (eq ? CNT_MATCH : CNT_MIS);
-        else if (uM - 4 == m) c = uC0 + CNT_INDEL;
-        else c = lC0 + CNT_INDEL;
-        M = m; C0 = c;
-      } else {
-        const char tc = tbuf[j - 1];
-        const bool eq = (tc == pc || tc == 'N' || pc == 'N');
-        int e = uE - 1, eo = uM - 5;
-        if (eo > e) e = eo;
-        int f = lF - 1, fo = lM - 5;
-        if (fo > f) f = fo;
-        const int dsc = dM + (eq ? 2 : -2);
-        int m = dsc;
-        if (e > m) m = e;
-        if (f > m) m = f;
-        const unsigned c1 = CNT_INDEL + ((eo == e) ? uC0 : uC1);
-        const unsigned c2 = CNT_INDEL + ((fo == f) ? lC0 : lC2);
-        unsigned c0;
-        if (dsc == m) c0 = dC0 + (eq ? CNT_MATCH : CNT_MIS);
-        else c0 = (f >= e) ? c2 : c1;
-        M = m; E = e; F = f; C0 = c0; C1 = c1; C2 = c2;
+    }
+    // ---- column B = 2L+1: upper neighbour from lane L+1's A (this pair)
+    int uM = rowDown1E(MA, negInf); unsigned uC0 = rowDown1E(C0A, 0u);
+    int uE = 0; unsigned uC1 = 0;
+    if (!PW) { uE = rowDown1E(EA, negInf); uC1 = rowDown1E(C1A, 0u); }
+    if (L == 7) { uM = negInf; uC0 = 0; uE = negInf; uC1 = 0; }    // column 16 is never inside a band of <= 16 columns
+    {
+      const int dcol = 2 * L + 1, j = i - leftBand + dcol;
+      if (rowOk && dcol < W && j >= 1 && j <= lent) {
+        int bM = MA, bF = FA; unsigned bC0 = C0A, bC2 = C2A;       // left neighbour (i, 2L): own A of this pair
+        int dM = oMB; unsigned dC0 = oC0B;
+        if (i == 1 || j == 1) {
+          if (j == 1) {
+            bM = -4 - 4 * i;
+            if (PW) bC0 = CNT_MATCH + CNT_INDEL * (unsigned)(i - 1);
+            else { bF = -4 - 4 * i; bC0 = CNT_INDEL * (unsigned)i; bC2 = CNT_INDEL * (unsigned)(1 + i); }
+          }
+          if (i == 1) {
+            uM = -4 - 4 * j;
+            if (PW) uC0 = CNT_MATCH + CNT_INDEL * (unsigned)(j - 1);
+            else { uE = e0; uC0 = CNT_INDEL * (unsigned)(j + (j > q4 ? 1 : 0)); uC1 = CNT_INDEL * (unsigned)(1 + j); }
+            const int jj = j - 1;
+            dM = jj == 0 ? 0 : -4 - 4 * jj;
+            dC0 = jj == 0 ? 0u : (PW ? CNT_MATCH + CNT_INDEL * (unsigned)(jj - 1) : CNT_INDEL * (unsigned)(jj + (jj > q4 ? 1 : 0)));
+          } else {
+            dM = -4 - 4 * (i - 1);
+            dC0 = PW ? CNT_MATCH + CNT_INDEL * (unsigned)(i - 2) : CNT_INDEL * (unsigned)(i - 1);
+          }
+        }
+        if (PW) {
+          const bool eq = baseEqualW(w[j - 1], pc);
+          const int dsc = dM + (eq ? 2 : -2);
+          int m = dsc;
+          if (bM - 4 > m) m = bM - 4;
+          if (uM - 4 > m) m = uM - 4;
+          unsigned c;
+          if (dsc == m) c = dC0 + (eq ? CNT_MATCH : CNT_MIS);
+          else if (uM - 4 == m) c = uC0 + CNT_INDEL;
+          else c = bC0 + CNT_INDEL;
+          MB = m; C0B = c;
+        } else {
+          const char tc = tbuf[j - 1];
+          const bool eq = (tc == pc || tc == 'N' || pc == 'N');
+          int e = uE - 1, eo = uM - 5;
+          if (eo > e) e = eo;
+          int f = bF - 1, fo = bM - 5;
+          if (fo > f) f = fo;
+          const int dsc = dM + (eq ? 2 : -2);
+          int m = dsc;
+          if (e > m) m = e;
+          if (f > m) m = f;
+          const unsigned c1 = CNT_INDEL + ((eo == e) ? uC0 : uC1);
+          const unsigned c2 = CNT_INDEL + ((fo == f) ? bC0 : bC2);
+          unsigned c0;
+          if (dsc == m) c0 = dC0 + (eq ? CNT_MATCH : CNT_MIS);
+          else c0 = (f >= e) ? c2 : c1;
+          MB = m; EB = e; FB = f; C0B = c0; C1B = c1; C2B = c2;
+        }
       }
     }
   }
-  int src = lent - lenp + leftBand;
-  if (src < 0 || src > 15) src = 0;
-  const unsigned fin = __shfl(C0, rowBase + src);
-  return run ? fin : result;
+  int dF = lent - lenp + leftBand;
+  if (dF < 0 || dF > 15) dF = 0;
+  const unsigned finA = __shfl(C0A, grpBase + (dF >> 1)), finB = __shfl(C0B, grpBase + (dF >> 1));
+  return run ? ((dF & 1) ? finB : finA) : result;
 }
-
 
 // Anchor walk of one overlap (SeqSet.hpp:1829-2019). One lane. The gap alignments themselves are hoisted out
 // of this data-dependent loop (a wavefront would otherwise execute them one lane at a time):
@@ -1561,13 +1633,13 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
     __syncthreads();
   }
   {
-    const int wave = lane >> 6, nw = NT >> 6, row = (lane >> 4) & 3;
-    // pairs is dead here (cap >= 1024 ints): one slice per wave, cut into the four rows' target buffers
-    const int rowCap = ((wm.cap * 4) / (nw * 4)) & ~15;
-    char *tbufWave = (char *)wm.pairs + wave * 4 * rowCap;
-    // (3a) four alignments per wavefront, one per row of 16 lanes (bands of <= 16 columns: almost all of them)
-    for (int q0 = wave * 4; q0 < nPend; q0 += nw * 4) {
-      const int q = q0 + row;
+    const int wave = lane >> 6, nw = NT >> 6, grp = (lane >> 3) & 7;
+    // pairs is dead here (cap >= 1024 ints): one slice per wave, cut into the eight groups' target buffers
+    const int rowCap = ((wm.cap * 4) / (nw * 8)) & ~15;
+    char *tbufWave = (char *)wm.pairs + wave * 8 * rowCap;
+    // (3a) eight alignments per wavefront, one per group of 8 lanes (bands of <= 16 columns: almost all of them)
+    for (int q0 = wave * 8; q0 < nPend; q0 += nw * 8) {
+      const int q = q0 + grp;
       const bool has = q < nPend;
       const unsigned job = has ? wm.cand[q] : 0u;
       const OvRec o = wm.ov[wm.ord[job & 0xFFFF]];
@@ -1583,9 +1655,9 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
       const T4SeqInfo si = ix.seqs[o.seqIdx];
       const bool asRef = has && si.isRef, asPw = has && !si.isRef;
       unsigned c = DP_FAIL;
-      if (__any(asRef)) { unsigned v = dpRow16<false>(asRef, ix.cons + si.consOff + pb + ix.k, (const T4PW *)0, lent, r, lenp, tbufWave + row * rowCap, rowCap); if (asRef) c = v; }
-      if (__any(asPw)) { unsigned v = dpRow16<true>(asPw, (const char *)0, ix.pw + si.pwOff + pb + ix.k, lent, r, lenp, tbufWave + row * rowCap, rowCap); if (asPw) c = v; }
-      if (has && (lane & 15) == 0) {
+      if (__any(asRef)) { unsigned v = dpOct<false>(asRef, ix.cons + si.consOff + pb + ix.k, (const T4PW *)0, lent, r, lenp, tbufWave + grp * rowCap, rowCap); if (asRef) c = v; }
+      if (__any(asPw)) { unsigned v = dpOct<true>(asPw, (const char *)0, ix.pw + si.pwOff + pb + ix.k, lent, r, lenp, tbufWave + grp * rowCap, rowCap); if (asPw) c = v; }
+      if (has && (lane & 7) == 0) {
         DBG_ADD(1, 1);
         if (c != DP_FAIL) {
           hc[o.chainLen + jj] = c;
@@ -1608,7 +1680,7 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
       const char *r = ((o.flags & OV_PLUS) ? wm.seg : wm.rc) + pa + ix.k;
       const T4SeqInfo si = ix.seqs[o.seqIdx];
       unsigned c = DP_FAIL;
-      if (lent <= 4 * rowCap || !si.isRef)
+      if (lent <= 8 * rowCap || !si.isRef)
         c = si.isRef ? dpWave<false>(ix.cons + si.consOff + pb + ix.k, (const T4PW *)0, lent, r, lenp, tbuf)
                      : dpWave<true>((const char *)0, ix.pw + si.pwOff + pb + ix.k, lent, r, lenp, tbuf);
       if (c == DP_FAIL && laneId() == 0) {   // band wider than a wavefront: lane-serial scratch version
@@ -2298,21 +2370,21 @@ __global__ __launch_bounds__(64) void gapDpKernel(int kind, int impl, int n, con
   DPScratch sc;
   sc.rows = dpRows + (size_t)blockIdx.x * (6 * T4_ROWW * 64);
   sc.dir = dpDir + ((size_t)blockIdx.x * 64 + lane) * T4_DIR_BYTES;
-  if (impl == 3) {   // four alignments per wavefront, one per 16-lane row; bands wider than 16 columns report status 2
-    const int row = lane >> 4;
-    for (int i0 = blockIdx.x * 4; i0 < n; i0 += gridDim.x * 4) {
-      const int i = i0 + row;
+  if (impl == 3) {   // eight alignments per wavefront, one per group of 8 lanes; bands wider than 16 columns report status 2
+    const int grp = lane >> 3;
+    for (int i0 = blockIdx.x * 8; i0 < n; i0 += gridDim.x * 8) {
+      const int i = i0 + grp;
       const bool has = i < n;
       int lent = 0, lenp = 0;
       if (has) { lent = (int)(tOff[i + 1] - tOff[i]); lenp = (int)(pOff[i + 1] - pOff[i]); }
       const bool fits = has && lenp <= T4_MAXGAP && lent <= T4_MAXGAP;
-      if (fits) for (int j = lane & 15; j < lenp; j += 16) s_p[row][j] = pChars[pOff[i] + j];
+      if (fits) for (int j = lane & 7; j < lenp; j += 8) s_p[grp][j] = pChars[pOff[i] + j];
       __syncthreads();
-      unsigned c = kind == 0 ? dpRow16<false>(fits, tChars + (has ? tOff[i] : 0), (const T4PW *)0, lent, s_p[row], lenp, s_p[4 + row], T4_MAXGAP)
-                             : dpRow16<true>(fits, (const char *)0, tW + (has ? tOff[i] : 0), lent, s_p[row], lenp, s_p[4 + row], T4_MAXGAP);
+      unsigned c = kind == 0 ? dpOct<false>(fits, tChars + (has ? tOff[i] : 0), (const T4PW *)0, lent, s_p[grp], lenp, s_p[8 + grp], T4_MAXGAP)
+                             : dpOct<true>(fits, (const char *)0, tW + (has ? tOff[i] : 0), lent, s_p[grp], lenp, s_p[8 + grp], T4_MAXGAP);
       if (!fits) c = DP_FAIL;
       __syncthreads();
-      if (has && (lane & 15) == 0) {
+      if (has && (lane & 7) == 0) {
         if (c == DP_FAIL) { out[4 * i] = out[4 * i + 1] = out[4 * i + 2] = 0; out[4 * i + 3] = 2; }
         else { out[4 * i] = (int)(c & 1023u); out[4 * i + 1] = (int)((c >> 10) & 1023u); out[4 * i + 2] = (int)(c >> 20); out[4 * i + 3] = 0; }
       }
