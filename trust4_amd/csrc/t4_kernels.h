@@ -2154,7 +2154,12 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
     for (int i = lane; i < n && i < qa.maxPerRead; i += NT) storeOverlap(qa.out + r * qa.maxPerRead + i, wm.fin[i]);
   } else if (VARIANT == 0) {
     loadSegment(bv, r, 0, len, wm);
-    if (lane == 0) contigIntervals(wm.seg, 7, ws);
+    if (lane == 0) {   // fewer than 7 N in the whole read: no window of 7 N can exist, the read is one contig
+      int nN = 0;
+      for (int w = 0; w < bv.wnm; ++w) nN += __popc(wm.nmRow[w]);
+      if (nN < 7 && len > 0) { ws->contigA[0] = 0; ws->contigB[0] = (short)(len - 1); ws->nContig = 1; }
+      else contigIntervals(wm.seg, 7, ws);
+    }
     __syncthreads();
     int nContig = ws->nContig;
     if (nContig > 64) { if (lane == 0) wk.status[r] = 1; return true; }
