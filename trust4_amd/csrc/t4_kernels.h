@@ -1413,8 +1413,11 @@ __device__ void walkOverlap(const T4IndexView &ix, WaveMem &wm, WaveState *ws, O
   const unsigned *res = hc + o.chainLen;
   int matchCnt = 2 * K, indelCnt = 0;
   bool simOne = true;
+  unsigned prevPair = hc[0];
   for (int j = 1; j < o.chainLen; ++j) {
-    int pa = PA(hc[j - 1]), pb = PB(hc[j - 1]), qa = PA(hc[j]), qb = PB(hc[j]);
+    const unsigned curPair = hc[j];
+    int pa = PA(prevPair), pb = PB(prevPair), qa = PA(curPair), qb = PB(curPair);
+    prevPair = curPair;
     int doDP = 0;
     if (pb - pa == qb - qa) {
       if (pa + K - 1 >= qa) matchCnt += 2 * (qa - pa);
