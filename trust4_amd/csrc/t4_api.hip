@@ -1151,7 +1151,7 @@ int t4_cellstore_prepare(t4_cellstore *cs, int max_slot, size_t bytes) {
 
 int t4_cellstore_stage(t4_cellstore *cs, int slot, int barcode, int nseq, const char *const *names, const char *const *cons,
                        const int32_t *const *pw, int64_t nkeys64, const uint64_t *keyCode, const int32_t *keyBucket, const int32_t *keyCnt,
-                       const int32_t *postIn, int64_t *pwOffsetInImage) {
+                       const int32_t *postIn, int64_t *pwOffsetInImage, const int32_t *seqBarcodes) {
   if (!cs || slot < 0 || slot >= (int)cs->slots.size() || !cs->slots[slot].live || nseq < 0 || nkeys64 < 0) return T4_ERR_ARG;
   t4_ctx *c = cs->ctx;
   (void)hipSetDevice(c->device);
@@ -1224,7 +1224,7 @@ int t4_cellstore_stage(t4_cellstore *cs, int slot, int barcode, int nseq, const 
   for (int i = 0; i < nseq; ++i) {
     T4SeqInfo &f = infos[i];
     const int l = (int)strlen(cons[i]);
-    f.consOff = (int)consAt; f.len = l; f.barcode = barcode; f.isRef = 0;
+    f.consOff = (int)consAt; f.len = l; f.barcode = seqBarcodes ? seqBarcodes[i] : barcode; f.isRef = 0;
     memcpy(consOut + consAt, cons[i], (size_t)l + 1);
     consAt += (size_t)l + 1;
     char nm[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -212,6 +212,8 @@ struct t4_assembler : InsertHook {
   t4_ctx *ctx;
   t4_index *dev = nullptr;   // device image of the current set
   t4_cellset *owner = nullptr;   // cell of a per-barcode set: the image lives in the owner's arena slot
+  t4_cellstore *priv = nullptr;  // stand-alone set whose index is not keyed by barcode: a private one-slot arena (the same
+                                 // staged images, predicate bytes and byte patches as the cells)
   int slot = -1, cellBarcode = -1;
   // cell mode: IsBaseEqual flips since the image was staged (most changes between two queries of a cell are single columns)
   struct PwPatch { int seq, pos; unsigned char val; };
@@ -246,14 +248,18 @@ struct t4_assembler : InsertHook {
     auto it = winKmers.find(Key{code, h});
     if (it != winKmers.end()) for (int slot : it->second) invalidateSlot(slot);
   }
-  // contig c changed in a way a query can observe (consensus, length, postings, an IsBaseEqual state of a column)
-  void structuralChange(int c) {
-    dirty = true; patches.clear();
+  // window entries whose query can observe a change of contig c
+  void invalidateFor(int c) {
     // a cell holds a handful of contigs which almost every read of the cell hits: any observable change ends its window
     if (owner) { for (size_t q = cacheHead; q < cache.size(); ++q) invalidateSlot((int)q); return; }
     if (winContigs.empty()) return;
     auto it = winContigs.find(c);
     if (it != winContigs.end()) for (int slot : it->second) invalidateSlot(slot);
+  }
+  // contig c changed in a way a query can observe (consensus, length, postings, an IsBaseEqual state of a column)
+  void structuralChange(int c) {
+    dirty = true; patches.clear();
+    invalidateFor(c);
   }
   // ++count[base] of one posWeight column; reports whether AlignAlgo::IsBaseEqual (AlignAlgo.hpp:49-55) can now answer differently
   void bumpWeight(int seqIdx, PosWeight &w, int base) {
@@ -263,8 +269,8 @@ struct t4_assembler : InsertHook {
     ++w.c[base]; ++sum;
     for (int x = 0; x < 4; ++x) after |= (sum < 3 * w.c[x]) ? (1u << x) : 0u;
     if (before == after) return;   // cannot be observed by a query: the image stays as it is
-    if (owner && !dirty && slot >= 0) {   // the resident image only needs this byte
-      for (size_t q = cacheHead; q < cache.size(); ++q) invalidateSlot((int)q);
+    if ((owner || priv) && !dirty && slot >= 0) {   // the resident image only needs this byte
+      invalidateFor(seqIdx);
       patches.push_back(PwPatch{seqIdx, (int)(&w - seqs[seqIdx].pw.data()), (unsigned char)after});
       return;
     }
@@ -274,13 +280,16 @@ struct t4_assembler : InsertHook {
   void beginWindow(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive);
   void endWindow(const int32_t *cnts, const t4_overlap *ov, const t4_overlap *ex, const int32_t *rets, int stride);
   int stageImage();   // cell mode: queue this cell's image in the owner's arena
+  int refreshPrivate();
   int releaseFinishedBarcode(int barcode);
 
   void setPrev(int seqIdx, int rs, int re, int ss, int se, int strand) {
     prevAdd.seqIdx = seqIdx; prevAdd.readStart = rs; prevAdd.readEnd = re; prevAdd.seqStart = ss; prevAdd.seqEnd = se; prevAdd.strand = strand;
   }
 
+  t4_cellstore *storeOf();
   int refreshDevice() {
+    if (!index.considerBarcode) return refreshPrivate();
     if (!dirty) return T4_OK;
     auto t0_ = std::chrono::steady_clock::now();
     struct Tm { double &acc; std::chrono::steady_clock::time_point t0; ~Tm() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tm_{secRefresh, t0_};
@@ -381,6 +390,7 @@ struct t4_assembler : InsertHook {
     for (int i = 0; i < (int)seqs.size(); ++i) index.build(seqs[i].cons.c_str(), (int)seqs[i].cons.size(), i, seqs[i].barcode, 0);
     setPrev(-1, -1, -1, -1, -1, 0);
     if (dev) { t4_index_destroy(dev); dev = nullptr; }   // nomatchGapLimit and the lookup layout depend on k
+    if (priv) { t4_cellstore_destroy(priv); priv = nullptr; slot = -1; patches.clear(); }
     dropWindow();
     dirty = true;
     return T4_OK;
@@ -747,14 +757,44 @@ int t4_assembler::stageImage() {   // thread-safe across cells once the owner ha
     for (const Post &p : kv.second) { post.push_back(p.idx); post.push_back(p.offset); }
   }
   int64_t oPw = 0;
-  r = t4_cellstore_stage(owner->store, slot, cellBarcode, n, names.data(), cons.data(), pw.data(), (int64_t)keyCode.size(), keyCode.data(),
-                         keyBucket.data(), keyCnt.data(), post.data(), &oPw);
+  std::vector<int32_t> seqBc;
+  if (!owner) { seqBc.resize(n); for (int i = 0; i < n; ++i) seqBc[i] = seqs[i].barcode; }
+  r = t4_cellstore_stage(storeOf(), slot, owner ? cellBarcode : -1, n, names.data(), cons.data(), pw.data(), (int64_t)keyCode.size(), keyCode.data(),
+                         keyBucket.data(), keyCnt.data(), post.data(), &oPw, owner ? nullptr : seqBc.data());
   if (r) return r;
   imgPwOff.resize(n);
   for (int i = 0; i < n; ++i) { imgPwOff[i] = oPw; oPw += (int64_t)strlen(cons[i]) + 1; }
   patches.clear();
-  dirty = false; ++refreshes; ++owner->stagedImages;
+  dirty = false; ++refreshes;
+  if (owner) ++owner->stagedImages;
   return T4_OK;
+}
+
+t4_cellstore *t4_assembler::storeOf() { return owner ? owner->store : priv; }
+
+// stand-alone set: bring the private image up to date (full image after a structural change, byte patches after flips)
+int t4_assembler::refreshPrivate() {
+  if (!dirty && patches.empty()) return T4_OK;
+  auto t0_ = std::chrono::steady_clock::now();
+  struct Tm { double &acc; std::chrono::steady_clock::time_point t0; ~Tm() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tm_{secRefresh, t0_};
+  int r;
+  if (!priv) {
+    if ((r = t4_cellstore_create(ctx, k, &priv))) return r;
+    dirty = true;
+  }
+  if ((r = t4_cellstore_set_params(priv, hitLenRequired, radius, novelSim))) return r;
+  if (slot < 0 && (r = t4_cellstore_open(priv, &slot))) return r;
+  if (dirty) {
+    int64_t consBytes = 0;
+    for (const Seq &q : seqs) consBytes += (q.released ? 0 : (int64_t)q.cons.size()) + 1;
+    const size_t bytes = t4_cellstore_image_bytes((int)seqs.size(), (int64_t)index.map.size(), (int64_t)index.total, consBytes);
+    if ((r = t4_cellstore_prepare(priv, slot, bytes))) return r;
+    return stageImage();
+  }
+  std::vector<int64_t> offs; std::vector<unsigned char> vals;
+  for (const PwPatch &pp : patches) { offs.push_back(imgPwOff[pp.seq] + pp.pos); vals.push_back(pp.val); }
+  patches.clear();
+  return t4_cellstore_patch(priv, slot, (int)offs.size(), offs.data(), vals.data());
 }
 
 void t4_assembler::beginWindow(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive) {
@@ -831,7 +871,13 @@ int t4_assembler::prefetch(int n, const char *const *reads, const int *strands, 
   const size_t m = (size_t)n * MAXOV;
   std::vector<t4_overlap> ov(m), ex(m);
   std::vector<int32_t> cnts(n), rets(m);
-  rc = t4_add_query(dev, n, bases.data(), offs.data(), bcs.data(), sts.data(), repetitive, fac.data(), MAXOV, cnts.data(), ov.data(), ex.data(), rets.data());
+  if (!index.considerBarcode) {
+    std::vector<int32_t> slots(n, slot);
+    rc = index.total == 0 ? T4_OK   // an empty set has no hit for anybody
+                          : t4_cellstore_query(priv, n, slots.data(), bases.data(), offs.data(), bcs.data(), sts.data(), repetitive, fac.data(), MAXOV,
+                                               cnts.data(), ov.data(), ex.data(), rets.data());
+  } else
+    rc = t4_add_query(dev, n, bases.data(), offs.data(), bcs.data(), sts.data(), repetitive, fac.data(), MAXOV, cnts.data(), ov.data(), ex.data(), rets.data());
   ++queries;
   if (rc) { dropWindow(); return rc; }
   endWindow(cnts.data(), ov.data(), ex.data(), rets.data(), MAXOV);
@@ -888,6 +934,7 @@ int t4_assembler_create(t4_ctx *ctx, int kmer_length, int consider_barcode, t4_a
 void t4_assembler_destroy(t4_assembler *a) {
   if (!a) return;
   if (a->dev) t4_index_destroy(a->dev);
+  if (a->priv) { t4_cellstore_destroy(a->priv); a->priv = nullptr; }
   if (a->owner) return;   // cells belong to their t4_cellset
   delete a;
 }

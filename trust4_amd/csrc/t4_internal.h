@@ -22,7 +22,8 @@ int t4_cellstore_close(t4_cellstore *cs, int slot);
 // (idx local to the cell, list order = the order KmerIndex holds them in).
 int t4_cellstore_stage(t4_cellstore *cs, int slot, int barcode, int nseq, const char *const *names, const char *const *cons,
                        const int32_t *const *pw, int64_t nkeys, const uint64_t *key_code, const int32_t *key_bucket,
-                       const int32_t *key_cnt, const int32_t *post, int64_t *pw_offset_in_image);
+                       const int32_t *key_cnt, const int32_t *post, int64_t *pw_offset_in_image,
+                       const int32_t *seq_barcodes /* nullable: per-sequence barcodes of a set that is not keyed by barcode */);
 // Overwrite posWeight predicate bytes of the slot's resident image (byte offsets as returned by the last stage + the
 // column's index); applied after the staged images of the same flush.
 int t4_cellstore_patch(t4_cellstore *cs, int slot, int n, const int64_t *byte_offsets, const unsigned char *values);
