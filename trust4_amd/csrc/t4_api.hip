@@ -835,7 +835,7 @@ namespace {
 // The query half of SeqSet::AddRead for a batch of reads, lean path: one blob in, one blob out. Either every read is
 // matched against `base` (viewOf == nullptr; first launch on the 8192-hit LDS tier) or read i against views[viewOf[i]]
 // (per-barcode images: reads meet a handful of contigs, so the first launch is the 1024-hit tier at 6 groups / CU).
-int addQueryImpl(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const int32_t *viewOf, int n, const char *bases,
+int addQueryImpl(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const int32_t *viewOf, bool smallFirst, int n, const char *bases,
                  const int64_t *offsets, const int32_t *barcodes, const int32_t *strands, int skip_repeats, const double *factors,
                  int max_per_read, int32_t *counts, t4_overlap *ov, t4_overlap *ext, int32_t *ext_ret) {
   (void)hipSetDevice(c->device);
@@ -906,7 +906,7 @@ int addQueryImpl(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
   qa.ret = (int *)(c->aqOut + pRet); qa.strandPerRead = (const int *)(c->aqIn + oSt); qa.factorPerRead = (const double *)(c->aqIn + oFa);
   if (views) { qa.views = views; qa.viewOf = (const int *)(c->aqIn + oVw); }
   const int threads = 256;
-  const int grid0 = views ? (n < c->cus * TIER_BLOCKS_PER_CU[0] ? n : c->cus * TIER_BLOCKS_PER_CU[0]) : n;
+  const int grid0 = smallFirst ? (n < c->cus * TIER_BLOCKS_PER_CU[0] ? n : c->cus * TIER_BLOCKS_PER_CU[0]) : n;
   if ((r = ensureScratch(c, (grid0 > c->cus * 2 ? grid0 : c->cus * 2) * threads))) return r;
   T4Work wk;
   memset(&wk, 0, sizeof wk);
@@ -914,13 +914,13 @@ int addQueryImpl(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
   wk.nextList = (int *)(c->aqOut + pNext); wk.nextCount = (int *)(c->aqOut + pTail);
   wk.status = (int *)(c->aqOut + pSta); wk.hitCounter = (unsigned long long *)(c->aqOut + pTail + 16);
   wk.dpRows = c->dpRows; wk.dpDir = c->dpDir;
-  if (views) launchTier<1024, 128, 256>(grid0, c->stream, base, bv, wk, qa);
+  if (smallFirst) launchTier<1024, 128, 256>(grid0, c->stream, base, bv, wk, qa);
   else launchTier<8192, 512, 256>(grid0, c->stream, base, bv, wk, qa);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(c->aqOutHost, c->aqOut, outBytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   int overflow = *(int *)(c->aqOutHost + pTail);
-  if (overflow > 0 && views) {   // reads beyond the 1024-hit tier: 8192-hit LDS tier
+  if (overflow > 0 && smallFirst) {   // reads beyond the 1024-hit tier: 8192-hit LDS tier
     T4Work w1 = wk;
     w1.list = (const int *)(c->aqOut + pNext); w1.nList = overflow;
     w1.nextList = (int *)(c->aqOut + pNext2); w1.nextCount = (int *)(c->aqOut + pTail + 8);
@@ -971,7 +971,7 @@ int t4_add_query(t4_index *ix, int n, const char *bases, const int64_t *offsets,
   if (!ix->committed) return fail(c, T4_ERR_STATE, "index not committed");
   if (ix->view.firstIsRef) return fail(c, T4_ERR_UNSUPPORTED, "t4_add_query needs a contig set");
   if (n == 0) return T4_OK;
-  return addQueryImpl(c, ix->view, nullptr, nullptr, n, bases, offsets, barcodes, strands, skip_repeats, factors, max_per_read, counts, ov, ext, ext_ret);
+  return addQueryImpl(c, ix->view, nullptr, nullptr, false, n, bases, offsets, barcodes, strands, skip_repeats, factors, max_per_read, counts, ov, ext, ext_ret);
 }
 
 }  // extern "C"
@@ -999,6 +999,7 @@ struct t4_cellstore {
   size_t patchCap = 0;
   int64_t bytesPatched = 0;
   int64_t bytesStaged = 0;
+  bool bigFirst = false;   // one big set (bulk mode): reads meet hundreds of contigs, start on the 8192-hit tier
   std::mutex mu;   // t4_cellstore_stage may run on several host threads after t4_cellstore_prepare
   static constexpr size_t CHUNK = (size_t)256 << 20;
 };
@@ -1273,8 +1274,9 @@ int t4_cellstore_query(t4_cellstore *cs, int n, const int32_t *slots, const char
   T4IndexView base;
   memset(&base, 0, sizeof base);
   base.k = cs->k;
-  return addQueryImpl(c, base, cs->dViews, slots, n, bases, offsets, barcodes, strands, skip_repeats, factors, max_per_read, counts, ov, ext, ext_ret);
+  return addQueryImpl(c, base, cs->dViews, slots, !cs->bigFirst, n, bases, offsets, barcodes, strands, skip_repeats, factors, max_per_read, counts, ov, ext, ext_ret);
 }
+int t4_cellstore_set_big_first(t4_cellstore *cs, int on) { if (!cs) return T4_ERR_ARG; cs->bigFirst = on != 0; return T4_OK; }
 int64_t t4_cellstore_bytes_staged(const t4_cellstore *cs) { return cs ? cs->bytesStaged + cs->bytesPatched : 0; }
 
 }  // extern "C"

@@ -780,6 +780,7 @@ int t4_assembler::refreshPrivate() {
   int r;
   if (!priv) {
     if ((r = t4_cellstore_create(ctx, k, &priv))) return r;
+    t4_cellstore_set_big_first(priv, 1);
     dirty = true;
   }
   if ((r = t4_cellstore_set_params(priv, hitLenRequired, radius, novelSim))) return r;

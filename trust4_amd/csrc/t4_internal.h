@@ -35,6 +35,7 @@ int t4_cellstore_prepare(t4_cellstore *cs, int max_slot, size_t bytes);
 int t4_cellstore_query(t4_cellstore *cs, int n, const int32_t *slots, const char *bases, const int64_t *offsets,
                        const int32_t *barcodes, const int32_t *strands, int skip_repeats, const double *factors,
                        int max_per_read, int32_t *counts, t4_overlap *ov, t4_overlap *ext, int32_t *ext_ret);
+int t4_cellstore_set_big_first(t4_cellstore *cs, int on);   // first launch on the 8192-hit tier (one big set) instead of the 1024-hit tier
 int64_t t4_cellstore_bytes_staged(const t4_cellstore *cs);
 
 }  // extern "C"

@@ -657,7 +657,7 @@ int main(int argc, char *argv[]) {
   std::vector<int> barcodeTotalReadCount(barcodeIntToStr.size(), 0), barcodeReadCount(barcodeIntToStr.size(), 0);
   if (hasBarcode) for (int i = 0; i < readCnt; ++i) if (sortedReads[i].barcode != -1) ++barcodeTotalReadCount[sortedReads[i].barcode];
   std::atomic<int> assembledReadCnt(0);
-  const int WINDOW = getenv("T4_WINDOW") ? atoi(getenv("T4_WINDOW")) : (hasBarcode ? 4 : 16);
+  const int WINDOW = getenv("T4_WINDOW") ? atoi(getenv("T4_WINDOW")) : 4;
   const int LANES = getenv("T4_LANES") ? atoi(getenv("T4_LANES")) : 4096;
 
   // AddRead arguments of read i that do not depend on the loop state (main.cpp:1609-1701)
