@@ -177,9 +177,14 @@ int t4_assembler_size(const t4_assembler *a);
 /* SeqSet::ChangeKmerLength (SeqSet.hpp:4624-4629): compacts the set (ids are renumbered) and re-indexes with the new k. */
 int t4_assembler_change_kmer_length(t4_assembler *a, int kmer_length);
 int64_t t4_assembler_index_postings(const t4_assembler *a);
-/* SeqSet::ReleaseFinishedBarcodeSeq({barcode}, removeFromIndex = true, contigMinCov = 0, earlyStop = true)
- * (SeqSet.hpp:10815-10935; main.cpp:1846-1859): the trailing contigs of that barcode leave the index and are final. */
-int t4_assembler_release_finished_barcode(t4_assembler *a, int barcode);
+/* SeqSet::ReleaseFinishedBarcodeSeq({barcode}, removeFromIndex = true, contigMinCov, earlyStop = true)
+ * (SeqSet.hpp:10815-10935; main.cpp:1846-1859): the trailing contigs of that barcode leave the index and are final
+ * (shallow ones, SeqSet::IsContigShallow, are dropped when contig_min_cov > 0). */
+int t4_assembler_release_finished_barcode(t4_assembler *a, int barcode, int contig_min_cov);
+/* SeqSet::ReleaseShallowContigs (SeqSet.hpp:10926-10936; main.cpp:1952-1955) */
+int t4_assembler_release_shallow_contigs(t4_assembler *a, int min_cov);
+/* SeqSet::Output(fp, &barcodeIntToStr) of a set that holds several barcodes (--keepNoBarcode, main.cpp:1968-1969) */
+int t4_assembler_output_barcodes(t4_assembler *a, const char *path, const char *const *barcode_names, int n_names);
 
 /* ---- per-barcode contig sets (barcode mode, main.cpp:1549-1559) ---------------------------------------
  * With --barcode the reference keys the k-mer index by barcode (SetConsiderBarcodeInIndexHash, KmerIndex.hpp:29-33)
@@ -208,6 +213,7 @@ int t4_cellset_prefetch(t4_cellset *cs, int n, t4_assembler *const *cells, const
  * touches that cell only, provided every AddRead it is offered was prefetched); one cell is never re-entrant. */
 int t4_cellset_set_threads(t4_cellset *cs, int host_threads);
 int t4_cellset_update_all_consensus(t4_cellset *cs);
+int t4_cellset_release_shallow_contigs(t4_cellset *cs, int min_cov);
 int t4_cellset_size(const t4_cellset *cs);   /* contig slots over all cells == seqSet.Size() */
 int t4_cellset_output(t4_cellset *cs, const char *path, const char *const *barcode_names, int n_names);
 int t4_cellset_counters(const t4_cellset *cs, int64_t *query_batches, int64_t *reads_queried, int64_t *images_staged,

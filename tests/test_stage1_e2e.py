@@ -99,3 +99,45 @@ def test_barcode_mode_emulated(tmp_path):
         subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, src, "-L" + os.path.dirname(lib), "-lt4hip_emu",
                         "-Wl,-rpath," + os.path.dirname(lib), "-lz", "-lpthread"], check=True)
     _barcode_case(tmp_path, exe, 160, 8, 6, {"T4_LANES": "8", "T4_WINDOW": "3", "T4_THREADS": "2"})
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not shipped")
+@pytest.mark.parametrize("extra", [["--contigMinCov", "3"], ["--keepNoBarcode"], ["--keepNoBarcode", "--contigMinCov", "2"]])
+def test_barcode_mode_options(tmp_path, extra):
+    """--contigMinCov (thin barcodes and shallow contigs dropped) and --keepNoBarcode (index not keyed by barcode: one set)"""
+    fa = str(tmp_path / "ref.fa")
+    _gunzip(REF_FA, fa)
+    pre = str(tmp_path / "c5")
+    subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, "1500", "0", "8", pre, "--cells", "40"], check=True)
+    # some reads lose their barcode, one cell is thin
+    lines = open(pre + "_bc.fa").read().split("\n")
+    for i in range(1, len(lines), 2):
+        if (i // 2) % 17 == 0 and lines[i]:
+            lines[i] = "missing_barcode"
+    open(pre + "_bc.fa", "w").write("\n".join(lines))
+    args = ["-f", fa, "-1", pre + "_1.fq", "-2", pre + "_2.fq", "--barcode", pre + "_bc.fa", "--UMI", pre + "_umi.fa"] + extra
+    ref_out, my_out = str(tmp_path / "ref"), str(tmp_path / "mine")
+    subprocess.run([REF_BIN, "-t", "1"] + args + ["-o", ref_out], check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([_driver(), "-t", "4"] + args + ["-o", my_out], check=True)
+    for suffix in ("_raw.out", "_assembled_reads.fa", "_final.out"):
+        assert filecmp.cmp(ref_out + suffix, my_out + suffix, shallow=False), (extra, suffix)
+    assert open(ref_out + "_raw.out").read().count(">") > 10
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not shipped")
+def test_trim_level_2_matches_reference_binary(tmp_path):
+    """--trimLevel 2: reference set with k = 7 and radius 0, V gene assignments used as barcodes"""
+    fa = str(tmp_path / "ref.fa")
+    _gunzip(REF_FA, fa)
+    r1, r2 = Synth(60, 3).next_pairs(1500)
+    f1, f2 = str(tmp_path / "s_1.fq"), str(tmp_path / "s_2.fq")
+    _write_fastq(f1, rows_to_strs(r1))
+    _write_fastq(f2, rows_to_strs(r2))
+    ref_out, my_out = str(tmp_path / "ref"), str(tmp_path / "mine")
+    args = ["--skipMateExtension", "--trimLevel", "2", "-f", fa, "-1", f1, "-2", f2]
+    subprocess.run([REF_BIN, "-t", "1"] + args + ["-o", ref_out], check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([_driver()] + args + ["-o", my_out], check=True)
+    for suffix in ("_raw.out", "_assembled_reads.fa", "_final.out"):
+        assert filecmp.cmp(ref_out + suffix, my_out + suffix, shallow=False), suffix

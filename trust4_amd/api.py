@@ -58,7 +58,8 @@ def _load():
         "t4_assembler_counters": (I, [P, P, P, P]),
         "t4_assembler_repeat_add_read": (I, [P, C.c_char_p]), "t4_assembler_update_all_consensus": (I, [P]),
         "t4_assembler_output": (I, [P, C.c_char_p]), "t4_assembler_size": (I, [P]), "t4_assembler_index_postings": (L, [P]),
-        "t4_assembler_release_finished_barcode": (I, [P, I]),
+        "t4_assembler_release_finished_barcode": (I, [P, I, I]), "t4_assembler_release_shallow_contigs": (I, [P, I]),
+        "t4_assembler_output_barcodes": (I, [P, C.c_char_p, P, I]), "t4_cellset_release_shallow_contigs": (I, [P, I]),
         "t4_cellset_create": (I, [P, I, C.POINTER(P)]), "t4_cellset_destroy": (None, [P]),
         "t4_cellset_set_params": (I, [P, I, I, C.c_double]), "t4_cellset_cell": (I, [P, I, C.POINTER(P)]),
         "t4_cellset_close_cell": (I, [P, P]), "t4_cellset_prefetch": (I, [P, I, P, P, P, I]),
@@ -146,8 +147,8 @@ class Assembler:
         self.h = h
         eng.check(eng.lib.t4_assembler_set_params(h, hit_len_required, radius, novel_seq_similarity))
 
-    def release_finished_barcode(self, barcode):
-        self.eng.check(self.eng.lib.t4_assembler_release_finished_barcode(self.h, barcode))
+    def release_finished_barcode(self, barcode, contig_min_cov=0):
+        self.eng.check(self.eng.lib.t4_assembler_release_finished_barcode(self.h, barcode, contig_min_cov))
 
     def _ret(self, r):
         if r < -50:

@@ -281,7 +281,9 @@ struct t4_assembler : InsertHook {
   void endWindow(const int32_t *cnts, const t4_overlap *ov, const t4_overlap *ex, const int32_t *rets, int stride);
   int stageImage();   // cell mode: queue this cell's image in the owner's arena
   int refreshPrivate();
-  int releaseFinishedBarcode(int barcode);
+  int releaseFinishedBarcode(int barcode, int contigMinCov);
+  bool isContigShallow(int i, int minCov) const;
+  void releaseShallowContigs(int minCov);
 
   void setPrev(int seqIdx, int rs, int re, int ss, int se, int strand) {
     prevAdd.seqIdx = seqIdx; prevAdd.readStart = rs; prevAdd.readEnd = re; prevAdd.seqStart = ss; prevAdd.seqEnd = se; prevAdd.strand = strand;
@@ -885,14 +887,39 @@ int t4_assembler::prefetch(int n, const char *const *reads, const int *strands, 
   return T4_OK;
 }
 
-// SeqSet::ReleaseFinishedBarcodeSeq({barcode}, removeFromIndex = true, contigMinCov = 0, earlyStop = true)
+// SeqSet::IsContigShallow (SeqSet.hpp:2512-2553): a base inside the covered stretch has fewer than minCov reads
+bool t4_assembler::isContigShallow(int i, int minCov) const {
+  const Seq &s = seqs[i];
+  if (s.released) return false;
+  const int len = (int)s.cons.size();
+  auto sum = [&](int j) { return s.pw[j].c[0] + s.pw[j].c[1] + s.pw[j].c[2] + s.pw[j].c[3]; };
+  int start, end, j;
+  for (j = 0; j < len; ++j) if (sum(j) >= minCov) break;
+  start = j;
+  for (j = len - 1; j >= start; --j) if (sum(j) >= minCov) break;
+  end = j;
+  for (j = start; j <= end; ++j) if (sum(j) < minCov) break;
+  return j <= end || end < start;
+}
+// SeqSet::ReleaseShallowContigs (SeqSet.hpp:10926-10936): at the end of the run, the index is not touched any more
+void t4_assembler::releaseShallowContigs(int minCov) {
+  for (int i = 0; i < (int)seqs.size(); ++i) if (isContigShallow(i, minCov)) { seqs[i].released = true; dirty = true; }
+}
+
+// SeqSet::ReleaseFinishedBarcodeSeq({barcode}, removeFromIndex = true, contigMinCov, earlyStop = true)
 // (SeqSet.hpp:10815-10935). The posWeight "compression" there is lossless for Output, so the counts are kept as they are.
-int t4_assembler::releaseFinishedBarcode(int barcode) {
+int t4_assembler::releaseFinishedBarcode(int barcode, int contigMinCov) {
   for (int i = (int)seqs.size() - 1; i >= 0; --i) {
     Seq &s = seqs[i];
     if (s.released) continue;
     if (s.frozen || s.pw.empty()) break;
     if (s.barcode != barcode) break;
+    if (contigMinCov > 0 && isContigShallow(i, contigMinCov)) {   // ReleaseSeq after taking it out of the index
+      index.removeSeq(s.cons.c_str(), (int)s.cons.size(), i, s.barcode, 0);
+      s.released = true;
+      structuralChange(i);
+      continue;
+    }
     s.frozen = true;   // before UpdateConsensus as in the reference: index = false, then the consensus is settled without re-indexing
     index.removeSeq(s.cons.c_str(), (int)s.cons.size(), i, s.barcode, 0);
     s.frozen = false; updateConsensus(i, false); s.frozen = true;
@@ -980,7 +1007,23 @@ int t4_assembler_change_kmer_length(t4_assembler *a, int kmer_length) {
   return a->changeKmerLength(kmer_length);
 }
 int64_t t4_assembler_index_postings(const t4_assembler *a) { return a ? (int64_t)a->index.total : 0; }
-int t4_assembler_release_finished_barcode(t4_assembler *a, int barcode) { return a ? a->releaseFinishedBarcode(barcode) : T4_ERR_ARG; }
+int t4_assembler_release_finished_barcode(t4_assembler *a, int barcode, int contig_min_cov) { return a ? a->releaseFinishedBarcode(barcode, contig_min_cov) : T4_ERR_ARG; }
+int t4_assembler_release_shallow_contigs(t4_assembler *a, int min_cov) { if (!a) return T4_ERR_ARG; a->releaseShallowContigs(min_cov); return T4_OK; }
+int t4_assembler_output_barcodes(t4_assembler *a, const char *path, const char *const *barcode_names, int n_names) {
+  if (!a || !path) return T4_ERR_ARG;
+  FILE *fp = fopen(path, "w");
+  if (!fp) return T4_ERR_IO;
+  // SeqSet::Output(fp, &barcodeIntToStr) of one set that holds several barcodes (--keepNoBarcode): the header depends on the record
+  for (int i = 0; i < (int)a->seqs.size(); ++i) {
+    const Seq &q = a->seqs[i];
+    if (q.released) continue;
+    std::vector<Seq> one(1, q);
+    const char *nm = (barcode_names && q.barcode >= 0 && q.barcode < n_names) ? barcode_names[q.barcode] : nullptr;
+    writeRecords(fp, one, i, nm);
+  }
+  fclose(fp);
+  return T4_OK;
+}
 
 // ---- t4_cellset ----------------------------------------------------------------------------------------------
 int t4_cellset_create(t4_ctx *ctx, int kmer_length, t4_cellset **out) {
@@ -1131,6 +1174,11 @@ int t4_cellset_output(t4_cellset *cs, const char *path, const char *const *barco
 int t4_cellset_set_threads(t4_cellset *cs, int host_threads) {
   if (!cs || host_threads < 1) return T4_ERR_ARG;
   cs->threads = host_threads > 64 ? 64 : host_threads;
+  return T4_OK;
+}
+int t4_cellset_release_shallow_contigs(t4_cellset *cs, int min_cov) {
+  if (!cs) return T4_ERR_ARG;
+  for (auto &kv : cs->cells) kv.second->releaseShallowContigs(min_cov);
   return T4_OK;
 }
 int t4_cellset_size(const t4_cellset *cs) {

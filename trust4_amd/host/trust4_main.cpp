@@ -12,7 +12,9 @@
 // Barcode mode (--barcode [--UMI]; main.cpp:797-842, 1123-1193, 1549-1559, 1846-1859): every cell is an independent
 // contig set (t4_cellset), so the Add queries of many cells run in one launch ("lanes") while each cell's reads are
 // committed in the reference's order; outputs are those of the reference's cell-after-cell pass.
-// Limits of this round: no --keepNoBarcode/--contigMinCov/-c/--debug-ns; without barcodes `_final.out` is written as a
+// --keepNoBarcode (main.cpp:1556-1559): the index is not keyed by barcode then, so the reads go through ONE contig set
+// with the barcode filter; --contigMinCov (main.cpp:822-828, 951-977, 1855, 1952-1955).
+// Limits of this round: no -c/--debug-ns; without barcodes `_final.out` is written as a
 // copy of `_raw.out` (the reference does the same under --skipMateExtension and always with barcodes; its mate-graph
 // extension tail is out of scope).
 #include <getopt.h>
@@ -53,6 +55,8 @@ const char *USAGE =
     "\t--cgeneEnd INT: skipping reads mapped to C gene coordinate greater than INT (default: 200)\n"
     "\t--barcode STRING: the path to the barcode file (default: not used)\n"
     "\t--UMI STRING: the path to the UMI file (default: not used)\n"
+    "\t--keepNoBarcode: assemble the reads with missing barcodes. (default: ignore the reads)\n"
+    "\t--contigMinCov INT: ignore contigs that have bases covered by fewer than INT reads (default: 0)\n"
     "Extension (multi-GPU, see trust4_amd/stage1_dist.py):\n"
     "\t--cellShard R/N: barcode mode only; assemble the R-th of N contiguous ranges of cells, write shard outputs\n";
 
@@ -402,7 +406,8 @@ int main(int argc, char *argv[]) {
                                          {"cellShard", required_argument, 0, 10100},
                                          {(char *)0, 0, 0, 0}};
   int indexKmerLength = 9, changeKmerLengthThreshold = 4096, trimLevel = 1, minHitLen = -1, constantGeneEnd = 200;
-  int shardRank = 0, shardCount = 1, threadCnt = 1;
+  int shardRank = 0, shardCount = 1, threadCnt = 1, contigMinCov = 0;
+  bool keepMissingBarcode = false;
   std::string refFa, outputPrefix = "trust";
   SeqReader reads, mateReads, barcodeFile, umiFile;
   bool hasMate = false, hasBarcode = false, hasUmi = false;
@@ -422,12 +427,13 @@ int main(int argc, char *argv[]) {
     else if (c == 10002) { barcodeFile.files.push_back(optarg); hasBarcode = true; }
     else if (c == 10004) { umiFile.files.push_back(optarg); hasUmi = true; }
     else if (c == 10100) { if (sscanf(optarg, "%d/%d", &shardRank, &shardCount) != 2 || shardCount < 1 || shardRank < 0 || shardRank >= shardCount) { fprintf(stderr, "--cellShard takes R/N with 0 <= R < N\n"); return EXIT_FAILURE; } }
-    else if (c == 10003 || c == 10007) { fprintf(stderr, "trust4-hip: --keepNoBarcode / --contigMinCov are not built yet.\n"); return EXIT_FAILURE; }
+    else if (c == 10003) keepMissingBarcode = true;
+    else if (c == 10007) contigMinCov = atoi(optarg);
     else { fprintf(stderr, "%s", USAGE); return EXIT_FAILURE; }
   }
   if (refFa.empty()) { fprintf(stderr, "Need to use -f to specify the receptor genome sequence.\n"); return EXIT_FAILURE; }
   if (getenv("T4_THREADS")) threadCnt = atoi(getenv("T4_THREADS")) > 0 ? atoi(getenv("T4_THREADS")) : 1;
-  if (shardCount > 1 && !hasBarcode) { fprintf(stderr, "--cellShard needs --barcode: without barcodes the Add pass does not shard (DESIGN.md 6).\n"); return EXIT_FAILURE; }
+  if (shardCount > 1 && (!hasBarcode || keepMissingBarcode)) { fprintf(stderr, "--cellShard needs --barcode: without barcodes the Add pass does not shard (DESIGN.md 6).\n"); return EXIT_FAILURE; }
 
   t4_ctx *ctx = nullptr;
   int rc = t4_init(getenv("T4_DEVICE") ? atoi(getenv("T4_DEVICE")) : 0, &ctx);
@@ -455,11 +461,12 @@ int main(int argc, char *argv[]) {
   int firstReadLen = -1, nIn = 0;
   std::unordered_map<std::string, int> barcodeStrToInt, umiStrToInt;
   std::vector<std::string> barcodeIntToStr;
+  std::vector<int> barcodePairCount;   // main.cpp:822-828 (only counted under --contigMinCov)
   while (reads.next()) {
     int barcode = -1, umi = -1;
     if (hasBarcode) {   // main.cpp:799-828
       barcodeFile.next();
-      if (barcodeFile.seq == "missing_barcode") {
+      if (barcodeFile.seq == "missing_barcode" && !keepMissingBarcode) {
         if (hasMate) mateReads.next();
         if (hasUmi) umiFile.next();
         continue;
@@ -467,6 +474,7 @@ int main(int argc, char *argv[]) {
       auto it = barcodeStrToInt.find(barcodeFile.seq);
       if (it != barcodeStrToInt.end()) barcode = it->second;
       else { barcode = (int)barcodeIntToStr.size(); barcodeStrToInt[barcodeFile.seq] = barcode; barcodeIntToStr.push_back(barcodeFile.seq); }
+      if (contigMinCov > 0) { if (barcode >= (int)barcodePairCount.size()) barcodePairCount.push_back(1); else ++barcodePairCount[barcode]; }
     }
     if (hasUmi) {       // main.cpp:831-842
       umiFile.next();
@@ -501,6 +509,12 @@ int main(int argc, char *argv[]) {
   auto writeEmpty = [&](const char *suffix) { FILE *fp = fopen((outputPrefix + suffix).c_str(), "w"); if (fp) fclose(fp); };
   if (readCnt <= 0) { writeEmpty("_raw.out"); writeEmpty("_assembled_reads.fa"); writeEmpty("_final.out"); return 0; }
 
+  if (contigMinCov > 0) {   // reads of barcodes with too few read pairs are dropped, after their k-mers were counted (main.cpp:951-977)
+    std::vector<SortRead> kept;
+    for (SortRead &r : sortedReads) if (!(r.barcode != -1 && barcodePairCount[r.barcode] < contigMinCov)) kept.push_back(std::move(r));
+    sortedReads.swap(kept);
+    readCnt = (int)sortedReads.size();
+  }
   // ---- count statistics + quality trimming (main.cpp:980-1061)
   parallelFor((long long)sortedReads.size(), threadCnt, [&](long long i) {
     SortRead &r = sortedReads[(size_t)i];
@@ -572,6 +586,13 @@ int main(int argc, char *argv[]) {
   std::vector<char> goodCandidate(readCnt, 0);
   for (int i = 0; i < readCnt; ++i) originToSorted[sortedReads[i].info] = i;
   for (int i = 0; i < readCnt; ++i) if (sortedReads[i].mateIdx != -1) sortedReads[i].mateIdx = originToSorted[sortedReads[i].mateIdx];
+  if (trimLevel > 1 && !hasBarcode) {   // the V gene assignment serves as a barcode (main.cpp:1224-1236)
+    for (int i = 0; i < readCnt; ++i)
+      if (sortedReads[i].g[0].seqIdx != -1 && sortedReads[i].g[0].similarity > 0.95) {
+        sortedReads[i].barcode = sortedReads[i].g[0].seqIdx;
+        if (sortedReads[i].mateIdx != -1) sortedReads[sortedReads[i].mateIdx].barcode = sortedReads[i].g[0].seqIdx;
+      }
+  }
   auto refName = [&](int idx) { return t4_index_seq_name(refSet, idx); };
   auto eraseFront = [](std::string &s, int n) { s.erase(0, n); };
   for (int i = 0; i < readCnt; ++i) {   // bases before the V gene
@@ -644,7 +665,8 @@ int main(int argc, char *argv[]) {
   if (firstReadLen / 2 < 31) { int l = firstReadLen / 2; if (l < 21) l = 21; hitLenRequired = l; }
   if (hasBarcode) hitLenRequired = 13;
   if (minHitLen != -1) hitLenRequired = minHitLen;
-  if (hasBarcode) {
+  const bool useCells = hasBarcode && !keepMissingBarcode;   // --keepNoBarcode: the index is not keyed by barcode, one set
+  if (useCells) {
     if (barcodeIntToStr.size() >= 1000003) { fprintf(stderr, "trust4-hip: more than 1000002 barcodes are not supported.\n"); return EXIT_FAILURE; }
     if ((rc = t4_cellset_create(ctx, indexKmerLength, &cellSet))) die(ctx, "t4_cellset_create", rc);
     t4_cellset_set_params(cellSet, hitLenRequired, 10, 0.9);
@@ -690,7 +712,7 @@ int main(int argc, char *argv[]) {
   };
   auto isNewRead = [&](int i) { return i == 0 || sortedReads[i].read != sortedReads[i - 1].read || sortedReads[i].barcode != sortedReads[i - 1].barcode; };
   std::vector<t4_assembler *> cellOf;   // barcode mode: the cell of every read this process assembles
-  auto setOf = [&](int i) { return hasBarcode ? cellOf[i] : seqSet; };
+  auto setOf = [&](int i) { return useCells ? cellOf[i] : seqSet; };
 
   // One walk = a run of consecutive reads processed in order: the whole input in bulk mode, one cell (or a chain of
   // cells whose boundary reads are identical, see below) in barcode mode.
@@ -766,8 +788,8 @@ int main(int argc, char *argv[]) {
         }
         if (good) { goodCandidate[tag] = 1; sortedReads[tag].info = i; }
       }
-      if (hasBarcode && barcode != -1) {   // a barcode whose every read was assembled leaves the index (main.cpp:1846-1859)
-        if (++barcodeReadCount[barcode] >= barcodeTotalReadCount[barcode]) t4_assembler_release_finished_barcode(set, barcode);
+      if (useCells && barcode != -1) {   // a barcode whose every read was assembled leaves the index (main.cpp:1846-1859)
+        if (++barcodeReadCount[barcode] >= barcodeTotalReadCount[barcode]) t4_assembler_release_finished_barcode(set, barcode, contigMinCov);
       }
     }
     w.prevAddRet = addRet;
@@ -789,25 +811,25 @@ int main(int argc, char *argv[]) {
   std::vector<int> assembledReadIdx;
   int rescueReadCnt = 0, rescuedCnt = 0;
   int64_t laneBatches = 0, fallbackQueries = 0;
-  if (!hasBarcode) {
+  if (!useCells) {
     Walk w;
     w.begin = 0; w.end = readCnt;
     while (w.cur < w.end) {
       const int i = w.cur;
       if (WINDOW > 1 && needsQuery(i) && !t4_assembler_window_valid(seqSet)) {   // speculate on the next distinct, unfiltered reads
-        std::vector<const char *> rs; std::vector<int> st;
+        std::vector<const char *> rs; std::vector<int> st, bc;
         for (int j = i; j < readCnt && (int)rs.size() < WINDOW; ++j) {
           if (!isNewRead(j)) continue;
           AddArgs b = addArgs(j);
           if (b.filter) continue;
-          rs.push_back(sortedReads[j].read.c_str()); st.push_back(b.strand);
+          rs.push_back(sortedReads[j].read.c_str()); st.push_back(b.strand); bc.push_back(sortedReads[j].barcode);
         }
-        if ((rc = t4_assembler_prefetch(seqSet, (int)rs.size(), rs.data(), st.data(), nullptr, trimLevel > 1))) die(ctx, "t4_assembler_prefetch", rc);
+        if ((rc = t4_assembler_prefetch(seqSet, (int)rs.size(), rs.data(), st.data(), bc.data(), trimLevel > 1))) die(ctx, "t4_assembler_prefetch", rc);
       }
       stepMain(w);
-      if (assembledReadCnt > 0 && assembledReadCnt % 10000 == 0) t4_assembler_update_all_consensus(seqSet);
+      if (assembledReadCnt > 0 && assembledReadCnt % 10000 == 0 && !hasBarcode) t4_assembler_update_all_consensus(seqSet);
       if ((i + 1) % 100000 == 0) PrintLog("Processed %d reads (%d are used for assembly).", i + 1, assembledReadCnt.load());
-      if (t4_assembler_size(seqSet) > changeKmerLengthThreshold && indexKmerLength < 16) {
+      if (t4_assembler_size(seqSet) > changeKmerLengthThreshold && indexKmerLength < 16 && !hasBarcode) {
         changeKmerLengthThreshold *= 4;
         indexKmerLength += 2;
         t4_assembler_change_kmer_length(seqSet, indexKmerLength);
@@ -947,9 +969,13 @@ int main(int argc, char *argv[]) {
   std::vector<const char *> bnames;
   for (const std::string &b : barcodeIntToStr) bnames.push_back(b.c_str());
   auto writeSet = [&](const std::string &path) {
-    if (hasBarcode) { if ((rc = t4_cellset_output(cellSet, path.c_str(), bnames.data(), (int)bnames.size()))) die(ctx, "t4_cellset_output", rc); }
+    if (useCells) { if ((rc = t4_cellset_output(cellSet, path.c_str(), bnames.data(), (int)bnames.size()))) die(ctx, "t4_cellset_output", rc); }
+    else if (hasBarcode) { if ((rc = t4_assembler_output_barcodes(seqSet, path.c_str(), bnames.data(), (int)bnames.size()))) die(ctx, "t4_assembler_output_barcodes", rc); }
     else if ((rc = t4_assembler_output(seqSet, path.c_str()))) die(ctx, "t4_assembler_output", rc);
   };
+  if (contigMinCov > 0) {   // main.cpp:1952-1955
+    if (useCells) t4_cellset_release_shallow_contigs(cellSet, contigMinCov); else t4_assembler_release_shallow_contigs(seqSet, contigMinCov);
+  }
   writeSet(outputPrefix + "_raw.out");
   size_t nMainAssembled = assembledReadIdx.size();
   if (shardCount > 1) nMainAssembled -= (size_t)rescuedCnt;
@@ -975,7 +1001,7 @@ int main(int argc, char *argv[]) {
     fprintf(fp, "shard %d %d\ncontig_slots %d\nreads %d\n", shardRank, shardCount, t4_cellset_size(cellSet), readCnt);
     fclose(fp);
   } else writeSet(outputPrefix + "_final.out");
-  if (hasBarcode) {
+  if (useCells) {
     int64_t qb = 0, rq = 0, im = 0, by = 0; double sq = 0, ss = 0;
     t4_cellset_counters(cellSet, &qb, &rq, &im, &by, &sq, &ss);
     PrintLog("Finish assembly. (%lld cells; GPU query batches %lld with %lld reads in %.2f s; %lld cell images, %.1f MB, staged in %.2f s)",
