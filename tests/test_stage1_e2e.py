@@ -141,3 +141,42 @@ def test_trim_level_2_matches_reference_binary(tmp_path):
     subprocess.run([_driver()] + args + ["-o", my_out], check=True)
     for suffix in ("_raw.out", "_assembled_reads.fa", "_final.out"):
         assert filecmp.cmp(ref_out + suffix, my_out + suffix, shallow=False), suffix
+
+
+def _edge_reads(seed):
+    """synthetic reads plus the edge cases the reference's own input handling has branches for: reads shorter than the 21-mer
+    and than k, N runs that split a read into contigs, all-N and low-complexity reads, a read-through pair, exact duplicates"""
+    import random
+    rnd = random.Random(seed)
+    rows = rows_to_strs(Synth(30, seed).next_reads(300))
+    r1, r2 = rows[0::2], rows[1::2]
+    def rc(s):
+        return s[::-1].translate(str.maketrans("ACGTN", "TGCAN"))
+    extra1, extra2 = [], []
+    base = r1[0]
+    extra1 += [base[:20], base[:8], base[:5], "N" * 60, "A" * 80, base[:60] + "N" * 9 + base[69:], base[:40] + "NNN" + base[43:]]
+    extra2 += [r2[0][:30], r2[0][:12], "ACGT", "N" * 40, "C" * 70, r2[0], r2[1]]
+    frag = r1[3][:100]                                   # read-through: the mates cover the same 100 bp fragment
+    extra1.append(frag + "AGATCGGAAGAGC"); extra2.append(rc(frag) + "AGATCGGAAGAGC")
+    extra1 += [r1[5]] * 3; extra2 += [r2[5]] * 3         # duplicates -> RepeatAddRead
+    return r1 + extra1, r2 + extra2
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not shipped")
+@pytest.mark.parametrize("mode", ["paired", "single", "empty"])
+def test_edge_inputs_match_reference_binary(tmp_path, mode):
+    fa = str(tmp_path / "ref.fa")
+    _gunzip(REF_FA, fa)
+    a, b = _edge_reads(21)
+    if mode == "empty":
+        a, b = [], []
+    f1, f2 = str(tmp_path / "e_1.fq"), str(tmp_path / "e_2.fq")
+    _write_fastq(f1, a)
+    _write_fastq(f2, b)
+    args = ["--skipMateExtension", "-f", fa] + (["-u", f1] if mode == "single" else ["-1", f1, "-2", f2])
+    ref_out, my_out = str(tmp_path / "ref"), str(tmp_path / "mine")
+    subprocess.run([REF_BIN, "-t", "1"] + args + ["-o", ref_out], check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([_driver()] + args + ["-o", my_out], check=True)
+    for suffix in ("_raw.out", "_assembled_reads.fa", "_final.out"):
+        assert filecmp.cmp(ref_out + suffix, my_out + suffix, shallow=False), (mode, suffix)
