@@ -141,6 +141,13 @@ int t4_add_query(t4_index *ix, int n, const char *bases, const int64_t *offsets,
                  const int32_t *strands, int skip_repeats, const double *factors, int max_per_read, int32_t *counts,
                  t4_overlap *ov, t4_overlap *ext, int32_t *ext_ret);
 
+/* AlignAlgo::IsMateOverlap (AlignAlgo.hpp:1027-1096; ProcessRead, main.cpp:292-330) for a batch of pairs: is a suffix of
+ * `first` a prefix of `second` at exactly one offset (length-dependent identity threshold, optional tandem-repeat veto)?
+ * Reads as concatenated ACGTN chars with n + 1 offsets each. out3[3*i..]: the function's return value (overlap size or
+ * -1), and its `offset` / `bestMatchCnt` outputs (those of the last passing offset; -1 when none passed). */
+int t4_mate_overlap(t4_ctx *ctx, int n, const int64_t *first_off, const char *first_chars, const int64_t *second_off,
+                    const char *second_chars, const int32_t *min_overlap, int check_tandem, int32_t *out3);
+
 /* ---- ordered contig builder (host-side commit logic + GPU queries) ----------------------------------
  * t4_assembler owns a mutable set of novel contigs (the reference's `SeqSet seqSet`, main.cpp:642) and exposes
  * the members stage 1 calls on it, with the same arguments and return values:

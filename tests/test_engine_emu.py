@@ -263,3 +263,51 @@ def check_equal_length_shortcut(eng, n_random):
 
 def test_affine_equal_length_shortcut(emu_engine):
     check_equal_length_shortcut(emu_engine, 3000)
+
+
+def mate_cases(seed, n):
+    """pairs with a true suffix/prefix overlap (with a few mismatches / N), unrelated pairs, tandem repeats, length extremes"""
+    rnd = random.Random(seed)
+    F, S, MO = [], [], []
+    for it in range(n):
+        kind = it % 6
+        L = rnd.randint(30, 150)
+        base = "".join(rnd.choice("ACGT") for _ in range(2 * L))
+        if kind in (0, 1, 2):
+            ov = rnd.randint(5, L)
+            f = base[:L]
+            s = list(base[L - ov: L - ov + rnd.randint(ov, L)])
+            for _ in range(rnd.choice([0, 0, 1, 2, 6])):
+                if s:
+                    s[rnd.randrange(min(len(s), ov))] = rnd.choice("ACGTN")
+            s = "".join(s)
+        elif kind == 3:
+            f, s = base[:L], "".join(rnd.choice("ACGT") for _ in range(rnd.randint(1, 150)))
+        elif kind == 4:
+            unit = "".join(rnd.choice("ACGT") for _ in range(rnd.randint(1, 5)))
+            f = base[: L // 2] + unit * 12
+            s = unit * rnd.randint(3, 20)
+        else:
+            f, s = base[: rnd.randint(1, 40)], base[: rnd.randint(1, 40)]
+        F.append(f); S.append(s)
+        MO.append(min(31, (len(f) + len(s)) // rnd.choice([10, 20])))
+    return F, S, MO
+
+
+def check_mate_overlap(eng, seed, n):
+    o = Oracle(9)
+    F, S, MO = mate_cases(seed, n)
+    for tandem in (0, 1):
+        got = eng.mate_overlap(F, S, MO, bool(tandem))
+        n_pos = 0
+        for i in range(n):
+            ret, off, best = o.is_mate_overlap(F[i], S[i], MO[i], tandem)
+            assert got[i, 0] == ret, (i, tandem, F[i], S[i], MO[i], got[i].tolist(), (ret, off, best))
+            if ret >= 0:
+                n_pos += 1
+                assert (got[i, 1], got[i, 2]) == (off, best), (i, got[i].tolist(), (ret, off, best))
+        assert n_pos > n // 8
+
+
+def test_mate_overlap_vs_oracle(emu_engine):
+    check_mate_overlap(emu_engine, 3, 400)

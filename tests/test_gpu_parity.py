@@ -127,3 +127,8 @@ def test_add_path_matches_reference(eng, tmp_path, seed, n_pairs, n_clones):
     records equal the unmodified reference SeqSet driven with the same calls."""
     from test_assembler_emu import run_case
     run_case(eng, tmp_path, seed, n_pairs, n_clones)
+
+
+def test_mate_overlap_vs_oracle(eng):
+    from test_engine_emu import check_mate_overlap
+    check_mate_overlap(eng, 3, 20000)

@@ -49,6 +49,7 @@ def _load():
         "t4_hits": (I, [P, P, I, I, P, P, L]), "t4_overlaps": (I, [P, P, I, I, I, P, P]),
         "t4_annotate_rough": (I, [P, P, P]),
         "t4_gap_dp": (I, [P, I, I, I, P, P, P, P, P]),
+        "t4_mate_overlap": (I, [P, I, P, P, P, P, P, I, P]),
         "t4_extend": (I, [P, P, I, P, P, C.c_double, P, P]), "t4_assign": (I, [P, P, I, P, P]),
         "t4_assembler_create": (I, [P, I, I, C.POINTER(P)]), "t4_assembler_destroy": (None, [P]),
         "t4_assembler_set_params": (I, [P, I, I, C.c_double]),
@@ -113,6 +114,20 @@ class Engine:
         out = np.zeros((n, 4), dtype=np.int32)
         self.check(self.lib.t4_gap_dp(self.h, kind, impl, n, toff.ctypes.data_as(C.c_void_p), poff.ctypes.data_as(C.c_void_p),
                                       tbuf.ctypes.data_as(C.c_void_p), pbuf.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def mate_overlap(self, firsts, seconds, min_overlaps, check_tandem=False):
+        """-> int32 [n, 3]: IsMateOverlap return value, offset, bestMatchCnt"""
+        n = len(firsts)
+        foff = np.zeros(n + 1, dtype=np.int64); soff = np.zeros(n + 1, dtype=np.int64)
+        foff[1:] = np.cumsum([len(x) for x in firsts]); soff[1:] = np.cumsum([len(x) for x in seconds])
+        fb = np.frombuffer(("".join(firsts) + "\0").encode(), dtype=np.uint8)
+        sb = np.frombuffer(("".join(seconds) + "\0").encode(), dtype=np.uint8)
+        mo = np.ascontiguousarray(min_overlaps, dtype=np.int32)
+        out = np.zeros((n, 3), dtype=np.int32)
+        V = C.c_void_p
+        self.check(self.lib.t4_mate_overlap(self.h, n, foff.ctypes.data_as(V), fb.ctypes.data_as(V), soff.ctypes.data_as(V), sb.ctypes.data_as(V),
+                                            mo.ctypes.data_as(V), 1 if check_tandem else 0, out.ctypes.data_as(V)))
         return out
 
     def index(self, k, consider_barcode=False):

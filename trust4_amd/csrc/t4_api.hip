@@ -781,6 +781,34 @@ int t4_gap_dp(t4_ctx *c, int kind, int impl, int n, const int64_t *t_off, const 
 }
 
 
+int t4_mate_overlap(t4_ctx *c, int n, const int64_t *f_off, const char *f_chars, const int64_t *s_off, const char *s_chars,
+                    const int32_t *min_overlap, int check_tandem, int32_t *out3) {
+  if (!c || n < 0 || (n > 0 && (!f_off || !f_chars || !s_off || !s_chars || !min_overlap || !out3))) return T4_ERR_ARG;
+  if (n == 0) return T4_OK;
+  (void)hipSetDevice(c->device);
+  int r;
+  long long *dF = nullptr, *dS = nullptr;
+  char *dFc = nullptr, *dSc = nullptr;
+  int *dMo = nullptr, *dOut = nullptr;
+  const size_t fn = (size_t)f_off[n], sn = (size_t)s_off[n];
+  if ((r = devAlloc(c, &dF, (size_t)n + 1)) || (r = devAlloc(c, &dS, (size_t)n + 1)) || (r = devAlloc(c, &dFc, fn + 16)) ||
+      (r = devAlloc(c, &dSc, sn + 16)) || (r = devAlloc(c, &dMo, (size_t)n)) || (r = devAlloc(c, &dOut, (size_t)n * 3))) return r;
+  HIPCHK(c, hipMemcpy(dF, f_off, sizeof(long long) * ((size_t)n + 1), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(dS, s_off, sizeof(long long) * ((size_t)n + 1), hipMemcpyHostToDevice));
+  if (fn) HIPCHK(c, hipMemcpy(dFc, f_chars, fn, hipMemcpyHostToDevice));
+  if (sn) HIPCHK(c, hipMemcpy(dSc, s_chars, sn, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(dMo, min_overlap, sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+  int grid = n < c->cus * 32 ? n : c->cus * 32;
+  hipLaunchKernelGGL(t4k::mateOverlapKernel, dim3(grid), dim3(64), 0, c->stream, n, dF, dFc, dS, dSc, dMo, check_tandem ? 1 : 0, dOut);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(out3, dOut, sizeof(int) * (size_t)n * 3, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  void *ptrs[] = {dF, dS, dFc, dSc, dMo, dOut};
+  for (void *q : ptrs) if (q) (void)hipFree(q);
+  for (int i = 0; i < n; ++i) if (out3[3 * i] == -2) return fail(c, T4_ERR_UNSUPPORTED, "pair %d has a read longer than %d bp", i, T4_MAXL);
+  return T4_OK;
+}
+
 int t4_assign(t4_index *ix, t4_batch *b, int strand, int32_t *ret, t4_overlap *out) {
   if (!ix || !b) return T4_ERR_ARG;
   t4_ctx *c = ix->ctx;

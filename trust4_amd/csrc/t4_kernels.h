@@ -2366,6 +2366,58 @@ __global__ __launch_bounds__(64) void hitsKernel(T4IndexView ix, T4BatchView bv,
 }
 
 
+// AlignAlgo::IsMateOverlap (AlignAlgo.hpp:1027-1096) for a batch of pairs, one pair per wavefront: does a suffix of `fr`
+// match a prefix of `sr` at exactly one offset? Offset j passes iff the mismatches over the compared stretch stay within
+// (flen - j) - int((flen - j) * thr(flen - j)) -- the reference's running test `matchCnt + rest < need` is monotone in the
+// mismatch count, so it equals the test on the total. Lanes take the offsets; the reference keeps the LAST passing offset.
+// out: 3 ints per pair (return value: overlap size or -1, offset, bestMatchCnt; the latter two are the reference's outputs
+// whenever at least one offset passed, else -1).
+__global__ __launch_bounds__(64) void mateOverlapKernel(int n, const long long *fOff, const char *fChars, const long long *sOff,
+                                                      const char *sChars, const int *minOverlap, int checkTandem, int *out) {
+  __shared__ char s_f[T4_MAXL + 8], s_s[T4_MAXL + 8];
+  const int lane = laneId();
+  for (int p = blockIdx.x; p < n; p += gridDim.x) {
+    const int flen = (int)(fOff[p + 1] - fOff[p]), slen = (int)(sOff[p + 1] - sOff[p]), mo = minOverlap[p];
+    if (flen > T4_MAXL || slen > T4_MAXL) { if (lane == 0) { out[3 * p] = -2; out[3 * p + 1] = -1; out[3 * p + 2] = -1; } continue; }
+    for (int i = lane; i < flen; i += 64) s_f[i] = fChars[fOff[p] + i];
+    for (int i = lane; i < slen; i += 64) s_s[i] = sChars[sOff[p] + i];
+    __syncthreads();
+    int cnt = 0, lastJ = -1, lastMatch = -1, lastSize = -1;
+    for (int j = lane; j < flen - mo; j += 64) {
+      const int rem = flen - j;
+      double thr = 0.95;
+      if (rem >= 100) thr = 0.85; else if (rem >= 50) thr = 0.85 + (rem - 50) / 50.0 * 0.1;
+      const int need = (int)(rem * thr), kEnd = rem < slen ? rem : slen;
+      int match = 0;
+      for (int k = 0; k < kEnd; ++k) match += s_f[j + k] == s_s[k] ? 1 : 0;
+      // the reference stops at the first k with match(0..k) + (rem - k - 1) < need, i.e. as soon as mismatches exceed rem - need
+      if (kEnd - match <= rem - need) { ++cnt; lastJ = j; lastMatch = match; lastSize = kEnd; }
+    }
+    const int total = waveSum(cnt);
+    // the last passing offset = the largest j: lanes hold increasing j's in their own stride, so take the maximum
+    int best = lastJ;
+    for (int o = 32; o > 0; o >>= 1) { int v = __shfl_xor(best, o); if (v > best) best = v; }
+    const int src = __ffsll((long long)__ballot(lastJ == best && best >= 0)) - 1;
+    const int bMatch = __shfl(lastMatch, src < 0 ? 0 : src), bSize = __shfl(lastSize, src < 0 ? 0 : src);
+    if (lane == 0) {
+      int ret = -1;
+      if (total == 1) {
+        ret = bSize;
+        if (checkTandem && bSize <= mo * 2) {
+          for (int i = 1; i <= bSize / 2 && ret >= 0; ++i) {
+            bool tandem = true;
+            for (int j = i; j + i - 1 < bSize && tandem; j += i)
+              for (int k = j; k <= j + i - 1; ++k) if (s_s[k - j] != s_s[k]) { tandem = false; break; }
+            if (tandem) ret = -1;
+          }
+        }
+      }
+      out[3 * p] = ret; out[3 * p + 1] = total > 0 ? best : -1; out[3 * p + 2] = total > 0 ? bMatch : -1;
+    }
+    __syncthreads();
+  }
+}
+
 // t4_gap_dp: a batch of independent gap alignments, one per lane. kind 0: AlignAlgo::GlobalAlignment on
 // chars, kind 1: GlobalAlignment_PosWeight on weights. impl 0: forward LDS version with scratch fallback
 // (what overlap scoring uses), impl 1: scratch + traceback version only. out: 3 ints per problem.
