@@ -269,7 +269,8 @@ struct t4_assembler : InsertHook {
     ++w.c[base]; ++sum;
     for (int x = 0; x < 4; ++x) after |= (sum < 3 * w.c[x]) ? (1u << x) : 0u;
     if (before == after) return;   // cannot be observed by a query: the image stays as it is
-    if ((owner || priv) && !dirty && slot >= 0) {   // the resident image only needs this byte
+    static const bool noPatch = getenv("T4_NO_PATCH") != nullptr;   // debugging aid
+    if (!noPatch && (owner || priv) && !dirty && slot >= 0) {   // the resident image only needs this byte
       invalidateFor(seqIdx);
       patches.push_back(PwPatch{seqIdx, (int)(&w - seqs[seqIdx].pw.data()), (unsigned char)after});
       return;
@@ -782,7 +783,7 @@ int t4_assembler::refreshPrivate() {
   int r;
   if (!priv) {
     if ((r = t4_cellstore_create(ctx, k, &priv))) return r;
-    t4_cellstore_set_big_first(priv, 1);
+    t4_cellstore_set_big_first(priv, getenv("T4_SMALL_FIRST") ? 0 : 1);
     dirty = true;
   }
   if ((r = t4_cellstore_set_params(priv, hitLenRequired, radius, novelSim))) return r;
