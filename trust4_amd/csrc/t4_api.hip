@@ -1009,7 +1009,7 @@ struct t4_cellstore {
   t4_ctx *ctx = nullptr;
   int k = 9, hitLenRequired = 31, radius = 10, nomatchGapLimit = 0;
   double novelSim = 0.9;
-  struct Slot { unsigned char *base = nullptr; size_t cap = 0; bool live = false; };
+  struct Slot { unsigned char *base = nullptr; size_t cap = 0; bool live = false; bool pending = false; };
   std::vector<Slot> slots;
   std::vector<int> freeIds;
   std::vector<unsigned char *> chunks;
@@ -1096,6 +1096,7 @@ int cellFlush(t4_cellstore *cs) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   cs->bytesStaged += (int64_t)cs->stUsed;
   cs->descs.clear(); cs->stUsed = 0;
+  for (t4_cellstore::Slot &sl : cs->slots) sl.pending = false;
   return cellFlushPatches(cs);
 }
 }  // namespace
@@ -1207,6 +1208,9 @@ int t4_cellstore_stage(t4_cellstore *cs, int slot, int barcode, int nseq, const 
   {
     std::lock_guard<std::mutex> lock(cs->mu);
     t4_cellstore::Slot &sl = cs->slots[slot];
+    // two images of one slot in the same flush would be scattered concurrently: the caller must launch (flush) in between
+    if (sl.pending) return fail(c, T4_ERR_STATE, "slot %d already has an image staged for the next launch", slot);
+    sl.pending = true;
     if (blobBytes > sl.cap) {
       if (sl.base) cs->freeBySize[sl.cap].push_back(sl.base);
       size_t cap = (size_t)64 << 10;

@@ -778,6 +778,8 @@ t4_cellstore *t4_assembler::storeOf() { return owner ? owner->store : priv; }
 // stand-alone set: bring the private image up to date (full image after a structural change, byte patches after flips)
 int t4_assembler::refreshPrivate() {
   if (!dirty && patches.empty()) return T4_OK;
+  if (index.total == 0) return T4_OK;   // nothing will be launched against an empty set (prefetch): stay dirty, stage later --
+                                        // an image staged now would still be pending when the next one is staged for the same slot
   auto t0_ = std::chrono::steady_clock::now();
   struct Tm { double &acc; std::chrono::steady_clock::time_point t0; ~Tm() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tm_{secRefresh, t0_};
   int r;
