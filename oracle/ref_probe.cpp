@@ -206,6 +206,13 @@ int ref_repeat_add_read(void *h, const char *read) {
   free(r);
   return ret;
 }
+// SeqSet::HasHitInSet (SeqSet.hpp:3144-3327): the stage-0 candidate test of FastqExtractor.cpp:129-134
+int ref_has_hit_in_set(void *h, const char *read, int mode) {
+  char *r = strdup(read);
+  int ret = ((SeqSet *)h)->HasHitInSet(r, mode);
+  free(r);
+  return ret;
+}
 void ref_update_all_consensus(void *h) { ((SeqSet *)h)->UpdateAllConsensus(); }
 // barcode mode (main.cpp:1549-1559, 1846-1859, 1968-1969)
 void ref_set_consider_barcode(void *h, int on) { ((SeqSet *)h)->SetConsiderBarcodeInIndexHash(on != 0); }

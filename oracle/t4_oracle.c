@@ -781,6 +781,75 @@ int t4o_is_mate_overlap(const char *fr, int flen, const char *sr, int slen, int 
   return overlapSize;
 }
 
+/* SeqSet::HasHitInSet (SeqSet.hpp:3144-3327): hits bucketed by (strand, sequence) in emission order, the bucket with the most
+ * distinct read offsets per strand, GetOverlapsFromHits (filter 1) on the chosen bucket(s). Returns -1 / 0 / 1. */
+int t4o_has_hit_in_set(t4o_set *s, const char *read, int mode) {
+  int len = (int)strlen(read), i, j, k;
+  if (len < s->k) return 0;
+  char *rc = (char *)malloc(len + 1);
+  hitvec hits = {0, 0, 0};
+  get_hits(s, read, rc, len, 0, -1, 0, &hits);
+  free(rc);
+  if (hits.n == 0) { free(hits.h); return 0; }
+  const int seqCnt = s->nseq;
+  /* bucket sort, stable: order[] lists the hits of bucket (tag, idx) consecutively */
+  int *cnt = (int *)calloc((size_t)2 * seqCnt + 1, sizeof(int));
+  for (i = 0; i < hits.n; ++i) ++cnt[(hits.h[i].strand == 1 ? seqCnt : 0) + hits.h[i].idx + 1];
+  for (i = 0; i < 2 * seqCnt; ++i) cnt[i + 1] += cnt[i];
+  hit_t *bk = (hit_t *)malloc(sizeof(hit_t) * hits.n);
+  int *fill = (int *)malloc(sizeof(int) * 2 * seqCnt);
+  memcpy(fill, cnt, sizeof(int) * 2 * seqCnt);
+  for (i = 0; i < hits.n; ++i) bk[fill[(hits.h[i].strand == 1 ? seqCnt : 0) + hits.h[i].idx]++] = hits.h[i];
+  int max[2] = {-1, -1}, maxSeqIdx[2] = {-1, -1}, maxTag = -1;
+  for (k = 0; k <= 1; ++k)
+    for (i = 0; i < seqCnt; ++i) {
+      const hit_t *b = bk + cnt[k * seqCnt + i];
+      int size = cnt[k * seqCnt + i + 1] - cnt[k * seqCnt + i], readHitCount = 1;
+      for (j = 1; j < size; ++j) if (b[j].readOffset != b[j - 1].readOffset) ++readHitCount;
+      if (size > 0 && readHitCount > max[k]) { maxSeqIdx[k] = i; max[k] = readHitCount; }
+    }
+  ovvec ov = {0, 0, 0};
+  const int K = s->k, hlr = s->hitLenRequired;
+  const int both = (max[0] + K - 1 >= hlr && max[1] + K - 1 >= hlr);
+  if (mode == 1 && both) {
+    maxTag = 1;
+    int maxMatchCnt = 0;
+    for (k = 0; k <= 1; ++k)
+      for (i = 0; i < seqCnt; ++i) {
+        const hit_t *b = bk + cnt[k * seqCnt + i];
+        int size = cnt[k * seqCnt + i + 1] - cnt[k * seqCnt + i], readHitCount = 1, l;
+        for (j = 1; j < size; ++j) if (b[j].readOffset != b[j - 1].readOffset) ++readHitCount;
+        if (readHitCount + K - 1 < hlr) continue;
+        ovvec tmp = {0, 0, 0};
+        overlaps_from_hits(s, b, size, hlr, 1, &tmp);
+        int taken = 0;
+        for (l = 0; l < tmp.n; ++l)
+          if (tmp.o[l].matchCnt > maxMatchCnt) {
+            ov_clear(&ov); free(ov.o);
+            ov = tmp; maxMatchCnt = ov.o[l].matchCnt; maxTag = ov.o[l].strand == 1 ? 1 : 0; taken = 1;
+            break;
+          }
+        if (!taken) { ov_clear(&tmp); free(tmp.o); }
+      }
+  } else if (both) {
+    ovvec t0 = {0, 0, 0}, t1 = {0, 0, 0};
+    overlaps_from_hits(s, bk + cnt[maxSeqIdx[0]], cnt[maxSeqIdx[0] + 1] - cnt[maxSeqIdx[0]], hlr, 1, &t0);
+    overlaps_from_hits(s, bk + cnt[seqCnt + maxSeqIdx[1]], cnt[seqCnt + maxSeqIdx[1] + 1] - cnt[seqCnt + maxSeqIdx[1]], hlr, 1, &t1);
+    if (t0.n > 0 && t1.n > 0) maxTag = t0.o[0].matchCnt >= t1.o[0].matchCnt ? 0 : 1;
+    else if (t0.n > 0) maxTag = 0;
+    else maxTag = 1;
+    if (maxTag == 0) { ov = t0; ov_clear(&t1); free(t1.o); } else { ov = t1; ov_clear(&t0); free(t0.o); }
+  } else {
+    maxTag = max[1] >= max[0] ? 1 : 0;
+    int at = maxTag * seqCnt + maxSeqIdx[maxTag];
+    overlaps_from_hits(s, bk + cnt[at], cnt[at + 1] - cnt[at], hlr, 1, &ov);
+  }
+  int n = ov.n;
+  ov_clear(&ov); free(ov.o); free(cnt); free(fill); free(bk); free(hits.h);
+  if (n == 0) return 0;
+  return maxTag == 0 ? -1 : 1;
+}
+
 /* SeqSet.hpp:570-587 */
 static void align_stats(const signed char *align, int update, int *m, int *mm, int *indel) {
   if (!update) *m = *mm = *indel = 0;

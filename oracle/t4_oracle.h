@@ -47,6 +47,7 @@ int t4o_assign_read(t4o_set *s, const char *read, int strand, int barcode, t4o_o
 int t4o_global_alignment(const char *t, int lent, const char *p, int lenp, signed char *align);
 int t4o_global_alignment_posweight(const int *w, int lent, const char *p, int lenp,
                                    signed char *align);
+int t4o_has_hit_in_set(t4o_set *s, const char *read, int mode);   /* SeqSet::HasHitInSet (SeqSet.hpp:3144-3327) */
 int t4o_is_mate_overlap(const char *fr, int flen, const char *sr, int slen, int minOverlap,
                         int *offset, int *bestMatchCnt, int checkTandem);
 int t4o_lis(const int *pairs, int n, int *out);

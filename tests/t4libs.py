@@ -121,6 +121,9 @@ class _SetAPI:
             out.append(v)
         return sc, out
 
+    def has_hit_in_set(self, read, mode=0):
+        return self._hashit(self.h, _b(read), mode)
+
     def is_mate_overlap(self, fr, sr, min_overlap, check_tandem=1):
         fr, sr = _b(fr), _b(sr)
         off, bm = C.c_int(-1), C.c_int(-1)
@@ -139,6 +142,7 @@ class _SetAPI:
         self._ga = self._f("global_alignment", I, C.c_char_p, I, C.c_char_p, I, C.POINTER(C.c_byte))
         self._gapw = self._f("global_alignment_posweight", I, IP, I, C.c_char_p, I, C.POINTER(C.c_byte))
         self._mate = self._f("is_mate_overlap", I, C.c_char_p, I, C.c_char_p, I, I, IP, IP, I)
+        self._hashit = self._f("has_hit_in_set", I, P, C.c_char_p, I)
 
 
 class Oracle(_SetAPI):

@@ -215,3 +215,29 @@ def test_novel_set_queries(k):
                 assert o.extend_overlap(rr, f, ov) == r.extend_overlap(rr, f, ov)
                 n_ext += 1
     assert n_ext > 50
+
+
+def has_hit_reads(seed):
+    """stage-0 style input: receptor reads, mutated ones, short ones, random genomic-like reads, chimeras of two genes on
+    opposite strands (the ambiguous-strand branch of HasHitInSet)"""
+    rnd = random.Random(seed)
+    reads = _reads(seed, 120)
+    rc = lambda s: s[::-1].translate(str.maketrans("ACGTN", "TGCAN"))
+    base = rows_to_strs(Synth(300, seed + 7).next_reads(60))
+    reads += [base[2 * i][:75] + rc(base[2 * i + 1])[:75] for i in range(30)]          # plus-strand half + minus-strand half
+    reads += ["".join(rnd.choice("ACGT") for _ in range(rnd.randint(20, 150))) for _ in range(80)]
+    reads += [x[rnd.randint(0, 100):][: rnd.randint(9, 60)] for x in base]
+    return reads
+
+
+@pytest.mark.parametrize("hit_len", [17, 27, 31])
+def test_has_hit_in_set(hit_len):
+    o, r = Oracle(9, REF_FA, hit_len), Ref(9, REF_FA, hit_len)
+    reads = has_hit_reads(5)
+    seen = {0: 0, 1: 0, -1: 0}
+    for mode in (0, 1):
+        for rd in reads:
+            a, b = o.has_hit_in_set(rd, mode), r.has_hit_in_set(rd, mode)
+            assert a == b, (mode, rd, a, b)
+            seen[a] += 1
+    assert seen[1] > 50 and seen[-1] > 50 and seen[0] > 50

@@ -223,7 +223,7 @@ const char *t4_last_error(t4_ctx *c) { return c ? c->err.c_str() : "null ctx"; }
 int t4_device_cus(t4_ctx *c) { return c ? c->cus : 0; }
 #ifdef T4_PHASE_TIMING
 // development aid: cycles spent per kernel phase (summed over workgroups) since the last call
-int t4_debug_phase_cycles(unsigned long long *out16) {
+int t4_debug_phase_cycles(unsigned long long *out16) {   // T4_NPHASE entries
   unsigned long long zero[T4_NPHASE] = {0};
   if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(t4k::g_phaseCycles), sizeof(zero)) != hipSuccess) return T4_ERR_HIP;
   if (hipMemcpyToSymbol(HIP_SYMBOL(t4k::g_phaseCycles), zero, sizeof(zero)) != hipSuccess) return T4_ERR_HIP;

@@ -646,7 +646,7 @@ __device__ __forceinline__ bool ovLess(const OvRec &a, const OvRec &b, bool scor
 // ------------------------------------------------------------------------------------------------
 // optional per-phase cycle accounting (build with -DT4_PHASE_TIMING; read back through T4Work.phase)
 #ifdef T4_PHASE_TIMING
-#define T4_NPHASE 16
+#define T4_NPHASE 20
 __device__ unsigned long long g_phaseCycles[T4_NPHASE];
 __device__ unsigned long long g_dbgCount[8];   // 0 jobs, 1 pending (banded) jobs, 2 wave-DP steps, 3 scratch fallbacks, 4 fallback cells, 5 fallback cycles
 #define DBG_ADD(i, v) do { atomicAdd(&g_dbgCount[i], (unsigned long long)(v)); } while (0)
@@ -2062,7 +2062,9 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
     __syncthreads();
     for (int i = lane; i < n; i += NT) { storeOverlap(qa.out + r * qa.maxPerRead + i, wm.fin[i]); wm.ord[i] = (unsigned short)i; }
     __syncthreads();
+    PHASE_MARK(ws, 16);
     extendOverlaps(ix, wm, ws, n, len, false, qa.factorPerRead[r], sides, dirbuf, res);
+    PHASE_MARK(ws, 17);
     for (int i = lane; i < n; i += NT) {
       const OvRec &o = wm.fin[i];
       T4OverlapOut t;
