@@ -141,6 +141,11 @@ int t4_add_query(t4_index *ix, int n, const char *bases, const int64_t *offsets,
                  const int32_t *strands, int skip_repeats, const double *factors, int max_per_read, int32_t *counts,
                  t4_overlap *ov, t4_overlap *ext, int32_t *ext_ret);
 
+/* SeqSet::HasHitInSet(read, mode) (SeqSet.hpp:3144-3327), the candidate test of the stage-0 extractors
+ * (FastqExtractor.cpp:129-134 calls it with mode 0 on reads that pass its IsLowComplexity): out[i] = -1 / 0 / 1
+ * (hit on the minus strand / no hit / hit on the plus strand). Uses the set's hit_len_required. Only mode 0 is built. */
+int t4_has_hit(t4_index *ref, t4_batch *b, int mode, int32_t *out);
+
 /* AlignAlgo::IsMateOverlap (AlignAlgo.hpp:1027-1096; ProcessRead, main.cpp:292-330) for a batch of pairs: is a suffix of
  * `first` a prefix of `second` at exactly one offset (length-dependent identity threshold, optional tandem-repeat veto)?
  * Reads as concatenated ACGTN chars with n + 1 offsets each. out3[3*i..]: the function's return value (overlap size or

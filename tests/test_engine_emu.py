@@ -311,3 +311,20 @@ def check_mate_overlap(eng, seed, n):
 
 def test_mate_overlap_vs_oracle(emu_engine):
     check_mate_overlap(emu_engine, 3, 400)
+
+
+def check_has_hit(eng, seed, hit_lens=(17, 27)):
+    from test_oracle_vs_ref import has_hit_reads
+    reads = [r for r in has_hit_reads(seed) if set(r) <= set("ACGTN")]
+    for hl in hit_lens:
+        o = Oracle(9, REF_FA, hl)
+        ix = eng.index(9).set_params(hl, 10, 0.9).load_ref_fasta(REF_FA).commit()
+        got = ix.has_hit(eng.upload(reads))
+        exp = [o.has_hit_in_set(r, 0) for r in reads]
+        bad = [i for i in range(len(reads)) if got[i] != exp[i]]
+        assert not bad, (hl, len(bad), [(reads[i], int(got[i]), exp[i]) for i in bad[:3]])
+        assert sum(1 for e in exp if e == 1) > 20 and sum(1 for e in exp if e == -1) > 20 and sum(1 for e in exp if e == 0) > 20
+
+
+def test_has_hit_vs_oracle(emu_engine):
+    check_has_hit(emu_engine, 5, hit_lens=(17,))

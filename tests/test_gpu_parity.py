@@ -132,3 +132,9 @@ def test_add_path_matches_reference(eng, tmp_path, seed, n_pairs, n_clones):
 def test_mate_overlap_vs_oracle(eng):
     from test_engine_emu import check_mate_overlap
     check_mate_overlap(eng, 3, 20000)
+
+
+def test_has_hit_vs_oracle(eng):
+    from test_engine_emu import check_has_hit
+    check_has_hit(eng, 5)
+    check_has_hit(eng, 9, hit_lens=(31,))

@@ -49,7 +49,7 @@ def _load():
         "t4_hits": (I, [P, P, I, I, P, P, L]), "t4_overlaps": (I, [P, P, I, I, I, P, P]),
         "t4_annotate_rough": (I, [P, P, P]),
         "t4_gap_dp": (I, [P, I, I, I, P, P, P, P, P]),
-        "t4_mate_overlap": (I, [P, I, P, P, P, P, P, I, P]),
+        "t4_mate_overlap": (I, [P, I, P, P, P, P, P, I, P]), "t4_has_hit": (I, [P, P, I, P]),
         "t4_extend": (I, [P, P, I, P, P, C.c_double, P, P]), "t4_assign": (I, [P, P, I, P, P]),
         "t4_assembler_create": (I, [P, I, I, C.POINTER(P)]), "t4_assembler_destroy": (None, [P]),
         "t4_assembler_set_params": (I, [P, I, I, C.c_double]),
@@ -359,6 +359,12 @@ class Index:
         self.eng.check(self.eng.lib.t4_assign(self.h, batch.h, strand, ret.ctypes.data_as(C.c_void_p),
                                               out.ctypes.data_as(C.c_void_p) if fetch else None))
         return ret, out
+
+    def has_hit(self, batch, mode=0):
+        """SeqSet::HasHitInSet per read -> int32 [n] of -1 / 0 / 1"""
+        out = np.zeros(batch.n, dtype=np.int32)
+        self.eng.check(self.eng.lib.t4_has_hit(self.h, batch.h, mode, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def annotate_rough(self, batch, fetch=True):
         out = np.zeros((batch.n, 4), dtype=OV_DTYPE) if fetch else None

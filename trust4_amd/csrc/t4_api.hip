@@ -565,7 +565,8 @@ namespace {
 template <int CAP, int MAXOV, int NT>
 void launchTier(int grid, hipStream_t st, const T4IndexView &iv, const T4BatchView &bv, const T4Work &wk, const T4QueryArgs &qa) {
   if (qa.views) hipLaunchKernelGGL((t4k::queryKernel<CAP, MAXOV, NT, 2>), dim3(grid), dim3(NT), 0, st, iv, bv, wk, qa);
-  else if (qa.mode >= 2) hipLaunchKernelGGL((t4k::queryKernel<CAP, MAXOV, NT, 1>), dim3(grid), dim3(NT), 0, st, iv, bv, wk, qa);
+  else if (qa.mode == 5) hipLaunchKernelGGL((t4k::queryKernel<CAP, MAXOV, NT, 3>), dim3(grid), dim3(NT), 0, st, iv, bv, wk, qa);
+  else if (qa.mode >= 2 && qa.mode <= 4) hipLaunchKernelGGL((t4k::queryKernel<CAP, MAXOV, NT, 1>), dim3(grid), dim3(NT), 0, st, iv, bv, wk, qa);
   else hipLaunchKernelGGL((t4k::queryKernel<CAP, MAXOV, NT, 0>), dim3(grid), dim3(NT), 0, st, iv, bv, wk, qa);
 }
 
@@ -806,6 +807,23 @@ int t4_mate_overlap(t4_ctx *c, int n, const int64_t *f_off, const char *f_chars,
   void *ptrs[] = {dF, dS, dFc, dSc, dMo, dOut};
   for (void *q : ptrs) if (q) (void)hipFree(q);
   for (int i = 0; i < n; ++i) if (out3[3 * i] == -2) return fail(c, T4_ERR_UNSUPPORTED, "pair %d has a read longer than %d bp", i, T4_MAXL);
+  return T4_OK;
+}
+
+int t4_has_hit(t4_index *ref, t4_batch *b, int mode, int32_t *out) {
+  if (!ref || !b || !out) return T4_ERR_ARG;
+  t4_ctx *c = ref->ctx;
+  if (mode != 0) return fail(c, T4_ERR_UNSUPPORTED, "t4_has_hit: only mode 0 (the stage-0 extractor's) is built");
+  int r;
+  if ((r = ensurePerCall(c, b->n))) return r;
+  T4QueryArgs qa;
+  memset(&qa, 0, sizeof qa);
+  qa.mode = 5; qa.ret = c->counts;
+  if ((r = runQuery(ref, b, qa, false))) return r;
+  if (b->n > 0) {
+    HIPCHK(c, hipMemcpyAsync(out, c->counts, sizeof(int) * (size_t)b->n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   return T4_OK;
 }
 

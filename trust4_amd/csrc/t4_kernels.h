@@ -675,6 +675,7 @@ struct WaveState { // wave-uniform scalars kept in LDS
   int novelMin[2];
   int red[16];
   short contigA[64], contigB[64];
+  unsigned hhBest[2];        // HasHitInSet: per strand, (distinct read offsets << 16) | (0xFFFF - bucket rank) of the best bucket
   long long phaseT0; int curPhase;
 };
 
@@ -2149,6 +2150,89 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
         qa.ret[r * qa.maxPerRead + i] = res[i].ret;
       }
     }
+  } else if (VARIANT == 3 && qa.mode == 5) {
+    // SeqSet::HasHitInSet(read, 0) (SeqSet.hpp:3144-3327), the stage-0 candidate test (FastqExtractor.cpp:129-134):
+    // hits -> buckets per (strand, sequence) -> the bucket with the most distinct read offsets per strand ->
+    // GetOverlapsFromHits (filter 1) on the chosen bucket(s). The sorted keys hold every bucket as one contiguous range.
+    int result = 0;
+    if (len >= ix.k) {
+      loadSegment(bv, r, 0, len, wm);
+      unsigned *posStart = (unsigned *)wm.ov, *posPref = wm.pairs;
+      const int nk = len - ix.k + 1;
+      int H = seedPositions(ix, wm, len, 0, -1, false, posStart, posPref, ws->red);
+      if (H > wm.cap) return false;
+      hitTotal += (unsigned long long)H;
+      if (H > 0) {
+        expandHits(ix, wm, nk, H, -1, false, posStart, posPref, ws->red);
+        __syncthreads();
+        if (H > 1) bitonicSort(wm.keys, H);
+        __syncthreads();
+        // bucket starts (compacted into wm.pairs) and, one lane per bucket, the number of distinct read offsets
+        unsigned *starts = wm.pairs;
+        int nB = 0;
+        if (lane == 0) { ws->hhBest[0] = 0; ws->hhBest[1] = 0; }
+        for (int i0 = 0; i0 < H; i0 += NT) {
+          const int i = i0 + lane;
+          const bool st = i < H && (i == 0 || KEY_G(wm.keys[i]) != KEY_G(wm.keys[i - 1]));
+          int tot;
+          const int inc = blockInclScan(st ? 1 : 0, ws->red, tot);
+          if (st) starts[nB + inc - 1] = (unsigned)i;
+          nB += tot;
+        }
+        __syncthreads();
+        for (int b = lane; b < nB; b += NT) {
+          const int s0 = (int)starts[b], e0 = b + 1 < nB ? (int)starts[b + 1] : H;
+          unsigned m[(T4_MAXL + 31) / 32];
+          for (int w = 0; w < (T4_MAXL + 31) / 32; ++w) m[w] = 0;
+          for (int t = s0; t < e0; ++t) {
+            const unsigned long long kt = wm.keys[t];
+            const int a = KEY_C(kt) - T4_C_BIAS + KEY_B(kt);
+            for (int w = 0; w < (T4_MAXL + 31) / 32; ++w) if (w == (a >> 5)) m[w] |= 1u << (a & 31);
+          }
+          int distinct = 0;
+          for (int w = 0; w < (T4_MAXL + 31) / 32; ++w) distinct += __popc(m[w]);
+          atomicMax(&ws->hhBest[KEY_PLUS(wm.keys[s0])], ((unsigned)distinct << 16) | (unsigned)(0xFFFF - b));
+        }
+        __syncthreads();
+        const unsigned best0 = ws->hhBest[0], best1 = ws->hhBest[1];
+        const int max0 = best0 ? (int)(best0 >> 16) : -1, max1 = best1 ? (int)(best1 >> 16) : -1;
+        const bool both = max0 + ix.k - 1 >= ix.hitLenRequired && max1 + ix.k - 1 >= ix.hitLenRequired;
+        int nOv[2] = {0, 0}, firstMatch[2] = {0, 0};
+        const int single = max1 >= max0 ? 1 : 0;
+        // bounds of the chosen buckets, read before the bucket list (wm.pairs) is reused by overlapsFromKeys
+        int bs[2] = {0, 0}, be[2] = {0, 0};
+        for (int tag = 0; tag <= 1; ++tag) {
+          const unsigned best = tag ? best1 : best0;
+          if (!best) continue;
+          const int b = 0xFFFF - (int)(best & 0xFFFF);
+          bs[tag] = (int)starts[b]; be[tag] = b + 1 < nB ? (int)starts[b + 1] : H;
+        }
+        for (int tag = 0; tag <= 1; ++tag) {
+          if (!both && tag != single) continue;
+          if (be[tag] == bs[tag]) continue;
+          __syncthreads();
+          if (lane == 0) ws->ovCount = 0;
+          __syncthreads();
+          WaveMem wb = wm;
+          wb.keys = wm.keys + bs[tag];
+          overlapsFromKeys(ix, wb, ws, be[tag] - bs[tag], ix.hitLenRequired, 1);
+          __syncthreads();
+          if (ws->overflow) return false;
+          const int n = ws->ovCount < wm.maxOv ? ws->ovCount : wm.maxOv;
+          int firstPos = 0x7FFFFFFF, fm = 0;       // the reference's tmpOverlaps[0]: the run lowest in diagonal order
+          for (int i = 0; i < n; ++i) if (wm.ov[i].chainPos < firstPos) { firstPos = wm.ov[i].chainPos; fm = wm.ov[i].matchCnt; }
+          nOv[tag] = n; firstMatch[tag] = fm;
+        }
+        int maxTag;
+        if (both) {
+          if (nOv[0] > 0 && nOv[1] > 0) maxTag = firstMatch[0] >= firstMatch[1] ? 0 : 1;
+          else if (nOv[0] > 0) maxTag = 0;
+          else maxTag = 1;
+        } else maxTag = single;
+        result = nOv[maxTag] == 0 ? 0 : (maxTag == 0 ? -1 : 1);
+      }
+    }
+    if (lane == 0) qa.ret[r] = result;
   } else if (VARIANT == 0 && qa.mode == 0) {
     int barcode = bv.barcode ? bv.barcode[r] : -1;
     loadSegment(bv, r, 0, len, wm);
@@ -2217,7 +2301,8 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
 }
 
 // The query kernel. CAP > 0: LDS tier; CAP == 0: global-scratch tier. Persistent grid, one wave/block.
-// VARIANT 0 / 1: see processRead; VARIANT 2: mode 4 with every read matched against its own per-barcode image
+// VARIANT 0 / 1: see processRead; VARIANT 3: HasHitInSet (mode 5) alone, so that its bucket bit masks cost the annotation
+// kernels no registers; VARIANT 2: mode 4 with every read matched against its own per-barcode image
 // (qa.views[qa.viewOf[read]]).
 template <int CAP, int MAXOV, int NTHREADS, int VARIANT>
 __global__ __launch_bounds__(NTHREADS)
@@ -2255,7 +2340,7 @@ void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
   for (int w = blockIdx.x; w < wk.nList; w += gridDim.x) {
     long long r = wk.list[w];
     if (VARIANT == 2) ix = qa.views[qa.viewOf[r]];   // uniform address: scalar loads
-    bool done = processRead<(VARIANT == 0 ? 0 : 1)>(ix, bv, wk, qa, wm, &s_ws, r, sc);
+    bool done = processRead<(VARIANT == 0 ? 0 : VARIANT == 3 ? 3 : 1)>(ix, bv, wk, qa, wm, &s_ws, r, sc);
     if (!done && tid() == 0) {
       if (wk.nextList) { int slot = atomicAdd(wk.nextCount, 1); wk.nextList[slot] = (int)r; }
       else wk.status[r] = 2;
