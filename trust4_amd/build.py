@@ -7,7 +7,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "t4_api.hip")
 SRC_HOST = os.path.join(HERE, "csrc", "t4_assembler.cpp")
 OUT = os.path.join(HERE, "libt4hip.so")
-DEPS = [SRC, SRC_HOST, os.path.join(HERE, "host", "trust4_main.cpp"), os.path.join(HERE, "csrc", "t4_kernels.h"), os.path.join(HERE, "csrc", "t4_device.h"),
+DEPS = [SRC, SRC_HOST, os.path.join(HERE, "host", "trust4_main.cpp"), os.path.join(HERE, "host", "fastq_extractor_main.cpp"),
+        os.path.join(HERE, "host", "seq_reader.h"), os.path.join(HERE, "csrc", "t4_internal.h"),
+        os.path.join(HERE, "csrc", "t4_kernels.h"), os.path.join(HERE, "csrc", "t4_device.h"),
         os.path.join(os.path.dirname(HERE), "include", "trust4_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
@@ -25,15 +27,18 @@ def build(force=False, verbose=False):
 
 
 def build_driver(verbose=False):
-    """trust4_amd/bin/trust4-hip: the stage-1 driver with the reference's trust4 command line, linked against libt4hip.so."""
-    src = os.path.join(HERE, "host", "trust4_main.cpp")
+    """trust4_amd/bin/trust4-hip (stage 1, the reference's trust4 command line) and trust4_amd/bin/fastq-extractor-hip (stage-0
+    candidate filter, the reference's fastq-extractor for plain reads), linked against libt4hip.so."""
     out_dir = os.path.join(HERE, "bin")
     os.makedirs(out_dir, exist_ok=True)
-    out = os.path.join(out_dir, "trust4-hip")
-    cmd = ["g++", "-O2", "-std=c++17", "-o", out, src, "-L" + HERE, "-lt4hip", "-Wl,-rpath," + HERE, "-Wl,-rpath,$ORIGIN/..", "-lz", "-lpthread"]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    out = None
+    for name, src in (("fastq-extractor-hip", "fastq_extractor_main.cpp"), ("trust4-hip", "trust4_main.cpp")):
+        out = os.path.join(out_dir, name)
+        cmd = ["g++", "-O2", "-std=c++17", "-o", out, os.path.join(HERE, "host", src), "-L" + HERE, "-lt4hip", "-Wl,-rpath," + HERE,
+               "-Wl,-rpath,$ORIGIN/..", "-lz", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
     return out
 
 

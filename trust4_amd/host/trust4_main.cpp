@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "../../include/trust4_hip.h"
+#include "seq_reader.h"
 
 namespace {
 
@@ -78,62 +79,6 @@ void revCompInPlace(std::string &s) {
   std::reverse(s.begin(), s.end());
   for (char &c : s) if (c != 'N') { int n = nucNum(c); c = n >= 0 ? NUM2NUC[3 - n] : 'N'; }
 }
-
-// ---- FASTA / FASTQ (optionally gzip) reader with kseq's record model ---------------------------------
-struct SeqReader {
-  std::vector<std::string> files;
-  size_t cur = 0;
-  gzFile fp = nullptr;
-  std::string pending;   // look-ahead line
-  bool havePending = false;
-  std::string id, seq, qual;
-  bool hasQual = false;
-  bool getLine(std::string &out) {
-    if (havePending) { out.swap(pending); havePending = false; return true; }
-    out.clear();
-    char buf[1 << 16];
-    bool any = false;
-    while (gzgets(fp, buf, sizeof buf)) {
-      any = true;
-      size_t l = strlen(buf);
-      bool eol = l > 0 && buf[l - 1] == '\n';
-      while (l > 0 && (buf[l - 1] == '\n' || buf[l - 1] == '\r')) buf[--l] = 0;
-      out.append(buf, l);
-      if (eol) break;
-    }
-    return any;
-  }
-  bool next() {
-    for (;;) {
-      if (!fp) {
-        if (cur >= files.size()) return false;
-        fp = gzopen(files[cur].c_str(), "rb");
-        if (!fp) { fprintf(stderr, "Could not open %s\n", files[cur].c_str()); exit(EXIT_FAILURE); }
-      }
-      std::string line;
-      bool got = false;
-      while (getLine(line)) if (!line.empty() && (line[0] == '>' || line[0] == '@')) { got = true; break; }
-      if (!got) { gzclose(fp); fp = nullptr; ++cur; havePending = false; continue; }
-      size_t e = 1;
-      while (e < line.size() && line[e] != ' ' && line[e] != '\t') ++e;
-      id.assign(line, 1, e - 1);
-      size_t n = id.size();   // ReadFiles.hpp:180-185
-      if (n >= 2 && (id[n - 1] == '1' || id[n - 1] == '2') && id[n - 2] == '/') id.resize(n - 2);
-      seq.clear(); qual.clear(); hasQual = false;
-      bool plus = false;
-      while (getLine(line)) {
-        if (!line.empty() && (line[0] == '>' || line[0] == '@')) { pending.swap(line); havePending = true; break; }
-        if (!line.empty() && line[0] == '+') { plus = true; break; }
-        for (char c : line) if (c > ' ' && c < 127) seq.push_back(c);
-      }
-      if (plus) {
-        hasQual = true;
-        while (qual.size() < seq.size() && getLine(line)) qual += line;
-      }
-      return true;
-    }
-  }
-};
 
 // ---- AlignAlgo::IsMateOverlap (AlignAlgo.hpp:1027-1096) ---------------------------------------------
 int isMateOverlap(const std::string &fr, const std::string &sr, int minOverlap, int &offset, int &bestMatchCnt, bool checkTandem) {
