@@ -105,6 +105,50 @@ def stage1_e2e(pairs, cells):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def stage0_e2e(pairs, receptor_fraction=0.02):
+    """Stage-0 candidate filter (fastq-extractor-hip) vs oracle/_ref/fastq-extractor (when it travelled) on the same FASTQ files."""
+    import filecmp
+    import gzip
+    import shutil
+    import subprocess
+    import tempfile
+    import t4libs
+    tmp = tempfile.mkdtemp()
+    try:
+        fa = os.path.join(tmp, "ref.fa")
+        with gzip.open(t4libs.REF_FA, "rb") as f, open(fa, "wb") as g:
+            shutil.copyfileobj(f, g)
+        nrec = int(pairs * receptor_fraction)
+        r1, r2 = t4libs.Synth(2000, 1).next_pairs(nrec)
+        rnd = np.random.RandomState(5)
+        acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+        gens = [acgt[rnd.randint(0, 4, size=(pairs - nrec, 150))] for _ in range(2)]
+        order = rnd.permutation(pairs)
+        for name, rec, gen in (("in_1.fq", r1, gens[0]), ("in_2.fq", r2, gens[1])):
+            rows = [bytes(x[:150]) for x in rec] + [x.tobytes() for x in gen]
+            with open(os.path.join(tmp, name), "wb") as f:
+                q = b"F" * 150
+                for i in order:
+                    f.write(b"@q%d\n%s\n+\n%s\n" % (i, rows[i], q))
+        argv = ["-f", fa, "-1", os.path.join(tmp, "in_1.fq"), "-2", os.path.join(tmp, "in_2.fq")]
+        t0 = time.perf_counter()
+        subprocess.run([os.path.join(ROOT, "trust4_amd", "bin", "fastq-extractor-hip")] + argv + ["-o", os.path.join(tmp, "mine")], check=True, stderr=subprocess.DEVNULL)
+        t_mine = time.perf_counter() - t0
+        out = {"workload": "%d synthetic 150 bp PE pairs, %.0f %% receptor pairs in random pairs; FASTQ in -> candidate _1.fq/_2.fq out" % (pairs, 100 * receptor_fraction),
+               "pairs_per_s": pairs / t_mine, "seconds": t_mine, "host_threads": 1}
+        ref_bin = os.path.join(ROOT, "oracle", "_ref", "fastq-extractor")
+        if os.path.exists(ref_bin):
+            cores = min(8, os.cpu_count() or 1)
+            t0 = time.perf_counter()
+            subprocess.run([ref_bin, "-t", str(cores)] + argv + ["-o", os.path.join(tmp, "ref")], check=True, stderr=subprocess.DEVNULL)
+            t_ref = time.perf_counter() - t0
+            out.update({"reference_pairs_per_s": pairs / t_ref, "reference_seconds": t_ref, "reference_threads": cores,
+                        "identical": all(filecmp.cmp(os.path.join(tmp, "ref" + x), os.path.join(tmp, "mine" + x), shallow=False) for x in ("_1.fq", "_2.fq"))})
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,6 +242,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(reads, args.cpu_sample)
         if args.e2e_pairs > 0 and world == 1:
             out["stage1_e2e"] = stage1_e2e(args.e2e_pairs, max(1, args.e2e_pairs // 100))
+            out["stage0_e2e"] = stage0_e2e(4 * args.e2e_pairs)
         print(json.dumps(out))
     if dist:
         dist.barrier()
