@@ -1972,36 +1972,60 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
     sides[q] = e;
   }
   __syncthreads();
-  // E2: gapped sides, one at a time on wavefront 0
-  if (lane < 64) {
-    for (int q = 0; q < 2 * n; ++q) {
-      if (!sides[q].pending) continue;           // wave-uniform
-      const OvRec &o = wm.fin[wm.ord[q >> 1]];
-      const int side = q & 1, size = sides[q].size;
-      const T4SeqInfo si = ix.seqs[o.seqIdx];
-      const char *r = (useFirstStrand ? plus0 : (o.flags & OV_PLUS)) ? wm.seg : wm.rc;
-      const int t0 = side == 0 ? o.ss - size : o.se + 1, p0 = side == 0 ? o.rs - size : o.re + 1;
-      dpWaveTracePW(ix.pw + si.pwOff + t0, size, r + p0, dirbuf);
-      if (lane == 0) {
-        signed char *align = (signed char *)(dirbuf + (size + 1) * 11);
-        int alen = tracebackPW(dirbuf, size, align);
-        int m = 0, mm = 0, ind = 0, good = 0, tmp = 0;
-        for (int k = 0; k < alen; ++k) { if (align[k] == 0) ++m; else if (align[k] == 1) ++mm; else ++ind; }
-        if (side == 0) {
-          for (int i = alen - 1, k = 1; i >= 0; --i, ++k) {
-            if (align[i] == 0) { ++tmp; if (tmp > 0.75 * k) good = k; }
-            else if (align[i] != 1) break;
+  // E2: gapped sides: compacted into a list (wm.cand is dead here), one wavefront per side with its own slice of the
+  // direction buffer; a side whose traceback does not fit a slice waits for the serial pass that owns the whole buffer
+  int nPendSides = 0;
+  for (int q0 = 0; q0 < 2 * n; q0 += NT) {
+    const int q = q0 + lane;
+    const bool pend = q < 2 * n && sides[q].pending;
+    int tot;
+    const int inc = blockInclScan(pend ? 1 : 0, ws->red, tot);
+    if (pend) wm.cand[nPendSides + inc - 1] = (unsigned)q;
+    nPendSides += tot;
+  }
+  __syncthreads();
+  {
+    const int wave = lane >> 6, nw = NT >> 6, wl = lane & 63;
+    const int slice = ((wm.cap * 8) / nw) & ~15;
+    for (int pass = 0; pass < 2; ++pass) {
+      // pass 0: every wavefront takes sides that fit its slice; pass 1: wavefront 0 takes the rest with the whole buffer
+      unsigned char *buf = pass == 0 ? dirbuf + wave * slice : dirbuf;
+      const int room = pass == 0 ? slice : wm.cap * 8;
+      for (int t = pass == 0 ? wave : 0; t < nPendSides; t += pass == 0 ? nw : 1) {
+        if (pass == 1 && wave != 0) break;
+        const int q = (int)wm.cand[t];
+        const int size = sides[q].size;
+        const bool fits = (size + 1) * 11 + 2 * size + 8 <= slice;
+        if ((pass == 0) != fits) continue;       // wave-uniform
+        if ((size + 1) * 11 + 2 * size + 8 > room) { if (wl == 0) ws->unsupported = 1; continue; }
+        const OvRec &o = wm.fin[wm.ord[q >> 1]];
+        const int side = q & 1;
+        const T4SeqInfo si = ix.seqs[o.seqIdx];
+        const char *r = (useFirstStrand ? plus0 : (o.flags & OV_PLUS)) ? wm.seg : wm.rc;
+        const int t0 = side == 0 ? o.ss - size : o.se + 1, p0 = side == 0 ? o.rs - size : o.re + 1;
+        dpWaveTracePW(ix.pw + si.pwOff + t0, size, r + p0, buf);
+        if (wl == 0) {
+          signed char *align = (signed char *)(buf + (size + 1) * 11);
+          int alen = tracebackPW(buf, size, align);
+          int m = 0, mm = 0, ind = 0, good = 0, tmp = 0;
+          for (int k = 0; k < alen; ++k) { if (align[k] == 0) ++m; else if (align[k] == 1) ++mm; else ++ind; }
+          if (side == 0) {
+            for (int i = alen - 1, k = 1; i >= 0; --i, ++k) {
+              if (align[i] == 0) { ++tmp; if (tmp > 0.75 * k) good = k; }
+              else if (align[i] != 1) break;
+            }
+          } else {
+            for (int i = 0; i < alen; ++i) {
+              if (align[i] == 0) { ++tmp; if (tmp > 0.75 * (i + 1)) good = i + 1; }
+              else if (align[i] != 1) break;
+            }
           }
-        } else {
-          for (int i = 0; i < alen; ++i) {
-            if (align[i] == 0) { ++tmp; if (tmp > 0.75 * (i + 1)) good = i + 1; }
-            else if (align[i] != 1) break;
-          }
+          ExtSide e = sides[q];
+          e.match = (short)m; e.mis = (short)mm; e.indel = (short)ind; e.good = (short)good; e.pending = 0;
+          sides[q] = e;
         }
-        ExtSide e = sides[q];
-        e.match = (short)m; e.mis = (short)mm; e.indel = (short)ind; e.good = (short)good; e.pending = 0;
-        sides[q] = e;
       }
+      __syncthreads();
     }
   }
   __syncthreads();
