@@ -328,3 +328,75 @@ def check_has_hit(eng, seed, hit_lens=(17, 27)):
 
 def test_has_hit_vs_oracle(emu_engine):
     check_has_hit(emu_engine, 5, hit_lens=(17,))
+
+
+def check_novel_min_statistics(eng, seed=4, n_contigs=180, k=9):
+    """More than 100 novel groups of more than 3 hits on a strand: GetOverlapsFromHits raises its minimum run size from the
+    group statistics (SeqSet.hpp:784-821), including the `i = j; ++i` stepping that skips the first hit of every other group.
+    The set: many near-identical contigs plus one-k-mer decoys interleaved in the id order, so that one-hit groups sit between
+    the big ones."""
+    rnd = random.Random(seed)
+    core = "".join(rnd.choice("ACGT") for _ in range(260))
+    o = Oracle(k)
+    ix = eng.index(k)
+    for i in range(n_contigs):
+        s = list(core)
+        for _ in range(rnd.randint(0, 3)):
+            s[rnd.randrange(len(s))] = rnd.choice("ACGT")
+        s = "".join(s)
+        if i % 3 == 1:   # decoy: shares a single k-mer with the core
+            st = rnd.randint(0, 200)
+            s = "".join(rnd.choice("ACGT") for _ in range(60)) + core[st: st + k] + "".join(rnd.choice("ACGT") for _ in range(60))
+        w = np.zeros((len(s), 4), dtype=np.int32)
+        for j, ch in enumerate(s):
+            w[j, "ACGT".index(ch)] = rnd.randint(1, 9)
+        assert o.add_novel("c%d" % i, s, 1, -1, w) == ix.add_contig("c%d" % i, s, -1, w)
+    o.set_hit_len_required(17)
+    ix.set_params(17, 10, 0.9).commit()
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    reads = []
+    for _ in range(12):
+        st = rnd.randint(0, 150)
+        rd = core[st: st + rnd.randint(40, 110)]
+        reads.append(rd if rnd.random() < 0.5 else "".join(comp[x] for x in reversed(rd)))
+    b = eng.upload(reads)
+    cnt, ov = ix.overlaps(b, 0, 0, 128)
+    assert t4check.check_overlaps(cnt, ov, reads, o) == []
+    off, hits = ix.hits(b, 0, 0)
+    assert t4check.check_hits(off, hits, reads, o) == []
+    assert (np.diff(off) > 100 * 4 * 2).all() and (cnt > 0).all()   # > 100 groups of > 3 hits per read
+
+
+def test_novel_min_statistics(emu_engine):
+    check_novel_min_statistics(emu_engine)
+
+
+def test_group_stepping_closed_form():
+    """The kernel's closed form of the reference's `i = j; ++i` group walk (SeqSet.hpp:784-811): which groups are measured and
+    with which size, against a literal simulation of the loop, over random group layouts."""
+    def serial(sizes):
+        elems = [g for g, n in enumerate(sizes) for _ in range(n)]
+        out, i = [], 0
+        while i < len(elems):
+            j = i + 1
+            while j < len(elems) and elems[j] == elems[i]:
+                j += 1
+            out.append((elems[i], j - i))
+            i = j + 1
+        return out
+
+    def closed(sizes):
+        out = []
+        for t, n in enumerate(sizes):
+            skip = False
+            if t >= 1:
+                r = max(x for x in range(t) if x == 0 or sizes[x] >= 2)
+                skip = (t - r - 1) % 2 == 0
+            if n - skip > 0:
+                out.append((t, n - skip))
+        return out
+
+    rnd = random.Random(1)
+    for _ in range(5000):
+        sizes = [rnd.choice([1, 1, 1, 2, 3, 5]) for _ in range(rnd.randint(1, 14))]
+        assert serial(sizes) == closed(sizes), sizes

@@ -138,3 +138,9 @@ def test_has_hit_vs_oracle(eng):
     from test_engine_emu import check_has_hit
     check_has_hit(eng, 5)
     check_has_hit(eng, 9, hit_lens=(31,))
+
+
+def test_novel_min_statistics(eng):
+    from test_engine_emu import check_novel_min_statistics
+    check_novel_min_statistics(eng)
+    check_novel_min_statistics(eng, seed=8, n_contigs=260)

@@ -58,6 +58,19 @@ __device__ __forceinline__ int blockInclScan(int v, int *red, int &total) {
   total = tot;
   return inc + off;
 }
+// workgroup inclusive MAX scan; total = the maximum over the whole group. Two barriers.
+__device__ __forceinline__ int blockInclMaxScan(int v, int *red, int &total) {
+  const int lane = laneId();
+  for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(v, d); if (lane >= d && t > v) v = t; }
+  const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if (lane == 63) red[wave] = v;
+  __syncthreads();
+  int pre = -0x7FFFFFFF, tot = -0x7FFFFFFF;
+  for (int w = 0; w < nw; ++w) { int x = red[w]; if (w < wave && x > pre) pre = x; if (x > tot) tot = x; }
+  __syncthreads();
+  total = tot;
+  return pre > v ? pre : v;
+}
 __device__ __forceinline__ int blockSum(int v, int *red) {
   v = waveSum(v);
   int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
@@ -675,6 +688,7 @@ struct WaveState { // wave-uniform scalars kept in LDS
   int novelMin[2];
   int red[16];
   short contigA[64], contigB[64];
+  int nvPossible[2], nvLongest[2];   // novel group statistics of GetOverlapsFromHits (filter 1)
   unsigned hhBest[2];        // HasHitInSet: per strand, (distinct read offsets << 16) | (0xFFFF - bucket rank) of the best bucket
   long long phaseT0; int curPhase;
 };
@@ -938,30 +952,57 @@ __device__ void chainRun(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int 
 // impossible while H <= 65535 only if ... it is handled by the caller refusing such reads (status).
 __device__ void overlapsFromKeys(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int Hv, int hitLenRequired, int filter) {
   const int lane = tid(), NT = nthr(), K = ix.k;
-  if (lane == 0) {
-    ws->novelMin[0] = ws->novelMin[1] = 3;
-    ws->candCount = 0;
-    if (filter == 1 && ix.hasNovel) {
-      // group statistics with the reference's `i = j` + `++i` stepping (SeqSet.hpp:784-811)
-      int possible[2] = {0, 0}, longest[2] = {0, 0};
-      for (int i = 0; i < Hv; ++i) {
-        unsigned g = KEY_G(wm.keys[i]);
-        int j;
-        for (j = i + 1; j < Hv; ++j) if (KEY_G(wm.keys[j]) != g) break;
-        int plus = KEY_PLUS(wm.keys[i]);
-        if (!seqIsRef(ix, KEY_IDX(wm.keys[i]))) {
-          if (j - i > 3) ++possible[plus];
-          if (j - i > longest[plus]) longest[plus] = j - i;
-        }
-        i = j;
+  if (lane == 0) { ws->novelMin[0] = ws->novelMin[1] = 3; ws->candCount = 0; ws->nvPossible[0] = ws->nvPossible[1] = 0; ws->nvLongest[0] = ws->nvLongest[1] = 0; }
+  if (filter == 1 && ix.hasNovel) {
+    // Group statistics of the novel sequences (SeqSet.hpp:784-811). The reference walks the groups with `i = j` followed
+    // by the loop's `++i`, i.e. it skips the first hit of the group that follows a measured one (a one-hit group vanishes,
+    // and the group after it is measured in full). With n_t the true group sizes: skip_0 = false, skip_(t+1) = !(skip_t &&
+    // n_t == 1), which unrolls to skip_t = (t - r - 1 is even) for r = the last index < t that is 0 or has n_r >= 2.
+    // So: groups by scan/compaction, r by a max-scan, one lane per group.
+    unsigned *gs = wm.pairs;   // dead until R1
+    int nG = 0;
+    for (int i0 = 0; i0 < Hv; i0 += NT) {
+      const int i = i0 + lane;
+      const bool st = i < Hv && (i == 0 || KEY_G(wm.keys[i]) != KEY_G(wm.keys[i - 1]));
+      int tot;
+      const int inc = blockInclScan(st ? 1 : 0, ws->red, tot);
+      if (st) gs[nG + inc - 1] = (unsigned)i;
+      nG += tot;
+    }
+    __syncthreads();
+    int carry = -1;
+    for (int t0 = 0; t0 < nG; t0 += NT) {
+      const int t = t0 + lane;
+      int u = -1, nT = 0, s0 = 0;
+      if (t < nG) {
+        s0 = (int)gs[t];
+        nT = (t + 1 < nG ? (int)gs[t + 1] : Hv) - s0;
+        if (t >= 1) { const int nPrev = s0 - (int)gs[t - 1]; if (t - 1 == 0 || nPrev >= 2) u = t - 1; }
       }
-      for (int t = 0; t <= 1; ++t) {
-        if (possible[t] > 100000) ws->novelMin[t] = (int)(longest[t] * 0.75);
-        else if (possible[t] > 10000) ws->novelMin[t] = longest[t] / 2;
-        else if (possible[t] > 1000) ws->novelMin[t] = longest[t] / 3;
-        else if (possible[t] > 100) ws->novelMin[t] = longest[t] / 4;
+      int tot;
+      int r = blockInclMaxScan(u, ws->red, tot);
+      if (carry > r) r = carry;
+      if (tot > carry) carry = tot;
+      if (t < nG) {
+        const bool skip = t >= 1 && (((t - r - 1) & 1) == 0);
+        const int m = nT - (skip ? 1 : 0);
+        const unsigned long long k0 = wm.keys[s0];
+        if (m > 0 && !seqIsRef(ix, KEY_IDX(k0))) {
+          const int plus = KEY_PLUS(k0);
+          if (m > 3) atomicAdd(&ws->nvPossible[plus], 1);
+          atomicMax(&ws->nvLongest[plus], m);
+        }
       }
     }
+    __syncthreads();
+    if (lane == 0)
+      for (int t = 0; t <= 1; ++t) {
+        const int possible = ws->nvPossible[t], longest = ws->nvLongest[t];
+        if (possible > 100000) ws->novelMin[t] = (int)(longest * 0.75);
+        else if (possible > 10000) ws->novelMin[t] = longest / 2;
+        else if (possible > 1000) ws->novelMin[t] = longest / 3;
+        else if (possible > 100) ws->novelMin[t] = longest / 4;
+      }
   }
   __syncthreads();
   PHASE_MARK(ws, 5);
