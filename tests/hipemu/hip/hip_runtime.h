@@ -116,6 +116,7 @@ static inline unsigned long long __ballot(int pred) {
 }
 static inline int __any(int p) { return __ballot(p) != 0; }
 static inline int __all(int p) { return __ballot(!p) == 0; }
+static inline unsigned long long __brevll(unsigned long long x) { unsigned long long r = 0; for (int i = 0; i < 64; ++i) if (x >> i & 1) r |= 1ull << (63 - i); return r; }
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }

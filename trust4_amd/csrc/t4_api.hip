@@ -534,7 +534,8 @@ int t4_reads_upload(t4_ctx *c, const char *bases, const int64_t *offsets, const 
     }
   }
   int r;
-  if ((r = devAlloc(c, &b->dPk, pk.size())) || (r = devAlloc(c, &b->dNm, nm.size())) || (r = devAlloc(c, &b->dLen, len.size()))) { t4_batch_destroy(b); return r; }
+  // + 4 words: the packed k-mer extraction reads one word past a read's row (masked out), also for the last read
+  if ((r = devAlloc(c, &b->dPk, pk.size() + 4)) || (r = devAlloc(c, &b->dNm, nm.size() + 4)) || (r = devAlloc(c, &b->dLen, len.size()))) { t4_batch_destroy(b); return r; }
   if (n > 0) {
     HIPCHK(c, hipMemcpy(b->dPk, pk.data(), sizeof(unsigned) * pk.size(), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(b->dNm, nm.data(), sizeof(unsigned) * nm.size(), hipMemcpyHostToDevice));

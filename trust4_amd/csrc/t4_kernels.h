@@ -723,6 +723,31 @@ __device__ __forceinline__ unsigned long long kmerAt(const char *S, int p, int K
   return code;
 }
 
+// The same code from the read's 2-bit packed words (K <= 16): position p of the forward segment, or of its reverse
+// complement (rc == true). The words hold base j at bits 2j (little-endian digits); the index wants the first base in the
+// most significant digit, so the forward code is the digit reversal of the extracted window, while the reverse-complement
+// code is the window itself with every digit complemented (its digits already come in reverse order). N is packed as 0,
+// which is also what nuc2('N') gives; its complement must stay 0.
+__device__ __forceinline__ unsigned long long kmerPacked(const WaveMem &wm, bool rc, int p, int segLen, int K, bool &valid) {
+  const int g = wm.segAbs + (rc ? segLen - K - p : p);
+  const int w = g >> 4, sh = (g & 15) * 2;
+  const unsigned long long win = ((unsigned long long)wm.pkRow[w] | ((unsigned long long)wm.pkRow[w + 1] << 32)) >> sh;
+  const int wn = g >> 5;
+  const unsigned nwin = (unsigned)((((unsigned long long)wm.nmRow[wn] | ((unsigned long long)wm.nmRow[wn + 1] << 32)) >> (g & 31)) & ((1ull << K) - 1ull));
+  valid = nwin == 0;
+  const unsigned long long m2 = (1ull << (2 * K)) - 1ull;
+  if (rc) {
+    unsigned long long nd = nwin;                       // N flags -> both bits of their digits
+    nd = (nd | (nd << 16)) & 0x0000FFFF0000FFFFull; nd = (nd | (nd << 8)) & 0x00FF00FF00FF00FFull;
+    nd = (nd | (nd << 4)) & 0x0F0F0F0F0F0F0F0Full; nd = (nd | (nd << 2)) & 0x3333333333333333ull;
+    nd = (nd | (nd << 1)) & 0x5555555555555555ull; nd |= nd << 1;
+    return (~win & m2) & ~nd;
+  }
+  unsigned long long r = __brevll(win & m2);            // bit reversal, then the two bits of every digit back in order
+  r = ((r & 0x5555555555555555ull) << 1) | ((r >> 1) & 0x5555555555555555ull);
+  return r >> (64 - 2 * K);
+}
+
 // Seed stage of one pass: fills posStart/posPref (aliased on wm.ov / wm.pairs) and returns the number
 // of hit records H that GetHitsFromRead would emit (before the barcode filter). Wave-uniform result.
 // vjOnly only changes the later expansion.
@@ -743,7 +768,7 @@ __device__ int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int
     const char *S = st ? wm.rc : wm.seg;
     unsigned start = 0, cnt = 0;
     bool valid;
-    const unsigned long long code = kmerAt(S, p, K, valid) & mask;
+    const unsigned long long code = (K <= 16 ? kmerPacked(wm, st != 0, p, segLen, K, valid) : kmerAt(S, p, K, valid)) & mask;
     if (active && valid) indexLookup(ix, code, barcode, start, cnt);
     bool same = false;
     if (p > 0) same = (((code >> 2) | ((unsigned long long)nuc2(S[p - 1]) << (2 * (K - 1)))) == code);
