@@ -400,3 +400,37 @@ def test_group_stepping_closed_form():
     for _ in range(5000):
         sizes = [rnd.choice([1, 1, 1, 2, 3, 5]) for _ in range(rnd.randint(1, 14))]
         assert serial(sizes) == closed(sizes), sizes
+
+
+def check_long_reads_and_limits(eng, n=40):
+    """reads up to the engine's maximum (T4_MAXL = 384 bp: merged mates reach ~290 bp in stage 1), ragged lengths in one batch,
+    and the loud failure one base beyond the limit"""
+    import trust4_amd
+    rnd = random.Random(12)
+    o = Oracle(9, REF_FA, 17)
+    ix = eng.index(9).set_params(17, 10, 0.9).load_ref_fasta(REF_FA).commit()
+    # long reads = stretches of reference genes (V ... C) glued with random linkers
+    names = [o.name(i) for i in range(o.size())]
+    seqs = [o.consensus(i) for i in range(o.size())]
+    reads = []
+    for _ in range(n):
+        parts = []
+        while sum(len(x) for x in parts) < 384:
+            s = seqs[rnd.randrange(len(seqs))]
+            st = rnd.randint(0, max(0, len(s) - 60))
+            parts.append(s[st: st + rnd.randint(40, 200)])
+            parts.append("".join(rnd.choice("ACGT") for _ in range(rnd.randint(0, 12))))
+        rd = "".join(parts).replace("N", "A")
+        reads.append(rd[: rnd.choice([384, 384, 383, 300, 257, 200])])
+    reads += ["ACGT", "", "A" * 384, reads[0][:9], reads[1][:8]]
+    ann = ix.annotate_rough(eng.upload(reads))
+    assert t4check.check_annotate(ann, reads, o) == []
+    assert (ann["seqIdx"][:, 0] != -1).sum() + (ann["seqIdx"][:, 2] != -1).sum() + (ann["seqIdx"][:, 3] != -1).sum() > n // 2
+    with pytest.raises(trust4_amd.T4Error):
+        eng.upload([("ACGT" * 97)[:385]])       # 385 bp
+    with pytest.raises(trust4_amd.T4Error):
+        eng.upload(["ACGTRYACGT" * 5])          # IUPAC letters are refused, not guessed
+
+
+def test_long_reads_and_limits(emu_engine):
+    check_long_reads_and_limits(emu_engine, n=12)

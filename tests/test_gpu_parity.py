@@ -144,3 +144,8 @@ def test_novel_min_statistics(eng):
     from test_engine_emu import check_novel_min_statistics
     check_novel_min_statistics(eng)
     check_novel_min_statistics(eng, seed=8, n_contigs=260)
+
+
+def test_long_reads_and_limits(eng):
+    from test_engine_emu import check_long_reads_and_limits
+    check_long_reads_and_limits(eng, n=400)
