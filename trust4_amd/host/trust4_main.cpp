@@ -240,7 +240,9 @@ bool isLowComplexity(const std::string &s) {   // main.cpp:183-205
 
 // ProcessRead (main.cpp:224-449): read-through clipping, mate merging, low-complexity filter; the 21-mer counting of the
 // surviving reads (same multiset of AddCount calls) is done afterwards over the whole read list
-void processRead(SortRead r1, SortRead r2, bool hasMate2, std::vector<SortRead> &out) {
+void processRead(const SortRead &in1, const SortRead &in2, bool hasMate2, std::vector<SortRead> &out) {
+  // private copies: every string this function frees was allocated by the calling thread (no cross-thread allocator traffic)
+  SortRead r1 = in1, r2 = in2;
   int rWeight = 1;
   bool r2Alive = hasMate2;
   if (hasMate2) {
@@ -397,11 +399,16 @@ int main(int argc, char *argv[]) {
   struct InPair { SortRead a, b; bool haveMate; };
   std::vector<InPair> block;
   const size_t BLOCK = 262144;
+  double secProcess = 0, secMerge = 0;
   auto flushBlock = [&]() {   // ProcessRead of every pair of the block on the host threads, results appended in input order
+    auto t0 = std::chrono::steady_clock::now();
     std::vector<std::vector<SortRead>> outs(block.size());
-    parallelFor((long long)block.size(), threadCnt, [&](long long i) { processRead(std::move(block[(size_t)i].a), std::move(block[(size_t)i].b), block[(size_t)i].haveMate, outs[(size_t)i]); });
+    parallelFor((long long)block.size(), threadCnt, [&](long long i) { processRead(block[(size_t)i].a, block[(size_t)i].b, block[(size_t)i].haveMate, outs[(size_t)i]); });
+    auto t1 = std::chrono::steady_clock::now();
     for (auto &v : outs) for (SortRead &r : v) sortedReads.push_back(std::move(r));
     block.clear();
+    secProcess += std::chrono::duration<double>(t1 - t0).count();
+    secMerge += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
   };
   int firstReadLen = -1, nIn = 0;
   std::unordered_map<std::string, int> barcodeStrToInt, umiStrToInt;
@@ -444,7 +451,7 @@ int main(int argc, char *argv[]) {
     if (block.size() >= BLOCK) flushBlock();
   }
   flushBlock();
-  if (getenv("T4_TIMING")) PrintLog("timing: input parsed and mates processed");
+  if (getenv("T4_TIMING")) PrintLog("timing: input parsed and mates processed (ProcessRead %.2f s on %d threads, merge %.2f s)", secProcess, threadCnt, secMerge);
   int readCnt = (int)sortedReads.size();
   int maxReadLen = 0;
   for (const SortRead &r : sortedReads) if ((int)r.read.size() > maxReadLen) maxReadLen = (int)r.read.size();
