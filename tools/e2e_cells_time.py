@@ -21,5 +21,5 @@ same = all(filecmp.cmp(os.path.join(tmp, "ref" + s), os.path.join(tmp, "mine" + 
 print("pairs %d cells %d: reference -t %s %.1f s (%.0f pairs/s) | trust4-hip %.1f s (%.0f pairs/s) | identical=%s | contigs %d" % (
     pairs, cells, threads, t_ref, pairs / t_ref, t_mine, pairs / t_mine, same, open(os.path.join(tmp, "ref_raw.out")).read().count(">")))
 print("--- reference log"); print("\n".join(pr.stderr.strip().split("\n")[-9:]))
-print("--- trust4-hip log"); print("\n".join(p.stderr.strip().split("\n")[-10:]))
+print("--- trust4-hip log"); print("\n".join([l for l in p.stderr.strip().split("\n") if "timing" in l or "Start" in l or "Found" in l] + p.stderr.strip().split("\n")[-10:]))
 shutil.rmtree(tmp, ignore_errors=True)
