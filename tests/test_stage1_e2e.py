@@ -91,13 +91,7 @@ def test_barcode_mode_matches_reference_binary(tmp_path, pairs, cells, seed, lan
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
 def test_barcode_mode_emulated(tmp_path):
     """the same driver source linked against the emulator build of the kernels (test infrastructure): tiny case for the CPU suite"""
-    import t4check
-    lib = t4check.build_emulator_lib()
-    exe = os.path.join(ROOT, "tests", "hipemu", "trust4-hip-emu")
-    src = os.path.join(ROOT, "trust4_amd", "host", "trust4_main.cpp")
-    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(lib)):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, src, "-L" + os.path.dirname(lib), "-lt4hip_emu",
-                        "-Wl,-rpath," + os.path.dirname(lib), "-lz", "-lpthread"], check=True)
+    exe = _emulated_driver()
     _barcode_case(tmp_path, exe, 160, 8, 6, {"T4_LANES": "8", "T4_WINDOW": "3", "T4_THREADS": "2"})
 
 
@@ -180,3 +174,75 @@ def test_edge_inputs_match_reference_binary(tmp_path, mode):
     subprocess.run([_driver()] + args + ["-o", my_out], check=True)
     for suffix in ("_raw.out", "_assembled_reads.fa", "_final.out"):
         assert filecmp.cmp(ref_out + suffix, my_out + suffix, shallow=False), (mode, suffix)
+
+
+def _emulated_driver():
+    """the driver source linked against the emulator build of the kernels (test infrastructure, CPU suite only)"""
+    import t4check
+    lib = t4check.build_emulator_lib()
+    exe = os.path.join(ROOT, "tests", "hipemu", "trust4-hip-emu")
+    src = os.path.join(ROOT, "trust4_amd", "host", "trust4_main.cpp")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(lib)):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, src, "-L" + os.path.dirname(lib), "-lt4hip_emu",
+                        "-Wl,-rpath," + os.path.dirname(lib), "-lz", "-lpthread"], check=True)
+    return exe
+
+
+def _kmer_count_file(path, reads, k=21):
+    """a k-mer counter's dump (">COUNT\\nKMER" records) as `-c` reads it: counts of the k-mers as written, singletons included
+    (both programs skip them), one k-mer listed twice (the later record wins)"""
+    from collections import Counter
+    cnt = Counter()
+    for r in reads:
+        for i in range(len(r) - k + 1):
+            cnt[r[i:i + k]] += 1
+    items = sorted(cnt.items())
+    with open(path, "w") as f:
+        for km, c in items:
+            f.write(">%d\n%s\n" % (c, km))
+        for km, c in items[:3]:
+            f.write(">%d\n%s\n" % (c + 5, km))
+
+
+def _driver_options_case(tmp_path, driver, pairs, clones, seed):
+    """-c (k-mer counts from a file), --debug-ns (contigs preloaded from a FASTA file) and `-o -PREFIX` (contig files on stdout)"""
+    fa = str(tmp_path / "ref.fa")
+    _gunzip(REF_FA, fa)
+    r1, r2 = Synth(clones, seed).next_pairs(pairs)
+    s1, s2 = rows_to_strs(r1), rows_to_strs(r2)
+    f1, f2 = str(tmp_path / "s_1.fq"), str(tmp_path / "s_2.fq")
+    _write_fastq(f1, s1)
+    _write_fastq(f2, s2)
+    cfile = str(tmp_path / "counts.fa")
+    _kmer_count_file(cfile, s1 + s2)
+    ns = str(tmp_path / "ns.fa")
+    with open(ns, "w") as f:
+        f.write(">IGHV_seed extra\n%s\n>other\n%s\n" % (s1[0][:120], s1[1][10:140]))
+    base = ["--skipMateExtension", "-f", fa, "-1", f1, "-2", f2]
+    for name, extra in (("c", ["-c", cfile]), ("ns", ["--debug-ns", ns]), ("k", ["-k", "11", "--debug-ns", ns, "-c", cfile])):
+        ref_out, my_out = str(tmp_path / ("ref_" + name)), str(tmp_path / ("mine_" + name))
+        subprocess.run([REF_BIN, "-t", "1"] + base + extra + ["-o", ref_out], check=True, stderr=subprocess.DEVNULL)
+        subprocess.run([driver] + base + extra + ["-o", my_out], check=True)
+        for suffix in ("_raw.out", "_assembled_reads.fa", "_final.out"):
+            assert filecmp.cmp(ref_out + suffix, my_out + suffix, shallow=False), (name, suffix)
+    # stdout mode: both contig files on stdout, the assembled reads still in a file named after the prefix
+    outs = []
+    for exe, sub in ((REF_BIN, "so_ref"), (driver, "so_mine")):
+        d = tmp_path / sub
+        d.mkdir()
+        p = subprocess.run([exe] + (["-t", "1"] if exe == REF_BIN else []) + base + ["-o", "-x"], check=True, cwd=str(d),
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        outs.append((p.stdout, open(str(d / "-x_assembled_reads.fa"), "rb").read(), sorted(os.listdir(str(d)))))
+    assert outs[0] == outs[1]
+    assert outs[0][0].count(b">") > 2
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
+def test_driver_options_emulated(tmp_path):
+    _driver_options_case(tmp_path, _emulated_driver(), 60, 4, 9)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not shipped")
+def test_driver_options_match_reference_binary(tmp_path):
+    _driver_options_case(tmp_path, _driver(), 1500, 50, 9)

@@ -24,6 +24,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -48,6 +49,7 @@ const char *USAGE =
     "\t-1 STRING -2 STRING: path to paried-end read files\n"
     "Optional:\n"
     "\t-o STRING: prefix of the output file (default: trust)\n"
+    "\t-c STRING: the path to the kmer count file\n"
     "\t-t INT: number of host threads (default: 1); used by the barcode-mode Add pass (cells are independent)\n"
     "\t-k INT: the starting k-mer size for indexing contigs (default: 9)\n"
     "\t--minHitLen INT: the minimal hit length for a valid overlap (default: auto)\n"
@@ -167,6 +169,24 @@ struct KmerCounter {
         eachValid(r, [&](uint64_t kc) { if (S == 1 || (long long)(mix(kc) % (uint64_t)S) == s) ++m[kc]; });
       }
     });
+  }
+  // KmerCount::AddCountFromFile (KmerCount.hpp:99-120): records ">COUNT\nKMER"; counts <= 1 are skipped, the k-mer is keyed by its
+  // code as written (not made canonical), a later record overwrites an earlier one
+  bool addCountFromFile(const char *file) {
+    FILE *fp = fopen(file, "r");
+    if (!fp) return false;
+    char tok[100];
+    const uint64_t mask = k < 32 ? ((1ull << (2 * k)) - 1ull) : ~0ull;
+    while (fscanf(fp, "%99s", tok) != EOF) {
+      const int c = atoi(tok + 1);
+      if (fscanf(fp, "%99s", tok) == EOF) break;
+      if (c <= 1) continue;
+      uint64_t code = 0;
+      for (int i = 0; tok[i]; ++i) code = ((code << 2) & mask) | (uint64_t)(tok[i] == 'N' ? 0 : (nucNum(tok[i]) & 3));
+      shards[shardOf(code)][code] = c;
+    }
+    fclose(fp);
+    return true;
   }
   int count(uint64_t kc) const { const auto &m = shards[shardOf(kc)]; auto it = m.find(kc); return it == m.end() ? 0 : it->second; }
   // GetCountStatsAndTrim (KmerCount.hpp:177-288); read/qual are trimmed in place. qual == nullptr: no trimming.
@@ -350,16 +370,18 @@ int main(int argc, char *argv[]) {
                                          {"minHitLen", required_argument, 0, 10006}, {"cgeneEnd", required_argument, 0, 10008},
                                          {"barcode", required_argument, 0, 10002}, {"UMI", required_argument, 0, 10004},
                                          {"keepNoBarcode", no_argument, 0, 10003}, {"contigMinCov", required_argument, 0, 10007},
-                                         {"cellShard", required_argument, 0, 10100},
+                                         {"cellShard", required_argument, 0, 10100}, {"debug-ns", required_argument, 0, 10000},
                                          {(char *)0, 0, 0, 0}};
   int indexKmerLength = 9, changeKmerLengthThreshold = 4096, trimLevel = 1, minHitLen = -1, constantGeneEnd = 200;
   int shardRank = 0, shardCount = 1, threadCnt = 1, contigMinCov = 0;
-  bool keepMissingBarcode = false;
-  std::string refFa, outputPrefix = "trust";
+  bool keepMissingBarcode = false, skipMateExtension = false;
+  std::string refFa, outputPrefix = "trust", kmerCountFile;
+  struct NovelFa { std::string file; int kmerLength; };
+  std::vector<NovelFa> novelFa;   // --debug-ns: contigs put into the set before any read (main.cpp:709-712)
   SeqReader reads, mateReads, barcodeFile, umiFile;
   bool hasMate = false, hasBarcode = false, hasUmi = false;
   int c, oi = 0;
-  while ((c = getopt_long(argc, argv, "f:u:1:2:o:t:k:", long_options, &oi)) != -1) {
+  while ((c = getopt_long(argc, argv, "f:u:1:2:o:c:t:k:", long_options, &oi)) != -1) {
     if (c == 'f') refFa = optarg;
     else if (c == 'u') reads.files.push_back(optarg);
     else if (c == '1') { reads.files.push_back(optarg); hasMate = true; }
@@ -367,8 +389,10 @@ int main(int argc, char *argv[]) {
     else if (c == 'o') outputPrefix = optarg;
     else if (c == 't') threadCnt = atoi(optarg) > 0 ? atoi(optarg) : 1;
     else if (c == 'k') indexKmerLength = atoi(optarg);
+    else if (c == 'c') kmerCountFile = optarg;
+    else if (c == 10000) novelFa.push_back(NovelFa{optarg, indexKmerLength});
     else if (c == 10001) trimLevel = atoi(optarg);
-    else if (c == 10005) { /* always */ }
+    else if (c == 10005) skipMateExtension = true;
     else if (c == 10006) minHitLen = atoi(optarg);
     else if (c == 10008) constantGeneEnd = atoi(optarg);
     else if (c == 10002) { barcodeFile.files.push_back(optarg); hasBarcode = true; }
@@ -456,6 +480,10 @@ int main(int argc, char *argv[]) {
   int maxReadLen = 0;
   for (const SortRead &r : sortedReads) if ((int)r.read.size() > maxReadLen) maxReadLen = (int)r.read.size();
   kmerCount.maxReadLen = maxReadLen;   // KmerCount::SetBuffer (main.cpp:979)
+  if (!kmerCountFile.empty()) {   // -c: counts come from a k-mer counter's dump instead (main.cpp:694-699)
+    if (!kmerCount.addCountFromFile(kmerCountFile.c_str())) { fprintf(stderr, "Could not open %s\n", kmerCountFile.c_str()); return EXIT_FAILURE; }
+    PrintLog("Read in the kmer count information from %s", kmerCountFile.c_str());
+  } else
   kmerCount.addCountAll((long long)sortedReads.size(), threadCnt, [&](long long i) -> const std::string & { return sortedReads[(size_t)i].read; });
   if (getenv("T4_TIMING")) PrintLog("timing: 21-mers counted");
   auto writeEmpty = [&](const char *suffix) { FILE *fp = fopen((outputPrefix + suffix).c_str(), "w"); if (fp) fclose(fp); };
@@ -626,6 +654,13 @@ int main(int argc, char *argv[]) {
   } else {
     if ((rc = t4_assembler_create(ctx, indexKmerLength, 0, &seqSet))) die(ctx, "t4_assembler_create", rc);
     t4_assembler_set_params(seqSet, hitLenRequired, 10, 0.9);
+  }
+  for (const NovelFa &nf : novelFa) {   // SeqSet::InputNovelFa (SeqSet.hpp:2986-2993): every record becomes a contig, strand 1, no barcode
+    if (useCells) { fprintf(stderr, "trust4-hip: --debug-ns is not supported together with --barcode (use --keepNoBarcode).\n"); return EXIT_FAILURE; }
+    SeqReader fa;
+    fa.files.push_back(nf.file);
+    while (fa.next())
+      if ((rc = t4_assembler_input_novel_read(seqSet, fa.id.c_str(), fa.seq.c_str(), 1, -1)) < 0) die(ctx, "t4_assembler_input_novel_read", rc);
   }
   if (trimLevel > 1) changeKmerLengthThreshold /= 2;
   std::vector<int> barcodeTotalReadCount(barcodeIntToStr.size(), 0), barcodeReadCount(barcodeIntToStr.size(), 0);
@@ -928,7 +963,24 @@ int main(int argc, char *argv[]) {
   if (contigMinCov > 0) {   // main.cpp:1952-1955
     if (useCells) t4_cellset_release_shallow_contigs(cellSet, contigMinCov); else t4_assembler_release_shallow_contigs(seqSet, contigMinCov);
   }
-  writeSet(outputPrefix + "_raw.out");
+  // a prefix starting with '-' sends the two contig files to stdout (main.cpp:1960-1966, 2021-2027)
+  const bool toStdout = !outputPrefix.empty() && outputPrefix[0] == '-';
+  auto writeSetOrStdout = [&](const std::string &path) {
+    if (!toStdout) { writeSet(path); return; }
+    char tmpl[] = "/tmp/trust4hip_XXXXXX";
+    int fd = mkstemp(tmpl);
+    if (fd < 0) { fprintf(stderr, "trust4-hip: cannot create a temporary file\n"); exit(EXIT_FAILURE); }
+    close(fd);
+    writeSet(tmpl);
+    FILE *fp = fopen(tmpl, "r");
+    char buf[65536];
+    size_t n;
+    while (fp && (n = fread(buf, 1, sizeof(buf), fp)) > 0) fwrite(buf, 1, n, stdout);
+    if (fp) fclose(fp);
+    fflush(stdout);
+    unlink(tmpl);
+  };
+  writeSetOrStdout(outputPrefix + "_raw.out");
   size_t nMainAssembled = assembledReadIdx.size();
   if (shardCount > 1) nMainAssembled -= (size_t)rescuedCnt;
   {
@@ -952,7 +1004,11 @@ int main(int argc, char *argv[]) {
     FILE *fp = fopen((outputPrefix + "_shard.meta").c_str(), "w");
     fprintf(fp, "shard %d %d\ncontig_slots %d\nreads %d\n", shardRank, shardCount, t4_cellset_size(cellSet), readCnt);
     fclose(fp);
-  } else writeSet(outputPrefix + "_final.out");
+  } else {
+    if (!skipMateExtension && hasMate && !hasBarcode)   // main.cpp:2018: the reference would now run its mate-pair extension
+      PrintLog("NOTE: the mate-pair extension of assemblies is not part of this build; _final.out is the raw assembly (what the reference writes under --skipMateExtension).");
+    writeSetOrStdout(outputPrefix + "_final.out");
+  }
   if (useCells) {
     int64_t qb = 0, rq = 0, im = 0, by = 0; double sq = 0, ss = 0;
     t4_cellset_counters(cellSet, &qb, &rq, &im, &by, &sq, &ss);
