@@ -2,8 +2,9 @@
 // `fastq-extractor` (FastqExtractor.cpp) with the candidate test SeqSet::HasHitInSet on the MI355X (t4_has_hit):
 //   good = (!IsLowComplexity(read1) && HasHitInSet(read1, 0)) || (mate && !IsLowComplexity(read2) && HasHitInSet(read2, 0))
 // (FastqExtractor.cpp:105-134, 516-519), hitLenRequired from the first 1000 reads (436-455), outputs
-// <prefix>_1.fq / <prefix>_2.fq or <prefix>.fq in input order (136-143, 470-480). Plain reads only in this round: the
-// barcode / UMI / readFormat options of the reference are refused, not ignored.
+// <prefix>_1.fq / <prefix>_2.fq or <prefix>.fq in input order (136-143, 470-480), and with --barcode / --UMI the
+// <prefix>_bc.fa / <prefix>_umi.fa records of the kept reads (OutputBarcode, 147-203) after --readFormat / range
+// extraction, whitelist correction and translation (host/read_format.h).
 #include <getopt.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -14,6 +15,7 @@
 
 #include "../../include/trust4_hip.h"
 #include "seq_reader.h"
+#include "read_format.h"
 
 namespace {
 inline int nucNum(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
@@ -28,7 +30,7 @@ bool isLowComplexity(const std::string &s) {   // FastqExtractor.cpp:105-127
   return low >= 2;
 }
 
-struct Rec { std::string id, seq, qual; bool hasQual; };
+struct Rec { std::string id, seq, qual, comment; bool hasQual; };
 
 void die(t4_ctx *ctx, const char *what, int rc) {
   fprintf(stderr, "%s failed (%d): %s\n", what, rc, ctx ? t4_last_error(ctx) : "");
@@ -37,13 +39,23 @@ void die(t4_ctx *ctx, const char *what, int rc) {
 }  // namespace
 
 int main(int argc, char *argv[]) {
-  static struct option long_options[] = {{"barcode", required_argument, 0, 10000}, {"UMI", required_argument, 0, 10009},
-                                         {"readFormat", required_argument, 0, 10013}, {"barcodeWhitelist", required_argument, 0, 10004},
+  static struct option long_options[] = {{"barcode", required_argument, 0, 10000}, {"barcodeStart", required_argument, 0, 10001},
+                                         {"barcodeEnd", required_argument, 0, 10002}, {"barcodeRevComp", no_argument, 0, 10003},
+                                         {"barcodeWhitelist", required_argument, 0, 10004}, {"read1Start", required_argument, 0, 10005},
+                                         {"read1End", required_argument, 0, 10006}, {"read2Start", required_argument, 0, 10007},
+                                         {"read2End", required_argument, 0, 10008}, {"UMI", required_argument, 0, 10009},
+                                         {"umiStart", required_argument, 0, 10010}, {"umiEnd", required_argument, 0, 10011},
+                                         {"umiRevComp", no_argument, 0, 10012}, {"readFormat", required_argument, 0, 10013},
                                          {"barcodeTranslate", required_argument, 0, 10014}, {"skipBarcodeErrorRead", no_argument, 0, 10015},
                                          {(char *)0, 0, 0, 0}};
   std::string refFa, prefix = "toassemble";
-  SeqReader reads, mateReads;
-  bool hasMate = false;
+  SeqReader reads, mateReads, barcodeFile, umiFile;
+  ReadFormat fmt;
+  BarcodeWhitelist whitelist;
+  BarcodeTranslate translator;
+  bool hasMate = false, hasBarcode = false, hasUmi = false, hasWhitelist = false, skipBarcodeErrorRead = false;
+  int barcodeStart = 0, barcodeEnd = -1, read1Start = 0, read1End = -1, read2Start = 0, read2End = -1, umiStart = 0, umiEnd = -1;
+  bool barcodeRevComp = false, umiRevComp = false;
   int c, oi = 0;
   while ((c = getopt_long(argc, argv, "f:u:1:2:o:t:", long_options, &oi)) != -1) {
     if (c == 'f') refFa = optarg;
@@ -52,9 +64,30 @@ int main(int argc, char *argv[]) {
     else if (c == '2') { mateReads.files.push_back(optarg); hasMate = true; }
     else if (c == 'o') prefix = optarg;
     else if (c == 't') { /* the candidate test runs on the GPU */ }
-    else { fprintf(stderr, "fastq-extractor-hip: barcode / UMI / readFormat options are not built yet.\n"); return EXIT_FAILURE; }
+    else if (c == 10000) { hasBarcode = true; barcodeFile.files.push_back(optarg); }
+    else if (c == 10001) barcodeStart = atoi(optarg);
+    else if (c == 10002) barcodeEnd = atoi(optarg);
+    else if (c == 10003) barcodeRevComp = true;
+    else if (c == 10004) { hasWhitelist = true; whitelist.load(optarg); }
+    else if (c == 10005) read1Start = atoi(optarg);
+    else if (c == 10006) read1End = atoi(optarg);
+    else if (c == 10007) read2Start = atoi(optarg);
+    else if (c == 10008) read2End = atoi(optarg);
+    else if (c == 10009) { hasUmi = true; umiFile.files.push_back(optarg); }
+    else if (c == 10010) umiStart = atoi(optarg);
+    else if (c == 10011) umiEnd = atoi(optarg);
+    else if (c == 10012) umiRevComp = true;
+    else if (c == 10013) fmt.init(optarg);
+    else if (c == 10014) translator.load(optarg);
+    else if (c == 10015) skipBarcodeErrorRead = true;
+    else { fprintf(stderr, "Unknown parameter\n"); return EXIT_FAILURE; }
   }
-  if (refFa.empty() || reads.files.empty()) { fprintf(stderr, "usage: fastq-extractor-hip -f ref.fa (-u reads.fq | -1 r_1.fq -2 r_2.fq) [-o prefix]\n"); return EXIT_FAILURE; }
+  if (refFa.empty() || reads.files.empty()) { fprintf(stderr, "usage: fastq-extractor-hip -f ref.fa (-u reads.fq | -1 r_1.fq -2 r_2.fq) [-o prefix] [--barcode F] [--UMI F] [--readFormat S] [--barcodeWhitelist F] [--barcodeTranslate F] [--skipBarcodeErrorRead]\n"); return EXIT_FAILURE; }
+  // range options become segments (FastqExtractor.cpp:422-429; the read-2 range takes the read-1 numbers there, kept)
+  if (read1Start != 0 || read1End != -1) fmt.addSegment(read1Start, read1End, 1, FMT_READ1);
+  if (read2Start != 0 || read2End != -1) fmt.addSegment(read1Start, read1End, 1, FMT_READ2);
+  if (barcodeStart != 0 || barcodeEnd != -1 || barcodeRevComp) fmt.addSegment(barcodeStart, barcodeEnd, barcodeRevComp ? -1 : 1, FMT_BARCODE);
+  if (umiStart != 0 || umiEnd != -1 || umiRevComp) fmt.addSegment(umiStart, umiEnd, umiRevComp ? -1 : 1, FMT_UMI);
 
   t4_ctx *ctx = nullptr;
   int rc = t4_init(getenv("T4_DEVICE") ? atoi(getenv("T4_DEVICE")) : 0, &ctx);
@@ -72,17 +105,51 @@ int main(int argc, char *argv[]) {
   if ((rc = t4_index_set_params(refSet, hitLenRequired, 10, 0.9))) die(ctx, "t4_index_set_params", rc);
   if ((rc = t4_index_commit(refSet))) die(ctx, "t4_index_commit", rc);
   reads.rewind();
+  if (hasBarcode && hasWhitelist) {   // BarcodeCorrector::CollectBackgroundDistribution (BarcodeCorrector.hpp:141-153): first 2 M barcodes
+    int n = 0;
+    while (barcodeFile.next()) { whitelist.searchAndUpdate(fmt.extract(&barcodeFile.seq, FMT_BARCODE, true), 1); if (++n >= 2000000) break; }
+    barcodeFile.rewind();
+  }
 
+  FILE *fpBc = hasBarcode ? fopen((prefix + "_bc.fa").c_str(), "w") : nullptr;
+  FILE *fpUmi = hasUmi ? fopen((prefix + "_umi.fa").c_str(), "w") : nullptr;
   FILE *fp1 = fopen((prefix + (hasMate ? "_1.fq" : ".fq")).c_str(), "w");
   FILE *fp2 = hasMate ? fopen((prefix + "_2.fq").c_str(), "w") : nullptr;
   if (!fp1 || (hasMate && !fp2)) { fprintf(stderr, "Could not open the output files of %s\n", prefix.c_str()); return EXIT_FAILURE; }
-  auto outputSeq = [](FILE *fp, const Rec &r) {   // OutputSeq (FastqExtractor.cpp:136-143)
-    if (r.hasQual) fprintf(fp, "@%s\n%s\n+\n%s\n", r.id.c_str(), r.seq.c_str(), r.qual.c_str());
-    else fprintf(fp, ">%s\n%s\n", r.id.c_str(), r.seq.c_str());
+  auto outputSeq = [&](FILE *fp, const std::string &name, const Rec &r, int cat) {   // OutputSeq (FastqExtractor.cpp:136-143)
+    if (r.hasQual) fprintf(fp, "@%s\n%s\n+\n%s\n", name.c_str(), fmt.extract(&r.seq, cat, true).c_str(), fmt.extract(&r.qual, cat, false).c_str());
+    else fprintf(fp, ">%s\n%s\n", name.c_str(), fmt.extract(&r.seq, cat, true).c_str());
+  };
+  // OutputBarcode (FastqExtractor.cpp:147-203); 0 = the read is to be skipped
+  auto outputBarcode = [&](FILE *fp, const std::string &name, const Rec &b, int cat, bool correct, bool translate, bool skipError) -> int {
+    if (!b.seq.empty()) {
+      const bool inComment = fmt.isInComment(cat);
+      std::string bc = fmt.extract(inComment ? (b.comment.empty() ? nullptr : &b.comment) : &b.seq, cat, true);
+      int result = 0;
+      if (correct) result = whitelist.correct(bc, b.hasQual ? &b.qual : nullptr);
+      if (result >= 0) {
+        if (translate) {
+          std::string nb = translator.translate(bc);
+          if (nb.empty()) {
+            if (skipError) return 0;
+            fprintf(stderr, "Barcode %s does not exist in the translation table.\n", bc.c_str());
+            exit(-1);
+          }
+          fprintf(fp, ">%s\n%s\n", name.c_str(), nb.c_str());
+        } else fprintf(fp, ">%s\n%s\n", name.c_str(), bc.c_str());
+      } else {
+        if (skipError) return 0;
+        fprintf(fp, ">%s\nmissing_barcode\n", name.c_str());
+      }
+    } else {
+      if (skipError) return 0;
+      fprintf(fp, ">%s\nmissing_barcode\n", name.c_str());
+    }
+    return 1;
   };
 
   const size_t BATCH = getenv("T4_BATCH") ? (size_t)atol(getenv("T4_BATCH")) : (size_t)1 << 20;
-  std::vector<Rec> r1, r2;
+  std::vector<Rec> r1, r2, rb, ru;
   long long total = 0, kept = 0;
   auto test = [&](const std::vector<Rec> &rs, const std::vector<char> *already, std::vector<char> &good) {
     // HasHitInSet for the reads that still need it and pass the low-complexity filter
@@ -104,20 +171,34 @@ int main(int argc, char *argv[]) {
     std::vector<char> good(r1.size(), 0);
     test(r1, nullptr, good);
     if (hasMate) test(r2, &good, good);
-    for (size_t k = 0; k < r1.size(); ++k)
-      if (good[k]) { outputSeq(fp1, r1[k]); if (hasMate) outputSeq(fp2, r2[k]); ++kept; }
+    for (size_t k = 0; k < r1.size(); ++k) {
+      if (!good[k]) continue;
+      // a barcode record that is the read itself (reads carrying their barcode) and of low complexity (FastqExtractor.cpp:521-527)
+      if (hasBarcode && (rb[k].seq == r1[k].seq || (hasMate && rb[k].seq == r2[k].seq)) && isLowComplexity(rb[k].seq)) continue;
+      if (hasBarcode && !outputBarcode(fpBc, r1[k].id, rb[k], FMT_BARCODE, hasWhitelist, translator.set, skipBarcodeErrorRead)) continue;
+      outputSeq(fp1, r1[k].id, r1[k], FMT_READ1);
+      if (hasMate) outputSeq(fp2, r1[k].id, r2[k], FMT_READ2);
+      if (hasUmi) outputBarcode(fpUmi, r1[k].id, ru[k], FMT_UMI, false, false, false);
+      ++kept;
+    }
     total += (long long)r1.size();
-    r1.clear(); r2.clear();
+    r1.clear(); r2.clear(); rb.clear(); ru.clear();
   };
   while (reads.next()) {
     if (hasMate && !mateReads.next()) { fprintf(stderr, "The two mate-pair read files have different number of reads.\n"); exit(1); }
-    r1.push_back(Rec{reads.id, reads.seq, reads.qual, reads.hasQual});
-    if (hasMate) r2.push_back(Rec{mateReads.id, mateReads.seq, mateReads.qual, mateReads.hasQual});
+    if (hasBarcode && !barcodeFile.next()) { fprintf(stderr, "Read file and barcode file  have different number of reads.\n"); exit(1); }
+    if (hasUmi && !umiFile.next()) { fprintf(stderr, "Read file and UMI file have different number of reads.\n"); exit(1); }
+    r1.push_back(Rec{reads.id, reads.seq, reads.qual, std::string(), reads.hasQual});
+    if (hasMate) r2.push_back(Rec{mateReads.id, mateReads.seq, mateReads.qual, std::string(), mateReads.hasQual});
+    if (hasBarcode) rb.push_back(Rec{barcodeFile.id, barcodeFile.seq, barcodeFile.qual, barcodeFile.comment, barcodeFile.hasQual});
+    if (hasUmi) ru.push_back(Rec{umiFile.id, umiFile.seq, umiFile.qual, umiFile.comment, umiFile.hasQual});
     if (r1.size() >= BATCH) flush();
   }
   flush();
   fclose(fp1);
   if (fp2) fclose(fp2);
+  if (fpBc) fclose(fpBc);
+  if (fpUmi) fclose(fpUmi);
   fprintf(stderr, "fastq-extractor-hip: %lld of %lld %s kept (hitLenRequired %d)\n", kept, total, hasMate ? "pairs" : "reads", hitLenRequired);
   t4_index_destroy(refSet);
   t4_destroy(ctx);

@@ -15,7 +15,7 @@ struct SeqReader {
   gzFile fp = nullptr;
   std::string pending;   // look-ahead line
   bool havePending = false;
-  std::string id, seq, qual;
+  std::string id, seq, qual, comment;   // comment: rest of the header line after the separator that ends the name (kseq)
   bool hasQual = false;
   bool getLine(std::string &out) {
     if (havePending) { out.swap(pending); havePending = false; return true; }
@@ -47,6 +47,7 @@ struct SeqReader {
       size_t e = 1;
       while (e < line.size() && line[e] != ' ' && line[e] != '\t') ++e;
       id.assign(line, 1, e - 1);
+      if (e < line.size()) comment.assign(line, e + 1, std::string::npos); else comment.clear();
       size_t n = id.size();   // ReadFiles.hpp:180-185
       if (n >= 2 && (id[n - 1] == '1' || id[n - 1] == '2') && id[n - 2] == '/') id.resize(n - 2);
       seq.clear(); qual.clear(); hasQual = false;
