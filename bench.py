@@ -238,7 +238,7 @@ def main():
                          "kernel": "t4k::queryKernel (all tiers of one pass)", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": alg},
         }
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:   # CPU legs on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(reads, args.cpu_sample)
         if args.e2e_pairs > 0 and world == 1:
             out["stage1_e2e"] = stage1_e2e(args.e2e_pairs, max(1, args.e2e_pairs // 100))
