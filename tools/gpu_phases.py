@@ -10,7 +10,7 @@ ref = eng.index(9).set_params(17, 10, 0.9).load_ref_fasta(t4libs.REF_FA).commit(
 arr = t4libs.Synth(20000, 1).next_reads(n // 2)
 b = eng.upload(arr)
 ref.annotate_rough(b, fetch=False)
-buf = (C.c_ulonglong * 16)()
+buf = (C.c_ulonglong * 32)()
 dbg = (C.c_ulonglong * 8)()
 eng.lib.t4_debug_phase_cycles(buf)
 eng.lib.t4_debug_counters(dbg)

@@ -486,6 +486,7 @@ int commitWithPostings(t4_index *ix, std::vector<Rec> &recs) {
   v.firstIsRef = (!ix->seqs.empty() && ix->seqs[0].isRef) ? 1 : 0;
   for (const HostSeq &q : ix->seqs) if (q.isRef) { hasRef = true; break; }
   v.hasNovel = hasNovel ? (hasRef ? 1 : 2) : 0;
+  { int maxLen = 0; for (const HostSeq &q : ix->seqs) if ((int)q.cons.size() > maxLen) maxLen = (int)q.cons.size(); v.key32 = t4Key32Bits(v.nseq, maxLen); }
   v.novelSim = ix->novelSim; v.refSim = ix->refSim; v.repeatSim = ix->repeatSim;
   ix->committed = true;
   return T4_OK;
@@ -1296,6 +1297,7 @@ int t4_cellstore_stage(t4_cellstore *cs, int slot, int barcode, int nseq, const 
   v.seqs = (const T4SeqInfo *)(slotBase + oSeq); v.cons = (const char *)(slotBase + oCons); v.pw = (const T4PW *)(slotBase + oPw);
   v.radius = cs->radius; v.hitLenRequired = cs->hitLenRequired; v.nomatchGapLimit = cs->nomatchGapLimit;
   v.firstIsRef = 0; v.hasNovel = 2;
+  { int maxLen = 0; for (int i = 0; i < nseq; ++i) if (infos[i].len > maxLen) maxLen = infos[i].len; v.key32 = t4Key32Bits(nseq, maxLen); }
   v.novelSim = cs->novelSim; v.refSim = 0.75; v.repeatSim = 0.95;
   return T4_OK;
 }

@@ -61,8 +61,20 @@ struct alignas(16) T4IndexView {   // 128 bytes: per-barcode views are scattered
   const T4PW *pw;            // posWeight predicate bytes of novel contigs
   const T4HashEntC *ctab;    // direct == 2
   int radius, hitLenRequired, nomatchGapLimit, firstIsRef, hasNovel /* 0 no novel contig, 1 mixed set, 2 novel contigs only */;
+  int key32;                 // 0, or idxBits | cBits << 8 when (strand, idx, diagonal, read offset) fit 32 bits (t4Key32Bits)
   double novelSim, refSim, repeatSim;
 };
+
+// Small sets (the reference genes; one cell's contigs) sort their hits as 32-bit keys: strand:1 | idx:idxBits | diagonal:cBits |
+// read offset:9. The diagonal is biased by 2^cBits - 512 (read offsets are < 512, sequence offsets < maxSeqLen <= 2^cBits - 512);
+// for one (strand, idx, diagonal) the read offset orders like the sequence offset, so the order equals that of the 64-bit keys.
+// idx never reaches all ones, which keeps 0xFFFFFFFF free for dropped hits. Returns 0 when the set does not fit.
+static inline int t4Key32Bits(int nseq, int maxSeqLen) {
+  int idxBits = 1, cBits = 10;
+  while ((1 << idxBits) <= nseq) ++idxBits;              // nseq + 1 values
+  while ((1 << cBits) - 512 < maxSeqLen) ++cBits;
+  return 1 + idxBits + cBits + 9 <= 32 ? (idxBits | cBits << 8) : 0;
+}
 
 struct T4BatchView {
   const unsigned *pk;        // 2-bit bases, 16 per word, wpk words per read

@@ -25,6 +25,12 @@ namespace t4k {
 // ------------------------------------------------------------------------------------------------
 // A workgroup (NT = blockDim.x threads, a multiple of 64) owns one read; wave-level helpers below are
 // combined through a few LDS words into workgroup-level scans / reductions.
+#ifndef T4_OPT_ROWWALK
+#define T4_OPT_ROWWALK 1
+#endif
+#ifndef T4_NI_R3
+#define T4_NI_R3 0
+#endif
 __device__ __forceinline__ int laneId() { return threadIdx.x & 63; }
 __device__ __forceinline__ int tid() { return threadIdx.x; }
 __device__ __forceinline__ int nthr() { return blockDim.x; }
@@ -831,9 +837,10 @@ __device__ int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int
 // Expand postings into sortable keys. Returns the number of valid keys (after barcode / VJ filters);
 // invalid slots get the all-ones key and sort to the end.
 __device__ int expandHits(const T4IndexView &ix, WaveMem &wm, int nk, int H, int barcode, bool vjOnly,
-                          const unsigned *posStart, const unsigned *posPref, int *red) {
+                          const unsigned *posStart, const unsigned *posPref, int *red, int k32 = 0) {
   const int lane = tid(), NT = nthr();
   int dropped = 0;
+  const int cBits32 = (k32 >> 8) & 255, bias32 = (1 << cBits32) - 512;
   for (int s = lane; s < H; s += NT) {
     int lo = 0, hi = 2 * nk - 1;   // last q with posPref[q] <= s
     while (lo < hi) {
@@ -859,7 +866,11 @@ __device__ int expandHits(const T4IndexView &ix, WaveMem &wm, int nk, int H, int
       key = (sb << 63) | ((unsigned long long)po.x << (T4_C_BITS + T4_B_BITS)) |
             ((unsigned long long)(a - po.y + T4_C_BIAS) << T4_B_BITS) | (unsigned long long)po.y;
     } else ++dropped;
-    wm.keys[s] = key;
+    if (k32) {   // 32-bit form of the same order (t4Key32Bits), sorted as such and widened afterwards (seedChainPass)
+      unsigned k = ~0u;
+      if (keep) k = (st ? 0u : 1u << 31) | ((unsigned)po.x << (cBits32 + 9)) | ((unsigned)(a - po.y + bias32) << 9) | (unsigned)a;
+      ((unsigned *)wm.keys)[s] = k;
+    } else wm.keys[s] = key;
   }
   dropped = blockSum(dropped, red);
   return H - dropped;
@@ -874,7 +885,8 @@ __device__ __forceinline__ void waveLdsSync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
-__device__ void bitonicSort(unsigned long long *keys, int n) {
+template <class KeyT>
+__device__ void bitonicSort(KeyT *keys, int n) {
   const int lane = tid(), NT = nthr();
   int n2 = 1;
   while (n2 < n) n2 <<= 1;
@@ -887,13 +899,13 @@ __device__ void bitonicSort(unsigned long long *keys, int n) {
     if (j > 64) {
       for (int t = lane; t < half; t += NT) {
         const int low = t & (j - 1), i = ((t & ~(j - 1)) << 1) | low, p = (i & ~(k - 1)) + (k - 1 - low);
-        if (p < n) { unsigned long long a = keys[i], b = keys[p]; if (a > b) { keys[i] = b; keys[p] = a; } }
+        if (p < n) { KeyT a = keys[i], b = keys[p]; if (a > b) { keys[i] = b; keys[p] = a; } }
       }
       __syncthreads();
       for (j >>= 1; j > 64; j >>= 1) {
         for (int t = lane; t < half; t += NT) {
           const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
-          if (p < n) { unsigned long long a = keys[i], b = keys[p]; if (a > b) { keys[i] = b; keys[p] = a; } }
+          if (p < n) { KeyT a = keys[i], b = keys[p]; if (a > b) { keys[i] = b; keys[p] = a; } }
         }
         __syncthreads();
       }
@@ -905,7 +917,7 @@ __device__ void bitonicSort(unsigned long long *keys, int n) {
         if (t < half) {
           const int low = t & (jj - 1), i = ((t & ~(jj - 1)) << 1) | low;
           const int p = (jj == (k >> 1)) ? (i & ~(k - 1)) + (k - 1 - low) : (i | jj);
-          if (p < n) { unsigned long long a = keys[i], b = keys[p]; if (a > b) { keys[i] = b; keys[p] = a; } }
+          if (p < n) { KeyT a = keys[i], b = keys[p]; if (a > b) { keys[i] = b; keys[p] = a; } }
         }
         waveLdsSync();
       }
@@ -914,6 +926,82 @@ __device__ void bitonicSort(unsigned long long *keys, int n) {
   }
 }
 
+#ifndef T4_OPT_REGSORT
+#define T4_OPT_REGSORT 1
+#endif
+
+#if T4_OPT_REGSORT
+// The same network for 32-bit keys with the chunk-local sub-steps in registers: a lane holds elements wl and wl + 64 of its
+// wavefront's 128-element chunk, partners are reached by lane exchanges (wl ^ mask), and a chunk is read and written once
+// per stage instead of once per sub-step -- 56 of the 66 sub-steps of a 2048-key sort are chunk-local, and the LDS version
+// is bound by LDS bandwidth. Out of line: its registers are its own.
+__device__ __forceinline__ void cmpExch32(unsigned &lo, unsigned &hi, int mask, bool keepMax) {
+  const unsigned olo = __shfl_xor(lo, mask), ohi = __shfl_xor(hi, mask);
+  lo = keepMax ? (olo > lo ? olo : lo) : (olo < lo ? olo : lo);
+  hi = keepMax ? (ohi > hi ? ohi : hi) : (ohi < hi ? ohi : hi);
+}
+__device__ __attribute__((noinline)) void bitonicSort32(unsigned *keys, int n) {
+  const int lane = tid(), NT = nthr();
+  int n2 = 1;
+  while (n2 < n) n2 <<= 1;
+  const int half = n2 >> 1;
+  const int nChunk = (n + 127) >> 7;          // chunks of 128 elements that hold a real key
+  const int wave = lane >> 6, nw = NT >> 6, wl = lane & 63;
+  // stages k = 2 .. 128 never leave a chunk
+  for (int c = wave; c < nChunk; c += nw) {
+    const int base = c << 7;
+    unsigned lo = base + wl < n ? keys[base + wl] : ~0u;
+    unsigned hi = base + 64 + wl < n ? keys[base + 64 + wl] : ~0u;
+    for (int k = 2; k <= 64; k <<= 1) {
+      cmpExch32(lo, hi, k - 1, (wl & (k >> 1)) != 0);                      // mirrored partner inside the k-block
+      for (int jj = k >> 2; jj > 0; jj >>= 1) cmpExch32(lo, hi, jj, (wl & jj) != 0);
+    }
+    {   // k = 128: element wl meets 127 - wl = the upper element of lane 63 - wl, and the other way round
+      const unsigned olo = __shfl_xor(lo, 63), ohi = __shfl_xor(hi, 63);
+      lo = ohi < lo ? ohi : lo;
+      hi = olo > hi ? olo : hi;
+      for (int jj = 32; jj > 0; jj >>= 1) cmpExch32(lo, hi, jj, (wl & jj) != 0);
+    }
+    if (base + wl < n) keys[base + wl] = lo;
+    if (base + 64 + wl < n) keys[base + 64 + wl] = hi;
+  }
+  __syncthreads();
+  for (int k = 256; k <= n2; k <<= 1) {
+    int j = k >> 1;
+    for (int t = lane; t < half; t += NT) {   // first sub-step of the stage: mirrored partner
+      const int low = t & (j - 1), i = ((t & ~(j - 1)) << 1) | low, p = (i & ~(k - 1)) + (k - 1 - low);
+      if (p < n) { unsigned a = keys[i], b = keys[p]; if (a > b) { keys[i] = b; keys[p] = a; } }
+    }
+    __syncthreads();
+    for (j >>= 1; j > 64; j >>= 1) {
+      for (int t = lane; t < half; t += NT) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
+        if (p < n) { unsigned a = keys[i], b = keys[p]; if (a > b) { keys[i] = b; keys[p] = a; } }
+      }
+      __syncthreads();
+    }
+    for (int c = wave; c < nChunk; c += nw) {   // j = 64 .. 1 in registers
+      const int base = c << 7;
+      unsigned lo = base + wl < n ? keys[base + wl] : ~0u;
+      unsigned hi = base + 64 + wl < n ? keys[base + 64 + wl] : ~0u;
+      if (lo > hi) { const unsigned t = lo; lo = hi; hi = t; }
+      for (int jj = 32; jj > 0; jj >>= 1) cmpExch32(lo, hi, jj, (wl & jj) != 0);
+      if (base + wl < n) keys[base + wl] = lo;
+      if (base + 64 + wl < n) keys[base + 64 + wl] = hi;
+    }
+    __syncthreads();
+  }
+}
+#endif
+#ifndef T4_OPT_ROWCHAIN
+#define T4_OPT_ROWCHAIN 1
+#endif
+#ifndef T4_OPT_R2CHECK
+#define T4_OPT_R2CHECK 1
+#endif
+#ifndef T4_OPT_KEY32
+#define T4_OPT_KEY32 1
+#endif
 #define KEY_G(k) ((unsigned)((k) >> (T4_C_BITS + T4_B_BITS)))
 #define KEY_IDX(k) ((int)(((k) >> (T4_C_BITS + T4_B_BITS)) & ((1u << T4_IDX_BITS) - 1)))
 #define KEY_PLUS(k) ((int)((k) >> 63))
@@ -921,31 +1009,13 @@ __device__ void bitonicSort(unsigned long long *keys, int n) {
 #define KEY_B(k) ((int)((k) & ((1u << T4_B_BITS) - 1)))
 
 // Chain one run [s, s+n) whose pairs are already in wm.pairs sorted by (b, a); append the overlap.
-__device__ void chainRun(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int s, int n, int seqIdx, int plus,
-                         bool isRef, int hitLenRequired) {
+// Tail of chainRun: `mono` runs arrive with lisOut filled and both hit-length sums known; the others take the lane-serial LIS.
+__device__ void chainFinish(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int s, int n, int seqIdx, int plus,
+                            bool isRef, int hitLenRequired, bool mono, int hitLen, int hitLenSeq) {
   const int K = ix.k;
   unsigned *lisOut = (unsigned *)(wm.keys + s);
   unsigned short *top = (unsigned short *)(lisOut + n);
   unsigned short *link = top + n;
-  // A run whose (b, a)-sorted hits are strictly increasing in both coordinates is its own LIS: the
-  // equal-b collapse and the replacement sweep of LongestIncreasingSubsequence are then identities.
-  // One pass for the common case: copy the run, test monotonicity and accumulate both GetTotalHitLength sums (for an
-  // increasing chain, sum over segments of (last - first + K) == K + sum over neighbours of min(step, K)).
-  bool mono = true;
-  int hitLen = K, hitLenSeq = K;
-  {
-    unsigned prev = wm.pairs[s];
-    lisOut[0] = prev;
-    for (int t = 1; t < n; ++t) {
-      const unsigned cur = wm.pairs[s + t];
-      const int da = PA(cur) - PA(prev), db = PB(cur) - PB(prev);
-      mono = mono && da > 0 && db > 0;
-      hitLen += da < K ? da : K;
-      hitLenSeq += db < K ? db : K;
-      lisOut[t] = cur;
-      prev = cur;
-    }
-  }
   int lisSize = n;
   if (!mono) {
     lisSize = lisLane(wm.pairs + s, n, lisOut, top, link);
@@ -971,6 +1041,107 @@ __device__ void chainRun(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int 
   if (slot < wm.maxOv) wm.ov[slot] = o; else ws->overflow = 1;
 }
 
+__device__ void chainRun(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int s, int n, int seqIdx, int plus,
+                         bool isRef, int hitLenRequired) {
+  const int K = ix.k;
+  unsigned *lisOut = (unsigned *)(wm.keys + s);
+  // A run whose (b, a)-sorted hits are strictly increasing in both coordinates is its own LIS: the
+  // equal-b collapse and the replacement sweep of LongestIncreasingSubsequence are then identities.
+  // One pass for the common case: copy the run, test monotonicity and accumulate both GetTotalHitLength sums (for an
+  // increasing chain, sum over segments of (last - first + K) == K + sum over neighbours of min(step, K)).
+  bool mono = true;
+  int hitLen = K, hitLenSeq = K;
+  {
+    unsigned prev = wm.pairs[s];
+    lisOut[0] = prev;
+    for (int t = 1; t < n; ++t) {
+      const unsigned cur = wm.pairs[s + t];
+      const int da = PA(cur) - PA(prev), db = PB(cur) - PB(prev);
+      mono = mono && da > 0 && db > 0;
+      hitLen += da < K ? da : K;
+      hitLenSeq += db < K ? db : K;
+      lisOut[t] = cur;
+      prev = cur;
+    }
+  }
+  chainFinish(ix, wm, ws, s, n, seqIdx, plus, isRef, hitLenRequired, mono, hitLen, hitLenSeq);
+}
+
+
+// R3 of overlapsFromKeys, one 16-lane row per candidate run (a read has ~65 candidate runs of ~12 hits and a few of 100+: one
+// lane per run left the wavefront waiting for its longest run). Extraction, the (b, a) order test, the rank sort of the few
+// unordered runs, the monotonicity test and both GetTotalHitLength sums run across the row; only a run that is not its own
+// LIS (2 % of them) falls back to the lane-serial LongestIncreasingSubsequence. Loops hold no wave-level operation, so the
+// rows of a wavefront may run different trip counts. T4_NI_R3: out of line (own register budget).
+#if T4_NI_R3
+__device__ __attribute__((noinline))
+#else
+__device__ __forceinline__
+#endif
+void chainRunsRows(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int nCand, int hitLenRequired) {
+  const int lane = tid(), NT = nthr(), K = ix.k;
+    const int row = lane >> 4, rl = lane & 15, nRows = NT >> 4, rowShift = (lane & 63) & ~15;
+    for (int c0 = 0; c0 < nCand; c0 += nRows) {
+      const int c = c0 + row;
+      const bool has = c < nCand;
+      int s = 0, n = 0, idx = 0, plus = 0, adjustRadius = 0;
+      bool isRef = false;
+      if (has) {
+        s = wm.cand[c] & 0xFFFF; n = wm.cand[c] >> 16;
+        const unsigned long long ks = wm.keys[s];
+        idx = KEY_IDX(ks); plus = KEY_PLUS(ks);
+        isRef = seqIsRef(ix, idx);
+        adjustRadius = isRef ? ix.radius : 0;
+      }
+      const bool big = adjustRadius > 0 && n > 48;   // ordered by R2 already
+      waveLdsSync();                                  // every row has read its keys[s] before anything is overwritten
+      if (has && !big)
+        for (int t = rl; t < n; t += 16) {
+          const unsigned long long kt = wm.keys[s + t];
+          const int b = KEY_B(kt), a = KEY_C(kt) - T4_C_BIAS + b;
+          wm.pairs[s + t] = ((unsigned)b << 12) | (unsigned)a;
+        }
+      waveLdsSync();
+      bool unsorted = false;
+      if (has && !big && adjustRadius > 0)
+        for (int t = rl + 1; t < n; t += 16) unsorted = unsorted || wm.pairs[s + t - 1] > wm.pairs[s + t];
+      unsorted = ((__ballot(unsorted) >> rowShift) & 0xFFFFull) != 0;
+      if (__any(unsorted)) {   // a run is a union of a few diagonals: rank sort across the row (pairs of one run are distinct)
+        unsigned *tmp = (unsigned *)(wm.keys + s) + n;
+        if (unsorted)
+          for (int t = rl; t < n; t += 16) {
+            const unsigned v = wm.pairs[s + t];
+            int rank = 0;
+            for (int u = 0; u < n; ++u) rank += wm.pairs[s + u] < v ? 1 : 0;
+            tmp[rank] = v;
+          }
+        waveLdsSync();
+        if (unsorted) for (int t = rl; t < n; t += 16) wm.pairs[s + t] = tmp[t];
+        waveLdsSync();
+      }
+      // a run whose (b, a)-sorted hits increase strictly in both coordinates is its own LIS (see chainRun)
+      unsigned *lisOut = (unsigned *)(wm.keys + s);
+      bool bad = false;
+      int hitLen = 0, hitLenSeq = 0;
+      if (has)
+        for (int t = rl; t < n; t += 16) {
+          const unsigned cur = wm.pairs[s + t];
+          if (t > 0) {
+            const unsigned prev = wm.pairs[s + t - 1];
+            const int da = PA(cur) - PA(prev), db = PB(cur) - PB(prev);
+            bad = bad || !(da > 0 && db > 0);
+            hitLen += da < K ? da : K;
+            hitLenSeq += db < K ? db : K;
+          }
+          lisOut[t] = cur;
+        }
+      bad = ((__ballot(bad) >> rowShift) & 0xFFFFull) != 0;
+      hitLen = rowSum16(hitLen) + K;
+      hitLenSeq = rowSum16(hitLenSeq) + K;
+      waveLdsSync();
+      if (has && rl == 0) chainFinish(ix, wm, ws, s, n, idx, plus, isRef, hitLenRequired, !bad, hitLen, hitLenSeq);
+    }
+}
 
 // GetOverlapsFromHits (SeqSet.hpp:763-1063) on the sorted keys [0, Hv). Overlaps land in wm.ov.
 // `filter` is the reference's filter argument. removeOnlyRepeats needs a hit with repeats > 10000,
@@ -1085,6 +1256,13 @@ __device__ void overlapsFromKeys(const T4IndexView &ix, WaveMem &wm, WaveState *
         wm.pairs[s + t] = ((unsigned)b << 12) | (unsigned)a;
       }
       waveLdsSync();
+#if T4_OPT_R2CHECK
+      {   // a long run on a single diagonal (an exact gene match) is in (b, a) order already
+        bool unsorted = false;
+        for (int t = wl + 1; t < n; t += 64) unsorted = unsorted || wm.pairs[s + t - 1] > wm.pairs[s + t];
+        if (!__any(unsorted)) continue;                       // wave-uniform
+      }
+#endif
       for (int t = wl; t < n; t += 64) {
         unsigned v = wm.pairs[s + t];
         int rank = 0;
@@ -1098,6 +1276,11 @@ __device__ void overlapsFromKeys(const T4IndexView &ix, WaveMem &wm, WaveState *
   }
   __syncthreads();   // R3 overwrites key areas that R2's wave-uniform tests read
   PHASE_MARK(ws, 7);
+#if T4_OPT_ROWCHAIN
+  chainRunsRows(ix, wm, ws, nCand, hitLenRequired);
+  __syncthreads();
+}
+#else
   // R3: one lane per candidate run: extract (b << 12 | a), order by (b, a), chain
   for (int c = lane; c < nCand; c += NT) {
     int s = wm.cand[c] & 0xFFFF, n = wm.cand[c] >> 16;
@@ -1124,6 +1307,7 @@ __device__ void overlapsFromKeys(const T4IndexView &ix, WaveMem &wm, WaveState *
   }
   __syncthreads();
 }
+#endif
 
 // IsOverlapLowComplex (SeqSet.hpp:590-617)
 // SeqSet::IsLowComplexity-style test of GetOverlapsFromRead (SeqSet.hpp:2036-2062) on segment positions [rs, re] of the
@@ -1532,6 +1716,72 @@ __device__ void walkOverlap(const T4IndexView &ix, WaveMem &wm, WaveState *ws, O
   if (lowComplex(wm, (o.flags & OV_PLUS) != 0, o.rs, o.re)) o.flags |= OV_SIMZERO;
 }
 
+#if T4_OPT_ROWWALK
+// The collecting walk of every kept overlap, one 16-lane row per overlap (experiment; out of line so that its registers do
+// not add to the kernel's pressure). For a reference-gene overlap under radius > 0 the walk only ever stops on geometry (a
+// gap beyond nomatchGapLimit), so its sums are prefix sums up to that anchor pair j*: find j*, add the pairs before it (pair
+// j* itself has added its 2K before the reference looks at the gap), list their gap jobs.
+__device__ __attribute__((noinline)) void walkOverlapsRows(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int overlapCnt) {
+  const int lane = tid(), NT = nthr(), K = ix.k;
+  const int row = lane >> 4, rl = lane & 15, nRows = NT >> 4;
+  for (int i0 = 0; i0 < overlapCnt; i0 += nRows) {
+    const int i = i0 + row;
+    const bool has = i < overlapCnt;
+    int chainPos = 0, chainLen = 0, ovSlot = 0;
+    bool fast = false;
+    if (has) {
+      ovSlot = wm.ord[i];
+      const OvRec &o = wm.ov[ovSlot];
+      chainPos = o.chainPos; chainLen = o.chainLen;
+      fast = (o.flags & OV_ISREF) != 0 && ix.radius > 0;
+      if (!fast && rl == 0) { OvRec oc = o; walkOverlap(ix, wm, ws, oc, i, true); }
+    }
+    const unsigned *hc = (const unsigned *)(wm.keys + chainPos);
+    int jStop = 0x7FFFFFFF;
+    if (fast)
+      for (int j = 1 + rl; j < chainLen; j += 16) {
+        const unsigned pp = hc[j - 1], cp = hc[j];
+        const int pa = PA(pp), pb = PB(pp), qa = PA(cp), qb = PB(cp);
+        const bool gapA = pa + K - 1 < qa, gapB = pb + K - 1 < qb;
+        const bool doDP = (pb - pa == qb - qa) ? gapA : (gapA && gapB);
+        if (doDP && (qb - (pb + K) > ix.nomatchGapLimit || qa - (pa + K) > ix.nomatchGapLimit)) { jStop = j; break; }
+      }
+    for (int m = 1; m < 16; m <<= 1) { const int other = __shfl_xor(jStop, m); jStop = other < jStop ? other : jStop; }
+    int matchCnt = 0, indelCnt = 0;
+    if (fast)
+      for (int j = 1 + rl; j < chainLen && j <= jStop; j += 16) {
+        if (j == jStop) { matchCnt += 2 * K; break; }
+        const unsigned pp = hc[j - 1], cp = hc[j];
+        const int pa = PA(pp), pb = PB(pp), qa = PA(cp), qb = PB(cp);
+        bool doDP = false;
+        if (pb - pa == qb - qa) {
+          if (pa + K - 1 >= qa) matchCnt += 2 * (qa - pa);
+          else { matchCnt += 2 * K; doDP = true; }
+        } else if (pa + K - 1 >= qa && pb + K - 1 < qb) { matchCnt += 2 * (qa - pa); indelCnt += (qb - (pb + K) + (qa + K - pa)); }
+        else if (pa + K - 1 < qa && pb + K - 1 >= qb) { matchCnt += 2 * (qb - pb); indelCnt += (qa - (pa + K) + (qb + K - pb)); }
+        else if (pa + K - 1 >= qa && pb + K - 1 >= qb) {
+          const int da = qa - pa, db = qb - pb;
+          matchCnt += 2 * (da < db ? da : db);
+          const int d = (qa - qb) - (pa - pb);
+          indelCnt += d < 0 ? -d : d;
+        } else { matchCnt += 2 * K; doDP = true; }
+        if (doDP) {
+          const int slot = atomicAdd(&ws->jobCount, 1);
+          if (slot < wm.candCap) wm.cand[slot] = (unsigned)i | ((unsigned)j << 16); else ws->overflow = 1;
+        }
+      }
+    matchCnt = rowSum16(matchCnt);
+    indelCnt = rowSum16(indelCnt);
+    if (fast && rl == 0) {
+      ((unsigned *)hc)[chainLen] = (unsigned)(matchCnt + 2 * K);
+      OvRec &dst = wm.ov[ovSlot];
+      dst.indelCnt = indelCnt;
+      if (jStop == 0x7FFFFFFF) dst.flags &= ~OV_SIMZERO; else dst.flags |= OV_SIMZERO;
+    }
+  }
+}
+#endif
+
 // result of one gap alignment of overlap slot `ovSlot` (fast class of walkOverlap): add it where the finishing pass expects it
 __device__ __forceinline__ void addGapResult(WaveMem &wm, WaveState *ws, int ovSlot, unsigned c) {
   OvRec &o = wm.ov[ovSlot];
@@ -1589,10 +1839,39 @@ __device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, 
   int H = seedPositions(ix, wm, segLen, strandArg, barcode, allowTotalSkip, posStart, posPref, ws->red);
   if (H > wm.cap) return -1;
   PHASE_MARK(ws, 2);
-  int Hv = expandHits(ix, wm, nk, H, barcode, vjOnly, posStart, posPref, ws->red);
+#if T4_OPT_KEY32
+  const int k32 = ix.key32;
+#else
+  const int k32 = 0;
+#endif
+  int Hv = expandHits(ix, wm, nk, H, barcode, vjOnly, posStart, posPref, ws->red, k32);
   __syncthreads();
   PHASE_MARK(ws, 3);
-  if (H > 1) bitonicSort(wm.keys, H);
+  if (k32) {
+    // half the LDS traffic of the sort; the keys are widened to the 64-bit layout the later stages read (through pairs,
+    // whose prefix sums died with expandHits: element i of the wide array overlays elements 2i, 2i + 1 of the narrow one)
+    unsigned *k32v = (unsigned *)wm.keys;
+#if T4_OPT_REGSORT
+    if (H > 1) bitonicSort32(k32v, H);
+#else
+    if (H > 1) bitonicSort(k32v, H);
+#endif
+    for (int i = lane; i < H; i += NT) wm.pairs[i] = k32v[i];
+    __syncthreads();
+    const int cBits = (k32 >> 8) & 255, bias32 = (1 << cBits) - 512;
+    for (int i = lane; i < H; i += NT) {
+      const unsigned v = wm.pairs[i];
+      unsigned long long key = ~0ull;
+      if (v != ~0u) {
+        const int a = (int)(v & 511u), c = (int)((v >> 9) & ((1u << cBits) - 1u)) - bias32;
+        const unsigned long long idx = (v & 0x7FFFFFFFu) >> (cBits + 9);
+        key = ((unsigned long long)(v >> 31) << 63) | (idx << (T4_C_BITS + T4_B_BITS)) |
+              ((unsigned long long)(c + T4_C_BIAS) << T4_B_BITS) | (unsigned long long)(a - c);
+      }
+      wm.keys[i] = key;
+    }
+    __syncthreads();
+  } else if (H > 1) bitonicSort(wm.keys, H);
   PHASE_MARK(ws, 4);
   overlapsFromKeys(ix, wm, ws, Hv, hitLenRequired, filter);
   PHASE_MARK(ws, 0);
@@ -1673,10 +1952,14 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
   // (1) collect the gap-alignment jobs of every kept overlap (job list = the dead cand array)
   if (lane == 0) ws->jobCount = 0;
   __syncthreads();
+#if T4_OPT_ROWWALK
+  walkOverlapsRows(ix, wm, ws, overlapCnt);
+#else
   for (int i = lane; i < overlapCnt; i += NT) {
     OvRec o = wm.ov[wm.ord[i]];
     walkOverlap(ix, wm, ws, o, i, true);
   }
+#endif
   __syncthreads();
   if (ws->overflow) return -2;
   const int nJobs = ws->jobCount;
