@@ -159,7 +159,10 @@ def test_extractor_barcode_options_emulated(tmp_path, case):
 def test_extractor_barcode_options_match_reference_binary(tmp_path, case):
     import trust4_amd.build as b
     b.build()
-    run_barcode_case(tmp_path, os.path.join(ROOT, "trust4_amd", "bin", "fastq-extractor-hip"), case, 300, 1500)
+    # header_fields stays at the emulated size: with header-comment fields the REFERENCE binary double-frees (glibc abort) on every
+    # larger input of this generator that was tried (>= 320 pairs), so there is nothing to compare with beyond that
+    n_rec, n_other = (80, 120) if case == "header_fields" else (300, 1500)
+    run_barcode_case(tmp_path, os.path.join(ROOT, "trust4_amd", "bin", "fastq-extractor-hip"), case, n_rec, n_other)
 
 
 @pytest.mark.gpu
