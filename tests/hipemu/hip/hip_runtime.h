@@ -106,6 +106,7 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, i
   if (ctrl == 0x101) { int l = hipemu_lane(); return hipemu_shfl_any(src, (l & 15) != 15 ? l + 1 : l); }  // row_shl:1
   fprintf(stderr, "hipemu: dpp_ctrl 0x%x not emulated\n", ctrl); abort();
 }
+static inline int __builtin_amdgcn_readfirstlane(int v) { return hipemu_shfl_any(v, 0); }   // called with all lanes active
 static inline unsigned long long __ballot(int pred) {
   hipemu::xchg[hipemu::cur_tid.x] = pred ? 1 : 0;
   hipemu::wave_rendezvous(__builtin_return_address(0));

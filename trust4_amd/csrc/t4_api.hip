@@ -196,7 +196,7 @@ int t4_init(int device_ordinal, t4_ctx **out) {
   if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return T4_ERR_HIP; }
   for (int i = 0; i < 4; ++i) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return T4_ERR_HIP; }
   memset(&c->stats, 0, sizeof c->stats);
-  if (hipMalloc(&c->listCounts, sizeof(int) * 8) != hipSuccess || hipMalloc(&c->hitCounter, sizeof(unsigned long long)) != hipSuccess) { delete c; return T4_ERR_HIP; }
+  if (hipMalloc(&c->listCounts, sizeof(int) * 16) != hipSuccess || hipMalloc(&c->hitCounter, sizeof(unsigned long long)) != hipSuccess) { delete c; return T4_ERR_HIP; }
   *out = c;
   return T4_OK;
 }
@@ -588,7 +588,7 @@ int runQuery(t4_index *ix, t4_batch *b, T4QueryArgs qa, bool useBarcode, bool no
   for (int t = 0; t < T4_NTIER; ++t) { grids[t] = c->cus * TIER_BLOCKS_PER_CU[t]; if (grids[t] * TIER_THREADS[t] > maxGrid) maxGrid = grids[t] * TIER_THREADS[t]; }
   if ((r = ensureScratch(c, maxGrid))) return r;
   if ((r = ensurePerCall(c, n))) return r;
-  HIPCHK(c, hipMemsetAsync(c->listCounts, 0, sizeof(int) * 8, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->listCounts, 0, sizeof(int) * 16, c->stream));   // [0..8) tier counts, [8..16) tier work counters
   HIPCHK(c, hipMemsetAsync(c->status, 0, sizeof(int) * (size_t)n, c->stream));
   HIPCHK(c, hipMemsetAsync(c->hitCounter, 0, sizeof(unsigned long long), c->stream));
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
@@ -609,11 +609,15 @@ int runQuery(t4_index *ix, t4_batch *b, T4QueryArgs qa, bool useBarcode, bool no
     int cnt = hostCounts[t];
     c->stats.tier_reads[t] = cnt;
     if (cnt == 0) continue;
+#ifdef T4_PHASE_TIMING
+    if (getenv("T4_ONLY_TIER") && atoi(getenv("T4_ONLY_TIER")) >= 0 && atoi(getenv("T4_ONLY_TIER")) != t) continue;   // per-tier phase profiles
+#endif
     T4Work wk;
     memset(&wk, 0, sizeof wk);
     wk.list = c->lists + (size_t)t * n; wk.nList = cnt;
     wk.nextList = t + 1 < T4_NTIER ? c->lists + (size_t)(t + 1) * n : nullptr;
     wk.nextCount = t + 1 < T4_NTIER ? c->listCounts + (t + 1) : nullptr;
+    wk.workNext = getenv("T4_STATIC_STRIDE") ? nullptr : c->listCounts + 8 + t;   // reads cost very different amounts: blocks fetch their next read
     wk.status = c->status; wk.hitCounter = c->hitCounter;
     wk.dpRows = c->dpRows; wk.dpDir = c->dpDir;
     int grid = grids[t] < cnt ? grids[t] : cnt;

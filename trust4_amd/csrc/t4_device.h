@@ -92,6 +92,7 @@ struct T4Work {              // per-launch work description
   int nList;
   int *nextList;             // overflow -> next tier
   int *nextCount;
+  int *workNext;             // dynamic distribution of the list over the persistent grid (zeroed per launch); null: static stride
   int *status;               // per read: 0 ok, 1 unsupported
   unsigned long long *hitCounter;
   // scratch (per persistent block)

@@ -25,6 +25,12 @@ namespace t4k {
 // ------------------------------------------------------------------------------------------------
 // A workgroup (NT = blockDim.x threads, a multiple of 64) owns one read; wave-level helpers below are
 // combined through a few LDS words into workgroup-level scans / reductions.
+#ifndef T4_OPT_JOBSORT
+#define T4_OPT_JOBSORT 1
+#endif
+#ifndef T4_OPT_OCT2
+#define T4_OPT_OCT2 0
+#endif
 #ifndef T4_OPT_ROWWALK
 #define T4_OPT_ROWWALK 1
 #endif
@@ -685,6 +691,7 @@ struct WaveMem {
   unsigned *cand;            // [cap / 3 + 1] candidate runs: start | len << 16
   char *seg, *rc;            // [T4_MAXL + 8] current segment, forward and reverse complement
   int cap, maxOv, maxFin, candCap;
+  int ldsArrays;                   // keys / pairs / ov live in LDS (every tier but the global-scratch one)
   const unsigned *pkRow, *nmRow;   // the read's packed words (global), set by loadSegment
   int segAbs, segLen;              // position of the current segment inside the read
 };
@@ -1471,6 +1478,60 @@ __device__ unsigned dpWave(const char *t, const T4PW *w, int lent, const char *p
 }
 
 
+#ifdef __HIPCC__
+#define T4_LDS_AS __attribute__((address_space(3)))
+#else
+#define T4_LDS_AS   /* the emulator build has one address space */
+#endif
+template <bool LDS> struct T4TbufPtr { typedef const char *type; };
+template <> struct T4TbufPtr<true> { typedef const T4_LDS_AS char *type; };
+
+// One cell (i, j) of dpOct from its upper (i-1, j), left (i, j-1) and diagonal (i-1, j-1) neighbours, branch-free. `border`
+// is wave-uniform: while it holds, neighbours in row 0 / column 0 take the reference's closed forms (its matrices have the
+// whole first row and column initialised, also outside the band).
+template <bool PW>
+__device__ __forceinline__ void octCell(bool border, int i, int j, bool eq, int e0, int q4, int uM, int uE, unsigned uC0, unsigned uC1,
+                                        int lM, int lF, unsigned lC0, unsigned lC2, int dM, unsigned dC0,
+                                        int &M, int &E, int &F, unsigned &C0, unsigned &C1, unsigned &C2) {
+  if (border) {
+    const bool j1 = j == 1, i1 = i == 1;
+    lM = j1 ? -4 - 4 * i : lM;
+    if (PW) lC0 = j1 ? CNT_MATCH + CNT_INDEL * (unsigned)(i - 1) : lC0;
+    else { lF = j1 ? -4 - 4 * i : lF; lC0 = j1 ? CNT_INDEL * (unsigned)i : lC0; lC2 = j1 ? CNT_INDEL * (unsigned)(1 + i) : lC2; }
+    uM = i1 ? -4 - 4 * j : uM;
+    if (PW) uC0 = i1 ? CNT_MATCH + CNT_INDEL * (unsigned)(j - 1) : uC0;
+    else { uE = i1 ? e0 : uE; uC0 = i1 ? CNT_INDEL * (unsigned)(j + (j > q4 ? 1 : 0)) : uC0; uC1 = i1 ? CNT_INDEL * (unsigned)(1 + j) : uC1; }
+    const int jj = j - 1;
+    const int dMi = jj == 0 ? 0 : -4 - 4 * jj;                                       // (0, j-1)
+    const unsigned dCi = jj == 0 ? 0u : (PW ? CNT_MATCH + CNT_INDEL * (unsigned)(jj - 1) : CNT_INDEL * (unsigned)(jj + (jj > q4 ? 1 : 0)));
+    const int dMj = -4 - 4 * (i - 1);                                                // (i-1, 0), i >= 2
+    const unsigned dCj = PW ? CNT_MATCH + CNT_INDEL * (unsigned)(i - 2) : CNT_INDEL * (unsigned)(i - 1);
+    dM = i1 ? dMi : (j1 ? dMj : dM);
+    dC0 = i1 ? dCi : (j1 ? dCj : dC0);
+  }
+  const int dsc = dM + (eq ? 2 : -2);
+  const unsigned cd = dC0 + (eq ? CNT_MATCH : CNT_MIS);
+  if (PW) {
+    const int lm = lM - 4, um = uM - 4;
+    int m = lm > um ? lm : um;
+    m = dsc > m ? dsc : m;
+    C0 = (dsc == m) ? cd : ((um == m) ? uC0 + CNT_INDEL : lC0 + CNT_INDEL);
+    M = m;
+  } else {
+    const int eo = uM - 5, fo = lM - 5;
+    int e = uE - 1, f = lF - 1;
+    e = eo > e ? eo : e;
+    f = fo > f ? fo : f;
+    int m = e > f ? e : f;
+    m = dsc > m ? dsc : m;
+    const unsigned c1 = CNT_INDEL + ((eo == e) ? uC0 : uC1);
+    const unsigned c2 = CNT_INDEL + ((fo == f) ? lC0 : lC2);
+    C0 = (dsc == m) ? cd : ((f >= e) ? c2 : c1);
+    M = m; E = e; F = f; C1 = c1; C2 = c2;
+  }
+}
+
+
 // The same recurrences with EIGHT alignments per wavefront and no idle cell slot. A band is 11 + |lent - lenp| columns,
 // almost always <= 16; in the skewed order s = 2i + d a lane that owns ONE column has a cell only every other step. So
 // lane L of a group of 8 owns the column pair (2L, 2L+1): in step pair u it computes row i = u - L of both columns,
@@ -1479,9 +1540,14 @@ __device__ unsigned dpWave(const char *t, const T4PW *w, int lent, const char *p
 // i.e. 8 DPP moves and two full cell updates per pair, every lane busy, two alignments per 16-lane DPP row. Every lane
 // passes the job of its group of 8 (has == false: none); jobs whose band is wider than 16 columns or whose sides exceed
 // T4_MAXGAP (or the group's tcap bytes of LDS at tbuf, affine only) get DP_FAIL and are left to dpWave. All 64 lanes call it.
-template <bool PW>
+// p always lives in LDS (the read's segment); TLDS says that tbuf does too (every tier but the global-scratch one): the loop then
+// reads its characters with ds_read (lgkmcnt only, in order) instead of flat loads, which the prefetch of the next step needs.
+template <bool PW, bool TLDS>
 __device__ __attribute__((noinline)) unsigned dpOct(bool has, const char *t, const T4PW *w, int lent, const char *p, int lenp, char *tbuf, int tcap) {
   const int L = laneId() & 7, grpBase = laneId() & 56;
+  const T4_LDS_AS char *const pl = (const T4_LDS_AS char *)p;
+  typedef typename T4TbufPtr<TLDS>::type TbufPtr;
+  const TbufPtr tl = (TbufPtr)tbuf;
   unsigned result = 0u;
   bool run = has;
   if (run && (lent == 0 || lenp == 0)) { result = 0u; run = false; }
@@ -1522,10 +1588,74 @@ __device__ __attribute__((noinline)) unsigned dpOct(bool has, const char *t, con
   const int lastPair = run ? lenp + ((W - 1) >> 1) : 0;
   int maxPair = lastPair;
   for (int o = 8; o < 64; o <<= 1) { int v = __shfl_xor(maxPair, o); if (v > maxPair) maxPair = v; }
+#if T4_OPT_OCT2
+  // Straight-line step pair: one exec-masked region per cell, the border closed forms behind a SCALAR test (they can only be
+  // needed while u <= max(8, leftBand + 1)), the three characters of a step fetched one step ahead (clamped indices, loads
+  // unconditional: p and tbuf are valid for every lane), so that the loop body is selects and max3 instead of nested branches.
+  const int uEnd = __builtin_amdgcn_readfirstlane(maxPair);
+  int borderU = run ? (leftBand + 1 > 8 ? leftBand + 1 : 8) : 0;
+  for (int o = 1; o < 64; o <<= 1) { int v = __shfl_xor(borderU, o); if (v > borderU) borderU = v; }
+  const int uBorder = __builtin_amdgcn_readfirstlane(borderU);
+  const int pMax = lenp > 0 ? lenp - 1 : 0, tMax = lent > 0 ? lent - 1 : 0;
+  const int jBase = -L - leftBand + 2 * L;      // j of column A in step u is u + jBase
+  char nPc, nTa = 'A', nTb = 'A';
+  {
+    int ip = 1 - L - 1; ip = ip < 0 ? 0 : (ip > pMax ? pMax : ip);
+    nPc = pl[ip];
+    if (!PW) {
+      int ja = 1 + jBase - 1; ja = ja < 0 ? 0 : (ja > tMax ? tMax : ja);
+      int jb = 1 + jBase;     jb = jb < 0 ? 0 : (jb > tMax ? tMax : jb);
+      nTa = tl[ja]; nTb = tl[jb];
+    }
+  }
+  for (int u = 1; u <= uEnd; ++u) {
+    const int i = u - L;
+    const bool rowOk = run && u <= lastPair && i >= 1 && i <= lenp;
+    const bool border = u <= uBorder;
+    const char pc = nPc, tcA = nTa, tcB = nTb;
+    {
+      int ip = u - L; ip = ip < 0 ? 0 : (ip > pMax ? pMax : ip);            // step u + 1: p[(i + 1) - 1]
+      nPc = pl[ip];
+      if (!PW) {
+        int ja = u + jBase;     ja = ja < 0 ? 0 : (ja > tMax ? tMax : ja);   // tbuf[(jA + 1) - 1]
+        int jb = u + 1 + jBase; jb = jb < 0 ? 0 : (jb > tMax ? tMax : jb);
+        nTa = tl[ja]; nTb = tl[jb];
+      }
+    }
+    // ---- column A = 2L: left neighbour from lane L-1's B (previous pair)
+    int lM = rowUp1E(MB, negInf); unsigned lC0 = rowUp1E(C0B, 0u);
+    int lF = 0; unsigned lC2 = 0;
+    if (!PW) { lF = rowUp1E(FB, negInf); lC2 = rowUp1E(C2B, 0u); }
+    if (L == 0) { lM = negInf; lC0 = 0; lF = negInf; lC2 = 0; }   // the group's first lane: column -1 (the DPP edge only covers the row's)
+    const int oMA = MA; const unsigned oC0A = C0A;                 // A's diagonal neighbour (i-1, 2L): own A of the previous pair
+    const int oMB = MB, oEB = EB; const unsigned oC0B = C0B, oC1B = C1B;   // A's upper and B's diagonal neighbour: own B of the previous pair
+    {
+      const int j = u + jBase;
+      if (rowOk && 2 * L < W && j >= 1 && j <= lent) {
+        bool eq;
+        if (PW) eq = baseEqualW(w[j - 1], pc); else eq = (tcA == pc || tcA == 'N' || pc == 'N');
+        octCell<PW>(border, i, j, eq, e0, q4, oMB, oEB, oC0B, oC1B, lM, lF, lC0, lC2, oMA, oC0A, MA, EA, FA, C0A, C1A, C2A);
+      }
+    }
+    // ---- column B = 2L+1: upper neighbour from lane L+1's A (this pair)
+    int uM = rowDown1E(MA, negInf); unsigned uC0 = rowDown1E(C0A, 0u);
+    int uE = 0; unsigned uC1 = 0;
+    if (!PW) { uE = rowDown1E(EA, negInf); uC1 = rowDown1E(C1A, 0u); }
+    if (L == 7) { uM = negInf; uC0 = 0; uE = negInf; uC1 = 0; }    // column 16 is never inside a band of <= 16 columns
+    {
+      const int j = u + jBase + 1;
+      if (rowOk && 2 * L + 1 < W && j >= 1 && j <= lent) {
+        bool eq;
+        if (PW) eq = baseEqualW(w[j - 1], pc); else eq = (tcB == pc || tcB == 'N' || pc == 'N');
+        octCell<PW>(border, i, j, eq, e0, q4, uM, uE, uC0, uC1, MA, FA, C0A, C2A, oMB, oC0B, MB, EB, FB, C0B, C1B, C2B);   // left: own A of this pair
+      }
+    }
+  }
+#else
   for (int u = 1; u <= maxPair; ++u) {
     const int i = u - L;
     const bool rowOk = run && u <= lastPair && i >= 1 && i <= lenp;
-    const char pc = rowOk ? p[i - 1] : 'A';
+    const char pc = rowOk ? pl[i - 1] : 'A';
     // ---- column A = 2L: left neighbour from lane L-1's B (previous pair)
     int lM = rowUp1E(MB, negInf); unsigned lC0 = rowUp1E(C0B, 0u);
     int lF = 0; unsigned lC2 = 0;
@@ -1568,7 +1698,7 @@ __device__ __attribute__((noinline)) unsigned dpOct(bool has, const char *t, con
           else c = lC0 + CNT_INDEL;
           MA = m; C0A = c;
         } else {
-          const char tc = tbuf[j - 1];
+          const char tc = tl[j - 1];
           const bool eq = (tc == pc || tc == 'N' || pc == 'N');
           int e = uE - 1, eo = uM - 5;
           if (eo > e) e = eo;
@@ -1627,7 +1757,7 @@ __device__ __attribute__((noinline)) unsigned dpOct(bool has, const char *t, con
           else c = bC0 + CNT_INDEL;
           MB = m; C0B = c;
         } else {
-          const char tc = tbuf[j - 1];
+          const char tc = tl[j - 1];
           const bool eq = (tc == pc || tc == 'N' || pc == 'N');
           int e = uE - 1, eo = uM - 5;
           if (eo > e) e = eo;
@@ -1647,6 +1777,7 @@ __device__ __attribute__((noinline)) unsigned dpOct(bool has, const char *t, con
       }
     }
   }
+#endif
   int dF = lent - lenp + leftBand;
   if (dF < 0 || dF > 15) dF = 0;
   const unsigned finA = __shfl(C0A, grpBase + (dF >> 1)), finB = __shfl(C0B, grpBase + (dF >> 1));
@@ -1985,6 +2116,30 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
     nPend += tot;
     __syncthreads();
   }
+#if T4_OPT_JOBSORT
+  // Longest jobs first: a wavefront steps its eight alignments together, i.e. for as long as the longest of them, so batches
+  // of similar length waste the fewest steps (results are sums per overlap: the order of the jobs is not observable).
+  if (nPend > 8 && nPend <= NT) {
+    unsigned job = 0u;
+    if (lane < nPend) {
+      job = wm.cand[lane];
+      const OvRec &o = wm.ov[wm.ord[job & 0xFFFF]];
+      const unsigned *hc = (const unsigned *)(wm.keys + o.chainPos);
+      const int jj = (int)(job >> 16);
+      const int lenp = PA(hc[jj]) - (PA(hc[jj - 1]) + ix.k), lent = PB(hc[jj]) - (PB(hc[jj - 1]) + ix.k);
+      const int steps = lenp + ((10 + (lent > lenp ? lent - lenp : lenp - lent)) >> 1);
+      wm.pairs[lane] = ((unsigned)steps << 16) | (unsigned)(0xFFFF - lane);
+    }
+    __syncthreads();
+    if (lane < nPend) {
+      const unsigned mine = wm.pairs[lane];
+      int rank = 0;
+      for (int j = 0; j < nPend; ++j) rank += wm.pairs[j] > mine ? 1 : 0;
+      wm.cand[rank] = job;
+    }
+    __syncthreads();
+  }
+#endif
   {
     const int wave = lane >> 6, nw = NT >> 6, grp = (lane >> 3) & 7;
     // pairs is dead here (cap >= 1024 ints): one slice per wave, cut into the eight groups' target buffers
@@ -2008,8 +2163,18 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
       const T4SeqInfo si = ix.seqs[o.seqIdx];
       const bool asRef = has && si.isRef, asPw = has && !si.isRef;
       unsigned c = DP_FAIL;
-      if (__any(asRef)) { unsigned v = dpOct<false>(asRef, ix.cons + si.consOff + pb + ix.k, (const T4PW *)0, lent, r, lenp, tbufWave + grp * rowCap, rowCap); if (asRef) c = v; }
-      if (__any(asPw)) { unsigned v = dpOct<true>(asPw, (const char *)0, ix.pw + si.pwOff + pb + ix.k, lent, r, lenp, tbufWave + grp * rowCap, rowCap); if (asPw) c = v; }
+      if (__any(asRef)) {
+        const char *tq = ix.cons + si.consOff + pb + ix.k;
+        unsigned v = wm.ldsArrays ? dpOct<false, true>(asRef, tq, (const T4PW *)0, lent, r, lenp, tbufWave + grp * rowCap, rowCap)
+                                  : dpOct<false, false>(asRef, tq, (const T4PW *)0, lent, r, lenp, tbufWave + grp * rowCap, rowCap);
+        if (asRef) c = v;
+      }
+      if (__any(asPw)) {
+        const T4PW *wq = ix.pw + si.pwOff + pb + ix.k;
+        unsigned v = wm.ldsArrays ? dpOct<true, true>(asPw, (const char *)0, wq, lent, r, lenp, tbufWave + grp * rowCap, rowCap)
+                                  : dpOct<true, false>(asPw, (const char *)0, wq, lent, r, lenp, tbufWave + grp * rowCap, rowCap);
+        if (asPw) c = v;
+      }
       if (has && (lane & 7) == 0) {
         DBG_ADD(1, 1);
         if (c != DP_FAIL) {
@@ -2695,7 +2860,7 @@ void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
   WaveMem wm;
   if (CAP > 0) {
     wm.keys = s_keys; wm.pairs = s_pairs; wm.cand = s_pairs + C; wm.ov = s_ov; wm.fin = s_fin; wm.ord = s_ord;
-    wm.cap = CAP; wm.maxOv = MAXOV; wm.maxFin = MAXOV; wm.candCap = C / 3 + 2;
+    wm.cap = CAP; wm.maxOv = MAXOV; wm.maxFin = MAXOV; wm.candCap = C / 3 + 2; wm.ldsArrays = 1;
   } else {
     size_t b = blockIdx.x;
     wm.keys = wk.gKeys + b * (size_t)wk.gCap;
@@ -2704,20 +2869,29 @@ void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
     wm.ov = (OvRec *)(wk.gOv + b * (size_t)wk.gMaxOv * 10);
     wm.fin = (OvRec *)(wk.gFin + b * (size_t)wk.gMaxOv * 10);
     wm.ord = wk.gOrd + b * (size_t)wk.gMaxOv;
-    wm.cap = wk.gCap; wm.maxOv = wk.gMaxOv; wm.maxFin = wk.gMaxOv; wm.candCap = wk.gCap;
+    wm.cap = wk.gCap; wm.maxOv = wk.gMaxOv; wm.maxFin = wk.gMaxOv; wm.candCap = wk.gCap; wm.ldsArrays = 0;
   }
   wm.seg = s_seg; wm.rc = s_rc;
   DPScratch sc;
   sc.rows = wk.dpRows + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (6 * T4_ROWW * 64);
   sc.dir = wk.dpDir + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * T4_DIR_BYTES;
-  for (int w = blockIdx.x; w < wk.nList; w += gridDim.x) {
+  // Persistent grid; the cost of a read varies by orders of magnitude, so a block fetches its next list position from a counter
+  // when it is done with one (a static stride leaves most of the grid waiting for the unluckiest block at the end of a launch).
+  __shared__ int s_nextW;
+  int w = blockIdx.x;
+  while (w < wk.nList) {
     long long r = wk.list[w];
     if (VARIANT == 2) ix = qa.views[qa.viewOf[r]];   // uniform address: scalar loads
     bool done = processRead<(VARIANT == 0 ? 0 : VARIANT == 3 ? 3 : 1)>(ix, bv, wk, qa, wm, &s_ws, r, sc);
-    if (!done && tid() == 0) {
-      if (wk.nextList) { int slot = atomicAdd(wk.nextCount, 1); wk.nextList[slot] = (int)r; }
-      else wk.status[r] = 2;
+    if (tid() == 0) {
+      if (!done) {
+        if (wk.nextList) { int slot = atomicAdd(wk.nextCount, 1); wk.nextList[slot] = (int)r; }
+        else wk.status[r] = 2;
+      }
+      s_nextW = wk.workNext ? (int)gridDim.x + atomicAdd(wk.workNext, 1) : w + (int)gridDim.x;
     }
+    __syncthreads();
+    w = s_nextW;
     __syncthreads();
   }
 }
@@ -2900,8 +3074,8 @@ __global__ __launch_bounds__(64) void gapDpKernel(int kind, int impl, int n, con
       const bool fits = has && lenp <= T4_MAXGAP && lent <= T4_MAXGAP;
       if (fits) for (int j = lane & 7; j < lenp; j += 8) s_p[grp][j] = pChars[pOff[i] + j];
       __syncthreads();
-      unsigned c = kind == 0 ? dpOct<false>(fits, tChars + (has ? tOff[i] : 0), (const T4PW *)0, lent, s_p[grp], lenp, s_p[8 + grp], T4_MAXGAP)
-                             : dpOct<true>(fits, (const char *)0, tW + (has ? tOff[i] : 0), lent, s_p[grp], lenp, s_p[8 + grp], T4_MAXGAP);
+      unsigned c = kind == 0 ? dpOct<false, true>(fits, tChars + (has ? tOff[i] : 0), (const T4PW *)0, lent, s_p[grp], lenp, s_p[8 + grp], T4_MAXGAP)
+                             : dpOct<true, true>(fits, (const char *)0, tW + (has ? tOff[i] : 0), lent, s_p[grp], lenp, s_p[8 + grp], T4_MAXGAP);
       if (!fits) c = DP_FAIL;
       __syncthreads();
       if (has && (lane & 7) == 0) {
