@@ -35,7 +35,7 @@ const int TIER_CAP[T4_NTIER - 1] = {1024, 2048, 3072, 4096, 8192};
 // 8 x 20 KB of LDS, tier 1 4 groups of 4 waves in 4 x 39 KB, both at 128 VGPRs (4 waves / SIMD); the 3072-hit tier exists
 // because 3 of its groups fit a CU where only 2 of the 4096-hit tier do. 512/1024 threads per read in the upper tiers
 // measured slower (barriers).
-const int TIER_THREADS[T4_NTIER] = {128, 256, 256, 256, 256, 256};
+const int TIER_THREADS[T4_NTIER] = {128, 256, 256, 256, 512, 256};   // the 8192-hit tier has one group per CU (LDS): eight waves of it
 const int TIER_BLOCKS_PER_CU[T4_NTIER] = {8, 4, 3, 2, 1, 2};
 const int G_CAP = 32768, G_MAXOV = 4096;
 
@@ -585,7 +585,13 @@ int runQuery(t4_index *ix, t4_batch *b, T4QueryArgs qa, bool useBarcode, bool no
   int r;
   int grids[T4_NTIER];
   int maxGrid = 1;
-  for (int t = 0; t < T4_NTIER; ++t) { grids[t] = c->cus * TIER_BLOCKS_PER_CU[t]; if (grids[t] * TIER_THREADS[t] > maxGrid) maxGrid = grids[t] * TIER_THREADS[t]; }
+  static const int bigThreads[3] = {getenv("T4_T2_THREADS") ? atoi(getenv("T4_T2_THREADS")) : TIER_THREADS[2], getenv("T4_T3_THREADS") ? atoi(getenv("T4_T3_THREADS")) : TIER_THREADS[3],
+                                    getenv("T4_T4_THREADS") ? atoi(getenv("T4_T4_THREADS")) : TIER_THREADS[4]};
+  for (int t = 0; t < T4_NTIER; ++t) {
+    grids[t] = c->cus * TIER_BLOCKS_PER_CU[t];
+    const int th = (t >= 2 && t <= 4) ? bigThreads[t - 2] : TIER_THREADS[t];
+    if (grids[t] * th > maxGrid) maxGrid = grids[t] * th;
+  }
   if ((r = ensureScratch(c, maxGrid))) return r;
   if ((r = ensurePerCall(c, n))) return r;
   HIPCHK(c, hipMemsetAsync(c->listCounts, 0, sizeof(int) * 16, c->stream));   // [0..8) tier counts, [8..16) tier work counters
@@ -595,7 +601,8 @@ int runQuery(t4_index *ix, t4_batch *b, T4QueryArgs qa, bool useBarcode, bool no
   T4TierCaps caps;
   for (int t = 0; t < T4_NTIER - 1; ++t) caps.cap[t] = TIER_CAP[t];
   if (noHits) caps.cap[0] = 1 << 30;
-  int binGrid = c->cus * 8;
+  static const int binBlocks = getenv("T4_BIN_BLOCKS") ? atoi(getenv("T4_BIN_BLOCKS")) : 8;
+  int binGrid = c->cus * binBlocks;
   if ((long long)binGrid > n) binGrid = (int)n;
   hipLaunchKernelGGL(t4k::binKernel, dim3(binGrid), dim3(64), 0, c->stream, ix->view, b->view, useBarcode ? 1 : 0,
                      caps, c->lists, c->listCounts, (long long)n);
@@ -642,9 +649,9 @@ int runQuery(t4_index *ix, t4_batch *b, T4QueryArgs qa, bool useBarcode, bool no
       if (mo1 == 64) launchTier<2048, 64, 256>(g1, c->stream, ix->view, b->view, wk, qa);
       else launchTier<2048, 128, 256>(g1, c->stream, ix->view, b->view, wk, qa);
     }
-    else if (t == 2) launchTier<3072, 128, 256>(grid, c->stream, ix->view, b->view, wk, qa);
-    else if (t == 3) launchTier<4096, 256, 256>(grid, c->stream, ix->view, b->view, wk, qa);
-    else launchTier<8192, 512, 256>(grid, c->stream, ix->view, b->view, wk, qa);
+    else if (t == 2) { if (bigThreads[0] == 512) launchTier<3072, 128, 512>(grid, c->stream, ix->view, b->view, wk, qa); else launchTier<3072, 128, 256>(grid, c->stream, ix->view, b->view, wk, qa); }
+    else if (t == 3) { if (bigThreads[1] == 512) launchTier<4096, 256, 512>(grid, c->stream, ix->view, b->view, wk, qa); else launchTier<4096, 256, 256>(grid, c->stream, ix->view, b->view, wk, qa); }
+    else { if (bigThreads[2] == 512) launchTier<8192, 512, 512>(grid, c->stream, ix->view, b->view, wk, qa); else launchTier<8192, 512, 256>(grid, c->stream, ix->view, b->view, wk, qa); }
     HIPCHK(c, hipGetLastError());
     ++c->stats.launches;
   }
