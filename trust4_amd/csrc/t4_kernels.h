@@ -2920,8 +2920,14 @@ __global__ __launch_bounds__(64) void binKernel(T4IndexView ix, T4BatchView bv, 
   __shared__ char s_seg[T4_MAXL + 8];
   __shared__ char s_rc[T4_MAXL + 8];
   __shared__ int s_red[16];
+  // Reads are appended to their tier's list 64 at a time: one atomicAdd per read on the same few counters bounded this kernel
+  // (2 M same-address atomics took ~20 of its 23.5 ms); the order inside a list is not observable.
+  __shared__ int s_buf[T4_NTIER][64];
+  __shared__ int s_cnt[T4_NTIER];
   WaveMem wm;
   wm.seg = s_seg; wm.rc = s_rc;
+  if (laneId() < T4_NTIER) s_cnt[laneId()] = 0;
+  __syncthreads();
   for (long long r = blockIdx.x; r < bv.n; r += gridDim.x) {
     int len = bv.len[r];
     int H = 0;
@@ -2930,13 +2936,28 @@ __global__ __launch_bounds__(64) void binKernel(T4IndexView ix, T4BatchView bv, 
       int barcode = (useBarcode && bv.barcode) ? bv.barcode[r] : -1;
       H = seedPositions(ix, wm, len, 0, barcode, false, s_posStart, s_posPref, s_red);
     }
-    if (laneId() == 0) {
-      int t = 0;
-      while (t < T4_NTIER - 1 && H > caps.cap[t]) ++t;
-      int slot = atomicAdd(&counts[t], 1);
-      lists[t * listStride + slot] = (int)r;
-    }
+    H = __shfl(H, 0);
+    int t = 0;
+    while (t < T4_NTIER - 1 && H > caps.cap[t]) ++t;
+    if (laneId() == 0) { s_buf[t][s_cnt[t]] = (int)r; ++s_cnt[t]; }
     __syncthreads();
+    const int filled = s_cnt[t];
+    __syncthreads();        // everyone has read the count before lane 0 resets it
+    if (filled == 64) {     // uniform
+      int base = 0;
+      if (laneId() == 0) { base = atomicAdd(&counts[t], 64); s_cnt[t] = 0; }
+      base = __shfl(base, 0);
+      lists[t * listStride + base + laneId()] = s_buf[t][laneId()];
+      __syncthreads();
+    }
+  }
+  for (int t = 0; t < T4_NTIER; ++t) {
+    const int n = s_cnt[t];
+    if (n == 0) continue;   // uniform
+    int base = 0;
+    if (laneId() == 0) base = atomicAdd(&counts[t], n);
+    base = __shfl(base, 0);
+    if (laneId() < n) lists[t * listStride + base + laneId()] = s_buf[t][laneId()];
   }
 }
 
