@@ -28,9 +28,6 @@ namespace t4k {
 #ifndef T4_OPT_JOBSORT
 #define T4_OPT_JOBSORT 1
 #endif
-#ifndef T4_OPT_OCT2
-#define T4_OPT_OCT2 0
-#endif
 #ifndef T4_OPT_ROWWALK
 #define T4_OPT_ROWWALK 1
 #endif
@@ -1486,52 +1483,6 @@ __device__ unsigned dpWave(const char *t, const T4PW *w, int lent, const char *p
 template <bool LDS> struct T4TbufPtr { typedef const char *type; };
 template <> struct T4TbufPtr<true> { typedef const T4_LDS_AS char *type; };
 
-// One cell (i, j) of dpOct from its upper (i-1, j), left (i, j-1) and diagonal (i-1, j-1) neighbours, branch-free. `border`
-// is wave-uniform: while it holds, neighbours in row 0 / column 0 take the reference's closed forms (its matrices have the
-// whole first row and column initialised, also outside the band).
-template <bool PW>
-__device__ __forceinline__ void octCell(bool border, int i, int j, bool eq, int e0, int q4, int uM, int uE, unsigned uC0, unsigned uC1,
-                                        int lM, int lF, unsigned lC0, unsigned lC2, int dM, unsigned dC0,
-                                        int &M, int &E, int &F, unsigned &C0, unsigned &C1, unsigned &C2) {
-  if (border) {
-    const bool j1 = j == 1, i1 = i == 1;
-    lM = j1 ? -4 - 4 * i : lM;
-    if (PW) lC0 = j1 ? CNT_MATCH + CNT_INDEL * (unsigned)(i - 1) : lC0;
-    else { lF = j1 ? -4 - 4 * i : lF; lC0 = j1 ? CNT_INDEL * (unsigned)i : lC0; lC2 = j1 ? CNT_INDEL * (unsigned)(1 + i) : lC2; }
-    uM = i1 ? -4 - 4 * j : uM;
-    if (PW) uC0 = i1 ? CNT_MATCH + CNT_INDEL * (unsigned)(j - 1) : uC0;
-    else { uE = i1 ? e0 : uE; uC0 = i1 ? CNT_INDEL * (unsigned)(j + (j > q4 ? 1 : 0)) : uC0; uC1 = i1 ? CNT_INDEL * (unsigned)(1 + j) : uC1; }
-    const int jj = j - 1;
-    const int dMi = jj == 0 ? 0 : -4 - 4 * jj;                                       // (0, j-1)
-    const unsigned dCi = jj == 0 ? 0u : (PW ? CNT_MATCH + CNT_INDEL * (unsigned)(jj - 1) : CNT_INDEL * (unsigned)(jj + (jj > q4 ? 1 : 0)));
-    const int dMj = -4 - 4 * (i - 1);                                                // (i-1, 0), i >= 2
-    const unsigned dCj = PW ? CNT_MATCH + CNT_INDEL * (unsigned)(i - 2) : CNT_INDEL * (unsigned)(i - 1);
-    dM = i1 ? dMi : (j1 ? dMj : dM);
-    dC0 = i1 ? dCi : (j1 ? dCj : dC0);
-  }
-  const int dsc = dM + (eq ? 2 : -2);
-  const unsigned cd = dC0 + (eq ? CNT_MATCH : CNT_MIS);
-  if (PW) {
-    const int lm = lM - 4, um = uM - 4;
-    int m = lm > um ? lm : um;
-    m = dsc > m ? dsc : m;
-    C0 = (dsc == m) ? cd : ((um == m) ? uC0 + CNT_INDEL : lC0 + CNT_INDEL);
-    M = m;
-  } else {
-    const int eo = uM - 5, fo = lM - 5;
-    int e = uE - 1, f = lF - 1;
-    e = eo > e ? eo : e;
-    f = fo > f ? fo : f;
-    int m = e > f ? e : f;
-    m = dsc > m ? dsc : m;
-    const unsigned c1 = CNT_INDEL + ((eo == e) ? uC0 : uC1);
-    const unsigned c2 = CNT_INDEL + ((fo == f) ? lC0 : lC2);
-    C0 = (dsc == m) ? cd : ((f >= e) ? c2 : c1);
-    M = m; E = e; F = f; C1 = c1; C2 = c2;
-  }
-}
-
-
 // The same recurrences with EIGHT alignments per wavefront and no idle cell slot. A band is 11 + |lent - lenp| columns,
 // almost always <= 16; in the skewed order s = 2i + d a lane that owns ONE column has a cell only every other step. So
 // lane L of a group of 8 owns the column pair (2L, 2L+1): in step pair u it computes row i = u - L of both columns,
@@ -1588,70 +1539,6 @@ __device__ __attribute__((noinline)) unsigned dpOct(bool has, const char *t, con
   const int lastPair = run ? lenp + ((W - 1) >> 1) : 0;
   int maxPair = lastPair;
   for (int o = 8; o < 64; o <<= 1) { int v = __shfl_xor(maxPair, o); if (v > maxPair) maxPair = v; }
-#if T4_OPT_OCT2
-  // Straight-line step pair: one exec-masked region per cell, the border closed forms behind a SCALAR test (they can only be
-  // needed while u <= max(8, leftBand + 1)), the three characters of a step fetched one step ahead (clamped indices, loads
-  // unconditional: p and tbuf are valid for every lane), so that the loop body is selects and max3 instead of nested branches.
-  const int uEnd = __builtin_amdgcn_readfirstlane(maxPair);
-  int borderU = run ? (leftBand + 1 > 8 ? leftBand + 1 : 8) : 0;
-  for (int o = 1; o < 64; o <<= 1) { int v = __shfl_xor(borderU, o); if (v > borderU) borderU = v; }
-  const int uBorder = __builtin_amdgcn_readfirstlane(borderU);
-  const int pMax = lenp > 0 ? lenp - 1 : 0, tMax = lent > 0 ? lent - 1 : 0;
-  const int jBase = -L - leftBand + 2 * L;      // j of column A in step u is u + jBase
-  char nPc, nTa = 'A', nTb = 'A';
-  {
-    int ip = 1 - L - 1; ip = ip < 0 ? 0 : (ip > pMax ? pMax : ip);
-    nPc = pl[ip];
-    if (!PW) {
-      int ja = 1 + jBase - 1; ja = ja < 0 ? 0 : (ja > tMax ? tMax : ja);
-      int jb = 1 + jBase;     jb = jb < 0 ? 0 : (jb > tMax ? tMax : jb);
-      nTa = tl[ja]; nTb = tl[jb];
-    }
-  }
-  for (int u = 1; u <= uEnd; ++u) {
-    const int i = u - L;
-    const bool rowOk = run && u <= lastPair && i >= 1 && i <= lenp;
-    const bool border = u <= uBorder;
-    const char pc = nPc, tcA = nTa, tcB = nTb;
-    {
-      int ip = u - L; ip = ip < 0 ? 0 : (ip > pMax ? pMax : ip);            // step u + 1: p[(i + 1) - 1]
-      nPc = pl[ip];
-      if (!PW) {
-        int ja = u + jBase;     ja = ja < 0 ? 0 : (ja > tMax ? tMax : ja);   // tbuf[(jA + 1) - 1]
-        int jb = u + 1 + jBase; jb = jb < 0 ? 0 : (jb > tMax ? tMax : jb);
-        nTa = tl[ja]; nTb = tl[jb];
-      }
-    }
-    // ---- column A = 2L: left neighbour from lane L-1's B (previous pair)
-    int lM = rowUp1E(MB, negInf); unsigned lC0 = rowUp1E(C0B, 0u);
-    int lF = 0; unsigned lC2 = 0;
-    if (!PW) { lF = rowUp1E(FB, negInf); lC2 = rowUp1E(C2B, 0u); }
-    if (L == 0) { lM = negInf; lC0 = 0; lF = negInf; lC2 = 0; }   // the group's first lane: column -1 (the DPP edge only covers the row's)
-    const int oMA = MA; const unsigned oC0A = C0A;                 // A's diagonal neighbour (i-1, 2L): own A of the previous pair
-    const int oMB = MB, oEB = EB; const unsigned oC0B = C0B, oC1B = C1B;   // A's upper and B's diagonal neighbour: own B of the previous pair
-    {
-      const int j = u + jBase;
-      if (rowOk && 2 * L < W && j >= 1 && j <= lent) {
-        bool eq;
-        if (PW) eq = baseEqualW(w[j - 1], pc); else eq = (tcA == pc || tcA == 'N' || pc == 'N');
-        octCell<PW>(border, i, j, eq, e0, q4, oMB, oEB, oC0B, oC1B, lM, lF, lC0, lC2, oMA, oC0A, MA, EA, FA, C0A, C1A, C2A);
-      }
-    }
-    // ---- column B = 2L+1: upper neighbour from lane L+1's A (this pair)
-    int uM = rowDown1E(MA, negInf); unsigned uC0 = rowDown1E(C0A, 0u);
-    int uE = 0; unsigned uC1 = 0;
-    if (!PW) { uE = rowDown1E(EA, negInf); uC1 = rowDown1E(C1A, 0u); }
-    if (L == 7) { uM = negInf; uC0 = 0; uE = negInf; uC1 = 0; }    // column 16 is never inside a band of <= 16 columns
-    {
-      const int j = u + jBase + 1;
-      if (rowOk && 2 * L + 1 < W && j >= 1 && j <= lent) {
-        bool eq;
-        if (PW) eq = baseEqualW(w[j - 1], pc); else eq = (tcB == pc || tcB == 'N' || pc == 'N');
-        octCell<PW>(border, i, j, eq, e0, q4, uM, uE, uC0, uC1, MA, FA, C0A, C2A, oMB, oC0B, MB, EB, FB, C0B, C1B, C2B);   // left: own A of this pair
-      }
-    }
-  }
-#else
   for (int u = 1; u <= maxPair; ++u) {
     const int i = u - L;
     const bool rowOk = run && u <= lastPair && i >= 1 && i <= lenp;
@@ -1777,7 +1664,6 @@ __device__ __attribute__((noinline)) unsigned dpOct(bool has, const char *t, con
       }
     }
   }
-#endif
   int dF = lent - lenp + leftBand;
   if (dF < 0 || dF > 15) dF = 0;
   const unsigned finA = __shfl(C0A, grpBase + (dF >> 1)), finB = __shfl(C0B, grpBase + (dF >> 1));
