@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/trust4_hip.h"
@@ -89,21 +90,32 @@ int main(int argc, char *argv[]) {
   if (barcodeStart != 0 || barcodeEnd != -1 || barcodeRevComp) fmt.addSegment(barcodeStart, barcodeEnd, barcodeRevComp ? -1 : 1, FMT_BARCODE);
   if (umiStart != 0 || umiEnd != -1 || umiRevComp) fmt.addSegment(umiStart, umiEnd, umiRevComp ? -1 : 1, FMT_UMI);
 
+  // The device, its runtime and the reference set come up on their own thread while the first batch of reads is parsed;
+  // gpuReady() (first candidate test) joins it, reports its errors as the serial code did and commits the set.
   t4_ctx *ctx = nullptr;
-  int rc = t4_init(getenv("T4_DEVICE") ? atoi(getenv("T4_DEVICE")) : 0, &ctx);
-  if (rc) { fprintf(stderr, "fastq-extractor-hip needs an MI355X (t4_init failed: %d); there is no CPU path.\n", rc); return EXIT_FAILURE; }
   t4_index *refSet = nullptr;
-  if ((rc = t4_index_create(ctx, 9, 0, &refSet))) die(ctx, "t4_index_create", rc);
-  if ((rc = t4_index_load_ref_fasta(refSet, refFa.c_str()))) die(ctx, "t4_index_load_ref_fasta", rc);
+  int rc = 0, initRc = 0, hitLenRequired = 27;
+  const char *initWhat = nullptr;
+  std::thread initThread([&]() {
+    if ((initRc = t4_init(getenv("T4_DEVICE") ? atoi(getenv("T4_DEVICE")) : 0, &ctx))) { initWhat = "t4_init"; return; }
+    if ((initRc = t4_index_create(ctx, 9, 0, &refSet))) { initWhat = "t4_index_create"; return; }
+    if ((initRc = t4_index_load_ref_fasta(refSet, refFa.c_str()))) initWhat = "t4_index_load_ref_fasta";
+  });
+  auto gpuReady = [&]() {
+    if (!initThread.joinable()) return;
+    initThread.join();
+    if (initRc && !ctx) { fprintf(stderr, "fastq-extractor-hip needs an MI355X (t4_init failed: %d); there is no CPU path.\n", initRc); exit(EXIT_FAILURE); }
+    if (initRc) die(ctx, initWhat, initRc);
+    if ((rc = t4_index_set_params(refSet, hitLenRequired, 10, 0.9))) die(ctx, "t4_index_set_params", rc);
+    if ((rc = t4_index_commit(refSet))) die(ctx, "t4_index_commit", rc);
+  };
 
   // hitLenRequired from the first 1000 reads (FastqExtractor.cpp:436-455)
-  int hitLenRequired = 27, i, len = 0;
+  int i, len = 0;
   for (i = 0; i < 1000; ++i) { if (!reads.next()) break; len += (int)reads.seq.size(); }
-  if (i == 0) { fprintf(stderr, "Read file is empty.\n"); return EXIT_FAILURE; }
+  if (i == 0) { fprintf(stderr, "Read file is empty.\n"); gpuReady(); return EXIT_FAILURE; }
   if (len / (i * 5) > hitLenRequired) hitLenRequired = len / (i * 5);
   if (hitLenRequired > 101) hitLenRequired = 101;
-  if ((rc = t4_index_set_params(refSet, hitLenRequired, 10, 0.9))) die(ctx, "t4_index_set_params", rc);
-  if ((rc = t4_index_commit(refSet))) die(ctx, "t4_index_commit", rc);
   reads.rewind();
   if (hasBarcode && hasWhitelist) {   // BarcodeCorrector::CollectBackgroundDistribution (BarcodeCorrector.hpp:141-153): first 2 M barcodes
     int n = 0;
@@ -115,7 +127,7 @@ int main(int argc, char *argv[]) {
   FILE *fpUmi = hasUmi ? fopen((prefix + "_umi.fa").c_str(), "w") : nullptr;
   FILE *fp1 = fopen((prefix + (hasMate ? "_1.fq" : ".fq")).c_str(), "w");
   FILE *fp2 = hasMate ? fopen((prefix + "_2.fq").c_str(), "w") : nullptr;
-  if (!fp1 || (hasMate && !fp2)) { fprintf(stderr, "Could not open the output files of %s\n", prefix.c_str()); return EXIT_FAILURE; }
+  if (!fp1 || (hasMate && !fp2)) { fprintf(stderr, "Could not open the output files of %s\n", prefix.c_str()); gpuReady(); return EXIT_FAILURE; }
   auto outputSeq = [&](FILE *fp, const std::string &name, const Rec &r, int cat) {   // OutputSeq (FastqExtractor.cpp:136-143)
     if (r.hasQual) fprintf(fp, "@%s\n%s\n+\n%s\n", name.c_str(), fmt.extract(&r.seq, cat, true).c_str(), fmt.extract(&r.qual, cat, false).c_str());
     else fprintf(fp, ">%s\n%s\n", name.c_str(), fmt.extract(&r.seq, cat, true).c_str());
@@ -160,6 +172,7 @@ int main(int argc, char *argv[]) {
       bases += rs[k].seq; off.push_back((int64_t)bases.size()); which.push_back((int)k);
     }
     if (which.empty()) return;
+    gpuReady();
     t4_batch *b = nullptr;
     if ((rc = t4_reads_upload(ctx, bases.data(), off.data(), nullptr, (int64_t)which.size(), &b))) die(ctx, "t4_reads_upload", rc);
     std::vector<int32_t> out(which.size());
@@ -185,9 +198,9 @@ int main(int argc, char *argv[]) {
     r1.clear(); r2.clear(); rb.clear(); ru.clear();
   };
   while (reads.next()) {
-    if (hasMate && !mateReads.next()) { fprintf(stderr, "The two mate-pair read files have different number of reads.\n"); exit(1); }
-    if (hasBarcode && !barcodeFile.next()) { fprintf(stderr, "Read file and barcode file  have different number of reads.\n"); exit(1); }
-    if (hasUmi && !umiFile.next()) { fprintf(stderr, "Read file and UMI file have different number of reads.\n"); exit(1); }
+    if (hasMate && !mateReads.next()) { fprintf(stderr, "The two mate-pair read files have different number of reads.\n"); if (initThread.joinable()) initThread.join(); exit(1); }
+    if (hasBarcode && !barcodeFile.next()) { fprintf(stderr, "Read file and barcode file  have different number of reads.\n"); if (initThread.joinable()) initThread.join(); exit(1); }
+    if (hasUmi && !umiFile.next()) { fprintf(stderr, "Read file and UMI file have different number of reads.\n"); if (initThread.joinable()) initThread.join(); exit(1); }
     r1.push_back(Rec{reads.id, reads.seq, reads.qual, std::string(), reads.hasQual});
     if (hasMate) r2.push_back(Rec{mateReads.id, mateReads.seq, mateReads.qual, std::string(), mateReads.hasQual});
     if (hasBarcode) rb.push_back(Rec{barcodeFile.id, barcodeFile.seq, barcodeFile.qual, barcodeFile.comment, barcodeFile.hasQual});
@@ -200,6 +213,7 @@ int main(int argc, char *argv[]) {
   if (fpBc) fclose(fpBc);
   if (fpUmi) fclose(fpUmi);
   fprintf(stderr, "fastq-extractor-hip: %lld of %lld %s kept (hitLenRequired %d)\n", kept, total, hasMate ? "pairs" : "reads", hitLenRequired);
+  gpuReady();   // also when no read needed the candidate test: a missing GPU is still an error
   t4_index_destroy(refSet);
   t4_destroy(ctx);
   return 0;

@@ -406,15 +406,28 @@ int main(int argc, char *argv[]) {
   if (getenv("T4_THREADS")) threadCnt = atoi(getenv("T4_THREADS")) > 0 ? atoi(getenv("T4_THREADS")) : 1;
   if (shardCount > 1 && (!hasBarcode || keepMissingBarcode)) { fprintf(stderr, "--cellShard needs --barcode: without barcodes the Add pass does not shard (DESIGN.md 6).\n"); return EXIT_FAILURE; }
 
+  // The device, its runtime and the reference set come up on their own thread while the reads are parsed, merged and counted
+  // (nothing before the rough annotation touches the GPU); gpuReady() joins it and reports its errors as the serial code did.
   t4_ctx *ctx = nullptr;
-  int rc = t4_init(getenv("T4_DEVICE") ? atoi(getenv("T4_DEVICE")) : 0, &ctx);
-  if (rc) { fprintf(stderr, "trust4-hip needs an MI355X (t4_init failed: %d); there is no CPU path.\n", rc); return EXIT_FAILURE; }
   t4_index *refSet = nullptr;
-  if ((rc = t4_index_create(ctx, trimLevel > 1 ? 7 : 9, 0, &refSet))) die(ctx, "t4_index_create", rc);
-  if ((rc = t4_index_set_params(refSet, 17, trimLevel > 1 ? 0 : 10, 0.9))) die(ctx, "t4_index_set_params", rc);
-  if ((rc = t4_index_load_ref_fasta(refSet, refFa.c_str()))) die(ctx, "t4_index_load_ref_fasta", rc);
-  if (t4_index_size(refSet) == 0) { fprintf(stderr, "Need to use -f to specify the receptor genome sequence.\n"); return EXIT_FAILURE; }
-  if ((rc = t4_index_commit(refSet))) die(ctx, "t4_index_commit", rc);
+  int rc = 0, initRc = 0;
+  const char *initWhat = nullptr;
+  std::thread initThread([&]() {
+    if ((initRc = t4_init(getenv("T4_DEVICE") ? atoi(getenv("T4_DEVICE")) : 0, &ctx))) { initWhat = "t4_init"; return; }
+    if ((initRc = t4_index_create(ctx, trimLevel > 1 ? 7 : 9, 0, &refSet))) { initWhat = "t4_index_create"; return; }
+    if ((initRc = t4_index_set_params(refSet, 17, trimLevel > 1 ? 0 : 10, 0.9))) { initWhat = "t4_index_set_params"; return; }
+    if ((initRc = t4_index_load_ref_fasta(refSet, refFa.c_str()))) { initWhat = "t4_index_load_ref_fasta"; return; }
+    if (t4_index_size(refSet) == 0) return;
+    if ((initRc = t4_index_commit(refSet))) initWhat = "t4_index_commit";
+  });
+  auto gpuReady = [&]() {
+    if (!initThread.joinable()) return;
+    initThread.join();
+    if (initRc && !ctx) { fprintf(stderr, "trust4-hip needs an MI355X (t4_init failed: %d); there is no CPU path.\n", initRc); exit(EXIT_FAILURE); }
+    if (initRc) die(ctx, initWhat, initRc);
+    if (t4_index_size(refSet) == 0) { fprintf(stderr, "Need to use -f to specify the receptor genome sequence.\n"); exit(EXIT_FAILURE); }
+  };
+  if (getenv("T4_SYNC_INIT")) gpuReady();   // the serial order, for timing comparisons
   PrintLog("Start to assemble reads.");
 
   // ---- read input, mate processing, 21-mer counting (main.cpp:787-915)
@@ -470,7 +483,7 @@ int main(int argc, char *argv[]) {
       mate.id = mateReads.id; mate.read = mateReads.seq; mate.qual = mateReads.qual; mate.hasQual = mateReads.hasQual;
       ++nIn;
       if (nIn % 100000 == 0) PrintLog("Read in and count kmers for %d reads.", nIn);
-    } else if (hasMate) { fprintf(stderr, "The two mate-pair read files have different number of reads.\n"); exit(1); }
+    } else if (hasMate) { fprintf(stderr, "The two mate-pair read files have different number of reads.\n"); initThread.join(); exit(1); }
     block.push_back(InPair{std::move(nr), std::move(mate), haveMate});
     if (block.size() >= BLOCK) flushBlock();
   }
@@ -481,11 +494,12 @@ int main(int argc, char *argv[]) {
   for (const SortRead &r : sortedReads) if ((int)r.read.size() > maxReadLen) maxReadLen = (int)r.read.size();
   kmerCount.maxReadLen = maxReadLen;   // KmerCount::SetBuffer (main.cpp:979)
   if (!kmerCountFile.empty()) {   // -c: counts come from a k-mer counter's dump instead (main.cpp:694-699)
-    if (!kmerCount.addCountFromFile(kmerCountFile.c_str())) { fprintf(stderr, "Could not open %s\n", kmerCountFile.c_str()); return EXIT_FAILURE; }
+    if (!kmerCount.addCountFromFile(kmerCountFile.c_str())) { fprintf(stderr, "Could not open %s\n", kmerCountFile.c_str()); initThread.join(); return EXIT_FAILURE; }
     PrintLog("Read in the kmer count information from %s", kmerCountFile.c_str());
   } else
   kmerCount.addCountAll((long long)sortedReads.size(), threadCnt, [&](long long i) -> const std::string & { return sortedReads[(size_t)i].read; });
   if (getenv("T4_TIMING")) PrintLog("timing: 21-mers counted");
+  gpuReady();
   auto writeEmpty = [&](const char *suffix) { FILE *fp = fopen((outputPrefix + suffix).c_str(), "w"); if (fp) fclose(fp); };
   if (readCnt <= 0) { writeEmpty("_raw.out"); writeEmpty("_assembled_reads.fa"); writeEmpty("_final.out"); return 0; }
 
