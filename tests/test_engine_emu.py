@@ -434,3 +434,20 @@ def check_long_reads_and_limits(eng, n=40):
 
 def test_long_reads_and_limits(emu_engine):
     check_long_reads_and_limits(emu_engine, n=12)
+
+
+def test_work_distribution_is_not_observable(emu_engine, ref_index, monkeypatch):
+    """Blocks fetch their next read from a per-launch counter (or stride statically under T4_STATIC_STRIDE); the tier lists are
+    appended 64 reads at a time in whatever order the blocks get there. Neither may change a result."""
+    reads = rows_to_strs(Synth(300, 11).next_reads(150)) + ["A" * 150, "ACGTACGTA", "", "N" * 40]
+    b = emu_engine.upload(reads)
+    monkeypatch.delenv("T4_STATIC_STRIDE", raising=False)
+    a1 = ref_index.annotate_rough(b).copy()
+    tiers = emu_engine.stats()["tier_reads"]
+    assert sum(tiers) == len(reads) and sum(1 for x in tiers if x) >= 2   # more than one tier list was filled
+    monkeypatch.setenv("T4_STATIC_STRIDE", "1")
+    a2 = ref_index.annotate_rough(b).copy()
+    assert a1.tobytes() == a2.tobytes()
+    rev = emu_engine.upload(reads[::-1])                                # another list order, another batch composition
+    a3 = ref_index.annotate_rough(rev).copy()
+    assert a1.tobytes() == a3[::-1].tobytes()
