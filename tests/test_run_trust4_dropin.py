@@ -1,0 +1,109 @@
+"""Process-level drop-in: the reference's own `run-trust4` driver runs the whole pipeline twice -- once over the
+reference binaries, once with `trust4` and `fastq-extractor` replaced by this repo's programs -- and every file it leaves behind must
+be byte-identical (stage-0 candidates, stage-1 contigs, and everything the reference's annotator and report scripts derive from them).
+
+`run-trust4` finds its programs next to itself, so each run gets a scratch directory holding a copy of the script (made at test
+time, from /root/reference, into tmp -- nothing of the reference enters the repo), links to the reference's perl report scripts
+and links named `trust4` / `fastq-extractor` / `annotator` that point at the binaries under test. Needs /root/reference and perl:
+it runs in the development container (emulator build of the kernels, CPU) and, with `-m gpu`, against the hipcc build where the
+reference tree exists."""
+import filecmp
+import gzip
+import os
+import shutil
+import subprocess
+
+import pytest
+
+import t4libs
+from t4libs import REF_FA, ROOT
+
+REF_TREE = "/root/reference"
+REF_BIN = os.path.join(ROOT, "oracle", "_ref")
+needs_reference = pytest.mark.skipif(
+    not (os.path.exists(os.path.join(REF_TREE, "run-trust4")) and shutil.which("perl")
+         and all(os.path.exists(os.path.join(REF_BIN, b)) for b in ("trust4", "fastq-extractor", "annotator"))),
+    reason="needs /root/reference (run-trust4, report scripts), perl and oracle/_ref/{trust4,fastq-extractor,annotator}")
+
+
+def install_dir(path, trust4_bin, extractor_bin):
+    os.makedirs(path)
+    shutil.copy(os.path.join(REF_TREE, "run-trust4"), os.path.join(path, "run-trust4"))   # abs_path($0) must resolve to THIS directory
+    for f in os.listdir(REF_TREE):
+        if f.endswith(".pl"):
+            os.symlink(os.path.join(REF_TREE, f), os.path.join(path, f))
+    os.symlink(trust4_bin, os.path.join(path, "trust4"))
+    os.symlink(extractor_bin, os.path.join(path, "fastq-extractor"))
+    os.symlink(os.path.join(REF_BIN, "annotator"), os.path.join(path, "annotator"))
+    return os.path.join(path, "run-trust4")
+
+
+def run_both(tmp_path, my_trust4, my_extractor, args):
+    runs = {"ref": install_dir(str(tmp_path / "inst_ref"), os.path.join(REF_BIN, "trust4"), os.path.join(REF_BIN, "fastq-extractor")),
+            "mine": install_dir(str(tmp_path / "inst_mine"), my_trust4, my_extractor)}
+    outs = {}
+    for tag, script in runs.items():
+        od = tmp_path / ("out_" + tag)
+        od.mkdir()
+        # the report scripts break count ties in perl hash order: pin the hash seed, as one would to compare two reference runs
+        env = dict(os.environ, PERL_HASH_SEED="0", PERL_PERTURB_KEYS="0")
+        p = subprocess.run(["perl", script] + args + ["-o", "T", "--od", str(od)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+        assert p.returncode == 0, (tag, p.stderr[-2000:])
+        outs[tag] = str(od)
+    names = sorted(os.listdir(outs["ref"]))
+    assert sorted(os.listdir(outs["mine"])) == names
+    for must in ("T_raw.out", "T_final.out", "T_assembled_reads.fa", "T_annot.fa", "T_cdr3.out", "T_report.tsv", "T_airr.tsv"):
+        assert must in names, (must, names)
+    for f in names:
+        assert filecmp.cmp(os.path.join(outs["ref"], f), os.path.join(outs["mine"], f), shallow=False), f
+    return outs["ref"], names
+
+
+def emulated_programs():
+    from test_stage0_e2e import _emulated_extractor
+    from test_stage1_e2e import _emulated_driver
+    return _emulated_driver(), _emulated_extractor()
+
+
+def cells_input(tmp_path, pairs, cells, seed):
+    t4libs.build_checkers()
+    fa = str(tmp_path / "ref.fa")
+    with gzip.open(REF_FA, "rb") as f, open(fa, "wb") as g:
+        shutil.copyfileobj(f, g)
+    pre = str(tmp_path / "c5")
+    subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, str(pairs), "0", str(seed), pre, "--cells", str(cells)], check=True, stdout=subprocess.DEVNULL)
+    return fa, pre
+
+
+def example_args():
+    return ["-f", os.path.join(REF_TREE, "hg38_bcrtcr.fa"), "--ref", os.path.join(REF_TREE, "human_IMGT+C.fa"),
+            "-1", os.path.join(REF_TREE, "example", "example_1.fq"), "-2", os.path.join(REF_TREE, "example", "example_2.fq"), "-t", "2"]
+
+
+@needs_reference
+def test_example_pipeline_emulated(tmp_path):
+    """BASELINE config[0] through run-trust4 (stage 0 -> 1 -> 2 -> 3). Bulk mode: --skipMateExtension, the mate-graph tail of
+    stage 1 is not built."""
+    trust4, extractor = emulated_programs()
+    od, names = run_both(tmp_path, trust4, extractor, example_args() + ["--skipMateExtension"])
+    assert "T_toassemble_1.fq" in names and os.path.getsize(os.path.join(od, "T_report.tsv")) > 100
+
+
+@needs_reference
+def test_barcode_pipeline_emulated(tmp_path):
+    """10x-style input (barcode + UMI files) through run-trust4: stage 1 runs as the reference does by default (no option added),
+    the barcode reports are compared as well."""
+    trust4, extractor = emulated_programs()
+    fa, pre = cells_input(tmp_path, 300, 6, 9)
+    od, names = run_both(tmp_path, trust4, extractor, ["-f", fa, "--ref", os.path.join(REF_TREE, "human_IMGT+C.fa"), "-1", pre + "_1.fq", "-2", pre + "_2.fq",
+                                                       "--barcode", pre + "_bc.fa", "--UMI", pre + "_umi.fa", "-t", "2"])
+    assert "T_barcode_report.tsv" in names and "T_toassemble_bc.fa" in names
+
+
+@pytest.mark.gpu
+@needs_reference
+def test_example_pipeline_gpu(tmp_path):
+    import trust4_amd.build as b
+    b.build()
+    run_both(tmp_path, os.path.join(ROOT, "trust4_amd", "bin", "trust4-hip"), os.path.join(ROOT, "trust4_amd", "bin", "fastq-extractor-hip"),
+             example_args() + ["--skipMateExtension"])

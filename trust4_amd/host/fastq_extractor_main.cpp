@@ -64,7 +64,10 @@ int main(int argc, char *argv[]) {
     else if (c == '1') { reads.files.push_back(optarg); hasMate = true; }
     else if (c == '2') { mateReads.files.push_back(optarg); hasMate = true; }
     else if (c == 'o') prefix = optarg;
-    else if (c == 't') { /* the candidate test runs on the GPU */ }
+    else if (c == 't') {   // the candidate test runs on the GPU; what -t changes in the reference's OUTPUT is kept: with more than one
+      // thread it reads batches through NextWithBuffer, which leaves a trailing /1 or /2 on the read ids (FastqExtractor.cpp:549-660)
+      if (atoi(optarg) > 1) reads.stripMateSuffix = false;
+    }
     else if (c == 10000) { hasBarcode = true; barcodeFile.files.push_back(optarg); }
     else if (c == 10001) barcodeStart = atoi(optarg);
     else if (c == 10002) barcodeEnd = atoi(optarg);

@@ -17,6 +17,7 @@ struct SeqReader {
   bool havePending = false;
   std::string id, seq, qual, comment;   // comment: rest of the header line after the separator that ends the name (kseq)
   bool hasQual = false;
+  bool stripMateSuffix = true;          // false: ids as written (what the reference's threaded extractor path prints)
   bool getLine(std::string &out) {
     if (havePending) { out.swap(pending); havePending = false; return true; }
     out.clear();
@@ -48,8 +49,8 @@ struct SeqReader {
       while (e < line.size() && line[e] != ' ' && line[e] != '\t') ++e;
       id.assign(line, 1, e - 1);
       if (e < line.size()) comment.assign(line, e + 1, std::string::npos); else comment.clear();
-      size_t n = id.size();   // ReadFiles.hpp:180-185
-      if (n >= 2 && (id[n - 1] == '1' || id[n - 1] == '2') && id[n - 2] == '/') id.resize(n - 2);
+      size_t n = id.size();   // ReadFiles.hpp:180-185 (Next() drops a /1 or /2; the batch reader NextWithBuffer, 200-241, does not)
+      if (stripMateSuffix && n >= 2 && (id[n - 1] == '1' || id[n - 1] == '2') && id[n - 2] == '/') id.resize(n - 2);
       seq.clear(); qual.clear(); hasQual = false;
       bool plus = false;
       while (getLine(line)) {
