@@ -11,6 +11,10 @@
 #include <string.h>
 
 #include <string>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -32,6 +36,52 @@ bool isLowComplexity(const std::string &s) {   // FastqExtractor.cpp:105-127
 }
 
 struct Rec { std::string id, seq, qual, comment; bool hasQual; };
+
+// One input file set read ahead on its own thread, handed over in chunks of records: parsing (and inflating) the read, mate,
+// barcode and UMI files is what this program spends its time on (the candidate test of a million reads takes 0.06 s on the GPU),
+// so the files are parsed side by side instead of record by record in turn. Chunks have the same size in every stream, i.e.
+// chunk n of each stream holds the same records; a shorter chunk means that file has ended.
+struct ChunkStream {
+  static constexpr size_t CHUNK = 16384, DEPTH = 4;
+  SeqReader *rd = nullptr;
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::deque<std::vector<Rec>> q;
+  bool done = false, stop = false;
+  void start(SeqReader *r) {
+    rd = r;
+    th = std::thread([this]() {
+      for (;;) {
+        std::vector<Rec> v;
+        v.reserve(CHUNK);
+        while (v.size() < CHUNK && rd->next()) v.push_back(Rec{rd->id, rd->seq, rd->qual, rd->comment, rd->hasQual});
+        const bool last = v.size() < CHUNK;
+        std::unique_lock<std::mutex> lk(m);
+        if (!v.empty()) q.push_back(std::move(v));
+        if (last) { done = true; cv.notify_all(); return; }
+        cv.notify_all();
+        cv.wait(lk, [this]() { return q.size() < DEPTH || stop; });
+        if (stop) { done = true; return; }
+      }
+    });
+  }
+  bool pop(std::vector<Rec> &out) {   // false: the stream has ended
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [this]() { return !q.empty() || done; });
+    if (q.empty()) return false;
+    out = std::move(q.front());
+    q.pop_front();
+    cv.notify_all();
+    return true;
+  }
+  void finish() {
+    if (!th.joinable()) return;
+    { std::lock_guard<std::mutex> lk(m); stop = true; }
+    cv.notify_all();
+    th.join();
+  }
+};
 
 void die(t4_ctx *ctx, const char *what, int rc) {
   fprintf(stderr, "%s failed (%d): %s\n", what, rc, ctx ? t4_last_error(ctx) : "");
@@ -200,17 +250,38 @@ int main(int argc, char *argv[]) {
     total += (long long)r1.size();
     r1.clear(); r2.clear(); rb.clear(); ru.clear();
   };
-  while (reads.next()) {
-    if (hasMate && !mateReads.next()) { fprintf(stderr, "The two mate-pair read files have different number of reads.\n"); if (initThread.joinable()) initThread.join(); exit(1); }
-    if (hasBarcode && !barcodeFile.next()) { fprintf(stderr, "Read file and barcode file  have different number of reads.\n"); if (initThread.joinable()) initThread.join(); exit(1); }
-    if (hasUmi && !umiFile.next()) { fprintf(stderr, "Read file and UMI file have different number of reads.\n"); if (initThread.joinable()) initThread.join(); exit(1); }
-    r1.push_back(Rec{reads.id, reads.seq, reads.qual, std::string(), reads.hasQual});
-    if (hasMate) r2.push_back(Rec{mateReads.id, mateReads.seq, mateReads.qual, std::string(), mateReads.hasQual});
-    if (hasBarcode) rb.push_back(Rec{barcodeFile.id, barcodeFile.seq, barcodeFile.qual, barcodeFile.comment, barcodeFile.hasQual});
-    if (hasUmi) ru.push_back(Rec{umiFile.id, umiFile.seq, umiFile.qual, umiFile.comment, umiFile.hasQual});
-    if (r1.size() >= BATCH) flush();
+  ChunkStream s1, s2, sb, su;
+  s1.start(&reads);
+  if (hasMate) s2.start(&mateReads);
+  if (hasBarcode) sb.start(&barcodeFile);
+  if (hasUmi) su.start(&umiFile);
+  auto bail = [&](const char *msg) {
+    fprintf(stderr, "%s", msg);
+    s1.finish(); s2.finish(); sb.finish(); su.finish();
+    if (initThread.joinable()) initThread.join();
+    exit(1);
+  };
+  std::vector<Rec> c1, c2, cb, cu;
+  auto append = [](std::vector<Rec> &dst, std::vector<Rec> &src, size_t n) { for (size_t k = 0; k < n; ++k) dst.push_back(std::move(src[k])); src.clear(); };
+  double secWait = 0, secFlush = 0;
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tw = now();
+  while (s1.pop(c1)) {
+    const size_t n = c1.size();
+    if (hasMate && (!s2.pop(c2) || c2.size() < n)) bail("The two mate-pair read files have different number of reads.\n");
+    if (hasBarcode && (!sb.pop(cb) || cb.size() < n)) bail("Read file and barcode file  have different number of reads.\n");
+    if (hasUmi && (!su.pop(cu) || cu.size() < n)) bail("Read file and UMI file have different number of reads.\n");
+    append(r1, c1, n);
+    if (hasMate) append(r2, c2, n);
+    if (hasBarcode) append(rb, cb, n);
+    if (hasUmi) append(ru, cu, n);
+    secWait += now() - tw;
+    if (r1.size() >= BATCH) { const double tf = now(); flush(); secFlush += now() - tf; }
+    tw = now();
   }
-  flush();
+  s1.finish(); s2.finish(); sb.finish(); su.finish();
+  { const double tf = now(); flush(); secFlush += now() - tf; }
+  if (getenv("T4_TIMING")) fprintf(stderr, "timing: %.2f s waiting for parsed chunks, %.2f s in candidate tests and output\n", secWait, secFlush);
   fclose(fp1);
   if (fp2) fclose(fp2);
   if (fpBc) fclose(fpBc);
