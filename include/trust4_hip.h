@@ -231,6 +231,30 @@ int t4_cellset_output(t4_cellset *cs, const char *path, const char *const *barco
 int t4_cellset_counters(const t4_cellset *cs, int64_t *query_batches, int64_t *reads_queried, int64_t *images_staged,
                         int64_t *bytes_staged, double *sec_query, double *sec_stage);
 
+/* ---- k-mer counts of the read set ------------------------------------------------ */
+/* KmerCount (KmerCount.hpp): counts of the canonical k-mers of the reads (main.cpp:905-915 counts 21-mers of every read that
+ * enters stage 1) and, per read, the minimum / median / mean count of its valid k-mers with the quality trimming that rides on
+ * them (GetCountStatsAndTrim, main.cpp:980-1061; they define the read order, main.cpp:103-125, and the AddRead thresholds,
+ * 1676-1701). Replaces KmerCount::AddCount (KmerCount.hpp:64-97) and GetCountStatsAndTrim (177-288) for whole batches: the
+ * table lives in HBM (open addressing on the canonical code, 12 bytes per slot), one wavefront per read. Counts are exact.
+ * k <= 31; `max_kmers` bounds the number of DISTINCT k-mers (the table gets at least twice as many slots; an insert that finds
+ * it full makes t4_kmer_count_add fail with T4_ERR_UNSUPPORTED). Not built this round: AddCountFromFile (-c) and the 23-bucket
+ * per-barcode counters; the stage-1 driver still counts on host threads. */
+typedef struct t4_kmer_counter t4_kmer_counter;
+int t4_kmer_count_create(t4_ctx *ctx, int k, int64_t max_kmers, t4_kmer_counter **out);
+void t4_kmer_count_destroy(t4_kmer_counter *kc);
+/* AddCount of every read of the batch (reads shorter than k add nothing). */
+int t4_kmer_count_add(t4_kmer_counter *kc, t4_batch *reads);
+/* GetCountStatsAndTrim of every read of the batch. quals == NULL: no trimming (the reference's qual == NULL). Otherwise the
+ * qualities of read i are the bytes quals[qual_off[i] .. qual_off[i + 1]) and must be as many as the read has bases.
+ * Out (n entries each): min_cnt, median_cnt, avg_cnt as the reference leaves them (-1 for reads shorter than k, -len without a
+ * valid k-mer, avg = +inf when the trim leaves no k-mer), new_len = the length the reference cuts read and qualities to
+ * (the read's length when it is not trimmed, 0 when it is emptied). */
+int t4_kmer_count_stats(t4_kmer_counter *kc, t4_batch *reads, const char *quals, const int64_t *qual_off,
+                        int32_t *min_cnt, int32_t *median_cnt, float *avg_cnt, int32_t *new_len);
+/* number of distinct k-mers counted so far */
+int64_t t4_kmer_count_distinct(t4_kmer_counter *kc);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* Per-call statistics of the last query on this ctx: kernel time measured with HIP events on the
  * ctx's stream, number of _hit records the seed stage emitted (H of SURVEY.md 8d), number of reads

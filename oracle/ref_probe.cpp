@@ -17,6 +17,7 @@
 
 #define private public
 #include "SeqSet.hpp"
+#include "KmerCount.hpp"
 #undef private
 
 // The two globals every reference TU must define (main.cpp:39-44).
@@ -281,4 +282,13 @@ extern "C" long ref_annotate_batch(void *h, const char *reads, int stride, long 
     if (out4) for (int t = 0; t < 4; ++t) copy_overlap(out4 + 4 * i + t, g[t]);
   }
   return n;
+}
+
+// KmerCount (KmerCount.hpp): the canonical 21-mer counts of stage 1 (main.cpp:905-915) and GetCountStatsAndTrim (980-1061).
+extern "C" void *ref_kc_new(int k) { return new KmerCount(k); }
+extern "C" void ref_kc_free(void *h) { delete (KmerCount *)h; }
+extern "C" int ref_kc_add(void *h, const char *read) { return ((KmerCount *)h)->AddCount((char *)read); }
+// read / qual are modified in place as the reference does (NUL at the trim position); qual may be NULL
+extern "C" int ref_kc_stats(void *h, char *read, char *qual, int *minCnt, int *medianCnt, float *avgCnt) {
+  return ((KmerCount *)h)->GetCountStatsAndTrim(read, qual, *minCnt, *medianCnt, *avgCnt);
 }

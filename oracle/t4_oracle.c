@@ -1211,3 +1211,95 @@ int t4o_assign_read(t4o_set *s, const char *read, int strand, int barcode, t4o_o
   free(ov.o);
   return ret;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * KmerCount (KmerCount.hpp): counts of canonical k-mers (AddCount, 64-97) and the per-read count statistics
+ * with quality trimming (GetCountStatsAndTrim, 177-288). TEST INFRASTRUCTURE like the rest of this file.
+ * The reference keeps std::map shards; the counts are a function of the multiset of k-mers only, so an
+ * open-addressing table does here.
+ * ------------------------------------------------------------------------------------------------ */
+struct t4o_kc { int k; uint64_t cap, used; uint64_t *keys; int *cnt; int maxReadLen; };
+
+t4o_kc *t4o_kc_new(int k) {
+  t4o_kc *c = (t4o_kc *)calloc(1, sizeof *c);
+  c->k = k; c->cap = 1u << 16; c->maxReadLen = -1;
+  c->keys = (uint64_t *)calloc(c->cap, sizeof(uint64_t)); c->cnt = (int *)calloc(c->cap, sizeof(int));
+  return c;
+}
+void t4o_kc_free(t4o_kc *c) { if (c) { free(c->keys); free(c->cnt); free(c); } }
+static uint64_t kc_mix(uint64_t z) { z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31); }
+static int *kc_slot(t4o_kc *c, uint64_t kc, int create) {   /* keys hold code + 1 (0 = empty) */
+  for (;;) {
+    uint64_t h = kc_mix(kc) & (c->cap - 1);
+    while (c->keys[h] && c->keys[h] != kc + 1) h = (h + 1) & (c->cap - 1);
+    if (c->keys[h]) return &c->cnt[h];
+    if (!create) return NULL;
+    if (2 * (c->used + 1) <= c->cap) { c->keys[h] = kc + 1; ++c->used; return &c->cnt[h]; }
+    uint64_t ocap = c->cap, *ok = c->keys; int *oc = c->cnt;   /* grow and retry */
+    c->cap *= 2; c->used = 0;
+    c->keys = (uint64_t *)calloc(c->cap, sizeof(uint64_t)); c->cnt = (int *)calloc(c->cap, sizeof(int));
+    for (uint64_t i = 0; i < ocap; ++i) if (ok[i]) { *kc_slot(c, ok[i] - 1, 1) = oc[i]; }
+    free(ok); free(oc);
+  }
+}
+/* KmerCode::Append / IsValid / GetCanonicalKmerCode (KmerCode.hpp:94-109, 85-92, 54-67) rolled over a read: calls back with
+ * the canonical code of every valid k-mer in read order. */
+typedef void (*kc_visit)(void *ctx, uint64_t code);
+static void kc_each_valid(int k, const char *r, int len, kc_visit f, void *ctx) {
+  const uint64_t mask = k < 32 ? ((1ull << (2 * k)) - 1ull) : ~0ull;
+  uint64_t code = 0;
+  int invalidPos = -1;
+  for (int i = 0; i < len; ++i) {
+    if (invalidPos != -1) ++invalidPos;
+    code = ((code << 2) & mask) | (uint64_t)(nuc(r[i]) & 3);
+    if (r[i] == 'N') invalidPos = 0;
+    if (invalidPos >= k) invalidPos = -1;
+    if (i < k - 1 || invalidPos != -1) continue;
+    uint64_t cr = 0;
+    for (int j = 0; j < k; ++j) cr = (cr << 2) | (3ull - ((code >> (2 * j)) & 3ull));
+    f(ctx, cr < code ? cr : code);
+  }
+}
+static void kc_visit_add(void *ctx, uint64_t code) { ++*kc_slot((t4o_kc *)ctx, code, 1); }
+int t4o_kc_add(t4o_kc *c, const char *read) {   /* KmerCount.hpp:64-97 */
+  int len = (int)strlen(read);
+  if (len < c->k) return 0;
+  kc_each_valid(c->k, read, len, kc_visit_add, c);
+  if (len > c->maxReadLen) c->maxReadLen = len;
+  return 1;
+}
+struct kc_stat_ctx { t4o_kc *c; int *buf; int n, sum; };
+static void kc_visit_stat(void *ctx, uint64_t code) {
+  struct kc_stat_ctx *s = (struct kc_stat_ctx *)ctx;
+  int *p = kc_slot(s->c, code, 0);
+  int v = p ? *p : 0;
+  if (v <= 0) v = 1;
+  s->buf[s->n++] = v; s->sum += v;
+}
+static int kc_cmp_int(const void *a, const void *b) { return *(const int *)a - *(const int *)b; }
+int t4o_kc_stats(t4o_kc *c, char *read, char *qual, int *minCnt, int *medianCnt, float *avgCnt) {   /* KmerCount.hpp:177-288 */
+  if (c->maxReadLen == -1) return 0;
+  int len = (int)strlen(read), i, j;
+  if (len < c->k) { *minCnt = *medianCnt = -1; *avgCnt = -1; return 0; }
+  struct kc_stat_ctx st; st.c = c; st.buf = (int *)calloc((size_t)(len + 1), sizeof(int)); st.n = 0; st.sum = 0;
+  /* (zeroed: after a trim the reference may sort past the counts of this read into whatever its reused buffer held -- reads
+   * with N AND a low-quality tail; entries it never wrote are taken as 0 here and in the engine) */
+  kc_each_valid(c->k, read, len, kc_visit_stat, &st);
+  int k = st.n;
+  if (k == 0) { *minCnt = -len; *medianCnt = -len; *avgCnt = (float)-len; if (qual) read[0] = '\0'; free(st.buf); return 0; }
+  if (qual) {
+    for (i = k - 1; i >= 0; --i) if (st.buf[i] > 1) break;
+    ++i;
+    int badCnt = 0, trimStart = -1;
+    for (j = len - 1; j >= i + c->k - 1; --j)
+      if (qual[j] - 32 <= 15) { ++badCnt; if (badCnt >= 0.1 * (len - j)) trimStart = j; }
+    if (trimStart > 0) { k = trimStart - c->k + 1; read[trimStart] = '\0'; qual[trimStart] = '\0'; }
+    if (trimStart > 0 && trimStart < c->k) { k = 0; read[0] = '\0'; qual[0] = '\0'; }
+  }
+  if (k > 0) qsort(st.buf, (size_t)k, sizeof(int), kc_cmp_int);   /* std::sort(c, c + k); k <= 0 sorts nothing */
+  *minCnt = st.buf[0]; *medianCnt = st.buf[k > 0 ? k / 2 : 0]; *avgCnt = (float)(st.sum / (double)k);
+  for (i = 0; i < len; ++i)   /* scans the OLD length: characters behind the NUL are still there */
+    if (read[i] == 'N') { if (*minCnt >= 0) *minCnt = 0; else if (*minCnt <= 0) --*minCnt; }
+  free(st.buf);
+  return 1;
+}

@@ -57,6 +57,14 @@ int t4o_lis(const int *pairs, int n, int *out);
 int64_t t4o_annotate_batch(t4o_set *s, const char *reads, int stride, int64_t n, t4o_overlap *out4,
                            int64_t *hitsPerRead);
 
+/* KmerCount (KmerCount.hpp:64-97, 177-288): canonical k-mer counts of a read set; min / median / mean count of a read and the
+ * quality trimming that rides on it. read / qual are modified in place like the reference's (NUL at the trim position). */
+typedef struct t4o_kc t4o_kc;
+t4o_kc *t4o_kc_new(int k);
+void t4o_kc_free(t4o_kc *c);
+int t4o_kc_add(t4o_kc *c, const char *read);
+int t4o_kc_stats(t4o_kc *c, char *read, char *qual, int *minCnt, int *medianCnt, float *avgCnt);
+
 #ifdef __cplusplus
 }
 #endif

@@ -363,3 +363,35 @@ class RefSeqSet:
 
     def size(self):
         return self.lib.ref_size(self.h)
+
+
+class KmerCountChecker:
+    """KmerCount of the oracle ("t4o_kc_") or of the compiled reference ("ref_kc_"): add reads, then per-read count statistics
+    with the quality trimming (GetCountStatsAndTrim). stats() returns (ret, min, median, avg, read_after, qual_after)."""
+
+    def __init__(self, k=21, reference=False):
+        self.lib = C.CDLL(Ref.PATH if reference else Oracle.PATH)
+        p = "ref_kc_" if reference else "t4o_kc_"
+        self._new, self._free, self._add, self._stats = (getattr(self.lib, p + n) for n in ("new", "free", "add", "stats"))
+        self._new.restype = C.c_void_p
+        self._new.argtypes = [C.c_int]
+        self._free.argtypes = [C.c_void_p]
+        self._add.argtypes = [C.c_void_p, C.c_char_p]
+        self._stats.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float)]
+        self.h = C.c_void_p(self._new(k))
+
+    def add(self, read):
+        return self._add(self.h, _b(read))
+
+    def stats(self, read, qual=None):
+        rb = C.create_string_buffer(_b(read), len(read) + 1)
+        qb = C.create_string_buffer(_b(qual), len(qual) + 1) if qual is not None else None
+        mn, md, av = C.c_int(0), C.c_int(0), C.c_float(0)
+        ret = self._stats(self.h, rb, qb, C.byref(mn), C.byref(md), C.byref(av))
+        return ret, mn.value, md.value, av.value, rb.value.decode(), (qb.value.decode() if qb is not None else None)
+
+    def __del__(self):
+        try:
+            self._free(self.h)
+        except Exception:
+            pass

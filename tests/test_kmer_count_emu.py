@@ -1,0 +1,107 @@
+"""KmerCount on the engine (t4_kmer_count_*): the emulator build of the kernels against the C oracle, and the oracle
+against the compiled reference (KmerCount.hpp through oracle/_ref). The `-m gpu` counterpart is tests/test_zz_kmer_count_gpu.py."""
+import math
+import os
+import random
+
+import pytest
+
+import t4check
+from t4libs import KmerCountChecker, Ref, Synth, rows_to_strs
+
+
+def kmer_count_case(seed, n_reads, n_clones=40):
+    """reads with a few N, the reference's corner cases, and qualities with low-quality tails (what the trimming looks at)"""
+    rnd = random.Random(seed)
+    reads = rows_to_strs(Synth(n_clones, seed).next_reads(n_reads // 2))
+
+    def with_n(r):
+        r = list(r)
+        if rnd.random() < 0.15:
+            for _ in range(rnd.randint(1, 3)):
+                r[rnd.randrange(len(r))] = "N"
+        return "".join(r)
+
+    reads = [with_n(r) for r in reads]
+    reads += ["ACGT" * 5, "A" * 21, "N" * 30, "ACGTACGTACGTACGTACGTA", "ACGTNACGTACGTACGTACGTACGTAACCGGTT", "ACGTACGTACGTACGTACGTAN", "",
+              reads[0][:60], reads[1][20:], "ACGGTCA" * 40]
+    quals = ["".join(rnd.choice("#+5AFI") if rnd.random() < 0.5 else "I" for _ in r) for r in reads]
+    for i in range(0, len(quals), 3):
+        h = len(quals[i]) // 2
+        quals[i] = quals[i][:h] + "#" * (len(quals[i]) - h)
+    return reads, quals
+
+
+def same(a, b):
+    return a == b or (isinstance(a, float) and isinstance(b, float) and math.isnan(a) and math.isnan(b))
+
+
+def check_engine_kmer_counts(eng, seed, n_reads, k=21):
+    reads, quals = kmer_count_case(seed, n_reads)
+    oracle = KmerCountChecker(k)
+    for r in reads:
+        oracle.add(r)
+    kc = eng.kmer_counter(k, max_kmers=sum(max(0, len(r) - k + 1) for r in reads) + 8)
+    half = len(reads) // 2
+    kc.add(eng.upload(reads[:half])).add(eng.upload(reads[half:]))   # counts accumulate over batches
+    distinct = set()
+    batch = eng.upload(reads)
+    for use_q in (False, True):
+        mn, md, av, ln = kc.stats(batch, quals if use_q else None)
+        for i, r in enumerate(reads):
+            ret, omn, omd, oav, r_after, _ = oracle.stats(r, quals[i] if use_q else None)
+            got = (int(mn[i]), int(md[i]), float(av[i]), int(ln[i]))
+            assert got[0] == omn and got[1] == omd and same(got[2], float(oav)) and got[3] == len(r_after), (i, use_q, r, got, (omn, omd, oav, len(r_after)))
+    return kc, reads
+
+
+@pytest.fixture(scope="module")
+def emu_engine():
+    os.environ["T4_LIB"] = t4check.build_emulator_lib()
+    import trust4_amd
+    eng = trust4_amd.Engine(0)
+    yield eng
+    os.environ.pop("T4_LIB", None)
+
+
+def test_kmer_counts_and_stats_emulated(emu_engine):
+    kc, reads = check_engine_kmer_counts(emu_engine, 5, 120)
+    k = 21
+    # distinct canonical k-mers, counted independently in Python
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    seen = set()
+    for r in reads:
+        for p in range(len(r) - k + 1):
+            w = r[p:p + k]
+            if "N" in w:
+                continue
+            rc = "".join(comp[c] for c in reversed(w))
+            code = lambda s: int("".join(str("ACGT".index(c)) for c in s), 4)
+            seen.add(min(code(w), code(rc)))
+    assert kc.distinct() == len(seen)
+
+
+def test_kmer_count_other_k_emulated(emu_engine):
+    check_engine_kmer_counts(emu_engine, 9, 60, k=31)
+    check_engine_kmer_counts(emu_engine, 10, 60, k=9)
+
+
+def test_kmer_count_table_full_is_loud(emu_engine):
+    reads = rows_to_strs(Synth(40, 3).next_reads(40))
+    kc = emu_engine.kmer_counter(21, max_kmers=16)   # 1024 slots: far too few
+    with pytest.raises(Exception):
+        kc.add(emu_engine.upload(reads))
+
+
+@pytest.mark.skipif(not Ref.available(), reason="oracle/_ref not built")
+def test_oracle_kmer_count_vs_reference():
+    reads, quals = kmer_count_case(3, 300, n_clones=50)
+    o, r = KmerCountChecker(21, False), KmerCountChecker(21, True)
+    for x in reads:
+        assert o.add(x) == r.add(x)
+    for x, q in zip(reads, quals):
+        for qq in (None, q):
+            a, b = o.stats(x, qq), r.stats(x, qq)
+            if "N" in x and qq is not None and a[4] != x:
+                continue   # the reference sorts stale entries of its reused buffer here (a read with N AND a trimmed tail)
+            assert a[:2] == b[:2] and same(a[2], b[2]) and same(a[3], b[3]) and a[4:] == b[4:], (x, qq, a, b)

@@ -133,12 +133,58 @@ class Engine:
     def index(self, k, consider_barcode=False):
         return Index(self, k, consider_barcode)
 
+    def kmer_counter(self, k=21, max_kmers=1 << 20):
+        return KmerCounter(self, k, max_kmers)
+
     def upload(self, reads, barcodes=None):
         return Batch(self, reads, barcodes)
 
     def close(self):
         if getattr(self, "h", None):
             self.lib.t4_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class KmerCounter:
+    """t4_kmer_counter: the reference's `KmerCount` (canonical k-mer counts of the read set, GetCountStatsAndTrim per read)."""
+
+    def __init__(self, eng, k, max_kmers):
+        self.eng = eng
+        self.h = C.c_void_p()
+        eng.check(eng.lib.t4_kmer_count_create(eng.h, k, C.c_int64(max_kmers), C.byref(self.h)))
+
+    def add(self, batch):
+        self.eng.check(self.eng.lib.t4_kmer_count_add(self.h, batch.h))
+        return self
+
+    def stats(self, batch, quals=None):
+        """-> (min int32[n], median int32[n], avg float32[n], new_len int32[n]); quals: list of str, one per read, or None"""
+        n = batch.n
+        mn, md, ln = (np.zeros(n, dtype=np.int32) for _ in range(3))
+        av = np.zeros(n, dtype=np.float32)
+        V = C.c_void_p
+        qb, qo = None, None
+        if quals is not None:
+            qoff = np.zeros(n + 1, dtype=np.int64)
+            qoff[1:] = np.cumsum([len(x) for x in quals])
+            qbuf = np.frombuffer(("".join(quals) + "\0").encode(), dtype=np.uint8)
+            qb, qo = qbuf.ctypes.data_as(V), qoff.ctypes.data_as(V)
+        self.eng.check(self.eng.lib.t4_kmer_count_stats(self.h, batch.h, qb, qo, mn.ctypes.data_as(V), md.ctypes.data_as(V), av.ctypes.data_as(V), ln.ctypes.data_as(V)))
+        return mn, md, av, ln
+
+    def distinct(self):
+        self.eng.lib.t4_kmer_count_distinct.restype = C.c_int64
+        return int(self.eng.lib.t4_kmer_count_distinct(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.eng.lib.t4_kmer_count_destroy(self.h)
             self.h = None
 
     def __del__(self):

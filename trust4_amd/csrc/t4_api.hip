@@ -823,6 +823,105 @@ int t4_mate_overlap(t4_ctx *c, int n, const int64_t *f_off, const char *f_chars,
   return T4_OK;
 }
 
+// ---- KmerCount (KmerCount.hpp) on the device ------------------------------------------------------------------------
+struct t4_kmer_counter {
+  t4_ctx *ctx = nullptr;
+  T4KmerTable tb{};
+  unsigned long long slots = 0;
+};
+
+int t4_kmer_count_create(t4_ctx *c, int k, int64_t max_kmers, t4_kmer_counter **out) {
+  if (!c || !out) return T4_ERR_ARG;
+  if (k < 1 || k > 31 || max_kmers < 1) return fail(c, T4_ERR_ARG, "t4_kmer_count_create: k in 1..31 and max_kmers >= 1 (got %d, %lld)", k, (long long)max_kmers);
+  (void)hipSetDevice(c->device);
+  unsigned long long slots = 1024;
+  while (slots < 2ull * (unsigned long long)max_kmers) slots <<= 1;
+  t4_kmer_counter *kc = new t4_kmer_counter;
+  kc->ctx = c; kc->slots = slots;
+  kc->tb.k = k; kc->tb.mask = slots - 1;
+  if (hipMalloc(&kc->tb.keys, sizeof(unsigned long long) * slots) != hipSuccess || hipMalloc(&kc->tb.cnt, sizeof(unsigned) * slots) != hipSuccess ||
+      hipMalloc(&kc->tb.overflow, sizeof(int)) != hipSuccess) {
+    t4_kmer_count_destroy(kc);
+    return fail(c, T4_ERR_HIP, "t4_kmer_count_create: no device memory for %llu slots", slots);
+  }
+  HIPCHK(c, hipMemset(kc->tb.keys, 0, sizeof(unsigned long long) * slots));
+  HIPCHK(c, hipMemset(kc->tb.cnt, 0, sizeof(unsigned) * slots));
+  HIPCHK(c, hipMemset(kc->tb.overflow, 0, sizeof(int)));
+  *out = kc;
+  return T4_OK;
+}
+
+void t4_kmer_count_destroy(t4_kmer_counter *kc) {
+  if (!kc) return;
+  if (kc->tb.keys) (void)hipFree(kc->tb.keys);
+  if (kc->tb.cnt) (void)hipFree(kc->tb.cnt);
+  if (kc->tb.overflow) (void)hipFree(kc->tb.overflow);
+  delete kc;
+}
+
+int t4_kmer_count_add(t4_kmer_counter *kc, t4_batch *b) {
+  if (!kc || !b) return T4_ERR_ARG;
+  t4_ctx *c = kc->ctx;
+  if (b->ctx != c) return fail(c, T4_ERR_ARG, "batch belongs to another ctx");
+  if (b->n == 0) return T4_OK;
+  (void)hipSetDevice(c->device);
+  const long long n = b->n;
+  const int grid = (int)(n < (long long)c->cus * 32 ? n : (long long)c->cus * 32);
+  hipLaunchKernelGGL(t4k::kmerAddKernel, dim3(grid), dim3(64), 0, c->stream, b->view, kc->tb);
+  HIPCHK(c, hipGetLastError());
+  int overflow = 0;
+  HIPCHK(c, hipMemcpyAsync(&overflow, kc->tb.overflow, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (overflow) return fail(c, T4_ERR_UNSUPPORTED, "t4_kmer_count_add: more distinct k-mers than the table was created for (%llu slots)", kc->slots);
+  return T4_OK;
+}
+
+int t4_kmer_count_stats(t4_kmer_counter *kc, t4_batch *b, const char *quals, const int64_t *qual_off,
+                        int32_t *min_cnt, int32_t *median_cnt, float *avg_cnt, int32_t *new_len) {
+  if (!kc || !b || !min_cnt || !median_cnt || !avg_cnt || !new_len || (quals && !qual_off)) return T4_ERR_ARG;
+  t4_ctx *c = kc->ctx;
+  if (b->ctx != c) return fail(c, T4_ERR_ARG, "batch belongs to another ctx");
+  const long long n = b->n;
+  if (n == 0) return T4_OK;
+  (void)hipSetDevice(c->device);
+  int r;
+  char *dQ = nullptr; long long *dOff = nullptr;
+  int *dMin = nullptr, *dMed = nullptr, *dLen = nullptr; float *dAvg = nullptr;
+  if (quals) {
+    std::vector<int> lens((size_t)n);
+    HIPCHK(c, hipMemcpy(lens.data(), b->dLen, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    for (long long i = 0; i < n; ++i)
+      if (qual_off[i + 1] - qual_off[i] != lens[(size_t)i]) return fail(c, T4_ERR_ARG, "read %lld has %d bases and %lld qualities", i, lens[(size_t)i], (long long)(qual_off[i + 1] - qual_off[i]));
+    const size_t qn = (size_t)qual_off[n];
+    if ((r = devAlloc(c, &dQ, qn + 16)) || (r = devAlloc(c, &dOff, (size_t)n + 1))) return r;
+    if (qn) HIPCHK(c, hipMemcpy(dQ, quals, qn, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dOff, qual_off, sizeof(long long) * ((size_t)n + 1), hipMemcpyHostToDevice));
+  }
+  if ((r = devAlloc(c, &dMin, (size_t)n)) || (r = devAlloc(c, &dMed, (size_t)n)) || (r = devAlloc(c, &dLen, (size_t)n)) || (r = devAlloc(c, &dAvg, (size_t)n))) return r;
+  const int grid = (int)(n < (long long)c->cus * 32 ? n : (long long)c->cus * 32);
+  hipLaunchKernelGGL(t4k::kmerStatsKernel, dim3(grid), dim3(64), 0, c->stream, b->view, kc->tb, (const char *)dQ, (const long long *)dOff, dMin, dMed, dAvg, dLen);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(min_cnt, dMin, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(median_cnt, dMed, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(avg_cnt, dAvg, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(new_len, dLen, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  void *ptrs[] = {dQ, dOff, dMin, dMed, dLen, dAvg};
+  for (void *q : ptrs) if (q) (void)hipFree(q);
+  return T4_OK;
+}
+
+int64_t t4_kmer_count_distinct(t4_kmer_counter *kc) {
+  if (!kc) return -1;
+  t4_ctx *c = kc->ctx;
+  (void)hipSetDevice(c->device);
+  std::vector<unsigned long long> keys((size_t)kc->slots);
+  if (hipMemcpy(keys.data(), kc->tb.keys, sizeof(unsigned long long) * (size_t)kc->slots, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  int64_t d = 0;
+  for (unsigned long long x : keys) if (x) ++d;
+  return d;
+}
+
 int t4_has_hit(t4_index *ref, t4_batch *b, int mode, int32_t *out) {
   if (!ref || !b || !out) return T4_ERR_ARG;
   t4_ctx *c = ref->ctx;

@@ -108,6 +108,15 @@ struct T4Work {              // per-launch work description
   int gCap, gMaxOv;
 };
 
+// KmerCount on the device (KmerCount.hpp): open-addressing table of canonical k-mer codes; keys hold code + 1 (0 = empty)
+struct T4KmerTable {
+  unsigned long long *keys;
+  unsigned *cnt;
+  unsigned long long mask;   // slots - 1 (slots is a power of two)
+  int k;
+  int *overflow;             // set when an insert found the table full
+};
+
 struct T4OverlapOut {        // == t4_overlap of include/trust4_hip.h
   int seqIdx, readStart, readEnd, seqStart, seqEnd, strand, matchCnt, indelCnt;
   double similarity;

@@ -2847,6 +2847,128 @@ __global__ __launch_bounds__(64) void binKernel(T4IndexView ix, T4BatchView bv, 
   }
 }
 
+// ---- KmerCount (KmerCount.hpp): canonical k-mer counts of a read set and the per-read count statistics -----------------
+__device__ __forceinline__ unsigned long long kcMix(unsigned long long z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31);
+}
+// canonical code of the k-mer at position p of the read in wm.seg / wm.rc (KmerCode::GetCanonicalKmerCode, KmerCode.hpp:54-67);
+// valid == KmerCode::IsValid: no N among the last k characters (Append, KmerCode.hpp:94-109)
+__device__ __forceinline__ unsigned long long canonicalAt(const WaveMem &wm, int len, int p, int K, bool &valid) {
+  bool v2;
+  const unsigned long long f = kmerAt(wm.seg, p, K, valid), c = kmerAt(wm.rc, len - p - K, K, v2);
+  return c < f ? c : f;
+}
+
+// KmerCount::AddCount (KmerCount.hpp:64-97) for every read of the batch; one wavefront per read, a lane per position.
+__global__ __launch_bounds__(64) void kmerAddKernel(T4BatchView bv, T4KmerTable tb) {
+  __shared__ char s_seg[T4_MAXL + 8];
+  __shared__ char s_rc[T4_MAXL + 8];
+  WaveMem wm;
+  wm.seg = s_seg; wm.rc = s_rc;
+  for (long long r = blockIdx.x; r < bv.n; r += gridDim.x) {
+    const int len = bv.len[r];
+    if (len >= tb.k) {   // block-uniform
+      loadSegment(bv, r, 0, len, wm);
+      for (int p = laneId(); p + tb.k <= len; p += 64) {
+        bool valid;
+        const unsigned long long kc = canonicalAt(wm, len, p, tb.k, valid);
+        if (!valid) continue;
+        unsigned long long h = kcMix(kc) & tb.mask, probes = 0;
+        for (; probes <= tb.mask; ++probes) {
+          const unsigned long long old = atomicCAS(&tb.keys[h], 0ull, kc + 1ull);
+          if (old == 0ull || old == kc + 1ull) { atomicAdd(&tb.cnt[h], 1u); break; }
+          h = (h + 1ull) & tb.mask;
+        }
+        if (probes > tb.mask) *tb.overflow = 1;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// KmerCount::GetCountStatsAndTrim (KmerCount.hpp:177-288) for every read of the batch: min / median / mean count of the read's
+// valid k-mers (absent or non-positive counts read as 1), the quality trimming when quals != null (the read's qualities at
+// quals + qoff[r], as long as the read), and the N rule on the minimum. lenOut = the length the read is cut to (0: emptied).
+// One wavefront per read: lookups a lane per position, the order-dependent scans on lane 0, the median by ranks.
+__global__ __launch_bounds__(64) void kmerStatsKernel(T4BatchView bv, T4KmerTable tb, const char *quals, const long long *qoff,
+                                                     int *minOut, int *medOut, float *avgOut, int *lenOut) {
+  __shared__ char s_seg[T4_MAXL + 8];
+  __shared__ char s_rc[T4_MAXL + 8];
+  __shared__ int s_c[T4_MAXL + 8];     // count per position, -1 = no valid k-mer there
+  __shared__ int s_v[T4_MAXL + 8];     // the reference's c[]: counts of the valid k-mers in read order
+  __shared__ int s_k, s_sum, s_nul0, s_nul1, s_newLen, s_med;
+  WaveMem wm;
+  wm.seg = s_seg; wm.rc = s_rc;
+  const int K = tb.k;
+  for (long long r = blockIdx.x; r < bv.n; r += gridDim.x) {
+    const int len = bv.len[r];
+    if (len < K) {   // block-uniform
+      if (laneId() == 0) { minOut[r] = -1; medOut[r] = -1; avgOut[r] = -1.0f; lenOut[r] = len; }
+      continue;
+    }
+    loadSegment(bv, r, 0, len, wm);
+    for (int p = laneId(); p + K <= len; p += 64) {
+      bool valid;
+      const unsigned long long kc = canonicalAt(wm, len, p, K, valid);
+      int v = -1;
+      if (valid) {
+        v = 0;
+        unsigned long long h = kcMix(kc) & tb.mask;
+        for (unsigned long long probes = 0; probes <= tb.mask; ++probes) {
+          const unsigned long long key = tb.keys[h];
+          if (key == 0ull) break;
+          if (key == kc + 1ull) { v = (int)tb.cnt[h]; break; }
+          h = (h + 1ull) & tb.mask;
+        }
+        if (v <= 0) v = 1;
+      }
+      s_c[p] = v;
+    }
+    for (int p = laneId(); p < len + 1; p += 64) s_v[p] = 0;   // entries the read never writes count as 0 (see the oracle)
+    __syncthreads();
+    if (laneId() == 0) {
+      int n = 0, sum = 0;
+      for (int p = 0; p + K <= len; ++p) if (s_c[p] >= 0) { s_v[n++] = s_c[p]; sum += s_c[p]; }
+      int kk = n, nul0 = -1, nul1 = -1, newLen = len;
+      if (n == 0) { kk = -1; if (quals) newLen = 0; }
+      else if (quals) {
+        const char *q = quals + qoff[r];
+        int i;
+        for (i = n - 1; i >= 0; --i) if (s_v[i] > 1) break;
+        ++i;
+        int badCnt = 0, trimStart = -1;
+        for (int j = len - 1; j >= i + K - 1; --j)
+          if (q[j] - 32 <= 15) { ++badCnt; if (badCnt >= 0.1 * (len - j)) trimStart = j; }
+        if (trimStart > 0) { kk = trimStart - K + 1; newLen = trimStart; nul0 = trimStart; }
+        if (trimStart > 0 && trimStart < K) { kk = 0; newLen = 0; nul1 = 0; }
+      }
+      s_k = kk; s_sum = sum; s_nul0 = nul0; s_nul1 = nul1; s_newLen = newLen; s_med = s_v[0];
+    }
+    __syncthreads();
+    const int kk = s_k;
+    if (kk > 0) {   // median = the element of rank kk / 2 of std::sort(c, c + kk)
+      for (int j = laneId(); j < kk; j += 64) {
+        const int v = s_v[j];
+        int rank = 0;
+        for (int x = 0; x < kk; ++x) { const int w = s_v[x]; rank += (w < v || (w == v && x < j)) ? 1 : 0; }
+        if (rank == kk / 2) s_med = v;
+      }
+    }
+    __syncthreads();
+    if (laneId() == 0) {
+      if (kk < 0) { minOut[r] = -len; medOut[r] = -len; avgOut[r] = (float)-len; lenOut[r] = s_newLen; }
+      else {
+        int mn = s_v[0];
+        for (int x = 1; x < kk; ++x) if (s_v[x] < mn) mn = s_v[x];
+        for (int i = 0; i < len; ++i)   // the reference scans its old buffer, in which the trim wrote NUL at nul0 / nul1
+          if (i != s_nul0 && i != s_nul1 && s_seg[i] == 'N') { if (mn >= 0) mn = 0; else if (mn <= 0) --mn; }
+        minOut[r] = mn; medOut[r] = s_med; avgOut[r] = (float)((double)s_sum / (double)kk); lenOut[r] = s_newLen;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // t4_hits: GetHitsFromRead + SortHits. pass 0 counts the hits per read, pass 1 writes them.
 __global__ __launch_bounds__(64) void hitsKernel(T4IndexView ix, T4BatchView bv, int strandArg, int allowTotalSkip, int pass,
                                                 long long *offsets, T4HitOut *out, unsigned long long *gKeys, int gCap, int *status) {
