@@ -95,6 +95,38 @@ def test_barcode_mode_emulated(tmp_path):
     _barcode_case(tmp_path, exe, 160, 8, 6, {"T4_LANES": "8", "T4_WINDOW": "3", "T4_THREADS": "2"})
 
 
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
+def test_device_kmer_counts_emulated(tmp_path):
+    """T4_GPU_KMERCOUNT=1: the 21-mer counts, the count statistics and the quality trimming come from t4_kmer_count_* instead of
+    the host threads (opt-in this round); the outputs must not move. FASTQ qualities with low tails so that the trim happens."""
+    import random
+    exe = _emulated_driver()
+    _barcode_case(tmp_path, exe, 160, 8, 6, {"T4_LANES": "8", "T4_WINDOW": "3", "T4_THREADS": "2", "T4_GPU_KMERCOUNT": "1"})
+    rnd = random.Random(5)
+    fa = str(tmp_path / "ref2.fa")
+    _gunzip(REF_FA, fa)
+    r1, r2 = Synth(12, 8).next_pairs(150)
+    files = []
+    for name, rows in (("q_1.fq", rows_to_strs(r1)), ("q_2.fq", rows_to_strs(r2))):
+        path = str(tmp_path / name)
+        with open(path, "w") as f:
+            for i, r in enumerate(rows):
+                tail = rnd.choice([0, 0, 10, 25, 60])
+                q = "".join(rnd.choice("FI:") for _ in range(len(r) - tail)) + "".join(rnd.choice("#+5") for _ in range(tail))
+                f.write("@r%d\n%s\n+\n%s\n" % (i, r, q))
+        files.append(path)
+    outs = {}
+    for tag, cmd, env in (("ref", [REF_BIN, "-t", "1"], {}), ("mine", [exe], {"T4_GPU_KMERCOUNT": "1"}), ("host", [exe], {})):
+        outs[tag] = str(tmp_path / ("bulk_" + tag))
+        subprocess.run(cmd + ["--skipMateExtension", "-f", fa, "-1", files[0], "-2", files[1], "-o", outs[tag]], check=True,
+                       stderr=subprocess.DEVNULL, env=dict(os.environ, **env))
+    for suffix in ("_raw.out", "_assembled_reads.fa", "_final.out"):
+        assert filecmp.cmp(outs["ref"] + suffix, outs["mine"] + suffix, shallow=False), suffix
+        assert filecmp.cmp(outs["ref"] + suffix, outs["host"] + suffix, shallow=False), suffix
+    trimmed = [len(l.strip()) for l in open(outs["ref"] + "_assembled_reads.fa") if not l.startswith(">")]
+    assert trimmed and min(trimmed) < 150   # the trim did happen
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not shipped")
 @pytest.mark.parametrize("extra", [["--contigMinCov", "3"], ["--keepNoBarcode"], ["--keepNoBarcode", "--contigMinCov", "2"]])

@@ -496,9 +496,38 @@ int main(int argc, char *argv[]) {
   if (!kmerCountFile.empty()) {   // -c: counts come from a k-mer counter's dump instead (main.cpp:694-699)
     if (!kmerCount.addCountFromFile(kmerCountFile.c_str())) { fprintf(stderr, "Could not open %s\n", kmerCountFile.c_str()); initThread.join(); return EXIT_FAILURE; }
     PrintLog("Read in the kmer count information from %s", kmerCountFile.c_str());
-  } else
+  }
+  // T4_GPU_KMERCOUNT=1 (opt-in this round): the 21-mer counts and the count statistics on the device
+  // (t4_kmer_count_*). Needs what the device path takes: no -c file, reads of at most 384 bp, qualities on every read or on none.
+  t4_kmer_counter *gpuKc = nullptr;
+  bool gpuQual = false;
+  const size_t KC_CHUNK = 1u << 22;
+  auto uploadChunk = [&](size_t lo, size_t hi, std::string &bases, std::vector<int64_t> &off) -> t4_batch * {
+    bases.clear(); off.assign(1, 0);
+    for (size_t i = lo; i < hi; ++i) { bases += sortedReads[i].read; off.push_back((int64_t)bases.size()); }
+    t4_batch *b = nullptr;
+    if ((rc = t4_reads_upload(ctx, bases.data(), off.data(), nullptr, (int64_t)(hi - lo), &b))) die(ctx, "t4_reads_upload", rc);
+    return b;
+  };
+  if (getenv("T4_GPU_KMERCOUNT") && atoi(getenv("T4_GPU_KMERCOUNT")) != 0 && kmerCountFile.empty() && readCnt > 0) {
+    size_t nQual = 0;
+    long long kmers = 0;
+    for (const SortRead &r : sortedReads) { if (r.hasQual) ++nQual; if ((int)r.read.size() >= 21) kmers += (long long)r.read.size() - 20; }
+    if (maxReadLen > 384) { fprintf(stderr, "trust4-hip: T4_GPU_KMERCOUNT takes reads of at most 384 bp (longest here: %d)\n", maxReadLen); initThread.join(); return EXIT_FAILURE; }
+    if (trimLevel != 0 && nQual != 0 && nQual != sortedReads.size()) { fprintf(stderr, "trust4-hip: T4_GPU_KMERCOUNT needs qualities on every read or on none\n"); initThread.join(); return EXIT_FAILURE; }
+    gpuQual = trimLevel != 0 && nQual == sortedReads.size();
+    gpuReady();
+    if ((rc = t4_kmer_count_create(ctx, 21, kmers + 16 < (1ll << 30) ? kmers + 16 : (1ll << 30), &gpuKc))) die(ctx, "t4_kmer_count_create", rc);
+    std::string bases; std::vector<int64_t> off;
+    for (size_t lo = 0; lo < sortedReads.size(); lo += KC_CHUNK) {
+      const size_t hi = lo + KC_CHUNK < sortedReads.size() ? lo + KC_CHUNK : sortedReads.size();
+      t4_batch *b = uploadChunk(lo, hi, bases, off);
+      if ((rc = t4_kmer_count_add(gpuKc, b))) die(ctx, "t4_kmer_count_add", rc);
+      t4_batch_destroy(b);
+    }
+  } else if (kmerCountFile.empty())
   kmerCount.addCountAll((long long)sortedReads.size(), threadCnt, [&](long long i) -> const std::string & { return sortedReads[(size_t)i].read; });
-  if (getenv("T4_TIMING")) PrintLog("timing: 21-mers counted");
+  if (getenv("T4_TIMING")) PrintLog("timing: 21-mers counted%s", gpuKc ? " (on the device)" : "");
   gpuReady();
   auto writeEmpty = [&](const char *suffix) { FILE *fp = fopen((outputPrefix + suffix).c_str(), "w"); if (fp) fclose(fp); };
   if (readCnt <= 0) { writeEmpty("_raw.out"); writeEmpty("_assembled_reads.fa"); writeEmpty("_final.out"); return 0; }
@@ -510,6 +539,27 @@ int main(int argc, char *argv[]) {
     readCnt = (int)sortedReads.size();
   }
   // ---- count statistics + quality trimming (main.cpp:980-1061)
+  if (gpuKc) {
+    std::string bases, quals; std::vector<int64_t> off;
+    std::vector<int32_t> mn, md, nl; std::vector<float> av;
+    for (size_t lo = 0; lo < sortedReads.size(); lo += KC_CHUNK) {
+      const size_t hi = lo + KC_CHUNK < sortedReads.size() ? lo + KC_CHUNK : sortedReads.size(), n = hi - lo;
+      t4_batch *b = uploadChunk(lo, hi, bases, off);
+      if (gpuQual) { quals.clear(); for (size_t i = lo; i < hi; ++i) quals += sortedReads[i].qual; }
+      mn.resize(n); md.resize(n); nl.resize(n); av.resize(n);
+      if ((rc = t4_kmer_count_stats(gpuKc, b, gpuQual ? quals.data() : nullptr, gpuQual ? off.data() : nullptr, mn.data(), md.data(), av.data(), nl.data()))) die(ctx, "t4_kmer_count_stats", rc);
+      t4_batch_destroy(b);
+      for (size_t i = 0; i < n; ++i) {
+        SortRead &r = sortedReads[lo + i];
+        r.minCnt = mn[i]; r.medianCnt = md[i]; r.avgCnt = av[i];
+        if ((size_t)nl[i] < r.read.size()) r.read.resize((size_t)nl[i]);
+        r.qual.clear(); r.qual.shrink_to_fit(); r.hasQual = false;
+        if (r.read.empty()) r.dead = true;
+      }
+    }
+    t4_kmer_count_destroy(gpuKc);
+    gpuKc = nullptr;
+  } else
   parallelFor((long long)sortedReads.size(), threadCnt, [&](long long i) {
     SortRead &r = sortedReads[(size_t)i];
     kmerCount.statsAndTrim(r.read, (trimLevel == 0 || !r.hasQual) ? nullptr : &r.qual, r.minCnt, r.medianCnt, r.avgCnt);
