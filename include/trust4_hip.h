@@ -239,7 +239,7 @@ int t4_cellset_counters(const t4_cellset *cs, int64_t *query_batches, int64_t *r
  * table lives in HBM (open addressing on the canonical code, 12 bytes per slot), one wavefront per read. Counts are exact.
  * k <= 31; `max_kmers` bounds the number of DISTINCT k-mers (the table gets at least twice as many slots; an insert that finds
  * it full makes t4_kmer_count_add fail with T4_ERR_UNSUPPORTED). Not built this round: AddCountFromFile (-c) and the 23-bucket
- * per-barcode counters; the stage-1 driver still counts on host threads. */
+ * per-barcode counters; the stage-1 driver calls this under T4_GPU_KMERCOUNT=1 and counts on host threads otherwise. */
 typedef struct t4_kmer_counter t4_kmer_counter;
 int t4_kmer_count_create(t4_ctx *ctx, int k, int64_t max_kmers, t4_kmer_counter **out);
 void t4_kmer_count_destroy(t4_kmer_counter *kc);
