@@ -98,10 +98,11 @@ def test_barcode_mode_emulated(tmp_path):
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
 def test_device_kmer_counts_emulated(tmp_path):
     """T4_GPU_KMERCOUNT=1: the 21-mer counts, the count statistics and the quality trimming come from t4_kmer_count_* instead of
-    the host threads (opt-in this round); the outputs must not move. FASTQ qualities with low tails so that the trim happens."""
+    the host threads; T4_GPU_MATEOVERLAP=1: ProcessRead's two IsMateOverlap tests per pair come from t4_mate_overlap (both opt-in
+    this round); the outputs must not move. FASTQ qualities with low tails so that the trim happens."""
     import random
     exe = _emulated_driver()
-    _barcode_case(tmp_path, exe, 160, 8, 6, {"T4_LANES": "8", "T4_WINDOW": "3", "T4_THREADS": "2", "T4_GPU_KMERCOUNT": "1"})
+    _barcode_case(tmp_path, exe, 160, 8, 6, {"T4_LANES": "8", "T4_WINDOW": "3", "T4_THREADS": "2", "T4_GPU_KMERCOUNT": "1", "T4_GPU_MATEOVERLAP": "1"})
     rnd = random.Random(5)
     fa = str(tmp_path / "ref2.fa")
     _gunzip(REF_FA, fa)
@@ -116,7 +117,7 @@ def test_device_kmer_counts_emulated(tmp_path):
                 f.write("@r%d\n%s\n+\n%s\n" % (i, r, q))
         files.append(path)
     outs = {}
-    for tag, cmd, env in (("ref", [REF_BIN, "-t", "1"], {}), ("mine", [exe], {"T4_GPU_KMERCOUNT": "1"}), ("host", [exe], {})):
+    for tag, cmd, env in (("ref", [REF_BIN, "-t", "1"], {}), ("mine", [exe], {"T4_GPU_KMERCOUNT": "1", "T4_GPU_MATEOVERLAP": "1"}), ("host", [exe], {})):
         outs[tag] = str(tmp_path / ("bulk_" + tag))
         subprocess.run(cmd + ["--skipMateExtension", "-f", fa, "-1", files[0], "-2", files[1], "-o", outs[tag]], check=True,
                        stderr=subprocess.DEVNULL, env=dict(os.environ, **env))

@@ -260,7 +260,9 @@ bool isLowComplexity(const std::string &s) {   // main.cpp:183-205
 
 // ProcessRead (main.cpp:224-449): read-through clipping, mate merging, low-complexity filter; the 21-mer counting of the
 // surviving reads (same multiset of AddCount calls) is done afterwards over the whole read list
-void processRead(const SortRead &in1, const SortRead &in2, bool hasMate2, std::vector<SortRead> &out) {
+// `pre` (optional): the two IsMateOverlap tests of this pair as t4_mate_overlap computed them for the whole block --
+// {ret, offset, bestMatchCnt} of (rc(mate 2), mate 1, minOverlap, no tandem check) and of (mate 1, rc(mate 2), minOverlap2, tandem check)
+void processRead(const SortRead &in1, const SortRead &in2, bool hasMate2, std::vector<SortRead> &out, const int32_t *pre = nullptr) {
   // private copies: every string this function frees was allocated by the calling thread (no cross-thread allocator traffic)
   SortRead r1 = in1, r2 = in2;
   int rWeight = 1;
@@ -273,7 +275,8 @@ void processRead(const SortRead &in1, const SortRead &in2, bool hasMate2, std::v
     if (minOverlap > 31) minOverlap = 31;
     if (minOverlap2 > 31) minOverlap2 = 31;
     int offset = -1, best = -1;
-    int ov = isMateOverlap(r2.read, r1.read, minOverlap, offset, best, false);
+    int ov;
+    if (pre) { ov = pre[0]; offset = pre[1]; best = pre[2]; } else ov = isMateOverlap(r2.read, r1.read, minOverlap, offset, best, false);
     if (ov >= 0) {   // read-through: keep the overlapped part of read 1
       r1.read.resize(ov);
       if (r1.hasQual) {
@@ -282,7 +285,7 @@ void processRead(const SortRead &in1, const SortRead &in2, bool hasMate2, std::v
           if (r2.qual[j + offset] > r1.qual[j] || r1.read[j] == 'N') { r1.read[j] = r2.read[j + offset]; r1.qual[j] = r2.qual[j + offset]; }
       }
       r2Alive = false;
-    } else if ((ov = isMateOverlap(r1.read, r2.read, minOverlap2, offset, best, true)) >= 0) {
+    } else if ((ov = pre ? (offset = pre[4], best = pre[5], (int)pre[3]) : isMateOverlap(r1.read, r2.read, minOverlap2, offset, best, true)) >= 0) {
       if (best >= 0.95 * ov) {   // merge the mates
         std::string r(slen + flen + 1, '\0'), q(slen + flen + 1, '\0');
         for (int j = 0; j < flen; ++j) { r[offset + j] = r2.read[j]; q[offset + j] = r2.hasQual ? r2.qual[j] : 0; }
@@ -437,10 +440,39 @@ int main(int argc, char *argv[]) {
   std::vector<InPair> block;
   const size_t BLOCK = 262144;
   double secProcess = 0, secMerge = 0;
+  // T4_GPU_MATEOVERLAP=1 (opt-in this round): the two AlignAlgo::IsMateOverlap tests of every pair of a block come from
+  // t4_mate_overlap (one pair per wavefront) instead of the host threads; the merge itself stays on the host.
+  const bool gpuMate = getenv("T4_GPU_MATEOVERLAP") && atoi(getenv("T4_GPU_MATEOVERLAP")) != 0;
   auto flushBlock = [&]() {   // ProcessRead of every pair of the block on the host threads, results appended in input order
     auto t0 = std::chrono::steady_clock::now();
     std::vector<std::vector<SortRead>> outs(block.size());
-    parallelFor((long long)block.size(), threadCnt, [&](long long i) { processRead(block[(size_t)i].a, block[(size_t)i].b, block[(size_t)i].haveMate, outs[(size_t)i]); });
+    std::vector<int32_t> pre;
+    bool anyMate = false;
+    for (const InPair &ip : block) if (ip.haveMate) { anyMate = true; break; }
+    if (gpuMate && anyMate) {
+      gpuReady();
+      const int n = (int)block.size();
+      std::string fc, sc;
+      std::vector<int64_t> fo(1, 0), so(1, 0);
+      std::vector<int32_t> mo1((size_t)n), mo2((size_t)n), o1((size_t)n * 3), o2((size_t)n * 3);
+      for (int i = 0; i < n; ++i) {
+        if (block[(size_t)i].haveMate) {
+          std::string rcMate = block[(size_t)i].b.read;
+          revCompInPlace(rcMate);
+          fc += rcMate; sc += block[(size_t)i].a.read;
+        }
+        fo.push_back((int64_t)fc.size()); so.push_back((int64_t)sc.size());
+        const int tot = block[(size_t)i].haveMate ? (int)(block[(size_t)i].a.read.size() + block[(size_t)i].b.read.size()) : 0;
+        mo1[(size_t)i] = tot / 10 > 31 ? 31 : tot / 10; mo2[(size_t)i] = tot / 20 > 31 ? 31 : tot / 20;
+      }
+      if ((rc = t4_mate_overlap(ctx, n, fo.data(), fc.data(), so.data(), sc.data(), mo1.data(), 0, o1.data()))) die(ctx, "t4_mate_overlap", rc);
+      if ((rc = t4_mate_overlap(ctx, n, so.data(), sc.data(), fo.data(), fc.data(), mo2.data(), 1, o2.data()))) die(ctx, "t4_mate_overlap", rc);
+      pre.resize((size_t)n * 6);
+      for (int i = 0; i < n; ++i) for (int j = 0; j < 3; ++j) { pre[(size_t)i * 6 + j] = o1[(size_t)i * 3 + j]; pre[(size_t)i * 6 + 3 + j] = o2[(size_t)i * 3 + j]; }
+    }
+    parallelFor((long long)block.size(), threadCnt, [&](long long i) {
+      processRead(block[(size_t)i].a, block[(size_t)i].b, block[(size_t)i].haveMate, outs[(size_t)i], pre.empty() ? nullptr : &pre[(size_t)i * 6]);
+    });
     auto t1 = std::chrono::steady_clock::now();
     for (auto &v : outs) for (SortRead &r : v) sortedReads.push_back(std::move(r));
     block.clear();
