@@ -100,9 +100,41 @@ def stage1_e2e(pairs, cells):
             out.update({"reference_pairs_per_s": pairs / t_ref, "reference_seconds": t_ref, "reference_threads": cores,
                         "identical": all(filecmp.cmp(os.path.join(tmp, "ref" + x), os.path.join(tmp, "mine" + x), shallow=False)
                                          for x in ("_raw.out", "_final.out", "_assembled_reads.fa"))})
+        # the same run with the opt-in device paths of the host phases (21-mer counts + count statistics, ProcessRead's mate tests);
+        # a failure here is reported, it does not take the bench line down
+        try:
+            env = dict(os.environ, T4_GPU_KMERCOUNT="1", T4_GPU_MATEOVERLAP="1")
+            t0 = time.perf_counter()
+            subprocess.run([os.path.join(ROOT, "trust4_amd", "bin", "trust4-hip"), "-t", str(cores)] + argv + ["-o", os.path.join(tmp, "dev")], check=True, stderr=subprocess.DEVNULL, env=env)
+            t_dev = time.perf_counter() - t0
+            out["device_host_phases"] = {"switches": "T4_GPU_KMERCOUNT=1 T4_GPU_MATEOVERLAP=1", "seconds": t_dev, "pairs_per_s": pairs / t_dev,
+                                         "identical_to_default": all(filecmp.cmp(os.path.join(tmp, "dev" + x), os.path.join(tmp, "mine" + x), shallow=False)
+                                                                     for x in ("_raw.out", "_final.out", "_assembled_reads.fa"))}
+        except Exception as e:   # noqa: BLE001
+            out["device_host_phases"] = {"error": repr(e)[:300]}
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def kmer_count_leg(eng, batch, n_reads):
+    """canonical 21-mer counts of the resident batch + count statistics of every read (t4_kmer_count_*), event-free
+    wall clock around the two calls (each ends with a stream synchronize)."""
+    try:
+        kc = eng.kmer_counter(21, max_kmers=33 * n_reads)
+        eng.check(eng.lib.t4_sync(eng.h))
+        t0 = time.perf_counter()
+        kc.add(batch)
+        t1 = time.perf_counter()
+        mn, md, av, ln = kc.stats(batch)
+        t2 = time.perf_counter()
+        out = {"workload": "21-mers of the %d resident reads: count (KmerCount::AddCount), then min / median / mean count per read (GetCountStatsAndTrim, no qualities)" % n_reads,
+               "count_reads_per_s": n_reads / (t1 - t0), "count_seconds": t1 - t0, "stats_reads_per_s": n_reads / (t2 - t1), "stats_seconds": t2 - t1,
+               "distinct_kmers": kc.distinct(), "mean_min_count": float(mn.mean())}
+        kc.close()
+        return out
+    except Exception as e:   # noqa: BLE001
+        return {"error": repr(e)[:300]}
 
 
 def stage0_e2e(pairs, receptor_fraction=0.02):
@@ -241,6 +273,7 @@ def main():
         if args.cpu_sample > 0 and world == 1:   # CPU legs on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(reads, args.cpu_sample)
         if args.e2e_pairs > 0 and world == 1:
+            out["kmer_count"] = kmer_count_leg(eng, batch, n_reads)
             out["stage1_e2e"] = stage1_e2e(args.e2e_pairs, max(1, args.e2e_pairs // 100))
             out["stage0_e2e"] = stage0_e2e(4 * args.e2e_pairs)
         print(json.dumps(out))

@@ -23,3 +23,29 @@ def test_kmer_counts_and_stats_gpu(eng):
 
 def test_kmer_count_k31_gpu(eng):
     check_engine_kmer_counts(eng, 22, 600, k=31)
+
+
+def test_driver_with_device_host_phases_gpu(tmp_path):
+    """trust4-hip with T4_GPU_KMERCOUNT=1 T4_GPU_MATEOVERLAP=1 (opt-in this round): same files as without the switches and, when
+    the reference binary travelled, as the reference's."""
+    import filecmp
+    import subprocess
+    from test_stage1_e2e import REF_BIN, _driver, _gunzip
+    from t4libs import REF_FA, ROOT
+    import t4libs
+    t4libs.build_checkers()
+    fa = str(tmp_path / "ref.fa")
+    _gunzip(REF_FA, fa)
+    pre = str(tmp_path / "c5")
+    subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, "3000", "0", "4", pre, "--cells", "60"], check=True, stdout=subprocess.DEVNULL)
+    args = ["-t", "4", "-f", fa, "-1", pre + "_1.fq", "-2", pre + "_2.fq", "--barcode", pre + "_bc.fa", "--UMI", pre + "_umi.fa"]
+    outs = {}
+    for tag, env in (("host", {}), ("dev", {"T4_GPU_KMERCOUNT": "1", "T4_GPU_MATEOVERLAP": "1"})):
+        outs[tag] = str(tmp_path / tag)
+        subprocess.run([_driver()] + args + ["-o", outs[tag]], check=True, env=dict(os.environ, **env), stderr=subprocess.DEVNULL)
+    if os.path.exists(REF_BIN):
+        outs["ref"] = str(tmp_path / "ref")
+        subprocess.run([REF_BIN] + args + ["-o", outs["ref"]], check=True, stderr=subprocess.DEVNULL)
+    for suffix in ("_raw.out", "_assembled_reads.fa", "_final.out"):
+        for tag in outs:
+            assert filecmp.cmp(outs["host"] + suffix, outs[tag] + suffix, shallow=False), (tag, suffix)
