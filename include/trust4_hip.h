@@ -238,10 +238,12 @@ int t4_cellset_counters(const t4_cellset *cs, int64_t *query_batches, int64_t *r
  * 1676-1701). Replaces KmerCount::AddCount (KmerCount.hpp:64-97) and GetCountStatsAndTrim (177-288) for whole batches: the
  * table lives in HBM (open addressing on the canonical code, 12 bytes per slot), one wavefront per read. Counts are exact.
  * k <= 31; `max_kmers` bounds the number of DISTINCT k-mers (the table gets at least twice as many slots; an insert that finds
- * it full makes t4_kmer_count_add fail with T4_ERR_UNSUPPORTED). Not built this round: AddCountFromFile (-c) and the 23-bucket
- * per-barcode counters; the stage-1 driver calls this under T4_GPU_KMERCOUNT=1 and counts on host threads otherwise. */
+ * it full makes t4_kmer_count_add fail with T4_ERR_UNSUPPORTED). Not built this round: AddCountFromFile (-c); the stage-1 driver calls this under T4_GPU_KMERCOUNT=1 and counts on host threads otherwise. */
 typedef struct t4_kmer_counter t4_kmer_counter;
-int t4_kmer_count_create(t4_ctx *ctx, int k, int64_t max_kmers, t4_kmer_counter **out);
+/* per_barcode != 0: one KmerCount per barcode in the same table -- the reference's `KmerCount barcodeKmerCount(21, 23)` that is
+ * filled, read and cleared barcode after barcode (main.cpp:1126-1160): the read's barcode (t4_reads_upload; at most 2^20 - 2) is
+ * part of the key, so reads only see the counts of their own barcode. Takes k <= 21. */
+int t4_kmer_count_create(t4_ctx *ctx, int k, int64_t max_kmers, int per_barcode, t4_kmer_counter **out);
 void t4_kmer_count_destroy(t4_kmer_counter *kc);
 /* AddCount of every read of the batch (reads shorter than k add nothing). */
 int t4_kmer_count_add(t4_kmer_counter *kc, t4_batch *reads);

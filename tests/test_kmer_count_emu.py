@@ -86,6 +86,31 @@ def test_kmer_count_other_k_emulated(emu_engine):
     check_engine_kmer_counts(emu_engine, 10, 60, k=9)
 
 
+def check_per_barcode_counts(eng, seed, n_reads, n_barcodes=7):
+    """per_barcode: one KmerCount per barcode in one table == a separate oracle counter per barcode (main.cpp:1126-1160)"""
+    rnd = random.Random(seed)
+    reads, _ = kmer_count_case(seed, n_reads, n_clones=6)   # few clones: the same k-mers in several barcodes
+    bcs = [rnd.randrange(-1, n_barcodes) for _ in reads]     # -1: reads without a barcode under --keepNoBarcode
+    oracles = {}
+    for r, b in zip(reads, bcs):
+        oracles.setdefault(b, KmerCountChecker(21)).add(r)
+    kc = eng.kmer_counter(21, max_kmers=sum(max(0, len(r) - 20) for r in reads) + 8, per_barcode=True)
+    batch = eng.upload(reads, bcs)
+    kc.add(batch)
+    mn, md, av, ln = kc.stats(batch)
+    for i, (r, b) in enumerate(zip(reads, bcs)):
+        _, omn, omd, oav, r_after, _ = oracles[b].stats(r, None)
+        assert (int(mn[i]), int(md[i])) == (omn, omd) and same(float(av[i]), float(oav)) and int(ln[i]) == len(r), (i, b, r)
+    with pytest.raises(Exception):
+        kc.add(eng.upload(reads))            # a batch without barcodes is refused
+    with pytest.raises(Exception):
+        eng.kmer_counter(31, 100, per_barcode=True)
+
+
+def test_per_barcode_counts_emulated(emu_engine):
+    check_per_barcode_counts(emu_engine, 14, 120)
+
+
 def test_kmer_count_table_full_is_loud(emu_engine):
     reads = rows_to_strs(Synth(40, 3).next_reads(40))
     kc = emu_engine.kmer_counter(21, max_kmers=16)   # 1024 slots: far too few

@@ -3,7 +3,7 @@ import os
 
 import pytest
 
-from test_kmer_count_emu import check_engine_kmer_counts
+from test_kmer_count_emu import check_engine_kmer_counts, check_per_barcode_counts
 
 pytestmark = pytest.mark.gpu
 
@@ -23,6 +23,10 @@ def test_kmer_counts_and_stats_gpu(eng):
 
 def test_kmer_count_k31_gpu(eng):
     check_engine_kmer_counts(eng, 22, 600, k=31)
+
+
+def test_per_barcode_counts_gpu(eng):
+    check_per_barcode_counts(eng, 23, 2000, n_barcodes=40)
 
 
 def test_driver_with_device_host_phases_gpu(tmp_path):

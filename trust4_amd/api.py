@@ -133,8 +133,8 @@ class Engine:
     def index(self, k, consider_barcode=False):
         return Index(self, k, consider_barcode)
 
-    def kmer_counter(self, k=21, max_kmers=1 << 20):
-        return KmerCounter(self, k, max_kmers)
+    def kmer_counter(self, k=21, max_kmers=1 << 20, per_barcode=False):
+        return KmerCounter(self, k, max_kmers, per_barcode)
 
     def upload(self, reads, barcodes=None):
         return Batch(self, reads, barcodes)
@@ -154,10 +154,10 @@ class Engine:
 class KmerCounter:
     """t4_kmer_counter: the reference's `KmerCount` (canonical k-mer counts of the read set, GetCountStatsAndTrim per read)."""
 
-    def __init__(self, eng, k, max_kmers):
+    def __init__(self, eng, k, max_kmers, per_barcode=False):
         self.eng = eng
         self.h = C.c_void_p()
-        eng.check(eng.lib.t4_kmer_count_create(eng.h, k, C.c_int64(max_kmers), C.byref(self.h)))
+        eng.check(eng.lib.t4_kmer_count_create(eng.h, k, C.c_int64(max_kmers), 1 if per_barcode else 0, C.byref(self.h)))
 
     def add(self, batch):
         self.eng.check(self.eng.lib.t4_kmer_count_add(self.h, batch.h))

@@ -830,15 +830,16 @@ struct t4_kmer_counter {
   unsigned long long slots = 0;
 };
 
-int t4_kmer_count_create(t4_ctx *c, int k, int64_t max_kmers, t4_kmer_counter **out) {
+int t4_kmer_count_create(t4_ctx *c, int k, int64_t max_kmers, int per_barcode, t4_kmer_counter **out) {
   if (!c || !out) return T4_ERR_ARG;
   if (k < 1 || k > 31 || max_kmers < 1) return fail(c, T4_ERR_ARG, "t4_kmer_count_create: k in 1..31 and max_kmers >= 1 (got %d, %lld)", k, (long long)max_kmers);
+  if (per_barcode && k > 21) return fail(c, T4_ERR_UNSUPPORTED, "t4_kmer_count_create: per-barcode counts take k <= 21 (the barcode shares the 64-bit key)");
   (void)hipSetDevice(c->device);
   unsigned long long slots = 1024;
   while (slots < 2ull * (unsigned long long)max_kmers) slots <<= 1;
   t4_kmer_counter *kc = new t4_kmer_counter;
   kc->ctx = c; kc->slots = slots;
-  kc->tb.k = k; kc->tb.mask = slots - 1;
+  kc->tb.k = k; kc->tb.mask = slots - 1; kc->tb.perBarcode = per_barcode ? 1 : 0;
   if (hipMalloc(&kc->tb.keys, sizeof(unsigned long long) * slots) != hipSuccess || hipMalloc(&kc->tb.cnt, sizeof(unsigned) * slots) != hipSuccess ||
       hipMalloc(&kc->tb.overflow, sizeof(int)) != hipSuccess) {
     t4_kmer_count_destroy(kc);
@@ -866,6 +867,7 @@ int t4_kmer_count_add(t4_kmer_counter *kc, t4_batch *b) {
   if (b->n == 0) return T4_OK;
   (void)hipSetDevice(c->device);
   const long long n = b->n;
+  if (kc->tb.perBarcode && !b->dBarcode) return fail(c, T4_ERR_ARG, "t4_kmer_count_add: per-barcode counts need a batch uploaded with barcodes");
   const int grid = (int)(n < (long long)c->cus * 32 ? n : (long long)c->cus * 32);
   hipLaunchKernelGGL(t4k::kmerAddKernel, dim3(grid), dim3(64), 0, c->stream, b->view, kc->tb);
   HIPCHK(c, hipGetLastError());
@@ -883,6 +885,7 @@ int t4_kmer_count_stats(t4_kmer_counter *kc, t4_batch *b, const char *quals, con
   if (b->ctx != c) return fail(c, T4_ERR_ARG, "batch belongs to another ctx");
   const long long n = b->n;
   if (n == 0) return T4_OK;
+  if (kc->tb.perBarcode && !b->dBarcode) return fail(c, T4_ERR_ARG, "t4_kmer_count_stats: per-barcode counts need a batch uploaded with barcodes");
   (void)hipSetDevice(c->device);
   int r;
   char *dQ = nullptr; long long *dOff = nullptr;

@@ -114,6 +114,7 @@ struct T4KmerTable {
   unsigned *cnt;
   unsigned long long mask;   // slots - 1 (slots is a power of two)
   int k;
+  int perBarcode;            // 1: the read's barcode is part of the key (bits 42..62; k <= 21) -- one KmerCount per barcode
   int *overflow;             // set when an insert found the table full
 };
 

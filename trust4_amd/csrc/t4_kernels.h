@@ -2869,9 +2869,10 @@ __global__ __launch_bounds__(64) void kmerAddKernel(T4BatchView bv, T4KmerTable 
     const int len = bv.len[r];
     if (len >= tb.k) {   // block-uniform
       loadSegment(bv, r, 0, len, wm);
+      const unsigned long long salt = (tb.perBarcode && bv.barcode) ? ((unsigned long long)(bv.barcode[r] + 1) << 42) : 0ull;
       for (int p = laneId(); p + tb.k <= len; p += 64) {
         bool valid;
-        const unsigned long long kc = canonicalAt(wm, len, p, tb.k, valid);
+        const unsigned long long kc = canonicalAt(wm, len, p, tb.k, valid) | salt;
         if (!valid) continue;
         unsigned long long h = kcMix(kc) & tb.mask, probes = 0;
         for (; probes <= tb.mask; ++probes) {
@@ -2907,9 +2908,10 @@ __global__ __launch_bounds__(64) void kmerStatsKernel(T4BatchView bv, T4KmerTabl
       continue;
     }
     loadSegment(bv, r, 0, len, wm);
+    const unsigned long long salt = (tb.perBarcode && bv.barcode) ? ((unsigned long long)(bv.barcode[r] + 1) << 42) : 0ull;
     for (int p = laneId(); p + K <= len; p += 64) {
       bool valid;
-      const unsigned long long kc = canonicalAt(wm, len, p, K, valid);
+      const unsigned long long kc = canonicalAt(wm, len, p, K, valid) | salt;
       int v = -1;
       if (valid) {
         v = 0;

@@ -534,13 +534,15 @@ int main(int argc, char *argv[]) {
   t4_kmer_counter *gpuKc = nullptr;
   bool gpuQual = false;
   const size_t KC_CHUNK = 1u << 22;
-  auto uploadChunk = [&](size_t lo, size_t hi, std::string &bases, std::vector<int64_t> &off) -> t4_batch * {
+  auto uploadChunk = [&](size_t lo, size_t hi, std::string &bases, std::vector<int64_t> &off, bool withBarcodes = false) -> t4_batch * {
     bases.clear(); off.assign(1, 0);
-    for (size_t i = lo; i < hi; ++i) { bases += sortedReads[i].read; off.push_back((int64_t)bases.size()); }
+    std::vector<int32_t> bcs;
+    for (size_t i = lo; i < hi; ++i) { bases += sortedReads[i].read; off.push_back((int64_t)bases.size()); if (withBarcodes) bcs.push_back(sortedReads[i].barcode); }
     t4_batch *b = nullptr;
-    if ((rc = t4_reads_upload(ctx, bases.data(), off.data(), nullptr, (int64_t)(hi - lo), &b))) die(ctx, "t4_reads_upload", rc);
+    if ((rc = t4_reads_upload(ctx, bases.data(), off.data(), withBarcodes ? bcs.data() : nullptr, (int64_t)(hi - lo), &b))) die(ctx, "t4_reads_upload", rc);
     return b;
   };
+  bool gpuKmerCounts = false;   // T4_GPU_KMERCOUNT was taken: the barcode-wise counts follow it
   if (getenv("T4_GPU_KMERCOUNT") && atoi(getenv("T4_GPU_KMERCOUNT")) != 0 && kmerCountFile.empty() && readCnt > 0) {
     size_t nQual = 0;
     long long kmers = 0;
@@ -548,8 +550,9 @@ int main(int argc, char *argv[]) {
     if (maxReadLen > 384) { fprintf(stderr, "trust4-hip: T4_GPU_KMERCOUNT takes reads of at most 384 bp (longest here: %d)\n", maxReadLen); initThread.join(); return EXIT_FAILURE; }
     if (trimLevel != 0 && nQual != 0 && nQual != sortedReads.size()) { fprintf(stderr, "trust4-hip: T4_GPU_KMERCOUNT needs qualities on every read or on none\n"); initThread.join(); return EXIT_FAILURE; }
     gpuQual = trimLevel != 0 && nQual == sortedReads.size();
+    gpuKmerCounts = true;
     gpuReady();
-    if ((rc = t4_kmer_count_create(ctx, 21, kmers + 16 < (1ll << 30) ? kmers + 16 : (1ll << 30), &gpuKc))) die(ctx, "t4_kmer_count_create", rc);
+    if ((rc = t4_kmer_count_create(ctx, 21, kmers + 16 < (1ll << 30) ? kmers + 16 : (1ll << 30), 0, &gpuKc))) die(ctx, "t4_kmer_count_create", rc);
     std::string bases; std::vector<int64_t> off;
     for (size_t lo = 0; lo < sortedReads.size(); lo += KC_CHUNK) {
       const size_t hi = lo + KC_CHUNK < sortedReads.size() ? lo + KC_CHUNK : sortedReads.size();
@@ -641,6 +644,27 @@ int main(int argc, char *argv[]) {
       groups.push_back({i, j});
       i = j;
     }
+    if (gpuKmerCounts) {   // one device table for all barcodes, the barcode being part of the key (t4_kmer_count_create, per_barcode)
+      long long kmers = 0;
+      for (const SortRead &r : sortedReads) if ((int)r.read.size() >= 21) kmers += (long long)r.read.size() - 20;
+      t4_kmer_counter *bkc = nullptr;
+      if ((rc = t4_kmer_count_create(ctx, 21, kmers + 16 < (1ll << 30) ? kmers + 16 : (1ll << 30), 1, &bkc))) die(ctx, "t4_kmer_count_create", rc);
+      std::string bases; std::vector<int64_t> off;
+      std::vector<int32_t> mn, md, nl; std::vector<float> av;
+      for (int pass = 0; pass < 2; ++pass)
+        for (size_t lo = 0; lo < sortedReads.size(); lo += KC_CHUNK) {
+          const size_t hi = lo + KC_CHUNK < sortedReads.size() ? lo + KC_CHUNK : sortedReads.size(), n = hi - lo;
+          t4_batch *b = uploadChunk(lo, hi, bases, off, true);
+          if (pass == 0) { if ((rc = t4_kmer_count_add(bkc, b))) die(ctx, "t4_kmer_count_add", rc); }
+          else {
+            mn.resize(n); md.resize(n); nl.resize(n); av.resize(n);
+            if ((rc = t4_kmer_count_stats(bkc, b, nullptr, nullptr, mn.data(), md.data(), av.data(), nl.data()))) die(ctx, "t4_kmer_count_stats", rc);
+            for (size_t i = 0; i < n; ++i) { SortRead &r = sortedReads[lo + i]; r.barcodeMinCnt = mn[i]; r.barcodeMedianCnt = md[i]; r.barcodeAvgCnt = av[i]; }
+          }
+          t4_batch_destroy(b);
+        }
+      t4_kmer_count_destroy(bkc);
+    } else
     parallelFor((long long)groups.size(), threadCnt, [&](long long gI) {   // one private counter per barcode
       const int i = groups[(size_t)gI].first, j = groups[(size_t)gI].second;
       KmerCounter bkc(21);
