@@ -21,3 +21,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 [ -f $R/gpurun_out/pmc_FETCH_SIZE.csv ] && [ -f $R/gpurun_out/pmc_WRITE_SIZE.csv ] && python $R/tools/pmc_summary.py $R/gpurun_out/pmc_FETCH_SIZE.csv $R/gpurun_out/pmc_WRITE_SIZE.csv $R/gpurun_out/pmc_summary.json
 echo "pmc done $(( $(date +%s) - T0 )) s"
+# host phases on the device (opt-in switches) and the k-mer kernels: whole stage 1 with and without, the counting benchmark
+cd $R
+python tools/kmer_count_bench.py 2000000 100000 > gpurun_out/kmer_count.txt 2>&1; tail -2 gpurun_out/kmer_count.txt
+T4_TIMING=1 python tools/e2e_cells_time.py 100000 1000 4 8 2>&1 | grep "pairs 100000\|timing" > gpurun_out/e2e_host.txt; head -1 gpurun_out/e2e_host.txt
+T4_GPU_KMERCOUNT=1 T4_GPU_MATEOVERLAP=1 T4_TIMING=1 python tools/e2e_cells_time.py 100000 1000 4 8 2>&1 | grep "pairs 100000\|timing" > gpurun_out/e2e_device.txt; head -1 gpurun_out/e2e_device.txt
+echo "opt-in legs done $(( $(date +%s) - T0 )) s"
