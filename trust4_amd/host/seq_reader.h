@@ -39,6 +39,7 @@ struct SeqReader {
       if (!fp) {
         if (cur >= files.size()) return false;
         fp = gzopen(files[cur].c_str(), "rb");
+        if (fp) gzbuffer(fp, 1 << 20);
         if (!fp) { fprintf(stderr, "Could not open %s\n", files[cur].c_str()); exit(EXIT_FAILURE); }
       }
       std::string line;
