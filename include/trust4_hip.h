@@ -238,7 +238,7 @@ int t4_cellset_counters(const t4_cellset *cs, int64_t *query_batches, int64_t *r
  * 1676-1701). Replaces KmerCount::AddCount (KmerCount.hpp:64-97) and GetCountStatsAndTrim (177-288) for whole batches: the
  * table lives in HBM (open addressing on the canonical code, 12 bytes per slot), one wavefront per read. Counts are exact.
  * k <= 31; `max_kmers` bounds the number of DISTINCT k-mers (the table gets at least twice as many slots; an insert that finds
- * it full makes t4_kmer_count_add fail with T4_ERR_UNSUPPORTED). Not built this round: AddCountFromFile (-c); the stage-1 driver calls this under T4_GPU_KMERCOUNT=1 and counts on host threads otherwise. */
+ * it full makes t4_kmer_count_add fail with T4_ERR_UNSUPPORTED). the stage-1 driver calls this under T4_GPU_KMERCOUNT=1 and counts on host threads otherwise. */
 typedef struct t4_kmer_counter t4_kmer_counter;
 /* per_barcode != 0: one KmerCount per barcode in the same table -- the reference's `KmerCount barcodeKmerCount(21, 23)` that is
  * filled, read and cleared barcode after barcode (main.cpp:1126-1160): the read's barcode (t4_reads_upload; at most 2^20 - 2) is
@@ -247,6 +247,10 @@ int t4_kmer_count_create(t4_ctx *ctx, int k, int64_t max_kmers, int per_barcode,
 void t4_kmer_count_destroy(t4_kmer_counter *kc);
 /* AddCount of every read of the batch (reads shorter than k add nothing). */
 int t4_kmer_count_add(t4_kmer_counter *kc, t4_batch *reads);
+/* KmerCount::AddCountFromFile (KmerCount.hpp:99-120; `-c FILE`, main.cpp:694-699) after the file was parsed on the host: the count of
+ * code[i] becomes counts[i] (codes as written in the file, NOT made canonical -- the reference does not either; of two records
+ * of one k-mer the later one stays). Not for per-barcode counters. */
+int t4_kmer_count_set(t4_kmer_counter *kc, const uint64_t *codes, const int32_t *counts, int64_t n);
 /* GetCountStatsAndTrim of every read of the batch. quals == NULL: no trimming (the reference's qual == NULL). Otherwise the
  * qualities of read i are the bytes quals[qual_off[i] .. qual_off[i + 1]) and must be as many as the read has bases.
  * Out (n entries each): min_cnt, median_cnt, avg_cnt as the reference leaves them (-1 for reads shorter than k, -len without a

@@ -111,6 +111,22 @@ def test_per_barcode_counts_emulated(emu_engine):
     check_per_barcode_counts(emu_engine, 14, 120)
 
 
+def test_kmer_count_set_emulated(emu_engine):
+    """AddCountFromFile semantics: counts keyed by the code as given, the later record of a k-mer stays"""
+    import ctypes as C
+    import numpy as np
+    kc = emu_engine.kmer_counter(21, max_kmers=64)
+    code = lambda s: int("".join(str("ACGT".index(c)) for c in s), 4)
+    canon, noncanon = "A" * 21, "T" * 20 + "G"            # AAAA..A is canonical (its reverse complement is TTTT..T)
+    codes = np.array([code(canon), code(noncanon), code(canon)], dtype=np.uint64)
+    vals = np.array([5, 9, 7], dtype=np.int32)
+    emu_engine.check(emu_engine.lib.t4_kmer_count_set(kc.h, codes.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p), C.c_int64(3)))
+    assert kc.distinct() == 2
+    mn, md, av, ln = kc.stats(emu_engine.upload([canon, "T" * 21, noncanon, "C" * 20 + "A" ]))
+    # A*21 and T*21 both look up the canonical A*21 (7: the later record); T..TG looks up its canonical form C A..A, which was never set
+    assert list(mn) == [7, 7, 1, 1]
+
+
 def test_kmer_count_table_full_is_loud(emu_engine):
     reads = rows_to_strs(Synth(40, 3).next_reads(40))
     kc = emu_engine.kmer_counter(21, max_kmers=16)   # 1024 slots: far too few

@@ -237,7 +237,7 @@ def _kmer_count_file(path, reads, k=21):
             f.write(">%d\n%s\n" % (c + 5, km))
 
 
-def _driver_options_case(tmp_path, driver, pairs, clones, seed):
+def _driver_options_case(tmp_path, driver, pairs, clones, seed, env=None):
     """-c (k-mer counts from a file), --debug-ns (contigs preloaded from a FASTA file) and `-o -PREFIX` (contig files on stdout)"""
     fa = str(tmp_path / "ref.fa")
     _gunzip(REF_FA, fa)
@@ -255,7 +255,7 @@ def _driver_options_case(tmp_path, driver, pairs, clones, seed):
     for name, extra in (("c", ["-c", cfile]), ("ns", ["--debug-ns", ns]), ("k", ["-k", "11", "--debug-ns", ns, "-c", cfile])):
         ref_out, my_out = str(tmp_path / ("ref_" + name)), str(tmp_path / ("mine_" + name))
         subprocess.run([REF_BIN, "-t", "1"] + base + extra + ["-o", ref_out], check=True, stderr=subprocess.DEVNULL)
-        subprocess.run([driver] + base + extra + ["-o", my_out], check=True)
+        subprocess.run([driver] + base + extra + ["-o", my_out], check=True, env=dict(os.environ, **(env or {})))
         for suffix in ("_raw.out", "_assembled_reads.fa", "_final.out"):
             assert filecmp.cmp(ref_out + suffix, my_out + suffix, shallow=False), (name, suffix)
     # stdout mode: both contig files on stdout, the assembled reads still in a file named after the prefix
@@ -273,6 +273,12 @@ def _driver_options_case(tmp_path, driver, pairs, clones, seed):
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
 def test_driver_options_emulated(tmp_path):
     _driver_options_case(tmp_path, _emulated_driver(), 60, 4, 9)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
+def test_driver_options_device_kmer_counts_emulated(tmp_path):
+    """-c with the counts on the device (T4_GPU_KMERCOUNT=1: t4_kmer_count_set)"""
+    _driver_options_case(tmp_path, _emulated_driver(), 60, 4, 9, {"T4_GPU_KMERCOUNT": "1"})
 
 
 @pytest.mark.gpu

@@ -878,6 +878,35 @@ int t4_kmer_count_add(t4_kmer_counter *kc, t4_batch *b) {
   return T4_OK;
 }
 
+int t4_kmer_count_set(t4_kmer_counter *kc, const uint64_t *codes, const int32_t *counts, int64_t n) {
+  if (!kc || n < 0 || (n > 0 && (!codes || !counts))) return T4_ERR_ARG;
+  t4_ctx *c = kc->ctx;
+  if (kc->tb.perBarcode) return fail(c, T4_ERR_ARG, "t4_kmer_count_set: not for per-barcode counters");
+  if (n == 0) return T4_OK;
+  (void)hipSetDevice(c->device);
+  std::unordered_map<uint64_t, int32_t> last;   // a later record of the same k-mer overwrites an earlier one
+  last.reserve((size_t)n * 2);
+  for (int64_t i = 0; i < n; ++i) last[codes[i]] = counts[i];
+  std::vector<unsigned long long> hc; std::vector<int> hv;
+  hc.reserve(last.size()); hv.reserve(last.size());
+  for (const auto &kv : last) { hc.push_back((unsigned long long)kv.first); hv.push_back((int)kv.second); }
+  const long long m = (long long)hc.size();
+  int r;
+  unsigned long long *dC = nullptr; int *dV = nullptr;
+  if ((r = devAlloc(c, &dC, (size_t)m)) || (r = devAlloc(c, &dV, (size_t)m))) return r;
+  HIPCHK(c, hipMemcpy(dC, hc.data(), sizeof(unsigned long long) * (size_t)m, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(dV, hv.data(), sizeof(int) * (size_t)m, hipMemcpyHostToDevice));
+  const int grid = (int)((m + 255) / 256 < (long long)c->cus * 8 ? (m + 255) / 256 : (long long)c->cus * 8);
+  hipLaunchKernelGGL(t4k::kmerSetKernel, dim3(grid), dim3(256), 0, c->stream, kc->tb, (const unsigned long long *)dC, (const int *)dV, m);
+  HIPCHK(c, hipGetLastError());
+  int overflow = 0;
+  HIPCHK(c, hipMemcpyAsync(&overflow, kc->tb.overflow, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(dC); (void)hipFree(dV);
+  if (overflow) return fail(c, T4_ERR_UNSUPPORTED, "t4_kmer_count_set: more distinct k-mers than the table was created for (%llu slots)", kc->slots);
+  return T4_OK;
+}
+
 int t4_kmer_count_stats(t4_kmer_counter *kc, t4_batch *b, const char *quals, const int64_t *qual_off,
                         int32_t *min_cnt, int32_t *median_cnt, float *avg_cnt, int32_t *new_len) {
   if (!kc || !b || !min_cnt || !median_cnt || !avg_cnt || !new_len || (quals && !qual_off)) return T4_ERR_ARG;

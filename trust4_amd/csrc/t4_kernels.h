@@ -2887,6 +2887,21 @@ __global__ __launch_bounds__(64) void kmerAddKernel(T4BatchView bv, T4KmerTable 
   }
 }
 
+// KmerCount::AddCountFromFile (KmerCount.hpp:99-120): counts given for k-mer codes as they were written (the host has already let
+// the later of two records of one k-mer win): count[code] = value.
+__global__ __launch_bounds__(256) void kmerSetKernel(T4KmerTable tb, const unsigned long long *codes, const int *counts, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const unsigned long long kc = codes[i];
+    unsigned long long h = kcMix(kc) & tb.mask, probes = 0;
+    for (; probes <= tb.mask; ++probes) {
+      const unsigned long long old = atomicCAS(&tb.keys[h], 0ull, kc + 1ull);
+      if (old == 0ull || old == kc + 1ull) { tb.cnt[h] = (unsigned)counts[i]; break; }
+      h = (h + 1ull) & tb.mask;
+    }
+    if (probes > tb.mask) *tb.overflow = 1;
+  }
+}
+
 // KmerCount::GetCountStatsAndTrim (KmerCount.hpp:177-288) for every read of the batch: min / median / mean count of the read's
 // valid k-mers (absent or non-positive counts read as 1), the quality trimming when quals != null (the read's qualities at
 // quals + qoff[r], as long as the read), and the N rule on the minimum. lenOut = the length the read is cut to (0: emptied).

@@ -543,7 +543,7 @@ int main(int argc, char *argv[]) {
     return b;
   };
   bool gpuKmerCounts = false;   // T4_GPU_KMERCOUNT was taken: the barcode-wise counts follow it
-  if (getenv("T4_GPU_KMERCOUNT") && atoi(getenv("T4_GPU_KMERCOUNT")) != 0 && kmerCountFile.empty() && readCnt > 0) {
+  if (getenv("T4_GPU_KMERCOUNT") && atoi(getenv("T4_GPU_KMERCOUNT")) != 0 && readCnt > 0) {
     size_t nQual = 0;
     long long kmers = 0;
     for (const SortRead &r : sortedReads) { if (r.hasQual) ++nQual; if ((int)r.read.size() >= 21) kmers += (long long)r.read.size() - 20; }
@@ -552,8 +552,14 @@ int main(int argc, char *argv[]) {
     gpuQual = trimLevel != 0 && nQual == sortedReads.size();
     gpuKmerCounts = true;
     gpuReady();
+    if (!kmerCountFile.empty()) { kmers = 16; for (const auto &m : kmerCount.shards) kmers += (long long)m.size(); }
     if ((rc = t4_kmer_count_create(ctx, 21, kmers + 16 < (1ll << 30) ? kmers + 16 : (1ll << 30), 0, &gpuKc))) die(ctx, "t4_kmer_count_create", rc);
     std::string bases; std::vector<int64_t> off;
+    if (!kmerCountFile.empty()) {   // -c: the counts parsed from the file above, as they are (t4_kmer_count_set)
+      std::vector<uint64_t> codes; std::vector<int32_t> vals;
+      for (const auto &m : kmerCount.shards) for (const auto &kv : m) { codes.push_back(kv.first); vals.push_back(kv.second); }
+      if ((rc = t4_kmer_count_set(gpuKc, codes.data(), vals.data(), (int64_t)codes.size()))) die(ctx, "t4_kmer_count_set", rc);
+    } else
     for (size_t lo = 0; lo < sortedReads.size(); lo += KC_CHUNK) {
       const size_t hi = lo + KC_CHUNK < sortedReads.size() ? lo + KC_CHUNK : sortedReads.size();
       t4_batch *b = uploadChunk(lo, hi, bases, off);
