@@ -273,6 +273,15 @@ def main():
         if args.cpu_sample > 0 and world == 1:   # CPU legs on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(reads, args.cpu_sample)
         if args.e2e_pairs > 0 and world == 1:
+            try:   # what the dynamic distribution of reads over the persistent grid buys: the same pass with the static stride
+                os.environ["T4_STATIC_STRIDE"] = "1"
+                step()
+                eng.check(eng.lib.t4_sync(eng.h))
+                out["scheduling_ab"] = {"static_stride_kernel_ms": eng.stats()["chain_kernel_ms"], "dynamic_kernel_ms": k_ms}
+            except Exception as e:   # noqa: BLE001
+                out["scheduling_ab"] = {"error": repr(e)[:300]}
+            finally:
+                os.environ.pop("T4_STATIC_STRIDE", None)
             out["kmer_count"] = kmer_count_leg(eng, batch, n_reads)
             out["stage1_e2e"] = stage1_e2e(args.e2e_pairs, max(1, args.e2e_pairs // 100))
             out["stage0_e2e"] = stage0_e2e(4 * args.e2e_pairs)
