@@ -26,7 +26,7 @@ needs_reference = pytest.mark.skipif(
     reason="needs /root/reference (run-trust4, report scripts), perl and oracle/_ref/{trust4,fastq-extractor,annotator}")
 
 
-def install_dir(path, trust4_bin, extractor_bin):
+def install_dir(path, trust4_bin, extractor_bin, bam_extractor_bin=None):
     os.makedirs(path)
     shutil.copy(os.path.join(REF_TREE, "run-trust4"), os.path.join(path, "run-trust4"))   # abs_path($0) must resolve to THIS directory
     for f in os.listdir(REF_TREE):
@@ -35,12 +35,15 @@ def install_dir(path, trust4_bin, extractor_bin):
     os.symlink(trust4_bin, os.path.join(path, "trust4"))
     os.symlink(extractor_bin, os.path.join(path, "fastq-extractor"))
     os.symlink(os.path.join(REF_BIN, "annotator"), os.path.join(path, "annotator"))
+    if bam_extractor_bin:
+        os.symlink(bam_extractor_bin, os.path.join(path, "bam-extractor"))
     return os.path.join(path, "run-trust4")
 
 
-def run_both(tmp_path, my_trust4, my_extractor, args):
-    runs = {"ref": install_dir(str(tmp_path / "inst_ref"), os.path.join(REF_BIN, "trust4"), os.path.join(REF_BIN, "fastq-extractor")),
-            "mine": install_dir(str(tmp_path / "inst_mine"), my_trust4, my_extractor)}
+def run_both(tmp_path, my_trust4, my_extractor, args, my_bam_extractor=None):
+    ref_bamx = os.path.join(REF_BIN, "bam-extractor")
+    runs = {"ref": install_dir(str(tmp_path / "inst_ref"), os.path.join(REF_BIN, "trust4"), os.path.join(REF_BIN, "fastq-extractor"), ref_bamx if my_bam_extractor else None),
+            "mine": install_dir(str(tmp_path / "inst_mine"), my_trust4, my_extractor, my_bam_extractor)}
     outs = {}
     for tag, script in runs.items():
         od = tmp_path / ("out_" + tag)
@@ -98,6 +101,17 @@ def test_barcode_pipeline_emulated(tmp_path):
     od, names = run_both(tmp_path, trust4, extractor, ["-f", fa, "--ref", os.path.join(REF_TREE, "human_IMGT+C.fa"), "-1", pre + "_1.fq", "-2", pre + "_2.fq",
                                                        "--barcode", pre + "_bc.fa", "--UMI", pre + "_umi.fa", "-t", "2"])
     assert "T_barcode_report.tsv" in names and "T_toassemble_bc.fa" in names
+
+
+@needs_reference
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_BIN, "bam-extractor")), reason="oracle/_ref/bam-extractor not built")
+def test_example_bam_pipeline_emulated(tmp_path):
+    """the same example from its BAM file: run-trust4 -b, stage 0 by bam-extractor (replaced by bam-extractor-hip)"""
+    from test_bam_extractor import emulated_bam_extractor
+    trust4, extractor = emulated_programs()
+    od, names = run_both(tmp_path, trust4, extractor, ["-f", os.path.join(REF_TREE, "hg38_bcrtcr.fa"), "--ref", os.path.join(REF_TREE, "human_IMGT+C.fa"),
+                                                       "-b", os.path.join(REF_TREE, "example", "example.bam"), "-t", "1", "--skipMateExtension"], emulated_bam_extractor())
+    assert "T_toassemble_1.fq" in names and os.path.getsize(os.path.join(od, "T_report.tsv")) > 100
 
 
 @pytest.mark.gpu

@@ -8,6 +8,7 @@ SRC = os.path.join(HERE, "csrc", "t4_api.hip")
 SRC_HOST = os.path.join(HERE, "csrc", "t4_assembler.cpp")
 OUT = os.path.join(HERE, "libt4hip.so")
 DEPS = [SRC, SRC_HOST, os.path.join(HERE, "host", "trust4_main.cpp"), os.path.join(HERE, "host", "fastq_extractor_main.cpp"),
+        os.path.join(HERE, "host", "bam_extractor_main.cpp"), os.path.join(HERE, "host", "bam_reader.h"), os.path.join(HERE, "host", "read_format.h"),
         os.path.join(HERE, "host", "seq_reader.h"), os.path.join(HERE, "csrc", "t4_internal.h"),
         os.path.join(HERE, "csrc", "t4_kernels.h"), os.path.join(HERE, "csrc", "t4_device.h"),
         os.path.join(os.path.dirname(HERE), "include", "trust4_hip.h")]
@@ -28,11 +29,12 @@ def build(force=False, verbose=False):
 
 def build_driver(verbose=False):
     """trust4_amd/bin/trust4-hip (stage 1, the reference's trust4 command line) and trust4_amd/bin/fastq-extractor-hip (stage-0
-    candidate filter, the reference's fastq-extractor for plain reads), linked against libt4hip.so."""
+    candidate filter, the reference's fastq-extractor) and trust4_amd/bin/bam-extractor-hip (the same for BAM input, the reference's
+    bam-extractor), linked against libt4hip.so."""
     out_dir = os.path.join(HERE, "bin")
     os.makedirs(out_dir, exist_ok=True)
     out = None
-    for name, src in (("fastq-extractor-hip", "fastq_extractor_main.cpp"), ("trust4-hip", "trust4_main.cpp")):
+    for name, src in (("fastq-extractor-hip", "fastq_extractor_main.cpp"), ("bam-extractor-hip", "bam_extractor_main.cpp"), ("trust4-hip", "trust4_main.cpp")):
         out = os.path.join(out_dir, name)
         cmd = ["g++", "-O2", "-std=c++17", "-o", out, os.path.join(HERE, "host", src), "-L" + HERE, "-lt4hip", "-Wl,-rpath," + HERE,
                "-Wl,-rpath,$ORIGIN/..", "-lz", "-lpthread"]
