@@ -195,11 +195,3 @@ def test_bam_extractor_synthetic_emulated(tmp_path):
 def test_bam_extractor_example_emulated(tmp_path):
     kept = compare(tmp_path, emulated_bam_extractor(), "/root/reference/example/example.bam", "/root/reference/hg38_bcrtcr.fa", [], True, False)
     assert kept == 198
-
-
-@pytest.mark.gpu
-@needs_ref
-def test_bam_extractor_synthetic_gpu(tmp_path):
-    import trust4_amd.build as b
-    b.build()
-    synthetic_cases(tmp_path, os.path.join(ROOT, "trust4_amd", "bin", "bam-extractor-hip"), 400)

@@ -1,4 +1,6 @@
-"""-m gpu: t4_kmer_count_* of the hipcc build against the C oracle (same checks as tests/test_kmer_count_emu.py, larger)."""
+"""-m gpu, last in the suite: what was written after the GPU budget of round 1 was spent and has only run in the emulator so far
+(plus the t4_kmer_count_* checks that did run on the MI355X) -- t4_kmer_count_* of the hipcc build against the C oracle (same checks as
+tests/test_kmer_count_emu.py, larger), the driver with the opt-in device host phases, bam-extractor-hip against the reference binary."""
 import os
 
 import pytest
@@ -53,3 +55,13 @@ def test_driver_with_device_host_phases_gpu(tmp_path):
     for suffix in ("_raw.out", "_assembled_reads.fa", "_final.out"):
         for tag in outs:
             assert filecmp.cmp(outs["host"] + suffix, outs[tag] + suffix, shallow=False), (tag, suffix)
+
+
+def test_bam_extractor_synthetic_gpu(tmp_path):
+    from test_bam_extractor import REF_BAMX, synthetic_cases
+    if not os.path.exists(REF_BAMX):
+        pytest.skip("oracle/_ref/bam-extractor not shipped")
+    import trust4_amd.build as b
+    from t4libs import ROOT
+    b.build()
+    synthetic_cases(tmp_path, os.path.join(ROOT, "trust4_amd", "bin", "bam-extractor-hip"), 400)
