@@ -183,6 +183,10 @@ def synthetic_cases(tmp_path, driver, n):
         synthetic_bam(bam, fa, paired, 7 + len(tag), barcodes, n)
         kept = compare(d, driver, bam, fa, (["--barcode", "CB", "--UMI", "UB"] if barcodes else []), paired, barcodes)
         assert kept >= n // 6, (tag, kept)
+        if not barcodes:   # -u: unaligned templates are not expected to come in adjacent records; both scans treat them differently
+            du = d / "u"
+            du.mkdir()
+            compare(du, driver, bam, fa, ["-u"], paired, False)
 
 
 @needs_ref
