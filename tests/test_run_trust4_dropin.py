@@ -114,6 +114,22 @@ def test_example_bam_pipeline_emulated(tmp_path):
     assert "T_toassemble_1.fq" in names and os.path.getsize(os.path.join(od, "T_report.tsv")) > 100
 
 
+@needs_reference
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_BIN, "bam-extractor")), reason="oracle/_ref/bam-extractor not built")
+def test_barcode_bam_pipeline_emulated(tmp_path):
+    """10x-style BAM input: run-trust4 -b in.bam --barcode CB --UMI UB (barcode and UMI from the BAM fields)"""
+    import test_bam_extractor as tb
+    fa = str(tmp_path / "ref.fa")
+    with gzip.open(REF_FA, "rb") as f, open(fa, "wb") as g:
+        shutil.copyfileobj(f, g)
+    bam = str(tmp_path / "in.bam")
+    tb.synthetic_bam(bam, fa, True, 12, True, 80)
+    trust4, extractor = emulated_programs()
+    od, names = run_both(tmp_path, trust4, extractor, ["-f", fa, "--ref", os.path.join(REF_TREE, "human_IMGT+C.fa"), "-b", bam, "--barcode", "CB", "--UMI", "UB", "-t", "1"],
+                         tb.emulated_bam_extractor())
+    assert "T_toassemble_bc.fa" in names and "T_barcode_report.tsv" in names
+
+
 @pytest.mark.gpu
 @needs_reference
 def test_example_pipeline_gpu(tmp_path):
