@@ -44,7 +44,6 @@ def check_engine_kmer_counts(eng, seed, n_reads, k=21):
     kc = eng.kmer_counter(k, max_kmers=sum(max(0, len(r) - k + 1) for r in reads) + 8)
     half = len(reads) // 2
     kc.add(eng.upload(reads[:half])).add(eng.upload(reads[half:]))   # counts accumulate over batches
-    distinct = set()
     batch = eng.upload(reads)
     for use_q in (False, True):
         mn, md, av, ln = kc.stats(batch, quals if use_q else None)
