@@ -74,6 +74,36 @@ int t4_index_commit(t4_index *ix);
  * UpdateIndexFromRead (KmerIndex.hpp:66-181) left behind, which is not a function of the sequences alone. */
 int t4_index_commit_postings(t4_index *ix, int64_t n, const uint64_t *code, const int32_t *bucket,
                              const int32_t *idx, const int32_t *offset);
+/* ---- mutable contig set on the device: the image is patched, never rebuilt ---------------------
+ * Replaces what KmerIndex::Insert / Remove / UpdateIndexFromRead / RemoveIndexFromRead (KmerIndex.hpp:66-101, 144-201)
+ * and the consensus / posWeight edits of SeqSet::AddRead (SeqSet.hpp:3988-4115, 4168-4360) do to the reference's in-memory
+ * set, for the device image of a set whose index is NOT keyed by barcode. The posting multiset of a mutated set is history
+ * dependent (not a function of the sequences), so the caller -- t4_assembler, which replays those edits on its host
+ * replica -- describes the change itself, by position in the image's four arrays:
+ *   table     open addressing on the k-mer code, slot = first free of mix64(code) & (table_slots - 1), +1, ... ; a slot is
+ *             (code, start, cnt): the key's postings are post[start .. start + cnt); keys are never removed (cnt may be 0)
+ *   post      (seq id, offset) pairs; the order inside a list is free (nothing downstream of SortHits observes it)
+ *   seqs      per contig: where its bases live, length, barcode, first 8 chars of the name
+ *   bases     consensus chars and IsBaseEqual predicate bytes (bit x = sum < 3 * count[x], bit 4 = sum == 0;
+ *             AlignAlgo.hpp:49-55) in one offset space, one terminator column after every contig
+ * Every destination is written once per call with its final value; capacities only grow (contents are kept), except
+ * that table_rebuilt != 0 means the table was re-hashed: it is emptied first and the delta carries every key.
+ * The first call turns an empty t4_index (consider_barcode == 0) into a live set; t4_add_query / t4_overlaps / t4_extend /
+ * t4_assign then run against it. Queries already launched are ordered before the patch on the ctx's stream. */
+typedef struct { int64_t base_off; int32_t len, barcode; char name[8]; } t4_seq_record;
+typedef struct {
+  int64_t table_slots;   /* power of two */
+  int32_t table_rebuilt;
+  int32_t seq_cap;
+  int64_t post_cap, base_cap;
+  int32_t nseq, max_seq_len;
+  int64_t n_slots; const int64_t *slot; const uint64_t *slot_code; const uint32_t *slot_start, *slot_cnt;
+  int64_t n_post_runs; const int64_t *post_at; const int32_t *post_len; const int32_t *post_data;   /* (idx, offset) pairs of all runs, concatenated */
+  int32_t n_seqs; const int32_t *seq_id; const t4_seq_record *seq;
+  int64_t n_base_runs; const int64_t *base_at; const int32_t *base_len; const char *base_cons; const uint8_t *base_pw;   /* bytes of all runs, concatenated */
+} t4_index_delta;
+int t4_index_apply_delta(t4_index *ix, const t4_index_delta *delta);
+
 /* Forget every sequence (keeps k, barcode mode and parameters) so the handle can be re-filled. */
 int t4_index_clear(t4_index *ix);
 int t4_index_size(const t4_index *ix);
@@ -180,6 +210,13 @@ int t4_assembler_repeat_add_read(t4_assembler *a, const char *read);
 int t4_assembler_prefetch(t4_assembler *a, int n, const char *const *reads, const int *strands, const int *barcodes,
                           int repetitive_data);
 int t4_assembler_window_valid(const t4_assembler *a);
+/* Host threads that derive the window's dependency sets while the GPU runs a query batch (default 1). */
+int t4_assembler_set_threads(t4_assembler *a, int host_threads);
+/* Counters of a set whose index is not keyed by barcode (device image by deltas, sliding window), up to 16 values:
+ * query rounds, reads queried, deltas, delta bytes, invalidations (total; by an index change of one of the read's keys; by a
+ * list crossing 100 postings; by a changed region within reach; by a left extension; by a whole-contig change; by exhausted
+ * tolerance), tolerated index changes, microseconds in deltas / dependency sets / event examination / query batches. */
+int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n);
 int t4_assembler_counters(const t4_assembler *a, int64_t *queries, int64_t *refreshes, int64_t *window_hits);
 /* host seconds spent refreshing the device image / in GPU query batches (upload + kernels + download) */
 int t4_assembler_timers(const t4_assembler *a, double *sec_refresh, double *sec_query);

@@ -21,7 +21,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline
-#define __shared__ static
+#define __shared__ static thread_local   /* one workgroup at a time per host worker thread */
 #define __launch_bounds__(...)
 #define __restrict__
 
@@ -46,10 +46,10 @@ struct hipDeviceProp_t { int multiProcessorCount; char name[64]; char gcnArchNam
 
 namespace hipemu {
 struct Tid { unsigned x, y, z; };
-extern Tid cur_tid, cur_bid;
-extern dim3 cur_bdim, cur_gdim;
-extern uint64_t xchg[1024];
-extern int nthreads, nalive;
+extern thread_local Tid cur_tid, cur_bid;
+extern thread_local dim3 cur_bdim, cur_gdim;
+extern thread_local uint64_t xchg[1024];
+extern thread_local int nthreads, nalive;
 void yield_lane(void *site = nullptr);
 void block_barrier(void *site);
 void wave_rendezvous(void *site);
@@ -124,20 +124,21 @@ static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long l
 static inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz((unsigned)x); }
 static inline int __clzll(long long x) { return x == 0 ? 64 : __builtin_clzll((unsigned long long)x); }
 
-template <class T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
-template <class T> static inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
-template <class T> static inline T atomicMin(T *p, T v) { T o = *p; if (v < o) *p = v; return o; }
-template <class T> static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
-template <class T> static inline T atomicCAS(T *p, T cmp, T v) { T o = *p; if (o == cmp) *p = v; return o; }
-template <class T> static inline T atomicExch(T *p, T v) { T o = *p; *p = v; return o; }
-static inline void __threadfence() {}
+// workgroups of one launch run on several host threads: real atomics (LDS atomics pay for it too, harmlessly)
+template <class T> static inline T atomicAdd(T *p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+template <class T> static inline T atomicMax(T *p, T v) { T o = __atomic_load_n(p, __ATOMIC_SEQ_CST); while (v > o && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {} return o; }
+template <class T> static inline T atomicMin(T *p, T v) { T o = __atomic_load_n(p, __ATOMIC_SEQ_CST); while (v < o && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {} return o; }
+template <class T> static inline T atomicOr(T *p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+template <class T> static inline T atomicCAS(T *p, T cmp, T v) { __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST); return cmp; }
+template <class T> static inline T atomicExch(T *p, T v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline void __threadfence_block() {}
 
 // ---- host API
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
-  memset(p, 0, sizeof(*p)); p->multiProcessorCount = 2; strcpy(p->name, "hipemu"); strcpy(p->gcnArchName, "emu");
+  memset(p, 0, sizeof(*p)); p->multiProcessorCount = 8; strcpy(p->name, "hipemu"); strcpy(p->gcnArchName, "emu");
   p->totalGlobalMem = 1ull << 34; return hipSuccess;
 }
 template <class T> static inline hipError_t hipMalloc(T **p, size_t n) { *p = (T *)calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorUnknown; }
@@ -165,3 +166,5 @@ static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t
 }
 #define hipStreamNonBlocking 1
 #define hipHostMallocDefault 0
+#define hipHostMallocMapped 2
+static inline hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { *d = h; return hipSuccess; }

@@ -16,7 +16,9 @@ for name, arr in (("s_1.fq", r1), ("s_2.fq", r2)):
 f1, f2 = os.path.join(tmp, "s_1.fq"), os.path.join(tmp, "s_2.fq")
 ref_bin = os.path.join(ROOT, "oracle", "_ref", "trust4")
 t0 = time.time(); subprocess.run([ref_bin, "-t", threads, "--skipMateExtension", "-f", fa, "-1", f1, "-2", f2, "-o", os.path.join(tmp, "ref")], check=True, stderr=subprocess.DEVNULL); t_ref = time.time() - t0
-t0 = time.time(); p = subprocess.run([os.path.join(ROOT, "trust4_amd", "bin", "trust4-hip"), "--skipMateExtension", "-f", fa, "-1", f1, "-2", f2, "-o", os.path.join(tmp, "mine")], check=True, stderr=subprocess.PIPE, text=True); t_mine = time.time() - t0
+t0 = time.time(); p = subprocess.run([os.path.join(ROOT, "trust4_amd", "bin", "trust4-hip"), "-t", threads, "--skipMateExtension", "-f", fa, "-1", f1, "-2", f2, "-o", os.path.join(tmp, "mine")], stderr=subprocess.PIPE, text=True); t_mine = time.time() - t0
+if p.returncode:
+    print("trust4-hip failed (%d):\n%s" % (p.returncode, "\n".join(p.stderr.strip().split("\n")[-12:]))); sys.exit(1)
 same = all(filecmp.cmp(os.path.join(tmp, "ref" + s), os.path.join(tmp, "mine" + s), shallow=False) for s in ("_raw.out", "_assembled_reads.fa", "_final.out"))
 print("pairs %d clones %d: reference -t %s %.1f s (%.0f pairs/s) | trust4-hip %.1f s (%.0f pairs/s) | identical=%s | contigs %d" % (
     pairs, clones, threads, t_ref, pairs / t_ref, t_mine, pairs / t_mine, same, open(os.path.join(tmp, "ref_raw.out")).read().count(">")))

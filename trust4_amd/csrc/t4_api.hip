@@ -35,9 +35,12 @@ const int TIER_CAP[T4_NTIER - 1] = {1024, 2048, 3072, 4096, 8192};
 // 8 x 20 KB of LDS, tier 1 4 groups of 4 waves in 4 x 39 KB, both at 128 VGPRs (4 waves / SIMD); the 3072-hit tier exists
 // because 3 of its groups fit a CU where only 2 of the 4096-hit tier do. 512/1024 threads per read in the upper tiers
 // measured slower (barriers).
-const int TIER_THREADS[T4_NTIER] = {128, 256, 256, 256, 512, 256};   // the 8192-hit tier has one group per CU (LDS): eight waves of it
+const int TIER_THREADS[T4_NTIER] = {128, 256, 256, 256, 512, 512};   // the 8192-hit tier has one group per CU (LDS): eight waves of it
 const int TIER_BLOCKS_PER_CU[T4_NTIER] = {8, 4, 3, 2, 1, 2};
-const int G_CAP = 32768, G_MAXOV = 4096;
+// global-scratch tier: hits and overlaps of one read pass (SURVEY 6 measured 50 036 hits for one AssignRead query at k = 17 and
+// 100 k pairs; a read of a gene segment that thousands of contigs share meets every one of them)
+const int G_CAP = 262144, G_MAXOV = 16384;
+constexpr int G_THREADS = 512;
 
 struct HostSeq {
   std::string name, cons;
@@ -76,6 +79,8 @@ struct t4_ctx {
   unsigned char *aqIn = nullptr, *aqOut = nullptr;      // device blobs
   unsigned char *aqInHost = nullptr, *aqOutHost = nullptr;   // pinned staging
   size_t aqInBytes = 0, aqOutBytes = 0;
+  unsigned char *aqPool = nullptr, *aqPoolDev = nullptr;   // result records of t4_add_query*: pinned host memory the kernels write
+  int aqPoolCap = 0;
 };
 
 struct t4_index {
@@ -95,6 +100,15 @@ struct t4_index {
   char *dCons = nullptr;
   T4PW *dPw = nullptr;
   T4IndexView view;
+  // live set (t4_index_apply_delta): capacities of the four arrays, staging of one delta
+  bool live = false;
+  T4HashEntC *dCtab = nullptr;
+  int64_t capTable = 0, capPost = 0, capBase = 0;
+  int capSeq = 0, liveNseq = 0;
+  unsigned char *stHost = nullptr, *stDev = nullptr;
+  size_t stCap = 0;
+  hipEvent_t stEvent = 0;
+  bool stPending = false;
 };
 
 struct t4_batch {
@@ -208,6 +222,7 @@ void t4_destroy(t4_ctx *c) {
                   c->listCounts, c->status, c->counts, c->hitCounter, c->result, c->aqIn, c->aqOut};
   if (c->aqInHost) (void)hipHostFree(c->aqInHost);
   if (c->aqOutHost) (void)hipHostFree(c->aqOutHost);
+  if (c->aqPool) (void)hipHostFree(c->aqPool);
   for (void *p : ptrs) if (p) (void)hipFree(p);
   for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -256,8 +271,11 @@ int t4_index_create(t4_ctx *c, int k, int consider_barcode, t4_index **out) {
 
 void t4_index_destroy(t4_index *ix) {
   if (!ix) return;
-  void *ptrs[] = {ix->dTable, ix->dHtab, ix->dPost, ix->dSeqs, ix->dCons, ix->dPw};
+  if (ix->live) (void)hipStreamSynchronize(ix->ctx->stream);
+  void *ptrs[] = {ix->dTable, ix->dHtab, ix->dPost, ix->dSeqs, ix->dCons, ix->dPw, ix->dCtab, ix->stDev};
   for (void *p : ptrs) if (p) (void)hipFree(p);
+  if (ix->stHost) (void)hipHostFree(ix->stHost);
+  if (ix->stEvent) (void)hipEventDestroy(ix->stEvent);
   delete ix;
 }
 
@@ -493,9 +511,143 @@ int commitWithPostings(t4_index *ix, std::vector<Rec> &recs) {
 }
 }  // namespace
 
+// ---- live set: patch the device image (see trust4_hip.h) ----------------------------------------------------------
+namespace {
+// grow a device array to `want` elements keeping its first `keep` elements (stream-ordered copy; the old block is freed
+// once the copy is done)
+template <class T> int growKeep(t4_ctx *c, T **p, int64_t keep, int64_t want) {
+  T *np = nullptr;
+  HIPCHK(c, hipMalloc(&np, sizeof(T) * (size_t)(want > 0 ? want : 1)));
+  if (*p && keep > 0) HIPCHK(c, hipMemcpyAsync(np, *p, sizeof(T) * (size_t)keep, hipMemcpyDeviceToDevice, c->stream));
+  if (*p) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(*p); }
+  *p = np;
+  return T4_OK;
+}
+}  // namespace
+
 extern "C" {
 
-int t4_index_size(const t4_index *ix) { return ix ? (int)ix->seqs.size() : 0; }
+int t4_index_apply_delta(t4_index *ix, const t4_index_delta *d) {
+  if (!ix || !d) return T4_ERR_ARG;
+  t4_ctx *c = ix->ctx;
+  (void)hipSetDevice(c->device);
+  if (ix->considerBarcode) return fail(c, T4_ERR_ARG, "t4_index_apply_delta: the index of a live set is not keyed by barcode");
+  if (!ix->live && (!ix->seqs.empty() || ix->committed)) return fail(c, T4_ERR_STATE, "t4_index_apply_delta on an index that was filled through t4_index_add_*");
+  if (d->table_slots < 2 || (d->table_slots & (d->table_slots - 1))) return fail(c, T4_ERR_ARG, "table_slots must be a power of two");
+  if (d->nseq < 0 || d->nseq > T4_MAX_SEQS) return fail(c, T4_ERR_UNSUPPORTED, "more than %d sequences", T4_MAX_SEQS);
+  if (d->max_seq_len > T4_MAX_SEQLEN) return fail(c, T4_ERR_UNSUPPORTED, "contig longer than %d", T4_MAX_SEQLEN);
+  if (d->post_cap > 0xFFFFFFFFll) return fail(c, T4_ERR_UNSUPPORTED, "more than 2^32 postings");
+  int r;
+  if (!ix->stEvent) HIPCHK(c, hipEventCreate(&ix->stEvent));
+  // capacities
+  if (d->table_slots != ix->capTable || d->table_rebuilt) {
+    if (d->table_slots != ix->capTable) {
+      if (ix->dCtab) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(ix->dCtab); ix->dCtab = nullptr; }
+      HIPCHK(c, hipMalloc(&ix->dCtab, sizeof(T4HashEntC) * (size_t)d->table_slots));
+      ix->capTable = d->table_slots;
+    }
+    HIPCHK(c, hipMemsetAsync(ix->dCtab, 0xFF, sizeof(T4HashEntC) * (size_t)ix->capTable, c->stream));   // code ~0 = empty
+  }
+  if (d->post_cap > ix->capPost) { int64_t want = d->post_cap + d->post_cap / 2; if ((r = growKeep(c, &ix->dPost, ix->capPost, want))) return r; ix->capPost = want; }
+  if (d->seq_cap > ix->capSeq) { int want = d->seq_cap + d->seq_cap / 2; if ((r = growKeep(c, &ix->dSeqs, (int64_t)ix->capSeq, (int64_t)want))) return r; ix->capSeq = want; }
+  if (d->base_cap > ix->capBase) {
+    int64_t want = d->base_cap + d->base_cap / 2;
+    if ((r = growKeep(c, &ix->dCons, ix->capBase, want))) return r;
+    if ((r = growKeep(c, &ix->dPw, ix->capBase, want))) return r;
+    ix->capBase = want;
+  }
+  // staging: descriptors, then the payload (8-byte aligned pieces)
+  auto al8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
+  int64_t postTotal = 0, baseTotal = 0;
+  for (int64_t i = 0; i < d->n_post_runs; ++i) {
+    if (d->post_at[i] < 0 || d->post_len[i] < 0 || d->post_at[i] + d->post_len[i] > ix->capPost) return fail(c, T4_ERR_ARG, "posting run %lld outside the image", (long long)i);
+    postTotal += d->post_len[i];
+  }
+  for (int64_t i = 0; i < d->n_base_runs; ++i) {
+    if (d->base_at[i] < 0 || d->base_len[i] < 0 || d->base_at[i] + d->base_len[i] > ix->capBase) return fail(c, T4_ERR_ARG, "base run %lld outside the image", (long long)i);
+    baseTotal += d->base_len[i];
+  }
+  const size_t nDesc = (size_t)d->n_slots + (size_t)d->n_post_runs + (size_t)d->n_seqs + 2 * (size_t)d->n_base_runs;
+  if (nDesc == 0) goto view;
+  {
+    size_t bytes = al8(sizeof(T4CopyDesc) * nDesc) + sizeof(T4HashEntC) * (size_t)d->n_slots + 8 * (size_t)postTotal + al8(sizeof(T4SeqInfo)) * (size_t)d->n_seqs;
+    for (int64_t i = 0; i < d->n_base_runs; ++i) bytes += 2 * al8((size_t)d->base_len[i]);
+    if (ix->stPending) { HIPCHK(c, hipEventSynchronize(ix->stEvent)); ix->stPending = false; }
+    if (bytes > ix->stCap) {
+      if (ix->stHost) (void)hipHostFree(ix->stHost);
+      if (ix->stDev) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(ix->stDev); }
+      ix->stHost = nullptr; ix->stDev = nullptr;
+      ix->stCap = bytes * 2 > ((size_t)1 << 20) ? bytes * 2 : ((size_t)1 << 20);
+      HIPCHK(c, hipHostMalloc(&ix->stHost, ix->stCap, hipHostMallocDefault));
+      HIPCHK(c, hipMalloc(&ix->stDev, ix->stCap));
+    }
+    T4CopyDesc *desc = (T4CopyDesc *)ix->stHost;
+    size_t at = al8(sizeof(T4CopyDesc) * nDesc), nd = 0;
+    for (int64_t i = 0; i < d->n_slots; ++i) {
+      if (d->slot[i] < 0 || d->slot[i] >= ix->capTable) return fail(c, T4_ERR_ARG, "table slot %lld outside the table", (long long)d->slot[i]);
+      T4HashEntC e; e.code = d->slot_code[i]; e.start = d->slot_start[i]; e.cnt = d->slot_cnt[i];
+      memcpy(ix->stHost + at, &e, sizeof e);
+      desc[nd].srcOff = at; desc[nd].dst = (unsigned char *)(ix->dCtab + d->slot[i]); desc[nd].bytes = sizeof e; ++nd;
+      at += sizeof e;
+    }
+    int64_t pAt = 0;
+    for (int64_t i = 0; i < d->n_post_runs; ++i) {
+      const size_t b = 8 * (size_t)d->post_len[i];
+      memcpy(ix->stHost + at, d->post_data + 2 * pAt, b);
+      desc[nd].srcOff = at; desc[nd].dst = (unsigned char *)(ix->dPost + d->post_at[i]); desc[nd].bytes = b; ++nd;
+      at += b; pAt += d->post_len[i];
+    }
+    for (int i = 0; i < d->n_seqs; ++i) {
+      const int id = d->seq_id[i];
+      if (id < 0 || id >= ix->capSeq || id >= d->nseq) return fail(c, T4_ERR_ARG, "sequence id %d outside the image", id);
+      const t4_seq_record &q = d->seq[i];
+      if (q.len < 0 || q.base_off < 0 || q.base_off + q.len + 1 > ix->capBase || q.base_off > 0x7FFFFFFFll) return fail(c, T4_ERR_ARG, "sequence %d outside the base arena", id);
+      T4SeqInfo f;
+      memset(&f, 0, sizeof f);
+      f.consOff = (int)q.base_off; f.len = q.len; f.pwOff = (int)q.base_off; f.barcode = q.barcode; f.isRef = 0;
+      char nm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      memcpy(nm, q.name, 8);
+      const int gt = geneType(nm);
+      f.geneType = gt < 0 ? 255 : (unsigned char)gt;
+      f.name0 = (unsigned char)nm[0]; f.name1 = (unsigned char)nm[1]; f.name2 = (unsigned char)nm[2]; f.name3 = (unsigned char)nm[3];
+      memset(ix->stHost + at, 0, al8(sizeof f));
+      memcpy(ix->stHost + at, &f, sizeof f);
+      desc[nd].srcOff = at; desc[nd].dst = (unsigned char *)(ix->dSeqs + id); desc[nd].bytes = sizeof f; ++nd;
+      at += al8(sizeof f);
+    }
+    int64_t bAt = 0;
+    for (int64_t i = 0; i < d->n_base_runs; ++i) {
+      const size_t b = (size_t)d->base_len[i];
+      memcpy(ix->stHost + at, d->base_cons + bAt, b);
+      desc[nd].srcOff = at; desc[nd].dst = (unsigned char *)(ix->dCons + d->base_at[i]); desc[nd].bytes = b; ++nd;
+      at += al8(b);
+      memcpy(ix->stHost + at, d->base_pw + bAt, b);
+      desc[nd].srcOff = at; desc[nd].dst = (unsigned char *)(ix->dPw + d->base_at[i]); desc[nd].bytes = b; ++nd;
+      at += al8(b);
+      bAt += d->base_len[i];
+    }
+    HIPCHK(c, hipMemcpyAsync(ix->stDev, ix->stHost, at, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(ix->stEvent, c->stream));
+    ix->stPending = true;
+    int grid = (int)((nd + 3) / 4);
+    if (grid > c->cus * 8) grid = c->cus * 8;
+    hipLaunchKernelGGL(t4k::deltaKernel, dim3(grid), dim3(256), 0, c->stream, (const unsigned char *)ix->stDev, (const T4CopyDesc *)ix->stDev, (int)nd);
+    HIPCHK(c, hipGetLastError());
+  }
+view:
+  ix->live = true; ix->committed = true; ix->liveNseq = d->nseq;
+  T4IndexView &v = ix->view;
+  memset(&v, 0, sizeof v);
+  v.k = ix->k; v.nseq = d->nseq; v.direct = 3; v.considerBarcode = 0;
+  v.hashMask = (unsigned long long)ix->capTable - 1; v.ctab = ix->dCtab; v.post = ix->dPost; v.seqs = ix->dSeqs; v.cons = ix->dCons; v.pw = ix->dPw;
+  v.radius = ix->radius; v.hitLenRequired = ix->hitLenRequired; v.nomatchGapLimit = ix->nomatchGapLimit;
+  v.firstIsRef = 0; v.hasNovel = 2;
+  v.key32 = t4Key32Bits(d->nseq, d->max_seq_len);
+  v.novelSim = ix->novelSim; v.refSim = ix->refSim; v.repeatSim = ix->repeatSim;
+  return T4_OK;
+}
+
+int t4_index_size(const t4_index *ix) { return ix ? (ix->live ? ix->liveNseq : (int)ix->seqs.size()) : 0; }
 int t4_index_seq_len(const t4_index *ix, int i) { return (ix && i >= 0 && i < (int)ix->seqs.size()) ? (int)ix->seqs[i].cons.size() : -1; }
 const char *t4_index_seq_name(const t4_index *ix, int i) { return (ix && i >= 0 && i < (int)ix->seqs.size()) ? ix->seqs[i].name.c_str() : nullptr; }
 const char *t4_index_seq_consensus(const t4_index *ix, int i) { return (ix && i >= 0 && i < (int)ix->seqs.size()) ? ix->seqs[i].cons.c_str() : nullptr; }
@@ -632,7 +784,7 @@ int runQuery(t4_index *ix, t4_batch *b, T4QueryArgs qa, bool useBarcode, bool no
       if ((r = ensureGlobalTier(c, grids[T4_NTIER - 1]))) return r;
       wk.gKeys = c->gKeys; wk.gPairs = c->gPairs; wk.gCand = c->gCand; wk.gOv = c->gOv; wk.gFin = c->gFin; wk.gOrd = c->gOrd;
       wk.gCap = G_CAP; wk.gMaxOv = G_MAXOV;
-      launchTier<0, 0, 256>(grid, c->stream, ix->view, b->view, wk, qa);
+      launchTier<0, 0, G_THREADS>(grid, c->stream, ix->view, b->view, wk, qa);
     } else if (t == 0) {
       static const int nt0 = getenv("T4_T0_THREADS") ? atoi(getenv("T4_T0_THREADS")) : TIER_THREADS[0];
       static const int bl0 = getenv("T4_T0_BLOCKS") ? atoi(getenv("T4_T0_BLOCKS")) : TIER_BLOCKS_PER_CU[0];
@@ -668,7 +820,7 @@ int runQuery(t4_index *ix, t4_batch *b, T4QueryArgs qa, bool useBarcode, bool no
   for (long long i = 0; i < n; ++i)
     if (status[i] != 0)
       return fail(c, T4_ERR_UNSUPPORTED, "read %lld exceeds the engine limits (status %d: %s)", i, status[i],
-                  status[i] == 2 ? "more than 32768 k-mer hits or 4096 overlaps" : "gap DP or contig count beyond scratch");
+                  status[i] == 2 ? "more than 262144 k-mer hits or 16384 overlaps" : "gap DP or contig count beyond scratch");
   return T4_OK;
 }
 
@@ -1022,12 +1174,15 @@ int t4_extend(t4_index *ix, t4_batch *b, int max_per_read, const int32_t *counts
 }  // extern "C"
 
 namespace {
-// The query half of SeqSet::AddRead for a batch of reads, lean path: one blob in, one blob out. Either every read is
+// The query half of SeqSet::AddRead for a batch of reads, lean path: one blob in, a small header blob out, and the result
+// records written by the kernel straight into a pinned host pool (variable number per read, SeqSet's std::vector<_overlap>):
+// one launch (plus one per overflow tier that is needed) and one stream synchronisation per call. Either every read is
 // matched against `base` (viewOf == nullptr; first launch on the 8192-hit LDS tier) or read i against views[viewOf[i]]
 // (per-barcode images: reads meet a handful of contigs, so the first launch is the 1024-hit tier at 6 groups / CU).
-int addQueryImpl(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const int32_t *viewOf, bool smallFirst, int n, const char *bases,
-                 const int64_t *offsets, const int32_t *barcodes, const int32_t *strands, int skip_repeats, const double *factors,
-                 int max_per_read, int32_t *counts, t4_overlap *ov, t4_overlap *ext, int32_t *ext_ret) {
+// On return counts[i] records of read i start at index base[i] of ov / ext / ret (valid until the next call on this ctx).
+struct AqResult { const int32_t *counts, *base; const t4_overlap *ov, *ext; const int32_t *ret; };
+int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const int32_t *viewOf, bool smallFirst, int n, const char *bases,
+                 const int64_t *offsets, const int32_t *barcodes, const int32_t *strands, int skip_repeats, const double *factors, AqResult *res) {
   (void)hipSetDevice(c->device);
   int maxLen = 1;
   for (int i = 0; i < n; ++i) {
@@ -1037,15 +1192,14 @@ int addQueryImpl(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
   }
   const int wpk = (maxLen + 15) / 16, wnm = (maxLen + 31) / 32;
   // input blob: pk | nm | len | barcode | strand | list(iota) | viewOf | factor
-  // output blob: counts | status | next1 | next2 | ov | ext | ret | tail{overflow1, overflow2, hits}
+  // header blob: counts | status | next1 | next2 | outBase | tail{overflow1, overflow2, hits, pool cursor}
   auto al8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
   const size_t oPk = 0, oNm = al8(oPk + sizeof(unsigned) * (size_t)n * wpk), oLen = al8(oNm + sizeof(unsigned) * (size_t)n * wnm),
                oBc = al8(oLen + sizeof(int) * (size_t)n), oSt = al8(oBc + sizeof(int) * (size_t)n), oLs = al8(oSt + sizeof(int) * (size_t)n),
                oVw = al8(oLs + sizeof(int) * (size_t)n), oFa = al8(oVw + sizeof(int) * (size_t)n), inBytes = al8(oFa + sizeof(double) * (size_t)n);
-  const size_t m = (size_t)n * max_per_read;
   const size_t pCnt = 0, pSta = al8(pCnt + sizeof(int) * (size_t)n), pNext = al8(pSta + sizeof(int) * (size_t)n),
-               pNext2 = al8(pNext + sizeof(int) * (size_t)n), pOv = al8(pNext2 + sizeof(int) * (size_t)n),
-               pEx = al8(pOv + sizeof(t4_overlap) * m), pRet = al8(pEx + sizeof(t4_overlap) * m), pTail = al8(pRet + sizeof(int) * m), outBytes = pTail + 24;
+               pNext2 = al8(pNext + sizeof(int) * (size_t)n), pBase = al8(pNext2 + sizeof(int) * (size_t)n),
+               pTail = al8(pBase + sizeof(int) * (size_t)n), outBytes = pTail + 32;
   int r;
   if (inBytes > c->aqInBytes) {
     if (c->aqIn) (void)hipFree(c->aqIn);
@@ -1082,71 +1236,104 @@ int addQueryImpl(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
       p[j >> 4] |= (unsigned)v << ((j & 15) * 2);
     }
   }
-  HIPCHK(c, hipMemcpyAsync(c->aqIn, h, inBytes, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->aqOut, 0, pOv, c->stream));          // counts, status, overflow lists
-  HIPCHK(c, hipMemsetAsync(c->aqOut + pTail, 0, 24, c->stream));
-  T4BatchView bv;
-  bv.pk = (const unsigned *)(c->aqIn + oPk); bv.nm = (const unsigned *)(c->aqIn + oNm); bv.len = (const int *)(c->aqIn + oLen);
-  bv.barcode = (const int *)(c->aqIn + oBc); bv.wpk = wpk; bv.wnm = wnm; bv.n = n;
-  T4QueryArgs qa;
-  memset(&qa, 0, sizeof qa);
-  memset(&qa, 0, sizeof qa);
-  qa.mode = 4; qa.skipRepeats = skip_repeats; qa.maxPerRead = max_per_read;
-  qa.counts = (int *)(c->aqOut + pCnt); qa.out = (T4OverlapOut *)(c->aqOut + pOv); qa.outExt = (T4OverlapOut *)(c->aqOut + pEx);
-  qa.ret = (int *)(c->aqOut + pRet); qa.strandPerRead = (const int *)(c->aqIn + oSt); qa.factorPerRead = (const double *)(c->aqIn + oFa);
-  if (views) { qa.views = views; qa.viewOf = (const int *)(c->aqIn + oVw); }
-  const int threads = 256;
-  const int grid0 = smallFirst ? (n < c->cus * TIER_BLOCKS_PER_CU[0] ? n : c->cus * TIER_BLOCKS_PER_CU[0]) : n;
-  if ((r = ensureScratch(c, (grid0 > c->cus * 2 ? grid0 : c->cus * 2) * threads))) return r;
-  T4Work wk;
-  memset(&wk, 0, sizeof wk);
-  wk.list = (const int *)(c->aqIn + oLs); wk.nList = n;
-  wk.nextList = (int *)(c->aqOut + pNext); wk.nextCount = (int *)(c->aqOut + pTail);
-  wk.status = (int *)(c->aqOut + pSta); wk.hitCounter = (unsigned long long *)(c->aqOut + pTail + 16);
-  wk.dpRows = c->dpRows; wk.dpDir = c->dpDir;
-  if (smallFirst) launchTier<1024, 128, 256>(grid0, c->stream, base, bv, wk, qa);
-  else launchTier<8192, 512, 256>(grid0, c->stream, base, bv, wk, qa);
-  HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(c->aqOutHost, c->aqOut, outBytes, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  int overflow = *(int *)(c->aqOutHost + pTail);
-  if (overflow > 0 && smallFirst) {   // reads beyond the 1024-hit tier: 8192-hit LDS tier
-    T4Work w1 = wk;
-    w1.list = (const int *)(c->aqOut + pNext); w1.nList = overflow;
-    w1.nextList = (int *)(c->aqOut + pNext2); w1.nextCount = (int *)(c->aqOut + pTail + 8);
-    if ((r = ensureScratch(c, (overflow > c->cus * 2 ? overflow : c->cus * 2) * threads))) return r;
-    w1.dpRows = c->dpRows; w1.dpDir = c->dpDir;
-    launchTier<8192, 512, 256>(overflow, c->stream, base, bv, w1, qa);
+  for (int attempt = 0;; ++attempt) {
+    if (!c->aqPool) {
+      if (!c->aqPoolCap) c->aqPoolCap = 1 << 16;
+      const size_t rec = (size_t)c->aqPoolCap;
+      HIPCHK(c, hipHostMalloc(&c->aqPool, rec * (2 * sizeof(t4_overlap) + sizeof(int32_t)), hipHostMallocMapped));
+      HIPCHK(c, hipHostGetDevicePointer((void **)&c->aqPoolDev, c->aqPool, 0));
+    }
+    const size_t rec = (size_t)c->aqPoolCap;
+    HIPCHK(c, hipMemcpyAsync(c->aqIn, h, inBytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->aqOut, 0, outBytes, c->stream));   // counts, status, overflow lists, bases, tail
+    T4BatchView bv;
+    bv.pk = (const unsigned *)(c->aqIn + oPk); bv.nm = (const unsigned *)(c->aqIn + oNm); bv.len = (const int *)(c->aqIn + oLen);
+    bv.barcode = (const int *)(c->aqIn + oBc); bv.wpk = wpk; bv.wnm = wnm; bv.n = n;
+    T4QueryArgs qa;
+    memset(&qa, 0, sizeof qa);
+    qa.mode = 4; qa.skipRepeats = skip_repeats; qa.maxPerRead = 0;
+    qa.counts = (int *)(c->aqOut + pCnt);
+    qa.out = (T4OverlapOut *)c->aqPoolDev; qa.outExt = qa.out + rec; qa.ret = (int *)(qa.outExt + rec);
+    qa.outBase = (int *)(c->aqOut + pBase); qa.poolCursor = (unsigned *)(c->aqOut + pTail + 24); qa.poolCap = c->aqPoolCap;
+    qa.strandPerRead = (const int *)(c->aqIn + oSt); qa.factorPerRead = (const double *)(c->aqIn + oFa);
+    if (views) { qa.views = views; qa.viewOf = (const int *)(c->aqIn + oVw); }
+    const int threads = 256;
+    const int grid0 = smallFirst ? (n < c->cus * TIER_BLOCKS_PER_CU[0] ? n : c->cus * TIER_BLOCKS_PER_CU[0]) : n;
+    if ((r = ensureScratch(c, (grid0 > c->cus * 2 ? grid0 : c->cus * 2) * threads))) return r;
+    T4Work wk;
+    memset(&wk, 0, sizeof wk);
+    wk.list = (const int *)(c->aqIn + oLs); wk.nList = n;
+    wk.nextList = (int *)(c->aqOut + pNext); wk.nextCount = (int *)(c->aqOut + pTail);
+    wk.status = (int *)(c->aqOut + pSta); wk.hitCounter = (unsigned long long *)(c->aqOut + pTail + 16);
+    wk.dpRows = c->dpRows; wk.dpDir = c->dpDir;
+    if (smallFirst) launchTier<1024, 128, 256>(grid0, c->stream, base, bv, wk, qa);
+    else launchTier<8192, 512, 256>(grid0, c->stream, base, bv, wk, qa);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->aqOutHost, c->aqOut, outBytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    overflow = *(int *)(c->aqOutHost + pTail + 8);
-    wk.nextList = (int *)(c->aqOut + pNext2);
+    int overflow = *(int *)(c->aqOutHost + pTail);
+    if (overflow > 0 && smallFirst) {   // reads beyond the 1024-hit tier: 8192-hit LDS tier
+      T4Work w1 = wk;
+      w1.list = (const int *)(c->aqOut + pNext); w1.nList = overflow;
+      w1.nextList = (int *)(c->aqOut + pNext2); w1.nextCount = (int *)(c->aqOut + pTail + 8);
+      if ((r = ensureScratch(c, (overflow > c->cus * 2 ? overflow : c->cus * 2) * threads))) return r;
+      w1.dpRows = c->dpRows; w1.dpDir = c->dpDir;
+      launchTier<8192, 512, 256>(overflow, c->stream, base, bv, w1, qa);
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipMemcpyAsync(c->aqOutHost, c->aqOut, outBytes, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      overflow = *(int *)(c->aqOutHost + pTail + 8);
+      wk.nextList = (int *)(c->aqOut + pNext2);
+    }
+    if (overflow > 0) {   // reads beyond the LDS tiers: global-scratch tier
+      if ((r = ensureGlobalTier(c, overflow))) return r;
+      if ((r = ensureScratch(c, (overflow > c->cus * 2 ? overflow : c->cus * 2) * G_THREADS))) return r;
+      T4Work w2 = wk;
+      w2.list = wk.nextList; w2.nList = overflow; w2.nextList = nullptr; w2.nextCount = nullptr;
+      w2.gKeys = c->gKeys; w2.gPairs = c->gPairs; w2.gCand = c->gCand; w2.gOv = c->gOv; w2.gFin = c->gFin; w2.gOrd = c->gOrd;
+      w2.gCap = G_CAP; w2.gMaxOv = G_MAXOV;
+      w2.dpRows = c->dpRows; w2.dpDir = c->dpDir;
+      launchTier<0, 0, G_THREADS>(overflow, c->stream, base, bv, w2, qa);
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipMemcpyAsync(c->aqOutHost, c->aqOut, outBytes, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    const unsigned char *o = c->aqOutHost;
+    const int *status = (const int *)(o + pSta);
+    bool poolFull = false;
+    for (int i = 0; i < n; ++i) {
+      if (status[i] == 3) poolFull = true;
+      else if (status[i]) return fail(c, T4_ERR_UNSUPPORTED, "read %d exceeds the engine limits (status %d: %s)", i, status[i],
+                                      status[i] == 2 ? "more k-mer hits or overlaps than the global tier holds" : "gap DP or contig count beyond scratch");
+    }
+    if (poolFull) {   // more result records than the pool holds: a larger pool, and the whole call again
+      if (attempt >= 8) return fail(c, T4_ERR_UNSUPPORTED, "result pool of %d records overflows", c->aqPoolCap);
+      (void)hipHostFree(c->aqPool);
+      c->aqPool = nullptr; c->aqPoolDev = nullptr; c->aqPoolCap *= 4;
+      continue;
+    }
+    res->counts = (const int32_t *)(o + pCnt); res->base = (const int32_t *)(o + pBase);
+    res->ov = (const t4_overlap *)c->aqPool; res->ext = res->ov + rec; res->ret = (const int32_t *)(res->ext + rec);
+    return T4_OK;
   }
-  if (overflow > 0) {   // reads beyond the LDS tiers: global-scratch tier
-    if ((r = ensureGlobalTier(c, overflow))) return r;
-    T4Work w2 = wk;
-    w2.list = wk.nextList; w2.nList = overflow; w2.nextList = nullptr; w2.nextCount = nullptr;
-    w2.gKeys = c->gKeys; w2.gPairs = c->gPairs; w2.gCand = c->gCand; w2.gOv = c->gOv; w2.gFin = c->gFin; w2.gOrd = c->gOrd;
-    w2.gCap = G_CAP; w2.gMaxOv = G_MAXOV;
-    w2.dpRows = c->dpRows; w2.dpDir = c->dpDir;
-    launchTier<0, 0, 256>(overflow, c->stream, base, bv, w2, qa);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->aqOutHost, c->aqOut, outBytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-  }
-  const unsigned char *o = c->aqOutHost;
-  const int *status = (const int *)(o + pSta);
-  for (int i = 0; i < n; ++i) if (status[i]) return fail(c, T4_ERR_UNSUPPORTED, "read %d exceeds the engine limits (status %d)", i, status[i]);
-  memcpy(counts, o + pCnt, sizeof(int) * (size_t)n);
-  const int *cn = (const int *)(o + pCnt);
-  for (int i = 0; i < n; ++i) {   // only the records that exist
-    const int k2 = cn[i] > 0 ? (cn[i] < max_per_read ? cn[i] : max_per_read) : 0;
+}
+
+// the same with the fixed-stride result layout of t4_add_query / t4_cellstore_query
+int addQueryImpl(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const int32_t *viewOf, bool smallFirst, int n, const char *bases,
+                 const int64_t *offsets, const int32_t *barcodes, const int32_t *strands, int skip_repeats, const double *factors,
+                 int max_per_read, int32_t *counts, t4_overlap *ov, t4_overlap *ext, int32_t *ext_ret) {
+  AqResult res;
+  int r = addQueryPool(c, base, views, viewOf, smallFirst, n, bases, offsets, barcodes, strands, skip_repeats, factors, &res);
+  if (r) return r;
+  for (int i = 0; i < n; ++i) {
+    counts[i] = res.counts[i];
+    if (res.counts[i] > max_per_read) return fail(c, T4_ERR_UNSUPPORTED, "read %d has %d overlaps, the caller made room for %d", i, res.counts[i], max_per_read);
+    const int k2 = res.counts[i] > 0 ? res.counts[i] : 0;
     if (!k2) continue;
     const size_t at = (size_t)i * max_per_read;
-    memcpy(ov + at, o + pOv + sizeof(t4_overlap) * at, sizeof(t4_overlap) * k2);
-    memcpy(ext + at, o + pEx + sizeof(t4_overlap) * at, sizeof(t4_overlap) * k2);
-    memcpy(ext_ret + at, o + pRet + sizeof(int) * at, sizeof(int) * k2);
+    memcpy(ov + at, res.ov + res.base[i], sizeof(t4_overlap) * k2);
+    memcpy(ext + at, res.ext + res.base[i], sizeof(t4_overlap) * k2);
+    memcpy(ext_ret + at, res.ret + res.base[i], sizeof(int) * k2);
   }
   return T4_OK;
 }
@@ -1154,9 +1341,23 @@ int addQueryImpl(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
 
 extern "C" {
 
+int t4_add_query_pool(t4_index *ix, int n, const char *bases, const int64_t *offsets, const int32_t *barcodes, const int32_t *strands,
+                      int skip_repeats, const double *factors, const int32_t **counts, const int32_t **base, const t4_overlap **ov,
+                      const t4_overlap **ext, const int32_t **ext_ret) {
+  if (!ix || n <= 0 || !bases || !offsets || !strands || !factors || !counts || !base || !ov || !ext || !ext_ret) return T4_ERR_ARG;
+  t4_ctx *c = ix->ctx;
+  if (!ix->committed) return fail(c, T4_ERR_STATE, "index not committed");
+  if (ix->view.firstIsRef) return fail(c, T4_ERR_UNSUPPORTED, "t4_add_query needs a contig set");
+  AqResult res;
+  int r = addQueryPool(c, ix->view, nullptr, nullptr, false, n, bases, offsets, barcodes, strands, skip_repeats, factors, &res);
+  if (r) return r;
+  *counts = res.counts; *base = res.base; *ov = res.ov; *ext = res.ext; *ext_ret = res.ret;
+  return T4_OK;
+}
+
 int t4_add_query(t4_index *ix, int n, const char *bases, const int64_t *offsets, const int32_t *barcodes, const int32_t *strands,
                  int skip_repeats, const double *factors, int max_per_read, int32_t *counts, t4_overlap *ov, t4_overlap *ext, int32_t *ext_ret) {
-  if (!ix || n < 0 || max_per_read <= 0 || max_per_read > 128 || (n > 0 && (!bases || !offsets || !strands || !factors || !counts || !ov || !ext || !ext_ret))) return T4_ERR_ARG;
+  if (!ix || n < 0 || max_per_read <= 0 || (n > 0 && (!bases || !offsets || !strands || !factors || !counts || !ov || !ext || !ext_ret))) return T4_ERR_ARG;
   t4_ctx *c = ix->ctx;
   if (!ix->committed) return fail(c, T4_ERR_STATE, "index not committed");
   if (ix->view.firstIsRef) return fail(c, T4_ERR_UNSUPPORTED, "t4_add_query needs a contig set");
@@ -1458,7 +1659,7 @@ int t4_cellstore_patch(t4_cellstore *cs, int slot, int n, const int64_t *byteOff
 int t4_cellstore_query(t4_cellstore *cs, int n, const int32_t *slots, const char *bases, const int64_t *offsets, const int32_t *barcodes,
                        const int32_t *strands, int skip_repeats, const double *factors, int max_per_read, int32_t *counts,
                        t4_overlap *ov, t4_overlap *ext, int32_t *ext_ret) {
-  if (!cs || n < 0 || max_per_read <= 0 || max_per_read > 128 || (n > 0 && (!slots || !bases || !offsets || !strands || !factors || !counts || !ov || !ext || !ext_ret))) return T4_ERR_ARG;
+  if (!cs || n < 0 || max_per_read <= 0 || (n > 0 && (!slots || !bases || !offsets || !strands || !factors || !counts || !ov || !ext || !ext_ret))) return T4_ERR_ARG;
   t4_ctx *c = cs->ctx;
   (void)hipSetDevice(c->device);
   int r;

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <deque>
 #include <thread>
 #include <map>
 #include <memory>
@@ -31,6 +32,11 @@
 
 namespace {
 
+// a posWeight column as the kernels see it (== t4PwByte, t4_device.h): bit x = (sum < 3 * count[x]), bit 4 = (sum == 0)
+inline unsigned char t4PwByte(int a, int c, int g, int t) {
+  const int sum = a + c + g + t;
+  return (unsigned char)((sum == 0 ? 16 : 0) | (sum < 3 * a ? 1 : 0) | (sum < 3 * c ? 2 : 0) | (sum < 3 * g ? 4 : 0) | (sum < 3 * t ? 8 : 0));
+}
 inline int nucNum(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
 const char NUM2NUC[4] = {'A', 'C', 'G', 'T'};
 
@@ -60,31 +66,103 @@ struct KeyHash {
     return (size_t)(z ^ (z >> 31));
   }
 };
+inline uint64_t mix64h(uint64_t z) {   // == t4k::mix64 (t4_kernels.h): slot of a code in the device table of a live set
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
 
-// The mutable KmerIndex: a posting multiset per (code, bucket) with the reference's edit operations.
-struct InsertHook { virtual void onInsert(uint64_t code, int h) = 0; virtual ~InsertHook() {} };
+// The mutable KmerIndex: a posting multiset per (code, bucket) with the reference's edit operations. The order inside a
+// list is not kept (nothing downstream of SortHits observes it, SURVEY 7 hard part 4; Remove and UpdateIndexFromRead only
+// ever pick among EQUAL postings), so a removal fills the hole with the last posting. Lists live in one flat arena whose
+// layout IS the layout of the device image of a live set: `mirror` turns on the bookkeeping of what changed
+// since the last t4_index_apply_delta (table slots and postings by position).
+struct ListRef { uint32_t start = 0, cnt = 0, cap = 0; int64_t slot = -1; bool dirty = false; };
+struct IndexListener {
+  virtual void onInsert(uint64_t code, int h, int idx, int off, uint32_t sizeAfter) = 0;
+  virtual void onRemove(uint64_t code, int h, int idx, int off, uint32_t sizeAfter) = 0;
+  virtual void onMove(uint64_t code, int h, int oldIdx, int oldOff, int idx, int off) = 0;
+  virtual ~IndexListener() {}
+};
 struct HostIndex {
   int k; bool considerBarcode = false;
-  InsertHook *hook = nullptr;
-  std::unordered_map<Key, std::vector<Post>, KeyHash> map;
+  IndexListener *hook = nullptr;
+  typedef std::unordered_map<Key, ListRef, KeyHash> Map;
+  Map map;
+  std::vector<Post> arena;
+  size_t arenaUsed = 0, garbage = 0;
   size_t total = 0;
+  // ---- device mirror bookkeeping (live sets only)
+  bool mirror = false;
+  std::vector<unsigned char> tabOcc;          // occupancy of the device table's slots
+  int64_t tabSlots = 0, tabKeys = 0;
+  bool tabRebuilt = false;                    // every slot goes into the next delta
+  std::vector<Map::value_type *> dirtyKeys;
+  std::vector<uint32_t> dirtyPost;
+  std::vector<unsigned char> dirtyPostFlag;
   explicit HostIndex(int kl) : k(kl) {}
   int bucket(uint64_t code, int barcode) const { return (int)((code + (uint64_t)(int64_t)(considerBarcode ? barcode + 1 : 0)) % 1000003ull); }
+  void markPost(uint32_t at) {
+    if (!mirror) return;
+    if (dirtyPostFlag.size() < arena.size()) dirtyPostFlag.resize(arena.size(), 0);
+    if (!dirtyPostFlag[at]) { dirtyPostFlag[at] = 1; dirtyPost.push_back(at); }
+  }
+  void markKey(Map::value_type *kv) { if (mirror && !kv->second.dirty) { kv->second.dirty = true; dirtyKeys.push_back(kv); } }
+  int64_t probeSlot(uint64_t code) {
+    uint64_t s = mix64h(code) & (uint64_t)(tabSlots - 1);
+    while (tabOcc[s]) s = (s + 1) & (uint64_t)(tabSlots - 1);
+    tabOcc[s] = 1;
+    return (int64_t)s;
+  }
+  void growTable() {   // load <= 1/2; every key gets a new slot
+    tabSlots = tabSlots ? tabSlots * 2 : ((int64_t)1 << 16);
+    while (tabSlots < 2 * (tabKeys + 1)) tabSlots *= 2;
+    tabOcc.assign((size_t)tabSlots, 0);
+    for (auto &kv : map) kv.second.slot = probeSlot(kv.first.code);
+    tabRebuilt = true;
+  }
+  Map::value_type *listOf(const Key &key) {
+    auto ins = map.emplace(key, ListRef());
+    Map::value_type *kv = &*ins.first;
+    if (ins.second && mirror) {
+      ++tabKeys;
+      if (2 * tabKeys > tabSlots) growTable(); else kv->second.slot = probeSlot(key.code);
+    }
+    return kv;
+  }
   void insert(const KCode &kc, int idx, int off, int barcode) {
     if (!kc.valid()) return;
     const int h = bucket(kc.code, barcode);
-    map[Key{kc.code, h}].push_back(Post{idx, off});
-    ++total;
-    if (hook) hook->onInsert(kc.code, h);
+    Map::value_type *kv = listOf(Key{kc.code, h});
+    ListRef &l = kv->second;
+    if (l.cnt == l.cap) {   // move the list to the end of the arena with twice the room
+      const uint32_t ncap = l.cap ? l.cap * 2 : 2;
+      if (arenaUsed + ncap > arena.size()) arena.resize((arenaUsed + ncap) * 2 > 1024 ? (arenaUsed + ncap) * 2 : 1024);
+      for (uint32_t i = 0; i < l.cnt; ++i) { arena[arenaUsed + i] = arena[l.start + i]; markPost((uint32_t)arenaUsed + i); }
+      garbage += l.cap;
+      l.start = (uint32_t)arenaUsed; l.cap = ncap; arenaUsed += ncap;
+    }
+    arena[l.start + l.cnt] = Post{idx, off};
+    markPost(l.start + l.cnt);
+    ++l.cnt; ++total;
+    markKey(kv);
+    if (hook) hook->onInsert(kc.code, h, idx, off, l.cnt);
   }
-  void remove(const KCode &kc, int idx, int off, int barcode) {  // first posting equal to (idx, off)
+  void remove(const KCode &kc, int idx, int off, int barcode) {  // one posting equal to (idx, off)
     if (!kc.valid()) return;
-    auto it = map.find(Key{kc.code, bucket(kc.code, barcode)});
+    const int h = bucket(kc.code, barcode);
+    auto it = map.find(Key{kc.code, h});
     if (it == map.end()) return;
-    auto &l = it->second;
-    for (size_t i = 0; i < l.size(); ++i)
-      if (l[i].idx == idx && l[i].offset == off) { l.erase(l.begin() + i); --total; break; }
-    if (l.empty()) map.erase(it);
+    ListRef &l = it->second;
+    for (uint32_t i = 0; i < l.cnt; ++i)
+      if (arena[l.start + i].idx == idx && arena[l.start + i].offset == off) {
+        if (i + 1 != l.cnt) { arena[l.start + i] = arena[l.start + l.cnt - 1]; markPost(l.start + i); }
+        --l.cnt; --total;
+        markKey(&*it);
+        if (hook) hook->onRemove(kc.code, h, idx, off, l.cnt);
+        break;
+      }
+    if (l.cnt == 0 && !mirror) { garbage += l.cap; map.erase(it); }   // a live set keeps the key (its table slot) with an empty list
   }
   void build(const char *s, int len, int id, int barcode, int shift = 0) {  // BuildIndexFromRead
     if (len < k) return;
@@ -105,10 +183,18 @@ struct HostIndex {
     for (; i < len; ++i) {
       kc.append(s[i]);
       if (!kc.valid()) continue;
-      auto it = map.find(Key{kc.code, bucket(kc.code, barcode)});
+      const int h = bucket(kc.code, barcode);
+      auto it = map.find(Key{kc.code, h});
       if (it == map.end()) continue;
-      for (auto &p : it->second)
-        if (p.idx == oldId && p.offset == i - k + 1) { p.idx = id; p.offset += shift; break; }
+      ListRef &l = it->second;
+      for (uint32_t t = 0; t < l.cnt; ++t) {
+        Post &p = arena[l.start + t];
+        if (p.idx == oldId && p.offset == i - k + 1) {
+          p.idx = id; p.offset += shift; markPost(l.start + t);
+          if (hook) hook->onMove(kc.code, h, oldId, i - k + 1, id, p.offset);
+          break;
+        }
+      }
     }
   }
   void removeSeq(const char *s, int len, int id, int barcode, int offset) {  // RemoveIndexFromRead
@@ -118,6 +204,7 @@ struct HostIndex {
     for (i = 0; i < k - 1; ++i) kc.append(s[i]);
     for (; i < len; ++i) { kc.append(s[i]); if (kc.valid()) remove(kc, id, i - k + 1 + offset, barcode); }
   }
+  const ListRef *find(uint64_t code, int h) const { auto it = map.find(Key{code, h}); return it == map.end() ? nullptr : &it->second; }
 };
 
 struct PosWeight { int c[4]; };
@@ -127,6 +214,9 @@ struct Seq {
   bool released = false;
   bool frozen = false;   // ReleaseFinishedBarcodeSeq: out of the index, posWeight final (SeqSet.hpp:10847-10935)
   int minLeftExtAnchor = 0, minRightExtAnchor = 0, barcode = -1, numRead = 0;
+  // live set: place in the device arena of consensus chars / predicate bytes, and what of it changed since the last delta
+  int64_t baseOff = -1; int baseCap = 0;
+  bool devDirty = false; int dLo = 0, dHi = 0;
 };
 
 struct Ov {  // struct _overlap fields that the Add path reads or writes
@@ -207,13 +297,54 @@ void reverseComplement(std::string &rc, const std::string &s) {
 
 }  // namespace
 
+// ---- speculation window of a live set -----------------------------------------------------------------
+// What the cached query result of an upcoming read depends on, tracked exactly enough to be safe:
+//   * the posting lists of the read's own k-mers (both strands): every insertion / removal of such a key is examined;
+//   * for a contig the read has three or more hits with on one strand (fewer can never form a candidate run,
+//     SeqSet.hpp:923-925), the posWeight columns and the contig ends within reach of the read (hull of its hits +- read length).
+// Per (strand, contig) the number of hits and the hull of their offsets, from the host replica of the index (a superset
+// of what GetHitsFromRead emits: no repeat skipping, no barcode filter).
+struct Grp { uint32_t key; uint32_t cnt; int32_t lo, hi; };   // key = contig * 2 + (strand == 1); 0xFFFFFFFF = empty
+struct GroupTable {
+  std::vector<Grp> t;
+  uint32_t mask = 0, n = 0;
+  void reset(uint32_t expect) {
+    uint32_t sz = 64;
+    while (sz < 2 * expect + 2) sz <<= 1;
+    if (t.size() != sz) t.resize(sz);
+    for (Grp &g : t) g.key = 0xFFFFFFFFu;
+    mask = sz - 1; n = 0;
+  }
+  static uint32_t hashOf(uint32_t k) { k *= 0x9E3779B1u; return k ^ (k >> 15); }
+  Grp *find(uint32_t key) {
+    if (t.empty()) return nullptr;
+    for (uint32_t s = hashOf(key) & mask;; s = (s + 1) & mask) {
+      if (t[s].key == key) return &t[s];
+      if (t[s].key == 0xFFFFFFFFu) return nullptr;
+    }
+  }
+  Grp &get(uint32_t key) {
+    if (t.empty() || 2 * (n + 1) > t.size()) grow();
+    for (uint32_t s = hashOf(key) & mask;; s = (s + 1) & mask) {
+      if (t[s].key == key) return t[s];
+      if (t[s].key == 0xFFFFFFFFu) { t[s].key = key; t[s].cnt = 0; t[s].lo = 0x7FFFFFFF; t[s].hi = -0x7FFFFFFF; ++n; return t[s]; }
+    }
+  }
+  void grow() {
+    std::vector<Grp> old; old.swap(t);
+    uint32_t sz = old.empty() ? 64 : (uint32_t)old.size() * 2;
+    t.resize(sz);
+    for (Grp &g : t) g.key = 0xFFFFFFFFu;
+    mask = sz - 1; n = 0;
+    for (const Grp &g : old) if (g.key != 0xFFFFFFFFu) { Grp &d = get(g.key); d.cnt = g.cnt; d.lo = g.lo; d.hi = g.hi; }
+  }
+};
+
 struct t4_cellset;
-struct t4_assembler : InsertHook {
+struct t4_assembler : IndexListener {
   t4_ctx *ctx;
   t4_index *dev = nullptr;   // device image of the current set
   t4_cellset *owner = nullptr;   // cell of a per-barcode set: the image lives in the owner's arena slot
-  t4_cellstore *priv = nullptr;  // stand-alone set whose index is not keyed by barcode: a private one-slot arena (the same
-                                 // staged images, predicate bytes and byte patches as the cells)
   int slot = -1, cellBarcode = -1;
   // cell mode: IsBaseEqual flips since the image was staged (most changes between two queries of a cell are single columns)
   struct PwPatch { int seq, pos; unsigned char val; };
@@ -229,37 +360,84 @@ struct t4_assembler : InsertHook {
   std::string err;
   int64_t queries = 0, refreshes = 0, cacheHits = 0;
   double secRefresh = 0, secQuery = 0;
-  // speculation window: query results of upcoming reads, valid while `epoch` (bumped by every change a query can
-  // observe: index, consensus, contig creation/release, a flip of a posWeight column's IsBaseEqual state) stands
-  struct Cached { std::string read; int strand, barcode, skip; int32_t cnt; bool valid; std::vector<t4_overlap> ov, ext; std::vector<int32_t> extRet; };
+  // speculation window: query results of upcoming reads. Cells: valid until any change a query of the cell can observe.
+  struct Cached {
+    std::string read; int strand, barcode, skip; int32_t cnt; bool valid; std::vector<t4_overlap> ov, ext; std::vector<int32_t> extRet;
+    // live sets
+    int64_t uid = 0;
+    bool fragile = false;        // any change of one of its keys' lists invalidates it
+    int slack = 0;               // tolerated hit-set changes left before possibleOverlapCnt could pass 100 (SeqSet.hpp:813-823)
+    GroupTable groups;
+  };
   std::vector<Cached> cache;
   size_t cacheHead = 0;
-  // What a cached query result depends on ("speculation window"): the contigs the read has any k-mer hit with,
-  // and the absence of its k-mers among the postings inserted since the snapshot. Both are tracked exactly:
-  std::unordered_map<Key, std::vector<int>, KeyHash> winKmers;   // (code, bucket) of every window read k-mer -> window slots
-  std::unordered_map<int, std::vector<int>> winContigs;          // contig id -> window slots whose hit set contains it
   int64_t invalidations = 0;
+  // ---- live set (index not keyed by barcode): the device image is patched (t4_index_apply_delta), never rebuilt, and the
+  // window slides: entries stay valid across commits that cannot change their query (rules above)
+  bool live() const { return !owner && !index.considerBarcode; }
+  int threads = 1;
+  int64_t nextUid = 1;
+  struct KOcc { int64_t uid; int slot; unsigned char f, r; };   // occurrences of a key in a window read, forward / reverse-complement
+  std::unordered_map<Key, std::vector<KOcc>, KeyHash> winKmers;
+  size_t winKmerRefs = 0, winKmerLive = 0;
+  std::vector<Cached *> pool;      // window entries by slot (stable while the entry lives)
+  std::vector<int> freeSlots;
+  std::deque<int> order;           // slots of the upcoming reads, head first
+  struct IdxEv { uint64_t code; int h, idx, off, delta; uint32_t sizeAfter; };
+  std::vector<IdxEv> idxEvents;
+  struct StructEv { int kind /* 0 region, 1 shift, 2 whole contig */, c, a, b; };
+  std::vector<StructEv> structEvents;
+  double runEma = 8; int64_t hitsAtLastRound = 0;   // reads served per round, recently
+  int64_t baseUsed = 0;            // device arena of consensus chars / posWeight predicate bytes (one offset space)
+  std::vector<int> dirtySeqs;
+  bool liveReset = true;           // the next delta describes the whole image (first upload, k change)
+  int64_t deltas = 0, deltaBytes = 0, rounds = 0, readsQueried = 0, invKey = 0, invCross = 0, invRegion = 0, invShift = 0, invContig = 0, invFragile = 0, tolerated = 0;
+  double secDelta = 0, secGroups = 0, secEvents = 0;
+
   t4_assembler(t4_ctx *c, int kl) : ctx(c), k(kl), index(kl) { prevAdd.readStart = -1; index.hook = this; }
-  void dropWindow() { cache.clear(); cacheHead = 0; winKmers.clear(); winContigs.clear(); }
+  ~t4_assembler() { for (Cached *c : pool) delete c; }
+  void dropWindow() {
+    cache.clear(); cacheHead = 0;
+    for (int s : order) { pool[s]->valid = false; pool[s]->uid = 0; freeSlots.push_back(s); }
+    order.clear(); winKmers.clear(); winKmerRefs = winKmerLive = 0;
+    idxEvents.clear(); structEvents.clear();
+  }
   void invalidateSlot(int slot) { if (slot >= (int)cacheHead && slot < (int)cache.size() && cache[slot].valid) { cache[slot].valid = false; ++invalidations; } }
-  void onInsert(uint64_t code, int h) override {
-    if (owner) { for (size_t q = cacheHead; q < cache.size(); ++q) invalidateSlot((int)q); return; }
-    if (winKmers.empty()) return;
-    auto it = winKmers.find(Key{code, h});
-    if (it != winKmers.end()) for (int slot : it->second) invalidateSlot(slot);
+  void invalidateCell() { for (size_t q = cacheHead; q < cache.size(); ++q) invalidateSlot((int)q); }
+  // IndexListener: cells end their window on any index change; live sets examine the change at the end of the commit
+  void onInsert(uint64_t code, int h, int idx, int off, uint32_t sizeAfter) override {
+    if (!live()) { invalidateCell(); return; }
+    if (!order.empty()) idxEvents.push_back(IdxEv{code, h, idx, off, +1, sizeAfter});
   }
-  // window entries whose query can observe a change of contig c
-  void invalidateFor(int c) {
-    // a cell holds a handful of contigs which almost every read of the cell hits: any observable change ends its window
-    if (owner) { for (size_t q = cacheHead; q < cache.size(); ++q) invalidateSlot((int)q); return; }
-    if (winContigs.empty()) return;
-    auto it = winContigs.find(c);
-    if (it != winContigs.end()) for (int slot : it->second) invalidateSlot(slot);
+  void onRemove(uint64_t code, int h, int idx, int off, uint32_t sizeAfter) override {
+    if (!live()) { invalidateCell(); return; }
+    if (!order.empty()) idxEvents.push_back(IdxEv{code, h, idx, off, -1, sizeAfter});
   }
-  // contig c changed in a way a query can observe (consensus, length, postings, an IsBaseEqual state of a column)
-  void structuralChange(int c) {
+  void onMove(uint64_t code, int h, int oldIdx, int oldOff, int idx, int off) override {
+    if (!live()) { invalidateCell(); return; }
+    if (order.empty() || oldIdx == idx) return;   // a shift of one contig's postings is one structural event (evShift)
+    idxEvents.push_back(IdxEv{code, h, oldIdx, oldOff, -1, 0xFFFFFFFFu});   // sizes unchanged
+    idxEvents.push_back(IdxEv{code, h, idx, off, +1, 0xFFFFFFFFu});
+  }
+  // ---- what a commit changed, for the window of a live set
+  void evRegion(int c, int lo, int hi) { if (live() && !order.empty()) structEvents.push_back(StructEv{0, c, lo, hi}); }   // columns [lo, hi) of contig c (current coordinates)
+  void evShift(int c, int shift) { if (live() && !order.empty()) structEvents.push_back(StructEv{1, c, shift, 0}); }       // bases prepended: every offset of c moves
+  void evContig(int c) { if (live() && !order.empty()) structEvents.push_back(StructEv{2, c, 0, 0}); }                       // anything about c
+  void processEvents();
+  void markSeqDirty(int c) { if (live() && !seqs[c].devDirty) { seqs[c].devDirty = true; dirtySeqs.push_back(c); } seqs[c].dLo = 0; seqs[c].dHi = 0x7FFFFFFF; }
+  void markBaseDirty(int c, int pos) {
+    if (!live()) return;
+    Seq &q = seqs[c];
+    if (!q.devDirty) { q.devDirty = true; dirtySeqs.push_back(c); q.dLo = pos; q.dHi = pos + 1; return; }
+    if (pos < q.dLo) q.dLo = pos;
+    if (pos + 1 > q.dHi) q.dHi = pos + 1;
+  }
+  // contig c changed in a way a query can observe (consensus, length, postings, an IsBaseEqual state of a column).
+  // fine == true: the caller described the change to the window itself (evRegion / evShift)
+  void structuralChange(int c, bool fine = false) {
     dirty = true; patches.clear();
-    invalidateFor(c);
+    if (live()) { markSeqDirty(c); if (!fine) evContig(c); }
+    else invalidateCell();
   }
   // ++count[base] of one posWeight column; reports whether AlignAlgo::IsBaseEqual (AlignAlgo.hpp:49-55) can now answer differently
   void bumpWeight(int seqIdx, PosWeight &w, int base) {
@@ -269,19 +447,24 @@ struct t4_assembler : InsertHook {
     ++w.c[base]; ++sum;
     for (int x = 0; x < 4; ++x) after |= (sum < 3 * w.c[x]) ? (1u << x) : 0u;
     if (before == after) return;   // cannot be observed by a query: the image stays as it is
+    const int pos = (int)(&w - seqs[seqIdx].pw.data());
+    if (live()) { markBaseDirty(seqIdx, pos); evRegion(seqIdx, pos, pos + 1); return; }
     static const bool noPatch = getenv("T4_NO_PATCH") != nullptr;   // debugging aid
-    if (!noPatch && (owner || priv) && !dirty && slot >= 0) {   // the resident image only needs this byte
-      invalidateFor(seqIdx);
-      patches.push_back(PwPatch{seqIdx, (int)(&w - seqs[seqIdx].pw.data()), (unsigned char)after});
+    if (!noPatch && owner && !dirty && slot >= 0) {   // the resident image only needs this byte
+      invalidateCell();
+      patches.push_back(PwPatch{seqIdx, pos, (unsigned char)after});
       return;
     }
     structuralChange(seqIdx);
   }
   int prefetch(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive);
+  int prefetchLive(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive);
+  void buildGroups(Cached &e);
+  void registerKmers(Cached &e, int slot);
+  int flushLive();
   void beginWindow(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive);
   void endWindow(const int32_t *cnts, const t4_overlap *ov, const t4_overlap *ex, const int32_t *rets, int stride);
   int stageImage();   // cell mode: queue this cell's image in the owner's arena
-  int refreshPrivate();
   int releaseFinishedBarcode(int barcode, int contigMinCov);
   bool isContigShallow(int i, int minCov) const;
   void releaseShallowContigs(int minCov);
@@ -290,9 +473,8 @@ struct t4_assembler : InsertHook {
     prevAdd.seqIdx = seqIdx; prevAdd.readStart = rs; prevAdd.readEnd = re; prevAdd.seqStart = ss; prevAdd.seqEnd = se; prevAdd.strand = strand;
   }
 
-  t4_cellstore *storeOf();
+  // stand-alone set whose index IS keyed by barcode (not what trust4-hip builds; kept for the C ABI): whole image per change
   int refreshDevice() {
-    if (!index.considerBarcode) return refreshPrivate();
     if (!dirty) return T4_OK;
     auto t0_ = std::chrono::steady_clock::now();
     struct Tm { double &acc; std::chrono::steady_clock::time_point t0; ~Tm() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tm_{secRefresh, t0_};
@@ -309,7 +491,10 @@ struct t4_assembler : InsertHook {
     std::vector<uint64_t> code; std::vector<int32_t> bucket, idx, off;
     code.reserve(index.total); bucket.reserve(index.total); idx.reserve(index.total); off.reserve(index.total);
     for (const auto &kv : index.map)
-      for (const Post &p : kv.second) { code.push_back(kv.first.code); bucket.push_back(kv.first.h); idx.push_back(p.idx); off.push_back(p.offset); }
+      for (uint32_t t = 0; t < kv.second.cnt; ++t) {
+        const Post &p = index.arena[kv.second.start + t];
+        code.push_back(kv.first.code); bucket.push_back(kv.first.h); idx.push_back(p.idx); off.push_back(p.offset);
+      }
     if ((r = t4_index_commit_postings(dev, (int64_t)code.size(), code.data(), bucket.data(), idx.data(), off.data()))) return r;
     dirty = false; ++refreshes;
     return T4_OK;
@@ -328,7 +513,7 @@ struct t4_assembler : InsertHook {
     seqs.push_back(ns);
     index.build(seqs[seqIdx].cons.c_str(), len, seqIdx, barcode);
     setPrev(seqIdx, 0, len - 1, 0, len - 1, strand);
-    structuralChange(seqIdx);
+    structuralChange(seqIdx, true);   // a new contig reaches the window through its index insertions only
     return seqIdx;
   }
 
@@ -346,9 +531,9 @@ struct t4_assembler : InsertHook {
     }
     if (changes.empty()) return;
     if (updateIndex) index.removeSeq(s.cons.c_str(), (int)s.cons.size(), seqIdx, s.barcode, 0);
-    for (auto &c : changes) s.cons[c.first] = NUM2NUC[c.second];
+    for (auto &c : changes) { s.cons[c.first] = NUM2NUC[c.second]; evRegion(seqIdx, c.first, c.first + 1); }
     if (updateIndex) index.build(s.cons.c_str(), (int)s.cons.size(), seqIdx, s.barcode, 0);
-    structuralChange(seqIdx);
+    structuralChange(seqIdx, true);
   }
   void updateAllConsensus() { for (int i = 0; i < (int)seqs.size(); ++i) if (!seqs[i].released) updateConsensus(i, true); }
 
@@ -363,7 +548,8 @@ struct t4_assembler : InsertHook {
     index.removeSeq(s.cons.c_str() + start, end - start + 1, seqIdx, s.barcode, start);
     s.cons[pos] = c;
     index.build(s.cons.c_str() + start, end - start + 1, seqIdx, s.barcode, start);
-    structuralChange(seqIdx);
+    evRegion(seqIdx, pos, pos + 1);
+    structuralChange(seqIdx, true);
   }
 
   // RepeatAddRead (SeqSet.hpp:4477-4507)
@@ -385,16 +571,21 @@ struct t4_assembler : InsertHook {
   int changeKmerLength(int kl) {
     k = kl;
     bool cb = index.considerBarcode;
+    dropWindow();
     index = HostIndex(kl);
     index.considerBarcode = cb;
+    index.hook = this;
+    index.mirror = live();
     std::vector<Seq> kept;
     for (Seq &s : seqs) if (!s.released) kept.push_back(std::move(s));
     seqs.swap(kept);
     for (int i = 0; i < (int)seqs.size(); ++i) index.build(seqs[i].cons.c_str(), (int)seqs[i].cons.size(), i, seqs[i].barcode, 0);
     setPrev(-1, -1, -1, -1, -1, 0);
     if (dev) { t4_index_destroy(dev); dev = nullptr; }   // nomatchGapLimit and the lookup layout depend on k
-    if (priv) { t4_cellstore_destroy(priv); priv = nullptr; slot = -1; patches.clear(); }
-    dropWindow();
+    if (live()) {   // a fresh image: every contig gets a new place in the arena
+      liveReset = true; baseUsed = 0; dirtySeqs.clear();
+      for (int i = 0; i < (int)seqs.size(); ++i) { seqs[i].baseOff = -1; seqs[i].baseCap = 0; seqs[i].devDirty = false; markSeqDirty(i); }
+    }
     dirty = true;
     return T4_OK;
   }
@@ -412,27 +603,42 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
   setPrev(-1, -1, -1, -1, -1, 0);
   // GetOverlapsFromRead + the ExtendOverlap of every overlap: from the speculation window when it is still valid,
   // else from a fresh GPU query of this read
-  const int MAXOV = 128;
   std::vector<t4_overlap> ovBuf, extBuf;
   std::vector<int32_t> extRet;
   int32_t cnt = 0;
-  bool served = false;
-  if (cacheHead < cache.size()) {
-    Cached &c = cache[cacheHead];
-    if (c.valid && c.read == read && c.strand == *strandIO && c.barcode == barcode && c.skip == (repetitiveData ? 1 : 0)) {
-      cnt = c.cnt; ovBuf.swap(c.ov); extBuf.swap(c.ext); extRet.swap(c.extRet);
-      ++cacheHead; ++cacheHits; served = true;
+  if (live()) {
+    auto matches = [&](const Cached &c) { return c.valid && c.read == read && c.strand == *strandIO && c.barcode == barcode && c.skip == (repetitiveData ? 1 : 0); };
+    if (!order.empty() && matches(*pool[order.front()])) ++cacheHits;
+    else {
+      const char *one = read.c_str();
+      int st = *strandIO, bcOne = barcode;
+      int rc = prefetchLive(1, &one, &st, &bcOne, repetitiveData ? 1 : 0);
+      if (rc) return -100 + rc;
     }
-  }
-  if (!served) {
-    dropWindow();
-    const char *one = read.c_str();
-    int st = *strandIO, bcOne = barcode;
-    int rc = prefetch(1, &one, &st, &bcOne, repetitiveData ? 1 : 0);
-    if (rc) return -100 + rc;
-    Cached &c = cache[0];
+    const int sl = order.front();
+    Cached &c = *pool[sl];
     cnt = c.cnt; ovBuf.swap(c.ov); extBuf.swap(c.ext); extRet.swap(c.extRet);
-    cacheHead = 1;
+    order.pop_front();
+    c.valid = false; c.uid = 0; freeSlots.push_back(sl); --winKmerLive;   // its winKmers references are stale from here on
+  } else {
+    bool served = false;
+    if (cacheHead < cache.size()) {
+      Cached &c = cache[cacheHead];
+      if (c.valid && c.read == read && c.strand == *strandIO && c.barcode == barcode && c.skip == (repetitiveData ? 1 : 0)) {
+        cnt = c.cnt; ovBuf.swap(c.ov); extBuf.swap(c.ext); extRet.swap(c.extRet);
+        ++cacheHead; ++cacheHits; served = true;
+      }
+    }
+    if (!served) {
+      dropWindow();
+      const char *one = read.c_str();
+      int st = *strandIO, bcOne = barcode;
+      int rc = prefetch(1, &one, &st, &bcOne, repetitiveData ? 1 : 0);
+      if (rc) return -100 + rc;
+      Cached &c = cache[0];
+      cnt = c.cnt; ovBuf.swap(c.ov); extBuf.swap(c.ext); extRet.swap(c.extRet);
+      cacheHead = 1;
+    }
   }
   int overlapCnt = cnt;
   if (overlapCnt <= 0) return -1;
@@ -684,7 +890,11 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
       if (ext[0].readEnd < len - 1) seq.minRightExtAnchor = 0;
       readInConsensusOffset = ext[0].seqStart > 0 ? ext[0].seqStart : 0;
       seq.cons = newCons;
-      structuralChange(seqIdx);
+      // what the window sees: bases prepended (every offset moves; the two lowered end columns are inside the new reach of
+      // the left end), bases appended from two columns before the old end
+      if (shift > 0) evShift(seqIdx, shift);
+      if (ext[0].readEnd < len - 1) evRegion(seqIdx, shift + oldLen - 2, 0x7FFFFFFF);
+      structuralChange(seqIdx, true);
       for (auto &p : replacement) substituteConsensusPos(seqIdx, p.first, (char)p.second);
     } else readInConsensusOffset = ext[0].seqStart;
   }
@@ -707,7 +917,8 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
       int end = nPos[j - 1] + K - 1 + readInConsensusOffset;
       if (end >= (int)seq.cons.size()) end = (int)seq.cons.size() - 1;
       index.build(seq.cons.c_str() + start, end - start + 1, seqIdx, barcode, start);
-      structuralChange(seqIdx);
+      evRegion(seqIdx, start, end + 1);
+      structuralChange(seqIdx, true);
       i = j;
     }
     ret = seqIdx;
@@ -741,7 +952,7 @@ struct t4_cellset {
 int t4_assembler::stageImage() {   // thread-safe across cells once the owner has run t4_cellstore_prepare
   if (!dirty) return T4_OK;
   int r;
-  if (slot < 0) return T4_ERR_STATE;
+  if (slot < 0 || !owner) return T4_ERR_STATE;
   const int n = (int)seqs.size();
   std::vector<const char *> names(n), cons(n);
   std::vector<const int32_t *> pw(n);
@@ -756,51 +967,362 @@ int t4_assembler::stageImage() {   // thread-safe across cells once the owner ha
   static thread_local std::vector<uint64_t> keyCode; static thread_local std::vector<int32_t> keyBucket, keyCnt, post;
   keyCode.clear(); keyBucket.clear(); keyCnt.clear(); post.clear();
   for (const auto &kv : index.map) {
-    keyCode.push_back(kv.first.code); keyBucket.push_back(kv.first.h); keyCnt.push_back((int32_t)kv.second.size());
-    for (const Post &p : kv.second) { post.push_back(p.idx); post.push_back(p.offset); }
+    keyCode.push_back(kv.first.code); keyBucket.push_back(kv.first.h); keyCnt.push_back((int32_t)kv.second.cnt);
+    for (uint32_t t = 0; t < kv.second.cnt; ++t) { const Post &p = index.arena[kv.second.start + t]; post.push_back(p.idx); post.push_back(p.offset); }
   }
   int64_t oPw = 0;
-  std::vector<int32_t> seqBc;
-  if (!owner) { seqBc.resize(n); for (int i = 0; i < n; ++i) seqBc[i] = seqs[i].barcode; }
-  r = t4_cellstore_stage(storeOf(), slot, owner ? cellBarcode : -1, n, names.data(), cons.data(), pw.data(), (int64_t)keyCode.size(), keyCode.data(),
-                         keyBucket.data(), keyCnt.data(), post.data(), &oPw, owner ? nullptr : seqBc.data());
+  r = t4_cellstore_stage(owner->store, slot, cellBarcode, n, names.data(), cons.data(), pw.data(), (int64_t)keyCode.size(), keyCode.data(),
+                         keyBucket.data(), keyCnt.data(), post.data(), &oPw, nullptr);
   if (r) return r;
   imgPwOff.resize(n);
   for (int i = 0; i < n; ++i) { imgPwOff[i] = oPw; oPw += (int64_t)strlen(cons[i]) + 1; }
   patches.clear();
   dirty = false; ++refreshes;
-  if (owner) ++owner->stagedImages;
+  ++owner->stagedImages;
   return T4_OK;
 }
 
-t4_cellstore *t4_assembler::storeOf() { return owner ? owner->store : priv; }
+// ---- live set: device image by deltas, sliding speculation window ---------------------------------------------------
 
-// stand-alone set: bring the private image up to date (full image after a structural change, byte patches after flips)
-int t4_assembler::refreshPrivate() {
-  if (!dirty && patches.empty()) return T4_OK;
-  if (index.total == 0) return T4_OK;   // nothing will be launched against an empty set (prefetch): stay dirty, stage later --
-                                        // an image staged now would still be pending when the next one is staged for the same slot
+// Bring the device image up to date: everything that changed since the last call, each destination once with its final value.
+int t4_assembler::flushLive() {
   auto t0_ = std::chrono::steady_clock::now();
-  struct Tm { double &acc; std::chrono::steady_clock::time_point t0; ~Tm() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tm_{secRefresh, t0_};
+  struct Tm { double &acc; std::chrono::steady_clock::time_point t0; ~Tm() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tm_{secDelta, t0_};
   int r;
-  if (!priv) {
-    if ((r = t4_cellstore_create(ctx, k, &priv))) return r;
-    t4_cellstore_set_big_first(priv, getenv("T4_SMALL_FIRST") ? 0 : 1);
-    dirty = true;
+  if (!dev) {
+    if ((r = t4_index_create(ctx, k, 0, &dev))) return r;
+    liveReset = true;
   }
-  if ((r = t4_cellstore_set_params(priv, hitLenRequired, radius, novelSim))) return r;
-  if (slot < 0 && (r = t4_cellstore_open(priv, &slot))) return r;
-  if (dirty) {
-    int64_t consBytes = 0;
-    for (const Seq &q : seqs) consBytes += (q.released ? 0 : (int64_t)q.cons.size()) + 1;
-    const size_t bytes = t4_cellstore_image_bytes((int)seqs.size(), (int64_t)index.map.size(), (int64_t)index.total, consBytes);
-    if ((r = t4_cellstore_prepare(priv, slot, bytes))) return r;
-    return stageImage();
+  if ((r = t4_index_set_params(dev, hitLenRequired, radius, novelSim))) return r;
+  if (liveReset) {   // everything is new to the device
+    index.tabRebuilt = true;
+    index.dirtyPost.clear();
+    for (uint32_t at = 0; at < (uint32_t)index.arenaUsed; ++at) index.dirtyPost.push_back(at);
+    for (int i = 0; i < (int)seqs.size(); ++i) markSeqDirty(i);
   }
-  std::vector<int64_t> offs; std::vector<unsigned char> vals;
-  for (const PwPatch &pp : patches) { offs.push_back(imgPwOff[pp.seq] + pp.pos); vals.push_back(pp.val); }
-  patches.clear();
-  return t4_cellstore_patch(priv, slot, (int)offs.size(), offs.data(), vals.data());
+  t4_index_delta d;
+  memset(&d, 0, sizeof d);
+  // table slots
+  std::vector<int64_t> slot; std::vector<uint64_t> slotCode; std::vector<uint32_t> slotStart, slotCnt;
+  auto putKey = [&](const HostIndex::Map::value_type &kv) {
+    slot.push_back(kv.second.slot); slotCode.push_back(kv.first.code); slotStart.push_back(kv.second.start); slotCnt.push_back(kv.second.cnt);
+  };
+  if (index.tabRebuilt) { for (auto &kv : index.map) { putKey(kv); kv.second.dirty = false; } }
+  else for (auto *kv : index.dirtyKeys) { putKey(*kv); kv->second.dirty = false; }
+  index.dirtyKeys.clear();
+  // postings: runs of consecutive dirty positions
+  std::vector<int64_t> postAt; std::vector<int32_t> postLen, postData;
+  std::sort(index.dirtyPost.begin(), index.dirtyPost.end());
+  for (size_t i = 0; i < index.dirtyPost.size();) {
+    size_t j = i + 1;
+    while (j < index.dirtyPost.size() && index.dirtyPost[j] == index.dirtyPost[j - 1] + 1) ++j;
+    postAt.push_back(index.dirtyPost[i]); postLen.push_back((int32_t)(j - i));
+    for (size_t t = i; t < j; ++t) { const Post &p = index.arena[index.dirtyPost[t]]; postData.push_back(p.idx); postData.push_back(p.offset); if (index.dirtyPost[t] < index.dirtyPostFlag.size()) index.dirtyPostFlag[index.dirtyPost[t]] = 0; }
+    i = j;
+  }
+  index.dirtyPost.clear();
+  // sequences: record + the changed stretch of consensus chars / predicate bytes (one terminator column past the end)
+  std::vector<int32_t> seqId; std::vector<t4_seq_record> seqRec;
+  std::vector<int64_t> baseAt; std::vector<int32_t> baseLen; std::string baseCons; std::vector<uint8_t> basePw;
+  int maxLen = 0;
+  for (int c : dirtySeqs) {
+    Seq &q = seqs[c];
+    q.devDirty = false;
+    const int len = q.released ? 0 : (int)q.cons.size();
+    int lo = q.dLo, hi = q.dHi;
+    if (len + 1 > q.baseCap) {   // a new place with room to grow
+      q.baseCap = len + 1 + (len < 512 ? 256 : len / 2);
+      q.baseOff = baseUsed; baseUsed += q.baseCap;
+      lo = 0; hi = len + 1;
+    }
+    if (hi > len + 1) hi = len + 1;
+    if (lo < 0) lo = 0;
+    t4_seq_record rec;
+    memset(&rec, 0, sizeof rec);
+    rec.base_off = q.baseOff; rec.len = len; rec.barcode = q.barcode;
+    for (int t = 0; t < 8 && t < (int)q.name.size() && !q.released; ++t) rec.name[t] = q.name[t];
+    seqId.push_back(c); seqRec.push_back(rec);
+    if (hi > lo) {
+      baseAt.push_back(q.baseOff + lo); baseLen.push_back(hi - lo);
+      for (int t = lo; t < hi; ++t) {
+        if (t < len) { baseCons.push_back(q.cons[t]); basePw.push_back(t4PwByte(q.pw[t].c[0], q.pw[t].c[1], q.pw[t].c[2], q.pw[t].c[3])); }
+        else { baseCons.push_back('\0'); basePw.push_back(t4PwByte(0, 0, 0, 0)); }
+      }
+    }
+  }
+  dirtySeqs.clear();
+  for (const Seq &q : seqs) if (!q.released && (int)q.cons.size() > maxLen) maxLen = (int)q.cons.size();
+  d.table_slots = index.tabSlots; d.table_rebuilt = index.tabRebuilt ? 1 : 0;
+  d.post_cap = (int64_t)index.arena.size(); d.base_cap = baseUsed + 1024; d.seq_cap = (int32_t)seqs.size() + 64;
+  d.nseq = (int32_t)seqs.size(); d.max_seq_len = maxLen;
+  d.n_slots = (int64_t)slot.size(); d.slot = slot.data(); d.slot_code = slotCode.data(); d.slot_start = slotStart.data(); d.slot_cnt = slotCnt.data();
+  d.n_post_runs = (int64_t)postAt.size(); d.post_at = postAt.data(); d.post_len = postLen.data(); d.post_data = postData.data();
+  d.n_seqs = (int32_t)seqId.size(); d.seq_id = seqId.data(); d.seq = seqRec.data();
+  d.n_base_runs = (int64_t)baseAt.size(); d.base_at = baseAt.data(); d.base_len = baseLen.data(); d.base_cons = baseCons.data(); d.base_pw = basePw.data();
+  if ((r = t4_index_apply_delta(dev, &d))) return r;
+  index.tabRebuilt = false; liveReset = false;
+  ++deltas; deltaBytes += (int64_t)(slot.size() * 16 + postData.size() * 4 + seqRec.size() * sizeof(t4_seq_record) + baseCons.size() * 2);
+  return T4_OK;
+}
+
+// the read's keys (every valid k-mer of both strands) join the window's inverted map
+void t4_assembler::registerKmers(Cached &e, int slotId) {
+  std::string rcs;
+  reverseComplement(rcs, e.read);
+  std::unordered_map<Key, std::pair<int, int>, KeyHash> occ;
+  for (int st = 0; st < 2; ++st) {
+    const std::string &r = st ? rcs : e.read;
+    if ((int)r.size() < k) continue;
+    KCode kc(k);
+    for (int i = 0; i < (int)r.size(); ++i) {
+      kc.append(r[i]);
+      if (i < k - 1 || !kc.valid()) continue;
+      auto &o = occ[Key{kc.code, index.bucket(kc.code, e.barcode)}];
+      if (st) ++o.second; else ++o.first;
+    }
+  }
+  for (auto &kv : occ) {
+    winKmers[kv.first].push_back(KOcc{e.uid, slotId, (unsigned char)(kv.second.first > 255 ? 255 : kv.second.first), (unsigned char)(kv.second.second > 255 ? 255 : kv.second.second)});
+    ++winKmerRefs;
+  }
+  ++winKmerLive;
+}
+
+// Hits of the read per (strand, contig) against the current index (host replica; read-only here): the number of hits, and the
+// stretch of the contig the read lies on along every diagonal that holds three or more hits -- a candidate run of a novel
+// contig is a run of hits on ONE diagonal (adjustRadius 0, SeqSet.hpp:906-919) of at least minHitRequired >= 3 hits, and
+// everything the query then reads of the contig (gap DPs, ExtendOverlap, the distance tests to the contig ends) lies within
+// the read's projection along that diagonal +- radius.
+void t4_assembler::buildGroups(Cached &e) {
+  std::string rcs;
+  reverseComplement(rcs, e.read);
+  const int len = (int)e.read.size();
+  static thread_local std::vector<uint64_t> hits;
+  hits.clear();
+  uint32_t maxList = 0;
+  for (int st = 0; st < 2; ++st) {
+    const std::string &r = st ? rcs : e.read;
+    if ((int)r.size() < k) continue;
+    const uint64_t plus = st ? 0u : 1u;
+    KCode kc(k);
+    for (int i = 0; i < (int)r.size(); ++i) {
+      kc.append(r[i]);
+      if (i < k - 1 || !kc.valid()) continue;
+      const ListRef *l = index.find(kc.code, index.bucket(kc.code, e.barcode));
+      if (!l) continue;
+      if (l->cnt > maxList) maxList = l->cnt;
+      const int a = i - k + 1;
+      for (uint32_t t = 0; t < l->cnt; ++t) {
+        const Post &p = index.arena[l->start + t];
+        hits.push_back((((uint64_t)(uint32_t)p.idx * 2u + plus) << 32) | (uint32_t)(p.offset - a + (1 << 30)));   // contig, strand, start of the read on the contig
+      }
+    }
+  }
+  std::sort(hits.begin(), hits.end());
+  uint32_t nGroups = 0;
+  for (size_t i = 0; i < hits.size(); ++i) if (i == 0 || (hits[i] >> 32) != (hits[i - 1] >> 32)) ++nGroups;
+  e.groups.reset(nGroups);
+  int u4 = 0;
+  for (size_t i = 0; i < hits.size();) {
+    size_t j = i;
+    Grp &g = e.groups.get((uint32_t)(hits[i] >> 32));
+    while (j < hits.size() && (hits[j] >> 32) == (hits[i] >> 32)) {
+      size_t d = j;
+      while (d < hits.size() && hits[d] == hits[j]) ++d;
+      if (d - j >= 3) {
+        const int at = (int)(uint32_t)hits[j] - (1 << 30);
+        if (at < g.lo) g.lo = at;
+        if (at + len - 1 > g.hi) g.hi = at + len - 1;
+      }
+      j = d;
+    }
+    g.cnt = (uint32_t)(j - i);
+    if (g.cnt >= 4) ++u4;
+    i = j;
+  }
+  // possibleOverlapCnt counts groups measured at more than 3 hits (SeqSet.hpp:784-810); while it cannot pass 100 the
+  // group statistics of GetOverlapsFromHits leave novelMinHitRequired at 3 whatever small groups come and go
+  e.slack = 99 - u4;
+  e.fragile = e.slack < 0 || maxList > 10000;   // lists beyond 10000 postings drive removeOnlyRepeats (SeqSet.hpp:802)
+}
+
+// Examine what the commit(s) since the last call changed for every window entry that is still valid.
+void t4_assembler::processEvents() {
+  if (!live()) return;
+  if (order.empty() || (idxEvents.empty() && structEvents.empty())) { idxEvents.clear(); structEvents.clear(); return; }
+  auto t0_ = std::chrono::steady_clock::now();
+  struct Tm { double &acc; std::chrono::steady_clock::time_point t0; ~Tm() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tm_{secEvents, t0_};
+  auto kill = [&](Cached &e, int64_t &why) { if (e.valid) { e.valid = false; ++invalidations; ++why; } };
+  // structural events, in the order they happened
+  for (const StructEv &ev : structEvents) {
+    for (int sl : order) {
+      Cached &e = *pool[sl];
+      if (!e.valid) continue;
+      const int margin = radius + 2;
+      for (uint32_t plus = 0; plus < 2; ++plus) {
+        Grp *g = e.groups.find((uint32_t)ev.c * 2u + plus);
+        if (!g || g->cnt == 0) continue;
+        if (ev.kind == 2) { kill(e, invContig); break; }
+        if (g->lo > g->hi) continue;   // no diagonal with three hits: nothing of the contig is read
+        if (ev.kind == 0) {
+          if (ev.a <= g->hi + margin && ev.b > g->lo - margin) { kill(e, invRegion); break; }
+        } else {   // shift: the old columns 0 and 1 changed and the left end moved away
+          if (g->lo - margin < 2) { kill(e, invShift); break; }
+          g->lo += ev.a; g->hi += ev.a;
+        }
+      }
+      if (ev.kind == 1 && e.valid) {
+        for (t4_overlap &o : e.ov) if (o.seqIdx == ev.c) { o.seqStart += ev.a; o.seqEnd += ev.a; }
+        for (t4_overlap &o : e.ext) if (o.seqIdx == ev.c) { o.seqStart += ev.a; o.seqEnd += ev.a; }
+      }
+    }
+  }
+  structEvents.clear();
+  // index events: net effect per (key, posting)
+  if (!idxEvents.empty()) {
+    bool ins = false, rem = false;
+    for (const IdxEv &ev : idxEvents) { if (ev.delta > 0) ins = true; else rem = true; }
+    struct Net { int delta; };
+    std::vector<IdxEv> net;
+    if (ins && rem) {
+      struct PK { uint64_t code; int h, idx, off; bool operator==(const PK &o) const { return code == o.code && h == o.h && idx == o.idx && off == o.off; } };
+      struct PKH { size_t operator()(const PK &p) const { return (size_t)mix64h(p.code * 1000003ull + (uint64_t)(uint32_t)p.idx * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)p.off); } };
+      std::unordered_map<PK, int, PKH> sum;
+      for (const IdxEv &ev : idxEvents) sum[PK{ev.code, ev.h, ev.idx, ev.off}] += ev.delta;
+      for (const IdxEv &ev : idxEvents) {
+        auto it = sum.find(PK{ev.code, ev.h, ev.idx, ev.off});
+        if (it == sum.end() || it->second == 0) continue;
+        IdxEv x = ev; x.delta = it->second; net.push_back(x);
+        it->second = 0;
+      }
+    } else net = idxEvents;
+    // list sizes before the first and after the last event of every key: a size that crosses 100 changes which k-mers
+    // GetHitsFromRead skips (SeqSet.hpp:1381-1391)
+    std::unordered_map<Key, std::pair<uint32_t, uint32_t>, KeyHash> sizes;
+    for (const IdxEv &ev : idxEvents) {
+      if (ev.sizeAfter == 0xFFFFFFFFu) continue;
+      auto it = sizes.find(Key{ev.code, ev.h});
+      const uint32_t before = ev.delta > 0 ? ev.sizeAfter - 1 : ev.sizeAfter + 1;
+      if (it == sizes.end()) sizes.emplace(Key{ev.code, ev.h}, std::make_pair(before, ev.sizeAfter));
+      else it->second.second = ev.sizeAfter;
+    }
+    for (const auto &kv : sizes) {
+      if ((kv.second.first >= 100) == (kv.second.second >= 100)) continue;
+      auto it = winKmers.find(kv.first);
+      if (it == winKmers.end()) continue;
+      for (const KOcc &o : it->second) { Cached &e = *pool[o.slot]; if (e.uid == o.uid) kill(e, invCross); }
+    }
+    for (const IdxEv &ev : net) {
+      auto it = winKmers.find(Key{ev.code, ev.h});
+      if (it == winKmers.end()) continue;
+      for (const KOcc &o : it->second) {
+        Cached &e = *pool[o.slot];
+        if (e.uid != o.uid || !e.valid) continue;
+        if (e.fragile) { kill(e, invFragile); continue; }
+        for (uint32_t plus = 0; plus < 2 && e.valid; ++plus) {
+          const int n = (plus ? o.f : o.r) * (ev.delta > 0 ? ev.delta : -ev.delta);
+          if (!n) continue;
+          if (ev.delta > 0) {
+            Grp &g = e.groups.get((uint32_t)ev.idx * 2u + plus);
+            g.cnt += (uint32_t)n;
+            if (g.cnt >= 3) { kill(e, invKey); break; }
+          } else {
+            Grp *g = e.groups.find((uint32_t)ev.idx * 2u + plus);
+            if (g && g->cnt >= 3) { kill(e, invKey); break; }
+            if (g) g->cnt = g->cnt > (uint32_t)n ? g->cnt - (uint32_t)n : 0;
+          }
+          ++tolerated;
+          if (--e.slack < 0) { kill(e, invFragile); break; }
+        }
+      }
+    }
+    idxEvents.clear();
+  }
+}
+
+// The driver announces the next n reads it will offer to AddRead, in order, with the arguments it will offer them with.
+// Entries already in the window that still stand are kept; every other one is (re-)queried in ONE batch against the patched
+// device image. Returns with a valid head.
+int t4_assembler::prefetchLive(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive) {
+  processEvents();
+  // match the announced reads against the window; what does not line up is dropped
+  size_t keep = 0;
+  for (; keep < order.size() && keep < (size_t)n; ++keep) {
+    const Cached &c = *pool[order[keep]];
+    if (c.read != reads[keep] || c.strand != strands[keep] || c.barcode != (barcodes ? barcodes[keep] : -1) || c.skip != repetitive) break;
+  }
+  while (order.size() > keep && keep < (size_t)n) {   // (entries beyond the announced ones stay when every announced read lined up)
+    const int sl = order.back(); order.pop_back();
+    pool[sl]->valid = false; pool[sl]->uid = 0; freeSlots.push_back(sl); --winKmerLive;
+  }
+  if (winKmerRefs > 64 * 284 && winKmerRefs > 4 * (winKmerLive + 1) * 284) {   // mostly references of retired entries: rebuild
+    winKmers.clear(); winKmerRefs = 0; winKmerLive = 0;
+    for (int sl : order) registerKmers(*pool[sl], sl);
+  }
+  for (size_t i = keep; i < (size_t)n; ++i) {
+    int sl;
+    if (!freeSlots.empty()) { sl = freeSlots.back(); freeSlots.pop_back(); }
+    else { sl = (int)pool.size(); pool.push_back(new Cached()); }
+    Cached &c = *pool[sl];
+    c.read = reads[i]; c.strand = strands[i]; c.barcode = barcodes ? barcodes[i] : -1; c.skip = repetitive; c.cnt = 0; c.valid = false;
+    c.ov.clear(); c.ext.clear(); c.extRet.clear();
+    c.uid = nextUid++;
+    registerKmers(c, sl);
+    order.push_back(sl);
+  }
+  // Entries far behind the head rarely survive until they are consumed: (re-)query only as far ahead as a few times what a
+  // round has recently served (every read queried adds to the latency of the round: it ends with its slowest read)
+  {
+    const double served = (double)(cacheHits - hitsAtLastRound);
+    hitsAtLastRound = cacheHits;
+    if (rounds > 0) runEma = 0.8 * runEma + 0.2 * served;
+  }
+  static const int fixedAhead = getenv("T4_QUERY_AHEAD") ? atoi(getenv("T4_QUERY_AHEAD")) : 0;
+  size_t ahead = fixedAhead > 0 ? (size_t)fixedAhead : (size_t)(3.0 * runEma) + 12;
+  std::vector<int> todo;
+  for (size_t i = 0; i < order.size() && i < ahead; ++i) if (!pool[order[i]]->valid) todo.push_back(order[i]);
+  if (todo.empty()) return T4_OK;
+  int rc;
+  const int m = (int)todo.size();
+  if (index.total == 0) {   // an empty set has no hit for anybody
+    for (int sl : todo) { Cached &c = *pool[sl]; c.cnt = 0; c.valid = true; c.groups.reset(16); c.slack = 99; c.fragile = false; }
+    return T4_OK;
+  }
+  if ((rc = flushLive())) return rc;
+  auto tq0_ = std::chrono::steady_clock::now();
+  struct Tq { double &acc; std::chrono::steady_clock::time_point t0; ~Tq() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tq_{secQuery, tq0_};
+  std::string bases; std::vector<int64_t> offs(1, 0); std::vector<int32_t> bcs(m), sts(m); std::vector<double> fac(m);
+  for (int i = 0; i < m; ++i) {
+    const Cached &c = *pool[todo[i]];
+    bases += c.read; offs.push_back((int64_t)bases.size()); bcs[i] = c.barcode; sts[i] = c.strand;
+    fac[i] = (c.barcode == -1 && !repetitive) ? 1.0 : 2.0;   // ExtendOverlap's mismatch factor (SeqSet.hpp:3597-3598)
+  }
+  if (bases.empty()) bases.push_back('A');
+  // the hit groups of the queried reads come from the host replica of the index while the GPU runs the query
+  std::atomic<int> nextG(0);
+  auto groupWorker = [&]() { for (;;) { int i = nextG.fetch_add(1); if (i >= m) break; buildGroups(*pool[todo[i]]); } };
+  std::vector<std::thread> helpers;
+  const int nHelp = m >= 4 ? (threads - 1 < m / 2 ? threads - 1 : m / 2) : 0;
+  for (int t = 0; t < nHelp; ++t) helpers.emplace_back(groupWorker);
+  const int32_t *cnts = nullptr, *bas = nullptr, *rets = nullptr;
+  const t4_overlap *ov = nullptr, *ex = nullptr;
+  rc = t4_add_query_pool(dev, m, bases.data(), offs.data(), bcs.data(), sts.data(), repetitive, fac.data(), &cnts, &bas, &ov, &ex, &rets);
+  auto tg1 = std::chrono::steady_clock::now();
+  groupWorker();
+  for (auto &th : helpers) th.join();
+  secGroups += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg1).count();
+  ++queries; ++rounds; readsQueried += m;
+  if (rc) { dropWindow(); return rc; }
+  for (int i = 0; i < m; ++i) {
+    Cached &c = *pool[todo[i]];
+    c.cnt = cnts[i];
+    const int k2 = c.cnt > 0 ? c.cnt : 0;
+    c.ov.assign(ov + bas[i], ov + bas[i] + k2);
+    c.ext.assign(ex + bas[i], ex + bas[i] + k2);
+    c.extRet.assign(rets + bas[i], rets + bas[i] + k2);
+    c.valid = true;
+  }
+  return T4_OK;
 }
 
 void t4_assembler::beginWindow(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive) {
@@ -813,35 +1335,9 @@ void t4_assembler::beginWindow(int n, const char *const *reads, const int *stran
   }
 }
 
-// results of the window's query (stride records per read) + the dependency sets of every window read, from the host
-// copy of the index (both strands, every valid k-mer)
+// results of the window's query (stride records per read)
 void t4_assembler::endWindow(const int32_t *cnts, const t4_overlap *ov, const t4_overlap *ex, const int32_t *rets, int stride) {
   const int n = (int)cache.size();
-  if (n > 1 && !owner) {
-    std::string rcs;
-    for (int q = 0; q < n; ++q) {
-      const Cached &c = cache[q];
-      reverseComplement(rcs, c.read);
-      std::vector<int> contigs;
-      for (int st = 0; st < 2; ++st) {
-        const std::string &r = st ? rcs : c.read;
-        if ((int)r.size() < k) continue;
-        KCode kc(k);
-        for (int i = 0; i < (int)r.size(); ++i) {
-          kc.append(r[i]);
-          if (i < k - 1 || !kc.valid()) continue;
-          Key key{kc.code, index.bucket(kc.code, c.barcode)};
-          auto &slots = winKmers[key];
-          if (slots.empty() || slots.back() != q) slots.push_back(q);
-          auto it = index.map.find(key);
-          if (it != index.map.end()) for (const Post &p : it->second) contigs.push_back(p.idx);
-        }
-      }
-      std::sort(contigs.begin(), contigs.end());
-      contigs.erase(std::unique(contigs.begin(), contigs.end()), contigs.end());
-      for (int cid : contigs) winContigs[cid].push_back(q);
-    }
-  }
   for (int q = 0; q < n; ++q) {
     Cached &c = cache[q];
     c.cnt = cnts ? cnts[q] : 0;
@@ -863,6 +1359,7 @@ int t4_assembler::prefetch(int n, const char *const *reads, const int *strands, 
     std::vector<t4_assembler *> who(n, this);
     return t4_cellset_prefetch(owner, n, who.data(), reads, strands, repetitive);
   }
+  if (live()) return n > 0 ? prefetchLive(n, reads, strands, barcodes, repetitive) : T4_OK;
   if ((rc = refreshDevice())) return rc;
   auto tq0_ = std::chrono::steady_clock::now();
   struct Tq { double &acc; std::chrono::steady_clock::time_point t0; ~Tq() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tq_{secQuery, tq0_};
@@ -877,13 +1374,8 @@ int t4_assembler::prefetch(int n, const char *const *reads, const int *strands, 
   const size_t m = (size_t)n * MAXOV;
   std::vector<t4_overlap> ov(m), ex(m);
   std::vector<int32_t> cnts(n), rets(m);
-  if (!index.considerBarcode) {
-    std::vector<int32_t> slots(n, slot);
-    rc = index.total == 0 ? T4_OK   // an empty set has no hit for anybody
-                          : t4_cellstore_query(priv, n, slots.data(), bases.data(), offs.data(), bcs.data(), sts.data(), repetitive, fac.data(), MAXOV,
-                                               cnts.data(), ov.data(), ex.data(), rets.data());
-  } else
-    rc = t4_add_query(dev, n, bases.data(), offs.data(), bcs.data(), sts.data(), repetitive, fac.data(), MAXOV, cnts.data(), ov.data(), ex.data(), rets.data());
+  rc = index.total == 0 ? T4_OK   // an empty set has no hit for anybody
+                        : t4_add_query(dev, n, bases.data(), offs.data(), bcs.data(), sts.data(), repetitive, fac.data(), MAXOV, cnts.data(), ov.data(), ex.data(), rets.data());
   ++queries;
   if (rc) { dropWindow(); return rc; }
   endWindow(cnts.data(), ov.data(), ex.data(), rets.data(), MAXOV);
@@ -959,13 +1451,13 @@ int t4_assembler_create(t4_ctx *ctx, int kmer_length, int consider_barcode, t4_a
   if (!ctx || !out || kmer_length < 2 || kmer_length > 31) return T4_ERR_ARG;
   t4_assembler *a = new t4_assembler(ctx, kmer_length);
   a->index.considerBarcode = consider_barcode != 0;
+  a->index.mirror = a->live();
   *out = a;
   return T4_OK;
 }
 void t4_assembler_destroy(t4_assembler *a) {
   if (!a) return;
   if (a->dev) t4_index_destroy(a->dev);
-  if (a->priv) { t4_cellstore_destroy(a->priv); a->priv = nullptr; }
   if (a->owner) return;   // cells belong to their t4_cellset
   delete a;
 }
@@ -976,18 +1468,26 @@ int t4_assembler_set_params(t4_assembler *a, int hit_len_required, int radius, d
 }
 int t4_assembler_input_novel_read(t4_assembler *a, const char *id, const char *read, int strand, int barcode) {
   if (!a || !id || !read) return T4_ERR_ARG - 100;
-  return a->inputNovelRead(id, read, strand, barcode);
+  const int r = a->inputNovelRead(id, read, strand, barcode);
+  a->processEvents();
+  return r;
 }
 int t4_assembler_add_read(t4_assembler *a, const char *read, const char *gene_name, int *strand, int barcode, int min_kmer_count,
                           int repetitive_data, double similarity_threshold) {
   if (!a || !read || !gene_name || !strand) return T4_ERR_ARG - 100;
-  return a->addRead(read, gene_name, strand, barcode, min_kmer_count, repetitive_data != 0, similarity_threshold);
+  const int r = a->addRead(read, gene_name, strand, barcode, min_kmer_count, repetitive_data != 0, similarity_threshold);
+  a->processEvents();
+  return r;
 }
 int t4_assembler_prefetch(t4_assembler *a, int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive_data) {
   if (!a || n < 0 || (n > 0 && (!reads || !strands))) return T4_ERR_ARG;
   return a->prefetch(n, reads, strands, barcodes, repetitive_data ? 1 : 0);
 }
-int t4_assembler_window_valid(const t4_assembler *a) { return a && a->cacheHead < a->cache.size() && a->cache[a->cacheHead].valid; }
+int t4_assembler_window_valid(const t4_assembler *a) {
+  if (!a) return 0;
+  if (a->live()) return !a->order.empty() && a->pool[a->order.front()]->valid;
+  return a->cacheHead < a->cache.size() && a->cache[a->cacheHead].valid;
+}
 int t4_assembler_counters(const t4_assembler *a, int64_t *queries, int64_t *refreshes, int64_t *window_hits) {
   if (!a) return T4_ERR_ARG;
   if (queries) *queries = a->queries;
@@ -1001,8 +1501,21 @@ int t4_assembler_timers(const t4_assembler *a, double *sec_refresh, double *sec_
   if (sec_query) *sec_query = a->secQuery;
   return T4_OK;
 }
-int t4_assembler_repeat_add_read(t4_assembler *a, const char *read) { return a ? a->repeatAddRead(read) : T4_ERR_ARG - 100; }
-int t4_assembler_update_all_consensus(t4_assembler *a) { if (!a) return T4_ERR_ARG; a->updateAllConsensus(); return T4_OK; }
+int t4_assembler_repeat_add_read(t4_assembler *a, const char *read) {
+  if (!a) return T4_ERR_ARG - 100;
+  const int r = a->repeatAddRead(read);
+  a->processEvents();
+  return r;
+}
+int t4_assembler_update_all_consensus(t4_assembler *a) { if (!a) return T4_ERR_ARG; a->updateAllConsensus(); a->processEvents(); return T4_OK; }
+int t4_assembler_set_threads(t4_assembler *a, int host_threads) { if (!a || host_threads < 1) return T4_ERR_ARG; a->threads = host_threads > 64 ? 64 : host_threads; return T4_OK; }
+int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n) {
+  if (!a || !out || n < 1) return T4_ERR_ARG;
+  const int64_t v[16] = {a->rounds, a->readsQueried, a->deltas, a->deltaBytes, a->invalidations, a->invKey, a->invCross, a->invRegion, a->invShift,
+                         a->invContig, a->invFragile, a->tolerated, (int64_t)(a->secDelta * 1e6), (int64_t)(a->secGroups * 1e6), (int64_t)(a->secEvents * 1e6), (int64_t)(a->secQuery * 1e6)};
+  for (int i = 0; i < n && i < 16; ++i) out[i] = v[i];
+  return T4_OK;
+}
 int t4_assembler_output(t4_assembler *a, const char *path) { return a ? a->output(path) : T4_ERR_ARG; }
 int t4_assembler_size(const t4_assembler *a) { return a ? (int)a->seqs.size() : 0; }
 int t4_assembler_change_kmer_length(t4_assembler *a, int kmer_length) {

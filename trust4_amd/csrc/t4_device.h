@@ -141,6 +141,11 @@ struct T4QueryArgs {
   const int *strandPerRead;
   const double *factorPerRead;
   T4OverlapOut *outExt;
+  // mode 4 results are variable-size: read r's records start at outBase[r] of out / outExt / ret (space taken from a pool by
+  // one atomic per read; a read that does not fit the pool gets status 3 and the host repeats the call with a larger one)
+  int *outBase;
+  unsigned *poolCursor;
+  int poolCap;
   // per-read set images (per-barcode contig sets): read r is matched against views[viewOf[r]]
   const T4IndexView *views;
   const int *viewOf;

@@ -38,4 +38,11 @@ int t4_cellstore_query(t4_cellstore *cs, int n, const int32_t *slots, const char
 int t4_cellstore_set_big_first(t4_cellstore *cs, int on);   // first launch on the 8192-hit tier (one big set) instead of the 1024-hit tier
 int64_t t4_cellstore_bytes_staged(const t4_cellstore *cs);
 
+// t4_add_query with variable-size results (a read may overlap thousands of contigs that share a gene segment): counts[i]
+// records of read i start at index base[i] of ov / ext / ext_ret, which point into pinned memory of the ctx that stays
+// valid until the next query on it.
+int t4_add_query_pool(t4_index *ix, int n, const char *bases, const int64_t *offsets, const int32_t *barcodes, const int32_t *strands,
+                      int skip_repeats, const double *factors, const int32_t **counts, const int32_t **base, const t4_overlap **ov,
+                      const t4_overlap **ext, const int32_t **ext_ret);
+
 }  // extern "C"

@@ -114,6 +114,15 @@ __device__ __forceinline__ void indexLookup(const T4IndexView &ix, unsigned long
       i = (i + 1) & ix.hashMask;
     }
   }
+  if (ix.direct == 3) {   // live set (t4_index_apply_delta): keys are never removed, an empty slot holds code ~0
+    unsigned long long i = mix64(code) & ix.hashMask;
+    for (;;) {
+      T4HashEntC e = ix.ctab[i];
+      if (e.code == code) { start = e.start; cnt = e.cnt; return; }
+      if (e.code == ~0ull) { start = 0; cnt = 0; return; }
+      i = (i + 1) & ix.hashMask;
+    }
+  }
   int h = (int)((code + (unsigned long long)(long long)(ix.considerBarcode ? barcode + 1 : 0)) % 1000003ull);
   unsigned long long i = mix64(code * 1000003ull + (unsigned long long)h) & ix.hashMask;
   for (;;) {
@@ -2483,9 +2492,16 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
     int ret = overlapsFromSegment(ix, wm, ws, len, qa.strandPerRead[r], barcode, qa.skipRepeats != 0, 0, sc, hitTotal);
     if (ret == -2) return false;
     int n = ret > 0 ? ret : 0;
-    if (n > qa.maxPerRead) { if (lane == 0) wk.status[r] = 2; n = 0; ret = 0; }
+    if (lane == 0) {   // room for this read's records in the result pool
+      const int base = n > 0 ? (int)atomicAdd(qa.poolCursor, (unsigned)n) : 0;
+      ws->red[15] = (base + n > qa.poolCap) ? -1 : base;
+    }
     __syncthreads();
-    for (int i = lane; i < n; i += NT) { storeOverlap(qa.out + r * qa.maxPerRead + i, wm.fin[i]); wm.ord[i] = (unsigned short)i; }
+    const long long base = ws->red[15];
+    __syncthreads();
+    if (base < 0) { if (lane == 0) { wk.status[r] = 3; qa.counts[r] = 0; } return true; }
+    if (lane == 0) qa.outBase[r] = (int)base;
+    for (int i = lane; i < n; i += NT) { storeOverlap(qa.out + base + i, wm.fin[i]); wm.ord[i] = (unsigned short)i; }
     __syncthreads();
     PHASE_MARK(ws, 16);
     extendOverlaps(ix, wm, ws, n, len, false, qa.factorPerRead[r], sides, dirbuf, res);
@@ -2497,8 +2513,8 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
       t.strand = (o.flags & OV_PLUS) ? 1 : -1; t.matchCnt = res[i].matchCnt;
       if (res[i].simFail) { t.indelCnt = o.indelCnt; t.similarity = ovSim(o); }
       else { t.indelCnt = 0; t.similarity = (double)t.matchCnt / (double)res[i].den; }
-      qa.outExt[r * qa.maxPerRead + i] = t;
-      qa.ret[r * qa.maxPerRead + i] = res[i].ret;
+      qa.outExt[base + i] = t;
+      qa.ret[base + i] = res[i].ret;
     }
     if (lane == 0) qa.counts[r] = ret;
   } else if (VARIANT == 1 && (qa.mode == 2 || qa.mode == 3)) {
@@ -2790,6 +2806,22 @@ __global__ __launch_bounds__(256) void scatterKernel(const unsigned char *stagin
     uint4 *dst = (uint4 *)cd.dst;
     const unsigned long long n16 = cd.bytes >> 4;
     for (unsigned long long i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+  }
+}
+
+// Patches of a live set's image (t4_index_apply_delta): run d copies bytes staging[srcOff ..) -> dst, one wavefront per run.
+// Runs never overlap (every destination is written once per delta).
+__global__ __launch_bounds__(256) void deltaKernel(const unsigned char *staging, const T4CopyDesc *desc, int nDesc) {
+  const int wavesPerBlock = blockDim.x >> 6, lane = threadIdx.x & 63;
+  for (int d = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6); d < nDesc; d += gridDim.x * wavesPerBlock) {
+    const T4CopyDesc cd = desc[d];
+    const unsigned char *src = staging + cd.srcOff;
+    unsigned char *dst = cd.dst;
+    if ((((unsigned long long)dst | (unsigned long long)src | cd.bytes) & 7ull) == 0) {
+      const unsigned long long n8 = cd.bytes >> 3;
+      for (unsigned long long i = lane; i < n8; i += 64) ((unsigned long long *)dst)[i] = ((const unsigned long long *)src)[i];
+    } else
+      for (unsigned long long i = lane; i < cd.bytes; i += 64) dst[i] = src[i];
   }
 }
 

@@ -780,6 +780,7 @@ int main(int argc, char *argv[]) {
   } else {
     if ((rc = t4_assembler_create(ctx, indexKmerLength, 0, &seqSet))) die(ctx, "t4_assembler_create", rc);
     t4_assembler_set_params(seqSet, hitLenRequired, 10, 0.9);
+    t4_assembler_set_threads(seqSet, threadCnt);
   }
   for (const NovelFa &nf : novelFa) {   // SeqSet::InputNovelFa (SeqSet.hpp:2986-2993): every record becomes a contig, strand 1, no barcode
     if (useCells) { fprintf(stderr, "trust4-hip: --debug-ns is not supported together with --barcode (use --keepNoBarcode).\n"); return EXIT_FAILURE; }
@@ -792,7 +793,9 @@ int main(int argc, char *argv[]) {
   std::vector<int> barcodeTotalReadCount(barcodeIntToStr.size(), 0), barcodeReadCount(barcodeIntToStr.size(), 0);
   if (hasBarcode) for (int i = 0; i < readCnt; ++i) if (sortedReads[i].barcode != -1) ++barcodeTotalReadCount[sortedReads[i].barcode];
   std::atomic<int> assembledReadCnt(0);
-  const int WINDOW = getenv("T4_WINDOW") ? atoi(getenv("T4_WINDOW")) : 4;
+  // upcoming AddRead reads queried per round: per cell in barcode mode (a cell's window ends at its first observable change);
+  // in bulk mode the window slides and keeps what still stands, so it is as wide as one launch serves at single-read latency
+  const int WINDOW = getenv("T4_WINDOW") ? atoi(getenv("T4_WINDOW")) : (hasBarcode && !keepMissingBarcode ? 4 : 192);
   const int LANES = getenv("T4_LANES") ? atoi(getenv("T4_LANES")) : 4096;
 
   // AddRead arguments of read i that do not depend on the loop state (main.cpp:1609-1701)
@@ -1149,7 +1152,14 @@ int main(int argc, char *argv[]) {
   t4_assembler_counters(seqSet, &q, &rf, &wh);
   double sr = 0, sq = 0;
   t4_assembler_timers(seqSet, &sr, &sq);
-  PrintLog("Finish assembly. (GPU query batches %lld in %.2f s, device image refreshes %lld in %.2f s, reads served from the speculation window %lld)", (long long)q, sq, (long long)rf, sr, (long long)wh);
+  int64_t lc[16] = {0};
+  t4_assembler_live_counters(seqSet, lc, 16);
+  PrintLog("Finish assembly. (GPU query rounds %lld with %lld reads in %.2f s; %lld image deltas, %.1f MB, in %.2f s; reads served from the window %lld; "
+           "window entries invalidated %lld: key %lld, list>=100 %lld, region %lld, shift %lld, contig %lld, tolerance %lld; tolerated index changes %lld; "
+           "dependency sets %.2f s, event examination %.2f s)",
+           (long long)lc[0], (long long)lc[1], lc[15] / 1e6, (long long)lc[2], lc[3] / 1e6, lc[12] / 1e6, (long long)wh, (long long)lc[4], (long long)lc[5], (long long)lc[6],
+           (long long)lc[7], (long long)lc[8], (long long)lc[9], (long long)lc[10], (long long)lc[11], lc[13] / 1e6, lc[14] / 1e6);
+  (void)q; (void)rf; (void)sr; (void)sq;
   t4_assembler_destroy(seqSet);
   t4_index_destroy(refSet);
   t4_destroy(ctx);
