@@ -1,22 +1,38 @@
 #!/usr/bin/env python3
-"""bench.py -- stage-1 hot path throughput on N MI355X of one node (driver contract in the task brief).
+"""bench.py -- whole stage-1 throughput on N MI355X of one node (driver contract in the task brief).
 
-A "step" is one pass of the GPU hot path over one resident batch of synthetic 150 bp paired-end reads
-(SURVEY.md 8d recipe, config C2: 1 M pairs, 20 k clones, seed 1, -f hg38_bcrtcr.fa, k = 9). The pass
-measured this round is the stage-1 rough-annotation pass of every read (main.cpp:1084-1120:
-GetHitsFromRead -> SortHits -> GetOverlapsFromHits -> GetOverlapsFromRead scoring -> AnnotateRead
-level 0), the data-parallel pass; the order-dependent AddRead loop is NOT part of `value`. Rank 0 at N=1 also
-reports, as the extra object `stage1_e2e`, the wall-clock of WHOLE stage 1 (FASTQ in -> _raw.out/_final.out out) of the
-`trust4-hip` driver on a bounded 10x-style sample (SURVEY 8d C5 recipe), next to the reference binary on the same files
-and with the outputs compared byte for byte.
-Inputs are 2-bit packed and resident in HBM before the timed region; results stay on the device.
-Read batches shard across ranks with no data-path collective (weak scaling: every rank owns its own
-C2-sized batch, seeded by rank).
+A "step" is ONE WHOLE STAGE 1 (`trust4_amd/bin/trust4-hip`: FASTQ in -> ProcessRead / 21-mer counts / sort -> rough
+annotation of every read on the GPU -> the order-dependent AddRead pass (host commits + GPU queries against a device
+image patched by deltas) -> `_raw.out`, `_assembled_reads.fa`, `_final.out`) over one batch of synthetic 150 bp
+paired-end reads of the SURVEY.md 8(d) C2 recipe (20 k clones per 1 M pairs, seed 1 + rank, -f hg38_bcrtcr.fa, k = 9,
+bulk mode). `value` = pairs of all ranks / wall clock of the slowest rank, process start to exit: the parse of the FASTQ
+text, device bring-up and every host phase are INSIDE the timed region (the boundary hands over files, as
+run-trust4:508 does, so there is no "inputs resident in HBM" variant of this metric; the kernel-only numbers are in
+`roofline` / `passes`).
+
+The default batch is 100 k pairs (C2 recipe at 1/10 of its size): the AddRead pass is a chain of dependent GPU round
+trips, whole C2 takes tens of minutes and the reference hours. `--pairs 1000000 --steps 1 --warmup 0`
+runs config C2 itself.
+
+Rank 0 at N = 1 also reports
+  cpu_baseline   the reference binary (oracle/_ref/trust4) on THE SAME files with -t <host cores>, outputs compared byte for
+                 byte with the GPU run's (`parity_on_bench_batch`), and with -t 1 on a stated prefix;
+  passes         kernel-level numbers of the two GPU passes of the timed runs (HIP-event kernel time, _hit records H,
+                 algorithmic bytes of SURVEY 8d) and the rough-annotation pass alone over a resident C2 batch (2 M reads);
+  stage1_cells   whole stage 1 in barcode mode (C5 recipe sample) next to the reference binary;
+  stage0_e2e     the stage-0 candidate filter next to the reference binary.
+Multi-GPU: bulk-mode stage 1 is one ordered chain (replicas only): every rank runs its own batch on its own
+GPU with no data-path collective; timing is barrier + max over ranks (weak scaling).
 """
 import argparse
+import filecmp
+import gzip
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -26,127 +42,152 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+DRIVER = os.path.join(ROOT, "trust4_amd", "bin", "trust4-hip")
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "trust4")
+OUT_SUFFIXES = ("_raw.out", "_assembled_reads.fa", "_final.out")
 
 
-def algorithmic_bytes(n_reads, read_len, total_hits):
+def annotate_bytes(n_reads, read_len, total_hits):
     """ceil(L/4) + ceil(L/8) + 8*H + 4*32 per read."""
     return n_reads * ((read_len + 3) // 4 + (read_len + 7) // 8 + 128) + 8 * total_hits
 
 
-def pmc_traffic(pairs):
-    """HBM-side traffic per pass from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE
-    need separate profiler runs, so they cannot be collected inside this process). Only valid for the workload
-    they were collected on (C2, 1 M pairs); otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if pairs != 1000000 or not os.path.exists(path):
-        return None
-    return json.load(open(path)).get("traffic_bytes")
+def add_bytes(n_queries, read_len, total_hits):
+    """SURVEY.md 8(d), AddRead pass: the same formula with its own H and + 16 * L for the posWeight read-modify-write."""
+    return n_queries * ((read_len + 3) // 4 + (read_len + 7) // 8 + 128 + 16 * read_len) + 8 * total_hits
 
 
-def cpu_baseline(reads_arr, sample_reads):
-    """Time the CPU path on this box's host cores over a bounded sample of the same workload.
-    Uses the compiled reference (oracle/_ref/libt4ref.so) when it travelled with the repo, else the C oracle."""
-    import ctypes as C
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def make_batch(tmp, pairs, clones, seed):
+    """FASTQ files of one batch (t4synth: the SURVEY 8d recipe) + the plain-text gene FASTA."""
+    fa = os.path.join(tmp, "ref.fa")
     import t4libs
-    n = min(sample_reads, len(reads_arr))
-    sample = np.ascontiguousarray(reads_arr[:n])
-    stride = sample.shape[1]
-    if t4libs.Ref.available():
-        r = t4libs.Ref(9, t4libs.REF_FA, 17)
-        fn = r.lib.ref_annotate_batch
-        fn.restype = C.c_long
-        fn.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_long, C.c_void_p]
-        t0 = time.perf_counter()
-        fn(r.h, sample.ctypes.data_as(C.c_char_p), stride, n, None)
-        dt = time.perf_counter() - t0
-        kind = "reference"
-    else:
-        o = t4libs.Oracle(9, t4libs.REF_FA, 17)
-        t0 = time.perf_counter()
-        o.annotate_batch(sample, stride, n)
-        dt = time.perf_counter() - t0
-        kind = "port"
-    return {"value": n / dt, "unit": "reads/s", "cores": 1, "kind": kind,
-            "sample": "first %d reads of the rank-0 batch, same rough-annotation pass, 1 thread, %.1f s" % (n, dt)}
+    if not os.path.exists(fa):
+        with gzip.open(t4libs.REF_FA, "rb") as f, open(fa, "wb") as g:
+            shutil.copyfileobj(f, g)
+    pre = os.path.join(tmp, "b%d" % seed)
+    subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, str(pairs), str(clones), str(seed), pre], check=True, stdout=subprocess.DEVNULL)
+    return fa, pre + "_1.fq", pre + "_2.fq"
 
 
-def stage1_e2e(pairs, cells):
+def run_stage1(fa, f1, f2, out, threads, device, stats=None, extra=()):
+    env = dict(os.environ, T4_DEVICE=str(device))
+    if stats:
+        env["T4_STATS_JSON"] = stats
+    t0 = time.perf_counter()
+    p = subprocess.run([DRIVER, "-t", str(threads), "--skipMateExtension", "-f", fa, "-1", f1, "-2", f2, "-o", out] + list(extra),
+                       env=env, stderr=subprocess.PIPE, text=True)
+    dt = time.perf_counter() - t0
+    if p.returncode:
+        raise SystemExit("trust4-hip failed (%d):\n%s" % (p.returncode, "\n".join(p.stderr.strip().split("\n")[-10:])))
+    return dt
+
+
+def head_fastq(src, dst, pairs):
+    with open(src) as f, open(dst, "w") as g:
+        for i, line in enumerate(f):
+            if i >= 4 * pairs:
+                break
+            g.write(line)
+
+
+def cpu_baseline(tmp, fa, f1, f2, pairs, mine_prefix, single_prefix_pairs):
+    """The reference's pthreads CPU path on the same files (all host cores), outputs compared with the GPU run's; and its
+    single-thread time on a prefix of the same files."""
+    cores = host_cores()
+    t0 = time.perf_counter()
+    subprocess.run([REF_BIN, "-t", str(cores), "--skipMateExtension", "-f", fa, "-1", f1, "-2", f2, "-o", os.path.join(tmp, "ref")],
+                   check=True, stderr=subprocess.DEVNULL)
+    dt = time.perf_counter() - t0
+    same = all(filecmp.cmp(os.path.join(tmp, "ref" + x), mine_prefix + x, shallow=False) for x in OUT_SUFFIXES)
+    out = {"value": pairs / dt, "unit": "pairs/s", "cores": cores, "kind": "reference",
+           "sample": "oracle/_ref/trust4 -t %d --skipMateExtension on the whole batch of the timed steps (%d pairs), %.1f s wall" % (cores, pairs, dt),
+           "seconds": dt}
+    if single_prefix_pairs > 0:
+        n1 = min(single_prefix_pairs, pairs)
+        h1, h2 = os.path.join(tmp, "p_1.fq"), os.path.join(tmp, "p_2.fq")
+        head_fastq(f1, h1, n1)
+        head_fastq(f2, h2, n1)
+        t0 = time.perf_counter()
+        subprocess.run([REF_BIN, "-t", "1", "--skipMateExtension", "-f", fa, "-1", h1, "-2", h2, "-o", os.path.join(tmp, "ref1")],
+                       check=True, stderr=subprocess.DEVNULL)
+        d1 = time.perf_counter() - t0
+        out["single_thread"] = {"value": n1 / d1, "unit": "pairs/s", "cores": 1, "sample": "the first %d pairs of the same files, -t 1, %.1f s wall" % (n1, d1)}
+    return out, same
+
+
+def annotate_pass_c2(device, pairs, clones, steps):
+    """The data-parallel pass alone over a resident C2-sized batch: stage-1 rough annotation of every read
+    (main.cpp:1084-1120), inputs 2-bit packed in HBM before the timed region, results left on the device."""
+    import t4libs
+    import trust4_amd
+    eng = trust4_amd.Engine(device)
+    ref = eng.index(9).set_params(17, 10, 0.9).load_ref_fasta(t4libs.REF_FA).commit()
+    reads = t4libs.Synth(clones, 1).next_reads(pairs)
+    n_reads = reads.shape[0]
+    batch = eng.upload(reads)
+    ref.annotate_rough(batch, fetch=False)
+    eng.check(eng.lib.t4_sync(eng.h))
+    t0 = time.perf_counter()
+    kms, hits = [], 0
+    for _ in range(steps):
+        ref.annotate_rough(batch, fetch=False)
+        st = eng.stats()
+        kms.append(st["chain_kernel_ms"])
+        hits = st["total_hits"]
+    eng.check(eng.lib.t4_sync(eng.h))
+    dt = time.perf_counter() - t0
+    k_ms = float(np.mean(kms))
+    alg = annotate_bytes(n_reads, 150, hits)
+    return {"workload": "C2: %d pairs (%d reads), %d clones, seed 1; rough annotation of every read, inputs resident, results on the device" % (pairs, n_reads, clones),
+            "reads_per_s": n_reads * steps / dt, "ms_per_pass": dt / steps * 1e3, "kernel_ms": k_ms, "hits_per_read": hits / n_reads,
+            "tier_reads": eng.stats()["tier_reads"],
+            "roofline": {"bound": "hbm", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "t4k::queryKernel<.., 0> (all tiers of one pass)", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg}}
+
+
+def stage1_cells(pairs, cells):
     """Whole stage 1 in barcode mode through trust4-hip vs oracle/_ref/trust4 (when it travelled) on the same files."""
-    import filecmp
-    import gzip
-    import shutil
-    import subprocess
-    import tempfile
-    import t4libs
     tmp = tempfile.mkdtemp()
     try:
+        import t4libs
         fa = os.path.join(tmp, "ref.fa")
         with gzip.open(t4libs.REF_FA, "rb") as f, open(fa, "wb") as g:
             shutil.copyfileobj(f, g)
         pre = os.path.join(tmp, "c5")
-        subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, str(pairs), "0", "4", pre, "--cells", str(cells)], check=True)
+        subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, str(pairs), "0", "4", pre, "--cells", str(cells)], check=True, stdout=subprocess.DEVNULL)
         argv = ["-f", fa, "-1", pre + "_1.fq", "-2", pre + "_2.fq", "--barcode", pre + "_bc.fa", "--UMI", pre + "_umi.fa"]
-        cores = min(8, os.cpu_count() or 1)   # same host-thread budget for both programs
+        cores = min(8, host_cores())   # same host-thread budget for both programs
         t0 = time.perf_counter()
-        subprocess.run([os.path.join(ROOT, "trust4_amd", "bin", "trust4-hip"), "-t", str(cores)] + argv + ["-o", os.path.join(tmp, "mine")], check=True, stderr=subprocess.DEVNULL)
+        subprocess.run([DRIVER, "-t", str(cores)] + argv + ["-o", os.path.join(tmp, "mine")], check=True, stderr=subprocess.DEVNULL)
         t_mine = time.perf_counter() - t0
         out = {"workload": "C5 recipe sample: %d synthetic 150 bp PE pairs, %d cells x 2 clones, barcode + UMI files; FASTQ in -> _raw.out/_final.out/_assembled_reads.fa out" % (pairs, cells),
                "pairs_per_s": pairs / t_mine, "seconds": t_mine, "host_threads": cores}
-        ref_bin = os.path.join(ROOT, "oracle", "_ref", "trust4")
-        if os.path.exists(ref_bin):
+        if os.path.exists(REF_BIN):
             t0 = time.perf_counter()
-            subprocess.run([ref_bin, "-t", str(cores)] + argv + ["-o", os.path.join(tmp, "ref")], check=True, stderr=subprocess.DEVNULL)
+            subprocess.run([REF_BIN, "-t", str(cores)] + argv + ["-o", os.path.join(tmp, "ref")], check=True, stderr=subprocess.DEVNULL)
             t_ref = time.perf_counter() - t0
             out.update({"reference_pairs_per_s": pairs / t_ref, "reference_seconds": t_ref, "reference_threads": cores,
-                        "identical": all(filecmp.cmp(os.path.join(tmp, "ref" + x), os.path.join(tmp, "mine" + x), shallow=False)
-                                         for x in ("_raw.out", "_final.out", "_assembled_reads.fa"))})
-        # the same run with the opt-in device paths of the host phases (21-mer counts + count statistics, ProcessRead's mate tests);
-        # a failure here is reported, it does not take the bench line down
-        try:
-            env = dict(os.environ, T4_GPU_KMERCOUNT="1", T4_GPU_MATEOVERLAP="1")
-            t0 = time.perf_counter()
-            subprocess.run([os.path.join(ROOT, "trust4_amd", "bin", "trust4-hip"), "-t", str(cores)] + argv + ["-o", os.path.join(tmp, "dev")], check=True, stderr=subprocess.DEVNULL, env=env)
-            t_dev = time.perf_counter() - t0
-            out["device_host_phases"] = {"switches": "T4_GPU_KMERCOUNT=1 T4_GPU_MATEOVERLAP=1", "seconds": t_dev, "pairs_per_s": pairs / t_dev,
-                                         "identical_to_default": all(filecmp.cmp(os.path.join(tmp, "dev" + x), os.path.join(tmp, "mine" + x), shallow=False)
-                                                                     for x in ("_raw.out", "_final.out", "_assembled_reads.fa"))}
-        except Exception as e:   # noqa: BLE001
-            out["device_host_phases"] = {"error": repr(e)[:300]}
+                        "identical": all(filecmp.cmp(os.path.join(tmp, "ref" + x), os.path.join(tmp, "mine" + x), shallow=False) for x in OUT_SUFFIXES)})
         return out
+    except Exception as e:   # noqa: BLE001  (a side leg never takes the bench line down)
+        return {"error": repr(e)[:300]}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def kmer_count_leg(eng, batch, n_reads):
-    """canonical 21-mer counts of the resident batch + count statistics of every read (t4_kmer_count_*), event-free
-    wall clock around the two calls (each ends with a stream synchronize)."""
-    try:
-        kc = eng.kmer_counter(21, max_kmers=33 * n_reads)
-        eng.check(eng.lib.t4_sync(eng.h))
-        t0 = time.perf_counter()
-        kc.add(batch)
-        t1 = time.perf_counter()
-        mn, md, av, ln = kc.stats(batch)
-        t2 = time.perf_counter()
-        out = {"workload": "21-mers of the %d resident reads: count (KmerCount::AddCount), then min / median / mean count per read (GetCountStatsAndTrim, no qualities)" % n_reads,
-               "count_reads_per_s": n_reads / (t1 - t0), "count_seconds": t1 - t0, "stats_reads_per_s": n_reads / (t2 - t1), "stats_seconds": t2 - t1,
-               "distinct_kmers": kc.distinct(), "mean_min_count": float(mn.mean())}
-        kc.close()
-        return out
-    except Exception as e:   # noqa: BLE001
-        return {"error": repr(e)[:300]}
-
-
 def stage0_e2e(pairs, receptor_fraction=0.02):
     """Stage-0 candidate filter (fastq-extractor-hip) vs oracle/_ref/fastq-extractor (when it travelled) on the same FASTQ files."""
-    import filecmp
-    import gzip
-    import shutil
-    import subprocess
-    import tempfile
-    import t4libs
     tmp = tempfile.mkdtemp()
     try:
+        import t4libs
         fa = os.path.join(tmp, "ref.fa")
         with gzip.open(t4libs.REF_FA, "rb") as f, open(fa, "wb") as g:
             shutil.copyfileobj(f, g)
@@ -170,13 +211,15 @@ def stage0_e2e(pairs, receptor_fraction=0.02):
                "pairs_per_s": pairs / t_mine, "seconds": t_mine, "host_threads": 1}
         ref_bin = os.path.join(ROOT, "oracle", "_ref", "fastq-extractor")
         if os.path.exists(ref_bin):
-            cores = min(8, os.cpu_count() or 1)
+            cores = min(8, host_cores())
             t0 = time.perf_counter()
             subprocess.run([ref_bin, "-t", str(cores)] + argv + ["-o", os.path.join(tmp, "ref")], check=True, stderr=subprocess.DEVNULL)
             t_ref = time.perf_counter() - t0
             out.update({"reference_pairs_per_s": pairs / t_ref, "reference_seconds": t_ref, "reference_threads": cores,
                         "identical": all(filecmp.cmp(os.path.join(tmp, "ref" + x), os.path.join(tmp, "mine" + x), shallow=False) for x in ("_1.fq", "_2.fq"))})
         return out
+    except Exception as e:   # noqa: BLE001
+        return {"error": repr(e)[:300]}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -184,27 +227,28 @@ def stage0_e2e(pairs, receptor_fraction=0.02):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=1000000, help="read pairs per GPU per step (C2 = 1M)")
-    ap.add_argument("--clones", type=int, default=20000)
-    ap.add_argument("--cpu-sample", type=int, default=100000, help="reads timed on the CPU baseline (0 = skip)")
-    ap.add_argument("--e2e-pairs", type=int, default=100000, help="pairs of the whole-stage-1 leg (0 = skip)")
+    ap.add_argument("--pairs", type=int, default=100000, help="read pairs per GPU per step (C2 = 1000000)")
+    ap.add_argument("--clones", type=int, default=0, help="clones of the batch (default: pairs / 50, the C2 ratio)")
+    ap.add_argument("--threads", type=int, default=8, help="host threads of trust4-hip (-t)")
+    ap.add_argument("--cpu-baseline", type=int, default=1, help="0 = skip the reference legs")
+    ap.add_argument("--cpu-single-pairs", type=int, default=20000, help="prefix timed with the reference's -t 1 (0 = skip)")
+    ap.add_argument("--side-legs", type=int, default=1, help="0 = skip passes.rough_annotation_c2 / stage1_cells / stage0_e2e")
     args = ap.parse_args()
+    clones = args.clones if args.clones > 0 else max(1, args.pairs // 50)
 
     import torch
-    import trust4_amd
     import trust4_amd.build
-    import t4libs
-
     import trust4_amd.dist as t4dist
+    import t4libs
     rank, local_rank, world = t4dist.env_rank()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the measured path")
     torch.cuda.set_device(local_rank)
-    dist = t4dist.init("nccl")   # RCCL; used for the barrier + max-reduce only (no data-path collective)
+    dist = t4dist.init("nccl")   # RCCL; used for the barrier + max-reduce only (bulk stage 1: replicas, no data-path collective)
 
     if rank == 0:
         trust4_amd.build.build()
@@ -212,80 +256,75 @@ def main():
     if dist:
         dist.barrier()
 
-    eng = trust4_amd.Engine(local_rank)
-    ref = eng.index(9).set_params(17, 10, 0.9).load_ref_fasta(t4libs.REF_FA).commit()
-    # synthetic batch of this rank (seed 1 on rank 0 == config C2), resident in HBM
-    synth = t4libs.Synth(args.clones, t4dist.shard_seed(1, rank))
-    reads = synth.next_reads(args.pairs)  # [2*pairs, 151] uint8, mates interleaved
-    n_reads = reads.shape[0]
-    batch = eng.upload(reads)
+    tmp = tempfile.mkdtemp(prefix="t4bench%d_" % rank)
+    try:
+        fa, f1, f2 = make_batch(tmp, args.pairs, clones, t4dist.shard_seed(1, rank))
+        threads = max(1, min(args.threads, host_cores() // max(1, world)))
+        mine = os.path.join(tmp, "mine")
+        stats_path = os.path.join(tmp, "stats.json")
 
-    def step():
-        ref.annotate_rough(batch, fetch=False)
+        def sync_all():
+            torch.cuda.synchronize()
+            if dist:
+                dist.barrier()
 
-    def sync_all():
-        eng.check(eng.lib.t4_sync(eng.h))
-        torch.cuda.synchronize()
-        if dist:
-            dist.barrier()
+        for _ in range(args.warmup):
+            run_stage1(fa, f1, f2, mine, threads, local_rank)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run_stage1(fa, f1, f2, mine, threads, local_rank, stats=stats_path)
+        sync_all()
+        dt = time.perf_counter() - t0
+        dt = t4dist.max_over_ranks(dist, dt, "cuda")
 
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    t0 = time.perf_counter()
-    kernel_ms = []
-    hits = 0
-    for _ in range(args.steps):
-        step()
-        st = eng.stats()
-        kernel_ms.append(st["chain_kernel_ms"])
-        hits = st["total_hits"]
-    sync_all()
-    dt = time.perf_counter() - t0
-    dt = t4dist.max_over_ranks(dist, dt, "cuda")
-    total_hits_all = t4dist.sum_over_ranks(dist, float(hits), "cuda")
-
-    if rank == 0:
-        total_reads = n_reads * world * args.steps
-        st = eng.stats()
-        # dominant kernels = the per-tier probe->sort->chain->score launches, event-timed on the engine's stream
-        k_ms = float(np.mean(kernel_ms))
-        alg = algorithmic_bytes(n_reads, 150, hits)
-        achieved = alg / (k_ms * 1e-3) / 1e9
-        out = {
-            "metric": "stage-1 assembly reads/sec (150 bp PE)",
-            "value": total_reads / dt,
-            "unit": "reads/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32/u64", "data": "synthetic",
-            "config": {"workload": "C2: %d synthetic 150 bp PE pairs per GPU (%d reads), %d clones, seed 1+rank, -f hg38_bcrtcr.fa, k=9; "
-                                   "pass = stage-1 rough annotation of every read (seed->sort->chain->score->V/J/C select); "
-                                   "AddRead loop not included (see stage1_e2e)" % (args.pairs, n_reads, args.clones),
-                       "pairs_per_gpu": args.pairs, "reads_per_gpu": n_reads, "hits_per_read": hits / n_reads, "hits_all_ranks": total_hits_all,
-                       "tier_reads": st["tier_reads"], "sharding": "reads sharded by rank, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.pairs),
-                         "kernel": "t4k::queryKernel (all tiers of one pass)", "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_launch": alg},
-        }
-        if args.cpu_sample > 0 and world == 1:   # CPU legs on rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(reads, args.cpu_sample)
-        if args.e2e_pairs > 0 and world == 1:
-            try:   # what the dynamic distribution of reads over the persistent grid buys: the same pass with the static stride
-                os.environ["T4_STATIC_STRIDE"] = "1"
-                step()
-                eng.check(eng.lib.t4_sync(eng.h))
-                out["scheduling_ab"] = {"static_stride_kernel_ms": eng.stats()["chain_kernel_ms"], "dynamic_kernel_ms": k_ms}
-            except Exception as e:   # noqa: BLE001
-                out["scheduling_ab"] = {"error": repr(e)[:300]}
-            finally:
-                os.environ.pop("T4_STATIC_STRIDE", None)
-            out["kmer_count"] = kmer_count_leg(eng, batch, n_reads)
-            out["stage1_e2e"] = stage1_e2e(args.e2e_pairs, max(1, args.e2e_pairs // 100))
-            out["stage0_e2e"] = stage0_e2e(4 * args.e2e_pairs)
-        print(json.dumps(out))
+        if rank == 0:
+            st = json.load(open(stats_path))
+            ph = st["phases_s"]
+            aq, ra = st["add_query"], st["rough_annotation"]
+            n_reads = 2 * args.pairs
+            # the dominant kernel of the step: the AddRead query kernel (t4k::queryKernel<.., 1>, mode 4), all its launches
+            # of one step; HIP-event time on the engine's stream, H from the engine's hit counter
+            alg_add = add_bytes(aq["reads_queried"], 150, aq["hits"])
+            alg_ann = annotate_bytes(ra["reads"], 150, ra["hits"])
+            ach_add = alg_add / (aq["kernel_ms"] * 1e-3) / 1e9
+            out = {
+                "metric": "stage-1 assembly read pairs/sec (150 bp PE), whole stage 1",
+                "value": args.pairs * world * args.steps / dt,
+                "unit": "pairs/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": dt / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "int32/u64", "data": "synthetic",
+                "config": {"workload": "C2 recipe%s: %d synthetic 150 bp PE pairs per GPU (%d clones, seed 1+rank), -f hg38_bcrtcr.fa, k=9, bulk mode; one step = "
+                                       "whole stage 1 through trust4-hip -t %d --skipMateExtension, FASTQ files in -> _raw.out / _assembled_reads.fa / _final.out out, "
+                                       "process start to exit" % (" (config C2 itself)" if args.pairs == 1000000 else " at %g of C2's size" % (args.pairs / 1e6), args.pairs, clones, threads),
+                           "pairs_per_gpu": args.pairs, "host_threads": threads, "contigs": st["contigs"], "assembled_reads": st["assembled_reads"],
+                           "sharding": "replicas: every rank assembles its own batch on its own GPU, no collective (bulk-mode AddRead is one ordered chain)",
+                           "phases_s": {"parse_processread_21mers": ph["input_processed_counted"], "sort": ph["sorted"] - ph["input_processed_counted"],
+                                        "rough_annotation": ph["rough_annotation"] - ph["sorted"], "trim": ph["trimmed_ready"] - ph["rough_annotation"],
+                                        "addread_pass": ph["assembled"] - ph["trimmed_ready"], "outputs": ph["outputs_written"] - ph["assembled"]}},
+                "roofline": {"bound": "hbm", "achieved": ach_add, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_add / HBM_PEAK_GBS, "traffic": None,
+                             "kernel": "t4k::queryKernel<.., 1> mode 4 (AddRead query: seed->sort->chain->score->ExtendOverlap), all %d query rounds of one step" % aq["rounds"],
+                             "kernel_ms": aq["kernel_ms"], "launch_ms_avg": aq["kernel_ms"] / max(1, aq["rounds"]),
+                             "algorithmic_bytes_per_step": alg_add, "reads_queried": aq["reads_queried"], "reads_served": aq["reads_served"],
+                             "hits": aq["hits"], "note": "a latency-bound chain of small launches (DESIGN 5b): bytes / kernel time says how little of the HBM rate a dependent round can use"},
+                "passes": {"add_query": aq,
+                           "rough_annotation_in_step": {"reads": ra["reads"], "hits": ra["hits"], "kernel_ms": ra["kernel_ms"],
+                                                        "achieved_GBs": alg_ann / (max(ra["kernel_ms"], 1e-6) * 1e-3) / 1e9}},
+            }
+            if args.cpu_baseline and world == 1 and os.path.exists(REF_BIN):
+                out["cpu_baseline"], out["parity_on_bench_batch"] = cpu_baseline(tmp, fa, f1, f2, args.pairs, mine, args.cpu_single_pairs)
+            if args.side_legs and world == 1:
+                try:
+                    out["passes"]["rough_annotation_c2"] = annotate_pass_c2(local_rank, 1000000, 20000, 3)
+                except Exception as e:   # noqa: BLE001
+                    out["passes"]["rough_annotation_c2"] = {"error": repr(e)[:300]}
+                out["stage1_cells"] = stage1_cells(100000, 1000)
+                out["stage0_e2e"] = stage0_e2e(400000)
+            print(json.dumps(out))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -212,10 +212,12 @@ int t4_assembler_prefetch(t4_assembler *a, int n, const char *const *reads, cons
 int t4_assembler_window_valid(const t4_assembler *a);
 /* Host threads that derive the window's dependency sets while the GPU runs a query batch (default 1). */
 int t4_assembler_set_threads(t4_assembler *a, int host_threads);
-/* Counters of a set whose index is not keyed by barcode (device image by deltas, sliding window), up to 16 values:
+/* Counters of a set whose index is not keyed by barcode (device image by deltas, sliding window), up to 23 values:
  * query rounds, reads queried, deltas, delta bytes, invalidations (total; by an index change of one of the read's keys; by a
  * list crossing 100 postings; by a changed region within reach; by a left extension; by a whole-contig change; by exhausted
- * tolerance), tolerated index changes, microseconds in deltas / dependency sets / event examination / query batches. */
+ * tolerance), tolerated index changes, microseconds in deltas / dependency sets / event examination / query batches; then of
+ * the ctx's AddRead query path: calls, reads, launches of the global-scratch tier, reads it served, result records,
+ * microseconds of its kernels (HIP events), _hit records its seed stages emitted. */
 int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n);
 int t4_assembler_counters(const t4_assembler *a, int64_t *queries, int64_t *refreshes, int64_t *window_hits);
 /* host seconds spent refreshing the device image / in GPU query batches (upload + kernels + download) */
@@ -311,6 +313,9 @@ typedef struct {
   int64_t launches;       /* kernel launches in the call */
 } t4_stats;
 int t4_last_stats(t4_ctx *ctx, t4_stats *out);
+/* Development aid: libraries built with -DT4_PHASE_TIMING count cycles per kernel phase (dumped by t4_destroy under
+ * T4_PHASE_DUMP=1); this forgets what was counted so far. A no-op in the product build. */
+int t4_debug_phase_reset(void);
 
 #ifdef __cplusplus
 }

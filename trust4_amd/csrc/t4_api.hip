@@ -12,6 +12,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <string>
@@ -54,6 +55,8 @@ struct HostSeq {
 struct t4_ctx {
   int device = 0, cus = 0;
   hipStream_t stream = 0;
+  hipStream_t stream2 = 0;   // AddRead queries: reads known to need the global-scratch tier run beside the LDS tier
+  hipEvent_t evIn = 0, evG = 0;
   hipEvent_t ev[4] = {0, 0, 0, 0};
   std::string err;
   t4_stats stats;
@@ -81,6 +84,10 @@ struct t4_ctx {
   size_t aqInBytes = 0, aqOutBytes = 0;
   unsigned char *aqPool = nullptr, *aqPoolDev = nullptr;   // result records of t4_add_query*: pinned host memory the kernels write
   int aqPoolCap = 0;
+  int64_t aqCalls = 0, aqReads = 0, aqGlobalLaunches = 0, aqGlobalReads = 0, aqRecords = 0;
+  double aqSecPack = 0, aqSecFirst = 0, aqSecGlobal = 0;
+  double aqKernelMs = 0;    // HIP-event time of the query kernels of all AddRead query calls (per call: first launch .. last kernel)
+  int64_t aqHits = 0;       // _hit records their seed stages emitted (H of SURVEY 8d)
 };
 
 struct t4_index {
@@ -218,6 +225,17 @@ int t4_init(int device_ordinal, t4_ctx **out) {
 void t4_destroy(t4_ctx *c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+#ifdef T4_PHASE_TIMING
+  if (getenv("T4_PHASE_DUMP")) {   // development aid: cycles per kernel phase over the life of the ctx
+    unsigned long long ph[T4_NPHASE];
+    if (hipMemcpyFromSymbol(ph, HIP_SYMBOL(t4k::g_phaseCycles), sizeof(ph)) == hipSuccess) {
+      static const char *names[T4_NPHASE] = {"other", "seed", "expand", "sort", "stats", "runs", "bigsort", "chain", "ovsort", "score", "prefilter", "final", "annotate", "score:quick", "score:banded", "score:finish", "extend", "after-extend", "-", "-"};
+      unsigned long long tot = 0;
+      for (int i = 0; i < T4_NPHASE; ++i) tot += ph[i];
+      for (int i = 0; i < T4_NPHASE; ++i) if (ph[i]) fprintf(stderr, "phase %-13s %6.2f%%  %.3e cycles\n", names[i], 100.0 * (double)ph[i] / (double)tot, (double)ph[i]);
+    }
+  }
+#endif
   void *ptrs[] = {c->dpRows, c->dpDir, c->gKeys, c->gPairs, c->gCand, c->gOv, c->gFin, c->gOrd, c->hitsKeys, c->lists,
                   c->listCounts, c->status, c->counts, c->hitCounter, c->result, c->aqIn, c->aqOut};
   if (c->aqInHost) (void)hipHostFree(c->aqInHost);
@@ -226,6 +244,9 @@ void t4_destroy(t4_ctx *c) {
   for (void *p : ptrs) if (p) (void)hipFree(p);
   for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->stream2) (void)hipStreamDestroy(c->stream2);
+  if (c->evIn) (void)hipEventDestroy(c->evIn);
+  if (c->evG) (void)hipEventDestroy(c->evG);
   delete c;
 }
 
@@ -251,6 +272,14 @@ int t4_debug_counters(unsigned long long *out8) {
   return T4_OK;
 }
 #endif
+// development aid (T4_PHASE_TIMING builds): forget the phase cycles counted so far; a no-op otherwise
+int t4_debug_phase_reset(void) {
+#ifdef T4_PHASE_TIMING
+  unsigned long long zero[T4_NPHASE] = {0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(t4k::g_phaseCycles), zero, sizeof(zero)) != hipSuccess) return T4_ERR_HIP;
+#endif
+  return T4_OK;
+}
 int t4_last_stats(t4_ctx *c, t4_stats *out) {
   if (!c || !out) return T4_ERR_ARG;
   *out = c->stats;
@@ -1181,8 +1210,11 @@ namespace {
 // (per-barcode images: reads meet a handful of contigs, so the first launch is the 1024-hit tier at 6 groups / CU).
 // On return counts[i] records of read i start at index base[i] of ov / ext / ret (valid until the next call on this ctx).
 struct AqResult { const int32_t *counts, *base; const t4_overlap *ov, *ext; const int32_t *ret; };
+// tierHint (nullable, in/out): nonzero = the read is known to outgrow the LDS tiers, it is launched on the global-scratch tier
+// at once, on a second stream beside the LDS tier; on return nonzero for every read the global-scratch tier served.
 int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const int32_t *viewOf, bool smallFirst, int n, const char *bases,
-                 const int64_t *offsets, const int32_t *barcodes, const int32_t *strands, int skip_repeats, const double *factors, AqResult *res) {
+                 const int64_t *offsets, const int32_t *barcodes, const int32_t *strands, int skip_repeats, const double *factors, AqResult *res,
+                 unsigned char *tierHint = nullptr) {
   (void)hipSetDevice(c->device);
   int maxLen = 1;
   for (int i = 0; i < n; ++i) {
@@ -1217,6 +1249,9 @@ int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
     HIPCHK(c, hipHostMalloc(&c->aqOutHost, outBytes * 2, hipHostMallocDefault));
     c->aqOutBytes = outBytes * 2;
   }
+  auto tNow = [] { return std::chrono::steady_clock::now(); };
+  auto tSince = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+  auto tp0 = tNow();
   unsigned char *h = c->aqInHost;
   memset(h, 0, inBytes);
   unsigned *pk = (unsigned *)(h + oPk), *nm = (unsigned *)(h + oNm);
@@ -1225,7 +1260,7 @@ int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
   for (int i = 0; i < n; ++i) {
     const char *s = bases + offsets[i];
     int l = (int)(offsets[i + 1] - offsets[i]);
-    len[i] = l; bc[i] = barcodes ? barcodes[i] : -1; st[i] = strands[i]; ls[i] = i; fa[i] = factors[i]; vw[i] = viewOf ? viewOf[i] : 0;
+    len[i] = l; bc[i] = barcodes ? barcodes[i] : -1; st[i] = strands[i]; fa[i] = factors[i]; vw[i] = viewOf ? viewOf[i] : 0;
     unsigned *p = pk + (size_t)i * wpk, *q = nm + (size_t)i * wnm;
     for (int j = 0; j < l; ++j) {
       int v = nucNum(s[j]);
@@ -1236,6 +1271,14 @@ int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
       p[j >> 4] |= (unsigned)v << ((j & 15) * 2);
     }
   }
+  // work lists: the reads of the first LDS launch, then those that go to the global-scratch tier at once
+  static const bool forceGlobal = getenv("T4_AQ_FORCE_GLOBAL") != nullptr;   // testing aid: every read on the global-scratch tier
+  std::vector<unsigned char> allGlobal;
+  if (forceGlobal && !smallFirst) { allGlobal.assign((size_t)n, 1); tierHint = allGlobal.data(); }
+  int nFirst = 0, nDirect = 0;
+  for (int i = 0; i < n; ++i) if (!(tierHint && tierHint[i] && !smallFirst)) ls[nFirst++] = i;
+  for (int i = 0; i < n; ++i) if (tierHint && tierHint[i] && !smallFirst) ls[nFirst + nDirect++] = i;
+  c->aqSecPack += tSince(tp0);
   for (int attempt = 0;; ++attempt) {
     if (!c->aqPool) {
       if (!c->aqPoolCap) c->aqPoolCap = 1 << 16;
@@ -1244,6 +1287,7 @@ int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
       HIPCHK(c, hipHostGetDevicePointer((void **)&c->aqPoolDev, c->aqPool, 0));
     }
     const size_t rec = (size_t)c->aqPoolCap;
+    auto tf0 = tNow();
     HIPCHK(c, hipMemcpyAsync(c->aqIn, h, inBytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->aqOut, 0, outBytes, c->stream));   // counts, status, overflow lists, bases, tail
     T4BatchView bv;
@@ -1258,34 +1302,68 @@ int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
     qa.strandPerRead = (const int *)(c->aqIn + oSt); qa.factorPerRead = (const double *)(c->aqIn + oFa);
     if (views) { qa.views = views; qa.viewOf = (const int *)(c->aqIn + oVw); }
     const int threads = 256;
-    const int grid0 = smallFirst ? (n < c->cus * TIER_BLOCKS_PER_CU[0] ? n : c->cus * TIER_BLOCKS_PER_CU[0]) : n;
-    if ((r = ensureScratch(c, (grid0 > c->cus * 2 ? grid0 : c->cus * 2) * threads))) return r;
+    const int grid0 = smallFirst ? (n < c->cus * TIER_BLOCKS_PER_CU[0] ? n : c->cus * TIER_BLOCKS_PER_CU[0]) : (nFirst > 0 ? nFirst : 1);
+    // scratch of the fallback DPs: the blocks of the LDS launch first, those of a concurrent global-tier launch behind them
+    if ((r = ensureScratch(c, (grid0 > c->cus * 2 ? grid0 : c->cus * 2) * threads + nDirect * G_THREADS))) return r;
     T4Work wk;
     memset(&wk, 0, sizeof wk);
-    wk.list = (const int *)(c->aqIn + oLs); wk.nList = n;
+    wk.list = (const int *)(c->aqIn + oLs); wk.nList = nFirst;
     wk.nextList = (int *)(c->aqOut + pNext); wk.nextCount = (int *)(c->aqOut + pTail);
     wk.status = (int *)(c->aqOut + pSta); wk.hitCounter = (unsigned long long *)(c->aqOut + pTail + 16);
     wk.dpRows = c->dpRows; wk.dpDir = c->dpDir;
-    if (smallFirst) launchTier<1024, 128, 256>(grid0, c->stream, base, bv, wk, qa);
-    else launchTier<8192, 512, 256>(grid0, c->stream, base, bv, wk, qa);
-    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    if (nDirect > 0) {   // beside the LDS tier, on the second stream (its own blocks of the DP scratch)
+      if (!c->stream2) { HIPCHK(c, hipStreamCreate(&c->stream2)); HIPCHK(c, hipEventCreate(&c->evIn)); HIPCHK(c, hipEventCreate(&c->evG)); }
+      if ((r = ensureGlobalTier(c, nDirect))) return r;
+      HIPCHK(c, hipEventRecord(c->evIn, c->stream));
+      HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evIn, 0));
+      T4Work wd = wk;
+      wd.list = (const int *)(c->aqIn + oLs) + nFirst; wd.nList = nDirect; wd.nextList = nullptr; wd.nextCount = nullptr;
+      wd.gKeys = c->gKeys; wd.gPairs = c->gPairs; wd.gCand = c->gCand; wd.gOv = c->gOv; wd.gFin = c->gFin; wd.gOrd = c->gOrd;
+      wd.gCap = G_CAP; wd.gMaxOv = G_MAXOV;
+      wd.dpRows = c->dpRows + (size_t)((grid0 > c->cus * 2 ? grid0 : c->cus * 2) * threads / 64) * (6 * T4_ROWW * 64);
+      wd.dpDir = c->dpDir + (size_t)(grid0 > c->cus * 2 ? grid0 : c->cus * 2) * threads * T4_DIR_BYTES;
+      launchTier<0, 0, G_THREADS>(nDirect, c->stream2, base, bv, wd, qa);
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipEventRecord(c->evG, c->stream2));
+      ++c->aqGlobalLaunches; c->aqGlobalReads += nDirect;
+    }
+    if (nFirst > 0) {
+      if (smallFirst) launchTier<1024, 128, 256>(grid0, c->stream, base, bv, wk, qa);
+      else launchTier<8192, 512, 256>(grid0, c->stream, base, bv, wk, qa);
+      HIPCHK(c, hipGetLastError());
+    }
+    if (nDirect > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->evG, 0));
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipMemcpyAsync(c->aqOutHost, c->aqOut, outBytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    { float ms = 0; if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->aqKernelMs += ms; }
     int overflow = *(int *)(c->aqOutHost + pTail);
+    c->aqSecFirst += tSince(tf0);
+    auto tg0 = tNow();
     if (overflow > 0 && smallFirst) {   // reads beyond the 1024-hit tier: 8192-hit LDS tier
       T4Work w1 = wk;
       w1.list = (const int *)(c->aqOut + pNext); w1.nList = overflow;
       w1.nextList = (int *)(c->aqOut + pNext2); w1.nextCount = (int *)(c->aqOut + pTail + 8);
       if ((r = ensureScratch(c, (overflow > c->cus * 2 ? overflow : c->cus * 2) * threads))) return r;
       w1.dpRows = c->dpRows; w1.dpDir = c->dpDir;
+      HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
       launchTier<8192, 512, 256>(overflow, c->stream, base, bv, w1, qa);
       HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
       HIPCHK(c, hipMemcpyAsync(c->aqOutHost, c->aqOut, outBytes, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
+      { float ms = 0; if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->aqKernelMs += ms; }
       overflow = *(int *)(c->aqOutHost + pTail + 8);
       wk.nextList = (int *)(c->aqOut + pNext2);
     }
+    ++c->aqCalls; c->aqReads += n;
+    if (overflow > 0 && tierHint) {   // remembered by the caller for the next query of these reads
+      const int *lst = (const int *)(c->aqOutHost + (wk.nextList == (int *)(c->aqOut + pNext2) ? pNext2 : pNext));
+      for (int t = 0; t < overflow; ++t) tierHint[lst[t]] = 1;
+    }
     if (overflow > 0) {   // reads beyond the LDS tiers: global-scratch tier
+      ++c->aqGlobalLaunches; c->aqGlobalReads += overflow;
       if ((r = ensureGlobalTier(c, overflow))) return r;
       if ((r = ensureScratch(c, (overflow > c->cus * 2 ? overflow : c->cus * 2) * G_THREADS))) return r;
       T4Work w2 = wk;
@@ -1293,11 +1371,15 @@ int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
       w2.gKeys = c->gKeys; w2.gPairs = c->gPairs; w2.gCand = c->gCand; w2.gOv = c->gOv; w2.gFin = c->gFin; w2.gOrd = c->gOrd;
       w2.gCap = G_CAP; w2.gMaxOv = G_MAXOV;
       w2.dpRows = c->dpRows; w2.dpDir = c->dpDir;
+      HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
       launchTier<0, 0, G_THREADS>(overflow, c->stream, base, bv, w2, qa);
       HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
       HIPCHK(c, hipMemcpyAsync(c->aqOutHost, c->aqOut, outBytes, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
+      { float ms = 0; if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->aqKernelMs += ms; }
     }
+    c->aqSecGlobal += tSince(tg0);
     const unsigned char *o = c->aqOutHost;
     const int *status = (const int *)(o + pSta);
     bool poolFull = false;
@@ -1312,6 +1394,8 @@ int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
       c->aqPool = nullptr; c->aqPoolDev = nullptr; c->aqPoolCap *= 4;
       continue;
     }
+    c->aqRecords += *(const unsigned *)(o + pTail + 24);
+    c->aqHits += (int64_t) * (const unsigned long long *)(o + pTail + 16);
     res->counts = (const int32_t *)(o + pCnt); res->base = (const int32_t *)(o + pBase);
     res->ov = (const t4_overlap *)c->aqPool; res->ext = res->ov + rec; res->ret = (const int32_t *)(res->ext + rec);
     return T4_OK;
@@ -1341,15 +1425,23 @@ int addQueryImpl(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
 
 extern "C" {
 
+int t4_add_query_stats(t4_ctx *c, int64_t *out5) {   // 7 values
+  if (!c || !out5) return T4_ERR_ARG;
+  out5[0] = c->aqCalls; out5[1] = c->aqReads; out5[2] = c->aqGlobalLaunches; out5[3] = c->aqGlobalReads; out5[4] = c->aqRecords;
+  out5[5] = (int64_t)(c->aqKernelMs * 1e3); out5[6] = c->aqHits;
+  if (getenv("T4_TIMING")) fprintf(stderr, "timing: AddRead query path host seconds: pack %.3f, first launch to sync %.3f, overflow tiers %.3f\n", c->aqSecPack, c->aqSecFirst, c->aqSecGlobal);
+  return T4_OK;
+}
+
 int t4_add_query_pool(t4_index *ix, int n, const char *bases, const int64_t *offsets, const int32_t *barcodes, const int32_t *strands,
                       int skip_repeats, const double *factors, const int32_t **counts, const int32_t **base, const t4_overlap **ov,
-                      const t4_overlap **ext, const int32_t **ext_ret) {
+                      const t4_overlap **ext, const int32_t **ext_ret, unsigned char *tier_hint) {
   if (!ix || n <= 0 || !bases || !offsets || !strands || !factors || !counts || !base || !ov || !ext || !ext_ret) return T4_ERR_ARG;
   t4_ctx *c = ix->ctx;
   if (!ix->committed) return fail(c, T4_ERR_STATE, "index not committed");
   if (ix->view.firstIsRef) return fail(c, T4_ERR_UNSUPPORTED, "t4_add_query needs a contig set");
   AqResult res;
-  int r = addQueryPool(c, ix->view, nullptr, nullptr, false, n, bases, offsets, barcodes, strands, skip_repeats, factors, &res);
+  int r = addQueryPool(c, ix->view, nullptr, nullptr, false, n, bases, offsets, barcodes, strands, skip_repeats, factors, &res, tier_hint);
   if (r) return r;
   *counts = res.counts; *base = res.base; *ov = res.ov; *ext = res.ext; *ext_ret = res.ret;
   return T4_OK;

@@ -19,7 +19,10 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <deque>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <map>
 #include <memory>
@@ -164,8 +167,11 @@ struct HostIndex {
       }
     if (l.cnt == 0 && !mirror) { garbage += l.cap; map.erase(it); }   // a live set keeps the key (its table slot) with an empty list
   }
+  double secOps = 0;   // seconds in build / update / removeSeq (live sets report it)
+  struct OpTimer { double &acc; std::chrono::steady_clock::time_point t0; explicit OpTimer(double &a) : acc(a), t0(std::chrono::steady_clock::now()) {} ~OpTimer() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } };
   void build(const char *s, int len, int id, int barcode, int shift = 0) {  // BuildIndexFromRead
     if (len < k) return;
+    OpTimer tm_(secOps);
     KCode kc(k), prev(k);
     int i;
     for (i = 0; i < k - 1; ++i) kc.append(s[i]);
@@ -177,6 +183,7 @@ struct HostIndex {
   }
   void update(const char *s, int len, int barcode, int shift, int oldId, int id) {  // UpdateIndexFromRead
     if (len < k) return;
+    OpTimer tm_(secOps);
     KCode kc(k);
     int i;
     for (i = 0; i < k - 1; ++i) kc.append(s[i]);
@@ -199,6 +206,7 @@ struct HostIndex {
   }
   void removeSeq(const char *s, int len, int id, int barcode, int offset) {  // RemoveIndexFromRead
     if (len < k) return;
+    OpTimer tm_(secOps);
     KCode kc(k);
     int i;
     for (i = 0; i < k - 1; ++i) kc.append(s[i]);
@@ -340,6 +348,44 @@ struct GroupTable {
   }
 };
 
+// Host threads that help the caller with one job at a time (the dependency sets of a query round are derived while the GPU
+// runs the query): started once, parked on a condition variable in between.
+struct HelperPool {
+  std::mutex mu;
+  std::condition_variable cvJob, cvDone;
+  std::vector<std::thread> th;
+  const std::function<void()> *job = nullptr;
+  long long gen = 0;
+  int wanted = 0, running = 0;
+  bool quit = false;
+  ~HelperPool() {
+    { std::lock_guard<std::mutex> lk(mu); quit = true; ++gen; }
+    cvJob.notify_all();
+    for (auto &t : th) t.join();
+  }
+  void worker(int rank) {
+    long long seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> lk(mu);
+      cvJob.wait(lk, [&] { return gen != seen; });
+      seen = gen;
+      if (quit) return;
+      if (rank >= wanted) continue;
+      const std::function<void()> *fn = job;
+      lk.unlock();
+      (*fn)();
+      lk.lock();
+      if (--running == 0) cvDone.notify_all();
+    }
+  }
+  void start(int n, const std::function<void()> &fn) {   // n helpers run fn; the caller goes on and calls wait() later
+    while ((int)th.size() < n) { const int rank = (int)th.size(); th.emplace_back([this, rank] { worker(rank); }); }
+    { std::lock_guard<std::mutex> lk(mu); job = &fn; wanted = n; running = n; ++gen; }
+    cvJob.notify_all();
+  }
+  void wait() { std::unique_lock<std::mutex> lk(mu); cvDone.wait(lk, [&] { return running == 0; }); }
+};
+
 struct t4_cellset;
 struct t4_assembler : IndexListener {
   t4_ctx *ctx;
@@ -365,6 +411,7 @@ struct t4_assembler : IndexListener {
     std::string read; int strand, barcode, skip; int32_t cnt; bool valid; std::vector<t4_overlap> ov, ext; std::vector<int32_t> extRet;
     // live sets
     int64_t uid = 0;
+    unsigned char tier = 0;      // the last query of this read ended on the global-scratch tier
     bool fragile = false;        // any change of one of its keys' lists invalidates it
     int slack = 0;               // tolerated hit-set changes left before possibleOverlapCnt could pass 100 (SeqSet.hpp:813-823)
     GroupTable groups;
@@ -376,9 +423,39 @@ struct t4_assembler : IndexListener {
   // window slides: entries stay valid across commits that cannot change their query (rules above)
   bool live() const { return !owner && !index.considerBarcode; }
   int threads = 1;
+  std::unique_ptr<HelperPool> helpers;
   int64_t nextUid = 1;
-  struct KOcc { int64_t uid; int slot; unsigned char f, r; };   // occurrences of a key in a window read, forward / reverse-complement
-  std::unordered_map<Key, std::vector<KOcc>, KeyHash> winKmers;
+  struct KOcc { int64_t uid; int slot; unsigned char f, r; int next; };   // occurrences of a key in a window read, forward / reverse-complement
+  // inverted map key -> window reads that hold it: open addressing on (code, bucket), chains of KOcc nodes; references of
+  // retired reads stay (their uid no longer matches) until the map is rebuilt
+  struct WinKmers {
+    struct Bucket { uint64_t code; int h; int head; };
+    std::vector<Bucket> tab;
+    std::vector<KOcc> nodes;
+    size_t used = 0;
+    void clear() { tab.clear(); nodes.clear(); used = 0; }
+    static size_t hashOf(uint64_t code, int h) { return (size_t)mix64h(code * 1000003ull + (uint64_t)(uint32_t)h); }
+    void grow() {
+      std::vector<Bucket> old; old.swap(tab);
+      tab.assign(old.empty() ? 4096 : old.size() * 2, Bucket{0, 0, -2});
+      for (const Bucket &b : old) if (b.head != -2) { size_t s = hashOf(b.code, b.h) & (tab.size() - 1); while (tab[s].head != -2) s = (s + 1) & (tab.size() - 1); tab[s] = b; }
+    }
+    void add(uint64_t code, int h, const KOcc &o) {
+      if (2 * (used + 1) > tab.size()) grow();
+      size_t s = hashOf(code, h) & (tab.size() - 1);
+      while (tab[s].head != -2 && !(tab[s].code == code && tab[s].h == h)) s = (s + 1) & (tab.size() - 1);
+      if (tab[s].head == -2) { tab[s].code = code; tab[s].h = h; tab[s].head = -1; ++used; }
+      nodes.push_back(o);
+      nodes.back().next = tab[s].head;
+      tab[s].head = (int)nodes.size() - 1;
+    }
+    int find(uint64_t code, int h) const {   // first node of the key's chain, -1 when none
+      if (tab.empty()) return -1;
+      size_t s = hashOf(code, h) & (tab.size() - 1);
+      while (tab[s].head != -2) { if (tab[s].code == code && tab[s].h == h) return tab[s].head; s = (s + 1) & (tab.size() - 1); }
+      return -1;
+    }
+  } winKmers;
   size_t winKmerRefs = 0, winKmerLive = 0;
   std::vector<Cached *> pool;      // window entries by slot (stable while the entry lives)
   std::vector<int> freeSlots;
@@ -392,7 +469,7 @@ struct t4_assembler : IndexListener {
   std::vector<int> dirtySeqs;
   bool liveReset = true;           // the next delta describes the whole image (first upload, k change)
   int64_t deltas = 0, deltaBytes = 0, rounds = 0, readsQueried = 0, invKey = 0, invCross = 0, invRegion = 0, invShift = 0, invContig = 0, invFragile = 0, tolerated = 0;
-  double secDelta = 0, secGroups = 0, secEvents = 0;
+  double secDelta = 0, secGroups = 0, secEvents = 0, secRegister = 0, secPrefetch = 0, secAddTotal = 0;
 
   t4_assembler(t4_ctx *c, int kl) : ctx(c), k(kl), index(kl) { prevAdd.readStart = -1; index.hook = this; }
   ~t4_assembler() { for (Cached *c : pool) delete c; }
@@ -1067,9 +1144,12 @@ int t4_assembler::flushLive() {
 
 // the read's keys (every valid k-mer of both strands) join the window's inverted map
 void t4_assembler::registerKmers(Cached &e, int slotId) {
+  auto t0_ = std::chrono::steady_clock::now();
+  struct Tm { double &acc; std::chrono::steady_clock::time_point t0; ~Tm() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tm_{secRegister, t0_};
   std::string rcs;
   reverseComplement(rcs, e.read);
-  std::unordered_map<Key, std::pair<int, int>, KeyHash> occ;
+  static thread_local std::vector<std::pair<uint64_t, int>> codes;   // (code, strand)
+  codes.clear();
   for (int st = 0; st < 2; ++st) {
     const std::string &r = st ? rcs : e.read;
     if ((int)r.size() < k) continue;
@@ -1077,13 +1157,17 @@ void t4_assembler::registerKmers(Cached &e, int slotId) {
     for (int i = 0; i < (int)r.size(); ++i) {
       kc.append(r[i]);
       if (i < k - 1 || !kc.valid()) continue;
-      auto &o = occ[Key{kc.code, index.bucket(kc.code, e.barcode)}];
-      if (st) ++o.second; else ++o.first;
+      codes.push_back({kc.code, st});
     }
   }
-  for (auto &kv : occ) {
-    winKmers[kv.first].push_back(KOcc{e.uid, slotId, (unsigned char)(kv.second.first > 255 ? 255 : kv.second.first), (unsigned char)(kv.second.second > 255 ? 255 : kv.second.second)});
+  std::sort(codes.begin(), codes.end());
+  for (size_t i = 0; i < codes.size();) {
+    size_t j = i;
+    int f = 0, r = 0;
+    while (j < codes.size() && codes[j].first == codes[i].first) { if (codes[j].second) ++r; else ++f; ++j; }
+    winKmers.add(codes[i].first, index.bucket(codes[i].first, e.barcode), KOcc{e.uid, slotId, (unsigned char)(f > 255 ? 255 : f), (unsigned char)(r > 255 ? 255 : r), -1});
     ++winKmerRefs;
+    i = j;
   }
   ++winKmerLive;
 }
@@ -1097,49 +1181,58 @@ void t4_assembler::buildGroups(Cached &e) {
   std::string rcs;
   reverseComplement(rcs, e.read);
   const int len = (int)e.read.size();
-  static thread_local std::vector<uint64_t> hits;
-  hits.clear();
+  // (contig, strand, start of the read on the contig) -> hits, in a scratch table of this thread (a list of 100+ postings
+  // brings thousands of hits that the kernel's repeat skipping drops: counting must not cost a sort)
+  struct Slot { uint64_t key; uint32_t cnt; };
+  static thread_local std::vector<Slot> tab;
+  static thread_local std::vector<uint32_t> usedSlots;
+  size_t nPost = 0;
   uint32_t maxList = 0;
-  for (int st = 0; st < 2; ++st) {
-    const std::string &r = st ? rcs : e.read;
-    if ((int)r.size() < k) continue;
-    const uint64_t plus = st ? 0u : 1u;
-    KCode kc(k);
-    for (int i = 0; i < (int)r.size(); ++i) {
-      kc.append(r[i]);
-      if (i < k - 1 || !kc.valid()) continue;
-      const ListRef *l = index.find(kc.code, index.bucket(kc.code, e.barcode));
-      if (!l) continue;
-      if (l->cnt > maxList) maxList = l->cnt;
-      const int a = i - k + 1;
-      for (uint32_t t = 0; t < l->cnt; ++t) {
-        const Post &p = index.arena[l->start + t];
-        hits.push_back((((uint64_t)(uint32_t)p.idx * 2u + plus) << 32) | (uint32_t)(p.offset - a + (1 << 30)));   // contig, strand, start of the read on the contig
+  for (int pass = 0; pass < 2; ++pass) {   // pass 0 sizes the table, pass 1 fills it
+    if (pass == 1) {
+      size_t sz = 1024;
+      while (sz < 2 * nPost + 2) sz <<= 1;
+      if (tab.size() < sz) tab.assign(sz, Slot{~0ull, 0});
+      usedSlots.clear();
+    }
+    const size_t mask = tab.size() - 1;
+    for (int st = 0; st < 2; ++st) {
+      const std::string &r = st ? rcs : e.read;
+      if ((int)r.size() < k) continue;
+      const uint64_t plus = st ? 0u : 1u;
+      KCode kc(k);
+      for (int i = 0; i < (int)r.size(); ++i) {
+        kc.append(r[i]);
+        if (i < k - 1 || !kc.valid()) continue;
+        const ListRef *l = index.find(kc.code, index.bucket(kc.code, e.barcode));
+        if (!l) continue;
+        if (pass == 0) { nPost += l->cnt; if (l->cnt > maxList) maxList = l->cnt; continue; }
+        const int a = i - k + 1;
+        for (uint32_t t = 0; t < l->cnt; ++t) {
+          const Post &p = index.arena[l->start + t];
+          const uint64_t key = (((uint64_t)(uint32_t)p.idx * 2u + plus) << 32) | (uint32_t)(p.offset - a + (1 << 30));
+          size_t s2 = (size_t)mix64h(key) & mask;
+          while (tab[s2].key != key && tab[s2].key != ~0ull) s2 = (s2 + 1) & mask;
+          if (tab[s2].key == ~0ull) { tab[s2].key = key; tab[s2].cnt = 0; usedSlots.push_back((uint32_t)s2); }
+          ++tab[s2].cnt;
+        }
       }
     }
   }
-  std::sort(hits.begin(), hits.end());
-  uint32_t nGroups = 0;
-  for (size_t i = 0; i < hits.size(); ++i) if (i == 0 || (hits[i] >> 32) != (hits[i - 1] >> 32)) ++nGroups;
-  e.groups.reset(nGroups);
+  e.groups.reset((uint32_t)(usedSlots.size() < 64 ? 64 : usedSlots.size()));
+  for (uint32_t s2 : usedSlots) {
+    const Slot &x = tab[s2];
+    Grp &g = e.groups.get((uint32_t)(x.key >> 32));
+    g.cnt += x.cnt;
+    if (x.cnt >= 3) {
+      const int at = (int)(uint32_t)x.key - (1 << 30);
+      if (at < g.lo) g.lo = at;
+      if (at + len - 1 > g.hi) g.hi = at + len - 1;
+    }
+  }
+  for (uint32_t s2 : usedSlots) tab[s2].key = ~0ull;   // leave the scratch table empty
   int u4 = 0;
-  for (size_t i = 0; i < hits.size();) {
-    size_t j = i;
-    Grp &g = e.groups.get((uint32_t)(hits[i] >> 32));
-    while (j < hits.size() && (hits[j] >> 32) == (hits[i] >> 32)) {
-      size_t d = j;
-      while (d < hits.size() && hits[d] == hits[j]) ++d;
-      if (d - j >= 3) {
-        const int at = (int)(uint32_t)hits[j] - (1 << 30);
-        if (at < g.lo) g.lo = at;
-        if (at + len - 1 > g.hi) g.hi = at + len - 1;
-      }
-      j = d;
-    }
-    g.cnt = (uint32_t)(j - i);
-    if (g.cnt >= 4) ++u4;
-    i = j;
-  }
+  for (const Grp &g : e.groups.t) if (g.key != 0xFFFFFFFFu && g.cnt >= 4) ++u4;
   // possibleOverlapCnt counts groups measured at more than 3 hits (SeqSet.hpp:784-810); while it cannot pass 100 the
   // group statistics of GetOverlapsFromHits leave novelMinHitRequired at 3 whatever small groups come and go
   e.slack = 99 - u4;
@@ -1208,14 +1301,15 @@ void t4_assembler::processEvents() {
     }
     for (const auto &kv : sizes) {
       if ((kv.second.first >= 100) == (kv.second.second >= 100)) continue;
-      auto it = winKmers.find(kv.first);
-      if (it == winKmers.end()) continue;
-      for (const KOcc &o : it->second) { Cached &e = *pool[o.slot]; if (e.uid == o.uid) kill(e, invCross); }
+      for (int nd = winKmers.find(kv.first.code, kv.first.h); nd >= 0; nd = winKmers.nodes[nd].next) {
+        const KOcc &o = winKmers.nodes[nd];
+        Cached &e = *pool[o.slot];
+        if (e.uid == o.uid) kill(e, invCross);
+      }
     }
     for (const IdxEv &ev : net) {
-      auto it = winKmers.find(Key{ev.code, ev.h});
-      if (it == winKmers.end()) continue;
-      for (const KOcc &o : it->second) {
+      for (int nd = winKmers.find(ev.code, ev.h); nd >= 0; nd = winKmers.nodes[nd].next) {
+        const KOcc &o = winKmers.nodes[nd];
         Cached &e = *pool[o.slot];
         if (e.uid != o.uid || !e.valid) continue;
         if (e.fragile) { kill(e, invFragile); continue; }
@@ -1244,6 +1338,8 @@ void t4_assembler::processEvents() {
 // Entries already in the window that still stand are kept; every other one is (re-)queried in ONE batch against the patched
 // device image. Returns with a valid head.
 int t4_assembler::prefetchLive(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive) {
+  auto tp0_ = std::chrono::steady_clock::now();
+  struct Tp { double &acc; std::chrono::steady_clock::time_point t0; ~Tp() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tp_{secPrefetch, tp0_};
   processEvents();
   // match the announced reads against the window; what does not line up is dropped
   size_t keep = 0;
@@ -1266,7 +1362,7 @@ int t4_assembler::prefetchLive(int n, const char *const *reads, const int *stran
     Cached &c = *pool[sl];
     c.read = reads[i]; c.strand = strands[i]; c.barcode = barcodes ? barcodes[i] : -1; c.skip = repetitive; c.cnt = 0; c.valid = false;
     c.ov.clear(); c.ext.clear(); c.extRet.clear();
-    c.uid = nextUid++;
+    c.uid = nextUid++; c.tier = 0;
     registerKmers(c, sl);
     order.push_back(sl);
   }
@@ -1300,16 +1396,17 @@ int t4_assembler::prefetchLive(int n, const char *const *reads, const int *stran
   if (bases.empty()) bases.push_back('A');
   // the hit groups of the queried reads come from the host replica of the index while the GPU runs the query
   std::atomic<int> nextG(0);
-  auto groupWorker = [&]() { for (;;) { int i = nextG.fetch_add(1); if (i >= m) break; buildGroups(*pool[todo[i]]); } };
-  std::vector<std::thread> helpers;
-  const int nHelp = m >= 4 ? (threads - 1 < m / 2 ? threads - 1 : m / 2) : 0;
-  for (int t = 0; t < nHelp; ++t) helpers.emplace_back(groupWorker);
+  const std::function<void()> groupWorker = [&]() { for (;;) { int i = nextG.fetch_add(1); if (i >= m) break; buildGroups(*pool[todo[i]]); } };
+  const int nHelp = m >= 2 ? (threads - 1 < m - 1 ? threads - 1 : m - 1) : 0;
+  if (nHelp > 0) { if (!helpers) helpers.reset(new HelperPool()); helpers->start(nHelp, groupWorker); }
   const int32_t *cnts = nullptr, *bas = nullptr, *rets = nullptr;
   const t4_overlap *ov = nullptr, *ex = nullptr;
-  rc = t4_add_query_pool(dev, m, bases.data(), offs.data(), bcs.data(), sts.data(), repetitive, fac.data(), &cnts, &bas, &ov, &ex, &rets);
+  std::vector<unsigned char> hint(m);
+  for (int i = 0; i < m; ++i) hint[i] = pool[todo[i]]->tier;
+  rc = t4_add_query_pool(dev, m, bases.data(), offs.data(), bcs.data(), sts.data(), repetitive, fac.data(), &cnts, &bas, &ov, &ex, &rets, hint.data());
   auto tg1 = std::chrono::steady_clock::now();
   groupWorker();
-  for (auto &th : helpers) th.join();
+  if (nHelp > 0) helpers->wait();
   secGroups += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg1).count();
   ++queries; ++rounds; readsQueried += m;
   if (rc) { dropWindow(); return rc; }
@@ -1320,7 +1417,7 @@ int t4_assembler::prefetchLive(int n, const char *const *reads, const int *stran
     c.ov.assign(ov + bas[i], ov + bas[i] + k2);
     c.ext.assign(ex + bas[i], ex + bas[i] + k2);
     c.extRet.assign(rets + bas[i], rets + bas[i] + k2);
-    c.valid = true;
+    c.valid = true; c.tier = hint[i];
   }
   return T4_OK;
 }
@@ -1475,8 +1572,10 @@ int t4_assembler_input_novel_read(t4_assembler *a, const char *id, const char *r
 int t4_assembler_add_read(t4_assembler *a, const char *read, const char *gene_name, int *strand, int barcode, int min_kmer_count,
                           int repetitive_data, double similarity_threshold) {
   if (!a || !read || !gene_name || !strand) return T4_ERR_ARG - 100;
+  auto t0 = std::chrono::steady_clock::now();
   const int r = a->addRead(read, gene_name, strand, barcode, min_kmer_count, repetitive_data != 0, similarity_threshold);
   a->processEvents();
+  a->secAddTotal += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return r;
 }
 int t4_assembler_prefetch(t4_assembler *a, int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive_data) {
@@ -1514,6 +1613,9 @@ int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n) {
   const int64_t v[16] = {a->rounds, a->readsQueried, a->deltas, a->deltaBytes, a->invalidations, a->invKey, a->invCross, a->invRegion, a->invShift,
                          a->invContig, a->invFragile, a->tolerated, (int64_t)(a->secDelta * 1e6), (int64_t)(a->secGroups * 1e6), (int64_t)(a->secEvents * 1e6), (int64_t)(a->secQuery * 1e6)};
   for (int i = 0; i < n && i < 16; ++i) out[i] = v[i];
+  if (n >= 23) t4_add_query_stats(a->ctx, out + 16);
+  if (getenv("T4_TIMING")) fprintf(stderr, "timing: assembler host seconds: add_read calls %.3f (incl. fallback queries), prefetch calls %.3f (of which query %.3f, deltas %.3f, registering k-mers %.3f), event examination %.3f, index edits %.3f\n",
+                                   a->secAddTotal, a->secPrefetch, a->secQuery, a->secDelta, a->secRegister, a->secEvents, a->index.secOps);
   return T4_OK;
 }
 int t4_assembler_output(t4_assembler *a, const char *path) { return a ? a->output(path) : T4_ERR_ARG; }

@@ -40,9 +40,14 @@ int64_t t4_cellstore_bytes_staged(const t4_cellstore *cs);
 
 // t4_add_query with variable-size results (a read may overlap thousands of contigs that share a gene segment): counts[i]
 // records of read i start at index base[i] of ov / ext / ext_ret, which point into pinned memory of the ctx that stays
-// valid until the next query on it.
+// valid until the next query on it. tier_hint (nullable, n bytes, in/out): nonzero = the read outgrew the LDS tiers the last
+// time it was queried, so it starts on the global-scratch tier, beside the launch of the others.
 int t4_add_query_pool(t4_index *ix, int n, const char *bases, const int64_t *offsets, const int32_t *barcodes, const int32_t *strands,
                       int skip_repeats, const double *factors, const int32_t **counts, const int32_t **base, const t4_overlap **ov,
-                      const t4_overlap **ext, const int32_t **ext_ret);
+                      const t4_overlap **ext, const int32_t **ext_ret, unsigned char *tier_hint);
+
+// AddRead query path of this ctx, 7 values: calls, reads, launches of the global-scratch tier, reads it served, result records,
+// microseconds of its kernels (HIP events on the ctx's stream), _hit records its seed stages emitted
+int t4_add_query_stats(t4_ctx *ctx, int64_t *out7);
 
 }  // extern "C"

@@ -2326,6 +2326,35 @@ __device__ void dpWaveTracePW(const T4PW *w, int L, const char *p, unsigned char
     }
   }
 }
+// The same DP for FOUR problems per wavefront, one per 16-lane DPP row (the band is 11 columns wide, so a whole wavefront per
+// problem left 53 lanes idle): every row has its own (w, L, p, dirbuf); Lmax = the longest L of the wavefront's rows
+// (wave-uniform trip count; a row with L == 0 computes nothing).
+__device__ void dpRowTracePW(const T4PW *w, int L, const char *p, unsigned char *dirbuf, int Lmax) {
+  const int d = laneId() & 15, W = 11, leftBand = 5;
+  const int negInf = (L + 1) * (L + 1) * (-4);
+  int M = negInf;
+  { int j0 = d - leftBand; if (d < W && j0 >= 0 && j0 <= L) M = j0 == 0 ? 0 : -4 - 4 * j0; }
+  const int lastStep = 2 * Lmax + W - 1;
+  for (int s = 2; s <= lastStep; ++s) {
+    int lM = rowUp1(M), uM = rowDown1(M);
+    const int i2 = s - d, i = i2 >> 1, j = i - leftBand + d;
+    if (d < W && (i2 & 1) == 0 && i >= 1 && i <= L && j >= 1 && j <= L) {
+      if (j == 1) lM = -4 - 4 * i; else if (d == 0) lM = negInf;
+      if (i == 1) uM = -4 - 4 * j; else if (d + 1 >= W) uM = negInf;
+      int dM;
+      if (i == 1) dM = (j - 1 == 0) ? 0 : -4 - 4 * (j - 1);
+      else if (j == 1) dM = -4 - 4 * (i - 1);
+      else dM = M;
+      const bool eq = baseEqualW(w[j - 1], p[i - 1]);
+      const int dsc = dM + (eq ? 2 : -2);
+      int m = dsc;
+      if (lM - 4 > m) m = lM - 4;
+      if (uM - 4 > m) m = uM - 4;
+      dirbuf[i * W + d] = (unsigned char)((lM - 4 == m ? 1 : 0) | (uM - 4 == m ? 2 : 0) | (dsc == m ? 4 : 0) | (eq ? 8 : 0));
+      M = m;
+    }
+  }
+}
 // traceback of the above (AlignAlgo.hpp:160-205); align[] receives the edit string, returns its length. One lane.
 __device__ int tracebackPW(const unsigned char *dirbuf, int L, signed char *align) {
   const int W = 11, leftBand = 5;
@@ -2381,28 +2410,89 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
     sides[q] = e;
   }
   __syncthreads();
-  // E2: gapped sides: compacted into a list (wm.cand is dead here), one wavefront per side with its own slice of the
-  // direction buffer; a side whose traceback does not fit a slice waits for the serial pass that owns the whole buffer
-  int nPendSides = 0;
-  for (int q0 = 0; q0 < 2 * n; q0 += NT) {
-    const int q = q0 + lane;
-    const bool pend = q < 2 * n && sides[q].pending;
-    int tot;
-    const int inc = blockInclScan(pend ? 1 : 0, ws->red, tot);
-    if (pend) wm.cand[nPendSides + inc - 1] = (unsigned)q;
-    nPendSides += tot;
+  // E2: gapped sides, compacted into a list (wm.cand is dead here): first those whose direction bytes fit a quarter of a
+  // wavefront's share of the buffer -- four per wavefront (one per 16-lane row), their tracebacks one lane per side -- then the
+  // longer ones, one wavefront per side with its own slice; a side that fits no slice waits for the serial pass that owns the
+  // whole buffer
+  const int nwE = NT >> 6, perChunk = nwE * 4;
+  const int qslice = ((wm.cap * 8) / perChunk) & ~15;
+  int nFit = 0, nPendSides = 0;
+  for (int part = 0; part < 2; ++part) {
+    for (int q0 = 0; q0 < 2 * n; q0 += NT) {
+      const int q = q0 + lane;
+      bool pend = q < 2 * n && sides[q].pending;
+      if (pend) { const int size = sides[q].size; const bool fitsQ = (size + 1) * 11 + 2 * size + 8 <= qslice; pend = (part == 0) == fitsQ; }
+      int tot;
+      const int inc = blockInclScan(pend ? 1 : 0, ws->red, tot);
+      if (pend) wm.cand[nPendSides + inc - 1] = (unsigned)q;
+      nPendSides += tot;
+    }
+    if (part == 0) nFit = nPendSides;
   }
   __syncthreads();
+  // finish one side from its edit string (any lane)
+  auto finishSide = [&](int q, const signed char *align, int alen) {
+    const int side = q & 1;
+    int m = 0, mm = 0, ind = 0, good = 0, tmp = 0;
+    for (int k = 0; k < alen; ++k) { if (align[k] == 0) ++m; else if (align[k] == 1) ++mm; else ++ind; }
+    if (side == 0) {
+      for (int i = alen - 1, k = 1; i >= 0; --i, ++k) {
+        if (align[i] == 0) { ++tmp; if (tmp > 0.75 * k) good = k; }
+        else if (align[i] != 1) break;
+      }
+    } else {
+      for (int i = 0; i < alen; ++i) {
+        if (align[i] == 0) { ++tmp; if (tmp > 0.75 * (i + 1)) good = i + 1; }
+        else if (align[i] != 1) break;
+      }
+    }
+    ExtSide e = sides[q];
+    e.match = (short)m; e.mis = (short)mm; e.indel = (short)ind; e.good = (short)good; e.pending = 0;
+    sides[q] = e;
+  };
+  {
+    const int wave = lane >> 6, wl = lane & 63, row = wl >> 4;
+    for (int c0 = 0; c0 < nFit; c0 += perChunk) {
+      const int t = c0 + wave * 4 + row;
+      int L = 0;
+      const T4PW *w = ix.pw;
+      const char *pr = wm.seg;
+      if (t < nFit) {
+        const int q = (int)wm.cand[t];
+        const OvRec &o = wm.fin[wm.ord[q >> 1]];
+        const int side = q & 1;
+        L = sides[q].size;
+        const T4SeqInfo si = ix.seqs[o.seqIdx];
+        const char *r = (useFirstStrand ? plus0 : (o.flags & OV_PLUS)) ? wm.seg : wm.rc;
+        w = ix.pw + si.pwOff + (side == 0 ? o.ss - L : o.se + 1);
+        pr = r + (side == 0 ? o.rs - L : o.re + 1);
+      }
+      int Lmax = L;
+      { int x = __shfl_xor(Lmax, 16); if (x > Lmax) Lmax = x; x = __shfl_xor(Lmax, 32); if (x > Lmax) Lmax = x; }
+      dpRowTracePW(w, L, pr, dirbuf + (size_t)(wave * 4 + row) * qslice, Lmax);
+      __syncthreads();
+      if (lane < perChunk && c0 + lane < nFit) {
+        const int q = (int)wm.cand[c0 + lane];
+        const int size = sides[q].size;
+        unsigned char *buf = dirbuf + (size_t)lane * qslice;
+        signed char *align = (signed char *)(buf + (size + 1) * 11);
+        const int alen = tracebackPW(buf, size, align);
+        finishSide(q, align, alen);
+      }
+      __syncthreads();
+    }
+  }
   {
     const int wave = lane >> 6, nw = NT >> 6, wl = lane & 63;
     const int slice = ((wm.cap * 8) / nw) & ~15;
-    for (int pass = 0; pass < 2; ++pass) {
+    const int nBig = nPendSides - nFit;
+    for (int pass = 0; pass < 2 && nBig > 0; ++pass) {
       // pass 0: every wavefront takes sides that fit its slice; pass 1: wavefront 0 takes the rest with the whole buffer
       unsigned char *buf = pass == 0 ? dirbuf + wave * slice : dirbuf;
       const int room = pass == 0 ? slice : wm.cap * 8;
-      for (int t = pass == 0 ? wave : 0; t < nPendSides; t += pass == 0 ? nw : 1) {
+      for (int t = pass == 0 ? wave : 0; t < nBig; t += pass == 0 ? nw : 1) {
         if (pass == 1 && wave != 0) break;
-        const int q = (int)wm.cand[t];
+        const int q = (int)wm.cand[nFit + t];
         const int size = sides[q].size;
         const bool fits = (size + 1) * 11 + 2 * size + 8 <= slice;
         if ((pass == 0) != fits) continue;       // wave-uniform
@@ -2415,23 +2505,8 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
         dpWaveTracePW(ix.pw + si.pwOff + t0, size, r + p0, buf);
         if (wl == 0) {
           signed char *align = (signed char *)(buf + (size + 1) * 11);
-          int alen = tracebackPW(buf, size, align);
-          int m = 0, mm = 0, ind = 0, good = 0, tmp = 0;
-          for (int k = 0; k < alen; ++k) { if (align[k] == 0) ++m; else if (align[k] == 1) ++mm; else ++ind; }
-          if (side == 0) {
-            for (int i = alen - 1, k = 1; i >= 0; --i, ++k) {
-              if (align[i] == 0) { ++tmp; if (tmp > 0.75 * k) good = k; }
-              else if (align[i] != 1) break;
-            }
-          } else {
-            for (int i = 0; i < alen; ++i) {
-              if (align[i] == 0) { ++tmp; if (tmp > 0.75 * (i + 1)) good = i + 1; }
-              else if (align[i] != 1) break;
-            }
-          }
-          ExtSide e = sides[q];
-          e.match = (short)m; e.mis = (short)mm; e.indel = (short)ind; e.good = (short)good; e.pending = 0;
-          sides[q] = e;
+          const int alen = tracebackPW(buf, size, align);
+          finishSide(q, align, alen);
         }
       }
       __syncthreads();

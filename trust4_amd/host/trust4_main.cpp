@@ -432,6 +432,11 @@ int main(int argc, char *argv[]) {
   };
   if (getenv("T4_SYNC_INIT")) gpuReady();   // the serial order, for timing comparisons
   PrintLog("Start to assemble reads.");
+  // wall-clock marks of the phases (written to $T4_STATS_JSON for bench.py)
+  const auto tStart = std::chrono::steady_clock::now();
+  std::vector<std::pair<std::string, double>> phaseMarks;
+  auto mark = [&](const char *name) { phaseMarks.push_back({name, std::chrono::duration<double>(std::chrono::steady_clock::now() - tStart).count()}); };
+  double annotKernelMs = 0; long long annotHits = 0, annotReads = 0;
 
   // ---- read input, mate processing, 21-mer counting (main.cpp:787-915)
   KmerCounter kmerCount(21, threadCnt);
@@ -613,12 +618,14 @@ int main(int argc, char *argv[]) {
     sortedReads.swap(kept);
     readCnt = (int)sortedReads.size();
   }
+  mark("input_processed_counted");
   PrintLog("Found %i reads.", readCnt);
   kmerCount.shards.clear();
   for (int i = 0; i < readCnt; ++i) { sortedReads[i].info = i; sortedReads[i].mateIdx = -1; }
   for (int i = 0; i < readCnt - 1; ++i)
     if (sortedReads[i].id == sortedReads[i + 1].id) { sortedReads[i].mateIdx = i + 1; sortedReads[i + 1].mateIdx = i; ++i; }
   std::sort(sortedReads.begin(), sortedReads.end());
+  mark("sorted");
   PrintLog("Finish sorting the reads.");
 
   // ---- rough annotation on the GPU (main.cpp:1084-1120)
@@ -631,12 +638,14 @@ int main(int argc, char *argv[]) {
     if ((rc = t4_reads_upload(ctx, bases.data(), off.data(), nullptr, n, &batch))) die(ctx, "t4_reads_upload", rc);
     std::vector<t4_overlap> out(4 * (size_t)n);
     if ((rc = t4_annotate_rough(refSet, batch, out.data()))) die(ctx, "t4_annotate_rough", rc);
+    { t4_stats st; if (t4_last_stats(ctx, &st) == T4_OK) { annotKernelMs += st.chain_kernel_ms; annotHits += st.total_hits; annotReads += st.reads; } }
     t4_batch_destroy(batch);
     for (int k = -1, i = 0; i < readCnt; ++i) {
       if (k + 1 < n && firstOf[k + 1] == i) ++k;
       for (int j = 0; j < 4; ++j) sortedReads[i].g[j] = out[4 * (size_t)k + j];
     }
   }
+  mark("rough_annotation");
   PrintLog("Finish rough annotations.");
 
   // ---- barcode order: by barcode, then by the barcode-wise 21-mer support (main.cpp:1123-1193)
@@ -924,6 +933,8 @@ int main(int argc, char *argv[]) {
     if (addRet >= 0) { ++assembledReadCnt; w.assembledRescue.push_back(idx); }
   };
 
+  mark("trimmed_ready");
+  if (getenv("T4_PHASE_DUMP")) t4_debug_phase_reset();
   std::vector<int> assembledReadIdx;
   int rescueReadCnt = 0, rescuedCnt = 0;
   int64_t laneBatches = 0, fallbackQueries = 0;
@@ -1081,6 +1092,7 @@ int main(int argc, char *argv[]) {
     PrintLog("Rescued %d reads.", rescuedCnt);
   }
 
+  mark("assembled");
   // ---- outputs (main.cpp:1959-2036)
   std::vector<const char *> bnames;
   for (const std::string &b : barcodeIntToStr) bnames.push_back(b.c_str());
@@ -1152,8 +1164,24 @@ int main(int argc, char *argv[]) {
   t4_assembler_counters(seqSet, &q, &rf, &wh);
   double sr = 0, sq = 0;
   t4_assembler_timers(seqSet, &sr, &sq);
-  int64_t lc[16] = {0};
-  t4_assembler_live_counters(seqSet, lc, 16);
+  int64_t lc[23] = {0};
+  t4_assembler_live_counters(seqSet, lc, 23);
+  mark("outputs_written");
+  if (const char *sj = getenv("T4_STATS_JSON")) {
+    FILE *fp = fopen(sj, "w");
+    if (fp) {
+      fprintf(fp, "{\"reads\": %d, \"threads\": %d, \"phases_s\": {", readCnt, threadCnt);
+      for (size_t i = 0; i < phaseMarks.size(); ++i) fprintf(fp, "%s\"%s\": %.4f", i ? ", " : "", phaseMarks[i].first.c_str(), phaseMarks[i].second);
+      fprintf(fp, "}, \"rough_annotation\": {\"reads\": %lld, \"hits\": %lld, \"kernel_ms\": %.3f}, ", annotReads, annotHits, annotKernelMs);
+      fprintf(fp, "\"add_query\": {\"rounds\": %lld, \"reads_queried\": %lld, \"reads_served\": %lld, \"kernel_ms\": %.3f, \"hits\": %lld, \"records\": %lld, "
+                  "\"global_tier_launches\": %lld, \"global_tier_reads\": %lld, \"deltas\": %lld, \"delta_bytes\": %lld, \"invalidations\": %lld, \"query_wall_s\": %.3f}, ",
+              (long long)lc[0], (long long)lc[1], (long long)wh, lc[21] / 1e3, (long long)lc[22], (long long)lc[20], (long long)lc[18], (long long)lc[19], (long long)lc[2],
+              (long long)lc[3], (long long)lc[4], lc[15] / 1e6);
+      fprintf(fp, "\"contigs\": %d, \"assembled_reads\": %d}\n", t4_assembler_size(seqSet), (int)assembledReadIdx.size());
+      fclose(fp);
+    }
+  }
+  if (getenv("T4_TIMING")) PrintLog("timing: AddRead query path: %lld calls, %lld reads, global-scratch tier %lld launches for %lld reads, %lld result records", (long long)lc[16], (long long)lc[17], (long long)lc[18], (long long)lc[19], (long long)lc[20]);
   PrintLog("Finish assembly. (GPU query rounds %lld with %lld reads in %.2f s; %lld image deltas, %.1f MB, in %.2f s; reads served from the window %lld; "
            "window entries invalidated %lld: key %lld, list>=100 %lld, region %lld, shift %lld, contig %lld, tolerance %lld; tolerated index changes %lld; "
            "dependency sets %.2f s, event examination %.2f s)",
