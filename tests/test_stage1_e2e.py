@@ -285,3 +285,42 @@ def test_driver_options_device_kmer_counts_emulated(tmp_path):
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not shipped")
 def test_driver_options_match_reference_binary(tmp_path):
     _driver_options_case(tmp_path, _driver(), 1500, 50, 9)
+
+
+def _bulk_case(tmp_path, driver, pairs, clones, seed, env, threads="4"):
+    """bulk paired-end input through `driver` (with the testing aids of `env`) and through the reference binary"""
+    fa = str(tmp_path / "ref.fa")
+    _gunzip(REF_FA, fa)
+    pre = str(tmp_path / "b")
+    subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, str(pairs), str(clones), str(seed), pre], check=True, stdout=subprocess.DEVNULL)
+    args = ["--skipMateExtension", "-f", fa, "-1", pre + "_1.fq", "-2", pre + "_2.fq"]
+    ref_out, my_out = str(tmp_path / "ref"), str(tmp_path / "mine")
+    subprocess.run([REF_BIN, "-t", "1"] + args + ["-o", ref_out], check=True, stderr=subprocess.DEVNULL)
+    e = dict(os.environ)
+    e.update(env)
+    e["T4_TIMING"] = "1"
+    p = subprocess.run([driver, "-t", threads] + args + ["-o", my_out], check=True, env=e, stderr=subprocess.PIPE, text=True)
+    for suffix in ("_raw.out", "_assembled_reads.fa", "_final.out"):
+        assert filecmp.cmp(ref_out + suffix, my_out + suffix, shallow=False), (env, suffix)
+    return p.stderr
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
+@pytest.mark.parametrize("env", [{"T4_AQ_CAP_LIMIT": "120"}, {"T4_AQ_FORCE_GLOBAL": "1"}, {"T4_QUERY_AHEAD": "3", "T4_WINDOW": "7"}])
+def test_bulk_live_set_paths_emulated(tmp_path, env):
+    """Bulk mode = the live set (device image by t4_index_apply_delta, sliding speculation window). The testing aids send a
+    small input down the paths large sets take: reads that outgrow the LDS arrays and go on in global scratch inside the launch
+    (T4_AQ_CAP_LIMIT), the global-scratch tier launched beside the LDS tier (T4_AQ_FORCE_GLOBAL), a window that is re-queried
+    a few reads at a time (T4_QUERY_AHEAD). Outputs must equal the reference binary's byte for byte."""
+    log = _bulk_case(tmp_path, _emulated_driver(), 240, 5, 11, env)
+    if "T4_AQ_CAP_LIMIT" in env or "T4_AQ_FORCE_GLOBAL" in env:
+        import re
+        m = re.search(r"global-scratch tier (\d+) launches for (\d+) reads", log)
+        assert m and int(m.group(2)) > 0, log[-600:]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not shipped")
+@pytest.mark.parametrize("env", [{}, {"T4_AQ_CAP_LIMIT": "2000"}, {"T4_AQ_FORCE_GLOBAL": "1"}])
+def test_bulk_live_set_paths_gpu(tmp_path, env):
+    _bulk_case(tmp_path, _driver(), 6000, 120, 12, env, threads="8")

@@ -180,6 +180,7 @@ int ensureScratch(t4_ctx *c, int threads) {
 }
 int ensureGlobalTier(t4_ctx *c, int grid) {
   if (grid <= c->gGrid) return T4_OK;
+  { int g = c->gGrid > 0 ? c->gGrid : 32; while (g < grid) g *= 2; grid = g; }   // 5.4 MB per block: grow rarely
   int r;
   if ((r = devAlloc(c, &c->gKeys, (size_t)grid * G_CAP))) return r;
   if ((r = devAlloc(c, &c->gPairs, (size_t)grid * G_CAP * 2))) return r;   // pairs + cand, contiguous per block
@@ -1311,10 +1312,12 @@ int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
     wk.nextList = (int *)(c->aqOut + pNext); wk.nextCount = (int *)(c->aqOut + pTail);
     wk.status = (int *)(c->aqOut + pSta); wk.hitCounter = (unsigned long long *)(c->aqOut + pTail + 16);
     wk.dpRows = c->dpRows; wk.dpDir = c->dpDir;
+    static const int capLimit = getenv("T4_AQ_CAP_LIMIT") ? atoi(getenv("T4_AQ_CAP_LIMIT")) : 0;   // testing aid
+    wk.capLimit = capLimit;
+    if (!smallFirst && (r = ensureGlobalTier(c, grid0 + nDirect))) return r;   // before anything of this call runs: growing it frees the old arrays
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     if (nDirect > 0) {   // beside the LDS tier, on the second stream (its own blocks of the DP scratch)
       if (!c->stream2) { HIPCHK(c, hipStreamCreate(&c->stream2)); HIPCHK(c, hipEventCreate(&c->evIn)); HIPCHK(c, hipEventCreate(&c->evG)); }
-      if ((r = ensureGlobalTier(c, nDirect))) return r;
       HIPCHK(c, hipEventRecord(c->evIn, c->stream));
       HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evIn, 0));
       T4Work wd = wk;
@@ -1330,7 +1333,14 @@ int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
     }
     if (nFirst > 0) {
       if (smallFirst) launchTier<1024, 128, 256>(grid0, c->stream, base, bv, wk, qa);
-      else launchTier<8192, 512, 256>(grid0, c->stream, base, bv, wk, qa);
+      else {   // a read that outgrows the LDS arrays goes on in global scratch inside the same launch
+        T4Work wf = wk;
+        const size_t skip = (size_t)nDirect;   // the blocks of a concurrent global-tier launch own the first slices
+        wf.gKeys = c->gKeys + skip * G_CAP; wf.gPairs = c->gPairs + skip * G_CAP * 2; wf.gCand = c->gCand;
+        wf.gOv = c->gOv + skip * G_MAXOV * 10; wf.gFin = c->gFin + skip * G_MAXOV * 10; wf.gOrd = c->gOrd + skip * G_MAXOV;
+        wf.gCap = G_CAP; wf.gMaxOv = G_MAXOV;
+        launchTier<8192, 512, 256>(grid0, c->stream, base, bv, wf, qa);
+      }
       HIPCHK(c, hipGetLastError());
     }
     if (nDirect > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->evG, 0));
@@ -1339,6 +1349,7 @@ int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
     HIPCHK(c, hipStreamSynchronize(c->stream));
     { float ms = 0; if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->aqKernelMs += ms; }
     int overflow = *(int *)(c->aqOutHost + pTail);
+    { const int inKernel = *(int *)(c->aqOutHost + pTail + 8); if (!smallFirst && inKernel > 0) { c->aqGlobalReads += inKernel; ++c->aqGlobalLaunches; } }
     c->aqSecFirst += tSince(tf0);
     auto tg0 = tNow();
     if (overflow > 0 && smallFirst) {   // reads beyond the 1024-hit tier: 8192-hit LDS tier

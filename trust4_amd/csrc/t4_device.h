@@ -106,6 +106,7 @@ struct T4Work {              // per-launch work description
   int *gFin;                 // [grid][maxov * 10]
   unsigned short *gOrd;      // [grid][maxov]
   int gCap, gMaxOv;
+  int capLimit;              // testing aid: an LDS tier pretends its hit capacity is this small (0 = off), so that small inputs reach the overflow paths
 };
 
 // KmerCount on the device (KmerCount.hpp): open-addressing table of canonical k-mer codes; keys hold code + 1 (0 = empty)

@@ -635,6 +635,9 @@ struct OvRec {
   int chainLen;
   int flags;         // bit0: strand == 1, bit1: similarity forced to 0, bit2: isRef
 };
+#define CAND_START_BITS 18
+#define CAND_START(c) ((int)((c) & ((1u << CAND_START_BITS) - 1u)))
+#define CAND_LEN(c) ((int)((c) >> CAND_START_BITS))
 #define OV_PLUS 1
 #define OV_SIMZERO 2
 #define OV_ISREF 4
@@ -694,9 +697,10 @@ struct WaveMem {
   OvRec *ov;                 // [maxOv] overlaps of the current pass; first: posStart
   OvRec *fin;                // [maxFin] accumulated final overlaps (annotate) / result (overlaps)
   unsigned short *ord;       // [maxOv] sort order
-  unsigned *cand;            // [cap / 3 + 1] candidate runs: start | len << 16
+  unsigned *cand;            // [cap / 3 + 1] candidate runs: start | len << 18 (hits of one pass: at most 2^18, the global-scratch tier's capacity)
   char *seg, *rc;            // [T4_MAXL + 8] current segment, forward and reverse complement
   int cap, maxOv, maxFin, candCap;
+  int hitLimit;                    // hits of one pass the arrays take: cap, or less under the testing aid T4Work::capLimit
   int ldsArrays;                   // keys / pairs / ov live in LDS (every tier but the global-scratch one)
   const unsigned *pkRow, *nmRow;   // the read's packed words (global), set by loadSegment
   int segAbs, segLen;              // position of the current segment inside the read
@@ -1100,7 +1104,7 @@ void chainRunsRows(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int nCand,
       int s = 0, n = 0, idx = 0, plus = 0, adjustRadius = 0;
       bool isRef = false;
       if (has) {
-        s = wm.cand[c] & 0xFFFF; n = wm.cand[c] >> 16;
+        s = CAND_START(wm.cand[c]); n = CAND_LEN(wm.cand[c]);
         const unsigned long long ks = wm.keys[s];
         idx = KEY_IDX(ks); plus = KEY_PLUS(ks);
         isRef = seqIsRef(ix, idx);
@@ -1245,7 +1249,8 @@ __device__ void overlapsFromKeys(const T4IndexView &ix, WaveMem &wm, WaveState *
     const int minHit = isRef ? 3 : ws->novelMin[KEY_PLUS(ki)];
     if (n >= minHit && n * K >= hitLenRequired) {
       int slot = atomicAdd(&ws->candCount, 1);
-      if (slot < wm.candCap) wm.cand[slot] = (unsigned)i | ((unsigned)n << 16);
+      if (n >= (1 << (32 - CAND_START_BITS))) ws->unsupported = 1;   // a run of 16384 hits: not with reads of a few hundred bases
+      else if (slot < wm.candCap) wm.cand[slot] = (unsigned)i | ((unsigned)n << CAND_START_BITS);
       else ws->overflow = 1;
     }
   }
@@ -1257,7 +1262,7 @@ __device__ void overlapsFromKeys(const T4IndexView &ix, WaveMem &wm, WaveState *
   if (ix.radius > 0) {
     const int wave = lane >> 6, nw = NT >> 6, wl = lane & 63;
     for (int c = wave; c < nCand; c += nw) {
-      int s = wm.cand[c] & 0xFFFF, n = wm.cand[c] >> 16;
+      int s = CAND_START(wm.cand[c]), n = CAND_LEN(wm.cand[c]);
       if (n <= 48) continue;                                  // wave-uniform
       unsigned long long ks = wm.keys[s];
       if (!seqIsRef(ix, KEY_IDX(ks))) continue;               // wave-uniform
@@ -1296,7 +1301,7 @@ __device__ void overlapsFromKeys(const T4IndexView &ix, WaveMem &wm, WaveState *
 #else
   // R3: one lane per candidate run: extract (b << 12 | a), order by (b, a), chain
   for (int c = lane; c < nCand; c += NT) {
-    int s = wm.cand[c] & 0xFFFF, n = wm.cand[c] >> 16;
+    int s = CAND_START(wm.cand[c]), n = CAND_LEN(wm.cand[c]);
     unsigned long long ks = wm.keys[s];
     int idx = KEY_IDX(ks), plus = KEY_PLUS(ks);
     bool isRef = seqIsRef(ix, idx);
@@ -1863,7 +1868,7 @@ __device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, 
   if (lane == 0) ws->ovCount = 0;
   PHASE_MARK(ws, 1);
   int H = seedPositions(ix, wm, segLen, strandArg, barcode, allowTotalSkip, posStart, posPref, ws->red);
-  if (H > wm.cap) return -1;
+  if (H > wm.hitLimit) return -1;
   PHASE_MARK(ws, 2);
 #if T4_OPT_KEY32
   const int k32 = ix.key32;
@@ -2675,7 +2680,7 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
       unsigned *posStart = (unsigned *)wm.ov, *posPref = wm.pairs;
       const int nk = len - ix.k + 1;
       int H = seedPositions(ix, wm, len, 0, -1, false, posStart, posPref, ws->red);
-      if (H > wm.cap) return false;
+      if (H > wm.hitLimit) return false;
       hitTotal += (unsigned long long)H;
       if (H > 0) {
         expandHits(ix, wm, nk, H, -1, false, posStart, posPref, ws->red);
@@ -2838,6 +2843,7 @@ void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
   if (CAP > 0) {
     wm.keys = s_keys; wm.pairs = s_pairs; wm.cand = s_pairs + C; wm.ov = s_ov; wm.fin = s_fin; wm.ord = s_ord;
     wm.cap = CAP; wm.maxOv = MAXOV; wm.maxFin = MAXOV; wm.candCap = C / 3 + 2; wm.ldsArrays = 1;
+    wm.hitLimit = (wk.capLimit > 0 && wk.capLimit < CAP) ? wk.capLimit : CAP;
   } else {
     size_t b = blockIdx.x;
     wm.keys = wk.gKeys + b * (size_t)wk.gCap;
@@ -2847,6 +2853,7 @@ void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
     wm.fin = (OvRec *)(wk.gFin + b * (size_t)wk.gMaxOv * 10);
     wm.ord = wk.gOrd + b * (size_t)wk.gMaxOv;
     wm.cap = wk.gCap; wm.maxOv = wk.gMaxOv; wm.maxFin = wk.gMaxOv; wm.candCap = wk.gCap; wm.ldsArrays = 0;
+    wm.hitLimit = wk.gCap;
   }
   wm.seg = s_seg; wm.rc = s_rc;
   DPScratch sc;
@@ -2860,6 +2867,22 @@ void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
     long long r = wk.list[w];
     if (VARIANT == 2) ix = qa.views[qa.viewOf[r]];   // uniform address: scalar loads
     bool done = processRead<(VARIANT == 0 ? 0 : VARIANT == 3 ? 3 : 1)>(ix, bv, wk, qa, wm, &s_ws, r, sc);
+    if (CAP == 8192 && VARIANT == 1 && !done && wk.gKeys) {
+      // The read outgrew the LDS arrays (known right after its seed stage): the same workgroup goes on in its block's slice of
+      // the global-scratch arrays instead of leaving the read to another launch -- an AddRead query round is one launch.
+      WaveMem wg = wm;
+      const size_t b = blockIdx.x;
+      wg.keys = wk.gKeys + b * (size_t)wk.gCap;
+      wg.pairs = wk.gPairs + b * (size_t)wk.gCap * 2;
+      wg.cand = wg.pairs + wk.gCap;
+      wg.ov = (OvRec *)(wk.gOv + b * (size_t)wk.gMaxOv * 10);
+      wg.fin = (OvRec *)(wk.gFin + b * (size_t)wk.gMaxOv * 10);
+      wg.ord = wk.gOrd + b * (size_t)wk.gMaxOv;
+      wg.cap = wk.gCap; wg.maxOv = wk.gMaxOv; wg.maxFin = wk.gMaxOv; wg.candCap = wk.gCap; wg.ldsArrays = 0; wg.hitLimit = wk.gCap;
+      __syncthreads();
+      done = processRead<1>(ix, bv, wk, qa, wg, &s_ws, r, sc);
+      if (tid() == 0 && done && wk.nextCount) atomicAdd(wk.nextCount + 2, 1);   // statistics: reads served this way
+    }
     if (tid() == 0) {
       if (!done) {
         if (wk.nextList) { int slot = atomicAdd(wk.nextCount, 1); wk.nextList[slot] = (int)r; }
