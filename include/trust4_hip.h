@@ -117,6 +117,15 @@ const char *t4_index_seq_consensus(const t4_index *ix, int seq_id);
  * packed (+1 bit/base N mask) on the host and copied to HBM. */
 int t4_reads_upload(t4_ctx *ctx, const char *bases, const int64_t *offsets, const int32_t *barcode,
                     int64_t n_reads, t4_batch **out);
+/* The same with flags. T4_READS_KMERS_ONLY: upper-case letters other than ACGTN are taken as KmerCode::Append takes them
+ * (KmerCode.hpp:99-106: nucToNum[c - 'A'] & 3 = 3, a VALID 'T'; only 'N' invalidates a k-mer). Such a batch is for the
+ * queries that look at k-mer codes only -- t4_has_hit (the stage-0 filter), t4_hits, t4_kmer_count_* -- where this is exactly
+ * the reference. The alignment queries are refused such letters without the flag and must not be given such a batch: the
+ * reference compares the letter itself in GlobalAlignment and reads _posWeight::count[-1] for it in IsBaseEqual
+ * (AlignAlgo.hpp:49-55 with nucToNum = -1), which is not behaviour a drop-in can reproduce. */
+#define T4_READS_KMERS_ONLY 1
+int t4_reads_upload_flags(t4_ctx *ctx, const char *bases, const int64_t *offsets, const int32_t *barcode,
+                          int64_t n_reads, int flags, t4_batch **out);
 void t4_batch_destroy(t4_batch *b);
 int64_t t4_batch_size(const t4_batch *b);
 

@@ -37,11 +37,17 @@ def write_fq(path, seqs):
             f.write("@q%d\n%s\n+\n%s\n" % (i, s, "F" * len(s)))
 
 
-def run_case(tmp_path, driver, mode):
+def run_case(tmp_path, driver, mode, n_receptor=300, n_other=1500, trim=None):
+    """trim = (lo, hi): every read cut to a length in [lo, hi] -- short single-end reads, where the reference's
+    hitLenRequired is 23 (FastqExtractor.cpp:436-438) instead of the 27 of paired input or the len / 5 of long reads"""
     fa = str(tmp_path / "ref.fa")
     with gzip.open(REF_FA, "rb") as f, open(fa, "wb") as g:
         shutil.copyfileobj(f, g)
-    pairs = stage0_input(11, 300, 1500)
+    pairs = stage0_input(11, n_receptor, n_other)
+    if trim:
+        rnd = random.Random(7)
+        cut = lambda s: s[:rnd.randint(trim[0], trim[1])] if len(s) > trim[0] else s
+        pairs = [(cut(a), cut(b)) for a, b in pairs]
     f1, f2 = str(tmp_path / "in_1.fq"), str(tmp_path / "in_2.fq")
     write_fq(f1, [p[0] for p in pairs])
     write_fq(f2, [p[1] for p in pairs])
@@ -53,7 +59,7 @@ def run_case(tmp_path, driver, mode):
     for s in names:
         assert filecmp.cmp(ref_o + s, my_o + s, shallow=False), s
     n_kept = open(ref_o + names[0]).read().count("\n") // 4
-    assert 300 <= n_kept < len(pairs) // 2
+    assert n_receptor * (2 if trim else 3) // 3 <= n_kept < len(pairs) // 2
 
 
 def barcode_inputs(tmp_path, seed, n_receptor_pairs, n_other_pairs):
@@ -172,6 +178,18 @@ def test_extractor_matches_reference_binary(tmp_path, mode):
     import trust4_amd.build as b
     b.build()
     run_case(tmp_path, os.path.join(ROOT, "trust4_amd", "bin", "fastq-extractor-hip"), mode)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_EXT), reason="oracle/_ref/fastq-extractor not shipped")
+def test_extractor_short_single_end_matches_reference_binary(tmp_path):
+    run_case(tmp_path, os.path.join(ROOT, "trust4_amd", "bin", "fastq-extractor-hip"), "single", trim=(75, 100))
+
+
+@pytest.mark.skipif(not os.path.exists(REF_EXT), reason="oracle/_ref/fastq-extractor not built")
+def test_extractor_short_single_end_emulated(tmp_path):
+    """75-100 bp single-end reads: hitLenRequired 23 (between the 27 of paired input and what len / 5 gives for long reads)"""
+    run_case(tmp_path, _emulated_extractor(), "single", n_receptor=60, n_other=150, trim=(75, 100))
 
 
 @pytest.mark.skipif(not os.path.exists(REF_EXT), reason="oracle/_ref/fastq-extractor not built")

@@ -684,6 +684,10 @@ const char *t4_index_seq_consensus(const t4_index *ix, int i) { return (ix && i 
 
 // ---- reads -------------------------------------------------------------------------------------
 int t4_reads_upload(t4_ctx *c, const char *bases, const int64_t *offsets, const int32_t *barcode, int64_t n, t4_batch **out) {
+  return t4_reads_upload_flags(c, bases, offsets, barcode, n, 0, out);
+}
+
+int t4_reads_upload_flags(t4_ctx *c, const char *bases, const int64_t *offsets, const int32_t *barcode, int64_t n, int flags, t4_batch **out) {
   if (!c || !out || n < 0 || (n > 0 && (!bases || !offsets))) return T4_ERR_ARG;
   *out = nullptr;
   (void)hipSetDevice(c->device);
@@ -709,25 +713,28 @@ int t4_reads_upload(t4_ctx *c, const char *bases, const int64_t *offsets, const 
     for (int j = 0; j < l; ++j) {
       int v = nucNum(s[j]);
       if (v < 0) {
-        if (s[j] != 'N') { delete b; return fail(c, T4_ERR_UNSUPPORTED, "read %lld has base '%c' (alphabet is ACGTN)", (long long)i, s[j]); }
-        m[j >> 5] |= 1u << (j & 31);
-        v = 0;
+        if (s[j] == 'N') { m[j >> 5] |= 1u << (j & 31); v = 0; }
+        else if ((flags & T4_READS_KMERS_ONLY) && s[j] >= 'A' && s[j] <= 'Z') v = 3;   // nucToNum[c - 'A'] & 3 of KmerCode::Append (KmerCode.hpp:99-106): a valid 'T'
+        else { delete b; return fail(c, T4_ERR_UNSUPPORTED, "read %lld has base '%c' (alphabet is ACGTN)", (long long)i, s[j]); }
       }
       p[j >> 4] |= (unsigned)v << ((j & 15) * 2);
     }
   }
   int r;
+  // a HIP error below must not leak the batch and its device buffers
+  #define UPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { t4_batch_destroy(b); return fail(c, T4_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); } } while (0)
   // + 4 words: the packed k-mer extraction reads one word past a read's row (masked out), also for the last read
   if ((r = devAlloc(c, &b->dPk, pk.size() + 4)) || (r = devAlloc(c, &b->dNm, nm.size() + 4)) || (r = devAlloc(c, &b->dLen, len.size()))) { t4_batch_destroy(b); return r; }
   if (n > 0) {
-    HIPCHK(c, hipMemcpy(b->dPk, pk.data(), sizeof(unsigned) * pk.size(), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(b->dNm, nm.data(), sizeof(unsigned) * nm.size(), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(b->dLen, len.data(), sizeof(int) * len.size(), hipMemcpyHostToDevice));
+    UPCHK(hipMemcpy(b->dPk, pk.data(), sizeof(unsigned) * pk.size(), hipMemcpyHostToDevice));
+    UPCHK(hipMemcpy(b->dNm, nm.data(), sizeof(unsigned) * nm.size(), hipMemcpyHostToDevice));
+    UPCHK(hipMemcpy(b->dLen, len.data(), sizeof(int) * len.size(), hipMemcpyHostToDevice));
   }
   if (barcode) {
     if ((r = devAlloc(c, &b->dBarcode, (size_t)n))) { t4_batch_destroy(b); return r; }
-    if (n > 0) HIPCHK(c, hipMemcpy(b->dBarcode, barcode, sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+    if (n > 0) UPCHK(hipMemcpy(b->dBarcode, barcode, sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
   }
+  #undef UPCHK
   b->view.pk = b->dPk; b->view.nm = b->dNm; b->view.len = b->dLen; b->view.barcode = b->dBarcode;
   b->view.wpk = b->wpk; b->view.wnm = b->wnm; b->view.n = n;
   *out = b;
@@ -1698,6 +1705,7 @@ int t4_cellstore_stage(t4_cellstore *cs, int slot, int barcode, int nseq, const 
   }
   memset(b, 0, blobBytes + viewBytes);
   T4HashEntC *ht = (T4HashEntC *)(b + oHt);
+  for (size_t t = 0; t < sz; ++t) ht[t].code = ~0ull;   // empty slots
   int2 *post = (int2 *)(b + oPost);
   const unsigned long long hashMask = sz - 1;
   size_t at = 0;
@@ -1712,7 +1720,7 @@ int t4_cellstore_stage(t4_cellstore *cs, int slot, int barcode, int nseq, const 
     if (cnt <= 0) continue;
     if (hb != (int)((cd + (unsigned long long)(long long)(barcode + 1)) % 1000003ull)) return fail(c, T4_ERR_ARG, "key of another barcode in the image of barcode %d", barcode);
     unsigned long long s = t4k::mix64(cd) & hashMask;
-    while (ht[s].cnt != 0) s = (s + 1) & hashMask;
+    while (ht[s].code != ~0ull) s = (s + 1) & hashMask;
     ht[s].code = cd; ht[s].start = (unsigned)at; ht[s].cnt = (unsigned)cnt;
     at += (size_t)cnt;
   }

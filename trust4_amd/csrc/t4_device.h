@@ -38,7 +38,7 @@ T4PW t4PwByte(int a, int c, int g, int t) {
   return (T4PW)((sum == 0 ? 16 : 0) | (sum < 3 * a ? 1 : 0) | (sum < 3 * c ? 2 : 0) | (sum < 3 * g ? 4 : 0) | (sum < 3 * t ? 8 : 0));
 }
 
-struct T4HashEntC {          // slot of a per-barcode image: one barcode, so the bucket is implied by the code; cnt == 0 = empty
+struct T4HashEntC {          // slot of a per-barcode image or of a live set: the bucket is implied by the code; code == ~0 = empty
   unsigned long long code;
   unsigned start, cnt;
 };

@@ -25,6 +25,12 @@ namespace t4k {
 // ------------------------------------------------------------------------------------------------
 // A workgroup (NT = blockDim.x threads, a multiple of 64) owns one read; wave-level helpers below are
 // combined through a few LDS words into workgroup-level scans / reductions.
+// out-of-line device functions keep their registers to themselves (and cost a stack frame in scratch): T4_INLINE_ALL inlines them
+#ifdef T4_INLINE_ALL
+#define T4_NI
+#else
+#define T4_NI __attribute__((noinline))
+#endif
 #ifndef T4_OPT_JOBSORT
 #define T4_OPT_JOBSORT 1
 #endif
@@ -105,16 +111,8 @@ __device__ __forceinline__ void indexLookup(const T4IndexView &ix, unsigned long
     start = e.x; cnt = e.y;
     return;
   }
-  if (ix.direct == 2) {   // per-barcode image
-    unsigned long long i = mix64(code) & ix.hashMask;
-    for (;;) {
-      T4HashEntC e = ix.ctab[i];
-      if (e.cnt == 0) { start = 0; cnt = 0; return; }
-      if (e.code == code) { start = e.start; cnt = e.cnt; return; }
-      i = (i + 1) & ix.hashMask;
-    }
-  }
-  if (ix.direct == 3) {   // live set (t4_index_apply_delta): keys are never removed, an empty slot holds code ~0
+  if (ix.direct >= 2) {   // per-barcode image (2) or live set (3, t4_index_apply_delta): open addressing on the code, an empty
+                          // slot holds code ~0; the keys of a live set are never removed (a list may be empty)
     unsigned long long i = mix64(code) & ix.hashMask;
     for (;;) {
       T4HashEntC e = ix.ctab[i];
@@ -957,7 +955,7 @@ __device__ __forceinline__ void cmpExch32(unsigned &lo, unsigned &hi, int mask, 
   lo = keepMax ? (olo > lo ? olo : lo) : (olo < lo ? olo : lo);
   hi = keepMax ? (ohi > hi ? ohi : hi) : (ohi < hi ? ohi : hi);
 }
-__device__ __attribute__((noinline)) void bitonicSort32(unsigned *keys, int n) {
+__device__ T4_NI void bitonicSort32(unsigned *keys, int n) {
   const int lane = tid(), NT = nthr();
   int n2 = 1;
   while (n2 < n) n2 <<= 1;
@@ -1091,7 +1089,7 @@ __device__ void chainRun(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int 
 // LIS (2 % of them) falls back to the lane-serial LongestIncreasingSubsequence. Loops hold no wave-level operation, so the
 // rows of a wavefront may run different trip counts. T4_NI_R3: out of line (own register budget).
 #if T4_NI_R3
-__device__ __attribute__((noinline))
+__device__ T4_NI
 #else
 __device__ __forceinline__
 #endif
@@ -1508,7 +1506,7 @@ template <> struct T4TbufPtr<true> { typedef const T4_LDS_AS char *type; };
 // p always lives in LDS (the read's segment); TLDS says that tbuf does too (every tier but the global-scratch one): the loop then
 // reads its characters with ds_read (lgkmcnt only, in order) instead of flat loads, which the prefetch of the next step needs.
 template <bool PW, bool TLDS>
-__device__ __attribute__((noinline)) unsigned dpOct(bool has, const char *t, const T4PW *w, int lent, const char *p, int lenp, char *tbuf, int tcap) {
+__device__ T4_NI unsigned dpOct(bool has, const char *t, const T4PW *w, int lent, const char *p, int lenp, char *tbuf, int tcap) {
   const int L = laneId() & 7, grpBase = laneId() & 56;
   const T4_LDS_AS char *const pl = (const T4_LDS_AS char *)p;
   typedef typename T4TbufPtr<TLDS>::type TbufPtr;
@@ -1752,7 +1750,7 @@ __device__ void walkOverlap(const T4IndexView &ix, WaveMem &wm, WaveState *ws, O
 // not add to the kernel's pressure). For a reference-gene overlap under radius > 0 the walk only ever stops on geometry (a
 // gap beyond nomatchGapLimit), so its sums are prefix sums up to that anchor pair j*: find j*, add the pairs before it (pair
 // j* itself has added its 2K before the reference looks at the gap), list their gap jobs.
-__device__ __attribute__((noinline)) void walkOverlapsRows(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int overlapCnt) {
+__device__ T4_NI void walkOverlapsRows(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int overlapCnt) {
   const int lane = tid(), NT = nthr(), K = ix.k;
   const int row = lane >> 4, rl = lane & 15, nRows = NT >> 4;
   for (int i0 = 0; i0 < overlapCnt; i0 += nRows) {
@@ -2824,10 +2822,13 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
 // VARIANT 0 / 1: see processRead; VARIANT 3: HasHitInSet (mode 5) alone, so that its bucket bit masks cost the annotation
 // kernels no registers; VARIANT 2: mode 4 with every read matched against its own per-barcode image
 // (qa.views[qa.viewOf[read]]).
+#ifndef T4_WPE_SMALL
+#define T4_WPE_SMALL 4
+#endif
 template <int CAP, int MAXOV, int NTHREADS, int VARIANT>
 __global__ __launch_bounds__(NTHREADS)
 // rough-annotation kernels of the two small tiers: register budget for 4 waves / SIMD (LDS lets that many groups in)
-__attribute__((amdgpu_waves_per_eu((VARIANT == 0 && CAP > 0 && CAP <= 2048) ? 4 : 1)))
+__attribute__((amdgpu_waves_per_eu((VARIANT == 0 && CAP > 0 && CAP <= 2048) ? T4_WPE_SMALL : 1)))
 void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
   constexpr int C = CAP > 0 ? CAP : 1;
   constexpr int M = CAP > 0 ? MAXOV : 1;

@@ -170,7 +170,7 @@ int main(int argc, char *argv[]) {
     std::vector<int32_t> hit(testOff.size() - 1, 0);
     if (!hit.empty()) {
       t4_batch *b = nullptr;
-      if ((rc = t4_reads_upload(ctx, testBases.data(), testOff.data(), nullptr, (int64_t)hit.size(), &b))) die(ctx, "t4_reads_upload", rc);
+      if ((rc = t4_reads_upload_flags(ctx, testBases.data(), testOff.data(), nullptr, (int64_t)hit.size(), T4_READS_KMERS_ONLY, &b))) die(ctx, "t4_reads_upload", rc);
       if ((rc = t4_has_hit(refSet, b, 0, hit.data()))) die(ctx, "t4_has_hit", rc);
       t4_batch_destroy(b);
     }

@@ -163,7 +163,9 @@ int main(int argc, char *argv[]) {
     if ((rc = t4_index_commit(refSet))) die(ctx, "t4_index_commit", rc);
   };
 
-  // hitLenRequired from the first 1000 reads (FastqExtractor.cpp:436-455)
+  // hitLenRequired: 27 with mates, 23 without, at least a fifth of the mean length of the first 1000 reads
+  // (FastqExtractor.cpp:436-455)
+  if (!hasMate) hitLenRequired = 23;
   int i, len = 0;
   for (i = 0; i < 1000; ++i) { if (!reads.next()) break; len += (int)reads.seq.size(); }
   if (i == 0) { fprintf(stderr, "Read file is empty.\n"); gpuReady(); return EXIT_FAILURE; }
@@ -227,7 +229,7 @@ int main(int argc, char *argv[]) {
     if (which.empty()) return;
     gpuReady();
     t4_batch *b = nullptr;
-    if ((rc = t4_reads_upload(ctx, bases.data(), off.data(), nullptr, (int64_t)which.size(), &b))) die(ctx, "t4_reads_upload", rc);
+    if ((rc = t4_reads_upload_flags(ctx, bases.data(), off.data(), nullptr, (int64_t)which.size(), T4_READS_KMERS_ONLY, &b))) die(ctx, "t4_reads_upload", rc);   // HasHitInSet looks at k-mer codes only: other letters count as T (KmerCode.hpp:99-106)
     std::vector<int32_t> out(which.size());
     if ((rc = t4_has_hit(refSet, b, 0, out.data()))) die(ctx, "t4_has_hit", rc);
     t4_batch_destroy(b);

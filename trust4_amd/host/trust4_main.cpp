@@ -53,7 +53,8 @@ const char *USAGE =
     "\t-t INT: number of host threads (default: 1); used by the barcode-mode Add pass (cells are independent)\n"
     "\t-k INT: the starting k-mer size for indexing contigs (default: 9)\n"
     "\t--minHitLen INT: the minimal hit length for a valid overlap (default: auto)\n"
-    "\t--skipMateExtension: accepted; _final.out is always the raw assembly in this build\n"
+    "\t--skipMateExtension: REQUIRED for paired-end input without barcodes: the mate-pair extension of the assemblies\n"
+    "\t\t(main.cpp:2047-2312) is not part of this build, _final.out is the raw assembly\n"
     "\t--trimLevel INT: 0: no trim; 1: trim low quality; 2: trim unmatched (default: 1)\n"
     "\t--cgeneEnd INT: skipping reads mapped to C gene coordinate greater than INT (default: 200)\n"
     "\t--barcode STRING: the path to the barcode file (default: not used)\n"
@@ -406,6 +407,13 @@ int main(int argc, char *argv[]) {
     else { fprintf(stderr, "%s", USAGE); return EXIT_FAILURE; }
   }
   if (refFa.empty()) { fprintf(stderr, "Need to use -f to specify the receptor genome sequence.\n"); return EXIT_FAILURE; }
+  if (hasMate && !hasBarcode && !skipMateExtension && !getenv("T4_ALLOW_RAW_FINAL")) {
+    // main.cpp:2018-2312: the reference would go on to its mate-pair extension (ExtendSeqFromReads, RemoveRedundantSeq) and the
+    // annotator reads _final.out. A silent copy of the raw assembly there would change contigs and CDR3 calls downstream.
+    fprintf(stderr, "trust4-hip: the mate-pair extension of the assemblies (what the reference runs for paired-end input without barcodes) is not part of this build.\n"
+                    "Pass --skipMateExtension (run-trust4 forwards it; _final.out is then the raw assembly, as in the reference), or set T4_ALLOW_RAW_FINAL=1 to get that file without the flag.\n");
+    return EXIT_FAILURE;
+  }
   if (getenv("T4_THREADS")) threadCnt = atoi(getenv("T4_THREADS")) > 0 ? atoi(getenv("T4_THREADS")) : 1;
   if (shardCount > 1 && (!hasBarcode || keepMissingBarcode)) { fprintf(stderr, "--cellShard needs --barcode: without barcodes the Add pass does not shard (DESIGN.md 6).\n"); return EXIT_FAILURE; }
 
@@ -513,7 +521,10 @@ int main(int argc, char *argv[]) {
     nr.id = reads.id; nr.read = reads.seq; nr.qual = reads.qual; nr.hasQual = reads.hasQual;
     ++nIn;
     if (nIn % 100000 == 0) PrintLog("Read in and count kmers for %d reads.", nIn);
-    if (firstReadLen == -1) firstReadLen = (int)reads.seq.size();
+    if (firstReadLen == -1) {
+      firstReadLen = (int)reads.seq.size();
+      if (firstReadLen > 200) { fprintf(stderr, "trust4-hip: long-read mode (first read > 200 bp, main.cpp:1467-1481) is not built.\n"); return EXIT_FAILURE; }
+    }
     bool haveMate = false;
     if (mateReads.next()) {
       haveMate = true;
@@ -1146,8 +1157,8 @@ int main(int argc, char *argv[]) {
     fprintf(fp, "shard %d %d\ncontig_slots %d\nreads %d\n", shardRank, shardCount, t4_cellset_size(cellSet), readCnt);
     fclose(fp);
   } else {
-    if (!skipMateExtension && hasMate && !hasBarcode)   // main.cpp:2018: the reference would now run its mate-pair extension
-      PrintLog("NOTE: the mate-pair extension of assemblies is not part of this build; _final.out is the raw assembly (what the reference writes under --skipMateExtension).");
+    if (!skipMateExtension && hasMate && !hasBarcode)   // only reachable under T4_ALLOW_RAW_FINAL=1 (checked with the options)
+      PrintLog("NOTE: T4_ALLOW_RAW_FINAL=1: _final.out is the raw assembly (what the reference writes under --skipMateExtension), NOT its mate-pair extension.");
     writeSetOrStdout(outputPrefix + "_final.out");
   }
   if (useCells) {
