@@ -698,6 +698,8 @@ struct WaveMem {
   unsigned *cand;            // [cap / 3 + 1] candidate runs: start | len << 18 (hits of one pass: at most 2^18, the global-scratch tier's capacity)
   char *seg, *rc;            // [T4_MAXL + 8] current segment, forward and reverse complement
   int cap, maxOv, maxFin, candCap;
+  unsigned long long *ldsSort;     // global-scratch mode: LDS staging buffer of the hit sort (null: none)
+  int ldsSortCap;
   int hitLimit;                    // hits of one pass the arrays take: cap, or less under the testing aid T4Work::capLimit
   int ldsArrays;                   // keys / pairs / ov live in LDS (every tier but the global-scratch one)
   const unsigned *pkRow, *nmRow;   // the read's packed words (global), set by loadSegment
@@ -938,6 +940,63 @@ __device__ void bitonicSort(KeyT *keys, int n) {
       }
     }
     __syncthreads();
+  }
+}
+
+// The same network for keys in GLOBAL memory (the global-scratch tier: tens of thousands of hits) staged through an LDS
+// buffer of B keys (B a power of two): every sub-step whose partners lie inside an aligned block of B keys runs on the block
+// in LDS, only the sub-steps with j >= B touch global memory -- 10 global sub-steps instead of 153 for 131072 keys.
+// Padding up to the block size is an explicit +inf (all ones: no key is larger; dropped hits carry it too).
+template <class KeyT>
+__device__ void bitonicSortBlocked(KeyT *keys, int n, KeyT *lds, int B) {
+  const int lane = tid(), NT = nthr();
+  const KeyT INF = ~(KeyT)0;
+  if (n <= B) {   // fits the buffer: one round trip
+    for (int i = lane; i < n; i += NT) lds[i] = keys[i];
+    __syncthreads();
+    bitonicSort(lds, n);
+    for (int i = lane; i < n; i += NT) keys[i] = lds[i];
+    __syncthreads();
+    return;
+  }
+  int n2 = 1;
+  while (n2 < n) n2 <<= 1;
+  for (int b0 = 0; b0 < n; b0 += B) {   // stages k = 2 .. B: every block sorted ascending
+    for (int i = lane; i < B; i += NT) lds[i] = b0 + i < n ? keys[b0 + i] : INF;
+    __syncthreads();
+    bitonicSort(lds, B);
+    for (int i = lane; i < B; i += NT) if (b0 + i < n) keys[b0 + i] = lds[i];
+    __syncthreads();
+  }
+  const int half = n2 >> 1;
+  for (int k = 2 * B; k <= n2; k <<= 1) {
+    int j = k >> 1;
+    for (int t = lane; t < half; t += NT) {   // first sub-step of the stage: partner mirrored inside the k-block
+      const int low = t & (j - 1), i = ((t & ~(j - 1)) << 1) | low, p = (i & ~(k - 1)) + (k - 1 - low);
+      if (p < n) { KeyT a = keys[i], b = keys[p]; if (a > b) { keys[i] = b; keys[p] = a; } }
+    }
+    __syncthreads();
+    for (j >>= 1; j >= B; j >>= 1) {
+      for (int t = lane; t < half; t += NT) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
+        if (p < n) { KeyT a = keys[i], b = keys[p]; if (a > b) { keys[i] = b; keys[p] = a; } }
+      }
+      __syncthreads();
+    }
+    for (int b0 = 0; b0 < n; b0 += B) {   // sub-steps j = B / 2 .. 1 of the stage, block by block in LDS
+      for (int i = lane; i < B; i += NT) lds[i] = b0 + i < n ? keys[b0 + i] : INF;
+      __syncthreads();
+      for (int jj = B >> 1; jj > 0; jj >>= 1) {
+        for (int t = lane; t < (B >> 1); t += NT) {
+          const int i = ((t & ~(jj - 1)) << 1) | (t & (jj - 1)), p = i | jj;
+          KeyT a = lds[i], b = lds[p];
+          if (a > b) { lds[i] = b; lds[p] = a; }
+        }
+        __syncthreads();
+      }
+      for (int i = lane; i < B; i += NT) if (b0 + i < n) keys[b0 + i] = lds[i];
+      __syncthreads();
+    }
   }
 }
 
@@ -1900,7 +1959,10 @@ __device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, 
       wm.keys[i] = key;
     }
     __syncthreads();
-  } else if (H > 1) bitonicSort(wm.keys, H);
+  } else if (H > 1) {
+    if (!wm.ldsArrays && wm.ldsSort) bitonicSortBlocked(wm.keys, H, wm.ldsSort, wm.ldsSortCap);
+    else bitonicSort(wm.keys, H);
+  }
   PHASE_MARK(ws, 4);
   overlapsFromKeys(ix, wm, ws, Hv, hitLenRequired, filter);
   PHASE_MARK(ws, 0);
@@ -2390,27 +2452,41 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
                                double factor, ExtSide *sides, unsigned char *dirbuf, ExtOut *res) {
   const int lane = tid(), NT = nthr();
   const int plus0 = n > 0 ? (wm.fin[wm.ord[0]].flags & OV_PLUS) : 1;
-  // E1: ungapped evaluation of every (overlap, side)
-  for (int q = lane; q < 2 * n; q += NT) {
-    const OvRec &o = wm.fin[wm.ord[q >> 1]];
-    const int side = q & 1;
-    const T4SeqInfo si = ix.seqs[o.seqIdx];
-    const char *r = (useFirstStrand ? plus0 : (o.flags & OV_PLUS)) ? wm.seg : wm.rc;
-    ExtSide e;
-    int size, t0, p0;   // overhang length; first target / read position of the overhang
-    if (side == 0) { size = o.rs < o.ss ? o.rs : o.ss; t0 = o.ss - size; p0 = o.rs - size; }
-    else { int a = len - 1 - o.re, b = si.len - 1 - o.se; size = a < b ? a : b; t0 = o.se + 1; p0 = o.re + 1; }
-    const T4PW *w = ix.pw + si.pwOff + t0;
-    int mm = 0, good = 0, tmp = 0;
-    for (int k = 0; k < size; ++k) mm += baseEqualW(w[k], r[p0 + k]) ? 0 : 1;
-    e.size = (short)size; e.match = (short)(size - mm); e.mis = (short)mm; e.indel = 0; e.pending = 0;
-    if (size > 1 && !((size - mm) * 2 - mm * 2 >= size * 2 - 8)) e.pending = 1;   // needs the banded DP
-    else {
-      if (side == 0) { for (int k = 1; k <= size; ++k) if (baseEqualW(w[size - k], r[p0 + size - k])) { ++tmp; if (tmp > 0.75 * k) good = k; } }
-      else { for (int k = 0; k < size; ++k) if (baseEqualW(w[k], r[p0 + k])) { ++tmp; if (tmp > 0.75 * (k + 1)) good = k + 1; } }
+  // E1: ungapped evaluation of every (overlap, side), one side per wavefront at a time: 64 overhang positions per step
+  // (coalesced predicate bytes), mismatches by ballot, the "good" prefix (SeqSet.hpp:1187-1235: the longest stretch from the
+  // anchor outward whose matches exceed 3/4 of its length) from prefix popcounts
+  {
+    const int wave = lane >> 6, nwv = NT >> 6, wl = lane & 63;
+    for (int q = wave; q < 2 * n; q += nwv) {
+      const OvRec &o = wm.fin[wm.ord[q >> 1]];
+      const int side = q & 1;
+      const T4SeqInfo si = ix.seqs[o.seqIdx];
+      const char *r = (useFirstStrand ? plus0 : (o.flags & OV_PLUS)) ? wm.seg : wm.rc;
+      int size, t0, p0;   // overhang length; first target / read position of the overhang
+      if (side == 0) { size = o.rs < o.ss ? o.rs : o.ss; t0 = o.ss - size; p0 = o.rs - size; }
+      else { int a = len - 1 - o.re, b = si.len - 1 - o.se; size = a < b ? a : b; t0 = o.se + 1; p0 = o.re + 1; }
+      const T4PW *w = ix.pw + si.pwOff + t0;
+      int mm = 0, good = 0, tmpBase = 0;
+      for (int base = 0; base < size; base += 64) {
+        const int k = base + wl;                                   // step k + 1 of the scan from the anchor outward
+        const int pos = side == 0 ? size - 1 - k : k;              // the left overhang is scanned from its end
+        const bool in = k < size;
+        const bool eq = in && baseEqualW(w[pos], r[p0 + pos]);
+        const unsigned long long bal = __ballot(eq);
+        const int tmp = tmpBase + __popcll(bal & ((wl == 63) ? ~0ull : ((2ull << wl) - 1ull)));
+        const unsigned long long gb = __ballot(eq && tmp > 0.75 * (k + 1));
+        if (gb) good = base + 64 - __clzll((long long)gb);
+        mm += __popcll(__ballot(in && !eq));
+        tmpBase += __popcll(bal);
+      }
+      if (wl == 0) {
+        ExtSide e;
+        e.size = (short)size; e.match = (short)(size - mm); e.mis = (short)mm; e.indel = 0; e.pending = 0;
+        if (size > 1 && !((size - mm) * 2 - mm * 2 >= size * 2 - 8)) { e.pending = 1; good = 0; }   // needs the banded DP
+        e.good = (short)good;
+        sides[q] = e;
+      }
     }
-    e.good = (short)good;
-    sides[q] = e;
   }
   __syncthreads();
   // E2: gapped sides, compacted into a list (wm.cand is dead here): first those whose direction bytes fit a quarter of a
@@ -2840,11 +2916,13 @@ void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
   __shared__ char s_seg[T4_MAXL + 8];
   __shared__ char s_rc[T4_MAXL + 8];
   __shared__ WaveState s_ws;
+  __shared__ unsigned long long s_gsort[CAP > 0 ? 1 : 8192];   // global-scratch tier: staging buffer of the hit sort
   WaveMem wm;
   if (CAP > 0) {
     wm.keys = s_keys; wm.pairs = s_pairs; wm.cand = s_pairs + C; wm.ov = s_ov; wm.fin = s_fin; wm.ord = s_ord;
     wm.cap = CAP; wm.maxOv = MAXOV; wm.maxFin = MAXOV; wm.candCap = C / 3 + 2; wm.ldsArrays = 1;
     wm.hitLimit = (wk.capLimit > 0 && wk.capLimit < CAP) ? wk.capLimit : CAP;
+    wm.ldsSort = nullptr; wm.ldsSortCap = 0;
   } else {
     size_t b = blockIdx.x;
     wm.keys = wk.gKeys + b * (size_t)wk.gCap;
@@ -2855,6 +2933,7 @@ void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
     wm.ord = wk.gOrd + b * (size_t)wk.gMaxOv;
     wm.cap = wk.gCap; wm.maxOv = wk.gMaxOv; wm.maxFin = wk.gMaxOv; wm.candCap = wk.gCap; wm.ldsArrays = 0;
     wm.hitLimit = wk.gCap;
+    wm.ldsSort = s_gsort; wm.ldsSortCap = CAP > 0 ? 0 : 8192;
   }
   wm.seg = s_seg; wm.rc = s_rc;
   DPScratch sc;
@@ -2880,6 +2959,8 @@ void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
       wg.fin = (OvRec *)(wk.gFin + b * (size_t)wk.gMaxOv * 10);
       wg.ord = wk.gOrd + b * (size_t)wk.gMaxOv;
       wg.cap = wk.gCap; wg.maxOv = wk.gMaxOv; wg.maxFin = wk.gMaxOv; wg.candCap = wk.gCap; wg.ldsArrays = 0; wg.hitLimit = wk.gCap;
+      wg.ldsSort = s_keys; wg.ldsSortCap = C;   // the LDS arrays are free now: the hit sort is staged through the key array
+      if (wk.capLimit > 0 && wk.capLimit < C) { int bsz = 64; while (bsz * 2 <= wk.capLimit) bsz *= 2; wg.ldsSortCap = bsz; }   // testing aid: small blocks
       __syncthreads();
       done = processRead<1>(ix, bv, wk, qa, wg, &s_ws, r, sc);
       if (tid() == 0 && done && wk.nextCount) atomicAdd(wk.nextCount + 2, 1);   // statistics: reads served this way
