@@ -62,7 +62,7 @@ def _stage1_worker(rank, world, port, argv, prefix, driver, q):
     q.put((rank, rc))
 
 
-def run_stage1_two_ranks(tmp_path, driver, pairs, cells, seed):
+def run_stage1_two_ranks(tmp_path, driver, pairs, cells, seed, world=2):
     """barcode-mode stage 1 on 2 ranks (trust4_amd/stage1_dist.py: cells sharded by rank, contig records all-gathered and
     renumbered on rank 0) must reproduce the single-process outputs byte for byte"""
     import filecmp
@@ -83,14 +83,14 @@ def run_stage1_two_ranks(tmp_path, driver, pairs, cells, seed):
     q = ctx.Queue()
     port = 29900 + (os.getpid() % 90)
     merged = str(tmp_path / "merged")
-    procs = [ctx.Process(target=_stage1_worker, args=(r, 2, port, argv, merged, driver, q)) for r in range(2)]
+    procs = [ctx.Process(target=_stage1_worker, args=(r, world, port, argv, merged, driver, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=400) for _ in range(2))
+    res = sorted(q.get(timeout=600) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert res == [(0, 0), (1, 0)]
+    assert res == [(r, 0) for r in range(world)]
     for suffix in ("_raw.out", "_final.out", "_assembled_reads.fa"):
         assert filecmp.cmp(single + suffix, merged + suffix, shallow=False), suffix
     assert open(single + "_raw.out").read().count(">") >= cells
@@ -107,6 +107,18 @@ def test_two_rank_barcode_stage1(tmp_path):
         subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, src, "-L" + os.path.dirname(lib), "-lt4hip_emu",
                         "-Wl,-rpath," + os.path.dirname(lib), "-lz", "-lpthread"], check=True)
     run_stage1_two_ranks(tmp_path, exe, 120, 7, 9)
+
+
+def test_eight_rank_barcode_stage1(tmp_path):
+    """world size 8 (one node's worth of ranks; more ranks than some shards have cells): the merged outputs are still the
+    single-process ones byte for byte"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_stage1_e2e import _emulated_driver
+    os.environ["HIPEMU_THREADS"] = "1"   # eight emulated ranks share this host's cores
+    try:
+        run_stage1_two_ranks(tmp_path, _emulated_driver(), 100, 11, 10, world=8)
+    finally:
+        os.environ.pop("HIPEMU_THREADS", None)
 
 
 @pytest.mark.gpu

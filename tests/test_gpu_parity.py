@@ -156,3 +156,37 @@ def test_novel_min_statistics(eng):
 def test_long_reads_and_limits(eng):
     from test_engine_emu import check_long_reads_and_limits
     check_long_reads_and_limits(eng, n=400)
+
+
+def test_read_with_more_than_32768_hits(eng):
+    """A gene segment that thousands of contigs share (50 036 hits for one k = 17 AssignRead query at only 100 k
+    pairs; the C gene of a chain sits in every contig of that chain): one read pass emits far more than the 32 768 hits /
+    4 096 overlaps round 1 refused. 2 400 contigs = a shared 110-bp stretch with private flanks; reads from the shared stretch.
+    hits, overlaps (> 128 per read), ExtendOverlap and AssignRead against the oracle."""
+    import random
+    rnd = random.Random(21)
+    rand = lambda n: "".join(rnd.choice("ACGT") for _ in range(n))
+    k = 9
+    shared = rand(110)
+    o = Oracle(k)
+    ix = eng.index(k)
+    for i in range(2400):
+        seq = rand(rnd.randint(20, 60)) + shared + rand(rnd.randint(20, 60))
+        a = o.add_novel("IGHC%d" % i, seq, 1, -1, None)
+        assert a == ix.add_contig("IGHC%d" % i, seq, -1, None)
+    o.set_hit_len_required(31)
+    ix.set_params(31, 10, 0.9).commit()
+    reads = [shared[5:105], shared, rand(25) + shared[:90], shared[30:] + rand(30)]
+    b = eng.upload(reads)
+    off, hits = ix.hits(b, 0, 0)
+    assert int(off[-1]) > 4 * 32768, int(off[-1])
+    assert t4check.check_hits(off, hits, reads, o) == []
+    cnt, ov = ix.overlaps(b, 0, 0, 4096)
+    assert int(cnt.max()) > 2000, cnt
+    assert t4check.check_overlaps(cnt, ov, reads, o) == []
+    aret, aout = ix.assign(b, 0)
+    for i, rd in enumerate(reads):
+        eret, eout = o.assign_read(rd, 0, -1)
+        assert int(aret[i]) == eret, (i, eret, int(aret[i]))
+        if eret != -1:
+            assert tuple(aout[i].tolist()) == tuple(eout)

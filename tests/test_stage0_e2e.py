@@ -197,3 +197,32 @@ def test_extractor_emulated(tmp_path):
     """the same driver source linked against the emulator build of the kernels (test infrastructure)"""
     exe = _emulated_extractor()
     run_case(tmp_path, exe, "paired")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_EXT), reason="oracle/_ref/fastq-extractor not built")
+def test_extractor_iupac_letters_emulated(tmp_path):
+    """Reads with IUPAC letters (FASTA input, some aligners' output): the candidate test looks at k-mer codes only, where
+    KmerCode::Append (KmerCode.hpp:99-106) takes every letter but N as a valid base (nucToNum & 3 = T), so the filter keeps and
+    drops exactly what the reference does (batches uploaded with T4_READS_KMERS_ONLY) and writes the reads as they came."""
+    fa = str(tmp_path / "ref.fa")
+    with gzip.open(REF_FA, "rb") as f, open(fa, "wb") as g:
+        shutil.copyfileobj(f, g)
+    rnd = random.Random(3)
+    pairs = stage0_input(13, 50, 120)
+    def spice(s):
+        s = list(s)
+        for _ in range(rnd.choice([0, 1, 1, 2, 5])):
+            if s:
+                s[rnd.randrange(len(s))] = rnd.choice("RYKMSWBDHV")
+        return "".join(s)
+    pairs = [(spice(a), spice(b)) for a, b in pairs]
+    f1, f2 = str(tmp_path / "in_1.fq"), str(tmp_path / "in_2.fq")
+    write_fq(f1, [p[0] for p in pairs])
+    write_fq(f2, [p[1] for p in pairs])
+    args = ["-f", fa, "-1", f1, "-2", f2]
+    ref_o, my_o = str(tmp_path / "ref"), str(tmp_path / "mine")
+    subprocess.run([REF_EXT, "-t", "1"] + args + ["-o", ref_o], check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([_emulated_extractor()] + args + ["-o", my_o], check=True)
+    for s in ("_1.fq", "_2.fq"):
+        assert filecmp.cmp(ref_o + s, my_o + s, shallow=False), s
+    assert open(ref_o + "_1.fq").read().count("\n") // 4 >= 30

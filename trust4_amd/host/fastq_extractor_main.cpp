@@ -28,7 +28,8 @@ inline int nucNum(char c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 
 bool isLowComplexity(const std::string &s) {   // FastqExtractor.cpp:105-127
   int cnt[5] = {0, 0, 0, 0, 0};
   const int n = (int)s.size();
-  for (char ch : s) { if (ch == 'N') ++cnt[4]; else { int v = nucNum(ch); ++cnt[v < 0 ? 0 : v]; } }
+  // letters other than ACGTN: the reference increments cnt[nucToNum = -1], i.e. nothing this function looks at
+  for (char ch : s) { if (ch == 'N') ++cnt[4]; else { int v = nucNum(ch); if (v >= 0) ++cnt[v]; } }
   if (cnt[0] >= n / 2 || cnt[1] >= n / 2 || cnt[2] >= n / 2 || cnt[3] >= n / 2 || cnt[4] >= n / 10) return true;
   int low = 0;
   for (int i = 0; i < 4; ++i) if (cnt[i] <= 2) ++low;

@@ -1164,6 +1164,19 @@ int main(int argc, char *argv[]) {
   if (useCells) {
     int64_t qb = 0, rq = 0, im = 0, by = 0; double sq = 0, ss = 0;
     t4_cellset_counters(cellSet, &qb, &rq, &im, &by, &sq, &ss);
+    mark("outputs_written");
+    if (const char *sj = getenv("T4_STATS_JSON")) {
+      FILE *fp = fopen(sj, "w");
+      if (fp) {
+        fprintf(fp, "{\"reads\": %d, \"threads\": %d, \"phases_s\": {", readCnt, threadCnt);
+        for (size_t i = 0; i < phaseMarks.size(); ++i) fprintf(fp, "%s\"%s\": %.4f", i ? ", " : "", phaseMarks[i].first.c_str(), phaseMarks[i].second);
+        fprintf(fp, "}, \"rough_annotation\": {\"reads\": %lld, \"hits\": %lld, \"kernel_ms\": %.3f}, ", annotReads, annotHits, annotKernelMs);
+        fprintf(fp, "\"cells\": {\"query_batches\": %lld, \"reads_queried\": %lld, \"images_staged\": %lld, \"bytes_staged\": %lld, \"query_wall_s\": %.3f, \"stage_wall_s\": %.3f}, ",
+                (long long)qb, (long long)rq, (long long)im, (long long)by, sq, ss);
+        fprintf(fp, "\"contigs\": %d, \"assembled_reads\": %d}\n", t4_cellset_size(cellSet), (int)assembledReadIdx.size());
+        fclose(fp);
+      }
+    }
     PrintLog("Finish assembly. (%lld cells; GPU query batches %lld with %lld reads in %.2f s; %lld cell images, %.1f MB, staged in %.2f s)",
              (long long)barcodeIntToStr.size(), (long long)qb, (long long)rq, sq, (long long)im, by / 1e6, ss);
     t4_cellset_destroy(cellSet);

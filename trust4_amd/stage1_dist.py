@@ -90,7 +90,19 @@ def main(argv=None, driver=None):
     cmd = [driver] + argv + ["-o", shard_prefix]
     if world > 1:
         cmd += ["--cellShard", "%d/%d" % (rank, world)]
+    env["T4_STATS_JSON"] = shard_prefix + "_stats.json"
+    import time
+    t0 = time.perf_counter()
     subprocess.run(cmd, check=True, env=env)
+    t_run = time.perf_counter() - t0
+    try:   # where this rank's time went (phases of trust4-hip; everything before "trimmed_ready" is replicated on every rank)
+        import json
+        ph = json.load(open(shard_prefix + "_stats.json"))["phases_s"]
+        sys.stderr.write("stage1_dist rank %d/%d: %.2f s; replicated phases (parse, counts, sort, rough annotation, trim) %.2f s, Add pass of this rank's cells %.2f s, outputs %.2f s\n"
+                         % (rank, world, t_run, ph["trimmed_ready"], ph["assembled"] - ph["trimmed_ready"], ph["outputs_written"] - ph["assembled"]))
+        os.remove(shard_prefix + "_stats.json")
+    except Exception:   # noqa: BLE001  (reporting only)
+        pass
     if world == 1:
         for suffix in ("_raw.out", "_final.out", "_assembled_reads.fa"):
             os.replace(shard_prefix + suffix, prefix + suffix)
