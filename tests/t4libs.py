@@ -36,7 +36,8 @@ def _b(s):
 
 
 def build_checkers():
-    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"], check=True)
+    import sys
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "all"], check=True, stdout=sys.stderr)   # bench.py's stdout is ONE JSON line
     so = os.path.join(ROOT, "tools", "libt4synth.so")
     src = os.path.join(ROOT, "tools", "t4synth.c")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
