@@ -84,6 +84,9 @@ struct t4_ctx {
   size_t aqInBytes = 0, aqOutBytes = 0;
   unsigned char *aqPool = nullptr, *aqPoolDev = nullptr;   // result records of t4_add_query*: pinned host memory the kernels write
   int aqPoolCap = 0;
+  T4OverlapOut *aqRecDev = nullptr;   // device copy of the overlap records + the read of each, for the extension launch
+  int *aqRecRead = nullptr;
+  int aqRecCap = 0;
   int64_t aqCalls = 0, aqReads = 0, aqGlobalLaunches = 0, aqGlobalReads = 0, aqRecords = 0;
   double aqSecPack = 0, aqSecFirst = 0, aqSecGlobal = 0;
   double aqKernelMs = 0;    // HIP-event time of the query kernels of all AddRead query calls (per call: first launch .. last kernel)
@@ -242,6 +245,8 @@ void t4_destroy(t4_ctx *c) {
   if (c->aqInHost) (void)hipHostFree(c->aqInHost);
   if (c->aqOutHost) (void)hipHostFree(c->aqOutHost);
   if (c->aqPool) (void)hipHostFree(c->aqPool);
+  if (c->aqRecDev) (void)hipFree(c->aqRecDev);
+  if (c->aqRecRead) (void)hipFree(c->aqRecRead);
   for (void *p : ptrs) if (p) (void)hipFree(p);
   for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1309,6 +1314,20 @@ int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
     qa.outBase = (int *)(c->aqOut + pBase); qa.poolCursor = (unsigned *)(c->aqOut + pTail + 24); qa.poolCap = c->aqPoolCap;
     qa.strandPerRead = (const int *)(c->aqIn + oSt); qa.factorPerRead = (const double *)(c->aqIn + oFa);
     if (views) { qa.views = views; qa.viewOf = (const int *)(c->aqIn + oVw); }
+    // one big set: the ExtendOverlap calls of reads with more than this many overlaps run in their own launch (0: never)
+    static const int deferMin = getenv("T4_AQ_EXTEND_DEFER") ? atoi(getenv("T4_AQ_EXTEND_DEFER")) : 64;
+    const bool extendLater = deferMin > 0 && !views && !smallFirst;
+    if (extendLater) {
+      if (c->aqRecCap < c->aqPoolCap) {
+        if (c->aqRecDev) (void)hipFree(c->aqRecDev);
+        if (c->aqRecRead) (void)hipFree(c->aqRecRead);
+        c->aqRecDev = nullptr; c->aqRecRead = nullptr;
+        HIPCHK(c, hipMalloc(&c->aqRecDev, sizeof(T4OverlapOut) * (size_t)c->aqPoolCap));
+        HIPCHK(c, hipMalloc(&c->aqRecRead, sizeof(int) * (size_t)c->aqPoolCap));
+        c->aqRecCap = c->aqPoolCap;
+      }
+      qa.extendLater = deferMin; qa.outDev = c->aqRecDev; qa.recRead = c->aqRecRead;
+    }
     static const int bigThreads = getenv("T4_AQ_THREADS") ? atoi(getenv("T4_AQ_THREADS")) : 512;   // workgroup of the 8192-hit tier of this path
     const int threads = (!smallFirst && bigThreads == 512) ? 512 : 256;
     const int grid0 = smallFirst ? (n < c->cus * TIER_BLOCKS_PER_CU[0] ? n : c->cus * TIER_BLOCKS_PER_CU[0]) : (nFirst > 0 ? nFirst : 1);
@@ -1353,6 +1372,11 @@ int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
       HIPCHK(c, hipGetLastError());
     }
     if (nDirect > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->evG, 0));
+    if (extendLater) {   // all records of the batch, spread over the chip
+      const int grid = c->cus * 16;
+      hipLaunchKernelGGL(t4k::extendKernel, dim3(grid), dim3(64), 0, c->stream, base, bv, qa, 0);
+      HIPCHK(c, hipGetLastError());
+    }
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipMemcpyAsync(c->aqOutHost, c->aqOut, outBytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1392,8 +1416,13 @@ int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
       w2.gCap = G_CAP; w2.gMaxOv = G_MAXOV;
       w2.dpRows = c->dpRows; w2.dpDir = c->dpDir;
       HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+      const int recsBefore = (int)*(const unsigned *)(c->aqOutHost + pTail + 24);
       launchTier<0, 0, G_THREADS>(overflow, c->stream, base, bv, w2, qa);
       HIPCHK(c, hipGetLastError());
+      if (extendLater) {
+        hipLaunchKernelGGL(t4k::extendKernel, dim3(c->cus * 16), dim3(64), 0, c->stream, base, bv, qa, recsBefore < c->aqPoolCap ? recsBefore : c->aqPoolCap);
+        HIPCHK(c, hipGetLastError());
+      }
       HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
       HIPCHK(c, hipMemcpyAsync(c->aqOutHost, c->aqOut, outBytes, hipMemcpyDeviceToHost, c->stream));
       HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1408,6 +1437,7 @@ int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
       else if (status[i]) return fail(c, T4_ERR_UNSUPPORTED, "read %d exceeds the engine limits (status %d: %s)", i, status[i],
                                       status[i] == 2 ? "more k-mer hits or overlaps than the global tier holds" : "gap DP or contig count beyond scratch");
     }
+    if (*(const unsigned *)(o + pTail + 28)) return fail(c, T4_ERR_UNSUPPORTED, "an overhang alignment of this batch exceeds the extension kernel's direction buffer");
     if (poolFull) {   // more result records than the pool holds: a larger pool, and the whole call again
       if (attempt >= 8) return fail(c, T4_ERR_UNSUPPORTED, "result pool of %d records overflows", c->aqPoolCap);
       (void)hipHostFree(c->aqPool);

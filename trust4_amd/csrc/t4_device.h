@@ -147,6 +147,13 @@ struct T4QueryArgs {
   int *outBase;
   unsigned *poolCursor;
   int poolCap;
+  // mode 4 of one big set: the ExtendOverlap calls of a read that returned more than `extendLater` overlaps (0: never) run
+  // in a launch of their own (extendKernel: a read that overlaps thousands of contigs spreads over the chip instead of
+  // occupying one workgroup); the query kernel leaves a device copy of those records and marks every record with its read
+  // (-1: extended by the query kernel)
+  int extendLater;
+  T4OverlapOut *outDev;
+  int *recRead;
   // per-read set images (per-barcode contig sets): read r is matched against views[viewOf[r]]
   const T4IndexView *views;
   const int *viewOf;

@@ -2656,6 +2656,17 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
     if (base < 0) { if (lane == 0) { wk.status[r] = 3; qa.counts[r] = 0; } return true; }
     if (lane == 0) qa.outBase[r] = (int)base;
     for (int i = lane; i < n; i += NT) { storeOverlap(qa.out + base + i, wm.fin[i]); wm.ord[i] = (unsigned short)i; }
+    if (qa.extendLater) {
+      // a read with many overlaps leaves their extensions to extendKernel (spread over the chip); the others extend here,
+      // where a separate launch would only add its latency to the round
+      const bool defer = n > qa.extendLater;
+      for (int i = lane; i < n; i += NT) qa.recRead[base + i] = defer ? (int)r : -1;
+      if (defer) {
+        for (int i = lane; i < n; i += NT) storeOverlap(qa.outDev + base + i, wm.fin[i]);
+        if (lane == 0) qa.counts[r] = ret;
+        return true;
+      }
+    }
     __syncthreads();
     PHASE_MARK(ws, 16);
     extendOverlaps(ix, wm, ws, n, len, false, qa.factorPerRead[r], sides, dirbuf, res);
@@ -2975,6 +2986,68 @@ void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
     __syncthreads();
     w = s_nextW;
     __syncthreads();
+  }
+}
+
+// SeqSet::ExtendOverlap (SeqSet.hpp:1165-1277) of every record an AddRead query batch returned (T4QueryArgs::extendLater):
+// one wavefront per block takes T4_EXT_NREC consecutive records at a time (of one read: a block's range is cut at read
+// boundaries), rebuilds the read's characters from its packed words and runs the same extendOverlaps() the query kernel runs
+// inside a workgroup. The records of one read no longer wait for each other in one workgroup's eight wavefronts: a read that
+// overlaps two thousand contigs becomes a few hundred independent blocks.
+#define T4_EXT_NREC 8
+__global__ __launch_bounds__(64) void extendKernel(T4IndexView ix, T4BatchView bv, T4QueryArgs qa, int recBegin) {
+  __shared__ OvRec s_fin[T4_EXT_NREC];
+  __shared__ unsigned short s_ord[T4_EXT_NREC];
+  __shared__ ExtSide s_sides[2 * T4_EXT_NREC];
+  __shared__ ExtOut s_res[T4_EXT_NREC];
+  __shared__ unsigned s_cand[2 * T4_EXT_NREC + 2];
+  __shared__ unsigned long long s_dir[1024];   // 8 KiB of direction bytes: four sides of up to 170 bases at a time, longer ones one at a time
+  __shared__ char s_seg[T4_MAXL + 8];
+  __shared__ char s_rc[T4_MAXL + 8];
+  __shared__ WaveState s_ws;
+  WaveMem wm;
+  wm.keys = s_dir; wm.pairs = (unsigned *)s_sides; wm.ov = (OvRec *)s_res; wm.fin = s_fin; wm.ord = s_ord; wm.cand = s_cand;
+  wm.seg = s_seg; wm.rc = s_rc;
+  wm.cap = 1024; wm.maxOv = T4_EXT_NREC; wm.maxFin = T4_EXT_NREC; wm.candCap = 2 * T4_EXT_NREC + 2; wm.ldsArrays = 1;
+  wm.ldsSort = nullptr; wm.ldsSortCap = 0; wm.hitLimit = 0;
+  const int lane = tid();
+  const int nRec = (int)*qa.poolCursor < qa.poolCap ? (int)*qa.poolCursor : qa.poolCap;
+  for (int g = recBegin + (int)blockIdx.x * T4_EXT_NREC; g < nRec; g += (int)gridDim.x * T4_EXT_NREC) {
+    int i0 = g;
+    const int gEnd = g + T4_EXT_NREC < nRec ? g + T4_EXT_NREC : nRec;
+    while (i0 < gEnd) {
+      const int r = qa.recRead[i0];
+      int i1 = i0 + 1;
+      while (i1 < gEnd && qa.recRead[i1] == r) ++i1;
+      if (r < 0) { i0 = i1; continue; }   // extended by the query kernel itself
+      const int n = i1 - i0, len = bv.len[r];
+      if (lane == 0) { s_ws.overflow = 0; s_ws.unsupported = 0; }
+      loadSegment(bv, r, 0, len, wm);
+      if (lane < n) {
+        const T4OverlapOut t = qa.outDev[i0 + lane];
+        OvRec o;
+        o.seqIdx = t.seqIdx; o.rs = t.readStart; o.re = t.readEnd; o.ss = t.seqStart; o.se = t.seqEnd;
+        o.matchCnt = t.matchCnt; o.indelCnt = t.indelCnt; o.chainPos = 0; o.chainLen = 0;
+        o.flags = t.strand == 1 ? OV_PLUS : 0;   // contig sets only (t4_add_query refuses reference sets)
+        s_fin[lane] = o; s_ord[lane] = (unsigned short)lane;
+      }
+      __syncthreads();
+      extendOverlaps(ix, wm, &s_ws, n, len, false, qa.factorPerRead[r], s_sides, (unsigned char *)s_dir, s_res);
+      if (lane < n) {
+        const T4OverlapOut in = qa.outDev[i0 + lane];
+        const ExtOut e = s_res[lane];
+        T4OverlapOut t;
+        t.seqIdx = in.seqIdx; t.readStart = e.rs; t.readEnd = e.re; t.seqStart = e.ss; t.seqEnd = e.se;
+        t.strand = in.strand; t.matchCnt = e.matchCnt;
+        if (e.simFail) { t.indelCnt = in.indelCnt; t.similarity = in.similarity; }
+        else { t.indelCnt = 0; t.similarity = (double)t.matchCnt / (double)e.den; }
+        qa.outExt[i0 + lane] = t;
+        qa.ret[i0 + lane] = e.ret;
+      }
+      if (lane == 0 && s_ws.unsupported) qa.poolCursor[1] = 1u;   // an overhang beyond the direction buffer (reads of more than 600 bases)
+      __syncthreads();
+      i0 = i1;
+    }
   }
 }
 

@@ -639,21 +639,30 @@ int main(int argc, char *argv[]) {
   mark("sorted");
   PrintLog("Finish sorting the reads.");
 
-  // ---- rough annotation on the GPU (main.cpp:1084-1120)
+  // ---- rough annotation on the GPU (main.cpp:1084-1120): every distinct read once, in chunks (a 20 M-pair input must not need
+  // all packed reads and all 160-byte results at the same time)
   {
-    std::string bases; std::vector<int64_t> off(1, 0); std::vector<int> firstOf;
-    for (int i = 0; i < readCnt; ++i)
-      if (i == 0 || sortedReads[i].read != sortedReads[i - 1].read) { bases += sortedReads[i].read; off.push_back((int64_t)bases.size()); firstOf.push_back(i); }
-    const int n = (int)firstOf.size();
-    t4_batch *batch = nullptr;
-    if ((rc = t4_reads_upload(ctx, bases.data(), off.data(), nullptr, n, &batch))) die(ctx, "t4_reads_upload", rc);
-    std::vector<t4_overlap> out(4 * (size_t)n);
-    if ((rc = t4_annotate_rough(refSet, batch, out.data()))) die(ctx, "t4_annotate_rough", rc);
-    { t4_stats st; if (t4_last_stats(ctx, &st) == T4_OK) { annotKernelMs += st.chain_kernel_ms; annotHits += st.total_hits; annotReads += st.reads; } }
-    t4_batch_destroy(batch);
-    for (int k = -1, i = 0; i < readCnt; ++i) {
-      if (k + 1 < n && firstOf[k + 1] == i) ++k;
-      for (int j = 0; j < 4; ++j) sortedReads[i].g[j] = out[4 * (size_t)k + j];
+    const size_t CHUNK = getenv("T4_ANNOT_CHUNK") ? (size_t)atol(getenv("T4_ANNOT_CHUNK")) : ((size_t)4 << 20);
+    std::string bases; std::vector<int64_t> off; std::vector<int> firstOf; std::vector<t4_overlap> out;
+    int i = 0;
+    while (i < readCnt) {
+      bases.clear(); off.assign(1, 0); firstOf.clear();
+      const int chunkBegin = i;
+      for (; i < readCnt && firstOf.size() < CHUNK; ++i)
+        if (i == 0 || sortedReads[i].read != sortedReads[i - 1].read) { bases += sortedReads[i].read; off.push_back((int64_t)bases.size()); firstOf.push_back(i); }
+      while (i < readCnt && sortedReads[i].read == sortedReads[i - 1].read) ++i;   // the copies of the chunk's last read belong to it
+      const int n = (int)firstOf.size();
+      if (n == 0) break;
+      t4_batch *batch = nullptr;
+      if ((rc = t4_reads_upload(ctx, bases.data(), off.data(), nullptr, n, &batch))) die(ctx, "t4_reads_upload", rc);
+      out.resize(4 * (size_t)n);
+      if ((rc = t4_annotate_rough(refSet, batch, out.data()))) die(ctx, "t4_annotate_rough", rc);
+      { t4_stats st; if (t4_last_stats(ctx, &st) == T4_OK) { annotKernelMs += st.chain_kernel_ms; annotHits += st.total_hits; annotReads += st.reads; } }
+      t4_batch_destroy(batch);
+      for (int k = -1, t = chunkBegin; t < i; ++t) {
+        if (k + 1 < n && firstOf[k + 1] == t) ++k;
+        for (int j = 0; j < 4; ++j) sortedReads[t].g[j] = out[4 * (size_t)k + j];
+      }
     }
   }
   mark("rough_annotation");
