@@ -324,3 +324,25 @@ def test_bulk_live_set_paths_emulated(tmp_path, env):
 @pytest.mark.parametrize("env", [{}, {"T4_AQ_CAP_LIMIT": "2000"}, {"T4_AQ_FORCE_GLOBAL": "1"}, {"T4_AQ_EXTEND_DEFER": "2"}])
 def test_bulk_live_set_paths_gpu(tmp_path, env):
     _bulk_case(tmp_path, _driver(), 6000, 120, 12, env, threads="8")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
+def test_bulk_paired_needs_skip_mate_extension_emulated(tmp_path):
+    """Paired-end input without barcodes and without --skipMateExtension: the reference would run its mate-pair extension and the
+    annotator reads _final.out, so the driver refuses (exit 1, before touching the input) instead of writing the raw assembly under
+    that name; T4_ALLOW_RAW_FINAL=1 gives that file knowingly. Single-end input needs no flag (main.cpp:2018)."""
+    fa = str(tmp_path / "ref.fa")
+    _gunzip(REF_FA, fa)
+    pre = str(tmp_path / "b")
+    subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, "60", "3", "5", pre], check=True, stdout=subprocess.DEVNULL)
+    exe = _emulated_driver()
+    args = ["-f", fa, "-1", pre + "_1.fq", "-2", pre + "_2.fq", "-o", str(tmp_path / "x")]
+    p = subprocess.run([exe] + args, stderr=subprocess.PIPE, text=True)
+    assert p.returncode != 0 and "--skipMateExtension" in p.stderr and not os.path.exists(str(tmp_path / "x_final.out"))
+    subprocess.run([exe] + args, check=True, env=dict(os.environ, T4_ALLOW_RAW_FINAL="1"), stderr=subprocess.DEVNULL)
+    assert filecmp.cmp(str(tmp_path / "x_raw.out"), str(tmp_path / "x_final.out"), shallow=False)
+    ref_out, my_out = str(tmp_path / "ref_u"), str(tmp_path / "mine_u")
+    subprocess.run([REF_BIN, "-t", "1", "-f", fa, "-u", pre + "_1.fq", "-o", ref_out], check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([exe, "-f", fa, "-u", pre + "_1.fq", "-o", my_out], check=True, stderr=subprocess.DEVNULL)
+    for suffix in ("_raw.out", "_assembled_reads.fa", "_final.out"):
+        assert filecmp.cmp(ref_out + suffix, my_out + suffix, shallow=False), suffix
