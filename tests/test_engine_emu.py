@@ -451,3 +451,128 @@ def test_work_distribution_is_not_observable(emu_engine, ref_index, monkeypatch)
     rev = emu_engine.upload(reads[::-1])                                # another list order, another batch composition
     a3 = ref_index.annotate_rough(rev).copy()
     assert a1.tobytes() == a3[::-1].tobytes()
+
+
+class LiveImage:
+    """A Python-side replica of the layout t4_index_apply_delta patches (the role HostIndex plays in t4_assembler.cpp): table on
+    the k-mer code, posting lists with room to grow, one arena of bases. add() follows KmerIndex::BuildIndexFromRead
+    (KmerIndex.hpp:118-141) as the oracle's add_novel does; flush() ships what changed since the last flush."""
+
+    def __init__(self, k, table_slots=64):
+        self.k, self.slots = k, table_slots
+        self.keys = {}            # code -> [slot, start, cnt, cap]
+        self.occ = set()
+        self.post = []            # flat arena of (idx, offset) / None
+        self.seqs = []            # (base_off, cons, pw bytes, name)
+        self.bases_used = 0
+        self.dirty_keys, self.dirty_post, self.dirty_seq = set(), set(), set()
+        self.rebuilt = True
+
+    def _slot(self, code):
+        from trust4_amd.api import mix64
+        s = mix64(code) & (self.slots - 1)
+        while s in self.occ:
+            s = (s + 1) & (self.slots - 1)
+        self.occ.add(s)
+        return s
+
+    def _insert(self, code, idx, off):
+        if code not in self.keys:
+            if 2 * (len(self.keys) + 1) > self.slots:   # re-hash: every key moves
+                self.slots *= 2
+                self.occ = set()
+                for c in self.keys:
+                    self.keys[c][0] = self._slot(c)
+                self.rebuilt = True
+            self.keys[code] = [self._slot(code), 0, 0, 0]
+        e = self.keys[code]
+        if e[2] == e[3]:
+            ncap = max(2, 2 * e[3])
+            start = len(self.post)
+            self.post += [None] * ncap
+            for t in range(e[2]):
+                self.post[start + t] = self.post[e[1] + t]
+                self.dirty_post.add(start + t)
+            e[1], e[3] = start, ncap
+        self.post[e[1] + e[2]] = (idx, off)
+        self.dirty_post.add(e[1] + e[2])
+        e[2] += 1
+        self.dirty_keys.add(code)
+
+    def add(self, name, cons, weights=None):
+        idx = len(self.seqs)
+        num = {"A": 0, "C": 1, "G": 2, "T": 3}
+        code, prev, invalid = 0, 0, -1
+        mask = (1 << (2 * self.k)) - 1
+        for i, ch in enumerate(cons):
+            if invalid != -1:
+                invalid += 1
+            code = ((code << 2) & mask) | (num.get(ch, 3) & 3)   # nucToNum['N' - 'A'] & 3 is 0 in the reference; N windows are invalid anyway
+            if ch == "N":
+                invalid = 0
+            if invalid >= self.k:
+                invalid = -1
+            if i >= self.k - 1 and len(cons) >= self.k:
+                if invalid == -1 and (i == self.k or code != prev):
+                    self._insert(code, idx, i - self.k + 1)
+                prev = code
+        pw = bytearray()
+        for i, ch in enumerate(cons):
+            w = [0, 0, 0, 0]
+            if weights is not None:
+                w = [int(x) for x in weights[i]]
+            elif ch != "N":
+                w[num[ch]] = 1
+            sm = sum(w)
+            pw.append((16 if sm == 0 else 0) | sum((1 << x) for x in range(4) if sm < 3 * w[x]))
+        pw.append(16)
+        self.seqs.append((self.bases_used, cons, bytes(pw), name))
+        self.bases_used += len(cons) + 1 + 17   # room nobody uses: arenas need not be dense
+        self.dirty_seq.add(idx)
+        return idx
+
+    def flush(self, ix):
+        keys = self.keys if self.rebuilt else {c: self.keys[c] for c in self.dirty_keys}
+        slots = [(e[0], c, e[1], e[2]) for c, e in keys.items()]
+        runs, cur = [], None
+        for at in sorted(self.dirty_post):
+            if cur is not None and at == cur[0] + len(cur[1]):
+                cur[1].append(self.post[at])
+            else:
+                cur = [at, [self.post[at]]]
+                runs.append(cur)
+        seqs = [(i, self.seqs[i][0], len(self.seqs[i][1]), -1, self.seqs[i][3]) for i in sorted(self.dirty_seq)]
+        bases = [(self.seqs[i][0], self.seqs[i][1].encode() + b"\0", self.seqs[i][2]) for i in sorted(self.dirty_seq)]
+        ix.apply_delta(self.slots, 1 if self.rebuilt else 0, len(self.post) + 8, self.bases_used + 8, len(self.seqs) + 4, len(self.seqs),
+                       max(len(x[1]) for x in self.seqs), slots, [(r[0], r[1]) for r in runs], seqs, bases)
+        self.dirty_keys, self.dirty_post, self.dirty_seq, self.rebuilt = set(), set(), set(), False
+
+
+def check_apply_delta(eng, seed=31, k=9):
+    """t4_index_apply_delta through the C ABI alone (no t4_assembler): the image of a contig set is written by position from a
+    Python replica, queried (hits, overlaps, AssignRead vs the oracle holding the same contigs), then GROWN by a second delta
+    (more contigs: longer lists that move, new keys, a re-hashed table) and queried again."""
+    contigs, reads, _ = make_novel_case(seed, k)
+    o = Oracle(k)
+    img = LiveImage(k)
+    ix = eng.index(k).set_params(31, 10, 0.9)
+    half = len(contigs) // 2
+    for part in (contigs[:half], contigs[half:]):
+        for name, seq, bc, w in part:
+            assert o.add_novel(name, seq, 1, bc, w) == img.add(name, seq, w)
+        o.set_hit_len_required(31)
+        img.flush(ix)
+        b = eng.upload(reads)
+        off, hits = ix.hits(b, 0, 0)
+        assert t4check.check_hits(off, hits, reads, o) == []
+        cnt, ov = ix.overlaps(b, 0, 0, 128)
+        assert t4check.check_overlaps(cnt, ov, reads, o) == []
+        aret, aout = ix.assign(b, 0)
+        for i, rd in enumerate(reads):
+            eret, eout = o.assign_read(rd, 0, -1)
+            assert int(aret[i]) == eret and (eret == -1 or tuple(aout[i].tolist()) == tuple(eout)), i
+    assert (cnt > 0).sum() > len(reads) // 3
+
+
+def test_apply_delta_through_the_abi(emu_engine):
+    check_apply_delta(emu_engine)

@@ -190,3 +190,9 @@ def test_read_with_more_than_32768_hits(eng):
         assert int(aret[i]) == eret, (i, eret, int(aret[i]))
         if eret != -1:
             assert tuple(aout[i].tolist()) == tuple(eout)
+
+
+def test_apply_delta_through_the_abi(eng):
+    from test_engine_emu import check_apply_delta
+    check_apply_delta(eng)
+    check_apply_delta(eng, seed=32, k=11)

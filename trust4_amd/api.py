@@ -24,6 +24,27 @@ class T4Error(RuntimeError):
         self.code = code
 
 
+class SeqRecord(C.Structure):   # t4_seq_record
+    _fields_ = [("base_off", C.c_int64), ("len", C.c_int32), ("barcode", C.c_int32), ("name", C.c_char * 8)]
+
+
+class IndexDelta(C.Structure):   # t4_index_delta
+    _fields_ = [("table_slots", C.c_int64), ("table_rebuilt", C.c_int32), ("seq_cap", C.c_int32), ("post_cap", C.c_int64),
+                ("base_cap", C.c_int64), ("nseq", C.c_int32), ("max_seq_len", C.c_int32),
+                ("n_slots", C.c_int64), ("slot", C.c_void_p), ("slot_code", C.c_void_p), ("slot_start", C.c_void_p), ("slot_cnt", C.c_void_p),
+                ("n_post_runs", C.c_int64), ("post_at", C.c_void_p), ("post_len", C.c_void_p), ("post_data", C.c_void_p),
+                ("n_seqs", C.c_int32), ("seq_id", C.c_void_p), ("seq", C.c_void_p),
+                ("n_base_runs", C.c_int64), ("base_at", C.c_void_p), ("base_len", C.c_void_p), ("base_cons", C.c_void_p), ("base_pw", C.c_void_p)]
+
+
+def mix64(z):
+    """slot hash of the table of a live set (== t4k::mix64): first free slot of mix64(code) & (slots - 1), +1, ..."""
+    m = (1 << 64) - 1
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    return z ^ (z >> 31)
+
+
 def lib_path():
     """The product library. T4_LIB overrides it (the CPU test-suite points it at the emulator build)."""
     return os.environ.get("T4_LIB", os.path.join(HERE, "libt4hip.so"))
@@ -42,6 +63,7 @@ def _load():
         "t4_index_set_params": (I, [P, I, I, C.c_double]), "t4_index_load_ref_fasta": (I, [P, C.c_char_p]),
         "t4_index_add_ref_record": (I, [P, C.c_char_p, C.c_char_p, C.POINTER(I)]),
         "t4_index_add_contig": (I, [P, C.c_char_p, C.c_char_p, I, P, C.POINTER(I)]),
+        "t4_index_apply_delta": (I, [P, C.POINTER(IndexDelta)]), "t4_reads_upload_flags": (I, [P, P, P, P, L, I, C.POINTER(P)]),
         "t4_index_commit": (I, [P]), "t4_index_size": (I, [P]), "t4_index_seq_len": (I, [P, I]),
         "t4_index_seq_name": (C.c_char_p, [P, I]), "t4_index_seq_consensus": (C.c_char_p, [P, I]),
         "t4_reads_upload": (I, [P, P, P, P, L, C.POINTER(P)]), "t4_batch_destroy": (None, [P]),
@@ -359,6 +381,36 @@ class Index:
 
     def commit(self):
         self.eng.check(self.eng.lib.t4_index_commit(self.h))
+        return self
+
+    def apply_delta(self, table_slots, table_rebuilt, post_cap, base_cap, seq_cap, nseq, max_seq_len, slots=(), post_runs=(), seqs=(), base_runs=()):
+        """t4_index_apply_delta. slots: (slot, code, start, cnt); post_runs: (at, [(idx, offset), ...]); seqs: (id, base_off, len,
+        barcode, name); base_runs: (at, consensus bytes, predicate bytes)."""
+        d = IndexDelta()
+        d.table_slots, d.table_rebuilt, d.post_cap, d.base_cap, d.seq_cap, d.nseq, d.max_seq_len = table_slots, table_rebuilt, post_cap, base_cap, seq_cap, nseq, max_seq_len
+        keep = []
+
+        def arr(values, dtype):
+            a = np.ascontiguousarray(np.array(list(values), dtype=dtype))
+            keep.append(a)
+            return a.ctypes.data_as(C.c_void_p)
+        d.n_slots = len(slots)
+        d.slot, d.slot_code = arr((x[0] for x in slots), np.int64), arr((x[1] for x in slots), np.uint64)
+        d.slot_start, d.slot_cnt = arr((x[2] for x in slots), np.uint32), arr((x[3] for x in slots), np.uint32)
+        d.n_post_runs = len(post_runs)
+        d.post_at, d.post_len = arr((r[0] for r in post_runs), np.int64), arr((len(r[1]) for r in post_runs), np.int32)
+        d.post_data = arr((v for r in post_runs for p in r[1] for v in p), np.int32)
+        recs = (SeqRecord * max(1, len(seqs)))()
+        for i, (sid, off, ln, bc, nm) in enumerate(seqs):
+            recs[i].base_off, recs[i].len, recs[i].barcode, recs[i].name = off, ln, bc, nm.encode()[:8]
+        keep.append(recs)
+        d.n_seqs, d.seq_id, d.seq = len(seqs), arr((x[0] for x in seqs), np.int32), C.cast(recs, C.c_void_p)
+        d.n_base_runs = len(base_runs)
+        d.base_at, d.base_len = arr((r[0] for r in base_runs), np.int64), arr((len(r[1]) for r in base_runs), np.int32)
+        cons, pw = b"".join(r[1] for r in base_runs), b"".join(r[2] for r in base_runs)
+        keep += [cons, pw]
+        d.base_cons, d.base_pw = C.cast(C.c_char_p(cons), C.c_void_p), C.cast(C.c_char_p(pw), C.c_void_p)
+        self.eng.check(self.eng.lib.t4_index_apply_delta(self.h, C.byref(d)))
         return self
 
     def size(self):

@@ -1146,28 +1146,27 @@ int t4_assembler::flushLive() {
 void t4_assembler::registerKmers(Cached &e, int slotId) {
   auto t0_ = std::chrono::steady_clock::now();
   struct Tm { double &acc; std::chrono::steady_clock::time_point t0; ~Tm() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tm_{secRegister, t0_};
-  std::string rcs;
-  reverseComplement(rcs, e.read);
-  static thread_local std::vector<std::pair<uint64_t, int>> codes;   // (code, strand)
-  codes.clear();
-  for (int st = 0; st < 2; ++st) {
-    const std::string &r = st ? rcs : e.read;
-    if ((int)r.size() < k) continue;
+  // one reference per occurrence (a k-mer that occurs twice in the read is examined twice, each time for one occurrence: the
+  // same verdicts, a tolerance budget spent a little faster); the reverse strand's codes are the reverse complements of the
+  // forward ones, position by position
+  const int len = (int)e.read.size();
+  if (len >= k) {
     KCode kc(k);
-    for (int i = 0; i < (int)r.size(); ++i) {
-      kc.append(r[i]);
+    const uint64_t top = 2ull * (uint64_t)(k - 1);
+    uint64_t rcCode = 0;
+    int sinceN = 0;   // bases since the last N (k-mer valid once k of them)
+    for (int i = 0; i < len; ++i) {
+      const char c = e.read[i];
+      kc.append(c);
+      const int v = nucNum(c);
+      rcCode = (rcCode >> 2) | ((uint64_t)(3 - (v < 0 ? 0 : v)) << top);
+      sinceN = c == 'N' ? 0 : sinceN + 1;
       if (i < k - 1 || !kc.valid()) continue;
-      codes.push_back({kc.code, st});
+      (void)sinceN;
+      winKmers.add(kc.code, index.bucket(kc.code, e.barcode), KOcc{e.uid, slotId, 1, 0, -1});
+      winKmers.add(rcCode, index.bucket(rcCode, e.barcode), KOcc{e.uid, slotId, 0, 1, -1});
+      winKmerRefs += 2;
     }
-  }
-  std::sort(codes.begin(), codes.end());
-  for (size_t i = 0; i < codes.size();) {
-    size_t j = i;
-    int f = 0, r = 0;
-    while (j < codes.size() && codes[j].first == codes[i].first) { if (codes[j].second) ++r; else ++f; ++j; }
-    winKmers.add(codes[i].first, index.bucket(codes[i].first, e.barcode), KOcc{e.uid, slotId, (unsigned char)(f > 255 ? 255 : f), (unsigned char)(r > 255 ? 255 : r), -1});
-    ++winKmerRefs;
-    i = j;
   }
   ++winKmerLive;
 }
