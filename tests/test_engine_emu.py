@@ -576,3 +576,24 @@ def check_apply_delta(eng, seed=31, k=9):
 
 def test_apply_delta_through_the_abi(emu_engine):
     check_apply_delta(emu_engine)
+
+
+def test_threaded_read_packing(emu_engine):
+    """t4_reads_upload packs large batches on several host threads: the same batch packed by one and by five threads gives the
+    same hits; a base outside the alphabet is reported for the right read either way"""
+    import trust4_amd
+    reads = rows_to_strs(Synth(50, 4).next_reads(150)) + ["ACGTNNACGT" * 9, "", "A"]
+    ref = emu_engine.index(9).set_params(17, 10, 0.9).load_ref_fasta(REF_FA).commit()
+    off1, h1 = ref.hits(emu_engine.upload(reads), 0, 0)
+    os.environ.update(T4_PACK_MIN="1", T4_PACK_THREADS="5")
+    try:
+        off2, h2 = ref.hits(emu_engine.upload(reads), 0, 0)
+        assert (off1 == off2).all() and (h1 == h2).all()
+        bad = list(reads)
+        bad[207] = bad[207][:10] + "R" + bad[207][11:]
+        with pytest.raises(trust4_amd.T4Error) as e:
+            emu_engine.upload(bad)
+        assert "read 207" in str(e.value) and "'R'" in str(e.value)
+    finally:
+        os.environ.pop("T4_PACK_MIN", None)
+        os.environ.pop("T4_PACK_THREADS", None)

@@ -216,7 +216,8 @@ int main(int argc, char *argv[]) {
     return 1;
   };
 
-  const size_t BATCH = getenv("T4_BATCH") ? (size_t)atol(getenv("T4_BATCH")) : (size_t)1 << 20;
+  // pairs per candidate-test batch: small enough that the parser threads work on the next batch while this one is tested
+  const size_t BATCH = getenv("T4_BATCH") ? (size_t)atol(getenv("T4_BATCH")) : (size_t)1 << 18;
   std::vector<Rec> r1, r2, rb, ru;
   long long total = 0, kept = 0;
   auto test = [&](const std::vector<Rec> &rs, const std::vector<char> *already, std::vector<char> &good) {
