@@ -1234,8 +1234,8 @@ void t4_assembler::buildGroups(Cached &e) {
   for (const Grp &g : e.groups.t) if (g.key != 0xFFFFFFFFu && g.cnt >= 4) ++u4;
   // possibleOverlapCnt counts groups measured at more than 3 hits (SeqSet.hpp:784-810); while it cannot pass 100 the
   // group statistics of GetOverlapsFromHits leave novelMinHitRequired at 3 whatever small groups come and go
-  e.slack = 99 - u4;
-  e.fragile = e.slack < 0 || maxList > 10000;   // lists beyond 10000 postings drive removeOnlyRepeats (SeqSet.hpp:802)
+  e.slack = 99 - u4;               // negative: no tolerated edit at all (the statistics are live for this read)
+  e.fragile = maxList > 10000;     // lists beyond 10000 postings drive removeOnlyRepeats (SeqSet.hpp:802)
 }
 
 // Examine what the commit(s) since the last call changed for every window entry that is still valid.
