@@ -211,11 +211,13 @@ int t4_assembler_input_novel_read(t4_assembler *a, const char *id, const char *r
 int t4_assembler_add_read(t4_assembler *a, const char *read, const char *gene_name, int *strand, int barcode,
                           int min_kmer_count, int repetitive_data, double similarity_threshold);
 int t4_assembler_repeat_add_read(t4_assembler *a, const char *read);
-/* Speculation window: query the GPU once for the next n reads (in the order they will be offered to
- * t4_assembler_add_read, with the strand / barcode / repetitive_data arguments they will be offered with). The
- * results are consumed by the following add_read calls for as long as no commit changed anything a query can
- * observe (index, consensus, contig creation, an IsBaseEqual state flip); after that add_read falls back to a
- * fresh query and t4_assembler_window_valid returns 0 so that the caller can prefetch again. Never changes results. */
+/* Speculation window: announce the next n reads (in the order they will be offered to t4_assembler_add_read, with the
+ * strand / barcode / repetitive_data arguments they will be offered with). Entries of an earlier announcement that still
+ * stand are kept; the others are queried on the GPU in one batch. A result is consumed by add_read for as long as no commit
+ * can have changed it: for a set whose index is not keyed by barcode that is tracked per entry (the posting lists of the
+ * read's own k-mers, and the stretch of every contig it has three or more hits with), for a cell of a
+ * t4_cellset any observable change ends the window. When the head entry has fallen, t4_assembler_window_valid returns 0 so
+ * that the caller announces again (add_read would otherwise query that one read by itself). Never changes results. */
 int t4_assembler_prefetch(t4_assembler *a, int n, const char *const *reads, const int *strands, const int *barcodes,
                           int repetitive_data);
 int t4_assembler_window_valid(const t4_assembler *a);

@@ -5,9 +5,12 @@
 // This file is the ordered-commit half of that design: it owns the mutable contig set and its k-mer
 // index on the host and replays the reference's bookkeeping exactly, while everything that is
 // expensive and read-only per read -- GetOverlapsFromRead and the ExtendOverlap alignments -- is
-// obtained from the GPU through the C ABI of include/trust4_hip.h (t4_overlaps, t4_extend) against a
-// device image of the set. Round 1 refreshes that image whenever the set changed (commit window of
-// one read: exact, not yet fast); the windowed speculation described in DESIGN.md builds on this.
+// obtained from the GPU (t4_add_query* : GetOverlapsFromRead + the ExtendOverlap of every overlap) against a device
+// image of the set, for a window of upcoming reads at a time.
+//   * A set whose index is not keyed by barcode (bulk mode) is a LIVE set: the host index stores its posting lists in the
+//     layout of the device image and every edit is shipped by position (t4_index_apply_delta); the window slides and an
+//     entry is kept exactly as long as no commit can have changed its query (the rules and why they are safe).
+//   * A cell of a per-barcode set (t4_cellset) has its image rebuilt after an observable change and its window ends there.
 //
 // Reference semantics followed: SeqSet::AddRead (SeqSet.hpp:3426-4473), RepeatAddRead (4477-4507),
 // InputNovelRead (3028-3073), UpdateConsensus / UpdateAllConsensus (4525-4588), SubstituteConsensusPos
