@@ -947,6 +947,7 @@ __device__ void bitonicSort(KeyT *keys, int n) {
 // buffer of B keys (B a power of two): every sub-step whose partners lie inside an aligned block of B keys runs on the block
 // in LDS, only the sub-steps with j >= B touch global memory -- 10 global sub-steps instead of 153 for 131072 keys.
 // Padding up to the block size is an explicit +inf (all ones: no key is larger; dropped hits carry it too).
+template <class KeyT> __device__ void bitonicSortReg(KeyT *keys, int n);   // below: chunk-local sub-steps in registers
 template <class KeyT>
 __device__ void bitonicSortBlocked(KeyT *keys, int n, KeyT *lds, int B) {
   const int lane = tid(), NT = nthr();
@@ -954,7 +955,7 @@ __device__ void bitonicSortBlocked(KeyT *keys, int n, KeyT *lds, int B) {
   if (n <= B) {   // fits the buffer: one round trip
     for (int i = lane; i < n; i += NT) lds[i] = keys[i];
     __syncthreads();
-    bitonicSort(lds, n);
+    bitonicSortReg(lds, n);
     for (int i = lane; i < n; i += NT) keys[i] = lds[i];
     __syncthreads();
     return;
@@ -964,7 +965,7 @@ __device__ void bitonicSortBlocked(KeyT *keys, int n, KeyT *lds, int B) {
   for (int b0 = 0; b0 < n; b0 += B) {   // stages k = 2 .. B: every block sorted ascending
     for (int i = lane; i < B; i += NT) lds[i] = b0 + i < n ? keys[b0 + i] : INF;
     __syncthreads();
-    bitonicSort(lds, B);
+    bitonicSortReg(lds, B);
     for (int i = lane; i < B; i += NT) if (b0 + i < n) keys[b0 + i] = lds[i];
     __syncthreads();
   }
@@ -1003,18 +1004,24 @@ __device__ void bitonicSortBlocked(KeyT *keys, int n, KeyT *lds, int B) {
 #ifndef T4_OPT_REGSORT
 #define T4_OPT_REGSORT 1
 #endif
+#ifndef T4_OPT_REGSORT64
+#define T4_OPT_REGSORT64 1
+#endif
 
 #if T4_OPT_REGSORT
 // The same network for 32-bit keys with the chunk-local sub-steps in registers: a lane holds elements wl and wl + 64 of its
 // wavefront's 128-element chunk, partners are reached by lane exchanges (wl ^ mask), and a chunk is read and written once
 // per stage instead of once per sub-step -- 56 of the 66 sub-steps of a 2048-key sort are chunk-local, and the LDS version
 // is bound by LDS bandwidth. Out of line: its registers are its own.
-__device__ __forceinline__ void cmpExch32(unsigned &lo, unsigned &hi, int mask, bool keepMax) {
-  const unsigned olo = __shfl_xor(lo, mask), ohi = __shfl_xor(hi, mask);
+template <class KeyT>
+__device__ __forceinline__ void cmpExchReg(KeyT &lo, KeyT &hi, int mask, bool keepMax) {
+  const KeyT olo = __shfl_xor(lo, mask), ohi = __shfl_xor(hi, mask);
   lo = keepMax ? (olo > lo ? olo : lo) : (olo < lo ? olo : lo);
   hi = keepMax ? (ohi > hi ? ohi : hi) : (ohi < hi ? ohi : hi);
 }
-__device__ T4_NI void bitonicSort32(unsigned *keys, int n) {
+template <class KeyT>
+__device__ T4_NI void bitonicSortReg(KeyT *keys, int n) {
+  const KeyT INF = ~(KeyT)0;
   const int lane = tid(), NT = nthr();
   int n2 = 1;
   while (n2 < n) n2 <<= 1;
@@ -1024,17 +1031,17 @@ __device__ T4_NI void bitonicSort32(unsigned *keys, int n) {
   // stages k = 2 .. 128 never leave a chunk
   for (int c = wave; c < nChunk; c += nw) {
     const int base = c << 7;
-    unsigned lo = base + wl < n ? keys[base + wl] : ~0u;
-    unsigned hi = base + 64 + wl < n ? keys[base + 64 + wl] : ~0u;
+    KeyT lo = base + wl < n ? keys[base + wl] : INF;
+    KeyT hi = base + 64 + wl < n ? keys[base + 64 + wl] : INF;
     for (int k = 2; k <= 64; k <<= 1) {
-      cmpExch32(lo, hi, k - 1, (wl & (k >> 1)) != 0);                      // mirrored partner inside the k-block
-      for (int jj = k >> 2; jj > 0; jj >>= 1) cmpExch32(lo, hi, jj, (wl & jj) != 0);
+      cmpExchReg(lo, hi, k - 1, (wl & (k >> 1)) != 0);                      // mirrored partner inside the k-block
+      for (int jj = k >> 2; jj > 0; jj >>= 1) cmpExchReg(lo, hi, jj, (wl & jj) != 0);
     }
     {   // k = 128: element wl meets 127 - wl = the upper element of lane 63 - wl, and the other way round
-      const unsigned olo = __shfl_xor(lo, 63), ohi = __shfl_xor(hi, 63);
+      const KeyT olo = __shfl_xor(lo, 63), ohi = __shfl_xor(hi, 63);
       lo = ohi < lo ? ohi : lo;
       hi = olo > hi ? olo : hi;
-      for (int jj = 32; jj > 0; jj >>= 1) cmpExch32(lo, hi, jj, (wl & jj) != 0);
+      for (int jj = 32; jj > 0; jj >>= 1) cmpExchReg(lo, hi, jj, (wl & jj) != 0);
     }
     if (base + wl < n) keys[base + wl] = lo;
     if (base + 64 + wl < n) keys[base + 64 + wl] = hi;
@@ -1044,28 +1051,29 @@ __device__ T4_NI void bitonicSort32(unsigned *keys, int n) {
     int j = k >> 1;
     for (int t = lane; t < half; t += NT) {   // first sub-step of the stage: mirrored partner
       const int low = t & (j - 1), i = ((t & ~(j - 1)) << 1) | low, p = (i & ~(k - 1)) + (k - 1 - low);
-      if (p < n) { unsigned a = keys[i], b = keys[p]; if (a > b) { keys[i] = b; keys[p] = a; } }
+      if (p < n) { KeyT a = keys[i], b = keys[p]; if (a > b) { keys[i] = b; keys[p] = a; } }
     }
     __syncthreads();
     for (j >>= 1; j > 64; j >>= 1) {
       for (int t = lane; t < half; t += NT) {
         const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
-        if (p < n) { unsigned a = keys[i], b = keys[p]; if (a > b) { keys[i] = b; keys[p] = a; } }
+        if (p < n) { KeyT a = keys[i], b = keys[p]; if (a > b) { keys[i] = b; keys[p] = a; } }
       }
       __syncthreads();
     }
     for (int c = wave; c < nChunk; c += nw) {   // j = 64 .. 1 in registers
       const int base = c << 7;
-      unsigned lo = base + wl < n ? keys[base + wl] : ~0u;
-      unsigned hi = base + 64 + wl < n ? keys[base + 64 + wl] : ~0u;
-      if (lo > hi) { const unsigned t = lo; lo = hi; hi = t; }
-      for (int jj = 32; jj > 0; jj >>= 1) cmpExch32(lo, hi, jj, (wl & jj) != 0);
+      KeyT lo = base + wl < n ? keys[base + wl] : INF;
+      KeyT hi = base + 64 + wl < n ? keys[base + 64 + wl] : INF;
+      if (lo > hi) { const KeyT t = lo; lo = hi; hi = t; }
+      for (int jj = 32; jj > 0; jj >>= 1) cmpExchReg(lo, hi, jj, (wl & jj) != 0);
       if (base + wl < n) keys[base + wl] = lo;
       if (base + 64 + wl < n) keys[base + 64 + wl] = hi;
     }
     __syncthreads();
   }
 }
+__device__ __forceinline__ void bitonicSort32(unsigned *keys, int n) { bitonicSortReg<unsigned>(keys, n); }
 #endif
 #ifndef T4_OPT_ROWCHAIN
 #define T4_OPT_ROWCHAIN 1
@@ -1961,6 +1969,9 @@ __device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, 
     __syncthreads();
   } else if (H > 1) {
     if (!wm.ldsArrays && wm.ldsSort) bitonicSortBlocked(wm.keys, H, wm.ldsSort, wm.ldsSortCap);
+#if T4_OPT_REGSORT64
+    else if (wm.ldsArrays) bitonicSortReg(wm.keys, H);   // 64-bit keys of a big set: chunk-local sub-steps in registers as for the 32-bit keys
+#endif
     else bitonicSort(wm.keys, H);
   }
   PHASE_MARK(ws, 4);
