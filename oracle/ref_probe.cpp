@@ -215,6 +215,7 @@ int ref_has_hit_in_set(void *h, const char *read, int mode) {
   return ret;
 }
 void ref_update_all_consensus(void *h) { ((SeqSet *)h)->UpdateAllConsensus(); }
+void ref_change_kmer_length(void *h, int k) { ((SeqSet *)h)->ChangeKmerLength(k); }   // SeqSet.hpp:4624-4629 (main.cpp:1874-1879)
 // barcode mode (main.cpp:1549-1559, 1846-1859, 1968-1969)
 void ref_set_consider_barcode(void *h, int on) { ((SeqSet *)h)->SetConsiderBarcodeInIndexHash(on != 0); }
 void ref_release_finished_barcode(void *h, int barcode, int total) {

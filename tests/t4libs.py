@@ -329,6 +329,7 @@ class RefSeqSet:
         self.lib.ref_add_read.argtypes = [P, C.c_char_p, C.c_char_p, C.POINTER(I), I, I, I, C.c_double]
         self.lib.ref_repeat_add_read.argtypes = [P, C.c_char_p]
         self.lib.ref_update_all_consensus.argtypes = [P]
+        self.lib.ref_change_kmer_length.argtypes = [P, I]
         self.lib.ref_output.argtypes = [P, C.c_char_p]
         self.lib.ref_size.argtypes = [P]
         self.lib.ref_set_consider_barcode.argtypes = [P, I]
@@ -358,6 +359,9 @@ class RefSeqSet:
 
     def update_all_consensus(self):
         self.lib.ref_update_all_consensus(self.h)
+
+    def change_kmer_length(self, k):
+        self.lib.ref_change_kmer_length(self.h, k)
 
     def output(self, path):
         self.lib.ref_output(self.h, _b(path))

@@ -27,10 +27,14 @@ def make_reads(seed, n_pairs, n_clones):
     return reads
 
 
-def drive(asm, reads, names, thresholds, update_every=150, window=0):
+def drive(asm, reads, names, thresholds, update_every=150, window=0, grow_at=None):
+    """grow_at = (i, k): SeqSet::ChangeKmerLength(k) before read i (main.cpp:1874-1879 does it when the set passes 4096 * 4^n
+    contigs: the set is compacted, contig ids are renumbered, the whole index is rebuilt with the new k)"""
     log = []
     prev_ret, n_ok = -1, 0
     for i, rd in enumerate(reads):
+        if grow_at and i == grow_at[0]:
+            asm.change_kmer_length(grow_at[1])   # Clean() forgets prevAddInfo: a RepeatAddRead right after returns -1 (SeqSet.hpp:4619)
         if window and not (i > 0 and rd == reads[i - 1]) and not asm.window_valid():
             nxt = [reads[j] for j in range(i, len(reads)) if j == 0 or reads[j] != reads[j - 1]][:window]
             asm.prefetch(nxt, [0] * len(nxt))
@@ -52,7 +56,7 @@ def drive(asm, reads, names, thresholds, update_every=150, window=0):
     return log
 
 
-def run_case(eng, tmp_path, seed, n_pairs, n_clones, k=9, window=0):
+def run_case(eng, tmp_path, seed, n_pairs, n_clones, k=9, window=0, grow_at=None):
     import trust4_amd
     reads = make_reads(seed, n_pairs, n_clones)
     # gene names come from the rough annotation, as in main.cpp:1609-1620 (first 4 letters of the last annotated gene)
@@ -69,8 +73,8 @@ def run_case(eng, tmp_path, seed, n_pairs, n_clones, k=9, window=0):
         thr.append(rnd.choice([0.9, 0.95, 0.97]))
     ref = RefSeqSet(k)
     mine = trust4_amd.Assembler(eng, k)
-    log_ref = drive(ref, reads, names, thr)
-    log_mine = drive(mine, reads, names, thr, window=window)
+    log_ref = drive(ref, reads, names, thr, grow_at=grow_at)
+    log_mine = drive(mine, reads, names, thr, window=window, grow_at=grow_at)
     if window:
         c = mine.counters()
         assert c["window_hits"] > 0 and c["queries"] < sum(1 for x in log_mine if x[0] == "add")
@@ -101,3 +105,9 @@ def test_add_path_matches_reference(emu_engine, tmp_path, seed):
 
 def test_speculation_window_is_exact(emu_engine, tmp_path):
     run_case(emu_engine, tmp_path, 5, 200, 10, window=32)
+
+
+def test_kmer_length_growth_in_lock_step(emu_engine, tmp_path):
+    """ChangeKmerLength in the middle of an assembly (k 9 -> 11), with a speculation window standing: the live set is compacted,
+    renumbered, re-indexed and its device image sent anew; everything after must still equal the reference call for call"""
+    run_case(emu_engine, tmp_path, 7, 160, 10, window=24, grow_at=(170, 11))

@@ -196,3 +196,9 @@ def test_apply_delta_through_the_abi(eng):
     from test_engine_emu import check_apply_delta
     check_apply_delta(eng)
     check_apply_delta(eng, seed=32, k=11)
+
+
+@pytest.mark.skipif(not Ref.available(), reason="oracle/_ref not shipped")
+def test_kmer_length_growth_in_lock_step(eng, tmp_path):
+    from test_assembler_emu import run_case
+    run_case(eng, tmp_path, 7, 400, 25, window=48, grow_at=(420, 11))

@@ -80,6 +80,7 @@ def _load():
         "t4_assembler_prefetch": (I, [P, I, P, P, P, I]), "t4_assembler_window_valid": (I, [P]),
         "t4_assembler_counters": (I, [P, P, P, P]),
         "t4_assembler_repeat_add_read": (I, [P, C.c_char_p]), "t4_assembler_update_all_consensus": (I, [P]),
+        "t4_assembler_change_kmer_length": (I, [P, I]),
         "t4_assembler_output": (I, [P, C.c_char_p]), "t4_assembler_size": (I, [P]), "t4_assembler_index_postings": (L, [P]),
         "t4_assembler_release_finished_barcode": (I, [P, I, I]), "t4_assembler_release_shallow_contigs": (I, [P, I]),
         "t4_assembler_output_barcodes": (I, [P, C.c_char_p, P, I]), "t4_cellset_release_shallow_contigs": (I, [P, I]),
@@ -265,6 +266,9 @@ class Assembler:
         q, r, h = C.c_int64(), C.c_int64(), C.c_int64()
         self.eng.check(self.eng.lib.t4_assembler_counters(self.h, C.byref(q), C.byref(r), C.byref(h)))
         return {"queries": q.value, "refreshes": r.value, "window_hits": h.value}
+
+    def change_kmer_length(self, k):
+        self.eng.check(self.eng.lib.t4_assembler_change_kmer_length(self.h, k))
 
     def update_all_consensus(self):
         self.eng.check(self.eng.lib.t4_assembler_update_all_consensus(self.h))
