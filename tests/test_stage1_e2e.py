@@ -128,15 +128,13 @@ def test_device_kmer_counts_emulated(tmp_path):
     assert trimmed and min(trimmed) < 150   # the trim did happen
 
 
-@pytest.mark.gpu
-@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not shipped")
-@pytest.mark.parametrize("extra", [["--contigMinCov", "3"], ["--keepNoBarcode"], ["--keepNoBarcode", "--contigMinCov", "2"]])
-def test_barcode_mode_options(tmp_path, extra):
-    """--contigMinCov (thin barcodes and shallow contigs dropped) and --keepNoBarcode (index not keyed by barcode: one set)"""
+def _barcode_options_case(tmp_path, driver, extra, pairs, cells):
+    """--contigMinCov (thin barcodes and shallow contigs dropped) and --keepNoBarcode (index not keyed by barcode: one set --
+    the live set of bulk mode, here with the barcode filter on every hit)"""
     fa = str(tmp_path / "ref.fa")
     _gunzip(REF_FA, fa)
     pre = str(tmp_path / "c5")
-    subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, "1500", "0", "8", pre, "--cells", "40"], check=True)
+    subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, str(pairs), "0", "8", pre, "--cells", str(cells)], check=True)
     # some reads lose their barcode, one cell is thin
     lines = open(pre + "_bc.fa").read().split("\n")
     for i in range(1, len(lines), 2):
@@ -146,10 +144,22 @@ def test_barcode_mode_options(tmp_path, extra):
     args = ["-f", fa, "-1", pre + "_1.fq", "-2", pre + "_2.fq", "--barcode", pre + "_bc.fa", "--UMI", pre + "_umi.fa"] + extra
     ref_out, my_out = str(tmp_path / "ref"), str(tmp_path / "mine")
     subprocess.run([REF_BIN, "-t", "1"] + args + ["-o", ref_out], check=True, stderr=subprocess.DEVNULL)
-    subprocess.run([_driver(), "-t", "4"] + args + ["-o", my_out], check=True)
+    subprocess.run([driver, "-t", "4"] + args + ["-o", my_out], check=True)
     for suffix in ("_raw.out", "_assembled_reads.fa", "_final.out"):
         assert filecmp.cmp(ref_out + suffix, my_out + suffix, shallow=False), (extra, suffix)
-    assert open(ref_out + "_raw.out").read().count(">") > 10
+    assert open(ref_out + "_raw.out").read().count(">") > cells // 4
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not shipped")
+@pytest.mark.parametrize("extra", [["--contigMinCov", "3"], ["--keepNoBarcode"], ["--keepNoBarcode", "--contigMinCov", "2"]])
+def test_barcode_mode_options(tmp_path, extra):
+    _barcode_options_case(tmp_path, _driver(), extra, 1500, 40)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
+def test_keep_no_barcode_emulated(tmp_path):
+    _barcode_options_case(tmp_path, _emulated_driver(), ["--keepNoBarcode"], 200, 8)
 
 
 @pytest.mark.gpu
