@@ -707,7 +707,7 @@ struct WaveMem {
 };
 
 struct WaveState { // wave-uniform scalars kept in LDS
-  int ovCount, candCount, jobCount, overflow, unsupported, finCount, nContig;
+  int ovCount, candCount, jobCount, overflow, unsupported, finCount, nContig, sortBad;
   int novelMin[2];
   int red[16];
   short contigA[64], contigB[64];
@@ -948,6 +948,7 @@ __device__ void bitonicSort(KeyT *keys, int n) {
 // in LDS, only the sub-steps with j >= B touch global memory -- 10 global sub-steps instead of 153 for 131072 keys.
 // Padding up to the block size is an explicit +inf (all ones: no key is larger; dropped hits carry it too).
 template <class KeyT> __device__ void bitonicSortReg(KeyT *keys, int n);   // below: chunk-local sub-steps in registers
+template <class KeyT> __device__ __forceinline__ void cmpExchReg(KeyT &lo, KeyT &hi, int mask, bool keepMax);
 template <class KeyT>
 __device__ void bitonicSortBlocked(KeyT *keys, int n, KeyT *lds, int B) {
   const int lane = tid(), NT = nthr();
@@ -987,11 +988,23 @@ __device__ void bitonicSortBlocked(KeyT *keys, int n, KeyT *lds, int B) {
     for (int b0 = 0; b0 < n; b0 += B) {   // sub-steps j = B / 2 .. 1 of the stage, block by block in LDS
       for (int i = lane; i < B; i += NT) lds[i] = b0 + i < n ? keys[b0 + i] : INF;
       __syncthreads();
-      for (int jj = B >> 1; jj > 0; jj >>= 1) {
+      const int jLow = B >= 128 ? 64 : 0;   // sub-steps j <= 64 stay inside chunks of 128 keys: in registers, one LDS round trip
+      for (int jj = B >> 1; jj > jLow; jj >>= 1) {
         for (int t = lane; t < (B >> 1); t += NT) {
           const int i = ((t & ~(jj - 1)) << 1) | (t & (jj - 1)), p = i | jj;
           KeyT a = lds[i], b = lds[p];
           if (a > b) { lds[i] = b; lds[p] = a; }
+        }
+        __syncthreads();
+      }
+      if (jLow) {
+        const int wave = lane >> 6, nw = NT >> 6, wl = lane & 63;
+        for (int c = wave; c < (B >> 7); c += nw) {
+          const int base = c << 7;
+          KeyT lo = lds[base + wl], hi = lds[base + 64 + wl];
+          if (lo > hi) { const KeyT t = lo; lo = hi; hi = t; }
+          for (int jj = 32; jj > 0; jj >>= 1) cmpExchReg(lo, hi, jj, (wl & jj) != 0);
+          lds[base + wl] = lo; lds[base + 64 + wl] = hi;
         }
         __syncthreads();
       }
@@ -1074,6 +1087,9 @@ __device__ T4_NI void bitonicSortReg(KeyT *keys, int n) {
   }
 }
 __device__ __forceinline__ void bitonicSort32(unsigned *keys, int n) { bitonicSortReg<unsigned>(keys, n); }
+#endif
+#ifndef T4_OPT_OVKEYSORT
+#define T4_OPT_OVKEYSORT 1
 #endif
 #ifndef T4_OPT_ROWCHAIN
 #define T4_OPT_ROWCHAIN 1
@@ -1820,6 +1836,15 @@ __device__ void walkOverlap(const T4IndexView &ix, WaveMem &wm, WaveState *ws, O
 __device__ T4_NI void walkOverlapsRows(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int overlapCnt) {
   const int lane = tid(), NT = nthr(), K = ix.k;
   const int row = lane >> 4, rl = lane & 15, nRows = NT >> 4;
+  // the other class (novel sequences -- every contig of an AddRead query -- or radius 0) stops on alignment geometry too:
+  // the data-dependent walk, one lane per overlap (a row per overlap left 15 of 16 lanes idle through thousands of them)
+  int anyFast = 0;
+  for (int i = lane; i < overlapCnt; i += NT) {
+    OvRec oc = wm.ov[wm.ord[i]];
+    if ((oc.flags & OV_ISREF) != 0 && ix.radius > 0) anyFast = 1;
+    else walkOverlap(ix, wm, ws, oc, i, true);
+  }
+  if (blockSum(anyFast, ws->red) == 0) return;
   for (int i0 = 0; i0 < overlapCnt; i0 += nRows) {
     const int i = i0 + row;
     const bool has = i < overlapCnt;
@@ -1830,7 +1855,6 @@ __device__ T4_NI void walkOverlapsRows(const T4IndexView &ix, WaveMem &wm, WaveS
       const OvRec &o = wm.ov[ovSlot];
       chainPos = o.chainPos; chainLen = o.chainLen;
       fast = (o.flags & OV_ISREF) != 0 && ix.radius > 0;
-      if (!fast && rl == 0) { OvRec oc = o; walkOverlap(ix, wm, ws, oc, i, true); }
     }
     const unsigned *hc = (const unsigned *)(wm.keys + chainPos);
     int jStop = 0x7FFFFFFF;
@@ -1980,6 +2004,119 @@ __device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, 
   return H;
 }
 
+// std::sort(overlaps) for thousands of overlaps (a read inside a gene segment that every contig carries; the rank sort of
+// overlapsFromSegment is quadratic). The first four criteria of _overlap::operator< (matchCnt desc, read span desc, seqIdx,
+// strand) fit 45 bits: sort (those | index) with the hit sorter, then settle the rare groups that tie on all four with the full
+// comparison. Returns false (nothing done) when a field does not fit. Out of line: its registers are its own.
+__device__ T4_NI bool sortOverlapsByKey(WaveMem &wm, WaveState *ws, int overlapCnt) {
+  const int lane = tid(), NT = nthr();
+  bool keySorted = false;
+  if (lane == 0) ws->sortBad = 0;
+  __syncthreads();
+  unsigned long long *sk = overlapCnt <= wm.ldsSortCap ? wm.ldsSort : (unsigned long long *)wm.pairs;   // pairs: dead until the DPs
+  for (int i = lane; i < overlapCnt; i += NT) {
+    const OvRec o = wm.ov[i];
+    const int span = o.re - o.rs;
+    if (o.matchCnt < 0 || o.matchCnt > 4095 || span < 0 || span > 1023) ws->sortBad = 1;
+    sk[i] = ((unsigned long long)(4095 - (o.matchCnt & 4095)) << 47) | ((unsigned long long)(1023 - (span & 1023)) << 37) |
+            ((unsigned long long)(unsigned)o.seqIdx << 15) | ((unsigned long long)((o.flags & OV_PLUS) ? 1 : 0) << 14) |
+            (unsigned long long)i;
+  }
+  __syncthreads();
+  if (!ws->sortBad) {
+    if (overlapCnt <= wm.ldsSortCap) bitonicSortReg(sk, overlapCnt);
+    else bitonicSortBlocked(sk, overlapCnt, wm.ldsSort, wm.ldsSortCap);
+    __syncthreads();
+    for (int p = lane; p < overlapCnt; p += NT) {
+      const unsigned long long key = sk[p], pre = key >> 14;
+      const int i = (int)(key & 16383);
+      int gs = p, ge = p + 1;
+      while (gs > 0 && (sk[gs - 1] >> 14) == pre) --gs;
+      while (ge < overlapCnt && (sk[ge] >> 14) == pre) ++ge;
+      int rank = 0;
+      if (ge - gs > 1) {
+        const OvRec me = wm.ov[i];
+        for (int q = gs; q < ge; ++q) {
+          const int j = (int)(sk[q] & 16383);
+          if (j == i) continue;
+          const int cm = ovCmp(wm.ov[j], me, false);
+          if (cm < 0 || (cm == 0 && j < i)) ++rank;
+        }
+      }
+      wm.ord[gs + rank] = (unsigned short)i;
+#ifdef T4_PATHDBG
+      if (ge - gs > 1 && p == gs) printf("PATHDBG keysort tie group %d of %d\n", ge - gs, overlapCnt);
+      if (p == 0) printf("PATHDBG keysort n %d %s\n", overlapCnt, overlapCnt <= wm.ldsSortCap ? "lds" : "blocked");
+#endif
+    }
+    keySorted = true;
+  }
+  __syncthreads();
+  return keySorted;
+}
+
+// The fast pre-filters of GetOverlapsFromRead against the best novel overlap so far (SeqSet.hpp:1705-1794), on the scored list
+// wm.ov[wm.ord[0 .. overlapCnt)]. Out of line: its registers are its own.
+__device__ T4_NI void prefilterNovel(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int overlapCnt, int segLen) {
+  const int lane = tid(), NT = nthr();
+  // the fast pre-filters against the best novel overlap (SeqSet.hpp:1705-1794) are order dependent: overlap i is judged
+  // against the best scored novel overlap among 0 .. i-1. That best changes a handful of times over thousands of overlaps,
+  // so the list is replayed a workgroup-wide chunk at a time: every undecided overlap is judged against the current best,
+  // the first one that would replace it is found, everything before it is final, everything after it is judged again.
+  int best = -1;
+  OvRec bn = wm.ov[wm.ord[0]];
+  const int len = segLen;
+  for (int i0 = 0; i0 < overlapCnt; i0 += NT) {
+    const int i = i0 + lane;
+    const bool has = i < overlapCnt;
+    const int slot = has ? wm.ord[i] : 0;
+    OvRec o = wm.ov[slot];
+    const bool novel = has && !(o.flags & OV_ISREF);
+    int from = i0;
+    for (;;) {
+      bool cut = false, cand = false;
+      if (novel && i >= from) {
+        const int m0 = o.chainLen;
+        if (best != -1) {
+          const double bs = ovSim(bn);
+          if (bn.rs == 0 && bn.re == len - 1) {
+            if (bs == 1) cut = true;
+            else if (bs > ix.repeatSim && m0 < 0.9 * bn.matchCnt) cut = true;
+          }
+          if (!cut && bn.rs + len - 1 - bn.re < ix.radius) {
+            if (bs == 1 && m0 < 0.9 * bn.matchCnt) cut = true;
+            else if (bs > ix.repeatSim && m0 < 0.8 * bn.matchCnt) cut = true;
+          }
+          if (!cut && o.ss - o.rs >= ix.radius && o.se + (len - 1 - o.re) + ix.radius < ix.seqs[o.seqIdx].len &&
+              bn.matchCnt > 0.97 * (2 * len) && bs > ix.repeatSim && m0 < 0.9 * bn.matchCnt) cut = true;
+          if (!cut && m0 < 0.4 * bn.matchCnt) cut = true;
+          if (!cut && overlapCnt > 1000 && m0 < 0.9 * bn.matchCnt) cut = true;
+        }
+        if (!cut && !(o.flags & OV_SIMZERO) && ovSim(o) > 0 && (best == -1 || ovLess(o, bn, true))) cand = true;
+      }
+      if (lane == 0) ws->red[0] = 0x7FFFFFFF;
+      __syncthreads();
+      if (cand) atomicMin(&ws->red[0], i);
+      __syncthreads();
+      const int f = ws->red[0];
+      if (cut && i < f) {   // final: the best it was judged against is the one the sequential pass would have used
+        o.matchCnt = o.chainLen; o.indelCnt = 0; o.flags |= OV_SIMZERO;
+        wm.ov[slot] = o;
+        from = 0x7FFFFFFF;
+      }
+      __syncthreads();
+      if (f == 0x7FFFFFFF) break;
+#ifdef T4_PATHDBG
+      if (lane == 0) printf("PATHDBG prefilter best %d -> %d of %d\n", best, f, overlapCnt);
+#endif
+      best = f;
+      bn = wm.ov[wm.ord[f]];
+      from = from == 0x7FFFFFFF ? from : f + 1;
+    }
+  }
+  __syncthreads();
+}
+
 // SeqSet::GetOverlapsFromRead (SeqSet.hpp:1508-2124, readType 0) for the segment in wm.seg / wm.rc.
 // Scored and filtered overlaps are appended to wm.fin (coordinates shifted by `shift`).
 // Returns the reference's return value (-1, 0 or the overlap count); -2 on capacity overflow.
@@ -2022,7 +2159,14 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
 #endif
   if (ws->overflow || overlapCnt > wm.maxOv) return -2;
   PHASE_MARK(ws, 8);
-  // std::sort(overlaps) by operator< : rank sort (the order is total on distinct overlaps)
+  // std::sort(overlaps) by operator< (the order is total on distinct overlaps)
+  bool keySorted = false;
+#if T4_OPT_OVKEYSORT
+  // (threshold: 256 overlaps; lower when the testing aid T4Work::capLimit has shrunk the staging block, so that small cases come here)
+  if (!wm.ldsArrays && wm.ldsSort && overlapCnt > (wm.ldsSortCap >= 4096 ? 256 : wm.ldsSortCap / 16) && overlapCnt <= 16384)
+    keySorted = sortOverlapsByKey(wm, ws, overlapCnt);
+#endif
+  if (!keySorted)
   for (int i = lane; i < overlapCnt; i += NT) {
     OvRec me = wm.ov[i];
     int rank = 0;
@@ -2200,41 +2344,7 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
   }
   __syncthreads();
   PHASE_MARK(ws, 10);
-  if (ix.hasNovel && overlapCnt > 50) {
-    // the fast pre-filters against the best novel overlap (SeqSet.hpp:1705-1794) are order dependent:
-    // replay them sequentially over the already scored list
-    if (lane == 0) {
-      int best = -1;
-      const int len = segLen;
-      for (int i = 0; i < overlapCnt; ++i) {
-        OvRec &o = wm.ov[wm.ord[i]];
-        bool isRef = (o.flags & OV_ISREF) != 0;
-        if (!isRef && best != -1) {
-          const OvRec &bn = wm.ov[wm.ord[best]];
-          double bs = ovSim(bn);
-          int m0 = o.chainLen;
-          bool cut = false;
-          if (bn.rs == 0 && bn.re == len - 1) {
-            if (bs == 1) cut = true;
-            else if (bs > ix.repeatSim && m0 < 0.9 * bn.matchCnt) cut = true;
-          }
-          if (!cut && bn.rs + len - 1 - bn.re < ix.radius) {
-            if (bs == 1 && m0 < 0.9 * bn.matchCnt) cut = true;
-            else if (bs > ix.repeatSim && m0 < 0.8 * bn.matchCnt) cut = true;
-          }
-          if (!cut && o.ss - o.rs >= ix.radius && o.se + (len - 1 - o.re) + ix.radius < ix.seqs[o.seqIdx].len &&
-              bn.matchCnt > 0.97 * (2 * len) && bs > ix.repeatSim && m0 < 0.9 * bn.matchCnt) cut = true;
-          if (!cut && m0 < 0.4 * bn.matchCnt) cut = true;
-          if (!cut && overlapCnt > 1000 && m0 < 0.9 * bn.matchCnt) cut = true;
-          if (cut) { o.matchCnt = m0; o.indelCnt = 0; o.flags |= OV_SIMZERO; continue; }
-        }
-        if (!isRef && !(o.flags & OV_SIMZERO) && ovSim(o) > 0) {
-          if (best == -1 || ovLess(o, wm.ov[wm.ord[best]], true)) best = i;
-        }
-      }
-    }
-    __syncthreads();
-  }
+  if (ix.hasNovel && overlapCnt > 50) prefilterNovel(ix, wm, ws, overlapCnt, segLen);
 #ifdef T4_DEBUG
   if (lane == 0) for (int i = 0; i < overlapCnt; ++i) { OvRec o = wm.ov[wm.ord[i]]; printf("DBG ov %d seq %d %d-%d %d-%d m %d ind %d fl %d sim %f\n", i, o.seqIdx, o.rs, o.re, o.ss, o.se, o.matchCnt, o.indelCnt, o.flags, ovSim(o)); }
 #endif
