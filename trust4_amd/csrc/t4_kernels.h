@@ -702,6 +702,8 @@ struct WaveMem {
   int ldsSortCap;
   int hitLimit;                    // hits of one pass the arrays take: cap, or less under the testing aid T4Work::capLimit
   int ldsArrays;                   // keys / pairs / ov live in LDS (every tier but the global-scratch one)
+  unsigned char *dirBuf;           // buffer of the overhang alignments (ExtendOverlap): LDS in every tier (the key array or the
+  int dirBytes;                    // sort's staging block, both dead by then)
   const unsigned *pkRow, *nmRow;   // the read's packed words (global), set by loadSegment
   int segAbs, segLen;              // position of the current segment inside the read
 };
@@ -1838,13 +1840,18 @@ __device__ T4_NI void walkOverlapsRows(const T4IndexView &ix, WaveMem &wm, WaveS
   const int row = lane >> 4, rl = lane & 15, nRows = NT >> 4;
   // the other class (novel sequences -- every contig of an AddRead query -- or radius 0) stops on alignment geometry too:
   // the data-dependent walk, one lane per overlap (a row per overlap left 15 of 16 lanes idle through thousands of them)
+  // -- unless the list is short: then a row per overlap walks its chain sixteen pairs at a time here too. That walk stops at
+  // the first pair off the diagonal or whose gap is beyond nomatchGapLimit, and lists the gaps before it.
+  const bool rowsForAll = overlapCnt <= 4 * nRows;
   int anyFast = 0;
-  for (int i = lane; i < overlapCnt; i += NT) {
-    OvRec oc = wm.ov[wm.ord[i]];
-    if ((oc.flags & OV_ISREF) != 0 && ix.radius > 0) anyFast = 1;
-    else walkOverlap(ix, wm, ws, oc, i, true);
+  if (!rowsForAll) {
+    for (int i = lane; i < overlapCnt; i += NT) {
+      OvRec oc = wm.ov[wm.ord[i]];
+      if ((oc.flags & OV_ISREF) != 0 && ix.radius > 0) anyFast = 1;
+      else walkOverlap(ix, wm, ws, oc, i, true);
+    }
+    if (blockSum(anyFast, ws->red) == 0) return;
   }
-  if (blockSum(anyFast, ws->red) == 0) return;
   for (int i0 = 0; i0 < overlapCnt; i0 += nRows) {
     const int i = i0 + row;
     const bool has = i < overlapCnt;
@@ -1858,6 +1865,13 @@ __device__ T4_NI void walkOverlapsRows(const T4IndexView &ix, WaveMem &wm, WaveS
     }
     const unsigned *hc = (const unsigned *)(wm.keys + chainPos);
     int jStop = 0x7FFFFFFF;
+    const bool slow = has && !fast && rowsForAll;
+    if (slow)
+      for (int j = 1 + rl; j < chainLen; j += 16) {
+        const unsigned pp = hc[j - 1], cp = hc[j];
+        const int pa = PA(pp), pb = PB(pp), qa = PA(cp), qb = PB(cp);
+        if (pb - pa != qb - qa || (pa + K - 1 < qa && (qb - (pb + K) > ix.nomatchGapLimit || qa - (pa + K) > ix.nomatchGapLimit))) { jStop = j; break; }
+      }
     if (fast)
       for (int j = 1 + rl; j < chainLen; j += 16) {
         const unsigned pp = hc[j - 1], cp = hc[j];
@@ -1868,6 +1882,13 @@ __device__ T4_NI void walkOverlapsRows(const T4IndexView &ix, WaveMem &wm, WaveS
       }
     for (int m = 1; m < 16; m <<= 1) { const int other = __shfl_xor(jStop, m); jStop = other < jStop ? other : jStop; }
     int matchCnt = 0, indelCnt = 0;
+    if (slow)
+      for (int j = 1 + rl; j < chainLen && j < jStop; j += 16) {
+        if (PA(hc[j - 1]) + K - 1 < PA(hc[j])) {
+          const int slot = atomicAdd(&ws->jobCount, 1);
+          if (slot < wm.candCap) wm.cand[slot] = (unsigned)i | ((unsigned)j << 16); else ws->overflow = 1;
+        }
+      }
     if (fast)
       for (int j = 1 + rl; j < chainLen && j <= jStop; j += 16) {
         if (j == jStop) { matchCnt += 2 * K; break; }
@@ -1897,6 +1918,86 @@ __device__ T4_NI void walkOverlapsRows(const T4IndexView &ix, WaveMem &wm, WaveS
       OvRec &dst = wm.ov[ovSlot];
       dst.indelCnt = indelCnt;
       if (jStop == 0x7FFFFFFF) dst.flags &= ~OV_SIMZERO; else dst.flags |= OV_SIMZERO;
+    }
+  }
+}
+
+// The finishing pass of the same class for a short list, a row per overlap: with the gap results in place the sequential walk
+// (walkOverlap, collect == false) stops at the first pair that is off the diagonal, has a gap beyond nomatchGapLimit, has a
+// failed alignment or an alignment with indels; its sums are those of the pairs before that one plus what that pair had added
+// before the stop. Reference-gene overlaps under radius > 0 take their sums as the lane-per-overlap loop does.
+__device__ T4_NI void finishOverlapsRows(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int overlapCnt) {
+  const int lane = tid(), NT = nthr(), K = ix.k;
+  const int row = lane >> 4, rl = lane & 15, nRows = NT >> 4;
+  for (int i0 = 0; i0 < overlapCnt; i0 += nRows) {
+    const int i = i0 + row;
+    const bool has = i < overlapCnt;
+    OvRec o = wm.ov[wm.ord[has ? i : 0]];
+    const bool fast = (o.flags & OV_ISREF) != 0 && ix.radius > 0;
+    const unsigned *hc = (const unsigned *)(wm.keys + o.chainPos);
+    const unsigned *res = hc + o.chainLen;
+    int jBreak = 0x7FFFFFFF, add = 0, ind = 0, failed = 0;
+    if (has && !fast)
+      for (int j = 1 + rl; j < o.chainLen; j += 16) {
+        const unsigned pp = hc[j - 1], cp = hc[j];
+        const int pa = PA(pp), pb = PB(pp), qa = PA(cp), qb = PB(cp);
+        bool stop = false;
+        int a = 0;
+        if (pb - pa != qb - qa) stop = true;
+        else if (pa + K - 1 >= qa) a = 2 * (qa - pa);
+        else {
+          a = 2 * K;
+          if (qb - (pb + K) > ix.nomatchGapLimit || qa - (pa + K) > ix.nomatchGapLimit) stop = true;
+          else {
+            const unsigned c = res[j];
+            if (c == DP_FAIL) { stop = true; failed = 1; }
+            else { a += 2 * (int)(c & 1023u); if (c >> 20) { stop = true; ind = (int)(c >> 20); } }
+          }
+        }
+        if (stop) { jBreak = j; add += a; break; }   // a lane's later pairs lie beyond the stop: not walked
+        add += a;
+      }
+    int jb = jBreak;
+    for (int m = 1; m < 16; m <<= 1) { const int other = __shfl_xor(jb, m); jb = other < jb ? other : jb; }
+    // what the lanes added for pairs beyond the row's stop does not count
+    if (has && !fast && jb != 0x7FFFFFFF) {
+      add = 0; 
+      for (int j = 1 + rl; j < o.chainLen && j <= jb; j += 16) {
+        const unsigned pp = hc[j - 1], cp = hc[j];
+        const int pa = PA(pp), pb = PB(pp), qa = PA(cp), qb = PB(cp);
+        if (pb - pa != qb - qa) continue;                      // only the stop itself can be off the diagonal: adds nothing
+        if (pa + K - 1 >= qa) { add += 2 * (qa - pa); continue; }
+        add += 2 * K;
+        if (qb - (pb + K) > ix.nomatchGapLimit || qa - (pa + K) > ix.nomatchGapLimit) continue;
+        const unsigned c = res[j];
+        if (c != DP_FAIL) add += 2 * (int)(c & 1023u);
+      }
+      if (jBreak != jb) { ind = 0; failed = 0; }
+    }
+    add = rowSum16(add);
+    ind = rowSum16(ind);
+    failed = rowSum16(failed);
+    if (has && rl == 0) {
+      const int m0 = o.matchCnt;
+      if (fast) {
+        o.matchCnt = (int)res[0];
+        if (lowComplex(wm, (o.flags & OV_PLUS) != 0, o.rs, o.re)) o.flags |= OV_SIMZERO;
+      } else {
+        if (failed) ws->unsupported = 1;
+        o.matchCnt = 2 * K + add; o.indelCnt = ind;
+        if (jb == 0x7FFFFFFF) o.flags &= ~OV_SIMZERO; else o.flags |= OV_SIMZERO;
+        if (lowComplex(wm, (o.flags & OV_PLUS) != 0, o.rs, o.re)) o.flags |= OV_SIMZERO;
+      }
+#ifdef T4_PATHDBG
+      if (!fast) {   // cross-check against the sequential walk
+        OvRec chk = wm.ov[wm.ord[i]];
+        walkOverlap(ix, wm, ws, chk, i, false);
+        const int kind = jb == 0x7FFFFFFF ? 0 : failed ? 3 : ind ? 2 : 1;
+        printf("PATHDBG finishrows kind %d %s\n", kind, (chk.matchCnt == o.matchCnt && chk.indelCnt == o.indelCnt && chk.flags == o.flags) ? "ok" : "MISMATCH");
+      }
+#endif
+      o.chainLen = m0;
+      wm.ov[wm.ord[i]] = o;
     }
   }
 }
@@ -2120,6 +2221,9 @@ __device__ T4_NI void prefilterNovel(const T4IndexView &ix, WaveMem &wm, WaveSta
 // SeqSet::GetOverlapsFromRead (SeqSet.hpp:1508-2124, readType 0) for the segment in wm.seg / wm.rc.
 // Scored and filtered overlaps are appended to wm.fin (coordinates shifted by `shift`).
 // Returns the reference's return value (-1, 0 or the overlap count); -2 on capacity overflow.
+// ROWS: the row-per-overlap finishing pass for short lists (the AddRead / AssignRead kernels; the rough-annotation kernels, whose
+// overlaps are reference genes, keep their register budget).
+template <bool ROWS>
 __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int segLen, int strandArg, int barcode,
                                    bool skipRepeats, int shift, DPScratch sc, unsigned long long &hitTotal) {
   const int lane = tid(), NT = nthr();
@@ -2332,6 +2436,10 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
   __syncthreads();
   // (4) finish the overlaps
   PHASE_MARK(ws, 15);
+#if T4_OPT_ROWWALK
+  if (ROWS && overlapCnt <= 4 * (NT >> 4)) finishOverlapsRows(ix, wm, ws, overlapCnt);
+  else
+#endif
   for (int i = lane; i < overlapCnt; i += NT) {
     OvRec o = wm.ov[wm.ord[i]];
     int m0 = o.matchCnt;
@@ -2485,9 +2593,17 @@ __device__ void annotateSelect(const T4IndexView &ix, WaveMem &wm, int n, int re
 struct ExtSide { short size, good, match, mis, indel, pending; };
 struct ExtOut { int ret, rs, re, ss, se, matchCnt, simFail, den; };   // similarity = matchCnt / den unless simFail
 
+// Bytes of one overhang alignment's buffer: direction bytes (L + 1) * 11, the edit string 2 * L + 8, and the L predicate bytes
+// of the target staged beside them -- every step of the anti-diagonal sweep reads one target byte per lane, and from global
+// memory that load's latency (not its bandwidth) was the whole cost of a step.
+#define T4_EXT_BYTES(L) (((L) + 1) * 11 + 3 * (L) + 8)
+#define T4_EXT_WST(buf, L) ((buf) + ((L) + 1) * 11 + 2 * (L) + 8)
 // banded posWeight DP of an L x L problem (W = 11) by one wavefront; dir bytes -> dirbuf[i * 11 + d]
 __device__ void dpWaveTracePW(const T4PW *w, int L, const char *p, unsigned char *dirbuf) {
   const int d = laneId(), W = 11, leftBand = 5;
+  unsigned char *wst = T4_EXT_WST(dirbuf, L);
+  for (int t = d; t < L; t += 64) wst[t] = w[t];
+  waveLdsSync();
   const int negInf = (L + 1) * (L + 1) * (-4);
   int M = negInf;
   { int j0 = d - leftBand; if (d < W && j0 >= 0 && j0 <= L) M = j0 == 0 ? 0 : -4 - 4 * j0; }
@@ -2502,7 +2618,7 @@ __device__ void dpWaveTracePW(const T4PW *w, int L, const char *p, unsigned char
       if (i == 1) dM = (j - 1 == 0) ? 0 : -4 - 4 * (j - 1);
       else if (j == 1) dM = -4 - 4 * (i - 1);
       else dM = M;
-      const bool eq = baseEqualW(w[j - 1], p[i - 1]);
+      const bool eq = baseEqualW(wst[j - 1], p[i - 1]);
       const int dsc = dM + (eq ? 2 : -2);
       int m = dsc;
       if (lM - 4 > m) m = lM - 4;
@@ -2517,6 +2633,9 @@ __device__ void dpWaveTracePW(const T4PW *w, int L, const char *p, unsigned char
 // (wave-uniform trip count; a row with L == 0 computes nothing).
 __device__ void dpRowTracePW(const T4PW *w, int L, const char *p, unsigned char *dirbuf, int Lmax) {
   const int d = laneId() & 15, W = 11, leftBand = 5;
+  unsigned char *wst = T4_EXT_WST(dirbuf, L);
+  for (int t = d; t < L; t += 16) wst[t] = w[t];
+  waveLdsSync();
   const int negInf = (L + 1) * (L + 1) * (-4);
   int M = negInf;
   { int j0 = d - leftBand; if (d < W && j0 >= 0 && j0 <= L) M = j0 == 0 ? 0 : -4 - 4 * j0; }
@@ -2531,7 +2650,7 @@ __device__ void dpRowTracePW(const T4PW *w, int L, const char *p, unsigned char 
       if (i == 1) dM = (j - 1 == 0) ? 0 : -4 - 4 * (j - 1);
       else if (j == 1) dM = -4 - 4 * (i - 1);
       else dM = M;
-      const bool eq = baseEqualW(w[j - 1], p[i - 1]);
+      const bool eq = baseEqualW(wst[j - 1], p[i - 1]);
       const int dsc = dM + (eq ? 2 : -2);
       int m = dsc;
       if (lM - 4 > m) m = lM - 4;
@@ -2568,9 +2687,9 @@ __device__ int tracebackPW(const unsigned char *dirbuf, int L, signed char *alig
 
 // Extend the n overlaps wm.fin[ord[0..n)] of the read in wm.seg / wm.rc (length len). Results in `res[i]`.
 // useFirstStrand: AssignRead aligns every overlap against the strand of overlaps[0] (SeqSet.hpp:4657-4659).
-// Scratch: sides = 2 * n ExtSide records, dirbuf >= (len + 1) * 11 + 2 * len + 8 bytes. All LDS.
+// Scratch: sides = 2 * n ExtSide records, dirbuf = dirBytes >= T4_EXT_BYTES(len) bytes (LDS whenever the caller has any).
 __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int n, int len, bool useFirstStrand,
-                               double factor, ExtSide *sides, unsigned char *dirbuf, ExtOut *res) {
+                               double factor, ExtSide *sides, unsigned char *dirbuf, int dirBytes, ExtOut *res) {
   const int lane = tid(), NT = nthr();
   const int plus0 = n > 0 ? (wm.fin[wm.ord[0]].flags & OV_PLUS) : 1;
   // E1: ungapped evaluation of every (overlap, side), one side per wavefront at a time: 64 overhang positions per step
@@ -2615,13 +2734,13 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
   // longer ones, one wavefront per side with its own slice; a side that fits no slice waits for the serial pass that owns the
   // whole buffer
   const int nwE = NT >> 6, perChunk = nwE * 4;
-  const int qslice = ((wm.cap * 8) / perChunk) & ~15;
+  const int qslice = (dirBytes / perChunk) & ~15;
   int nFit = 0, nPendSides = 0;
   for (int part = 0; part < 2; ++part) {
     for (int q0 = 0; q0 < 2 * n; q0 += NT) {
       const int q = q0 + lane;
       bool pend = q < 2 * n && sides[q].pending;
-      if (pend) { const int size = sides[q].size; const bool fitsQ = (size + 1) * 11 + 2 * size + 8 <= qslice; pend = (part == 0) == fitsQ; }
+      if (pend) { const int size = sides[q].size; const bool fitsQ = T4_EXT_BYTES(size) <= qslice; pend = (part == 0) == fitsQ; }
       int tot;
       const int inc = blockInclScan(pend ? 1 : 0, ws->red, tot);
       if (pend) wm.cand[nPendSides + inc - 1] = (unsigned)q;
@@ -2684,19 +2803,19 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
   }
   {
     const int wave = lane >> 6, nw = NT >> 6, wl = lane & 63;
-    const int slice = ((wm.cap * 8) / nw) & ~15;
+    const int slice = (dirBytes / nw) & ~15;
     const int nBig = nPendSides - nFit;
     for (int pass = 0; pass < 2 && nBig > 0; ++pass) {
       // pass 0: every wavefront takes sides that fit its slice; pass 1: wavefront 0 takes the rest with the whole buffer
       unsigned char *buf = pass == 0 ? dirbuf + wave * slice : dirbuf;
-      const int room = pass == 0 ? slice : wm.cap * 8;
+      const int room = pass == 0 ? slice : dirBytes;
       for (int t = pass == 0 ? wave : 0; t < nBig; t += pass == 0 ? nw : 1) {
         if (pass == 1 && wave != 0) break;
         const int q = (int)wm.cand[nFit + t];
         const int size = sides[q].size;
-        const bool fits = (size + 1) * 11 + 2 * size + 8 <= slice;
+        const bool fits = T4_EXT_BYTES(size) <= slice;
         if ((pass == 0) != fits) continue;       // wave-uniform
-        if ((size + 1) * 11 + 2 * size + 8 > room) { if (wl == 0) ws->unsupported = 1; continue; }
+        if (T4_EXT_BYTES(size) > room) { if (wl == 0) ws->unsupported = 1; continue; }
         const OvRec &o = wm.fin[wm.ord[q >> 1]];
         const int side = q & 1;
         const T4SeqInfo si = ix.seqs[o.seqIdx];
@@ -2761,10 +2880,10 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
     // consumed by the host-side ordered commit (t4_assembler)
     ExtSide *sides = (ExtSide *)wm.pairs;
     ExtOut *res = (ExtOut *)wm.ov;
-    unsigned char *dirbuf = (unsigned char *)wm.keys;
+    unsigned char *dirbuf = wm.dirBuf;
     int barcode = bv.barcode ? bv.barcode[r] : -1;
     loadSegment(bv, r, 0, len, wm);
-    int ret = overlapsFromSegment(ix, wm, ws, len, qa.strandPerRead[r], barcode, qa.skipRepeats != 0, 0, sc, hitTotal);
+    int ret = overlapsFromSegment<VARIANT != 0>(ix, wm, ws, len, qa.strandPerRead[r], barcode, qa.skipRepeats != 0, 0, sc, hitTotal);
     if (ret == -2) return false;
     int n = ret > 0 ? ret : 0;
     if (lane == 0) {   // room for this read's records in the result pool
@@ -2790,7 +2909,7 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
     }
     __syncthreads();
     PHASE_MARK(ws, 16);
-    extendOverlaps(ix, wm, ws, n, len, false, qa.factorPerRead[r], sides, dirbuf, res);
+    extendOverlaps(ix, wm, ws, n, len, false, qa.factorPerRead[r], sides, dirbuf, wm.dirBytes, res);
     PHASE_MARK(ws, 17);
     for (int i = lane; i < n; i += NT) {
       const OvRec &o = wm.fin[i];
@@ -2807,13 +2926,13 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
     // scratch carved from the arrays that are dead after overlapsFromSegment: pairs (+cand) and the key area
     ExtSide *sides = (ExtSide *)wm.pairs;                 // 2 * maxFin * 12 B  <= cap * 4 B
     ExtOut *res = (ExtOut *)wm.ov;                         // maxFin * 32 B      <= maxOv * 40 B
-    unsigned char *dirbuf = (unsigned char *)wm.keys;      // (len + 1) * 11 + 2 * len + 8 <= cap * 8 B
+    unsigned char *dirbuf = wm.dirBuf;                     // T4_EXT_BYTES(len) <= 8192 B in every tier
     int barcode = bv.barcode ? bv.barcode[r] : -1;
     loadSegment(bv, r, 0, len, wm);
     int n;
     if (qa.mode == 2) {
       // SeqSet::AssignRead (SeqSet.hpp:4632-4701)
-      int ret = overlapsFromSegment(ix, wm, ws, len, qa.strand, barcode, false, 0, sc, hitTotal);
+      int ret = overlapsFromSegment<VARIANT != 0>(ix, wm, ws, len, qa.strand, barcode, false, 0, sc, hitTotal);
       if (ret == -2) return false;
       n = ret > 0 ? ret : 0;
       __syncthreads();
@@ -2829,7 +2948,7 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
         wm.ord[rank] = (unsigned short)i;
       }
       __syncthreads();
-      extendOverlaps(ix, wm, ws, n, len, true, barcode == -1 ? 1.0 : 2.0, sides, dirbuf, res);
+      extendOverlaps(ix, wm, ws, n, len, true, barcode == -1 ? 1.0 : 2.0, sides, dirbuf, wm.dirBytes, res);
       if (lane == 0) {
         int hit = -1, staleIndel = 0;
         for (int i = 0; i < n; ++i) {
@@ -2864,7 +2983,7 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
         wm.fin[i] = o; wm.ord[i] = (unsigned short)i;
       }
       __syncthreads();
-      extendOverlaps(ix, wm, ws, n, len, false, qa.mismatchFactor, sides, dirbuf, res);
+      extendOverlaps(ix, wm, ws, n, len, false, qa.mismatchFactor, sides, dirbuf, wm.dirBytes, res);
       for (int i = lane; i < n; i += NT) {
         const OvRec &o = wm.fin[i];
         T4OverlapOut t;
@@ -2962,7 +3081,7 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
   } else if (VARIANT == 0 && qa.mode == 0) {
     int barcode = bv.barcode ? bv.barcode[r] : -1;
     loadSegment(bv, r, 0, len, wm);
-    int ret = overlapsFromSegment(ix, wm, ws, len, qa.strand, barcode, qa.skipRepeats != 0, 0, sc, hitTotal);
+    int ret = overlapsFromSegment<VARIANT != 0>(ix, wm, ws, len, qa.strand, barcode, qa.skipRepeats != 0, 0, sc, hitTotal);
     if (ret == -2) return false;
     int n = ret > 0 ? ret : 0;
     if (lane == 0) qa.counts[r] = ret;
@@ -2981,7 +3100,7 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
     for (int c = 0; c < nContig; ++c) {
       int a = ws->contigA[c], b = ws->contigB[c];
       if (nContig > 1 || a != 0 || b != len - 1) { __syncthreads(); loadSegment(bv, r, a, b - a + 1, wm); }
-      int ret = overlapsFromSegment(ix, wm, ws, b - a + 1, 0, -1, false, a, sc, hitTotal);
+      int ret = overlapsFromSegment<VARIANT != 0>(ix, wm, ws, b - a + 1, 0, -1, false, a, sc, hitTotal);
       if (ret == -2) return false;
       __syncthreads();
     }
@@ -3055,6 +3174,7 @@ void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
     wm.cap = CAP; wm.maxOv = MAXOV; wm.maxFin = MAXOV; wm.candCap = C / 3 + 2; wm.ldsArrays = 1;
     wm.hitLimit = (wk.capLimit > 0 && wk.capLimit < CAP) ? wk.capLimit : CAP;
     wm.ldsSort = nullptr; wm.ldsSortCap = 0;
+    wm.dirBuf = (unsigned char *)s_keys; wm.dirBytes = C * 8;
   } else {
     size_t b = blockIdx.x;
     wm.keys = wk.gKeys + b * (size_t)wk.gCap;
@@ -3066,6 +3186,7 @@ void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
     wm.cap = wk.gCap; wm.maxOv = wk.gMaxOv; wm.maxFin = wk.gMaxOv; wm.candCap = wk.gCap; wm.ldsArrays = 0;
     wm.hitLimit = wk.gCap;
     wm.ldsSort = s_gsort; wm.ldsSortCap = CAP > 0 ? 0 : 8192;
+    wm.dirBuf = (unsigned char *)s_gsort; wm.dirBytes = (int)sizeof s_gsort;
   }
   wm.seg = s_seg; wm.rc = s_rc;
   DPScratch sc;
@@ -3092,6 +3213,7 @@ void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
       wg.ord = wk.gOrd + b * (size_t)wk.gMaxOv;
       wg.cap = wk.gCap; wg.maxOv = wk.gMaxOv; wg.maxFin = wk.gMaxOv; wg.candCap = wk.gCap; wg.ldsArrays = 0; wg.hitLimit = wk.gCap;
       wg.ldsSort = s_keys; wg.ldsSortCap = C;   // the LDS arrays are free now: the hit sort is staged through the key array
+      wg.dirBuf = (unsigned char *)s_keys; wg.dirBytes = C * 8;
       if (wk.capLimit > 0 && wk.capLimit < C) { int bsz = 64; while (bsz * 2 <= wk.capLimit) bsz *= 2; wg.ldsSortCap = bsz; }   // testing aid: small blocks
       __syncthreads();
       done = processRead<1>(ix, bv, wk, qa, wg, &s_ws, r, sc);
@@ -3130,7 +3252,7 @@ __global__ __launch_bounds__(64) void extendKernel(T4IndexView ix, T4BatchView b
   wm.keys = s_dir; wm.pairs = (unsigned *)s_sides; wm.ov = (OvRec *)s_res; wm.fin = s_fin; wm.ord = s_ord; wm.cand = s_cand;
   wm.seg = s_seg; wm.rc = s_rc;
   wm.cap = 1024; wm.maxOv = T4_EXT_NREC; wm.maxFin = T4_EXT_NREC; wm.candCap = 2 * T4_EXT_NREC + 2; wm.ldsArrays = 1;
-  wm.ldsSort = nullptr; wm.ldsSortCap = 0; wm.hitLimit = 0;
+  wm.ldsSort = nullptr; wm.ldsSortCap = 0; wm.hitLimit = 0; wm.dirBuf = (unsigned char *)s_dir; wm.dirBytes = (int)sizeof s_dir;
   const int lane = tid();
   const int nRec = (int)*qa.poolCursor < qa.poolCap ? (int)*qa.poolCursor : qa.poolCap;
   for (int g = recBegin + (int)blockIdx.x * T4_EXT_NREC; g < nRec; g += (int)gridDim.x * T4_EXT_NREC) {
@@ -3153,7 +3275,7 @@ __global__ __launch_bounds__(64) void extendKernel(T4IndexView ix, T4BatchView b
         s_fin[lane] = o; s_ord[lane] = (unsigned short)lane;
       }
       __syncthreads();
-      extendOverlaps(ix, wm, &s_ws, n, len, false, qa.factorPerRead[r], s_sides, (unsigned char *)s_dir, s_res);
+      extendOverlaps(ix, wm, &s_ws, n, len, false, qa.factorPerRead[r], s_sides, (unsigned char *)s_dir, (int)sizeof s_dir, s_res);
       if (lane < n) {
         const T4OverlapOut in = qa.outDev[i0 + lane];
         const ExtOut e = s_res[lane];
