@@ -414,6 +414,8 @@ struct t4_assembler : IndexListener {
     std::string read; int strand, barcode, skip; int32_t cnt; bool valid; std::vector<t4_overlap> ov, ext; std::vector<int32_t> extRet;
     // live sets
     int64_t uid = 0;
+    bool heavy = false;          // its k-mers' lists hold more postings than the LDS tiers take (known from its first query on)
+    bool registered = false;     // its k-mers are in winKmers (done beside its first query: nothing looks an entry up before it holds a result)
     unsigned char tier = 0;      // the last query of this read ended on the global-scratch tier
     bool fragile = false;        // any change of one of its keys' lists invalidates it
     int slack = 0;               // tolerated hit-set changes left before possibleOverlapCnt could pass 100 (SeqSet.hpp:813-823)
@@ -699,7 +701,8 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
     Cached &c = *pool[sl];
     cnt = c.cnt; ovBuf.swap(c.ov); extBuf.swap(c.ext); extRet.swap(c.extRet);
     order.pop_front();
-    c.valid = false; c.uid = 0; freeSlots.push_back(sl); --winKmerLive;   // its winKmers references are stale from here on
+    c.valid = false; c.uid = 0; freeSlots.push_back(sl);   // its winKmers references are stale from here on
+    if (c.registered) { --winKmerLive; c.registered = false; }
   } else {
     bool served = false;
     if (cacheHead < cache.size()) {
@@ -1172,6 +1175,7 @@ void t4_assembler::registerKmers(Cached &e, int slotId) {
     }
   }
   ++winKmerLive;
+  e.registered = true;
 }
 
 // Hits of the read per (strand, contig) against the current index (host replica; read-only here): the number of hits, and the
@@ -1239,6 +1243,7 @@ void t4_assembler::buildGroups(Cached &e) {
   // group statistics of GetOverlapsFromHits leave novelMinHitRequired at 3 whatever small groups come and go
   e.slack = 99 - u4;               // negative: no tolerated edit at all (the statistics are live for this read)
   e.fragile = maxList > 10000;     // lists beyond 10000 postings drive removeOnlyRepeats (SeqSet.hpp:802)
+  e.heavy = nPost > 8192;
 }
 
 // Examine what the commit(s) since the last call changed for every window entry that is still valid.
@@ -1351,11 +1356,12 @@ int t4_assembler::prefetchLive(int n, const char *const *reads, const int *stran
   }
   while (order.size() > keep && keep < (size_t)n) {   // (entries beyond the announced ones stay when every announced read lined up)
     const int sl = order.back(); order.pop_back();
-    pool[sl]->valid = false; pool[sl]->uid = 0; freeSlots.push_back(sl); --winKmerLive;
+    pool[sl]->valid = false; pool[sl]->uid = 0; freeSlots.push_back(sl);
+    if (pool[sl]->registered) { --winKmerLive; pool[sl]->registered = false; }
   }
   if (winKmerRefs > 64 * 284 && winKmerRefs > 4 * (winKmerLive + 1) * 284) {   // mostly references of retired entries: rebuild
     winKmers.clear(); winKmerRefs = 0; winKmerLive = 0;
-    for (int sl : order) registerKmers(*pool[sl], sl);
+    for (int sl : order) if (pool[sl]->registered) registerKmers(*pool[sl], sl);
   }
   for (size_t i = keep; i < (size_t)n; ++i) {
     int sl;
@@ -1364,8 +1370,7 @@ int t4_assembler::prefetchLive(int n, const char *const *reads, const int *stran
     Cached &c = *pool[sl];
     c.read = reads[i]; c.strand = strands[i]; c.barcode = barcodes ? barcodes[i] : -1; c.skip = repetitive; c.cnt = 0; c.valid = false;
     c.ov.clear(); c.ext.clear(); c.extRet.clear();
-    c.uid = nextUid++; c.tier = 0;
-    registerKmers(c, sl);
+    c.uid = nextUid++; c.tier = 0; c.registered = false; c.heavy = false;
     order.push_back(sl);
   }
   // Entries far behind the head rarely survive until they are consumed: (re-)query only as far ahead as a few times what a
@@ -1378,12 +1383,18 @@ int t4_assembler::prefetchLive(int n, const char *const *reads, const int *stran
   static const int fixedAhead = getenv("T4_QUERY_AHEAD") ? atoi(getenv("T4_QUERY_AHEAD")) : 0;
   size_t ahead = fixedAhead > 0 ? (size_t)fixedAhead : (size_t)(3.0 * runEma) + 12;
   std::vector<int> todo;
-  for (size_t i = 0; i < order.size() && i < ahead; ++i) if (!pool[order[i]]->valid) todo.push_back(order[i]);
+  // A read that met thousands of contigs last time (it ended on the global-scratch tier) makes its round last as long as it
+  // takes, and dies with nearly every commit: it is asked again only when it is about to be consumed.
+  static const size_t heavyAhead = getenv("T4_HEAVY_AHEAD") ? (size_t)atoi(getenv("T4_HEAVY_AHEAD")) : 0;
+  for (size_t i = 0; i < order.size() && i < ahead; ++i) {
+    const Cached &c = *pool[order[i]];
+    if (!c.valid && !(heavyAhead > 0 && c.heavy && i >= heavyAhead)) todo.push_back(order[i]);
+  }
   if (todo.empty()) return T4_OK;
   int rc;
   const int m = (int)todo.size();
   if (index.total == 0) {   // an empty set has no hit for anybody
-    for (int sl : todo) { Cached &c = *pool[sl]; c.cnt = 0; c.valid = true; c.groups.reset(16); c.slack = 99; c.fragile = false; }
+    for (int sl : todo) { Cached &c = *pool[sl]; c.cnt = 0; c.valid = true; c.groups.reset(16); c.slack = 99; c.fragile = false; if (!c.registered) registerKmers(c, sl); }
     return T4_OK;
   }
   if ((rc = flushLive())) return rc;
@@ -1397,8 +1408,15 @@ int t4_assembler::prefetchLive(int n, const char *const *reads, const int *stran
   }
   if (bases.empty()) bases.push_back('A');
   // the hit groups of the queried reads come from the host replica of the index while the GPU runs the query
+  // ... and so do the window's inverted k-mer map entries of the reads queried for the first time (one thread: the map has one
+  // writer and, until the results are in, no reader)
   std::atomic<int> nextG(0);
-  const std::function<void()> groupWorker = [&]() { for (;;) { int i = nextG.fetch_add(1); if (i >= m) break; buildGroups(*pool[todo[i]]); } };
+  std::atomic<bool> regTaken(false);
+  const auto registerNew = [&]() { for (int sl : todo) if (!pool[sl]->registered) registerKmers(*pool[sl], sl); };
+  const std::function<void()> groupWorker = [&]() {
+    if (!regTaken.exchange(true)) registerNew();
+    for (;;) { int i = nextG.fetch_add(1); if (i >= m) break; buildGroups(*pool[todo[i]]); }
+  };
   const int nHelp = m >= 2 ? (threads - 1 < m - 1 ? threads - 1 : m - 1) : 0;
   if (nHelp > 0) { if (!helpers) helpers.reset(new HelperPool()); helpers->start(nHelp, groupWorker); }
   const int32_t *cnts = nullptr, *bas = nullptr, *rets = nullptr;
