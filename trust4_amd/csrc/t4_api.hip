@@ -214,6 +214,9 @@ int t4_init(int device_ordinal, t4_ctx **out) {
   *out = nullptr;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_ordinal < 0 || device_ordinal >= ndev) return T4_ERR_HIP;
+  // a dependent chain of small launches (the AddRead query rounds) waits on the stream tens of thousands of times: the waiting
+  // thread may spin instead of sleeping (T4_SCHEDULE_SPIN=1; it must be asked for before the device is first used)
+  if (getenv("T4_SCHEDULE_SPIN") && atoi(getenv("T4_SCHEDULE_SPIN")) > 0) (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
   if (hipSetDevice(device_ordinal) != hipSuccess) return T4_ERR_HIP;
   t4_ctx *c = new t4_ctx();
   c->device = device_ordinal;

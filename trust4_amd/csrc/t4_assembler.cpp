@@ -462,6 +462,7 @@ struct t4_assembler : IndexListener {
     }
   } winKmers;
   size_t winKmerRefs = 0, winKmerLive = 0;
+  int64_t heavyQueried = 0;   // queries of reads already known as heavy (re-queries)
   std::vector<Cached *> pool;      // window entries by slot (stable while the entry lives)
   std::vector<int> freeSlots;
   std::deque<int> order;           // slots of the upcoming reads, head first
@@ -1243,7 +1244,8 @@ void t4_assembler::buildGroups(Cached &e) {
   // group statistics of GetOverlapsFromHits leave novelMinHitRequired at 3 whatever small groups come and go
   e.slack = 99 - u4;               // negative: no tolerated edit at all (the statistics are live for this read)
   e.fragile = maxList > 10000;     // lists beyond 10000 postings drive removeOnlyRepeats (SeqSet.hpp:802)
-  e.heavy = nPost > 8192;
+  static const size_t heavyPostings = getenv("T4_HEAVY_POSTINGS") ? (size_t)atol(getenv("T4_HEAVY_POSTINGS")) : 8192;   // (development aid: what counts as heavy)
+  e.heavy = nPost > heavyPostings;
 }
 
 // Examine what the commit(s) since the last call changed for every window entry that is still valid.
@@ -1429,6 +1431,7 @@ int t4_assembler::prefetchLive(int n, const char *const *reads, const int *stran
   if (nHelp > 0) helpers->wait();
   secGroups += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg1).count();
   ++queries; ++rounds; readsQueried += m;
+  for (int sl : todo) if (pool[sl]->heavy) ++heavyQueried;
   if (rc) { dropWindow(); return rc; }
   for (int i = 0; i < m; ++i) {
     Cached &c = *pool[todo[i]];
@@ -1634,8 +1637,8 @@ int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n) {
                          a->invContig, a->invFragile, a->tolerated, (int64_t)(a->secDelta * 1e6), (int64_t)(a->secGroups * 1e6), (int64_t)(a->secEvents * 1e6), (int64_t)(a->secQuery * 1e6)};
   for (int i = 0; i < n && i < 16; ++i) out[i] = v[i];
   if (n >= 23) t4_add_query_stats(a->ctx, out + 16);
-  if (getenv("T4_TIMING")) fprintf(stderr, "timing: assembler host seconds: add_read calls %.3f (incl. fallback queries), prefetch calls %.3f (of which query %.3f, deltas %.3f, registering k-mers %.3f), event examination %.3f, index edits %.3f\n",
-                                   a->secAddTotal, a->secPrefetch, a->secQuery, a->secDelta, a->secRegister, a->secEvents, a->index.secOps);
+  if (getenv("T4_TIMING")) fprintf(stderr, "timing: assembler host seconds: add_read calls %.3f (incl. fallback queries), prefetch calls %.3f (of which query %.3f, deltas %.3f, registering k-mers %.3f), event examination %.3f, index edits %.3f; re-queries of heavy reads %lld\n",
+                                   a->secAddTotal, a->secPrefetch, a->secQuery, a->secDelta, a->secRegister, a->secEvents, a->index.secOps, (long long)a->heavyQueried);
   return T4_OK;
 }
 int t4_assembler_output(t4_assembler *a, const char *path) { return a ? a->output(path) : T4_ERR_ARG; }
