@@ -136,8 +136,6 @@ static inline void __threadfence_block() {}
 
 // ---- host API
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
-#define hipDeviceScheduleSpin 1u
-static inline hipError_t hipSetDeviceFlags(unsigned) { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
   memset(p, 0, sizeof(*p)); p->multiProcessorCount = 8; strcpy(p->name, "hipemu"); strcpy(p->gcnArchName, "emu");

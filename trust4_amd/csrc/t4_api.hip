@@ -214,9 +214,6 @@ int t4_init(int device_ordinal, t4_ctx **out) {
   *out = nullptr;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_ordinal < 0 || device_ordinal >= ndev) return T4_ERR_HIP;
-  // a dependent chain of small launches (the AddRead query rounds) waits on the stream tens of thousands of times: the waiting
-  // thread may spin instead of sleeping (T4_SCHEDULE_SPIN=1; it must be asked for before the device is first used)
-  if (getenv("T4_SCHEDULE_SPIN") && atoi(getenv("T4_SCHEDULE_SPIN")) > 0) (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
   if (hipSetDevice(device_ordinal) != hipSuccess) return T4_ERR_HIP;
   t4_ctx *c = new t4_ctx();
   c->device = device_ordinal;
@@ -1358,7 +1355,7 @@ int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
       qa.extendLater = deferMin; qa.outDev = c->aqRecDev; qa.recRead = c->aqRecRead;
     }
     static const int bigThreads = getenv("T4_AQ_THREADS") ? atoi(getenv("T4_AQ_THREADS")) : 512;   // workgroup of the 8192-hit tier of this path
-    const int threads = smallFirst ? 256 : (bigThreads == 1024 && !views) ? 1024 : bigThreads == 512 ? 512 : 256;
+    const int threads = (!smallFirst && bigThreads == 512) ? 512 : 256;
     const int grid0 = smallFirst ? (n < c->cus * TIER_BLOCKS_PER_CU[0] ? n : c->cus * TIER_BLOCKS_PER_CU[0]) : (nFirst > 0 ? nFirst : 1);
     // scratch of the fallback DPs: the blocks of the LDS launch first, those of a concurrent global-tier launch behind them
     if ((r = ensureScratch(c, (grid0 > c->cus * 2 ? grid0 : c->cus * 2) * threads + nDirect * G_THREADS))) return r;
@@ -1395,8 +1392,7 @@ int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
         wf.gKeys = c->gKeys + skip * G_CAP; wf.gPairs = c->gPairs + skip * G_CAP * 2; wf.gCand = c->gCand;
         wf.gOv = c->gOv + skip * G_MAXOV * 10; wf.gFin = c->gFin + skip * G_MAXOV * 10; wf.gOrd = c->gOrd + skip * G_MAXOV;
         wf.gCap = G_CAP; wf.gMaxOv = G_MAXOV;
-        if (threads == 1024) hipLaunchKernelGGL((t4k::queryKernel<8192, 512, 1024, 1>), dim3(grid0), dim3(1024), 0, c->stream, base, bv, wf, qa);
-        else if (threads == 512) launchTier<8192, 512, 512>(grid0, c->stream, base, bv, wf, qa);
+        if (threads == 512) launchTier<8192, 512, 512>(grid0, c->stream, base, bv, wf, qa);
         else launchTier<8192, 512, 256>(grid0, c->stream, base, bv, wf, qa);
       }
       HIPCHK(c, hipGetLastError());

@@ -414,7 +414,6 @@ struct t4_assembler : IndexListener {
     std::string read; int strand, barcode, skip; int32_t cnt; bool valid; std::vector<t4_overlap> ov, ext; std::vector<int32_t> extRet;
     // live sets
     int64_t uid = 0;
-    bool heavy = false;          // its k-mers' lists hold more postings than the LDS tiers take (known from its first query on)
     bool registered = false;     // its k-mers are in winKmers (done beside its first query: nothing looks an entry up before it holds a result)
     unsigned char tier = 0;      // the last query of this read ended on the global-scratch tier
     bool fragile = false;        // any change of one of its keys' lists invalidates it
@@ -462,7 +461,6 @@ struct t4_assembler : IndexListener {
     }
   } winKmers;
   size_t winKmerRefs = 0, winKmerLive = 0;
-  int64_t heavyQueried = 0;   // queries of reads already known as heavy (re-queries)
   std::vector<Cached *> pool;      // window entries by slot (stable while the entry lives)
   std::vector<int> freeSlots;
   std::deque<int> order;           // slots of the upcoming reads, head first
@@ -1244,8 +1242,6 @@ void t4_assembler::buildGroups(Cached &e) {
   // group statistics of GetOverlapsFromHits leave novelMinHitRequired at 3 whatever small groups come and go
   e.slack = 99 - u4;               // negative: no tolerated edit at all (the statistics are live for this read)
   e.fragile = maxList > 10000;     // lists beyond 10000 postings drive removeOnlyRepeats (SeqSet.hpp:802)
-  static const size_t heavyPostings = getenv("T4_HEAVY_POSTINGS") ? (size_t)atol(getenv("T4_HEAVY_POSTINGS")) : 8192;   // (development aid: what counts as heavy)
-  e.heavy = nPost > heavyPostings;
 }
 
 // Examine what the commit(s) since the last call changed for every window entry that is still valid.
@@ -1372,7 +1368,7 @@ int t4_assembler::prefetchLive(int n, const char *const *reads, const int *stran
     Cached &c = *pool[sl];
     c.read = reads[i]; c.strand = strands[i]; c.barcode = barcodes ? barcodes[i] : -1; c.skip = repetitive; c.cnt = 0; c.valid = false;
     c.ov.clear(); c.ext.clear(); c.extRet.clear();
-    c.uid = nextUid++; c.tier = 0; c.registered = false; c.heavy = false;
+    c.uid = nextUid++; c.tier = 0; c.registered = false;
     order.push_back(sl);
   }
   // Entries far behind the head rarely survive until they are consumed: (re-)query only as far ahead as a few times what a
@@ -1385,13 +1381,7 @@ int t4_assembler::prefetchLive(int n, const char *const *reads, const int *stran
   static const int fixedAhead = getenv("T4_QUERY_AHEAD") ? atoi(getenv("T4_QUERY_AHEAD")) : 0;
   size_t ahead = fixedAhead > 0 ? (size_t)fixedAhead : (size_t)(3.0 * runEma) + 12;
   std::vector<int> todo;
-  // A read that met thousands of contigs last time (it ended on the global-scratch tier) makes its round last as long as it
-  // takes, and dies with nearly every commit: it is asked again only when it is about to be consumed.
-  static const size_t heavyAhead = getenv("T4_HEAVY_AHEAD") ? (size_t)atoi(getenv("T4_HEAVY_AHEAD")) : 0;
-  for (size_t i = 0; i < order.size() && i < ahead; ++i) {
-    const Cached &c = *pool[order[i]];
-    if (!c.valid && !(heavyAhead > 0 && c.heavy && i >= heavyAhead)) todo.push_back(order[i]);
-  }
+  for (size_t i = 0; i < order.size() && i < ahead; ++i) if (!pool[order[i]]->valid) todo.push_back(order[i]);
   if (todo.empty()) return T4_OK;
   int rc;
   const int m = (int)todo.size();
@@ -1431,7 +1421,6 @@ int t4_assembler::prefetchLive(int n, const char *const *reads, const int *stran
   if (nHelp > 0) helpers->wait();
   secGroups += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg1).count();
   ++queries; ++rounds; readsQueried += m;
-  for (int sl : todo) if (pool[sl]->heavy) ++heavyQueried;
   if (rc) { dropWindow(); return rc; }
   for (int i = 0; i < m; ++i) {
     Cached &c = *pool[todo[i]];
@@ -1637,8 +1626,8 @@ int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n) {
                          a->invContig, a->invFragile, a->tolerated, (int64_t)(a->secDelta * 1e6), (int64_t)(a->secGroups * 1e6), (int64_t)(a->secEvents * 1e6), (int64_t)(a->secQuery * 1e6)};
   for (int i = 0; i < n && i < 16; ++i) out[i] = v[i];
   if (n >= 23) t4_add_query_stats(a->ctx, out + 16);
-  if (getenv("T4_TIMING")) fprintf(stderr, "timing: assembler host seconds: add_read calls %.3f (incl. fallback queries), prefetch calls %.3f (of which query %.3f, deltas %.3f, registering k-mers %.3f), event examination %.3f, index edits %.3f; re-queries of heavy reads %lld\n",
-                                   a->secAddTotal, a->secPrefetch, a->secQuery, a->secDelta, a->secRegister, a->secEvents, a->index.secOps, (long long)a->heavyQueried);
+  if (getenv("T4_TIMING")) fprintf(stderr, "timing: assembler host seconds: add_read calls %.3f (incl. fallback queries), prefetch calls %.3f (of which query %.3f, deltas %.3f, registering k-mers %.3f), event examination %.3f, index edits %.3f\n",
+                                   a->secAddTotal, a->secPrefetch, a->secQuery, a->secDelta, a->secRegister, a->secEvents, a->index.secOps);
   return T4_OK;
 }
 int t4_assembler_output(t4_assembler *a, const char *path) { return a ? a->output(path) : T4_ERR_ARG; }

@@ -1494,7 +1494,9 @@ __device__ unsigned dpWave(const char *t, const T4PW *w, int lent, const char *p
   if (lent > lenp) rightBand += lent - lenp; else if (lent < lenp) leftBand += lenp - lent;
   const int W = leftBand + rightBand + 1;
   if (W > 64 || lent > T4_MAXGAP || lenp > T4_MAXGAP) return DP_FAIL;
-  if (!PW) { for (int i = d; i < lent; i += 64) tbuf[i] = t[i]; }
+  // the target's characters / predicate bytes next to the wavefront (one byte per lane per step: read from global memory its
+  // latency would be the cost of the step)
+  for (int i = d; i < lent; i += 64) tbuf[i] = PW ? (char)w[i] : t[i];
   const int negInf = (lent + 1) * (lenp + 1) * (-4);
   const int e0 = -4 + (lenp + 1) * (-4);
   const int q4 = 4 * (lenp + 1);
@@ -1538,7 +1540,7 @@ __device__ unsigned dpWave(const char *t, const T4PW *w, int lent, const char *p
       } else { dM = M; dC0 = C0; }
       const char pc = p[i - 1];
       if (PW) {
-        const bool eq = baseEqualW(w[j - 1], pc);
+        const bool eq = baseEqualW((T4PW)tbuf[j - 1], pc);
         const int dsc = dM + (eq ? 2 : -2);
         int m = dsc;
         if (lM - 4 > m) m = lM - 4;
@@ -1587,7 +1589,7 @@ template <> struct T4TbufPtr<true> { typedef const T4_LDS_AS char *type; };
 //   B = (i, 2L+1): left = own new A, upper (i-1, 2L+2) = lane L+1's new A (one DPP row shift), diagonal = own old B
 // i.e. 8 DPP moves and two full cell updates per pair, every lane busy, two alignments per 16-lane DPP row. Every lane
 // passes the job of its group of 8 (has == false: none); jobs whose band is wider than 16 columns or whose sides exceed
-// T4_MAXGAP (or the group's tcap bytes of LDS at tbuf, affine only) get DP_FAIL and are left to dpWave. All 64 lanes call it.
+// T4_MAXGAP (or the group's tcap bytes of LDS at tbuf) get DP_FAIL and are left to dpWave. All 64 lanes call it.
 // p always lives in LDS (the read's segment); TLDS says that tbuf does too (every tier but the global-scratch one): the loop then
 // reads its characters with ds_read (lgkmcnt only, in order) instead of flat loads, which the prefetch of the next step needs.
 template <bool PW, bool TLDS>
@@ -1613,8 +1615,8 @@ __device__ T4_NI unsigned dpOct(bool has, const char *t, const T4PW *w, int lent
   int leftBand = 5, rightBand = 5;
   if (lent > lenp) rightBand += lent - lenp; else if (lent < lenp) leftBand += lenp - lent;
   const int W = leftBand + rightBand + 1;
-  if (run && (W > 16 || lent > T4_MAXGAP || lenp > T4_MAXGAP || (!PW && lent > tcap))) { result = DP_FAIL; run = false; }
-  if (!PW && run) { for (int i = L; i < lent; i += 8) tbuf[i] = t[i]; }
+  if (run && (W > 16 || lent > T4_MAXGAP || lenp > T4_MAXGAP || lent > tcap)) { result = DP_FAIL; run = false; }
+  if (run) { for (int i = L; i < lent; i += 8) tbuf[i] = PW ? (char)w[i] : t[i]; }
   const int negInf = (lent + 1) * (lenp + 1) * (-4);
   const int e0 = -4 + (lenp + 1) * (-4);
   const int q4 = 4 * (lenp + 1);
@@ -1671,7 +1673,7 @@ __device__ T4_NI unsigned dpOct(bool has, const char *t, const T4PW *w, int lent
           }
         }
         if (PW) {
-          const bool eq = baseEqualW(w[j - 1], pc);
+          const bool eq = baseEqualW((T4PW)tl[j - 1], pc);
           const int dsc = dM + (eq ? 2 : -2);
           int m = dsc;
           if (lM - 4 > m) m = lM - 4;
@@ -1730,7 +1732,7 @@ __device__ T4_NI unsigned dpOct(bool has, const char *t, const T4PW *w, int lent
           }
         }
         if (PW) {
-          const bool eq = baseEqualW(w[j - 1], pc);
+          const bool eq = baseEqualW((T4PW)tl[j - 1], pc);
           const int dsc = dM + (eq ? 2 : -2);
           int m = dsc;
           if (bM - 4 > m) m = bM - 4;
@@ -2361,9 +2363,11 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
 #endif
   {
     const int wave = lane >> 6, nw = NT >> 6, grp = (lane >> 3) & 7;
-    // pairs is dead here (cap >= 1024 ints): one slice per wave, cut into the eight groups' target buffers
-    const int rowCap = ((wm.cap * 4) / (nw * 8)) & ~15;
-    char *tbufWave = (char *)wm.pairs + wave * 8 * rowCap;
+    // target buffers in LDS, one slice per wave, cut into the eight groups' buffers: pairs is dead here (cap >= 1024 ints); the
+    // global-scratch tier, whose pairs are global memory, takes the LDS block the sorts staged through
+    char *const tbufAll = wm.ldsArrays ? (char *)wm.pairs : (char *)wm.dirBuf;
+    const int rowCap = (((wm.ldsArrays ? wm.cap * 4 : wm.dirBytes)) / (nw * 8)) & ~15;
+    char *tbufWave = tbufAll + wave * 8 * rowCap;
     // (3a) eight alignments per wavefront, one per group of 8 lanes (bands of <= 16 columns: almost all of them)
     for (int q0 = wave * 8; q0 < nPend; q0 += nw * 8) {
       const int q = q0 + grp;
@@ -2384,14 +2388,12 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
       unsigned c = DP_FAIL;
       if (__any(asRef)) {
         const char *tq = ix.cons + si.consOff + pb + ix.k;
-        unsigned v = wm.ldsArrays ? dpOct<false, true>(asRef, tq, (const T4PW *)0, lent, r, lenp, tbufWave + grp * rowCap, rowCap)
-                                  : dpOct<false, false>(asRef, tq, (const T4PW *)0, lent, r, lenp, tbufWave + grp * rowCap, rowCap);
+        unsigned v = dpOct<false, true>(asRef, tq, (const T4PW *)0, lent, r, lenp, tbufWave + grp * rowCap, rowCap);
         if (asRef) c = v;
       }
       if (__any(asPw)) {
         const T4PW *wq = ix.pw + si.pwOff + pb + ix.k;
-        unsigned v = wm.ldsArrays ? dpOct<true, true>(asPw, (const char *)0, wq, lent, r, lenp, tbufWave + grp * rowCap, rowCap)
-                                  : dpOct<true, false>(asPw, (const char *)0, wq, lent, r, lenp, tbufWave + grp * rowCap, rowCap);
+        unsigned v = dpOct<true, true>(asPw, (const char *)0, wq, lent, r, lenp, tbufWave + grp * rowCap, rowCap);
         if (asPw) c = v;
       }
       if (has && (lane & 7) == 0) {
@@ -2417,7 +2419,7 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
       const char *r = ((o.flags & OV_PLUS) ? wm.seg : wm.rc) + pa + ix.k;
       const T4SeqInfo si = ix.seqs[o.seqIdx];
       unsigned c = DP_FAIL;
-      if (lent <= 8 * rowCap || !si.isRef)
+      if (lent <= 8 * rowCap)
         c = si.isRef ? dpWave<false>(ix.cons + si.consOff + pb + ix.k, (const T4PW *)0, lent, r, lenp, tbuf)
                      : dpWave<true>((const char *)0, ix.pw + si.pwOff + pb + ix.k, lent, r, lenp, tbuf);
       if (c == DP_FAIL && laneId() == 0) {   // band wider than a wavefront: lane-serial scratch version
