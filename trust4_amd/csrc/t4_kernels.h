@@ -1090,6 +1090,16 @@ __device__ T4_NI void bitonicSortReg(KeyT *keys, int n) {
 }
 __device__ __forceinline__ void bitonicSort32(unsigned *keys, int n) { bitonicSortReg<unsigned>(keys, n); }
 #endif
+#ifndef T4_V0_NOKEYSORT
+#define T4_V0_NOKEYSORT 0
+#endif
+#ifndef T4_V0_SERIALPRE
+#define T4_V0_SERIALPRE 0
+#endif
+// (out of line, the call cost the rough-annotation kernels 9 % -- profiles/r02_annotate_inline_ab.txt -- although they never make it)
+#ifndef T4_PREFILTER_NI
+#define T4_PREFILTER_NI __forceinline__
+#endif
 #ifndef T4_OPT_OVKEYSORT
 #define T4_OPT_OVKEYSORT 1
 #endif
@@ -1837,6 +1847,8 @@ __device__ void walkOverlap(const T4IndexView &ix, WaveMem &wm, WaveState *ws, O
 // not add to the kernel's pressure). For a reference-gene overlap under radius > 0 the walk only ever stops on geometry (a
 // gap beyond nomatchGapLimit), so its sums are prefix sums up to that anchor pair j*: find j*, add the pairs before it (pair
 // j* itself has added its 2K before the reference looks at the gap), list their gap jobs.
+// ALL: the row walk covers the other class as well when the list is short (the AddRead / AssignRead kernels).
+template <bool ALL>
 __device__ T4_NI void walkOverlapsRows(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int overlapCnt) {
   const int lane = tid(), NT = nthr(), K = ix.k;
   const int row = lane >> 4, rl = lane & 15, nRows = NT >> 4;
@@ -1844,9 +1856,9 @@ __device__ T4_NI void walkOverlapsRows(const T4IndexView &ix, WaveMem &wm, WaveS
   // the data-dependent walk, one lane per overlap (a row per overlap left 15 of 16 lanes idle through thousands of them)
   // -- unless the list is short: then a row per overlap walks its chain sixteen pairs at a time here too. That walk stops at
   // the first pair off the diagonal or whose gap is beyond nomatchGapLimit, and lists the gaps before it.
-  const bool rowsForAll = overlapCnt <= 4 * nRows;
+  const bool rowsForAll = ALL && overlapCnt <= 4 * nRows;
   int anyFast = 0;
-  if (!rowsForAll) {
+  if (ALL && !rowsForAll) {
     for (int i = lane; i < overlapCnt; i += NT) {
       OvRec oc = wm.ov[wm.ord[i]];
       if ((oc.flags & OV_ISREF) != 0 && ix.radius > 0) anyFast = 1;
@@ -1864,10 +1876,11 @@ __device__ T4_NI void walkOverlapsRows(const T4IndexView &ix, WaveMem &wm, WaveS
       const OvRec &o = wm.ov[ovSlot];
       chainPos = o.chainPos; chainLen = o.chainLen;
       fast = (o.flags & OV_ISREF) != 0 && ix.radius > 0;
+      if (!ALL && !fast && rl == 0) { OvRec oc = o; walkOverlap(ix, wm, ws, oc, i, true); }   // (rough annotation: the rare novel overlap of a mixed set)
     }
     const unsigned *hc = (const unsigned *)(wm.keys + chainPos);
     int jStop = 0x7FFFFFFF;
-    const bool slow = has && !fast && rowsForAll;
+    const bool slow = ALL && has && !fast && rowsForAll;
     if (slow)
       for (int j = 1 + rl; j < chainLen; j += 16) {
         const unsigned pp = hc[j - 1], cp = hc[j];
@@ -2159,8 +2172,8 @@ __device__ T4_NI bool sortOverlapsByKey(WaveMem &wm, WaveState *ws, int overlapC
 }
 
 // The fast pre-filters of GetOverlapsFromRead against the best novel overlap so far (SeqSet.hpp:1705-1794), on the scored list
-// wm.ov[wm.ord[0 .. overlapCnt)]. Out of line: its registers are its own.
-__device__ T4_NI void prefilterNovel(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int overlapCnt, int segLen) {
+// wm.ov[wm.ord[0 .. overlapCnt)].
+__device__ T4_PREFILTER_NI void prefilterNovel(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int overlapCnt, int segLen) {
   const int lane = tid(), NT = nthr();
   // the fast pre-filters against the best novel overlap (SeqSet.hpp:1705-1794) are order dependent: overlap i is judged
   // against the best scored novel overlap among 0 .. i-1. That best changes a handful of times over thousands of overlaps,
@@ -2269,7 +2282,7 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
   bool keySorted = false;
 #if T4_OPT_OVKEYSORT
   // (threshold: 256 overlaps; lower when the testing aid T4Work::capLimit has shrunk the staging block, so that small cases come here)
-  if (!wm.ldsArrays && wm.ldsSort && overlapCnt > (wm.ldsSortCap >= 4096 ? 256 : wm.ldsSortCap / 16) && overlapCnt <= 16384)
+  if ((ROWS || !T4_V0_NOKEYSORT) && !wm.ldsArrays && wm.ldsSort && overlapCnt > (wm.ldsSortCap >= 4096 ? 256 : wm.ldsSortCap / 16) && overlapCnt <= 16384)
     keySorted = sortOverlapsByKey(wm, ws, overlapCnt);
 #endif
   if (!keySorted)
@@ -2305,7 +2318,7 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
   if (lane == 0) ws->jobCount = 0;
   __syncthreads();
 #if T4_OPT_ROWWALK
-  walkOverlapsRows(ix, wm, ws, overlapCnt);
+  walkOverlapsRows<ROWS>(ix, wm, ws, overlapCnt);
 #else
   for (int i = lane; i < overlapCnt; i += NT) {
     OvRec o = wm.ov[wm.ord[i]];
@@ -2454,7 +2467,43 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
   }
   __syncthreads();
   PHASE_MARK(ws, 10);
-  if (ix.hasNovel && overlapCnt > 50) prefilterNovel(ix, wm, ws, overlapCnt, segLen);
+  if (ix.hasNovel && overlapCnt > 50) {
+    if (ROWS || !T4_V0_SERIALPRE) prefilterNovel(ix, wm, ws, overlapCnt, segLen);
+    else {
+      // (rough-annotation kernels: the sequential form, inline -- the out-of-line call cost them a tenth of their speed)
+      if (lane == 0) {
+        int best = -1;
+        const int len = segLen;
+        for (int i = 0; i < overlapCnt; ++i) {
+          OvRec &o = wm.ov[wm.ord[i]];
+          bool isRef = (o.flags & OV_ISREF) != 0;
+          if (!isRef && best != -1) {
+            const OvRec &bn = wm.ov[wm.ord[best]];
+            double bs = ovSim(bn);
+            int m0 = o.chainLen;
+            bool cut = false;
+            if (bn.rs == 0 && bn.re == len - 1) {
+              if (bs == 1) cut = true;
+              else if (bs > ix.repeatSim && m0 < 0.9 * bn.matchCnt) cut = true;
+            }
+            if (!cut && bn.rs + len - 1 - bn.re < ix.radius) {
+              if (bs == 1 && m0 < 0.9 * bn.matchCnt) cut = true;
+              else if (bs > ix.repeatSim && m0 < 0.8 * bn.matchCnt) cut = true;
+            }
+            if (!cut && o.ss - o.rs >= ix.radius && o.se + (len - 1 - o.re) + ix.radius < ix.seqs[o.seqIdx].len &&
+                bn.matchCnt > 0.97 * (2 * len) && bs > ix.repeatSim && m0 < 0.9 * bn.matchCnt) cut = true;
+            if (!cut && m0 < 0.4 * bn.matchCnt) cut = true;
+            if (!cut && overlapCnt > 1000 && m0 < 0.9 * bn.matchCnt) cut = true;
+            if (cut) { o.matchCnt = m0; o.indelCnt = 0; o.flags |= OV_SIMZERO; continue; }
+          }
+          if (!isRef && !(o.flags & OV_SIMZERO) && ovSim(o) > 0) {
+            if (best == -1 || ovLess(o, wm.ov[wm.ord[best]], true)) best = i;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
 #ifdef T4_DEBUG
   if (lane == 0) for (int i = 0; i < overlapCnt; ++i) { OvRec o = wm.ov[wm.ord[i]]; printf("DBG ov %d seq %d %d-%d %d-%d m %d ind %d fl %d sim %f\n", i, o.seqIdx, o.rs, o.re, o.ss, o.se, o.matchCnt, o.indelCnt, o.flags, ovSim(o)); }
 #endif
