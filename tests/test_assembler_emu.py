@@ -111,3 +111,83 @@ def test_kmer_length_growth_in_lock_step(emu_engine, tmp_path):
     """ChangeKmerLength in the middle of an assembly (k 9 -> 11), with a speculation window standing: the live set is compacted,
     renumbered, re-indexed and its device image sent anew; everything after must still equal the reference call for call"""
     run_case(emu_engine, tmp_path, 7, 160, 10, window=24, grow_at=(170, 11))
+
+
+def _shared_segment_case(n_contigs, seed):
+    """contigs that all carry one 130 bp segment (with up to two substitutions each) between random flanks, and reads out of
+    that segment: every such read meets every contig -- the shape of a constant-gene read in a set of thousands of contigs"""
+    rnd = random.Random(seed)
+    rand = lambda n: "".join(rnd.choice("ACGT") for _ in range(n))
+    core = rand(130)
+    contigs = []
+    for c in range(n_contigs):
+        x = list(core)
+        for _ in range(rnd.choice([0, 0, 1, 2])):
+            p = rnd.randrange(len(x))
+            x[p] = rnd.choice([b for b in "ACGT" if b != x[p]])
+        contigs.append(rand(60) + "".join(x) + rand(60))
+    reads = []
+    for r in range(14):
+        c = contigs[rnd.randrange(n_contigs)]
+        a = rnd.choice([40, 55, 60, 70, 90])
+        rd = list(c[a:a + 140])
+        for _ in range(rnd.choice([0, 0, 1, 3])):
+            p = rnd.randrange(len(rd))
+            rd[p] = rnd.choice("ACGT")
+        reads.append("".join(rd))
+    reads += reads[:3]
+    return contigs, reads
+
+
+def _run_shared_segment(eng, tmp_path, n_contigs, window):
+    import trust4_amd
+    contigs, reads = _shared_segment_case(n_contigs, 11)
+
+    def play(asm, win):
+        log = []
+        for c, s in enumerate(contigs):
+            log.append(("new", asm.input_novel_read("C%d" % c, s, 1, -1)))
+        for i, rd in enumerate(reads):
+            if win and not asm.window_valid():
+                asm.prefetch(reads[i:i + win], [0] * len(reads[i:i + win]))
+            ret, strand = asm.add_read(rd, "", 0, -1, 1, 0, 0.9)
+            log.append(("add", ret, strand))
+            if ret < 0 and i % 2 == 0:
+                log.append(("new", asm.input_novel_read("N%d" % i, rd, 1, -1)))
+            if i % 5 == 4:
+                asm.update_all_consensus()
+        asm.update_all_consensus()
+        return log
+    ref, mine = RefSeqSet(9), trust4_amd.Assembler(eng, 9)
+    log_ref, log_mine = play(ref, 0), play(mine, window)
+    first_diff = next((i for i, (a, b) in enumerate(zip(log_ref, log_mine)) if a != b), None)
+    assert first_diff is None, (first_diff, log_ref[first_diff], log_mine[first_diff])
+    pa, pb = str(tmp_path / "ref_raw.out"), str(tmp_path / "mine_raw.out")
+    ref.output(pa)
+    mine.output(pb)
+    assert filecmp.cmp(pa, pb, shallow=False)
+    assert sum(1 for x in log_ref if x[0] == "add" and x[1] >= 0) >= 4
+    return log_ref
+
+
+def test_read_meeting_hundreds_of_contigs(emu_engine, tmp_path):
+    """600 overlaps per read: the read outgrows the LDS arrays inside its launch (tens of thousands of hits), its overlaps are
+    ordered by the key sort (more than 256 of them), the pre-filters against the best novel overlap are replayed in chunks (more
+    than 50 novel overlaps) and their ExtendOverlaps run in the extension kernel (more than 64)"""
+    _run_shared_segment(emu_engine, tmp_path, 600, 4)
+
+
+def test_read_meeting_hundreds_of_contigs_small_blocks(tmp_path):
+    """the same with the testing aid that shrinks the LDS staging block to 64 keys (T4_AQ_CAP_LIMIT is read once per process:
+    own process): hit sort and overlap key sort both go through the blocked sort in global scratch"""
+    import subprocess
+    import sys
+    code = ("import os, sys, pathlib\n"
+            "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import t4check\n"
+            "os.environ['T4_LIB'] = t4check.build_emulator_lib()\n"
+            "import trust4_amd, test_assembler_emu as t\n"
+            "t._run_shared_segment(trust4_amd.Engine(0), pathlib.Path(%r), 300, 4)\n"
+            "print('identical')\n") % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, T4_AQ_CAP_LIMIT="120"), capture_output=True, text=True)
+    assert p.returncode == 0 and "identical" in p.stdout, p.stderr[-1500:]
