@@ -203,10 +203,3 @@ def test_kmer_length_growth_in_lock_step(eng, tmp_path):
     from test_assembler_emu import run_case
     run_case(eng, tmp_path, 7, 400, 25, window=48, grow_at=(420, 11))
 
-
-@pytest.mark.skipif(not Ref.available(), reason="oracle/_ref not shipped")
-def test_read_meeting_a_thousand_contigs(eng, tmp_path):
-    """a thousand overlaps per read (key sort of the overlaps, chunked pre-filter replay, extension kernel, global-scratch
-    continuation) in lock-step with the reference SeqSet"""
-    from test_assembler_emu import _run_shared_segment
-    _run_shared_segment(eng, tmp_path, 1000, 6)
