@@ -199,3 +199,24 @@ def test_bam_extractor_synthetic_emulated(tmp_path):
 def test_bam_extractor_example_emulated(tmp_path):
     kept = compare(tmp_path, emulated_bam_extractor(), "/root/reference/example/example.bam", "/root/reference/hg38_bcrtcr.fa", [], True, False)
     assert kept == 198
+
+
+def test_bam_extractor_refuses_damaged_records(tmp_path):
+    """a record whose lengths do not add up, and a file cut inside a record: exit 1 with the reason, not partial output with exit 0"""
+    fa = str(tmp_path / "ref.fa")
+    with gzip.open(os.path.join(ROOT, "data", "hg38_bcrtcr.fa.gz"), "rb") as f, open(fa, "wb") as g:
+        g.write(f.read())
+    chroms = []
+    for line in open(fa):
+        if line.startswith(">") and line.split()[1] not in chroms:
+            chroms.append(line.split()[1])
+    refs = [(c, 1 << 28) for c in chroms]
+    good = bam_record("r1", 0, 0, 100, [(20, "M")], "ACGT" * 5, "I" * 20)
+    bad = bytearray(bam_record("r2", 0, 0, 200, [(20, "M")], "ACGT" * 5, "I" * 20))
+    bad[4 + 16:4 + 20] = struct.pack("<i", 5000)          # l_seq far beyond the record
+    exe = emulated_bam_extractor()
+    for name, payload, what in (("lens.bam", [good, bytes(bad)], "field lengths"), ("cut.bam", [good, good[:len(good) - 7]], "cut short")):
+        bam = str(tmp_path / name)
+        write_bam(bam, refs, payload)
+        p = subprocess.run([exe, "-b", bam, "-f", fa, "-o", str(tmp_path / "o")], capture_output=True, text=True)
+        assert p.returncode == 1 and what in p.stderr, (name, p.returncode, p.stderr[-300:])

@@ -68,6 +68,7 @@ struct BamRecord {
       else if (ty == 'A' || ty == 'c' || ty == 'C') i += 1;
       else if (ty == 's' || ty == 'S') i += 2;
       else if (ty == 'i' || ty == 'I' || ty == 'f') i += 4;
+      else if (ty == 'd') i += 8;
       else if (ty == 'B') {
         if (i + 5 > n) break;
         const char sub = (char)aux[i]; uint32_t cnt; memcpy(&cnt, &aux[i + 1], 4);
@@ -112,16 +113,26 @@ struct BamReader {
   }
   void rewind() { gzrewind(fp); header(); }
   void close() { if (fp) { gzclose(fp); fp = nullptr; } }
+  // false at the end of the file; a record that is cut short or whose lengths do not add up ends the program (a truncated or
+  // corrupt BAM must not pass for a shorter one)
+  [[noreturn]] void corrupt(const char *what) const {
+    fprintf(stderr, "%s: %s -- truncated or corrupt BAM\n", path.c_str(), what);
+    exit(1);
+  }
   bool next(BamRecord &r) {
     int32_t block = 0;
-    if (gzread(fp, &block, 4) != 4 || block < 32) return false;
+    const int got = gzread(fp, &block, 4);
+    if (got == 0) return false;                        // clean end of the file, at a record boundary
+    if (got != 4) corrupt("record header cut short");
+    if (block < 32 || block > (1 << 28)) corrupt("implausible record size");
     std::vector<uint8_t> buf((size_t)block);
-    if (!readExact(buf.data(), (size_t)block)) return false;
+    if (!readExact(buf.data(), (size_t)block)) corrupt("record cut short");
     const uint8_t *p = buf.data();
     uint8_t lname; uint16_t ncig, flag; int32_t lseq;
     memcpy(&r.tid, p, 4); memcpy(&r.pos, p + 4, 4); lname = p[8]; memcpy(&ncig, p + 12, 2); memcpy(&flag, p + 14, 2);
     memcpy(&lseq, p + 16, 4); memcpy(&r.mtid, p + 20, 4); memcpy(&r.mpos, p + 24, 4);
     r.flag = flag; r.ncigar = ncig; r.lseq = lseq;
+    if (lseq < 0 || 32 + (size_t)lname + 4 * (size_t)ncig + ((size_t)lseq + 1) / 2 + (size_t)lseq > (size_t)block) corrupt("field lengths exceed the record");
     size_t o = 32;
     r.name.assign((const char *)p + o, lname ? (size_t)lname - 1 : 0); o += lname;
     r.cigar.resize(ncig);
