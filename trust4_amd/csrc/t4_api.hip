@@ -235,10 +235,10 @@ void t4_destroy(t4_ctx *c) {
   if (getenv("T4_PHASE_DUMP")) {   // development aid: cycles per kernel phase over the life of the ctx
     unsigned long long ph[T4_NPHASE];
     if (hipMemcpyFromSymbol(ph, HIP_SYMBOL(t4k::g_phaseCycles), sizeof(ph)) == hipSuccess) {
-      static const char *names[T4_NPHASE] = {"other", "seed", "expand", "sort", "stats", "runs", "bigsort", "chain", "ovsort", "score", "prefilter", "final", "annotate", "score:quick", "score:banded", "score:finish", "extend", "after-extend", "-", "-"};
+      static const char *names[32] = {"other", "seed:lookup", "expand", "sort", "stats", "runs", "bigsort", "chain", "ovsort", "score", "prefilter", "final", "annotate", "score:quick", "score:banded", "score:finish", "extend:ungapped", "after-extend", "extend:list", "extend:dp4", "extend:dp1", "extend:combine", "seed:replay", "seed:scan", "-", "-", "-", "-", "-", "-", "-", "-"};
       unsigned long long tot = 0;
       for (int i = 0; i < T4_NPHASE; ++i) tot += ph[i];
-      for (int i = 0; i < T4_NPHASE; ++i) if (ph[i]) fprintf(stderr, "phase %-13s %6.2f%%  %.3e cycles\n", names[i], 100.0 * (double)ph[i] / (double)tot, (double)ph[i]);
+      for (int i = 0; i < T4_NPHASE; ++i) if (ph[i]) fprintf(stderr, "phase %-16s %-7s %6.2f%%  %.3e cycles\n", names[i & 31], i < 32 ? "lds" : "global", 100.0 * (double)ph[i] / (double)tot, (double)ph[i]);
     }
   }
 #endif

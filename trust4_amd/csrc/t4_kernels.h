@@ -678,14 +678,16 @@ __device__ __forceinline__ bool ovLess(const OvRec &a, const OvRec &b, bool scor
 // ------------------------------------------------------------------------------------------------
 // optional per-phase cycle accounting (build with -DT4_PHASE_TIMING; read back through T4Work.phase)
 #ifdef T4_PHASE_TIMING
-#define T4_NPHASE 20
+#define T4_NPHASE 64   // ids 0-31: reads in the LDS tiers; the same + 32: reads in global scratch (WaveState::phaseBase)
 __device__ unsigned long long g_phaseCycles[T4_NPHASE];
 __device__ unsigned long long g_dbgCount[8];   // 0 jobs, 1 pending (banded) jobs, 2 wave-DP steps, 3 scratch fallbacks, 4 fallback cells, 5 fallback cycles
 #define DBG_ADD(i, v) do { atomicAdd(&g_dbgCount[i], (unsigned long long)(v)); } while (0)
 #define PHASE_MARK(ws, id)                                                                  \
-  do { if (threadIdx.x == 0) { long long now_ = clock64(); atomicAdd(&g_phaseCycles[(ws)->curPhase], (unsigned long long)(now_ - (ws)->phaseT0)); (ws)->phaseT0 = now_; (ws)->curPhase = (id); } } while (0)
+  do { if (threadIdx.x == 0) { long long now_ = clock64(); atomicAdd(&g_phaseCycles[(ws)->curPhase], (unsigned long long)(now_ - (ws)->phaseT0)); (ws)->phaseT0 = now_; (ws)->curPhase = (id) + (ws)->phaseBase; } } while (0)
+#define PHASE_MARK_RED(red, id) PHASE_MARK((WaveState *)((char *)(red) - offsetof(WaveState, red)), id)
 #else
 #define PHASE_MARK(ws, id) do { } while (0)
+#define PHASE_MARK_RED(red, id) do { } while (0)
 #define DBG_ADD(i, v) do { } while (0)
 #endif
 
@@ -715,7 +717,7 @@ struct WaveState { // wave-uniform scalars kept in LDS
   short contigA[64], contigB[64];
   int nvPossible[2], nvLongest[2];   // novel group statistics of GetOverlapsFromHits (filter 1)
   unsigned hhBest[2];        // HasHitInSet: per strand, (distinct read offsets << 16) | (0xFFFF - bucket rank) of the best bucket
-  long long phaseT0; int curPhase;
+  long long phaseT0; int curPhase, phaseBase;
 };
 
 // Build segment chars (forward + reverse complement of the segment) from the packed read.
@@ -801,6 +803,7 @@ __device__ int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int
     if (cnt >= 100) big = 1;
   }
   big = blockSum(big, red) != 0;
+  PHASE_MARK_RED(red, 22);   // seed: the repeat-skip replay
   if ((skipLimit == 0 && !allowTotalSkip) || !big) {
     // no `continue` can fire: prevKmerCode is always the code of the previous position
     for (int q = lane; q < 2 * nk; q += NT) {
@@ -838,6 +841,7 @@ __device__ int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int
     }
   }
   __syncthreads();
+  PHASE_MARK_RED(red, 23);   // seed: prefix sums
   // exclusive prefix sums over the 2*nk positions
   int carry = 0;
   for (int q0 = 0; q0 < 2 * nk; q0 += NT) {
@@ -2780,6 +2784,7 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
     }
   }
   __syncthreads();
+  PHASE_MARK(ws, 18);   // extend: list of the gapped sides
   // E2: gapped sides, compacted into a list (wm.cand is dead here): first those whose direction bytes fit a quarter of a
   // wavefront's share of the buffer -- four per wavefront (one per 16-lane row), their tracebacks one lane per side -- then the
   // longer ones, one wavefront per side with its own slice; a side that fits no slice waits for the serial pass that owns the
@@ -2820,6 +2825,7 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
     e.match = (short)m; e.mis = (short)mm; e.indel = (short)ind; e.good = (short)good; e.pending = 0;
     sides[q] = e;
   };
+  PHASE_MARK(ws, 19);   // extend: four overhang DPs per wavefront + tracebacks
   {
     const int wave = lane >> 6, wl = lane & 63, row = wl >> 4;
     for (int c0 = 0; c0 < nFit; c0 += perChunk) {
@@ -2852,6 +2858,7 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
       __syncthreads();
     }
   }
+  PHASE_MARK(ws, 20);   // extend: the longer sides, one per wavefront
   {
     const int wave = lane >> 6, nw = NT >> 6, wl = lane & 63;
     const int slice = (dirBytes / nw) & ~15;
@@ -2883,6 +2890,7 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
     }
   }
   __syncthreads();
+  PHASE_MARK(ws, 21);   // extend: combine
   // E3: combine (SeqSet.hpp:1179-1266)
   for (int i = lane; i < n; i += NT) {
     const OvRec &o = wm.fin[wm.ord[i]];
@@ -2923,7 +2931,7 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
   unsigned long long hitTotal = 0;
   if (lane == 0) { ws->overflow = 0; ws->unsupported = 0; ws->finCount = 0; ws->nContig = 0; ws->ovCount = 0; }
 #ifdef T4_PHASE_TIMING
-  if (lane == 0) { ws->phaseT0 = clock64(); ws->curPhase = 0; }
+  if (lane == 0) { ws->phaseT0 = clock64(); ws->phaseBase = wm.ldsArrays ? 0 : 32; ws->curPhase = ws->phaseBase; }
 #endif
   __syncthreads();
   if (VARIANT == 1 && qa.mode == 4) {
