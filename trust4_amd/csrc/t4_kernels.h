@@ -287,9 +287,11 @@ __device__ bool dpAffine(const char *t, int lent, const char *p, int lenp, DPScr
 }
 
 // AlignAlgo::IsBaseEqual (AlignAlgo.hpp:49-55)
+// c is a character of an unpacked read (A, C, G, T or N): bits 1-2 of the four letters' codes tell them apart (A 00, C 01,
+// T 10, G 11), so the predicate bit is picked without a branch -- this test sits in the innermost loop of every alignment
+// against a novel contig, one character per lane, and a chain of comparisons there compiles to divergent branches.
 __device__ __forceinline__ bool baseEqualW(T4PW w, char c) {
-  if ((w & 16) || c == 'N') return true;
-  return (w >> nuc2(c)) & 1;
+  return (((unsigned)w >> 4) | (unsigned)(c == 'N') | ((unsigned)w >> ((0xB4u >> (c & 6)) & 3u))) & 1u;
 }
 
 // AlignAlgo::GlobalAlignment_PosWeight (AlignAlgo.hpp:57-216). When `align` is non-null the edit
