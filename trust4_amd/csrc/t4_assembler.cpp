@@ -84,6 +84,83 @@ inline uint64_t mix64h(uint64_t z) {   // == t4k::mix64 (t4_kernels.h): slot of 
 // layout IS the layout of the device image of a live set: `mirror` turns on the bookkeeping of what changed
 // since the last t4_index_apply_delta (table slots and postings by position).
 struct ListRef { uint32_t start = 0, cnt = 0, cap = 0; int64_t slot = -1; bool dirty = false; };
+// (code, bucket) -> ListRef: open addressing over entry numbers, the entries themselves in a deque (their addresses are kept
+// by the dirty-key list). The index edits of a commit are tens of thousands of lookups; a node-based map spent most of the
+// time of those edits chasing its nodes.
+struct KeyMap {
+  struct value_type { Key first; ListRef second; bool live = false; };
+  std::deque<value_type> store;
+  std::vector<int32_t> table;      // entry number, -1 empty, -2 erased
+  std::vector<int32_t> freeEntries;
+  size_t nLive = 0, nSlotsUsed = 0;
+  struct iterator {
+    KeyMap *m; size_t i;
+    value_type &operator*() const { return m->store[i]; }
+    value_type *operator->() const { return &m->store[i]; }
+    iterator &operator++() { ++i; while (i < m->store.size() && !m->store[i].live) ++i; return *this; }
+    bool operator!=(const iterator &o) const { return i != o.i; }
+    bool operator==(const iterator &o) const { return i == o.i; }
+  };
+  iterator begin() { size_t i = 0; while (i < store.size() && !store[i].live) ++i; return iterator{this, i}; }
+  iterator end() { return iterator{this, store.size()}; }
+  struct const_iterator {
+    const KeyMap *m; size_t i;
+    const value_type &operator*() const { return m->store[i]; }
+    const value_type *operator->() const { return &m->store[i]; }
+    const_iterator &operator++() { ++i; while (i < m->store.size() && !m->store[i].live) ++i; return *this; }
+    bool operator!=(const const_iterator &o) const { return i != o.i; }
+    bool operator==(const const_iterator &o) const { return i == o.i; }
+  };
+  const_iterator begin() const { size_t i = 0; while (i < store.size() && !store[i].live) ++i; return const_iterator{this, i}; }
+  const_iterator end() const { return const_iterator{this, store.size()}; }
+  size_t size() const { return nLive; }
+  void clear() { store.clear(); table.clear(); freeEntries.clear(); nLive = nSlotsUsed = 0; }
+  int64_t probe(const Key &k) const {   // entry number or -1
+    if (table.empty()) return -1;
+    const size_t mask = table.size() - 1;
+    for (size_t s = KeyHash()(k) & mask;; s = (s + 1) & mask) {
+      const int32_t e = table[s];
+      if (e == -1) return -1;
+      if (e >= 0 && store[(size_t)e].first == k) return e;
+    }
+  }
+  void rehash(size_t n) {
+    table.assign(n, -1);
+    const size_t mask = n - 1;
+    for (size_t e = 0; e < store.size(); ++e) if (store[e].live) {
+      size_t s = KeyHash()(store[e].first) & mask;
+      while (table[s] != -1) s = (s + 1) & mask;
+      table[s] = (int32_t)e;
+    }
+    nSlotsUsed = nLive;
+  }
+  iterator find(const Key &k) { const int64_t e = probe(k); return e < 0 ? end() : iterator{this, (size_t)e}; }
+  const_iterator find(const Key &k) const { const int64_t e = probe(k); return e < 0 ? end() : const_iterator{this, (size_t)e}; }
+  std::pair<iterator, bool> emplace(const Key &k, const ListRef &v) {
+    const int64_t e0 = probe(k);
+    if (e0 >= 0) return std::make_pair(iterator{this, (size_t)e0}, false);
+    if (2 * (nSlotsUsed + 1) > table.size()) rehash(table.empty() ? 1024 : (2 * (nLive + 1) > table.size() / 2 ? table.size() * 2 : table.size()));
+    size_t e;
+    if (!freeEntries.empty()) { e = (size_t)freeEntries.back(); freeEntries.pop_back(); }
+    else { e = store.size(); store.emplace_back(); }
+    value_type &x = store[e];
+    x.first = k; x.second = v; x.live = true;
+    const size_t mask = table.size() - 1;
+    size_t s = KeyHash()(k) & mask;
+    while (table[s] >= 0) s = (s + 1) & mask;
+    if (table[s] == -1) ++nSlotsUsed;
+    table[s] = (int32_t)e;
+    ++nLive;
+    return std::make_pair(iterator{this, e}, true);
+  }
+  void erase(iterator it) {
+    const size_t mask = table.size() - 1;
+    for (size_t s = KeyHash()(it->first) & mask;; s = (s + 1) & mask) if (table[s] == (int32_t)it.i) { table[s] = -2; break; }
+    store[it.i].live = false;
+    freeEntries.push_back((int32_t)it.i);
+    --nLive;
+  }
+};
 struct IndexListener {
   virtual void onInsert(uint64_t code, int h, int idx, int off, uint32_t sizeAfter) = 0;
   virtual void onRemove(uint64_t code, int h, int idx, int off, uint32_t sizeAfter) = 0;
@@ -93,7 +170,7 @@ struct IndexListener {
 struct HostIndex {
   int k; bool considerBarcode = false;
   IndexListener *hook = nullptr;
-  typedef std::unordered_map<Key, ListRef, KeyHash> Map;
+  typedef KeyMap Map;
   Map map;
   std::vector<Post> arena;
   size_t arenaUsed = 0, garbage = 0;
@@ -465,7 +542,9 @@ struct t4_assembler : IndexListener {
   std::vector<int> freeSlots;
   std::deque<int> order;           // slots of the upcoming reads, head first
   struct IdxEv { uint64_t code; int h, idx, off, delta; uint32_t sizeAfter; };
-  std::vector<IdxEv> idxEvents;
+  std::vector<IdxEv> idxEvents, evNet;
+  std::vector<uint32_t> evOrder;
+  std::vector<int> evSum;
   struct StructEv { int kind /* 0 region, 1 shift, 2 whole contig */, c, a, b; };
   std::vector<StructEv> structEvents;
   double runEma = 8; int64_t hitsAtLastRound = 0;   // reads served per round, recently
@@ -1280,33 +1359,51 @@ void t4_assembler::processEvents() {
   if (!idxEvents.empty()) {
     bool ins = false, rem = false;
     for (const IdxEv &ev : idxEvents) { if (ev.delta > 0) ins = true; else rem = true; }
-    struct Net { int delta; };
-    std::vector<IdxEv> net;
+    // (both by sorting event numbers in scratch vectors that live with the builder: this runs after every commit, and hash
+    // maps built and torn down each time were most of its cost)
+    std::vector<IdxEv> &net = evNet;
+    net.clear();
+    std::vector<uint32_t> &ordv = evOrder;
+    const uint32_t nEv = (uint32_t)idxEvents.size();
     if (ins && rem) {
-      struct PK { uint64_t code; int h, idx, off; bool operator==(const PK &o) const { return code == o.code && h == o.h && idx == o.idx && off == o.off; } };
-      struct PKH { size_t operator()(const PK &p) const { return (size_t)mix64h(p.code * 1000003ull + (uint64_t)(uint32_t)p.idx * 0x9E3779B97F4A7C15ull + (uint64_t)(uint32_t)p.off); } };
-      std::unordered_map<PK, int, PKH> sum;
-      for (const IdxEv &ev : idxEvents) sum[PK{ev.code, ev.h, ev.idx, ev.off}] += ev.delta;
-      for (const IdxEv &ev : idxEvents) {
-        auto it = sum.find(PK{ev.code, ev.h, ev.idx, ev.off});
-        if (it == sum.end() || it->second == 0) continue;
-        IdxEv x = ev; x.delta = it->second; net.push_back(x);
-        it->second = 0;
+      ordv.resize(nEv);
+      for (uint32_t i = 0; i < nEv; ++i) ordv[i] = i;
+      std::sort(ordv.begin(), ordv.end(), [&](uint32_t x, uint32_t y) {
+        const IdxEv &p = idxEvents[x], &q = idxEvents[y];
+        if (p.code != q.code) return p.code < q.code;
+        if (p.h != q.h) return p.h < q.h;
+        if (p.idx != q.idx) return p.idx < q.idx;
+        if (p.off != q.off) return p.off < q.off;
+        return x < y;
+      });
+      evSum.assign(nEv, 0);   // net delta, kept at the first event of every (key, posting)
+      for (uint32_t g = 0; g < nEv;) {
+        uint32_t e2 = g; int sum = 0;
+        const IdxEv &p = idxEvents[ordv[g]];
+        while (e2 < nEv) { const IdxEv &q = idxEvents[ordv[e2]]; if (q.code != p.code || q.h != p.h || q.idx != p.idx || q.off != p.off) break; sum += q.delta; ++e2; }
+        evSum[ordv[g]] = sum;
+        g = e2;
       }
+      for (uint32_t i = 0; i < nEv; ++i) if (evSum[i] != 0) { IdxEv x = idxEvents[i]; x.delta = evSum[i]; net.push_back(x); }
     } else net = idxEvents;
     // list sizes before the first and after the last event of every key: a size that crosses 100 changes which k-mers
     // GetHitsFromRead skips (SeqSet.hpp:1381-1391)
-    std::unordered_map<Key, std::pair<uint32_t, uint32_t>, KeyHash> sizes;
-    for (const IdxEv &ev : idxEvents) {
-      if (ev.sizeAfter == 0xFFFFFFFFu) continue;
-      auto it = sizes.find(Key{ev.code, ev.h});
-      const uint32_t before = ev.delta > 0 ? ev.sizeAfter - 1 : ev.sizeAfter + 1;
-      if (it == sizes.end()) sizes.emplace(Key{ev.code, ev.h}, std::make_pair(before, ev.sizeAfter));
-      else it->second.second = ev.sizeAfter;
-    }
-    for (const auto &kv : sizes) {
-      if ((kv.second.first >= 100) == (kv.second.second >= 100)) continue;
-      for (int nd = winKmers.find(kv.first.code, kv.first.h); nd >= 0; nd = winKmers.nodes[nd].next) {
+    ordv.clear();
+    for (uint32_t i = 0; i < nEv; ++i) if (idxEvents[i].sizeAfter != 0xFFFFFFFFu) ordv.push_back(i);
+    std::sort(ordv.begin(), ordv.end(), [&](uint32_t x, uint32_t y) {
+      const IdxEv &p = idxEvents[x], &q = idxEvents[y];
+      if (p.code != q.code) return p.code < q.code;
+      if (p.h != q.h) return p.h < q.h;
+      return x < y;
+    });
+    for (size_t g = 0; g < ordv.size();) {
+      size_t e2 = g;
+      const IdxEv &first = idxEvents[ordv[g]];
+      while (e2 < ordv.size() && idxEvents[ordv[e2]].code == first.code && idxEvents[ordv[e2]].h == first.h) ++e2;
+      const uint32_t before = first.delta > 0 ? first.sizeAfter - 1 : first.sizeAfter + 1, after = idxEvents[ordv[e2 - 1]].sizeAfter;
+      g = e2;
+      if ((before >= 100) == (after >= 100)) continue;
+      for (int nd = winKmers.find(first.code, first.h); nd >= 0; nd = winKmers.nodes[nd].next) {
         const KOcc &o = winKmers.nodes[nd];
         Cached &e = *pool[o.slot];
         if (e.uid == o.uid) kill(e, invCross);
