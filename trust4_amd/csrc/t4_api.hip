@@ -91,6 +91,7 @@ struct t4_ctx {
   int aqRecCap = 0;
   int64_t aqCalls = 0, aqReads = 0, aqGlobalLaunches = 0, aqGlobalReads = 0, aqRecords = 0;
   double aqSecPack = 0, aqSecFirst = 0, aqSecGlobal = 0;
+  int aqPoolGrows = 0;
   double aqKernelMs = 0;    // HIP-event time of the query kernels of all AddRead query calls (per call: first launch .. last kernel)
   int64_t aqHits = 0;       // _hit records their seed stages emitted (H of SURVEY 8d)
 };
@@ -1320,7 +1321,8 @@ int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
   c->aqSecPack += tSince(tp0);
   for (int attempt = 0;; ++attempt) {
     if (!c->aqPool) {
-      if (!c->aqPoolCap) c->aqPoolCap = 1 << 16;
+      static const int poolCap0 = getenv("T4_AQ_POOL_CAP") ? atoi(getenv("T4_AQ_POOL_CAP")) : 0;   // testing aid: a small pool forces the grow-and-repeat path
+      if (!c->aqPoolCap) c->aqPoolCap = poolCap0 > 0 ? poolCap0 : 1 << 16;
       const size_t rec = (size_t)c->aqPoolCap;
       HIPCHK(c, hipHostMalloc(&c->aqPool, rec * (2 * sizeof(t4_overlap) + sizeof(int32_t)), hipHostMallocMapped));
       HIPCHK(c, hipHostGetDevicePointer((void **)&c->aqPoolDev, c->aqPool, 0));
@@ -1356,7 +1358,7 @@ int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
     }
     static const int bigThreads = getenv("T4_AQ_THREADS") ? atoi(getenv("T4_AQ_THREADS")) : 512;   // workgroup of the 8192-hit tier of this path
     const int threads = (!smallFirst && bigThreads == 512) ? 512 : 256;
-    const int grid0 = smallFirst ? (n < c->cus * TIER_BLOCKS_PER_CU[0] ? n : c->cus * TIER_BLOCKS_PER_CU[0]) : (nFirst > 0 ? nFirst : 1);
+    const int grid0 = smallFirst ? (n < c->cus * TIER_BLOCKS_PER_CU[0] ? n : c->cus * TIER_BLOCKS_PER_CU[0]) : (nFirst > 0 ? (nFirst < c->cus * 2 ? nFirst : c->cus * 2) : 1);   // persistent grid: a large batch strides (and the per-block global scratch stays bounded)
     // scratch of the fallback DPs: the blocks of the LDS launch first, those of a concurrent global-tier launch behind them
     if ((r = ensureScratch(c, (grid0 > c->cus * 2 ? grid0 : c->cus * 2) * threads + nDirect * G_THREADS))) return r;
     T4Work wk;
@@ -1467,7 +1469,7 @@ int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
     if (poolFull) {   // more result records than the pool holds: a larger pool, and the whole call again
       if (attempt >= 8) return fail(c, T4_ERR_UNSUPPORTED, "result pool of %d records overflows", c->aqPoolCap);
       (void)hipHostFree(c->aqPool);
-      c->aqPool = nullptr; c->aqPoolDev = nullptr; c->aqPoolCap *= 4;
+      c->aqPool = nullptr; c->aqPoolDev = nullptr; c->aqPoolCap *= 4; ++c->aqPoolGrows;
       continue;
     }
     c->aqRecords += *(const unsigned *)(o + pTail + 24);
@@ -1505,7 +1507,7 @@ int t4_add_query_stats(t4_ctx *c, int64_t *out5) {   // 7 values
   if (!c || !out5) return T4_ERR_ARG;
   out5[0] = c->aqCalls; out5[1] = c->aqReads; out5[2] = c->aqGlobalLaunches; out5[3] = c->aqGlobalReads; out5[4] = c->aqRecords;
   out5[5] = (int64_t)(c->aqKernelMs * 1e3); out5[6] = c->aqHits;
-  if (getenv("T4_TIMING")) fprintf(stderr, "timing: AddRead query path host seconds: pack %.3f, first launch to sync %.3f, overflow tiers %.3f\n", c->aqSecPack, c->aqSecFirst, c->aqSecGlobal);
+  if (getenv("T4_TIMING")) fprintf(stderr, "timing: AddRead query path host seconds: pack %.3f, first launch to sync %.3f, overflow tiers %.3f; result pool grown %d times\n", c->aqSecPack, c->aqSecFirst, c->aqSecGlobal, c->aqPoolGrows);
   return T4_OK;
 }
 

@@ -767,6 +767,7 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
   std::vector<int32_t> extRet;
   int32_t cnt = 0;
   if (live()) {
+    processEvents();   // a release_* call or UpdateAllConsensus may have changed the set since the last commit was examined
     auto matches = [&](const Cached &c) { return c.valid && c.read == read && c.strand == *strandIO && c.barcode == barcode && c.skip == (repetitiveData ? 1 : 0); };
     if (!order.empty() && matches(*pool[order.front()])) ++cacheHits;
     else {
@@ -1402,7 +1403,7 @@ void t4_assembler::processEvents() {
       while (e2 < ordv.size() && idxEvents[ordv[e2]].code == first.code && idxEvents[ordv[e2]].h == first.h) ++e2;
       const uint32_t before = first.delta > 0 ? first.sizeAfter - 1 : first.sizeAfter + 1, after = idxEvents[ordv[e2 - 1]].sizeAfter;
       g = e2;
-      if ((before >= 100) == (after >= 100)) continue;
+      if ((before >= 100) == (after >= 100) && (before > 10000) == (after > 10000)) continue;   // 10000: removeOnlyRepeats / the repeat test of a run (SeqSet.hpp:802, 876, 936)
       for (int nd = winKmers.find(first.code, first.h); nd >= 0; nd = winKmers.nodes[nd].next) {
         const KOcc &o = winKmers.nodes[nd];
         Cached &e = *pool[o.slot];
@@ -1693,7 +1694,7 @@ int t4_assembler_prefetch(t4_assembler *a, int n, const char *const *reads, cons
 }
 int t4_assembler_window_valid(const t4_assembler *a) {
   if (!a) return 0;
-  if (a->live()) return !a->order.empty() && a->pool[a->order.front()]->valid;
+  if (a->live()) return a->idxEvents.empty() && a->structEvents.empty() && !a->order.empty() && a->pool[a->order.front()]->valid;
   return a->cacheHead < a->cache.size() && a->cache[a->cacheHead].valid;
 }
 int t4_assembler_counters(const t4_assembler *a, int64_t *queries, int64_t *refreshes, int64_t *window_hits) {
@@ -1734,8 +1735,13 @@ int t4_assembler_change_kmer_length(t4_assembler *a, int kmer_length) {
   return a->changeKmerLength(kmer_length);
 }
 int64_t t4_assembler_index_postings(const t4_assembler *a) { return a ? (int64_t)a->index.total : 0; }
-int t4_assembler_release_finished_barcode(t4_assembler *a, int barcode, int contig_min_cov) { return a ? a->releaseFinishedBarcode(barcode, contig_min_cov) : T4_ERR_ARG; }
-int t4_assembler_release_shallow_contigs(t4_assembler *a, int min_cov) { if (!a) return T4_ERR_ARG; a->releaseShallowContigs(min_cov); return T4_OK; }
+int t4_assembler_release_finished_barcode(t4_assembler *a, int barcode, int contig_min_cov) {
+  if (!a) return T4_ERR_ARG;
+  const int r = a->releaseFinishedBarcode(barcode, contig_min_cov);
+  a->processEvents();   // the window of a live set sees the removals before its next entry is served
+  return r;
+}
+int t4_assembler_release_shallow_contigs(t4_assembler *a, int min_cov) { if (!a) return T4_ERR_ARG; a->releaseShallowContigs(min_cov); a->processEvents(); return T4_OK; }
 int t4_assembler_output_barcodes(t4_assembler *a, const char *path, const char *const *barcode_names, int n_names) {
   if (!a || !path) return T4_ERR_ARG;
   FILE *fp = fopen(path, "w");

@@ -2950,11 +2950,19 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
     if (lane == 0) {   // room for this read's records in the result pool
       const int base = n > 0 ? (int)atomicAdd(qa.poolCursor, (unsigned)n) : 0;
       ws->red[15] = (base + n > qa.poolCap) ? -1 : base;
+      ws->red[14] = base;
     }
     __syncthreads();
     const long long base = ws->red[15];
+    const int reserved = ws->red[14];
     __syncthreads();
-    if (base < 0) { if (lane == 0) { wk.status[r] = 3; qa.counts[r] = 0; } return true; }
+    if (base < 0) {
+      // the pool is full: the host grows it and repeats the call. The part of the range this read reserved inside the pool must
+      // not look like records to extendKernel (it runs over [0, min(cursor, poolCap)) before the host sees the status)
+      if (qa.extendLater && qa.recRead) for (int i = reserved + lane; i < qa.poolCap && i < reserved + n; i += NT) if (i >= 0) qa.recRead[i] = -1;
+      if (lane == 0) { wk.status[r] = 3; qa.counts[r] = 0; }
+      return true;
+    }
     if (lane == 0) qa.outBase[r] = (int)base;
     for (int i = lane; i < n; i += NT) { storeOverlap(qa.out + base + i, wm.fin[i]); wm.ord[i] = (unsigned short)i; }
     if (qa.extendLater) {
