@@ -153,6 +153,64 @@ def annotate_pass_c2(device, pairs, clones, steps):
                          "kernel": "t4k::queryKernel<.., 0> (all tiers of one pass)", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg}}
 
 
+def file_md5(path):
+    import hashlib
+    h = hashlib.md5()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 22), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def config_leg(name, threads, device, mode="skipMateExtension"):
+    """One whole stage 1 through trust4-hip on a BASELINE config itself (C2 = 1 M pairs, 20 k clones, seed 1; `c3p*` = a stated
+    prefix of C3's read stream), under this run's clock, outputs compared with the md5 sums of the REFERENCE's outputs on the same
+    files (tests/golden/c2_digests.json, produced by tools/c2_digests.py from oracle/_ref/trust4; the input files are
+    regenerated here and their md5 sums are checked too)."""
+    tmp = tempfile.mkdtemp(prefix="t4%s_" % name)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import c2_digests
+        golden = json.load(open(c2_digests.OUT)).get(name)
+        fa, f1, f2, n = c2_digests.make_inputs(tmp, name)
+        pairs, clones, seed, prefix = c2_digests.CONFIGS[name]
+        out = {"workload": "config %s: %d synthetic 150 bp PE pairs%s, %d clones, seed %d, -f hg38_bcrtcr.fa, bulk mode; whole stage 1 through trust4-hip -t %d%s, "
+                           "FASTQ files in -> three files out, process start to exit" % (name.upper(), n, " (the first %d of the config's %d)" % (n, pairs) if prefix else "",
+                                                                                          clones, seed, threads, " --skipMateExtension" if mode == "skipMateExtension" else ""),
+               "pairs": n}
+        inputs_ok = golden is not None and [file_md5(f1), file_md5(f2)] == golden["inputs_md5"]
+        mine, stats_path = os.path.join(tmp, "mine"), os.path.join(tmp, "stats.json")
+        env = dict(os.environ, T4_DEVICE=str(device), T4_STATS_JSON=stats_path)
+        argv = [DRIVER, "-t", str(threads)] + (["--skipMateExtension"] if mode == "skipMateExtension" else []) + ["-f", fa, "-1", f1, "-2", f2, "-o", mine]
+        t0 = time.perf_counter()
+        p = subprocess.run(argv, env=env, stderr=subprocess.PIPE, text=True)
+        dt = time.perf_counter() - t0
+        if p.returncode:
+            out["error"] = "trust4-hip exit %d: %s" % (p.returncode, " | ".join(p.stderr.strip().split("\n")[-3:]))[:400]
+            return out
+        st = json.load(open(stats_path))
+        aq = st["add_query"]
+        md5s = {x: file_md5(mine + x) for x in OUT_SUFFIXES}
+        out.update({"seconds": dt, "pairs_per_s": n / dt, "contigs": st["contigs"], "assembled_reads": st["assembled_reads"],
+                    "rounds": aq["rounds"], "reads_queried": aq["reads_queried"], "reads_served": aq["reads_served"], "invalidations": aq["invalidations"],
+                    "kernel_ms": aq["kernel_ms"], "launch_ms_avg": aq["kernel_ms"] / max(1, aq["rounds"]), "hits": aq["hits"], "query_wall_s": aq["query_wall_s"],
+                    "addread_pass_s": st["phases_s"]["assembled"] - st["phases_s"]["trimmed_ready"], "md5": md5s})
+        if golden is None or mode not in golden.get("modes", {}):
+            out["identical"] = None
+            out["note"] = "no reference digests committed for this config / mode"
+        else:
+            g = golden["modes"][mode]
+            out["identical"] = bool(inputs_ok and all(md5s[x] == g["md5"][x] for x in OUT_SUFFIXES))
+            out["inputs_identical"] = bool(inputs_ok)
+            out["reference"] = {"seconds": g["reference_seconds"], "threads": g["reference_threads"], "pairs_per_s": n / g["reference_seconds"],
+                                "where": "the builder's container (tools/c2_digests.py), not this box"}
+        return out
+    except Exception as e:   # noqa: BLE001  (a side leg never takes the bench line down)
+        return {"error": repr(e)[:300]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def stage1_cells(pairs, cells):
     """Whole stage 1 in barcode mode through trust4-hip vs oracle/_ref/trust4 (when it travelled) on the same files."""
     tmp = tempfile.mkdtemp()
@@ -235,6 +293,8 @@ def main():
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 = skip the reference legs")
     ap.add_argument("--cpu-single-pairs", type=int, default=20000, help="prefix timed with the reference's -t 1 (0 = skip)")
     ap.add_argument("--side-legs", type=int, default=1, help="0 = skip passes.rough_annotation_c2 / stage1_cells / stage0_e2e")
+    ap.add_argument("--c2", type=int, default=1, help="0 = skip the `c2` leg (one whole stage 1 on config C2 itself, 1 M pairs, compared with the reference's digests)")
+    ap.add_argument("--config-leg", default="", help="additional config legs, comma separated (c3p2, c3p5: prefixes of C3)")
     args = ap.parse_args()
     clones = args.clones if args.clones > 0 else max(1, args.pairs // 50)
 
@@ -320,6 +380,10 @@ def main():
                     out["passes"]["rough_annotation_c2"] = annotate_pass_c2(local_rank, 1000000, 20000, 3)
                 except Exception as e:   # noqa: BLE001
                     out["passes"]["rough_annotation_c2"] = {"error": repr(e)[:300]}
+                if args.c2:
+                    out["c2"] = config_leg("c2", threads, local_rank)
+                for extra in [x for x in args.config_leg.split(",") if x]:
+                    out[extra] = config_leg(extra, threads, local_rank)
                 out["stage1_cells"] = stage1_cells(100000, 1000)
                 out["stage0_e2e"] = stage0_e2e(400000)
             print(json.dumps(out))

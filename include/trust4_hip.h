@@ -161,6 +161,19 @@ int t4_extend(t4_index *ix, t4_batch *b, int max_per_read, const int32_t *counts
  * -1), out[i] = `assign` (seqIdx -1 when no overlap extends over the whole read). Contig sets only. */
 int t4_assign(t4_index *ix, t4_batch *b, int strand, int32_t *ret, t4_overlap *out);
 
+/* The same with the strand argument of every read given apiece: the bulk `_final.out` tail assigns every assembled read
+ * with the strand its AddRead settled on (main.cpp:2075-2116, AssignReads_Thread 607-626). */
+int t4_assign_strands(t4_index *ix, t4_batch *b, const int32_t *strands, int32_t *ret, t4_overlap *out);
+
+/* SeqSet::RecomputePosWeight (SeqSet.hpp:4705-4738; main.cpp:2118) on a committed contig set: every posWeight column is zeroed,
+ * every read with assign[i].seqIdx != -1 adds mult[i] (NULL: 1) to the column of each of its non-N bases on the strand
+ * assign[i].strand from column assign[i].seqStart on (UpdatePosWeightFromRead, SeqSet.hpp:2466-2474), and columns no read covers
+ * get count 1 on their consensus base. posweight receives 4 int32 (A, C, G, T) per base, contigs in id order (what
+ * t4_index_add_contig took), posweight_cap = its capacity in int32 values. The set's own image is not changed (rebuild it
+ * with the new weights when queries against them are needed). */
+int t4_posweight_recompute(t4_index *ix, t4_batch *b, const t4_overlap *assign, const int32_t *mult, int32_t *posweight,
+                           int64_t posweight_cap);
+
 /* AlignAlgo::GlobalAlignment (kind 0; AlignAlgo.hpp:218-424; t_data = chars) or
  * AlignAlgo::GlobalAlignment_PosWeight (kind 1; AlignAlgo.hpp:57-216; t_data = 4 int32 weights per base)
  * for n independent (target, pattern) pairs given as CSR offsets; out4[4*i..] = GetAlignStats of
@@ -236,6 +249,15 @@ int t4_assembler_timers(const t4_assembler *a, double *sec_refresh, double *sec_
 int t4_assembler_update_all_consensus(t4_assembler *a);
 int t4_assembler_output(t4_assembler *a, const char *path);
 int t4_assembler_size(const t4_assembler *a);
+/* One slot of the set as the reference's `_seqWrapper` holds it (SeqSet.hpp:19-51): what a host driver needs to hand the contigs
+ * on to reference code that stays on the host (SeqSet::InputSeqSet for the mate-pair extension tail, main.cpp:2047-2048;
+ * INTEGRATION.md 5). A released slot has consensus == NULL. Pointers stay valid until the next call that changes the set. */
+typedef struct {
+  const char *name, *consensus;
+  const int32_t *posweight;   /* 4 counts (A, C, G, T) per base */
+  int32_t len, barcode, num_read, min_left_ext_anchor, min_right_ext_anchor, in_index;
+} t4_contig_view;
+int t4_assembler_contig(const t4_assembler *a, int i, t4_contig_view *out);
 /* SeqSet::ChangeKmerLength (SeqSet.hpp:4624-4629): compacts the set (ids are renumbered) and re-indexes with the new k. */
 int t4_assembler_change_kmer_length(t4_assembler *a, int kmer_length);
 int64_t t4_assembler_index_postings(const t4_assembler *a);

@@ -187,6 +187,20 @@ int ref_assign_read(void *h, const char *read, int strand, int barcode, ref_over
   return ret;
 }
 
+// RecomputePosWeight (SeqSet.hpp:4705-4738) from assigned reads (main.cpp:2118).
+void ref_recompute_posweight(void *h, int n, const char *const *reads, const ref_overlap_t *assign) {
+  SeqSet *s = (SeqSet *)h;
+  std::vector<struct _assignRead> v((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    v[i].id = NULL; v[i].read = strdup(reads[i]); v[i].barcode = -1; v[i].umi = -1; v[i].info = i;
+    v[i].overlap.seqIdx = assign[i].seqIdx; v[i].overlap.strand = assign[i].strand; v[i].overlap.seqStart = assign[i].seqStart;
+    v[i].overlap.seqEnd = assign[i].seqEnd; v[i].overlap.readStart = assign[i].readStart; v[i].overlap.readEnd = assign[i].readEnd;
+  }
+  s->RecomputePosWeight(v);
+  for (int i = 0; i < n; ++i) free(v[i].read);
+}
+void ref_set_novel_seq_similarity(void *h, double v) { ((SeqSet *)h)->SetNovelSeqSimilarity(v); }
+
 // AddRead (SeqSet.hpp:3426) -- mutates the set.
 int ref_add_read(void *h, const char *read, const char *geneName, int *strand, int barcode,
                  int minKmerCount, int repetitiveData, double similarityThreshold) {

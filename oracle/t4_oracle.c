@@ -1212,6 +1212,32 @@ int t4o_assign_read(t4o_set *s, const char *read, int strand, int barcode, t4o_o
   return ret;
 }
 
+/* SeqSet::RecomputePosWeight (SeqSet.hpp:4705-4738) with UpdatePosWeightFromRead (2466-2474): the weights of every contig
+ * from the reads assigned to it. reads[i] is added on strand assign[i].strand from column assign[i].seqStart on; entries with
+ * seqIdx == -1 are skipped; columns left at zero get count 1 on their consensus base unless it is 'N'. */
+void t4o_recompute_posweight(t4o_set *s, int n, const char *const *reads, const t4o_overlap *assign) {
+  int i, j;
+  for (i = 0; i < s->nseq; ++i) if (s->seqs[i].pw) memset(s->seqs[i].pw, 0, sizeof(int) * 4 * (size_t)s->seqs[i].len);
+  for (i = 0; i < n; ++i) {
+    if (assign[i].seqIdx == -1) continue;
+    seq_t *q = &s->seqs[assign[i].seqIdx];
+    int len = (int)strlen(reads[i]);
+    char *r = (char *)malloc(len + 1);
+    if (assign[i].strand == 1) memcpy(r, reads[i], len + 1); else reverse_complement(r, reads[i], len);
+    for (j = 0; j < len; ++j)
+      if (r[j] != 'N') ++q->pw[4 * (j + assign[i].seqStart) + nuc(r[j])];
+    free(r);
+  }
+  for (i = 0; i < s->nseq; ++i) {
+    seq_t *q = &s->seqs[i];
+    if (!q->pw) continue;
+    for (j = 0; j < q->len; ++j)
+      if (q->cons[j] != 'N' && q->pw[4 * j] + q->pw[4 * j + 1] + q->pw[4 * j + 2] + q->pw[4 * j + 3] == 0) q->pw[4 * j + nuc(q->cons[j])] = 1;
+  }
+}
+int t4o_kmer_length(t4o_set *s) { return s->k; }
+void t4o_seq_posweight(t4o_set *s, int i, int *out) { if (s->seqs[i].pw) memcpy(out, s->seqs[i].pw, sizeof(int) * 4 * (size_t)s->seqs[i].len); }
+
 /* ------------------------------------------------------------------------------------------------
  * KmerCount (KmerCount.hpp): counts of canonical k-mers (AddCount, 64-97) and the per-read count statistics
  * with quality trimming (GetCountStatsAndTrim, 177-288). TEST INFRASTRUCTURE like the rest of this file.

@@ -43,6 +43,10 @@ int t4o_annotate_read0(t4o_set *s, const char *read, t4o_overlap out[4]);
 int t4o_extend_overlap(t4o_set *s, const char *read, double mmFactor, const t4o_overlap *in,
                        t4o_overlap *out);
 int t4o_assign_read(t4o_set *s, const char *read, int strand, int barcode, t4o_overlap *out);
+/* RecomputePosWeight (SeqSet.hpp:4705-4738) from assigned reads; t4o_seq_posweight reads a contig's weights back (4 ints / base) */
+void t4o_recompute_posweight(t4o_set *s, int n, const char *const *reads, const t4o_overlap *assign);
+void t4o_seq_posweight(t4o_set *s, int i, int *out);
+int t4o_kmer_length(t4o_set *s);
 
 int t4o_global_alignment(const char *t, int lent, const char *p, int lenp, signed char *align);
 int t4o_global_alignment_posweight(const int *w, int lent, const char *p, int lenp,

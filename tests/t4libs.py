@@ -98,6 +98,25 @@ class _SetAPI:
         ret = self._asg(self.h, _b(read), strand, barcode, C.byref(b))
         return ret, b.tup()
 
+    def recompute_posweight(self, reads, assign):
+        """SeqSet::RecomputePosWeight (SeqSet.hpp:4705-4738): reads = list of str, assign = list of overlap tuples"""
+        n = len(reads)
+        arr = (C.c_char_p * max(n, 1))(*[_b(r) for r in reads])
+        ov = (Overlap * max(n, 1))(*[Overlap(*a) for a in assign])
+        fn = self._f("recompute_posweight", None, C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(Overlap))
+        fn(self.h, n, arr, ov)
+
+    def posweight(self, i):
+        n = self._slen(self.h, i)
+        out = np.zeros((n, 4), dtype=np.int32)
+        fn = self._f("seq_posweight", None, C.c_void_p, C.c_int, C.POINTER(C.c_int))
+        fn(self.h, i, out.ctypes.data_as(C.POINTER(C.c_int)))
+        return out
+
+    def set_novel_similarity(self, v):
+        fn = self._f("set_novel_seq_similarity" if self.P == "ref_" else "set_novel_similarity", None, C.c_void_p, C.c_double)
+        fn(self.h, v)
+
     def global_alignment(self, t, p):
         t, p = _b(t), _b(p)
         al = (C.c_byte * (2 * (len(t) + len(p)) + 8))()

@@ -2,6 +2,7 @@
 emulator in tests/hipemu, compared with the golden vectors and the oracle. This is test
 infrastructure for a container without a GPU -- the `-m gpu` suite runs the same checks on the real
 hipcc build."""
+import ctypes
 import os
 import random
 
@@ -9,7 +10,7 @@ import numpy as np
 import pytest
 
 import t4check
-from t4libs import REF_FA, ROOT, Oracle, Synth, rows_to_strs
+from t4libs import REF_FA, ROOT, Oracle, Ref, Synth, rows_to_strs
 
 
 @pytest.fixture(scope="module")
@@ -141,6 +142,57 @@ def run_novel_case(eng, seed, k, barcodes=False, hit_len=31):
             assert tuple(aout[i].tolist()) == tuple(eout), (i, eout, tuple(aout[i].tolist()))
             n_asg += 1
     assert n_asg > 5
+    if not barcodes:
+        run_final_tail_case(eng, o, ix, b, reads, contigs, hit_len)
+
+
+def run_final_tail_case(eng, o, ix, b, reads, contigs, hit_len):
+    """The read-level part of the bulk `_final.out` tail (main.cpp:2075-2118): AssignRead of every read with its own strand
+    argument at novelSeqSimilarity 0.95, then RecomputePosWeight from the assignments -- engine vs oracle, and the oracle vs the
+    compiled reference when it is there."""
+    rnd = np.random.RandomState(len(reads))
+    strands = rnd.choice([-1, 0, 1], size=len(reads)).astype(np.int32)
+    o.set_novel_similarity(0.95)
+    ix.set_params(hit_len, 10, 0.95)
+    aret, aout = ix.assign_strands(b, strands)
+    exp = []
+    for i, rd in enumerate(reads):
+        eret, eout = o.assign_read(rd, int(strands[i]), -1)
+        assert int(aret[i]) == eret, (i, eret, int(aret[i]))
+        if eret != -1:
+            assert tuple(aout[i].tolist()) == tuple(eout), (i, eout, tuple(aout[i].tolist()))
+        exp.append(eout if eret != -1 else (-1, -1, -1, -1, -1, 1, 0, 0, 0.0))
+    assert sum(1 for e in exp if e[0] != -1) > 5
+    mult = rnd.randint(1, 4, size=len(reads)).astype(np.int32)
+    lens = [len(c[1]) for c in contigs]
+    asg = np.zeros(len(reads), dtype=aout.dtype)
+    for i, e in enumerate(exp):
+        asg[i] = e
+    got = ix.posweight_recompute(b, asg, sum(lens), mult)
+    rep_reads, rep_asg = [], []
+    for i, rd in enumerate(reads):
+        rep_reads += [rd] * int(mult[i])
+        rep_asg += [exp[i]] * int(mult[i])
+    o.recompute_posweight(rep_reads, rep_asg)
+    at = 0
+    for c, ln in enumerate(lens):
+        assert (got[at:at + ln] == o.posweight(c)).all(), c
+        at += ln
+    assert got.sum() > sum(lens)
+    if Ref.available():
+        r = Ref(o_k(o))
+        for name, seq, bc, w in contigs:
+            r.add_novel(name, seq, 1, bc, w)
+        r.recompute_posweight(rep_reads, rep_asg)
+        for c in range(len(lens)):
+            assert (r.posweight(c) == o.posweight(c)).all(), c
+    o.set_novel_similarity(0.9)
+
+
+def o_k(o):
+    o.lib.t4o_kmer_length.restype = ctypes.c_int
+    o.lib.t4o_kmer_length.argtypes = [ctypes.c_void_p]
+    return o.lib.t4o_kmer_length(o.h)
 
 
 @pytest.mark.parametrize("k", [9, 11, 17])

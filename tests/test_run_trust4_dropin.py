@@ -18,12 +18,16 @@ import pytest
 import t4libs
 from t4libs import REF_FA, ROOT
 
-REF_TREE = "/root/reference"
 REF_BIN = os.path.join(ROOT, "oracle", "_ref")
+# the reference's driver script, report scripts, IMGT file and example reads: from the reference tree where it exists (this
+# container), else from the copies integration/make_dropin.py staged next to the checker binaries (git-ignored oracle/_ref/pipeline,
+# which travels to the GPU box)
+REF_TREE = "/root/reference" if os.path.exists("/root/reference/run-trust4") else os.path.join(REF_BIN, "pipeline")
+DROPIN = os.path.join(REF_BIN, "trust4-dropin")
 needs_reference = pytest.mark.skipif(
     not (os.path.exists(os.path.join(REF_TREE, "run-trust4")) and shutil.which("perl")
          and all(os.path.exists(os.path.join(REF_BIN, b)) for b in ("trust4", "fastq-extractor", "annotator"))),
-    reason="needs /root/reference (run-trust4, report scripts), perl and oracle/_ref/{trust4,fastq-extractor,annotator}")
+    reason="needs run-trust4 + report scripts (/root/reference or oracle/_ref/pipeline), perl and oracle/_ref/{trust4,fastq-extractor,annotator}")
 
 
 def install_dir(path, trust4_bin, extractor_bin, bam_extractor_bin=None):
@@ -83,6 +87,61 @@ def example_args():
             "-1", os.path.join(REF_TREE, "example", "example_1.fq"), "-2", os.path.join(REF_TREE, "example", "example_2.fq"), "-t", "2"]
 
 
+def emulated_dropin():
+    """the reference's main.cpp bound to the C ABI (integration/make_dropin.py), linked with the emulator build of the kernels"""
+    import t4check
+    lib = t4check.build_emulator_lib()
+    exe = os.path.join(ROOT, "tests", "hipemu", "trust4-dropin-emu")
+    deps = [lib, os.path.join(ROOT, "integration", "t4_dropin.hpp"), os.path.join(ROOT, "integration", "make_dropin.py")]
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
+        subprocess.run(["python3", os.path.join(ROOT, "integration", "make_dropin.py"), "--emu"], check=True, stdout=subprocess.DEVNULL)
+    return exe
+
+
+def synthetic_pe(tmp_path, pairs, clones, seed):
+    t4libs.build_checkers()
+    fa = str(tmp_path / "ref.fa")
+    with gzip.open(REF_FA, "rb") as f, open(fa, "wb") as g:
+        shutil.copyfileobj(f, g)
+    pre = str(tmp_path / "pe")
+    subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, str(pairs), str(clones), str(seed), pre], check=True, stdout=subprocess.DEVNULL)
+    return fa, pre
+
+
+needs_main_cpp = pytest.mark.skipif(not os.path.exists("/root/reference/main.cpp"), reason="the emulated drop-in is built from /root/reference/main.cpp")
+
+
+@needs_reference
+@needs_main_cpp
+def test_example_pipeline_default_options_dropin_emulated(tmp_path):
+    """BASELINE config[0] under run-trust4's DEFAULT options (no --skipMateExtension): stage 1 is the reference's own main.cpp
+    with its three hot loops bound to the C ABI (rough annotation, the AddRead pass, AssignRead + RecomputePosWeight) and its
+    mate-pair extension tail left in place on the host; `_final.out` and everything derived from it byte-identical."""
+    _, extractor = emulated_programs()
+    od, names = run_both(tmp_path, emulated_dropin(), extractor, example_args())
+    assert not filecmp.cmp(os.path.join(od, "T_raw.out"), os.path.join(od, "T_final.out"), shallow=False)   # the tail did run
+
+
+@needs_reference
+@needs_main_cpp
+def test_synthetic_pe_default_options_dropin_emulated(tmp_path):
+    """a synthetic paired-end set (SURVEY 8d recipe) through the whole pipeline with default options"""
+    _, extractor = emulated_programs()
+    fa, pre = synthetic_pe(tmp_path, 1200, 24, 21)
+    od, names = run_both(tmp_path, emulated_dropin(), extractor, ["-f", fa, "--ref", os.path.join(REF_TREE, "human_IMGT+C.fa"), "-1", pre + "_1.fq", "-2", pre + "_2.fq", "-t", "3"])
+    assert not filecmp.cmp(os.path.join(od, "T_raw.out"), os.path.join(od, "T_final.out"), shallow=False)
+
+
+@needs_reference
+@needs_main_cpp
+def test_barcode_pipeline_dropin_emulated(tmp_path):
+    """the same binding with 10x-style input: the one SeqSet keyed by barcode (main.cpp:1556-1559) behind t4_assembler_*"""
+    _, extractor = emulated_programs()
+    fa, pre = cells_input(tmp_path, 200, 5, 19)
+    run_both(tmp_path, emulated_dropin(), extractor, ["-f", fa, "--ref", os.path.join(REF_TREE, "human_IMGT+C.fa"), "-1", pre + "_1.fq", "-2", pre + "_2.fq",
+                                                      "--barcode", pre + "_bc.fa", "--UMI", pre + "_umi.fa", "-t", "2"])
+
+
 @needs_reference
 def test_example_pipeline_emulated(tmp_path):
     """BASELINE config[0] through run-trust4 (stage 0 -> 1 -> 2 -> 3). Bulk mode: --skipMateExtension, the mate-graph tail of
@@ -137,3 +196,26 @@ def test_example_pipeline_gpu(tmp_path):
     b.build()
     run_both(tmp_path, os.path.join(ROOT, "trust4_amd", "bin", "trust4-hip"), os.path.join(ROOT, "trust4_amd", "bin", "fastq-extractor-hip"),
              example_args() + ["--skipMateExtension"])
+
+
+needs_dropin = pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/trust4-dropin not built (integration/make_dropin.py, needs /root/reference at build time)")
+
+
+@pytest.mark.gpu
+@needs_reference
+@needs_dropin
+def test_example_pipeline_default_options_dropin_gpu(tmp_path):
+    """run-trust4 with its default options on the example, stage 1 = the reference's main.cpp bound to libt4hip.so"""
+    od, names = run_both(tmp_path, DROPIN, os.path.join(ROOT, "trust4_amd", "bin", "fastq-extractor-hip"), example_args())
+    assert not filecmp.cmp(os.path.join(od, "T_raw.out"), os.path.join(od, "T_final.out"), shallow=False)
+
+
+@pytest.mark.gpu
+@needs_reference
+@needs_dropin
+def test_synthetic_pe_default_options_dropin_gpu(tmp_path):
+    """4 k synthetic pairs with default options (VERDICT r2 #6): `_final.out` after the mate-pair extension identical"""
+    fa, pre = synthetic_pe(tmp_path, 4000, 80, 22)
+    od, names = run_both(tmp_path, DROPIN, os.path.join(ROOT, "trust4_amd", "bin", "fastq-extractor-hip"),
+                         ["-f", fa, "--ref", os.path.join(REF_TREE, "human_IMGT+C.fa"), "-1", pre + "_1.fq", "-2", pre + "_2.fq", "-t", "8"])
+    assert not filecmp.cmp(os.path.join(od, "T_raw.out"), os.path.join(od, "T_final.out"), shallow=False)

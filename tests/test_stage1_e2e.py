@@ -363,3 +363,33 @@ def test_bulk_paired_needs_skip_mate_extension_emulated(tmp_path):
     subprocess.run([exe, "-f", fa, "-u", pre + "_1.fq", "-o", my_out], check=True, stderr=subprocess.DEVNULL)
     for suffix in ("_raw.out", "_assembled_reads.fa", "_final.out"):
         assert filecmp.cmp(ref_out + suffix, my_out + suffix, shallow=False), suffix
+
+
+def _verify_window_case(tmp_path, driver, pairs, clones, seed, knobs, threads="4"):
+    """T4_VERIFY_WINDOW=1: every window entry is queried again, alone, at the moment it is served, and must equal its cached
+    result -- the rules that keep a cached query alive across commits (t4_assembler::processEvents) tested directly, under
+    window shapes drawn at random. The run stops with an error at the first difference."""
+    import random
+    import re
+    rnd = random.Random(knobs)
+    env = {"T4_VERIFY_WINDOW": "1", "T4_WINDOW": str(rnd.choice([5, 17, 48, 192, 400])), "T4_QUERY_AHEAD": str(rnd.choice([0, 2, 9, 40, 150]))}
+    if env["T4_QUERY_AHEAD"] == "0":
+        del env["T4_QUERY_AHEAD"]
+    log = _bulk_case(tmp_path, driver, pairs, clones, seed, env, threads=threads)
+    m = re.search(r"T4_VERIFY_WINDOW: (\d+) served window entries", log)
+    assert m and int(m.group(1)) > pairs // 4, (env, log[-800:])
+    return int(m.group(1))
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
+@pytest.mark.parametrize("knobs", [1, 2, 3])
+def test_window_validity_rules_emulated(tmp_path, knobs):
+    _verify_window_case(tmp_path, _emulated_driver(), 300, 6, 20 + knobs, knobs)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not shipped")
+@pytest.mark.parametrize("knobs", [11, 12])
+def test_window_validity_rules_gpu(tmp_path, knobs):
+    """>= 50 k pairs: the k-growth step (4 096 contigs) is not reached at this size, list sizes cross 100 many times"""
+    _verify_window_case(tmp_path, _driver(), 50000, 1000, 30 + knobs, knobs, threads="8")

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""tools/c2_digests.py -- digests of the REFERENCE's stage-1 outputs on a BASELINE config, for bench.py's `c2` leg.
+
+The reference binary (oracle/_ref/trust4, built by oracle/Makefile from /root/reference as it lies) takes 10-20 minutes on
+config C2 (1 M pairs), more than a default bench run can spend next to the GPU run, so its outputs are digested once, here,
+and the md5 sums are committed (tests/golden/c2_digests.json). bench.py regenerates the same input files with
+tools/t4synth (the SURVEY 8d recipe is deterministic: the input md5 sums are checked too), runs trust4-hip on them and compares.
+
+  python tools/c2_digests.py [--config c2|c3p5] [--threads N]
+
+Test infrastructure (a checker of the product), never on the product path.
+"""
+import argparse
+import gzip
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_BIN = os.path.join(ROOT, "oracle", "_ref", "trust4")
+OUT = os.path.join(ROOT, "tests", "golden", "c2_digests.json")
+SUFFIXES = ("_raw.out", "_assembled_reads.fa", "_final.out")
+# name -> (pairs, clones, seed, prefix pairs or 0): SURVEY.md 8(d)
+CONFIGS = {"c2": (1000000, 20000, 1, 0), "c3p5": (20000000, 200000, 2, 5000000), "c3p2": (20000000, 200000, 2, 2000000)}
+
+
+def md5(path):
+    h = hashlib.md5()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 22), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def make_inputs(tmp, name):
+    """the config's FASTQ files (a prefix of the config's read stream when the config says so) + the plain gene FASTA"""
+    pairs, clones, seed, prefix = CONFIGS[name]
+    fa = os.path.join(tmp, "ref.fa")
+    with gzip.open(os.path.join(ROOT, "data", "hg38_bcrtcr.fa.gz"), "rb") as f, open(fa, "wb") as g:
+        shutil.copyfileobj(f, g)
+    pre = os.path.join(tmp, name)
+    n = prefix if prefix else pairs
+    # t4synth draws the clone table from (clones, seed) and then the pairs one after the other: asking for n pairs of the
+    # config's clone table IS the config's first n pairs
+    subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, str(n), str(clones), str(seed), pre], check=True, stdout=subprocess.DEVNULL)
+    return fa, pre + "_1.fq", pre + "_2.fq", n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
+    ap.add_argument("--keep", default="", help="directory to keep the files in (default: a temporary one)")
+    args = ap.parse_args()
+    tmp = args.keep or tempfile.mkdtemp(prefix="t4c2_")
+    os.makedirs(tmp, exist_ok=True)
+    try:
+        fa, f1, f2, n = make_inputs(tmp, args.config)
+        rec = {"pairs": n, "clones": CONFIGS[args.config][1], "seed": CONFIGS[args.config][2], "inputs_md5": [md5(f1), md5(f2)], "modes": {}}
+        for mode, extra in (("skipMateExtension", ["--skipMateExtension"]), ("default", [])):
+            out = os.path.join(tmp, "ref_" + mode)
+            t0 = time.time()
+            subprocess.run([REF_BIN, "-t", str(args.threads)] + extra + ["-f", fa, "-1", f1, "-2", f2, "-o", out], check=True, stderr=subprocess.DEVNULL)
+            rec["modes"][mode] = {"md5": {s: md5(out + s) for s in SUFFIXES}, "bytes": {s: os.path.getsize(out + s) for s in SUFFIXES},
+                                  "reference_seconds": round(time.time() - t0, 1), "reference_threads": args.threads}
+            print(mode, rec["modes"][mode], file=sys.stderr)
+        allrec = json.load(open(OUT)) if os.path.exists(OUT) else {}
+        allrec[args.config] = rec
+        with open(OUT, "w") as f:
+            json.dump(allrec, f, indent=1, sort_keys=True)
+            f.write("\n")
+    finally:
+        if not args.keep:
+            shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

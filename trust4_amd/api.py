@@ -72,7 +72,8 @@ def _load():
         "t4_annotate_rough": (I, [P, P, P]),
         "t4_gap_dp": (I, [P, I, I, I, P, P, P, P, P]),
         "t4_mate_overlap": (I, [P, I, P, P, P, P, P, I, P]), "t4_has_hit": (I, [P, P, I, P]),
-        "t4_extend": (I, [P, P, I, P, P, C.c_double, P, P]), "t4_assign": (I, [P, P, I, P, P]),
+        "t4_extend": (I, [P, P, I, P, P, C.c_double, P, P]), "t4_assign": (I, [P, P, I, P, P]), "t4_assign_strands": (I, [P, P, P, P, P]),
+        "t4_posweight_recompute": (I, [P, P, P, P, P, C.c_int64]),
         "t4_assembler_create": (I, [P, I, I, C.POINTER(P)]), "t4_assembler_destroy": (None, [P]),
         "t4_assembler_set_params": (I, [P, I, I, C.c_double]),
         "t4_assembler_input_novel_read": (I, [P, C.c_char_p, C.c_char_p, I, I]),
@@ -461,6 +462,23 @@ class Index:
         self.eng.check(self.eng.lib.t4_assign(self.h, batch.h, strand, ret.ctypes.data_as(C.c_void_p),
                                               out.ctypes.data_as(C.c_void_p) if fetch else None))
         return ret, out
+
+    def assign_strands(self, batch, strands):
+        """SeqSet::AssignRead with every read's own strand argument (main.cpp:2075-2116) -> (ret int32 [n], out OV_DTYPE [n])"""
+        st = np.ascontiguousarray(strands, dtype=np.int32)
+        ret = np.zeros(batch.n, dtype=np.int32)
+        out = np.zeros(batch.n, dtype=OV_DTYPE)
+        self.eng.check(self.eng.lib.t4_assign_strands(self.h, batch.h, st.ctypes.data_as(C.c_void_p), ret.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
+        return ret, out
+
+    def posweight_recompute(self, batch, assign, total_bases, mult=None):
+        """SeqSet::RecomputePosWeight (SeqSet.hpp:4705-4738) -> int32 [total_bases, 4], contigs in id order"""
+        assign = np.ascontiguousarray(assign, dtype=OV_DTYPE)
+        out = np.zeros((total_bases, 4), dtype=np.int32)
+        m = None if mult is None else np.ascontiguousarray(mult, dtype=np.int32)
+        self.eng.check(self.eng.lib.t4_posweight_recompute(self.h, batch.h, assign.ctypes.data_as(C.c_void_p), None if m is None else m.ctypes.data_as(C.c_void_p),
+                                                           out.ctypes.data_as(C.c_void_p), out.size))
+        return out
 
     def has_hit(self, batch, mode=0):
         """SeqSet::HasHitInSet per read -> int32 [n] of -1 / 0 / 1"""

@@ -1209,6 +1209,81 @@ int t4_assign(t4_index *ix, t4_batch *b, int strand, int32_t *ret, t4_overlap *o
   return T4_OK;
 }
 
+int t4_assign_strands(t4_index *ix, t4_batch *b, const int32_t *strands, int32_t *ret, t4_overlap *out) {
+  if (!ix || !b || (b->n > 0 && !strands)) return T4_ERR_ARG;
+  t4_ctx *c = ix->ctx;
+  if (ix->committed && ix->view.firstIsRef) return fail(c, T4_ERR_UNSUPPORTED, "t4_assign_strands needs a contig set (ExtendOverlap aligns against posWeight)");
+  if (b->n == 0) return T4_OK;
+  (void)hipSetDevice(c->device);
+  int r;
+  if ((r = ensurePerCall(c, b->n))) return r;
+  if ((r = ensureResult(c, (size_t)b->n))) return r;
+  int *dSt = nullptr;
+  if ((r = devAlloc(c, &dSt, (size_t)b->n))) return r;
+  HIPCHK(c, hipMemcpy(dSt, strands, sizeof(int) * (size_t)b->n, hipMemcpyHostToDevice));
+  T4QueryArgs qa;
+  memset(&qa, 0, sizeof qa);
+  qa.mode = 2; qa.strand = 0; qa.strandPerRead = dSt; qa.skipRepeats = 0; qa.maxPerRead = 1; qa.counts = nullptr; qa.out = c->result; qa.ret = c->counts;
+  r = runQuery(ix, b, qa, true);
+  if (r == T4_OK && ret) { if (hipMemcpy(ret, c->counts, sizeof(int) * (size_t)b->n, hipMemcpyDeviceToHost) != hipSuccess) r = fail(c, T4_ERR_HIP, "copy of the AssignRead return values failed"); }
+  if (r == T4_OK && out) { if (hipMemcpy(out, c->result, sizeof(t4_overlap) * (size_t)b->n, hipMemcpyDeviceToHost) != hipSuccess) r = fail(c, T4_ERR_HIP, "copy of the AssignRead results failed"); }
+  (void)hipFree(dSt);
+  return r;
+}
+
+int t4_posweight_recompute(t4_index *ix, t4_batch *b, const t4_overlap *assign, const int32_t *mult, int32_t *posweight, int64_t posweight_cap) {
+  if (!ix || !b || (b->n > 0 && !assign) || !posweight) return T4_ERR_ARG;
+  t4_ctx *c = ix->ctx;
+  if (!ix->committed) return fail(c, T4_ERR_STATE, "index not committed");
+  if (ix->live) return fail(c, T4_ERR_UNSUPPORTED, "t4_posweight_recompute takes a committed contig set (the extendedSeq of main.cpp:2047), not a live one");
+  if (b->ctx != c) return fail(c, T4_ERR_ARG, "batch belongs to another ctx");
+  int64_t bases = 0;
+  for (const HostSeq &q : ix->seqs) { if (q.isRef) return fail(c, T4_ERR_UNSUPPORTED, "t4_posweight_recompute needs a contig set"); bases += (int64_t)q.cons.size(); }
+  if (posweight_cap < 4 * bases) return fail(c, T4_ERR_ARG, "posweight buffer holds %lld values, the set needs %lld", (long long)posweight_cap, (long long)(4 * bases));
+  if (bases == 0) return T4_OK;
+  (void)hipSetDevice(c->device);
+  int r;
+  int *dCnt = nullptr, *dMult = nullptr;
+  T4OverlapOut *dAs = nullptr;
+  const size_t n = (size_t)b->n;
+  const size_t cols = (size_t)bases + ix->seqs.size();   // the image's column space: every contig is followed by one terminator column (T4SeqInfo::pwOff)
+  if ((r = devAlloc(c, &dCnt, cols * 4))) return r;
+  auto freeAll = [&] { if (dCnt) (void)hipFree(dCnt); if (dMult) (void)hipFree(dMult); if (dAs) (void)hipFree(dAs); };
+  #define PWCHK(x) do { if ((x) != hipSuccess) { freeAll(); return fail(c, T4_ERR_HIP, "HIP error in t4_posweight_recompute: %s", hipGetErrorString(hipGetLastError())); } } while (0)
+  PWCHK(hipMemsetAsync(dCnt, 0, sizeof(int) * cols * 4, c->stream));   // posWeight.SetZero of every contig
+  if (n > 0) {
+    if ((r = devAlloc(c, &dAs, n))) { freeAll(); return r; }
+    PWCHK(hipMemcpyAsync(dAs, assign, sizeof(t4_overlap) * n, hipMemcpyHostToDevice, c->stream));
+    if (mult) {
+      if ((r = devAlloc(c, &dMult, n))) { freeAll(); return r; }
+      PWCHK(hipMemcpyAsync(dMult, mult, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
+    }
+    const int grid = (int)(n < (size_t)c->cus * 32 ? n : (size_t)c->cus * 32);
+    hipLaunchKernelGGL(t4k::posWeightAccumulateKernel, dim3(grid), dim3(64), 0, c->stream, ix->view, b->view, (const T4OverlapOut *)dAs, (const int *)dMult, dCnt);
+    PWCHK(hipGetLastError());
+  }
+  {
+    const int nseq = (int)ix->seqs.size();
+    const int grid = nseq < c->cus * 8 ? nseq : c->cus * 8;
+    hipLaunchKernelGGL(t4k::posWeightFinishKernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, c->stream, ix->view, dCnt);
+    PWCHK(hipGetLastError());
+  }
+  std::vector<int32_t> all(cols * 4);
+  PWCHK(hipMemcpyAsync(all.data(), dCnt, sizeof(int) * cols * 4, hipMemcpyDeviceToHost, c->stream));
+  PWCHK(hipStreamSynchronize(c->stream));
+  {   // contig after contig, without the terminator columns
+    size_t from = 0, to = 0;
+    for (const HostSeq &q : ix->seqs) {
+      const size_t ln = q.cons.size();
+      if (ln) memcpy(posweight + 4 * to, all.data() + 4 * from, sizeof(int32_t) * 4 * ln);
+      from += ln + 1; to += ln;
+    }
+  }
+  #undef PWCHK
+  freeAll();
+  return T4_OK;
+}
+
 int t4_extend(t4_index *ix, t4_batch *b, int max_per_read, const int32_t *counts, const t4_overlap *in, double mismatch_factor,
               int32_t *ret, t4_overlap *out) {
   if (!ix || !b || max_per_read <= 0 || (b->n > 0 && (!counts || !in))) return T4_ERR_ARG;

@@ -622,6 +622,8 @@ struct t4_assembler : IndexListener {
   void buildGroups(Cached &e);
   void registerKmers(Cached &e, int slot);
   int flushLive();
+  int verifyServed(const Cached &c);
+  int64_t verified = 0;
   void beginWindow(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive);
   void endWindow(const int32_t *cnts, const t4_overlap *ov, const t4_overlap *ex, const int32_t *rets, int stride);
   int stageImage();   // cell mode: queue this cell's image in the owner's arena
@@ -778,6 +780,8 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
     }
     const int sl = order.front();
     Cached &c = *pool[sl];
+    static const bool verifyWindow = getenv("T4_VERIFY_WINDOW") != nullptr;
+    if (verifyWindow) { const int rc = verifyServed(c); if (rc) return -100 + rc; }
     cnt = c.cnt; ovBuf.swap(c.ov); extBuf.swap(c.ext); extRet.swap(c.extRet);
     order.pop_front();
     c.valid = false; c.uid = 0; freeSlots.push_back(sl);   // its winKmers references are stale from here on
@@ -1225,6 +1229,42 @@ int t4_assembler::flushLive() {
   index.tabRebuilt = false; liveReset = false;
   ++deltas; deltaBytes += (int64_t)(slot.size() * 16 + postData.size() * 4 + seqRec.size() * sizeof(t4_seq_record) + baseCons.size() * 2);
   return T4_OK;
+}
+
+// T4_VERIFY_WINDOW=1 (testing aid): the entry about to be served is queried again, alone, against the set as it is NOW, and
+// must equal the cached result record for record -- a direct test of the rules that let a cached result survive commits
+// (processEvents), instead of relying on the outputs coming out equal.
+int t4_assembler::verifyServed(const Cached &c) {
+  if (index.total == 0) return c.cnt == 0 ? T4_OK : T4_ERR_STATE;
+  int rc;
+  if ((rc = flushLive())) return rc;
+  const char *bases = c.read.empty() ? "A" : c.read.c_str();
+  const int64_t offs[2] = {0, (int64_t)c.read.size()};
+  const int32_t bc = c.barcode, st = c.strand;
+  const double fac = (c.barcode == -1 && !c.skip) ? 1.0 : 2.0;
+  const int32_t *cnts = nullptr, *bas = nullptr, *rets = nullptr;
+  const t4_overlap *ov = nullptr, *ex = nullptr;
+  unsigned char hint = c.tier;
+  if ((rc = t4_add_query_pool(dev, 1, bases, offs, &bc, &st, c.skip, &fac, &cnts, &bas, &ov, &ex, &rets, &hint))) return rc;
+  ++verified;
+  auto same = [](const t4_overlap &a, const t4_overlap &b) {
+    return a.seqIdx == b.seqIdx && a.readStart == b.readStart && a.readEnd == b.readEnd && a.seqStart == b.seqStart && a.seqEnd == b.seqEnd &&
+           a.strand == b.strand && a.matchCnt == b.matchCnt && a.indelCnt == b.indelCnt && a.similarity == b.similarity;
+  };
+  bool ok = cnts[0] == c.cnt;
+  const int n = c.cnt > 0 ? c.cnt : 0;
+  for (int i = 0; ok && i < n; ++i) ok = same(ov[bas[0] + i], c.ov[i]) && same(ex[bas[0] + i], c.ext[i]) && rets[bas[0] + i] == c.extRet[i];
+  if (ok) return T4_OK;
+  fprintf(stderr, "T4_VERIFY_WINDOW: the cached query of a served read differs from a fresh one (entry %lld, read %s, strand %d): cached %d overlaps, fresh %d\n",
+          (long long)c.uid, c.read.c_str(), c.strand, c.cnt, cnts[0]);
+  for (int i = 0; i < n && i < (cnts[0] > 0 ? cnts[0] : 0) && i < 6; ++i) {
+    const t4_overlap &a = c.ov[i], &b = ov[bas[0] + i], &ea = c.ext[i], &eb = ex[bas[0] + i];
+    fprintf(stderr, "  #%d cached seq %d read %d-%d seq %d-%d m %d sim %.6f | ext %d-%d %d-%d ret %d   fresh seq %d read %d-%d seq %d-%d m %d sim %.6f | ext %d-%d %d-%d ret %d\n", i,
+            a.seqIdx, a.readStart, a.readEnd, a.seqStart, a.seqEnd, a.matchCnt, a.similarity, ea.readStart, ea.readEnd, ea.seqStart, ea.seqEnd, c.extRet[i],
+            b.seqIdx, b.readStart, b.readEnd, b.seqStart, b.seqEnd, b.matchCnt, b.similarity, eb.readStart, eb.readEnd, eb.seqStart, eb.seqEnd, rets[bas[0] + i]);
+  }
+  err = "T4_VERIFY_WINDOW mismatch";
+  return T4_ERR_STATE;
 }
 
 // the read's keys (every valid k-mer of both strands) join the window's inverted map
@@ -1724,12 +1764,24 @@ int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n) {
                          a->invContig, a->invFragile, a->tolerated, (int64_t)(a->secDelta * 1e6), (int64_t)(a->secGroups * 1e6), (int64_t)(a->secEvents * 1e6), (int64_t)(a->secQuery * 1e6)};
   for (int i = 0; i < n && i < 16; ++i) out[i] = v[i];
   if (n >= 23) t4_add_query_stats(a->ctx, out + 16);
+  if (getenv("T4_VERIFY_WINDOW")) fprintf(stderr, "T4_VERIFY_WINDOW: %lld served window entries queried again at serve time, all equal to their cached results\n", (long long)a->verified);
   if (getenv("T4_TIMING")) fprintf(stderr, "timing: assembler host seconds: add_read calls %.3f (incl. fallback queries), prefetch calls %.3f (of which query %.3f, deltas %.3f, registering k-mers %.3f), event examination %.3f, index edits %.3f\n",
                                    a->secAddTotal, a->secPrefetch, a->secQuery, a->secDelta, a->secRegister, a->secEvents, a->index.secOps);
   return T4_OK;
 }
 int t4_assembler_output(t4_assembler *a, const char *path) { return a ? a->output(path) : T4_ERR_ARG; }
 int t4_assembler_size(const t4_assembler *a) { return a ? (int)a->seqs.size() : 0; }
+int t4_assembler_contig(const t4_assembler *a, int i, t4_contig_view *out) {
+  if (!a || !out || i < 0 || i >= (int)a->seqs.size()) return T4_ERR_ARG;
+  const Seq &s = a->seqs[i];
+  memset(out, 0, sizeof *out);
+  out->name = s.name.c_str();
+  out->consensus = s.released ? nullptr : s.cons.c_str();
+  out->posweight = s.released || s.pw.empty() ? nullptr : (const int32_t *)s.pw.data();
+  out->len = s.released ? 0 : (int32_t)s.cons.size(); out->barcode = s.barcode; out->num_read = s.numRead;
+  out->min_left_ext_anchor = s.minLeftExtAnchor; out->min_right_ext_anchor = s.minRightExtAnchor; out->in_index = s.frozen ? 0 : 1;
+  return T4_OK;
+}
 int t4_assembler_change_kmer_length(t4_assembler *a, int kmer_length) {
   if (!a || kmer_length < 2 || kmer_length > 31) return T4_ERR_ARG;
   return a->changeKmerLength(kmer_length);

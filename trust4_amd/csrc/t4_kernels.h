@@ -3001,7 +3001,7 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
     int n;
     if (qa.mode == 2) {
       // SeqSet::AssignRead (SeqSet.hpp:4632-4701)
-      int ret = overlapsFromSegment<VARIANT != 0>(ix, wm, ws, len, qa.strand, barcode, false, 0, sc, hitTotal);
+      int ret = overlapsFromSegment<VARIANT != 0>(ix, wm, ws, len, qa.strandPerRead ? qa.strandPerRead[r] : qa.strand, barcode, false, 0, sc, hitTotal);
       if (ret == -2) return false;
       n = ret > 0 ? ret : 0;
       __syncthreads();
@@ -3359,6 +3359,43 @@ __global__ __launch_bounds__(64) void extendKernel(T4IndexView ix, T4BatchView b
       if (lane == 0 && s_ws.unsupported) qa.poolCursor[1] = 1u;   // an overhang beyond the direction buffer (reads of more than 600 bases)
       __syncthreads();
       i0 = i1;
+    }
+  }
+}
+
+// SeqSet::RecomputePosWeight (SeqSet.hpp:4705-4738) -- the posWeight columns of every contig rebuilt from the reads assigned to it
+// (SeqSet::AssignRead results): UpdatePosWeightFromRead (SeqSet.hpp:2466-2474) of every assigned read, on the strand of its
+// assignment, then count 1 on the consensus base of every column no read covers. One wavefront per read, a lane per base, integer
+// atomics on the 4 x int32 columns (the columns of a deep clone are hot, the adds of one read are to distinct addresses);
+// `mult` = number of identical reads the entry stands for (main.cpp:2080 assigns identical consecutive reads once).
+__global__ __launch_bounds__(64) void posWeightAccumulateKernel(T4IndexView ix, T4BatchView bv, const T4OverlapOut *assign, const int *mult, int *counts) {
+  const int lane = threadIdx.x;
+  for (long long r = blockIdx.x; r < bv.n; r += gridDim.x) {
+    const T4OverlapOut a = assign[r];
+    if (a.seqIdx < 0 || a.seqIdx >= ix.nseq) continue;
+    const T4SeqInfo sq = ix.seqs[a.seqIdx];
+    if (sq.pwOff < 0) continue;
+    const int len = bv.len[r], m = mult ? mult[r] : 1;
+    const unsigned *pk = bv.pk + r * bv.wpk, *nm = bv.nm + r * bv.wnm;
+    for (int j = lane; j < len; j += 64) {
+      const int p = a.strand == 1 ? j : len - 1 - j;   // base j of the strand that was assigned
+      if ((nm[p >> 5] >> (p & 31)) & 1u) continue;     // 'N' adds nothing
+      int code = (int)((pk[p >> 4] >> ((p & 15) * 2)) & 3u);
+      if (a.strand != 1) code = 3 - code;
+      const int col = a.seqStart + j;
+      if (col < 0 || col >= sq.len) continue;          // an assignment covers the whole read inside the contig; nothing to add outside it
+      atomicAdd(&counts[((long long)sq.pwOff + col) * 4 + code], m);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void posWeightFinishKernel(T4IndexView ix, int *counts) {
+  for (int c = blockIdx.x; c < ix.nseq; c += gridDim.x) {
+    const T4SeqInfo sq = ix.seqs[c];
+    if (sq.pwOff < 0) continue;
+    for (int j = threadIdx.x; j < sq.len; j += blockDim.x) {
+      int *w = counts + ((long long)sq.pwOff + j) * 4;
+      const char ch = ix.cons[sq.consOff + j];
+      if (ch != 'N' && w[0] + w[1] + w[2] + w[3] == 0) w[nuc2(ch)] = 1;
     }
   }
 }
