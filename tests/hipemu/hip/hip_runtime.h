@@ -161,6 +161,7 @@ static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new hipemu_event; 
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = 0) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }   /* launches run to completion at once */
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
   *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess;

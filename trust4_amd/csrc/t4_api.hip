@@ -54,6 +54,22 @@ struct HostSeq {
 
 }  // namespace
 
+// The call is split in two so that a caller can keep the host busy while the kernels run (t4_assembler commits reads whose cached
+// queries still stand): aqBegin packs the input and enqueues copies + kernels + the header copy on the ctx's stream; aqEnd waits
+// for them, runs whatever overflow launch is still needed (rare paths, synchronous) and hands out the result. One call in flight
+// per ctx. tierHint must stay alive until aqEnd.
+struct AqCall {
+  bool active = false;
+  T4IndexView base; const T4IndexView *views = nullptr; bool hasViewOf = false, smallFirst = false;
+  int n = 0, skipRepeats = 0, wpk = 0, wnm = 0, attempt = 0, nFirst = 0, nDirect = 0, threads = 512;
+  unsigned char *tierHint = nullptr;
+  std::vector<unsigned char> allGlobal;
+  size_t oPk, oNm, oLen, oBc, oSt, oLs, oVw, oFa, inBytes, pCnt, pSta, pNext, pNext2, pBase, pTick, pTail, outBytes;
+  bool extendLater = false;
+  T4BatchView bv; T4QueryArgs qa; T4Work wk;
+  std::chrono::steady_clock::time_point tf0;
+};
+
 struct t4_ctx {
   int device = 0, cus = 0;
   hipStream_t stream = 0;
@@ -92,6 +108,9 @@ struct t4_ctx {
   int64_t aqCalls = 0, aqReads = 0, aqGlobalLaunches = 0, aqGlobalReads = 0, aqRecords = 0;
   double aqSecPack = 0, aqSecFirst = 0, aqSecGlobal = 0;
   int aqPoolGrows = 0;
+  const int32_t *aqLastTicks = nullptr; int aqLastN = 0;   // per-read wall-clock ticks (10 ns) of the last AddRead query call (in the pinned header blob)
+  double aqLastMs = 0;
+  AqCall aq;
   double aqKernelMs = 0;    // HIP-event time of the query kernels of all AddRead query calls (per call: first launch .. last kernel)
   int64_t aqHits = 0;       // _hit records their seed stages emitted (H of SURVEY 8d)
 };
@@ -1327,175 +1346,219 @@ namespace {
 struct AqResult { const int32_t *counts, *base; const t4_overlap *ov, *ext; const int32_t *ret; };
 // tierHint (nullable, in/out): nonzero = the read is known to outgrow the LDS tiers, it is launched on the global-scratch tier
 // at once, on a second stream beside the LDS tier; on return nonzero for every read the global-scratch tier served.
-int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const int32_t *viewOf, bool smallFirst, int n, const char *bases,
-                 const int64_t *offsets, const int32_t *barcodes, const int32_t *strands, int skip_repeats, const double *factors, AqResult *res,
-                 unsigned char *tierHint = nullptr) {
+int aqLaunch(t4_ctx *c);
+int aqBegin(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const int32_t *viewOf, bool smallFirst, int n, const char *bases,
+            const int64_t *offsets, const int32_t *barcodes, const int32_t *strands, int skip_repeats, const double *factors,
+            unsigned char *tierHint = nullptr) {
   (void)hipSetDevice(c->device);
+  AqCall &q = c->aq;
+  if (q.active) return fail(c, T4_ERR_STATE, "an AddRead query is already in flight on this ctx");
   int maxLen = 1;
   for (int i = 0; i < n; ++i) {
     int64_t l = offsets[i + 1] - offsets[i];
     if (l < 0 || l > T4_MAXL) return fail(c, T4_ERR_UNSUPPORTED, "read %d is %lld bp; this engine takes reads up to %d bp", i, (long long)l, T4_MAXL);
     if (l > maxLen) maxLen = (int)l;
   }
+  q.base = base; q.views = views; q.hasViewOf = viewOf != nullptr; q.smallFirst = smallFirst; q.n = n; q.skipRepeats = skip_repeats; q.tierHint = tierHint; q.attempt = 0;
   const int wpk = (maxLen + 15) / 16, wnm = (maxLen + 31) / 32;
+  q.wpk = wpk; q.wnm = wnm;
   // input blob: pk | nm | len | barcode | strand | list(iota) | viewOf | factor
-  // header blob: counts | status | next1 | next2 | outBase | tail{overflow1, overflow2, hits, pool cursor}
+  // header blob: counts | status | next1 | next2 | outBase | ticks | tail{overflow1, overflow2, hits, pool cursor}
   auto al8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
-  const size_t oPk = 0, oNm = al8(oPk + sizeof(unsigned) * (size_t)n * wpk), oLen = al8(oNm + sizeof(unsigned) * (size_t)n * wnm),
-               oBc = al8(oLen + sizeof(int) * (size_t)n), oSt = al8(oBc + sizeof(int) * (size_t)n), oLs = al8(oSt + sizeof(int) * (size_t)n),
-               oVw = al8(oLs + sizeof(int) * (size_t)n), oFa = al8(oVw + sizeof(int) * (size_t)n), inBytes = al8(oFa + sizeof(double) * (size_t)n);
-  const size_t pCnt = 0, pSta = al8(pCnt + sizeof(int) * (size_t)n), pNext = al8(pSta + sizeof(int) * (size_t)n),
-               pNext2 = al8(pNext + sizeof(int) * (size_t)n), pBase = al8(pNext2 + sizeof(int) * (size_t)n),
-               pTail = al8(pBase + sizeof(int) * (size_t)n), outBytes = pTail + 32;
-  int r;
-  if (inBytes > c->aqInBytes) {
+  q.oPk = 0; q.oNm = al8(q.oPk + sizeof(unsigned) * (size_t)n * wpk); q.oLen = al8(q.oNm + sizeof(unsigned) * (size_t)n * wnm);
+  q.oBc = al8(q.oLen + sizeof(int) * (size_t)n); q.oSt = al8(q.oBc + sizeof(int) * (size_t)n); q.oLs = al8(q.oSt + sizeof(int) * (size_t)n);
+  q.oVw = al8(q.oLs + sizeof(int) * (size_t)n); q.oFa = al8(q.oVw + sizeof(int) * (size_t)n); q.inBytes = al8(q.oFa + sizeof(double) * (size_t)n);
+  q.pCnt = 0; q.pSta = al8(q.pCnt + sizeof(int) * (size_t)n); q.pNext = al8(q.pSta + sizeof(int) * (size_t)n);
+  q.pNext2 = al8(q.pNext + sizeof(int) * (size_t)n); q.pBase = al8(q.pNext2 + sizeof(int) * (size_t)n);
+  q.pTick = al8(q.pBase + sizeof(int) * (size_t)n); q.pTail = al8(q.pTick + sizeof(int) * (size_t)n); q.outBytes = q.pTail + 32;
+  if (q.inBytes > c->aqInBytes) {
     if (c->aqIn) (void)hipFree(c->aqIn);
     if (c->aqInHost) (void)hipHostFree(c->aqInHost);
     c->aqIn = nullptr; c->aqInHost = nullptr;
-    HIPCHK(c, hipMalloc(&c->aqIn, inBytes * 2));
-    HIPCHK(c, hipHostMalloc(&c->aqInHost, inBytes * 2, hipHostMallocDefault));
-    c->aqInBytes = inBytes * 2;
+    HIPCHK(c, hipMalloc(&c->aqIn, q.inBytes * 2));
+    HIPCHK(c, hipHostMalloc(&c->aqInHost, q.inBytes * 2, hipHostMallocDefault));
+    c->aqInBytes = q.inBytes * 2;
   }
-  if (outBytes > c->aqOutBytes) {
+  if (q.outBytes > c->aqOutBytes) {
     if (c->aqOut) (void)hipFree(c->aqOut);
     if (c->aqOutHost) (void)hipHostFree(c->aqOutHost);
     c->aqOut = nullptr; c->aqOutHost = nullptr;
-    HIPCHK(c, hipMalloc(&c->aqOut, outBytes * 2));
-    HIPCHK(c, hipHostMalloc(&c->aqOutHost, outBytes * 2, hipHostMallocDefault));
-    c->aqOutBytes = outBytes * 2;
+    HIPCHK(c, hipMalloc(&c->aqOut, q.outBytes * 2));
+    HIPCHK(c, hipHostMalloc(&c->aqOutHost, q.outBytes * 2, hipHostMallocDefault));
+    c->aqOutBytes = q.outBytes * 2;
   }
   auto tNow = [] { return std::chrono::steady_clock::now(); };
   auto tSince = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
   auto tp0 = tNow();
   unsigned char *h = c->aqInHost;
-  memset(h, 0, inBytes);
-  unsigned *pk = (unsigned *)(h + oPk), *nm = (unsigned *)(h + oNm);
-  int *len = (int *)(h + oLen), *bc = (int *)(h + oBc), *st = (int *)(h + oSt), *ls = (int *)(h + oLs), *vw = (int *)(h + oVw);
-  double *fa = (double *)(h + oFa);
+  memset(h, 0, q.inBytes);
+  unsigned *pk = (unsigned *)(h + q.oPk), *nm = (unsigned *)(h + q.oNm);
+  int *len = (int *)(h + q.oLen), *bc = (int *)(h + q.oBc), *st = (int *)(h + q.oSt), *ls = (int *)(h + q.oLs), *vw = (int *)(h + q.oVw);
+  double *fa = (double *)(h + q.oFa);
   for (int i = 0; i < n; ++i) {
     const char *s = bases + offsets[i];
     int l = (int)(offsets[i + 1] - offsets[i]);
     len[i] = l; bc[i] = barcodes ? barcodes[i] : -1; st[i] = strands[i]; fa[i] = factors[i]; vw[i] = viewOf ? viewOf[i] : 0;
-    unsigned *p = pk + (size_t)i * wpk, *q = nm + (size_t)i * wnm;
+    unsigned *p = pk + (size_t)i * wpk, *qn = nm + (size_t)i * wnm;
     for (int j = 0; j < l; ++j) {
       int v = nucNum(s[j]);
       if (v < 0) {
         if (s[j] != 'N') return fail(c, T4_ERR_UNSUPPORTED, "read %d has base '%c' (alphabet is ACGTN)", i, s[j]);
-        q[j >> 5] |= 1u << (j & 31); v = 0;
+        qn[j >> 5] |= 1u << (j & 31); v = 0;
       }
       p[j >> 4] |= (unsigned)v << ((j & 15) * 2);
     }
   }
   // work lists: the reads of the first LDS launch, then those that go to the global-scratch tier at once
   static const bool forceGlobal = getenv("T4_AQ_FORCE_GLOBAL") != nullptr;   // testing aid: every read on the global-scratch tier
-  std::vector<unsigned char> allGlobal;
-  if (forceGlobal && !smallFirst) { allGlobal.assign((size_t)n, 1); tierHint = allGlobal.data(); }
+  if (forceGlobal && !smallFirst) { q.allGlobal.assign((size_t)n, 1); q.tierHint = tierHint = q.allGlobal.data(); }
   int nFirst = 0, nDirect = 0;
   for (int i = 0; i < n; ++i) if (!(tierHint && tierHint[i] && !smallFirst)) ls[nFirst++] = i;
   for (int i = 0; i < n; ++i) if (tierHint && tierHint[i] && !smallFirst) ls[nFirst + nDirect++] = i;
+  q.nFirst = nFirst; q.nDirect = nDirect;
   c->aqSecPack += tSince(tp0);
-  for (int attempt = 0;; ++attempt) {
-    if (!c->aqPool) {
-      static const int poolCap0 = getenv("T4_AQ_POOL_CAP") ? atoi(getenv("T4_AQ_POOL_CAP")) : 0;   // testing aid: a small pool forces the grow-and-repeat path
-      if (!c->aqPoolCap) c->aqPoolCap = poolCap0 > 0 ? poolCap0 : 1 << 16;
-      const size_t rec = (size_t)c->aqPoolCap;
-      HIPCHK(c, hipHostMalloc(&c->aqPool, rec * (2 * sizeof(t4_overlap) + sizeof(int32_t)), hipHostMallocMapped));
-      HIPCHK(c, hipHostGetDevicePointer((void **)&c->aqPoolDev, c->aqPool, 0));
-    }
+  const int r = aqLaunch(c);
+  if (r == T4_OK) q.active = true;
+  return r;
+}
+
+// copies, kernels and the header copy of one attempt, enqueued on the ctx's stream (nothing waits here)
+int aqLaunch(t4_ctx *c) {
+  AqCall &q = c->aq;
+  const int n = q.n, nFirst = q.nFirst, nDirect = q.nDirect;
+  const bool smallFirst = q.smallFirst;
+  int r;
+  if (!c->aqPool) {
+    static const int poolCap0 = getenv("T4_AQ_POOL_CAP") ? atoi(getenv("T4_AQ_POOL_CAP")) : 0;   // testing aid: a small pool forces the grow-and-repeat path
+    if (!c->aqPoolCap) c->aqPoolCap = poolCap0 > 0 ? poolCap0 : 1 << 16;
     const size_t rec = (size_t)c->aqPoolCap;
-    auto tf0 = tNow();
-    HIPCHK(c, hipMemcpyAsync(c->aqIn, h, inBytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->aqOut, 0, outBytes, c->stream));   // counts, status, overflow lists, bases, tail
-    T4BatchView bv;
-    bv.pk = (const unsigned *)(c->aqIn + oPk); bv.nm = (const unsigned *)(c->aqIn + oNm); bv.len = (const int *)(c->aqIn + oLen);
-    bv.barcode = (const int *)(c->aqIn + oBc); bv.wpk = wpk; bv.wnm = wnm; bv.n = n;
-    T4QueryArgs qa;
-    memset(&qa, 0, sizeof qa);
-    qa.mode = 4; qa.skipRepeats = skip_repeats; qa.maxPerRead = 0;
-    qa.counts = (int *)(c->aqOut + pCnt);
-    qa.out = (T4OverlapOut *)c->aqPoolDev; qa.outExt = qa.out + rec; qa.ret = (int *)(qa.outExt + rec);
-    qa.outBase = (int *)(c->aqOut + pBase); qa.poolCursor = (unsigned *)(c->aqOut + pTail + 24); qa.poolCap = c->aqPoolCap;
-    qa.strandPerRead = (const int *)(c->aqIn + oSt); qa.factorPerRead = (const double *)(c->aqIn + oFa);
-    if (views) { qa.views = views; qa.viewOf = (const int *)(c->aqIn + oVw); }
-    // one big set: the ExtendOverlap calls of reads with more than this many overlaps run in their own launch (0: never)
-    static const int deferMin = getenv("T4_AQ_EXTEND_DEFER") ? atoi(getenv("T4_AQ_EXTEND_DEFER")) : 64;
-    const bool extendLater = deferMin > 0 && !views && !smallFirst;
-    if (extendLater) {
-      if (c->aqRecCap < c->aqPoolCap) {
-        if (c->aqRecDev) (void)hipFree(c->aqRecDev);
-        if (c->aqRecRead) (void)hipFree(c->aqRecRead);
-        c->aqRecDev = nullptr; c->aqRecRead = nullptr;
-        HIPCHK(c, hipMalloc(&c->aqRecDev, sizeof(T4OverlapOut) * (size_t)c->aqPoolCap));
-        HIPCHK(c, hipMalloc(&c->aqRecRead, sizeof(int) * (size_t)c->aqPoolCap));
-        c->aqRecCap = c->aqPoolCap;
-      }
-      qa.extendLater = deferMin; qa.outDev = c->aqRecDev; qa.recRead = c->aqRecRead;
+    HIPCHK(c, hipHostMalloc(&c->aqPool, rec * (2 * sizeof(t4_overlap) + sizeof(int32_t)), hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer((void **)&c->aqPoolDev, c->aqPool, 0));
+  }
+  const size_t rec = (size_t)c->aqPoolCap;
+  q.tf0 = std::chrono::steady_clock::now();
+  HIPCHK(c, hipMemcpyAsync(c->aqIn, c->aqInHost, q.inBytes, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->aqOut, 0, q.outBytes, c->stream));   // counts, status, overflow lists, bases, tail
+  T4BatchView &bv = q.bv;
+  bv.pk = (const unsigned *)(c->aqIn + q.oPk); bv.nm = (const unsigned *)(c->aqIn + q.oNm); bv.len = (const int *)(c->aqIn + q.oLen);
+  bv.barcode = (const int *)(c->aqIn + q.oBc); bv.wpk = q.wpk; bv.wnm = q.wnm; bv.n = n;
+  T4QueryArgs &qa = q.qa;
+  memset(&qa, 0, sizeof qa);
+  qa.mode = 4; qa.skipRepeats = q.skipRepeats; qa.maxPerRead = 0;
+  qa.counts = (int *)(c->aqOut + q.pCnt);
+  qa.out = (T4OverlapOut *)c->aqPoolDev; qa.outExt = qa.out + rec; qa.ret = (int *)(qa.outExt + rec);
+  qa.outBase = (int *)(c->aqOut + q.pBase); qa.poolCursor = (unsigned *)(c->aqOut + q.pTail + 24); qa.poolCap = c->aqPoolCap;
+  qa.strandPerRead = (const int *)(c->aqIn + q.oSt); qa.factorPerRead = (const double *)(c->aqIn + q.oFa);
+  qa.readTicks = (int *)(c->aqOut + q.pTick);
+  if (q.views) { qa.views = q.views; qa.viewOf = (const int *)(c->aqIn + q.oVw); }
+  // one big set: the ExtendOverlap calls of reads with more than this many overlaps run in their own launch (0: never)
+  static const int deferMin = getenv("T4_AQ_EXTEND_DEFER") ? atoi(getenv("T4_AQ_EXTEND_DEFER")) : 64;
+  const bool extendLater = deferMin > 0 && !q.views && !smallFirst;
+  q.extendLater = extendLater;
+  if (extendLater) {
+    if (c->aqRecCap < c->aqPoolCap) {
+      if (c->aqRecDev) (void)hipFree(c->aqRecDev);
+      if (c->aqRecRead) (void)hipFree(c->aqRecRead);
+      c->aqRecDev = nullptr; c->aqRecRead = nullptr;
+      HIPCHK(c, hipMalloc(&c->aqRecDev, sizeof(T4OverlapOut) * (size_t)c->aqPoolCap));
+      HIPCHK(c, hipMalloc(&c->aqRecRead, sizeof(int) * (size_t)c->aqPoolCap));
+      c->aqRecCap = c->aqPoolCap;
     }
-    static const int bigThreads = getenv("T4_AQ_THREADS") ? atoi(getenv("T4_AQ_THREADS")) : 512;   // workgroup of the 8192-hit tier of this path
-    const int threads = (!smallFirst && bigThreads == 512) ? 512 : 256;
-    const int grid0 = smallFirst ? (n < c->cus * TIER_BLOCKS_PER_CU[0] ? n : c->cus * TIER_BLOCKS_PER_CU[0]) : (nFirst > 0 ? (nFirst < c->cus * 2 ? nFirst : c->cus * 2) : 1);   // persistent grid: a large batch strides (and the per-block global scratch stays bounded)
-    // scratch of the fallback DPs: the blocks of the LDS launch first, those of a concurrent global-tier launch behind them
-    if ((r = ensureScratch(c, (grid0 > c->cus * 2 ? grid0 : c->cus * 2) * threads + nDirect * G_THREADS))) return r;
-    T4Work wk;
-    memset(&wk, 0, sizeof wk);
-    wk.list = (const int *)(c->aqIn + oLs); wk.nList = nFirst;
-    wk.nextList = (int *)(c->aqOut + pNext); wk.nextCount = (int *)(c->aqOut + pTail);
-    wk.status = (int *)(c->aqOut + pSta); wk.hitCounter = (unsigned long long *)(c->aqOut + pTail + 16);
-    wk.dpRows = c->dpRows; wk.dpDir = c->dpDir;
-    static const int capLimit = getenv("T4_AQ_CAP_LIMIT") ? atoi(getenv("T4_AQ_CAP_LIMIT")) : 0;   // testing aid
-    wk.capLimit = capLimit;
-    if (!smallFirst && (r = ensureGlobalTier(c, grid0 + nDirect))) return r;   // before anything of this call runs: growing it frees the old arrays
-    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    if (nDirect > 0) {   // beside the LDS tier, on the second stream (its own blocks of the DP scratch)
-      if (!c->stream2) { HIPCHK(c, hipStreamCreate(&c->stream2)); HIPCHK(c, hipEventCreate(&c->evIn)); HIPCHK(c, hipEventCreate(&c->evG)); }
-      HIPCHK(c, hipEventRecord(c->evIn, c->stream));
-      HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evIn, 0));
-      T4Work wd = wk;
-      wd.list = (const int *)(c->aqIn + oLs) + nFirst; wd.nList = nDirect; wd.nextList = nullptr; wd.nextCount = nullptr;
-      wd.gKeys = c->gKeys; wd.gPairs = c->gPairs; wd.gCand = c->gCand; wd.gOv = c->gOv; wd.gFin = c->gFin; wd.gOrd = c->gOrd;
-      wd.gCap = G_CAP; wd.gMaxOv = G_MAXOV;
-      wd.dpRows = c->dpRows + (size_t)((grid0 > c->cus * 2 ? grid0 : c->cus * 2) * threads / 64) * (6 * T4_ROWW * 64);
-      wd.dpDir = c->dpDir + (size_t)(grid0 > c->cus * 2 ? grid0 : c->cus * 2) * threads * T4_DIR_BYTES;
-      launchTier<0, 0, G_THREADS>(nDirect, c->stream2, base, bv, wd, qa);
-      HIPCHK(c, hipGetLastError());
-      HIPCHK(c, hipEventRecord(c->evG, c->stream2));
-      ++c->aqGlobalLaunches; c->aqGlobalReads += nDirect;
+    qa.extendLater = deferMin; qa.outDev = c->aqRecDev; qa.recRead = c->aqRecRead;
+  }
+  static const int bigThreads = getenv("T4_AQ_THREADS") ? atoi(getenv("T4_AQ_THREADS")) : 512;   // workgroup of the 8192-hit tier of this path
+  const int threads = (!smallFirst && bigThreads == 512) ? 512 : 256;
+  q.threads = threads;
+  const int grid0 = smallFirst ? (n < c->cus * TIER_BLOCKS_PER_CU[0] ? n : c->cus * TIER_BLOCKS_PER_CU[0])
+                               : (nFirst > 0 ? (nFirst < c->cus * 2 ? nFirst : c->cus * 2) : 1);   // persistent grid: a large batch strides (and the per-block global scratch stays bounded)
+  // scratch of the fallback DPs: the blocks of the LDS launch first, those of a concurrent global-tier launch behind them
+  if ((r = ensureScratch(c, (grid0 > c->cus * 2 ? grid0 : c->cus * 2) * threads + nDirect * G_THREADS))) return r;
+  T4Work &wk = q.wk;
+  memset(&wk, 0, sizeof wk);
+  wk.list = (const int *)(c->aqIn + q.oLs); wk.nList = nFirst;
+  wk.nextList = (int *)(c->aqOut + q.pNext); wk.nextCount = (int *)(c->aqOut + q.pTail);
+  wk.status = (int *)(c->aqOut + q.pSta); wk.hitCounter = (unsigned long long *)(c->aqOut + q.pTail + 16);
+  wk.dpRows = c->dpRows; wk.dpDir = c->dpDir;
+  static const int capLimit = getenv("T4_AQ_CAP_LIMIT") ? atoi(getenv("T4_AQ_CAP_LIMIT")) : 0;   // testing aid
+  wk.capLimit = capLimit;
+  if (!smallFirst && (r = ensureGlobalTier(c, grid0 + nDirect))) return r;   // before anything of this call runs: growing it frees the old arrays
+  HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  if (nDirect > 0) {   // beside the LDS tier, on the second stream (its own blocks of the DP scratch)
+    if (!c->stream2) { HIPCHK(c, hipStreamCreate(&c->stream2)); HIPCHK(c, hipEventCreate(&c->evIn)); HIPCHK(c, hipEventCreate(&c->evG)); }
+    HIPCHK(c, hipEventRecord(c->evIn, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evIn, 0));
+    T4Work wd = wk;
+    wd.list = (const int *)(c->aqIn + q.oLs) + nFirst; wd.nList = nDirect; wd.nextList = nullptr; wd.nextCount = nullptr;
+    wd.gKeys = c->gKeys; wd.gPairs = c->gPairs; wd.gCand = c->gCand; wd.gOv = c->gOv; wd.gFin = c->gFin; wd.gOrd = c->gOrd;
+    wd.gCap = G_CAP; wd.gMaxOv = G_MAXOV;
+    wd.dpRows = c->dpRows + (size_t)((grid0 > c->cus * 2 ? grid0 : c->cus * 2) * threads / 64) * (6 * T4_ROWW * 64);
+    wd.dpDir = c->dpDir + (size_t)(grid0 > c->cus * 2 ? grid0 : c->cus * 2) * threads * T4_DIR_BYTES;
+    launchTier<0, 0, G_THREADS>(nDirect, c->stream2, q.base, bv, wd, qa);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->evG, c->stream2));
+    ++c->aqGlobalLaunches; c->aqGlobalReads += nDirect;
+  }
+  if (nFirst > 0) {
+    if (smallFirst) launchTier<1024, 128, 256>(grid0, c->stream, q.base, bv, wk, qa);
+    else {   // a read that outgrows the LDS arrays goes on in global scratch inside the same launch
+      T4Work wf = wk;
+      const size_t skip = (size_t)nDirect;   // the blocks of a concurrent global-tier launch own the first slices
+      wf.gKeys = c->gKeys + skip * G_CAP; wf.gPairs = c->gPairs + skip * G_CAP * 2; wf.gCand = c->gCand;
+      wf.gOv = c->gOv + skip * G_MAXOV * 10; wf.gFin = c->gFin + skip * G_MAXOV * 10; wf.gOrd = c->gOrd + skip * G_MAXOV;
+      wf.gCap = G_CAP; wf.gMaxOv = G_MAXOV;
+      if (threads == 512) launchTier<8192, 512, 512>(grid0, c->stream, q.base, bv, wf, qa);
+      else launchTier<8192, 512, 256>(grid0, c->stream, q.base, bv, wf, qa);
     }
-    if (nFirst > 0) {
-      if (smallFirst) launchTier<1024, 128, 256>(grid0, c->stream, base, bv, wk, qa);
-      else {   // a read that outgrows the LDS arrays goes on in global scratch inside the same launch
-        T4Work wf = wk;
-        const size_t skip = (size_t)nDirect;   // the blocks of a concurrent global-tier launch own the first slices
-        wf.gKeys = c->gKeys + skip * G_CAP; wf.gPairs = c->gPairs + skip * G_CAP * 2; wf.gCand = c->gCand;
-        wf.gOv = c->gOv + skip * G_MAXOV * 10; wf.gFin = c->gFin + skip * G_MAXOV * 10; wf.gOrd = c->gOrd + skip * G_MAXOV;
-        wf.gCap = G_CAP; wf.gMaxOv = G_MAXOV;
-        if (threads == 512) launchTier<8192, 512, 512>(grid0, c->stream, base, bv, wf, qa);
-        else launchTier<8192, 512, 256>(grid0, c->stream, base, bv, wf, qa);
-      }
-      HIPCHK(c, hipGetLastError());
-    }
-    if (nDirect > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->evG, 0));
-    if (extendLater) {   // all records of the batch, spread over the chip
-      const int grid = c->cus * 16;
-      hipLaunchKernelGGL(t4k::extendKernel, dim3(grid), dim3(64), 0, c->stream, base, bv, qa, 0);
-      HIPCHK(c, hipGetLastError());
-    }
-    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->aqOutHost, c->aqOut, outBytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipGetLastError());
+  }
+  if (nDirect > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->evG, 0));
+  if (extendLater) {   // all records of the batch, spread over the chip
+    const int grid = c->cus * 16;
+    hipLaunchKernelGGL(t4k::extendKernel, dim3(grid), dim3(64), 0, c->stream, q.base, bv, qa, 0);
+    HIPCHK(c, hipGetLastError());
+  }
+  HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->aqOutHost, c->aqOut, q.outBytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev[3], c->stream));   // the call's results are on the host once this event has passed
+  return T4_OK;
+}
+
+// has the call in flight finished on the device? (1 yes or nothing in flight, 0 not yet)
+int aqDone(t4_ctx *c) {
+  if (!c->aq.active) return 1;
+  (void)hipSetDevice(c->device);
+  return hipEventQuery(c->ev[3]) == hipSuccess ? 1 : 0;
+}
+
+int aqEnd(t4_ctx *c, AqResult *res) {
+  AqCall &q = c->aq;
+  if (!q.active) return fail(c, T4_ERR_STATE, "no AddRead query in flight on this ctx");
+  q.active = false;
+  (void)hipSetDevice(c->device);
+  auto tNow = [] { return std::chrono::steady_clock::now(); };
+  auto tSince = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+  const int n = q.n;
+  const bool smallFirst = q.smallFirst;
+  const size_t pTail = q.pTail, pNext = q.pNext, pNext2 = q.pNext2, outBytes = q.outBytes;
+  T4Work &wk = q.wk;
+  T4QueryArgs &qa = q.qa;
+  T4BatchView &bv = q.bv;
+  int r;
+  for (;;) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    { float ms = 0; if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) c->aqKernelMs += ms; }
+    { float ms = 0; if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) { c->aqKernelMs += ms; c->aqLastMs = ms; } }
     int overflow = *(int *)(c->aqOutHost + pTail);
     { const int inKernel = *(int *)(c->aqOutHost + pTail + 8); if (!smallFirst && inKernel > 0) { c->aqGlobalReads += inKernel; ++c->aqGlobalLaunches; } }
-    c->aqSecFirst += tSince(tf0);
+    c->aqSecFirst += tSince(q.tf0);
     auto tg0 = tNow();
     if (overflow > 0 && smallFirst) {   // reads beyond the 1024-hit tier: 8192-hit LDS tier
       T4Work w1 = wk;
       w1.list = (const int *)(c->aqOut + pNext); w1.nList = overflow;
       w1.nextList = (int *)(c->aqOut + pNext2); w1.nextCount = (int *)(c->aqOut + pTail + 8);
-      if ((r = ensureScratch(c, (overflow > c->cus * 2 ? overflow : c->cus * 2) * threads))) return r;
+      if ((r = ensureScratch(c, (overflow > c->cus * 2 ? overflow : c->cus * 2) * q.threads))) return r;
       w1.dpRows = c->dpRows; w1.dpDir = c->dpDir;
       HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-      launchTier<8192, 512, 256>(overflow, c->stream, base, bv, w1, qa);
+      launchTier<8192, 512, 256>(overflow, c->stream, q.base, bv, w1, qa);
       HIPCHK(c, hipGetLastError());
       HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
       HIPCHK(c, hipMemcpyAsync(c->aqOutHost, c->aqOut, outBytes, hipMemcpyDeviceToHost, c->stream));
@@ -1505,9 +1568,9 @@ int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
       wk.nextList = (int *)(c->aqOut + pNext2);
     }
     ++c->aqCalls; c->aqReads += n;
-    if (overflow > 0 && tierHint) {   // remembered by the caller for the next query of these reads
+    if (overflow > 0 && q.tierHint) {   // remembered by the caller for the next query of these reads
       const int *lst = (const int *)(c->aqOutHost + (wk.nextList == (int *)(c->aqOut + pNext2) ? pNext2 : pNext));
-      for (int t = 0; t < overflow; ++t) tierHint[lst[t]] = 1;
+      for (int t = 0; t < overflow; ++t) q.tierHint[lst[t]] = 1;
     }
     if (overflow > 0) {   // reads beyond the LDS tiers: global-scratch tier
       ++c->aqGlobalLaunches; c->aqGlobalReads += overflow;
@@ -1520,10 +1583,10 @@ int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
       w2.dpRows = c->dpRows; w2.dpDir = c->dpDir;
       HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
       const int recsBefore = (int)*(const unsigned *)(c->aqOutHost + pTail + 24);
-      launchTier<0, 0, G_THREADS>(overflow, c->stream, base, bv, w2, qa);
+      launchTier<0, 0, G_THREADS>(overflow, c->stream, q.base, bv, w2, qa);
       HIPCHK(c, hipGetLastError());
-      if (extendLater) {
-        hipLaunchKernelGGL(t4k::extendKernel, dim3(c->cus * 16), dim3(64), 0, c->stream, base, bv, qa, recsBefore < c->aqPoolCap ? recsBefore : c->aqPoolCap);
+      if (q.extendLater) {
+        hipLaunchKernelGGL(t4k::extendKernel, dim3(c->cus * 16), dim3(64), 0, c->stream, q.base, bv, qa, recsBefore < c->aqPoolCap ? recsBefore : c->aqPoolCap);
         HIPCHK(c, hipGetLastError());
       }
       HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
@@ -1533,7 +1596,7 @@ int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
     }
     c->aqSecGlobal += tSince(tg0);
     const unsigned char *o = c->aqOutHost;
-    const int *status = (const int *)(o + pSta);
+    const int *status = (const int *)(o + q.pSta);
     bool poolFull = false;
     for (int i = 0; i < n; ++i) {
       if (status[i] == 3) poolFull = true;
@@ -1542,17 +1605,29 @@ int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
     }
     if (*(const unsigned *)(o + pTail + 28)) return fail(c, T4_ERR_UNSUPPORTED, "an overhang alignment of this batch exceeds the extension kernel's direction buffer");
     if (poolFull) {   // more result records than the pool holds: a larger pool, and the whole call again
-      if (attempt >= 8) return fail(c, T4_ERR_UNSUPPORTED, "result pool of %d records overflows", c->aqPoolCap);
+      if (q.attempt >= 8) return fail(c, T4_ERR_UNSUPPORTED, "result pool of %d records overflows", c->aqPoolCap);
       (void)hipHostFree(c->aqPool);
       c->aqPool = nullptr; c->aqPoolDev = nullptr; c->aqPoolCap *= 4; ++c->aqPoolGrows;
+      ++q.attempt;
+      if ((r = aqLaunch(c))) return r;
       continue;
     }
+    const size_t rec = (size_t)c->aqPoolCap;
     c->aqRecords += *(const unsigned *)(o + pTail + 24);
     c->aqHits += (int64_t) * (const unsigned long long *)(o + pTail + 16);
-    res->counts = (const int32_t *)(o + pCnt); res->base = (const int32_t *)(o + pBase);
+    c->aqLastTicks = (const int32_t *)(o + q.pTick); c->aqLastN = n;
+    res->counts = (const int32_t *)(o + q.pCnt); res->base = (const int32_t *)(o + q.pBase);
     res->ov = (const t4_overlap *)c->aqPool; res->ext = res->ov + rec; res->ret = (const int32_t *)(res->ext + rec);
     return T4_OK;
   }
+}
+
+int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const int32_t *viewOf, bool smallFirst, int n, const char *bases,
+                 const int64_t *offsets, const int32_t *barcodes, const int32_t *strands, int skip_repeats, const double *factors, AqResult *res,
+                 unsigned char *tierHint = nullptr) {
+  int r = aqBegin(c, base, views, viewOf, smallFirst, n, bases, offsets, barcodes, strands, skip_repeats, factors, tierHint);
+  if (r) return r;
+  return aqEnd(c, res);
 }
 
 // the same with the fixed-stride result layout of t4_add_query / t4_cellstore_query
@@ -1586,6 +1661,16 @@ int t4_add_query_stats(t4_ctx *c, int64_t *out5) {   // 7 values
   return T4_OK;
 }
 
+// development aid (T4_ROUND_LOG): kernel milliseconds of the last AddRead query call on this ctx and, per read of that call, the
+// microseconds one workgroup spent on it
+int t4_add_query_last_call(t4_ctx *c, double *kernel_ms, const int32_t **ticks10ns, int *n) {
+  if (!c) return T4_ERR_ARG;
+  if (kernel_ms) *kernel_ms = c->aqLastMs;
+  if (ticks10ns) *ticks10ns = c->aqLastTicks;
+  if (n) *n = c->aqLastN;
+  return T4_OK;
+}
+
 int t4_add_query_pool(t4_index *ix, int n, const char *bases, const int64_t *offsets, const int32_t *barcodes, const int32_t *strands,
                       int skip_repeats, const double *factors, const int32_t **counts, const int32_t **base, const t4_overlap **ov,
                       const t4_overlap **ext, const int32_t **ext_ret, unsigned char *tier_hint) {
@@ -1595,6 +1680,26 @@ int t4_add_query_pool(t4_index *ix, int n, const char *bases, const int64_t *off
   if (ix->view.firstIsRef) return fail(c, T4_ERR_UNSUPPORTED, "t4_add_query needs a contig set");
   AqResult res;
   int r = addQueryPool(c, ix->view, nullptr, nullptr, false, n, bases, offsets, barcodes, strands, skip_repeats, factors, &res, tier_hint);
+  if (r) return r;
+  *counts = res.counts; *base = res.base; *ov = res.ov; *ext = res.ext; *ext_ret = res.ret;
+  return T4_OK;
+}
+
+// The two halves of t4_add_query_pool: begin enqueues the call on ix's ctx and returns; the host goes on; end waits and hands the
+// result out (same lifetime rules). tier_hint must stay alive until end. One call in flight per ctx.
+int t4_add_query_pool_begin(t4_index *ix, int n, const char *bases, const int64_t *offsets, const int32_t *barcodes, const int32_t *strands,
+                            int skip_repeats, const double *factors, unsigned char *tier_hint) {
+  if (!ix || n <= 0 || !bases || !offsets || !strands || !factors) return T4_ERR_ARG;
+  t4_ctx *c = ix->ctx;
+  if (!ix->committed) return fail(c, T4_ERR_STATE, "index not committed");
+  if (ix->view.firstIsRef) return fail(c, T4_ERR_UNSUPPORTED, "t4_add_query needs a contig set");
+  return aqBegin(c, ix->view, nullptr, nullptr, false, n, bases, offsets, barcodes, strands, skip_repeats, factors, tier_hint);
+}
+int t4_add_query_pool_done(t4_ctx *c) { return c ? aqDone(c) : 1; }
+int t4_add_query_pool_end(t4_ctx *c, const int32_t **counts, const int32_t **base, const t4_overlap **ov, const t4_overlap **ext, const int32_t **ext_ret) {
+  if (!c || !counts || !base || !ov || !ext || !ext_ret) return T4_ERR_ARG;
+  AqResult res;
+  int r = aqEnd(c, &res);
   if (r) return r;
   *counts = res.counts; *base = res.base; *ov = res.ov; *ext = res.ext; *ext_ret = res.ret;
   return T4_OK;

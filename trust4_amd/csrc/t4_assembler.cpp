@@ -1560,6 +1560,16 @@ int t4_assembler::prefetchLive(int n, const char *const *reads, const int *stran
   secGroups += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg1).count();
   ++queries; ++rounds; readsQueried += m;
   if (rc) { dropWindow(); return rc; }
+  {   // T4_ROUND_LOG=path (development aid): one line per query round -- reads, kernel ms, and per read: us in its workgroup / overlaps / tier
+    static FILE *roundLog = getenv("T4_ROUND_LOG") ? fopen(getenv("T4_ROUND_LOG"), "w") : nullptr;
+    if (roundLog) {
+      double ms = 0; const int32_t *ticks = nullptr; int nn = 0;
+      t4_add_query_last_call(ctx, &ms, &ticks, &nn);
+      fprintf(roundLog, "%lld %d %.4f %d |", (long long)rounds, m, ms, (int)seqs.size());
+      for (int i = 0; i < m && i < nn; ++i) fprintf(roundLog, " %d/%d/%d", ticks ? ticks[i] / 100 : -1, cnts[i], (int)hint[i]);
+      fputc('\n', roundLog);
+    }
+  }
   for (int i = 0; i < m; ++i) {
     Cached &c = *pool[todo[i]];
     c.cnt = cnts[i];

@@ -154,6 +154,7 @@ struct T4QueryArgs {
   int extendLater;
   T4OverlapOut *outDev;
   int *recRead;
+  int *readTicks;            // mode 4, nullable: wall-clock ticks (10 ns) one workgroup spent on the read (the latency a dependent round pays)
   // per-read set images (per-barcode contig sets): read r is matched against views[viewOf[r]]
   const T4IndexView *views;
   const int *viewOf;

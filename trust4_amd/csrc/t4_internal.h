@@ -46,8 +46,16 @@ int t4_add_query_pool(t4_index *ix, int n, const char *bases, const int64_t *off
                       int skip_repeats, const double *factors, const int32_t **counts, const int32_t **base, const t4_overlap **ov,
                       const t4_overlap **ext, const int32_t **ext_ret, unsigned char *tier_hint);
 
+// the same in two halves, so that the caller's host work overlaps the kernels: begin enqueues, done polls (1 = finished or idle),
+// end waits and returns the result. tier_hint must stay alive until end; one call in flight per ctx.
+int t4_add_query_pool_begin(t4_index *ix, int n, const char *bases, const int64_t *offsets, const int32_t *barcodes, const int32_t *strands,
+                            int skip_repeats, const double *factors, unsigned char *tier_hint);
+int t4_add_query_pool_done(t4_ctx *ctx);
+int t4_add_query_pool_end(t4_ctx *ctx, const int32_t **counts, const int32_t **base, const t4_overlap **ov, const t4_overlap **ext, const int32_t **ext_ret);
+
 // AddRead query path of this ctx, 7 values: calls, reads, launches of the global-scratch tier, reads it served, result records,
 // microseconds of its kernels (HIP events on the ctx's stream), _hit records its seed stages emitted
 int t4_add_query_stats(t4_ctx *ctx, int64_t *out7);
+int t4_add_query_last_call(t4_ctx *ctx, double *kernel_ms, const int32_t **ticks10ns, int *n);   // development aid (T4_ROUND_LOG)
 
 }  // extern "C"

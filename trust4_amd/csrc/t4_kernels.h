@@ -3268,6 +3268,9 @@ void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
   while (w < wk.nList) {
     long long r = wk.list[w];
     if (VARIANT == 2) ix = qa.views[qa.viewOf[r]];   // uniform address: scalar loads
+#ifdef __HIPCC__
+    const unsigned long long tick0 = (VARIANT == 1 && qa.readTicks) ? wall_clock64() : 0ull;
+#endif
     bool done = processRead<(VARIANT == 0 ? 0 : VARIANT == 3 ? 3 : 1)>(ix, bv, wk, qa, wm, &s_ws, r, sc);
     if (CAP == 8192 && VARIANT == 1 && !done && wk.gKeys) {
       // The read outgrew the LDS arrays (known right after its seed stage): the same workgroup goes on in its block's slice of
@@ -3289,6 +3292,9 @@ void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
       if (tid() == 0 && done && wk.nextCount) atomicAdd(wk.nextCount + 2, 1);   // statistics: reads served this way
     }
     if (tid() == 0) {
+#ifdef __HIPCC__
+      if (VARIANT == 1 && qa.readTicks) qa.readTicks[r] = (int)(wall_clock64() - tick0);
+#endif
       if (!done) {
         if (wk.nextList) { int slot = atomicAdd(wk.nextCount, 1); wk.nextList[slot] = (int)r; }
         else wk.status[r] = 2;
