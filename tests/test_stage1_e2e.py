@@ -372,24 +372,26 @@ def _verify_window_case(tmp_path, driver, pairs, clones, seed, knobs, threads="4
     import random
     import re
     rnd = random.Random(knobs)
-    env = {"T4_VERIFY_WINDOW": "1", "T4_WINDOW": str(rnd.choice([5, 17, 48, 192, 400])), "T4_QUERY_AHEAD": str(rnd.choice([0, 2, 9, 40, 150]))}
+    env = {"T4_VERIFY_WINDOW": "1", "T4_WINDOW": str(rnd.choice([5, 17, 48, 192, 400])), "T4_QUERY_AHEAD": str(rnd.choice([0, 2, 9, 40, 150])),
+           "T4_LIVE_HARVEST_DELAY": str(rnd.choice([0, 2, 7, 25])), "T4_LIVE_MIN_BATCH": str(rnd.choice([1, 2, 4, 9])), "T4_LIVE_LANES": str(rnd.choice([1, 2, 3, 5]))}
     if env["T4_QUERY_AHEAD"] == "0":
         del env["T4_QUERY_AHEAD"]
     log = _bulk_case(tmp_path, driver, pairs, clones, seed, env, threads=threads)
     m = re.search(r"T4_VERIFY_WINDOW: (\d+) served window entries", log)
     assert m and int(m.group(1)) > pairs // 4, (env, log[-800:])
+    print(env, re.findall(r"timing: query lanes.*", log))
     return int(m.group(1))
 
 
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
-@pytest.mark.parametrize("knobs", [1, 2, 3])
+@pytest.mark.parametrize("knobs", [1, 2, 3, 4, 5, 6])
 def test_window_validity_rules_emulated(tmp_path, knobs):
     _verify_window_case(tmp_path, _emulated_driver(), 300, 6, 20 + knobs, knobs)
 
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not shipped")
-@pytest.mark.parametrize("knobs", [11, 12])
+@pytest.mark.parametrize("knobs", [11, 12, 13])
 def test_window_validity_rules_gpu(tmp_path, knobs):
     """>= 50 k pairs: the k-growth step (4 096 contigs) is not reached at this size, list sizes cross 100 many times"""
     _verify_window_case(tmp_path, _driver(), 50000, 1000, 30 + knobs, knobs, threads="8")

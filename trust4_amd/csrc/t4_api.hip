@@ -285,6 +285,7 @@ int t4_sync(t4_ctx *c) {
 }
 const char *t4_last_error(t4_ctx *c) { return c ? c->err.c_str() : "null ctx"; }
 int t4_device_cus(t4_ctx *c) { return c ? c->cus : 0; }
+int t4_ctx_device(t4_ctx *c) { return c ? c->device : 0; }
 #ifdef T4_PHASE_TIMING
 // development aid: cycles spent per kernel phase (summed over workgroups) since the last call
 int t4_debug_phase_cycles(unsigned long long *out16) {   // T4_NPHASE entries

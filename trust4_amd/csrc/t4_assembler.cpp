@@ -496,6 +496,12 @@ struct t4_assembler : IndexListener {
     bool fragile = false;        // any change of one of its keys' lists invalidates it
     int slack = 0;               // tolerated hit-set changes left before possibleOverlapCnt could pass 100 (SeqSet.hpp:813-823)
     GroupTable groups;
+    // a (re-)query of this entry is running on a lane: commits since its launch are examined against its dependency sets like
+    // those of an entry that holds a result; `killed` = one of them invalidated it (the result is dropped when it arrives),
+    // `shifts` = left extensions of contigs it meets, to be applied to the records when they arrive
+    bool inflight = false, killed = false;
+    std::vector<std::pair<int, int>> shifts;
+    bool standing() const { return valid || (inflight && !killed); }
   };
   std::vector<Cached> cache;
   size_t cacheHead = 0;
@@ -555,10 +561,15 @@ struct t4_assembler : IndexListener {
   double secDelta = 0, secGroups = 0, secEvents = 0, secRegister = 0, secPrefetch = 0, secAddTotal = 0;
 
   t4_assembler(t4_ctx *c, int kl) : ctx(c), k(kl), index(kl) { prevAdd.readStart = -1; index.hook = this; }
-  ~t4_assembler() { for (Cached *c : pool) delete c; }
+  ~t4_assembler() {
+    abandonJobs();
+    for (Lane &L : lanes) { if (L.dev) t4_index_destroy(L.dev); if (L.ownCtx && L.ctx) t4_destroy(L.ctx); }
+    for (Cached *c : pool) delete c;
+  }
   void dropWindow() {
     cache.clear(); cacheHead = 0;
-    for (int s : order) { pool[s]->valid = false; pool[s]->uid = 0; freeSlots.push_back(s); }
+    abandonJobs();
+    for (int s : order) { pool[s]->valid = false; pool[s]->inflight = false; pool[s]->uid = 0; freeSlots.push_back(s); }
     order.clear(); winKmers.clear(); winKmerRefs = winKmerLive = 0;
     idxEvents.clear(); structEvents.clear();
   }
@@ -621,7 +632,41 @@ struct t4_assembler : IndexListener {
   int prefetchLive(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive);
   void buildGroups(Cached &e);
   void registerKmers(Cached &e, int slot);
-  int flushLive();
+  // ---- asynchronous query lanes of a live set. Every lane owns a ctx (its stream and scratch) and a REPLICA of the device image;
+  // a delta is built once (makeDelta) and applied to a lane right before that lane's next launch, so a query always runs against
+  // an image nothing else touches while the host goes on committing reads -- and later deltas go to the other replicas.
+  struct DeltaRec {
+    std::vector<int64_t> slot; std::vector<uint64_t> slotCode; std::vector<uint32_t> slotStart, slotCnt;
+    std::vector<int64_t> postAt; std::vector<int32_t> postLen, postData;
+    std::vector<int32_t> seqId; std::vector<t4_seq_record> seqRec;
+    std::vector<int64_t> baseAt; std::vector<int32_t> baseLen; std::string baseCons; std::vector<uint8_t> basePw;
+    t4_index_delta d;
+    int64_t version = 0;
+  };
+  struct Lane {
+    t4_ctx *ctx = nullptr; bool ownCtx = false;
+    t4_index *dev = nullptr;
+    int64_t version = 0;   // deltas applied to this replica
+    bool busy = false;
+    int polls = 0;
+    std::vector<int> slots; std::vector<int64_t> uids; std::vector<unsigned char> hint;
+    std::string bases; std::vector<int64_t> offs; std::vector<int32_t> bcs, sts; std::vector<double> fac;
+    int repetitive = 0;
+  };
+  std::vector<Lane> lanes;
+  std::deque<std::unique_ptr<DeltaRec>> deltaLog;
+  int64_t deltaVersion = 0;
+  int64_t launches = 0, launchesUrgent = 0, headWaits = 0, killedInFlight = 0;
+  double secHeadWait = 0, secLaunch = 0, secHarvest = 0;
+  int ensureLanes();
+  int flushLive(Lane **out);
+  int makeDelta();
+  int bringUpToDate(Lane &L);
+  int launchOn(Lane &L, const std::vector<int> &todo, int repetitive);
+  int harvest(Lane &L);
+  void abandonJobs();
+  int pumpLive(bool needHead, int repetitive);
+  void announceLive(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive);
   int verifyServed(const Cached &c);
   int64_t verified = 0;
   void beginWindow(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive);
@@ -745,6 +790,8 @@ struct t4_assembler : IndexListener {
     setPrev(-1, -1, -1, -1, -1, 0);
     if (dev) { t4_index_destroy(dev); dev = nullptr; }   // nomatchGapLimit and the lookup layout depend on k
     if (live()) {   // a fresh image: every contig gets a new place in the arena
+      for (Lane &L : lanes) { if (L.dev) { t4_index_destroy(L.dev); L.dev = nullptr; } L.version = deltaVersion; }   // (no job is in flight: dropWindow above)
+      deltaLog.clear();
       liveReset = true; baseUsed = 0; dirtySeqs.clear();
       for (int i = 0; i < (int)seqs.size(); ++i) { seqs[i].baseOff = -1; seqs[i].baseCap = 0; seqs[i].devDirty = false; markSeqDirty(i); }
     }
@@ -770,9 +817,11 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
   int32_t cnt = 0;
   if (live()) {
     processEvents();   // a release_* call or UpdateAllConsensus may have changed the set since the last commit was examined
-    auto matches = [&](const Cached &c) { return c.valid && c.read == read && c.strand == *strandIO && c.barcode == barcode && c.skip == (repetitiveData ? 1 : 0); };
-    if (!order.empty() && matches(*pool[order.front()])) ++cacheHits;
-    else {
+    auto lines = [&](const Cached &c) { return c.read == read && c.strand == *strandIO && c.barcode == barcode && c.skip == (repetitiveData ? 1 : 0); };
+    if (!order.empty() && lines(*pool[order.front()])) {
+      if (pool[order.front()]->valid) ++cacheHits;
+      { const int rc = pumpLive(true, repetitiveData ? 1 : 0); if (rc) return -100 + rc; }   // background re-queries; waits for the head when it has no result yet
+    } else {
       const char *one = read.c_str();
       int st = *strandIO, bcOne = barcode;
       int rc = prefetchLive(1, &one, &st, &bcOne, repetitiveData ? 1 : 0);
@@ -1151,45 +1200,40 @@ int t4_assembler::stageImage() {   // thread-safe across cells once the owner ha
 // ---- live set: device image by deltas, sliding speculation window ---------------------------------------------------
 
 // Bring the device image up to date: everything that changed since the last call, each destination once with its final value.
-int t4_assembler::flushLive() {
+// What changed in the set since the last delta, described by position in the image's four arrays (the host replica stores its lists
+// in the device layout). Built once; every lane applies it to its own replica before its next launch (bringUpToDate).
+int t4_assembler::makeDelta() {
   auto t0_ = std::chrono::steady_clock::now();
   struct Tm { double &acc; std::chrono::steady_clock::time_point t0; ~Tm() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tm_{secDelta, t0_};
-  int r;
-  if (!dev) {
-    if ((r = t4_index_create(ctx, k, 0, &dev))) return r;
-    liveReset = true;
-  }
-  if ((r = t4_index_set_params(dev, hitLenRequired, radius, novelSim))) return r;
+  if (!liveReset && !index.tabRebuilt && index.dirtyKeys.empty() && index.dirtyPost.empty() && dirtySeqs.empty()) return T4_OK;   // the replicas are current
   if (liveReset) {   // everything is new to the device
     index.tabRebuilt = true;
     index.dirtyPost.clear();
     for (uint32_t at = 0; at < (uint32_t)index.arenaUsed; ++at) index.dirtyPost.push_back(at);
     for (int i = 0; i < (int)seqs.size(); ++i) markSeqDirty(i);
   }
-  t4_index_delta d;
+  std::unique_ptr<DeltaRec> recp(new DeltaRec());
+  DeltaRec &R = *recp;
+  t4_index_delta &d = R.d;
   memset(&d, 0, sizeof d);
   // table slots
-  std::vector<int64_t> slot; std::vector<uint64_t> slotCode; std::vector<uint32_t> slotStart, slotCnt;
   auto putKey = [&](const HostIndex::Map::value_type &kv) {
-    slot.push_back(kv.second.slot); slotCode.push_back(kv.first.code); slotStart.push_back(kv.second.start); slotCnt.push_back(kv.second.cnt);
+    R.slot.push_back(kv.second.slot); R.slotCode.push_back(kv.first.code); R.slotStart.push_back(kv.second.start); R.slotCnt.push_back(kv.second.cnt);
   };
   if (index.tabRebuilt) { for (auto &kv : index.map) { putKey(kv); kv.second.dirty = false; } }
   else for (auto *kv : index.dirtyKeys) { putKey(*kv); kv->second.dirty = false; }
   index.dirtyKeys.clear();
   // postings: runs of consecutive dirty positions
-  std::vector<int64_t> postAt; std::vector<int32_t> postLen, postData;
   std::sort(index.dirtyPost.begin(), index.dirtyPost.end());
   for (size_t i = 0; i < index.dirtyPost.size();) {
     size_t j = i + 1;
     while (j < index.dirtyPost.size() && index.dirtyPost[j] == index.dirtyPost[j - 1] + 1) ++j;
-    postAt.push_back(index.dirtyPost[i]); postLen.push_back((int32_t)(j - i));
-    for (size_t t = i; t < j; ++t) { const Post &p = index.arena[index.dirtyPost[t]]; postData.push_back(p.idx); postData.push_back(p.offset); if (index.dirtyPost[t] < index.dirtyPostFlag.size()) index.dirtyPostFlag[index.dirtyPost[t]] = 0; }
+    R.postAt.push_back(index.dirtyPost[i]); R.postLen.push_back((int32_t)(j - i));
+    for (size_t t = i; t < j; ++t) { const Post &p = index.arena[index.dirtyPost[t]]; R.postData.push_back(p.idx); R.postData.push_back(p.offset); if (index.dirtyPost[t] < index.dirtyPostFlag.size()) index.dirtyPostFlag[index.dirtyPost[t]] = 0; }
     i = j;
   }
   index.dirtyPost.clear();
   // sequences: record + the changed stretch of consensus chars / predicate bytes (one terminator column past the end)
-  std::vector<int32_t> seqId; std::vector<t4_seq_record> seqRec;
-  std::vector<int64_t> baseAt; std::vector<int32_t> baseLen; std::string baseCons; std::vector<uint8_t> basePw;
   int maxLen = 0;
   for (int c : dirtySeqs) {
     Seq &q = seqs[c];
@@ -1207,12 +1251,12 @@ int t4_assembler::flushLive() {
     memset(&rec, 0, sizeof rec);
     rec.base_off = q.baseOff; rec.len = len; rec.barcode = q.barcode;
     for (int t = 0; t < 8 && t < (int)q.name.size() && !q.released; ++t) rec.name[t] = q.name[t];
-    seqId.push_back(c); seqRec.push_back(rec);
+    R.seqId.push_back(c); R.seqRec.push_back(rec);
     if (hi > lo) {
-      baseAt.push_back(q.baseOff + lo); baseLen.push_back(hi - lo);
+      R.baseAt.push_back(q.baseOff + lo); R.baseLen.push_back(hi - lo);
       for (int t = lo; t < hi; ++t) {
-        if (t < len) { baseCons.push_back(q.cons[t]); basePw.push_back(t4PwByte(q.pw[t].c[0], q.pw[t].c[1], q.pw[t].c[2], q.pw[t].c[3])); }
-        else { baseCons.push_back('\0'); basePw.push_back(t4PwByte(0, 0, 0, 0)); }
+        if (t < len) { R.baseCons.push_back(q.cons[t]); R.basePw.push_back(t4PwByte(q.pw[t].c[0], q.pw[t].c[1], q.pw[t].c[2], q.pw[t].c[3])); }
+        else { R.baseCons.push_back('\0'); R.basePw.push_back(t4PwByte(0, 0, 0, 0)); }
       }
     }
   }
@@ -1221,13 +1265,71 @@ int t4_assembler::flushLive() {
   d.table_slots = index.tabSlots; d.table_rebuilt = index.tabRebuilt ? 1 : 0;
   d.post_cap = (int64_t)index.arena.size(); d.base_cap = baseUsed + 1024; d.seq_cap = (int32_t)seqs.size() + 64;
   d.nseq = (int32_t)seqs.size(); d.max_seq_len = maxLen;
-  d.n_slots = (int64_t)slot.size(); d.slot = slot.data(); d.slot_code = slotCode.data(); d.slot_start = slotStart.data(); d.slot_cnt = slotCnt.data();
-  d.n_post_runs = (int64_t)postAt.size(); d.post_at = postAt.data(); d.post_len = postLen.data(); d.post_data = postData.data();
-  d.n_seqs = (int32_t)seqId.size(); d.seq_id = seqId.data(); d.seq = seqRec.data();
-  d.n_base_runs = (int64_t)baseAt.size(); d.base_at = baseAt.data(); d.base_len = baseLen.data(); d.base_cons = baseCons.data(); d.base_pw = basePw.data();
-  if ((r = t4_index_apply_delta(dev, &d))) return r;
+  d.n_slots = (int64_t)R.slot.size(); d.slot = R.slot.data(); d.slot_code = R.slotCode.data(); d.slot_start = R.slotStart.data(); d.slot_cnt = R.slotCnt.data();
+  d.n_post_runs = (int64_t)R.postAt.size(); d.post_at = R.postAt.data(); d.post_len = R.postLen.data(); d.post_data = R.postData.data();
+  d.n_seqs = (int32_t)R.seqId.size(); d.seq_id = R.seqId.data(); d.seq = R.seqRec.data();
+  d.n_base_runs = (int64_t)R.baseAt.size(); d.base_at = R.baseAt.data(); d.base_len = R.baseLen.data(); d.base_cons = R.baseCons.data(); d.base_pw = R.basePw.data();
   index.tabRebuilt = false; liveReset = false;
-  ++deltas; deltaBytes += (int64_t)(slot.size() * 16 + postData.size() * 4 + seqRec.size() * sizeof(t4_seq_record) + baseCons.size() * 2);
+  R.version = ++deltaVersion;
+  ++deltas; deltaBytes += (int64_t)(R.slot.size() * 16 + R.postData.size() * 4 + R.seqRec.size() * sizeof(t4_seq_record) + R.baseCons.size() * 2);
+  deltaLog.push_back(std::move(recp));
+  return T4_OK;
+}
+
+int t4_assembler::ensureLanes() {
+  if (!lanes.empty()) return T4_OK;
+  // One lane by default: measured on an MI355X (profiles/r03b_lanes_sweep.txt), re-querying invalidated entries in the background on
+  // further lanes does not shorten the chain -- the entry a commit invalidates is nearly always the next one to be served, so the
+  // head waits for a whole query either way (17.9 k waits at 100 k pairs with 3 lanes against 17.8 k with one) -- while every
+  // extra launch costs the one host thread its packing, delta and dependency-set time. The machinery stays for T4_LIVE_LANES > 1.
+  static const int nLanes = getenv("T4_LIVE_LANES") ? atoi(getenv("T4_LIVE_LANES")) : 1;
+  lanes.resize(nLanes < 1 ? 1 : (nLanes > 8 ? 8 : nLanes));
+  lanes[0].ctx = ctx;
+  for (size_t i = 1; i < lanes.size(); ++i) {
+    const int r = t4_init(t4_ctx_device(ctx), &lanes[i].ctx);
+    if (r) { err = "a query lane could not be created"; lanes.resize(i); return lanes.size() > 0 ? T4_OK : r; }
+    lanes[i].ownCtx = true;
+  }
+  for (Lane &L : lanes) L.version = deltaVersion - (int64_t)deltaLog.size();
+  return T4_OK;
+}
+
+// the lane's replica takes every delta it has not seen yet (in order); deltas every lane has applied leave the log
+int t4_assembler::bringUpToDate(Lane &L) {
+  int r;
+  if (!L.dev) { if ((r = t4_index_create(L.ctx, k, 0, &L.dev))) return r; }
+  if ((r = t4_index_set_params(L.dev, hitLenRequired, radius, novelSim))) return r;
+  for (const auto &rec : deltaLog) {
+    if (rec->version <= L.version) continue;
+    if ((r = t4_index_apply_delta(L.dev, &rec->d))) return r;
+    L.version = rec->version;
+  }
+  int64_t minV = deltaVersion;
+  for (const Lane &x : lanes) if (x.version < minV) minV = x.version;
+  while (!deltaLog.empty() && deltaLog.front()->version <= minV) deltaLog.pop_front();
+  return T4_OK;
+}
+
+// results of jobs nobody waits for any more (the window is dropped): let the kernels finish, forget what they return
+void t4_assembler::abandonJobs() {
+  for (Lane &L : lanes) {
+    if (!L.busy) continue;
+    const int32_t *a = nullptr, *b = nullptr, *e = nullptr; const t4_overlap *c = nullptr, *d2 = nullptr;
+    (void)t4_add_query_pool_end(L.ctx, &a, &b, &c, &d2, &e);
+    L.busy = false;
+    for (size_t i = 0; i < L.slots.size(); ++i) { Cached &en = *pool[L.slots[i]]; if (en.uid == L.uids[i]) { en.inflight = false; en.killed = false; en.shifts.clear(); } }
+  }
+}
+
+int t4_assembler::flushLive(Lane **out) {   // synchronous users (T4_VERIFY_WINDOW): an idle lane's replica, current
+  int r;
+  if ((r = ensureLanes())) return r;
+  Lane *L = nullptr;
+  for (Lane &x : lanes) if (!x.busy) { L = &x; break; }
+  if (!L) { L = &lanes.back(); if ((r = harvest(*L))) return r; }
+  if ((r = makeDelta())) return r;
+  if ((r = bringUpToDate(*L))) return r;
+  *out = L;
   return T4_OK;
 }
 
@@ -1237,7 +1339,8 @@ int t4_assembler::flushLive() {
 int t4_assembler::verifyServed(const Cached &c) {
   if (index.total == 0) return c.cnt == 0 ? T4_OK : T4_ERR_STATE;
   int rc;
-  if ((rc = flushLive())) return rc;
+  Lane *L = nullptr;
+  if ((rc = flushLive(&L))) return rc;
   const char *bases = c.read.empty() ? "A" : c.read.c_str();
   const int64_t offs[2] = {0, (int64_t)c.read.size()};
   const int32_t bc = c.barcode, st = c.strand;
@@ -1245,7 +1348,7 @@ int t4_assembler::verifyServed(const Cached &c) {
   const int32_t *cnts = nullptr, *bas = nullptr, *rets = nullptr;
   const t4_overlap *ov = nullptr, *ex = nullptr;
   unsigned char hint = c.tier;
-  if ((rc = t4_add_query_pool(dev, 1, bases, offs, &bc, &st, c.skip, &fac, &cnts, &bas, &ov, &ex, &rets, &hint))) return rc;
+  if ((rc = t4_add_query_pool(L->dev, 1, bases, offs, &bc, &st, c.skip, &fac, &cnts, &bas, &ov, &ex, &rets, &hint))) return rc;
   ++verified;
   auto same = [](const t4_overlap &a, const t4_overlap &b) {
     return a.seqIdx == b.seqIdx && a.readStart == b.readStart && a.readEnd == b.readEnd && a.seqStart == b.seqStart && a.seqEnd == b.seqEnd &&
@@ -1370,12 +1473,17 @@ void t4_assembler::processEvents() {
   if (order.empty() || (idxEvents.empty() && structEvents.empty())) { idxEvents.clear(); structEvents.clear(); return; }
   auto t0_ = std::chrono::steady_clock::now();
   struct Tm { double &acc; std::chrono::steady_clock::time_point t0; ~Tm() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tm_{secEvents, t0_};
-  auto kill = [&](Cached &e, int64_t &why) { if (e.valid) { e.valid = false; ++invalidations; ++why; } };
+  // (an entry whose query is still running is examined like one that holds a result: its dependency sets were derived at launch,
+  // from the state its lane's replica holds)
+  auto kill = [&](Cached &e, int64_t &why) {
+    if (e.valid) { e.valid = false; ++invalidations; ++why; }
+    else if (e.inflight && !e.killed) { e.killed = true; ++invalidations; ++why; }
+  };
   // structural events, in the order they happened
   for (const StructEv &ev : structEvents) {
     for (int sl : order) {
       Cached &e = *pool[sl];
-      if (!e.valid) continue;
+      if (!e.standing()) continue;
       const int margin = radius + 2;
       for (uint32_t plus = 0; plus < 2; ++plus) {
         Grp *g = e.groups.find((uint32_t)ev.c * 2u + plus);
@@ -1392,7 +1500,7 @@ void t4_assembler::processEvents() {
       if (ev.kind == 1 && e.valid) {
         for (t4_overlap &o : e.ov) if (o.seqIdx == ev.c) { o.seqStart += ev.a; o.seqEnd += ev.a; }
         for (t4_overlap &o : e.ext) if (o.seqIdx == ev.c) { o.seqStart += ev.a; o.seqEnd += ev.a; }
-      }
+      } else if (ev.kind == 1 && e.standing()) e.shifts.push_back({ev.c, ev.a});   // its records are still to come
     }
   }
   structEvents.clear();
@@ -1454,9 +1562,9 @@ void t4_assembler::processEvents() {
       for (int nd = winKmers.find(ev.code, ev.h); nd >= 0; nd = winKmers.nodes[nd].next) {
         const KOcc &o = winKmers.nodes[nd];
         Cached &e = *pool[o.slot];
-        if (e.uid != o.uid || !e.valid) continue;
+        if (e.uid != o.uid || !e.standing()) continue;
         if (e.fragile) { kill(e, invFragile); continue; }
-        for (uint32_t plus = 0; plus < 2 && e.valid; ++plus) {
+        for (uint32_t plus = 0; plus < 2 && e.standing(); ++plus) {
           const int n = (plus ? o.f : o.r) * (ev.delta > 0 ? ev.delta : -ev.delta);
           if (!n) continue;
           if (ev.delta > 0) {
@@ -1478,13 +1586,9 @@ void t4_assembler::processEvents() {
 }
 
 // The driver announces the next n reads it will offer to AddRead, in order, with the arguments it will offer them with.
-// Entries already in the window that still stand are kept; every other one is (re-)queried in ONE batch against the patched
-// device image. Returns with a valid head.
-int t4_assembler::prefetchLive(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive) {
-  auto tp0_ = std::chrono::steady_clock::now();
-  struct Tp { double &acc; std::chrono::steady_clock::time_point t0; ~Tp() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tp_{secPrefetch, tp0_};
-  processEvents();
-  // match the announced reads against the window; what does not line up is dropped
+// Entries already in the window that line up are kept (with their results, or with the query that is running for them);
+// what does not line up is dropped, the rest of the announcement becomes new entries without a result.
+void t4_assembler::announceLive(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive) {
   size_t keep = 0;
   for (; keep < order.size() && keep < (size_t)n; ++keep) {
     const Cached &c = *pool[order[keep]];
@@ -1492,7 +1596,7 @@ int t4_assembler::prefetchLive(int n, const char *const *reads, const int *stran
   }
   while (order.size() > keep && keep < (size_t)n) {   // (entries beyond the announced ones stay when every announced read lined up)
     const int sl = order.back(); order.pop_back();
-    pool[sl]->valid = false; pool[sl]->uid = 0; freeSlots.push_back(sl);
+    pool[sl]->valid = false; pool[sl]->inflight = false; pool[sl]->uid = 0; freeSlots.push_back(sl);   // a running query of it is ignored when it returns (uid)
     if (pool[sl]->registered) { --winKmerLive; pool[sl]->registered = false; }
   }
   if (winKmerRefs > 64 * 284 && winKmerRefs > 4 * (winKmerLive + 1) * 284) {   // mostly references of retired entries: rebuild
@@ -1505,41 +1609,44 @@ int t4_assembler::prefetchLive(int n, const char *const *reads, const int *stran
     else { sl = (int)pool.size(); pool.push_back(new Cached()); }
     Cached &c = *pool[sl];
     c.read = reads[i]; c.strand = strands[i]; c.barcode = barcodes ? barcodes[i] : -1; c.skip = repetitive; c.cnt = 0; c.valid = false;
+    c.inflight = false; c.killed = false; c.shifts.clear();
     c.ov.clear(); c.ext.clear(); c.extRet.clear();
     c.uid = nextUid++; c.tier = 0; c.registered = false;
     order.push_back(sl);
   }
-  // Entries far behind the head rarely survive until they are consumed: (re-)query only as far ahead as a few times what a
-  // round has recently served (every read queried adds to the latency of the round: it ends with its slowest read)
-  {
-    const double served = (double)(cacheHits - hitsAtLastRound);
-    hitsAtLastRound = cacheHits;
-    if (rounds > 0) runEma = 0.8 * runEma + 0.2 * served;
-  }
-  static const int fixedAhead = getenv("T4_QUERY_AHEAD") ? atoi(getenv("T4_QUERY_AHEAD")) : 0;
-  size_t ahead = fixedAhead > 0 ? (size_t)fixedAhead : (size_t)(3.0 * runEma) + 12;
-  std::vector<int> todo;
-  for (size_t i = 0; i < order.size() && i < ahead; ++i) if (!pool[order[i]]->valid) todo.push_back(order[i]);
-  if (todo.empty()) return T4_OK;
+}
+
+// One query launch: the lane's replica is brought up to date, the reads go out, and while the kernels run the dependency sets of the
+// queried reads are derived from the host replica (which IS the state the lane's replica now holds). Returns without waiting.
+int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive) {
+  auto tl0_ = std::chrono::steady_clock::now();
+  struct Tl { double &acc; std::chrono::steady_clock::time_point t0; ~Tl() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tl_{secLaunch, tl0_};
   int rc;
+  if ((rc = makeDelta())) return rc;
+  { auto t0 = std::chrono::steady_clock::now(); rc = bringUpToDate(L); secDelta += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); if (rc) return rc; }
   const int m = (int)todo.size();
-  if (index.total == 0) {   // an empty set has no hit for anybody
-    for (int sl : todo) { Cached &c = *pool[sl]; c.cnt = 0; c.valid = true; c.groups.reset(16); c.slack = 99; c.fragile = false; if (!c.registered) registerKmers(c, sl); }
-    return T4_OK;
-  }
-  if ((rc = flushLive())) return rc;
-  auto tq0_ = std::chrono::steady_clock::now();
-  struct Tq { double &acc; std::chrono::steady_clock::time_point t0; ~Tq() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tq_{secQuery, tq0_};
-  std::string bases; std::vector<int64_t> offs(1, 0); std::vector<int32_t> bcs(m), sts(m); std::vector<double> fac(m);
+  L.slots = todo; L.uids.resize(m); L.hint.resize(m); L.bcs.resize(m); L.sts.resize(m); L.fac.resize(m);
+  L.bases.clear(); L.offs.assign(1, 0); L.repetitive = repetitive;
   for (int i = 0; i < m; ++i) {
-    const Cached &c = *pool[todo[i]];
-    bases += c.read; offs.push_back((int64_t)bases.size()); bcs[i] = c.barcode; sts[i] = c.strand;
-    fac[i] = (c.barcode == -1 && !repetitive) ? 1.0 : 2.0;   // ExtendOverlap's mismatch factor (SeqSet.hpp:3597-3598)
+    Cached &c = *pool[todo[i]];
+    L.uids[i] = c.uid; L.hint[i] = c.tier;
+    L.bases += c.read; L.offs.push_back((int64_t)L.bases.size()); L.bcs[i] = c.barcode; L.sts[i] = c.strand;
+    L.fac[i] = (c.barcode == -1 && !repetitive) ? 1.0 : 2.0;   // ExtendOverlap's mismatch factor (SeqSet.hpp:3597-3598)
+    c.inflight = true; c.killed = false; c.shifts.clear();
   }
-  if (bases.empty()) bases.push_back('A');
+  if (L.bases.empty()) L.bases.push_back('A');
+  {
+    auto tq0 = std::chrono::steady_clock::now();
+    rc = t4_add_query_pool_begin(L.dev, m, L.bases.data(), L.offs.data(), L.bcs.data(), L.sts.data(), repetitive, L.fac.data(), L.hint.data());
+    secQuery += std::chrono::duration<double>(std::chrono::steady_clock::now() - tq0).count();
+  }
+  if (rc) { for (int sl : todo) pool[sl]->inflight = false; return rc; }
+  L.busy = true; L.polls = 0;
+  ++queries; ++rounds; ++launches; readsQueried += m;
   // the hit groups of the queried reads come from the host replica of the index while the GPU runs the query
   // ... and so do the window's inverted k-mer map entries of the reads queried for the first time (one thread: the map has one
-  // writer and, until the results are in, no reader)
+  // writer and, until this returns, no reader)
+  auto tg1 = std::chrono::steady_clock::now();
   std::atomic<int> nextG(0);
   std::atomic<bool> regTaken(false);
   const auto registerNew = [&]() { for (int sl : todo) if (!pool[sl]->registered) registerKmers(*pool[sl], sl); };
@@ -1549,37 +1656,143 @@ int t4_assembler::prefetchLive(int n, const char *const *reads, const int *stran
   };
   const int nHelp = m >= 2 ? (threads - 1 < m - 1 ? threads - 1 : m - 1) : 0;
   if (nHelp > 0) { if (!helpers) helpers.reset(new HelperPool()); helpers->start(nHelp, groupWorker); }
-  const int32_t *cnts = nullptr, *bas = nullptr, *rets = nullptr;
-  const t4_overlap *ov = nullptr, *ex = nullptr;
-  std::vector<unsigned char> hint(m);
-  for (int i = 0; i < m; ++i) hint[i] = pool[todo[i]]->tier;
-  rc = t4_add_query_pool(dev, m, bases.data(), offs.data(), bcs.data(), sts.data(), repetitive, fac.data(), &cnts, &bas, &ov, &ex, &rets, hint.data());
-  auto tg1 = std::chrono::steady_clock::now();
   groupWorker();
   if (nHelp > 0) helpers->wait();
   secGroups += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg1).count();
-  ++queries; ++rounds; readsQueried += m;
-  if (rc) { dropWindow(); return rc; }
-  {   // T4_ROUND_LOG=path (development aid): one line per query round -- reads, kernel ms, and per read: us in its workgroup / overlaps / tier
-    static FILE *roundLog = getenv("T4_ROUND_LOG") ? fopen(getenv("T4_ROUND_LOG"), "w") : nullptr;
-    if (roundLog) {
-      double ms = 0; const int32_t *ticks = nullptr; int nn = 0;
-      t4_add_query_last_call(ctx, &ms, &ticks, &nn);
-      fprintf(roundLog, "%lld %d %.4f %d |", (long long)rounds, m, ms, (int)seqs.size());
-      for (int i = 0; i < m && i < nn; ++i) fprintf(roundLog, " %d/%d/%d", ticks ? ticks[i] / 100 : -1, cnts[i], (int)hint[i]);
-      fputc('\n', roundLog);
-    }
+  return T4_OK;
+}
+
+// The lane's job is over (waits for it if need be): entries that still stand take their records, with the left extensions that
+// happened meanwhile applied; entries a commit killed in flight stay without a result.
+int t4_assembler::harvest(Lane &L) {
+  if (!L.busy) return T4_OK;
+  auto th0_ = std::chrono::steady_clock::now();
+  struct Th { double &acc; std::chrono::steady_clock::time_point t0; ~Th() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } th_{secHarvest, th0_};
+  const int32_t *cnts = nullptr, *bas = nullptr, *rets = nullptr;
+  const t4_overlap *ov = nullptr, *ex = nullptr;
+  int rc;
+  {
+    auto tq0 = std::chrono::steady_clock::now();
+    rc = t4_add_query_pool_end(L.ctx, &cnts, &bas, &ov, &ex, &rets);
+    secQuery += std::chrono::duration<double>(std::chrono::steady_clock::now() - tq0).count();
+  }
+  L.busy = false;
+  const int m = (int)L.slots.size();
+  if (rc) {
+    if (L.ctx != ctx) err = t4_last_error(L.ctx);
+    for (int i = 0; i < m; ++i) { Cached &c = *pool[L.slots[i]]; if (c.uid == L.uids[i]) { c.inflight = false; c.killed = false; } }
+    dropWindow();
+    return rc;
+  }
+  static FILE *roundLog = getenv("T4_ROUND_LOG") ? fopen(getenv("T4_ROUND_LOG"), "w") : nullptr;   // development aid: one line per launch -- reads, kernel ms, per read: us in its workgroup / overlaps / tier / killed in flight
+  if (roundLog) {
+    double ms = 0; const int32_t *ticks = nullptr; int nn = 0;
+    t4_add_query_last_call(L.ctx, &ms, &ticks, &nn);
+    fprintf(roundLog, "%lld %d %.4f %d |", (long long)rounds, m, ms, (int)seqs.size());
+    for (int i = 0; i < m && i < nn; ++i) fprintf(roundLog, " %d/%d/%d/%d", ticks ? ticks[i] / 100 : -1, cnts[i], (int)L.hint[i], pool[L.slots[i]]->uid == L.uids[i] ? (int)pool[L.slots[i]]->killed : 2);
+    fputc('\n', roundLog);
   }
   for (int i = 0; i < m; ++i) {
-    Cached &c = *pool[todo[i]];
+    Cached &c = *pool[L.slots[i]];
+    if (c.uid != L.uids[i] || !c.inflight) continue;   // the entry was retired (or re-announced) meanwhile
+    c.inflight = false;
+    c.tier = L.hint[i];
+    if (c.killed) { c.killed = false; c.shifts.clear(); ++killedInFlight; continue; }
     c.cnt = cnts[i];
     const int k2 = c.cnt > 0 ? c.cnt : 0;
     c.ov.assign(ov + bas[i], ov + bas[i] + k2);
     c.ext.assign(ex + bas[i], ex + bas[i] + k2);
     c.extRet.assign(rets + bas[i], rets + bas[i] + k2);
-    c.valid = true; c.tier = hint[i];
+    for (const auto &sh : c.shifts) {
+      for (t4_overlap &o : c.ov) if (o.seqIdx == sh.first) { o.seqStart += sh.second; o.seqEnd += sh.second; }
+      for (t4_overlap &o : c.ext) if (o.seqIdx == sh.first) { o.seqStart += sh.second; o.seqEnd += sh.second; }
+    }
+    c.shifts.clear();
+    c.valid = true;
   }
   return T4_OK;
+}
+
+// Keep the window's queries going. Finished lanes are harvested; entries near the head that have no result and no running query
+// are sent out -- at once when the head itself needs one (it is what the caller waits for), else when a few have gathered and a
+// lane beside the one kept for the head is idle. needHead: return only when the head entry holds a result.
+int t4_assembler::pumpLive(bool needHead, int repetitive) {
+  int rc;
+  if ((rc = ensureLanes())) return rc;
+  static const int fixedAhead = getenv("T4_QUERY_AHEAD") ? atoi(getenv("T4_QUERY_AHEAD")) : 0;
+  static const int minBatch = getenv("T4_LIVE_MIN_BATCH") ? atoi(getenv("T4_LIVE_MIN_BATCH")) : 4;
+  static const bool syncMode = getenv("T4_LIVE_SYNC") != nullptr;   // testing aid: every launch is waited for at once (the round structure of round 2)
+  // Entries far behind the head rarely survive until they are consumed: (re-)query only as far ahead as a few times what a launch
+  // for the head has recently served (every read queried adds to the latency of the launch: it ends with its slowest read)
+  const size_t ahead = fixedAhead > 0 ? (size_t)fixedAhead : (lanes.size() > 1 ? 24 : (size_t)(3.0 * runEma) + 12);
+  for (;;) {
+    // T4_LIVE_HARVEST_DELAY=n (testing aid): a finished launch is only noticed n calls later, so that commits pile up against queries in flight
+    static const int harvestDelay = getenv("T4_LIVE_HARVEST_DELAY") ? atoi(getenv("T4_LIVE_HARVEST_DELAY")) : 0;
+    for (Lane &L : lanes) if (L.busy && ++L.polls > harvestDelay && t4_add_query_pool_done(L.ctx)) { if ((rc = harvest(L))) return rc; }
+    if (order.empty()) return T4_OK;
+    if (index.total == 0) {   // an empty set has no hit for anybody
+      for (size_t i = 0; i < order.size() && i < ahead; ++i) {
+        Cached &c = *pool[order[i]];
+        if (c.valid || c.inflight) continue;
+        c.cnt = 0; c.valid = true; c.groups.reset(16); c.slack = 99; c.fragile = false;
+        if (!c.registered) registerKmers(c, order[i]);
+      }
+      return T4_OK;
+    }
+    Cached &head = *pool[order.front()];
+    std::vector<int> light, heavy;
+    for (size_t i = 0; i < order.size() && i < ahead; ++i) {
+      Cached &c = *pool[order[i]];
+      if (c.valid || c.inflight) continue;
+      (c.tier ? heavy : light).push_back(order[i]);
+    }
+    const bool headWaits_ = !head.valid && !head.inflight;
+    int idle = 0; Lane *free1 = nullptr;
+    for (Lane &L : lanes) if (!L.busy) { ++idle; if (!free1) free1 = &L; }
+    bool launched = false;
+    if (headWaits_) {
+      if (!free1) {   // every lane is busy: the first to finish serves the head
+        for (Lane &L : lanes) if (L.busy) { if ((rc = harvest(L))) return rc; break; }
+        continue;
+      }
+      // the head's launch carries the entries of its own weight class; the other class goes beside it when a lane is free
+      std::vector<int> &mine = head.tier ? heavy : light, &other = head.tier ? light : heavy;
+      if (lanes.size() == 1) { mine.insert(mine.end(), other.begin(), other.end()); other.clear(); }   // one launch: the heavy ones run beside the others on the ctx's second stream
+      {
+        const double served = (double)(cacheHits - hitsAtLastRound);
+        hitsAtLastRound = cacheHits;
+        if (launchesUrgent > 0) runEma = 0.8 * runEma + 0.2 * served;
+      }
+      if ((rc = launchOn(*free1, mine, repetitive))) return rc;
+      ++launchesUrgent; launched = true;
+      if (!other.empty() && idle >= 2) for (Lane &L : lanes) if (!L.busy) { if ((rc = launchOn(L, other, repetitive))) return rc; break; }
+    } else if ((int)(light.size() + heavy.size()) >= minBatch && idle >= 2) {   // one lane stays free for the head
+      std::vector<int> all = light; all.insert(all.end(), heavy.begin(), heavy.end());
+      if ((rc = launchOn(*free1, all, repetitive))) return rc;
+      launched = true;
+    }
+    if (syncMode && launched) { for (Lane &L : lanes) if (L.busy && (rc = harvest(L))) return rc; continue; }
+    if (!needHead || pool[order.front()]->valid) return T4_OK;
+    if (pool[order.front()]->inflight) {   // wait for the lane that carries the head
+      auto tw0 = std::chrono::steady_clock::now();
+      const int hs = order.front();
+      for (Lane &L : lanes) {
+        if (!L.busy) continue;
+        bool has = false;
+        for (size_t i = 0; i < L.slots.size(); ++i) if (L.slots[i] == hs && L.uids[i] == pool[hs]->uid) { has = true; break; }
+        if (has) { if ((rc = harvest(L))) return rc; break; }
+      }
+      ++headWaits; secHeadWait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw0).count();
+    }
+  }
+}
+
+int t4_assembler::prefetchLive(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive) {
+  auto tp0_ = std::chrono::steady_clock::now();
+  struct Tp { double &acc; std::chrono::steady_clock::time_point t0; ~Tp() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tp_{secPrefetch, tp0_};
+  processEvents();
+  announceLive(n, reads, strands, barcodes, repetitive);
+  return pumpLive(true, repetitive);
 }
 
 void t4_assembler::beginWindow(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive) {
@@ -1775,8 +1988,12 @@ int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n) {
   for (int i = 0; i < n && i < 16; ++i) out[i] = v[i];
   if (n >= 23) t4_add_query_stats(a->ctx, out + 16);
   if (getenv("T4_VERIFY_WINDOW")) fprintf(stderr, "T4_VERIFY_WINDOW: %lld served window entries queried again at serve time, all equal to their cached results\n", (long long)a->verified);
-  if (getenv("T4_TIMING")) fprintf(stderr, "timing: assembler host seconds: add_read calls %.3f (incl. fallback queries), prefetch calls %.3f (of which query %.3f, deltas %.3f, registering k-mers %.3f), event examination %.3f, index edits %.3f\n",
-                                   a->secAddTotal, a->secPrefetch, a->secQuery, a->secDelta, a->secRegister, a->secEvents, a->index.secOps);
+  if (getenv("T4_TIMING")) {
+    fprintf(stderr, "timing: assembler host seconds: add_read calls %.3f (incl. waits for the head), prefetch calls %.3f; launching %.3f (of which deltas %.3f, dependency sets %.3f, registering k-mers %.3f), harvesting %.3f, event examination %.3f, index edits %.3f\n",
+            a->secAddTotal, a->secPrefetch, a->secLaunch, a->secDelta, a->secGroups, a->secRegister, a->secHarvest, a->secEvents, a->index.secOps);
+    fprintf(stderr, "timing: query lanes %d: %lld launches (%lld for a head without a result), %lld waits for the head's lane in %.3f s, %lld queries killed in flight\n",
+            (int)a->lanes.size(), (long long)a->launches, (long long)a->launchesUrgent, (long long)a->headWaits, a->secHeadWait, (long long)a->killedInFlight);
+  }
   return T4_OK;
 }
 int t4_assembler_output(t4_assembler *a, const char *path) { return a ? a->output(path) : T4_ERR_ARG; }

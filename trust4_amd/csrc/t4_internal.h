@@ -51,6 +51,7 @@ int t4_add_query_pool(t4_index *ix, int n, const char *bases, const int64_t *off
 int t4_add_query_pool_begin(t4_index *ix, int n, const char *bases, const int64_t *offsets, const int32_t *barcodes, const int32_t *strands,
                             int skip_repeats, const double *factors, unsigned char *tier_hint);
 int t4_add_query_pool_done(t4_ctx *ctx);
+int t4_ctx_device(t4_ctx *ctx);   // the device ordinal the ctx was created on (t4_assembler opens further ctxs beside it: one per query lane)
 int t4_add_query_pool_end(t4_ctx *ctx, const int32_t **counts, const int32_t **base, const t4_overlap **ov, const t4_overlap **ext, const int32_t **ext_ret);
 
 // AddRead query path of this ctx, 7 values: calls, reads, launches of the global-scratch tier, reads it served, result records,

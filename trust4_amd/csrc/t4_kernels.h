@@ -2779,8 +2779,8 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
       if (wl == 0) {
         ExtSide e;
         e.size = (short)size; e.match = (short)(size - mm); e.mis = (short)mm; e.indel = 0; e.pending = 0;
-        if (size > 1 && !((size - mm) * 2 - mm * 2 >= size * 2 - 8)) { e.pending = 1; good = 0; }   // needs the banded DP
-        e.good = (short)good;
+        if (size > 1 && !((size - mm) * 2 - mm * 2 >= size * 2 - 8)) e.pending = 1;   // needs the banded DP; `good` is what the ungapped
+        e.good = (short)good;                                                           // alignment gives, final if the DP's traceback never leaves the diagonal
         sides[q] = e;
       }
     }
@@ -2848,14 +2848,32 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
       int Lmax = L;
       { int x = __shfl_xor(Lmax, 16); if (x > Lmax) Lmax = x; x = __shfl_xor(Lmax, 32); if (x > Lmax) Lmax = x; }
       dpRowTracePW(w, L, pr, dirbuf + (size_t)(wave * 4 + row) * qslice, Lmax);
+      waveLdsSync();
+      // The traceback (AlignAlgo.hpp:160-205) starts at (L, L) and takes the diagonal whenever the diagonal predecessor gives the
+      // cell's score. If that holds in every cell of the main diagonal the alignment IS the ungapped one, whose counts and "good"
+      // prefix the ungapped evaluation already left in sides[q]: sixteen lanes look at the L diagonal cells at once, and only a
+      // side whose path leaves the diagonal is walked by one lane.
+      {
+        const unsigned char *buf = dirbuf + (size_t)(wave * 4 + row) * qslice;
+        int offDiag = 0;
+        for (int i = 1 + (wl & 15); i <= L; i += 16) if (!(buf[i * 11 + 5] & 4)) offDiag = 1;
+        offDiag |= __shfl_xor(offDiag, 1); offDiag |= __shfl_xor(offDiag, 2); offDiag |= __shfl_xor(offDiag, 4); offDiag |= __shfl_xor(offDiag, 8);
+        if ((wl & 15) == 0 && t < nFit) {
+          const int q = (int)wm.cand[t];
+          if (!offDiag) { ExtSide e = sides[q]; e.pending = 0; sides[q] = e; }
+          else { ExtSide e = sides[q]; e.pending = 2; sides[q] = e; }
+        }
+      }
       __syncthreads();
       if (lane < perChunk && c0 + lane < nFit) {
         const int q = (int)wm.cand[c0 + lane];
-        const int size = sides[q].size;
-        unsigned char *buf = dirbuf + (size_t)lane * qslice;
-        signed char *align = (signed char *)(buf + (size + 1) * 11);
-        const int alen = tracebackPW(buf, size, align);
-        finishSide(q, align, alen);
+        if (sides[q].pending == 2) {
+          const int size = sides[q].size;
+          unsigned char *buf = dirbuf + (size_t)lane * qslice;
+          signed char *align = (signed char *)(buf + (size + 1) * 11);
+          const int alen = tracebackPW(buf, size, align);
+          finishSide(q, align, alen);
+        }
       }
       __syncthreads();
     }
@@ -2882,10 +2900,17 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
         const char *r = (useFirstStrand ? plus0 : (o.flags & OV_PLUS)) ? wm.seg : wm.rc;
         const int t0 = side == 0 ? o.ss - size : o.se + 1, p0 = side == 0 ? o.rs - size : o.re + 1;
         dpWaveTracePW(ix.pw + si.pwOff + t0, size, r + p0, buf);
+        waveLdsSync();
+        int offDiag = 0;
+        for (int i = 1 + wl; i <= size; i += 64) if (!(buf[i * 11 + 5] & 4)) offDiag = 1;
+        offDiag = __ballot(offDiag != 0) != 0ull;
         if (wl == 0) {
-          signed char *align = (signed char *)(buf + (size + 1) * 11);
-          const int alen = tracebackPW(buf, size, align);
-          finishSide(q, align, alen);
+          if (!offDiag) { ExtSide e = sides[q]; e.pending = 0; sides[q] = e; }   // the ungapped alignment (see above)
+          else {
+            signed char *align = (signed char *)(buf + (size + 1) * 11);
+            const int alen = tracebackPW(buf, size, align);
+            finishSide(q, align, alen);
+          }
         }
       }
       __syncthreads();
