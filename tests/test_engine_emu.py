@@ -382,13 +382,16 @@ def test_has_hit_vs_oracle(emu_engine):
     check_has_hit(emu_engine, 5, hit_lens=(17,))
 
 
-def check_novel_min_statistics(eng, seed=4, n_contigs=180, k=9):
+def check_novel_min_statistics(eng, seed=4, n_contigs=180, k=9, repeats=False):
     """More than 100 novel groups of more than 3 hits on a strand: GetOverlapsFromHits raises its minimum run size from the
     group statistics (SeqSet.hpp:784-821), including the `i = j; ++i` stepping that skips the first hit of every other group.
     The set: many near-identical contigs plus one-k-mer decoys interleaved in the id order, so that one-hit groups sit between
     the big ones."""
     rnd = random.Random(seed)
     core = "".join(rnd.choice("ACGT") for _ in range(260))
+    if repeats:   # tandem repeats of period 1, 2, 3 and 5: k-mers that equal the one 1 .. 5 positions back, between k-mers of 100+ postings
+        rn = lambda n: "".join(rnd.choice("ACGT") for _ in range(n))
+        core = rn(40) + "AC" * 11 + rn(25) + "A" * 19 + rn(30) + "ACG" * 8 + rn(22) + "GATTC" * 5 + rn(40) + "T" * 12 + rn(30)
     o = Oracle(k)
     ix = eng.index(k)
     for i in range(n_contigs):
@@ -407,20 +410,37 @@ def check_novel_min_statistics(eng, seed=4, n_contigs=180, k=9):
     ix.set_params(17, 10, 0.9).commit()
     comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
     reads = []
-    for _ in range(12):
-        st = rnd.randint(0, 150)
+    comp["N"] = "N"
+    for _ in range(40 if repeats else 12):
+        st = rnd.randint(0, len(core) - 110)
         rd = core[st: st + rnd.randint(40, 110)]
+        if repeats and rnd.random() < 0.3:
+            at = rnd.randrange(len(rd))
+            rd = rd[:at] + "N" + rd[at + 1:]
         reads.append(rd if rnd.random() < 0.5 else "".join(comp[x] for x in reversed(rd)))
     b = eng.upload(reads)
-    cnt, ov = ix.overlaps(b, 0, 0, 128)
-    assert t4check.check_overlaps(cnt, ov, reads, o) == []
+    room = 128 if n_contigs * 2 // 3 <= 128 else 512   # a read may overlap every copy of the core
+    for strand in ((0, 1, -1) if repeats else (0,)):
+        cnt, ov = ix.overlaps(b, strand, 0, room)
+        assert cnt.max() <= room
+        assert t4check.check_overlaps(cnt, ov, reads, o, strand=strand) == []
+    if repeats:   # skipRepeats (allowTotalSkip) keeps the one-lane replay of the rule
+        cnt1, ov1 = ix.overlaps(b, 0, 1, room)
+        assert t4check.check_overlaps(cnt1, ov1, reads, o, skip_repeats=1) == []
     off, hits = ix.hits(b, 0, 0)
     assert t4check.check_hits(off, hits, reads, o) == []
-    assert (np.diff(off) > 100 * 4 * 2).all() and (cnt > 0).all()   # > 100 groups of > 3 hits per read
+    if not repeats:
+        assert (np.diff(off) > 100 * 4 * 2).all() and (cnt > 0).all()   # > 100 groups of > 3 hits per read
 
 
 def test_novel_min_statistics(emu_engine):
     check_novel_min_statistics(emu_engine)
+
+
+def test_repeat_skip_rule_on_tandem_repeats(emu_engine):
+    """GetHitsFromRead's repeat-skip rule (SeqSet.hpp:1381-1391) where it bites: lists of 100+ postings, k-mers equal to the one
+    1 - 5 positions back, N in the reads; the query kernel replays the rule over bit masks (seedPositions), the oracle walks it"""
+    check_novel_min_statistics(emu_engine, seed=9, n_contigs=170, repeats=True)
 
 
 def test_group_stepping_closed_form():

@@ -151,6 +151,8 @@ def test_novel_min_statistics(eng):
     from test_engine_emu import check_novel_min_statistics
     check_novel_min_statistics(eng)
     check_novel_min_statistics(eng, seed=8, n_contigs=260)
+    check_novel_min_statistics(eng, seed=9, n_contigs=170, repeats=True)    # the repeat-skip rule over tandem repeats (bit-mask replay in seedPositions)
+    check_novel_min_statistics(eng, seed=10, n_contigs=300, repeats=True)   # up to 200 overlaps per read
 
 
 def test_long_reads_and_limits(eng):

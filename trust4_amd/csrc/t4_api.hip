@@ -60,7 +60,7 @@ struct HostSeq {
 // per ctx. tierHint must stay alive until aqEnd.
 struct AqCall {
   bool active = false;
-  T4IndexView base; const T4IndexView *views = nullptr; bool hasViewOf = false, smallFirst = false;
+  T4IndexView base; const T4IndexView *views = nullptr; bool hasViewOf = false, smallFirst = false, lean = false;
   int n = 0, skipRepeats = 0, wpk = 0, wnm = 0, attempt = 0, nFirst = 0, nDirect = 0, threads = 512;
   unsigned char *tierHint = nullptr;
   std::vector<unsigned char> allGlobal;
@@ -255,11 +255,14 @@ void t4_destroy(t4_ctx *c) {
   if (getenv("T4_PHASE_DUMP")) {   // development aid: cycles per kernel phase over the life of the ctx
     unsigned long long ph[T4_NPHASE];
     if (hipMemcpyFromSymbol(ph, HIP_SYMBOL(t4k::g_phaseCycles), sizeof(ph)) == hipSuccess) {
-      static const char *names[32] = {"other", "seed:lookup", "expand", "sort", "stats", "runs", "bigsort", "chain", "ovsort", "score", "prefilter", "final", "annotate", "score:quick", "score:banded", "score:finish", "extend:ungapped", "after-extend", "extend:list", "extend:dp4", "extend:dp1", "extend:combine", "seed:replay", "seed:scan", "-", "-", "-", "-", "-", "-", "-", "-"};
+      static const char *names[32] = {"other", "seed:lookup", "expand", "sort", "stats", "runs", "bigsort", "chain", "ovsort", "score", "prefilter", "final", "annotate", "score:quick", "score:banded", "score:finish", "extend:ungapped", "after-extend", "extend:list", "extend:dp4", "extend:dp1", "extend:combine", "seed:replay", "seed:scan", "extend:launch", "-", "-", "-", "-", "-", "-", "-"};
       unsigned long long tot = 0;
       for (int i = 0; i < T4_NPHASE; ++i) tot += ph[i];
       for (int i = 0; i < T4_NPHASE; ++i) if (ph[i]) fprintf(stderr, "phase %-16s %-7s %6.2f%%  %.3e cycles\n", names[i & 31], i < 32 ? "lds" : "global", 100.0 * (double)ph[i] / (double)tot, (double)ph[i]);
     }
+    unsigned long long dc[8];
+    if (hipMemcpyFromSymbol(dc, HIP_SYMBOL(t4k::g_dbgCount), sizeof(dc)) == hipSuccess)
+      fprintf(stderr, "debug counters: gap jobs %llu, banded %llu, wave-DP steps %llu, scratch fallbacks %llu; overhang DPs %llu, of which %llu leave the diagonal\n", dc[0], dc[1], dc[2], dc[3], dc[6], dc[7]);
   }
 #endif
   void *ptrs[] = {c->dpRows, c->dpDir, c->gKeys, c->gPairs, c->gCand, c->gOv, c->gFin, c->gOrd, c->hitsKeys, c->lists,
@@ -1350,7 +1353,7 @@ struct AqResult { const int32_t *counts, *base; const t4_overlap *ov, *ext; cons
 int aqLaunch(t4_ctx *c);
 int aqBegin(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const int32_t *viewOf, bool smallFirst, int n, const char *bases,
             const int64_t *offsets, const int32_t *barcodes, const int32_t *strands, int skip_repeats, const double *factors,
-            unsigned char *tierHint = nullptr) {
+            unsigned char *tierHint = nullptr, bool lean = false) {
   (void)hipSetDevice(c->device);
   AqCall &q = c->aq;
   if (q.active) return fail(c, T4_ERR_STATE, "an AddRead query is already in flight on this ctx");
@@ -1360,6 +1363,7 @@ int aqBegin(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const 
     if (l < 0 || l > T4_MAXL) return fail(c, T4_ERR_UNSUPPORTED, "read %d is %lld bp; this engine takes reads up to %d bp", i, (long long)l, T4_MAXL);
     if (l > maxLen) maxLen = (int)l;
   }
+  q.lean = lean;
   q.base = base; q.views = views; q.hasViewOf = viewOf != nullptr; q.smallFirst = smallFirst; q.n = n; q.skipRepeats = skip_repeats; q.tierHint = tierHint; q.attempt = 0;
   const int wpk = (maxLen + 15) / 16, wnm = (maxLen + 31) / 32;
   q.wpk = wpk; q.wnm = wnm;
@@ -1451,6 +1455,7 @@ int aqLaunch(t4_ctx *c) {
   qa.outBase = (int *)(c->aqOut + q.pBase); qa.poolCursor = (unsigned *)(c->aqOut + q.pTail + 24); qa.poolCap = c->aqPoolCap;
   qa.strandPerRead = (const int *)(c->aqIn + q.oSt); qa.factorPerRead = (const double *)(c->aqIn + q.oFa);
   qa.readTicks = (int *)(c->aqOut + q.pTick);
+  qa.leanExt = q.lean ? 1 : 0;
   if (q.views) { qa.views = q.views; qa.viewOf = (const int *)(c->aqIn + q.oVw); }
   // one big set: the ExtendOverlap calls of reads with more than this many overlaps run in their own launch (0: never)
   static const int deferMin = getenv("T4_AQ_EXTEND_DEFER") ? atoi(getenv("T4_AQ_EXTEND_DEFER")) : 64;
@@ -1625,8 +1630,8 @@ int aqEnd(t4_ctx *c, AqResult *res) {
 
 int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const int32_t *viewOf, bool smallFirst, int n, const char *bases,
                  const int64_t *offsets, const int32_t *barcodes, const int32_t *strands, int skip_repeats, const double *factors, AqResult *res,
-                 unsigned char *tierHint = nullptr) {
-  int r = aqBegin(c, base, views, viewOf, smallFirst, n, bases, offsets, barcodes, strands, skip_repeats, factors, tierHint);
+                 unsigned char *tierHint = nullptr, bool lean = false) {
+  int r = aqBegin(c, base, views, viewOf, smallFirst, n, bases, offsets, barcodes, strands, skip_repeats, factors, tierHint, lean);
   if (r) return r;
   return aqEnd(c, res);
 }
@@ -1634,9 +1639,9 @@ int addQueryPool(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, c
 // the same with the fixed-stride result layout of t4_add_query / t4_cellstore_query
 int addQueryImpl(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const int32_t *viewOf, bool smallFirst, int n, const char *bases,
                  const int64_t *offsets, const int32_t *barcodes, const int32_t *strands, int skip_repeats, const double *factors,
-                 int max_per_read, int32_t *counts, t4_overlap *ov, t4_overlap *ext, int32_t *ext_ret) {
+                 int max_per_read, int32_t *counts, t4_overlap *ov, t4_overlap *ext, int32_t *ext_ret, bool lean = false) {
   AqResult res;
-  int r = addQueryPool(c, base, views, viewOf, smallFirst, n, bases, offsets, barcodes, strands, skip_repeats, factors, &res);
+  int r = addQueryPool(c, base, views, viewOf, smallFirst, n, bases, offsets, barcodes, strands, skip_repeats, factors, &res, nullptr, lean);
   if (r) return r;
   for (int i = 0; i < n; ++i) {
     counts[i] = res.counts[i];
@@ -1680,7 +1685,7 @@ int t4_add_query_pool(t4_index *ix, int n, const char *bases, const int64_t *off
   if (!ix->committed) return fail(c, T4_ERR_STATE, "index not committed");
   if (ix->view.firstIsRef) return fail(c, T4_ERR_UNSUPPORTED, "t4_add_query needs a contig set");
   AqResult res;
-  int r = addQueryPool(c, ix->view, nullptr, nullptr, false, n, bases, offsets, barcodes, strands, skip_repeats, factors, &res, tier_hint);
+  int r = addQueryPool(c, ix->view, nullptr, nullptr, false, n, bases, offsets, barcodes, strands, skip_repeats, factors, &res, tier_hint, true);
   if (r) return r;
   *counts = res.counts; *base = res.base; *ov = res.ov; *ext = res.ext; *ext_ret = res.ret;
   return T4_OK;
@@ -1694,7 +1699,7 @@ int t4_add_query_pool_begin(t4_index *ix, int n, const char *bases, const int64_
   t4_ctx *c = ix->ctx;
   if (!ix->committed) return fail(c, T4_ERR_STATE, "index not committed");
   if (ix->view.firstIsRef) return fail(c, T4_ERR_UNSUPPORTED, "t4_add_query needs a contig set");
-  return aqBegin(c, ix->view, nullptr, nullptr, false, n, bases, offsets, barcodes, strands, skip_repeats, factors, tier_hint);
+  return aqBegin(c, ix->view, nullptr, nullptr, false, n, bases, offsets, barcodes, strands, skip_repeats, factors, tier_hint, true);   // for t4_assembler: lean records (extendOverlaps)
 }
 int t4_add_query_pool_done(t4_ctx *c) { return c ? aqDone(c) : 1; }
 int t4_add_query_pool_end(t4_ctx *c, const int32_t **counts, const int32_t **base, const t4_overlap **ov, const t4_overlap **ext, const int32_t **ext_ret) {
@@ -2022,7 +2027,7 @@ int t4_cellstore_query(t4_cellstore *cs, int n, const int32_t *slots, const char
   T4IndexView base;
   memset(&base, 0, sizeof base);
   base.k = cs->k;
-  return addQueryImpl(c, base, cs->dViews, slots, !cs->bigFirst, n, bases, offsets, barcodes, strands, skip_repeats, factors, max_per_read, counts, ov, ext, ext_ret);
+  return addQueryImpl(c, base, cs->dViews, slots, !cs->bigFirst, n, bases, offsets, barcodes, strands, skip_repeats, factors, max_per_read, counts, ov, ext, ext_ret, true);   // consumed by t4_assembler::addRead only: lean records
 }
 int t4_cellstore_set_big_first(t4_cellstore *cs, int on) { if (!cs) return T4_ERR_ARG; cs->bigFirst = on != 0; return T4_OK; }
 int64_t t4_cellstore_bytes_staged(const t4_cellstore *cs) { return cs ? cs->bytesStaged + cs->bytesPatched : 0; }

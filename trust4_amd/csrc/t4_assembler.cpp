@@ -1901,9 +1901,25 @@ static void writeRecords(FILE *fp, const std::vector<Seq> &seqs, int idBase, con
     if (s.released) continue;
     if (barcodeName) fprintf(fp, ">%s_%d %s\n%s\n", barcodeName, idBase + i, s.name.c_str(), s.cons.c_str());
     else fprintf(fp, ">assemble%d %s\n%s\n", idBase + i, s.name.c_str(), s.cons.c_str());
+    // the four count lines ("%d " per column, SeqSet.hpp:10962): digits written into one buffer per line -- a printf per number was
+    // most of the output phase (50 M calls for the 25 k contigs of a 1 M-pair barcode run)
+    std::string line;
     for (int c = 0; c < 4; ++c) {
-      for (size_t j = 0; j < s.cons.size(); ++j) fprintf(fp, "%d ", s.pw[j].c[c]);
-      fprintf(fp, "\n");
+      line.clear();
+      line.reserve(s.cons.size() * 4 + 2);
+      char tmp[16];
+      for (size_t j = 0; j < s.cons.size(); ++j) {
+        int v = s.pw[j].c[c];
+        if (v >= 0 && v < 10) { line.push_back((char)('0' + v)); line.push_back(' '); continue; }
+        unsigned u = v < 0 ? 0u - (unsigned)v : (unsigned)v;
+        int n = 0;
+        do { tmp[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+        if (v < 0) line.push_back('-');
+        while (n) line.push_back(tmp[--n]);
+        line.push_back(' ');
+      }
+      line.push_back('\n');
+      fwrite(line.data(), 1, line.size(), fp);
     }
   }
 }

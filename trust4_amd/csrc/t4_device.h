@@ -154,6 +154,7 @@ struct T4QueryArgs {
   int extendLater;
   T4OverlapOut *outDev;
   int *recRead;
+  int leanExt;               // mode 4: records of overlaps whose extension meets an indel carry exact coordinates and return value only (extendOverlaps)
   int *readTicks;            // mode 4, nullable: wall-clock ticks (10 ns) one workgroup spent on the read (the latency a dependent round pays)
   // per-read set images (per-barcode contig sets): read r is matched against views[viewOf[r]]
   const T4IndexView *views;

@@ -682,7 +682,7 @@ __device__ __forceinline__ bool ovLess(const OvRec &a, const OvRec &b, bool scor
 #ifdef T4_PHASE_TIMING
 #define T4_NPHASE 64   // ids 0-31: reads in the LDS tiers; the same + 32: reads in global scratch (WaveState::phaseBase)
 __device__ unsigned long long g_phaseCycles[T4_NPHASE];
-__device__ unsigned long long g_dbgCount[8];   // 0 jobs, 1 pending (banded) jobs, 2 wave-DP steps, 3 scratch fallbacks, 4 fallback cells, 5 fallback cycles
+__device__ unsigned long long g_dbgCount[8];   // 0 jobs, 1 pending (banded) jobs, 2 wave-DP steps, 3 scratch fallbacks, 4 fallback cells, 5 fallback cycles, 6 overhang DPs (four per wavefront), 7 of which leave the diagonal
 #define DBG_ADD(i, v) do { atomicAdd(&g_dbgCount[i], (unsigned long long)(v)); } while (0)
 #define PHASE_MARK(ws, id)                                                                  \
   do { if (threadIdx.x == 0) { long long now_ = clock64(); atomicAdd(&g_phaseCycles[(ws)->curPhase], (unsigned long long)(now_ - (ws)->phaseT0)); (ws)->phaseT0 = now_; (ws)->curPhase = (id) + (ws)->phaseBase; } } while (0)
@@ -780,8 +780,15 @@ __device__ __forceinline__ unsigned long long kmerPacked(const WaveMem &wm, bool
 // Seed stage of one pass: fills posStart/posPref (aliased on wm.ov / wm.pairs) and returns the number
 // of hit records H that GetHitsFromRead would emit (before the barcode filter). Wave-uniform result.
 // vjOnly only changes the later expansion.
+#ifdef __HIPCC__
+#define T4_READLANE(v, l) ((unsigned)__builtin_amdgcn_readlane((int)(v), (l)))
+#else
+#define T4_READLANE(v, l) ((unsigned)__shfl((int)(v), (l)))
+#endif
+// flagBuf (nullable): 2 * nk words of scratch for the wave-wide replay of the repeat-skip rule (below); without it the rule is
+// replayed by one lane.
 __device__ int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int strandArg, int barcode,
-                             bool allowTotalSkip, unsigned *posStart, unsigned *posPref, int *red) {
+                             bool allowTotalSkip, unsigned *posStart, unsigned *posPref, int *red, unsigned *flagBuf = nullptr, WaveState *phaseWs = nullptr) {
   const int K = ix.k, lane = tid(), NT = nthr();
   const int nk = segLen - K + 1;           // k-mers per strand
   const unsigned long long mask = K < 32 ? ((1ull << (2 * K)) - 1ull) : ~0ull;
@@ -805,13 +812,59 @@ __device__ int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int
     if (cnt >= 100) big = 1;
   }
   big = blockSum(big, red) != 0;
-  PHASE_MARK_RED(red, 22);   // seed: the repeat-skip replay
+  if (phaseWs) PHASE_MARK(phaseWs, 22);   // seed: the repeat-skip replay (phase-timing builds; callers whose `red` is not inside a WaveState pass no phaseWs)
   if ((skipLimit == 0 && !allowTotalSkip) || !big) {
     // no `continue` can fire: prevKmerCode is always the code of the previous position
     for (int q = lane; q < 2 * nk; q += NT) {
       const unsigned v = posPref[q];
       posPref[q] = (v & SAME) ? 0u : v;
     }
+#ifndef T4_SEED_SERIAL
+  } else if (flagBuf && !allowTotalSkip && K <= 16) {
+    // The skip rule of GetHitsFromRead (SeqSet.hpp:1381-1391) is a small transducer: a k-mer with 100+ postings is passed over
+    // (without becoming the "previous k-mer") while fewer than skipLimit have been passed over since the last emitted one; every
+    // other k-mer is compared with the previous one that was not passed over, which lies at most skipLimit + 1 positions back.
+    // So a position needs two facts that all lanes derive at once -- is its list big, and which of the skipLimit + 1 k-mers
+    // before it have its code -- and the replay itself runs over those bits in scalar registers, 64 positions per pass of the
+    // first wavefront, instead of one lane walking the arrays in LDS.
+    const int D = skipLimit + 1;
+    for (int q = lane; q < 2 * nk; q += NT) {
+      const int st = q >= nk, p = st ? q - nk : q;
+      const unsigned cnt = posPref[q] & ~SAME;
+      unsigned f = cnt >= 100u ? 1u : 0u;
+      bool vv;
+      const unsigned long long code = kmerPacked(wm, st != 0, p, segLen, K, vv) & mask;
+      for (int d = 1; d <= D && d <= p; ++d) if ((kmerPacked(wm, st != 0, p - d, segLen, K, vv) & mask) == code) f |= 1u << d;
+      flagBuf[q] = f;
+      posPref[q] = cnt;
+    }
+    __syncthreads();
+    if (lane < 64) {
+      for (int st = 0; st < 2; ++st) {
+        const bool active = st ? (strandArg != 1) : (strandArg != -1);
+        if (!active) continue;
+        int skipCnt = 0, dist = 1;
+        for (int c0 = 0; c0 < nk; c0 += 64) {
+          const int p = c0 + lane;
+          const unsigned F = p < nk ? flagBuf[st * nk + p] : 0u;
+          unsigned long long emitMask = 0;
+          const int lim = nk - c0 < 64 ? nk - c0 : 64;
+          for (int t = 0; t < lim; ++t) {
+            const unsigned f = T4_READLANE(F, t);
+            const int pp = c0 + t;
+            if (pp == 0) { skipCnt = 0; dist = 1; emitMask |= 1ull; continue; }
+            if (!((f >> dist) & 1u)) {   // differs from the previous k-mer that was not passed over
+              if ((f & 1u) && pp != nk - 1 && skipCnt < skipLimit) { ++skipCnt; ++dist; continue; }
+              skipCnt = 0;
+              emitMask |= 1ull << t;
+            }
+            dist = 1;
+          }
+          if (p < nk && !((emitMask >> lane) & 1ull)) posPref[st * nk + p] = 0;
+        }
+      }
+    }
+#endif
   } else {
     for (int q = lane; q < 2 * nk; q += NT) posPref[q] &= ~SAME;
     __syncthreads();
@@ -843,7 +896,7 @@ __device__ int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int
     }
   }
   __syncthreads();
-  PHASE_MARK_RED(red, 23);   // seed: prefix sums
+  if (phaseWs) PHASE_MARK(phaseWs, 23);   // seed: prefix sums
   // exclusive prefix sums over the 2*nk positions
   int carry = 0;
   for (int q0 = 0; q0 < 2 * nk; q0 += NT) {
@@ -2078,7 +2131,7 @@ __device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, 
   const int nk = segLen - ix.k + 1;
   if (lane == 0) ws->ovCount = 0;
   PHASE_MARK(ws, 1);
-  int H = seedPositions(ix, wm, segLen, strandArg, barcode, allowTotalSkip, posStart, posPref, ws->red);
+  int H = seedPositions(ix, wm, segLen, strandArg, barcode, allowTotalSkip, posStart, posPref, ws->red, (unsigned *)wm.keys, ws);   // the key array is free until the hits are expanded
   if (H > wm.hitLimit) return -1;
   PHASE_MARK(ws, 2);
 #if T4_OPT_KEY32
@@ -2745,8 +2798,14 @@ __device__ int tracebackPW(const unsigned char *dirbuf, int L, signed char *alig
 // Extend the n overlaps wm.fin[ord[0..n)] of the read in wm.seg / wm.rc (length len). Results in `res[i]`.
 // useFirstStrand: AssignRead aligns every overlap against the strand of overlaps[0] (SeqSet.hpp:4657-4659).
 // Scratch: sides = 2 * n ExtSide records, dirbuf = dirBytes >= T4_EXT_BYTES(len) bytes (LDS whenever the caller has any).
+// lean: the caller is the ordered contig builder (mode 4). SeqSet::AddRead reads nothing but readStart / readEnd of an overlap whose
+// ExtendOverlap returned 0 (SeqSet.hpp:3597-3700: such records only enter its `failedExtendedOverlaps` containment test), and an
+// alignment that leaves the diagonal has an indel, which alone makes ExtendOverlap return 0 (SeqSet.hpp:1203-1214). So for such a
+// side only the "good" prefix from the anchor outward is derived -- for a left overhang the traceback starts at the anchor and stops
+// at the first indel -- and the record of an overlap with a gapped side carries exact coordinates, return value 0, and the
+// overlap's own matchCnt / similarity in place of the counts nobody reads.
 __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int n, int len, bool useFirstStrand,
-                               double factor, ExtSide *sides, unsigned char *dirbuf, int dirBytes, ExtOut *res) {
+                               double factor, ExtSide *sides, unsigned char *dirbuf, int dirBytes, ExtOut *res, bool lean = false) {
   const int lane = tid(), NT = nthr();
   const int plus0 = n > 0 ? (wm.fin[wm.ord[0]].flags & OV_PLUS) : 1;
   // E1: ungapped evaluation of every (overlap, side), one side per wavefront at a time: 64 overhang positions per step
@@ -2827,6 +2886,31 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
     e.match = (short)m; e.mis = (short)mm; e.indel = (short)ind; e.good = (short)good; e.pending = 0;
     sides[q] = e;
   };
+  // lean form of traceback + finishSide for a side whose path leaves the diagonal: only `good` (and the fact that there is an indel)
+  auto leanSide = [&](int q, const unsigned char *buf, int L, signed char *align) {
+    const int side = q & 1;
+    int good = 0, tmp = 0;
+    if (side == 0) {   // the anchor is where the traceback starts: walk until the first indel
+      const int W = 11, leftBand = 5;
+      int tagi = L, tagj = L, k = 0;
+      while (tagi > 0 && tagj > 0) {
+        const unsigned char bits = buf[tagi * W + (tagj - tagi + leftBand)];
+        if (!(bits & 4)) break;            // insert or delete (AlignAlgo.hpp:172-190: the diagonal wins whenever it gives the score)
+        ++k;
+        if (bits & 8) { ++tmp; if (tmp > 0.75 * k) good = k; }
+        --tagi; --tagj;
+      }
+    } else {           // the anchor is where the traceback ends: the whole walk, then the prefix up to the first indel
+      const int alen = tracebackPW(buf, L, align);
+      for (int i = 0; i < alen; ++i) {
+        if (align[i] == 0) { ++tmp; if (tmp > 0.75 * (i + 1)) good = i + 1; }
+        else if (align[i] != 1) break;
+      }
+    }
+    ExtSide e = sides[q];
+    e.match = 0; e.mis = 0; e.indel = 1; e.good = (short)good; e.pending = 0;
+    sides[q] = e;
+  };
   PHASE_MARK(ws, 19);   // extend: four overhang DPs per wavefront + tracebacks
   {
     const int wave = lane >> 6, wl = lane & 63, row = wl >> 4;
@@ -2862,6 +2946,7 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
           const int q = (int)wm.cand[t];
           if (!offDiag) { ExtSide e = sides[q]; e.pending = 0; sides[q] = e; }
           else { ExtSide e = sides[q]; e.pending = 2; sides[q] = e; }
+          DBG_ADD(6, 1); DBG_ADD(7, offDiag);
         }
       }
       __syncthreads();
@@ -2871,8 +2956,11 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
           const int size = sides[q].size;
           unsigned char *buf = dirbuf + (size_t)lane * qslice;
           signed char *align = (signed char *)(buf + (size + 1) * 11);
-          const int alen = tracebackPW(buf, size, align);
-          finishSide(q, align, alen);
+          if (lean) leanSide(q, buf, size, align);
+          else {
+            const int alen = tracebackPW(buf, size, align);
+            finishSide(q, align, alen);
+          }
         }
       }
       __syncthreads();
@@ -2908,8 +2996,11 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
           if (!offDiag) { ExtSide e = sides[q]; e.pending = 0; sides[q] = e; }   // the ungapped alignment (see above)
           else {
             signed char *align = (signed char *)(buf + (size + 1) * 11);
-            const int alen = tracebackPW(buf, size, align);
-            finishSide(q, align, alen);
+            if (lean) leanSide(q, buf, size, align);
+            else {
+              const int alen = tracebackPW(buf, size, align);
+              finishSide(q, align, alen);
+            }
           }
         }
       }
@@ -2940,6 +3031,7 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
     double sim = (double)e.matchCnt / (double)e.den;
     bool isRef = (o.flags & OV_ISREF) != 0;
     if ((isRef && sim < ix.refSim) || (!isRef && sim < ix.novelSim)) { e.simFail = 1; e.matchCnt = o.matchCnt; ret = 0; }
+    if (lean && (L.indel > 0 || R.indel > 0)) { e.simFail = 1; e.matchCnt = o.matchCnt; ret = 0; }   // the counts of a gapped side were not derived
     if (ret == 0) { e.rs = o.rs - L.good; e.re = o.re + R.good; e.ss = o.ss - L.good; e.se = o.se + R.good; }
     e.ret = ret;
     res[i] = e;
@@ -3003,7 +3095,7 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
     }
     __syncthreads();
     PHASE_MARK(ws, 16);
-    extendOverlaps(ix, wm, ws, n, len, false, qa.factorPerRead[r], sides, dirbuf, wm.dirBytes, res);
+    extendOverlaps(ix, wm, ws, n, len, false, qa.factorPerRead[r], sides, dirbuf, wm.dirBytes, res, qa.leanExt != 0);
     PHASE_MARK(ws, 17);
     for (int i = lane; i < n; i += NT) {
       const OvRec &o = wm.fin[i];
@@ -3365,6 +3457,9 @@ __global__ __launch_bounds__(64) void extendKernel(T4IndexView ix, T4BatchView b
       if (r < 0) { i0 = i1; continue; }   // extended by the query kernel itself
       const int n = i1 - i0, len = bv.len[r];
       if (lane == 0) { s_ws.overflow = 0; s_ws.unsupported = 0; }
+#ifdef T4_PHASE_TIMING
+      if (lane == 0) { s_ws.phaseT0 = clock64(); s_ws.phaseBase = 0; s_ws.curPhase = 24; }   // phase 24: extension launch (the marks inside extendOverlaps take over)
+#endif
       loadSegment(bv, r, 0, len, wm);
       if (lane < n) {
         const T4OverlapOut t = qa.outDev[i0 + lane];
@@ -3375,7 +3470,7 @@ __global__ __launch_bounds__(64) void extendKernel(T4IndexView ix, T4BatchView b
         s_fin[lane] = o; s_ord[lane] = (unsigned short)lane;
       }
       __syncthreads();
-      extendOverlaps(ix, wm, &s_ws, n, len, false, qa.factorPerRead[r], s_sides, (unsigned char *)s_dir, (int)sizeof s_dir, s_res);
+      extendOverlaps(ix, wm, &s_ws, n, len, false, qa.factorPerRead[r], s_sides, (unsigned char *)s_dir, (int)sizeof s_dir, s_res, qa.leanExt != 0);
       if (lane < n) {
         const T4OverlapOut in = qa.outDev[i0 + lane];
         const ExtOut e = s_res[lane];

@@ -5,7 +5,11 @@
 #include <string.h>
 #include <zlib.h>
 
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 // ---- FASTA / FASTQ (optionally gzip) reader with kseq's record model ---------------------------------
@@ -68,3 +72,66 @@ struct SeqReader {
   }
 };
 
+
+// The same reader on a thread of its own: records arrive in blocks through a bounded queue, so the files of one run (mate 1, mate 2,
+// barcodes, UMIs) are read and split side by side while the driver's loop consumes them in lock-step. Same members as SeqReader
+// for the consumer (files / next() / id / seq / qual / hasQual / comment).
+struct ThreadedSeqReader {
+  std::vector<std::string> files;
+  bool stripMateSuffix = true;
+  std::string id, seq, qual, comment;
+  bool hasQual = false;
+  struct Rec { std::string id, seq, qual, comment; bool hasQual; };
+  typedef std::vector<Rec> Block;
+  enum { BLOCK = 16384, DEPTH = 4 };
+  bool next() {
+    if (!started) start();
+    if (at >= cur.size()) {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return !ready.empty() || done; });
+      if (ready.empty()) return false;
+      cur.swap(ready.front());
+      ready.pop_front();
+      at = 0;
+      lk.unlock();
+      cv.notify_all();
+      if (cur.empty()) return false;
+    }
+    Rec &r = cur[at++];
+    id.swap(r.id); seq.swap(r.seq); qual.swap(r.qual); comment.swap(r.comment); hasQual = r.hasQual;
+    return true;
+  }
+  ~ThreadedSeqReader() {
+    { std::lock_guard<std::mutex> lk(mu); quit = true; }
+    cv.notify_all();
+    if (th.joinable()) th.join();
+  }
+ private:
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<Block> ready;
+  Block cur;
+  size_t at = 0;
+  bool started = false, done = false, quit = false;
+  void start() {
+    started = true;
+    th = std::thread([this] {
+      SeqReader in;
+      in.files = files; in.stripMateSuffix = stripMateSuffix;
+      for (;;) {
+        Block b;
+        b.reserve(BLOCK);
+        while (b.size() < (size_t)BLOCK && in.next()) { b.emplace_back(); Rec &r = b.back(); r.id.swap(in.id); r.seq.swap(in.seq); r.qual.swap(in.qual); r.comment.swap(in.comment); r.hasQual = in.hasQual; }
+        const bool last = b.size() < (size_t)BLOCK;
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return ready.size() < (size_t)DEPTH || quit; });
+        if (quit) return;
+        if (!b.empty()) ready.push_back(std::move(b));
+        if (last) { done = true; lk.unlock(); cv.notify_all(); return; }
+        lk.unlock();
+        cv.notify_all();
+      }
+    });
+  }
+};

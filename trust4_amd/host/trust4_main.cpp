@@ -382,7 +382,7 @@ int main(int argc, char *argv[]) {
   std::string refFa, outputPrefix = "trust", kmerCountFile;
   struct NovelFa { std::string file; int kmerLength; };
   std::vector<NovelFa> novelFa;   // --debug-ns: contigs put into the set before any read (main.cpp:709-712)
-  SeqReader reads, mateReads, barcodeFile, umiFile;
+  ThreadedSeqReader reads, mateReads, barcodeFile, umiFile;   // each file is read and split on its own thread
   bool hasMate = false, hasBarcode = false, hasUmi = false;
   int c, oi = 0;
   while ((c = getopt_long(argc, argv, "f:u:1:2:o:c:t:k:", long_options, &oi)) != -1) {
