@@ -1699,7 +1699,8 @@ int t4_add_query_pool_begin(t4_index *ix, int n, const char *bases, const int64_
   t4_ctx *c = ix->ctx;
   if (!ix->committed) return fail(c, T4_ERR_STATE, "index not committed");
   if (ix->view.firstIsRef) return fail(c, T4_ERR_UNSUPPORTED, "t4_add_query needs a contig set");
-  return aqBegin(c, ix->view, nullptr, nullptr, false, n, bases, offsets, barcodes, strands, skip_repeats, factors, tier_hint, true);   // for t4_assembler: lean records (extendOverlaps)
+  static const bool leanOff = getenv("T4_LEAN_OFF") != nullptr;   // testing aid: exact ExtendOverlap records for the builder too
+  return aqBegin(c, ix->view, nullptr, nullptr, false, n, bases, offsets, barcodes, strands, skip_repeats, factors, tier_hint, !leanOff);   // for t4_assembler: lean records (extendOverlaps)
 }
 int t4_add_query_pool_done(t4_ctx *c) { return c ? aqDone(c) : 1; }
 int t4_add_query_pool_end(t4_ctx *c, const int32_t **counts, const int32_t **base, const t4_overlap **ov, const t4_overlap **ext, const int32_t **ext_ret) {

@@ -785,10 +785,10 @@ __device__ __forceinline__ unsigned long long kmerPacked(const WaveMem &wm, bool
 #else
 #define T4_READLANE(v, l) ((unsigned)__shfl((int)(v), (l)))
 #endif
-// flagBuf (nullable): 2 * nk words of scratch for the wave-wide replay of the repeat-skip rule (below); without it the rule is
-// replayed by one lane.
+// codeBuf (nullable): 2 * nk 64-bit words of scratch (the k-mer code of every position) for the wave-wide replay of the repeat-skip
+// rule (below); without it the rule is replayed by one lane.
 __device__ int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int strandArg, int barcode,
-                             bool allowTotalSkip, unsigned *posStart, unsigned *posPref, int *red, unsigned *flagBuf = nullptr, WaveState *phaseWs = nullptr) {
+                             bool allowTotalSkip, unsigned *posStart, unsigned *posPref, int *red, unsigned long long *codeBuf = nullptr, WaveState *phaseWs = nullptr) {
   const int K = ix.k, lane = tid(), NT = nthr();
   const int nk = segLen - K + 1;           // k-mers per strand
   const unsigned long long mask = K < 32 ? ((1ull << (2 * K)) - 1ull) : ~0ull;
@@ -809,6 +809,7 @@ __device__ int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int
     bool same = false;
     if (p > 0) same = (((code >> 2) | ((unsigned long long)nuc2(S[p - 1]) << (2 * (K - 1)))) == code);
     posStart[q] = start; posPref[q] = cnt | (same ? SAME : 0u);
+    if (codeBuf) codeBuf[q] = code;
     if (cnt >= 100) big = 1;
   }
   big = blockSum(big, red) != 0;
@@ -820,24 +821,15 @@ __device__ int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int
       posPref[q] = (v & SAME) ? 0u : v;
     }
 #ifndef T4_SEED_SERIAL
-  } else if (flagBuf && !allowTotalSkip && K <= 16) {
+  } else if (codeBuf && !allowTotalSkip) {
     // The skip rule of GetHitsFromRead (SeqSet.hpp:1381-1391) is a small transducer: a k-mer with 100+ postings is passed over
     // (without becoming the "previous k-mer") while fewer than skipLimit have been passed over since the last emitted one; every
     // other k-mer is compared with the previous one that was not passed over, which lies at most skipLimit + 1 positions back.
-    // So a position needs two facts that all lanes derive at once -- is its list big, and which of the skipLimit + 1 k-mers
-    // before it have its code -- and the replay itself runs over those bits in scalar registers, 64 positions per pass of the
-    // first wavefront, instead of one lane walking the arrays in LDS.
-    const int D = skipLimit + 1;
-    for (int q = lane; q < 2 * nk; q += NT) {
-      const int st = q >= nk, p = st ? q - nk : q;
-      const unsigned cnt = posPref[q] & ~SAME;
-      unsigned f = cnt >= 100u ? 1u : 0u;
-      bool vv;
-      const unsigned long long code = kmerPacked(wm, st != 0, p, segLen, K, vv) & mask;
-      for (int d = 1; d <= D && d <= p; ++d) if ((kmerPacked(wm, st != 0, p - d, segLen, K, vv) & mask) == code) f |= 1u << d;
-      flagBuf[q] = f;
-      posPref[q] = cnt;
-    }
+    // So a position needs two facts that a lane derives for it from the codes of its neighbours -- is its list big, and which of
+    // the skipLimit + 1 k-mers before it have its code -- and the replay itself runs over those bits in scalar registers, 64
+    // positions per pass of the first wavefront, instead of one lane walking the arrays in LDS.
+    const int D = skipLimit + 1;   // <= 16: k <= 31
+    for (int q = lane; q < 2 * nk; q += NT) posPref[q] &= ~SAME;
     __syncthreads();
     if (lane < 64) {
       for (int st = 0; st < 2; ++st) {
@@ -846,7 +838,13 @@ __device__ int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int
         int skipCnt = 0, dist = 1;
         for (int c0 = 0; c0 < nk; c0 += 64) {
           const int p = c0 + lane;
-          const unsigned F = p < nk ? flagBuf[st * nk + p] : 0u;
+          unsigned F = 0u;
+          if (p < nk) {
+            const int q = st * nk + p;
+            if (posPref[q] >= 100u) F = 1u;
+            const unsigned long long code = codeBuf[q];
+            for (int d = 1; d <= D && d <= p; ++d) if (codeBuf[q - d] == code) F |= 1u << d;
+          }
           unsigned long long emitMask = 0;
           const int lim = nk - c0 < 64 ? nk - c0 : 64;
           for (int t = 0; t < lim; ++t) {
@@ -2131,7 +2129,7 @@ __device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, 
   const int nk = segLen - ix.k + 1;
   if (lane == 0) ws->ovCount = 0;
   PHASE_MARK(ws, 1);
-  int H = seedPositions(ix, wm, segLen, strandArg, barcode, allowTotalSkip, posStart, posPref, ws->red, (unsigned *)wm.keys, ws);   // the key array is free until the hits are expanded
+  int H = seedPositions(ix, wm, segLen, strandArg, barcode, allowTotalSkip, posStart, posPref, ws->red, wm.keys, ws);   // the key array is free until the hits are expanded
   if (H > wm.hitLimit) return -1;
   PHASE_MARK(ws, 2);
 #if T4_OPT_KEY32
@@ -2708,18 +2706,41 @@ struct ExtOut { int ret, rs, re, ss, se, matchCnt, simFail, den; };   // similar
 // memory that load's latency (not its bandwidth) was the whole cost of a step.
 #define T4_EXT_BYTES(L) (((L) + 1) * 11 + 3 * (L) + 8)
 #define T4_EXT_WST(buf, L) ((buf) + ((L) + 1) * 11 + 2 * (L) + 8)
-// banded posWeight DP of an L x L problem (W = 11) by one wavefront; dir bytes -> dirbuf[i * 11 + d]
-__device__ void dpWaveTracePW(const T4PW *w, int L, const char *p, unsigned char *dirbuf) {
+// What ExtendOverlap wants to know about the traceback path from the origin to a cell, carried along with the score so that no
+// walk is needed for it: has the path met an indel yet, and if not, over its k steps so far, the number of matches `tmp` and the
+// "good" length (the largest k' with more than 3/4 matches among the first k' steps, at a match; SeqSet.hpp:1224-1235). A cell
+// inherits the state of the predecessor the traceback would take from it (diagonal before insert before delete,
+// AlignAlgo.hpp:172-190). Packed: good | tmp << 9 | k << 18 | indel << 27.
+#define PS_INDEL (1u << 27)
+__device__ __forceinline__ unsigned pathStepDiag(unsigned s, bool eq) {
+  if (s & PS_INDEL) return s;
+  unsigned good = s & 511u, tmp = (s >> 9) & 511u, k = ((s >> 18) & 511u) + 1u;
+  if (eq) { ++tmp; if (4u * tmp > 3u * k) good = k; }
+  return good | tmp << 9 | k << 18;
+}
+// Path state of a border cell (i0, 0) or (0, j0), n = i0 + j0 >= 1. The reference's traceback walks a border by indels -- except
+// for its last step: at (1, 0) and (0, 1) the border recurrence does not reproduce m[0][0] = 0, so the step is recorded as a MATCH
+// that consumes both sequences (AlignAlgo.hpp:191-203; the walk then ends below zero). An alignment through a border cell thus
+// starts with one match; further out on the border, indels follow it.
+__device__ __forceinline__ unsigned pathBorder(int n) {
+  const unsigned one = 1u | 1u << 9 | 1u << 18;   // k = 1, tmp = 1, good = 1
+  return n == 1 ? one : (one | PS_INDEL);
+}
+// banded posWeight DP of an L x L problem (W = 11) by one wavefront; dir bytes -> dirbuf[i * 11 + d]; returns (to every lane) the
+// path state of the end cell (L, L)
+__device__ unsigned dpWaveTracePW(const T4PW *w, int L, const char *p, unsigned char *dirbuf) {
   const int d = laneId(), W = 11, leftBand = 5;
   unsigned char *wst = T4_EXT_WST(dirbuf, L);
   for (int t = d; t < L; t += 64) wst[t] = w[t];
   waveLdsSync();
   const int negInf = (L + 1) * (L + 1) * (-4);
   int M = negInf;
+  unsigned S = PS_INDEL, fin = PS_INDEL;
   { int j0 = d - leftBand; if (d < W && j0 >= 0 && j0 <= L) M = j0 == 0 ? 0 : -4 - 4 * j0; }
   const int lastStep = 2 * L + W - 1;
   for (int s = 2; s <= lastStep; ++s) {
     int lM = waveUp1(M), uM = waveDown1(M);
+    const unsigned lS = waveUp1(S), uS = waveDown1(S);
     const int i2 = s - d, i = i2 >> 1, j = i - leftBand + d;
     if (d < W && (i2 & 1) == 0 && i >= 1 && i <= L && j >= 1 && j <= L) {
       if (j == 1) lM = -4 - 4 * i; else if (d == 0) lM = negInf;
@@ -2734,24 +2755,32 @@ __device__ void dpWaveTracePW(const T4PW *w, int L, const char *p, unsigned char
       if (lM - 4 > m) m = lM - 4;
       if (uM - 4 > m) m = uM - 4;
       dirbuf[i * W + d] = (unsigned char)((lM - 4 == m ? 1 : 0) | (uM - 4 == m ? 2 : 0) | (dsc == m ? 4 : 0) | (eq ? 8 : 0));
+      // the predecessor's path state
+      if (dsc == m) S = pathStepDiag((i == 1 && j == 1) ? 0u : ((i == 1 || j == 1) ? pathBorder(i + j - 2) : S), eq);
+      else if (uM - 4 == m) S = (i == 1 ? pathBorder(j) : uS) | PS_INDEL;
+      else S = (j == 1 ? pathBorder(i) : lS) | PS_INDEL;
+      if (i == L && j == L) fin = S;
       M = m;
     }
   }
+  return (unsigned)__shfl((int)fin, leftBand);   // the end cell (L, L) is lane leftBand's
 }
 // The same DP for FOUR problems per wavefront, one per 16-lane DPP row (the band is 11 columns wide, so a whole wavefront per
 // problem left 53 lanes idle): every row has its own (w, L, p, dirbuf); Lmax = the longest L of the wavefront's rows
 // (wave-uniform trip count; a row with L == 0 computes nothing).
-__device__ void dpRowTracePW(const T4PW *w, int L, const char *p, unsigned char *dirbuf, int Lmax) {
+__device__ unsigned dpRowTracePW(const T4PW *w, int L, const char *p, unsigned char *dirbuf, int Lmax) {
   const int d = laneId() & 15, W = 11, leftBand = 5;
   unsigned char *wst = T4_EXT_WST(dirbuf, L);
   for (int t = d; t < L; t += 16) wst[t] = w[t];
   waveLdsSync();
   const int negInf = (L + 1) * (L + 1) * (-4);
   int M = negInf;
+  unsigned S = PS_INDEL, fin = PS_INDEL;
   { int j0 = d - leftBand; if (d < W && j0 >= 0 && j0 <= L) M = j0 == 0 ? 0 : -4 - 4 * j0; }
   const int lastStep = 2 * Lmax + W - 1;
   for (int s = 2; s <= lastStep; ++s) {
     int lM = rowUp1(M), uM = rowDown1(M);
+    const unsigned lS = rowUp1(S), uS = rowDown1(S);
     const int i2 = s - d, i = i2 >> 1, j = i - leftBand + d;
     if (d < W && (i2 & 1) == 0 && i >= 1 && i <= L && j >= 1 && j <= L) {
       if (j == 1) lM = -4 - 4 * i; else if (d == 0) lM = negInf;
@@ -2766,9 +2795,65 @@ __device__ void dpRowTracePW(const T4PW *w, int L, const char *p, unsigned char 
       if (lM - 4 > m) m = lM - 4;
       if (uM - 4 > m) m = uM - 4;
       dirbuf[i * W + d] = (unsigned char)((lM - 4 == m ? 1 : 0) | (uM - 4 == m ? 2 : 0) | (dsc == m ? 4 : 0) | (eq ? 8 : 0));
+      if (dsc == m) S = pathStepDiag((i == 1 && j == 1) ? 0u : ((i == 1 || j == 1) ? pathBorder(i + j - 2) : S), eq);   // see dpWaveTracePW
+      else if (uM - 4 == m) S = (i == 1 ? pathBorder(j) : uS) | PS_INDEL;
+      else S = (j == 1 ? pathBorder(i) : lS) | PS_INDEL;
+      if (i == L && j == L) fin = S;
       M = m;
     }
   }
+  return (unsigned)__shfl((int)fin, (laneId() & ~15) + leftBand);   // the end cell (L, L) is the row's lane leftBand
+}
+// The lean form for the ordered contig builder (extendOverlaps, lean): EIGHT problems per wavefront and nothing written but scores.
+// An anti-diagonal sweep keeps a lane busy every other step only (lane d owns cell i = (s - d) / 2 when s - d is even), so a
+// second problem of the same 16-lane row takes the odd steps: lane d computes for problem par = (s - d) & 1, and its three
+// neighbours' values of the step before (and its own of two steps before) belong to the same problem by parity. What ExtendOverlap
+// needs comes out of the sweep itself: the path state of the end cell (pathStepDiag) and, for a left overhang -- anchored at the
+// END of the alignment -- the number of diagonal steps the traceback takes from (L, L) before its first indel, i.e. the run of
+// main-diagonal cells ending at (L, L) whose score comes from the diagonal. wstA / wstB: the target stretches staged in LDS.
+// Returns, to the row's lanes, state | run << 32 of problem A in outA and of problem B in outB.
+__device__ void dpRowPairLean(const unsigned char *wstA, int LA, const char *pA, const unsigned char *wstB, int LB, const char *pB,
+                              int Lmax, unsigned long long &outA, unsigned long long &outB) {
+  const int d = laneId() & 15, W = 11, leftBand = 5;
+  int M1 = 0, M2 = 0;
+  unsigned S1 = PS_INDEL, S2 = PS_INDEL;
+  int R1 = 0, R2 = 0;
+  unsigned long long finA = PS_INDEL, finB = PS_INDEL;
+  const int lastStep = 2 * Lmax + W;
+  for (int s = 2; s <= lastStep; ++s) {
+    int lM = rowUp1(M1), uM = rowDown1(M1);
+    const unsigned lS = rowUp1(S1), uS = rowDown1(S1);
+    const int par = (s - d) & 1;
+    const int i = (s - d - par) >> 1, j = i - leftBand + d;
+    const int L = par ? LB : LA;
+    int m = M1;
+    unsigned S = S1;
+    int R = 0;
+    if (d < W && i >= 1 && i <= L && j >= 1 && j <= L) {
+      const unsigned char *wst = par ? wstB : wstA;
+      const char *p = par ? pB : pA;
+      const int negInf = (L + 1) * (L + 1) * (-4);
+      if (j == 1) lM = -4 - 4 * i; else if (d == 0) lM = negInf;
+      if (i == 1) uM = -4 - 4 * j; else if (d + 1 >= W) uM = negInf;
+      int dM;
+      if (i == 1) dM = (j - 1 == 0) ? 0 : -4 - 4 * (j - 1);
+      else if (j == 1) dM = -4 - 4 * (i - 1);
+      else dM = M2;
+      const bool eq = baseEqualW(wst[j - 1], p[i - 1]);
+      const int dsc = dM + (eq ? 2 : -2);
+      m = dsc;
+      if (lM - 4 > m) m = lM - 4;
+      if (uM - 4 > m) m = uM - 4;
+      if (dsc == m) { S = pathStepDiag((i == 1 && j == 1) ? 0u : ((i == 1 || j == 1) ? pathBorder(i + j - 2) : S2), eq); R = (i == 1 ? 0 : R2) + 1; }
+      else if (uM - 4 == m) S = (i == 1 ? pathBorder(j) : uS) | PS_INDEL;
+      else S = (j == 1 ? pathBorder(i) : lS) | PS_INDEL;
+      if (i == L && j == L) { const unsigned long long f = (unsigned long long)S | ((unsigned long long)(unsigned)R << 32); if (par) finB = f; else finA = f; }
+    }
+    M2 = M1; M1 = m; S2 = S1; S1 = S; R2 = R1; R1 = R;
+  }
+  const int src = (laneId() & ~15) + leftBand;   // the end cells (L, L) are the row's lane leftBand's
+  outA = ((unsigned long long)(unsigned)__shfl((int)(finA >> 32), src) << 32) | (unsigned)__shfl((int)(unsigned)finA, src);
+  outB = ((unsigned long long)(unsigned)__shfl((int)(finB >> 32), src) << 32) | (unsigned)__shfl((int)(unsigned)finB, src);
 }
 // traceback of the above (AlignAlgo.hpp:160-205); align[] receives the edit string, returns its length. One lane.
 __device__ int tracebackPW(const unsigned char *dirbuf, int L, signed char *align) {
@@ -2846,6 +2931,84 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
   }
   __syncthreads();
   PHASE_MARK(ws, 18);   // extend: list of the gapped sides
+  if (lean) {
+    // E2, lean form: every pending side goes through dpRowPairLean, eight per wavefront; the only scratch is the staged target bytes
+    int nPend = 0, maxL = 0;
+    for (int q0 = 0; q0 < 2 * n; q0 += NT) {
+      const int q = q0 + lane;
+      const bool pend = q < 2 * n && sides[q].pending;
+      int tot;
+      const int inc = blockInclScan(pend ? 1 : 0, ws->red, tot);
+      if (pend) wm.cand[nPend + inc - 1] = (unsigned)q;
+      nPend += tot;
+      int mx;
+      blockInclMaxScan(pend ? (int)sides[q].size : 0, ws->red, mx);
+      if (mx > maxL) maxL = mx;
+    }
+    __syncthreads();
+    PHASE_MARK(ws, 19);
+    const int nw = NT >> 6, slice = (maxL + 15) & ~15;
+    int perChunk = nw * 8;
+    if (slice > 0 && perChunk * slice > dirBytes) perChunk = (dirBytes / slice) & ~7;
+    if (nPend > 0 && perChunk < 8) { if (lane == 0) ws->unsupported = 1; nPend = 0; }
+    const int wave = lane >> 6, wl = lane & 63, row = wl >> 4, l16 = wl & 15;
+    for (int c0 = 0; c0 < nPend; c0 += perChunk) {
+      // this row's two problems
+      int Lq[2] = {0, 0}, qq[2] = {-1, -1};
+      const unsigned char *wst[2] = {dirbuf, dirbuf};
+      const char *pr[2] = {wm.seg, wm.seg};
+      for (int z = 0; z < 2; ++z) {
+        const int slot = wave * 8 + row * 2 + z, t = c0 + slot;
+        if (slot < perChunk && t < nPend) {
+          const int q = (int)wm.cand[t];
+          const OvRec &o = wm.fin[wm.ord[q >> 1]];
+          const int side = q & 1, L = sides[q].size;
+          const T4SeqInfo si = ix.seqs[o.seqIdx];
+          const char *r = (useFirstStrand ? plus0 : (o.flags & OV_PLUS)) ? wm.seg : wm.rc;
+          const T4PW *w = ix.pw + si.pwOff + (side == 0 ? o.ss - L : o.se + 1);
+          unsigned char *dst = dirbuf + (size_t)slot * slice;
+          for (int x = l16; x < L; x += 16) dst[x] = w[x];
+          Lq[z] = L; qq[z] = q; wst[z] = dst; pr[z] = r + (side == 0 ? o.rs - L : o.re + 1);
+        }
+      }
+      waveLdsSync();
+      int Lmax = Lq[0] > Lq[1] ? Lq[0] : Lq[1];
+      { int x = __shfl_xor(Lmax, 16); if (x > Lmax) Lmax = x; x = __shfl_xor(Lmax, 32); if (x > Lmax) Lmax = x; }
+      unsigned long long out[2];
+      dpRowPairLean(wst[0], Lq[0], pr[0], wst[1], Lq[1], pr[1], Lmax, out[0], out[1]);
+      for (int z = 0; z < 2; ++z) {   // (wave-uniform control flow: the ballots below are taken by whole wavefronts)
+        const bool have = qq[z] >= 0;
+        const unsigned pst = (unsigned)out[z];
+        const int q = have ? qq[z] : 0, side = q & 1, L = Lq[z];
+        const bool gapped = have && (pst & PS_INDEL) != 0;
+        DBG_ADD(6, (have && l16 == 0) ? 1 : 0); DBG_ADD(7, (gapped && l16 == 0) ? 1 : 0);
+        // left overhang: its last `run` steps are the main-diagonal cells next to the anchor; "good" is the ungapped scan of E1 cut
+        // off there (steps k = 1 .. run from the anchor outward, position L - k of the overhang)
+        const int run = (gapped && side == 0) ? (int)(out[z] >> 32) : 0;
+        int runMax = run;
+        { int x = __shfl_xor(runMax, 16); if (x > runMax) runMax = x; x = __shfl_xor(runMax, 32); if (x > runMax) runMax = x; }
+        int good = 0, tmpBase = 0;
+        for (int base = 0; base < runMax; base += 16) {
+          const int k = base + l16;
+          const bool eq = k < run && baseEqualW(wst[z][L - 1 - k], pr[z][L - 1 - k]);
+          const unsigned bal = (unsigned)((__ballot(eq) >> (wl & 48)) & 0xFFFFull);
+          const int tmp = tmpBase + __popc(bal & ((2u << l16) - 1u));
+          const unsigned gb = (unsigned)((__ballot(eq && 4 * tmp > 3 * (k + 1)) >> (wl & 48)) & 0xFFFFull);
+          if (gb) good = base + 32 - __clz(gb);
+          tmpBase += __popc(bal);
+        }
+        if (gapped && side == 1) good = (int)(pst & 511u);
+        if (have && l16 == 0) {
+          ExtSide e = sides[q];
+          if (gapped) { e.match = 0; e.mis = 0; e.indel = 1; e.good = (short)good; }   // else: the ungapped alignment, the counts of E1 stand
+          e.pending = 0;
+          sides[q] = e;
+        }
+      }
+      __syncthreads();
+    }
+    PHASE_MARK(ws, 21);
+  } else {
   // E2: gapped sides, compacted into a list (wm.cand is dead here): first those whose direction bytes fit a quarter of a
   // wavefront's share of the buffer -- four per wavefront (one per 16-lane row), their tracebacks one lane per side -- then the
   // longer ones, one wavefront per side with its own slice; a side that fits no slice waits for the serial pass that owns the
@@ -2931,23 +3094,19 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
       }
       int Lmax = L;
       { int x = __shfl_xor(Lmax, 16); if (x > Lmax) Lmax = x; x = __shfl_xor(Lmax, 32); if (x > Lmax) Lmax = x; }
-      dpRowTracePW(w, L, pr, dirbuf + (size_t)(wave * 4 + row) * qslice, Lmax);
-      waveLdsSync();
-      // The traceback (AlignAlgo.hpp:160-205) starts at (L, L) and takes the diagonal whenever the diagonal predecessor gives the
-      // cell's score. If that holds in every cell of the main diagonal the alignment IS the ungapped one, whose counts and "good"
-      // prefix the ungapped evaluation already left in sides[q]: sixteen lanes look at the L diagonal cells at once, and only a
-      // side whose path leaves the diagonal is walked by one lane.
-      {
-        const unsigned char *buf = dirbuf + (size_t)(wave * 4 + row) * qslice;
-        int offDiag = 0;
-        for (int i = 1 + (wl & 15); i <= L; i += 16) if (!(buf[i * 11 + 5] & 4)) offDiag = 1;
-        offDiag |= __shfl_xor(offDiag, 1); offDiag |= __shfl_xor(offDiag, 2); offDiag |= __shfl_xor(offDiag, 4); offDiag |= __shfl_xor(offDiag, 8);
-        if ((wl & 15) == 0 && t < nFit) {
-          const int q = (int)wm.cand[t];
-          if (!offDiag) { ExtSide e = sides[q]; e.pending = 0; sides[q] = e; }
-          else { ExtSide e = sides[q]; e.pending = 2; sides[q] = e; }
-          DBG_ADD(6, 1); DBG_ADD(7, offDiag);
-        }
+      const unsigned pst = dpRowTracePW(w, L, pr, dirbuf + (size_t)(wave * 4 + row) * qslice, Lmax);
+      // The path state of the end cell says whether the traceback (AlignAlgo.hpp:160-205) meets an indel. If not, the alignment IS
+      // the ungapped one, whose counts and "good" prefix the ungapped evaluation already left in sides[q]. If it does and the
+      // caller is the ordered builder (lean), a right overhang -- anchored where the path starts -- has its "good" length in the
+      // state as well; a left overhang is walked from the anchor to its first indel, any other case is walked whole, by one lane.
+      if ((wl & 15) == 0 && t < nFit) {
+        const int q = (int)wm.cand[t];
+        ExtSide e = sides[q];
+        if (!(pst & PS_INDEL)) e.pending = 0;
+        else if (lean && (q & 1)) { e.match = 0; e.mis = 0; e.indel = 1; e.good = (short)(pst & 511u); e.pending = 0; }
+        else e.pending = 2;
+        sides[q] = e;
+        DBG_ADD(6, 1); DBG_ADD(7, (pst & PS_INDEL) ? 1 : 0);
       }
       __syncthreads();
       if (lane < perChunk && c0 + lane < nFit) {
@@ -2987,13 +3146,11 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
         const T4SeqInfo si = ix.seqs[o.seqIdx];
         const char *r = (useFirstStrand ? plus0 : (o.flags & OV_PLUS)) ? wm.seg : wm.rc;
         const int t0 = side == 0 ? o.ss - size : o.se + 1, p0 = side == 0 ? o.rs - size : o.re + 1;
-        dpWaveTracePW(ix.pw + si.pwOff + t0, size, r + p0, buf);
+        const unsigned pst = dpWaveTracePW(ix.pw + si.pwOff + t0, size, r + p0, buf);
         waveLdsSync();
-        int offDiag = 0;
-        for (int i = 1 + wl; i <= size; i += 64) if (!(buf[i * 11 + 5] & 4)) offDiag = 1;
-        offDiag = __ballot(offDiag != 0) != 0ull;
         if (wl == 0) {
-          if (!offDiag) { ExtSide e = sides[q]; e.pending = 0; sides[q] = e; }   // the ungapped alignment (see above)
+          if (!(pst & PS_INDEL)) { ExtSide e = sides[q]; e.pending = 0; sides[q] = e; }   // the ungapped alignment (see above)
+          else if (lean && side == 1) { ExtSide e = sides[q]; e.match = 0; e.mis = 0; e.indel = 1; e.good = (short)(pst & 511u); e.pending = 0; sides[q] = e; }
           else {
             signed char *align = (signed char *)(buf + (size + 1) * 11);
             if (lean) leanSide(q, buf, size, align);
@@ -3007,6 +3164,7 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
       __syncthreads();
     }
   }
+  }   // !lean
   __syncthreads();
   PHASE_MARK(ws, 21);   // extend: combine
   // E3: combine (SeqSet.hpp:1179-1266)
