@@ -211,6 +211,43 @@ def config_leg(name, threads, device, mode="skipMateExtension"):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def pmc_traffic(fa, f1, f2, threads, device, tmp, kernels=("queryKernel", "extendKernel")):
+    """HBM-side bytes of the dominant kernels of ONE step, from rocprofv3's TCC counters: the step's own command run twice more
+    under `rocprofv3 --pmc <C> --kernel-trace` (FETCH_SIZE and WRITE_SIZE in separate passes, as the counter slots demand),
+    the counter summed over every launch of the query kernels. Correction of MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts
+    128-byte requests at 64 bytes on gfx950, so it is doubled; WRITE_SIZE is taken as is (uncalibrated for this access pattern).
+    Counter units are KB. Infinity-Cache hits are counted too: this is L2 <-> fabric traffic, an upper bound of DRAM traffic."""
+    import csv
+    import glob
+    import re
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, {"error": "rocprofv3 not found"}
+    raw = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = os.path.join(tmp, "pmc_" + counter)
+        cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+               DRIVER, "-t", str(threads), "--skipMateExtension", "-f", fa, "-1", f1, "-2", f2, "-o", os.path.join(tmp, "pmcrun")]
+        p = subprocess.run(cmd, env=dict(os.environ, T4_DEVICE=str(device), TMPDIR="/tmp"), cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if p.returncode or not files:
+            return None, {"error": "rocprofv3 --pmc %s failed (%d): %s" % (counter, p.returncode, p.stderr.strip().split("\n")[-1][:200])}
+        tot, launches = 0.0, 0
+        with open(files[0]) as f:
+            for row in csv.DictReader(f):
+                if row.get("Counter_Name") != counter:
+                    continue
+                name = re.sub(r"\(.*", "", row["Kernel_Name"])
+                if any(k in name for k in kernels):
+                    tot += float(row["Counter_Value"])
+                    launches += 1
+        raw[counter] = {"counter_units_KB": tot, "launches": launches}
+        shutil.rmtree(d, ignore_errors=True)
+    traffic = (2.0 * raw["FETCH_SIZE"]["counter_units_KB"] + raw["WRITE_SIZE"]["counter_units_KB"]) * 1024.0
+    return traffic, {"raw": raw, "fetch_bytes_corrected": 2.0 * raw["FETCH_SIZE"]["counter_units_KB"] * 1024.0, "write_bytes": raw["WRITE_SIZE"]["counter_units_KB"] * 1024.0,
+                     "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace (separate passes) on the step's command; FETCH_SIZE x 2 (gfx950), units KB; queryKernel + extendKernel launches of one step"}
+
+
 def stage1_cells(pairs, cells):
     """Whole stage 1 in barcode mode through trust4-hip vs oracle/_ref/trust4 (when it travelled) on the same files."""
     tmp = tempfile.mkdtemp()
@@ -293,6 +330,7 @@ def main():
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 = skip the reference legs")
     ap.add_argument("--cpu-single-pairs", type=int, default=20000, help="prefix timed with the reference's -t 1 (0 = skip)")
     ap.add_argument("--side-legs", type=int, default=1, help="0 = skip passes.rough_annotation_c2 / stage1_cells / stage0_e2e")
+    ap.add_argument("--traffic", type=int, default=1, help="0 = skip the two rocprofv3 PMC passes that measure roofline.traffic")
     ap.add_argument("--c2", type=int, default=1, help="0 = skip the `c2` leg (one whole stage 1 on config C2 itself, 1 M pairs, compared with the reference's digests)")
     ap.add_argument("--config-leg", default="", help="additional config legs, comma separated (c3p2, c3p5: prefixes of C3)")
     args = ap.parse_args()
@@ -365,7 +403,7 @@ def main():
                                         "rough_annotation": ph["rough_annotation"] - ph["sorted"], "trim": ph["trimmed_ready"] - ph["rough_annotation"],
                                         "addread_pass": ph["assembled"] - ph["trimmed_ready"], "outputs": ph["outputs_written"] - ph["assembled"]}},
                 "roofline": {"bound": "hbm", "achieved": ach_add, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_add / HBM_PEAK_GBS, "traffic": None,
-                             "kernel": "t4k::queryKernel<.., 1> mode 4 (AddRead query: seed->sort->chain->score->ExtendOverlap), all %d query rounds of one step" % aq["rounds"],
+                             "kernel": "t4k::queryKernel<.., 1> mode 4 (AddRead query: seed->sort->chain->score->ExtendOverlap) + t4k::extendKernel behind it (kernel_ms brackets both), all %d query launches of one step" % aq["rounds"],
                              "kernel_ms": aq["kernel_ms"], "launch_ms_avg": aq["kernel_ms"] / max(1, aq["rounds"]),
                              "algorithmic_bytes_per_step": alg_add, "reads_queried": aq["reads_queried"], "reads_served": aq["reads_served"],
                              "hits": aq["hits"], "note": "a latency-bound chain of small launches (DESIGN 5b): bytes / kernel time says how little of the HBM rate a dependent round can use"},
@@ -373,6 +411,19 @@ def main():
                            "rough_annotation_in_step": {"reads": ra["reads"], "hits": ra["hits"], "kernel_ms": ra["kernel_ms"],
                                                         "achieved_GBs": alg_ann / (max(ra["kernel_ms"], 1e-6) * 1e-3) / 1e9}},
             }
+            # what the reference's own query count would move: SURVEY 8(d) defines H over the reads the reference queries once each
+            out["roofline"]["algorithmic_bytes_per_step_reads_served_only"] = add_bytes(aq["reads_served"], 150, int(aq["hits"] * aq["reads_served"] / max(1, aq["reads_queried"])))
+            out["roofline"]["frac_reads_served_only"] = out["roofline"]["algorithmic_bytes_per_step_reads_served_only"] / (aq["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            out["roofline"]["note"] += "; `achieved` counts every query the engine ran (re-queries of invalidated window entries included), `frac_reads_served_only` scales the bytes to one query per served read as the reference does"
+            if args.traffic and world == 1:
+                try:
+                    tr, detail = pmc_traffic(fa, f1, f2, threads, local_rank, tmp)
+                except Exception as e:   # noqa: BLE001
+                    tr, detail = None, {"error": repr(e)[:300]}
+                out["roofline"]["traffic"] = tr
+                out["roofline"]["traffic_detail"] = detail
+                if tr:
+                    out["roofline"]["traffic_over_algorithmic"] = tr / alg_add
             if args.cpu_baseline and world == 1 and os.path.exists(REF_BIN):
                 out["cpu_baseline"], out["parity_on_bench_batch"] = cpu_baseline(tmp, fa, f1, f2, args.pairs, mine, args.cpu_single_pairs)
             if args.side_legs and world == 1:

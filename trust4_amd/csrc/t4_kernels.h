@@ -40,6 +40,13 @@ namespace t4k {
 #ifndef T4_NI_R3
 #define T4_NI_R3 0
 #endif
+#ifdef __HIPCC__
+#define T4_LDS_AS __attribute__((address_space(3)))
+#else
+#define T4_LDS_AS   /* the emulator build has one address space */
+#endif
+// (a pointer known to address LDS, cast so: ds_read / ds_write instead of flat instructions, which are slower and tie the LDS counter to
+// the vector-memory one)
 __device__ __forceinline__ int laneId() { return threadIdx.x & 63; }
 __device__ __forceinline__ int tid() { return threadIdx.x; }
 __device__ __forceinline__ int nthr() { return blockDim.x; }
@@ -781,9 +788,9 @@ __device__ __forceinline__ unsigned long long kmerPacked(const WaveMem &wm, bool
 // of hit records H that GetHitsFromRead would emit (before the barcode filter). Wave-uniform result.
 // vjOnly only changes the later expansion.
 #ifdef __HIPCC__
-#define T4_READLANE(v, l) ((unsigned)__builtin_amdgcn_readlane((int)(v), (l)))
+#define T4_UNIFORM(v) (__builtin_amdgcn_readfirstlane((int)(v)))   // a value every lane holds alike, declared so
 #else
-#define T4_READLANE(v, l) ((unsigned)__shfl((int)(v), (l)))
+#define T4_UNIFORM(v) ((int)(v))
 #endif
 // codeBuf (nullable): 2 * nk 64-bit words of scratch (the k-mer code of every position) for the wave-wide replay of the repeat-skip
 // rule (below); without it the rule is replayed by one lane.
@@ -832,33 +839,37 @@ __device__ int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int
     for (int q = lane; q < 2 * nk; q += NT) posPref[q] &= ~SAME;
     __syncthreads();
     if (lane < 64) {
+      // everything the replay branches on is made wave-uniform for the compiler (readfirstlane / ballot), so that the loop over the
+      // positions of a chunk is scalar code: bit tests on 64-bit masks, counters in SGPRs
+      const int nkU = T4_UNIFORM(nk), skipLimitU = T4_UNIFORM(skipLimit), strandU = T4_UNIFORM(strandArg);
       for (int st = 0; st < 2; ++st) {
-        const bool active = st ? (strandArg != 1) : (strandArg != -1);
+        const bool active = st ? (strandU != 1) : (strandU != -1);
         if (!active) continue;
         int skipCnt = 0, dist = 1;
-        for (int c0 = 0; c0 < nk; c0 += 64) {
+        for (int c0 = 0; c0 < nkU; c0 += 64) {
           const int p = c0 + lane;
           unsigned F = 0u;
-          if (p < nk) {
-            const int q = st * nk + p;
+          if (p < nkU) {
+            const int q = st * nkU + p;
             if (posPref[q] >= 100u) F = 1u;
             const unsigned long long code = codeBuf[q];
             for (int d = 1; d <= D && d <= p; ++d) if (codeBuf[q - d] == code) F |= 1u << d;
           }
+          const unsigned long long bigM = __ballot((F & 1u) != 0), eq1 = __ballot((F & 2u) != 0);
+          unsigned long long curEq = dist == 1 ? eq1 : __ballot(((F >> dist) & 1u) != 0);   // equality with the k-mer `dist` positions back
           unsigned long long emitMask = 0;
-          const int lim = nk - c0 < 64 ? nk - c0 : 64;
+          const int lim = nkU - c0 < 64 ? nkU - c0 : 64;
           for (int t = 0; t < lim; ++t) {
-            const unsigned f = T4_READLANE(F, t);
             const int pp = c0 + t;
-            if (pp == 0) { skipCnt = 0; dist = 1; emitMask |= 1ull; continue; }
-            if (!((f >> dist) & 1u)) {   // differs from the previous k-mer that was not passed over
-              if ((f & 1u) && pp != nk - 1 && skipCnt < skipLimit) { ++skipCnt; ++dist; continue; }
+            if (pp == 0) { skipCnt = 0; emitMask |= 1ull; if (dist != 1) { dist = 1; curEq = eq1; } continue; }
+            if (!((curEq >> t) & 1ull)) {   // differs from the previous k-mer that was not passed over
+              if (((bigM >> t) & 1ull) && pp != nkU - 1 && skipCnt < skipLimitU) { ++skipCnt; ++dist; curEq = __ballot(((F >> dist) & 1u) != 0); continue; }
               skipCnt = 0;
               emitMask |= 1ull << t;
             }
-            dist = 1;
+            if (dist != 1) { dist = 1; curEq = eq1; }
           }
-          if (p < nk && !((emitMask >> lane) & 1ull)) posPref[st * nk + p] = 0;
+          if (p < nkU && !((emitMask >> lane) & 1ull)) posPref[st * nkU + p] = 0;
         }
       }
     }
@@ -1007,6 +1018,7 @@ __device__ void bitonicSort(KeyT *keys, int n) {
 // in LDS, only the sub-steps with j >= B touch global memory -- 10 global sub-steps instead of 153 for 131072 keys.
 // Padding up to the block size is an explicit +inf (all ones: no key is larger; dropped hits carry it too).
 template <class KeyT> __device__ void bitonicSortReg(KeyT *keys, int n);   // below: chunk-local sub-steps in registers
+template <class KeyT> __device__ void bitonicSortRegLds(KeyT *keys, int n);   // the same for keys known to live in LDS (ds_ instructions)
 template <class KeyT> __device__ __forceinline__ void cmpExchReg(KeyT &lo, KeyT &hi, int mask, bool keepMax);
 template <class KeyT>
 __device__ void bitonicSortBlocked(KeyT *keys, int n, KeyT *lds, int B) {
@@ -1015,7 +1027,7 @@ __device__ void bitonicSortBlocked(KeyT *keys, int n, KeyT *lds, int B) {
   if (n <= B) {   // fits the buffer: one round trip
     for (int i = lane; i < n; i += NT) lds[i] = keys[i];
     __syncthreads();
-    bitonicSortReg(lds, n);
+    bitonicSortRegLds(lds, n);
     for (int i = lane; i < n; i += NT) keys[i] = lds[i];
     __syncthreads();
     return;
@@ -1025,7 +1037,7 @@ __device__ void bitonicSortBlocked(KeyT *keys, int n, KeyT *lds, int B) {
   for (int b0 = 0; b0 < n; b0 += B) {   // stages k = 2 .. B: every block sorted ascending
     for (int i = lane; i < B; i += NT) lds[i] = b0 + i < n ? keys[b0 + i] : INF;
     __syncthreads();
-    bitonicSortReg(lds, B);
+    bitonicSortRegLds(lds, B);
     for (int i = lane; i < B; i += NT) if (b0 + i < n) keys[b0 + i] = lds[i];
     __syncthreads();
   }
@@ -1091,8 +1103,8 @@ __device__ __forceinline__ void cmpExchReg(KeyT &lo, KeyT &hi, int mask, bool ke
   lo = keepMax ? (olo > lo ? olo : lo) : (olo < lo ? olo : lo);
   hi = keepMax ? (ohi > hi ? ohi : hi) : (ohi < hi ? ohi : hi);
 }
-template <class KeyT>
-__device__ T4_NI void bitonicSortReg(KeyT *keys, int n) {
+template <class KeyT, class KeyPtr>
+__device__ T4_NI void bitonicSortRegP(KeyPtr keys, int n) {
   const KeyT INF = ~(KeyT)0;
   const int lane = tid(), NT = nthr();
   int n2 = 1;
@@ -1145,6 +1157,8 @@ __device__ T4_NI void bitonicSortReg(KeyT *keys, int n) {
     __syncthreads();
   }
 }
+template <class KeyT> __device__ __forceinline__ void bitonicSortReg(KeyT *keys, int n) { bitonicSortRegP<KeyT, KeyT *>(keys, n); }
+template <class KeyT> __device__ __forceinline__ void bitonicSortRegLds(KeyT *keys, int n) { bitonicSortRegP<KeyT, T4_LDS_AS KeyT *>((T4_LDS_AS KeyT *)keys, n); }
 __device__ __forceinline__ void bitonicSort32(unsigned *keys, int n) { bitonicSortReg<unsigned>(keys, n); }
 #endif
 #ifndef T4_V0_NOKEYSORT
@@ -1641,11 +1655,6 @@ __device__ unsigned dpWave(const char *t, const T4PW *w, int lent, const char *p
 }
 
 
-#ifdef __HIPCC__
-#define T4_LDS_AS __attribute__((address_space(3)))
-#else
-#define T4_LDS_AS   /* the emulator build has one address space */
-#endif
 template <bool LDS> struct T4TbufPtr { typedef const char *type; };
 template <> struct T4TbufPtr<true> { typedef const T4_LDS_AS char *type; };
 
@@ -2121,6 +2130,7 @@ __device__ int selectVJPair(const T4IndexView &ix, WaveMem &wm, int n) {
 
 // One GetHitsFromRead + GetOverlapsFromHits pass over the current segment. Returns H (hit records
 // emitted by the seed stage) or -1 on capacity overflow. Overlaps are left in wm.ov / ws->ovCount.
+template <bool NOVEL>   // NOVEL: the kernel variants that meet contig sets (repeat-skip rule live); the reference-set variants keep their register budget
 __device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int segLen, int strandArg, int barcode,
                              bool allowTotalSkip, bool vjOnly, int hitLenRequired, int filter) {
   const int lane = tid(), NT = nthr();
@@ -2129,7 +2139,7 @@ __device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, 
   const int nk = segLen - ix.k + 1;
   if (lane == 0) ws->ovCount = 0;
   PHASE_MARK(ws, 1);
-  int H = seedPositions(ix, wm, segLen, strandArg, barcode, allowTotalSkip, posStart, posPref, ws->red, wm.keys, ws);   // the key array is free until the hits are expanded
+  int H = seedPositions(ix, wm, segLen, strandArg, barcode, allowTotalSkip, posStart, posPref, ws->red, NOVEL ? wm.keys : nullptr, ws);   // the key array is free until the hits are expanded
   if (H > wm.hitLimit) return -1;
   PHASE_MARK(ws, 2);
 #if T4_OPT_KEY32
@@ -2145,7 +2155,7 @@ __device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, 
     // whose prefix sums died with expandHits: element i of the wide array overlays elements 2i, 2i + 1 of the narrow one)
     unsigned *k32v = (unsigned *)wm.keys;
 #if T4_OPT_REGSORT
-    if (H > 1) bitonicSort32(k32v, H);
+    if (H > 1) { if (wm.ldsArrays) bitonicSortRegLds<unsigned>(k32v, H); else bitonicSort32(k32v, H); }
 #else
     if (H > 1) bitonicSort(k32v, H);
 #endif
@@ -2167,7 +2177,7 @@ __device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, 
   } else if (H > 1) {
     if (!wm.ldsArrays && wm.ldsSort) bitonicSortBlocked(wm.keys, H, wm.ldsSort, wm.ldsSortCap);
 #if T4_OPT_REGSORT64
-    else if (wm.ldsArrays) bitonicSortReg(wm.keys, H);   // 64-bit keys of a big set: chunk-local sub-steps in registers as for the 32-bit keys
+    else if (wm.ldsArrays) bitonicSortRegLds(wm.keys, H);   // 64-bit keys of a big set: chunk-local sub-steps in registers as for the 32-bit keys
 #endif
     else bitonicSort(wm.keys, H);
   }
@@ -2302,7 +2312,7 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
   if (segLen < ix.k) return -1;
   int overlapCnt = 0;
   if (skipRepeats) {
-    int H = seedChainPass(ix, wm, ws, segLen, strandArg, barcode, true, false, ix.hitLenRequired, 0);
+    int H = seedChainPass<ROWS>(ix, wm, ws, segLen, strandArg, barcode, true, false, ix.hitLenRequired, 0);
     if (H < 0) return -2;
     hitTotal += (unsigned long long)H;
     __syncthreads();
@@ -2310,7 +2320,7 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
   }
   if (overlapCnt == 0) {
     __syncthreads();
-    int H = seedChainPass(ix, wm, ws, segLen, strandArg, barcode, false, false, ix.hitLenRequired, 1);
+    int H = seedChainPass<ROWS>(ix, wm, ws, segLen, strandArg, barcode, false, false, ix.hitLenRequired, 1);
     if (H < 0) return -2;
     hitTotal += (unsigned long long)H;
     __syncthreads();
@@ -2318,7 +2328,7 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
     if (overlapCnt == 0) {
       // VJ junction rescue on the hits of this pass (SeqSet.hpp:1570-1575)
       __syncthreads();
-      int H2 = seedChainPass(ix, wm, ws, segLen, strandArg, barcode, false, true, 17, 0);
+      int H2 = seedChainPass<ROWS>(ix, wm, ws, segLen, strandArg, barcode, false, true, 17, 0);
       if (H2 < 0) return -2;
       __syncthreads();
       int n = ws->ovCount;
@@ -2830,8 +2840,8 @@ __device__ void dpRowPairLean(const unsigned char *wstA, int LA, const char *pA,
     unsigned S = S1;
     int R = 0;
     if (d < W && i >= 1 && i <= L && j >= 1 && j <= L) {
-      const unsigned char *wst = par ? wstB : wstA;
-      const char *p = par ? pB : pA;
+      const T4_LDS_AS unsigned char *wst = (const T4_LDS_AS unsigned char *)(par ? wstB : wstA);   // both live in LDS (staged target bytes, the read's characters)
+      const T4_LDS_AS char *p = (const T4_LDS_AS char *)(par ? pB : pA);
       const int negInf = (L + 1) * (L + 1) * (-4);
       if (j == 1) lM = -4 - 4 * i; else if (d == 0) lM = negInf;
       if (i == 1) uM = -4 - 4 * j; else if (d + 1 >= W) uM = negInf;
