@@ -333,6 +333,18 @@ int t4_kmer_count_stats(t4_kmer_counter *kc, t4_batch *reads, const char *quals,
 /* number of distinct k-mers counted so far */
 int64_t t4_kmer_count_distinct(t4_kmer_counter *kc);
 
+/* ---- ranks of one node: the one exchange of barcode mode, inside the engine ---------------------------------
+ * Barcode mode shards by cell ranges with no exchange during assembly (main.cpp:1126-1192, 1549-1559 make cells independent); what
+ * remains is ONE variable-size all-gather of every rank's contig records at the end. t4_comm does it with RCCL (ncclAllGather over
+ * xGMI; one process per GPU) from C++: no file, tensor or Python in the path. The communicator is bootstrapped through a file: rank 0
+ * writes the ncclUniqueId to id_path (created atomically), the other ranks wait for it (same node, shared file system).
+ * t4_comm_allgather_bytes: every rank contributes n bytes; *all receives a malloc'ed buffer with the contributions of ranks
+ * 0 .. nranks-1 back to back (the caller frees it), sizes[r] their lengths. Collective: every rank of the communicator calls it. */
+typedef struct t4_comm t4_comm;
+int t4_comm_init(t4_ctx *ctx, int rank, int nranks, const char *id_path, t4_comm **out);
+int t4_comm_allgather_bytes(t4_comm *cm, const void *mine, int64_t n, void **all, int64_t *sizes);
+void t4_comm_destroy(t4_comm *cm);
+
 /* ---- measurement ----------------------------------------------------------------------------- */
 /* Per-call statistics of the last query on this ctx: kernel time measured with HIP events on the
  * ctx's stream, number of _hit records the seed stage emitted (H of SURVEY.md 8d), number of reads

@@ -395,3 +395,22 @@ def test_window_validity_rules_emulated(tmp_path, knobs):
 def test_window_validity_rules_gpu(tmp_path, knobs):
     """>= 50 k pairs: the k-growth step (4 096 contigs) is not reached at this size, list sizes cross 100 many times"""
     _verify_window_case(tmp_path, _driver(), 50000, 1000, 30 + knobs, knobs, threads="8")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not shipped")
+def test_rccl_gather_inside_the_engine_gpu(tmp_path):
+    """`trust4-hip --cellShard 0/1 --rcclId FILE`: the shard results go through t4_comm (ncclCommInitRank, two ncclAllGather
+    per payload) and rank 0's merge in C++ -- with one rank here (a box has one GPU), which still runs every call of the path;
+    the files must equal the reference binary's."""
+    fa = str(tmp_path / "ref.fa")
+    _gunzip(REF_FA, fa)
+    pre = str(tmp_path / "c5")
+    subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, "3000", "0", "4", pre, "--cells", "40"], check=True, stdout=subprocess.DEVNULL)
+    args = ["-f", fa, "-1", pre + "_1.fq", "-2", pre + "_2.fq", "--barcode", pre + "_bc.fa", "--UMI", pre + "_umi.fa"]
+    ref_out, my_out = str(tmp_path / "ref"), str(tmp_path / "mine")
+    subprocess.run([REF_BIN, "-t", "2"] + args + ["-o", ref_out], check=True, stderr=subprocess.DEVNULL)
+    p = subprocess.run([_driver(), "-t", "4"] + args + ["-o", my_out, "--cellShard", "0/1", "--rcclId", str(tmp_path / "id")], stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0 and "over RCCL" in p.stderr, p.stderr[-800:]
+    for suffix in ("_raw.out", "_assembled_reads.fa", "_final.out"):
+        assert filecmp.cmp(ref_out + suffix, my_out + suffix, shallow=False), suffix

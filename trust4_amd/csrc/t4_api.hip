@@ -21,6 +21,10 @@
 #include <unordered_map>
 #include <vector>
 
+#ifdef __HIPCC__
+#include <rccl/rccl.h>
+#include <unistd.h>
+#endif
 #include "../../include/trust4_hip.h"
 #include "t4_kernels.h"
 #include "t4_internal.h"
@@ -2032,5 +2036,97 @@ int t4_cellstore_query(t4_cellstore *cs, int n, const int32_t *slots, const char
 }
 int t4_cellstore_set_big_first(t4_cellstore *cs, int on) { if (!cs) return T4_ERR_ARG; cs->bigFirst = on != 0; return T4_OK; }
 int64_t t4_cellstore_bytes_staged(const t4_cellstore *cs) { return cs ? cs->bytesStaged + cs->bytesPatched : 0; }
+
+}  // extern "C"
+
+// ---- t4_comm: RCCL all-gather of byte strings between the ranks of one node (one process per GPU) -------------------------------
+struct t4_comm {
+  t4_ctx *ctx = nullptr;
+  int rank = 0, nranks = 1;
+#ifdef __HIPCC__
+  ncclComm_t comm = nullptr;
+#endif
+};
+
+extern "C" {
+
+int t4_comm_init(t4_ctx *c, int rank, int nranks, const char *id_path, t4_comm **out) {
+  if (!c || !out || nranks < 1 || rank < 0 || rank >= nranks || !id_path) return T4_ERR_ARG;
+#ifdef __HIPCC__
+  (void)hipSetDevice(c->device);
+  ncclUniqueId id;
+  if (rank == 0) {
+    if (ncclGetUniqueId(&id) != ncclSuccess) return fail(c, T4_ERR_HIP, "ncclGetUniqueId failed");
+    const std::string tmp = std::string(id_path) + ".tmp";
+    FILE *fp = fopen(tmp.c_str(), "wb");
+    if (!fp || fwrite(&id, sizeof id, 1, fp) != 1) { if (fp) fclose(fp); return fail(c, T4_ERR_IO, "cannot write %s", tmp.c_str()); }
+    fclose(fp);
+    if (rename(tmp.c_str(), id_path)) return fail(c, T4_ERR_IO, "cannot create %s", id_path);
+  } else {
+    bool got = false;
+    for (int tries = 0; tries < 6000 && !got; ++tries) {   // up to ten minutes: rank 0 may still be parsing its input
+      FILE *fp = fopen(id_path, "rb");
+      if (fp) { got = fread(&id, sizeof id, 1, fp) == 1; fclose(fp); }
+      if (!got) usleep(100000);
+    }
+    if (!got) return fail(c, T4_ERR_IO, "no communicator id appeared at %s", id_path);
+  }
+  t4_comm *cm = new t4_comm();
+  cm->ctx = c; cm->rank = rank; cm->nranks = nranks;
+  if (ncclCommInitRank(&cm->comm, nranks, id, rank) != ncclSuccess) { delete cm; return fail(c, T4_ERR_HIP, "ncclCommInitRank(%d of %d) failed", rank, nranks); }
+  *out = cm;
+  return T4_OK;
+#else
+  (void)out;
+  return fail(c, T4_ERR_UNSUPPORTED, "t4_comm needs the hipcc build (RCCL)");
+#endif
+}
+
+int t4_comm_allgather_bytes(t4_comm *cm, const void *mine, int64_t n, void **all, int64_t *sizes) {
+  if (!cm || n < 0 || (n > 0 && !mine) || !all || !sizes) return T4_ERR_ARG;
+#ifdef __HIPCC__
+  t4_ctx *c = cm->ctx;
+  (void)hipSetDevice(c->device);
+  const int R = cm->nranks;
+  // lengths first (8 bytes per rank), then the payloads padded to the longest: two ncclAllGather calls on the ctx's stream
+  unsigned long long *dLen = nullptr;
+  HIPCHK(c, hipMalloc(&dLen, sizeof(unsigned long long) * (size_t)(R + 1)));
+  const unsigned long long myLen = (unsigned long long)n;
+  HIPCHK(c, hipMemcpyAsync(dLen + R, &myLen, sizeof myLen, hipMemcpyHostToDevice, c->stream));
+  if (ncclAllGather(dLen + R, dLen, 1, ncclUint64, cm->comm, c->stream) != ncclSuccess) { (void)hipFree(dLen); return fail(c, T4_ERR_HIP, "ncclAllGather (lengths) failed"); }
+  std::vector<unsigned long long> lens((size_t)R);
+  HIPCHK(c, hipMemcpyAsync(lens.data(), dLen, sizeof(unsigned long long) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(dLen);
+  size_t cap = 8, total = 0;
+  for (int r = 0; r < R; ++r) { sizes[r] = (int64_t)lens[(size_t)r]; total += (size_t)lens[(size_t)r]; if ((size_t)lens[(size_t)r] > cap) cap = (size_t)lens[(size_t)r]; }
+  cap = (cap + 7) & ~(size_t)7;
+  unsigned char *dSend = nullptr, *dRecv = nullptr;
+  HIPCHK(c, hipMalloc(&dSend, cap));
+  if (hipMalloc(&dRecv, cap * (size_t)R) != hipSuccess) { (void)hipFree(dSend); return fail(c, T4_ERR_HIP, "out of device memory for the gather"); }
+  if (n > 0) HIPCHK(c, hipMemcpyAsync(dSend, mine, (size_t)n, hipMemcpyHostToDevice, c->stream));
+  if (ncclAllGather(dSend, dRecv, cap, ncclUint8, cm->comm, c->stream) != ncclSuccess) { (void)hipFree(dSend); (void)hipFree(dRecv); return fail(c, T4_ERR_HIP, "ncclAllGather (payload) failed"); }
+  unsigned char *host = (unsigned char *)malloc(total ? total : 1);
+  size_t at = 0;
+  for (int r = 0; r < R; ++r) {
+    if (lens[(size_t)r]) HIPCHK(c, hipMemcpyAsync(host + at, dRecv + cap * (size_t)r, (size_t)lens[(size_t)r], hipMemcpyDeviceToHost, c->stream));
+    at += (size_t)lens[(size_t)r];
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(dSend); (void)hipFree(dRecv);
+  *all = host;
+  return T4_OK;
+#else
+  return T4_ERR_UNSUPPORTED;
+#endif
+}
+
+void t4_comm_destroy(t4_comm *cm) {
+  if (!cm) return;
+#ifdef __HIPCC__
+  if (cm->comm) (void)ncclCommDestroy(cm->comm);
+#endif
+  delete cm;
+}
 
 }  // extern "C"

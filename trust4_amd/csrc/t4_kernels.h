@@ -859,8 +859,20 @@ __device__ int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int
           unsigned long long curEq = dist == 1 ? eq1 : __ballot(((F >> dist) & 1u) != 0);   // equality with the k-mer `dist` positions back
           unsigned long long emitMask = 0;
           const int lim = nkU - c0 < 64 ? nkU - c0 : 64;
+          // ordinary positions -- a new code with a short list -- are emitted and reset the counter; whole runs of them are passed
+          // in one step (most of a read), the rule itself is only walked through the others
+          const unsigned long long ordinary = ~eq1 & ~bigM;
           for (int t = 0; t < lim; ++t) {
             const int pp = c0 + t;
+            if (dist == 1 && pp != 0 && ((ordinary >> t) & 1ull)) {
+              const unsigned long long rest = ~(ordinary >> t);                      // first position from t on that is not ordinary
+              int run = rest ? (int)__builtin_ctzll(rest) : 64 - t;
+              if (run > lim - t) run = lim - t;
+              emitMask |= (run >= 64 ? ~0ull : ((1ull << run) - 1ull)) << t;
+              skipCnt = 0;
+              t += run - 1;
+              continue;
+            }
             if (pp == 0) { skipCnt = 0; emitMask |= 1ull; if (dist != 1) { dist = 1; curEq = eq1; } continue; }
             if (!((curEq >> t) & 1ull)) {   // differs from the previous k-mer that was not passed over
               if (((bigM >> t) & 1ull) && pp != nkU - 1 && skipCnt < skipLimitU) { ++skipCnt; ++dist; curEq = __ballot(((F >> dist) & 1u) != 0); continue; }
@@ -2825,45 +2837,57 @@ __device__ unsigned dpRowTracePW(const T4PW *w, int L, const char *p, unsigned c
 __device__ void dpRowPairLean(const unsigned char *wstA, int LA, const char *pA, const unsigned char *wstB, int LB, const char *pB,
                               int Lmax, unsigned long long &outA, unsigned long long &outB) {
   const int d = laneId() & 15, W = 11, leftBand = 5;
-  int M1 = 0, M2 = 0;
-  unsigned S1 = PS_INDEL, S2 = PS_INDEL;
-  int R1 = 0, R2 = 0;
-  unsigned long long finA = PS_INDEL, finB = PS_INDEL;
-  const int lastStep = 2 * Lmax + W;
-  for (int s = 2; s <= lastStep; ++s) {
-    int lM = rowUp1(M1), uM = rowDown1(M1);
-    const unsigned lS = rowUp1(S1), uS = rowDown1(S1);
-    const int par = (s - d) & 1;
-    const int i = (s - d - par) >> 1, j = i - leftBand + d;
-    const int L = par ? LB : LA;
-    int m = M1;
-    unsigned S = S1;
-    int R = 0;
-    if (d < W && i >= 1 && i <= L && j >= 1 && j <= L) {
-      const T4_LDS_AS unsigned char *wst = (const T4_LDS_AS unsigned char *)(par ? wstB : wstA);   // both live in LDS (staged target bytes, the read's characters)
-      const T4_LDS_AS char *p = (const T4_LDS_AS char *)(par ? pB : pA);
-      const int negInf = (L + 1) * (L + 1) * (-4);
-      if (j == 1) lM = -4 - 4 * i; else if (d == 0) lM = negInf;
-      if (i == 1) uM = -4 - 4 * j; else if (d + 1 >= W) uM = negInf;
-      int dM;
-      if (i == 1) dM = (j - 1 == 0) ? 0 : -4 - 4 * (j - 1);
-      else if (j == 1) dM = -4 - 4 * (i - 1);
-      else dM = M2;
-      const bool eq = baseEqualW(wst[j - 1], p[i - 1]);
-      const int dsc = dM + (eq ? 2 : -2);
-      m = dsc;
-      if (lM - 4 > m) m = lM - 4;
-      if (uM - 4 > m) m = uM - 4;
-      if (dsc == m) { S = pathStepDiag((i == 1 && j == 1) ? 0u : ((i == 1 || j == 1) ? pathBorder(i + j - 2) : S2), eq); R = (i == 1 ? 0 : R2) + 1; }
-      else if (uM - 4 == m) S = (i == 1 ? pathBorder(j) : uS) | PS_INDEL;
-      else S = (j == 1 ? pathBorder(i) : lS) | PS_INDEL;
-      if (i == L && j == L) { const unsigned long long f = (unsigned long long)S | ((unsigned long long)(unsigned)R << 32); if (par) finB = f; else finA = f; }
-    }
-    M2 = M1; M1 = m; S2 = S1; S1 = S; R2 = R1; R1 = R;
+  // The sweep is instruction-bound (one VALU instruction of a wavefront is four cycles whatever the number of active lanes), so the
+  // loop is written for few instructions per step: a lane's problem on EVEN steps is fixed (problem d & 1), on odd steps it is the
+  // other one, which makes every per-problem quantity loop-invariant per lane; the row index advances by one per pair of steps;
+  // a lane keeps its last value per problem (E / O registers), and its neighbours' values of the step before are their registers
+  // of the other parity. The end cell (L, L) of either problem is the last cell lane leftBand computes for it.
+  typedef const T4_LDS_AS unsigned char *LdsB;
+  typedef const T4_LDS_AS char *LdsC;
+  const bool odd = (d & 1) != 0;
+  const int LE = odd ? LB : LA, LO = odd ? LA : LB;
+  const LdsB wE = (LdsB)(odd ? wstB : wstA), wO = (LdsB)(odd ? wstA : wstB);
+  const LdsC pE = (LdsC)(odd ? pB : pA), pO = (LdsC)(odd ? pA : pB);
+  const int negE = (LE + 1) * (LE + 1) * (-4), negO = (LO + 1) * (LO + 1) * (-4);
+  const bool inBand = d < W, first = d == 0, last = d + 1 >= W;
+  int ME = 0, MO = 0, RE = 0, RO = 0;
+  unsigned SE = PS_INDEL, SO = PS_INDEL;
+  // step s = 2, 3, ...: even steps s = 2u serve cell i = u - (d + odd) / 2 ... in closed form i = (s - d - par) >> 1
+  int iE = (2 - d - (odd ? 1 : 0)) >> 1;          // row of the even-step problem at s = 2
+  int iO = (3 - d - (odd ? 0 : 1)) >> 1;          // row of the odd-step problem at s = 3
+  const int nPair = (2 * Lmax + W) / 2 + 1;
+#define T4_PAIR_STEP(Mself, Mnb, Sself, Snb, Rself, L_, w_, p_, neg_, i_)                                                               \
+  {                                                                                                                                   \
+    int lM = rowUp1(Mnb), uM = rowDown1(Mnb);                                                                                          \
+    const unsigned lS = rowUp1(Snb), uS = rowDown1(Snb);                                                                               \
+    const int i = (i_), j = i - leftBand + d;                                                                                          \
+    if (inBand && (unsigned)(i - 1) < (unsigned)(L_) && (unsigned)(j - 1) < (unsigned)(L_)) {                                          \
+      if (j == 1) lM = -4 - 4 * i; else if (first) lM = (neg_);                                                                        \
+      if (i == 1) uM = -4 - 4 * j; else if (last) uM = (neg_);                                                                         \
+      const int dM = i == 1 ? (j == 1 ? 0 : -4 * j) : (j == 1 ? -4 * i : Mself);                                                       \
+      const bool eq = baseEqualW((w_)[j - 1], (p_)[i - 1]);                                                                            \
+      const int dsc = dM + (eq ? 2 : -2);                                                                                              \
+      int m = dsc;                                                                                                                     \
+      if (lM - 4 > m) m = lM - 4;                                                                                                      \
+      if (uM - 4 > m) m = uM - 4;                                                                                                      \
+      if (dsc == m) { Sself = pathStepDiag((i == 1 && j == 1) ? 0u : ((i == 1 || j == 1) ? pathBorder(i + j - 2) : Sself), eq); Rself = (i == 1 ? 0 : Rself) + 1; } \
+      else if (uM - 4 == m) { Sself = (i == 1 ? pathBorder(j) : uS) | PS_INDEL; Rself = 0; }                                           \
+      else { Sself = (j == 1 ? pathBorder(i) : lS) | PS_INDEL; Rself = 0; }                                                            \
+      Mself = m;                                                                                                                       \
+    }                                                                                                                                  \
   }
-  const int src = (laneId() & ~15) + leftBand;   // the end cells (L, L) are the row's lane leftBand's
-  outA = ((unsigned long long)(unsigned)__shfl((int)(finA >> 32), src) << 32) | (unsigned)__shfl((int)(unsigned)finA, src);
-  outB = ((unsigned long long)(unsigned)__shfl((int)(finB >> 32), src) << 32) | (unsigned)__shfl((int)(unsigned)finB, src);
+  for (int u = 0; u < nPair; ++u) {
+    T4_PAIR_STEP(ME, MO, SE, SO, RE, LE, wE, pE, negE, iE)   // even step: neighbours computed this problem on the odd step before
+    T4_PAIR_STEP(MO, ME, SO, SE, RO, LO, wO, pO, negO, iO)   // odd step
+    ++iE; ++iO;
+  }
+#undef T4_PAIR_STEP
+  // lane leftBand = 5 is odd: its even-step problem is B, its odd-step problem A
+  const int src = (laneId() & ~15) + leftBand;
+  const unsigned sA = (unsigned)__shfl((int)SO, src), sB = (unsigned)__shfl((int)SE, src);
+  const unsigned rA = (unsigned)__shfl(RO, src), rB = (unsigned)__shfl(RE, src);
+  outA = (unsigned long long)sA | ((unsigned long long)rA << 32);
+  outB = (unsigned long long)sB | ((unsigned long long)rB << 32);
 }
 // traceback of the above (AlignAlgo.hpp:160-205); align[] receives the edit string, returns its length. One lane.
 __device__ int tracebackPW(const unsigned char *dirbuf, int L, signed char *align) {

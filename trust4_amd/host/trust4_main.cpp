@@ -62,7 +62,8 @@ const char *USAGE =
     "\t--keepNoBarcode: assemble the reads with missing barcodes. (default: ignore the reads)\n"
     "\t--contigMinCov INT: ignore contigs that have bases covered by fewer than INT reads (default: 0)\n"
     "Extension (multi-GPU, see trust4_amd/stage1_dist.py):\n"
-    "\t--cellShard R/N: barcode mode only; assemble the R-th of N contiguous ranges of cells, write shard outputs\n";
+    "\t--cellShard R/N: barcode mode only; assemble the R-th of N contiguous ranges of cells, write shard outputs\n"
+    "\t--rcclId FILE: with --cellShard, one process per GPU: gather the shards over RCCL (rank 0 creates FILE, the communicator id) and let rank 0 write the merged -o files\n";
 
 void PrintLog(const char *fmt, ...) {
   char buf[2048], stime[256];
@@ -374,10 +375,11 @@ int main(int argc, char *argv[]) {
                                          {"minHitLen", required_argument, 0, 10006}, {"cgeneEnd", required_argument, 0, 10008},
                                          {"barcode", required_argument, 0, 10002}, {"UMI", required_argument, 0, 10004},
                                          {"keepNoBarcode", no_argument, 0, 10003}, {"contigMinCov", required_argument, 0, 10007},
-                                         {"cellShard", required_argument, 0, 10100}, {"debug-ns", required_argument, 0, 10000},
+                                         {"cellShard", required_argument, 0, 10100}, {"rcclId", required_argument, 0, 10101}, {"debug-ns", required_argument, 0, 10000},
                                          {(char *)0, 0, 0, 0}};
   int indexKmerLength = 9, changeKmerLengthThreshold = 4096, trimLevel = 1, minHitLen = -1, constantGeneEnd = 200;
   int shardRank = 0, shardCount = 1, threadCnt = 1, contigMinCov = 0;
+  std::string rcclIdPath;   // --rcclId FILE: the shards' results are gathered inside the engine (t4_comm: RCCL), rank 0 writes the merged files
   bool keepMissingBarcode = false, skipMateExtension = false;
   std::string refFa, outputPrefix = "trust", kmerCountFile;
   struct NovelFa { std::string file; int kmerLength; };
@@ -401,6 +403,7 @@ int main(int argc, char *argv[]) {
     else if (c == 10008) constantGeneEnd = atoi(optarg);
     else if (c == 10002) { barcodeFile.files.push_back(optarg); hasBarcode = true; }
     else if (c == 10004) { umiFile.files.push_back(optarg); hasUmi = true; }
+    else if (c == 10101) rcclIdPath = optarg;
     else if (c == 10100) { if (sscanf(optarg, "%d/%d", &shardRank, &shardCount) != 2 || shardCount < 1 || shardRank < 0 || shardRank >= shardCount) { fprintf(stderr, "--cellShard takes R/N with 0 <= R < N\n"); return EXIT_FAILURE; } }
     else if (c == 10003) keepMissingBarcode = true;
     else if (c == 10007) contigMinCov = atoi(optarg);
@@ -1141,6 +1144,80 @@ int main(int argc, char *argv[]) {
     fflush(stdout);
     unlink(tmpl);
   };
+  if (!rcclIdPath.empty()) {
+    // ---- the one exchange of barcode mode, inside the engine: every rank's contig records (ids local to its cells), assembled
+    // reads and slot count are all-gathered over RCCL; rank 0 renumbers the contigs as the reference's cell-after-cell pass does
+    // (ids shifted by the slots of the earlier ranks) and writes the three files.
+    if (!useCells) { fprintf(stderr, "trust4-hip: --rcclId needs --barcode (without barcodes the Add pass does not shard).\n"); return EXIT_FAILURE; }
+    t4_comm *comm = nullptr;
+    if ((rc = t4_comm_init(ctx, shardRank, shardCount, rcclIdPath.c_str(), &comm))) die(ctx, "t4_comm_init", rc);
+    const std::string tmpRaw = outputPrefix + ".shard" + std::to_string(shardRank) + "_raw.tmp";
+    writeSet(tmpRaw);
+    std::string rawText;
+    { FILE *fp = fopen(tmpRaw.c_str(), "rb"); char buf[1 << 16]; size_t n; while (fp && (n = fread(buf, 1, sizeof buf, fp)) > 0) rawText.append(buf, n); if (fp) fclose(fp); unlink(tmpRaw.c_str()); }
+    std::string mainText, rescueText;
+    {
+      const size_t nMain = assembledReadIdx.size() - (size_t)rescuedCnt;
+      size_t w = 0;
+      for (int idx : assembledReadIdx) {
+        const SortRead &sr = sortedReads[idx];
+        std::string extra;
+        if (hasBarcode) extra += " barcode:" + barcodeIntToStr[sr.barcode];
+        if (hasUmi) extra += " umi:" + std::to_string(sr.umi);
+        std::string &dst = w++ < nMain ? mainText : rescueText;
+        dst += ">" + sr.id + " " + std::to_string(sr.strand) + " " + std::to_string(sr.minCnt) + " " + std::to_string(sr.medianCnt) + extra + "\n" + sr.read + "\n";
+      }
+    }
+    const std::string slotText = std::to_string(t4_cellset_size(cellSet));
+    const std::string *parts[4] = {&rawText, &mainText, &rescueText, &slotText};
+    std::vector<std::vector<std::string>> got(4, std::vector<std::string>((size_t)shardCount));
+    for (int k = 0; k < 4; ++k) {
+      void *all = nullptr;
+      std::vector<int64_t> sizes((size_t)shardCount);
+      if ((rc = t4_comm_allgather_bytes(comm, parts[k]->data(), (int64_t)parts[k]->size(), &all, sizes.data()))) die(ctx, "t4_comm_allgather_bytes", rc);
+      size_t at = 0;
+      for (int r = 0; r < shardCount; ++r) { got[(size_t)k][(size_t)r].assign((const char *)all + at, (size_t)sizes[(size_t)r]); at += (size_t)sizes[(size_t)r]; }
+      free(all);
+    }
+    if (shardRank == 0) {
+      std::string merged;
+      long long base = 0;
+      for (int r = 0; r < shardCount; ++r) {
+        const std::string &t = got[0][(size_t)r];
+        for (size_t i = 0; i < t.size();) {   // `>BARCODE_<id> name` header lines (SeqSet.hpp:10951) get id += base
+          size_t e = t.find('\n', i);
+          if (e == std::string::npos) e = t.size();
+          if (base > 0 && t[i] == '>') {
+            size_t sp = t.find(' ', i);
+            if (sp == std::string::npos || sp > e) sp = e;
+            const size_t us = t.rfind('_', sp - 1);
+            merged.append(t, i, us + 1 - i);
+            merged += std::to_string(atoll(t.substr(us + 1, sp - us - 1).c_str()) + base);
+            merged.append(t, sp, e - sp);
+          } else merged.append(t, i, e - i);
+          if (e < t.size()) merged.push_back('\n');
+          i = e + 1;
+        }
+        base += atoll(got[3][(size_t)r].c_str());
+      }
+      for (const char *suffix : {"_raw.out", "_final.out"}) {   // with barcodes _final.out is a second dump of the raw set (main.cpp:2018-2036)
+        FILE *fp = fopen((outputPrefix + suffix).c_str(), "wb");
+        if (!fp) { fprintf(stderr, "trust4-hip: cannot write %s%s\n", outputPrefix.c_str(), suffix); return EXIT_FAILURE; }
+        fwrite(merged.data(), 1, merged.size(), fp); fclose(fp);
+      }
+      FILE *fp = fopen((outputPrefix + "_assembled_reads.fa").c_str(), "wb");
+      for (int r = 0; r < shardCount; ++r) fwrite(got[1][(size_t)r].data(), 1, got[1][(size_t)r].size(), fp);
+      for (int r = 0; r < shardCount; ++r) fwrite(got[2][(size_t)r].data(), 1, got[2][(size_t)r].size(), fp);
+      fclose(fp);
+      PrintLog("Gathered %d shards over RCCL: %lld contig slots.", shardCount, base);
+    }
+    t4_comm_destroy(comm);
+    mark("outputs_written");
+    t4_cellset_destroy(cellSet);
+    t4_index_destroy(refSet);
+    t4_destroy(ctx);
+    return 0;
+  }
   writeSetOrStdout(outputPrefix + "_raw.out");
   size_t nMainAssembled = assembledReadIdx.size();
   if (shardCount > 1) nMainAssembled -= (size_t)rescuedCnt;

@@ -4,8 +4,9 @@
 Every rank runs `trust4-hip --cellShard RANK/N` on its own GPU: input, 21-mer counts and the rough annotation are replicated
 (they define the global read order), the order-dependent Add pass -- the part that does not parallelise inside a cell --
 runs on a contiguous range of cells per rank with no exchange. The one collective is at the end: the contig records of
-every rank (text of its shard `_raw.out`, ids local to the shard) are all-gathered (RCCL over xGMI with the nccl backend,
-gloo in the CPU tests) together with the contig-slot counts; rank 0 shifts every id by the slots of the earlier ranks --
+every rank (text of its shard `_raw.out`, ids local to the shard) are all-gathered together with the contig-slot counts -- on GPUs
+by the engine itself (`trust4-hip --rcclId`: t4_comm, ncclAllGather over xGMI from C++), in the CPU tests by torch.distributed
+over gloo; rank 0 shifts every id by the slots of the earlier ranks --
 the numbering the reference's cell-after-cell pass produces -- and writes PREFIX_raw.out / _final.out /
 _assembled_reads.fa byte-identical to a single-process run."""
 import os
@@ -84,6 +85,22 @@ def main(argv=None, driver=None):
     device = "cuda:%d" % local_rank if on_gpu else "cpu"
     if on_gpu:
         torch.cuda.set_device(local_rank)
+    if on_gpu and world > 1 and not os.environ.get("T4_DIST_PY"):
+        # the exchange happens inside the engine: every rank's trust4-hip joins one RCCL communicator (bootstrapped through a file
+        # that rank 0 creates) and all-gathers the shard results itself; rank 0 of the engine writes PREFIX_*.  Nothing goes
+        # through Python or torch (T4_DIST_PY=1 keeps the torch.distributed path below, which is also what the gloo tests run).
+        id_file = "%s.rcclid.%s" % (prefix, os.environ.get("MASTER_PORT", "0"))
+        if rank == 0 and os.path.exists(id_file):
+            os.remove(id_file)
+        dist.barrier()
+        env = dict(os.environ)
+        env["T4_DEVICE"] = str(local_rank)
+        subprocess.run([driver] + argv + ["-o", prefix, "--cellShard", "%d/%d" % (rank, world), "--rcclId", id_file], check=True, env=env)
+        dist.barrier()
+        if rank == 0 and os.path.exists(id_file):
+            os.remove(id_file)
+        dist.destroy_process_group()
+        return 0
     shard_prefix = "%s.shard%d" % (prefix, rank)
     env = dict(os.environ)
     env["T4_DEVICE"] = os.environ.get("T4_DEVICE_OVERRIDE", str(local_rank))   # the override is for the one-device CPU tests
