@@ -167,6 +167,9 @@ def config_leg(name, threads, device, mode="skipMateExtension"):
     prefix of C3's read stream), under this run's clock, outputs compared with the md5 sums of the REFERENCE's outputs on the same
     files (tests/golden/c2_digests.json, produced by tools/c2_digests.py from oracle/_ref/trust4; the input files are
     regenerated here and their md5 sums are checked too)."""
+    name, _, variant = name.partition(":")
+    if variant == "dropin":   # the reference's main.cpp bound to the C ABI (integration/), run-trust4's DEFAULT options: mate-pair extension tail included
+        mode = "default"
     tmp = tempfile.mkdtemp(prefix="t4%s_" % name)
     try:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -181,20 +184,25 @@ def config_leg(name, threads, device, mode="skipMateExtension"):
         inputs_ok = golden is not None and [file_md5(f1), file_md5(f2)] == golden["inputs_md5"]
         mine, stats_path = os.path.join(tmp, "mine"), os.path.join(tmp, "stats.json")
         env = dict(os.environ, T4_DEVICE=str(device), T4_STATS_JSON=stats_path)
-        argv = [DRIVER, "-t", str(threads)] + (["--skipMateExtension"] if mode == "skipMateExtension" else []) + ["-f", fa, "-1", f1, "-2", f2, "-o", mine]
+        exe = os.path.join(ROOT, "oracle", "_ref", "trust4-dropin") if variant == "dropin" else DRIVER
+        if variant == "dropin":
+            out["workload"] = out["workload"].replace("through trust4-hip", "through oracle/_ref/trust4-dropin (the reference's main.cpp with its three hot loops bound to libt4hip.so, integration/; default options: mate-pair extension tail on the host)")
+        argv = [exe, "-t", str(threads)] + (["--skipMateExtension"] if mode == "skipMateExtension" else []) + ["-f", fa, "-1", f1, "-2", f2, "-o", mine]
         t0 = time.perf_counter()
         p = subprocess.run(argv, env=env, stderr=subprocess.PIPE, text=True)
         dt = time.perf_counter() - t0
         if p.returncode:
-            out["error"] = "trust4-hip exit %d: %s" % (p.returncode, " | ".join(p.stderr.strip().split("\n")[-3:]))[:400]
+            out["error"] = "%s exit %d: %s" % (os.path.basename(exe), p.returncode, " | ".join(p.stderr.strip().split("\n")[-3:]))[:400]
             return out
-        st = json.load(open(stats_path))
-        aq = st["add_query"]
         md5s = {x: file_md5(mine + x) for x in OUT_SUFFIXES}
-        out.update({"seconds": dt, "pairs_per_s": n / dt, "contigs": st["contigs"], "assembled_reads": st["assembled_reads"],
-                    "rounds": aq["rounds"], "reads_queried": aq["reads_queried"], "reads_served": aq["reads_served"], "invalidations": aq["invalidations"],
-                    "kernel_ms": aq["kernel_ms"], "launch_ms_avg": aq["kernel_ms"] / max(1, aq["rounds"]), "hits": aq["hits"], "query_wall_s": aq["query_wall_s"],
-                    "addread_pass_s": st["phases_s"]["assembled"] - st["phases_s"]["trimmed_ready"], "md5": md5s})
+        out.update({"seconds": dt, "pairs_per_s": n / dt, "md5": md5s})
+        if variant != "dropin":
+            st = json.load(open(stats_path))
+            aq = st["add_query"]
+            out.update({"contigs": st["contigs"], "assembled_reads": st["assembled_reads"],
+                        "rounds": aq["rounds"], "reads_queried": aq["reads_queried"], "reads_served": aq["reads_served"], "invalidations": aq["invalidations"],
+                        "kernel_ms": aq["kernel_ms"], "launch_ms_avg": aq["kernel_ms"] / max(1, aq["rounds"]), "hits": aq["hits"], "query_wall_s": aq["query_wall_s"],
+                        "addread_pass_s": st["phases_s"]["assembled"] - st["phases_s"]["trimmed_ready"]})
         if golden is None or mode not in golden.get("modes", {}):
             out["identical"] = None
             out["note"] = "no reference digests committed for this config / mode"
@@ -332,7 +340,7 @@ def main():
     ap.add_argument("--side-legs", type=int, default=1, help="0 = skip passes.rough_annotation_c2 / stage1_cells / stage0_e2e")
     ap.add_argument("--traffic", type=int, default=1, help="0 = skip the two rocprofv3 PMC passes that measure roofline.traffic")
     ap.add_argument("--c2", type=int, default=1, help="0 = skip the `c2` leg (one whole stage 1 on config C2 itself, 1 M pairs, compared with the reference's digests)")
-    ap.add_argument("--config-leg", default="", help="additional config legs, comma separated (c3p2, c3p5: prefixes of C3)")
+    ap.add_argument("--config-leg", default="", help="additional config legs, comma separated (c3p2, c3p5: prefixes of C3; c2:dropin = C2 with default options through the reference's main.cpp bound to the C ABI)")
     args = ap.parse_args()
     clones = args.clones if args.clones > 0 else max(1, args.pairs // 50)
 
@@ -434,7 +442,7 @@ def main():
                 if args.c2:
                     out["c2"] = config_leg("c2", threads, local_rank)
                 for extra in [x for x in args.config_leg.split(",") if x]:
-                    out[extra] = config_leg(extra, threads, local_rank)
+                    out[extra.replace(":", "_")] = config_leg(extra, threads, local_rank)
                 out["stage1_cells"] = stage1_cells(100000, 1000)
                 out["stage0_e2e"] = stage0_e2e(400000)
             print(json.dumps(out))

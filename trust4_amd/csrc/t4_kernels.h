@@ -794,7 +794,8 @@ __device__ __forceinline__ unsigned long long kmerPacked(const WaveMem &wm, bool
 #endif
 // codeBuf (nullable): 2 * nk 64-bit words of scratch (the k-mer code of every position) for the wave-wide replay of the repeat-skip
 // rule (below); without it the rule is replayed by one lane.
-__device__ int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int strandArg, int barcode,
+template <bool NOVEL = false>   // NOVEL: compiled with the wave-wide replay (the kernel variants that meet contig sets); the others keep the code they had
+__device__ T4_NI int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int strandArg, int barcode,
                              bool allowTotalSkip, unsigned *posStart, unsigned *posPref, int *red, unsigned long long *codeBuf = nullptr, WaveState *phaseWs = nullptr) {
   const int K = ix.k, lane = tid(), NT = nthr();
   const int nk = segLen - K + 1;           // k-mers per strand
@@ -816,7 +817,7 @@ __device__ int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int
     bool same = false;
     if (p > 0) same = (((code >> 2) | ((unsigned long long)nuc2(S[p - 1]) << (2 * (K - 1)))) == code);
     posStart[q] = start; posPref[q] = cnt | (same ? SAME : 0u);
-    if (codeBuf) codeBuf[q] = code;
+    if (NOVEL && codeBuf) codeBuf[q] = code;
     if (cnt >= 100) big = 1;
   }
   big = blockSum(big, red) != 0;
@@ -828,7 +829,7 @@ __device__ int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int
       posPref[q] = (v & SAME) ? 0u : v;
     }
 #ifndef T4_SEED_SERIAL
-  } else if (codeBuf && !allowTotalSkip) {
+  } else if (NOVEL && codeBuf && !allowTotalSkip) {
     // The skip rule of GetHitsFromRead (SeqSet.hpp:1381-1391) is a small transducer: a k-mer with 100+ postings is passed over
     // (without becoming the "previous k-mer") while fewer than skipLimit have been passed over since the last emitted one; every
     // other k-mer is compared with the previous one that was not passed over, which lies at most skipLimit + 1 positions back.
@@ -2151,7 +2152,7 @@ __device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, 
   const int nk = segLen - ix.k + 1;
   if (lane == 0) ws->ovCount = 0;
   PHASE_MARK(ws, 1);
-  int H = seedPositions(ix, wm, segLen, strandArg, barcode, allowTotalSkip, posStart, posPref, ws->red, NOVEL ? wm.keys : nullptr, ws);   // the key array is free until the hits are expanded
+  int H = seedPositions<NOVEL>(ix, wm, segLen, strandArg, barcode, allowTotalSkip, posStart, posPref, ws->red, NOVEL ? wm.keys : nullptr, ws);   // the key array is free until the hits are expanded
   if (H > wm.hitLimit) return -1;
   PHASE_MARK(ws, 2);
 #if T4_OPT_KEY32
@@ -2167,7 +2168,7 @@ __device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, 
     // whose prefix sums died with expandHits: element i of the wide array overlays elements 2i, 2i + 1 of the narrow one)
     unsigned *k32v = (unsigned *)wm.keys;
 #if T4_OPT_REGSORT
-    if (H > 1) { if (wm.ldsArrays) bitonicSortRegLds<unsigned>(k32v, H); else bitonicSort32(k32v, H); }
+    if (H > 1) { if (NOVEL && wm.ldsArrays) bitonicSortRegLds<unsigned>(k32v, H); else bitonicSort32(k32v, H); }
 #else
     if (H > 1) bitonicSort(k32v, H);
 #endif
@@ -2189,7 +2190,8 @@ __device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, 
   } else if (H > 1) {
     if (!wm.ldsArrays && wm.ldsSort) bitonicSortBlocked(wm.keys, H, wm.ldsSort, wm.ldsSortCap);
 #if T4_OPT_REGSORT64
-    else if (wm.ldsArrays) bitonicSortRegLds(wm.keys, H);   // 64-bit keys of a big set: chunk-local sub-steps in registers as for the 32-bit keys
+    else if (NOVEL && wm.ldsArrays) bitonicSortRegLds(wm.keys, H);   // 64-bit keys of a big set
+    else if (wm.ldsArrays) bitonicSortReg(wm.keys, H);   // chunk-local sub-steps in registers as for the 32-bit keys
 #endif
     else bitonicSort(wm.keys, H);
   }
@@ -3534,7 +3536,7 @@ template <int CAP, int MAXOV, int NTHREADS, int VARIANT>
 __global__ __launch_bounds__(NTHREADS)
 // rough-annotation kernels of the two small tiers: register budget for 4 waves / SIMD (LDS lets that many groups in)
 __attribute__((amdgpu_waves_per_eu((VARIANT == 0 && CAP > 0 && CAP <= 2048) ? T4_WPE_SMALL : 1)))
-void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
+void queryKernel(T4IndexView ixArg, T4BatchView bvArg, T4Work wkArg, T4QueryArgs qaArg) {
   constexpr int C = CAP > 0 ? CAP : 1;
   constexpr int M = CAP > 0 ? MAXOV : 1;
   __shared__ unsigned long long s_keys[C];
@@ -3546,27 +3548,50 @@ void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
   __shared__ char s_rc[T4_MAXL + 8];
   __shared__ WaveState s_ws;
   __shared__ unsigned long long s_gsort[CAP > 0 ? 1 : 8192];   // global-scratch tier: staging buffer of the hit sort
-  WaveMem wm;
-  if (CAP > 0) {
-    wm.keys = s_keys; wm.pairs = s_pairs; wm.cand = s_pairs + C; wm.ov = s_ov; wm.fin = s_fin; wm.ord = s_ord;
-    wm.cap = CAP; wm.maxOv = MAXOV; wm.maxFin = MAXOV; wm.candCap = C / 3 + 2; wm.ldsArrays = 1;
-    wm.hitLimit = (wk.capLimit > 0 && wk.capLimit < CAP) ? wk.capLimit : CAP;
-    wm.ldsSort = nullptr; wm.ldsSortCap = 0;
-    wm.dirBuf = (unsigned char *)s_keys; wm.dirBytes = C * 8;
-  } else {
-    size_t b = blockIdx.x;
-    wm.keys = wk.gKeys + b * (size_t)wk.gCap;
-    wm.pairs = wk.gPairs + b * (size_t)wk.gCap * 2;
-    wm.cand = wm.pairs + wk.gCap;
-    wm.ov = (OvRec *)(wk.gOv + b * (size_t)wk.gMaxOv * 10);
-    wm.fin = (OvRec *)(wk.gFin + b * (size_t)wk.gMaxOv * 10);
-    wm.ord = wk.gOrd + b * (size_t)wk.gMaxOv;
-    wm.cap = wk.gCap; wm.maxOv = wk.gMaxOv; wm.maxFin = wk.gMaxOv; wm.candCap = wk.gCap; wm.ldsArrays = 0;
-    wm.hitLimit = wk.gCap;
-    wm.ldsSort = s_gsort; wm.ldsSortCap = CAP > 0 ? 0 : 8192;
-    wm.dirBuf = (unsigned char *)s_gsort; wm.dirBytes = (int)sizeof s_gsort;
+  // The argument structs and the working-memory description are handed to out-of-line device functions by reference. As by-value
+  // kernel parameters / locals that forces a copy of each into every lane's private stack (736 bytes of scratch per lane in the
+  // AddRead kernel: ~370 KB written per workgroup, the bulk of the 68 GB of WRITE_SIZE per step that profiles/r03k_bench.json
+  // shows). The variants that meet contig sets keep ONE copy per workgroup in LDS instead; the reference-set variants (VARIANT 0),
+  // whose register budget is tuned, stay as they were.
+  constexpr bool SHARED_ARGS = VARIANT != 0;
+  __shared__ T4IndexView s_ix;
+  __shared__ T4BatchView s_bv;
+  __shared__ T4Work s_wk;
+  __shared__ T4QueryArgs s_qa;
+  __shared__ WaveMem s_wm, s_wg;
+  if (SHARED_ARGS) {
+    if (threadIdx.x == 0) { s_ix = ixArg; s_bv = bvArg; s_wk = wkArg; s_qa = qaArg; }
+    __syncthreads();
   }
-  wm.seg = s_seg; wm.rc = s_rc;
+  T4IndexView &ix = SHARED_ARGS ? s_ix : ixArg;
+  const T4BatchView &bv = SHARED_ARGS ? s_bv : bvArg;
+  const T4Work &wk = SHARED_ARGS ? s_wk : wkArg;
+  const T4QueryArgs &qa = SHARED_ARGS ? s_qa : qaArg;
+  WaveMem wmLocal;
+  WaveMem &wm = SHARED_ARGS ? s_wm : wmLocal;
+  if (!SHARED_ARGS || threadIdx.x == 0) {
+    if (CAP > 0) {
+      wm.keys = s_keys; wm.pairs = s_pairs; wm.cand = s_pairs + C; wm.ov = s_ov; wm.fin = s_fin; wm.ord = s_ord;
+      wm.cap = CAP; wm.maxOv = MAXOV; wm.maxFin = MAXOV; wm.candCap = C / 3 + 2; wm.ldsArrays = 1;
+      wm.hitLimit = (wk.capLimit > 0 && wk.capLimit < CAP) ? wk.capLimit : CAP;
+      wm.ldsSort = nullptr; wm.ldsSortCap = 0;
+      wm.dirBuf = (unsigned char *)s_keys; wm.dirBytes = C * 8;
+    } else {
+      size_t b = blockIdx.x;
+      wm.keys = wk.gKeys + b * (size_t)wk.gCap;
+      wm.pairs = wk.gPairs + b * (size_t)wk.gCap * 2;
+      wm.cand = wm.pairs + wk.gCap;
+      wm.ov = (OvRec *)(wk.gOv + b * (size_t)wk.gMaxOv * 10);
+      wm.fin = (OvRec *)(wk.gFin + b * (size_t)wk.gMaxOv * 10);
+      wm.ord = wk.gOrd + b * (size_t)wk.gMaxOv;
+      wm.cap = wk.gCap; wm.maxOv = wk.gMaxOv; wm.maxFin = wk.gMaxOv; wm.candCap = wk.gCap; wm.ldsArrays = 0;
+      wm.hitLimit = wk.gCap;
+      wm.ldsSort = s_gsort; wm.ldsSortCap = CAP > 0 ? 0 : 8192;
+      wm.dirBuf = (unsigned char *)s_gsort; wm.dirBytes = (int)sizeof s_gsort;
+    }
+    wm.seg = s_seg; wm.rc = s_rc;
+  }
+  if (SHARED_ARGS) __syncthreads();
   DPScratch sc;
   sc.rows = wk.dpRows + ((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (6 * T4_ROWW * 64);
   sc.dir = wk.dpDir + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * T4_DIR_BYTES;
@@ -3576,7 +3601,10 @@ void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
   int w = blockIdx.x;
   while (w < wk.nList) {
     long long r = wk.list[w];
-    if (VARIANT == 2) ix = qa.views[qa.viewOf[r]];   // uniform address: scalar loads
+    if (VARIANT == 2) {   // the read's own set image
+      if (SHARED_ARGS) { __syncthreads(); if (threadIdx.x == 0) s_ix = qa.views[qa.viewOf[r]]; __syncthreads(); }
+      else ix = qa.views[qa.viewOf[r]];
+    }
 #ifdef __HIPCC__
     const unsigned long long tick0 = (VARIANT == 1 && qa.readTicks) ? wall_clock64() : 0ull;
 #endif
@@ -3584,18 +3612,23 @@ void queryKernel(T4IndexView ix, T4BatchView bv, T4Work wk, T4QueryArgs qa) {
     if (CAP == 8192 && VARIANT == 1 && !done && wk.gKeys) {
       // The read outgrew the LDS arrays (known right after its seed stage): the same workgroup goes on in its block's slice of
       // the global-scratch arrays instead of leaving the read to another launch -- an AddRead query round is one launch.
-      WaveMem wg = wm;
-      const size_t b = blockIdx.x;
-      wg.keys = wk.gKeys + b * (size_t)wk.gCap;
-      wg.pairs = wk.gPairs + b * (size_t)wk.gCap * 2;
-      wg.cand = wg.pairs + wk.gCap;
-      wg.ov = (OvRec *)(wk.gOv + b * (size_t)wk.gMaxOv * 10);
-      wg.fin = (OvRec *)(wk.gFin + b * (size_t)wk.gMaxOv * 10);
-      wg.ord = wk.gOrd + b * (size_t)wk.gMaxOv;
-      wg.cap = wk.gCap; wg.maxOv = wk.gMaxOv; wg.maxFin = wk.gMaxOv; wg.candCap = wk.gCap; wg.ldsArrays = 0; wg.hitLimit = wk.gCap;
-      wg.ldsSort = s_keys; wg.ldsSortCap = C;   // the LDS arrays are free now: the hit sort is staged through the key array
-      wg.dirBuf = (unsigned char *)s_keys; wg.dirBytes = C * 8;
-      if (wk.capLimit > 0 && wk.capLimit < C) { int bsz = 64; while (bsz * 2 <= wk.capLimit) bsz *= 2; wg.ldsSortCap = bsz; }   // testing aid: small blocks
+      WaveMem wgLocal;
+      WaveMem &wg = SHARED_ARGS ? s_wg : wgLocal;
+      __syncthreads();
+      if (!SHARED_ARGS || threadIdx.x == 0) {
+        wg = wm;
+        const size_t b = blockIdx.x;
+        wg.keys = wk.gKeys + b * (size_t)wk.gCap;
+        wg.pairs = wk.gPairs + b * (size_t)wk.gCap * 2;
+        wg.cand = wg.pairs + wk.gCap;
+        wg.ov = (OvRec *)(wk.gOv + b * (size_t)wk.gMaxOv * 10);
+        wg.fin = (OvRec *)(wk.gFin + b * (size_t)wk.gMaxOv * 10);
+        wg.ord = wk.gOrd + b * (size_t)wk.gMaxOv;
+        wg.cap = wk.gCap; wg.maxOv = wk.gMaxOv; wg.maxFin = wk.gMaxOv; wg.candCap = wk.gCap; wg.ldsArrays = 0; wg.hitLimit = wk.gCap;
+        wg.ldsSort = s_keys; wg.ldsSortCap = C;   // the LDS arrays are free now: the hit sort is staged through the key array
+        wg.dirBuf = (unsigned char *)s_keys; wg.dirBytes = C * 8;
+        if (wk.capLimit > 0 && wk.capLimit < C) { int bsz = 64; while (bsz * 2 <= wk.capLimit) bsz *= 2; wg.ldsSortCap = bsz; }   // testing aid: small blocks
+      }
       __syncthreads();
       done = processRead<1>(ix, bv, wk, qa, wg, &s_ws, r, sc);
       if (tid() == 0 && done && wk.nextCount) atomicAdd(wk.nextCount + 2, 1);   // statistics: reads served this way
