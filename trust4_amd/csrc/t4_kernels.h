@@ -794,9 +794,87 @@ __device__ __forceinline__ unsigned long long kmerPacked(const WaveMem &wm, bool
 #endif
 // codeBuf (nullable): 2 * nk 64-bit words of scratch (the k-mer code of every position) for the wave-wide replay of the repeat-skip
 // rule (below); without it the rule is replayed by one lane.
-template <bool NOVEL = false>   // NOVEL: compiled with the wave-wide replay (the kernel variants that meet contig sets); the others keep the code they had
-__device__ T4_NI int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int strandArg, int barcode,
-                             bool allowTotalSkip, unsigned *posStart, unsigned *posPref, int *red, unsigned long long *codeBuf = nullptr, WaveState *phaseWs = nullptr) {
+__device__ int seedPositions(const T4IndexView &ix, WaveMem &wm, int segLen, int strandArg, int barcode,
+                             bool allowTotalSkip, unsigned *posStart, unsigned *posPref, int *red) {
+  const int K = ix.k, lane = tid(), NT = nthr();
+  const int nk = segLen - K + 1;           // k-mers per strand
+  const unsigned long long mask = K < 32 ? ((1ull << (2 * K)) - 1ull) : ~0ull;
+  int skipLimit = ix.firstIsRef ? 0 : K / 2;
+  // raw list sizes (0 for invalid k-mers) and starts, for both strands; bit 31 of the size marks a k-mer whose code
+  // equals the code of the previous position (K + 1 equal bases): the repeat test of SeqSet.hpp:1380 without a second
+  // and third pass over the characters
+  const unsigned SAME = 0x80000000u;
+  int big = 0;
+  for (int q = lane; q < 2 * nk; q += NT) {
+    int st = q >= nk, p = st ? q - nk : q;
+    bool active = st ? (strandArg != 1) : (strandArg != -1);
+    const char *S = st ? wm.rc : wm.seg;
+    unsigned start = 0, cnt = 0;
+    bool valid;
+    const unsigned long long code = (K <= 16 ? kmerPacked(wm, st != 0, p, segLen, K, valid) : kmerAt(S, p, K, valid)) & mask;
+    if (active && valid) indexLookup(ix, code, barcode, start, cnt);
+    bool same = false;
+    if (p > 0) same = (((code >> 2) | ((unsigned long long)nuc2(S[p - 1]) << (2 * (K - 1)))) == code);
+    posStart[q] = start; posPref[q] = cnt | (same ? SAME : 0u);
+    if (cnt >= 100) big = 1;
+  }
+  big = blockSum(big, red) != 0;
+  if ((skipLimit == 0 && !allowTotalSkip) || !big) {
+    // no `continue` can fire: prevKmerCode is always the code of the previous position
+    for (int q = lane; q < 2 * nk; q += NT) {
+      const unsigned v = posPref[q];
+      posPref[q] = (v & SAME) ? 0u : v;
+    }
+  } else {
+    for (int q = lane; q < 2 * nk; q += NT) posPref[q] &= ~SAME;
+    __syncthreads();
+    if (lane == 0) {
+    // sequential replay of the skip state machine (SeqSet.hpp:1370-1425, 1437-1498)
+    unsigned long long prev = 0;
+    for (int st = 0; st < 2; ++st) {
+      bool active = st ? (strandArg != 1) : (strandArg != -1);
+      if (!active) continue;
+      const char *S = st ? wm.rc : wm.seg;
+      unsigned long long code = 0;
+      int skipCnt = 0;
+      for (int i = 0; i < K - 1; ++i) code = ((code << 2) & mask) | (unsigned long long)nuc2(S[i]);
+      for (int i = K - 1; i < segLen; ++i) {
+        code = ((code << 2) & mask) | (unsigned long long)nuc2(S[i]);
+        int p = i - K + 1, q = st * nk + p;
+        unsigned size = posPref[q];
+        bool emit = false;
+        if (p == 0 || prev != code) {
+          if (size >= 100 && p != 0 && i != segLen - 1 && skipCnt < skipLimit) { ++skipCnt; posPref[q] = 0; continue; }
+          if (size >= 100 && allowTotalSkip) { posPref[q] = 0; continue; }
+          skipCnt = 0;
+          emit = true;
+        }
+        if (!emit) posPref[q] = 0;
+        prev = code;
+      }
+    }
+    }
+  }
+  __syncthreads();
+  // exclusive prefix sums over the 2*nk positions
+  int carry = 0;
+  for (int q0 = 0; q0 < 2 * nk; q0 += NT) {
+    int q = q0 + lane;
+    int v = q < 2 * nk ? (int)posPref[q] : 0;
+    int tot;
+    int inc = blockInclScan(v, red, tot);
+    if (q < 2 * nk) posPref[q] = (unsigned)(carry + inc - v);
+    carry += tot;
+  }
+  if (lane == 0) posPref[2 * nk] = (unsigned)carry;
+  __syncthreads();
+  return carry;
+}
+
+// The same for the kernel variants that meet contig sets (repeat-skip rule live): the rule is replayed wave-wide, see below.
+__device__ T4_NI int seedPositionsNovel(const T4IndexView &ix, WaveMem &wm, int segLen, int strandArg, int barcode,
+                             bool allowTotalSkip, unsigned *posStart, unsigned *posPref, int *red, unsigned long long *codeBuf, WaveState *phaseWs) {
+  constexpr bool NOVEL = true;
   const int K = ix.k, lane = tid(), NT = nthr();
   const int nk = segLen - K + 1;           // k-mers per strand
   const unsigned long long mask = K < 32 ? ((1ull << (2 * K)) - 1ull) : ~0ull;
@@ -2152,7 +2230,8 @@ __device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, 
   const int nk = segLen - ix.k + 1;
   if (lane == 0) ws->ovCount = 0;
   PHASE_MARK(ws, 1);
-  int H = seedPositions<NOVEL>(ix, wm, segLen, strandArg, barcode, allowTotalSkip, posStart, posPref, ws->red, NOVEL ? wm.keys : nullptr, ws);   // the key array is free until the hits are expanded
+  int H = NOVEL ? seedPositionsNovel(ix, wm, segLen, strandArg, barcode, allowTotalSkip, posStart, posPref, ws->red, wm.keys, ws)
+                : seedPositions(ix, wm, segLen, strandArg, barcode, allowTotalSkip, posStart, posPref, ws->red);   // the key array is free until the hits are expanded
   if (H > wm.hitLimit) return -1;
   PHASE_MARK(ws, 2);
 #if T4_OPT_KEY32
@@ -3535,7 +3614,9 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
 template <int CAP, int MAXOV, int NTHREADS, int VARIANT>
 __global__ __launch_bounds__(NTHREADS)
 // rough-annotation kernels of the two small tiers: register budget for 4 waves / SIMD (LDS lets that many groups in)
-__attribute__((amdgpu_waves_per_eu((VARIANT == 0 && CAP > 0 && CAP <= 2048) ? T4_WPE_SMALL : 1)))
+// (and of the 3072-hit tier for 3: its LDS lets three groups of four wavefronts onto a CU; left to itself the allocator took 176
+// VGPRs in round 3 -- two groups -- and the tier ran 45 % longer, profiles/r03n_annotate_kernel_ab.txt)
+__attribute__((amdgpu_waves_per_eu((VARIANT == 0 && CAP > 0 && CAP <= 2048) ? T4_WPE_SMALL : (VARIANT == 0 && CAP == 3072) ? 3 : 1)))
 void queryKernel(T4IndexView ixArg, T4BatchView bvArg, T4Work wkArg, T4QueryArgs qaArg) {
   constexpr int C = CAP > 0 ? CAP : 1;
   constexpr int M = CAP > 0 ? MAXOV : 1;
