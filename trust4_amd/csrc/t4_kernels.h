@@ -3611,12 +3611,15 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
 #ifndef T4_WPE_SMALL
 #define T4_WPE_SMALL 4
 #endif
+#ifndef T4_WPE_CELLS
+#define T4_WPE_CELLS 1   // first launch of the per-barcode queries (1024-hit tier, VARIANT 2): wavefronts per SIMD the register allocation aims at
+#endif
 template <int CAP, int MAXOV, int NTHREADS, int VARIANT>
 __global__ __launch_bounds__(NTHREADS)
 // rough-annotation kernels of the two small tiers: register budget for 4 waves / SIMD (LDS lets that many groups in)
 // (and of the 3072-hit tier for 3: its LDS lets three groups of four wavefronts onto a CU; left to itself the allocator took 176
 // VGPRs in round 3 -- two groups -- and the tier ran 45 % longer, profiles/r03n_annotate_kernel_ab.txt)
-__attribute__((amdgpu_waves_per_eu((VARIANT == 0 && CAP > 0 && CAP <= 2048) ? T4_WPE_SMALL : (VARIANT == 0 && CAP == 3072) ? 3 : 1)))
+__attribute__((amdgpu_waves_per_eu((VARIANT == 0 && CAP > 0 && CAP <= 2048) ? T4_WPE_SMALL : (VARIANT == 0 && CAP == 3072) ? 3 : (VARIANT == 2 && CAP == 1024) ? T4_WPE_CELLS : 1)))
 void queryKernel(T4IndexView ixArg, T4BatchView bvArg, T4Work wkArg, T4QueryArgs qaArg) {
   constexpr int C = CAP > 0 ? CAP : 1;
   constexpr int M = CAP > 0 ? MAXOV : 1;

@@ -548,8 +548,8 @@ int main(int argc, char *argv[]) {
     if (!kmerCount.addCountFromFile(kmerCountFile.c_str())) { fprintf(stderr, "Could not open %s\n", kmerCountFile.c_str()); initThread.join(); return EXIT_FAILURE; }
     PrintLog("Read in the kmer count information from %s", kmerCountFile.c_str());
   }
-  // T4_GPU_KMERCOUNT=1 (opt-in this round): the 21-mer counts and the count statistics on the device
-  // (t4_kmer_count_*). Needs what the device path takes: no -c file, reads of at most 384 bp, qualities on every read or on none.
+  // The 21-mer counts and the count statistics on the device (t4_kmer_count_*). The device path takes: reads of at most 384 bp over
+  // ACGTN, qualities on every read or on none (a -c file is loaded into the device table as it is).
   t4_kmer_counter *gpuKc = nullptr;
   bool gpuQual = false;
   const size_t KC_CHUNK = 1u << 22;
@@ -561,8 +561,24 @@ int main(int argc, char *argv[]) {
     if ((rc = t4_reads_upload(ctx, bases.data(), off.data(), withBarcodes ? bcs.data() : nullptr, (int64_t)(hi - lo), &b))) die(ctx, "t4_reads_upload", rc);
     return b;
   };
-  bool gpuKmerCounts = false;   // T4_GPU_KMERCOUNT was taken: the barcode-wise counts follow it
-  if (getenv("T4_GPU_KMERCOUNT") && atoi(getenv("T4_GPU_KMERCOUNT")) != 0 && readCnt > 0) {
+  bool gpuKmerCounts = false;   // the device path was taken: the barcode-wise counts follow it
+  // Default since round 3 (1 M barcoded pairs: 23.9 -> 21.2 s, profiles/r03l_*): on the device whenever the input is what the device
+  // path takes; T4_GPU_KMERCOUNT=0 keeps the host threads, =1 insists (and says why it cannot).
+  bool wantGpuKc = false;
+  if (readCnt > 0) {
+    const char *ev = getenv("T4_GPU_KMERCOUNT");
+    if (ev) wantGpuKc = atoi(ev) != 0;
+    else {
+      size_t nQual = 0;
+      bool plain = maxReadLen <= 384;
+      for (const SortRead &r : sortedReads) {
+        if (r.hasQual) ++nQual;
+        if (plain) for (char ch : r.read) if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T' && ch != 'N') { plain = false; break; }
+      }
+      wantGpuKc = plain && (trimLevel == 0 || nQual == 0 || nQual == sortedReads.size());
+    }
+  }
+  if (wantGpuKc) {
     size_t nQual = 0;
     long long kmers = 0;
     for (const SortRead &r : sortedReads) { if (r.hasQual) ++nQual; if ((int)r.read.size() >= 21) kmers += (long long)r.read.size() - 20; }
