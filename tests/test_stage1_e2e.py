@@ -399,6 +399,31 @@ def test_window_validity_rules_gpu(tmp_path, knobs):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not shipped")
+@pytest.mark.parametrize("pairs,clones,seed", [(3000, 1500, 3), (30000, 15000, 7)])
+def test_window_entries_with_stable_group_statistics_gpu(tmp_path, pairs, clones, seed):
+    """Many clones on few genes: reads inside a shared gene meet hundreds of contigs, more than 100 groups of four hits, so
+    novelMinHitRequired follows the group statistics (SeqSet.hpp:813-823). The query reports when those statistics cannot move
+    under index edits of small groups (T4QueryArgs::statsStable) and the window then keeps the entry across such edits without a
+    budget. T4_VERIFY_WINDOW checks every served entry against a fresh query; the same input under the budget rule alone
+    (T4_NO_STABLE_STATS) must lose more entries to the tolerance rule."""
+    import re
+    logs = {}
+    for name, extra in (("stable", {}), ("budget", {"T4_NO_STABLE_STATS": "1"})):
+        d = tmp_path / name
+        d.mkdir()
+        env = {"T4_VERIFY_WINDOW": "1", "T4_TIMING": "1"}
+        env.update(extra)
+        logs[name] = _bulk_case(d, _driver(), pairs, clones, seed, env, threads="8")
+    pat = r"tolerated index edits (\d+), of which (\d+) met an entry whose group statistics cannot move.*tolerance kills (\d+)"
+    st, bu = re.search(pat, logs["stable"]), re.search(pat, logs["budget"])
+    assert st and bu, logs["stable"][-600:]
+    assert int(st.group(2)) > 0 and int(bu.group(2)) == 0
+    assert int(st.group(3)) < int(bu.group(3)), (st.groups(), bu.groups())
+    assert re.search(r"T4_VERIFY_WINDOW: (\d+) served window entries", logs["stable"])
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not shipped")
 def test_rccl_gather_inside_the_engine_gpu(tmp_path):
     """`trust4-hip --cellShard 0/1 --rcclId FILE`: the shard results go through t4_comm (ncclCommInitRank, two ncclAllGather
     per payload) and rank 0's merge in C++ -- with one rank here (a box has one GPU), which still runs every call of the path;

@@ -68,7 +68,7 @@ struct AqCall {
   int n = 0, skipRepeats = 0, wpk = 0, wnm = 0, attempt = 0, nFirst = 0, nDirect = 0, threads = 512;
   unsigned char *tierHint = nullptr;
   std::vector<unsigned char> allGlobal;
-  size_t oPk, oNm, oLen, oBc, oSt, oLs, oVw, oFa, inBytes, pCnt, pSta, pNext, pNext2, pBase, pTick, pTail, outBytes;
+  size_t oPk, oNm, oLen, oBc, oSt, oLs, oVw, oFa, inBytes, pCnt, pSta, pNext, pNext2, pBase, pTick, pStab, pTail, outBytes;
   bool extendLater = false;
   T4BatchView bv; T4QueryArgs qa; T4Work wk;
   std::chrono::steady_clock::time_point tf0;
@@ -112,6 +112,7 @@ struct t4_ctx {
   int64_t aqCalls = 0, aqReads = 0, aqGlobalLaunches = 0, aqGlobalReads = 0, aqRecords = 0;
   double aqSecPack = 0, aqSecFirst = 0, aqSecGlobal = 0;
   int aqPoolGrows = 0;
+  const int32_t *aqLastStable = nullptr;   // per-read flags of the last AddRead query call: group statistics that index edits of small groups cannot move
   const int32_t *aqLastTicks = nullptr; int aqLastN = 0;   // per-read wall-clock ticks (10 ns) of the last AddRead query call (in the pinned header blob)
   double aqLastMs = 0;
   AqCall aq;
@@ -263,6 +264,18 @@ void t4_destroy(t4_ctx *c) {
       unsigned long long tot = 0;
       for (int i = 0; i < T4_NPHASE; ++i) tot += ph[i];
       for (int i = 0; i < T4_NPHASE; ++i) if (ph[i]) fprintf(stderr, "phase %-16s %-7s %6.2f%%  %.3e cycles\n", names[i & 31], i < 32 ? "lds" : "global", 100.0 * (double)ph[i] / (double)tot, (double)ph[i]);
+    }
+    static unsigned long long cls[4 * T4_NPHASE];
+    if (hipMemcpyFromSymbol(cls, HIP_SYMBOL(t4k::g_phaseByOverlaps), sizeof(cls)) == hipSuccess) {
+      static const char *names[32] = {"other", "seed:lookup", "expand", "sort", "stats", "runs", "bigsort", "chain", "ovsort", "score", "prefilter", "final", "annotate", "score:quick", "score:banded", "score:finish", "extend:ungapped", "after-extend", "extend:list", "extend:dp4", "extend:dp1", "extend:combine", "seed:replay", "seed:scan", "extend:launch", "-", "-", "-", "-", "-", "-", "-"};
+      static const char *cname[4] = {"<5 overlaps", "5-19 overlaps", "20-64 overlaps", ">64 overlaps"};
+      for (int k = 0; k < 4; ++k) {
+        unsigned long long tot = 0;
+        for (int i = 0; i < T4_NPHASE; ++i) tot += cls[k * T4_NPHASE + i];
+        if (!tot) continue;
+        fprintf(stderr, "AddRead queries with %s: %.3e cycles in the query kernel\n", cname[k], (double)tot);
+        for (int i = 0; i < T4_NPHASE; ++i) if (cls[k * T4_NPHASE + i] * 200 >= tot) fprintf(stderr, "   %-16s %-7s %6.2f%%\n", names[i & 31], i < 32 ? "lds" : "global", 100.0 * (double)cls[k * T4_NPHASE + i] / (double)tot);
+      }
     }
     unsigned long long dc[8];
     if (hipMemcpyFromSymbol(dc, HIP_SYMBOL(t4k::g_dbgCount), sizeof(dc)) == hipSuccess)
@@ -1372,14 +1385,14 @@ int aqBegin(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const 
   const int wpk = (maxLen + 15) / 16, wnm = (maxLen + 31) / 32;
   q.wpk = wpk; q.wnm = wnm;
   // input blob: pk | nm | len | barcode | strand | list(iota) | viewOf | factor
-  // header blob: counts | status | next1 | next2 | outBase | ticks | tail{overflow1, overflow2, hits, pool cursor}
+  // header blob: counts | status | next1 | next2 | outBase | ticks | statistics-stable flags | tail{overflow1, overflow2, hits, pool cursor}
   auto al8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
   q.oPk = 0; q.oNm = al8(q.oPk + sizeof(unsigned) * (size_t)n * wpk); q.oLen = al8(q.oNm + sizeof(unsigned) * (size_t)n * wnm);
   q.oBc = al8(q.oLen + sizeof(int) * (size_t)n); q.oSt = al8(q.oBc + sizeof(int) * (size_t)n); q.oLs = al8(q.oSt + sizeof(int) * (size_t)n);
   q.oVw = al8(q.oLs + sizeof(int) * (size_t)n); q.oFa = al8(q.oVw + sizeof(int) * (size_t)n); q.inBytes = al8(q.oFa + sizeof(double) * (size_t)n);
   q.pCnt = 0; q.pSta = al8(q.pCnt + sizeof(int) * (size_t)n); q.pNext = al8(q.pSta + sizeof(int) * (size_t)n);
   q.pNext2 = al8(q.pNext + sizeof(int) * (size_t)n); q.pBase = al8(q.pNext2 + sizeof(int) * (size_t)n);
-  q.pTick = al8(q.pBase + sizeof(int) * (size_t)n); q.pTail = al8(q.pTick + sizeof(int) * (size_t)n); q.outBytes = q.pTail + 32;
+  q.pTick = al8(q.pBase + sizeof(int) * (size_t)n); q.pStab = al8(q.pTick + sizeof(int) * (size_t)n); q.pTail = al8(q.pStab + sizeof(int) * (size_t)n); q.outBytes = q.pTail + 32;
   if (q.inBytes > c->aqInBytes) {
     if (c->aqIn) (void)hipFree(c->aqIn);
     if (c->aqInHost) (void)hipHostFree(c->aqInHost);
@@ -1459,6 +1472,7 @@ int aqLaunch(t4_ctx *c) {
   qa.outBase = (int *)(c->aqOut + q.pBase); qa.poolCursor = (unsigned *)(c->aqOut + q.pTail + 24); qa.poolCap = c->aqPoolCap;
   qa.strandPerRead = (const int *)(c->aqIn + q.oSt); qa.factorPerRead = (const double *)(c->aqIn + q.oFa);
   qa.readTicks = (int *)(c->aqOut + q.pTick);
+  qa.statsStable = (int *)(c->aqOut + q.pStab);
   qa.leanExt = q.lean ? 1 : 0;
   if (q.views) { qa.views = q.views; qa.viewOf = (const int *)(c->aqIn + q.oVw); }
   // one big set: the ExtendOverlap calls of reads with more than this many overlaps run in their own launch (0: never)
@@ -1626,6 +1640,7 @@ int aqEnd(t4_ctx *c, AqResult *res) {
     c->aqRecords += *(const unsigned *)(o + pTail + 24);
     c->aqHits += (int64_t) * (const unsigned long long *)(o + pTail + 16);
     c->aqLastTicks = (const int32_t *)(o + q.pTick); c->aqLastN = n;
+    c->aqLastStable = (const int32_t *)(o + q.pStab);
     res->counts = (const int32_t *)(o + q.pCnt); res->base = (const int32_t *)(o + q.pBase);
     res->ov = (const t4_overlap *)c->aqPool; res->ext = res->ov + rec; res->ret = (const int32_t *)(res->ext + rec);
     return T4_OK;
@@ -1677,6 +1692,14 @@ int t4_add_query_last_call(t4_ctx *c, double *kernel_ms, const int32_t **ticks10
   if (!c) return T4_ERR_ARG;
   if (kernel_ms) *kernel_ms = c->aqLastMs;
   if (ticks10ns) *ticks10ns = c->aqLastTicks;
+  if (n) *n = c->aqLastN;
+  return T4_OK;
+}
+
+// per read of the last finished AddRead query call on this ctx: 1 when T4QueryArgs::statsStable says so (n entries, valid until the next call)
+int t4_add_query_last_stable(t4_ctx *c, const int32_t **flags, int *n) {
+  if (!c || !flags) return T4_ERR_ARG;
+  *flags = c->aqLastStable;
   if (n) *n = c->aqLastN;
   return T4_OK;
 }

@@ -495,6 +495,7 @@ struct t4_assembler : IndexListener {
     unsigned char tier = 0;      // the last query of this read ended on the global-scratch tier
     bool fragile = false;        // any change of one of its keys' lists invalidates it
     int slack = 0;               // tolerated hit-set changes left before possibleOverlapCnt could pass 100 (SeqSet.hpp:813-823)
+    bool statsStable = false;    // the query itself found that edits of small groups cannot move novelMinHitRequired (T4QueryArgs::statsStable): exact, needs no slack
     GroupTable groups;
     // a (re-)query of this entry is running on a lane: commits since its launch are examined against its dependency sets like
     // those of an entry that holds a result; `killed` = one of them invalidated it (the result is dropped when it arrives),
@@ -557,6 +558,7 @@ struct t4_assembler : IndexListener {
   int64_t baseUsed = 0;            // device arena of consensus chars / posWeight predicate bytes (one offset space)
   std::vector<int> dirtySeqs;
   bool liveReset = true;           // the next delta describes the whole image (first upload, k change)
+  int64_t toleratedStable = 0, invLongLists = 0;
   int64_t deltas = 0, deltaBytes = 0, rounds = 0, readsQueried = 0, invKey = 0, invCross = 0, invRegion = 0, invShift = 0, invContig = 0, invFragile = 0, tolerated = 0;
   double secDelta = 0, secGroups = 0, secEvents = 0, secRegister = 0, secPrefetch = 0, secAddTotal = 0;
 
@@ -1563,7 +1565,7 @@ void t4_assembler::processEvents() {
         const KOcc &o = winKmers.nodes[nd];
         Cached &e = *pool[o.slot];
         if (e.uid != o.uid || !e.standing()) continue;
-        if (e.fragile) { kill(e, invFragile); continue; }
+        if (e.fragile) { kill(e, invFragile); ++invLongLists; continue; }
         for (uint32_t plus = 0; plus < 2 && e.standing(); ++plus) {
           const int n = (plus ? o.f : o.r) * (ev.delta > 0 ? ev.delta : -ev.delta);
           if (!n) continue;
@@ -1577,6 +1579,7 @@ void t4_assembler::processEvents() {
             if (g) g->cnt = g->cnt > (uint32_t)n ? g->cnt - (uint32_t)n : 0;
           }
           ++tolerated;
+          if (e.statsStable) { ++toleratedStable; continue; }   // exact: the statistics of this read's query cannot move (overlapsFromKeys)
           if (--e.slack < 0) { kill(e, invFragile); break; }
         }
       }
@@ -1632,7 +1635,7 @@ int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive
     L.uids[i] = c.uid; L.hint[i] = c.tier;
     L.bases += c.read; L.offs.push_back((int64_t)L.bases.size()); L.bcs[i] = c.barcode; L.sts[i] = c.strand;
     L.fac[i] = (c.barcode == -1 && !repetitive) ? 1.0 : 2.0;   // ExtendOverlap's mismatch factor (SeqSet.hpp:3597-3598)
-    c.inflight = true; c.killed = false; c.shifts.clear();
+    c.inflight = true; c.killed = false; c.shifts.clear(); c.statsStable = false;
   }
   if (L.bases.empty()) L.bases.push_back('A');
   {
@@ -1692,11 +1695,15 @@ int t4_assembler::harvest(Lane &L) {
     for (int i = 0; i < m && i < nn; ++i) fprintf(roundLog, " %d/%d/%d/%d", ticks ? ticks[i] / 100 : -1, cnts[i], (int)L.hint[i], pool[L.slots[i]]->uid == L.uids[i] ? (int)pool[L.slots[i]]->killed : 2);
     fputc('\n', roundLog);
   }
+  const int32_t *stable = nullptr; int nStable = 0;
+  static const bool noStable = getenv("T4_NO_STABLE_STATS") != nullptr;   // A/B aid: the slack rule for every entry, as before round 3
+  if (!noStable) (void)t4_add_query_last_stable(L.ctx, &stable, &nStable);
   for (int i = 0; i < m; ++i) {
     Cached &c = *pool[L.slots[i]];
     if (c.uid != L.uids[i] || !c.inflight) continue;   // the entry was retired (or re-announced) meanwhile
     c.inflight = false;
     c.tier = L.hint[i];
+    c.statsStable = stable && i < nStable && stable[i] == 1;
     if (c.killed) { c.killed = false; c.shifts.clear(); ++killedInFlight; continue; }
     c.cnt = cnts[i];
     const int k2 = c.cnt > 0 ? c.cnt : 0;
@@ -2009,6 +2016,8 @@ int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n) {
             a->secAddTotal, a->secPrefetch, a->secLaunch, a->secDelta, a->secGroups, a->secRegister, a->secHarvest, a->secEvents, a->index.secOps);
     fprintf(stderr, "timing: query lanes %d: %lld launches (%lld for a head without a result), %lld waits for the head's lane in %.3f s, %lld queries killed in flight\n",
             (int)a->lanes.size(), (long long)a->launches, (long long)a->launchesUrgent, (long long)a->headWaits, a->secHeadWait, (long long)a->killedInFlight);
+    fprintf(stderr, "timing: tolerated index edits %lld, of which %lld met an entry whose group statistics cannot move (no budget spent); tolerance kills %lld, of which %lld for lists beyond 10000 postings\n",
+            (long long)a->tolerated, (long long)a->toleratedStable, (long long)a->invFragile, (long long)a->invLongLists);
   }
   return T4_OK;
 }

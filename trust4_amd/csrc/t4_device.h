@@ -155,7 +155,8 @@ struct T4QueryArgs {
   T4OverlapOut *outDev;
   int *recRead;
   int leanExt;               // mode 4: records of overlaps whose extension meets an indel carry exact coordinates and return value only (extendOverlaps)
-  int *readTicks;            // mode 4, nullable: wall-clock ticks (10 ns) one workgroup spent on the read (the latency a dependent round pays)
+  int *readTicks;
+  int *statsStable;          // per read: 1 when the group statistics of GetOverlapsFromHits (SeqSet.hpp:784-823) cannot move under index edits that leave every group of three or more hits alone (null: not wanted)            // mode 4, nullable: wall-clock ticks (10 ns) one workgroup spent on the read (the latency a dependent round pays)
   // per-read set images (per-barcode contig sets): read r is matched against views[viewOf[r]]
   const T4IndexView *views;
   const int *viewOf;

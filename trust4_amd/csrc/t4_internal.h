@@ -57,6 +57,7 @@ int t4_add_query_pool_end(t4_ctx *ctx, const int32_t **counts, const int32_t **b
 // AddRead query path of this ctx, 7 values: calls, reads, launches of the global-scratch tier, reads it served, result records,
 // microseconds of its kernels (HIP events on the ctx's stream), _hit records its seed stages emitted
 int t4_add_query_stats(t4_ctx *ctx, int64_t *out7);
+int t4_add_query_last_stable(t4_ctx *ctx, const int32_t **flags, int *n);   // see T4QueryArgs::statsStable
 int t4_add_query_last_call(t4_ctx *ctx, double *kernel_ms, const int32_t **ticks10ns, int *n);   // development aid (T4_ROUND_LOG)
 
 }  // extern "C"

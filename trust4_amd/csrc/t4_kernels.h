@@ -691,8 +691,9 @@ __device__ __forceinline__ bool ovLess(const OvRec &a, const OvRec &b, bool scor
 __device__ unsigned long long g_phaseCycles[T4_NPHASE];
 __device__ unsigned long long g_dbgCount[8];   // 0 jobs, 1 pending (banded) jobs, 2 wave-DP steps, 3 scratch fallbacks, 4 fallback cells, 5 fallback cycles, 6 overhang DPs (four per wavefront), 7 of which leave the diagonal
 #define DBG_ADD(i, v) do { atomicAdd(&g_dbgCount[i], (unsigned long long)(v)); } while (0)
+__device__ unsigned long long g_phaseByOverlaps[4 * T4_NPHASE];   // the same, per read of an AddRead query, by its number of overlaps: < 5, < 20, <= 64, more
 #define PHASE_MARK(ws, id)                                                                  \
-  do { if (threadIdx.x == 0) { long long now_ = clock64(); atomicAdd(&g_phaseCycles[(ws)->curPhase], (unsigned long long)(now_ - (ws)->phaseT0)); (ws)->phaseT0 = now_; (ws)->curPhase = (id) + (ws)->phaseBase; } } while (0)
+  do { if (threadIdx.x == 0) { long long now_ = clock64(); atomicAdd(&g_phaseCycles[(ws)->curPhase], (unsigned long long)(now_ - (ws)->phaseT0)); (ws)->phaseLocal[(ws)->curPhase & (T4_NPHASE - 1)] += (unsigned)(now_ - (ws)->phaseT0); (ws)->phaseT0 = now_; (ws)->curPhase = (id) + (ws)->phaseBase; } } while (0)
 #define PHASE_MARK_RED(red, id) PHASE_MARK((WaveState *)((char *)(red) - offsetof(WaveState, red)), id)
 #else
 #define PHASE_MARK(ws, id) do { } while (0)
@@ -725,8 +726,13 @@ struct WaveState { // wave-uniform scalars kept in LDS
   int red[16];
   short contigA[64], contigB[64];
   int nvPossible[2], nvLongest[2];   // novel group statistics of GetOverlapsFromHits (filter 1)
+  int nvN4[2], nvN5[2], nvSmax[2];   // groups of at least 4 / 5 hits and the largest group, TRUE sizes (the statistics measure a group one short or in full)
+  int statsStable;                   // no pass of this read so far whose novelMinHitRequired could move (see overlapsFromKeys)
   unsigned hhBest[2];        // HasHitInSet: per strand, (distinct read offsets << 16) | (0xFFFF - bucket rank) of the best bucket
   long long phaseT0; int curPhase, phaseBase;
+#ifdef T4_PHASE_TIMING
+  unsigned phaseLocal[T4_NPHASE];
+#endif
 };
 
 // Build segment chars (forward + reverse complement of the segment) from the packed read.
@@ -1420,7 +1426,8 @@ void chainRunsRows(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int nCand,
 // impossible while H <= 65535 only if ... it is handled by the caller refusing such reads (status).
 __device__ void overlapsFromKeys(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int Hv, int hitLenRequired, int filter) {
   const int lane = tid(), NT = nthr(), K = ix.k;
-  if (lane == 0) { ws->novelMin[0] = ws->novelMin[1] = 3; ws->candCount = 0; ws->nvPossible[0] = ws->nvPossible[1] = 0; ws->nvLongest[0] = ws->nvLongest[1] = 0; }
+  if (lane == 0) { ws->novelMin[0] = ws->novelMin[1] = 3; ws->candCount = 0; ws->nvPossible[0] = ws->nvPossible[1] = 0; ws->nvLongest[0] = ws->nvLongest[1] = 0;
+                   ws->nvN4[0] = ws->nvN4[1] = ws->nvN5[0] = ws->nvN5[1] = ws->nvSmax[0] = ws->nvSmax[1] = 0; }
   if (filter == 1 && ix.hasNovel) {
     // Group statistics of the novel sequences (SeqSet.hpp:784-811). The reference walks the groups with `i = j` followed
     // by the loop's `++i`, i.e. it skips the first hit of the group that follows a measured one (a one-hit group vanishes,
@@ -1460,6 +1467,12 @@ __device__ void overlapsFromKeys(const T4IndexView &ix, WaveMem &wm, WaveState *
           if (m > 3) atomicAdd(&ws->nvPossible[plus], 1);
           atomicMax(&ws->nvLongest[plus], m);
         }
+        if (nT >= 4 && !seqIsRef(ix, KEY_IDX(k0))) {
+          const int plus = KEY_PLUS(k0);
+          atomicAdd(&ws->nvN4[plus], 1);
+          if (nT >= 5) atomicAdd(&ws->nvN5[plus], 1);
+          atomicMax(&ws->nvSmax[plus], nT);
+        }
       }
     }
     __syncthreads();
@@ -1470,6 +1483,22 @@ __device__ void overlapsFromKeys(const T4IndexView &ix, WaveMem &wm, WaveState *
         else if (possible > 10000) ws->novelMin[t] = longest / 2;
         else if (possible > 1000) ws->novelMin[t] = longest / 3;
         else if (possible > 100) ws->novelMin[t] = longest / 4;
+        // Could these thresholds move while every group of three or more hits stays as it is? An index edit that only touches
+        // smaller groups changes which groups the walk above measures one short: a group of TRUE size n is measured n or
+        // n - 1 whatever happens around it, so `possible` stays within [groups of >= 5, groups of >= 4] and `longest`
+        // within [largest - 1, largest]. When both ends give the same threshold (and no smaller group can reach it), the
+        // result of this pass does not depend on such edits: the ordered contig builder keeps the read's cached result.
+        const int lo = ws->nvN5[t], hi = ws->nvN4[t], big = ws->nvSmax[t];
+        const int cLo = lo > 100000 ? 4 : lo > 10000 ? 3 : lo > 1000 ? 2 : lo > 100 ? 1 : 0;
+        const int cHi = hi > 100000 ? 4 : hi > 10000 ? 3 : hi > 1000 ? 2 : hi > 100 ? 1 : 0;
+        bool ok = cLo == cHi;
+        if (ok && cLo > 0) {
+          const int a = big - 1 > 0 ? big - 1 : 0;
+          const int fa = cLo == 4 ? (int)(a * 0.75) : cLo == 3 ? a / 2 : cLo == 2 ? a / 3 : a / 4;
+          const int fb = cLo == 4 ? (int)(big * 0.75) : cLo == 3 ? big / 2 : cLo == 2 ? big / 3 : big / 4;
+          ok = fa == fb && fa >= 3;
+        }
+        if (!ok) ws->statsStable = 0;
       }
   }
   __syncthreads();
@@ -3321,7 +3350,7 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
   const int lane = tid(), NT = nthr();
   const int len = bv.len[r];
   unsigned long long hitTotal = 0;
-  if (lane == 0) { ws->overflow = 0; ws->unsupported = 0; ws->finCount = 0; ws->nContig = 0; ws->ovCount = 0; }
+  if (lane == 0) { ws->overflow = 0; ws->unsupported = 0; ws->finCount = 0; ws->nContig = 0; ws->ovCount = 0; ws->statsStable = 1; }
 #ifdef T4_PHASE_TIMING
   if (lane == 0) { ws->phaseT0 = clock64(); ws->phaseBase = wm.ldsArrays ? 0 : 32; ws->curPhase = ws->phaseBase; }
 #endif
@@ -3337,6 +3366,7 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
     int ret = overlapsFromSegment<VARIANT != 0>(ix, wm, ws, len, qa.strandPerRead[r], barcode, qa.skipRepeats != 0, 0, sc, hitTotal);
     if (ret == -2) return false;
     int n = ret > 0 ? ret : 0;
+    if (lane == 0 && qa.statsStable) qa.statsStable[r] = ws->statsStable;
     if (lane == 0) {   // room for this read's records in the result pool
       const int base = n > 0 ? (int)atomicAdd(qa.poolCursor, (unsigned)n) : 0;
       ws->red[15] = (base + n > qa.poolCap) ? -1 : base;
@@ -3638,6 +3668,9 @@ void queryKernel(T4IndexView ixArg, T4BatchView bvArg, T4Work wkArg, T4QueryArgs
   // shows). The variants that meet contig sets keep ONE copy per workgroup in LDS instead; the reference-set variants (VARIANT 0),
   // whose register budget is tuned, stay as they were.
   constexpr bool SHARED_ARGS = VARIANT != 0;
+#ifdef T4_PHASE_TIMING
+  if (threadIdx.x < T4_NPHASE) s_ws.phaseLocal[threadIdx.x] = 0;
+#endif
   __shared__ T4IndexView s_ix;
   __shared__ T4BatchView s_bv;
   __shared__ T4Work s_wk;
@@ -3721,6 +3754,12 @@ void queryKernel(T4IndexView ixArg, T4BatchView bvArg, T4Work wkArg, T4QueryArgs
 #ifdef __HIPCC__
       if (VARIANT == 1 && qa.readTicks) qa.readTicks[r] = (int)(wall_clock64() - tick0);
 #endif
+#ifdef T4_PHASE_TIMING
+      if (VARIANT == 1 && qa.mode == 4) {   // this read's phases into the class of its overlap count
+        const int nOv = qa.counts[r], cls = nOv < 5 ? 0 : nOv < 20 ? 1 : nOv <= 64 ? 2 : 3;
+        for (int p_ = 0; p_ < T4_NPHASE; ++p_) if (s_ws.phaseLocal[p_]) { atomicAdd(&g_phaseByOverlaps[cls * T4_NPHASE + p_], (unsigned long long)s_ws.phaseLocal[p_]); s_ws.phaseLocal[p_] = 0; }
+      }
+#endif
       if (!done) {
         if (wk.nextList) { int slot = atomicAdd(wk.nextCount, 1); wk.nextList[slot] = (int)r; }
         else wk.status[r] = 2;
@@ -3738,7 +3777,9 @@ void queryKernel(T4IndexView ixArg, T4BatchView bvArg, T4Work wkArg, T4QueryArgs
 // boundaries), rebuilds the read's characters from its packed words and runs the same extendOverlaps() the query kernel runs
 // inside a workgroup. The records of one read no longer wait for each other in one workgroup's eight wavefronts: a read that
 // overlaps two thousand contigs becomes a few hundred independent blocks.
+#ifndef T4_EXT_NREC
 #define T4_EXT_NREC 8
+#endif
 __global__ __launch_bounds__(64) void extendKernel(T4IndexView ix, T4BatchView bv, T4QueryArgs qa, int recBegin) {
   __shared__ OvRec s_fin[T4_EXT_NREC];
   __shared__ unsigned short s_ord[T4_EXT_NREC];
