@@ -459,7 +459,8 @@ int main(int argc, char *argv[]) {
   // T4_GPU_MATEOVERLAP=1 (opt-in this round): the two AlignAlgo::IsMateOverlap tests of every pair of a block come from
   // t4_mate_overlap (one pair per wavefront) instead of the host threads; the merge itself stays on the host.
   const bool gpuMate = getenv("T4_GPU_MATEOVERLAP") && atoi(getenv("T4_GPU_MATEOVERLAP")) != 0;
-  auto flushBlock = [&]() {   // ProcessRead of every pair of the block on the host threads, results appended in input order
+  // (a block is processed on the host threads WHILE the next one is parsed: processBlock runs on its own thread, one block at a time)
+  auto processBlock = [&](std::vector<InPair> &block) {   // ProcessRead of every pair of the block on the host threads, results appended in input order
     auto t0 = std::chrono::steady_clock::now();
     std::vector<std::vector<SortRead>> outs(block.size());
     std::vector<int32_t> pre;
@@ -495,6 +496,15 @@ int main(int argc, char *argv[]) {
     secProcess += std::chrono::duration<double>(t1 - t0).count();
     secMerge += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
   };
+  std::vector<InPair> inProcess;
+  std::thread processThread;
+  auto flushBlock = [&]() {
+    if (processThread.joinable()) processThread.join();
+    inProcess.swap(block);
+    block.clear();
+    if (block.capacity() < BLOCK) block.reserve(BLOCK);
+    if (!inProcess.empty()) processThread = std::thread([&]() { processBlock(inProcess); });
+  };
   int firstReadLen = -1, nIn = 0;
   std::unordered_map<std::string, int> barcodeStrToInt, umiStrToInt;
   std::vector<std::string> barcodeIntToStr;
@@ -521,17 +531,17 @@ int main(int argc, char *argv[]) {
     }
     SortRead nr, mate;
     nr.barcode = mate.barcode = barcode; nr.umi = mate.umi = umi;
-    nr.id = reads.id; nr.read = reads.seq; nr.qual = reads.qual; nr.hasQual = reads.hasQual;
+    nr.id.swap(reads.id); nr.read.swap(reads.seq); nr.qual.swap(reads.qual); nr.hasQual = reads.hasQual;   // the reader hands every record over once
     ++nIn;
     if (nIn % 100000 == 0) PrintLog("Read in and count kmers for %d reads.", nIn);
     if (firstReadLen == -1) {
-      firstReadLen = (int)reads.seq.size();
+      firstReadLen = (int)nr.read.size();
       if (firstReadLen > 200) { fprintf(stderr, "trust4-hip: long-read mode (first read > 200 bp, main.cpp:1467-1481) is not built.\n"); return EXIT_FAILURE; }
     }
     bool haveMate = false;
     if (mateReads.next()) {
       haveMate = true;
-      mate.id = mateReads.id; mate.read = mateReads.seq; mate.qual = mateReads.qual; mate.hasQual = mateReads.hasQual;
+      mate.id.swap(mateReads.id); mate.read.swap(mateReads.seq); mate.qual.swap(mateReads.qual); mate.hasQual = mateReads.hasQual;
       ++nIn;
       if (nIn % 100000 == 0) PrintLog("Read in and count kmers for %d reads.", nIn);
     } else if (hasMate) { fprintf(stderr, "The two mate-pair read files have different number of reads.\n"); initThread.join(); exit(1); }
@@ -539,6 +549,7 @@ int main(int argc, char *argv[]) {
     if (block.size() >= BLOCK) flushBlock();
   }
   flushBlock();
+  if (processThread.joinable()) processThread.join();
   if (getenv("T4_TIMING")) PrintLog("timing: input parsed and mates processed (ProcessRead %.2f s on %d threads, merge %.2f s)", secProcess, threadCnt, secMerge);
   int readCnt = (int)sortedReads.size();
   int maxReadLen = 0;
