@@ -85,14 +85,14 @@ def _barcode_case(tmp_path, driver, pairs, cells, seed, env=None):
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not shipped")
 @pytest.mark.parametrize("pairs,cells,seed,lanes,window,threads", [(3000, 60, 4, 4096, 4, 8), (3000, 60, 5, 7, 1, 1)])
 def test_barcode_mode_matches_reference_binary(tmp_path, pairs, cells, seed, lanes, window, threads):
-    _barcode_case(tmp_path, _driver(), pairs, cells, seed, {"T4_LANES": str(lanes), "T4_WINDOW": str(window), "T4_THREADS": str(threads)})
+    _barcode_case(tmp_path, _driver(), pairs, cells, seed, {"T4_LANES": str(lanes), "T4_WINDOW": str(window), "T4_THREADS": str(threads), "T4_SORT_MIN": "256"})
 
 
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
 def test_barcode_mode_emulated(tmp_path):
     """the same driver source linked against the emulator build of the kernels (test infrastructure): tiny case for the CPU suite"""
     exe = _emulated_driver()
-    _barcode_case(tmp_path, exe, 160, 8, 6, {"T4_LANES": "8", "T4_WINDOW": "3", "T4_THREADS": "2"})
+    _barcode_case(tmp_path, exe, 160, 8, 6, {"T4_LANES": "8", "T4_WINDOW": "3", "T4_THREADS": "2", "T4_SORT_MIN": "64"})   # (the read list sorted on the threads)
 
 
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
@@ -317,7 +317,7 @@ def _bulk_case(tmp_path, driver, pairs, clones, seed, env, threads="4"):
 
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
 @pytest.mark.parametrize("env", [{"T4_AQ_CAP_LIMIT": "120"}, {"T4_AQ_FORCE_GLOBAL": "1"}, {"T4_QUERY_AHEAD": "3", "T4_WINDOW": "7"}, {"T4_AQ_EXTEND_DEFER": "1"}, {"T4_AQ_EXTEND_DEFER": "0"},
-                                 {"T4_AQ_POOL_CAP": "8", "T4_AQ_EXTEND_DEFER": "1"}, {"T4_AQ_POOL_CAP": "5"}])
+                                 {"T4_AQ_POOL_CAP": "8", "T4_AQ_EXTEND_DEFER": "1"}, {"T4_AQ_POOL_CAP": "5"}, {"T4_SORT_MIN": "64"}])
 def test_bulk_live_set_paths_emulated(tmp_path, env):
     """Bulk mode = the live set (device image by t4_index_apply_delta, sliding speculation window). The testing aids send a
     small input down the paths large sets take: reads that outgrow the LDS arrays and go on in global scratch inside the launch

@@ -250,6 +250,58 @@ bool compReadWithBarcode(const SortRead &a, const SortRead &b) {   // main.cpp:1
   return a < b;
 }
 
+// std::sort(v.begin(), v.end(), less) on the host threads. The reference sorts with std::sort, whose result is only defined by the
+// comparator when no two elements tie: the read list is sorted as a permutation on the threads, and only if no two neighbours of the result tie -- the order is then THE sorted order, whatever algorithm produced it --
+// is the permutation applied. With a tie (or when the caller knows the comparator is not a strict weak order for its input) the
+// list goes through std::sort itself, as before.
+template <class Less> void sortReadsOnThreads(std::vector<SortRead> &v, int threads, Less less, bool orderIsStrict = true) {
+  const size_t n = v.size();
+  static const size_t minN = getenv("T4_SORT_MIN") ? (size_t)atoll(getenv("T4_SORT_MIN")) : 65536;   // testing aid: small inputs through the threaded path
+  const size_t minChunk = minN / 64 > 8 ? minN / 64 : 8;
+  if (threads <= 1 || n < minN || n < 2 * minChunk || !orderIsStrict) { std::sort(v.begin(), v.end(), less); return; }
+  // sample sort of the permutation: splitters from a sorted sample, every element classified against them (a binary search), the
+  // buckets sorted side by side -- no serial merge at the end
+  int parts = 1;
+  while (parts < 2 * threads) parts *= 2;
+  if (parts > 256) parts = 256;   // (bucket numbers are kept in bytes)
+  while (parts > 1 && (size_t)parts * minChunk > n) parts /= 2;
+  auto byRead = [&](uint32_t a, uint32_t b) { return less(v[a], v[b]); };
+  std::vector<uint32_t> sample;
+  { const size_t want = (size_t)parts * 48 < n ? (size_t)parts * 48 : n; for (size_t i = 0; i < want; ++i) sample.push_back((uint32_t)(n * i / want)); }
+  std::sort(sample.begin(), sample.end(), byRead);
+  std::vector<uint32_t> split;
+  for (int p = 1; p < parts; ++p) split.push_back(sample[sample.size() * (size_t)p / (size_t)parts]);
+  const int slices = threads * 4;
+  auto sliceAt = [&](int i) { return n * (size_t)i / (size_t)slices; };
+  std::vector<unsigned char> bucketOf(n);
+  std::vector<size_t> counts((size_t)slices * parts, 0);
+  parallelFor(slices, threads, [&](long long sl) {
+    size_t *cnt = &counts[(size_t)sl * parts];
+    for (size_t i = sliceAt((int)sl); i < sliceAt((int)sl + 1); ++i) {
+      int lo = 0, hi = (int)split.size();   // bucket = number of splitters that are less than the element
+      while (lo < hi) { const int mid = (lo + hi) / 2; if (less(v[split[(size_t)mid]], v[i])) lo = mid + 1; else hi = mid; }
+      bucketOf[i] = (unsigned char)lo; ++cnt[lo];
+    }
+  });
+  std::vector<size_t> bucketStart((size_t)parts + 1, 0);
+  for (int p = 0; p < parts; ++p) { size_t c = 0; for (int sl = 0; sl < slices; ++sl) c += counts[(size_t)sl * parts + p]; bucketStart[(size_t)p + 1] = bucketStart[(size_t)p] + c; }
+  { std::vector<size_t> run(bucketStart.begin(), bucketStart.end() - 1);   // where each slice writes inside each bucket
+    for (int sl = 0; sl < slices; ++sl) for (int p = 0; p < parts; ++p) { const size_t c = counts[(size_t)sl * parts + p]; counts[(size_t)sl * parts + p] = run[(size_t)p]; run[(size_t)p] += c; } }
+  std::vector<uint32_t> perm(n);
+  parallelFor(slices, threads, [&](long long sl) {
+    size_t *at = &counts[(size_t)sl * parts];
+    for (size_t i = sliceAt((int)sl); i < sliceAt((int)sl + 1); ++i) perm[at[bucketOf[i]]++] = (uint32_t)i;
+  });
+  parallelFor(parts, threads, [&](long long p) { std::sort(perm.begin() + bucketStart[(size_t)p], perm.begin() + bucketStart[(size_t)p + 1], byRead); });
+  const uint32_t *src = perm.data();
+  std::atomic<bool> tie(false);
+  parallelFor((long long)n - 1, threads, [&](long long i) { if (!less(v[src[i]], v[src[i + 1]])) tie.store(true, std::memory_order_relaxed); });
+  if (tie.load()) { std::sort(v.begin(), v.end(), less); return; }
+  std::vector<SortRead> out(n);
+  parallelFor((long long)n, threads, [&](long long i) { out[(size_t)i] = std::move(v[src[i]]); });
+  v.swap(out);
+}
+
 bool isLowComplexity(const std::string &s) {   // main.cpp:183-205
   int cnt[5] = {0, 0, 0, 0, 0};
   const int n = (int)s.size();
@@ -665,7 +717,11 @@ int main(int argc, char *argv[]) {
   for (int i = 0; i < readCnt; ++i) { sortedReads[i].info = i; sortedReads[i].mateIdx = -1; }
   for (int i = 0; i < readCnt - 1; ++i)
     if (sortedReads[i].id == sortedReads[i + 1].id) { sortedReads[i].mateIdx = i + 1; sortedReads[i + 1].mateIdx = i; ++i; }
-  std::sort(sortedReads.begin(), sortedReads.end());
+  {
+    const auto ts0 = std::chrono::steady_clock::now();
+    sortReadsOnThreads(sortedReads, threadCnt, [](const SortRead &a, const SortRead &b) { return a < b; });
+    if (getenv("T4_TIMING")) PrintLog("timing: read list sorted in %.2f s on %d threads", std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count(), threadCnt);
+  }
   mark("sorted");
   PrintLog("Finish sorting the reads.");
 
@@ -700,7 +756,11 @@ int main(int argc, char *argv[]) {
 
   // ---- barcode order: by barcode, then by the barcode-wise 21-mer support (main.cpp:1123-1193)
   if (hasBarcode) {
-    std::sort(sortedReads.begin(), sortedReads.end(), compReadWithBarcode);
+    {   // compReadWithBarcode (main.cpp:128-136) is not a strict weak order once a read without barcode stands beside barcoded ones
+      bool allBarcoded = true;
+      for (const SortRead &r : sortedReads) if (r.barcode == -1) { allBarcoded = false; break; }
+      sortReadsOnThreads(sortedReads, threadCnt, compReadWithBarcode, allBarcoded);
+    }
     PrintLog("Get barcode-wise kmer count.");
     std::vector<std::pair<int, int>> groups;
     for (int i = 0; i < readCnt;) {
