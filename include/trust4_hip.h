@@ -174,6 +174,17 @@ int t4_assign_strands(t4_index *ix, t4_batch *b, const int32_t *strands, int32_t
 int t4_posweight_recompute(t4_index *ix, t4_batch *b, const t4_overlap *assign, const int32_t *mult, int32_t *posweight,
                            int64_t posweight_cap);
 
+/* The same followed by SeqSet::UpdateConsensus (SeqSet.hpp:4537-4588; UpdateAllConsensus, 4525-4535) of every contig from the
+ * rebuilt columns (in main.cpp the tail's ExtendSeqFromReads stands between the two, 2118 ... 2154, and runs from the reference's
+ * translation unit: the binding of INTEGRATION.md uses t4_posweight_recompute; this entry is the consensus kernel for callers that
+ * keep their contigs in the engine): per column the base with the largest count -- the first of equals -- replaces the consensus base when
+ * that one is strictly rarer; columns without counts keep theirs. consensus receives the bases of all contigs in id order, without
+ * separators (consensus_cap = its capacity), *changed the number of bases that differ from the set's (either may be NULL: without
+ * `consensus` this is t4_posweight_recompute). The k-mer index of a set whose consensus changes is the caller's to rebuild
+ * (UpdateConsensus does it with RemoveIndexFromRead + BuildIndexFromRead of the contig; here: t4_index_clear / add_contig / commit). */
+int t4_consensus_recompute(t4_index *ix, t4_batch *b, const t4_overlap *assign, const int32_t *mult, int32_t *posweight,
+                           int64_t posweight_cap, char *consensus, int64_t consensus_cap, int64_t *changed);
+
 /* AlignAlgo::GlobalAlignment (kind 0; AlignAlgo.hpp:218-424; t_data = chars) or
  * AlignAlgo::GlobalAlignment_PosWeight (kind 1; AlignAlgo.hpp:57-216; t_data = 4 int32 weights per base)
  * for n independent (target, pattern) pairs given as CSR offsets; out4[4*i..] = GetAlignStats of

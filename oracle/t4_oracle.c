@@ -1235,6 +1235,26 @@ void t4o_recompute_posweight(t4o_set *s, int n, const char *const *reads, const 
       if (q->cons[j] != 'N' && q->pw[4 * j] + q->pw[4 * j + 1] + q->pw[4 * j + 2] + q->pw[4 * j + 3] == 0) q->pw[4 * j + nuc(q->cons[j])] = 1;
   }
 }
+/* SeqSet::UpdateConsensus (SeqSet.hpp:4537-4588) of every contig, consensus characters only (UpdateAllConsensus, 4525-4535): per
+ * column the first base with the largest count replaces the consensus base when that one's count is strictly smaller; columns
+ * without counts stay; 'N' reads as base 0 (nucToNum, main.cpp:39-44). The k-mer index of the set is NOT rebuilt here (the
+ * reference removes and re-inserts the contig's k-mers): after this call the set is good for reading consensus strings only.
+ * Returns the number of bases changed. */
+int t4o_update_all_consensus_chars(t4o_set *s) {
+  int i, j, t, changed = 0;
+  for (i = 0; i < s->nseq; ++i) {
+    seq_t *q = &s->seqs[i];
+    if (!q->pw || q->isRef) continue;
+    for (j = 0; j < q->len; ++j) {
+      int mx = 0, tag = 0;
+      for (t = 0; t < 4; ++t) if (q->pw[4 * j + t] > mx) { mx = q->pw[4 * j + t]; tag = t; }
+      if (mx == 0) continue;
+      int cur = q->cons[j] == 'N' ? 0 : nuc(q->cons[j]);
+      if (cur != tag && q->pw[4 * j + cur] < mx) { q->cons[j] = "ACGT"[tag]; ++changed; }
+    }
+  }
+  return changed;
+}
 int t4o_kmer_length(t4o_set *s) { return s->k; }
 void t4o_seq_posweight(t4o_set *s, int i, int *out) { if (s->seqs[i].pw) memcpy(out, s->seqs[i].pw, sizeof(int) * 4 * (size_t)s->seqs[i].len); }
 

@@ -45,6 +45,7 @@ int t4o_extend_overlap(t4o_set *s, const char *read, double mmFactor, const t4o_
 int t4o_assign_read(t4o_set *s, const char *read, int strand, int barcode, t4o_overlap *out);
 /* RecomputePosWeight (SeqSet.hpp:4705-4738) from assigned reads; t4o_seq_posweight reads a contig's weights back (4 ints / base) */
 void t4o_recompute_posweight(t4o_set *s, int n, const char *const *reads, const t4o_overlap *assign);
+int t4o_update_all_consensus_chars(t4o_set *s);   /* UpdateConsensus of every contig, characters only (the index is not rebuilt) */
 void t4o_seq_posweight(t4o_set *s, int i, int *out);
 int t4o_kmer_length(t4o_set *s);
 

@@ -106,6 +106,15 @@ class _SetAPI:
         fn = self._f("recompute_posweight", None, C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(Overlap))
         fn(self.h, n, arr, ov)
 
+    def update_all_consensus_chars(self):
+        """UpdateConsensus of every contig (SeqSet.hpp:4537-4588); the oracle changes the characters only, the reference also its index"""
+        if self.P == "ref_":
+            fn = self._f("update_all_consensus", None, C.c_void_p)
+            fn(self.h)
+            return None
+        fn = self._f("update_all_consensus_chars", C.c_int, C.c_void_p)
+        return fn(self.h)
+
     def posweight(self, i):
         n = self._slen(self.h, i)
         out = np.zeros((n, 4), dtype=np.int32)

@@ -179,6 +179,11 @@ def run_final_tail_case(eng, o, ix, b, reads, contigs, hit_len):
         assert (got[at:at + ln] == o.posweight(c)).all(), c
         at += ln
     assert got.sum() > sum(lens)
+    # ... followed by UpdateConsensus of every contig (SeqSet.hpp:4537-4588): t4_consensus_recompute; the reads carry substitutions,
+    # so a column covered by such a read alone changes its base
+    got2, cons2, changed2 = ix.consensus_recompute(b, asg, sum(lens), mult)
+    assert (got2 == got).all()
+    r = None
     if Ref.available():
         r = Ref(o_k(o))
         for name, seq, bc, w in contigs:
@@ -186,7 +191,16 @@ def run_final_tail_case(eng, o, ix, b, reads, contigs, hit_len):
         r.recompute_posweight(rep_reads, rep_asg)
         for c in range(len(lens)):
             assert (r.posweight(c) == o.posweight(c)).all(), c
+    exp_changed = o.update_all_consensus_chars()
+    exp_cons = "".join(o.consensus(c) for c in range(len(lens)))
+    assert cons2.decode() == exp_cons and changed2 == exp_changed
+    if r is not None:
+        r.update_all_consensus_chars()
+        assert "".join(r.consensus(c) for c in range(len(lens))) == exp_cons
+    print("UpdateConsensus after RecomputePosWeight: %d of %d bases changed" % (changed2, sum(lens)))
+    assert changed2 > 0
     o.set_novel_similarity(0.9)
+    return changed2
 
 
 def o_k(o):

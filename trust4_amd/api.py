@@ -74,6 +74,7 @@ def _load():
         "t4_mate_overlap": (I, [P, I, P, P, P, P, P, I, P]), "t4_has_hit": (I, [P, P, I, P]),
         "t4_extend": (I, [P, P, I, P, P, C.c_double, P, P]), "t4_assign": (I, [P, P, I, P, P]), "t4_assign_strands": (I, [P, P, P, P, P]),
         "t4_posweight_recompute": (I, [P, P, P, P, P, C.c_int64]),
+        "t4_consensus_recompute": (I, [P, P, P, P, P, C.c_int64, P, C.c_int64, P]),
         "t4_assembler_create": (I, [P, I, I, C.POINTER(P)]), "t4_assembler_destroy": (None, [P]),
         "t4_assembler_set_params": (I, [P, I, I, C.c_double]),
         "t4_assembler_input_novel_read": (I, [P, C.c_char_p, C.c_char_p, I, I]),
@@ -481,6 +482,18 @@ class Index:
         self.eng.check(self.eng.lib.t4_posweight_recompute(self.h, batch.h, assign.ctypes.data_as(C.c_void_p), None if m is None else m.ctypes.data_as(C.c_void_p),
                                                            out.ctypes.data_as(C.c_void_p), out.size))
         return out
+
+    def consensus_recompute(self, batch, assign, total_bases, mult=None):
+        """RecomputePosWeight + UpdateConsensus of every contig (SeqSet.hpp:4705-4738, 4537-4588) -> (int32 [total_bases, 4], bytes of
+        the new consensus of all contigs in id order, number of changed bases)"""
+        assign = np.ascontiguousarray(assign, dtype=OV_DTYPE)
+        out = np.zeros((total_bases, 4), dtype=np.int32)
+        cons = C.create_string_buffer(max(total_bases, 1))
+        changed = C.c_int64(0)
+        m = None if mult is None else np.ascontiguousarray(mult, dtype=np.int32)
+        self.eng.check(self.eng.lib.t4_consensus_recompute(self.h, batch.h, assign.ctypes.data_as(C.c_void_p), None if m is None else m.ctypes.data_as(C.c_void_p),
+                                                           out.ctypes.data_as(C.c_void_p), out.size, C.cast(cons, C.c_void_p), total_bases, C.byref(changed)))
+        return out, cons.raw[:total_bases], int(changed.value)
 
     def has_hit(self, batch, mode=0):
         """SeqSet::HasHitInSet per read -> int32 [n] of -1 / 0 / 1"""

@@ -1272,6 +1272,11 @@ int t4_assign_strands(t4_index *ix, t4_batch *b, const int32_t *strands, int32_t
 }
 
 int t4_posweight_recompute(t4_index *ix, t4_batch *b, const t4_overlap *assign, const int32_t *mult, int32_t *posweight, int64_t posweight_cap) {
+  return t4_consensus_recompute(ix, b, assign, mult, posweight, posweight_cap, nullptr, 0, nullptr);
+}
+
+int t4_consensus_recompute(t4_index *ix, t4_batch *b, const t4_overlap *assign, const int32_t *mult, int32_t *posweight, int64_t posweight_cap,
+                           char *consensus, int64_t consensus_cap, int64_t *changed) {
   if (!ix || !b || (b->n > 0 && !assign) || !posweight) return T4_ERR_ARG;
   t4_ctx *c = ix->ctx;
   if (!ix->committed) return fail(c, T4_ERR_STATE, "index not committed");
@@ -1280,6 +1285,8 @@ int t4_posweight_recompute(t4_index *ix, t4_batch *b, const t4_overlap *assign, 
   int64_t bases = 0;
   for (const HostSeq &q : ix->seqs) { if (q.isRef) return fail(c, T4_ERR_UNSUPPORTED, "t4_posweight_recompute needs a contig set"); bases += (int64_t)q.cons.size(); }
   if (posweight_cap < 4 * bases) return fail(c, T4_ERR_ARG, "posweight buffer holds %lld values, the set needs %lld", (long long)posweight_cap, (long long)(4 * bases));
+  if (consensus && consensus_cap < bases) return fail(c, T4_ERR_ARG, "consensus buffer holds %lld bases, the set has %lld", (long long)consensus_cap, (long long)bases);
+  if (changed) *changed = 0;
   if (bases == 0) return T4_OK;
   (void)hipSetDevice(c->device);
   int r;
@@ -1288,7 +1295,9 @@ int t4_posweight_recompute(t4_index *ix, t4_batch *b, const t4_overlap *assign, 
   const size_t n = (size_t)b->n;
   const size_t cols = (size_t)bases + ix->seqs.size();   // the image's column space: every contig is followed by one terminator column (T4SeqInfo::pwOff)
   if ((r = devAlloc(c, &dCnt, cols * 4))) return r;
-  auto freeAll = [&] { if (dCnt) (void)hipFree(dCnt); if (dMult) (void)hipFree(dMult); if (dAs) (void)hipFree(dAs); };
+  char *dCons = nullptr;
+  unsigned long long *dChanged = nullptr;
+  auto freeAll = [&] { if (dCnt) (void)hipFree(dCnt); if (dMult) (void)hipFree(dMult); if (dAs) (void)hipFree(dAs); if (dCons) (void)hipFree(dCons); if (dChanged) (void)hipFree(dChanged); };
   #define PWCHK(x) do { if ((x) != hipSuccess) { freeAll(); return fail(c, T4_ERR_HIP, "HIP error in t4_posweight_recompute: %s", hipGetErrorString(hipGetLastError())); } } while (0)
   PWCHK(hipMemsetAsync(dCnt, 0, sizeof(int) * cols * 4, c->stream));   // posWeight.SetZero of every contig
   if (n > 0) {
@@ -1308,14 +1317,30 @@ int t4_posweight_recompute(t4_index *ix, t4_batch *b, const t4_overlap *assign, 
     hipLaunchKernelGGL(t4k::posWeightFinishKernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, c->stream, ix->view, dCnt);
     PWCHK(hipGetLastError());
   }
+  std::vector<char> allCons;
+  unsigned long long nChanged = 0;
+  if (consensus) {   // UpdateConsensus of every contig from the columns just rebuilt
+    if ((r = devAlloc(c, &dCons, cols))) { freeAll(); return r; }
+    if ((r = devAlloc(c, &dChanged, 1))) { freeAll(); return r; }
+    PWCHK(hipMemsetAsync(dChanged, 0, sizeof(unsigned long long), c->stream));
+    const int nseq = (int)ix->seqs.size();
+    const int grid = nseq < c->cus * 8 ? nseq : c->cus * 8;
+    hipLaunchKernelGGL(t4k::consensusArgmaxKernel, dim3(grid > 0 ? grid : 1), dim3(256), 0, c->stream, ix->view, (const int *)dCnt, dCons, dChanged);
+    PWCHK(hipGetLastError());
+    allCons.resize(cols);
+    PWCHK(hipMemcpyAsync(allCons.data(), dCons, cols, hipMemcpyDeviceToHost, c->stream));
+    PWCHK(hipMemcpyAsync(&nChanged, dChanged, sizeof nChanged, hipMemcpyDeviceToHost, c->stream));
+  }
   std::vector<int32_t> all(cols * 4);
   PWCHK(hipMemcpyAsync(all.data(), dCnt, sizeof(int) * cols * 4, hipMemcpyDeviceToHost, c->stream));
   PWCHK(hipStreamSynchronize(c->stream));
+  if (changed) *changed = (int64_t)nChanged;
   {   // contig after contig, without the terminator columns
     size_t from = 0, to = 0;
     for (const HostSeq &q : ix->seqs) {
       const size_t ln = q.cons.size();
       if (ln) memcpy(posweight + 4 * to, all.data() + 4 * from, sizeof(int32_t) * 4 * ln);
+      if (ln && consensus) memcpy(consensus + to, allCons.data() + from, ln);
       from += ln + 1; to += ln;
     }
   }

@@ -3876,6 +3876,33 @@ __global__ __launch_bounds__(256) void posWeightFinishKernel(T4IndexView ix, int
   }
 }
 
+// SeqSet::UpdateConsensus (SeqSet.hpp:4537-4588) of every contig from posWeight columns laid out like the image's (T4SeqInfo::pwOff):
+// the base with the largest count (the first of equals) replaces the consensus base when that one is strictly rarer; columns without
+// any count keep their base; an 'N' stands for base 0 as in the reference's nucToNum table. consOut: the column space of `counts`.
+// Elementwise, 17 bytes read and one written per column.
+__global__ __launch_bounds__(256) void consensusArgmaxKernel(T4IndexView ix, const int *counts, char *consOut, unsigned long long *changed) {
+  unsigned long long mine = 0;
+  for (int c = blockIdx.x; c < ix.nseq; c += gridDim.x) {
+    const T4SeqInfo sq = ix.seqs[c];
+    if (sq.pwOff < 0) continue;
+    for (int j = threadIdx.x; j < sq.len; j += blockDim.x) {
+      const int4 w = *(const int4 *)(counts + ((long long)sq.pwOff + j) * 4);
+      const char ch = ix.cons[sq.consOff + j];
+      int mx = 0, tag = 0;
+      if (w.x > mx) { mx = w.x; tag = 0; }
+      if (w.y > mx) { mx = w.y; tag = 1; }
+      if (w.z > mx) { mx = w.z; tag = 2; }
+      if (w.w > mx) { mx = w.w; tag = 3; }
+      const int cur = ch == 'N' ? 0 : nuc2(ch);
+      const int curCnt = cur == 0 ? w.x : cur == 1 ? w.y : cur == 2 ? w.z : w.w;
+      char out = ch;
+      if (mx > 0 && cur != tag && curCnt < mx) { out = tag == 0 ? 'A' : tag == 1 ? 'C' : tag == 2 ? 'G' : 'T'; ++mine; }
+      consOut[(long long)sq.pwOff + j] = out;
+    }
+  }
+  if (mine) atomicAdd(changed, mine);
+}
+
 // Scatter of freshly built per-barcode set images from the staging buffer to their slots (16-byte units).
 __global__ __launch_bounds__(256) void scatterKernel(const unsigned char *staging, const T4CopyDesc *desc, int nDesc) {
   for (int d = blockIdx.x; d < nDesc; d += gridDim.x) {
