@@ -216,6 +216,19 @@ int t4_has_hit(t4_index *ref, t4_batch *b, int mode, int32_t *out);
 int t4_mate_overlap(t4_ctx *ctx, int n, const int64_t *first_off, const char *first_chars, const int64_t *second_off,
                     const char *second_chars, const int32_t *min_overlap, int check_tandem, int32_t *out3);
 
+/* ProcessRead (main.cpp:224-449) with IsLowComplexity (183-205) for n mate pairs, one pair per wavefront: read-through clipping
+ * (IsMateOverlap of rc(read 2) against read 1: read 1 is cut to the overlap and takes read 2's base wherever that has the better
+ * quality), else mate merging (IsMateOverlap of read 1 against rc(read 2), tandem repeats refused: one read of weight 2 when at
+ * least 95 % of the overlap agrees, otherwise the mate of better quality stands for both), else both mates stay. off1 / off2: n + 1
+ * offsets into r1 / r2 (characters as read, any letter) and q1 / q2 (qualities; NULL when no read has any); has_qual[i]: bit 0
+ * read 1 of pair i has qualities, bit 1 read 2. out_off: n + 1 offsets into out_r / out_q with room for len1 + len2 + 1 per pair.
+ * meta4 receives 4 int32 per pair: kind (0 both mates stay, 1 read-through, 2 merged, 3 one mate for both), length of read 1
+ * afterwards, flags (1 read 1 kept = not of low complexity, 2 read 2 kept, 4 weight 2: the caller lists the merged read twice,
+ * the copy's id with ".1" appended, 8 read 1 has qualities, 16 read 1 changed: its bases / qualities are at out_off[i]), 0.
+ * A read 2 that stays is what ProcessRead leaves: reverse-complemented twice, i.e. letters other than ACGT turned into N. */
+int t4_process_pairs(t4_ctx *ctx, int n, const int64_t *off1, const char *r1, const char *q1, const int64_t *off2, const char *r2,
+                     const char *q2, const unsigned char *has_qual, const int64_t *out_off, char *out_r, char *out_q, int32_t *meta4);
+
 /* ---- ordered contig builder (host-side commit logic + GPU queries) ----------------------------------
  * t4_assembler owns a mutable set of novel contigs (the reference's `SeqSet seqSet`, main.cpp:642) and exposes
  * the members stage 1 calls on it, with the same arguments and return values:

@@ -781,6 +781,82 @@ int t4o_is_mate_overlap(const char *fr, int flen, const char *sr, int slen, int 
   return overlapSize;
 }
 
+/* IsLowComplexity (main.cpp:183-205) */
+static int is_low_complexity(const char *seq) {
+  int cnt[5] = {0, 0, 0, 0, 0}, i, low = 0;
+  for (i = 0; seq[i]; ++i) { if (seq[i] == 'N') ++cnt[4]; else ++cnt[nuc(seq[i])]; }
+  if (cnt[0] >= i / 2 || cnt[1] >= i / 2 || cnt[2] >= i / 2 || cnt[3] >= i / 2 || cnt[4] >= i / 10) return 1;
+  for (i = 0; i < 4; ++i) if (cnt[i] <= 2) ++low;
+  return low >= 2;
+}
+/* ProcessRead (main.cpp:224-449) for one pair of ACGTN reads with qualities on both mates or on none (the reference reads the
+ * qualities of both without asking, 282, 304, 309). r1 / q1 / r2 / q2: C strings (q1 = q2 = NULL: no qualities). outR / outQ (room
+ * for len1 + len2 + 1 each) receive read 1 as ProcessRead leaves it; *flags: 1 read 1 is pushed to the read list (not of low
+ * complexity), 2 read 2 is, 4 weight 2 (the merged read is listed twice), 8 read 1 has qualities. Returns the branch taken: 0 the
+ * mates stay, 1 read-through (248-287), 2 merged (291-337), 3 one mate stands for both (338-385). The k-mer counting of the
+ * surviving reads and the bookkeeping of ids are the caller's. PARITY: pinned through the reference BINARY only (tests compare
+ * whole stage 1 with the device path switched on); ProcessRead is a static function of main.cpp and cannot be linked. */
+int t4o_process_read(const char *r1in, const char *q1in, const char *r2in, const char *q2in, char *outR, char *outQ, int *flags) {
+  int slen = (int)strlen(r1in), flen = (int)strlen(r2in), j, k, kind = 0, rWeight = 1, r2Alive = 1;
+  char *r1 = strdup(r1in), *q1 = q1in ? strdup(q1in) : NULL;
+  char *r2 = (char *)malloc(flen + 1), *q2 = q2in ? strdup(q2in) : NULL;
+  reverse_complement(r2, r2in, flen);                     /* 234 */
+  if (q2) for (j = 0, k = flen - 1; j < k; ++j, --k) { char t = q2[j]; q2[j] = q2[k]; q2[k] = t; }
+  int minOverlap = (flen + slen) / 10, minOverlap2 = (flen + slen) / 20, offset = -1, best = -1;
+  if (minOverlap > 31) minOverlap = 31;
+  if (minOverlap2 > 31) minOverlap2 = 31;
+  int hasQ1 = q1 != NULL;
+  int ov = t4o_is_mate_overlap(r2, flen, r1, slen, minOverlap, &offset, &best, 0);
+  if (ov >= 0) {
+    kind = 1;
+    r1[ov] = 0;
+    if (q1) {
+      q1[ov] = 0;
+      for (j = 0; j < ov; ++j) if (q2[j + offset] > q1[j] || r1[j] == 'N') { r1[j] = r2[j + offset]; q1[j] = q2[j + offset]; }
+    }
+    r2Alive = 0;
+  } else if ((ov = t4o_is_mate_overlap(r1, slen, r2, flen, minOverlap2, &offset, &best, 1)) >= 0) {
+    if (best >= 0.95 * ov) {
+      kind = 2;
+      char *r = (char *)calloc(slen + flen + 1, 1), *q = (char *)calloc(slen + flen + 1, 1);
+      for (j = 0; j < flen; ++j) { r[offset + j] = r2[j]; q[offset + j] = q2 ? q2[j] : 0; }
+      int len = offset + j;
+      for (j = 0; j < slen && j < len; ++j)
+        if (j < offset || (q1 ? q1[j] : 0) >= q[j] - 14 || r[j] == 'N') { r[j] = r1[j]; q[j] = q1 ? q1[j] : 0; }
+      r[len] = q[len] = 0;
+      free(r1); free(q1);
+      r1 = r; q1 = q;                                      /* (q stands for "no qualities" when the input had none: hasQ1 says) */
+      r2Alive = 0; ++rWeight;
+    } else {
+      kind = 3;
+      int useFirst = 1;
+      if (q1) {
+        double a = 0, b = 0;
+        for (j = offset; j < slen; ++j) a += q1[j] - 32;
+        for (j = flen - 1; j >= flen - ov; --j) b += q2[j] - 32;
+        a /= ov; b /= ov;
+        if (a + 10 < b) useFirst = 0;
+      }
+      if (!useFirst) {
+        free(r1); free(q1);
+        r1 = (char *)malloc(flen + 1);
+        reverse_complement(r1, r2, flen);                 /* 366-367; the qualities stay reversed (368-377) */
+        q1 = q2 ? strdup(q2) : NULL;
+        hasQ1 = q2 != NULL;
+      }
+      r2Alive = 0;
+    }
+  }
+  int len1 = (int)strlen(r1);
+  memcpy(outR, r1, len1 + 1);
+  if (q1) memcpy(outQ, q1, len1 + 1); else memset(outQ, 0, len1 + 1);
+  *flags = (hasQ1 ? 8 : 0) | (rWeight == 2 ? 4 : 0);
+  if (!is_low_complexity(r1)) *flags |= 1;
+  if (r2Alive && !is_low_complexity(r2in)) *flags |= 2;   /* read 2 is reverse-complemented back (388-399): the same letters */
+  free(r1); free(q1); free(r2); free(q2);
+  return kind;
+}
+
 /* SeqSet::HasHitInSet (SeqSet.hpp:3144-3327): hits bucketed by (strand, sequence) in emission order, the bucket with the most
  * distinct read offsets per strand, GetOverlapsFromHits (filter 1) on the chosen bucket(s). Returns -1 / 0 / 1. */
 int t4o_has_hit_in_set(t4o_set *s, const char *read, int mode) {

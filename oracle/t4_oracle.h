@@ -53,6 +53,7 @@ int t4o_global_alignment(const char *t, int lent, const char *p, int lenp, signe
 int t4o_global_alignment_posweight(const int *w, int lent, const char *p, int lenp,
                                    signed char *align);
 int t4o_has_hit_in_set(t4o_set *s, const char *read, int mode);   /* SeqSet::HasHitInSet (SeqSet.hpp:3144-3327) */
+int t4o_process_read(const char *r1, const char *q1, const char *r2, const char *q2, char *outR, char *outQ, int *flags);   /* ProcessRead (main.cpp:224-449) */
 int t4o_is_mate_overlap(const char *fr, int flen, const char *sr, int slen, int minOverlap,
                         int *offset, int *bestMatchCnt, int checkTandem);
 int t4o_lis(const int *pairs, int n, int *out);

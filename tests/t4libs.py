@@ -153,6 +153,16 @@ class _SetAPI:
     def has_hit_in_set(self, read, mode=0):
         return self._hashit(self.h, _b(read), mode)
 
+    def process_read(self, r1, q1, r2, q2):
+        """ProcessRead (main.cpp:224-449), oracle only -> (kind, read 1 afterwards, its qualities as bytes, flags)"""
+        n = len(r1) + len(r2) + 1
+        outr, outq = C.create_string_buffer(n + 1), C.create_string_buffer(n + 1)
+        fl = C.c_int(0)
+        fn = self._f("process_read", C.c_int, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int))
+        kind = fn(_b(r1), None if q1 is None else _b(q1), _b(r2), None if q2 is None else _b(q2), outr, outq, C.byref(fl))
+        rd = outr.value.decode()
+        return kind, rd, outq.raw[:len(rd)], fl.value
+
     def is_mate_overlap(self, fr, sr, min_overlap, check_tandem=1):
         fr, sr = _b(fr), _b(sr)
         off, bm = C.c_int(-1), C.c_int(-1)

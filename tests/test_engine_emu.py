@@ -379,6 +379,62 @@ def test_mate_overlap_vs_oracle(emu_engine):
     check_mate_overlap(emu_engine, 3, 400)
 
 
+def pair_cases(seed, n):
+    """mate pairs as a sequencer gives them (read 2 from the other strand): fragments shorter than a read (read-through), mates
+    that overlap at their ends with few or many disagreements, tandem-repeat overlaps, mates apart, low-complexity reads"""
+    rnd = random.Random(seed)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    rc = lambda x: "".join(comp[c] for c in reversed(x))
+    R1, R2, Q1, Q2 = [], [], [], []
+    for _ in range(n):
+        L = rnd.choice([60, 100, 150])
+        kind = rnd.random()
+        if kind < 0.25:
+            frag = rnd.randint(25, L - 1)             # fragment shorter than the reads: read-through
+        elif kind < 0.65:
+            frag = rnd.randint(L + 1, 2 * L - 8)      # ends overlap
+        else:
+            frag = rnd.randint(2 * L + 1, 3 * L)      # apart
+        if rnd.random() < 0.08:
+            unit = "".join(rnd.choice("ACGT") for _ in range(rnd.randint(1, 6)))
+            t = (unit * 400)[:3 * L + 40]
+        elif rnd.random() < 0.08:
+            t = "".join(rnd.choice("AAAAAAAC") for _ in range(3 * L + 40))
+        else:
+            t = "".join(rnd.choice("ACGT") for _ in range(3 * L + 40))
+        adapter = "".join(rnd.choice("ACGT") for _ in range(L))
+        a = (t[:frag] + adapter)[:L] if frag < L else t[:L]
+        b = (rc(t[:frag]) + adapter)[:L] if frag < L else rc(t[frag - L:frag])
+        err = rnd.choice([0.0, 0.01, 0.04, 0.12])
+        mut = lambda x: "".join((rnd.choice("ACGTN") if rnd.random() < err else c) for c in x)
+        a, b = mut(a), mut(b)
+        R1.append(a); R2.append(b)
+        Q1.append("".join(chr(rnd.choice([35, 40, 50, 60, 70, 73])) for _ in a))
+        Q2.append("".join(chr(rnd.choice([35, 45, 55, 66, 73])) for _ in b))
+    return R1, Q1, R2, Q2
+
+
+def check_process_pairs(eng, seed, n):
+    """t4_process_pairs (ProcessRead + IsLowComplexity, main.cpp:224-449 / 183-205) against the oracle's restatement, with
+    qualities and without; every branch must be taken"""
+    o = Oracle(9)
+    R1, Q1, R2, Q2 = pair_cases(seed, n)
+    for with_q in (True, False):
+        got = eng.process_pairs(R1, Q1 if with_q else None, R2, Q2 if with_q else None)
+        kinds = [0, 0, 0, 0]
+        dropped = 0
+        for i in range(n):
+            exp = o.process_read(R1[i], Q1[i] if with_q else None, R2[i], Q2[i] if with_q else None)
+            assert got[i] == exp, (i, with_q, R1[i], R2[i], got[i], exp)
+            kinds[exp[0]] += 1
+            dropped += 0 if exp[3] & 1 else 1
+        assert min(kinds) > n // 40 and dropped > 0, (kinds, dropped)
+
+
+def test_process_pairs_vs_oracle(emu_engine):
+    check_process_pairs(emu_engine, 5, 500)
+
+
 def check_has_hit(eng, seed, hit_lens=(17, 27)):
     from test_oracle_vs_ref import has_hit_reads
     reads = [r for r in has_hit_reads(seed) if set(r) <= set("ACGTN")]

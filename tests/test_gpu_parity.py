@@ -136,6 +136,11 @@ def test_add_path_matches_reference(eng, tmp_path, seed, n_pairs, n_clones):
     run_case(eng, tmp_path, seed, n_pairs, n_clones)
 
 
+def test_process_pairs_vs_oracle(eng):
+    from test_engine_emu import check_process_pairs
+    check_process_pairs(eng, 5, 20000)
+
+
 def test_mate_overlap_vs_oracle(eng):
     from test_engine_emu import check_mate_overlap
     check_mate_overlap(eng, 3, 20000)

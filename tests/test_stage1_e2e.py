@@ -317,7 +317,7 @@ def _bulk_case(tmp_path, driver, pairs, clones, seed, env, threads="4"):
 
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
 @pytest.mark.parametrize("env", [{"T4_AQ_CAP_LIMIT": "120"}, {"T4_AQ_FORCE_GLOBAL": "1"}, {"T4_QUERY_AHEAD": "3", "T4_WINDOW": "7"}, {"T4_AQ_EXTEND_DEFER": "1"}, {"T4_AQ_EXTEND_DEFER": "0"},
-                                 {"T4_AQ_POOL_CAP": "8", "T4_AQ_EXTEND_DEFER": "1"}, {"T4_AQ_POOL_CAP": "5"}, {"T4_SORT_MIN": "64"}])
+                                 {"T4_AQ_POOL_CAP": "8", "T4_AQ_EXTEND_DEFER": "1"}, {"T4_AQ_POOL_CAP": "5"}, {"T4_SORT_MIN": "64"}, {"T4_GPU_PROCESSREAD": "1"}])
 def test_bulk_live_set_paths_emulated(tmp_path, env):
     """Bulk mode = the live set (device image by t4_index_apply_delta, sliding speculation window). The testing aids send a
     small input down the paths large sets take: reads that outgrow the LDS arrays and go on in global scratch inside the launch
@@ -325,6 +325,10 @@ def test_bulk_live_set_paths_emulated(tmp_path, env):
     a few reads at a time (T4_QUERY_AHEAD), a result pool that overflows so that the call is repeated with a larger one
     (T4_AQ_POOL_CAP; with the extensions deferred, extendKernel runs over the pool of the failed attempt first). Outputs must equal the reference binary's byte for byte."""
     log = _bulk_case(tmp_path, _emulated_driver(), 240, 5, 11, env)
+    if "T4_GPU_PROCESSREAD" in env:   # ProcessRead of every pair on the device (t4_process_pairs): mates must have been merged there
+        import re
+        m = re.search(r"ProcessRead on the device: (\d+) pairs stay as they are, (\d+) read-through, (\d+) merged", log)
+        assert m and int(m.group(3)) > 20, log[-600:]
     if "T4_AQ_CAP_LIMIT" in env or "T4_AQ_FORCE_GLOBAL" in env:
         import re
         m = re.search(r"global-scratch tier (\d+) launches for (\d+) reads", log)
@@ -338,7 +342,7 @@ def test_bulk_live_set_paths_emulated(tmp_path, env):
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not shipped")
 @pytest.mark.parametrize("env", [{}, {"T4_AQ_CAP_LIMIT": "2000"}, {"T4_AQ_FORCE_GLOBAL": "1"}, {"T4_AQ_EXTEND_DEFER": "2"},
-                                 {"T4_AQ_POOL_CAP": "16", "T4_AQ_EXTEND_DEFER": "2"}])
+                                 {"T4_AQ_POOL_CAP": "16", "T4_AQ_EXTEND_DEFER": "2"}, {"T4_GPU_PROCESSREAD": "1", "T4_SORT_MIN": "1024"}])
 def test_bulk_live_set_paths_gpu(tmp_path, env):
     _bulk_case(tmp_path, _driver(), 6000, 120, 12, env, threads="8")
 

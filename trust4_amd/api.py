@@ -72,6 +72,7 @@ def _load():
         "t4_annotate_rough": (I, [P, P, P]),
         "t4_gap_dp": (I, [P, I, I, I, P, P, P, P, P]),
         "t4_mate_overlap": (I, [P, I, P, P, P, P, P, I, P]), "t4_has_hit": (I, [P, P, I, P]),
+        "t4_process_pairs": (I, [P, I, P, P, P, P, P, P, P, P, P, P, P]),
         "t4_extend": (I, [P, P, I, P, P, C.c_double, P, P]), "t4_assign": (I, [P, P, I, P, P]), "t4_assign_strands": (I, [P, P, P, P, P]),
         "t4_posweight_recompute": (I, [P, P, P, P, P, C.c_int64]),
         "t4_consensus_recompute": (I, [P, P, P, P, P, C.c_int64, P, C.c_int64, P]),
@@ -156,6 +157,34 @@ class Engine:
         self.check(self.lib.t4_mate_overlap(self.h, n, foff.ctypes.data_as(V), fb.ctypes.data_as(V), soff.ctypes.data_as(V), sb.ctypes.data_as(V),
                                             mo.ctypes.data_as(V), 1 if check_tandem else 0, out.ctypes.data_as(V)))
         return out
+
+    def process_pairs(self, r1, q1, r2, q2):
+        """ProcessRead (main.cpp:224-449) of n mate pairs: r1 / r2 lists of str, q1 / q2 lists of str or None (no qualities).
+        -> list of (kind, read 1 afterwards, its qualities as bytes, flags) -- see t4_process_pairs"""
+        n = len(r1)
+        o1 = np.zeros(n + 1, dtype=np.int64); o2 = np.zeros(n + 1, dtype=np.int64); oo = np.zeros(n + 1, dtype=np.int64)
+        o1[1:] = np.cumsum([len(x) for x in r1]); o2[1:] = np.cumsum([len(x) for x in r2])
+        oo[1:] = np.cumsum([len(a) + len(b) + 1 for a, b in zip(r1, r2)])
+        V = C.c_void_p
+        buf = lambda strs: np.frombuffer(("".join(strs) + "\0").encode("latin-1"), dtype=np.uint8)
+        b1, b2 = buf(r1), buf(r2)
+        bq1 = buf(q1) if q1 is not None else None
+        bq2 = buf(q2) if q2 is not None else None
+        hq = np.full(n, (1 if q1 is not None else 0) | (2 if q2 is not None else 0), dtype=np.uint8)
+        outr = np.zeros(int(oo[n]) + 1, dtype=np.uint8); outq = np.zeros(int(oo[n]) + 1, dtype=np.uint8)
+        meta = np.zeros((n, 4), dtype=np.int32)
+        self.check(self.lib.t4_process_pairs(self.h, n, o1.ctypes.data_as(V), b1.ctypes.data_as(V), None if bq1 is None else bq1.ctypes.data_as(V),
+                                             o2.ctypes.data_as(V), b2.ctypes.data_as(V), None if bq2 is None else bq2.ctypes.data_as(V),
+                                             hq.ctypes.data_as(V), oo.ctypes.data_as(V), outr.ctypes.data_as(V), outq.ctypes.data_as(V), meta.ctypes.data_as(V)))
+        res = []
+        for i in range(n):
+            kind, ln, fl = int(meta[i, 0]), int(meta[i, 1]), int(meta[i, 2])
+            if fl & 16:
+                rd = outr[oo[i]:oo[i] + ln].tobytes().decode("latin-1"); ql = outq[oo[i]:oo[i] + ln].tobytes()
+            else:
+                rd = r1[i]; ql = q1[i].encode("latin-1") if q1 is not None else bytes(ln)
+            res.append((kind, rd, ql, fl & 15))
+        return res
 
     def index(self, k, consider_barcode=False):
         return Index(self, k, consider_barcode)

@@ -1084,6 +1084,48 @@ int t4_mate_overlap(t4_ctx *c, int n, const int64_t *f_off, const char *f_chars,
   return T4_OK;
 }
 
+int t4_process_pairs(t4_ctx *c, int n, const int64_t *off1, const char *r1, const char *q1, const int64_t *off2, const char *r2, const char *q2,
+                     const unsigned char *has_qual, const int64_t *out_off, char *out_r, char *out_q, int32_t *meta4) {
+  if (!c || n < 0 || (n > 0 && (!off1 || !r1 || !off2 || !r2 || !has_qual || !out_off || !out_r || !out_q || !meta4))) return T4_ERR_ARG;
+  if (n == 0) return T4_OK;
+  (void)hipSetDevice(c->device);
+  const size_t n1 = (size_t)off1[n], n2 = (size_t)off2[n], no = (size_t)out_off[n];
+  for (int i = 0; i < n; ++i) {
+    if (out_off[i + 1] - out_off[i] < (off1[i + 1] - off1[i]) + (off2[i + 1] - off2[i]) + 1) return fail(c, T4_ERR_ARG, "t4_process_pairs: pair %d needs an output slot of len1 + len2 + 1 characters", i);
+    if ((has_qual[i] & 1) && !q1) return fail(c, T4_ERR_ARG, "t4_process_pairs: pair %d says read 1 has qualities, q1 is null", i);
+    if ((has_qual[i] & 2) && !q2) return fail(c, T4_ERR_ARG, "t4_process_pairs: pair %d says read 2 has qualities, q2 is null", i);
+  }
+  int r;
+  long long *dO1 = nullptr, *dO2 = nullptr, *dOo = nullptr;
+  char *dR1 = nullptr, *dQ1 = nullptr, *dR2 = nullptr, *dQ2 = nullptr, *dOr = nullptr, *dOq = nullptr;
+  unsigned char *dHq = nullptr;
+  int4 *dMeta = nullptr;
+  auto freeAll = [&] { void *ptrs[] = {dO1, dO2, dOo, dR1, dQ1, dR2, dQ2, dOr, dOq, dHq, dMeta}; for (void *q : ptrs) if (q) (void)hipFree(q); };
+  #define PPCHK(x) do { if ((x) != hipSuccess) { freeAll(); return fail(c, T4_ERR_HIP, "HIP error in t4_process_pairs: %s", hipGetErrorString(hipGetLastError())); } } while (0)
+  if ((r = devAlloc(c, &dO1, (size_t)n + 1)) || (r = devAlloc(c, &dO2, (size_t)n + 1)) || (r = devAlloc(c, &dOo, (size_t)n + 1)) ||
+      (r = devAlloc(c, &dR1, n1 + 16)) || (r = devAlloc(c, &dR2, n2 + 16)) || (r = devAlloc(c, &dOr, no + 16)) || (r = devAlloc(c, &dOq, no + 16)) ||
+      (r = devAlloc(c, &dHq, (size_t)n)) || (r = devAlloc(c, &dMeta, (size_t)n)) || (q1 && (r = devAlloc(c, &dQ1, n1 + 16))) || (q2 && (r = devAlloc(c, &dQ2, n2 + 16)))) { freeAll(); return r; }
+  PPCHK(hipMemcpyAsync(dO1, off1, sizeof(long long) * ((size_t)n + 1), hipMemcpyHostToDevice, c->stream));
+  PPCHK(hipMemcpyAsync(dO2, off2, sizeof(long long) * ((size_t)n + 1), hipMemcpyHostToDevice, c->stream));
+  PPCHK(hipMemcpyAsync(dOo, out_off, sizeof(long long) * ((size_t)n + 1), hipMemcpyHostToDevice, c->stream));
+  if (n1) PPCHK(hipMemcpyAsync(dR1, r1, n1, hipMemcpyHostToDevice, c->stream));
+  if (n2) PPCHK(hipMemcpyAsync(dR2, r2, n2, hipMemcpyHostToDevice, c->stream));
+  if (q1 && n1) PPCHK(hipMemcpyAsync(dQ1, q1, n1, hipMemcpyHostToDevice, c->stream));
+  if (q2 && n2) PPCHK(hipMemcpyAsync(dQ2, q2, n2, hipMemcpyHostToDevice, c->stream));
+  PPCHK(hipMemcpyAsync(dHq, has_qual, (size_t)n, hipMemcpyHostToDevice, c->stream));
+  const int grid = n < c->cus * 32 ? n : c->cus * 32;
+  hipLaunchKernelGGL(t4k::processPairKernel, dim3(grid), dim3(64), 0, c->stream, n, dO1, dR1, dQ1, dO2, dR2, dQ2, dHq, dOo, dOr, dOq, dMeta);
+  PPCHK(hipGetLastError());
+  PPCHK(hipMemcpyAsync(meta4, dMeta, sizeof(int4) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+  PPCHK(hipMemcpyAsync(out_r, dOr, no, hipMemcpyDeviceToHost, c->stream));
+  PPCHK(hipMemcpyAsync(out_q, dOq, no, hipMemcpyDeviceToHost, c->stream));
+  PPCHK(hipStreamSynchronize(c->stream));
+  #undef PPCHK
+  freeAll();
+  for (int i = 0; i < n; ++i) if (meta4[4 * i] == -2) return fail(c, T4_ERR_UNSUPPORTED, "pair %d has a read longer than %d bp", i, T4_MAXL);
+  return T4_OK;
+}
+
 // ---- KmerCount (KmerCount.hpp) on the device ------------------------------------------------------------------------
 struct t4_kmer_counter {
   t4_ctx *ctx = nullptr;

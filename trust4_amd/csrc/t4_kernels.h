@@ -4189,6 +4189,42 @@ __global__ __launch_bounds__(64) void hitsKernel(T4IndexView ix, T4BatchView bv,
 // mismatch count, so it equals the test on the total. Lanes take the offsets; the reference keeps the LAST passing offset.
 // out: 3 ints per pair (return value: overlap size or -1, offset, bestMatchCnt; the latter two are the reference's outputs
 // whenever at least one offset passed, else -1).
+// (one wavefront; fr / sr in LDS; every lane returns the same values)
+__device__ int mateOverlapWave(const char *s_f, int flen, const char *s_s, int slen, int mo, bool checkTandem, int &offset, int &bestMatch) {
+  const int lane = laneId();
+  int cnt = 0, lastJ = -1, lastMatch = -1, lastSize = -1;
+  for (int j = lane; j < flen - mo; j += 64) {
+    const int rem = flen - j;
+    double thr = 0.95;
+    if (rem >= 100) thr = 0.85; else if (rem >= 50) thr = 0.85 + (rem - 50) / 50.0 * 0.1;
+    const int need = (int)(rem * thr), kEnd = rem < slen ? rem : slen;
+    int match = 0;
+    for (int k = 0; k < kEnd; ++k) match += s_f[j + k] == s_s[k] ? 1 : 0;
+    // the reference stops at the first k with match(0..k) + (rem - k - 1) < need, i.e. as soon as mismatches exceed rem - need
+    if (kEnd - match <= rem - need) { ++cnt; lastJ = j; lastMatch = match; lastSize = kEnd; }
+  }
+  const int total = waveSum(cnt);
+  // the last passing offset = the largest j: lanes hold increasing j's in their own stride, so take the maximum
+  int best = lastJ;
+  for (int o = 32; o > 0; o >>= 1) { int v = __shfl_xor(best, o); if (v > best) best = v; }
+  const int src = __ffsll((long long)__ballot(lastJ == best && best >= 0)) - 1;
+  const int bMatch = __shfl(lastMatch, src < 0 ? 0 : src), bSize = __shfl(lastSize, src < 0 ? 0 : src);
+  int ret = -1;
+  if (lane == 0 && total == 1) {
+    ret = bSize;
+    if (checkTandem && bSize <= mo * 2) {
+      for (int i = 1; i <= bSize / 2 && ret >= 0; ++i) {
+        bool tandem = true;
+        for (int j = i; j + i - 1 < bSize && tandem; j += i)
+          for (int k = j; k <= j + i - 1; ++k) if (s_s[k - j] != s_s[k]) { tandem = false; break; }
+        if (tandem) ret = -1;
+      }
+    }
+  }
+  offset = total > 0 ? best : -1;
+  bestMatch = total > 0 ? bMatch : -1;
+  return __shfl(ret, 0);
+}
 __global__ __launch_bounds__(64) void mateOverlapKernel(int n, const long long *fOff, const char *fChars, const long long *sOff,
                                                       const char *sChars, const int *minOverlap, int checkTandem, int *out) {
   __shared__ char s_f[T4_MAXL + 8], s_s[T4_MAXL + 8];
@@ -4199,38 +4235,92 @@ __global__ __launch_bounds__(64) void mateOverlapKernel(int n, const long long *
     for (int i = lane; i < flen; i += 64) s_f[i] = fChars[fOff[p] + i];
     for (int i = lane; i < slen; i += 64) s_s[i] = sChars[sOff[p] + i];
     __syncthreads();
-    int cnt = 0, lastJ = -1, lastMatch = -1, lastSize = -1;
-    for (int j = lane; j < flen - mo; j += 64) {
-      const int rem = flen - j;
-      double thr = 0.95;
-      if (rem >= 100) thr = 0.85; else if (rem >= 50) thr = 0.85 + (rem - 50) / 50.0 * 0.1;
-      const int need = (int)(rem * thr), kEnd = rem < slen ? rem : slen;
-      int match = 0;
-      for (int k = 0; k < kEnd; ++k) match += s_f[j + k] == s_s[k] ? 1 : 0;
-      // the reference stops at the first k with match(0..k) + (rem - k - 1) < need, i.e. as soon as mismatches exceed rem - need
-      if (kEnd - match <= rem - need) { ++cnt; lastJ = j; lastMatch = match; lastSize = kEnd; }
-    }
-    const int total = waveSum(cnt);
-    // the last passing offset = the largest j: lanes hold increasing j's in their own stride, so take the maximum
-    int best = lastJ;
-    for (int o = 32; o > 0; o >>= 1) { int v = __shfl_xor(best, o); if (v > best) best = v; }
-    const int src = __ffsll((long long)__ballot(lastJ == best && best >= 0)) - 1;
-    const int bMatch = __shfl(lastMatch, src < 0 ? 0 : src), bSize = __shfl(lastSize, src < 0 ? 0 : src);
-    if (lane == 0) {
-      int ret = -1;
-      if (total == 1) {
-        ret = bSize;
-        if (checkTandem && bSize <= mo * 2) {
-          for (int i = 1; i <= bSize / 2 && ret >= 0; ++i) {
-            bool tandem = true;
-            for (int j = i; j + i - 1 < bSize && tandem; j += i)
-              for (int k = j; k <= j + i - 1; ++k) if (s_s[k - j] != s_s[k]) { tandem = false; break; }
-            if (tandem) ret = -1;
-          }
+    int offset, bestMatch;
+    const int ret = mateOverlapWave(s_f, flen, s_s, slen, mo, checkTandem != 0, offset, bestMatch);
+    if (lane == 0) { out[3 * p] = ret; out[3 * p + 1] = offset; out[3 * p + 2] = bestMatch; }
+    __syncthreads();
+  }
+}
+
+// ProcessRead (main.cpp:224-449) of a batch of mate pairs, one pair per wavefront: read 2 is reverse-complemented; if it runs
+// through read 1 (IsMateOverlap of rc(read 2) against read 1) read 1 is cut to the overlap and takes the better-quality bases;
+// else if the mates overlap at their ends (IsMateOverlap of read 1 against rc(read 2), tandem repeats refused) they are merged
+// into one read of weight 2 when nearly all overlapped bases agree, or the mate of better quality stands for both; else both stay.
+// IsLowComplexity (main.cpp:183-205) of what is left. r1 / r2: chars as read (any letter), q1 / q2: their qualities (used when
+// the pair's bit in hasQual says so: bit 0 read 1, bit 1 read 2). Per pair, meta = {kind, length of the new read 1, flags, 0}:
+// kind 0 both mates stay as they are, 1 read-through, 2 merged, 3 one mate stands for both; flags: 1 read 1 kept (not of low
+// complexity), 2 read 2 kept, 4 weight 2 (the driver lists the merged read twice), 8 read 1 has qualities, 16 read 1 changed: its
+// new bases / qualities are in outR / outQ at outOff[p] (room for len1 + len2 + 1).
+__device__ __forceinline__ char rcChar(char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }
+__device__ bool lowComplexityWave(const char *s, int n) {
+  int cA = 0, cC = 0, cG = 0, cT = 0, cN = 0;
+  for (int i = laneId(); i < n; i += 64) { const char ch = s[i]; if (ch == 'N') ++cN; else if (ch == 'C') ++cC; else if (ch == 'G') ++cG; else if (ch == 'T') ++cT; else ++cA; }   // other letters count as base 0
+  cA = waveSum(cA); cC = waveSum(cC); cG = waveSum(cG); cT = waveSum(cT); cN = waveSum(cN);
+  if (cA >= n / 2 || cC >= n / 2 || cG >= n / 2 || cT >= n / 2 || cN >= n / 10) return true;
+  return ((cA <= 2) + (cC <= 2) + (cG <= 2) + (cT <= 2)) >= 2;
+}
+__global__ __launch_bounds__(64) void processPairKernel(int n, const long long *off1, const char *r1, const char *q1, const long long *off2, const char *r2,
+                                                      const char *q2, const unsigned char *hasQual, const long long *outOff, char *outR, char *outQ, int4 *meta) {
+  __shared__ char s_r1[T4_MAXL + 8], s_q1[T4_MAXL + 8], s_f[T4_MAXL + 8], s_fq[T4_MAXL + 8];
+  __shared__ char s_m[2 * T4_MAXL + 16], s_mq[2 * T4_MAXL + 16];
+  const int lane = laneId();
+  for (int p = blockIdx.x; p < n; p += gridDim.x) {
+    const int slen = (int)(off1[p + 1] - off1[p]), flen = (int)(off2[p + 1] - off2[p]);
+    if (flen > T4_MAXL || slen > T4_MAXL) { if (lane == 0) meta[p] = make_int4(-2, 0, 0, 0); continue; }
+    const bool hq1 = (hasQual[p] & 1) != 0, hq2 = (hasQual[p] & 2) != 0;
+    for (int i = lane; i < slen; i += 64) { s_r1[i] = r1[off1[p] + i]; s_q1[i] = hq1 ? q1[off1[p] + i] : 0; }
+    for (int i = lane; i < flen; i += 64) { s_f[i] = rcChar(r2[off2[p] + flen - 1 - i]); s_fq[i] = hq2 ? q2[off2[p] + flen - 1 - i] : 0; }
+    __syncthreads();
+    int mo = (flen + slen) / 10, mo2 = (flen + slen) / 20;
+    if (mo > 31) mo = 31;
+    if (mo2 > 31) mo2 = 31;
+    int kind = 0, outLen = slen, flags = hq1 ? 8 : 0, offset, best;
+    bool r2Alive = true;
+    const char *fin = s_r1;   // where the final read 1 stands
+    int ov = mateOverlapWave(s_f, flen, s_r1, slen, mo, false, offset, best);
+    if (ov >= 0) {
+      kind = 1; outLen = ov; r2Alive = false; flags |= 16;
+      for (int j = lane; j < ov; j += 64) {
+        char b = s_r1[j], q = s_q1[j];
+        if (hq1 && (s_fq[j + offset] > q || b == 'N')) { b = s_f[j + offset]; q = s_fq[j + offset]; }
+        s_m[j] = b; s_mq[j] = q;
+      }
+      fin = s_m;
+    } else if ((ov = mateOverlapWave(s_r1, slen, s_f, flen, mo2, true, offset, best)) >= 0) {
+      r2Alive = false;
+      if ((double)best >= 0.95 * (double)ov) {
+        kind = 2; flags |= 4 | 16;
+        const int len = offset + flen;
+        for (int j = lane; j < len; j += 64) {
+          char b = j >= offset ? s_f[j - offset] : 0, q = j >= offset ? s_fq[j - offset] : 0;   // qualities of a mate without any read as 0
+          if (j < slen && (j < offset || (int)s_q1[j] >= (int)q - 14 || b == 'N')) { b = s_r1[j]; q = s_q1[j]; }
+          s_m[j] = b; s_mq[j] = q;
+        }
+        outLen = len; fin = s_m;
+      } else {
+        kind = 3;
+        bool useFirst = true;
+        if (hq1) {
+          int a = 0, b = 0;
+          for (int j = offset + lane; j < slen; j += 64) a += (int)s_q1[j] - 32;
+          for (int j = flen - 1 - lane; j >= flen - ov; j -= 64) b += (int)s_fq[j] - 32;
+          a = waveSum(a); b = waveSum(b);
+          double da = (double)a, db = (double)b;
+          da /= ov; db /= ov;
+          if (da + 10 < db) useFirst = false;
+        }
+        if (!useFirst) {   // read 2 as it was read, with the qualities in the order of its reverse complement (as the reference leaves them)
+          flags = (flags & ~8) | (hq2 ? 8 : 0) | 16;
+          for (int j = lane; j < flen; j += 64) { s_m[j] = rcChar(s_f[flen - 1 - j]); s_mq[j] = s_fq[j]; }
+          outLen = flen; fin = s_m;
         }
       }
-      out[3 * p] = ret; out[3 * p + 1] = total > 0 ? best : -1; out[3 * p + 2] = total > 0 ? bMatch : -1;
     }
+    __syncthreads();
+    if (!lowComplexityWave(fin, outLen)) flags |= 1;
+    if (r2Alive && !lowComplexityWave(s_f, flen)) flags |= 2;
+    if (flags & 16) for (int j = lane; j < outLen; j += 64) { outR[outOff[p] + j] = s_m[j]; outQ[outOff[p] + j] = s_mq[j]; }
+    if (lane == 0) meta[p] = make_int4(kind, outLen, flags, 0);
     __syncthreads();
   }
 }

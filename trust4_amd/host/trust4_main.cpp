@@ -511,6 +511,8 @@ int main(int argc, char *argv[]) {
   // T4_GPU_MATEOVERLAP=1 (opt-in this round): the two AlignAlgo::IsMateOverlap tests of every pair of a block come from
   // t4_mate_overlap (one pair per wavefront) instead of the host threads; the merge itself stays on the host.
   const bool gpuMate = getenv("T4_GPU_MATEOVERLAP") && atoi(getenv("T4_GPU_MATEOVERLAP")) != 0;
+  const bool gpuProcess = getenv("T4_GPU_PROCESSREAD") && atoi(getenv("T4_GPU_PROCESSREAD")) != 0;
+  long long ppKinds[4] = {0, 0, 0, 0};
   // (a block is processed on the host threads WHILE the next one is parsed: processBlock runs on its own thread, one block at a time)
   auto processBlock = [&](std::vector<InPair> &block) {   // ProcessRead of every pair of the block on the host threads, results appended in input order
     auto t0 = std::chrono::steady_clock::now();
@@ -518,7 +520,7 @@ int main(int argc, char *argv[]) {
     std::vector<int32_t> pre;
     bool anyMate = false;
     for (const InPair &ip : block) if (ip.haveMate) { anyMate = true; break; }
-    if (gpuMate && anyMate) {
+    if (gpuMate && !gpuProcess && anyMate) {
       gpuReady();
       const int n = (int)block.size();
       std::string fc, sc;
@@ -539,8 +541,60 @@ int main(int argc, char *argv[]) {
       pre.resize((size_t)n * 6);
       for (int i = 0; i < n; ++i) for (int j = 0; j < 3; ++j) { pre[(size_t)i * 6 + j] = o1[(size_t)i * 3 + j]; pre[(size_t)i * 6 + 3 + j] = o2[(size_t)i * 3 + j]; }
     }
+    // T4_GPU_PROCESSREAD=1 (opt-in): the whole of ProcessRead for the pairs of the block on the device (t4_process_pairs: both
+    // IsMateOverlap tests, the read-through clip / merge / choice of a mate, IsLowComplexity); the host only builds the records
+    std::vector<int32_t> meta;
+    std::vector<int64_t> ppOut;
+    std::string ppR, ppQ;
+    if (gpuProcess && anyMate) {
+      gpuReady();
+      const int n = (int)block.size();
+      std::string c1, q1, c2, q2;
+      std::vector<int64_t> o1(1, 0), o2(1, 0);
+      std::vector<unsigned char> hq((size_t)n, 0);
+      ppOut.assign(1, 0);
+      bool anyQ1 = false, anyQ2 = false;
+      for (const InPair &ip : block) { if (ip.haveMate && ip.a.hasQual) anyQ1 = true; if (ip.haveMate && ip.b.hasQual) anyQ2 = true; }
+      for (int i = 0; i < n; ++i) {
+        const InPair &ip = block[(size_t)i];
+        if (ip.haveMate) {
+          c1 += ip.a.read; c2 += ip.b.read;
+          if (anyQ1) { if (ip.a.hasQual && ip.a.qual.size() == ip.a.read.size()) q1 += ip.a.qual; else q1.append(ip.a.read.size(), '\0'); }
+          if (anyQ2) { if (ip.b.hasQual && ip.b.qual.size() == ip.b.read.size()) q2 += ip.b.qual; else q2.append(ip.b.read.size(), '\0'); }
+          hq[(size_t)i] = (unsigned char)((ip.a.hasQual && ip.a.qual.size() == ip.a.read.size() ? 1 : 0) | (ip.b.hasQual && ip.b.qual.size() == ip.b.read.size() ? 2 : 0));
+          ppOut.push_back(ppOut.back() + (int64_t)(ip.a.read.size() + ip.b.read.size() + 1));
+        } else ppOut.push_back(ppOut.back() + 1);
+        o1.push_back((int64_t)c1.size()); o2.push_back((int64_t)c2.size());
+      }
+      ppR.assign((size_t)ppOut.back() + 1, '\0'); ppQ.assign((size_t)ppOut.back() + 1, '\0');
+      meta.assign((size_t)n * 4, 0);
+      if ((rc = t4_process_pairs(ctx, n, o1.data(), c1.data(), anyQ1 ? q1.data() : nullptr, o2.data(), c2.data(), anyQ2 ? q2.data() : nullptr, hq.data(),
+                                 ppOut.data(), &ppR[0], &ppQ[0], meta.data()))) die(ctx, "t4_process_pairs", rc);
+      for (int i = 0; i < n; ++i) if (block[(size_t)i].haveMate) ++ppKinds[meta[(size_t)i * 4] & 3];
+    }
     parallelFor((long long)block.size(), threadCnt, [&](long long i) {
-      processRead(block[(size_t)i].a, block[(size_t)i].b, block[(size_t)i].haveMate, outs[(size_t)i], pre.empty() ? nullptr : &pre[(size_t)i * 6]);
+      const InPair &ip = block[(size_t)i];
+      if (!meta.empty() && ip.haveMate) {
+        const int len = meta[(size_t)i * 4 + 1], fl = meta[(size_t)i * 4 + 2];
+        std::vector<SortRead> &out = outs[(size_t)i];
+        if (fl & 1) {
+          SortRead r1 = ip.a;
+          if (fl & 16) {
+            r1.read.assign(ppR, (size_t)ppOut[(size_t)i], (size_t)len);
+            if (fl & 8) r1.qual.assign(ppQ, (size_t)ppOut[(size_t)i], (size_t)len);
+          }
+          r1.hasQual = (fl & 8) != 0;
+          out.push_back(r1);
+          if (fl & 4) { SortRead w = r1; w.id += ".1"; out.push_back(w); }
+        }
+        if (fl & 2) {
+          SortRead r2 = ip.b;
+          for (char &ch : r2.read) if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T' && ch != 'N') ch = 'N';   // what two reverse complements leave
+          out.push_back(r2);
+        }
+        return;
+      }
+      processRead(ip.a, ip.b, ip.haveMate, outs[(size_t)i], pre.empty() ? nullptr : &pre[(size_t)i * 6]);
     });
     auto t1 = std::chrono::steady_clock::now();
     for (auto &v : outs) for (SortRead &r : v) sortedReads.push_back(std::move(r));
@@ -602,6 +656,7 @@ int main(int argc, char *argv[]) {
   }
   flushBlock();
   if (processThread.joinable()) processThread.join();
+  if (gpuProcess) PrintLog("ProcessRead on the device: %lld pairs stay as they are, %lld read-through, %lld merged, %lld with one mate for both", ppKinds[0], ppKinds[1], ppKinds[2], ppKinds[3]);
   if (getenv("T4_TIMING")) PrintLog("timing: input parsed and mates processed (ProcessRead %.2f s on %d threads, merge %.2f s)", secProcess, threadCnt, secMerge);
   int readCnt = (int)sortedReads.size();
   int maxReadLen = 0;
