@@ -241,15 +241,26 @@ def pmc_traffic(fa, f1, f2, threads, device, tmp, kernels=("queryKernel", "exten
         if p.returncode or not files:
             return None, {"error": "rocprofv3 --pmc %s failed (%d): %s" % (counter, p.returncode, p.stderr.strip().split("\n")[-1][:200])}
         tot, launches = 0.0, 0
+        per_kernel = {}
         with open(files[0]) as f:
             for row in csv.DictReader(f):
                 if row.get("Counter_Name") != counter:
                     continue
                 name = re.sub(r"\(.*", "", row["Kernel_Name"])
+                acc = per_kernel.setdefault(name, [0, 0.0])
+                acc[0] += 1
+                acc[1] += float(row["Counter_Value"])
                 if any(k in name for k in kernels):
                     tot += float(row["Counter_Value"])
                     launches += 1
         raw[counter] = {"counter_units_KB": tot, "launches": launches}
+        keep = os.environ.get("T4_BENCH_PMC_DIR")   # the per-kernel sums this number comes from, kept for profiles/
+        if keep:
+            os.makedirs(keep, exist_ok=True)
+            with open(os.path.join(keep, "step_pmc_%s.txt" % counter), "w") as g:
+                g.write("# rocprofv3 --pmc %s --kernel-trace on one step of bench.py (trust4-hip, the bench batch); counter units: KB; per kernel: launches, sum\n" % counter)
+                for name, (cnt, val) in sorted(per_kernel.items(), key=lambda kv: -kv[1][1]):
+                    g.write("%-110s %8d %16.0f\n" % (name, cnt, val))
         shutil.rmtree(d, ignore_errors=True)
     traffic = (2.0 * raw["FETCH_SIZE"]["counter_units_KB"] + raw["WRITE_SIZE"]["counter_units_KB"]) * 1024.0
     return traffic, {"raw": raw, "fetch_bytes_corrected": 2.0 * raw["FETCH_SIZE"]["counter_units_KB"] * 1024.0, "write_bytes": raw["WRITE_SIZE"]["counter_units_KB"] * 1024.0,
