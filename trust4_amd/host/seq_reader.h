@@ -101,6 +101,21 @@ struct ThreadedSeqReader {
     id.swap(r.id); seq.swap(r.seq); qual.swap(r.qual); comment.swap(r.comment); hasQual = r.hasQual;
     return true;
   }
+  // a whole block of records at once (not to be mixed with next()): the consumer's per-record work can then run on its own threads
+  bool nextBlock(Block &out) {
+    if (!started) start();
+    Block got;
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return !ready.empty() || done; });
+      if (ready.empty()) { out.clear(); return false; }
+      got.swap(ready.front());
+      ready.pop_front();
+    }
+    cv.notify_all();
+    out.swap(got);   // (what `out` held is freed here, outside the lock)
+    return !out.empty();
+  }
   ~ThreadedSeqReader() {
     { std::lock_guard<std::mutex> lk(mu); quit = true; }
     cv.notify_all();

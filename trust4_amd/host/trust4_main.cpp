@@ -602,60 +602,96 @@ int main(int argc, char *argv[]) {
     secProcess += std::chrono::duration<double>(t1 - t0).count();
     secMerge += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
   };
-  std::vector<InPair> inProcess;
+  // The readers deliver whole blocks of records; the only serial work per record is the numbering of barcodes and UMIs in order of
+  // first appearance (main.cpp:799-842). Everything else -- building the read records, ProcessRead -- runs on the host threads, one
+  // batch of blocks at a time, while the next batch is read.
+  struct Unit { ThreadedSeqReader::Block r, m; std::vector<int> bc, umi; std::vector<char> skip; };
+  std::vector<Unit> units, inProcess;
+  size_t unitPairs = 0;
   std::thread processThread;
+  double secWaitProcess = 0;
+  const auto tInput0 = std::chrono::steady_clock::now();
   auto flushBlock = [&]() {
-    if (processThread.joinable()) processThread.join();
-    inProcess.swap(block);
-    block.clear();
-    if (block.capacity() < BLOCK) block.reserve(BLOCK);
-    if (!inProcess.empty()) processThread = std::thread([&]() { processBlock(inProcess); });
+    { const auto tw = std::chrono::steady_clock::now(); if (processThread.joinable()) processThread.join(); secWaitProcess += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count(); }
+    inProcess.clear();
+    inProcess.swap(units);
+    unitPairs = 0;
+    if (inProcess.empty()) return;
+    processThread = std::thread([&]() {
+      std::vector<std::pair<uint32_t, uint32_t>> at;
+      for (size_t u = 0; u < inProcess.size(); ++u) for (size_t i = 0; i < inProcess[u].r.size(); ++i) if (!inProcess[u].skip[i]) at.push_back({(uint32_t)u, (uint32_t)i});
+      block.clear();
+      block.resize(at.size());
+      parallelFor((long long)at.size(), threadCnt, [&](long long k) {
+        Unit &un = inProcess[at[(size_t)k].first];
+        const size_t i = at[(size_t)k].second;
+        InPair &ip = block[(size_t)k];
+        ThreadedSeqReader::Rec &r = un.r[i];
+        ip.a.id.swap(r.id); ip.a.read.swap(r.seq); ip.a.qual.swap(r.qual); ip.a.hasQual = r.hasQual;
+        ip.a.barcode = ip.b.barcode = un.bc[i]; ip.a.umi = ip.b.umi = un.umi[i];
+        ip.haveMate = !un.m.empty();
+        if (ip.haveMate) { ThreadedSeqReader::Rec &m = un.m[i]; ip.b.id.swap(m.id); ip.b.read.swap(m.seq); ip.b.qual.swap(m.qual); ip.b.hasQual = m.hasQual; }
+      });
+      processBlock(block);
+    });
   };
   int firstReadLen = -1, nIn = 0;
   std::unordered_map<std::string, int> barcodeStrToInt, umiStrToInt;
   std::vector<std::string> barcodeIntToStr;
   std::vector<int> barcodePairCount;   // main.cpp:822-828 (only counted under --contigMinCov)
-  while (reads.next()) {
-    int barcode = -1, umi = -1;
-    if (hasBarcode) {   // main.cpp:799-828
-      barcodeFile.next();
-      if (barcodeFile.seq == "missing_barcode" && !keepMissingBarcode) {
-        if (hasMate) mateReads.next();
-        if (hasUmi) umiFile.next();
-        continue;
+  {
+    ThreadedSeqReader::Block bR, bM, bB, bU;
+    auto uneven = [&](const char *what) { fprintf(stderr, "%s\n", what); if (processThread.joinable()) processThread.join(); initThread.join(); exit(1); };
+    while (reads.nextBlock(bR)) {
+      Unit u;
+      u.r.swap(bR);
+      const size_t n = u.r.size();
+      if (hasMate) {
+        if (!mateReads.nextBlock(bM) || bM.size() != n) uneven("The two mate-pair read files have different number of reads.");
+        u.m.swap(bM);
       }
-      auto it = barcodeStrToInt.find(barcodeFile.seq);
-      if (it != barcodeStrToInt.end()) barcode = it->second;
-      else { barcode = (int)barcodeIntToStr.size(); barcodeStrToInt[barcodeFile.seq] = barcode; barcodeIntToStr.push_back(barcodeFile.seq); }
-      if (contigMinCov > 0) { if (barcode >= (int)barcodePairCount.size()) barcodePairCount.push_back(1); else ++barcodePairCount[barcode]; }
+      u.bc.assign(n, -1); u.umi.assign(n, -1); u.skip.assign(n, 0);
+      if (hasBarcode) {   // main.cpp:799-828
+        if (!barcodeFile.nextBlock(bB) || bB.size() < n) uneven("The barcode file has fewer records than the read file.");
+        for (size_t i = 0; i < n; ++i) {
+          const std::string &bs = bB[i].seq;
+          if (bs == "missing_barcode" && !keepMissingBarcode) { u.skip[i] = 1; continue; }
+          int barcode;
+          auto it = barcodeStrToInt.find(bs);
+          if (it != barcodeStrToInt.end()) barcode = it->second;
+          else { barcode = (int)barcodeIntToStr.size(); barcodeStrToInt[bs] = barcode; barcodeIntToStr.push_back(bs); }
+          if (contigMinCov > 0) { if (barcode >= (int)barcodePairCount.size()) barcodePairCount.push_back(1); else ++barcodePairCount[barcode]; }
+          u.bc[i] = barcode;
+        }
+      }
+      if (hasUmi) {       // main.cpp:831-842
+        if (!umiFile.nextBlock(bU) || bU.size() < n) uneven("The UMI file has fewer records than the read file.");
+        for (size_t i = 0; i < n; ++i) {
+          if (u.skip[i]) continue;
+          auto it = umiStrToInt.find(bU[i].seq);
+          if (it != umiStrToInt.end()) u.umi[i] = it->second;
+          else { const int umi = (int)umiStrToInt.size(); umiStrToInt[bU[i].seq] = umi; u.umi[i] = umi; }
+        }
+      }
+      size_t kept = 0;
+      for (size_t i = 0; i < n; ++i) if (!u.skip[i]) {
+        if (firstReadLen == -1) {
+          firstReadLen = (int)u.r[i].seq.size();
+          if (firstReadLen > 200) { fprintf(stderr, "trust4-hip: long-read mode (first read > 200 bp, main.cpp:1467-1481) is not built.\n"); if (processThread.joinable()) processThread.join(); initThread.join(); return EXIT_FAILURE; }
+        }
+        ++kept;
+      }
+      const int before = nIn;
+      nIn += (int)(kept * (hasMate ? 2 : 1));
+      for (int t = before / 100000 + 1; t <= nIn / 100000; ++t) PrintLog("Read in and count kmers for %d reads.", t * 100000);
+      unitPairs += kept;
+      units.push_back(std::move(u));
+      if (unitPairs >= BLOCK) flushBlock();
     }
-    if (hasUmi) {       // main.cpp:831-842
-      umiFile.next();
-      auto it = umiStrToInt.find(umiFile.seq);
-      if (it != umiStrToInt.end()) umi = it->second;
-      else { umi = (int)umiStrToInt.size(); umiStrToInt[umiFile.seq] = umi; }
-    }
-    SortRead nr, mate;
-    nr.barcode = mate.barcode = barcode; nr.umi = mate.umi = umi;
-    nr.id.swap(reads.id); nr.read.swap(reads.seq); nr.qual.swap(reads.qual); nr.hasQual = reads.hasQual;   // the reader hands every record over once
-    ++nIn;
-    if (nIn % 100000 == 0) PrintLog("Read in and count kmers for %d reads.", nIn);
-    if (firstReadLen == -1) {
-      firstReadLen = (int)nr.read.size();
-      if (firstReadLen > 200) { fprintf(stderr, "trust4-hip: long-read mode (first read > 200 bp, main.cpp:1467-1481) is not built.\n"); return EXIT_FAILURE; }
-    }
-    bool haveMate = false;
-    if (mateReads.next()) {
-      haveMate = true;
-      mate.id.swap(mateReads.id); mate.read.swap(mateReads.seq); mate.qual.swap(mateReads.qual); mate.hasQual = mateReads.hasQual;
-      ++nIn;
-      if (nIn % 100000 == 0) PrintLog("Read in and count kmers for %d reads.", nIn);
-    } else if (hasMate) { fprintf(stderr, "The two mate-pair read files have different number of reads.\n"); initThread.join(); exit(1); }
-    block.push_back(InPair{std::move(nr), std::move(mate), haveMate});
-    if (block.size() >= BLOCK) flushBlock();
   }
   flushBlock();
-  if (processThread.joinable()) processThread.join();
+  { const auto tw = std::chrono::steady_clock::now(); if (processThread.joinable()) processThread.join(); secWaitProcess += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count(); }
+  if (getenv("T4_TIMING")) PrintLog("timing: input loop %.2f s, of which %.2f s waiting for the ProcessRead of the batch before", std::chrono::duration<double>(std::chrono::steady_clock::now() - tInput0).count(), secWaitProcess);
   if (gpuProcess) PrintLog("ProcessRead on the device: %lld pairs stay as they are, %lld read-through, %lld merged, %lld with one mate for both", ppKinds[0], ppKinds[1], ppKinds[2], ppKinds[3]);
   if (getenv("T4_TIMING")) PrintLog("timing: input parsed and mates processed (ProcessRead %.2f s on %d threads, merge %.2f s)", secProcess, threadCnt, secMerge);
   int readCnt = (int)sortedReads.size();
