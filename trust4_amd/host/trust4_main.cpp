@@ -708,9 +708,17 @@ int main(int argc, char *argv[]) {
   bool gpuQual = false;
   const size_t KC_CHUNK = 1u << 22;
   auto uploadChunk = [&](size_t lo, size_t hi, std::string &bases, std::vector<int64_t> &off, bool withBarcodes = false) -> t4_batch * {
-    bases.clear(); off.assign(1, 0);
-    std::vector<int32_t> bcs;
-    for (size_t i = lo; i < hi; ++i) { bases += sortedReads[i].read; off.push_back((int64_t)bases.size()); if (withBarcodes) bcs.push_back(sortedReads[i].barcode); }
+    const size_t n = hi - lo;
+    off.resize(n + 1);
+    off[0] = 0;
+    for (size_t i = 0; i < n; ++i) off[i + 1] = off[i] + (int64_t)sortedReads[lo + i].read.size();
+    bases.resize((size_t)off[n]);
+    std::vector<int32_t> bcs(withBarcodes ? n : 0);
+    parallelFor((long long)n, threadCnt, [&](long long i) {   // the reads side by side (the copy of 150 bytes per read is all there is to do)
+      const std::string &r = sortedReads[lo + (size_t)i].read;
+      if (!r.empty()) memcpy(&bases[(size_t)off[(size_t)i]], r.data(), r.size());
+      if (withBarcodes) bcs[(size_t)i] = sortedReads[lo + (size_t)i].barcode;
+    });
     t4_batch *b = nullptr;
     if ((rc = t4_reads_upload(ctx, bases.data(), off.data(), withBarcodes ? bcs.data() : nullptr, (int64_t)(hi - lo), &b))) die(ctx, "t4_reads_upload", rc);
     return b;
@@ -723,13 +731,16 @@ int main(int argc, char *argv[]) {
     const char *ev = getenv("T4_GPU_KMERCOUNT");
     if (ev) wantGpuKc = atoi(ev) != 0;
     else {
-      size_t nQual = 0;
-      bool plain = maxReadLen <= 384;
-      for (const SortRead &r : sortedReads) {
-        if (r.hasQual) ++nQual;
-        if (plain) for (char ch : r.read) if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T' && ch != 'N') { plain = false; break; }
-      }
-      wantGpuKc = plain && (trimLevel == 0 || nQual == 0 || nQual == sortedReads.size());
+      std::atomic<long long> nQualA(0);
+      std::atomic<bool> other(false);
+      if (maxReadLen <= 384)
+        parallelFor((long long)sortedReads.size(), threadCnt, [&](long long i) {
+          const SortRead &r = sortedReads[(size_t)i];
+          if (r.hasQual) nQualA.fetch_add(1, std::memory_order_relaxed);
+          for (char ch : r.read) if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T' && ch != 'N') { other.store(true, std::memory_order_relaxed); break; }
+        });
+      const size_t nQual = (size_t)nQualA.load();
+      wantGpuKc = maxReadLen <= 384 && !other.load() && (trimLevel == 0 || nQual == 0 || nQual == sortedReads.size());
     }
   }
   if (wantGpuKc) {
@@ -775,17 +786,21 @@ int main(int argc, char *argv[]) {
     for (size_t lo = 0; lo < sortedReads.size(); lo += KC_CHUNK) {
       const size_t hi = lo + KC_CHUNK < sortedReads.size() ? lo + KC_CHUNK : sortedReads.size(), n = hi - lo;
       t4_batch *b = uploadChunk(lo, hi, bases, off);
-      if (gpuQual) { quals.clear(); for (size_t i = lo; i < hi; ++i) quals += sortedReads[i].qual; }
+      if (gpuQual) {   // (the qualities of a read stand where its bases stand: same offsets)
+        quals.resize(bases.size());
+        parallelFor((long long)n, threadCnt, [&](long long i) { const SortRead &r = sortedReads[lo + (size_t)i]; const size_t m = r.qual.size() < r.read.size() ? r.qual.size() : r.read.size(); if (m) memcpy(&quals[(size_t)off[(size_t)i]], r.qual.data(), m); });
+      }
       mn.resize(n); md.resize(n); nl.resize(n); av.resize(n);
       if ((rc = t4_kmer_count_stats(gpuKc, b, gpuQual ? quals.data() : nullptr, gpuQual ? off.data() : nullptr, mn.data(), md.data(), av.data(), nl.data()))) die(ctx, "t4_kmer_count_stats", rc);
       t4_batch_destroy(b);
-      for (size_t i = 0; i < n; ++i) {
+      parallelFor((long long)n, threadCnt, [&](long long ii) {
+        const size_t i = (size_t)ii;
         SortRead &r = sortedReads[lo + i];
         r.minCnt = mn[i]; r.medianCnt = md[i]; r.avgCnt = av[i];
         if ((size_t)nl[i] < r.read.size()) r.read.resize((size_t)nl[i]);
         r.qual.clear(); r.qual.shrink_to_fit(); r.hasQual = false;
         if (r.read.empty()) r.dead = true;
-      }
+      });
     }
     t4_kmer_count_destroy(gpuKc);
     gpuKc = nullptr;
@@ -797,9 +812,13 @@ int main(int argc, char *argv[]) {
     if (r.read.empty()) r.dead = true;
   });
   {
-    std::vector<SortRead> kept;
-    for (SortRead &r : sortedReads) if (!r.dead) { r.len = (int)r.read.size(); kept.push_back(std::move(r)); }
-    sortedReads.swap(kept);
+    std::atomic<bool> anyDead(false);
+    parallelFor((long long)sortedReads.size(), threadCnt, [&](long long i) { SortRead &r = sortedReads[(size_t)i]; if (r.dead) anyDead.store(true, std::memory_order_relaxed); else r.len = (int)r.read.size(); });
+    if (anyDead.load()) {
+      std::vector<SortRead> kept;
+      for (SortRead &r : sortedReads) if (!r.dead) kept.push_back(std::move(r));
+      sortedReads.swap(kept);
+    }
     readCnt = (int)sortedReads.size();
   }
   mark("input_processed_counted");
