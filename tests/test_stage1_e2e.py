@@ -348,6 +348,32 @@ def test_bulk_live_set_paths_gpu(tmp_path, env):
 
 
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
+def test_tied_reads_take_the_reference_sort_emulated(tmp_path):
+    """The driver sorts the read list on its threads only when no two reads tie under the reference's comparator (then the order is
+    THE sorted order); pairs whose mates carry the same id and the same sequence do tie, and the list must then go through
+    std::sort as in the reference -- the outputs stay byte-identical either way (T4_SORT_MIN sends this small input down the
+    threaded path first)."""
+    import random
+    fa = str(tmp_path / "ref.fa")
+    _gunzip(REF_FA, fa)
+    r1, r2 = Synth(6, 31).next_pairs(260)
+    a, b = rows_to_strs(r1), rows_to_strs(r2)
+    rnd = random.Random(5)
+    for at in (3, 40, 41, 120, 259):   # both mates of these pairs: one sequence (no overlap with its own reverse complement)
+        a[at] = b[at] = "".join(rnd.choice("ACGT") for _ in range(100))
+    f1, f2 = str(tmp_path / "t_1.fq"), str(tmp_path / "t_2.fq")
+    _write_fastq(f1, a)
+    _write_fastq(f2, b)
+    args = ["--skipMateExtension", "-f", fa, "-1", f1, "-2", f2]
+    ref_out, my_out = str(tmp_path / "ref"), str(tmp_path / "mine")
+    subprocess.run([REF_BIN, "-t", "1"] + args + ["-o", ref_out], check=True, stderr=subprocess.DEVNULL)
+    p = subprocess.run([_emulated_driver(), "-t", "4"] + args + ["-o", my_out], check=True, env=dict(os.environ, T4_SORT_MIN="64", T4_TIMING="1"), stderr=subprocess.PIPE, text=True)
+    assert "two reads of the list tie" in p.stderr
+    for suffix in ("_raw.out", "_assembled_reads.fa", "_final.out"):
+        assert filecmp.cmp(ref_out + suffix, my_out + suffix, shallow=False), suffix
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
 def test_bulk_paired_needs_skip_mate_extension_emulated(tmp_path):
     """Paired-end input without barcodes and without --skipMateExtension: the reference would run its mate-pair extension and the
     annotator reads _final.out, so the driver refuses (exit 1, before touching the input) instead of writing the raw assembly under

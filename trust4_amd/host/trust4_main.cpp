@@ -296,7 +296,11 @@ template <class Less> void sortReadsOnThreads(std::vector<SortRead> &v, int thre
   const uint32_t *src = perm.data();
   std::atomic<bool> tie(false);
   parallelFor((long long)n - 1, threads, [&](long long i) { if (!less(v[src[i]], v[src[i + 1]])) tie.store(true, std::memory_order_relaxed); });
-  if (tie.load()) { std::sort(v.begin(), v.end(), less); return; }
+  if (tie.load()) {
+    if (getenv("T4_TIMING")) fprintf(stderr, "timing: two reads of the list tie under the comparator: sorted by std::sort as in the reference\n");
+    std::sort(v.begin(), v.end(), less);
+    return;
+  }
   std::vector<SortRead> out(n);
   parallelFor((long long)n, threads, [&](long long i) { out[(size_t)i] = std::move(v[src[i]]); });
   v.swap(out);
