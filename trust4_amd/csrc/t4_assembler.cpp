@@ -495,6 +495,7 @@ struct t4_assembler : IndexListener {
     unsigned char tier = 0;      // the last query of this read ended on the global-scratch tier
     bool fragile = false;        // any change of one of its keys' lists invalidates it
     int slack = 0;               // tolerated hit-set changes left before possibleOverlapCnt could pass 100 (SeqSet.hpp:813-823)
+    int lastUs = 0;              // what this read's last query took in its workgroup (microseconds; 0: never queried): a launch lasts as long as its slowest read
     bool statsStable = false;    // the query itself found that edits of small groups cannot move novelMinHitRequired (T4QueryArgs::statsStable): exact, needs no slack
     GroupTable groups;
     // a (re-)query of this entry is running on a lane: commits since its launch are examined against its dependency sets like
@@ -558,7 +559,7 @@ struct t4_assembler : IndexListener {
   int64_t baseUsed = 0;            // device arena of consensus chars / posWeight predicate bytes (one offset space)
   std::vector<int> dirtySeqs;
   bool liveReset = true;           // the next delta describes the whole image (first upload, k change)
-  int64_t toleratedStable = 0, invLongLists = 0;
+  int64_t toleratedStable = 0, invLongLists = 0, slowSkipped = 0;
   int64_t deltas = 0, deltaBytes = 0, rounds = 0, readsQueried = 0, invKey = 0, invCross = 0, invRegion = 0, invShift = 0, invContig = 0, invFragile = 0, tolerated = 0;
   double secDelta = 0, secGroups = 0, secEvents = 0, secRegister = 0, secPrefetch = 0, secAddTotal = 0;
 
@@ -1614,7 +1615,7 @@ void t4_assembler::announceLive(int n, const char *const *reads, const int *stra
     c.read = reads[i]; c.strand = strands[i]; c.barcode = barcodes ? barcodes[i] : -1; c.skip = repetitive; c.cnt = 0; c.valid = false;
     c.inflight = false; c.killed = false; c.shifts.clear();
     c.ov.clear(); c.ext.clear(); c.extRet.clear();
-    c.uid = nextUid++; c.tier = 0; c.registered = false;
+    c.uid = nextUid++; c.tier = 0; c.lastUs = 0; c.registered = false;
     order.push_back(sl);
   }
 }
@@ -1695,6 +1696,8 @@ int t4_assembler::harvest(Lane &L) {
     for (int i = 0; i < m && i < nn; ++i) fprintf(roundLog, " %d/%d/%d/%d", ticks ? ticks[i] / 100 : -1, cnts[i], (int)L.hint[i], pool[L.slots[i]]->uid == L.uids[i] ? (int)pool[L.slots[i]]->killed : 2);
     fputc('\n', roundLog);
   }
+  const int32_t *ticks10ns = nullptr; int nTicks = 0;
+  { double ms_ = 0; (void)t4_add_query_last_call(L.ctx, &ms_, &ticks10ns, &nTicks); }
   const int32_t *stable = nullptr; int nStable = 0;
   static const bool noStable = getenv("T4_NO_STABLE_STATS") != nullptr;   // A/B aid: the slack rule for every entry, as before round 3
   if (!noStable) (void)t4_add_query_last_stable(L.ctx, &stable, &nStable);
@@ -1703,6 +1706,8 @@ int t4_assembler::harvest(Lane &L) {
     if (c.uid != L.uids[i] || !c.inflight) continue;   // the entry was retired (or re-announced) meanwhile
     c.inflight = false;
     c.tier = L.hint[i];
+    if (ticks10ns && i < nTicks) c.lastUs = ticks10ns[i] / 100;
+    { static const bool proxy = getenv("T4_SLOW_PROXY") != nullptr; if (proxy) c.lastUs = 50 + 12 * (cnts[i] > 0 ? cnts[i] : 0); }   // testing aid (the emulator has no clock): a time from the overlap count
     c.statsStable = stable && i < nStable && stable[i] == 1;
     if (c.killed) { c.killed = false; c.shifts.clear(); ++killedInFlight; continue; }
     c.cnt = cnts[i];
@@ -1748,9 +1753,15 @@ int t4_assembler::pumpLive(bool needHead, int repetitive) {
     }
     Cached &head = *pool[order.front()];
     std::vector<int> light, heavy;
+    // A launch ends with its slowest read. A read whose last query was slow is therefore left out of launches made for reads well
+    // before it: it joins one when it is about to be served (and is then not re-queried each time a commit far ahead of it
+    // invalidates it).
+    static const int slowUs = getenv("T4_SLOW_US") ? atoi(getenv("T4_SLOW_US")) : 0;
+    static const size_t slowAhead = getenv("T4_SLOW_AHEAD") ? (size_t)atoi(getenv("T4_SLOW_AHEAD")) : 3;
     for (size_t i = 0; i < order.size() && i < ahead; ++i) {
       Cached &c = *pool[order[i]];
       if (c.valid || c.inflight) continue;
+      if (slowUs > 0 && i >= slowAhead && c.lastUs > slowUs) { ++slowSkipped; continue; }
       (c.tier ? heavy : light).push_back(order[i]);
     }
     const bool headWaits_ = !head.valid && !head.inflight;
@@ -2016,6 +2027,7 @@ int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n) {
             a->secAddTotal, a->secPrefetch, a->secLaunch, a->secDelta, a->secGroups, a->secRegister, a->secHarvest, a->secEvents, a->index.secOps);
     fprintf(stderr, "timing: query lanes %d: %lld launches (%lld for a head without a result), %lld waits for the head's lane in %.3f s, %lld queries killed in flight\n",
             (int)a->lanes.size(), (long long)a->launches, (long long)a->launchesUrgent, (long long)a->headWaits, a->secHeadWait, (long long)a->killedInFlight);
+    if (a->slowSkipped) fprintf(stderr, "timing: %lld times a read whose last query was slow stayed out of a launch made for reads before it\n", (long long)a->slowSkipped);
     fprintf(stderr, "timing: tolerated index edits %lld, of which %lld met an entry whose group statistics cannot move (no budget spent); tolerance kills %lld, of which %lld for lists beyond 10000 postings\n",
             (long long)a->tolerated, (long long)a->toleratedStable, (long long)a->invFragile, (long long)a->invLongLists);
   }
