@@ -794,8 +794,9 @@ static int is_low_complexity(const char *seq) {
  * for len1 + len2 + 1 each) receive read 1 as ProcessRead leaves it; *flags: 1 read 1 is pushed to the read list (not of low
  * complexity), 2 read 2 is, 4 weight 2 (the merged read is listed twice), 8 read 1 has qualities. Returns the branch taken: 0 the
  * mates stay, 1 read-through (248-287), 2 merged (291-337), 3 one mate stands for both (338-385). The k-mer counting of the
- * surviving reads and the bookkeeping of ids are the caller's. PARITY: pinned through the reference BINARY only (tests compare
- * whole stage 1 with the device path switched on); ProcessRead is a static function of main.cpp and cannot be linked. */
+ * surviving reads and the bookkeeping of ids are the caller's. PARITY: pinned against the function itself -- the reference's main.cpp
+ * compiled as a library with its `main` renamed (oracle/ref_main_probe.cpp -> _ref/libt4refmain.so;
+ * tests/test_oracle_vs_ref.py::test_process_read_vs_the_reference_main) -- and through the reference binary (whole stage 1). */
 int t4o_process_read(const char *r1in, const char *q1in, const char *r2in, const char *q2in, char *outR, char *outQ, int *flags) {
   int slen = (int)strlen(r1in), flen = (int)strlen(r2in), j, k, kind = 0, rWeight = 1, r2Alive = 1;
   char *r1 = strdup(r1in), *q1 = q1in ? strdup(q1in) : NULL;

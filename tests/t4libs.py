@@ -47,6 +47,34 @@ def build_checkers():
         subprocess.run(["gcc", "-O2", "-std=gnu99", "-DT4SYNTH_MAIN", "-o", cli, src, "-lz"], check=True)
 
 
+class RefMain:
+    """Functions of the reference's main.cpp itself (oracle/_ref/libt4refmain.so: ProcessRead, IsLowComplexity)."""
+    PATH = os.path.join(ROOT, "oracle", "_ref", "libt4refmain.so")
+
+    @classmethod
+    def available(cls):
+        return os.path.exists(cls.PATH)
+
+    def __init__(self):
+        self.lib = C.CDLL(self.PATH)
+        self.lib.refmain_process_read.restype = C.c_int
+        self.lib.refmain_process_read.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_int)]
+        self.lib.refmain_is_low_complexity.restype = C.c_int
+        self.lib.refmain_is_low_complexity.argtypes = [C.c_char_p]
+
+    def process_read(self, r1, q1, r2, q2):
+        """-> (records pushed, read 1 as pushed or "", its qualities, flags: 1 read 1 pushed, 2 read 2 pushed, 4 weight 2, 8 qualities)"""
+        n = len(r1) + len(r2) + 2
+        outr, outq = C.create_string_buffer(n), C.create_string_buffer(n)
+        fl = C.c_int(0)
+        cnt = self.lib.refmain_process_read(_b(r1), None if q1 is None else _b(q1), _b(r2), None if q2 is None else _b(q2), outr, outq, C.byref(fl))
+        rd = outr.value.decode()
+        return cnt, rd, outq.raw[:len(rd)], fl.value
+
+    def is_low_complexity(self, s):
+        return self.lib.refmain_is_low_complexity(_b(s))
+
+
 class _SetAPI:
     """Common surface of Oracle and Ref (same call signatures)."""
     P = ""  # symbol prefix

@@ -139,6 +139,36 @@ def test_is_mate_overlap():
             assert o.is_mate_overlap(fr, sr, mo, ct) == r.is_mate_overlap(fr, sr, mo, ct)
 
 
+def test_process_read_vs_the_reference_main():
+    """The oracle's restatement of ProcessRead (main.cpp:224-449) against the function itself (the reference's main.cpp compiled as
+    a library, oracle/_ref/libt4refmain.so): which records are pushed, read 1 as pushed, its qualities, the weight. With qualities
+    on both mates (without them the reference's merge dereferences a null pointer, main.cpp:304-309)."""
+    from t4libs import RefMain
+    from test_engine_emu import pair_cases
+    if not RefMain.available():
+        pytest.skip("oracle/_ref/libt4refmain.so not built")
+    o, r = Oracle(9), RefMain()
+    R1, Q1, R2, Q2 = pair_cases(11, 1500)
+    kinds = [0, 0, 0, 0]
+    for i in range(len(R1)):
+        kind, rd, ql, fl = o.process_read(R1[i], Q1[i], R2[i], Q2[i])
+        cnt, rrd, rql, rfl = r.process_read(R1[i], Q1[i], R2[i], Q2[i])
+        kinds[kind] += 1
+        assert (fl & 3) == (rfl & 3), (i, R1[i], R2[i], fl, rfl)
+        assert cnt == (1 if fl & 1 else 0) * (2 if fl & 4 else 1) + (1 if fl & 2 else 0), (i, cnt, fl)
+        if fl & 1:
+            assert (rd, ql, fl & 12) == (rrd, rql, rfl & 12), (i, kind, R1[i], R2[i], rd, rrd)
+    assert min(kinds) > 20, kinds
+    rnd = random.Random(2)
+    # IsLowComplexity through a pair that cannot overlap: read 2 random, read 1 the string under test
+    for _ in range(300):
+        s = "".join(rnd.choice(rnd.choice(["ACGT", "AAAC", "ACGTN", "AC"])) for _ in range(rnd.randint(30, 120)))
+        other = "".join(rnd.choice("ACGT") for _ in range(100))
+        kind, rd, ql, fl = o.process_read(s, None, other, None)
+        if kind == 0:
+            assert (fl & 1) == (0 if r.is_low_complexity(s) else 1), s
+
+
 def test_lis():
     o, r = Oracle(9), Ref(9)
     rnd = random.Random(7)
