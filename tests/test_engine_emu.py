@@ -435,6 +435,25 @@ def test_process_pairs_vs_oracle(emu_engine):
     check_process_pairs(emu_engine, 5, 500)
 
 
+def check_process_pairs_edges(eng):
+    """empty and very short mates, a mate of the maximum length, one beyond it (refused loudly)"""
+    o = Oracle(9)
+    rnd = random.Random(9)
+    long_a = "".join(rnd.choice("ACGT") for _ in range(384))
+    R1 = ["", "A", "ACGTACGTAC", long_a, "ACGTTGCATGCATGCAAGGT"]
+    R2 = ["", "T", "", long_a[::-1], ""]
+    got = eng.process_pairs(R1, None, R2, None)
+    for i in range(len(R1)):
+        assert got[i] == o.process_read(R1[i], None, R2[i], None), (i, got[i])
+    with pytest.raises(Exception) as e:
+        eng.process_pairs([long_a + "A"], None, ["ACGT"], None)
+    assert "longer than" in str(e.value)
+
+
+def test_process_pairs_edges(emu_engine):
+    check_process_pairs_edges(emu_engine)
+
+
 def check_has_hit(eng, seed, hit_lens=(17, 27)):
     from test_oracle_vs_ref import has_hit_reads
     reads = [r for r in has_hit_reads(seed) if set(r) <= set("ACGTN")]

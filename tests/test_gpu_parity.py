@@ -137,8 +137,9 @@ def test_add_path_matches_reference(eng, tmp_path, seed, n_pairs, n_clones):
 
 
 def test_process_pairs_vs_oracle(eng):
-    from test_engine_emu import check_process_pairs
+    from test_engine_emu import check_process_pairs, check_process_pairs_edges
     check_process_pairs(eng, 5, 20000)
+    check_process_pairs_edges(eng)
 
 
 def test_mate_overlap_vs_oracle(eng):
