@@ -3,26 +3,31 @@
 
 A "step" is ONE WHOLE STAGE 1 (`trust4_amd/bin/trust4-hip`: FASTQ in -> ProcessRead / 21-mer counts / sort -> rough
 annotation of every read on the GPU -> the order-dependent AddRead pass (host commits + GPU queries against a device
-image patched by deltas) -> `_raw.out`, `_assembled_reads.fa`, `_final.out`) over one batch of synthetic 150 bp
-paired-end reads of the SURVEY.md 8(d) C2 recipe (20 k clones per 1 M pairs, seed 1 + rank, -f hg38_bcrtcr.fa, k = 9,
-bulk mode). `value` = pairs of all ranks / wall clock of the slowest rank, process start to exit: the parse of the FASTQ
-text, device bring-up and every host phase are INSIDE the timed region (the boundary hands over files, as
-run-trust4:508 does, so there is no "inputs resident in HBM" variant of this metric; the kernel-only numbers are in
-`roofline` / `passes`).
+image patched by deltas) -> `_raw.out`, `_assembled_reads.fa`, `_final.out`), process start to exit: the parse of the FASTQ
+text, device bring-up and every host phase are INSIDE the timed region (the boundary hands over files, as run-trust4:508 does,
+so there is no "inputs resident in HBM" variant of this metric; the kernel-only numbers are in `roofline` / `passes`).
 
-The default batch is 100 k pairs (C2 recipe at 1/10 of its size): the AddRead pass is a chain of dependent GPU round
-trips, whole C2 takes tens of minutes and the reference hours. `--pairs 1000000 --steps 1 --warmup 0`
-runs config C2 itself.
-
-Rank 0 at N = 1 also reports
-  cpu_baseline   the reference binary (oracle/_ref/trust4) on THE SAME files with -t <host cores>, outputs compared byte for
-                 byte with the GPU run's (`parity_on_bench_batch`), and with -t 1 on a stated prefix;
-  passes         kernel-level numbers of the two GPU passes of the timed runs (HIP-event kernel time, _hit records H,
-                 algorithmic bytes of SURVEY 8d) and the rough-annotation pass alone over a resident C2 batch (2 M reads);
+N = 1. The workload is BASELINE.json's config C2 ITSELF (1 M synthetic 150 bp PE pairs, 20 k clones, seed 1, -f hg38_bcrtcr.fa,
+bulk mode) whenever `steps + warmup` runs of it fit the time budget (T4_BENCH_BUDGET_S, default 1500 s): the first run is C2 in
+any case -- it is compared with the committed md5 sums of the reference's outputs, it is the first warm-up step when C2 is the
+workload, and it is reported as `c2` (with its own roofline block and a same-box reference timing on a stated prefix of the same
+files). When the runs do not fit, the steps are timed on the C2 recipe at 100 k pairs (`config.workload` says which ran).
+Rank 0 also reports
+  cpu_baseline   the reference binary (oracle/_ref/trust4) on the SAME box: on the whole batch of the timed steps when that is the
+                 100 k-pair batch (outputs compared byte for byte, `parity_on_bench_batch`), on the first 200 k pairs of C2's files
+                 when C2 is the workload (-t <host cores>; `sample` names the files);
+  roofline       the dominant kernels of a step (the AddRead query launches), HIP-event time on the engine's stream, bytes as
+                 SURVEY 8d defines them, `traffic` from two rocprofv3 PMC passes of the 100 k-pair command;
+  passes         kernel-level numbers of the two GPU passes and the rough-annotation pass alone over a resident C2 batch;
   stage1_cells   whole stage 1 in barcode mode (C5 recipe sample) next to the reference binary;
   stage0_e2e     the stage-0 candidate filter next to the reference binary.
-Multi-GPU: bulk-mode stage 1 is one ordered chain (replicas only): every rank runs its own batch on its own
-GPU with no data-path collective; timing is barrier + max over ranks (weak scaling).
+
+N > 1 measures the path that shards: ONE barcode-mode sample of the C5 recipe (`--cells-pairs` pairs and
+`--cells` cells per GPU of the job), cells sharded by rank through `trust4-hip --cellShard R/N --rcclId FILE` -- no exchange
+during assembly, one RCCL all-gather of the contig records inside the engine at the end, rank 0 writes the files. Strong scaling:
+the sample is fixed by N, `value` = its pairs / the slowest rank's wall time. Rank 0 then runs the same sample on one rank and
+compares the md5 sums of the three output files (`one_rank`), and reports the replicated-phase seconds of every rank.
+Bulk-mode stage 1 itself is one ordered chain (replicas only): it is what N = 1 measures.
 """
 import argparse
 import filecmp
@@ -162,7 +167,24 @@ def file_md5(path):
     return h.hexdigest()
 
 
-def config_leg(name, threads, device, mode="skipMateExtension"):
+def add_roofline(aq, note=""):
+    """roofline block of the AddRead query launches of one whole stage 1, from the engine's own counters (stats JSON)"""
+    alg = add_bytes(aq["reads_queried"], 150, aq["hits"])
+    alg1 = add_bytes(aq["reads_served"], 150, int(aq["hits"] * aq["reads_served"] / max(1, aq["reads_queried"])))
+    sec = max(aq["kernel_ms"], 1e-6) * 1e-3
+    return {"bound": "hbm", "achieved": alg / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / sec / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "t4k::queryKernel<8192, 512, 512, 1> mode 4 (AddRead query: seed->sort->chain->score->ExtendOverlap) + the wide query's kernels "
+                      "(t4k::wide{Scatter,Sort,Stats,Chain,Merge}Kernel, reads beyond the LDS tier spread over the chip) + t4k::extendKernel behind them "
+                      "(kernel_ms brackets a round's launches), all %d query rounds of one step" % aq["rounds"],
+            "kernel_ms": aq["kernel_ms"], "launch_ms_avg": aq["kernel_ms"] / max(1, aq["rounds"]),
+            "algorithmic_bytes_per_step": alg, "reads_queried": aq["reads_queried"], "reads_served": aq["reads_served"], "hits": aq["hits"],
+            "algorithmic_bytes_per_step_reads_served_only": alg1, "frac_reads_served_only": alg1 / sec / 1e9 / HBM_PEAK_GBS,
+            "note": "a latency-bound chain of dependent launches (DESIGN 3b): bytes / kernel time says how little of the HBM rate a dependent round can use; "
+                    "`achieved` counts every query the engine ran (re-queries of invalidated window entries included), `frac_reads_served_only` scales the "
+                    "bytes to one query per served read as the reference does" + note}
+
+
+def config_leg(name, threads, device, mode="skipMateExtension", keep=None, cpu_prefix_pairs=0):
     """One whole stage 1 through trust4-hip on a BASELINE config itself (C2 = 1 M pairs, 20 k clones, seed 1; `c3p*` = a stated
     prefix of C3's read stream), under this run's clock, outputs compared with the md5 sums of the REFERENCE's outputs on the same
     files (tests/golden/c2_digests.json, produced by tools/c2_digests.py from oracle/_ref/trust4; the input files are
@@ -170,7 +192,7 @@ def config_leg(name, threads, device, mode="skipMateExtension"):
     name, _, variant = name.partition(":")
     if variant == "dropin":   # the reference's main.cpp bound to the C ABI (integration/), run-trust4's DEFAULT options: mate-pair extension tail included
         mode = "default"
-    tmp = tempfile.mkdtemp(prefix="t4%s_" % name)
+    tmp = keep or tempfile.mkdtemp(prefix="t4%s_" % name)
     try:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import c2_digests
@@ -201,8 +223,11 @@ def config_leg(name, threads, device, mode="skipMateExtension"):
             aq = st["add_query"]
             out.update({"contigs": st["contigs"], "assembled_reads": st["assembled_reads"],
                         "rounds": aq["rounds"], "reads_queried": aq["reads_queried"], "reads_served": aq["reads_served"], "invalidations": aq["invalidations"],
-                        "kernel_ms": aq["kernel_ms"], "launch_ms_avg": aq["kernel_ms"] / max(1, aq["rounds"]), "hits": aq["hits"], "query_wall_s": aq["query_wall_s"],
-                        "addread_pass_s": st["phases_s"]["assembled"] - st["phases_s"]["trimmed_ready"]})
+                        "kernel_ms": aq["kernel_ms"], "launch_ms_avg": aq["kernel_ms"] / max(1, aq["rounds"]), "hits": aq["hits"],
+                        "host_wait_for_queries_s": aq.get("host_wait_for_queries_s"), "wide": aq.get("wide"),
+                        "addread_pass_s": st["phases_s"]["assembled"] - st["phases_s"]["trimmed_ready"], "phases_s": st["phases_s"],
+                        "roofline": add_roofline(aq)})
+            out["files"] = (fa, f1, f2, mine, stats_path)
         if golden is None or mode not in golden.get("modes", {}):
             out["identical"] = None
             out["note"] = "no reference digests committed for this config / mode"
@@ -210,13 +235,26 @@ def config_leg(name, threads, device, mode="skipMateExtension"):
             g = golden["modes"][mode]
             out["identical"] = bool(inputs_ok and all(md5s[x] == g["md5"][x] for x in OUT_SUFFIXES))
             out["inputs_identical"] = bool(inputs_ok)
-            out["reference"] = {"seconds": g["reference_seconds"], "threads": g["reference_threads"], "pairs_per_s": n / g["reference_seconds"],
-                                "where": "the builder's container (tools/c2_digests.py), not this box"}
+            out["reference_digest_run"] = {"seconds": g["reference_seconds"], "threads": g["reference_threads"], "pairs_per_s": n / g["reference_seconds"],
+                                           "where": "the builder's container (tools/c2_digests.py), not this box: a digest, not a baseline"}
+        if cpu_prefix_pairs > 0 and os.path.exists(REF_BIN):   # the reference on THIS box, on a stated prefix of the same files
+            np_ = min(cpu_prefix_pairs, n)
+            h1, h2 = os.path.join(tmp, "cpu_1.fq"), os.path.join(tmp, "cpu_2.fq")
+            head_fastq(f1, h1, np_)
+            head_fastq(f2, h2, np_)
+            cores = host_cores()
+            t0 = time.perf_counter()
+            subprocess.run([REF_BIN, "-t", str(cores), "--skipMateExtension", "-f", fa, "-1", h1, "-2", h2, "-o", os.path.join(tmp, "cpuref")], check=True, stderr=subprocess.DEVNULL)
+            dc = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": np_ / dc, "unit": "pairs/s", "cores": cores, "kind": "reference", "seconds": dc,
+                                   "sample": "oracle/_ref/trust4 -t %d --skipMateExtension on the first %d pairs of config %s's own files (%s, %s), on this box, %.1f s wall"
+                                             % (cores, np_, name.upper(), os.path.basename(f1), os.path.basename(f2), dc)}
         return out
     except Exception as e:   # noqa: BLE001  (a side leg never takes the bench line down)
         return {"error": repr(e)[:300]}
     finally:
-        shutil.rmtree(tmp, ignore_errors=True)
+        if not keep:
+            shutil.rmtree(tmp, ignore_errors=True)
 
 
 def pmc_traffic(fa, f1, f2, threads, device, tmp, kernels=("queryKernel", "extendKernel")):
@@ -338,22 +376,108 @@ def stage0_e2e(pairs, receptor_fraction=0.02):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def sharded_cells(args, rank, local_rank, world, dist):
+    """N > 1: one C5-recipe sample, cells sharded by rank, one RCCL all-gather inside the engine at the end (strong scaling)."""
+    import torch
+    import trust4_amd.dist as t4dist
+    pairs, cells = args.cells_pairs * world, args.cells * world
+    tmp = os.path.join(tempfile.gettempdir(), "t4bench_cells_%s" % os.environ.get("MASTER_PORT", "0"))
+    fa, pre = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "c5")
+    if rank == 0:
+        import t4libs
+        shutil.rmtree(tmp, ignore_errors=True)
+        os.makedirs(tmp)
+        with gzip.open(t4libs.REF_FA, "rb") as f, open(fa, "wb") as g:
+            shutil.copyfileobj(f, g)
+        subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, str(pairs), "0", "4", pre, "--cells", str(cells)], check=True, stdout=subprocess.DEVNULL)
+    dist.barrier()
+    argv = ["-f", fa, "-1", pre + "_1.fq", "-2", pre + "_2.fq", "--barcode", pre + "_bc.fa", "--UMI", pre + "_umi.fa"]
+    threads = max(1, min(args.cells_threads, host_cores() // world))
+    out = os.path.join(tmp, "sharded")
+    id_file = out + ".rcclid"
+
+    def one_step(timed):
+        if rank == 0 and os.path.exists(id_file):
+            os.remove(id_file)
+        torch.cuda.synchronize()
+        dist.barrier()
+        env = dict(os.environ, T4_DEVICE=str(local_rank), T4_STATS_JSON=os.path.join(tmp, "stats_rank%d.json" % rank))
+        t0 = time.perf_counter()
+        p = subprocess.run([DRIVER, "-t", str(threads)] + argv + ["-o", out, "--cellShard", "%d/%d" % (rank, world), "--rcclId", id_file], env=env, stderr=subprocess.PIPE, text=True)
+        if p.returncode:
+            raise SystemExit("rank %d: trust4-hip --cellShard failed (%d): %s" % (rank, p.returncode, " | ".join(p.stderr.strip().split("\n")[-4:])))
+        torch.cuda.synchronize()
+        dist.barrier()
+        return time.perf_counter() - t0
+
+    for _ in range(args.warmup):
+        one_step(False)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(True)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = t4dist.max_over_ranks(dist, time.perf_counter() - t0, "cuda")
+    # replicated-phase seconds of this rank (everything before the Add pass runs on every rank), gathered for the report
+    rep = add = 0.0
+    try:
+        ph = json.load(open(os.path.join(tmp, "stats_rank%d.json" % rank)))["phases_s"]
+        rep, add = ph["trimmed_ready"], ph["assembled"] - ph["trimmed_ready"]
+    except Exception:   # noqa: BLE001
+        pass
+    t = torch.tensor([rep, add], dtype=torch.float64, device="cuda")
+    parts = [torch.zeros(2, dtype=torch.float64, device="cuda") for _ in range(world)]
+    dist.all_gather(parts, t)
+    if rank == 0:
+        line = {"metric": "stage-1 assembly read pairs/sec (150 bp PE), whole stage 1, barcode mode, cells sharded over the GPUs", "value": pairs * args.steps / dt,
+                "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "int32/u64", "data": "synthetic",
+                "config": {"workload": "C5 recipe sample: %d synthetic 150 bp PE pairs, %d cells x 2 clones, barcode + UMI files; ONE sample over %d GPUs: every rank runs trust4-hip -t %d "
+                                       "--cellShard R/%d --rcclId (parse / ProcessRead / 21-mer counts / sort / rough annotation replicated, the Add pass of a contiguous range of cells per rank, "
+                                       "one ncclAllGather of the contig records inside the engine, rank 0 writes the files); process start to exit of the slowest rank"
+                                       % (pairs, cells, world, threads, world),
+                           "pairs": pairs, "cells": cells, "host_threads_per_rank": threads,
+                           "per_rank_s": {"replicated_phases": [float(x[0]) for x in parts], "add_pass_of_its_cells": [float(x[1]) for x in parts]}}}
+        md5s = {x: file_md5(out + x) for x in OUT_SUFFIXES}
+        one = os.path.join(tmp, "one_rank")
+        t1 = time.perf_counter()
+        p = subprocess.run([DRIVER, "-t", str(threads)] + argv + ["-o", one], env=dict(os.environ, T4_DEVICE=str(local_rank)), stderr=subprocess.PIPE, text=True)
+        d1 = time.perf_counter() - t1
+        if p.returncode:
+            line["one_rank"] = {"error": p.stderr.strip().split("\n")[-1][:300]}
+        else:
+            line["one_rank"] = {"seconds": d1, "pairs_per_s": pairs / d1, "identical": all(file_md5(one + x) == md5s[x] for x in OUT_SUFFIXES),
+                                "speedup_of_the_sharded_run": d1 / (dt / args.steps), "note": "the same sample through one trust4-hip on GPU 0 after the timed region; md5 of the three output files compared"}
+        line["md5"] = md5s
+        print(json.dumps(line))
+    dist.barrier()
+    if rank == 0:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=100000, help="read pairs per GPU per step (C2 = 1000000)")
+    ap.add_argument("--pairs", type=int, default=0, help="read pairs per step: 0 = config C2 itself (1 M pairs) when steps + warmup runs of it fit the budget, else the C2 recipe at 100 k pairs; "
+                                                         "a number forces the C2 recipe at that size")
     ap.add_argument("--clones", type=int, default=0, help="clones of the batch (default: pairs / 50, the C2 ratio)")
     ap.add_argument("--threads", type=int, default=8, help="host threads of trust4-hip (-t)")
+    ap.add_argument("--budget", type=float, default=float(os.environ.get("T4_BENCH_BUDGET_S", "1500")), help="seconds the warm-up + timed steps may take (decides whether C2 itself is the workload)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 = skip the reference legs")
     ap.add_argument("--cpu-single-pairs", type=int, default=20000, help="prefix timed with the reference's -t 1 (0 = skip)")
+    ap.add_argument("--cpu-c2-pairs", type=int, default=200000, help="prefix of C2's files the reference is timed on, on this box (0 = skip)")
     ap.add_argument("--side-legs", type=int, default=1, help="0 = skip passes.rough_annotation_c2 / stage1_cells / stage0_e2e")
     ap.add_argument("--traffic", type=int, default=1, help="0 = skip the two rocprofv3 PMC passes that measure roofline.traffic")
-    ap.add_argument("--c2", type=int, default=1, help="0 = skip the `c2` leg (one whole stage 1 on config C2 itself, 1 M pairs, compared with the reference's digests)")
-    ap.add_argument("--config-leg", default="", help="additional config legs, comma separated (c3p2, c3p5: prefixes of C3; c2:dropin = C2 with default options through the reference's main.cpp bound to the C ABI)")
+    ap.add_argument("--c2", type=int, default=1, help="0 = skip the run of config C2 itself (then the steps are timed on the 100 k-pair batch)")
+    ap.add_argument("--config-leg", default="", help="additional config legs, comma separated (c3p05, c3p2, c3p5: prefixes of C3; c2:dropin = C2 with default options through the reference's main.cpp bound to the C ABI)")
+    ap.add_argument("--cells-pairs", type=int, default=250000, help="N > 1: pairs of the barcode-mode sample per GPU of the job")
+    ap.add_argument("--cells", type=int, default=2500, help="N > 1: cells of the sample per GPU of the job")
+    ap.add_argument("--cells-threads", type=int, default=16, help="N > 1: host threads per rank")
     args = ap.parse_args()
-    clones = args.clones if args.clones > 0 else max(1, args.pairs // 50)
 
     import torch
     import trust4_amd.build
@@ -365,103 +489,141 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the measured path")
     torch.cuda.set_device(local_rank)
-    dist = t4dist.init("nccl")   # RCCL; used for the barrier + max-reduce only (bulk stage 1: replicas, no data-path collective)
+    dist = t4dist.init("nccl")   # RCCL: barrier + max-reduce of the timed interval (the data-path collective of the sharded run is inside the engine)
 
     if rank == 0:
         trust4_amd.build.build()
         t4libs.build_checkers()
     if dist:
         dist.barrier()
+    if world > 1:
+        sharded_cells(args, rank, local_rank, world, dist)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
 
-    tmp = tempfile.mkdtemp(prefix="t4bench%d_" % rank)
+    tmp = tempfile.mkdtemp(prefix="t4bench_")
     try:
-        fa, f1, f2 = make_batch(tmp, args.pairs, clones, t4dist.shard_seed(1, rank))
-        threads = max(1, min(args.threads, host_cores() // max(1, world)))
+        threads = max(1, min(args.threads, host_cores()))
+        t_bench0 = time.perf_counter()
+        c2 = None
+        use_c2 = False
+        if args.pairs == 0 and args.c2:
+            # config C2 itself, once: digest check, the first warm-up step if C2 is the workload, the `c2` record either way
+            c2dir = os.path.join(tmp, "c2")
+            os.makedirs(c2dir)
+            c2 = config_leg("c2", threads, local_rank, keep=c2dir)
+            use_c2 = "seconds" in c2 and c2["seconds"] * (args.steps + args.warmup) <= args.budget and args.warmup >= 1
+        pairs = 1000000 if use_c2 else (args.pairs if args.pairs > 0 else 100000)
+        clones = args.clones if args.clones > 0 else max(1, pairs // 50)
+        if use_c2:
+            fa, f1, f2, _, _ = c2["files"]
+        else:
+            fa, f1, f2 = make_batch(tmp, pairs, clones, 1)
         mine = os.path.join(tmp, "mine")
         stats_path = os.path.join(tmp, "stats.json")
 
-        def sync_all():
-            torch.cuda.synchronize()
-            if dist:
-                dist.barrier()
-
-        for _ in range(args.warmup):
+        for _ in range(args.warmup - (1 if use_c2 else 0)):
             run_stage1(fa, f1, f2, mine, threads, local_rank)
-        sync_all()
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             run_stage1(fa, f1, f2, mine, threads, local_rank, stats=stats_path)
-        sync_all()
+        torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        dt = t4dist.max_over_ranks(dist, dt, "cuda")
 
-        if rank == 0:
-            st = json.load(open(stats_path))
-            ph = st["phases_s"]
-            aq, ra = st["add_query"], st["rough_annotation"]
-            n_reads = 2 * args.pairs
-            # the dominant kernel of the step: the AddRead query kernel (t4k::queryKernel<.., 1>, mode 4), all its launches
-            # of one step; HIP-event time on the engine's stream, H from the engine's hit counter
-            alg_add = add_bytes(aq["reads_queried"], 150, aq["hits"])
-            alg_ann = annotate_bytes(ra["reads"], 150, ra["hits"])
-            ach_add = alg_add / (aq["kernel_ms"] * 1e-3) / 1e9
-            out = {
-                "metric": "stage-1 assembly read pairs/sec (150 bp PE), whole stage 1",
-                "value": args.pairs * world * args.steps / dt,
-                "unit": "pairs/s",
-                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": dt / args.steps * 1e3,
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "int32/u64", "data": "synthetic",
-                "config": {"workload": "C2 recipe%s: %d synthetic 150 bp PE pairs per GPU (%d clones, seed 1+rank), -f hg38_bcrtcr.fa, k=9, bulk mode; one step = "
-                                       "whole stage 1 through trust4-hip -t %d --skipMateExtension, FASTQ files in -> _raw.out / _assembled_reads.fa / _final.out out, "
-                                       "process start to exit" % (" (config C2 itself)" if args.pairs == 1000000 else " at %g of C2's size" % (args.pairs / 1e6), args.pairs, clones, threads),
-                           "pairs_per_gpu": args.pairs, "host_threads": threads, "contigs": st["contigs"], "assembled_reads": st["assembled_reads"],
-                           "sharding": "replicas: every rank assembles its own batch on its own GPU, no collective (bulk-mode AddRead is one ordered chain)",
-                           "phases_s": {"parse_processread_21mers": ph["input_processed_counted"], "sort": ph["sorted"] - ph["input_processed_counted"],
-                                        "rough_annotation": ph["rough_annotation"] - ph["sorted"], "trim": ph["trimmed_ready"] - ph["rough_annotation"],
-                                        "addread_pass": ph["assembled"] - ph["trimmed_ready"], "outputs": ph["outputs_written"] - ph["assembled"]}},
-                "roofline": {"bound": "hbm", "achieved": ach_add, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_add / HBM_PEAK_GBS, "traffic": None,
-                             "kernel": "t4k::queryKernel<.., 1> mode 4 (AddRead query: seed->sort->chain->score->ExtendOverlap) + t4k::extendKernel behind it (kernel_ms brackets both), all %d query launches of one step" % aq["rounds"],
-                             "kernel_ms": aq["kernel_ms"], "launch_ms_avg": aq["kernel_ms"] / max(1, aq["rounds"]),
-                             "algorithmic_bytes_per_step": alg_add, "reads_queried": aq["reads_queried"], "reads_served": aq["reads_served"],
-                             "hits": aq["hits"], "note": "a latency-bound chain of small launches (DESIGN 5b): bytes / kernel time says how little of the HBM rate a dependent round can use"},
-                "passes": {"add_query": aq,
-                           "rough_annotation_in_step": {"reads": ra["reads"], "hits": ra["hits"], "kernel_ms": ra["kernel_ms"],
-                                                        "achieved_GBs": alg_ann / (max(ra["kernel_ms"], 1e-6) * 1e-3) / 1e9}},
-            }
-            # what the reference's own query count would move: SURVEY 8(d) defines H over the reads the reference queries once each
-            out["roofline"]["algorithmic_bytes_per_step_reads_served_only"] = add_bytes(aq["reads_served"], 150, int(aq["hits"] * aq["reads_served"] / max(1, aq["reads_queried"])))
-            out["roofline"]["frac_reads_served_only"] = out["roofline"]["algorithmic_bytes_per_step_reads_served_only"] / (aq["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-            out["roofline"]["note"] += "; `achieved` counts every query the engine ran (re-queries of invalidated window entries included), `frac_reads_served_only` scales the bytes to one query per served read as the reference does"
-            if args.traffic and world == 1:
-                try:
-                    tr, detail = pmc_traffic(fa, f1, f2, threads, local_rank, tmp)
-                except Exception as e:   # noqa: BLE001
-                    tr, detail = None, {"error": repr(e)[:300]}
+        st = json.load(open(stats_path))
+        ph = st["phases_s"]
+        aq, ra = st["add_query"], st["rough_annotation"]
+        alg_ann = annotate_bytes(ra["reads"], 150, ra["hits"])
+        roof = add_roofline(aq)
+        workload = ("config C2 itself: 1000000 synthetic 150 bp PE pairs (20000 clones, seed 1)" if use_c2 else
+                    "C2 recipe, %d synthetic 150 bp PE pairs (%d clones, seed 1)%s" % (pairs, clones,
+                    ": config C2 itself takes %.1f s per step here, %d steps + %d warm-up do not fit the budget of %.0f s -- C2 is the `c2` record of this line"
+                    % (c2["seconds"], args.steps, args.warmup, args.budget) if c2 and "seconds" in c2 else ""))
+        out = {
+            "metric": "stage-1 assembly read pairs/sec (150 bp PE), whole stage 1",
+            "value": pairs * args.steps / dt,
+            "unit": "pairs/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32/u64", "data": "synthetic",
+            "config": {"workload": workload + ", -f hg38_bcrtcr.fa, k=9, bulk mode; one step = whole stage 1 through trust4-hip -t %d --skipMateExtension, FASTQ files in -> "
+                                              "_raw.out / _assembled_reads.fa / _final.out out, process start to exit" % threads,
+                       "pairs_per_step": pairs, "is_baseline_config_c2": bool(use_c2), "host_threads": threads, "contigs": st["contigs"], "assembled_reads": st["assembled_reads"],
+                       "sharding": "N = 1: bulk-mode stage 1 is one ordered chain; N > 1 measures the barcode-mode sample sharded by cells (see the docstring)",
+                       "phases_s": {"parse_processread_21mers": ph["input_processed_counted"], "sort": ph["sorted"] - ph["input_processed_counted"],
+                                    "rough_annotation": ph["rough_annotation"] - ph["sorted"], "trim": ph["trimmed_ready"] - ph["rough_annotation"],
+                                    "addread_pass": ph["assembled"] - ph["trimmed_ready"], "outputs": ph["outputs_written"] - ph["assembled"]}},
+            "roofline": roof,
+            "passes": {"add_query": aq,
+                       "rough_annotation_in_step": {"reads": ra["reads"], "hits": ra["hits"], "kernel_ms": ra["kernel_ms"],
+                                                    "achieved_GBs": alg_ann / (max(ra["kernel_ms"], 1e-6) * 1e-3) / 1e9}},
+        }
+        if use_c2:
+            out["parity_on_bench_batch"] = bool(c2.get("identical")) and all(file_md5(mine + x) == c2["md5"][x] for x in OUT_SUFFIXES)
+        # the reference on this box
+        if args.cpu_baseline and os.path.exists(REF_BIN):
+            if use_c2:
+                leg = config_leg_cpu_only(c2["files"], "c2", args.cpu_c2_pairs)
+                out["cpu_baseline"] = leg
+            else:
+                out["cpu_baseline"], out["parity_on_bench_batch"] = cpu_baseline(tmp, fa, f1, f2, pairs, mine, args.cpu_single_pairs)
+                if c2 and "files" in c2 and args.cpu_c2_pairs > 0:
+                    c2["cpu_baseline"] = config_leg_cpu_only(c2["files"], "c2", args.cpu_c2_pairs)
+        if args.traffic:
+            try:
+                pf = (fa, f1, f2) if not use_c2 else make_batch(tmp, 100000, 2000, 1)
+                tr, detail = pmc_traffic(pf[0], pf[1], pf[2], threads, local_rank, tmp)
+            except Exception as e:   # noqa: BLE001
+                tr, detail = None, {"error": repr(e)[:300]}
+            out["roofline"]["traffic_detail"] = detail
+            if tr and not use_c2:
                 out["roofline"]["traffic"] = tr
-                out["roofline"]["traffic_detail"] = detail
-                if tr:
-                    out["roofline"]["traffic_over_algorithmic"] = tr / alg_add
-            if args.cpu_baseline and world == 1 and os.path.exists(REF_BIN):
-                out["cpu_baseline"], out["parity_on_bench_batch"] = cpu_baseline(tmp, fa, f1, f2, args.pairs, mine, args.cpu_single_pairs)
-            if args.side_legs and world == 1:
+                out["roofline"]["traffic_over_algorithmic"] = tr / roof["algorithmic_bytes_per_step"]
+            elif tr:   # measured on the 100 k-pair batch of the same recipe: per step of THAT batch, next to its own algorithmic bytes
+                run_stage1(pf[0], pf[1], pf[2], os.path.join(tmp, "pmcb"), threads, local_rank, stats=os.path.join(tmp, "pmcb.json"))
+                aqb = json.load(open(os.path.join(tmp, "pmcb.json")))["add_query"]
+                algb = add_bytes(aqb["reads_queried"], 150, aqb["hits"])
+                out["roofline"]["traffic"] = tr / max(1, aqb["rounds"]) * aq["rounds"]
+                out["roofline"]["traffic_over_algorithmic"] = tr / algb
+                out["roofline"]["traffic_detail"]["basis"] = ("PMC passes ran on the C2 recipe at 100 k pairs (%d query rounds, %.3e algorithmic bytes); `traffic` scales its per-round average to this "
+                                                             "step's %d rounds, `traffic_over_algorithmic` is the 100 k-pair batch's own ratio" % (aqb["rounds"], algb, aq["rounds"]))
+        if c2 is not None:
+            c2.pop("files", None)
+            out["c2"] = c2
+        if args.side_legs:
+            left = 2400 - (time.perf_counter() - t_bench0)   # side legs only while the whole run stays well inside the driver's patience
+            for extra in [x for x in args.config_leg.split(",") if x]:
+                out[extra.replace(":", "_")] = config_leg(extra, threads, local_rank)
+                out[extra.replace(":", "_")].pop("files", None)
+            if left > 120:
                 try:
                     out["passes"]["rough_annotation_c2"] = annotate_pass_c2(local_rank, 1000000, 20000, 3)
                 except Exception as e:   # noqa: BLE001
                     out["passes"]["rough_annotation_c2"] = {"error": repr(e)[:300]}
-                if args.c2:
-                    out["c2"] = config_leg("c2", threads, local_rank)
-                for extra in [x for x in args.config_leg.split(",") if x]:
-                    out[extra.replace(":", "_")] = config_leg(extra, threads, local_rank)
                 out["stage1_cells"] = stage1_cells(100000, 1000)
                 out["stage0_e2e"] = stage0_e2e(400000)
-            print(json.dumps(out))
+        print(json.dumps(out))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+
+
+def config_leg_cpu_only(files, name, prefix_pairs):
+    """the reference on THIS box on the first prefix_pairs pairs of a config's own files"""
+    fa, f1, f2 = files[0], files[1], files[2]
+    tmp = os.path.dirname(f1)
+    h1, h2 = os.path.join(tmp, "cpu_1.fq"), os.path.join(tmp, "cpu_2.fq")
+    head_fastq(f1, h1, prefix_pairs)
+    head_fastq(f2, h2, prefix_pairs)
+    cores = host_cores()
+    t0 = time.perf_counter()
+    subprocess.run([REF_BIN, "-t", str(cores), "--skipMateExtension", "-f", fa, "-1", h1, "-2", h2, "-o", os.path.join(tmp, "cpuref")], check=True, stderr=subprocess.DEVNULL)
+    dc = time.perf_counter() - t0
+    return {"value": prefix_pairs / dc, "unit": "pairs/s", "cores": cores, "kind": "reference", "seconds": dc,
+            "sample": "oracle/_ref/trust4 -t %d --skipMateExtension on the first %d pairs of config %s's own files (%s, %s), on this box, %.1f s wall"
+                      % (cores, prefix_pairs, name.upper(), os.path.basename(f1), os.path.basename(f2), dc)}
 
 
 if __name__ == "__main__":

@@ -367,6 +367,8 @@ int64_t t4_kmer_count_distinct(t4_kmer_counter *kc);
 typedef struct t4_comm t4_comm;
 int t4_comm_init(t4_ctx *ctx, int rank, int nranks, const char *id_path, t4_comm **out);
 int t4_comm_allgather_bytes(t4_comm *cm, const void *mine, int64_t n, void **all, int64_t *sizes);
+/* the same contributions received by `root` alone (*all = NULL elsewhere): lengths by ncclAllGather, payloads by grouped ncclSend / ncclRecv, nothing padded */
+int t4_comm_gather_bytes(t4_comm *cm, const void *mine, int64_t n, int root, void **all, int64_t *sizes);
 void t4_comm_destroy(t4_comm *cm);
 
 /* ---- measurement ----------------------------------------------------------------------------- */

@@ -11,13 +11,14 @@ EMU_LIB = os.path.join(ROOT, "tests", "hipemu", "libt4hip_emu.so")
 
 def build_emulator_lib():
     """g++ build of the SAME kernel sources against tests/hipemu (fiber emulator). Test infra only."""
-    srcs = [os.path.join(ROOT, "trust4_amd", "csrc", f) for f in ("t4_api.hip", "t4_kernels.h", "t4_device.h", "t4_assembler.cpp")]
-    srcs += [os.path.join(ROOT, "tests", "hipemu", "hip_emu.cpp"), os.path.join(ROOT, "tests", "hipemu", "hip", "hip_runtime.h"),
-             os.path.join(ROOT, "include", "trust4_hip.h")]
-    if os.path.exists(EMU_LIB) and all(os.path.getmtime(EMU_LIB) >= os.path.getmtime(s) for s in srcs):
+    csrc = os.path.join(ROOT, "trust4_amd", "csrc")
+    units = [os.path.join(csrc, "t4_api.hip"), os.path.join(csrc, "t4_assembler.cpp"), os.path.join(ROOT, "tests", "hipemu", "hip_emu.cpp")]
+    deps = units + [os.path.join(csrc, f) for f in ("t4_kernels.h", "t4_wide.h", "t4_device.h", "t4_internal.h")]
+    deps += [os.path.join(ROOT, "tests", "hipemu", "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "trust4_hip.h")]
+    if os.path.exists(EMU_LIB) and all(os.path.getmtime(EMU_LIB) >= os.path.getmtime(d) for d in deps):
         return EMU_LIB
     subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-I",
-                    os.path.join(ROOT, "tests", "hipemu"), "-o", EMU_LIB, "-x", "c++", srcs[0], srcs[3], srcs[4], "-lz", "-lpthread"], check=True)
+                    os.path.join(ROOT, "tests", "hipemu"), "-o", EMU_LIB, "-x", "c++"] + units + ["-lz", "-lpthread"], check=True)
     return EMU_LIB
 
 

@@ -96,6 +96,60 @@ def run_stage1_two_ranks(tmp_path, driver, pairs, cells, seed, world=2):
     assert open(single + "_raw.out").read().count(">") >= cells
 
 
+def run_engine_merge(tmp_path, driver, pairs, cells, seed, world, env=None):
+    """The merge trust4-hip itself runs on a multi-GPU node (trust4_main.cpp: shard headers all-gathered, every rank renumbers its own
+    contig records, records gathered to rank 0, every rank writes its slice of _assembled_reads.fa at its offset), with the file
+    transport (--gatherDir) in place of RCCL: `world` processes of the driver, no Python in the exchange. Outputs must equal the
+    single-process run's byte for byte -- with world > 1 every rank beyond the first renumbers with base > 0."""
+    import filecmp
+    import gzip
+    import shutil
+    import subprocess
+    import t4libs
+    t4libs.build_checkers()
+    fa = str(tmp_path / "ref.fa")
+    with gzip.open(t4libs.REF_FA, "rb") as f, open(fa, "wb") as g:
+        shutil.copyfileobj(f, g)
+    pre = str(tmp_path / "c5")
+    subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, str(pairs), "0", str(seed), pre, "--cells", str(cells)], check=True)
+    argv = ["-f", fa, "-1", pre + "_1.fq", "-2", pre + "_2.fq", "--barcode", pre + "_bc.fa", "--UMI", pre + "_umi.fa"]
+    e = dict(os.environ)
+    e.update(env or {})
+    single = str(tmp_path / "single")
+    subprocess.run([driver] + argv + ["-o", single], check=True, env=e)
+    gdir = tmp_path / "gather"
+    gdir.mkdir()
+    merged = str(tmp_path / "merged")
+    procs = [subprocess.Popen([driver] + argv + ["-o", merged, "--cellShard", "%d/%d" % (r, world), "--gatherDir", str(gdir)], env=e, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    logs = [p.communicate(timeout=900)[1] for p in procs]
+    assert [p.returncode for p in procs] == [0] * world, logs
+    assert "Gathered %d shards over files" % world in logs[0]
+    for suffix in ("_raw.out", "_final.out", "_assembled_reads.fa"):
+        assert filecmp.cmp(single + suffix, merged + suffix, shallow=False), suffix
+    n = open(single + "_raw.out").read().count(">")
+    assert n >= cells
+    return n
+
+
+def test_engine_merge_two_and_eight_ranks(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_stage1_e2e import _emulated_driver
+    exe = _emulated_driver()
+    (tmp_path / "w2").mkdir()
+    (tmp_path / "w8").mkdir()
+    run_engine_merge(tmp_path / "w2", exe, 120, 7, 9, 2)
+    run_engine_merge(tmp_path / "w8", exe, 100, 11, 10, 8, env={"HIPEMU_THREADS": "1"})
+
+
+@pytest.mark.gpu
+def test_engine_merge_four_ranks_gpu(tmp_path):
+    """the same with the real engine: four ranks share the box's one GPU, file transport"""
+    import trust4_amd.build as b
+    b.build()
+    run_engine_merge(tmp_path, os.path.join(ROOT, "trust4_amd", "bin", "trust4-hip"), 4000, 60, 12, 4)
+
+
 def test_two_rank_barcode_stage1(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import subprocess

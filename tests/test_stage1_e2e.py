@@ -316,13 +316,16 @@ def _bulk_case(tmp_path, driver, pairs, clones, seed, env, threads="4"):
 
 
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
-@pytest.mark.parametrize("env", [{"T4_AQ_CAP_LIMIT": "120"}, {"T4_AQ_FORCE_GLOBAL": "1"}, {"T4_QUERY_AHEAD": "3", "T4_WINDOW": "7"}, {"T4_AQ_EXTEND_DEFER": "1"}, {"T4_AQ_EXTEND_DEFER": "0"},
+@pytest.mark.parametrize("env", [{"T4_AQ_CAP_LIMIT": "120"}, {"T4_AQ_CAP_LIMIT": "120", "T4_WIDE_PCAP": "512", "T4_WIDE_PARTS": "2", "T4_WIDE_GROUPS": "16"}, {"T4_AQ_CAP_LIMIT": "120", "T4_WIDE_OFF": "1"},
+                                 {"T4_AQ_FORCE_GLOBAL": "1"}, {"T4_QUERY_AHEAD": "3", "T4_WINDOW": "7"}, {"T4_AQ_EXTEND_DEFER": "1"}, {"T4_AQ_EXTEND_DEFER": "0"},
                                  {"T4_AQ_POOL_CAP": "8", "T4_AQ_EXTEND_DEFER": "1"}, {"T4_AQ_POOL_CAP": "5"}, {"T4_SORT_MIN": "64"}, {"T4_GPU_PROCESSREAD": "1"},
                                  {"T4_SLOW_US": "60", "T4_SLOW_PROXY": "1", "T4_SLOW_AHEAD": "2"}])
 def test_bulk_live_set_paths_emulated(tmp_path, env):
     """Bulk mode = the live set (device image by t4_index_apply_delta, sliding speculation window). The testing aids send a
-    small input down the paths large sets take: reads that outgrow the LDS arrays and go on in global scratch inside the launch
-    (T4_AQ_CAP_LIMIT), the global-scratch tier launched beside the LDS tier (T4_AQ_FORCE_GLOBAL), a window that is re-queried
+    small input down the paths large sets take: reads that outgrow the LDS arrays and are spread over the chip by the wide query
+    (T4_AQ_CAP_LIMIT; with T4_WIDE_PCAP / _PARTS / _GROUPS through many partitions and the grow-and-repeat paths of its pools; with
+    T4_WIDE_OFF they go on in one workgroup's global scratch inside the launch), the global-scratch tier launched beside the LDS tier
+    (T4_AQ_FORCE_GLOBAL), a window that is re-queried
     a few reads at a time (T4_QUERY_AHEAD), a result pool that overflows so that the call is repeated with a larger one
     (T4_AQ_POOL_CAP; with the extensions deferred, extendKernel runs over the pool of the failed attempt first). Outputs must equal the reference binary's byte for byte."""
     log = _bulk_case(tmp_path, _emulated_driver(), 240, 5, 11, env)
@@ -330,10 +333,14 @@ def test_bulk_live_set_paths_emulated(tmp_path, env):
         import re
         m = re.search(r"ProcessRead on the device: (\d+) pairs stay as they are, (\d+) read-through, (\d+) merged", log)
         assert m and int(m.group(3)) > 20, log[-600:]
-    if "T4_AQ_CAP_LIMIT" in env or "T4_AQ_FORCE_GLOBAL" in env:
+    if ("T4_AQ_CAP_LIMIT" in env and "T4_WIDE_OFF" in env) or "T4_AQ_FORCE_GLOBAL" in env:
         import re
         m = re.search(r"global-scratch tier (\d+) launches for (\d+) reads", log)
         assert m and int(m.group(2)) > 0, log[-600:]
+    elif "T4_AQ_CAP_LIMIT" in env:
+        import re
+        m = re.search(r"wide query served (\d+) window entries \((\d+) dependency records", log)
+        assert m and int(m.group(1)) > 0 and int(m.group(2)) > 0, log[-600:]
     if "T4_AQ_POOL_CAP" in env:
         import re
         m = re.search(r"result pool grown (\d+) times", log)
@@ -342,7 +349,7 @@ def test_bulk_live_set_paths_emulated(tmp_path, env):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not shipped")
-@pytest.mark.parametrize("env", [{}, {"T4_AQ_CAP_LIMIT": "2000"}, {"T4_AQ_FORCE_GLOBAL": "1"}, {"T4_AQ_EXTEND_DEFER": "2"},
+@pytest.mark.parametrize("env", [{}, {"T4_AQ_CAP_LIMIT": "2000"}, {"T4_AQ_CAP_LIMIT": "2000", "T4_WIDE_PCAP": "512", "T4_WIDE_PARTS": "8"}, {"T4_AQ_CAP_LIMIT": "2000", "T4_WIDE_OFF": "1"}, {"T4_AQ_FORCE_GLOBAL": "1"}, {"T4_AQ_EXTEND_DEFER": "2"},
                                  {"T4_AQ_POOL_CAP": "16", "T4_AQ_EXTEND_DEFER": "2"}, {"T4_GPU_PROCESSREAD": "1", "T4_SORT_MIN": "1024"}])
 def test_bulk_live_set_paths_gpu(tmp_path, env):
     _bulk_case(tmp_path, _driver(), 6000, 120, 12, env, threads="8")

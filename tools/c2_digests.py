@@ -26,7 +26,7 @@ REF_BIN = os.path.join(ROOT, "oracle", "_ref", "trust4")
 OUT = os.path.join(ROOT, "tests", "golden", "c2_digests.json")
 SUFFIXES = ("_raw.out", "_assembled_reads.fa", "_final.out")
 # name -> (pairs, clones, seed, prefix pairs or 0): SURVEY.md 8(d)
-CONFIGS = {"c2": (1000000, 20000, 1, 0), "c3p5": (20000000, 200000, 2, 5000000), "c3p2": (20000000, 200000, 2, 2000000)}
+CONFIGS = {"c2": (1000000, 20000, 1, 0), "c3p5": (20000000, 200000, 2, 5000000), "c3p2": (20000000, 200000, 2, 2000000), "c3p05": (20000000, 200000, 2, 500000)}
 
 
 def md5(path):

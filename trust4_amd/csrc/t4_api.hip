@@ -68,8 +68,9 @@ struct AqCall {
   int n = 0, skipRepeats = 0, wpk = 0, wnm = 0, attempt = 0, nFirst = 0, nDirect = 0, threads = 512;
   unsigned char *tierHint = nullptr;
   std::vector<unsigned char> allGlobal;
-  size_t oPk, oNm, oLen, oBc, oSt, oLs, oVw, oFa, inBytes, pCnt, pSta, pNext, pNext2, pBase, pTick, pStab, pTail, outBytes;
-  bool extendLater = false;
+  size_t oPk, oNm, oLen, oBc, oSt, oLs, oVw, oFa, oWide, inBytes, pCnt, pSta, pNext, pNext2, pBase, pTick, pStab, pTail, pWctl, pWplan, pWstat, outBytes;
+  bool extendLater = false, wide = false;
+  int wideSafety = 32;   // of sixteenths: partitions are planned for half of their capacity
   T4BatchView bv; T4QueryArgs qa; T4Work wk;
   std::chrono::steady_clock::time_point tf0;
 };
@@ -116,6 +117,11 @@ struct t4_ctx {
   const int32_t *aqLastTicks = nullptr; int aqLastN = 0;   // per-read wall-clock ticks (10 ns) of the last AddRead query call (in the pinned header blob)
   double aqLastMs = 0;
   AqCall aq;
+  // the wide query (t4_wide.h): pools of the deferred reads of one call, grown on demand
+  T4Wide wide;               // device pointers + capacities (a copy travels in every call's input blob)
+  bool wideInit = false;
+  unsigned char *grpPoolHost = nullptr;   // pinned; T4Wide::grpPool is its device address
+  int64_t wideReads = 0, wideParts = 0, wideRetries = 0, wideGroups = 0;
   double aqKernelMs = 0;    // HIP-event time of the query kernels of all AddRead query calls (per call: first launch .. last kernel)
   int64_t aqHits = 0;       // _hit records their seed stages emitted (H of SURVEY 8d)
 };
@@ -230,6 +236,58 @@ int ensurePerCall(t4_ctx *c, long long n) {
   return T4_OK;
 }
 
+
+// pools of the wide query (t4_wide.h): room for `reads` deferred reads, `parts` partitions of `pcap` keys and `groups` dependency
+// records per call; existing contents are never needed across calls, so growing reallocates
+int wideEnv(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+int ensureWide(t4_ctx *c, int reads, int parts, int groups) {
+  T4Wide &w = c->wide;
+  if (!c->wideInit) {
+    memset(&w, 0, sizeof w);
+    w.pcap = wideEnv("T4_WIDE_PCAP", 8192);   // testing aid: small partitions, so that small inputs spread over several
+    if (w.pcap < 64) w.pcap = 64;
+    if (w.pcap > 8192) w.pcap = 8192;
+    w.maxOvPart = 1 << T4_WIDE_OVBITS;
+    w.maxPartPerRead = T4_WIDE_MAXP;
+    c->wideInit = true;
+  }
+  int r;
+  if (reads > w.maxReads) {
+    int n = w.maxReads > 0 ? w.maxReads : 64;
+    while (n < reads) n *= 2;
+    if ((r = devAlloc(c, &w.seed, (size_t)n * T4_WIDE_SEEDS))) return r;
+    if ((r = devAlloc(c, &w.uniqPref, (size_t)n * (w.pcap + 1)))) return r;
+    if ((r = devAlloc(c, &w.sortTmp, (size_t)n * 2 * w.pcap))) return r;
+    w.maxReads = n;
+  }
+  if (parts > w.maxPart) {
+    int n = w.maxPart > 0 ? w.maxPart : wideEnv("T4_WIDE_PARTS", 1024);
+    while (n < parts) n *= 2;
+    if ((r = devAlloc(c, &w.pCnt, (size_t)n))) return r;
+    if ((r = devAlloc(c, &w.pRead, (size_t)n))) return r;
+    if ((r = devAlloc(c, &w.pKeys, (size_t)n * w.pcap))) return r;
+    if ((r = devAlloc(c, &w.gSize, (size_t)n * w.pcap))) return r;
+    if ((r = devAlloc(c, &w.gInfo, (size_t)n * w.pcap))) return r;
+    if ((r = devAlloc(c, &w.gCount, (size_t)n * 4))) return r;
+    if ((r = devAlloc(c, &w.gOff, (size_t)n * 2))) return r;
+    if ((r = devAlloc(c, &w.pRec, (size_t)n * w.maxOvPart * 10))) return r;
+    if ((r = devAlloc(c, &w.pRecCnt, (size_t)n))) return r;
+    if ((r = devAlloc(c, &w.mKeys, (size_t)n * w.maxOvPart))) return r;
+    if ((r = devAlloc(c, &w.mOrd, (size_t)n * w.maxOvPart))) return r;
+    w.maxPart = n;
+  }
+  if (groups > w.grpCap) {
+    int n = w.grpCap > 0 ? w.grpCap : wideEnv("T4_WIDE_GROUPS", 1 << 20);
+    while (n < groups) n *= 2;
+    if (c->grpPoolHost) (void)hipHostFree(c->grpPoolHost);
+    c->grpPoolHost = nullptr; w.grpPool = nullptr;
+    HIPCHK(c, hipHostMalloc(&c->grpPoolHost, sizeof(T4Grp) * (size_t)n, hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer((void **)&w.grpPool, c->grpPoolHost, 0));
+    w.grpCap = n;
+  }
+  return T4_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -289,6 +347,12 @@ void t4_destroy(t4_ctx *c) {
   if (c->aqPool) (void)hipHostFree(c->aqPool);
   if (c->aqRecDev) (void)hipFree(c->aqRecDev);
   if (c->aqRecRead) (void)hipFree(c->aqRecRead);
+  if (c->wideInit) {
+    void *wp[] = {c->wide.seed, c->wide.pCnt, c->wide.pRead, c->wide.pKeys, c->wide.gSize, c->wide.gInfo, c->wide.gCount, c->wide.gOff, c->wide.pRec,
+                  c->wide.pRecCnt, c->wide.uniqPref, c->wide.mKeys, c->wide.mOrd, c->wide.sortTmp};
+    for (void *p : wp) if (p) (void)hipFree(p);
+    if (c->grpPoolHost) (void)hipHostFree(c->grpPoolHost);
+  }
   for (void *p : ptrs) if (p) (void)hipFree(p);
   for (int i = 0; i < 4; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1456,10 +1520,13 @@ int aqBegin(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const 
   auto al8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
   q.oPk = 0; q.oNm = al8(q.oPk + sizeof(unsigned) * (size_t)n * wpk); q.oLen = al8(q.oNm + sizeof(unsigned) * (size_t)n * wnm);
   q.oBc = al8(q.oLen + sizeof(int) * (size_t)n); q.oSt = al8(q.oBc + sizeof(int) * (size_t)n); q.oLs = al8(q.oSt + sizeof(int) * (size_t)n);
-  q.oVw = al8(q.oLs + sizeof(int) * (size_t)n); q.oFa = al8(q.oVw + sizeof(int) * (size_t)n); q.inBytes = al8(q.oFa + sizeof(double) * (size_t)n);
+  q.oVw = al8(q.oLs + sizeof(int) * (size_t)n); q.oFa = al8(q.oVw + sizeof(int) * (size_t)n); q.oWide = al8(q.oFa + sizeof(double) * (size_t)n);
+  q.inBytes = al8(q.oWide + sizeof(T4Wide));
   q.pCnt = 0; q.pSta = al8(q.pCnt + sizeof(int) * (size_t)n); q.pNext = al8(q.pSta + sizeof(int) * (size_t)n);
   q.pNext2 = al8(q.pNext + sizeof(int) * (size_t)n); q.pBase = al8(q.pNext2 + sizeof(int) * (size_t)n);
-  q.pTick = al8(q.pBase + sizeof(int) * (size_t)n); q.pStab = al8(q.pTick + sizeof(int) * (size_t)n); q.pTail = al8(q.pStab + sizeof(int) * (size_t)n); q.outBytes = q.pTail + 32;
+  q.pTick = al8(q.pBase + sizeof(int) * (size_t)n); q.pStab = al8(q.pTick + sizeof(int) * (size_t)n); q.pTail = al8(q.pStab + sizeof(int) * (size_t)n);
+  q.pWctl = q.pTail + 32; q.pWplan = q.pWctl + 32; q.pWstat = al8(q.pWplan + sizeof(T4WidePlan) * (size_t)n); q.outBytes = al8(q.pWstat + sizeof(int) * T4_WIDE_STAT * (size_t)n);
+  q.wideSafety = 32;
   if (q.inBytes > c->aqInBytes) {
     if (c->aqIn) (void)hipFree(c->aqIn);
     if (c->aqInHost) (void)hipHostFree(c->aqInHost);
@@ -1498,9 +1565,13 @@ int aqBegin(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const 
       p[j >> 4] |= (unsigned)v << ((j & 15) * 2);
     }
   }
+  // one big contig set, plain passes: a read beyond the LDS tier goes to the wide query (t4_wide.h) instead of one workgroup's
+  // global scratch -- decided on the device, inside the one launch every read starts in (T4_WIDE_OFF: the global-scratch tier as before)
+  q.wide = !views && !smallFirst && !skip_repeats && base.hasNovel == 2 && !getenv("T4_WIDE_OFF");   // (a read with a barcode stays on the old path: wideWant in processRead)
   // work lists: the reads of the first LDS launch, then those that go to the global-scratch tier at once
-  static const bool forceGlobal = getenv("T4_AQ_FORCE_GLOBAL") != nullptr;   // testing aid: every read on the global-scratch tier
-  if (forceGlobal && !smallFirst) { q.allGlobal.assign((size_t)n, 1); q.tierHint = tierHint = q.allGlobal.data(); }
+  const bool forceGlobal = getenv("T4_AQ_FORCE_GLOBAL") != nullptr;   // testing aid: every read on the global-scratch tier
+  if (forceGlobal && !smallFirst) { q.allGlobal.assign((size_t)n, 1); q.tierHint = tierHint = q.allGlobal.data(); q.wide = false; }
+  if (q.wide) tierHint = nullptr;
   int nFirst = 0, nDirect = 0;
   for (int i = 0; i < n; ++i) if (!(tierHint && tierHint[i] && !smallFirst)) ls[nFirst++] = i;
   for (int i = 0; i < n; ++i) if (tierHint && tierHint[i] && !smallFirst) ls[nFirst + nDirect++] = i;
@@ -1526,6 +1597,13 @@ int aqLaunch(t4_ctx *c) {
   }
   const size_t rec = (size_t)c->aqPoolCap;
   q.tf0 = std::chrono::steady_clock::now();
+  if (q.wide) {
+    if ((r = ensureWide(c, n, 1, 1))) return r;
+    T4Wide w = c->wide;
+    w.enabled = 1; w.safetyNum = q.wideSafety;
+    w.ctl = (int *)(c->aqOut + q.pWctl); w.plan = (T4WidePlan *)(c->aqOut + q.pWplan); w.stat = (int *)(c->aqOut + q.pWstat);
+    memcpy(c->aqInHost + q.oWide, &w, sizeof w);
+  }
   HIPCHK(c, hipMemcpyAsync(c->aqIn, c->aqInHost, q.inBytes, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(c->aqOut, 0, q.outBytes, c->stream));   // counts, status, overflow lists, bases, tail
   T4BatchView &bv = q.bv;
@@ -1543,7 +1621,8 @@ int aqLaunch(t4_ctx *c) {
   qa.leanExt = q.lean ? 1 : 0;
   if (q.views) { qa.views = q.views; qa.viewOf = (const int *)(c->aqIn + q.oVw); }
   // one big set: the ExtendOverlap calls of reads with more than this many overlaps run in their own launch (0: never)
-  static const int deferMin = getenv("T4_AQ_EXTEND_DEFER") ? atoi(getenv("T4_AQ_EXTEND_DEFER")) : 64;
+  int deferMin = getenv("T4_AQ_EXTEND_DEFER") ? atoi(getenv("T4_AQ_EXTEND_DEFER")) : 64;   // testing aid
+  if (q.wide && deferMin <= 0) deferMin = 64;   // the wide query leaves every ExtendOverlap to extendKernel
   const bool extendLater = deferMin > 0 && !q.views && !smallFirst;
   q.extendLater = extendLater;
   if (extendLater) {
@@ -1570,8 +1649,8 @@ int aqLaunch(t4_ctx *c) {
   wk.nextList = (int *)(c->aqOut + q.pNext); wk.nextCount = (int *)(c->aqOut + q.pTail);
   wk.status = (int *)(c->aqOut + q.pSta); wk.hitCounter = (unsigned long long *)(c->aqOut + q.pTail + 16);
   wk.dpRows = c->dpRows; wk.dpDir = c->dpDir;
-  static const int capLimit = getenv("T4_AQ_CAP_LIMIT") ? atoi(getenv("T4_AQ_CAP_LIMIT")) : 0;   // testing aid
-  wk.capLimit = capLimit;
+  wk.capLimit = getenv("T4_AQ_CAP_LIMIT") ? atoi(getenv("T4_AQ_CAP_LIMIT")) : 0;   // testing aid
+  wk.wide = q.wide ? (const T4Wide *)(c->aqIn + q.oWide) : nullptr;
   if (!smallFirst && (r = ensureGlobalTier(c, grid0 + nDirect))) return r;   // before anything of this call runs: growing it frees the old arrays
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if (nDirect > 0) {   // beside the LDS tier, on the second stream (its own blocks of the DP scratch)
@@ -1603,6 +1682,17 @@ int aqLaunch(t4_ctx *c) {
     HIPCHK(c, hipGetLastError());
   }
   if (nDirect > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->evG, 0));
+  if (q.wide) {   // the reads the launch above deferred (none: five empty grids)
+    T4Wide w;
+    memcpy(&w, c->aqInHost + q.oWide, sizeof w);
+    const int cus = c->cus > 0 ? c->cus : 1;
+    hipLaunchKernelGGL(t4k::wideScatterKernel, dim3(cus * 4), dim3(256), 0, c->stream, q.base, w);
+    hipLaunchKernelGGL((t4k::wideSortKernel<8192>), dim3(cus * 2), dim3(512), 0, c->stream, q.base, w);
+    hipLaunchKernelGGL(t4k::wideStatsKernel, dim3(cus < 64 ? cus : 64), dim3(512), 0, c->stream, q.base, w);
+    hipLaunchKernelGGL((t4k::wideChainKernel<8192, 1 << T4_WIDE_OVBITS>), dim3(cus), dim3(512), 0, c->stream, q.base, bv, wk, qa, w);
+    hipLaunchKernelGGL(t4k::wideMergeKernel, dim3(cus < 64 ? cus : 64), dim3(512), 0, c->stream, q.base, bv, wk, qa, w);
+    HIPCHK(c, hipGetLastError());
+  }
   if (extendLater) {   // all records of the batch, spread over the chip
     const int grid = c->cus * 16;
     hipLaunchKernelGGL(t4k::extendKernel, dim3(grid), dim3(64), 0, c->stream, q.base, bv, qa, 0);
@@ -1687,6 +1777,23 @@ int aqEnd(t4_ctx *c, AqResult *res) {
     }
     c->aqSecGlobal += tSince(tg0);
     const unsigned char *o = c->aqOutHost;
+    if (q.wide) {
+      const int *ctl = (const int *)(o + q.pWctl);
+      const int flags = ctl[2];
+      if (flags) {   // a pool of the wide query ran out: larger pools / finer partitions, and the whole call again
+        if (q.attempt >= 12 || (flags & (1 | 32))) return fail(c, T4_ERR_UNSUPPORTED, "wide query: flags %d after %d attempts", flags, q.attempt);
+        if (flags & 2) {
+          if (ctl[1] <= c->wide.maxPart) return fail(c, T4_ERR_UNSUPPORTED, "a read of this batch needs more than %d partitions of %d k-mer hits", T4_WIDE_MAXP, c->wide.pcap);
+          if ((r = ensureWide(c, n, ctl[1], 1))) return r;
+        }
+        if (flags & (4 | 8)) { if (q.wideSafety >= 32 * 256) return fail(c, T4_ERR_UNSUPPORTED, "wide query: a contig range of one contig overflows a partition"); q.wideSafety *= 2; }
+        if (flags & 16) { if ((r = ensureWide(c, n, 1, ctl[3]))) return r; }
+        ++c->wideRetries; ++q.attempt;
+        if ((r = aqLaunch(c))) return r;
+        continue;
+      }
+      c->wideReads += ctl[0]; c->wideParts += ctl[1]; c->wideGroups += ctl[3];
+    }
     const int *status = (const int *)(o + q.pSta);
     bool poolFull = false;
     for (int i = 0; i < n; ++i) {
@@ -1760,6 +1867,37 @@ int t4_add_query_last_call(t4_ctx *c, double *kernel_ms, const int32_t **ticks10
   if (kernel_ms) *kernel_ms = c->aqLastMs;
   if (ticks10ns) *ticks10ns = c->aqLastTicks;
   if (n) *n = c->aqLastN;
+  return T4_OK;
+}
+
+// Dependency records of read i of the last finished AddRead query call on this ctx, when the wide query served it (t4_wide.h):
+// per (strand, contig) group its hits and the hull of its diagonals with three or more hits, minus-strand groups (even keys)
+// first, ascending by contig within a strand. Returns 1 and the records (pinned memory, valid until the next call), 0 when the read
+// was served by the LDS tier. huge: one of its lists holds more than 10000 postings; n4: groups of four or more hits.
+int t4_add_query_groups(t4_ctx *c, int i, const t4_grp **groups, int *n, int *huge, int *n4) {
+  if (!c || !groups || !n) return T4_ERR_ARG;
+  const AqCall &q = c->aq;
+  if (!q.wide || !c->aqOutHost) return 0;
+  const unsigned char *o = c->aqOutHost;
+  const int *ctl = (const int *)(o + q.pWctl);
+  const T4WidePlan *plan = (const T4WidePlan *)(o + q.pWplan);
+  const int *stat = (const int *)(o + q.pWstat);
+  const int nw = ctl[0] < q.n ? ctl[0] : q.n;
+  for (int w = 0; w < nw; ++w) {
+    if (plan[w].read != i) continue;
+    *groups = (const t4_grp *)c->grpPoolHost + plan[w].grpBase;
+    *n = stat[(size_t)w * T4_WIDE_STAT + WS_GROUPS];
+    if (huge) *huge = plan[w].huge;
+    if (n4) *n4 = stat[(size_t)w * T4_WIDE_STAT + WS_N4];
+    return 1;
+  }
+  return 0;
+}
+
+// wide query of this ctx, 4 values: reads it served, partitions, calls repeated with larger pools, dependency records
+int t4_add_query_wide_stats(t4_ctx *c, int64_t *out4) {
+  if (!c || !out4) return T4_ERR_ARG;
+  out4[0] = c->wideReads; out4[1] = c->wideParts; out4[2] = c->wideRetries; out4[3] = c->wideGroups;
   return T4_OK;
 }
 
@@ -2204,6 +2342,53 @@ int t4_comm_allgather_bytes(t4_comm *cm, const void *mine, int64_t n, void **all
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   (void)hipFree(dSend); (void)hipFree(dRecv);
+  *all = host;
+  return T4_OK;
+#else
+  return T4_ERR_UNSUPPORTED;
+#endif
+}
+
+// The same contributions, received by `root` only (the others get *all = NULL): lengths by one small ncclAllGather, payloads by one
+// group of ncclSend / ncclRecv -- nothing is padded and nothing lands on ranks that do not write the files.
+int t4_comm_gather_bytes(t4_comm *cm, const void *mine, int64_t n, int root, void **all, int64_t *sizes) {
+  if (!cm || n < 0 || (n > 0 && !mine) || !all || !sizes || root < 0 || root >= cm->nranks) return T4_ERR_ARG;
+  *all = nullptr;
+#ifdef __HIPCC__
+  t4_ctx *c = cm->ctx;
+  (void)hipSetDevice(c->device);
+  const int R = cm->nranks;
+  unsigned long long *dLen = nullptr;
+  HIPCHK(c, hipMalloc(&dLen, sizeof(unsigned long long) * (size_t)(R + 1)));
+  const unsigned long long myLen = (unsigned long long)n;
+  HIPCHK(c, hipMemcpyAsync(dLen + R, &myLen, sizeof myLen, hipMemcpyHostToDevice, c->stream));
+  if (ncclAllGather(dLen + R, dLen, 1, ncclUint64, cm->comm, c->stream) != ncclSuccess) { (void)hipFree(dLen); return fail(c, T4_ERR_HIP, "ncclAllGather (lengths) failed"); }
+  std::vector<unsigned long long> lens((size_t)R);
+  HIPCHK(c, hipMemcpyAsync(lens.data(), dLen, sizeof(unsigned long long) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(dLen);
+  size_t total = 0;
+  for (int r = 0; r < R; ++r) { sizes[r] = (int64_t)lens[(size_t)r]; total += (size_t)lens[(size_t)r]; }
+  unsigned char *dSend = nullptr, *dRecv = nullptr;
+  HIPCHK(c, hipMalloc(&dSend, n > 0 ? (size_t)n : 8));
+  if (n > 0) HIPCHK(c, hipMemcpyAsync(dSend, mine, (size_t)n, hipMemcpyHostToDevice, c->stream));
+  if (cm->rank == root && hipMalloc(&dRecv, total ? total : 8) != hipSuccess) { (void)hipFree(dSend); return fail(c, T4_ERR_HIP, "out of device memory for the gather"); }
+  bool ok = ncclGroupStart() == ncclSuccess;
+  if (ok && n > 0) ok = ncclSend(dSend, (size_t)n, ncclUint8, root, cm->comm, c->stream) == ncclSuccess;
+  if (ok && cm->rank == root) {
+    size_t at = 0;
+    for (int r = 0; r < R && ok; ++r) { if (lens[(size_t)r]) ok = ncclRecv(dRecv + at, (size_t)lens[(size_t)r], ncclUint8, r, cm->comm, c->stream) == ncclSuccess; at += (size_t)lens[(size_t)r]; }
+  }
+  ok = (ncclGroupEnd() == ncclSuccess) && ok;
+  if (!ok) { (void)hipFree(dSend); if (dRecv) (void)hipFree(dRecv); return fail(c, T4_ERR_HIP, "ncclSend / ncclRecv (gather) failed"); }
+  unsigned char *host = nullptr;
+  if (cm->rank == root) {
+    host = (unsigned char *)malloc(total ? total : 1);
+    if (total) HIPCHK(c, hipMemcpyAsync(host, dRecv, total, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(dSend);
+  if (dRecv) (void)hipFree(dRecv);
   *all = host;
   return T4_OK;
 #else

@@ -498,6 +498,23 @@ struct t4_assembler : IndexListener {
     int lastUs = 0;              // what this read's last query took in its workgroup (microseconds; 0: never queried): a launch lasts as long as its slowest read
     bool statsStable = false;    // the query itself found that edits of small groups cannot move novelMinHitRequired (T4QueryArgs::statsStable): exact, needs no slack
     GroupTable groups;
+    // Dependency records that came back from the wide query (csrc/t4_wide.h) instead of being derived here: the groups of the hits
+    // the query EMITTED (after the repeat-skip rule), sorted by contig within a strand, minus strand (even keys) first. Counts of
+    // groups below three hits only ever go up under later index edits (an edit of a k-mer the rule passed over is counted as if it
+    // had been emitted, a removal is not subtracted): a superset, as the table above is.
+    std::vector<Grp> devGroups;
+    size_t devSplit = 0;          // first plus-strand record
+    bool hasDev = false;
+    bool expectWide = false;      // the launch expects the wide query to serve this read: no table derived beside the launch
+    Grp *findGroup(uint32_t key) {
+      if (hasDev) {
+        size_t lo = (key & 1u) ? devSplit : 0, hi = (key & 1u) ? devGroups.size() : devSplit;
+        while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (devGroups[mid].key < key) lo = mid + 1; else hi = mid; }
+        if (lo < ((key & 1u) ? devGroups.size() : devSplit) && devGroups[lo].key == key) return &devGroups[lo];
+      }
+      return groups.find(key);
+    }
+    Grp &getGroup(uint32_t key) { Grp *g = findGroup(key); return g ? *g : groups.get(key); }
     // a (re-)query of this entry is running on a lane: commits since its launch are examined against its dependency sets like
     // those of an entry that holds a result; `killed` = one of them invalidated it (the result is dropped when it arrives),
     // `shifts` = left extensions of contigs it meets, to be applied to the records when they arrive
@@ -560,6 +577,9 @@ struct t4_assembler : IndexListener {
   std::vector<int> dirtySeqs;
   bool liveReset = true;           // the next delta describes the whole image (first upload, k change)
   int64_t toleratedStable = 0, invLongLists = 0, slowSkipped = 0;
+  int64_t wideServed = 0, wideGroupRecords = 0, wideMispredicted = 0;
+  bool wideQueries = true; int wideHitLimit = 8192;   // what t4_add_query_pool_begin will do with a read of that many emitted hits (set in ensureLanes)
+  int emittedHits(const Cached &e);
   int64_t deltas = 0, deltaBytes = 0, rounds = 0, readsQueried = 0, invKey = 0, invCross = 0, invRegion = 0, invShift = 0, invContig = 0, invFragile = 0, tolerated = 0;
   double secDelta = 0, secGroups = 0, secEvents = 0, secRegister = 0, secPrefetch = 0, secAddTotal = 0;
 
@@ -1403,6 +1423,38 @@ void t4_assembler::registerKmers(Cached &e, int slotId) {
   e.registered = true;
 }
 
+// _hit records GetHitsFromRead (SeqSet.hpp:1341-1501, allowTotalSkip false) emits for the entry's read against the current index:
+// the list sizes of its k-mers under the repeat-skip rule (a list of 100+ postings is passed over while fewer than k / 2 were since
+// the last emitted one; a k-mer equal to the last one not passed over is not looked up again). What the query kernel's seed stage
+// will find, so that the launch knows which reads the wide query will serve.
+int t4_assembler::emittedHits(const Cached &e) {
+  std::string rcs;
+  reverseComplement(rcs, e.read);
+  const int len = (int)e.read.size(), skipLimit = k / 2;
+  if (len < k) return 0;
+  int64_t H = 0;
+  uint64_t prev = 0;
+  for (int st = 0; st < 2; ++st) {
+    if (st == 0 ? e.strand == -1 : e.strand == 1) continue;
+    const std::string &r = st ? rcs : e.read;
+    KCode kc(k);
+    int skipCnt = 0;
+    for (int i = 0; i < len; ++i) {
+      kc.append(r[i]);
+      if (i < k - 1) continue;
+      if (i == k - 1 || prev != kc.code) {
+        const ListRef *l = kc.valid() ? index.find(kc.code, index.bucket(kc.code, e.barcode)) : nullptr;
+        const uint32_t size = l ? l->cnt : 0;
+        if (size >= 100 && i != k - 1 && i != len - 1 && skipCnt < skipLimit) { ++skipCnt; continue; }
+        skipCnt = 0;
+        H += size;
+      }
+      prev = kc.code;
+    }
+  }
+  return H > 0x7FFFFFFF ? 0x7FFFFFFF : (int)H;
+}
+
 // Hits of the read per (strand, contig) against the current index (host replica; read-only here): the number of hits, and the
 // stretch of the contig the read lies on along every diagonal that holds three or more hits -- a candidate run of a novel
 // contig is a run of hits on ONE diagonal (adjustRadius 0, SeqSet.hpp:906-919) of at least minHitRequired >= 3 hits, and
@@ -1487,9 +1539,10 @@ void t4_assembler::processEvents() {
     for (int sl : order) {
       Cached &e = *pool[sl];
       if (!e.standing()) continue;
+      if (e.inflight && e.expectWide && !e.hasDev) { kill(e, invContig); continue; }   // its dependency records are still on their way: nothing to examine the change against
       const int margin = radius + 2;
       for (uint32_t plus = 0; plus < 2; ++plus) {
-        Grp *g = e.groups.find((uint32_t)ev.c * 2u + plus);
+        Grp *g = e.findGroup((uint32_t)ev.c * 2u + plus);
         if (!g || g->cnt == 0) continue;
         if (ev.kind == 2) { kill(e, invContig); break; }
         if (g->lo > g->hi) continue;   // no diagonal with three hits: nothing of the contig is read
@@ -1566,18 +1619,19 @@ void t4_assembler::processEvents() {
         const KOcc &o = winKmers.nodes[nd];
         Cached &e = *pool[o.slot];
         if (e.uid != o.uid || !e.standing()) continue;
+        if (e.inflight && e.expectWide && !e.hasDev) { kill(e, invKey); continue; }
         if (e.fragile) { kill(e, invFragile); ++invLongLists; continue; }
         for (uint32_t plus = 0; plus < 2 && e.standing(); ++plus) {
           const int n = (plus ? o.f : o.r) * (ev.delta > 0 ? ev.delta : -ev.delta);
           if (!n) continue;
           if (ev.delta > 0) {
-            Grp &g = e.groups.get((uint32_t)ev.idx * 2u + plus);
+            Grp &g = e.getGroup((uint32_t)ev.idx * 2u + plus);
             g.cnt += (uint32_t)n;
             if (g.cnt >= 3) { kill(e, invKey); break; }
           } else {
-            Grp *g = e.groups.find((uint32_t)ev.idx * 2u + plus);
+            Grp *g = e.findGroup((uint32_t)ev.idx * 2u + plus);
             if (g && g->cnt >= 3) { kill(e, invKey); break; }
-            if (g) g->cnt = g->cnt > (uint32_t)n ? g->cnt - (uint32_t)n : 0;
+            if (g && !e.hasDev) g->cnt = g->cnt > (uint32_t)n ? g->cnt - (uint32_t)n : 0;   // (device records count emitted hits: see Cached::devGroups)
           }
           ++tolerated;
           if (e.statsStable) { ++toleratedStable; continue; }   // exact: the statistics of this read's query cannot move (overlapsFromKeys)
@@ -1616,6 +1670,7 @@ void t4_assembler::announceLive(int n, const char *const *reads, const int *stra
     c.inflight = false; c.killed = false; c.shifts.clear();
     c.ov.clear(); c.ext.clear(); c.extRet.clear();
     c.uid = nextUid++; c.tier = 0; c.lastUs = 0; c.registered = false;
+    c.hasDev = false; c.expectWide = false; c.devGroups.clear();
     order.push_back(sl);
   }
 }
@@ -1629,6 +1684,11 @@ int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive
   if ((rc = makeDelta())) return rc;
   { auto t0 = std::chrono::steady_clock::now(); rc = bringUpToDate(L); secDelta += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); if (rc) return rc; }
   const int m = (int)todo.size();
+  {   // what t4_add_query_pool_begin does with a heavy read under the testing aids of csrc/t4_api.hip
+    wideQueries = !getenv("T4_WIDE_OFF") && !getenv("T4_AQ_FORCE_GLOBAL");
+    const int lim = getenv("T4_AQ_CAP_LIMIT") ? atoi(getenv("T4_AQ_CAP_LIMIT")) : 0;
+    wideHitLimit = lim > 0 && lim < 8192 ? lim : 8192;
+  }
   L.slots = todo; L.uids.resize(m); L.hint.resize(m); L.bcs.resize(m); L.sts.resize(m); L.fac.resize(m);
   L.bases.clear(); L.offs.assign(1, 0); L.repetitive = repetitive;
   for (int i = 0; i < m; ++i) {
@@ -1637,6 +1697,7 @@ int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive
     L.bases += c.read; L.offs.push_back((int64_t)L.bases.size()); L.bcs[i] = c.barcode; L.sts[i] = c.strand;
     L.fac[i] = (c.barcode == -1 && !repetitive) ? 1.0 : 2.0;   // ExtendOverlap's mismatch factor (SeqSet.hpp:3597-3598)
     c.inflight = true; c.killed = false; c.shifts.clear(); c.statsStable = false;
+    c.hasDev = false; c.expectWide = false; c.devGroups.clear();
   }
   if (L.bases.empty()) L.bases.push_back('A');
   {
@@ -1656,7 +1717,15 @@ int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive
   const auto registerNew = [&]() { for (int sl : todo) if (!pool[sl]->registered) registerKmers(*pool[sl], sl); };
   const std::function<void()> groupWorker = [&]() {
     if (!regTaken.exchange(true)) registerNew();
-    for (;;) { int i = nextG.fetch_add(1); if (i >= m) break; buildGroups(*pool[todo[i]]); }
+    for (;;) {
+      int i = nextG.fetch_add(1);
+      if (i >= m) break;
+      Cached &e = *pool[todo[i]];
+      // a read whose emitted hits outgrow the LDS tier is served by the wide query, which returns its dependency records itself
+      // (deriving them here would cost several times the query: every posting of every k-mer, the ones the repeat-skip rule passes over included)
+      if (wideQueries && !repetitive && e.barcode == -1 && emittedHits(e) > wideHitLimit) { e.expectWide = true; e.groups.reset(16); e.slack = -1; e.fragile = true; }
+      else buildGroups(e);
+    }
   };
   const int nHelp = m >= 2 ? (threads - 1 < m - 1 ? threads - 1 : m - 1) : 0;
   if (nHelp > 0) { if (!helpers) helpers.reset(new HelperPool()); helpers->start(nHelp, groupWorker); }
@@ -1720,6 +1789,19 @@ int t4_assembler::harvest(Lane &L) {
       for (t4_overlap &o : c.ext) if (o.seqIdx == sh.first) { o.seqStart += sh.second; o.seqEnd += sh.second; }
     }
     c.shifts.clear();
+    {
+      const t4_grp *dg = nullptr; int ng = 0, huge = 0, n4 = 0;
+      if (t4_add_query_groups(L.ctx, i, &dg, &ng, &huge, &n4) == 1) {
+        static_assert(sizeof(t4_grp) == sizeof(Grp), "dependency record layout");
+        c.devGroups.assign((const Grp *)dg, (const Grp *)dg + ng);
+        c.devSplit = 0;
+        { size_t lo = 0, hi = c.devGroups.size(); while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (c.devGroups[mid].key & 1u) hi = mid; else lo = mid + 1; } c.devSplit = lo; }
+        c.hasDev = true; c.groups.reset(16);
+        c.slack = 99 - n4; c.fragile = huge != 0;
+        ++wideServed; wideGroupRecords += ng;
+      } else if (c.expectWide) { buildGroups(c); ++wideMispredicted; }   // (the LDS tier served it after all)
+      c.expectWide = false;
+    }
     c.valid = true;
   }
   return T4_OK;
@@ -2021,6 +2103,7 @@ int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n) {
                          a->invContig, a->invFragile, a->tolerated, (int64_t)(a->secDelta * 1e6), (int64_t)(a->secGroups * 1e6), (int64_t)(a->secEvents * 1e6), (int64_t)(a->secQuery * 1e6)};
   for (int i = 0; i < n && i < 16; ++i) out[i] = v[i];
   if (n >= 23) t4_add_query_stats(a->ctx, out + 16);
+  if (n >= 27) t4_add_query_wide_stats(a->ctx, out + 23);   // the wide query: reads it served, partitions, calls repeated with larger pools, dependency records
   if (getenv("T4_VERIFY_WINDOW")) fprintf(stderr, "T4_VERIFY_WINDOW: %lld served window entries queried again at serve time, all equal to their cached results\n", (long long)a->verified);
   if (getenv("T4_TIMING")) {
     fprintf(stderr, "timing: assembler host seconds: add_read calls %.3f (incl. waits for the head), prefetch calls %.3f; launching %.3f (of which deltas %.3f, dependency sets %.3f, registering k-mers %.3f), harvesting %.3f, event examination %.3f, index edits %.3f\n",
@@ -2030,6 +2113,7 @@ int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n) {
     if (a->slowSkipped) fprintf(stderr, "timing: %lld times a read whose last query was slow stayed out of a launch made for reads before it\n", (long long)a->slowSkipped);
     fprintf(stderr, "timing: tolerated index edits %lld, of which %lld met an entry whose group statistics cannot move (no budget spent); tolerance kills %lld, of which %lld for lists beyond 10000 postings\n",
             (long long)a->tolerated, (long long)a->toleratedStable, (long long)a->invFragile, (long long)a->invLongLists);
+    fprintf(stderr, "timing: wide query served %lld window entries (%lld dependency records came back with them), %lld reads it was expected for stayed on the LDS tier\n", (long long)a->wideServed, (long long)a->wideGroupRecords, (long long)a->wideMispredicted);
   }
   return T4_OK;
 }

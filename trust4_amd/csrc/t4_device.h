@@ -87,6 +87,38 @@ struct T4BatchView {
 
 struct T4TierCaps { int cap[T4_NTIER - 1]; };   // hit capacity of the LDS tiers, ascending
 
+// ---- the wide AddRead query: a read whose hits outgrow one workgroup's LDS is spread over the chip ---------------
+// The hits of such a read are scattered into PARTITIONS by contig range (every (strand, contig) group of GetOverlapsFromHits lies
+// in one partition); a partition is sorted, chained and scored by a workgroup of its own, the steps of GetOverlapsFromRead that
+// look across contigs (SeqSet.hpp:784-823 statistics, 1597 sort, 1601-1634 strand, 1705-1794 pre-filters, 2105-2119 cut) are
+// replayed over the partitions' records by one workgroup per read.
+struct T4Grp { unsigned key; unsigned cnt; int lo, hi; };   // dependency set of a query: key = contig * 2 + (strand == 1); hits; hull of the diagonals with >= 3 hits (lo > hi: none)
+struct T4WidePlan { int pBase, P, Wd, nk; unsigned H; int huge /* a list beyond 10000 postings */, read, grpBase; };
+#define T4_WIDE_STAT 24      // ints per read: see wideStatsKernel
+struct T4Wide {
+  int enabled;
+  int maxReads, maxPart, pcap, maxOvPart, safetyNum /* partitions are planned for pcap * 16 / safetyNum hits */, maxPartPerRead;
+  int *ctl;                  // [0] reads, [1] partitions, [2] overflow flags (1 reads, 2 partitions, 4 keys of a partition, 8 overlaps of a partition, 16 group pool), [3] group pool cursor
+  T4WidePlan *plan;          // [maxReads]
+  uint2 *seed;               // [maxReads][2 * T4_MAXL]: (start, emitted postings) of every k-mer position, forward strand first
+  unsigned *pCnt;            // [maxPart] keys
+  int *pRead;                // [maxPart] slot of the read
+  unsigned long long *pKeys; // [maxPart][pcap]
+  unsigned short *gSize;     // [maxPart][pcap] sizes of the (strand, contig) groups in key order
+  unsigned char *gInfo;      // [maxPart][pcap] huge reads: bits 0-2 = hits of the group whose list holds <= 10000 postings (capped at 4), bit 3 = its hit lowest on the read is one
+  int *gCount;               // [maxPart][4]: groups on the minus / plus strand, keys on the minus strand, spare
+  int *gOff;                 // [maxPart][2]: position of the partition's first minus / plus group among the read's groups (strand-major)
+  int *pRec;                 // [maxPart][maxOvPart] OvRec (10 ints)
+  int *pRecCnt;              // [maxPart]
+  int *stat;                 // [maxReads][T4_WIDE_STAT]
+  unsigned short *uniqPref;  // [maxReads][pcap + 1]: prefix counts of hits with <= 10000 postings over the head of the read's hit array in the reference's order (SeqSet.hpp:934-940)
+  unsigned long long *mKeys; // [maxPart * maxOvPart] sort keys of the merge
+  int *mOrd;                 // [maxPart * maxOvPart]
+  T4Grp *grpPool;            // pinned host memory (device pointer): dependency sets of the wide reads
+  int grpCap;
+  unsigned long long *sortTmp;  // [maxReads][2 * pcap] scratch of the statistics kernel (huge reads)
+};
+
 struct T4Work {              // per-launch work description
   const int *list;           // read ids of this tier
   int nList;
@@ -107,6 +139,7 @@ struct T4Work {              // per-launch work description
   unsigned short *gOrd;      // [grid][maxov]
   int gCap, gMaxOv;
   int capLimit;              // testing aid: an LDS tier pretends its hit capacity is this small (0 = off), so that small inputs reach the overflow paths
+  const T4Wide *wide;        // mode 4 of a contig set: reads beyond the LDS tier are handed to the wide query (device copy of its description; null: off)
 };
 
 // KmerCount on the device (KmerCount.hpp): open-addressing table of canonical k-mer codes; keys hold code + 1 (0 = empty)

@@ -728,6 +728,7 @@ struct WaveState { // wave-uniform scalars kept in LDS
   int nvPossible[2], nvLongest[2];   // novel group statistics of GetOverlapsFromHits (filter 1)
   int nvN4[2], nvN5[2], nvSmax[2];   // groups of at least 4 / 5 hits and the largest group, TRUE sizes (the statistics measure a group one short or in full)
   int statsStable;                   // no pass of this read so far whose novelMinHitRequired could move (see overlapsFromKeys)
+  int wideWant;                      // mode 4: a pass that outgrows the LDS arrays is handed to the wide query (t4_wide.h) instead of global scratch
   unsigned hhBest[2];        // HasHitInSet: per strand, (distinct read offsets << 16) | (0xFFFF - bucket rank) of the best bucket
   long long phaseT0; int curPhase, phaseBase;
 #ifdef T4_PHASE_TIMING
@@ -2261,7 +2262,7 @@ __device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, 
   PHASE_MARK(ws, 1);
   int H = NOVEL ? seedPositionsNovel(ix, wm, segLen, strandArg, barcode, allowTotalSkip, posStart, posPref, ws->red, wm.keys, ws)
                 : seedPositions(ix, wm, segLen, strandArg, barcode, allowTotalSkip, posStart, posPref, ws->red);   // the key array is free until the hits are expanded
-  if (H > wm.hitLimit) return -1;
+  if (H > wm.hitLimit) return (NOVEL && ws->wideWant && !allowTotalSkip && !vjOnly && filter == 1) ? -3 : -1;
   PHASE_MARK(ws, 2);
 #if T4_OPT_KEY32
   const int k32 = ix.key32;
@@ -2422,86 +2423,12 @@ __device__ T4_PREFILTER_NI void prefilterNovel(const T4IndexView &ix, WaveMem &w
   __syncthreads();
 }
 
-// SeqSet::GetOverlapsFromRead (SeqSet.hpp:1508-2124, readType 0) for the segment in wm.seg / wm.rc.
-// Scored and filtered overlaps are appended to wm.fin (coordinates shifted by `shift`).
-// Returns the reference's return value (-1, 0 or the overlap count); -2 on capacity overflow.
-// ROWS: the row-per-overlap finishing pass for short lists (the AddRead / AssignRead kernels; the rough-annotation kernels, whose
-// overlaps are reference genes, keep their register budget).
+// The scoring of GetOverlapsFromRead (SeqSet.hpp:1673-2094 without its pre-filters, which are replayed afterwards): every overlap
+// wm.ov[wm.ord[0 .. overlapCnt)] walks its chain, the gap alignments run eight (or one) per wavefront, the overlaps take their
+// matchCnt / indelCnt / similarity-zero flag; chainLen is left holding the matchCnt of GetOverlapsFromHits. false: a capacity ran out.
 template <bool ROWS>
-__device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int segLen, int strandArg, int barcode,
-                                   bool skipRepeats, int shift, DPScratch sc, unsigned long long &hitTotal) {
+__device__ __forceinline__ bool scoreOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int overlapCnt, DPScratch sc) {
   const int lane = tid(), NT = nthr();
-  if (segLen < ix.k) return -1;
-  int overlapCnt = 0;
-  if (skipRepeats) {
-    int H = seedChainPass<ROWS>(ix, wm, ws, segLen, strandArg, barcode, true, false, ix.hitLenRequired, 0);
-    if (H < 0) return -2;
-    hitTotal += (unsigned long long)H;
-    __syncthreads();
-    overlapCnt = ws->ovCount;
-  }
-  if (overlapCnt == 0) {
-    __syncthreads();
-    int H = seedChainPass<ROWS>(ix, wm, ws, segLen, strandArg, barcode, false, false, ix.hitLenRequired, 1);
-    if (H < 0) return -2;
-    hitTotal += (unsigned long long)H;
-    __syncthreads();
-    overlapCnt = ws->ovCount;
-    if (overlapCnt == 0) {
-      // VJ junction rescue on the hits of this pass (SeqSet.hpp:1570-1575)
-      __syncthreads();
-      int H2 = seedChainPass<ROWS>(ix, wm, ws, segLen, strandArg, barcode, false, true, 17, 0);
-      if (H2 < 0) return -2;
-      __syncthreads();
-      int n = ws->ovCount;
-      if (n > wm.maxOv) return -2;
-      __syncthreads();
-      if (lane == 0) ws->ovCount = selectVJPair(ix, wm, n);
-      __syncthreads();
-      overlapCnt = ws->ovCount;
-      if (overlapCnt == 0) return 0;
-    }
-  }
-#ifdef T4_DEBUG
-  if (lane == 0) printf("DBG seg len %d overlapCnt %d overflow %d\n", segLen, overlapCnt, ws->overflow);
-#endif
-  if (ws->overflow || overlapCnt > wm.maxOv) return -2;
-  PHASE_MARK(ws, 8);
-  // std::sort(overlaps) by operator< (the order is total on distinct overlaps)
-  bool keySorted = false;
-#if T4_OPT_OVKEYSORT
-  // (threshold: 256 overlaps; lower when the testing aid T4Work::capLimit has shrunk the staging block, so that small cases come here)
-  if ((ROWS || !T4_V0_NOKEYSORT) && !wm.ldsArrays && wm.ldsSort && overlapCnt > (wm.ldsSortCap >= 4096 ? 256 : wm.ldsSortCap / 16) && overlapCnt <= 16384)
-    keySorted = sortOverlapsByKey(wm, ws, overlapCnt);
-#endif
-  if (!keySorted)
-  for (int i = lane; i < overlapCnt; i += NT) {
-    OvRec me = wm.ov[i];
-    int rank = 0;
-    for (int j = 0; j < overlapCnt; ++j) {
-      if (j == i) continue;
-      OvRec ot = wm.ov[j];
-      const int cm = ovCmp(ot, me, false);
-      if (cm < 0 || (cm == 0 && j < i)) ++rank;
-    }
-    wm.ord[rank] = (unsigned short)i;
-  }
-  __syncthreads();
-  // keep the overlaps on the strand of the best one (SeqSet.hpp:1601-1616), order preserved
-  int strand0 = wm.ov[wm.ord[0]].flags & OV_PLUS;
-  int kept = 0;
-  for (int i0 = 0; i0 < overlapCnt; i0 += NT) {
-    int i = i0 + lane;
-    int o = i < overlapCnt ? wm.ord[i] : 0;
-    bool keep = i < overlapCnt && ((wm.ov[o].flags & OV_PLUS) == strand0);
-    int tot;
-    int inc = blockInclScan(keep ? 1 : 0, ws->red, tot);   // barriers inside: every ord[i] of the chunk is read
-    if (keep) wm.ord[kept + inc - 1] = (unsigned short)o;   // target <= i: compaction in place, chunk by chunk
-    kept += tot;
-    __syncthreads();
-  }
-  overlapCnt = kept;
-  PHASE_MARK(ws, 9);
   // score every kept overlap (one lane each)
   // (1) collect the gap-alignment jobs of every kept overlap (job list = the dead cand array)
   if (lane == 0) ws->jobCount = 0;
@@ -2515,7 +2442,7 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
   }
 #endif
   __syncthreads();
-  if (ws->overflow) return -2;
+  if (ws->overflow) return false;
   const int nJobs = ws->jobCount;
   if (lane == 0) DBG_ADD(0, nJobs);
   // (2) quick exits, one job per lane
@@ -2655,6 +2582,90 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
     wm.ov[wm.ord[i]] = o;
   }
   __syncthreads();
+  return true;
+}
+
+// SeqSet::GetOverlapsFromRead (SeqSet.hpp:1508-2124, readType 0) for the segment in wm.seg / wm.rc.
+// Scored and filtered overlaps are appended to wm.fin (coordinates shifted by `shift`).
+// Returns the reference's return value (-1, 0 or the overlap count); -2 on capacity overflow.
+// ROWS: the row-per-overlap finishing pass for short lists (the AddRead / AssignRead kernels; the rough-annotation kernels, whose
+// overlaps are reference genes, keep their register budget).
+template <bool ROWS>
+__device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int segLen, int strandArg, int barcode,
+                                   bool skipRepeats, int shift, DPScratch sc, unsigned long long &hitTotal) {
+  const int lane = tid(), NT = nthr();
+  if (segLen < ix.k) return -1;
+  int overlapCnt = 0;
+  if (skipRepeats) {
+    int H = seedChainPass<ROWS>(ix, wm, ws, segLen, strandArg, barcode, true, false, ix.hitLenRequired, 0);
+    if (H < 0) return -2;
+    hitTotal += (unsigned long long)H;
+    __syncthreads();
+    overlapCnt = ws->ovCount;
+  }
+  if (overlapCnt == 0) {
+    __syncthreads();
+    int H = seedChainPass<ROWS>(ix, wm, ws, segLen, strandArg, barcode, false, false, ix.hitLenRequired, 1);
+    if (H < 0) return H == -3 ? -3 : -2;
+    hitTotal += (unsigned long long)H;
+    __syncthreads();
+    overlapCnt = ws->ovCount;
+    if (overlapCnt == 0) {
+      // VJ junction rescue on the hits of this pass (SeqSet.hpp:1570-1575)
+      __syncthreads();
+      int H2 = seedChainPass<ROWS>(ix, wm, ws, segLen, strandArg, barcode, false, true, 17, 0);
+      if (H2 < 0) return -2;
+      __syncthreads();
+      int n = ws->ovCount;
+      if (n > wm.maxOv) return -2;
+      __syncthreads();
+      if (lane == 0) ws->ovCount = selectVJPair(ix, wm, n);
+      __syncthreads();
+      overlapCnt = ws->ovCount;
+      if (overlapCnt == 0) return 0;
+    }
+  }
+#ifdef T4_DEBUG
+  if (lane == 0) printf("DBG seg len %d overlapCnt %d overflow %d\n", segLen, overlapCnt, ws->overflow);
+#endif
+  if (ws->overflow || overlapCnt > wm.maxOv) return -2;
+  PHASE_MARK(ws, 8);
+  // std::sort(overlaps) by operator< (the order is total on distinct overlaps)
+  bool keySorted = false;
+#if T4_OPT_OVKEYSORT
+  // (threshold: 256 overlaps; lower when the testing aid T4Work::capLimit has shrunk the staging block, so that small cases come here)
+  if ((ROWS || !T4_V0_NOKEYSORT) && !wm.ldsArrays && wm.ldsSort && overlapCnt > (wm.ldsSortCap >= 4096 ? 256 : wm.ldsSortCap / 16) && overlapCnt <= 16384)
+    keySorted = sortOverlapsByKey(wm, ws, overlapCnt);
+#endif
+  if (!keySorted)
+  for (int i = lane; i < overlapCnt; i += NT) {
+    OvRec me = wm.ov[i];
+    int rank = 0;
+    for (int j = 0; j < overlapCnt; ++j) {
+      if (j == i) continue;
+      OvRec ot = wm.ov[j];
+      const int cm = ovCmp(ot, me, false);
+      if (cm < 0 || (cm == 0 && j < i)) ++rank;
+    }
+    wm.ord[rank] = (unsigned short)i;
+  }
+  __syncthreads();
+  // keep the overlaps on the strand of the best one (SeqSet.hpp:1601-1616), order preserved
+  int strand0 = wm.ov[wm.ord[0]].flags & OV_PLUS;
+  int kept = 0;
+  for (int i0 = 0; i0 < overlapCnt; i0 += NT) {
+    int i = i0 + lane;
+    int o = i < overlapCnt ? wm.ord[i] : 0;
+    bool keep = i < overlapCnt && ((wm.ov[o].flags & OV_PLUS) == strand0);
+    int tot;
+    int inc = blockInclScan(keep ? 1 : 0, ws->red, tot);   // barriers inside: every ord[i] of the chunk is read
+    if (keep) wm.ord[kept + inc - 1] = (unsigned short)o;   // target <= i: compaction in place, chunk by chunk
+    kept += tot;
+    __syncthreads();
+  }
+  overlapCnt = kept;
+  PHASE_MARK(ws, 9);
+  if (!scoreOverlaps<ROWS>(ix, wm, ws, overlapCnt, sc)) return -2;
   PHASE_MARK(ws, 10);
   if (ix.hasNovel && overlapCnt > 50) {
     if (ROWS || !T4_V0_SERIALPRE) prefilterNovel(ix, wm, ws, overlapCnt, segLen);
@@ -3344,13 +3355,15 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
 // Process one read in one wavefront. Returns false when the read has to move to a larger tier.
 // VARIANT 0: GetOverlapsFromRead / AnnotateRead level 0 (modes 0, 1); VARIANT 1: the modes that also run ExtendOverlap
 // (2, 3, 4). Separate instantiations: the extension code must not cost the rough-annotation kernels registers.
+#include "t4_wide.h"
+
 template <int VARIANT>
 __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const T4Work &wk, const T4QueryArgs &qa,
                             WaveMem &wm, WaveState *ws, long long r, DPScratch sc) {
   const int lane = tid(), NT = nthr();
   const int len = bv.len[r];
   unsigned long long hitTotal = 0;
-  if (lane == 0) { ws->overflow = 0; ws->unsupported = 0; ws->finCount = 0; ws->nContig = 0; ws->ovCount = 0; ws->statsStable = 1; }
+  if (lane == 0) { ws->overflow = 0; ws->unsupported = 0; ws->finCount = 0; ws->nContig = 0; ws->ovCount = 0; ws->statsStable = 1; ws->wideWant = 0; }
 #ifdef T4_PHASE_TIMING
   if (lane == 0) { ws->phaseT0 = clock64(); ws->phaseBase = wm.ldsArrays ? 0 : 32; ws->curPhase = ws->phaseBase; }
 #endif
@@ -3362,8 +3375,17 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
     ExtOut *res = (ExtOut *)wm.ov;
     unsigned char *dirbuf = wm.dirBuf;
     int barcode = bv.barcode ? bv.barcode[r] : -1;
+    // a pass that outgrows this workgroup's arrays (hits or overlaps) is spread over the chip: the wide query (t4_wide.h)
+    const bool wide = wk.wide != nullptr && wm.ldsArrays && !qa.skipRepeats && barcode == -1 && ix.hasNovel == 2 && !qa.views && qa.extendLater > 0;
+    if (lane == 0) ws->wideWant = wide ? 1 : 0;
     loadSegment(bv, r, 0, len, wm);
     int ret = overlapsFromSegment<VARIANT != 0>(ix, wm, ws, len, qa.strandPerRead[r], barcode, qa.skipRepeats != 0, 0, sc, hitTotal);
+    if (wide && (ret == -2 || ret == -3)) {
+      if (ret == -2) hitTotal = 0;   // (the pass is counted again by the wide query's seed stage)
+      wideDeferRead(ix, wm, ws, *wk.wide, len, qa.strandPerRead[r], r, hitTotal);
+      if (lane == 0) atomicAdd(wk.hitCounter, hitTotal);
+      return true;
+    }
     if (ret == -2) return false;
     int n = ret > 0 ? ret : 0;
     if (lane == 0 && qa.statsStable) qa.statsStable[r] = ws->statsStable;

@@ -17,6 +17,7 @@
 // Limits of this round: no -c/--debug-ns; without barcodes `_final.out` is written as a
 // copy of `_raw.out` (the reference does the same under --skipMateExtension and always with barcodes; its mate-graph
 // extension tail is out of scope).
+#include <fcntl.h>
 #include <getopt.h>
 #include <math.h>
 #include <stdarg.h>
@@ -63,7 +64,8 @@ const char *USAGE =
     "\t--contigMinCov INT: ignore contigs that have bases covered by fewer than INT reads (default: 0)\n"
     "Extension (multi-GPU, see trust4_amd/stage1_dist.py):\n"
     "\t--cellShard R/N: barcode mode only; assemble the R-th of N contiguous ranges of cells, write shard outputs\n"
-    "\t--rcclId FILE: with --cellShard, one process per GPU: gather the shards over RCCL (rank 0 creates FILE, the communicator id) and let rank 0 write the merged -o files\n";
+    "\t--rcclId FILE: with --cellShard, one process per GPU: gather the shards over RCCL (rank 0 creates FILE, the communicator id) and write the merged -o files\n"
+    "\t--gatherDir DIR: the same exchange through files in DIR (a directory every rank sees) instead of RCCL\n";
 
 void PrintLog(const char *fmt, ...) {
   char buf[2048], stime[256];
@@ -431,10 +433,11 @@ int main(int argc, char *argv[]) {
                                          {"minHitLen", required_argument, 0, 10006}, {"cgeneEnd", required_argument, 0, 10008},
                                          {"barcode", required_argument, 0, 10002}, {"UMI", required_argument, 0, 10004},
                                          {"keepNoBarcode", no_argument, 0, 10003}, {"contigMinCov", required_argument, 0, 10007},
-                                         {"cellShard", required_argument, 0, 10100}, {"rcclId", required_argument, 0, 10101}, {"debug-ns", required_argument, 0, 10000},
+                                         {"cellShard", required_argument, 0, 10100}, {"rcclId", required_argument, 0, 10101}, {"gatherDir", required_argument, 0, 10102}, {"debug-ns", required_argument, 0, 10000},
                                          {(char *)0, 0, 0, 0}};
   int indexKmerLength = 9, changeKmerLengthThreshold = 4096, trimLevel = 1, minHitLen = -1, constantGeneEnd = 200;
   int shardRank = 0, shardCount = 1, threadCnt = 1, contigMinCov = 0;
+  std::string gatherDir;    // --gatherDir DIR: the same exchange through files of a directory every rank sees (tests without RCCL)
   std::string rcclIdPath;   // --rcclId FILE: the shards' results are gathered inside the engine (t4_comm: RCCL), rank 0 writes the merged files
   bool keepMissingBarcode = false, skipMateExtension = false;
   std::string refFa, outputPrefix = "trust", kmerCountFile;
@@ -460,6 +463,7 @@ int main(int argc, char *argv[]) {
     else if (c == 10002) { barcodeFile.files.push_back(optarg); hasBarcode = true; }
     else if (c == 10004) { umiFile.files.push_back(optarg); hasUmi = true; }
     else if (c == 10101) rcclIdPath = optarg;
+    else if (c == 10102) gatherDir = optarg;
     else if (c == 10100) { if (sscanf(optarg, "%d/%d", &shardRank, &shardCount) != 2 || shardCount < 1 || shardRank < 0 || shardRank >= shardCount) { fprintf(stderr, "--cellShard takes R/N with 0 <= R < N\n"); return EXIT_FAILURE; } }
     else if (c == 10003) keepMissingBarcode = true;
     else if (c == 10007) contigMinCov = atoi(optarg);
@@ -1345,17 +1349,73 @@ int main(int argc, char *argv[]) {
     fflush(stdout);
     unlink(tmpl);
   };
-  if (!rcclIdPath.empty()) {
-    // ---- the one exchange of barcode mode, inside the engine: every rank's contig records (ids local to its cells), assembled
-    // reads and slot count are all-gathered over RCCL; rank 0 renumbers the contigs as the reference's cell-after-cell pass does
-    // (ids shifted by the slots of the earlier ranks) and writes the three files.
-    if (!useCells) { fprintf(stderr, "trust4-hip: --rcclId needs --barcode (without barcodes the Add pass does not shard).\n"); return EXIT_FAILURE; }
+  auto writeCellStats = [&]() {
+    int64_t qb = 0, rq = 0, im = 0, by = 0; double sq = 0, ss = 0;
+    t4_cellset_counters(cellSet, &qb, &rq, &im, &by, &sq, &ss);
+    if (const char *sj = getenv("T4_STATS_JSON")) {
+      FILE *fp = fopen(sj, "w");
+      if (fp) {
+        fprintf(fp, "{\"reads\": %d, \"threads\": %d, \"phases_s\": {", readCnt, threadCnt);
+        for (size_t i = 0; i < phaseMarks.size(); ++i) fprintf(fp, "%s\"%s\": %.4f", i ? ", " : "", phaseMarks[i].first.c_str(), phaseMarks[i].second);
+        fprintf(fp, "}, \"rough_annotation\": {\"reads\": %lld, \"hits\": %lld, \"kernel_ms\": %.3f}, ", annotReads, annotHits, annotKernelMs);
+        fprintf(fp, "\"cells\": {\"query_batches\": %lld, \"reads_queried\": %lld, \"images_staged\": %lld, \"bytes_staged\": %lld, \"query_wall_s\": %.3f, \"stage_wall_s\": %.3f}, ",
+                (long long)qb, (long long)rq, (long long)im, (long long)by, sq, ss);
+        fprintf(fp, "\"contigs\": %d, \"assembled_reads\": %d}\n", t4_cellset_size(cellSet), (int)assembledReadIdx.size());
+        fclose(fp);
+      }
+    }
+    PrintLog("Finish assembly. (%lld cells; GPU query batches %lld with %lld reads in %.2f s; %lld cell images, %.1f MB, staged in %.2f s)",
+             (long long)barcodeIntToStr.size(), (long long)qb, (long long)rq, sq, (long long)im, by / 1e6, ss);
+  };
+  if (!rcclIdPath.empty() || !gatherDir.empty()) {
+    // ---- the one exchange of barcode mode, inside the engine. Every rank holds the contig records of its cells (ids local to the
+    // shard) and its assembled reads. (1) a small all-gather: contig slots and byte counts of every rank; (2) every rank renumbers
+    // ITS OWN records as the reference's cell-after-cell pass numbers them (id += the slots of the earlier ranks); (3) the renumbered
+    // records are gathered to rank 0, which writes _raw.out / _final.out; (4) every rank writes its own slice of
+    // _assembled_reads.fa at the offset the byte counts give it -- the read texts (the bulk of the bytes) never travel.
+    // Transport: RCCL over xGMI (--rcclId: t4_comm, ncclAllGather + grouped ncclSend / ncclRecv from C++ on the ctx's stream), or
+    // files in a directory all ranks see (--gatherDir: the CPU tests; the merge below is the same code).
+    if (!useCells) { fprintf(stderr, "trust4-hip: --rcclId / --gatherDir need --barcode (without barcodes the Add pass does not shard).\n"); return EXIT_FAILURE; }
     t4_comm *comm = nullptr;
-    if ((rc = t4_comm_init(ctx, shardRank, shardCount, rcclIdPath.c_str(), &comm))) die(ctx, "t4_comm_init", rc);
+    if (gatherDir.empty() && (rc = t4_comm_init(ctx, shardRank, shardCount, rcclIdPath.c_str(), &comm))) die(ctx, "t4_comm_init", rc);
+    int exchangeNo = 0;
+    auto fileOf = [&](int no, int r) { return gatherDir + "/x" + std::to_string(no) + ".rank" + std::to_string(r); };
+    auto readWhole = [](const std::string &path, std::string &out) { FILE *fp = fopen(path.c_str(), "rb"); if (!fp) return false; char buf[1 << 16]; size_t n; out.clear(); while ((n = fread(buf, 1, sizeof buf, fp)) > 0) out.append(buf, n); fclose(fp); return true; };
+    // every rank contributes `mine`; everyRank: all ranks receive all contributions, else only `root` does
+    auto exchange = [&](const std::string &mine, bool everyRank, std::vector<std::string> &got) -> bool {
+      got.assign((size_t)shardCount, std::string());
+      const int no = exchangeNo++;
+      if (!gatherDir.empty()) {
+        const std::string tmp = fileOf(no, shardRank) + ".tmp";
+        FILE *fp = fopen(tmp.c_str(), "wb");
+        if (!fp || fwrite(mine.data(), 1, mine.size(), fp) != mine.size()) { if (fp) fclose(fp); return false; }
+        fclose(fp);
+        if (rename(tmp.c_str(), fileOf(no, shardRank).c_str())) return false;
+        if (!everyRank && shardRank != 0) return true;
+        for (int r = 0; r < shardCount; ++r) {
+          bool ok = false;
+          for (int tries = 0; tries < 36000 && !ok; ++tries) { ok = readWhole(fileOf(no, r), got[(size_t)r]); if (!ok) usleep(50000); }
+          if (!ok) return false;
+        }
+        return true;
+      }
+      void *all = nullptr;
+      std::vector<int64_t> sizes((size_t)shardCount);
+      const int rr = everyRank ? t4_comm_allgather_bytes(comm, mine.data(), (int64_t)mine.size(), &all, sizes.data())
+                               : t4_comm_gather_bytes(comm, mine.data(), (int64_t)mine.size(), 0, &all, sizes.data());
+      if (rr) die(ctx, everyRank ? "t4_comm_allgather_bytes" : "t4_comm_gather_bytes", rr);
+      if (all) {
+        size_t at = 0;
+        for (int r = 0; r < shardCount; ++r) { got[(size_t)r].assign((const char *)all + at, (size_t)sizes[(size_t)r]); at += (size_t)sizes[(size_t)r]; }
+        free(all);
+      }
+      return true;
+    };
     const std::string tmpRaw = outputPrefix + ".shard" + std::to_string(shardRank) + "_raw.tmp";
     writeSet(tmpRaw);
     std::string rawText;
-    { FILE *fp = fopen(tmpRaw.c_str(), "rb"); char buf[1 << 16]; size_t n; while (fp && (n = fread(buf, 1, sizeof buf, fp)) > 0) rawText.append(buf, n); if (fp) fclose(fp); unlink(tmpRaw.c_str()); }
+    readWhole(tmpRaw, rawText);
+    unlink(tmpRaw.c_str());
     std::string mainText, rescueText;
     {
       const size_t nMain = assembledReadIdx.size() - (size_t)rescuedCnt;
@@ -1369,51 +1429,66 @@ int main(int argc, char *argv[]) {
         dst += ">" + sr.id + " " + std::to_string(sr.strand) + " " + std::to_string(sr.minCnt) + " " + std::to_string(sr.medianCnt) + extra + "\n" + sr.read + "\n";
       }
     }
-    const std::string slotText = std::to_string(t4_cellset_size(cellSet));
-    const std::string *parts[4] = {&rawText, &mainText, &rescueText, &slotText};
-    std::vector<std::vector<std::string>> got(4, std::vector<std::string>((size_t)shardCount));
-    for (int k = 0; k < 4; ++k) {
-      void *all = nullptr;
-      std::vector<int64_t> sizes((size_t)shardCount);
-      if ((rc = t4_comm_allgather_bytes(comm, parts[k]->data(), (int64_t)parts[k]->size(), &all, sizes.data()))) die(ctx, "t4_comm_allgather_bytes", rc);
-      size_t at = 0;
-      for (int r = 0; r < shardCount; ++r) { got[(size_t)k][(size_t)r].assign((const char *)all + at, (size_t)sizes[(size_t)r]); at += (size_t)sizes[(size_t)r]; }
-      free(all);
-    }
-    if (shardRank == 0) {
-      std::string merged;
-      long long base = 0;
-      for (int r = 0; r < shardCount; ++r) {
-        const std::string &t = got[0][(size_t)r];
-        for (size_t i = 0; i < t.size();) {   // `>BARCODE_<id> name` header lines (SeqSet.hpp:10951) get id += base
-          size_t e = t.find('\n', i);
-          if (e == std::string::npos) e = t.size();
-          if (base > 0 && t[i] == '>') {
-            size_t sp = t.find(' ', i);
-            if (sp == std::string::npos || sp > e) sp = e;
-            const size_t us = t.rfind('_', sp - 1);
-            merged.append(t, i, us + 1 - i);
-            merged += std::to_string(atoll(t.substr(us + 1, sp - us - 1).c_str()) + base);
-            merged.append(t, sp, e - sp);
-          } else merged.append(t, i, e - i);
-          if (e < t.size()) merged.push_back('\n');
-          i = e + 1;
-        }
-        base += atoll(got[3][(size_t)r].c_str());
+    // (1) slots and byte counts of every rank
+    std::vector<std::string> heads;
+    if (!exchange(std::to_string(t4_cellset_size(cellSet)) + " " + std::to_string(mainText.size()) + " " + std::to_string(rescueText.size()), true, heads)) { fprintf(stderr, "trust4-hip: the exchange of the shard headers failed\n"); return EXIT_FAILURE; }
+    std::vector<long long> slots((size_t)shardCount), mainBytes((size_t)shardCount), rescueBytes((size_t)shardCount);
+    for (int r = 0; r < shardCount; ++r) if (sscanf(heads[(size_t)r].c_str(), "%lld %lld %lld", &slots[(size_t)r], &mainBytes[(size_t)r], &rescueBytes[(size_t)r]) != 3) { fprintf(stderr, "trust4-hip: bad shard header from rank %d\n", r); return EXIT_FAILURE; }
+    long long base = 0, mainAt = 0, rescueAt = 0, mainAll = 0, slotsAll = 0;
+    for (int r = 0; r < shardCount; ++r) { if (r < shardRank) { base += slots[(size_t)r]; mainAt += mainBytes[(size_t)r]; rescueAt += rescueBytes[(size_t)r]; } mainAll += mainBytes[(size_t)r]; slotsAll += slots[(size_t)r]; }
+    // (2) `>BARCODE_<id> name` header lines (SeqSet.hpp:10951) of this rank's records: id += base
+    std::string renum;
+    if (base == 0) renum.swap(rawText);
+    else {
+      renum.reserve(rawText.size() + rawText.size() / 64);
+      const std::string &t = rawText;
+      for (size_t i = 0; i < t.size();) {
+        size_t e = t.find('\n', i);
+        if (e == std::string::npos) e = t.size();
+        if (t[i] == '>') {
+          size_t sp = t.find(' ', i);
+          if (sp == std::string::npos || sp > e) sp = e;
+          const size_t us = t.rfind('_', sp - 1);
+          renum.append(t, i, us + 1 - i);
+          renum += std::to_string(atoll(t.substr(us + 1, sp - us - 1).c_str()) + base);
+          renum.append(t, sp, e - sp);
+        } else renum.append(t, i, e - i);
+        if (e < t.size()) renum.push_back('\n');
+        i = e + 1;
       }
+    }
+    // (3) contig records to rank 0
+    std::vector<std::string> raws;
+    if (!exchange(renum, false, raws)) { fprintf(stderr, "trust4-hip: the gather of the contig records failed\n"); return EXIT_FAILURE; }
+    const std::string readsPath = outputPrefix + "_assembled_reads.fa";
+    if (shardRank == 0) {
       for (const char *suffix : {"_raw.out", "_final.out"}) {   // with barcodes _final.out is a second dump of the raw set (main.cpp:2018-2036)
         FILE *fp = fopen((outputPrefix + suffix).c_str(), "wb");
         if (!fp) { fprintf(stderr, "trust4-hip: cannot write %s%s\n", outputPrefix.c_str(), suffix); return EXIT_FAILURE; }
-        fwrite(merged.data(), 1, merged.size(), fp); fclose(fp);
+        for (int r = 0; r < shardCount; ++r) fwrite(raws[(size_t)r].data(), 1, raws[(size_t)r].size(), fp);
+        fclose(fp);
       }
-      FILE *fp = fopen((outputPrefix + "_assembled_reads.fa").c_str(), "wb");
-      for (int r = 0; r < shardCount; ++r) fwrite(got[1][(size_t)r].data(), 1, got[1][(size_t)r].size(), fp);
-      for (int r = 0; r < shardCount; ++r) fwrite(got[2][(size_t)r].data(), 1, got[2][(size_t)r].size(), fp);
+      FILE *fp = fopen(readsPath.c_str(), "wb");   // created (and emptied) before any rank writes its slice
+      if (!fp) { fprintf(stderr, "trust4-hip: cannot write %s\n", readsPath.c_str()); return EXIT_FAILURE; }
       fclose(fp);
-      PrintLog("Gathered %d shards over RCCL: %lld contig slots.", shardCount, base);
     }
-    t4_comm_destroy(comm);
+    // (4) every rank's slices of _assembled_reads.fa: all main-pass reads by rank, then all rescue-pass reads by rank
+    std::vector<std::string> ready;
+    if (!exchange("file", true, ready)) { fprintf(stderr, "trust4-hip: the exchange before the read slices failed\n"); return EXIT_FAILURE; }
+    {
+      const int fd = open(readsPath.c_str(), O_WRONLY);
+      if (fd < 0) { fprintf(stderr, "trust4-hip: rank %d cannot open %s\n", shardRank, readsPath.c_str()); return EXIT_FAILURE; }
+      auto putAt = [&](const std::string &t, long long at) { size_t done = 0; while (done < t.size()) { const ssize_t w = pwrite(fd, t.data() + done, t.size() - done, (off_t)(at + (long long)done)); if (w <= 0) return false; done += (size_t)w; } return true; };
+      const bool ok = putAt(mainText, mainAt) && putAt(rescueText, mainAll + rescueAt);
+      close(fd);
+      if (!ok) { fprintf(stderr, "trust4-hip: rank %d could not write its reads into %s\n", shardRank, readsPath.c_str()); return EXIT_FAILURE; }
+    }
+    std::vector<std::string> doneAll;
+    if (!exchange("done", true, doneAll)) { fprintf(stderr, "trust4-hip: the last exchange failed\n"); return EXIT_FAILURE; }
+    if (shardRank == 0) PrintLog("Gathered %d shards over %s: %lld contig slots.", shardCount, gatherDir.empty() ? "RCCL" : "files", slotsAll);
+    if (comm) t4_comm_destroy(comm);
     mark("outputs_written");
+    writeCellStats();
     t4_cellset_destroy(cellSet);
     t4_index_destroy(refSet);
     t4_destroy(ctx);
@@ -1449,23 +1524,8 @@ int main(int argc, char *argv[]) {
     writeSetOrStdout(outputPrefix + "_final.out");
   }
   if (useCells) {
-    int64_t qb = 0, rq = 0, im = 0, by = 0; double sq = 0, ss = 0;
-    t4_cellset_counters(cellSet, &qb, &rq, &im, &by, &sq, &ss);
     mark("outputs_written");
-    if (const char *sj = getenv("T4_STATS_JSON")) {
-      FILE *fp = fopen(sj, "w");
-      if (fp) {
-        fprintf(fp, "{\"reads\": %d, \"threads\": %d, \"phases_s\": {", readCnt, threadCnt);
-        for (size_t i = 0; i < phaseMarks.size(); ++i) fprintf(fp, "%s\"%s\": %.4f", i ? ", " : "", phaseMarks[i].first.c_str(), phaseMarks[i].second);
-        fprintf(fp, "}, \"rough_annotation\": {\"reads\": %lld, \"hits\": %lld, \"kernel_ms\": %.3f}, ", annotReads, annotHits, annotKernelMs);
-        fprintf(fp, "\"cells\": {\"query_batches\": %lld, \"reads_queried\": %lld, \"images_staged\": %lld, \"bytes_staged\": %lld, \"query_wall_s\": %.3f, \"stage_wall_s\": %.3f}, ",
-                (long long)qb, (long long)rq, (long long)im, (long long)by, sq, ss);
-        fprintf(fp, "\"contigs\": %d, \"assembled_reads\": %d}\n", t4_cellset_size(cellSet), (int)assembledReadIdx.size());
-        fclose(fp);
-      }
-    }
-    PrintLog("Finish assembly. (%lld cells; GPU query batches %lld with %lld reads in %.2f s; %lld cell images, %.1f MB, staged in %.2f s)",
-             (long long)barcodeIntToStr.size(), (long long)qb, (long long)rq, sq, (long long)im, by / 1e6, ss);
+    writeCellStats();
     t4_cellset_destroy(cellSet);
     t4_index_destroy(refSet);
     t4_destroy(ctx);
@@ -1475,8 +1535,8 @@ int main(int argc, char *argv[]) {
   t4_assembler_counters(seqSet, &q, &rf, &wh);
   double sr = 0, sq = 0;
   t4_assembler_timers(seqSet, &sr, &sq);
-  int64_t lc[23] = {0};
-  t4_assembler_live_counters(seqSet, lc, 23);
+  int64_t lc[27] = {0};
+  t4_assembler_live_counters(seqSet, lc, 27);
   mark("outputs_written");
   if (const char *sj = getenv("T4_STATS_JSON")) {
     FILE *fp = fopen(sj, "w");
@@ -1485,9 +1545,10 @@ int main(int argc, char *argv[]) {
       for (size_t i = 0; i < phaseMarks.size(); ++i) fprintf(fp, "%s\"%s\": %.4f", i ? ", " : "", phaseMarks[i].first.c_str(), phaseMarks[i].second);
       fprintf(fp, "}, \"rough_annotation\": {\"reads\": %lld, \"hits\": %lld, \"kernel_ms\": %.3f}, ", annotReads, annotHits, annotKernelMs);
       fprintf(fp, "\"add_query\": {\"rounds\": %lld, \"reads_queried\": %lld, \"reads_served\": %lld, \"kernel_ms\": %.3f, \"hits\": %lld, \"records\": %lld, "
-                  "\"global_tier_launches\": %lld, \"global_tier_reads\": %lld, \"deltas\": %lld, \"delta_bytes\": %lld, \"invalidations\": %lld, \"query_wall_s\": %.3f}, ",
+                  "\"global_tier_launches\": %lld, \"global_tier_reads\": %lld, \"deltas\": %lld, \"delta_bytes\": %lld, \"invalidations\": %lld, \"host_wait_for_queries_s\": %.3f, "
+                  "\"wide\": {\"reads\": %lld, \"partitions\": %lld, \"calls_repeated\": %lld, \"dependency_records\": %lld}}, ",
               (long long)lc[0], (long long)lc[1], (long long)wh, lc[21] / 1e3, (long long)lc[22], (long long)lc[20], (long long)lc[18], (long long)lc[19], (long long)lc[2],
-              (long long)lc[3], (long long)lc[4], lc[15] / 1e6);
+              (long long)lc[3], (long long)lc[4], lc[15] / 1e6, (long long)lc[23], (long long)lc[24], (long long)lc[25], (long long)lc[26]);
       fprintf(fp, "\"contigs\": %d, \"assembled_reads\": %d}\n", t4_assembler_size(seqSet), (int)assembledReadIdx.size());
       fclose(fp);
     }
