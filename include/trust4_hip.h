@@ -195,6 +195,10 @@ int t4_consensus_recompute(t4_index *ix, t4_batch *b, const t4_overlap *assign, 
  * 16-lane DPP row (status 2 for bands wider than 16 columns): the two formulations overlap scoring runs on the GPU. */
 int t4_gap_dp(t4_ctx *ctx, int kind, int impl, int n, const int64_t *t_off, const int64_t *p_off,
               const void *t_data, const char *p_chars, int32_t *out4);
+/* impl 4, kind 1: the scratch-row aligner with its traceback; `align` receives the edit string of every alignment (AlignAlgo.hpp:160-205: 0 match, 1 mismatch,
+ * 2 insert, 3 delete, terminated by -1; align_stride bytes per alignment, >= lent + lenp + 2) */
+int t4_gap_dp_align(t4_ctx *ctx, int kind, int impl, int n, const int64_t *t_off, const int64_t *p_off, const void *t_data,
+                    const char *p_chars, int32_t *out4, signed char *align, int align_stride);
 
 /* The query half of SeqSet::AddRead for a (small) batch of reads in ONE launch and one host round trip:
  * GetOverlapsFromRead(read, strands[i], barcode, 0, skip_repeats) (SeqSet.hpp:3437) and the ExtendOverlap

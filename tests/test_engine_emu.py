@@ -264,13 +264,22 @@ def make_dp_cases(seed, n, posweight):
 
 
 def check_gap_dp(eng, seed, n):
+    """The scoring kernels return what GetOverlapsFromRead reads of an alignment, the GetAlignStats counts (matches, mismatches,
+    indels) -- compared here for four formulations of both aligners. The EDIT STRING itself, which only ExtendOverlap reads (of the posWeight aligner, SeqSet.hpp:1203-1235), is
+    compared through impl 4 (the scratch-row aligner with its traceback). The affine aligner's string is never read on this path."""
     o = Oracle(9)
     for kind in (0, 1):
         T, P = make_dp_cases(seed + kind, n, kind == 1)
-        exp = []
+        exp, exp_al = [], []
         for t, p in zip(T, P):
             sc, al = o.global_alignment(t, p) if kind == 0 else o.global_alignment_posweight(t, p)
             exp.append((al.count(0), al.count(1), al.count(2) + al.count(3)))
+            exp_al.append(al)
+        if kind == 1:
+            got4, strings = eng.gap_dp(1, T, P, 4)
+            bad = [i for i in range(n) if got4[i, 3] == 0 and (strings[i] != exp_al[i] or tuple(got4[i, :3]) != exp[i])]
+            assert not bad, (bad[:5], [(exp_al[i], strings[i]) for i in bad[:2]])
+            assert (got4[:, 3] == 0).sum() > n * 9 // 10
         for impl in (0, 1, 2, 3):
             got = eng.gap_dp(kind, T, P, impl)
             wide = got[:, 3] == 2     # impl 2 / 3 only: band wider than one wavefront / one 16-lane row (the scorer falls back)

@@ -246,10 +246,8 @@ def test_wide_query_beyond_the_old_limits_gpu(monkeypatch):
     core = "".join(rnd.choice("ACGT") for _ in range(170))
     contigs = []
     for i in range(n_contigs):
-        s = list(core)
-        if i % 7 == 3:
-            s[rnd.randrange(len(s))] = rnd.choice("ACGT")
-        s = "".join(s)
+        s = core      # identical copies: a copy with a variant of its own that the read shares would hold `unique` hits (lists of a few
+        #               postings), switch on removeOnlyRepeats and leave the read with that copy alone (test_wide_query_lists_beyond_10000...)
         w = np.zeros((len(s), 4), dtype=np.int32)
         for j, ch in enumerate(s):
             w[j, "ACGT".index(ch)] = rnd.randint(1, 9)
@@ -265,4 +263,4 @@ def test_wide_query_beyond_the_old_limits_gpu(monkeypatch):
             assert len(h) > 262144, len(h)
     # both strands (strand argument 0); with it, each copy yields two groups
     cnt, n_wide = check_wide(eng, o, ix, reads, [0, 0, 0], [1.0, 2.0, 1.0], room=2 * n_contigs + 64)
-    assert cnt[0] > 16384 // 2 and n_wide == 3, (cnt.tolist(), n_wide)
+    assert cnt[0] > 16384 and n_wide == 3, (cnt.tolist(), n_wide)

@@ -71,6 +71,7 @@ def _load():
         "t4_hits": (I, [P, P, I, I, P, P, L]), "t4_overlaps": (I, [P, P, I, I, I, P, P]),
         "t4_annotate_rough": (I, [P, P, P]),
         "t4_gap_dp": (I, [P, I, I, I, P, P, P, P, P]),
+        "t4_gap_dp_align": (I, [P, I, I, I, P, P, P, P, P, P, I]),
         "t4_mate_overlap": (I, [P, I, P, P, P, P, P, I, P]), "t4_has_hit": (I, [P, P, I, P]),
         "t4_process_pairs": (I, [P, I, P, P, P, P, P, P, P, P, P, P, P]),
         "t4_extend": (I, [P, P, I, P, P, C.c_double, P, P]), "t4_assign": (I, [P, P, I, P, P]), "t4_assign_strands": (I, [P, P, P, P, P]),
@@ -140,6 +141,17 @@ class Engine:
         else:
             tbuf = np.ascontiguousarray(np.concatenate([np.asarray(t, dtype=np.int32).reshape(-1, 4) for t in targets] + [np.zeros((1, 4), np.int32)]))
         out = np.zeros((n, 4), dtype=np.int32)
+        if impl == 4:   # posWeight aligner with its traceback: the edit strings come back too (lists of 0 match / 1 mismatch / 2 insert / 3 delete)
+            stride = int(max(len(t) + len(p) for t, p in zip(targets, patterns))) + 2 if n else 2
+            al = np.zeros((n, stride), dtype=np.int8)
+            self.check(self.lib.t4_gap_dp_align(self.h, kind, impl, n, toff.ctypes.data_as(C.c_void_p), poff.ctypes.data_as(C.c_void_p),
+                                                tbuf.ctypes.data_as(C.c_void_p), pbuf.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
+                                                al.ctypes.data_as(C.c_void_p), stride))
+            strings = []
+            for row in al:
+                end = np.nonzero(row == -1)[0]
+                strings.append(row[: int(end[0])].tolist() if len(end) else None)
+            return out, strings
         self.check(self.lib.t4_gap_dp(self.h, kind, impl, n, toff.ctypes.data_as(C.c_void_p), poff.ctypes.data_as(C.c_void_p),
                                       tbuf.ctypes.data_as(C.c_void_p), pbuf.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)))
         return out

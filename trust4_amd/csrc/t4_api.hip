@@ -122,6 +122,7 @@ struct t4_ctx {
   bool wideInit = false;
   unsigned char *grpPoolHost = nullptr;   // pinned; T4Wide::grpPool is its device address
   int64_t wideReads = 0, wideParts = 0, wideRetries = 0, wideGroups = 0;
+  int wideRecentParts = 0, wideRecentReads = 0;   // the largest counts of the last calls, decayed: sizes the (persistent) grids of the next call's wide kernels
   double aqKernelMs = 0;    // HIP-event time of the query kernels of all AddRead query calls (per call: first launch .. last kernel)
   int64_t aqHits = 0;       // _hit records their seed stages emitted (H of SURVEY 8d)
 };
@@ -1084,9 +1085,17 @@ int t4_hits(t4_index *ix, t4_batch *b, int strand, int allow_total_skip, int64_t
 }
 
 
+int t4_gap_dp_align(t4_ctx *c, int kind, int impl, int n, const int64_t *t_off, const int64_t *p_off, const void *t_data,
+                    const char *p_chars, int32_t *out4, signed char *align, int align_stride);
 int t4_gap_dp(t4_ctx *c, int kind, int impl, int n, const int64_t *t_off, const int64_t *p_off, const void *t_data,
               const char *p_chars, int32_t *out4) {
+  return t4_gap_dp_align(c, kind, impl, n, t_off, p_off, t_data, p_chars, out4, nullptr, 0);
+}
+// the same; impl 4 with kind 1 also returns the edit string of every alignment (align_stride bytes each, terminated by -1)
+int t4_gap_dp_align(t4_ctx *c, int kind, int impl, int n, const int64_t *t_off, const int64_t *p_off, const void *t_data,
+                    const char *p_chars, int32_t *out4, signed char *align, int align_stride) {
   if (!c || n < 0 || (n > 0 && (!t_off || !p_off || !t_data || !p_chars || !out4)) || (kind != 0 && kind != 1)) return T4_ERR_ARG;
+  if (align && (align_stride < 2 || impl != 4 || kind != 1)) return T4_ERR_ARG;
   if (n == 0) return T4_OK;
   (void)hipSetDevice(c->device);
   int grid = (n + 63) / 64;
@@ -1110,11 +1119,14 @@ int t4_gap_dp(t4_ctx *c, int kind, int impl, int n, const int64_t *t_off, const 
   HIPCHK(c, hipMemcpy(dT, t_off, sizeof(long long) * ((size_t)n + 1), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(dP, p_off, sizeof(long long) * ((size_t)n + 1), hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(dPc, p_chars, pn, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(t4k::gapDpKernel, dim3(grid), dim3(64), 0, c->stream, kind, impl, n, dT, dP, dTc, dTw, dPc, dOut, c->dpRows, c->dpDir);
+  signed char *dAl = nullptr;
+  if (align) { if ((r = devAlloc(c, &dAl, (size_t)n * align_stride))) return r; HIPCHK(c, hipMemsetAsync(dAl, 0xFF, (size_t)n * align_stride, c->stream)); }
+  hipLaunchKernelGGL(t4k::gapDpKernel, dim3(grid), dim3(64), 0, c->stream, kind, impl, n, dT, dP, dTc, dTw, dPc, dOut, c->dpRows, c->dpDir, dAl, align_stride);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(out4, dOut, sizeof(int) * (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  if (align) HIPCHK(c, hipMemcpyAsync(align, dAl, (size_t)n * align_stride, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  void *ptrs[] = {dT, dP, dTc, dPc, dTw, dOut};
+  void *ptrs[] = {dT, dP, dTc, dPc, dTw, dOut, dAl};
   for (void *q : ptrs) if (q) (void)hipFree(q);
   return T4_OK;
 }
@@ -1686,11 +1698,15 @@ int aqLaunch(t4_ctx *c) {
     T4Wide w;
     memcpy(&w, c->aqInHost + q.oWide, sizeof w);
     const int cus = c->cus > 0 ? c->cus : 1;
-    hipLaunchKernelGGL(t4k::wideScatterKernel, dim3(cus * 4), dim3(256), 0, c->stream, q.base, w);
-    hipLaunchKernelGGL((t4k::wideSortKernel<8192>), dim3(cus * 2), dim3(512), 0, c->stream, q.base, w);
-    hipLaunchKernelGGL(t4k::wideStatsKernel, dim3(cus < 64 ? cus : 64), dim3(512), 0, c->stream, q.base, w);
-    hipLaunchKernelGGL((t4k::wideChainKernel<8192, 1 << T4_WIDE_OVBITS>), dim3(cus), dim3(512), 0, c->stream, q.base, bv, wk, qa, w);
-    hipLaunchKernelGGL(t4k::wideMergeKernel, dim3(cus < 64 ? cus : 64), dim3(512), 0, c->stream, q.base, bv, wk, qa, w);
+    // The grids are persistent (any size serves any number of reads / partitions); most rounds defer nothing, and an empty grid of
+    // several hundred 100 KB-LDS workgroups still takes microseconds to come and go -- so they are sized for what recent calls needed.
+    auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; };
+    const int gParts = clampi(2 * c->wideRecentParts + 4, 4, cus * 2), gReads = clampi(2 * c->wideRecentReads + 2, 2, cus < 64 ? cus : 64);
+    hipLaunchKernelGGL(t4k::wideScatterKernel, dim3(clampi(2 * gParts, 8, cus * 4)), dim3(256), 0, c->stream, q.base, w);
+    hipLaunchKernelGGL((t4k::wideSortKernel<8192>), dim3(gParts), dim3(512), 0, c->stream, q.base, w);
+    hipLaunchKernelGGL(t4k::wideStatsKernel, dim3(gReads), dim3(512), 0, c->stream, q.base, w);
+    hipLaunchKernelGGL((t4k::wideChainKernel<8192, 1 << T4_WIDE_OVBITS>), dim3(gParts < cus ? gParts : cus), dim3(512), 0, c->stream, q.base, bv, wk, qa, w);
+    hipLaunchKernelGGL(t4k::wideMergeKernel, dim3(gReads), dim3(512), 0, c->stream, q.base, bv, wk, qa, w);
     HIPCHK(c, hipGetLastError());
   }
   if (extendLater) {   // all records of the batch, spread over the chip
@@ -1793,6 +1809,8 @@ int aqEnd(t4_ctx *c, AqResult *res) {
         continue;
       }
       c->wideReads += ctl[0]; c->wideParts += ctl[1]; c->wideGroups += ctl[3];
+      c->wideRecentParts = ctl[1] > c->wideRecentParts ? ctl[1] : (c->wideRecentParts * 7 + ctl[1]) / 8;
+      c->wideRecentReads = ctl[0] > c->wideRecentReads ? ctl[0] : (c->wideRecentReads * 7 + ctl[0]) / 8;
     }
     const int *status = (const int *)(o + q.pSta);
     bool poolFull = false;

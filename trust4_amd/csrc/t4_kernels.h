@@ -4352,7 +4352,7 @@ __global__ __launch_bounds__(64) void processPairKernel(int n, const long long *
 // (what overlap scoring uses), impl 1: scratch + traceback version only. out: 3 ints per problem.
 __global__ __launch_bounds__(64) void gapDpKernel(int kind, int impl, int n, const long long *tOff, const long long *pOff,
                                                  const char *tChars, const T4PW *tW, const char *pChars, int *out,
-                                                 int *dpRows, unsigned char *dpDir) {
+                                                 int *dpRows, unsigned char *dpDir, signed char *alignOut, int alignStride) {
   __shared__ int s_slots[4 * T4_DPW * 64];   // 32 KiB
   __shared__ char s_p[64][T4_MAXGAP + 8];
   const int lane = laneId();
@@ -4409,8 +4409,10 @@ __global__ __launch_bounds__(64) void gapDpKernel(int kind, int impl, int n, con
         bool done = false;
         if (impl == 0) done = kind == 0 ? dpAffineFwd(tChars + tOff[i], lent, s_p[lane], lenp, s_slots + lane, 64, c0, c1, c2)
                                         : dpPosWeightFwd(tW + tOff[i], lent, s_p[lane], lenp, s_slots + lane, 64, c0, c1, c2);
+        // impl 4 (posWeight aligner only): the traceback's edit string itself (AlignAlgo.hpp:160-205; what ExtendOverlap reads) goes out too
+        signed char *al = (impl == 4 && kind == 1 && alignOut && lent + lenp + 2 <= alignStride) ? alignOut + (size_t)i * alignStride : (signed char *)0;
         if (!done) ok = kind == 0 ? dpAffine(tChars + tOff[i], lent, s_p[lane], lenp, sc, lane, c0, c1, c2)
-                                  : dpPosWeight(tW + tOff[i], lent, s_p[lane], lenp, sc, lane, c0, c1, c2, (signed char *)0);
+                                  : dpPosWeight(tW + tOff[i], lent, s_p[lane], lenp, sc, lane, c0, c1, c2, al);
       }
       out[4 * i] = c0; out[4 * i + 1] = c1; out[4 * i + 2] = c2; out[4 * i + 3] = ok ? 0 : 1;
     }

@@ -93,19 +93,41 @@ __global__ __launch_bounds__(256) void wideScatterKernel(T4IndexView ix, T4Wide 
     __syncthreads();
     for (unsigned chunk = blockIdx.x; chunk < nChunks; chunk += gridDim.x) {
       const unsigned end = (chunk + 1u) * CH < pl.H ? (chunk + 1u) * CH : pl.H;
-      for (unsigned s = chunk * CH + (unsigned)lane; s < end; s += (unsigned)NT) {
-        int lo = 0, hi = nq - 1;   // last q with pref[q] <= s
-        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pref[mid] <= s) lo = mid; else hi = mid - 1; }
-        const int q = lo;
-        const int2 po = ix.post[s_start[q] + (s - s_pref[q])];
-        const int st = q >= pl.nk, a = st ? q - pl.nk : q;
-        const unsigned long long key = ((st ? 0ull : 1ull) << 63) | ((unsigned long long)po.x << (T4_C_BITS + T4_B_BITS)) |
-                                       ((unsigned long long)(a - po.y + T4_C_BIAS) << T4_B_BITS) | (unsigned long long)po.y;
-        int p = po.x / pl.Wd;
-        if (p >= pl.P) p = pl.P - 1;
-        const unsigned at = atomicAdd(&wd.pCnt[pl.pBase + p], 1u);
-        if (at < (unsigned)wd.pcap) wd.pKeys[(size_t)(pl.pBase + p) * wd.pcap + at] = key;
-        else atomicOr(&wd.ctl[2], 4);
+      for (unsigned s0 = chunk * CH; s0 < end; s0 += (unsigned)NT) {   // (uniform trip count: the wave-wide votes below need every lane)
+        const unsigned s = s0 + (unsigned)lane;
+        const bool has = s < end;
+        unsigned long long key = 0;
+        int p = -1;
+        if (has) {
+          int lo = 0, hi = nq - 1;   // last q with pref[q] <= s
+          while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pref[mid] <= s) lo = mid; else hi = mid - 1; }
+          const int q = lo;
+          const int2 po = ix.post[s_start[q] + (s - s_pref[q])];
+          const int st = q >= pl.nk, a = st ? q - pl.nk : q;
+          key = ((st ? 0ull : 1ull) << 63) | ((unsigned long long)po.x << (T4_C_BITS + T4_B_BITS)) |
+                ((unsigned long long)(a - po.y + T4_C_BIAS) << T4_B_BITS) | (unsigned long long)po.y;
+          p = po.x / pl.Wd;
+          if (p >= pl.P) p = pl.P - 1;
+        }
+        // One atomic per (wavefront, partition) instead of one per posting: consecutive postings of a list belong to neighbouring
+        // contigs, i.e. mostly to one partition -- 4096 lanes adding to a handful of counters one by one was the whole kernel
+        // (77 us per launch, profiles/r04b_*).
+        const int wl = lane & 63;
+        unsigned long long todo = __ballot(has);
+        while (todo) {
+          const int leader = __ffsll(todo) - 1;
+          const int p0 = __shfl(p, leader);
+          const unsigned long long same = __ballot(has && p == p0);
+          unsigned base = 0;
+          if (wl == leader) base = atomicAdd(&wd.pCnt[pl.pBase + p0], (unsigned)__popcll(same));
+          base = __shfl(base, leader);
+          if (has && p == p0) {
+            const unsigned at = base + (unsigned)__popcll(same & ((1ull << wl) - 1ull));
+            if (at < (unsigned)wd.pcap) wd.pKeys[(size_t)(pl.pBase + p0) * wd.pcap + at] = key;
+            else atomicOr(&wd.ctl[2], 4);
+          }
+          todo &= ~same;
+        }
       }
     }
   }
