@@ -68,7 +68,8 @@ struct AqCall {
   int n = 0, skipRepeats = 0, wpk = 0, wnm = 0, attempt = 0, nFirst = 0, nDirect = 0, threads = 512;
   unsigned char *tierHint = nullptr;
   std::vector<unsigned char> allGlobal;
-  size_t oPk, oNm, oLen, oBc, oSt, oLs, oVw, oFa, oWide, inBytes, pCnt, pSta, pNext, pNext2, pBase, pTick, pStab, pTail, pWctl, pWplan, pWstat, outBytes;
+  size_t oPk, oNm, oLen, oBc, oSt, oLs, oVw, oFa, oOnly, oWide, inBytes, pCnt, pSta, pNext, pNext2, pBase, pTick, pStab, pAux, pN4, pTail, pWctl, pWplan, pWstat, outBytes;
+  bool hasOnly = false;
   bool extendLater = false, wide = false;
   int wideSafety = 32;   // of sixteenths: partitions are planned for half of their capacity
   T4BatchView bv; T4QueryArgs qa; T4Work wk;
@@ -1513,7 +1514,7 @@ struct AqResult { const int32_t *counts, *base; const t4_overlap *ov, *ext; cons
 int aqLaunch(t4_ctx *c);
 int aqBegin(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const int32_t *viewOf, bool smallFirst, int n, const char *bases,
             const int64_t *offsets, const int32_t *barcodes, const int32_t *strands, int skip_repeats, const double *factors,
-            unsigned char *tierHint = nullptr, bool lean = false) {
+            unsigned char *tierHint = nullptr, bool lean = false, const int32_t *onlySeq = nullptr) {
   (void)hipSetDevice(c->device);
   AqCall &q = c->aq;
   if (q.active) return fail(c, T4_ERR_STATE, "an AddRead query is already in flight on this ctx");
@@ -1532,11 +1533,13 @@ int aqBegin(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const 
   auto al8 = [](size_t x) { return (x + 7) & ~(size_t)7; };
   q.oPk = 0; q.oNm = al8(q.oPk + sizeof(unsigned) * (size_t)n * wpk); q.oLen = al8(q.oNm + sizeof(unsigned) * (size_t)n * wnm);
   q.oBc = al8(q.oLen + sizeof(int) * (size_t)n); q.oSt = al8(q.oBc + sizeof(int) * (size_t)n); q.oLs = al8(q.oSt + sizeof(int) * (size_t)n);
-  q.oVw = al8(q.oLs + sizeof(int) * (size_t)n); q.oFa = al8(q.oVw + sizeof(int) * (size_t)n); q.oWide = al8(q.oFa + sizeof(double) * (size_t)n);
+  q.oVw = al8(q.oLs + sizeof(int) * (size_t)n); q.oFa = al8(q.oVw + sizeof(int) * (size_t)n); q.oOnly = al8(q.oFa + sizeof(double) * (size_t)n);
+  q.oWide = al8(q.oOnly + sizeof(int) * (size_t)n); q.hasOnly = onlySeq != nullptr;
   q.inBytes = al8(q.oWide + sizeof(T4Wide));
   q.pCnt = 0; q.pSta = al8(q.pCnt + sizeof(int) * (size_t)n); q.pNext = al8(q.pSta + sizeof(int) * (size_t)n);
   q.pNext2 = al8(q.pNext + sizeof(int) * (size_t)n); q.pBase = al8(q.pNext2 + sizeof(int) * (size_t)n);
-  q.pTick = al8(q.pBase + sizeof(int) * (size_t)n); q.pStab = al8(q.pTick + sizeof(int) * (size_t)n); q.pTail = al8(q.pStab + sizeof(int) * (size_t)n);
+  q.pTick = al8(q.pBase + sizeof(int) * (size_t)n); q.pStab = al8(q.pTick + sizeof(int) * (size_t)n); q.pAux = al8(q.pStab + sizeof(int) * (size_t)n);
+  q.pN4 = al8(q.pAux + sizeof(int) * (size_t)n); q.pTail = al8(q.pN4 + sizeof(int) * (size_t)n);
   q.pWctl = q.pTail + 32; q.pWplan = q.pWctl + 32; q.pWstat = al8(q.pWplan + sizeof(T4WidePlan) * (size_t)n); q.outBytes = al8(q.pWstat + sizeof(int) * T4_WIDE_STAT * (size_t)n);
   q.wideSafety = 32;
   if (q.inBytes > c->aqInBytes) {
@@ -1567,6 +1570,7 @@ int aqBegin(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const 
     const char *s = bases + offsets[i];
     int l = (int)(offsets[i + 1] - offsets[i]);
     len[i] = l; bc[i] = barcodes ? barcodes[i] : -1; st[i] = strands[i]; fa[i] = factors[i]; vw[i] = viewOf ? viewOf[i] : 0;
+    ((int *)(h + q.oOnly))[i] = onlySeq ? onlySeq[i] : -1;
     unsigned *p = pk + (size_t)i * wpk, *qn = nm + (size_t)i * wnm;
     for (int j = 0; j < l; ++j) {
       int v = nucNum(s[j]);
@@ -1630,6 +1634,8 @@ int aqLaunch(t4_ctx *c) {
   qa.strandPerRead = (const int *)(c->aqIn + q.oSt); qa.factorPerRead = (const double *)(c->aqIn + q.oFa);
   qa.readTicks = (int *)(c->aqOut + q.pTick);
   qa.statsStable = (int *)(c->aqOut + q.pStab);
+  qa.aux = (int *)(c->aqOut + q.pAux); qa.n4 = (int *)(c->aqOut + q.pN4);
+  if (q.hasOnly) qa.onlySeq = (const int *)(c->aqIn + q.oOnly);
   qa.leanExt = q.lean ? 1 : 0;
   if (q.views) { qa.views = q.views; qa.viewOf = (const int *)(c->aqIn + q.oVw); }
   // one big set: the ExtendOverlap calls of reads with more than this many overlaps run in their own launch (0: never)
@@ -1816,6 +1822,7 @@ int aqEnd(t4_ctx *c, AqResult *res) {
     bool poolFull = false;
     for (int i = 0; i < n; ++i) {
       if (status[i] == 3) poolFull = true;
+      else if (status[i] == 5) continue;   // a restricted re-query that one workgroup's arrays could not hold: reported to the caller (t4_add_query_last_aux)
       else if (status[i]) return fail(c, T4_ERR_UNSUPPORTED, "read %d exceeds the engine limits (status %d: %s)", i, status[i],
                                       status[i] == 2 ? "more k-mer hits or overlaps than the global tier holds" : "gap DP or contig count beyond scratch");
     }
@@ -1912,6 +1919,18 @@ int t4_add_query_groups(t4_ctx *c, int i, const t4_grp **groups, int *n, int *hu
   return 0;
 }
 
+// per read of the last finished AddRead query call on this ctx (n entries, valid until the next call): aux and n4 as T4QueryArgs
+// describes them, status (5: a restricted re-query that did not fit -- ask for the whole query)
+int t4_add_query_last_aux(t4_ctx *c, const int32_t **aux, const int32_t **n4, const int32_t **status, int *n) {
+  if (!c || !c->aqOutHost) return T4_ERR_ARG;
+  const AqCall &q = c->aq;
+  if (aux) *aux = (const int32_t *)(c->aqOutHost + q.pAux);
+  if (n4) *n4 = (const int32_t *)(c->aqOutHost + q.pN4);
+  if (status) *status = (const int32_t *)(c->aqOutHost + q.pSta);
+  if (n) *n = q.n;
+  return T4_OK;
+}
+
 // wide query of this ctx, 4 values: reads it served, partitions, calls repeated with larger pools, dependency records
 int t4_add_query_wide_stats(t4_ctx *c, int64_t *out4) {
   if (!c || !out4) return T4_ERR_ARG;
@@ -1944,13 +1963,13 @@ int t4_add_query_pool(t4_index *ix, int n, const char *bases, const int64_t *off
 // The two halves of t4_add_query_pool: begin enqueues the call on ix's ctx and returns; the host goes on; end waits and hands the
 // result out (same lifetime rules). tier_hint must stay alive until end. One call in flight per ctx.
 int t4_add_query_pool_begin(t4_index *ix, int n, const char *bases, const int64_t *offsets, const int32_t *barcodes, const int32_t *strands,
-                            int skip_repeats, const double *factors, unsigned char *tier_hint) {
+                            int skip_repeats, const double *factors, unsigned char *tier_hint, const int32_t *only_seq) {
   if (!ix || n <= 0 || !bases || !offsets || !strands || !factors) return T4_ERR_ARG;
   t4_ctx *c = ix->ctx;
   if (!ix->committed) return fail(c, T4_ERR_STATE, "index not committed");
   if (ix->view.firstIsRef) return fail(c, T4_ERR_UNSUPPORTED, "t4_add_query needs a contig set");
   static const bool leanOff = getenv("T4_LEAN_OFF") != nullptr;   // testing aid: exact ExtendOverlap records for the builder too
-  return aqBegin(c, ix->view, nullptr, nullptr, false, n, bases, offsets, barcodes, strands, skip_repeats, factors, tier_hint, !leanOff);   // for t4_assembler: lean records (extendOverlaps)
+  return aqBegin(c, ix->view, nullptr, nullptr, false, n, bases, offsets, barcodes, strands, skip_repeats, factors, tier_hint, !leanOff, only_seq);   // for t4_assembler: lean records (extendOverlaps)
 }
 int t4_add_query_pool_done(t4_ctx *c) { return c ? aqDone(c) : 1; }
 int t4_add_query_pool_end(t4_ctx *c, const int32_t **counts, const int32_t **base, const t4_overlap **ov, const t4_overlap **ext, const int32_t **ext_ret) {

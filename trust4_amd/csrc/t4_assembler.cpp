@@ -31,6 +31,7 @@
 #include <memory>
 #include <string>
 #include <unordered_map>
+#include <tuple>
 #include <vector>
 
 #include "../../include/trust4_hip.h"
@@ -515,12 +516,23 @@ struct t4_assembler : IndexListener {
       return groups.find(key);
     }
     Grp &getGroup(uint32_t key) { Grp *g = findGroup(key); return g ? *g : groups.get(key); }
+    // ---- restricted re-query. The full query left: nAll overlaps on the strand of the best one before the similarity
+    // cut, nOther on the other strand, that strand, n4 groups of four or more hits. While no overlap exists on the other strand,
+    // at most 50 on the best one's (the order-dependent pre-filters of SeqSet.hpp:1705-1794 stay off) and at most 100 groups of four
+    // hits (novelMinHitRequired stays 3, SeqSet.hpp:813-823), what the read's result takes from one contig is independent of every
+    // other contig: a commit that touches contig c of such an entry leaves the entry PARTIAL -- it keeps its records of the other
+    // contigs -- and only the overlaps with c are asked for again (t4_add_query_pool_begin, only_seq).
+    int nAll = 0, nOther = 0, n4 = 0, nAllBound = 0, restrictedCount = 0;
+    bool strand0Plus = false, auxOk = false;
+    bool partial = false, merged = false;
+    int pendingContig = -1;
+    std::vector<std::pair<uint64_t, int>> kmerPos;   // the read's k-mers of both strands, (code, position << 1 | plus), sorted by code (built on first use)
     // a (re-)query of this entry is running on a lane: commits since its launch are examined against its dependency sets like
     // those of an entry that holds a result; `killed` = one of them invalidated it (the result is dropped when it arrives),
     // `shifts` = left extensions of contigs it meets, to be applied to the records when they arrive
     bool inflight = false, killed = false;
     std::vector<std::pair<int, int>> shifts;
-    bool standing() const { return valid || (inflight && !killed); }
+    bool standing() const { return valid || partial || (inflight && !killed); }
   };
   std::vector<Cached> cache;
   size_t cacheHead = 0;
@@ -578,6 +590,12 @@ struct t4_assembler : IndexListener {
   bool liveReset = true;           // the next delta describes the whole image (first upload, k change)
   int64_t toleratedStable = 0, invLongLists = 0, slowSkipped = 0;
   int64_t wideServed = 0, wideGroupRecords = 0, wideMispredicted = 0;
+  int64_t restrictedMarks = 0, restrictedMerged = 0, restrictedFallbacks = 0, restrictedStale = 0;
+  bool restrictOn = true;
+  bool eligibleForRestricted(const Cached &e) const {
+    return restrictOn && e.valid && e.auxOk && !e.skip && e.barcode == -1 && !e.hasDev && !e.expectWide && !e.fragile && e.nOther == 0 && e.nAllBound <= 44 && e.n4 + 2 * e.restrictedCount + 2 <= 100;
+  }
+  void rebuildGroup(Cached &e, int c);
   bool wideQueries = true; int wideHitLimit = 8192;   // what t4_add_query_pool_begin will do with a read of that many emitted hits (set in ensureLanes)
   int emittedHits(const Cached &e);
   int64_t deltas = 0, deltaBytes = 0, rounds = 0, readsQueried = 0, invKey = 0, invCross = 0, invRegion = 0, invShift = 0, invContig = 0, invFragile = 0, tolerated = 0;
@@ -592,7 +610,7 @@ struct t4_assembler : IndexListener {
   void dropWindow() {
     cache.clear(); cacheHead = 0;
     abandonJobs();
-    for (int s : order) { pool[s]->valid = false; pool[s]->inflight = false; pool[s]->uid = 0; freeSlots.push_back(s); }
+    for (int s : order) { pool[s]->valid = false; pool[s]->partial = false; pool[s]->inflight = false; pool[s]->uid = 0; freeSlots.push_back(s); }
     order.clear(); winKmers.clear(); winKmerRefs = winKmerLive = 0;
     idxEvents.clear(); structEvents.clear();
   }
@@ -673,7 +691,7 @@ struct t4_assembler : IndexListener {
     bool busy = false;
     int polls = 0;
     std::vector<int> slots; std::vector<int64_t> uids; std::vector<unsigned char> hint;
-    std::string bases; std::vector<int64_t> offs; std::vector<int32_t> bcs, sts; std::vector<double> fac;
+    std::string bases; std::vector<int64_t> offs; std::vector<int32_t> bcs, sts, only; std::vector<double> fac;
     int repetitive = 0;
   };
   std::vector<Lane> lanes;
@@ -691,7 +709,7 @@ struct t4_assembler : IndexListener {
   int pumpLive(bool needHead, int repetitive);
   void announceLive(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive);
   int verifyServed(const Cached &c);
-  int64_t verified = 0;
+  int64_t verified = 0, verifiedMerged = 0;
   void beginWindow(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive);
   void endWindow(const int32_t *cnts, const t4_overlap *ov, const t4_overlap *ex, const int32_t *rets, int stride);
   int stageImage();   // cell mode: queue this cell's image in the owner's arena
@@ -856,7 +874,7 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
     if (verifyWindow) { const int rc = verifyServed(c); if (rc) return -100 + rc; }
     cnt = c.cnt; ovBuf.swap(c.ov); extBuf.swap(c.ext); extRet.swap(c.extRet);
     order.pop_front();
-    c.valid = false; c.uid = 0; freeSlots.push_back(sl);   // its winKmers references are stale from here on
+    c.valid = false; c.partial = false; c.uid = 0; freeSlots.push_back(sl);   // its winKmers references are stale from here on
     if (c.registered) { --winKmerLive; c.registered = false; }
   } else {
     bool served = false;
@@ -1377,8 +1395,19 @@ int t4_assembler::verifyServed(const Cached &c) {
     return a.seqIdx == b.seqIdx && a.readStart == b.readStart && a.readEnd == b.readEnd && a.seqStart == b.seqStart && a.seqEnd == b.seqEnd &&
            a.strand == b.strand && a.matchCnt == b.matchCnt && a.indelCnt == b.indelCnt && a.similarity == b.similarity;
   };
-  bool ok = cnts[0] == c.cnt;
   const int n = c.cnt > 0 ? c.cnt : 0;
+  bool ok = c.merged ? (cnts[0] > 0 ? cnts[0] : 0) == n : cnts[0] == c.cnt;
+  if (ok && c.merged) {
+    // an entry that was put together from restricted re-queries holds the records of the fresh query in another order (SeqSet::AddRead
+    // sorts them itself, SeqSet.hpp:3474): compared as sets
+    std::vector<int> pa(n), pb(n);
+    for (int i = 0; i < n; ++i) pa[i] = pb[i] = i;
+    auto key = [](const t4_overlap &o) { return std::make_tuple(o.seqIdx, o.strand, o.readStart, o.readEnd, o.seqStart, o.seqEnd); };
+    std::sort(pa.begin(), pa.end(), [&](int x, int y) { return key(c.ov[x]) < key(c.ov[y]); });
+    std::sort(pb.begin(), pb.end(), [&](int x, int y) { return key(ov[bas[0] + x]) < key(ov[bas[0] + y]); });
+    for (int i = 0; ok && i < n; ++i) ok = same(ov[bas[0] + pb[i]], c.ov[pa[i]]) && same(ex[bas[0] + pb[i]], c.ext[pa[i]]) && rets[bas[0] + pb[i]] == c.extRet[pa[i]];
+    if (ok) { ++verifiedMerged; return T4_OK; }
+  }
   for (int i = 0; ok && i < n; ++i) ok = same(ov[bas[0] + i], c.ov[i]) && same(ex[bas[0] + i], c.ext[i]) && rets[bas[0] + i] == c.extRet[i];
   if (ok) return T4_OK;
   fprintf(stderr, "T4_VERIFY_WINDOW: the cached query of a served read differs from a fresh one (entry %lld, read %s, strand %d): cached %d overlaps, fresh %d\n",
@@ -1421,6 +1450,54 @@ void t4_assembler::registerKmers(Cached &e, int slotId) {
   }
   ++winKmerLive;
   e.registered = true;
+}
+
+// The dependency record of ONE contig for a window entry, after a restricted re-query: hits of the read's k-mers with every
+// k-mer of the contig's consensus (a superset of the contig's postings: KmerIndex::BuildIndexFromRead leaves repeated k-mers out)
+// per strand, and the hull of the diagonals with three or more of them -- what buildGroups derives from the posting lists.
+void t4_assembler::rebuildGroup(Cached &e, int c) {
+  const int len = (int)e.read.size();
+  if (e.kmerPos.empty() && len >= k) {
+    std::string rcs;
+    reverseComplement(rcs, e.read);
+    for (int st = 0; st < 2; ++st) {
+      const std::string &r = st ? rcs : e.read;
+      KCode kc(k);
+      for (int i = 0; i < len; ++i) {
+        kc.append(r[i]);
+        if (i < k - 1 || !kc.valid()) continue;
+        e.kmerPos.push_back({kc.code, ((i - k + 1) << 1) | (st ? 0 : 1)});
+      }
+    }
+    std::sort(e.kmerPos.begin(), e.kmerPos.end());
+  }
+  for (uint32_t plus = 0; plus < 2; ++plus) { Grp *g = e.findGroup((uint32_t)c * 2u + plus); if (g) { g->cnt = 0; g->lo = 0x7FFFFFFF; g->hi = -0x7FFFFFFF; } }
+  if (c < 0 || c >= (int)seqs.size() || seqs[c].released) return;
+  const std::string &cons = seqs[c].cons;
+  static thread_local std::vector<int64_t> diag;   // (plus << 40) | (start of the read on the contig + 2^30), one per hit
+  diag.clear();
+  KCode kc(k);
+  for (int i = 0; i < (int)cons.size(); ++i) {
+    kc.append(cons[i]);
+    if (i < k - 1 || !kc.valid()) continue;
+    const int off = i - k + 1;
+    auto it = std::lower_bound(e.kmerPos.begin(), e.kmerPos.end(), std::make_pair(kc.code, 0));
+    for (; it != e.kmerPos.end() && it->first == kc.code; ++it) diag.push_back(((int64_t)(it->second & 1) << 40) | (int64_t)(off - (it->second >> 1) + (1 << 30)));
+  }
+  std::sort(diag.begin(), diag.end());
+  for (size_t i = 0; i < diag.size();) {
+    size_t j = i + 1;
+    while (j < diag.size() && diag[j] == diag[i]) ++j;
+    const uint32_t plus = (uint32_t)(diag[i] >> 40);
+    Grp &g = e.getGroup((uint32_t)c * 2u + plus);
+    g.cnt += (uint32_t)(j - i);
+    if (j - i >= 3) {
+      const int at = (int)(diag[i] & ((1ll << 40) - 1)) - (1 << 30);
+      if (at < g.lo) g.lo = at;
+      if (at + len - 1 > g.hi) g.hi = at + len - 1;
+    }
+    i = j;
+  }
 }
 
 // _hit records GetHitsFromRead (SeqSet.hpp:1341-1501, allowTotalSkip false) emits for the entry's read against the current index:
@@ -1530,9 +1607,21 @@ void t4_assembler::processEvents() {
   struct Tm { double &acc; std::chrono::steady_clock::time_point t0; ~Tm() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tm_{secEvents, t0_};
   // (an entry whose query is still running is examined like one that holds a result: its dependency sets were derived at launch,
   // from the state its lane's replica holds)
+  // the whole result of the entry falls
   auto kill = [&](Cached &e, int64_t &why) {
+    if (e.partial) { e.partial = false; e.pendingContig = -1; if (e.inflight) e.killed = true; ++invalidations; ++why; return; }
     if (e.valid) { e.valid = false; ++invalidations; ++why; }
     else if (e.inflight && !e.killed) { e.killed = true; ++invalidations; ++why; }
+  };
+  // what the entry's result takes from contig c falls: when the entry qualifies (Cached: restricted re-query) it keeps the rest
+  auto touch = [&](Cached &e, int c, int64_t &why) {
+    if (e.partial) {
+      if (c != e.pendingContig) { kill(e, why); return; }
+      if (e.inflight && !e.killed) { e.killed = true; ++restrictedStale; }   // the restricted query on its way saw the contig before this change
+      return;
+    }
+    if (eligibleForRestricted(e)) { e.valid = false; e.partial = true; e.pendingContig = c; ++invalidations; ++why; ++restrictedMarks; return; }
+    kill(e, why);
   };
   // structural events, in the order they happened
   for (const StructEv &ev : structEvents) {
@@ -1540,6 +1629,10 @@ void t4_assembler::processEvents() {
       Cached &e = *pool[sl];
       if (!e.standing()) continue;
       if (e.inflight && e.expectWide && !e.hasDev) { kill(e, invContig); continue; }   // its dependency records are still on their way: nothing to examine the change against
+      if (e.partial && e.pendingContig == ev.c) {   // (its records and its group of this contig are stale already: any change of it counts)
+        if (ev.kind == 2) kill(e, invContig); else touch(e, ev.c, ev.kind == 0 ? invRegion : invShift);
+        continue;
+      }
       const int margin = radius + 2;
       for (uint32_t plus = 0; plus < 2; ++plus) {
         Grp *g = e.findGroup((uint32_t)ev.c * 2u + plus);
@@ -1547,13 +1640,15 @@ void t4_assembler::processEvents() {
         if (ev.kind == 2) { kill(e, invContig); break; }
         if (g->lo > g->hi) continue;   // no diagonal with three hits: nothing of the contig is read
         if (ev.kind == 0) {
-          if (ev.a <= g->hi + margin && ev.b > g->lo - margin) { kill(e, invRegion); break; }
+          if (ev.a <= g->hi + margin && ev.b > g->lo - margin) { touch(e, ev.c, invRegion); break; }
         } else {   // shift: the old columns 0 and 1 changed and the left end moved away
-          if (g->lo - margin < 2) { kill(e, invShift); break; }
+          if (g->lo - margin < 2) { touch(e, ev.c, invShift); break; }
           g->lo += ev.a; g->hi += ev.a;
         }
       }
-      if (ev.kind == 1 && e.valid) {
+      if (ev.kind == 1 && e.partial && e.pendingContig == ev.c) {
+        // (the contig's other-strand group, if the loop stopped at the first: its hull moves all the same -- it is rebuilt with the re-query)
+      } else if (ev.kind == 1 && (e.valid || e.partial)) {
         for (t4_overlap &o : e.ov) if (o.seqIdx == ev.c) { o.seqStart += ev.a; o.seqEnd += ev.a; }
         for (t4_overlap &o : e.ext) if (o.seqIdx == ev.c) { o.seqStart += ev.a; o.seqEnd += ev.a; }
       } else if (ev.kind == 1 && e.standing()) e.shifts.push_back({ev.c, ev.a});   // its records are still to come
@@ -1621,16 +1716,17 @@ void t4_assembler::processEvents() {
         if (e.uid != o.uid || !e.standing()) continue;
         if (e.inflight && e.expectWide && !e.hasDev) { kill(e, invKey); continue; }
         if (e.fragile) { kill(e, invFragile); ++invLongLists; continue; }
+        if (e.partial && e.pendingContig == ev.idx) { touch(e, ev.idx, invKey); continue; }
         for (uint32_t plus = 0; plus < 2 && e.standing(); ++plus) {
           const int n = (plus ? o.f : o.r) * (ev.delta > 0 ? ev.delta : -ev.delta);
           if (!n) continue;
           if (ev.delta > 0) {
             Grp &g = e.getGroup((uint32_t)ev.idx * 2u + plus);
             g.cnt += (uint32_t)n;
-            if (g.cnt >= 3) { kill(e, invKey); break; }
+            if (g.cnt >= 3) { touch(e, ev.idx, invKey); break; }
           } else {
             Grp *g = e.findGroup((uint32_t)ev.idx * 2u + plus);
-            if (g && g->cnt >= 3) { kill(e, invKey); break; }
+            if (g && g->cnt >= 3) { touch(e, ev.idx, invKey); break; }
             if (g && !e.hasDev) g->cnt = g->cnt > (uint32_t)n ? g->cnt - (uint32_t)n : 0;   // (device records count emitted hits: see Cached::devGroups)
           }
           ++tolerated;
@@ -1654,7 +1750,7 @@ void t4_assembler::announceLive(int n, const char *const *reads, const int *stra
   }
   while (order.size() > keep && keep < (size_t)n) {   // (entries beyond the announced ones stay when every announced read lined up)
     const int sl = order.back(); order.pop_back();
-    pool[sl]->valid = false; pool[sl]->inflight = false; pool[sl]->uid = 0; freeSlots.push_back(sl);   // a running query of it is ignored when it returns (uid)
+    pool[sl]->valid = false; pool[sl]->partial = false; pool[sl]->inflight = false; pool[sl]->uid = 0; freeSlots.push_back(sl);   // a running query of it is ignored when it returns (uid)
     if (pool[sl]->registered) { --winKmerLive; pool[sl]->registered = false; }
   }
   if (winKmerRefs > 64 * 284 && winKmerRefs > 4 * (winKmerLive + 1) * 284) {   // mostly references of retired entries: rebuild
@@ -1671,6 +1767,7 @@ void t4_assembler::announceLive(int n, const char *const *reads, const int *stra
     c.ov.clear(); c.ext.clear(); c.extRet.clear();
     c.uid = nextUid++; c.tier = 0; c.lastUs = 0; c.registered = false;
     c.hasDev = false; c.expectWide = false; c.devGroups.clear();
+    c.partial = false; c.pendingContig = -1; c.merged = false; c.auxOk = false; c.restrictedCount = 0; c.kmerPos.clear();
     order.push_back(sl);
   }
 }
@@ -1689,20 +1786,25 @@ int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive
     const int lim = getenv("T4_AQ_CAP_LIMIT") ? atoi(getenv("T4_AQ_CAP_LIMIT")) : 0;
     wideHitLimit = lim > 0 && lim < 8192 ? lim : 8192;
   }
-  L.slots = todo; L.uids.resize(m); L.hint.resize(m); L.bcs.resize(m); L.sts.resize(m); L.fac.resize(m);
+  L.slots = todo; L.uids.resize(m); L.hint.resize(m); L.bcs.resize(m); L.sts.resize(m); L.fac.resize(m); L.only.resize(m);
   L.bases.clear(); L.offs.assign(1, 0); L.repetitive = repetitive;
+  bool anyOnly = false;
   for (int i = 0; i < m; ++i) {
     Cached &c = *pool[todo[i]];
     L.uids[i] = c.uid; L.hint[i] = c.tier;
     L.bases += c.read; L.offs.push_back((int64_t)L.bases.size()); L.bcs[i] = c.barcode; L.sts[i] = c.strand;
     L.fac[i] = (c.barcode == -1 && !repetitive) ? 1.0 : 2.0;   // ExtendOverlap's mismatch factor (SeqSet.hpp:3597-3598)
-    c.inflight = true; c.killed = false; c.shifts.clear(); c.statsStable = false;
+    c.inflight = true; c.killed = false; c.shifts.clear();
+    L.only[i] = c.partial ? c.pendingContig : -1;
+    if (c.partial) { anyOnly = true; continue; }   // restricted re-query: the entry keeps what it holds of the other contigs
+    c.statsStable = false;
     c.hasDev = false; c.expectWide = false; c.devGroups.clear();
+    c.auxOk = false; c.merged = false; c.restrictedCount = 0;
   }
   if (L.bases.empty()) L.bases.push_back('A');
   {
     auto tq0 = std::chrono::steady_clock::now();
-    rc = t4_add_query_pool_begin(L.dev, m, L.bases.data(), L.offs.data(), L.bcs.data(), L.sts.data(), repetitive, L.fac.data(), L.hint.data());
+    rc = t4_add_query_pool_begin(L.dev, m, L.bases.data(), L.offs.data(), L.bcs.data(), L.sts.data(), repetitive, L.fac.data(), L.hint.data(), anyOnly ? L.only.data() : nullptr);
     secQuery += std::chrono::duration<double>(std::chrono::steady_clock::now() - tq0).count();
   }
   if (rc) { for (int sl : todo) pool[sl]->inflight = false; return rc; }
@@ -1714,6 +1816,7 @@ int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive
   auto tg1 = std::chrono::steady_clock::now();
   std::atomic<int> nextG(0);
   std::atomic<bool> regTaken(false);
+  restrictOn = !getenv("T4_RESTRICT_OFF");   // testing / A-B aid: every invalidated entry is queried again in full
   const auto registerNew = [&]() { for (int sl : todo) if (!pool[sl]->registered) registerKmers(*pool[sl], sl); };
   const std::function<void()> groupWorker = [&]() {
     if (!regTaken.exchange(true)) registerNew();
@@ -1721,6 +1824,7 @@ int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive
       int i = nextG.fetch_add(1);
       if (i >= m) break;
       Cached &e = *pool[todo[i]];
+      if (e.partial) continue;   // (its group of the one contig is rebuilt when the records arrive)
       // a read whose emitted hits outgrow the LDS tier is served by the wide query, which returns its dependency records itself
       // (deriving them here would cost several times the query: every posting of every k-mer, the ones the repeat-skip rule passes over included)
       if (wideQueries && !repetitive && e.barcode == -1 && emittedHits(e) > wideHitLimit) { e.expectWide = true; e.groups.reset(16); e.slack = -1; e.fragile = true; }
@@ -1770,10 +1874,38 @@ int t4_assembler::harvest(Lane &L) {
   const int32_t *stable = nullptr; int nStable = 0;
   static const bool noStable = getenv("T4_NO_STABLE_STATS") != nullptr;   // A/B aid: the slack rule for every entry, as before round 3
   if (!noStable) (void)t4_add_query_last_stable(L.ctx, &stable, &nStable);
+  const int32_t *aux = nullptr, *n4s = nullptr, *qstatus = nullptr; int nAux = 0;
+  (void)t4_add_query_last_aux(L.ctx, &aux, &n4s, &qstatus, &nAux);
   for (int i = 0; i < m; ++i) {
     Cached &c = *pool[L.slots[i]];
     if (c.uid != L.uids[i] || !c.inflight) continue;   // the entry was retired (or re-announced) meanwhile
     c.inflight = false;
+    if (L.only[i] >= 0) {
+      // ---- a restricted re-query comes back: every overlap of the read with contig pc, scored and extended
+      const int pc = L.only[i];
+      if (c.killed) { c.killed = false; ++killedInFlight; continue; }   // the contig changed again meanwhile (the entry stays partial), or the whole entry fell
+      if (!c.partial || c.pendingContig != pc) continue;
+      const int k2 = cnts[i] > 0 ? cnts[i] : 0;
+      bool ok = !(qstatus && i < nAux && qstatus[i] == 5);
+      for (int t = 0; ok && t < k2; ++t) if ((ov[bas[i] + t].strand == 1) != c.strand0Plus) ok = false;   // an overlap on the other strand: which strand is the best one's is open again
+      c.nAllBound += k2;
+      if (c.nAllBound > 50) ok = false;   // (the pre-filters of SeqSet.hpp:1705 may be on now)
+      if (!ok) { c.partial = false; c.pendingContig = -1; ++restrictedFallbacks; continue; }   // neither valid nor partial: the whole query, next launch
+      size_t w = 0;
+      for (size_t t = 0; t < c.ov.size(); ++t) if (c.ov[t].seqIdx != pc) { if (w != t) { c.ov[w] = c.ov[t]; c.ext[w] = c.ext[t]; c.extRet[w] = c.extRet[t]; } ++w; }
+      c.ov.resize(w); c.ext.resize(w); c.extRet.resize(w);
+      for (int t = 0; t < k2; ++t) {
+        const t4_overlap &o = ov[bas[i] + t];
+        if (o.similarity < novelSim) continue;   // the similarity cut (SeqSet.hpp:2105-2119)
+        c.ov.push_back(o); c.ext.push_back(ex[bas[i] + t]); c.extRet.push_back(rets[bas[i] + t]);
+      }
+      c.cnt = (int32_t)c.ov.size();
+      rebuildGroup(c, pc);
+      c.partial = false; c.pendingContig = -1; c.merged = true; ++c.restrictedCount;
+      c.valid = true;
+      ++restrictedMerged;
+      continue;
+    }
     c.tier = L.hint[i];
     if (ticks10ns && i < nTicks) c.lastUs = ticks10ns[i] / 100;
     { static const bool proxy = getenv("T4_SLOW_PROXY") != nullptr; if (proxy) c.lastUs = 50 + 12 * (cnts[i] > 0 ? cnts[i] : 0); }   // testing aid (the emulator has no clock): a time from the overlap count
@@ -1789,6 +1921,8 @@ int t4_assembler::harvest(Lane &L) {
       for (t4_overlap &o : c.ext) if (o.seqIdx == sh.first) { o.seqStart += sh.second; o.seqEnd += sh.second; }
     }
     c.shifts.clear();
+    if (aux && i < nAux && aux[i] >= 0) { c.nAll = aux[i] & 32767; c.nOther = (aux[i] >> 15) & 32767; c.strand0Plus = ((aux[i] >> 30) & 1) != 0; c.n4 = n4s[i]; c.nAllBound = c.nAll; c.auxOk = true; }
+    else c.auxOk = false;
     {
       const t4_grp *dg = nullptr; int ng = 0, huge = 0, n4 = 0;
       if (t4_add_query_groups(L.ctx, i, &dg, &ng, &huge, &n4) == 1) {
@@ -2104,7 +2238,7 @@ int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n) {
   for (int i = 0; i < n && i < 16; ++i) out[i] = v[i];
   if (n >= 23) t4_add_query_stats(a->ctx, out + 16);
   if (n >= 27) t4_add_query_wide_stats(a->ctx, out + 23);   // the wide query: reads it served, partitions, calls repeated with larger pools, dependency records
-  if (getenv("T4_VERIFY_WINDOW")) fprintf(stderr, "T4_VERIFY_WINDOW: %lld served window entries queried again at serve time, all equal to their cached results\n", (long long)a->verified);
+  if (getenv("T4_VERIFY_WINDOW")) fprintf(stderr, "T4_VERIFY_WINDOW: %lld served window entries queried again at serve time, all equal to their cached results (%lld of them put together from restricted re-queries)\n", (long long)a->verified, (long long)a->verifiedMerged);
   if (getenv("T4_TIMING")) {
     fprintf(stderr, "timing: assembler host seconds: add_read calls %.3f (incl. waits for the head), prefetch calls %.3f; launching %.3f (of which deltas %.3f, dependency sets %.3f, registering k-mers %.3f), harvesting %.3f, event examination %.3f, index edits %.3f\n",
             a->secAddTotal, a->secPrefetch, a->secLaunch, a->secDelta, a->secGroups, a->secRegister, a->secHarvest, a->secEvents, a->index.secOps);
@@ -2113,6 +2247,8 @@ int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n) {
     if (a->slowSkipped) fprintf(stderr, "timing: %lld times a read whose last query was slow stayed out of a launch made for reads before it\n", (long long)a->slowSkipped);
     fprintf(stderr, "timing: tolerated index edits %lld, of which %lld met an entry whose group statistics cannot move (no budget spent); tolerance kills %lld, of which %lld for lists beyond 10000 postings\n",
             (long long)a->tolerated, (long long)a->toleratedStable, (long long)a->invFragile, (long long)a->invLongLists);
+    fprintf(stderr, "timing: restricted re-queries: %lld entries kept their other contigs when one contig changed, %lld merged, %lld fell back to the whole query, %lld in flight met another change of their contig\n",
+            (long long)a->restrictedMarks, (long long)a->restrictedMerged, (long long)a->restrictedFallbacks, (long long)a->restrictedStale);
     fprintf(stderr, "timing: wide query served %lld window entries (%lld dependency records came back with them), %lld reads it was expected for stayed on the LDS tier\n", (long long)a->wideServed, (long long)a->wideGroupRecords, (long long)a->wideMispredicted);
   }
   return T4_OK;

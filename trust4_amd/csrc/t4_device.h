@@ -190,6 +190,14 @@ struct T4QueryArgs {
   int leanExt;               // mode 4: records of overlaps whose extension meets an indel carry exact coordinates and return value only (extendOverlaps)
   int *readTicks;
   int *statsStable;          // per read: 1 when the group statistics of GetOverlapsFromHits (SeqSet.hpp:784-823) cannot move under index edits that leave every group of three or more hits alone (null: not wanted)            // mode 4, nullable: wall-clock ticks (10 ns) one workgroup spent on the read (the latency a dependent round pays)
+  // mode 4, nullable: onlySeq[r] >= 0 asks for the overlaps of read r with that ONE contig (all of them, both strands, scored and
+  // extended, no filter that looks across contigs): the ordered builder's re-query of a window entry after a commit that touched
+  // one contig of the forty it meets (t4_assembler: restricted re-query). aux[r] (full queries): overlaps on the strand of the best
+  // one before the similarity cut | overlaps on the other strand << 15 | (that strand is plus) << 30, -1 when the wide query served
+  // the read; n4[r]: (strand, contig) groups of four or more hits.
+  const int *onlySeq;
+  int *aux;
+  int *n4;
   // per-read set images (per-barcode contig sets): read r is matched against views[viewOf[r]]
   const T4IndexView *views;
   const int *viewOf;

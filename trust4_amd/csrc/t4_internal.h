@@ -48,8 +48,11 @@ int t4_add_query_pool(t4_index *ix, int n, const char *bases, const int64_t *off
 
 // the same in two halves, so that the caller's host work overlaps the kernels: begin enqueues, done polls (1 = finished or idle),
 // end waits and returns the result. tier_hint must stay alive until end; one call in flight per ctx.
+// only_seq (nullable): only_seq[i] >= 0 asks for the overlaps of read i with that one contig alone -- all of them, both strands,
+// scored and extended, none of the steps that look across contigs applied (the restricted re-query of a window entry)
 int t4_add_query_pool_begin(t4_index *ix, int n, const char *bases, const int64_t *offsets, const int32_t *barcodes, const int32_t *strands,
-                            int skip_repeats, const double *factors, unsigned char *tier_hint);
+                            int skip_repeats, const double *factors, unsigned char *tier_hint, const int32_t *only_seq);
+int t4_add_query_last_aux(t4_ctx *ctx, const int32_t **aux, const int32_t **n4, const int32_t **status, int *n);   // see T4QueryArgs::aux / n4
 int t4_add_query_pool_done(t4_ctx *ctx);
 int t4_ctx_device(t4_ctx *ctx);   // the device ordinal the ctx was created on (t4_assembler opens further ctxs beside it: one per query lane)
 int t4_add_query_pool_end(t4_ctx *ctx, const int32_t **counts, const int32_t **base, const t4_overlap **ov, const t4_overlap **ext, const int32_t **ext_ret);

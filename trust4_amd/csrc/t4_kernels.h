@@ -728,6 +728,7 @@ struct WaveState { // wave-uniform scalars kept in LDS
   int nvPossible[2], nvLongest[2];   // novel group statistics of GetOverlapsFromHits (filter 1)
   int nvN4[2], nvN5[2], nvSmax[2];   // groups of at least 4 / 5 hits and the largest group, TRUE sizes (the statistics measure a group one short or in full)
   int statsStable;                   // no pass of this read so far whose novelMinHitRequired could move (see overlapsFromKeys)
+  int nAll, nOther, strand0;          // GetOverlapsFromRead: overlaps on the strand of the best one (before the similarity cut), on the other strand, that strand
   int wideWant;                      // mode 4: a pass that outgrows the LDS arrays is handed to the wide query (t4_wide.h) instead of global scratch
   unsigned hhBest[2];        // HasHitInSet: per strand, (distinct read offsets << 16) | (0xFFFF - bucket rank) of the best bucket
   long long phaseT0; int curPhase, phaseBase;
@@ -1059,6 +1060,34 @@ __device__ int expandHits(const T4IndexView &ix, WaveMem &wm, int nk, int H, int
   }
   dropped = blockSum(dropped, red);
   return H - dropped;
+}
+
+// The hits with ONE sequence only (restricted re-query, T4QueryArgs::onlySeq), appended compactly: every posting of every emitted
+// k-mer is looked at (H may be far beyond the key array), the few that name `seq` are kept. Returns their number, -1 when they
+// outgrow the key array. Uses ws->candCount as the cursor.
+__device__ int expandHitsOnly(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int nk, int H, int seq, const unsigned *posStart, const unsigned *posPref) {
+  const int lane = tid(), NT = nthr();
+  if (lane == 0) ws->candCount = 0;
+  __syncthreads();
+  for (int s = lane; s < H; s += NT) {
+    int lo = 0, hi = 2 * nk - 1;   // last q with posPref[q] <= s
+    while (lo < hi) {
+      int mid = (lo + hi + 1) >> 1;
+      if (posPref[mid] <= (unsigned)s) lo = mid; else hi = mid - 1;
+    }
+    const int q = lo;
+    const int2 po = ix.post[posStart[q] + ((unsigned)s - posPref[q])];
+    if (po.x != seq) continue;
+    const int st = q >= nk, a = st ? q - nk : q;
+    const int at = atomicAdd(&ws->candCount, 1);
+    if (at < wm.hitLimit)
+      wm.keys[at] = ((st ? 0ull : 1ull) << 63) | ((unsigned long long)po.x << (T4_C_BITS + T4_B_BITS)) |
+                    ((unsigned long long)(a - po.y + T4_C_BIAS) << T4_B_BITS) | (unsigned long long)po.y;
+  }
+  __syncthreads();
+  const int n = ws->candCount;
+  __syncthreads();
+  return n <= wm.hitLimit ? n : -1;
 }
 
 // Workgroup bitonic sort of keys[0, n) (any n): the all-ascending network on the next power of two with VIRTUAL +inf
@@ -2253,7 +2282,7 @@ __device__ int selectVJPair(const T4IndexView &ix, WaveMem &wm, int n) {
 // emitted by the seed stage) or -1 on capacity overflow. Overlaps are left in wm.ov / ws->ovCount.
 template <bool NOVEL>   // NOVEL: the kernel variants that meet contig sets (repeat-skip rule live); the reference-set variants keep their register budget
 __device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int segLen, int strandArg, int barcode,
-                             bool allowTotalSkip, bool vjOnly, int hitLenRequired, int filter) {
+                             bool allowTotalSkip, bool vjOnly, int hitLenRequired, int filter, int onlySeq = -1) {
   const int lane = tid(), NT = nthr();
   unsigned *posStart = (unsigned *)wm.ov;   // dead before the first overlap record is written
   unsigned *posPref = wm.pairs;             // dead before the first pair is written
@@ -2262,6 +2291,14 @@ __device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, 
   PHASE_MARK(ws, 1);
   int H = NOVEL ? seedPositionsNovel(ix, wm, segLen, strandArg, barcode, allowTotalSkip, posStart, posPref, ws->red, wm.keys, ws)
                 : seedPositions(ix, wm, segLen, strandArg, barcode, allowTotalSkip, posStart, posPref, ws->red);   // the key array is free until the hits are expanded
+  if (NOVEL && onlySeq >= 0) {   // restricted re-query: the hits with one contig (a few hundred at most), whatever the read's total
+    const int Hv = expandHitsOnly(ix, wm, ws, nk, H, onlySeq, posStart, posPref);
+    if (Hv < 0) return -1;
+    if (Hv > 1) { if (wm.ldsArrays) bitonicSortRegLds(wm.keys, Hv); else bitonicSort(wm.keys, Hv); }
+    __syncthreads();
+    overlapsFromKeys(ix, wm, ws, Hv, hitLenRequired, 0);   // (filter 0: the thresholds stay at three hits -- the caller has made sure the group statistics leave them there)
+    return H;
+  }
   if (H > wm.hitLimit) return (NOVEL && ws->wideWant && !allowTotalSkip && !vjOnly && filter == 1) ? -3 : -1;
   PHASE_MARK(ws, 2);
 #if T4_OPT_KEY32
@@ -2592,10 +2629,30 @@ __device__ __forceinline__ bool scoreOverlaps(const T4IndexView &ix, WaveMem &wm
 // overlaps are reference genes, keep their register budget).
 template <bool ROWS>
 __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int segLen, int strandArg, int barcode,
-                                   bool skipRepeats, int shift, DPScratch sc, unsigned long long &hitTotal) {
+                                   bool skipRepeats, int shift, DPScratch sc, unsigned long long &hitTotal, int onlySeq = -1) {
   const int lane = tid(), NT = nthr();
   if (segLen < ix.k) return -1;
   int overlapCnt = 0;
+  if (lane == 0) { ws->nAll = 0; ws->nOther = 0; ws->strand0 = 0; }
+  if (ROWS && onlySeq >= 0) {
+    // Restricted re-query (T4QueryArgs::onlySeq): every overlap of the read with ONE contig, scored; nothing that looks across
+    // contigs is applied (strand of the best overlap, pre-filters, similarity cut: the caller merges with what it holds)
+    const int H = seedChainPass<ROWS>(ix, wm, ws, segLen, strandArg, barcode, false, false, ix.hitLenRequired, 0, onlySeq);
+    if (H < 0) return -2;
+    hitTotal += (unsigned long long)H;
+    __syncthreads();
+    overlapCnt = ws->ovCount;
+    if (ws->overflow || overlapCnt > wm.maxOv || overlapCnt > wm.maxFin) return -2;
+    if (overlapCnt == 0) return 0;
+    for (int i = lane; i < overlapCnt; i += NT) wm.ord[i] = (unsigned short)i;
+    __syncthreads();
+    if (!scoreOverlaps<ROWS>(ix, wm, ws, overlapCnt, sc)) return -2;
+    for (int i = lane; i < overlapCnt; i += NT) { OvRec o = wm.ov[i]; o.rs += shift; o.re += shift; o.chainLen = 0; wm.fin[i] = o; }
+    __syncthreads();
+    if (lane == 0) ws->finCount = overlapCnt;
+    __syncthreads();
+    return overlapCnt;
+  }
   if (skipRepeats) {
     int H = seedChainPass<ROWS>(ix, wm, ws, segLen, strandArg, barcode, true, false, ix.hitLenRequired, 0);
     if (H < 0) return -2;
@@ -2663,6 +2720,7 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
     kept += tot;
     __syncthreads();
   }
+  if (lane == 0) { ws->nAll = kept; ws->nOther = overlapCnt - kept; ws->strand0 = strand0 ? 1 : 0; }
   overlapCnt = kept;
   PHASE_MARK(ws, 9);
   if (!scoreOverlaps<ROWS>(ix, wm, ws, overlapCnt, sc)) return -2;
@@ -3363,7 +3421,7 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
   const int lane = tid(), NT = nthr();
   const int len = bv.len[r];
   unsigned long long hitTotal = 0;
-  if (lane == 0) { ws->overflow = 0; ws->unsupported = 0; ws->finCount = 0; ws->nContig = 0; ws->ovCount = 0; ws->statsStable = 1; ws->wideWant = 0; }
+  if (lane == 0) { ws->overflow = 0; ws->unsupported = 0; ws->finCount = 0; ws->nContig = 0; ws->ovCount = 0; ws->statsStable = 1; ws->wideWant = 0; ws->nvN4[0] = ws->nvN4[1] = 0; }
 #ifdef T4_PHASE_TIMING
   if (lane == 0) { ws->phaseT0 = clock64(); ws->phaseBase = wm.ldsArrays ? 0 : 32; ws->curPhase = ws->phaseBase; }
 #endif
@@ -3376,10 +3434,19 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
     unsigned char *dirbuf = wm.dirBuf;
     int barcode = bv.barcode ? bv.barcode[r] : -1;
     // a pass that outgrows this workgroup's arrays (hits or overlaps) is spread over the chip: the wide query (t4_wide.h)
-    const bool wide = wk.wide != nullptr && wm.ldsArrays && !qa.skipRepeats && barcode == -1 && ix.hasNovel == 2 && !qa.views && qa.extendLater > 0;
+    const int onlySeq = qa.onlySeq ? qa.onlySeq[r] : -1;
+    const bool wide = onlySeq < 0 && wk.wide != nullptr && wm.ldsArrays && !qa.skipRepeats && barcode == -1 && ix.hasNovel == 2 && !qa.views && qa.extendLater > 0;
     if (lane == 0) ws->wideWant = wide ? 1 : 0;
     loadSegment(bv, r, 0, len, wm);
-    int ret = overlapsFromSegment<VARIANT != 0>(ix, wm, ws, len, qa.strandPerRead[r], barcode, qa.skipRepeats != 0, 0, sc, hitTotal);
+    int ret = overlapsFromSegment<VARIANT != 0>(ix, wm, ws, len, qa.strandPerRead[r], barcode, qa.skipRepeats != 0, 0, sc, hitTotal, onlySeq);
+    if (onlySeq >= 0 && ret == -2) {   // (one contig's hits or overlaps beyond this workgroup's arrays: the caller asks for the whole query instead)
+      if (lane == 0) { wk.status[r] = 5; qa.counts[r] = 0; atomicAdd(wk.hitCounter, hitTotal); }
+      return true;
+    }
+    if (lane == 0 && onlySeq < 0) {
+      if (qa.aux) qa.aux[r] = (ret == -2 || ret == -3) ? -1 : ((ws->nAll > 32767 ? 32767 : ws->nAll) | ((ws->nOther > 32767 ? 32767 : ws->nOther) << 15) | (ws->strand0 << 30));
+      if (qa.n4) qa.n4[r] = ws->nvN4[0] + ws->nvN4[1];
+    }
     if (wide && (ret == -2 || ret == -3)) {
       if (ret == -2) hitTotal = 0;   // (the pass is counted again by the wide query's seed stage)
       wideDeferRead(ix, wm, ws, *wk.wide, len, qa.strandPerRead[r], r, hitTotal);

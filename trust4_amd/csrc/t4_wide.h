@@ -564,6 +564,8 @@ __global__ __launch_bounds__(512) void wideMergeKernel(T4IndexView ix, T4BatchVi
     __syncthreads();
     const int *st = wd.stat + (size_t)w * T4_WIDE_STAT;
     if (lane == 0 && qa.statsStable) qa.statsStable[r] = st[WS_STABLE];
+    if (lane == 0 && qa.aux) qa.aux[r] = -1;   // (no restricted re-query of a read the wide query served)
+    if (lane == 0 && qa.n4) qa.n4[r] = st[WS_N4];
     if (N == 0) { if (lane == 0) { qa.counts[r] = 0; qa.outBase[r] = 0; } continue; }
     // std::sort(overlaps) (SeqSet.hpp:1597) on the records as GetOverlapsFromHits left them: matchCnt (kept in chainLen), read span,
     // contig, strand in one key with the record's index; ties on all four are settled by the rest of operator<
