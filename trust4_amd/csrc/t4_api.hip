@@ -1617,6 +1617,11 @@ int aqLaunch(t4_ctx *c) {
     if ((r = ensureWide(c, n, 1, 1))) return r;
     T4Wide w = c->wide;
     w.enabled = 1; w.safetyNum = q.wideSafety;
+    // Reads of up to T4_WIDE_MIN_HITS emitted hits stay with one workgroup (LDS tier, then its slice of global scratch inside the same
+    // launch, beside the other reads of the round): the wide query's kernels run behind the launch and cost a round about 0.25 ms
+    // whatever the read's size (profiles/r04b-e), which pays from a few ten thousand hits on. The testing aid T4_AQ_CAP_LIMIT lowers
+    // the threshold with the LDS tier's capacity.
+    { const int lim = getenv("T4_AQ_CAP_LIMIT") ? atoi(getenv("T4_AQ_CAP_LIMIT")) : 0; w.minHits = lim > 0 ? lim : wideEnv("T4_WIDE_MIN_HITS", 32768); }
     w.ctl = (int *)(c->aqOut + q.pWctl); w.plan = (T4WidePlan *)(c->aqOut + q.pWplan); w.stat = (int *)(c->aqOut + q.pWstat);
     memcpy(c->aqInHost + q.oWide, &w, sizeof w);
   }

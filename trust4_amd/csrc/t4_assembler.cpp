@@ -1525,6 +1525,7 @@ int t4_assembler::emittedHits(const Cached &e) {
         if (size >= 100 && i != k - 1 && i != len - 1 && skipCnt < skipLimit) { ++skipCnt; continue; }
         skipCnt = 0;
         H += size;
+        if (size > 10000) return 0x7FFFFFFF;   // a list beyond 10000 postings: the wide query whatever the total (removeOnlyRepeats)
       }
       prev = kc.code;
     }
@@ -1784,7 +1785,7 @@ int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive
   {   // what t4_add_query_pool_begin does with a heavy read under the testing aids of csrc/t4_api.hip
     wideQueries = !getenv("T4_WIDE_OFF") && !getenv("T4_AQ_FORCE_GLOBAL");
     const int lim = getenv("T4_AQ_CAP_LIMIT") ? atoi(getenv("T4_AQ_CAP_LIMIT")) : 0;
-    wideHitLimit = lim > 0 && lim < 8192 ? lim : 8192;
+    wideHitLimit = lim > 0 ? lim : (getenv("T4_WIDE_MIN_HITS") ? atoi(getenv("T4_WIDE_MIN_HITS")) : 32768);
   }
   L.slots = todo; L.uids.resize(m); L.hint.resize(m); L.bcs.resize(m); L.sts.resize(m); L.fac.resize(m); L.only.resize(m);
   L.bases.clear(); L.offs.assign(1, 0); L.repetitive = repetitive;
@@ -1978,7 +1979,10 @@ int t4_assembler::pumpLive(bool needHead, int repetitive) {
       Cached &c = *pool[order[i]];
       if (c.valid || c.inflight) continue;
       if (slowUs > 0 && i >= slowAhead && c.lastUs > slowUs) { ++slowSkipped; continue; }
-      (c.tier ? heavy : light).push_back(order[i]);
+      // two classes of work: restricted re-queries (one contig of an entry that keeps the rest: tens of microseconds) and whole
+      // queries (hundreds; a read the wide query serves, more). With two lanes the head's restricted re-query does not wait for
+      // the whole queries of the entries behind it.
+      (c.partial ? light : heavy).push_back(order[i]);
     }
     const bool headWaits_ = !head.valid && !head.inflight;
     int idle = 0; Lane *free1 = nullptr;
@@ -1990,7 +1994,7 @@ int t4_assembler::pumpLive(bool needHead, int repetitive) {
         continue;
       }
       // the head's launch carries the entries of its own weight class; the other class goes beside it when a lane is free
-      std::vector<int> &mine = head.tier ? heavy : light, &other = head.tier ? light : heavy;
+      std::vector<int> &mine = head.partial ? light : heavy, &other = head.partial ? heavy : light;
       if (lanes.size() == 1) { mine.insert(mine.end(), other.begin(), other.end()); other.clear(); }   // one launch: the heavy ones run beside the others on the ctx's second stream
       {
         const double served = (double)(cacheHits - hitsAtLastRound);

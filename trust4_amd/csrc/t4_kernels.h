@@ -729,7 +729,7 @@ struct WaveState { // wave-uniform scalars kept in LDS
   int nvN4[2], nvN5[2], nvSmax[2];   // groups of at least 4 / 5 hits and the largest group, TRUE sizes (the statistics measure a group one short or in full)
   int statsStable;                   // no pass of this read so far whose novelMinHitRequired could move (see overlapsFromKeys)
   int nAll, nOther, strand0;          // GetOverlapsFromRead: overlaps on the strand of the best one (before the similarity cut), on the other strand, that strand
-  int wideWant;                      // mode 4: a pass that outgrows the LDS arrays is handed to the wide query (t4_wide.h) instead of global scratch
+  int wideWant;                      // mode 4, nonzero: a pass that emits more hits than this (or outgrows the global-scratch tier) is handed to the wide query (t4_wide.h)
   unsigned hhBest[2];        // HasHitInSet: per strand, (distinct read offsets << 16) | (0xFFFF - bucket rank) of the best bucket
   long long phaseT0; int curPhase, phaseBase;
 #ifdef T4_PHASE_TIMING
@@ -2299,7 +2299,15 @@ __device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, 
     overlapsFromKeys(ix, wm, ws, Hv, hitLenRequired, 0);   // (filter 0: the thresholds stay at three hits -- the caller has made sure the group statistics leave them there)
     return H;
   }
-  if (H > wm.hitLimit) return (NOVEL && ws->wideWant && !allowTotalSkip && !vjOnly && filter == 1) ? -3 : -1;
+  if (NOVEL && !allowTotalSkip && !vjOnly && filter == 1 && H > 10000) {
+    // a posting list beyond 10000 entries switches on removeOnlyRepeats and the run-relative repeats test (SeqSet.hpp:802, 876,
+    // 934-940): the wide query replays them, the single-workgroup tiers do not
+    int huge = 0;
+    for (int q = lane; q < 2 * nk; q += NT) if (posPref[q + 1] - posPref[q] > 10000u) huge = 1;
+    if (blockSum(huge, ws->red)) { if (ws->wideWant) return -3; if (lane == 0) ws->unsupported = 1; }
+  }
+  if (NOVEL && ws->wideWant && H > ws->wideWant && !allowTotalSkip && !vjOnly && filter == 1) return -3;   // heavy enough for the wide query (t4_wide.h)
+  if (H > wm.hitLimit) return (NOVEL && ws->wideWant && !wm.ldsArrays && !allowTotalSkip && !vjOnly && filter == 1) ? -3 : -1;
   PHASE_MARK(ws, 2);
 #if T4_OPT_KEY32
   const int k32 = ix.key32;
@@ -3435,8 +3443,8 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
     int barcode = bv.barcode ? bv.barcode[r] : -1;
     // a pass that outgrows this workgroup's arrays (hits or overlaps) is spread over the chip: the wide query (t4_wide.h)
     const int onlySeq = qa.onlySeq ? qa.onlySeq[r] : -1;
-    const bool wide = onlySeq < 0 && wk.wide != nullptr && wm.ldsArrays && !qa.skipRepeats && barcode == -1 && ix.hasNovel == 2 && !qa.views && qa.extendLater > 0;
-    if (lane == 0) ws->wideWant = wide ? 1 : 0;
+    const bool wide = onlySeq < 0 && wk.wide != nullptr && !qa.skipRepeats && barcode == -1 && ix.hasNovel == 2 && !qa.views && qa.extendLater > 0;
+    if (lane == 0) ws->wideWant = wide ? (wk.wide->minHits > 0 ? wk.wide->minHits : 1) : 0;
     loadSegment(bv, r, 0, len, wm);
     int ret = overlapsFromSegment<VARIANT != 0>(ix, wm, ws, len, qa.strandPerRead[r], barcode, qa.skipRepeats != 0, 0, sc, hitTotal, onlySeq);
     if (onlySeq >= 0 && ret == -2) {   // (one contig's hits or overlaps beyond this workgroup's arrays: the caller asks for the whole query instead)
@@ -3447,8 +3455,8 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
       if (qa.aux) qa.aux[r] = (ret == -2 || ret == -3) ? -1 : ((ws->nAll > 32767 ? 32767 : ws->nAll) | ((ws->nOther > 32767 ? 32767 : ws->nOther) << 15) | (ws->strand0 << 30));
       if (qa.n4) qa.n4[r] = ws->nvN4[0] + ws->nvN4[1];
     }
-    if (wide && (ret == -2 || ret == -3)) {
-      if (ret == -2) hitTotal = 0;   // (the pass is counted again by the wide query's seed stage)
+    if (wide && (ret == -3 || (ret == -2 && !wm.ldsArrays))) {   // (overlaps beyond the LDS tier's arrays: the global-scratch pass of this workgroup first)
+      hitTotal = 0;   // (the pass is counted by the wide query's seed stage)
       wideDeferRead(ix, wm, ws, *wk.wide, len, qa.strandPerRead[r], r, hitTotal);
       if (lane == 0) atomicAdd(wk.hitCounter, hitTotal);
       return true;
