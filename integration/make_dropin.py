@@ -7,10 +7,14 @@ gets the seven one-line edits below (anchored on unique strings of the file, eac
 against integration/t4_dropin.hpp (the binding) and linked with libt4hip.so (or, for the CPU test suite, with the emulator build of
 the same kernels). Everything else -- ProcessRead, counting, sorting, trimming, the loop bodies, ExtendSeqFromReads,
 RemoveRedundantSeq, the writers -- is the reference's code, compiled where it lies. The patched source is a temporary file; nothing
-of the reference is stored in the repository. Outputs go to oracle/_ref/ (git-ignored, travels to the GPU box) because the binary is
-reference-derived integration-test infrastructure, not the product.
+of the reference is stored in the repository, neither source nor binary (every output path below is git-ignored).
 
-  python integration/make_dropin.py [--emu] [--ref /root/reference] [-o PATH]
+  python integration/make_dropin.py --product --ref /path/to/TRUST4     ->  trust4_amd/bin/trust4-dropin
+      what a user of run-trust4 builds: the drop-in `trust4` for their own TRUST4 tree (point run-trust4's $WD/trust4 at it)
+  python integration/make_dropin.py [--ref /root/reference] [-o PATH]   ->  oracle/_ref/trust4-dropin (+ oracle/_ref/pipeline)
+      the same binary among the checker artefacts (travels to the GPU box with run-trust4 & co. for the process-level tests)
+  python integration/make_dropin.py --emu                               ->  oracle/_ref/trust4-dropin-emu
+      linked with the emulator build of the kernels (CPU test suite)
 """
 import argparse
 import os
@@ -86,6 +90,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--emu", action="store_true", help="link the emulator build of the kernels (tests/hipemu/libt4hip_emu.so; CPU test suite)")
+    ap.add_argument("--product", action="store_true", help="write trust4_amd/bin/trust4-dropin (the user-facing build, beside trust4-hip)")
     ap.add_argument("-o", default="")
     args = ap.parse_args()
     if not os.path.exists(os.path.join(args.ref, "main.cpp")):
@@ -93,7 +98,8 @@ def main():
         return
     libdir = os.path.join(ROOT, "tests", "hipemu") if args.emu else os.path.join(ROOT, "trust4_amd")
     lib = "t4hip_emu" if args.emu else "t4hip"
-    out = args.o or (os.path.join(ROOT, "tests", "hipemu", "trust4-dropin-emu") if args.emu else os.path.join(ROOT, "oracle", "_ref", "trust4-dropin"))
+    out = args.o or (os.path.join(ROOT, "oracle", "_ref", "trust4-dropin-emu") if args.emu else
+                     os.path.join(ROOT, "trust4_amd", "bin", "trust4-dropin") if args.product else os.path.join(ROOT, "oracle", "_ref", "trust4-dropin"))
     os.makedirs(os.path.dirname(out), exist_ok=True)
     with open(os.path.join(args.ref, "main.cpp")) as f:
         src = patch(f.read())
@@ -103,11 +109,11 @@ def main():
         with open(cpp, "w") as f:
             f.write(src)
         cmd = ["g++", "-O3", "-w", "-std=c++11", "-I" + args.ref, "-I" + os.path.join(ROOT, "integration"), "-I" + os.path.join(ROOT, "include"), "-o", out, cpp,
-               "-L" + libdir, "-l" + lib, "-Wl,-rpath," + libdir, "-Wl,-rpath,$ORIGIN/../../trust4_amd", "-lpthread", "-lz"]
+               "-L" + libdir, "-l" + lib, "-Wl,-rpath," + libdir, "-Wl,-rpath,$ORIGIN/../../trust4_amd", "-Wl,-rpath,$ORIGIN/..", "-lpthread", "-lz"]
         subprocess.run(cmd, check=True)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    if not args.emu:
+    if not args.emu and not args.product:
         stage_pipeline(args.ref, os.path.join(ROOT, "oracle", "_ref", "pipeline"))
     print(out)
 

@@ -318,8 +318,7 @@ def _bulk_case(tmp_path, driver, pairs, clones, seed, env, threads="4"):
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
 @pytest.mark.parametrize("env", [{"T4_AQ_CAP_LIMIT": "120"}, {"T4_AQ_CAP_LIMIT": "120", "T4_WIDE_PCAP": "512", "T4_WIDE_PARTS": "2", "T4_WIDE_GROUPS": "16"}, {"T4_AQ_CAP_LIMIT": "120", "T4_WIDE_OFF": "1"},
                                  {"T4_AQ_FORCE_GLOBAL": "1"}, {"T4_QUERY_AHEAD": "3", "T4_WINDOW": "7"}, {"T4_AQ_EXTEND_DEFER": "1"}, {"T4_AQ_EXTEND_DEFER": "0"},
-                                 {"T4_AQ_POOL_CAP": "8", "T4_AQ_EXTEND_DEFER": "1"}, {"T4_AQ_POOL_CAP": "5"}, {"T4_SORT_MIN": "64"}, {"T4_GPU_PROCESSREAD": "1"},
-                                 {"T4_SLOW_US": "60", "T4_SLOW_PROXY": "1", "T4_SLOW_AHEAD": "2"}])
+                                 {"T4_AQ_POOL_CAP": "8", "T4_AQ_EXTEND_DEFER": "1"}, {"T4_AQ_POOL_CAP": "5"}, {"T4_SORT_MIN": "64"}, {"T4_GPU_PROCESSREAD": "1"}])
 def test_bulk_live_set_paths_emulated(tmp_path, env):
     """Bulk mode = the live set (device image by t4_index_apply_delta, sliding speculation window). The testing aids send a
     small input down the paths large sets take: reads that outgrow the LDS arrays and are spread over the chip by the wide query

@@ -912,12 +912,9 @@ int runQuery(t4_index *ix, t4_batch *b, T4QueryArgs qa, bool useBarcode, bool no
   int r;
   int grids[T4_NTIER];
   int maxGrid = 1;
-  static const int bigThreads[3] = {getenv("T4_T2_THREADS") ? atoi(getenv("T4_T2_THREADS")) : TIER_THREADS[2], getenv("T4_T3_THREADS") ? atoi(getenv("T4_T3_THREADS")) : TIER_THREADS[3],
-                                    getenv("T4_T4_THREADS") ? atoi(getenv("T4_T4_THREADS")) : TIER_THREADS[4]};
   for (int t = 0; t < T4_NTIER; ++t) {
     grids[t] = c->cus * TIER_BLOCKS_PER_CU[t];
-    const int th = (t >= 2 && t <= 4) ? bigThreads[t - 2] : TIER_THREADS[t];
-    if (grids[t] * th > maxGrid) maxGrid = grids[t] * th;
+    if (grids[t] * TIER_THREADS[t] > maxGrid) maxGrid = grids[t] * TIER_THREADS[t];
   }
   if ((r = ensureScratch(c, maxGrid))) return r;
   if ((r = ensurePerCall(c, n))) return r;
@@ -928,8 +925,7 @@ int runQuery(t4_index *ix, t4_batch *b, T4QueryArgs qa, bool useBarcode, bool no
   T4TierCaps caps;
   for (int t = 0; t < T4_NTIER - 1; ++t) caps.cap[t] = TIER_CAP[t];
   if (noHits) caps.cap[0] = 1 << 30;
-  static const int binBlocks = getenv("T4_BIN_BLOCKS") ? atoi(getenv("T4_BIN_BLOCKS")) : 8;
-  int binGrid = c->cus * binBlocks;
+  int binGrid = c->cus * 8;
   if ((long long)binGrid > n) binGrid = (int)n;
   hipLaunchKernelGGL(t4k::binKernel, dim3(binGrid), dim3(64), 0, c->stream, ix->view, b->view, useBarcode ? 1 : 0,
                      caps, c->lists, c->listCounts, (long long)n);
@@ -943,9 +939,6 @@ int runQuery(t4_index *ix, t4_batch *b, T4QueryArgs qa, bool useBarcode, bool no
     int cnt = hostCounts[t];
     c->stats.tier_reads[t] = cnt;
     if (cnt == 0) continue;
-#ifdef T4_PHASE_TIMING
-    if (getenv("T4_ONLY_TIER") && atoi(getenv("T4_ONLY_TIER")) >= 0 && atoi(getenv("T4_ONLY_TIER")) != t) continue;   // per-tier phase profiles
-#endif
     T4Work wk;
     memset(&wk, 0, sizeof wk);
     wk.list = c->lists + (size_t)t * n; wk.nList = cnt;
@@ -960,25 +953,13 @@ int runQuery(t4_index *ix, t4_batch *b, T4QueryArgs qa, bool useBarcode, bool no
       wk.gKeys = c->gKeys; wk.gPairs = c->gPairs; wk.gCand = c->gCand; wk.gOv = c->gOv; wk.gFin = c->gFin; wk.gOrd = c->gOrd;
       wk.gCap = G_CAP; wk.gMaxOv = G_MAXOV;
       launchTier<0, 0, G_THREADS>(grid, c->stream, ix->view, b->view, wk, qa);
-    } else if (t == 0) {
-      static const int nt0 = getenv("T4_T0_THREADS") ? atoi(getenv("T4_T0_THREADS")) : TIER_THREADS[0];
-      static const int bl0 = getenv("T4_T0_BLOCKS") ? atoi(getenv("T4_T0_BLOCKS")) : TIER_BLOCKS_PER_CU[0];
-      static const int mo0 = getenv("T4_T0_MAXOV") ? atoi(getenv("T4_T0_MAXOV")) : 64;
-      int g0 = c->cus * bl0 < cnt ? c->cus * bl0 : cnt;
-      if (nt0 == 128 && mo0 == 64) launchTier<1024, 64, 128>(g0, c->stream, ix->view, b->view, wk, qa);
-      else if (nt0 == 128) launchTier<1024, 128, 128>(g0, c->stream, ix->view, b->view, wk, qa);
-      else if (mo0 == 64) launchTier<1024, 64, 256>(g0, c->stream, ix->view, b->view, wk, qa);
-      else launchTier<1024, 128, 256>(g0, c->stream, ix->view, b->view, wk, qa);
-    } else if (t == 1) {
-      static const int bl1 = getenv("T4_T1_BLOCKS") ? atoi(getenv("T4_T1_BLOCKS")) : TIER_BLOCKS_PER_CU[1];
-      static const int mo1 = getenv("T4_T1_MAXOV") ? atoi(getenv("T4_T1_MAXOV")) : 128;
-      int g1 = c->cus * bl1 < cnt ? c->cus * bl1 : cnt;
-      if (mo1 == 64) launchTier<2048, 64, 256>(g1, c->stream, ix->view, b->view, wk, qa);
-      else launchTier<2048, 128, 256>(g1, c->stream, ix->view, b->view, wk, qa);
     }
-    else if (t == 2) { if (bigThreads[0] == 512) launchTier<3072, 128, 512>(grid, c->stream, ix->view, b->view, wk, qa); else launchTier<3072, 128, 256>(grid, c->stream, ix->view, b->view, wk, qa); }
-    else if (t == 3) { if (bigThreads[1] == 512) launchTier<4096, 256, 512>(grid, c->stream, ix->view, b->view, wk, qa); else launchTier<4096, 256, 256>(grid, c->stream, ix->view, b->view, wk, qa); }
-    else { if (bigThreads[2] == 512) launchTier<8192, 512, 512>(grid, c->stream, ix->view, b->view, wk, qa); else launchTier<8192, 512, 256>(grid, c->stream, ix->view, b->view, wk, qa); }
+    // (threads per read and resident groups per CU of every tier: TIER_THREADS / TIER_BLOCKS_PER_CU above; measured in rounds 1-3)
+    else if (t == 0) launchTier<1024, 64, 128>(grid, c->stream, ix->view, b->view, wk, qa);
+    else if (t == 1) launchTier<2048, 128, 256>(grid, c->stream, ix->view, b->view, wk, qa);
+    else if (t == 2) launchTier<3072, 128, 256>(grid, c->stream, ix->view, b->view, wk, qa);
+    else if (t == 3) launchTier<4096, 256, 256>(grid, c->stream, ix->view, b->view, wk, qa);
+    else launchTier<8192, 512, 512>(grid, c->stream, ix->view, b->view, wk, qa);
     HIPCHK(c, hipGetLastError());
     ++c->stats.launches;
   }
@@ -1605,7 +1586,7 @@ int aqLaunch(t4_ctx *c) {
   const bool smallFirst = q.smallFirst;
   int r;
   if (!c->aqPool) {
-    static const int poolCap0 = getenv("T4_AQ_POOL_CAP") ? atoi(getenv("T4_AQ_POOL_CAP")) : 0;   // testing aid: a small pool forces the grow-and-repeat path
+    const int poolCap0 = getenv("T4_AQ_POOL_CAP") ? atoi(getenv("T4_AQ_POOL_CAP")) : 0;   // testing aid: a small pool forces the grow-and-repeat path
     if (!c->aqPoolCap) c->aqPoolCap = poolCap0 > 0 ? poolCap0 : 1 << 16;
     const size_t rec = (size_t)c->aqPoolCap;
     HIPCHK(c, hipHostMalloc(&c->aqPool, rec * (2 * sizeof(t4_overlap) + sizeof(int32_t)), hipHostMallocMapped));
@@ -1619,9 +1600,9 @@ int aqLaunch(t4_ctx *c) {
     w.enabled = 1; w.safetyNum = q.wideSafety;
     // Reads of up to T4_WIDE_MIN_HITS emitted hits stay with one workgroup (LDS tier, then its slice of global scratch inside the same
     // launch, beside the other reads of the round): the wide query's kernels run behind the launch and cost a round about 0.25 ms
-    // whatever the read's size (profiles/r04b-e), which pays from a few ten thousand hits on. The testing aid T4_AQ_CAP_LIMIT lowers
+    // whatever the read is (profiles/r04b-h); from the LDS tier.s capacity on it beats one workgroup.s global scratch (C2 122 -> 93 s, profiles/r04h_*). The testing aid T4_AQ_CAP_LIMIT lowers
     // the threshold with the LDS tier's capacity.
-    { const int lim = getenv("T4_AQ_CAP_LIMIT") ? atoi(getenv("T4_AQ_CAP_LIMIT")) : 0; w.minHits = lim > 0 ? lim : wideEnv("T4_WIDE_MIN_HITS", 32768); }
+    { const int lim = getenv("T4_AQ_CAP_LIMIT") ? atoi(getenv("T4_AQ_CAP_LIMIT")) : 0; w.minHits = lim > 0 ? lim : wideEnv("T4_WIDE_MIN_HITS", 8192); }
     w.ctl = (int *)(c->aqOut + q.pWctl); w.plan = (T4WidePlan *)(c->aqOut + q.pWplan); w.stat = (int *)(c->aqOut + q.pWstat);
     memcpy(c->aqInHost + q.oWide, &w, sizeof w);
   }
@@ -1659,8 +1640,7 @@ int aqLaunch(t4_ctx *c) {
     }
     qa.extendLater = deferMin; qa.outDev = c->aqRecDev; qa.recRead = c->aqRecRead;
   }
-  static const int bigThreads = getenv("T4_AQ_THREADS") ? atoi(getenv("T4_AQ_THREADS")) : 512;   // workgroup of the 8192-hit tier of this path
-  const int threads = (!smallFirst && bigThreads == 512) ? 512 : 256;
+  const int threads = !smallFirst ? 512 : 256;   // workgroup of the 8192-hit tier of this path
   q.threads = threads;
   const int grid0 = smallFirst ? (n < c->cus * TIER_BLOCKS_PER_CU[0] ? n : c->cus * TIER_BLOCKS_PER_CU[0])
                                : (nFirst > 0 ? (nFirst < c->cus * 2 ? nFirst : c->cus * 2) : 1);   // persistent grid: a large batch strides (and the per-block global scratch stays bounded)
@@ -1699,8 +1679,7 @@ int aqLaunch(t4_ctx *c) {
       wf.gKeys = c->gKeys + skip * G_CAP; wf.gPairs = c->gPairs + skip * G_CAP * 2; wf.gCand = c->gCand;
       wf.gOv = c->gOv + skip * G_MAXOV * 10; wf.gFin = c->gFin + skip * G_MAXOV * 10; wf.gOrd = c->gOrd + skip * G_MAXOV;
       wf.gCap = G_CAP; wf.gMaxOv = G_MAXOV;
-      if (threads == 512) launchTier<8192, 512, 512>(grid0, c->stream, q.base, bv, wf, qa);
-      else launchTier<8192, 512, 256>(grid0, c->stream, q.base, bv, wf, qa);
+      launchTier<8192, 512, 512>(grid0, c->stream, q.base, bv, wf, qa);
     }
     HIPCHK(c, hipGetLastError());
   }
@@ -1713,7 +1692,7 @@ int aqLaunch(t4_ctx *c) {
     // several hundred 100 KB-LDS workgroups still takes microseconds to come and go -- so they are sized for what recent calls needed.
     auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; };
     const int gParts = clampi(2 * c->wideRecentParts + 4, 4, cus * 2), gReads = clampi(2 * c->wideRecentReads + 2, 2, cus < 64 ? cus : 64);
-    hipLaunchKernelGGL(t4k::wideScatterKernel, dim3(clampi(2 * gParts, 8, cus * 4)), dim3(256), 0, c->stream, q.base, w);
+    hipLaunchKernelGGL(t4k::wideScatterKernel, dim3(clampi(8 * gParts, 16, cus * 8)), dim3(256), 0, c->stream, q.base, w);   // (a partition is planned for four of the kernel's chunks)
     hipLaunchKernelGGL((t4k::wideSortKernel<8192>), dim3(gParts), dim3(512), 0, c->stream, q.base, w);
     hipLaunchKernelGGL(t4k::wideStatsKernel, dim3(gReads), dim3(512), 0, c->stream, q.base, w);
     hipLaunchKernelGGL((t4k::wideChainKernel<8192, 1 << T4_WIDE_OVBITS>), dim3(gParts < cus ? gParts : cus), dim3(512), 0, c->stream, q.base, bv, wk, qa, w);
@@ -1973,8 +1952,7 @@ int t4_add_query_pool_begin(t4_index *ix, int n, const char *bases, const int64_
   t4_ctx *c = ix->ctx;
   if (!ix->committed) return fail(c, T4_ERR_STATE, "index not committed");
   if (ix->view.firstIsRef) return fail(c, T4_ERR_UNSUPPORTED, "t4_add_query needs a contig set");
-  static const bool leanOff = getenv("T4_LEAN_OFF") != nullptr;   // testing aid: exact ExtendOverlap records for the builder too
-  return aqBegin(c, ix->view, nullptr, nullptr, false, n, bases, offsets, barcodes, strands, skip_repeats, factors, tier_hint, !leanOff, only_seq);   // for t4_assembler: lean records (extendOverlaps)
+  return aqBegin(c, ix->view, nullptr, nullptr, false, n, bases, offsets, barcodes, strands, skip_repeats, factors, tier_hint, true, only_seq);   // for t4_assembler: lean records (extendOverlaps)
 }
 int t4_add_query_pool_done(t4_ctx *c) { return c ? aqDone(c) : 1; }
 int t4_add_query_pool_end(t4_ctx *c, const int32_t **counts, const int32_t **base, const t4_overlap **ov, const t4_overlap **ext, const int32_t **ext_ret) {

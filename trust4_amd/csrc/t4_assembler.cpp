@@ -588,7 +588,7 @@ struct t4_assembler : IndexListener {
   int64_t baseUsed = 0;            // device arena of consensus chars / posWeight predicate bytes (one offset space)
   std::vector<int> dirtySeqs;
   bool liveReset = true;           // the next delta describes the whole image (first upload, k change)
-  int64_t toleratedStable = 0, invLongLists = 0, slowSkipped = 0;
+  int64_t toleratedStable = 0, invLongLists = 0;
   int64_t wideServed = 0, wideGroupRecords = 0, wideMispredicted = 0;
   int64_t restrictedMarks = 0, restrictedMerged = 0, restrictedFallbacks = 0, restrictedStale = 0;
   bool restrictOn = true;
@@ -601,6 +601,20 @@ struct t4_assembler : IndexListener {
   int64_t deltas = 0, deltaBytes = 0, rounds = 0, readsQueried = 0, invKey = 0, invCross = 0, invRegion = 0, invShift = 0, invContig = 0, invFragile = 0, tolerated = 0;
   double secDelta = 0, secGroups = 0, secEvents = 0, secRegister = 0, secPrefetch = 0, secAddTotal = 0;
 
+  // testing / development aids, read from the environment ONCE per builder (none changes a result; DESIGN 7b lists them)
+  struct Knobs {
+    bool verifyWindow = false, noStableStats = false;
+    int lanes = 1, queryAhead = 0, minBatch = 4, harvestDelay = 0;
+    FILE *roundLog = nullptr;
+    Knobs() {
+      auto num = [](const char *n, int d) { const char *e = getenv(n); return e ? atoi(e) : d; };
+      verifyWindow = getenv("T4_VERIFY_WINDOW") != nullptr;     // every served window entry is queried again and compared
+      noStableStats = getenv("T4_NO_STABLE_STATS") != nullptr;  // A/B aid: the budget rule for every entry
+      lanes = num("T4_LIVE_LANES", 1); queryAhead = num("T4_QUERY_AHEAD", 0); minBatch = num("T4_LIVE_MIN_BATCH", 4); harvestDelay = num("T4_LIVE_HARVEST_DELAY", 0);
+      if (getenv("T4_ROUND_LOG")) roundLog = fopen(getenv("T4_ROUND_LOG"), "w");   // one line per launch: reads, kernel ms, per read us / overlaps / tier / killed in flight
+    }
+    ~Knobs() { if (roundLog) fclose(roundLog); }
+  } knobs;
   t4_assembler(t4_ctx *c, int kl) : ctx(c), k(kl), index(kl) { prevAdd.readStart = -1; index.hook = this; }
   ~t4_assembler() {
     abandonJobs();
@@ -661,8 +675,7 @@ struct t4_assembler : IndexListener {
     if (before == after) return;   // cannot be observed by a query: the image stays as it is
     const int pos = (int)(&w - seqs[seqIdx].pw.data());
     if (live()) { markBaseDirty(seqIdx, pos); evRegion(seqIdx, pos, pos + 1); return; }
-    static const bool noPatch = getenv("T4_NO_PATCH") != nullptr;   // debugging aid
-    if (!noPatch && owner && !dirty && slot >= 0) {   // the resident image only needs this byte
+    if (owner && !dirty && slot >= 0) {   // the resident image only needs this byte
       invalidateCell();
       patches.push_back(PwPatch{seqIdx, pos, (unsigned char)after});
       return;
@@ -870,8 +883,7 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
     }
     const int sl = order.front();
     Cached &c = *pool[sl];
-    static const bool verifyWindow = getenv("T4_VERIFY_WINDOW") != nullptr;
-    if (verifyWindow) { const int rc = verifyServed(c); if (rc) return -100 + rc; }
+    if (knobs.verifyWindow) { const int rc = verifyServed(c); if (rc) return -100 + rc; }
     cnt = c.cnt; ovBuf.swap(c.ov); extBuf.swap(c.ext); extRet.swap(c.extRet);
     order.pop_front();
     c.valid = false; c.partial = false; c.uid = 0; freeSlots.push_back(sl);   // its winKmers references are stale from here on
@@ -1323,7 +1335,7 @@ int t4_assembler::ensureLanes() {
   // further lanes does not shorten the chain -- the entry a commit invalidates is nearly always the next one to be served, so the
   // head waits for a whole query either way (17.9 k waits at 100 k pairs with 3 lanes against 17.8 k with one) -- while every
   // extra launch costs the one host thread its packing, delta and dependency-set time. The machinery stays for T4_LIVE_LANES > 1.
-  static const int nLanes = getenv("T4_LIVE_LANES") ? atoi(getenv("T4_LIVE_LANES")) : 1;
+  const int nLanes = knobs.lanes;
   lanes.resize(nLanes < 1 ? 1 : (nLanes > 8 ? 8 : nLanes));
   lanes[0].ctx = ctx;
   for (size_t i = 1; i < lanes.size(); ++i) {
@@ -1785,7 +1797,7 @@ int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive
   {   // what t4_add_query_pool_begin does with a heavy read under the testing aids of csrc/t4_api.hip
     wideQueries = !getenv("T4_WIDE_OFF") && !getenv("T4_AQ_FORCE_GLOBAL");
     const int lim = getenv("T4_AQ_CAP_LIMIT") ? atoi(getenv("T4_AQ_CAP_LIMIT")) : 0;
-    wideHitLimit = lim > 0 ? lim : (getenv("T4_WIDE_MIN_HITS") ? atoi(getenv("T4_WIDE_MIN_HITS")) : 32768);
+    wideHitLimit = lim > 0 ? lim : (getenv("T4_WIDE_MIN_HITS") ? atoi(getenv("T4_WIDE_MIN_HITS")) : 8192);
   }
   L.slots = todo; L.uids.resize(m); L.hint.resize(m); L.bcs.resize(m); L.sts.resize(m); L.fac.resize(m); L.only.resize(m);
   L.bases.clear(); L.offs.assign(1, 0); L.repetitive = repetitive;
@@ -1862,7 +1874,7 @@ int t4_assembler::harvest(Lane &L) {
     dropWindow();
     return rc;
   }
-  static FILE *roundLog = getenv("T4_ROUND_LOG") ? fopen(getenv("T4_ROUND_LOG"), "w") : nullptr;   // development aid: one line per launch -- reads, kernel ms, per read: us in its workgroup / overlaps / tier / killed in flight
+  FILE *roundLog = knobs.roundLog;
   if (roundLog) {
     double ms = 0; const int32_t *ticks = nullptr; int nn = 0;
     t4_add_query_last_call(L.ctx, &ms, &ticks, &nn);
@@ -1873,7 +1885,7 @@ int t4_assembler::harvest(Lane &L) {
   const int32_t *ticks10ns = nullptr; int nTicks = 0;
   { double ms_ = 0; (void)t4_add_query_last_call(L.ctx, &ms_, &ticks10ns, &nTicks); }
   const int32_t *stable = nullptr; int nStable = 0;
-  static const bool noStable = getenv("T4_NO_STABLE_STATS") != nullptr;   // A/B aid: the slack rule for every entry, as before round 3
+  const bool noStable = knobs.noStableStats;
   if (!noStable) (void)t4_add_query_last_stable(L.ctx, &stable, &nStable);
   const int32_t *aux = nullptr, *n4s = nullptr, *qstatus = nullptr; int nAux = 0;
   (void)t4_add_query_last_aux(L.ctx, &aux, &n4s, &qstatus, &nAux);
@@ -1909,7 +1921,6 @@ int t4_assembler::harvest(Lane &L) {
     }
     c.tier = L.hint[i];
     if (ticks10ns && i < nTicks) c.lastUs = ticks10ns[i] / 100;
-    { static const bool proxy = getenv("T4_SLOW_PROXY") != nullptr; if (proxy) c.lastUs = 50 + 12 * (cnts[i] > 0 ? cnts[i] : 0); }   // testing aid (the emulator has no clock): a time from the overlap count
     c.statsStable = stable && i < nStable && stable[i] == 1;
     if (c.killed) { c.killed = false; c.shifts.clear(); ++killedInFlight; continue; }
     c.cnt = cnts[i];
@@ -1948,15 +1959,13 @@ int t4_assembler::harvest(Lane &L) {
 int t4_assembler::pumpLive(bool needHead, int repetitive) {
   int rc;
   if ((rc = ensureLanes())) return rc;
-  static const int fixedAhead = getenv("T4_QUERY_AHEAD") ? atoi(getenv("T4_QUERY_AHEAD")) : 0;
-  static const int minBatch = getenv("T4_LIVE_MIN_BATCH") ? atoi(getenv("T4_LIVE_MIN_BATCH")) : 4;
-  static const bool syncMode = getenv("T4_LIVE_SYNC") != nullptr;   // testing aid: every launch is waited for at once (the round structure of round 2)
+  const int fixedAhead = knobs.queryAhead, minBatch = knobs.minBatch;
   // Entries far behind the head rarely survive until they are consumed: (re-)query only as far ahead as a few times what a launch
   // for the head has recently served (every read queried adds to the latency of the launch: it ends with its slowest read)
   const size_t ahead = fixedAhead > 0 ? (size_t)fixedAhead : (lanes.size() > 1 ? 24 : (size_t)(3.0 * runEma) + 12);
   for (;;) {
     // T4_LIVE_HARVEST_DELAY=n (testing aid): a finished launch is only noticed n calls later, so that commits pile up against queries in flight
-    static const int harvestDelay = getenv("T4_LIVE_HARVEST_DELAY") ? atoi(getenv("T4_LIVE_HARVEST_DELAY")) : 0;
+    const int harvestDelay = knobs.harvestDelay;
     for (Lane &L : lanes) if (L.busy && ++L.polls > harvestDelay && t4_add_query_pool_done(L.ctx)) { if ((rc = harvest(L))) return rc; }
     if (order.empty()) return T4_OK;
     if (index.total == 0) {   // an empty set has no hit for anybody
@@ -1970,15 +1979,9 @@ int t4_assembler::pumpLive(bool needHead, int repetitive) {
     }
     Cached &head = *pool[order.front()];
     std::vector<int> light, heavy;
-    // A launch ends with its slowest read. A read whose last query was slow is therefore left out of launches made for reads well
-    // before it: it joins one when it is about to be served (and is then not re-queried each time a commit far ahead of it
-    // invalidates it).
-    static const int slowUs = getenv("T4_SLOW_US") ? atoi(getenv("T4_SLOW_US")) : 0;
-    static const size_t slowAhead = getenv("T4_SLOW_AHEAD") ? (size_t)atoi(getenv("T4_SLOW_AHEAD")) : 3;
     for (size_t i = 0; i < order.size() && i < ahead; ++i) {
       Cached &c = *pool[order[i]];
       if (c.valid || c.inflight) continue;
-      if (slowUs > 0 && i >= slowAhead && c.lastUs > slowUs) { ++slowSkipped; continue; }
       // two classes of work: restricted re-queries (one contig of an entry that keeps the rest: tens of microseconds) and whole
       // queries (hundreds; a read the wide query serves, more). With two lanes the head's restricted re-query does not wait for
       // the whole queries of the entries behind it.
@@ -2009,7 +2012,7 @@ int t4_assembler::pumpLive(bool needHead, int repetitive) {
       if ((rc = launchOn(*free1, all, repetitive))) return rc;
       launched = true;
     }
-    if (syncMode && launched) { for (Lane &L : lanes) if (L.busy && (rc = harvest(L))) return rc; continue; }
+    (void)launched;
     if (!needHead || pool[order.front()]->valid) return T4_OK;
     if (pool[order.front()]->inflight) {   // wait for the lane that carries the head
       auto tw0 = std::chrono::steady_clock::now();
@@ -2248,7 +2251,6 @@ int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n) {
             a->secAddTotal, a->secPrefetch, a->secLaunch, a->secDelta, a->secGroups, a->secRegister, a->secHarvest, a->secEvents, a->index.secOps);
     fprintf(stderr, "timing: query lanes %d: %lld launches (%lld for a head without a result), %lld waits for the head's lane in %.3f s, %lld queries killed in flight\n",
             (int)a->lanes.size(), (long long)a->launches, (long long)a->launchesUrgent, (long long)a->headWaits, a->secHeadWait, (long long)a->killedInFlight);
-    if (a->slowSkipped) fprintf(stderr, "timing: %lld times a read whose last query was slow stayed out of a launch made for reads before it\n", (long long)a->slowSkipped);
     fprintf(stderr, "timing: tolerated index edits %lld, of which %lld met an entry whose group statistics cannot move (no budget spent); tolerance kills %lld, of which %lld for lists beyond 10000 postings\n",
             (long long)a->tolerated, (long long)a->toleratedStable, (long long)a->invFragile, (long long)a->invLongLists);
     fprintf(stderr, "timing: restricted re-queries: %lld entries kept their other contigs when one contig changed, %lld merged, %lld fell back to the whole query, %lld in flight met another change of their contig\n",

@@ -74,60 +74,81 @@ __device__ T4_NI void wideDeferRead(const T4IndexView &ix, WaveMem &wm, WaveStat
 __device__ __forceinline__ int wideReads(const T4Wide &wd) { const int n = wd.ctl[0]; return n < wd.maxReads ? n : wd.maxReads; }
 __device__ __forceinline__ int wideParts(const T4Wide &wd) { const int n = wd.ctl[1]; return n < wd.maxPart ? n : wd.maxPart; }
 
-// postings -> keys -> partitions. A block takes chunks of 4096 postings of every deferred read.
+// postings -> keys -> partitions. A work item is a chunk of 1024 postings of one deferred read; the items of all reads form one list
+// that the blocks stride over (a round's latency is what counts: every thread issues its four gathers before the first of the
+// dependent atomics, and no block walks one read's chunks one after the other).
+#define T4_WIDE_CH 1024u
 __global__ __launch_bounds__(256) void wideScatterKernel(T4IndexView ix, T4Wide wd) {
   __shared__ unsigned s_pref[T4_WIDE_SEEDS];
   __shared__ unsigned s_start[T4_WIDE_SEEDS];
+  __shared__ int s_item[2];
   if (wd.ctl[2]) return;
   const int nR = wideReads(wd), lane = threadIdx.x, NT = blockDim.x;
-  const unsigned CH = 4096u;
-  for (int w = 0; w < nR; ++w) {
+  int loaded = -1;
+  for (unsigned item = blockIdx.x;; item += gridDim.x) {
+    __syncthreads();
+    if (lane == 0) {   // which read, which of its chunks (a few dozen reads at most: a walk)
+      unsigned left = item;
+      int w = 0;
+      for (; w < nR; ++w) {
+        const T4WidePlan pw = wd.plan[w];
+        const unsigned nCh = pw.P > 0 ? (pw.H + T4_WIDE_CH - 1u) / T4_WIDE_CH : 0u;
+        if (left < nCh) break;
+        left -= nCh;
+      }
+      s_item[0] = w < nR ? w : -1; s_item[1] = (int)left;
+    }
+    __syncthreads();
+    const int w = s_item[0];
+    if (w < 0) break;
+    const unsigned chunk = (unsigned)s_item[1];
     const T4WidePlan pl = wd.plan[w];
-    if (pl.P <= 0) continue;
-    const unsigned nChunks = (pl.H + CH - 1u) / CH;
-    if (blockIdx.x >= nChunks) continue;   // uniform over the block
     const int nq = 2 * pl.nk;
-    __syncthreads();
-    const uint2 *sd = wd.seed + (size_t)w * T4_WIDE_SEEDS;
-    for (int q = lane; q <= nq; q += NT) { const uint2 v = sd[q]; s_start[q] = v.x; s_pref[q] = v.y; }
-    __syncthreads();
-    for (unsigned chunk = blockIdx.x; chunk < nChunks; chunk += gridDim.x) {
-      const unsigned end = (chunk + 1u) * CH < pl.H ? (chunk + 1u) * CH : pl.H;
-      for (unsigned s0 = chunk * CH; s0 < end; s0 += (unsigned)NT) {   // (uniform trip count: the wave-wide votes below need every lane)
-        const unsigned s = s0 + (unsigned)lane;
-        const bool has = s < end;
-        unsigned long long key = 0;
-        int p = -1;
-        if (has) {
-          int lo = 0, hi = nq - 1;   // last q with pref[q] <= s
-          while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pref[mid] <= s) lo = mid; else hi = mid - 1; }
-          const int q = lo;
-          const int2 po = ix.post[s_start[q] + (s - s_pref[q])];
-          const int st = q >= pl.nk, a = st ? q - pl.nk : q;
-          key = ((st ? 0ull : 1ull) << 63) | ((unsigned long long)po.x << (T4_C_BITS + T4_B_BITS)) |
-                ((unsigned long long)(a - po.y + T4_C_BIAS) << T4_B_BITS) | (unsigned long long)po.y;
-          p = po.x / pl.Wd;
-          if (p >= pl.P) p = pl.P - 1;
+    if (w != loaded) {
+      const uint2 *sd = wd.seed + (size_t)w * T4_WIDE_SEEDS;
+      for (int q = lane; q <= nq; q += NT) { const uint2 v = sd[q]; s_start[q] = v.x; s_pref[q] = v.y; }
+      loaded = w;
+      __syncthreads();
+    }
+    const unsigned s0 = chunk * T4_WIDE_CH, end = s0 + T4_WIDE_CH < pl.H ? s0 + T4_WIDE_CH : pl.H;
+    unsigned long long key[4];
+    int part[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const unsigned s = s0 + (unsigned)(t * 256 + lane);
+      part[t] = -1; key[t] = 0;
+      if (s < end) {
+        int lo = 0, hi = nq - 1;   // last q with pref[q] <= s
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_pref[mid] <= s) lo = mid; else hi = mid - 1; }
+        const int q = lo;
+        const int2 po = ix.post[s_start[q] + (s - s_pref[q])];
+        const int st = q >= pl.nk, a = st ? q - pl.nk : q;
+        key[t] = ((st ? 0ull : 1ull) << 63) | ((unsigned long long)po.x << (T4_C_BITS + T4_B_BITS)) |
+                 ((unsigned long long)(a - po.y + T4_C_BIAS) << T4_B_BITS) | (unsigned long long)po.y;
+        int p = po.x / pl.Wd;
+        part[t] = p >= pl.P ? pl.P - 1 : p;
+      }
+    }
+    // one atomic per (wavefront, partition) instead of one per posting: consecutive postings of a list belong to neighbouring
+    // contigs, i.e. mostly to one partition
+    const int wl = lane & 63;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bool has = part[t] >= 0;
+      unsigned long long todo = __ballot(has);
+      while (todo) {
+        const int leader = __ffsll(todo) - 1;
+        const int p0 = __shfl(part[t], leader);
+        const unsigned long long same = __ballot(has && part[t] == p0);
+        unsigned base = 0;
+        if (wl == leader) base = atomicAdd(&wd.pCnt[pl.pBase + p0], (unsigned)__popcll(same));
+        base = __shfl(base, leader);
+        if (has && part[t] == p0) {
+          const unsigned at = base + (unsigned)__popcll(same & ((1ull << wl) - 1ull));
+          if (at < (unsigned)wd.pcap) wd.pKeys[(size_t)(pl.pBase + p0) * wd.pcap + at] = key[t];
+          else atomicOr(&wd.ctl[2], 4);
         }
-        // One atomic per (wavefront, partition) instead of one per posting: consecutive postings of a list belong to neighbouring
-        // contigs, i.e. mostly to one partition -- 4096 lanes adding to a handful of counters one by one was the whole kernel
-        // (77 us per launch, profiles/r04b_*).
-        const int wl = lane & 63;
-        unsigned long long todo = __ballot(has);
-        while (todo) {
-          const int leader = __ffsll(todo) - 1;
-          const int p0 = __shfl(p, leader);
-          const unsigned long long same = __ballot(has && p == p0);
-          unsigned base = 0;
-          if (wl == leader) base = atomicAdd(&wd.pCnt[pl.pBase + p0], (unsigned)__popcll(same));
-          base = __shfl(base, leader);
-          if (has && p == p0) {
-            const unsigned at = base + (unsigned)__popcll(same & ((1ull << wl) - 1ull));
-            if (at < (unsigned)wd.pcap) wd.pKeys[(size_t)(pl.pBase + p0) * wd.pcap + at] = key;
-            else atomicOr(&wd.ctl[2], 4);
-          }
-          todo &= ~same;
-        }
+        todo &= ~same;
       }
     }
   }
@@ -154,20 +175,21 @@ __global__ __launch_bounds__(512) void wideSortKernel(T4IndexView ix, T4Wide wd)
     __syncthreads();
     for (int i = lane; i < n; i += NT) gk[i] = s_keys[i];
     // groups
-    int nG = 0, nMinusKeys = 0, nMinusGroups = 0;
+    int nG = 0;
     for (int i0 = 0; i0 < n; i0 += NT) {
       const int i = i0 + lane;
       const bool st = i < n && (i == 0 || KEY_G(s_keys[i]) != KEY_G(s_keys[i - 1]));
-      const bool minus = i < n && !KEY_PLUS(s_keys[i]);
       int tot;
       const int inc = blockInclScan(st ? 1 : 0, s_red, tot);
       if (st) s_gs[nG + inc - 1] = (unsigned)i;
       nG += tot;
-      nMinusKeys += blockSum(minus ? 1 : 0, s_red);
-      nMinusGroups += blockSum(st && minus ? 1 : 0, s_red);
     }
     if (lane == 0) s_gs[nG] = (unsigned)n;
     __syncthreads();
+    // the keys of the minus strand sort first: their number, and that of their groups, by bisection
+    int nMinusKeys, nMinusGroups;
+    { int lo = 0, hi = n; while (lo < hi) { const int mid = (lo + hi) >> 1; if (KEY_PLUS(s_keys[mid])) hi = mid; else lo = mid + 1; } nMinusKeys = lo; }
+    { int lo = 0, hi = nG; while (lo < hi) { const int mid = (lo + hi) >> 1; if ((int)s_gs[mid] >= nMinusKeys) hi = mid; else lo = mid + 1; } nMinusGroups = lo; }
     unsigned short *gz = wd.gSize + (size_t)pg * wd.pcap;
     for (int g = lane; g < nG; g += NT) gz[g] = (unsigned short)(s_gs[g + 1] - s_gs[g]);
     if (lane == 0) { int *gc = wd.gCount + (size_t)pg * 4; gc[0] = nMinusGroups; gc[1] = nG - nMinusGroups; gc[2] = nMinusKeys; gc[3] = 0; }

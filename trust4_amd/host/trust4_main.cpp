@@ -258,7 +258,7 @@ bool compReadWithBarcode(const SortRead &a, const SortRead &b) {   // main.cpp:1
 // list goes through std::sort itself, as before.
 template <class Less> void sortReadsOnThreads(std::vector<SortRead> &v, int threads, Less less, bool orderIsStrict = true) {
   const size_t n = v.size();
-  static const size_t minN = getenv("T4_SORT_MIN") ? (size_t)atoll(getenv("T4_SORT_MIN")) : 65536;   // testing aid: small inputs through the threaded path
+  const size_t minN = getenv("T4_SORT_MIN") ? (size_t)atoll(getenv("T4_SORT_MIN")) : 65536;   // testing aid: small inputs through the threaded path
   const size_t minChunk = minN / 64 > 8 ? minN / 64 : 8;
   if (threads <= 1 || n < minN || n < 2 * minChunk || !orderIsStrict) { std::sort(v.begin(), v.end(), less); return; }
   // sample sort of the permutation: splitters from a sorted sample, every element classified against them (a binary search), the
@@ -649,7 +649,7 @@ int main(int argc, char *argv[]) {
   std::vector<int> barcodePairCount;   // main.cpp:822-828 (only counted under --contigMinCov)
   {
     ThreadedSeqReader::Block bR, bM, bB, bU;
-    auto uneven = [&](const char *what) { fprintf(stderr, "%s\n", what); if (processThread.joinable()) processThread.join(); initThread.join(); exit(1); };
+    auto uneven = [&](const char *what) { fprintf(stderr, "%s\n", what); if (processThread.joinable()) processThread.join(); if (initThread.joinable()) initThread.join(); exit(1); };
     while (reads.nextBlock(bR)) {
       Unit u;
       u.r.swap(bR);
@@ -685,7 +685,7 @@ int main(int argc, char *argv[]) {
       for (size_t i = 0; i < n; ++i) if (!u.skip[i]) {
         if (firstReadLen == -1) {
           firstReadLen = (int)u.r[i].seq.size();
-          if (firstReadLen > 200) { fprintf(stderr, "trust4-hip: long-read mode (first read > 200 bp, main.cpp:1467-1481) is not built.\n"); if (processThread.joinable()) processThread.join(); initThread.join(); return EXIT_FAILURE; }
+          if (firstReadLen > 200) { fprintf(stderr, "trust4-hip: long-read mode (first read > 200 bp, main.cpp:1467-1481) is not built.\n"); if (processThread.joinable()) processThread.join(); if (initThread.joinable()) initThread.join(); return EXIT_FAILURE; }
         }
         ++kept;
       }
@@ -707,7 +707,7 @@ int main(int argc, char *argv[]) {
   for (const SortRead &r : sortedReads) if ((int)r.read.size() > maxReadLen) maxReadLen = (int)r.read.size();
   kmerCount.maxReadLen = maxReadLen;   // KmerCount::SetBuffer (main.cpp:979)
   if (!kmerCountFile.empty()) {   // -c: counts come from a k-mer counter's dump instead (main.cpp:694-699)
-    if (!kmerCount.addCountFromFile(kmerCountFile.c_str())) { fprintf(stderr, "Could not open %s\n", kmerCountFile.c_str()); initThread.join(); return EXIT_FAILURE; }
+    if (!kmerCount.addCountFromFile(kmerCountFile.c_str())) { fprintf(stderr, "Could not open %s\n", kmerCountFile.c_str()); if (initThread.joinable()) initThread.join(); return EXIT_FAILURE; }
     PrintLog("Read in the kmer count information from %s", kmerCountFile.c_str());
   }
   // The 21-mer counts and the count statistics on the device (t4_kmer_count_*). The device path takes: reads of at most 384 bp over
@@ -734,10 +734,10 @@ int main(int argc, char *argv[]) {
   bool gpuKmerCounts = false;   // the device path was taken: the barcode-wise counts follow it
   // Default since round 3 (1 M barcoded pairs: 23.9 -> 21.2 s, profiles/r03l_*): on the device whenever the input is what the device
   // path takes; T4_GPU_KMERCOUNT=0 keeps the host threads, =1 insists (and says why it cannot).
-  bool wantGpuKc = false;
+  bool wantGpuKc = false, insistGpuKc = false;
   if (readCnt > 0) {
     const char *ev = getenv("T4_GPU_KMERCOUNT");
-    if (ev) wantGpuKc = atoi(ev) != 0;
+    if (ev) { wantGpuKc = atoi(ev) != 0; insistGpuKc = wantGpuKc; }
     else {
       std::atomic<long long> nQualA(0);
       std::atomic<bool> other(false);
@@ -755,24 +755,36 @@ int main(int argc, char *argv[]) {
     size_t nQual = 0;
     long long kmers = 0;
     for (const SortRead &r : sortedReads) { if (r.hasQual) ++nQual; if ((int)r.read.size() >= 21) kmers += (long long)r.read.size() - 20; }
-    if (maxReadLen > 384) { fprintf(stderr, "trust4-hip: T4_GPU_KMERCOUNT takes reads of at most 384 bp (longest here: %d)\n", maxReadLen); initThread.join(); return EXIT_FAILURE; }
-    if (trimLevel != 0 && nQual != 0 && nQual != sortedReads.size()) { fprintf(stderr, "trust4-hip: T4_GPU_KMERCOUNT needs qualities on every read or on none\n"); initThread.join(); return EXIT_FAILURE; }
+    if (maxReadLen > 384) { fprintf(stderr, "trust4-hip: T4_GPU_KMERCOUNT takes reads of at most 384 bp (longest here: %d)\n", maxReadLen); if (initThread.joinable()) initThread.join(); return EXIT_FAILURE; }
+    if (trimLevel != 0 && nQual != 0 && nQual != sortedReads.size()) { fprintf(stderr, "trust4-hip: T4_GPU_KMERCOUNT needs qualities on every read or on none\n"); if (initThread.joinable()) initThread.join(); return EXIT_FAILURE; }
     gpuQual = trimLevel != 0 && nQual == sortedReads.size();
     gpuKmerCounts = true;
     gpuReady();
     if (!kmerCountFile.empty()) { kmers = 16; for (const auto &m : kmerCount.shards) kmers += (long long)m.size(); }
-    if ((rc = t4_kmer_count_create(ctx, 21, kmers + 16 < (1ll << 30) ? kmers + 16 : (1ll << 30), 0, &gpuKc))) die(ctx, "t4_kmer_count_create", rc);
+    // The table is sized for every k-mer position (an upper bound of the distinct k-mers), at most 2^30 of them. When the device path
+    // was chosen by default (not by T4_GPU_KMERCOUNT=1) and the table cannot be had or fills up -- a shared or smaller GPU, more than
+    // 2^30 distinct 21-mers -- the counts are taken on the host threads as before round 3, with a note; =1 insists and stops.
+    const char *why = nullptr;
+    rc = t4_kmer_count_create(ctx, 21, kmers + 16 < (1ll << 30) ? kmers + 16 : (1ll << 30), 0, &gpuKc);
+    if (rc) why = "t4_kmer_count_create";
     std::string bases; std::vector<int64_t> off;
-    if (!kmerCountFile.empty()) {   // -c: the counts parsed from the file above, as they are (t4_kmer_count_set)
+    if (!why && !kmerCountFile.empty()) {   // -c: the counts parsed from the file above, as they are (t4_kmer_count_set)
       std::vector<uint64_t> codes; std::vector<int32_t> vals;
       for (const auto &m : kmerCount.shards) for (const auto &kv : m) { codes.push_back(kv.first); vals.push_back(kv.second); }
-      if ((rc = t4_kmer_count_set(gpuKc, codes.data(), vals.data(), (int64_t)codes.size()))) die(ctx, "t4_kmer_count_set", rc);
-    } else
-    for (size_t lo = 0; lo < sortedReads.size(); lo += KC_CHUNK) {
+      if ((rc = t4_kmer_count_set(gpuKc, codes.data(), vals.data(), (int64_t)codes.size()))) why = "t4_kmer_count_set";
+    } else if (!why)
+    for (size_t lo = 0; lo < sortedReads.size() && !why; lo += KC_CHUNK) {
       const size_t hi = lo + KC_CHUNK < sortedReads.size() ? lo + KC_CHUNK : sortedReads.size();
       t4_batch *b = uploadChunk(lo, hi, bases, off);
-      if ((rc = t4_kmer_count_add(gpuKc, b))) die(ctx, "t4_kmer_count_add", rc);
+      if ((rc = t4_kmer_count_add(gpuKc, b))) why = "t4_kmer_count_add";
       t4_batch_destroy(b);
+    }
+    if (why) {
+      if (insistGpuKc) die(ctx, why, rc);
+      fprintf(stderr, "trust4-hip: 21-mer counts on the host threads (%s: %s)\n", why, t4_last_error(ctx));
+      if (gpuKc) { t4_kmer_count_destroy(gpuKc); gpuKc = nullptr; }
+      gpuKmerCounts = false; gpuQual = false;
+      if (kmerCountFile.empty()) kmerCount.addCountAll((long long)sortedReads.size(), threadCnt, [&](long long i) -> const std::string & { return sortedReads[(size_t)i].read; });
     }
   } else if (kmerCountFile.empty())
   kmerCount.addCountAll((long long)sortedReads.size(), threadCnt, [&](long long i) -> const std::string & { return sortedReads[(size_t)i].read; });
