@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 4, session k: C2 with the wide query from 4096 / 2048 emitted hits
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out/r4k; mkdir -p $O
+W=/tmp/w4k; mkdir -p $W; zcat data/hg38_bcrtcr.fa.gz > $W/ref.fa
+run() {
+  local name=$1 pre=$2 lim=$3; shift; shift; shift
+  ( time env T4_TIMING=1 T4_STATS_JSON=$O/stats_$name.json "$@" timeout $lim trust4_amd/bin/trust4-hip -t 8 --skipMateExtension -f $W/ref.fa -1 ${pre}_1.fq -2 ${pre}_2.fq -o $W/m_$name ) > $O/log_$name.txt 2>&1
+  md5sum $W/m_${name}_raw.out $W/m_${name}_assembled_reads.fa >> $O/log_$name.txt
+  echo "== $name: $(grep -h 'real' $O/log_$name.txt | tr '\n' ' ') $(grep -o 'GPU query rounds [0-9]* with [0-9]* reads' $O/log_$name.txt) $(grep -o 'wide query served [0-9]* window entries' $O/log_$name.txt)"
+  grep -o 'assembler host seconds.*' $O/log_$name.txt | cut -c1-300
+  grep -o '"kernel_ms": [0-9.]*' $O/stats_$name.json | tail -1
+  tail -2 $O/log_$name.txt | cut -c1-34
+}
+tools/t4synth $W/ref.fa 1000000 20000 1 $W/c2 > /dev/null
+run c2_w4k $W/c2 600 T4_WIDE_MIN_HITS=4096
+run c2_w2k $W/c2 600 T4_WIDE_MIN_HITS=2048

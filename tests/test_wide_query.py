@@ -78,6 +78,36 @@ def add_query(eng, ix, reads, strands, factors, room):
     return cnt, ov, ex, ret
 
 
+def add_query_pool(eng, ix, reads, strands, factors, hints):
+    """t4_add_query_pool (lean records, variable-size results) with per-read hints: a hinted read starts on the second stream
+    (wideSeedKernel) and its wide query runs beside the round's query kernel -> (counts, list of (ov, ext, ret) arrays per read)"""
+    from trust4_amd.api import OV_DTYPE
+    n = len(reads)
+    P = C.c_void_p
+    bases = "".join(reads).encode()
+    offs = np.zeros(n + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    st = np.asarray(strands, dtype=np.int32)
+    fac = np.asarray(factors, dtype=np.float64)
+    hint = np.asarray(hints, dtype=np.uint8).copy()
+    pc, pb, po, pe, pr = P(), P(), P(), P(), P()
+    eng.check(eng.lib.t4_add_query_pool(ix.h, n, bases, offs.ctypes.data_as(P), None, st.ctypes.data_as(P), 0, fac.ctypes.data_as(P), C.byref(pc), C.byref(pb), C.byref(po),
+                                        C.byref(pe), C.byref(pr), hint.ctypes.data_as(P)))
+    cnt = np.ctypeslib.as_array(C.cast(pc, C.POINTER(C.c_int32)), (n,)).copy()
+    base = np.ctypeslib.as_array(C.cast(pb, C.POINTER(C.c_int32)), (n,)).copy()
+    out = []
+    for i in range(n):
+        k = max(int(cnt[i]), 0)
+        if not k:
+            out.append(None)
+            continue
+        ov = np.frombuffer((C.c_char * (40 * k)).from_address(po.value + 40 * int(base[i])), dtype=OV_DTYPE, count=k).copy()
+        ex = np.frombuffer((C.c_char * (40 * k)).from_address(pe.value + 40 * int(base[i])), dtype=OV_DTYPE, count=k).copy()
+        ret = np.ctypeslib.as_array(C.cast(pr, C.POINTER(C.c_int32)), (int(base[i]) + k,))[int(base[i]):].copy()
+        out.append((ov, ex, ret))
+    return cnt, out, hint
+
+
 class Grp(C.Structure):
     _fields_ = [("key", C.c_uint32), ("cnt", C.c_uint32), ("lo", C.c_int32), ("hi", C.c_int32)]
 
@@ -167,6 +197,20 @@ def run_wide_cases(monkeypatch, make_engine, n_contigs=240, n_reads=14, pcap=256
         monkeypatch.delenv("T4_WIDE_OFF")
         cnt1, ov1, ex1, ret1 = add_query(eng, ix, reads, strands, factors, n_contigs + 16)
         assert (cnt1 == cnt2).all() and (ov1 == ov2).all() and (ex1 == ex2).all() and (ret1 == ret2).all()
+        # hints: the first call learns which reads are heavy, the second starts those on the second stream -- the same records either way
+        c0, r0, h0 = add_query_pool(eng, ix, reads, strands, factors, [0] * len(reads))
+        assert h0.sum() >= n_reads // 2          # (the call marks the reads the wide query served)
+        before = wide_stats(eng)[0]
+        c1, r1, h1 = add_query_pool(eng, ix, reads, strands, factors, h0)
+        assert wide_stats(eng)[0] - before == h0.sum() and (h1 == h0).all()
+        assert (c0 == c1).all() and (c0 == cnt1).all()
+        for a, b in zip(r0, r1):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert (a[0] == b[0]).all() and (a[1] == b[1]).all() and (a[2] == b[2]).all()
+        for i in range(len(reads)):
+            if h0[i]:
+                assert groups_of(eng, i)[0] == expected_groups(o, reads[i], int(strands[i])), (i, "dependency records of a hinted read")
     st = wide_stats(eng)
     assert st[0] > 0 and st[1] > st[0] and st[2] > 0, st   # reads, partitions (several per read), calls repeated with larger pools
     return st

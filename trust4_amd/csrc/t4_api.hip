@@ -68,7 +68,7 @@ struct AqCall {
   int n = 0, skipRepeats = 0, wpk = 0, wnm = 0, attempt = 0, nFirst = 0, nDirect = 0, threads = 512;
   unsigned char *tierHint = nullptr;
   std::vector<unsigned char> allGlobal;
-  size_t oPk, oNm, oLen, oBc, oSt, oLs, oVw, oFa, oOnly, oWide, inBytes, pCnt, pSta, pNext, pNext2, pBase, pTick, pStab, pAux, pN4, pTail, pWctl, pWplan, pWstat, outBytes;
+  size_t oPk, oNm, oLen, oBc, oSt, oLs, oVw, oFa, oOnly, oWide, oWideA, inBytes, pCnt, pSta, pNext, pNext2, pBase, pTick, pStab, pAux, pN4, pTail, pWctl, pWplan, pWstat, pWctlA, pWplanA, pWstatA, outBytes;
   bool hasOnly = false;
   bool extendLater = false, wide = false;
   int wideSafety = 32;   // of sixteenths: partitions are planned for half of their capacity
@@ -257,25 +257,26 @@ int ensureWide(t4_ctx *c, int reads, int parts, int groups) {
   if (reads > w.maxReads) {
     int n = w.maxReads > 0 ? w.maxReads : 64;
     while (n < reads) n *= 2;
-    if ((r = devAlloc(c, &w.seed, (size_t)n * T4_WIDE_SEEDS))) return r;
-    if ((r = devAlloc(c, &w.uniqPref, (size_t)n * (w.pcap + 1)))) return r;
-    if ((r = devAlloc(c, &w.sortTmp, (size_t)n * 2 * w.pcap))) return r;
+    if ((r = devAlloc(c, &w.seed, 2 * (size_t)n * T4_WIDE_SEEDS))) return r;   // (two of everything: wideHalf)
+    if ((r = devAlloc(c, &w.uniqPref, 2 * (size_t)n * (w.pcap + 1)))) return r;
+    if ((r = devAlloc(c, &w.sortTmp, 2 * (size_t)n * 2 * w.pcap))) return r;
     w.maxReads = n;
   }
   if (parts > w.maxPart) {
     int n = w.maxPart > 0 ? w.maxPart : wideEnv("T4_WIDE_PARTS", 1024);
     while (n < parts) n *= 2;
-    if ((r = devAlloc(c, &w.pCnt, (size_t)n))) return r;
-    if ((r = devAlloc(c, &w.pRead, (size_t)n))) return r;
-    if ((r = devAlloc(c, &w.pKeys, (size_t)n * w.pcap))) return r;
-    if ((r = devAlloc(c, &w.gSize, (size_t)n * w.pcap))) return r;
-    if ((r = devAlloc(c, &w.gInfo, (size_t)n * w.pcap))) return r;
-    if ((r = devAlloc(c, &w.gCount, (size_t)n * 4))) return r;
-    if ((r = devAlloc(c, &w.gOff, (size_t)n * 2))) return r;
-    if ((r = devAlloc(c, &w.pRec, (size_t)n * w.maxOvPart * 10))) return r;
-    if ((r = devAlloc(c, &w.pRecCnt, (size_t)n))) return r;
-    if ((r = devAlloc(c, &w.mKeys, (size_t)n * w.maxOvPart))) return r;
-    if ((r = devAlloc(c, &w.mOrd, (size_t)n * w.maxOvPart))) return r;
+    const size_t n2 = 2 * (size_t)n;
+    if ((r = devAlloc(c, &w.pCnt, n2))) return r;
+    if ((r = devAlloc(c, &w.pRead, n2))) return r;
+    if ((r = devAlloc(c, &w.pKeys, n2 * w.pcap))) return r;
+    if ((r = devAlloc(c, &w.gSize, n2 * w.pcap))) return r;
+    if ((r = devAlloc(c, &w.gInfo, n2 * w.pcap))) return r;
+    if ((r = devAlloc(c, &w.gCount, n2 * 4))) return r;
+    if ((r = devAlloc(c, &w.gOff, n2 * 2))) return r;
+    if ((r = devAlloc(c, &w.pRec, n2 * w.maxOvPart * 10))) return r;
+    if ((r = devAlloc(c, &w.pRecCnt, n2))) return r;
+    if ((r = devAlloc(c, &w.mKeys, n2 * w.maxOvPart))) return r;
+    if ((r = devAlloc(c, &w.mOrd, n2 * w.maxOvPart))) return r;
     w.maxPart = n;
   }
   if (groups > w.grpCap) {
@@ -283,11 +284,23 @@ int ensureWide(t4_ctx *c, int reads, int parts, int groups) {
     while (n < groups) n *= 2;
     if (c->grpPoolHost) (void)hipHostFree(c->grpPoolHost);
     c->grpPoolHost = nullptr; w.grpPool = nullptr;
-    HIPCHK(c, hipHostMalloc(&c->grpPoolHost, sizeof(T4Grp) * (size_t)n, hipHostMallocMapped));
+    HIPCHK(c, hipHostMalloc(&c->grpPoolHost, sizeof(T4Grp) * 2 * (size_t)n, hipHostMallocMapped));
     HIPCHK(c, hipHostGetDevicePointer((void **)&w.grpPool, c->grpPoolHost, 0));
     w.grpCap = n;
   }
   return T4_OK;
+}
+// The pools hold two pipelines' worth: half 0 serves the reads the round's query kernel defers, half 1 the reads that were known to
+// be heavy and started on the second stream (wideSeedKernel).
+T4Wide wideHalf(const t4_ctx *c, int half) {
+  T4Wide w = c->wide;
+  if (!half) return w;
+  const size_t R = (size_t)w.maxReads, P = (size_t)w.maxPart;
+  w.seed += R * T4_WIDE_SEEDS; w.uniqPref += R * (w.pcap + 1); w.sortTmp += R * 2 * w.pcap;
+  w.pCnt += P; w.pRead += P; w.pKeys += P * w.pcap; w.gSize += P * w.pcap; w.gInfo += P * w.pcap; w.gCount += P * 4; w.gOff += P * 2;
+  w.pRec += P * w.maxOvPart * 10; w.pRecCnt += P; w.mKeys += P * w.maxOvPart; w.mOrd += P * w.maxOvPart;
+  w.grpPool += w.grpCap;
+  return w;
 }
 
 }  // namespace
@@ -1516,12 +1529,14 @@ int aqBegin(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const 
   q.oBc = al8(q.oLen + sizeof(int) * (size_t)n); q.oSt = al8(q.oBc + sizeof(int) * (size_t)n); q.oLs = al8(q.oSt + sizeof(int) * (size_t)n);
   q.oVw = al8(q.oLs + sizeof(int) * (size_t)n); q.oFa = al8(q.oVw + sizeof(int) * (size_t)n); q.oOnly = al8(q.oFa + sizeof(double) * (size_t)n);
   q.oWide = al8(q.oOnly + sizeof(int) * (size_t)n); q.hasOnly = onlySeq != nullptr;
-  q.inBytes = al8(q.oWide + sizeof(T4Wide));
+  q.oWideA = al8(q.oWide + sizeof(T4Wide)); q.inBytes = al8(q.oWideA + sizeof(T4Wide));
   q.pCnt = 0; q.pSta = al8(q.pCnt + sizeof(int) * (size_t)n); q.pNext = al8(q.pSta + sizeof(int) * (size_t)n);
   q.pNext2 = al8(q.pNext + sizeof(int) * (size_t)n); q.pBase = al8(q.pNext2 + sizeof(int) * (size_t)n);
   q.pTick = al8(q.pBase + sizeof(int) * (size_t)n); q.pStab = al8(q.pTick + sizeof(int) * (size_t)n); q.pAux = al8(q.pStab + sizeof(int) * (size_t)n);
   q.pN4 = al8(q.pAux + sizeof(int) * (size_t)n); q.pTail = al8(q.pN4 + sizeof(int) * (size_t)n);
-  q.pWctl = q.pTail + 32; q.pWplan = q.pWctl + 32; q.pWstat = al8(q.pWplan + sizeof(T4WidePlan) * (size_t)n); q.outBytes = al8(q.pWstat + sizeof(int) * T4_WIDE_STAT * (size_t)n);
+  q.pWctl = q.pTail + 32; q.pWplan = q.pWctl + 32; q.pWstat = al8(q.pWplan + sizeof(T4WidePlan) * (size_t)n);
+  q.pWctlA = al8(q.pWstat + sizeof(int) * T4_WIDE_STAT * (size_t)n); q.pWplanA = q.pWctlA + 32; q.pWstatA = al8(q.pWplanA + sizeof(T4WidePlan) * (size_t)n);
+  q.outBytes = al8(q.pWstatA + sizeof(int) * T4_WIDE_STAT * (size_t)n);
   q.wideSafety = 32;
   if (q.inBytes > c->aqInBytes) {
     if (c->aqIn) (void)hipFree(c->aqIn);
@@ -1568,10 +1583,11 @@ int aqBegin(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const 
   // work lists: the reads of the first LDS launch, then those that go to the global-scratch tier at once
   const bool forceGlobal = getenv("T4_AQ_FORCE_GLOBAL") != nullptr;   // testing aid: every read on the global-scratch tier
   if (forceGlobal && !smallFirst) { q.allGlobal.assign((size_t)n, 1); q.tierHint = tierHint = q.allGlobal.data(); q.wide = false; }
-  if (q.wide) tierHint = nullptr;
+  // (with the wide query on, a hinted read -- served wide the last time -- starts on the second stream: wideSeedKernel)
+  auto direct = [&](int i) { return tierHint && tierHint[i] && !smallFirst && !(onlySeq && onlySeq[i] >= 0) && !(q.wide && getenv("T4_WIDE_NO_HINT")); };
   int nFirst = 0, nDirect = 0;
-  for (int i = 0; i < n; ++i) if (!(tierHint && tierHint[i] && !smallFirst)) ls[nFirst++] = i;
-  for (int i = 0; i < n; ++i) if (tierHint && tierHint[i] && !smallFirst) ls[nFirst + nDirect++] = i;
+  for (int i = 0; i < n; ++i) if (!direct(i)) ls[nFirst++] = i;
+  for (int i = 0; i < n; ++i) if (direct(i)) ls[nFirst + nDirect++] = i;
   q.nFirst = nFirst; q.nDirect = nDirect;
   c->aqSecPack += tSince(tp0);
   const int r = aqLaunch(c);
@@ -1596,7 +1612,7 @@ int aqLaunch(t4_ctx *c) {
   q.tf0 = std::chrono::steady_clock::now();
   if (q.wide) {
     if ((r = ensureWide(c, n, 1, 1))) return r;
-    T4Wide w = c->wide;
+    T4Wide w = wideHalf(c, 0), wa = wideHalf(c, 1);
     w.enabled = 1; w.safetyNum = q.wideSafety;
     // Reads of up to T4_WIDE_MIN_HITS emitted hits stay with one workgroup (LDS tier, then its slice of global scratch inside the same
     // launch, beside the other reads of the round): the wide query's kernels run behind the launch and cost a round about 0.25 ms
@@ -1605,6 +1621,9 @@ int aqLaunch(t4_ctx *c) {
     { const int lim = getenv("T4_AQ_CAP_LIMIT") ? atoi(getenv("T4_AQ_CAP_LIMIT")) : 0; w.minHits = lim > 0 ? lim : wideEnv("T4_WIDE_MIN_HITS", 8192); }
     w.ctl = (int *)(c->aqOut + q.pWctl); w.plan = (T4WidePlan *)(c->aqOut + q.pWplan); w.stat = (int *)(c->aqOut + q.pWstat);
     memcpy(c->aqInHost + q.oWide, &w, sizeof w);
+    wa.enabled = 1; wa.safetyNum = w.safetyNum; wa.minHits = w.minHits;
+    wa.ctl = (int *)(c->aqOut + q.pWctlA); wa.plan = (T4WidePlan *)(c->aqOut + q.pWplanA); wa.stat = (int *)(c->aqOut + q.pWstatA);
+    memcpy(c->aqInHost + q.oWideA, &wa, sizeof wa);
   }
   HIPCHK(c, hipMemcpyAsync(c->aqIn, c->aqInHost, q.inBytes, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(c->aqOut, 0, q.outBytes, c->stream));   // counts, status, overflow lists, bases, tail
@@ -1645,7 +1664,7 @@ int aqLaunch(t4_ctx *c) {
   const int grid0 = smallFirst ? (n < c->cus * TIER_BLOCKS_PER_CU[0] ? n : c->cus * TIER_BLOCKS_PER_CU[0])
                                : (nFirst > 0 ? (nFirst < c->cus * 2 ? nFirst : c->cus * 2) : 1);   // persistent grid: a large batch strides (and the per-block global scratch stays bounded)
   // scratch of the fallback DPs: the blocks of the LDS launch first, those of a concurrent global-tier launch behind them
-  if ((r = ensureScratch(c, (grid0 > c->cus * 2 ? grid0 : c->cus * 2) * threads + nDirect * G_THREADS))) return r;
+  if ((r = ensureScratch(c, (grid0 > c->cus * 2 ? grid0 : c->cus * 2) * threads + (q.wide ? (nDirect > 0 ? c->cus * 512 : 0) : nDirect * G_THREADS)))) return r;
   T4Work &wk = q.wk;
   memset(&wk, 0, sizeof wk);
   wk.list = (const int *)(c->aqIn + q.oLs); wk.nList = nFirst;
@@ -1654,7 +1673,7 @@ int aqLaunch(t4_ctx *c) {
   wk.dpRows = c->dpRows; wk.dpDir = c->dpDir;
   wk.capLimit = getenv("T4_AQ_CAP_LIMIT") ? atoi(getenv("T4_AQ_CAP_LIMIT")) : 0;   // testing aid
   wk.wide = q.wide ? (const T4Wide *)(c->aqIn + q.oWide) : nullptr;
-  if (!smallFirst && (r = ensureGlobalTier(c, grid0 + nDirect))) return r;   // before anything of this call runs: growing it frees the old arrays
+  if (!smallFirst && (r = ensureGlobalTier(c, grid0 + (q.wide ? 0 : nDirect)))) return r;   // before anything of this call runs: growing it frees the old arrays
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
   if (nDirect > 0) {   // beside the LDS tier, on the second stream (its own blocks of the DP scratch)
     if (!c->stream2) { HIPCHK(c, hipStreamCreate(&c->stream2)); HIPCHK(c, hipEventCreate(&c->evIn)); HIPCHK(c, hipEventCreate(&c->evG)); }
@@ -1662,20 +1681,36 @@ int aqLaunch(t4_ctx *c) {
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evIn, 0));
     T4Work wd = wk;
     wd.list = (const int *)(c->aqIn + q.oLs) + nFirst; wd.nList = nDirect; wd.nextList = nullptr; wd.nextCount = nullptr;
-    wd.gKeys = c->gKeys; wd.gPairs = c->gPairs; wd.gCand = c->gCand; wd.gOv = c->gOv; wd.gFin = c->gFin; wd.gOrd = c->gOrd;
-    wd.gCap = G_CAP; wd.gMaxOv = G_MAXOV;
     wd.dpRows = c->dpRows + (size_t)((grid0 > c->cus * 2 ? grid0 : c->cus * 2) * threads / 64) * (6 * T4_ROWW * 64);
     wd.dpDir = c->dpDir + (size_t)(grid0 > c->cus * 2 ? grid0 : c->cus * 2) * threads * T4_DIR_BYTES;
-    launchTier<0, 0, G_THREADS>(nDirect, c->stream2, q.base, bv, wd, qa);
+    if (q.wide) {
+      // the wide query of the reads known to be heavy, beside the round's query kernel: seed stage, then the same five kernels on the
+      // second half of the pools (wideHalf) and their own stretch of the DP scratch
+      T4Wide wa;
+      memcpy(&wa, c->aqInHost + q.oWideA, sizeof wa);
+      const int cus = c->cus > 0 ? c->cus : 1;
+      auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; };
+      const int gParts = clampi(2 * c->wideRecentParts + 4 * nDirect + 4, 4, cus * 2), gReads = clampi(nDirect, 1, cus < 64 ? cus : 64);
+      hipLaunchKernelGGL(t4k::wideSeedKernel, dim3(nDirect < cus ? nDirect : cus), dim3(512), 0, c->stream2, q.base, bv, wd, qa, wa, wd.list, nDirect);
+      hipLaunchKernelGGL(t4k::wideScatterKernel, dim3(clampi(8 * gParts, 16, cus * 8)), dim3(256), 0, c->stream2, q.base, wa);
+      hipLaunchKernelGGL((t4k::wideSortKernel<8192>), dim3(gParts), dim3(512), 0, c->stream2, q.base, wa);
+      hipLaunchKernelGGL(t4k::wideStatsKernel, dim3(gReads), dim3(512), 0, c->stream2, q.base, wa);
+      hipLaunchKernelGGL((t4k::wideChainKernel<8192, 1 << T4_WIDE_OVBITS>), dim3(gParts < cus ? gParts : cus), dim3(512), 0, c->stream2, q.base, bv, wd, qa, wa);
+      hipLaunchKernelGGL(t4k::wideMergeKernel, dim3(gReads), dim3(512), 0, c->stream2, q.base, bv, wd, qa, wa);
+    } else {
+      wd.gKeys = c->gKeys; wd.gPairs = c->gPairs; wd.gCand = c->gCand; wd.gOv = c->gOv; wd.gFin = c->gFin; wd.gOrd = c->gOrd;
+      wd.gCap = G_CAP; wd.gMaxOv = G_MAXOV;
+      launchTier<0, 0, G_THREADS>(nDirect, c->stream2, q.base, bv, wd, qa);
+      ++c->aqGlobalLaunches; c->aqGlobalReads += nDirect;
+    }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->evG, c->stream2));
-    ++c->aqGlobalLaunches; c->aqGlobalReads += nDirect;
   }
   if (nFirst > 0) {
     if (smallFirst) launchTier<1024, 128, 256>(grid0, c->stream, q.base, bv, wk, qa);
     else {   // a read that outgrows the LDS arrays goes on in global scratch inside the same launch
       T4Work wf = wk;
-      const size_t skip = (size_t)nDirect;   // the blocks of a concurrent global-tier launch own the first slices
+      const size_t skip = q.wide ? 0 : (size_t)nDirect;   // the blocks of a concurrent global-tier launch own the first slices
       wf.gKeys = c->gKeys + skip * G_CAP; wf.gPairs = c->gPairs + skip * G_CAP * 2; wf.gCand = c->gCand;
       wf.gOv = c->gOv + skip * G_MAXOV * 10; wf.gFin = c->gFin + skip * G_MAXOV * 10; wf.gOrd = c->gOrd + skip * G_MAXOV;
       wf.gCap = G_CAP; wf.gMaxOv = G_MAXOV;
@@ -1683,7 +1718,7 @@ int aqLaunch(t4_ctx *c) {
     }
     HIPCHK(c, hipGetLastError());
   }
-  if (nDirect > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->evG, 0));
+  if (nDirect > 0 && !q.wide) HIPCHK(c, hipStreamWaitEvent(c->stream, c->evG, 0));
   if (q.wide) {   // the reads the launch above deferred (none: five empty grids)
     T4Wide w;
     memcpy(&w, c->aqInHost + q.oWide, sizeof w);
@@ -1698,6 +1733,7 @@ int aqLaunch(t4_ctx *c) {
     hipLaunchKernelGGL((t4k::wideChainKernel<8192, 1 << T4_WIDE_OVBITS>), dim3(gParts < cus ? gParts : cus), dim3(512), 0, c->stream, q.base, bv, wk, qa, w);
     hipLaunchKernelGGL(t4k::wideMergeKernel, dim3(gReads), dim3(512), 0, c->stream, q.base, bv, wk, qa, w);
     HIPCHK(c, hipGetLastError());
+    if (nDirect > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->evG, 0));   // the other pipeline's records are in the pool before the extensions run
   }
   if (extendLater) {   // all records of the batch, spread over the chip
     const int grid = c->cus * 16;
@@ -1784,23 +1820,29 @@ int aqEnd(t4_ctx *c, AqResult *res) {
     c->aqSecGlobal += tSince(tg0);
     const unsigned char *o = c->aqOutHost;
     if (q.wide) {
-      const int *ctl = (const int *)(o + q.pWctl);
-      const int flags = ctl[2];
+      const int *ctl = (const int *)(o + q.pWctl), *ctlA = (const int *)(o + q.pWctlA);
+      const int flags = ctl[2] | ctlA[2];
       if (flags) {   // a pool of the wide query ran out: larger pools / finer partitions, and the whole call again
         if (q.attempt >= 12 || (flags & (1 | 32))) return fail(c, T4_ERR_UNSUPPORTED, "wide query: flags %d after %d attempts", flags, q.attempt);
         if (flags & 2) {
-          if (ctl[1] <= c->wide.maxPart) return fail(c, T4_ERR_UNSUPPORTED, "a read of this batch needs more than %d partitions of %d k-mer hits", T4_WIDE_MAXP, c->wide.pcap);
-          if ((r = ensureWide(c, n, ctl[1], 1))) return r;
+          const int need = ctl[1] > ctlA[1] ? ctl[1] : ctlA[1];
+          if (need <= c->wide.maxPart) return fail(c, T4_ERR_UNSUPPORTED, "a read of this batch needs more than %d partitions of %d k-mer hits", T4_WIDE_MAXP, c->wide.pcap);
+          if ((r = ensureWide(c, n, need, 1))) return r;
         }
         if (flags & (4 | 8)) { if (q.wideSafety >= 32 * 256) return fail(c, T4_ERR_UNSUPPORTED, "wide query: a contig range of one contig overflows a partition"); q.wideSafety *= 2; }
-        if (flags & 16) { if ((r = ensureWide(c, n, 1, ctl[3]))) return r; }
+        if (flags & 16) { if ((r = ensureWide(c, n, 1, ctl[3] > ctlA[3] ? ctl[3] : ctlA[3]))) return r; }
         ++c->wideRetries; ++q.attempt;
         if ((r = aqLaunch(c))) return r;
         continue;
       }
-      c->wideReads += ctl[0]; c->wideParts += ctl[1]; c->wideGroups += ctl[3];
+      c->wideReads += ctl[0] + ctlA[0]; c->wideParts += ctl[1] + ctlA[1]; c->wideGroups += ctl[3] + ctlA[3];
       c->wideRecentParts = ctl[1] > c->wideRecentParts ? ctl[1] : (c->wideRecentParts * 7 + ctl[1]) / 8;
       c->wideRecentReads = ctl[0] > c->wideRecentReads ? ctl[0] : (c->wideRecentReads * 7 + ctl[0]) / 8;
+      if (q.tierHint) {   // remembered by the caller: these reads start on the second stream the next time they are queried
+        const T4WidePlan *plans[2] = {(const T4WidePlan *)(o + q.pWplan), (const T4WidePlan *)(o + q.pWplanA)};
+        const int cnt[2] = {ctl[0] < n ? ctl[0] : n, ctlA[0] < n ? ctlA[0] : n};
+        for (int hlf = 0; hlf < 2; ++hlf) for (int w2 = 0; w2 < cnt[hlf]; ++w2) if (plans[hlf][w2].read >= 0 && plans[hlf][w2].read < n) q.tierHint[plans[hlf][w2].read] = 1;
+      }
     }
     const int *status = (const int *)(o + q.pSta);
     bool poolFull = false;
@@ -1888,17 +1930,19 @@ int t4_add_query_groups(t4_ctx *c, int i, const t4_grp **groups, int *n, int *hu
   const AqCall &q = c->aq;
   if (!q.wide || !c->aqOutHost) return 0;
   const unsigned char *o = c->aqOutHost;
-  const int *ctl = (const int *)(o + q.pWctl);
-  const T4WidePlan *plan = (const T4WidePlan *)(o + q.pWplan);
-  const int *stat = (const int *)(o + q.pWstat);
-  const int nw = ctl[0] < q.n ? ctl[0] : q.n;
-  for (int w = 0; w < nw; ++w) {
-    if (plan[w].read != i) continue;
-    *groups = (const t4_grp *)c->grpPoolHost + plan[w].grpBase;
-    *n = stat[(size_t)w * T4_WIDE_STAT + WS_GROUPS];
-    if (huge) *huge = plan[w].huge;
-    if (n4) *n4 = stat[(size_t)w * T4_WIDE_STAT + WS_N4];
-    return 1;
+  for (int half = 0; half < 2; ++half) {
+    const int *ctl = (const int *)(o + (half ? q.pWctlA : q.pWctl));
+    const T4WidePlan *plan = (const T4WidePlan *)(o + (half ? q.pWplanA : q.pWplan));
+    const int *stat = (const int *)(o + (half ? q.pWstatA : q.pWstat));
+    const int nw = ctl[0] < q.n ? ctl[0] : q.n;
+    for (int w = 0; w < nw; ++w) {
+      if (plan[w].read != i) continue;
+      *groups = (const t4_grp *)c->grpPoolHost + (half ? (size_t)c->wide.grpCap : 0) + plan[w].grpBase;
+      *n = stat[(size_t)w * T4_WIDE_STAT + WS_GROUPS];
+      if (huge) *huge = plan[w].huge;
+      if (n4) *n4 = stat[(size_t)w * T4_WIDE_STAT + WS_N4];
+      return 1;
+    }
   }
   return 0;
 }

@@ -71,6 +71,39 @@ __device__ T4_NI void wideDeferRead(const T4IndexView &ix, WaveMem &wm, WaveStat
   __syncthreads();
 }
 
+// Reads known to be heavy (the window entry's last query was served wide) skip the LDS tier: their seed stage runs here, on a
+// second stream, and the wide kernels behind it run BESIDE the round's query kernel instead of after it.
+__global__ __launch_bounds__(512) void wideSeedKernel(T4IndexView ixArg, T4BatchView bvArg, T4Work wk, T4QueryArgs qa, T4Wide wd, const int *list, int nList) {
+  __shared__ unsigned long long s_code[2 * T4_MAXL + 2];
+  __shared__ unsigned s_pref[2 * T4_MAXL + 2];
+  __shared__ unsigned s_start[2 * T4_MAXL + 2];
+  __shared__ char s_seg[T4_MAXL + 8];
+  __shared__ char s_rc[T4_MAXL + 8];
+  __shared__ WaveState s_ws;
+  __shared__ T4IndexView s_ix;
+  __shared__ T4BatchView s_bv;
+  __shared__ WaveMem s_wm;
+  if (threadIdx.x == 0) {
+    s_ix = ixArg; s_bv = bvArg;
+    WaveMem &m = s_wm;
+    m.keys = s_code; m.pairs = s_pref; m.cand = s_pref; m.ov = (OvRec *)s_start; m.fin = (OvRec *)s_start; m.ord = (unsigned short *)s_start;
+    m.cap = 2 * T4_MAXL; m.maxOv = 0; m.maxFin = 0; m.candCap = 0; m.ldsArrays = 1; m.hitLimit = 0;
+    m.ldsSort = nullptr; m.ldsSortCap = 0; m.dirBuf = (unsigned char *)s_code; m.dirBytes = 0;
+    m.seg = s_seg; m.rc = s_rc;
+  }
+  __syncthreads();
+  for (int w = blockIdx.x; w < nList; w += gridDim.x) {
+    const long long r = list[w];
+    const int len = s_bv.len[r];
+    __syncthreads();
+    if (len < s_ix.k) { if (threadIdx.x == 0) qa.counts[r] = -1; continue; }   // (GetOverlapsFromRead's own answer: no k-mer)
+    loadSegment(s_bv, r, 0, len, s_wm);
+    unsigned long long hitTotal = 0;
+    wideDeferRead(s_ix, s_wm, &s_ws, wd, len, qa.strandPerRead[r], r, hitTotal);
+    if (threadIdx.x == 0) atomicAdd(wk.hitCounter, hitTotal);
+  }
+}
+
 __device__ __forceinline__ int wideReads(const T4Wide &wd) { const int n = wd.ctl[0]; return n < wd.maxReads ? n : wd.maxReads; }
 __device__ __forceinline__ int wideParts(const T4Wide &wd) { const int n = wd.ctl[1]; return n < wd.maxPart ? n : wd.maxPart; }
 
