@@ -414,9 +414,10 @@ def _verify_window_case(tmp_path, driver, pairs, clones, seed, knobs, threads="4
     if env["T4_QUERY_AHEAD"] == "0":
         del env["T4_QUERY_AHEAD"]
     log = _bulk_case(tmp_path, driver, pairs, clones, seed, env, threads=threads)
-    m = re.search(r"T4_VERIFY_WINDOW: (\d+) served window entries", log)
+    m = re.search(r"T4_VERIFY_WINDOW: (\d+) served window entries queried again at serve time, all equal to their cached results \((\d+) of them put together", log)
     assert m and int(m.group(1)) > pairs // 4, (env, log[-800:])
-    print(env, re.findall(r"timing: query lanes.*", log))
+    assert int(m.group(2)) > pairs // 40, (env, m.groups())   # restricted re-queries: entries that kept the records of their other contigs were served, and verified as sets
+    print(env, re.findall(r"timing: query lanes.*", log), re.findall(r"timing: restricted.*", log))
     return int(m.group(1))
 
 

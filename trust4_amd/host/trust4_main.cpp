@@ -501,7 +501,6 @@ int main(int argc, char *argv[]) {
     if (initRc) die(ctx, initWhat, initRc);
     if (t4_index_size(refSet) == 0) { fprintf(stderr, "Need to use -f to specify the receptor genome sequence.\n"); exit(EXIT_FAILURE); }
   };
-  if (getenv("T4_SYNC_INIT")) gpuReady();   // the serial order, for timing comparisons
   PrintLog("Start to assemble reads.");
   // wall-clock marks of the phases (written to $T4_STATS_JSON for bench.py)
   const auto tStart = std::chrono::steady_clock::now();
@@ -858,7 +857,7 @@ int main(int argc, char *argv[]) {
   // ---- rough annotation on the GPU (main.cpp:1084-1120): every distinct read once, in chunks (a 20 M-pair input must not need
   // all packed reads and all 160-byte results at the same time)
   {
-    const size_t CHUNK = getenv("T4_ANNOT_CHUNK") ? (size_t)atol(getenv("T4_ANNOT_CHUNK")) : ((size_t)4 << 20);
+    const size_t CHUNK = (size_t)4 << 20;   // distinct reads per t4_annotate_rough call
     std::string bases; std::vector<int64_t> off; std::vector<int> firstOf; std::vector<t4_overlap> out;
     int i = 0;
     while (i < readCnt) {
