@@ -38,7 +38,7 @@ static inline uint2 make_uint2(unsigned x, unsigned y) { uint2 r = {x, y}; retur
 static inline int4 make_int4(int x, int y, int z, int w) { int4 r = {x, y, z, w}; return r; }
 
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorUnknown = 999 };
+enum { hipSuccess = 0, hipErrorNotReady = 600, hipErrorUnknown = 999 };
 typedef struct hipemu_stream *hipStream_t;
 typedef struct hipemu_event { std::chrono::steady_clock::time_point t; } *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };

@@ -19,18 +19,8 @@ eng.lib.t4_debug_phase_cycles(buf)
 eng.lib.t4_debug_counters(dbg)
 print("gap jobs %d (%.1f/read), banded %d (%.2f/read), wave-DP steps %d (%.0f/DP), scratch fallbacks %d, fallback cells %d, fallback cycles %.3e" % (
     dbg[0], dbg[0] / n, dbg[1], dbg[1] / n, dbg[2], dbg[2] / max(1, dbg[1] - dbg[3]), dbg[3], dbg[4], dbg[5]))
-def tier_profiles():
-    for t in range(5):
-        os.environ["T4_ONLY_TIER"] = str(t)
-        ref.annotate_rough(b, fetch=False)
-        eng.lib.t4_debug_phase_cycles(buf); eng.lib.t4_debug_counters(dbg)
-        st = eng.stats(); tot = sum(buf[:16]); nr = max(1, st["tier_reads"][t])
-        print("tier %d: reads %d, %.2f ms, gap jobs %.1f/read, banded %.1f/read, steps %.0f/DP" % (t, nr, st["chain_kernel_ms"], dbg[0] / nr, dbg[1] / nr, dbg[2] / max(1, dbg[1])))
-        print("   " + " ".join("%s %.1f" % (nm, 100.0 * buf[i] / max(1, tot)) for i, nm in enumerate(names)))
-    os.environ["T4_ONLY_TIER"] = "-1"
 names = ["other", "seed", "expand", "sort", "stats", "runs", "bigsort", "chain", "ovsort", "score", "prefilter", "final", "annotate", "score:quick", "score:banded", "score:finish"]
 tot = sum(buf[:16])
 print(eng.stats())
 for i, nm in enumerate(names):
     print("%-10s %6.2f%%  %.3e cycles" % (nm, 100.0 * buf[i] / tot, buf[i]))
-tier_profiles()

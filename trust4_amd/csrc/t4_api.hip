@@ -1768,6 +1768,9 @@ int aqEnd(t4_ctx *c, AqResult *res) {
   T4BatchView &bv = q.bv;
   int r;
   for (;;) {
+    // The caller sits on the ordered chain's critical path: poll for the round's last event before the blocking wait (a wait that
+    // sleeps wakes up tens of microseconds after the kernels are done; a round is a few hundred)
+    for (int spin = 0; spin < 200000 && hipEventQuery(c->ev[3]) == hipErrorNotReady; ++spin) { }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     { float ms = 0; if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) { c->aqKernelMs += ms; c->aqLastMs = ms; } }
     int overflow = *(int *)(c->aqOutHost + pTail);
@@ -2348,6 +2351,7 @@ int t4_comm_init(t4_ctx *c, int rank, int nranks, const char *id_path, t4_comm *
   (void)hipSetDevice(c->device);
   ncclUniqueId id;
   if (rank == 0) {
+    (void)unlink(id_path);   // (an id left by an earlier run must not be taken for this one's)
     if (ncclGetUniqueId(&id) != ncclSuccess) return fail(c, T4_ERR_HIP, "ncclGetUniqueId failed");
     const std::string tmp = std::string(id_path) + ".tmp";
     FILE *fp = fopen(tmp.c_str(), "wb");

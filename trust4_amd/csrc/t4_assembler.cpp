@@ -592,8 +592,15 @@ struct t4_assembler : IndexListener {
   int64_t wideServed = 0, wideGroupRecords = 0, wideMispredicted = 0;
   int64_t restrictedMarks = 0, restrictedMerged = 0, restrictedFallbacks = 0, restrictedStale = 0;
   bool restrictOn = true;
-  bool eligibleForRestricted(const Cached &e) const {
-    return restrictOn && e.valid && e.auxOk && !e.skip && e.barcode == -1 && !e.hasDev && !e.expectWide && !e.fragile && e.nOther == 0 && e.nAllBound <= 44 && e.n4 + 2 * e.restrictedCount + 2 <= 100;
+  int64_t whyNot[6] = {0, 0, 0, 0, 0, 0};   // entries that fell whole although one contig changed: lists beyond 10000 postings, overlaps on the other strand, more than 44 candidate overlaps, more than ~100 groups of four hits, no report from the query, other
+  bool eligibleForRestricted(const Cached &e) {
+    if (!restrictOn || !e.valid || e.skip || e.barcode != -1) { ++whyNot[5]; return false; }
+    if (!e.auxOk) { ++whyNot[4]; return false; }
+    if (e.fragile) { ++whyNot[0]; return false; }
+    if (e.nOther != 0) { ++whyNot[1]; return false; }
+    if (e.nAllBound > 44) { ++whyNot[2]; return false; }
+    if (e.n4 + 2 * e.restrictedCount + 2 > 100) { ++whyNot[3]; return false; }
+    return true;
   }
   void rebuildGroup(Cached &e, int c);
   bool wideQueries = true; int wideHitLimit = 8192;   // what t4_add_query_pool_begin will do with a read of that many emitted hits (set in ensureLanes)
@@ -2255,6 +2262,8 @@ int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n) {
             (long long)a->tolerated, (long long)a->toleratedStable, (long long)a->invFragile, (long long)a->invLongLists);
     fprintf(stderr, "timing: restricted re-queries: %lld entries kept their other contigs when one contig changed, %lld merged, %lld fell back to the whole query, %lld in flight met another change of their contig\n",
             (long long)a->restrictedMarks, (long long)a->restrictedMerged, (long long)a->restrictedFallbacks, (long long)a->restrictedStale);
+    fprintf(stderr, "timing: entries that fell whole when one contig changed: %lld with lists beyond 10000 postings, %lld with overlaps on the other strand, %lld with more than 44 candidate overlaps, %lld with ~100 groups of four hits, %lld without the query's report, %lld other\n",
+            (long long)a->whyNot[0], (long long)a->whyNot[1], (long long)a->whyNot[2], (long long)a->whyNot[3], (long long)a->whyNot[4], (long long)a->whyNot[5]);
     fprintf(stderr, "timing: wide query served %lld window entries (%lld dependency records came back with them), %lld reads it was expected for stayed on the LDS tier\n", (long long)a->wideServed, (long long)a->wideGroupRecords, (long long)a->wideMispredicted);
   }
   return T4_OK;

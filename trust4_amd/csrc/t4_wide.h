@@ -619,9 +619,8 @@ __global__ __launch_bounds__(512) void wideMergeKernel(T4IndexView ix, T4BatchVi
     __syncthreads();
     const int *st = wd.stat + (size_t)w * T4_WIDE_STAT;
     if (lane == 0 && qa.statsStable) qa.statsStable[r] = st[WS_STABLE];
-    if (lane == 0 && qa.aux) qa.aux[r] = -1;   // (no restricted re-query of a read the wide query served)
     if (lane == 0 && qa.n4) qa.n4[r] = st[WS_N4];
-    if (N == 0) { if (lane == 0) { qa.counts[r] = 0; qa.outBase[r] = 0; } continue; }
+    if (N == 0) { if (lane == 0) { qa.counts[r] = 0; qa.outBase[r] = 0; if (qa.aux) qa.aux[r] = 0; } continue; }
     // std::sort(overlaps) (SeqSet.hpp:1597) on the records as GetOverlapsFromHits left them: matchCnt (kept in chainLen), read span,
     // contig, strand in one key with the record's index; ties on all four are settled by the rest of operator<
     const bool inLds = N <= 8192;
@@ -677,6 +676,7 @@ __global__ __launch_bounds__(512) void wideMergeKernel(T4IndexView ix, T4BatchVi
       __syncthreads();
     }
     const int cnt = kept;
+    if (lane == 0 && qa.aux) qa.aux[r] = (cnt > 32767 ? 32767 : cnt) | ((N - cnt > 32767 ? 32767 : N - cnt) << 15) | ((strand0 ? 1 : 0) << 30);   // see T4QueryArgs::aux
     // the pre-filters against the best novel overlap so far (SeqSet.hpp:1705-1794), replayed as prefilterNovel does
     if (cnt > 50) {
       int best = -1;
