@@ -123,6 +123,8 @@ struct t4_ctx {
   bool wideInit = false;
   unsigned char *grpPoolHost = nullptr;   // pinned; T4Wide::grpPool is its device address
   int64_t wideReads = 0, wideParts = 0, wideRetries = 0, wideGroups = 0;
+  int wideSafetyKeep = 32, wideCallsSinceRepeat = 0;   // partition load factor that recent calls needed (of sixteenths: 32 = partitions planned half full); decays back when nothing overflows
+  int64_t wideFlagCounts[6] = {0, 0, 0, 0, 0, 0};     // calls repeated because: reads, partitions, keys of a partition, overlaps of a partition, dependency records, other
   int wideRecentParts = 0, wideRecentReads = 0;   // the largest counts of the last calls, decayed: sizes the (persistent) grids of the next call's wide kernels
   double aqKernelMs = 0;    // HIP-event time of the query kernels of all AddRead query calls (per call: first launch .. last kernel)
   int64_t aqHits = 0;       // _hit records their seed stages emitted (H of SURVEY 8d)
@@ -258,6 +260,7 @@ int ensureWide(t4_ctx *c, int reads, int parts, int groups) {
     int n = w.maxReads > 0 ? w.maxReads : 64;
     while (n < reads) n *= 2;
     if ((r = devAlloc(c, &w.seed, 2 * (size_t)n * T4_WIDE_SEEDS))) return r;   // (two of everything: wideHalf)
+    if ((r = devAlloc(c, &w.bounds, 2 * (size_t)n * (T4_WIDE_MAXP + 1)))) return r;
     if ((r = devAlloc(c, &w.uniqPref, 2 * (size_t)n * (w.pcap + 1)))) return r;
     if ((r = devAlloc(c, &w.sortTmp, 2 * (size_t)n * 2 * w.pcap))) return r;
     w.maxReads = n;
@@ -296,7 +299,7 @@ T4Wide wideHalf(const t4_ctx *c, int half) {
   T4Wide w = c->wide;
   if (!half) return w;
   const size_t R = (size_t)w.maxReads, P = (size_t)w.maxPart;
-  w.seed += R * T4_WIDE_SEEDS; w.uniqPref += R * (w.pcap + 1); w.sortTmp += R * 2 * w.pcap;
+  w.seed += R * T4_WIDE_SEEDS; w.bounds += R * (T4_WIDE_MAXP + 1); w.uniqPref += R * (w.pcap + 1); w.sortTmp += R * 2 * w.pcap;
   w.pCnt += P; w.pRead += P; w.pKeys += P * w.pcap; w.gSize += P * w.pcap; w.gInfo += P * w.pcap; w.gCount += P * 4; w.gOff += P * 2;
   w.pRec += P * w.maxOvPart * 10; w.pRecCnt += P; w.mKeys += P * w.maxOvPart; w.mOrd += P * w.maxOvPart;
   w.grpPool += w.grpCap;
@@ -363,7 +366,7 @@ void t4_destroy(t4_ctx *c) {
   if (c->aqRecDev) (void)hipFree(c->aqRecDev);
   if (c->aqRecRead) (void)hipFree(c->aqRecRead);
   if (c->wideInit) {
-    void *wp[] = {c->wide.seed, c->wide.pCnt, c->wide.pRead, c->wide.pKeys, c->wide.gSize, c->wide.gInfo, c->wide.gCount, c->wide.gOff, c->wide.pRec,
+    void *wp[] = {c->wide.seed, c->wide.bounds, c->wide.pCnt, c->wide.pRead, c->wide.pKeys, c->wide.gSize, c->wide.gInfo, c->wide.gCount, c->wide.gOff, c->wide.pRec,
                   c->wide.pRecCnt, c->wide.uniqPref, c->wide.mKeys, c->wide.mOrd, c->wide.sortTmp};
     for (void *p : wp) if (p) (void)hipFree(p);
     if (c->grpPoolHost) (void)hipHostFree(c->grpPoolHost);
@@ -1537,7 +1540,7 @@ int aqBegin(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const 
   q.pWctl = q.pTail + 32; q.pWplan = q.pWctl + 32; q.pWstat = al8(q.pWplan + sizeof(T4WidePlan) * (size_t)n);
   q.pWctlA = al8(q.pWstat + sizeof(int) * T4_WIDE_STAT * (size_t)n); q.pWplanA = q.pWctlA + 32; q.pWstatA = al8(q.pWplanA + sizeof(T4WidePlan) * (size_t)n);
   q.outBytes = al8(q.pWstatA + sizeof(int) * T4_WIDE_STAT * (size_t)n);
-  q.wideSafety = 32;
+  q.wideSafety = c->wideSafetyKeep;
   if (q.inBytes > c->aqInBytes) {
     if (c->aqIn) (void)hipFree(c->aqIn);
     if (c->aqInHost) (void)hipHostFree(c->aqInHost);
@@ -1832,13 +1835,21 @@ int aqEnd(t4_ctx *c, AqResult *res) {
           if (need <= c->wide.maxPart) return fail(c, T4_ERR_UNSUPPORTED, "a read of this batch needs more than %d partitions of %d k-mer hits", T4_WIDE_MAXP, c->wide.pcap);
           if ((r = ensureWide(c, n, need, 1))) return r;
         }
-        if (flags & (4 | 8)) { if (q.wideSafety >= 32 * 256) return fail(c, T4_ERR_UNSUPPORTED, "wide query: a contig range of one contig overflows a partition"); q.wideSafety *= 2; }
+        for (int b = 0; b < 6; ++b) if (flags & (1 << b)) ++c->wideFlagCounts[b];
+        if (flags & (4 | 8)) {
+          if (q.wideSafety >= 32 * 256) return fail(c, T4_ERR_UNSUPPORTED, "wide query: a contig range of one contig overflows a partition");
+          q.wideSafety *= 2;
+          // contigs that carry one gene segment cluster in the id order (clones of a family are seeded one after the other): ranges of equal
+          // width are unevenly filled, and a call that had to be repeated with finer partitions says the next ones will too
+          c->wideSafetyKeep = q.wideSafety; c->wideCallsSinceRepeat = 0;
+        }
         if (flags & 16) { if ((r = ensureWide(c, n, 1, ctl[3] > ctlA[3] ? ctl[3] : ctlA[3]))) return r; }
         ++c->wideRetries; ++q.attempt;
         if ((r = aqLaunch(c))) return r;
         continue;
       }
       c->wideReads += ctl[0] + ctlA[0]; c->wideParts += ctl[1] + ctlA[1]; c->wideGroups += ctl[3] + ctlA[3];
+      if (ctl[0] + ctlA[0] > 0 && ++c->wideCallsSinceRepeat >= 2048 && c->wideSafetyKeep > 32) { c->wideSafetyKeep /= 2; c->wideCallsSinceRepeat = 0; }
       c->wideRecentParts = ctl[1] > c->wideRecentParts ? ctl[1] : (c->wideRecentParts * 7 + ctl[1]) / 8;
       c->wideRecentReads = ctl[0] > c->wideRecentReads ? ctl[0] : (c->wideRecentReads * 7 + ctl[0]) / 8;
       if (q.tierHint) {   // remembered by the caller: these reads start on the second stream the next time they are queried
@@ -1911,6 +1922,8 @@ int t4_add_query_stats(t4_ctx *c, int64_t *out5) {   // 7 values
   out5[0] = c->aqCalls; out5[1] = c->aqReads; out5[2] = c->aqGlobalLaunches; out5[3] = c->aqGlobalReads; out5[4] = c->aqRecords;
   out5[5] = (int64_t)(c->aqKernelMs * 1e3); out5[6] = c->aqHits;
   if (getenv("T4_TIMING")) fprintf(stderr, "timing: AddRead query path host seconds: pack %.3f, first launch to sync %.3f, overflow tiers %.3f; result pool grown %d times\n", c->aqSecPack, c->aqSecFirst, c->aqSecGlobal, c->aqPoolGrows);
+  if (getenv("T4_TIMING")) fprintf(stderr, "timing: wide query: %lld calls repeated -- partition pool %lld, keys of a partition %lld, overlaps of a partition %lld, dependency records %lld; partitions planned %d/16 full at the end\n",
+                                   (long long)c->wideRetries, (long long)c->wideFlagCounts[1], (long long)c->wideFlagCounts[2], (long long)c->wideFlagCounts[3], (long long)c->wideFlagCounts[4], 16 * 16 / (c->wideSafetyKeep > 0 ? c->wideSafetyKeep : 32));
   return T4_OK;
 }
 

@@ -93,7 +93,8 @@ struct T4TierCaps { int cap[T4_NTIER - 1]; };   // hit capacity of the LDS tiers
 // look across contigs (SeqSet.hpp:784-823 statistics, 1597 sort, 1601-1634 strand, 1705-1794 pre-filters, 2105-2119 cut) are
 // replayed over the partitions' records by one workgroup per read.
 struct T4Grp { unsigned key; unsigned cnt; int lo, hi; };   // dependency set of a query: key = contig * 2 + (strand == 1); hits; hull of the diagonals with >= 3 hits (lo > hi: none)
-struct T4WidePlan { int pBase, P, Wd, nk; unsigned H; int huge /* a list beyond 10000 postings */, read, grpBase; };
+#define T4_WIDE_MAXP 2048     // partitions of one read (11 bits of the merge's record index)
+struct T4WidePlan { int pBase, P, Wd /* unused since the partitions follow the hits' distribution */, nk; unsigned H; int huge /* a list beyond 10000 postings */, read, grpBase; };
 #define T4_WIDE_STAT 24      // ints per read: see wideStatsKernel
 struct T4Wide {
   int enabled;
@@ -102,6 +103,7 @@ struct T4Wide {
   int *ctl;                  // [0] reads, [1] partitions, [2] overflow flags (1 reads, 2 partitions, 4 keys of a partition, 8 overlaps of a partition, 16 group pool), [3] group pool cursor
   T4WidePlan *plan;          // [maxReads]
   uint2 *seed;               // [maxReads][2 * T4_MAXL]: (start, emitted postings) of every k-mer position, forward strand first
+  int *bounds;               // [maxReads][T4_WIDE_MAXP + 1]: first contig of every partition of a read (quantiles of a sample of its hits' contigs)
   unsigned *pCnt;            // [maxPart] keys
   int *pRead;                // [maxPart] slot of the read
   unsigned long long *pKeys; // [maxPart][pcap]

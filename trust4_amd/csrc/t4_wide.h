@@ -24,7 +24,6 @@
 #pragma once
 
 #define T4_WIDE_SEEDS (2 * T4_MAXL + 2)
-#define T4_WIDE_MAXP 2048          // partitions of one read (11 bits of the merge's record index)
 #define T4_WIDE_OVBITS 9           // overlap records of one partition: 512
 
 // ws->red[13..15] are free for this (the scans use the first eight words)
@@ -48,8 +47,7 @@ __device__ T4_NI void wideDeferRead(const T4IndexView &ix, WaveMem &wm, WaveStat
       const int nseq = ix.nseq > 0 ? ix.nseq : 1;
       if (want < 1) want = 1;
       if (want > nseq) want = nseq;
-      Wd = (int)((nseq + want - 1) / want);
-      P = (nseq + Wd - 1) / Wd;
+      P = (int)want;
       if (P > wd.maxPartPerRead) { atomicOr(&wd.ctl[2], 2); P = 0; }
       else {
         pBase = atomicAdd(&wd.ctl[1], P);
@@ -63,6 +61,29 @@ __device__ T4_NI void wideDeferRead(const T4IndexView &ix, WaveMem &wm, WaveStat
   }
   __syncthreads();
   const int slot = ws->red[15], pBase = ws->red[14], P = ws->red[13];
+  if (slot >= 0 && P > 0) {
+    // Partition boundaries from the hits themselves: contigs that carry one gene segment cluster in the id order (the clones of a
+    // family are seeded one after the other), so contig ranges of equal width fill unevenly -- 38 % of the rounds of C3's first
+    // 500 k pairs had to be repeated with finer partitions (profiles/r04l_*). A sample of the hits' contigs (every H / n-th posting in
+    // list order), sorted; the partitions are its quantiles. A (strand, contig) group still lies in one partition.
+    int *bd = wd.bounds + (size_t)slot * (T4_WIDE_MAXP + 1);
+    unsigned *smp = (unsigned *)wm.keys;   // (the key array is free: the seed stage's code buffer died with it)
+    int nS = 2 * wm.cap < 4096 ? 2 * wm.cap : 4096;
+    if (nS > H) nS = H;
+    if (P > 1 && nS > 0) {
+      for (int j = lane; j < nS; j += NT) {
+        const unsigned s = (unsigned)((long long)j * H / nS);
+        int lo = 0, hi = 2 * nk - 1;   // last q with posPref[q] <= s
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (posPref[mid] <= s) lo = mid; else hi = mid - 1; }
+        smp[j] = (unsigned)ix.post[posStart[lo] + (s - posPref[lo])].x;
+      }
+      __syncthreads();
+      if (nS > 1) bitonicSort32(smp, nS);
+      __syncthreads();
+      for (int p = lane; p <= P; p += NT) bd[p] = p == 0 ? 0 : p == P ? 0x7FFFFFFF : (int)smp[(long long)p * nS / P];
+    } else if (lane == 0) { bd[0] = 0; for (int p = 1; p <= P; ++p) bd[p] = 0x7FFFFFFF; }
+    __syncthreads();
+  }
   if (slot >= 0) {
     uint2 *sd = wd.seed + (size_t)slot * T4_WIDE_SEEDS;
     for (int q = lane; q <= 2 * nk; q += NT) { uint2 v; v.x = q < 2 * nk ? posStart[q] : 0u; v.y = posPref[q]; sd[q] = v; }   // (start, exclusive prefix); entry 2 nk holds H
@@ -74,7 +95,7 @@ __device__ T4_NI void wideDeferRead(const T4IndexView &ix, WaveMem &wm, WaveStat
 // Reads known to be heavy (the window entry's last query was served wide) skip the LDS tier: their seed stage runs here, on a
 // second stream, and the wide kernels behind it run BESIDE the round's query kernel instead of after it.
 __global__ __launch_bounds__(512) void wideSeedKernel(T4IndexView ixArg, T4BatchView bvArg, T4Work wk, T4QueryArgs qa, T4Wide wd, const int *list, int nList) {
-  __shared__ unsigned long long s_code[2 * T4_MAXL + 2];
+  __shared__ unsigned long long s_code[2048];   // k-mer codes of the seed stage, then the sample of the hits' contigs (4096 x u32)
   __shared__ unsigned s_pref[2 * T4_MAXL + 2];
   __shared__ unsigned s_start[2 * T4_MAXL + 2];
   __shared__ char s_seg[T4_MAXL + 8];
@@ -87,7 +108,7 @@ __global__ __launch_bounds__(512) void wideSeedKernel(T4IndexView ixArg, T4Batch
     s_ix = ixArg; s_bv = bvArg;
     WaveMem &m = s_wm;
     m.keys = s_code; m.pairs = s_pref; m.cand = s_pref; m.ov = (OvRec *)s_start; m.fin = (OvRec *)s_start; m.ord = (unsigned short *)s_start;
-    m.cap = 2 * T4_MAXL; m.maxOv = 0; m.maxFin = 0; m.candCap = 0; m.ldsArrays = 1; m.hitLimit = 0;
+    m.cap = 2048; m.maxOv = 0; m.maxFin = 0; m.candCap = 0; m.ldsArrays = 1; m.hitLimit = 0;
     m.ldsSort = nullptr; m.ldsSortCap = 0; m.dirBuf = (unsigned char *)s_code; m.dirBytes = 0;
     m.seg = s_seg; m.rc = s_rc;
   }
@@ -114,6 +135,7 @@ __device__ __forceinline__ int wideParts(const T4Wide &wd) { const int n = wd.ct
 __global__ __launch_bounds__(256) void wideScatterKernel(T4IndexView ix, T4Wide wd) {
   __shared__ unsigned s_pref[T4_WIDE_SEEDS];
   __shared__ unsigned s_start[T4_WIDE_SEEDS];
+  __shared__ int s_bound[T4_WIDE_MAXP + 1];
   __shared__ int s_item[2];
   if (wd.ctl[2]) return;
   const int nR = wideReads(wd), lane = threadIdx.x, NT = blockDim.x;
@@ -140,6 +162,8 @@ __global__ __launch_bounds__(256) void wideScatterKernel(T4IndexView ix, T4Wide 
     if (w != loaded) {
       const uint2 *sd = wd.seed + (size_t)w * T4_WIDE_SEEDS;
       for (int q = lane; q <= nq; q += NT) { const uint2 v = sd[q]; s_start[q] = v.x; s_pref[q] = v.y; }
+      const int *bd = wd.bounds + (size_t)w * (T4_WIDE_MAXP + 1);
+      for (int p = lane; p <= pl.P; p += NT) s_bound[p] = bd[p];
       loaded = w;
       __syncthreads();
     }
@@ -158,8 +182,9 @@ __global__ __launch_bounds__(256) void wideScatterKernel(T4IndexView ix, T4Wide 
         const int st = q >= pl.nk, a = st ? q - pl.nk : q;
         key[t] = ((st ? 0ull : 1ull) << 63) | ((unsigned long long)po.x << (T4_C_BITS + T4_B_BITS)) |
                  ((unsigned long long)(a - po.y + T4_C_BIAS) << T4_B_BITS) | (unsigned long long)po.y;
-        int p = po.x / pl.Wd;
-        part[t] = p >= pl.P ? pl.P - 1 : p;
+        int plo = 0, phi = pl.P - 1;   // last partition whose first contig is <= this one
+        while (plo < phi) { const int mid = (plo + phi + 1) >> 1; if (s_bound[mid] <= po.x) plo = mid; else phi = mid - 1; }
+        part[t] = plo;
       }
     }
     // one atomic per (wavefront, partition) instead of one per posting: consecutive postings of a list belong to neighbouring
