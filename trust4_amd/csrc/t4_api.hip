@@ -1839,9 +1839,10 @@ int aqEnd(t4_ctx *c, AqResult *res) {
         if (flags & (4 | 8)) {
           if (q.wideSafety >= 32 * 256) return fail(c, T4_ERR_UNSUPPORTED, "wide query: a contig range of one contig overflows a partition");
           q.wideSafety *= 2;
-          // contigs that carry one gene segment cluster in the id order (clones of a family are seeded one after the other): ranges of equal
-          // width are unevenly filled, and a call that had to be repeated with finer partitions says the next ones will too
-          c->wideSafetyKeep = q.wideSafety; c->wideCallsSinceRepeat = 0;
+          // keys: the partitions are quantiles of a SAMPLE of the hits' contigs; when a sample misjudged one, the next calls (the same
+          // reads again, mostly) are planned less full as well. Overlaps of a partition: one read's matter (hundreds of short chains in
+          // one contig range) -- finer partitions for this call only.
+          if (flags & 4) { c->wideSafetyKeep = q.wideSafety < 128 ? q.wideSafety : 128; c->wideCallsSinceRepeat = 0; }
         }
         if (flags & 16) { if ((r = ensureWide(c, n, 1, ctl[3] > ctlA[3] ? ctl[3] : ctlA[3]))) return r; }
         ++c->wideRetries; ++q.attempt;
