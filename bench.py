@@ -380,6 +380,13 @@ def sharded_cells(args, rank, local_rank, world, dist):
     """N > 1: one C5-recipe sample, cells sharded by rank, one RCCL all-gather inside the engine at the end (strong scaling)."""
     import torch
     import trust4_amd.dist as t4dist
+    dry = bool(os.environ.get("T4_BENCH_CPU_DRYRUN"))   # tests/test_dist_gloo.py: the same plumbing over gloo, the emulated driver and the file transport
+    dev = "cpu" if dry else "cuda"
+    driver = os.environ.get("T4_DRIVER", DRIVER) if dry else DRIVER
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
     pairs, cells = args.cells_pairs * world, args.cells * world
     tmp = os.path.join(tempfile.gettempdir(), "t4bench_cells_%s" % os.environ.get("MASTER_PORT", "0"))
     fa, pre = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "c5")
@@ -395,31 +402,36 @@ def sharded_cells(args, rank, local_rank, world, dist):
     threads = max(1, min(args.cells_threads, host_cores() // world))
     out = os.path.join(tmp, "sharded")
     id_file = out + ".rcclid"
+    gdir = os.path.join(tmp, "gather")
 
     def one_step(timed):
         if rank == 0 and os.path.exists(id_file):
             os.remove(id_file)
-        torch.cuda.synchronize()
+        if rank == 0 and dry:
+            shutil.rmtree(gdir, ignore_errors=True)
+            os.makedirs(gdir)
+        sync()
         dist.barrier()
-        env = dict(os.environ, T4_DEVICE=str(local_rank), T4_STATS_JSON=os.path.join(tmp, "stats_rank%d.json" % rank))
+        env = dict(os.environ, T4_DEVICE="0" if dry else str(local_rank), T4_STATS_JSON=os.path.join(tmp, "stats_rank%d.json" % rank))
+        transport = ["--gatherDir", gdir] if dry else ["--rcclId", id_file]
         t0 = time.perf_counter()
-        p = subprocess.run([DRIVER, "-t", str(threads)] + argv + ["-o", out, "--cellShard", "%d/%d" % (rank, world), "--rcclId", id_file], env=env, stderr=subprocess.PIPE, text=True)
+        p = subprocess.run([driver, "-t", str(threads)] + argv + ["-o", out, "--cellShard", "%d/%d" % (rank, world)] + transport, env=env, stderr=subprocess.PIPE, text=True)
         if p.returncode:
             raise SystemExit("rank %d: trust4-hip --cellShard failed (%d): %s" % (rank, p.returncode, " | ".join(p.stderr.strip().split("\n")[-4:])))
-        torch.cuda.synchronize()
+        sync()
         dist.barrier()
         return time.perf_counter() - t0
 
     for _ in range(args.warmup):
         one_step(False)
-    torch.cuda.synchronize()
+    sync()
     dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step(True)
-    torch.cuda.synchronize()
+    sync()
     dist.barrier()
-    dt = t4dist.max_over_ranks(dist, time.perf_counter() - t0, "cuda")
+    dt = t4dist.max_over_ranks(dist, time.perf_counter() - t0, dev)
     # replicated-phase seconds of this rank (everything before the Add pass runs on every rank), gathered for the report
     rep = add = 0.0
     try:
@@ -427,8 +439,8 @@ def sharded_cells(args, rank, local_rank, world, dist):
         rep, add = ph["trimmed_ready"], ph["assembled"] - ph["trimmed_ready"]
     except Exception:   # noqa: BLE001
         pass
-    t = torch.tensor([rep, add], dtype=torch.float64, device="cuda")
-    parts = [torch.zeros(2, dtype=torch.float64, device="cuda") for _ in range(world)]
+    t = torch.tensor([rep, add], dtype=torch.float64, device=dev)
+    parts = [torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(world)]
     dist.all_gather(parts, t)
     if rank == 0:
         line = {"metric": "stage-1 assembly read pairs/sec (150 bp PE), whole stage 1, barcode mode, cells sharded over the GPUs", "value": pairs * args.steps / dt,
@@ -443,7 +455,7 @@ def sharded_cells(args, rank, local_rank, world, dist):
         md5s = {x: file_md5(out + x) for x in OUT_SUFFIXES}
         one = os.path.join(tmp, "one_rank")
         t1 = time.perf_counter()
-        p = subprocess.run([DRIVER, "-t", str(threads)] + argv + ["-o", one], env=dict(os.environ, T4_DEVICE=str(local_rank)), stderr=subprocess.PIPE, text=True)
+        p = subprocess.run([driver, "-t", str(threads)] + argv + ["-o", one], env=dict(os.environ, T4_DEVICE="0" if dry else str(local_rank)), stderr=subprocess.PIPE, text=True)
         d1 = time.perf_counter() - t1
         if p.returncode:
             line["one_rank"] = {"error": p.stderr.strip().split("\n")[-1][:300]}
@@ -486,13 +498,16 @@ def main():
     rank, local_rank, world = t4dist.env_rank()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
+    dry = bool(os.environ.get("T4_BENCH_CPU_DRYRUN")) and world > 1   # the N > 1 plumbing without GPUs (CPU test suite): gloo, emulated driver, file transport
+    if not dry and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the measured path")
-    torch.cuda.set_device(local_rank)
-    dist = t4dist.init("nccl")   # RCCL: barrier + max-reduce of the timed interval (the data-path collective of the sharded run is inside the engine)
+    if not dry:
+        torch.cuda.set_device(local_rank)
+    dist = t4dist.init("gloo" if dry else "nccl")   # RCCL: barrier + max-reduce of the timed interval (the data-path collective of the sharded run is inside the engine)
 
-    if rank == 0:
+    if rank == 0 and not dry:
         trust4_amd.build.build()
+    if rank == 0:
         t4libs.build_checkers()
     if dist:
         dist.barrier()

@@ -150,6 +150,33 @@ def test_engine_merge_four_ranks_gpu(tmp_path):
     run_engine_merge(tmp_path, os.path.join(ROOT, "trust4_amd", "bin", "trust4-hip"), 4000, 60, 12, 4)
 
 
+def test_bench_gpus2_plumbing_dry_run(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (one process per rank, RANK / WORLD_SIZE / MASTER_* in the environment), without
+    GPUs: T4_BENCH_CPU_DRYRUN swaps RCCL for gloo, trust4-hip for the emulated driver and --rcclId for the file transport. Everything
+    else is the code an 8-GPU node runs: the sample, the sharded steps, max over ranks, the per-rank phase report, the one-rank run and
+    the md5 comparison of its files with the sharded run's."""
+    import json
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_stage1_e2e import _emulated_driver
+    exe = _emulated_driver()
+    port = 29700 + (os.getpid() % 200)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   T4_BENCH_CPU_DRYRUN="1", T4_DRIVER=exe, HIPEMU_THREADS="2", TMPDIR=str(tmp_path))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--cells-pairs", "60", "--cells", "4",
+                                       "--cells-threads", "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], [o[1][-600:] for o in outs]
+    line = json.loads([x for x in outs[0][0].strip().split("\n") if x.startswith("{")][-1])
+    assert not [x for x in outs[1][0].split("\n") if x.startswith("{")]          # rank 0 alone prints the line
+    assert line["n_gpus"] == 2 and line["steps"] == 1 and line["warmup"] == 1 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["pairs"] == 120 and line["config"]["cells"] == 8
+    assert line["one_rank"]["identical"] is True
+    assert len(line["config"]["per_rank_s"]["replicated_phases"]) == 2 and min(line["config"]["per_rank_s"]["replicated_phases"]) > 0
+
+
 def test_two_rank_barcode_stage1(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import subprocess
