@@ -346,6 +346,25 @@ def test_bulk_live_set_paths_emulated(tmp_path, env):
         assert m and int(m.group(1)) > 0, log[-600:]
 
 
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
+def test_extra_mate_records_are_ignored_emulated(tmp_path):
+    """a mate file with more records than the first read file: the reference's `while ( reads.Next() )` (main.cpp:787-800) never reads
+    the extra ones; neither does the block-wise reader of trust4-hip"""
+    fa = str(tmp_path / "ref.fa")
+    _gunzip(REF_FA, fa)
+    pre = str(tmp_path / "b")
+    subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, "150", "4", "13", pre], check=True, stdout=subprocess.DEVNULL)
+    with open(pre + "_2.fq", "a") as f:
+        for i in range(3):
+            f.write("@extra%d\n%s\n+\n%s\n" % (i, "ACGT" * 30, "I" * 120))
+    args = ["--skipMateExtension", "-f", fa, "-1", pre + "_1.fq", "-2", pre + "_2.fq"]
+    ref_out, my_out = str(tmp_path / "ref"), str(tmp_path / "mine")
+    subprocess.run([REF_BIN, "-t", "1"] + args + ["-o", ref_out], check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([_emulated_driver(), "-t", "2"] + args + ["-o", my_out], check=True, stderr=subprocess.DEVNULL)
+    for suffix in ("_raw.out", "_assembled_reads.fa", "_final.out"):
+        assert filecmp.cmp(ref_out + suffix, my_out + suffix, shallow=False), suffix
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not shipped")
 @pytest.mark.parametrize("env", [{}, {"T4_AQ_CAP_LIMIT": "2000"}, {"T4_AQ_CAP_LIMIT": "2000", "T4_WIDE_PCAP": "512", "T4_WIDE_PARTS": "8"}, {"T4_AQ_CAP_LIMIT": "2000", "T4_WIDE_OFF": "1"}, {"T4_AQ_FORCE_GLOBAL": "1"}, {"T4_AQ_EXTEND_DEFER": "2"},

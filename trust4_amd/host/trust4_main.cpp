@@ -519,7 +519,7 @@ int main(int argc, char *argv[]) {
   // t4_mate_overlap (one pair per wavefront) instead of the host threads; the merge itself stays on the host.
   const bool gpuMate = getenv("T4_GPU_MATEOVERLAP") && atoi(getenv("T4_GPU_MATEOVERLAP")) != 0;
   const bool gpuProcess = getenv("T4_GPU_PROCESSREAD") && atoi(getenv("T4_GPU_PROCESSREAD")) != 0;
-  long long ppKinds[4] = {0, 0, 0, 0};
+  long long ppKinds[4] = {0, 0, 0, 0}, ppBlocksOnHost = 0;
   // (a block is processed on the host threads WHILE the next one is parsed: processBlock runs on its own thread, one block at a time)
   auto processBlock = [&](std::vector<InPair> &block) {   // ProcessRead of every pair of the block on the host threads, results appended in input order
     auto t0 = std::chrono::steady_clock::now();
@@ -575,9 +575,11 @@ int main(int argc, char *argv[]) {
       }
       ppR.assign((size_t)ppOut.back() + 1, '\0'); ppQ.assign((size_t)ppOut.back() + 1, '\0');
       meta.assign((size_t)n * 4, 0);
-      if ((rc = t4_process_pairs(ctx, n, o1.data(), c1.data(), anyQ1 ? q1.data() : nullptr, o2.data(), c2.data(), anyQ2 ? q2.data() : nullptr, hq.data(),
-                                 ppOut.data(), &ppR[0], &ppQ[0], meta.data()))) die(ctx, "t4_process_pairs", rc);
-      for (int i = 0; i < n; ++i) if (block[(size_t)i].haveMate) ++ppKinds[meta[(size_t)i * 4] & 3];
+      rc = t4_process_pairs(ctx, n, o1.data(), c1.data(), anyQ1 ? q1.data() : nullptr, o2.data(), c2.data(), anyQ2 ? q2.data() : nullptr, hq.data(),
+                            ppOut.data(), &ppR[0], &ppQ[0], meta.data());
+      if (rc == T4_ERR_UNSUPPORTED) { meta.clear(); ++ppBlocksOnHost; }   // (a mate beyond the kernel's 384 bp: this block takes the host's ProcessRead, which has no such limit)
+      else if (rc) die(ctx, "t4_process_pairs", rc);
+      else for (int i = 0; i < n; ++i) if (block[(size_t)i].haveMate) ++ppKinds[meta[(size_t)i * 4] & 3];
     }
     parallelFor((long long)block.size(), threadCnt, [&](long long i) {
       const InPair &ip = block[(size_t)i];
@@ -654,7 +656,10 @@ int main(int argc, char *argv[]) {
       u.r.swap(bR);
       const size_t n = u.r.size();
       if (hasMate) {
-        if (!mateReads.nextBlock(bM) || bM.size() != n) uneven("The two mate-pair read files have different number of reads.");
+        // (records of the mate file beyond the last read of the first file are ignored, as the reference's `while ( reads.Next() )`
+        // ignores them, main.cpp:787-800; a mate file that ends early is refused -- the reference reads stale buffers there)
+        if (!mateReads.nextBlock(bM) || bM.size() < n) uneven("The mate-pair read file has fewer reads than the first read file.");
+        if (bM.size() > n) bM.resize(n);
         u.m.swap(bM);
       }
       u.bc.assign(n, -1); u.umi.assign(n, -1); u.skip.assign(n, 0);
@@ -700,6 +705,7 @@ int main(int argc, char *argv[]) {
   { const auto tw = std::chrono::steady_clock::now(); if (processThread.joinable()) processThread.join(); secWaitProcess += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count(); }
   if (getenv("T4_TIMING")) PrintLog("timing: input loop %.2f s, of which %.2f s waiting for the ProcessRead of the batch before", std::chrono::duration<double>(std::chrono::steady_clock::now() - tInput0).count(), secWaitProcess);
   if (gpuProcess) PrintLog("ProcessRead on the device: %lld pairs stay as they are, %lld read-through, %lld merged, %lld with one mate for both", ppKinds[0], ppKinds[1], ppKinds[2], ppKinds[3]);
+  if (gpuProcess && ppBlocksOnHost) PrintLog("ProcessRead: %lld blocks held a mate beyond the device path's length and were processed on the host threads", ppBlocksOnHost);
   if (getenv("T4_TIMING")) PrintLog("timing: input parsed and mates processed (ProcessRead %.2f s on %d threads, merge %.2f s)", secProcess, threadCnt, secMerge);
   int readCnt = (int)sortedReads.size();
   int maxReadLen = 0;
