@@ -142,6 +142,76 @@ def test_engine_merge_two_and_eight_ranks(tmp_path):
     run_engine_merge(tmp_path / "w8", exe, 100, 11, 10, 8, env={"HIPEMU_THREADS": "1"})
 
 
+def run_read_shard(tmp_path, driver, pairs, clones, seed, world, env=None):
+    """--readShard R/N (bulk mode): one sample's rough-annotation pass cut into `world` ranges of the sorted distinct reads,
+    a process per range, the 160-byte records exchanged through --gatherDir; rank 0 runs the ordered pass alone and must write the
+    single-process files byte for byte, the other ranks end with status 0 after the exchange and write nothing."""
+    import filecmp
+    import gzip
+    import shutil
+    import subprocess
+    import t4libs
+    t4libs.build_checkers()
+    fa = str(tmp_path / "ref.fa")
+    with gzip.open(t4libs.REF_FA, "rb") as f, open(fa, "wb") as g:
+        shutil.copyfileobj(f, g)
+    pre = str(tmp_path / "bulk")
+    subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, str(pairs), str(clones), str(seed), pre], check=True)
+    argv = ["--skipMateExtension", "-f", fa, "-1", pre + "_1.fq", "-2", pre + "_2.fq"]
+    e = dict(os.environ)
+    e.update(env or {})
+    single = str(tmp_path / "single")
+    subprocess.run([driver] + argv + ["-o", single], check=True, env=e)
+    gdir = tmp_path / "gather"
+    gdir.mkdir()
+    outs = [str(tmp_path / ("rank%d" % r)) for r in range(world)]
+    procs = [subprocess.Popen([driver] + argv + ["-o", outs[r], "--readShard", "%d/%d" % (r, world), "--gatherDir", str(gdir)], env=e, stderr=subprocess.PIPE, text=True)
+             for r in range(world)]
+    logs = [p.communicate(timeout=900)[1] for p in procs]
+    assert [p.returncode for p in procs] == [0] * world, logs
+    for r in range(world):
+        assert "Rough annotations of %d read ranges exchanged" % world in logs[r]
+    for suffix in ("_raw.out", "_final.out", "_assembled_reads.fa"):
+        assert filecmp.cmp(single + suffix, outs[0] + suffix, shallow=False), suffix
+        for r in range(1, world):
+            assert not os.path.exists(outs[r] + suffix)
+    assert open(single + "_raw.out").read().count(">") > 0
+    return logs
+
+
+def test_read_shard_two_and_three_ranks(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_stage1_e2e import _emulated_driver
+    exe = _emulated_driver()
+    (tmp_path / "w2").mkdir()
+    (tmp_path / "w3").mkdir()
+    run_read_shard(tmp_path / "w2", exe, 300, 12, 21, 2)
+    logs = run_read_shard(tmp_path / "w3", exe, 200, 8, 22, 3, env={"HIPEMU_THREADS": "2"})
+    import re
+    spans = sorted(tuple(int(x) for x in re.search(r"this rank: reads (\d+)-(\d+) of (\d+)", l).groups()) for l in logs)
+    assert spans[0][0] == 0 and spans[-1][1] == spans[-1][2] and all(spans[i][1] == spans[i + 1][0] for i in range(2))   # the ranges tile the read list
+    assert all(b > a for a, b, _ in spans)
+
+
+def test_read_shard_refuses_without_transport_or_with_cell_shard(tmp_path):
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_stage1_e2e import _emulated_driver
+    exe = _emulated_driver()
+    r = subprocess.run([exe, "--skipMateExtension", "-f", "x.fa", "-1", "a", "-2", "b", "--readShard", "0/2"], stderr=subprocess.PIPE, text=True)
+    assert r.returncode != 0 and "--readShard needs" in r.stderr
+    r = subprocess.run([exe, "-f", "x.fa", "-1", "a", "-2", "b", "--readShard", "2/2", "--gatherDir", str(tmp_path)], stderr=subprocess.PIPE, text=True)
+    assert r.returncode != 0 and "R/N" in r.stderr
+
+
+@pytest.mark.gpu
+def test_read_shard_four_ranks_gpu(tmp_path):
+    """the same with the real engine: four ranks share the box's one GPU, file transport"""
+    import trust4_amd.build as b
+    b.build()
+    run_read_shard(tmp_path, os.path.join(ROOT, "trust4_amd", "bin", "trust4-hip"), 20000, 400, 23, 4)
+
+
 @pytest.mark.gpu
 def test_engine_merge_four_ranks_gpu(tmp_path):
     """the same with the real engine: four ranks share the box's one GPU, file transport"""

@@ -65,7 +65,9 @@ const char *USAGE =
     "Extension (multi-GPU, see trust4_amd/stage1_dist.py):\n"
     "\t--cellShard R/N: barcode mode only; assemble the R-th of N contiguous ranges of cells, write shard outputs\n"
     "\t--rcclId FILE: with --cellShard, one process per GPU: gather the shards over RCCL (rank 0 creates FILE, the communicator id) and write the merged -o files\n"
-    "\t--gatherDir DIR: the same exchange through files in DIR (a directory every rank sees) instead of RCCL\n";
+    "\t--gatherDir DIR: the same exchange through files in DIR (a directory every rank sees) instead of RCCL\n"
+    "\t--readShard R/N: one sample over N processes (one per GPU): the rough annotation of the R-th range of the distinct reads here, the results\n"
+    "\t                 all-gathered (--rcclId / --gatherDir); rank 0 runs the ordered assembly pass and writes the files, the others end after the exchange\n";
 
 void PrintLog(const char *fmt, ...) {
   char buf[2048], stime[256];
@@ -433,10 +435,11 @@ int main(int argc, char *argv[]) {
                                          {"minHitLen", required_argument, 0, 10006}, {"cgeneEnd", required_argument, 0, 10008},
                                          {"barcode", required_argument, 0, 10002}, {"UMI", required_argument, 0, 10004},
                                          {"keepNoBarcode", no_argument, 0, 10003}, {"contigMinCov", required_argument, 0, 10007},
-                                         {"cellShard", required_argument, 0, 10100}, {"rcclId", required_argument, 0, 10101}, {"gatherDir", required_argument, 0, 10102}, {"debug-ns", required_argument, 0, 10000},
+                                         {"cellShard", required_argument, 0, 10100}, {"rcclId", required_argument, 0, 10101}, {"gatherDir", required_argument, 0, 10102}, {"readShard", required_argument, 0, 10103}, {"debug-ns", required_argument, 0, 10000},
                                          {(char *)0, 0, 0, 0}};
   int indexKmerLength = 9, changeKmerLengthThreshold = 4096, trimLevel = 1, minHitLen = -1, constantGeneEnd = 200;
   int shardRank = 0, shardCount = 1, threadCnt = 1, contigMinCov = 0;
+  int annotRank = 0, annotCount = 1;   // --readShard R/N: the read-only pass of ONE sample (rough annotation) by read range over N processes, results all-gathered; rank 0 goes on alone
   std::string gatherDir;    // --gatherDir DIR: the same exchange through files of a directory every rank sees (tests without RCCL)
   std::string rcclIdPath;   // --rcclId FILE: the shards' results are gathered inside the engine (t4_comm: RCCL), rank 0 writes the merged files
   bool keepMissingBarcode = false, skipMateExtension = false;
@@ -464,6 +467,7 @@ int main(int argc, char *argv[]) {
     else if (c == 10004) { umiFile.files.push_back(optarg); hasUmi = true; }
     else if (c == 10101) rcclIdPath = optarg;
     else if (c == 10102) gatherDir = optarg;
+    else if (c == 10103) { if (sscanf(optarg, "%d/%d", &annotRank, &annotCount) != 2 || annotCount < 1 || annotRank < 0 || annotRank >= annotCount) { fprintf(stderr, "--readShard takes R/N with 0 <= R < N\n"); return EXIT_FAILURE; } }
     else if (c == 10100) { if (sscanf(optarg, "%d/%d", &shardRank, &shardCount) != 2 || shardCount < 1 || shardRank < 0 || shardRank >= shardCount) { fprintf(stderr, "--cellShard takes R/N with 0 <= R < N\n"); return EXIT_FAILURE; } }
     else if (c == 10003) keepMissingBarcode = true;
     else if (c == 10007) contigMinCov = atoi(optarg);
@@ -479,6 +483,8 @@ int main(int argc, char *argv[]) {
   }
   if (getenv("T4_THREADS")) threadCnt = atoi(getenv("T4_THREADS")) > 0 ? atoi(getenv("T4_THREADS")) : 1;
   if (shardCount > 1 && (!hasBarcode || keepMissingBarcode)) { fprintf(stderr, "--cellShard needs --barcode: without barcodes the Add pass does not shard (DESIGN.md 6).\n"); return EXIT_FAILURE; }
+  if (annotCount > 1 && shardCount > 1) { fprintf(stderr, "--readShard and --cellShard are two ways to spread one sample: take one.\n"); return EXIT_FAILURE; }
+  if (annotCount > 1 && rcclIdPath.empty() && gatherDir.empty()) { fprintf(stderr, "--readShard needs --rcclId FILE or --gatherDir DIR for the exchange of the annotations.\n"); return EXIT_FAILURE; }
 
   // The device, its runtime and the reference set come up on their own thread while the reads are parsed, merged and counted
   // (nothing before the rough annotation touches the GPU); gpuReady() joins it and reports its errors as the serial code did.
@@ -865,13 +871,20 @@ int main(int argc, char *argv[]) {
   {
     const size_t CHUNK = (size_t)4 << 20;   // distinct reads per t4_annotate_rough call
     std::string bases; std::vector<int64_t> off; std::vector<int> firstOf; std::vector<t4_overlap> out;
-    int i = 0;
-    while (i < readCnt) {
+    // --readShard R/N (bulk mode: "the read-only passes shard by read range, index replicated, no exchange except gathering
+    // 128-B results"): this process annotates the R-th of N ranges of read positions (cut where a new distinct read starts)
+    int sliceLo = 0, sliceHi = readCnt;
+    if (annotCount > 1) {
+      auto cut = [&](int r) { long long p = (long long)readCnt * r / annotCount; while (p > 0 && p < readCnt && sortedReads[(size_t)p].read == sortedReads[(size_t)p - 1].read) ++p; return (int)(p > readCnt ? readCnt : p); };
+      sliceLo = cut(annotRank); sliceHi = cut(annotRank + 1);
+    }
+    int i = sliceLo;
+    while (i < sliceHi) {
       bases.clear(); off.assign(1, 0); firstOf.clear();
       const int chunkBegin = i;
-      for (; i < readCnt && firstOf.size() < CHUNK; ++i)
+      for (; i < sliceHi && firstOf.size() < CHUNK; ++i)
         if (i == 0 || sortedReads[i].read != sortedReads[i - 1].read) { bases += sortedReads[i].read; off.push_back((int64_t)bases.size()); firstOf.push_back(i); }
-      while (i < readCnt && sortedReads[i].read == sortedReads[i - 1].read) ++i;   // the copies of the chunk's last read belong to it
+      while (i < sliceHi && sortedReads[i].read == sortedReads[i - 1].read) ++i;   // the copies of the chunk's last read belong to it
       const int n = (int)firstOf.size();
       if (n == 0) break;
       t4_batch *batch = nullptr;
@@ -883,6 +896,52 @@ int main(int argc, char *argv[]) {
       for (int k = -1, t = chunkBegin; t < i; ++t) {
         if (k + 1 < n && firstOf[k + 1] == t) ++k;
         for (int j = 0; j < 4; ++j) sortedReads[t].g[j] = out[4 * (size_t)k + j];
+      }
+    }
+    if (annotCount > 1) {
+      // the one exchange of this mode: every rank's annotation records (4 x 40 bytes per read position of its range) to every rank --
+      // RCCL all-gather on the ctx's stream (t4_comm) or files of a shared directory; the ranges are known to all, so no header travels
+      std::string mine((size_t)(sliceHi - sliceLo) * 4 * sizeof(t4_overlap), '\0');
+      for (int t = sliceLo; t < sliceHi; ++t) memcpy(&mine[(size_t)(t - sliceLo) * 4 * sizeof(t4_overlap)], sortedReads[(size_t)t].g, 4 * sizeof(t4_overlap));
+      std::vector<std::string> got((size_t)annotCount);
+      if (!gatherDir.empty()) {
+        const std::string mineP = gatherDir + "/annot.rank" + std::to_string(annotRank);
+        FILE *fp = fopen((mineP + ".tmp").c_str(), "wb");
+        if (!fp || fwrite(mine.data(), 1, mine.size(), fp) != mine.size()) { fprintf(stderr, "trust4-hip: cannot write %s\n", mineP.c_str()); return EXIT_FAILURE; }
+        fclose(fp);
+        if (rename((mineP + ".tmp").c_str(), mineP.c_str())) { fprintf(stderr, "trust4-hip: cannot create %s\n", mineP.c_str()); return EXIT_FAILURE; }
+        for (int r = 0; r < annotCount; ++r) {
+          if (r == annotRank) { got[(size_t)r] = mine; continue; }
+          bool ok = false;
+          for (int tries = 0; tries < 36000 && !ok; ++tries) {
+            FILE *fq = fopen((gatherDir + "/annot.rank" + std::to_string(r)).c_str(), "rb");
+            if (fq) { char buf[1 << 16]; size_t nr; std::string &dst = got[(size_t)r]; dst.clear(); while ((nr = fread(buf, 1, sizeof buf, fq)) > 0) dst.append(buf, nr); fclose(fq); ok = true; }
+            else usleep(50000);
+          }
+          if (!ok) { fprintf(stderr, "trust4-hip: no annotations from rank %d in %s\n", r, gatherDir.c_str()); return EXIT_FAILURE; }
+        }
+      } else {
+        t4_comm *comm = nullptr;
+        if ((rc = t4_comm_init(ctx, annotRank, annotCount, rcclIdPath.c_str(), &comm))) die(ctx, "t4_comm_init", rc);
+        void *all = nullptr;
+        std::vector<int64_t> sizes((size_t)annotCount);
+        if ((rc = t4_comm_allgather_bytes(comm, mine.data(), (int64_t)mine.size(), &all, sizes.data()))) die(ctx, "t4_comm_allgather_bytes", rc);
+        size_t at = 0;
+        for (int r = 0; r < annotCount; ++r) { got[(size_t)r].assign((const char *)all + at, (size_t)sizes[(size_t)r]); at += (size_t)sizes[(size_t)r]; }
+        free(all);
+        t4_comm_destroy(comm);
+      }
+      for (int r = 0; r < annotCount; ++r) {
+        auto cut = [&](int q) { long long p = (long long)readCnt * q / annotCount; while (p > 0 && p < readCnt && sortedReads[(size_t)p].read == sortedReads[(size_t)p - 1].read) ++p; return (int)(p > readCnt ? readCnt : p); };
+        const int lo = cut(r), hi = cut(r + 1);
+        if (got[(size_t)r].size() != (size_t)(hi - lo) * 4 * sizeof(t4_overlap)) { fprintf(stderr, "trust4-hip: rank %d sent %zu bytes of annotations, expected %zu\n", r, got[(size_t)r].size(), (size_t)(hi - lo) * 4 * sizeof(t4_overlap)); return EXIT_FAILURE; }
+        if (r != annotRank) for (int t = lo; t < hi; ++t) memcpy(sortedReads[(size_t)t].g, &got[(size_t)r][(size_t)(t - lo) * 4 * sizeof(t4_overlap)], 4 * sizeof(t4_overlap));
+      }
+      PrintLog("Rough annotations of %d read ranges exchanged (this rank: reads %d-%d of %d).", annotCount, sliceLo, sliceHi, readCnt);
+      if (annotRank != 0) {   // the ordered assembly pass is one chain: rank 0 runs it and writes the files
+        t4_index_destroy(refSet);
+        t4_destroy(ctx);
+        return 0;
       }
     }
   }
@@ -1384,7 +1443,7 @@ int main(int argc, char *argv[]) {
     PrintLog("Finish assembly. (%lld cells; GPU query batches %lld with %lld reads in %.2f s; %lld cell images, %.1f MB, staged in %.2f s)",
              (long long)barcodeIntToStr.size(), (long long)qb, (long long)rq, sq, (long long)im, by / 1e6, ss);
   };
-  if (!rcclIdPath.empty() || !gatherDir.empty()) {
+  if (annotCount == 1 && (!rcclIdPath.empty() || !gatherDir.empty())) {
     // ---- the one exchange of barcode mode, inside the engine. Every rank holds the contig records of its cells (ids local to the
     // shard) and its assembled reads. (1) a small all-gather: contig slots and byte counts of every rank; (2) every rank renumbers
     // ITS OWN records as the reference's cell-after-cell pass numbers them (id += the slots of the earlier ranks); (3) the renumbered
