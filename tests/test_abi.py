@@ -33,3 +33,16 @@ def test_no_cpu_fallback():
     import trust4_amd
     with pytest.raises(trust4_amd.T4Error):
         trust4_amd.Engine(0)
+
+
+def test_rccl_is_bound_at_run_time_not_at_load_time():
+    """libt4hip.so must load on a host without librccl (only t4_comm uses it, by dlopen at the first communicator): no NEEDED entry
+    and no undefined nccl* symbol."""
+    import subprocess
+    import trust4_amd.build as b
+    path = b.build()
+    dyn = subprocess.run(["readelf", "-d", path], check=True, stdout=subprocess.PIPE, text=True).stdout
+    needed = re.findall(r"\(NEEDED\)\s+Shared library: \[([^\]]+)\]", dyn)
+    assert needed and not [n for n in needed if "rccl" in n or "nccl" in n], needed
+    syms = subprocess.run(["nm", "-D", "--undefined-only", path], check=True, stdout=subprocess.PIPE, text=True).stdout
+    assert "nccl" not in syms

@@ -205,6 +205,31 @@ def test_read_shard_refuses_without_transport_or_with_cell_shard(tmp_path):
 
 
 @pytest.mark.gpu
+def test_read_shard_one_rank_rccl_gpu(tmp_path):
+    """`--readShard 0/1 --rcclId FILE`: the annotation records go through t4_comm_allgather_bytes (RCCL bound by dlopen, ncclCommInitRank,
+    two ncclAllGather) -- with one rank, a box has one GPU -- and the outputs are the plain run's."""
+    import filecmp
+    import gzip
+    import shutil
+    import subprocess
+    import t4libs
+    import trust4_amd.build as b
+    b.build()
+    exe = os.path.join(ROOT, "trust4_amd", "bin", "trust4-hip")
+    fa = str(tmp_path / "ref.fa")
+    with gzip.open(t4libs.REF_FA, "rb") as f, open(fa, "wb") as g:
+        shutil.copyfileobj(f, g)
+    pre = str(tmp_path / "bulk")
+    subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, "5000", "100", "24", pre], check=True, stdout=subprocess.DEVNULL)
+    argv = ["--skipMateExtension", "-f", fa, "-1", pre + "_1.fq", "-2", pre + "_2.fq"]
+    subprocess.run([exe] + argv + ["-o", str(tmp_path / "plain")], check=True, stderr=subprocess.DEVNULL)
+    p = subprocess.run([exe] + argv + ["-o", str(tmp_path / "rccl"), "--readShard", "0/1", "--rcclId", str(tmp_path / "id")], stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0 and "read ranges exchanged over RCCL" in p.stderr, p.stderr[-800:]
+    for suffix in ("_raw.out", "_final.out", "_assembled_reads.fa"):
+        assert filecmp.cmp(str(tmp_path / "plain") + suffix, str(tmp_path / "rccl") + suffix, shallow=False), suffix
+
+
+@pytest.mark.gpu
 def test_read_shard_four_ranks_gpu(tmp_path):
     """the same with the real engine: four ranks share the box's one GPU, file transport"""
     import trust4_amd.build as b

@@ -3,5 +3,5 @@
 cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p trust4_amd/variants/$name
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared "$@" -o trust4_amd/variants/$name/libt4hip.so trust4_amd/csrc/t4_api.hip trust4_amd/csrc/t4_assembler.cpp -lz -lpthread -L/opt/rocm/lib -lrccl 2>&1 | grep -i " error" | head
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared "$@" -o trust4_amd/variants/$name/libt4hip.so trust4_amd/csrc/t4_api.hip trust4_amd/csrc/t4_assembler.cpp -lz -lpthread -ldl 2>&1 | grep -i " error" | head
 echo "built $name"

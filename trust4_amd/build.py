@@ -19,7 +19,7 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-o", OUT, SRC, SRC_HOST, "-lz", "-lpthread", "-L/opt/rocm/lib", "-lrccl"]   # RCCL: t4_comm (the gather of barcode mode, ranks of one node)
+    cmd = [hipcc] + FLAGS + ["-o", OUT, SRC, SRC_HOST, "-lz", "-lpthread", "-ldl"]   # RCCL (t4_comm) is bound by dlopen when a communicator is first asked for
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -22,7 +22,9 @@
 #include <vector>
 
 #ifdef __HIPCC__
-#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is bound by dlopen in t4_comm_init
+#include <type_traits>
 #include <unistd.h>
 #endif
 #include "../../include/trust4_hip.h"
@@ -2349,13 +2351,77 @@ int64_t t4_cellstore_bytes_staged(const t4_cellstore *cs) { return cs ? cs->byte
 }  // extern "C"
 
 // ---- t4_comm: RCCL all-gather of byte strings between the ranks of one node (one process per GPU) -------------------------------
+#ifdef __HIPCC__
+// RCCL is bound when the first communicator is asked for (dlopen), not when libt4hip.so is loaded: a single-GPU host without
+// librccl still loads the library and runs everything but t4_comm. <rccl/rccl.h> gives the types only.
+struct RcclApi {
+  void *lib = nullptr;
+  decltype(&ncclGetUniqueId) getUniqueId = nullptr;
+  decltype(&ncclCommInitRank) commInitRank = nullptr;
+  decltype(&ncclCommDestroy) commDestroy = nullptr;
+  decltype(&ncclCommAbort) commAbort = nullptr;
+  decltype(&ncclCommGetAsyncError) commGetAsyncError = nullptr;
+  decltype(&ncclAllGather) allGather = nullptr;
+  decltype(&ncclSend) send = nullptr;
+  decltype(&ncclRecv) recv = nullptr;
+  decltype(&ncclGroupStart) groupStart = nullptr;
+  decltype(&ncclGroupEnd) groupEnd = nullptr;
+  std::string error;
+};
+static RcclApi *rcclApi() {
+  static std::mutex mu;
+  static RcclApi api;
+  std::lock_guard<std::mutex> lk(mu);
+  if (api.lib || !api.error.empty()) return &api;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  void *h = nullptr;
+  for (const char *nm : names) if ((h = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+  if (!h) { const char *e = dlerror(); api.error = std::string("librccl.so not found (") + (e ? e : "dlopen failed") + ")"; return &api; }
+  bool ok = true;
+  auto bind = [&](auto &fp, const char *sym) { fp = reinterpret_cast<std::remove_reference_t<decltype(fp)>>(dlsym(h, sym)); if (!fp) { ok = false; api.error = std::string("librccl.so lacks ") + sym; } };
+  bind(api.getUniqueId, "ncclGetUniqueId"); bind(api.commInitRank, "ncclCommInitRank"); bind(api.commDestroy, "ncclCommDestroy"); bind(api.commAbort, "ncclCommAbort"); bind(api.commGetAsyncError, "ncclCommGetAsyncError");
+  bind(api.allGather, "ncclAllGather"); bind(api.send, "ncclSend"); bind(api.recv, "ncclRecv");
+  bind(api.groupStart, "ncclGroupStart"); bind(api.groupEnd, "ncclGroupEnd");
+  if (!ok) { dlclose(h); return &api; }
+  api.lib = h;
+  return &api;
+}
+#endif
+
 struct t4_comm {
   t4_ctx *ctx = nullptr;
   int rank = 0, nranks = 1;
 #ifdef __HIPCC__
   ncclComm_t comm = nullptr;
+  RcclApi *rccl = nullptr;
 #endif
 };
+
+#ifdef __HIPCC__
+// The wait of a collective, bounded: a rank that died before it leaves the others in the kernel RCCL enqueued for ever.
+// Polls the stream; an asynchronous RCCL error or T4_COMM_TIMEOUT_S seconds (default 3600: ranks of a sharded sample may finish far
+// apart) abort the communicator and come back as an error instead of a hang.
+static int commWait(t4_comm *cm, const char *what) {
+  t4_ctx *c = cm->ctx;
+  const char *ev = getenv("T4_COMM_TIMEOUT_S");
+  const double limit = ev && atof(ev) > 0 ? atof(ev) : 3600.0;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (long long spin = 0;; ++spin) {
+    const hipError_t q = hipStreamQuery(c->stream);
+    if (q == hipSuccess) return T4_OK;
+    if (q != hipErrorNotReady) return fail(c, T4_ERR_HIP, "t4_comm (%s): %s", what, hipGetErrorString(q));
+    ncclResult_t ar = ncclSuccess;
+    const bool asyncBad = cm->comm && (spin & 1023) == 1023 && cm->rccl->commGetAsyncError(cm->comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress;
+    const bool late = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit;
+    if (asyncBad || late) {
+      if (cm->comm) { (void)cm->rccl->commAbort(cm->comm); cm->comm = nullptr; }
+      return fail(c, T4_ERR_HIP, late ? "t4_comm (%s): rank %d of %d waited %.0f s for the other ranks (T4_COMM_TIMEOUT_S); communicator aborted" : "t4_comm (%s): RCCL reported an asynchronous error on rank %d of %d (%.0f s); communicator aborted",
+                  what, cm->rank, cm->nranks, limit);
+    }
+    if (spin < 2000) std::this_thread::yield(); else usleep(200);
+  }
+}
+#endif
 
 extern "C" {
 
@@ -2363,10 +2429,12 @@ int t4_comm_init(t4_ctx *c, int rank, int nranks, const char *id_path, t4_comm *
   if (!c || !out || nranks < 1 || rank < 0 || rank >= nranks || !id_path) return T4_ERR_ARG;
 #ifdef __HIPCC__
   (void)hipSetDevice(c->device);
+  RcclApi *rccl = rcclApi();
+  if (!rccl->lib) return fail(c, T4_ERR_UNSUPPORTED, "t4_comm: %s", rccl->error.c_str());
   ncclUniqueId id;
   if (rank == 0) {
     (void)unlink(id_path);   // (an id left by an earlier run must not be taken for this one's)
-    if (ncclGetUniqueId(&id) != ncclSuccess) return fail(c, T4_ERR_HIP, "ncclGetUniqueId failed");
+    if (rccl->getUniqueId(&id) != ncclSuccess) return fail(c, T4_ERR_HIP, "ncclGetUniqueId failed");
     const std::string tmp = std::string(id_path) + ".tmp";
     FILE *fp = fopen(tmp.c_str(), "wb");
     if (!fp || fwrite(&id, sizeof id, 1, fp) != 1) { if (fp) fclose(fp); return fail(c, T4_ERR_IO, "cannot write %s", tmp.c_str()); }
@@ -2382,8 +2450,8 @@ int t4_comm_init(t4_ctx *c, int rank, int nranks, const char *id_path, t4_comm *
     if (!got) return fail(c, T4_ERR_IO, "no communicator id appeared at %s", id_path);
   }
   t4_comm *cm = new t4_comm();
-  cm->ctx = c; cm->rank = rank; cm->nranks = nranks;
-  if (ncclCommInitRank(&cm->comm, nranks, id, rank) != ncclSuccess) { delete cm; return fail(c, T4_ERR_HIP, "ncclCommInitRank(%d of %d) failed", rank, nranks); }
+  cm->ctx = c; cm->rank = rank; cm->nranks = nranks; cm->rccl = rccl;
+  if (rccl->commInitRank(&cm->comm, nranks, id, rank) != ncclSuccess) { delete cm; return fail(c, T4_ERR_HIP, "ncclCommInitRank(%d of %d) failed", rank, nranks); }
   *out = cm;
   return T4_OK;
 #else
@@ -2396,6 +2464,7 @@ int t4_comm_allgather_bytes(t4_comm *cm, const void *mine, int64_t n, void **all
   if (!cm || n < 0 || (n > 0 && !mine) || !all || !sizes) return T4_ERR_ARG;
 #ifdef __HIPCC__
   t4_ctx *c = cm->ctx;
+  if (!cm->comm) return fail(c, T4_ERR_ARG, "t4_comm: the communicator was aborted");
   (void)hipSetDevice(c->device);
   const int R = cm->nranks;
   // lengths first (8 bytes per rank), then the payloads padded to the longest: two ncclAllGather calls on the ctx's stream
@@ -2403,10 +2472,10 @@ int t4_comm_allgather_bytes(t4_comm *cm, const void *mine, int64_t n, void **all
   HIPCHK(c, hipMalloc(&dLen, sizeof(unsigned long long) * (size_t)(R + 1)));
   const unsigned long long myLen = (unsigned long long)n;
   HIPCHK(c, hipMemcpyAsync(dLen + R, &myLen, sizeof myLen, hipMemcpyHostToDevice, c->stream));
-  if (ncclAllGather(dLen + R, dLen, 1, ncclUint64, cm->comm, c->stream) != ncclSuccess) { (void)hipFree(dLen); return fail(c, T4_ERR_HIP, "ncclAllGather (lengths) failed"); }
+  if (cm->rccl->allGather(dLen + R, dLen, 1, ncclUint64, cm->comm, c->stream) != ncclSuccess) { (void)hipFree(dLen); return fail(c, T4_ERR_HIP, "ncclAllGather (lengths) failed"); }
   std::vector<unsigned long long> lens((size_t)R);
   HIPCHK(c, hipMemcpyAsync(lens.data(), dLen, sizeof(unsigned long long) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (int wr = commWait(cm, "the lengths")) return wr;
   (void)hipFree(dLen);
   size_t cap = 8, total = 0;
   for (int r = 0; r < R; ++r) { sizes[r] = (int64_t)lens[(size_t)r]; total += (size_t)lens[(size_t)r]; if ((size_t)lens[(size_t)r] > cap) cap = (size_t)lens[(size_t)r]; }
@@ -2415,14 +2484,14 @@ int t4_comm_allgather_bytes(t4_comm *cm, const void *mine, int64_t n, void **all
   HIPCHK(c, hipMalloc(&dSend, cap));
   if (hipMalloc(&dRecv, cap * (size_t)R) != hipSuccess) { (void)hipFree(dSend); return fail(c, T4_ERR_HIP, "out of device memory for the gather"); }
   if (n > 0) HIPCHK(c, hipMemcpyAsync(dSend, mine, (size_t)n, hipMemcpyHostToDevice, c->stream));
-  if (ncclAllGather(dSend, dRecv, cap, ncclUint8, cm->comm, c->stream) != ncclSuccess) { (void)hipFree(dSend); (void)hipFree(dRecv); return fail(c, T4_ERR_HIP, "ncclAllGather (payload) failed"); }
+  if (cm->rccl->allGather(dSend, dRecv, cap, ncclUint8, cm->comm, c->stream) != ncclSuccess) { (void)hipFree(dSend); (void)hipFree(dRecv); return fail(c, T4_ERR_HIP, "ncclAllGather (payload) failed"); }
   unsigned char *host = (unsigned char *)malloc(total ? total : 1);
   size_t at = 0;
   for (int r = 0; r < R; ++r) {
     if (lens[(size_t)r]) HIPCHK(c, hipMemcpyAsync(host + at, dRecv + cap * (size_t)r, (size_t)lens[(size_t)r], hipMemcpyDeviceToHost, c->stream));
     at += (size_t)lens[(size_t)r];
   }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (int wr = commWait(cm, "the all-gather")) return wr;
   (void)hipFree(dSend); (void)hipFree(dRecv);
   *all = host;
   return T4_OK;
@@ -2438,16 +2507,17 @@ int t4_comm_gather_bytes(t4_comm *cm, const void *mine, int64_t n, int root, voi
   *all = nullptr;
 #ifdef __HIPCC__
   t4_ctx *c = cm->ctx;
+  if (!cm->comm) return fail(c, T4_ERR_ARG, "t4_comm: the communicator was aborted");
   (void)hipSetDevice(c->device);
   const int R = cm->nranks;
   unsigned long long *dLen = nullptr;
   HIPCHK(c, hipMalloc(&dLen, sizeof(unsigned long long) * (size_t)(R + 1)));
   const unsigned long long myLen = (unsigned long long)n;
   HIPCHK(c, hipMemcpyAsync(dLen + R, &myLen, sizeof myLen, hipMemcpyHostToDevice, c->stream));
-  if (ncclAllGather(dLen + R, dLen, 1, ncclUint64, cm->comm, c->stream) != ncclSuccess) { (void)hipFree(dLen); return fail(c, T4_ERR_HIP, "ncclAllGather (lengths) failed"); }
+  if (cm->rccl->allGather(dLen + R, dLen, 1, ncclUint64, cm->comm, c->stream) != ncclSuccess) { (void)hipFree(dLen); return fail(c, T4_ERR_HIP, "ncclAllGather (lengths) failed"); }
   std::vector<unsigned long long> lens((size_t)R);
   HIPCHK(c, hipMemcpyAsync(lens.data(), dLen, sizeof(unsigned long long) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (int wr = commWait(cm, "the lengths")) return wr;
   (void)hipFree(dLen);
   size_t total = 0;
   for (int r = 0; r < R; ++r) { sizes[r] = (int64_t)lens[(size_t)r]; total += (size_t)lens[(size_t)r]; }
@@ -2455,20 +2525,20 @@ int t4_comm_gather_bytes(t4_comm *cm, const void *mine, int64_t n, int root, voi
   HIPCHK(c, hipMalloc(&dSend, n > 0 ? (size_t)n : 8));
   if (n > 0) HIPCHK(c, hipMemcpyAsync(dSend, mine, (size_t)n, hipMemcpyHostToDevice, c->stream));
   if (cm->rank == root && hipMalloc(&dRecv, total ? total : 8) != hipSuccess) { (void)hipFree(dSend); return fail(c, T4_ERR_HIP, "out of device memory for the gather"); }
-  bool ok = ncclGroupStart() == ncclSuccess;
-  if (ok && n > 0) ok = ncclSend(dSend, (size_t)n, ncclUint8, root, cm->comm, c->stream) == ncclSuccess;
+  bool ok = cm->rccl->groupStart() == ncclSuccess;
+  if (ok && n > 0) ok = cm->rccl->send(dSend, (size_t)n, ncclUint8, root, cm->comm, c->stream) == ncclSuccess;
   if (ok && cm->rank == root) {
     size_t at = 0;
-    for (int r = 0; r < R && ok; ++r) { if (lens[(size_t)r]) ok = ncclRecv(dRecv + at, (size_t)lens[(size_t)r], ncclUint8, r, cm->comm, c->stream) == ncclSuccess; at += (size_t)lens[(size_t)r]; }
+    for (int r = 0; r < R && ok; ++r) { if (lens[(size_t)r]) ok = cm->rccl->recv(dRecv + at, (size_t)lens[(size_t)r], ncclUint8, r, cm->comm, c->stream) == ncclSuccess; at += (size_t)lens[(size_t)r]; }
   }
-  ok = (ncclGroupEnd() == ncclSuccess) && ok;
+  ok = (cm->rccl->groupEnd() == ncclSuccess) && ok;
   if (!ok) { (void)hipFree(dSend); if (dRecv) (void)hipFree(dRecv); return fail(c, T4_ERR_HIP, "ncclSend / ncclRecv (gather) failed"); }
   unsigned char *host = nullptr;
   if (cm->rank == root) {
     host = (unsigned char *)malloc(total ? total : 1);
     if (total) HIPCHK(c, hipMemcpyAsync(host, dRecv, total, hipMemcpyDeviceToHost, c->stream));
   }
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (int wr = commWait(cm, "the gather")) return wr;
   (void)hipFree(dSend);
   if (dRecv) (void)hipFree(dRecv);
   *all = host;
@@ -2481,7 +2551,7 @@ int t4_comm_gather_bytes(t4_comm *cm, const void *mine, int64_t n, int root, voi
 void t4_comm_destroy(t4_comm *cm) {
   if (!cm) return;
 #ifdef __HIPCC__
-  if (cm->comm) (void)ncclCommDestroy(cm->comm);
+  if (cm->comm) (void)cm->rccl->commDestroy(cm->comm);
 #endif
   delete cm;
 }

@@ -439,6 +439,7 @@ int main(int argc, char *argv[]) {
                                          {(char *)0, 0, 0, 0}};
   int indexKmerLength = 9, changeKmerLengthThreshold = 4096, trimLevel = 1, minHitLen = -1, constantGeneEnd = 200;
   int shardRank = 0, shardCount = 1, threadCnt = 1, contigMinCov = 0;
+  bool annotSharded = false;
   int annotRank = 0, annotCount = 1;   // --readShard R/N: the read-only pass of ONE sample (rough annotation) by read range over N processes, results all-gathered; rank 0 goes on alone
   std::string gatherDir;    // --gatherDir DIR: the same exchange through files of a directory every rank sees (tests without RCCL)
   std::string rcclIdPath;   // --rcclId FILE: the shards' results are gathered inside the engine (t4_comm: RCCL), rank 0 writes the merged files
@@ -467,7 +468,7 @@ int main(int argc, char *argv[]) {
     else if (c == 10004) { umiFile.files.push_back(optarg); hasUmi = true; }
     else if (c == 10101) rcclIdPath = optarg;
     else if (c == 10102) gatherDir = optarg;
-    else if (c == 10103) { if (sscanf(optarg, "%d/%d", &annotRank, &annotCount) != 2 || annotCount < 1 || annotRank < 0 || annotRank >= annotCount) { fprintf(stderr, "--readShard takes R/N with 0 <= R < N\n"); return EXIT_FAILURE; } }
+    else if (c == 10103) { if (sscanf(optarg, "%d/%d", &annotRank, &annotCount) != 2 || annotCount < 1 || annotRank < 0 || annotRank >= annotCount) { fprintf(stderr, "--readShard takes R/N with 0 <= R < N\n"); return EXIT_FAILURE; } annotSharded = true; }
     else if (c == 10100) { if (sscanf(optarg, "%d/%d", &shardRank, &shardCount) != 2 || shardCount < 1 || shardRank < 0 || shardRank >= shardCount) { fprintf(stderr, "--cellShard takes R/N with 0 <= R < N\n"); return EXIT_FAILURE; } }
     else if (c == 10003) keepMissingBarcode = true;
     else if (c == 10007) contigMinCov = atoi(optarg);
@@ -483,8 +484,8 @@ int main(int argc, char *argv[]) {
   }
   if (getenv("T4_THREADS")) threadCnt = atoi(getenv("T4_THREADS")) > 0 ? atoi(getenv("T4_THREADS")) : 1;
   if (shardCount > 1 && (!hasBarcode || keepMissingBarcode)) { fprintf(stderr, "--cellShard needs --barcode: without barcodes the Add pass does not shard (DESIGN.md 6).\n"); return EXIT_FAILURE; }
-  if (annotCount > 1 && shardCount > 1) { fprintf(stderr, "--readShard and --cellShard are two ways to spread one sample: take one.\n"); return EXIT_FAILURE; }
-  if (annotCount > 1 && rcclIdPath.empty() && gatherDir.empty()) { fprintf(stderr, "--readShard needs --rcclId FILE or --gatherDir DIR for the exchange of the annotations.\n"); return EXIT_FAILURE; }
+  if (annotSharded && shardCount > 1) { fprintf(stderr, "--readShard and --cellShard are two ways to spread one sample: take one.\n"); return EXIT_FAILURE; }
+  if (annotSharded && rcclIdPath.empty() && gatherDir.empty()) { fprintf(stderr, "--readShard needs --rcclId FILE or --gatherDir DIR for the exchange of the annotations.\n"); return EXIT_FAILURE; }
 
   // The device, its runtime and the reference set come up on their own thread while the reads are parsed, merged and counted
   // (nothing before the rough annotation touches the GPU); gpuReady() joins it and reports its errors as the serial code did.
@@ -898,7 +899,7 @@ int main(int argc, char *argv[]) {
         for (int j = 0; j < 4; ++j) sortedReads[t].g[j] = out[4 * (size_t)k + j];
       }
     }
-    if (annotCount > 1) {
+    if (annotSharded) {   // (with N = 1 too: one rank still runs every call of the exchange)
       // the one exchange of this mode: every rank's annotation records (4 x 40 bytes per read position of its range) to every rank --
       // RCCL all-gather on the ctx's stream (t4_comm) or files of a shared directory; the ranges are known to all, so no header travels
       std::string mine((size_t)(sliceHi - sliceLo) * 4 * sizeof(t4_overlap), '\0');
@@ -937,7 +938,7 @@ int main(int argc, char *argv[]) {
         if (got[(size_t)r].size() != (size_t)(hi - lo) * 4 * sizeof(t4_overlap)) { fprintf(stderr, "trust4-hip: rank %d sent %zu bytes of annotations, expected %zu\n", r, got[(size_t)r].size(), (size_t)(hi - lo) * 4 * sizeof(t4_overlap)); return EXIT_FAILURE; }
         if (r != annotRank) for (int t = lo; t < hi; ++t) memcpy(sortedReads[(size_t)t].g, &got[(size_t)r][(size_t)(t - lo) * 4 * sizeof(t4_overlap)], 4 * sizeof(t4_overlap));
       }
-      PrintLog("Rough annotations of %d read ranges exchanged (this rank: reads %d-%d of %d).", annotCount, sliceLo, sliceHi, readCnt);
+      PrintLog("Rough annotations of %d read ranges exchanged over %s (this rank: reads %d-%d of %d).", annotCount, gatherDir.empty() ? "RCCL" : "files", sliceLo, sliceHi, readCnt);
       if (annotRank != 0) {   // the ordered assembly pass is one chain: rank 0 runs it and writes the files
         t4_index_destroy(refSet);
         t4_destroy(ctx);
@@ -1443,7 +1444,7 @@ int main(int argc, char *argv[]) {
     PrintLog("Finish assembly. (%lld cells; GPU query batches %lld with %lld reads in %.2f s; %lld cell images, %.1f MB, staged in %.2f s)",
              (long long)barcodeIntToStr.size(), (long long)qb, (long long)rq, sq, (long long)im, by / 1e6, ss);
   };
-  if (annotCount == 1 && (!rcclIdPath.empty() || !gatherDir.empty())) {
+  if (!annotSharded && (!rcclIdPath.empty() || !gatherDir.empty())) {
     // ---- the one exchange of barcode mode, inside the engine. Every rank holds the contig records of its cells (ids local to the
     // shard) and its assembled reads. (1) a small all-gather: contig slots and byte counts of every rank; (2) every rank renumbers
     // ITS OWN records as the reference's cell-after-cell pass numbers them (id += the slots of the earlier ranks); (3) the renumbered
