@@ -328,6 +328,11 @@ int t4_cellset_update_all_consensus(t4_cellset *cs);
 int t4_cellset_release_shallow_contigs(t4_cellset *cs, int min_cov);
 int t4_cellset_size(const t4_cellset *cs);   /* contig slots over all cells == seqSet.Size() */
 int t4_cellset_output(t4_cellset *cs, const char *path, const char *const *barcode_names, int n_names);
+/* SeqSet::Output(fp, &barcodeIntToStr) (SeqSet.hpp:10939-10994) of a t4_cellset that holds a contiguous range of the sample's cells:
+ * contig ids start at id_base (= the contig slots of the sets that hold the cells before it) and, with append != 0, the records
+ * follow what `path` already holds. Several cell sets (one per t4_ctx / stream / host thread, so that one set's query batch runs
+ * while the others commit) then write the file the single set would have written. */
+int t4_cellset_output_at(t4_cellset *cs, const char *path, const char *const *barcode_names, int n_names, int id_base, int append);
 int t4_cellset_counters(const t4_cellset *cs, int64_t *query_batches, int64_t *reads_queried, int64_t *images_staged,
                         int64_t *bytes_staged, double *sec_query, double *sec_stage);
 

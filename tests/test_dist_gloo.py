@@ -138,7 +138,7 @@ def test_engine_merge_two_and_eight_ranks(tmp_path):
     exe = _emulated_driver()
     (tmp_path / "w2").mkdir()
     (tmp_path / "w8").mkdir()
-    run_engine_merge(tmp_path / "w2", exe, 120, 7, 9, 2)
+    run_engine_merge(tmp_path / "w2", exe, 120, 7, 9, 2, env={"T4_CELL_GROUPS": "2", "T4_THREADS": "2", "HIPEMU_THREADS": "2"})   # (each rank: its cells in two groups)
     run_engine_merge(tmp_path / "w8", exe, 100, 11, 10, 8, env={"HIPEMU_THREADS": "1"})
 
 

@@ -96,6 +96,23 @@ def test_barcode_mode_emulated(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
+@pytest.mark.parametrize("groups,threads,cells", [(2, 2, 8), (3, 4, 8), (5, 2, 3)])
+def test_barcode_mode_cell_groups_emulated(tmp_path, groups, threads, cells):
+    """Cell groups (round 4): the cells in contiguous groups, each with its own t4_ctx / stream / image arena / host thread, so that one
+    group's query batch runs while the others commit; contig ids of a group follow the slots of the groups before it
+    (t4_cellset_output_at). Two and three groups, and more groups than cells (empty groups): the reference binary's bytes."""
+    exe = _emulated_driver()
+    _barcode_case(tmp_path, exe, 160, cells, 6, {"T4_LANES": "8", "T4_WINDOW": "3", "T4_THREADS": str(threads), "T4_CELL_GROUPS": str(groups), "HIPEMU_THREADS": "2"})
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not shipped")
+@pytest.mark.parametrize("groups", [1, 4, 7])
+def test_barcode_mode_cell_groups_gpu(tmp_path, groups):
+    _barcode_case(tmp_path, _driver(), 6000, 120, 7, {"T4_THREADS": "8", "T4_CELL_GROUPS": str(groups)})
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
 def test_device_kmer_counts_emulated(tmp_path):
     """T4_GPU_KMERCOUNT=1: the 21-mer counts, the count statistics and the quality trimming come from t4_kmer_count_* instead of
     the host threads; T4_GPU_MATEOVERLAP=1: ProcessRead's two IsMateOverlap tests per pair come from t4_mate_overlap (both opt-in
@@ -318,7 +335,8 @@ def _bulk_case(tmp_path, driver, pairs, clones, seed, env, threads="4"):
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
 @pytest.mark.parametrize("env", [{"T4_AQ_CAP_LIMIT": "120"}, {"T4_AQ_CAP_LIMIT": "120", "T4_WIDE_PCAP": "512", "T4_WIDE_PARTS": "2", "T4_WIDE_GROUPS": "16"}, {"T4_AQ_CAP_LIMIT": "120", "T4_WIDE_OFF": "1"},
                                  {"T4_AQ_FORCE_GLOBAL": "1"}, {"T4_QUERY_AHEAD": "3", "T4_WINDOW": "7"}, {"T4_AQ_EXTEND_DEFER": "1"}, {"T4_AQ_EXTEND_DEFER": "0"},
-                                 {"T4_AQ_POOL_CAP": "8", "T4_AQ_EXTEND_DEFER": "1"}, {"T4_AQ_POOL_CAP": "5"}, {"T4_SORT_MIN": "64"}, {"T4_GPU_PROCESSREAD": "1"}])
+                                 {"T4_AQ_POOL_CAP": "8", "T4_AQ_EXTEND_DEFER": "1"}, {"T4_AQ_POOL_CAP": "5"}, {"T4_SORT_MIN": "64"}, {"T4_GPU_PROCESSREAD": "1"},
+                                 {"T4_ANNOT_CHUNK": "7"}])
 def test_bulk_live_set_paths_emulated(tmp_path, env):
     """Bulk mode = the live set (device image by t4_index_apply_delta, sliding speculation window). The testing aids send a
     small input down the paths large sets take: reads that outgrow the LDS arrays and are spread over the chip by the wide query
@@ -326,7 +344,8 @@ def test_bulk_live_set_paths_emulated(tmp_path, env):
     T4_WIDE_OFF they go on in one workgroup's global scratch inside the launch), the global-scratch tier launched beside the LDS tier
     (T4_AQ_FORCE_GLOBAL), a window that is re-queried
     a few reads at a time (T4_QUERY_AHEAD), a result pool that overflows so that the call is repeated with a larger one
-    (T4_AQ_POOL_CAP; with the extensions deferred, extendKernel runs over the pool of the failed attempt first). Outputs must equal the reference binary's byte for byte."""
+    (T4_AQ_POOL_CAP; with the extensions deferred, extendKernel runs over the pool of the failed attempt first), the rough annotation
+    in chunks of seven distinct reads (T4_ANNOT_CHUNK: chunk boundaries between the copies of a read). Outputs must equal the reference binary's byte for byte."""
     log = _bulk_case(tmp_path, _emulated_driver(), 240, 5, 11, env)
     if "T4_GPU_PROCESSREAD" in env:   # ProcessRead of every pair on the device (t4_process_pairs): mates must have been merged there
         import re

@@ -2443,10 +2443,15 @@ int t4_cellset_prefetch(t4_cellset *cs, int n, t4_assembler *const *cells, const
 // SeqSet::Output(fp, &barcodeIntToStr) of the set the reference would hold: cells in barcode order, contig ids numbered in
 // creation order across the cells (contig slots are only ever created by InputNovelRead; merges reuse a slot)
 int t4_cellset_output(t4_cellset *cs, const char *path, const char *const *barcode_names, int n_names) {
-  if (!cs || !path) return T4_ERR_ARG;
-  FILE *fp = fopen(path, "w");
+  return t4_cellset_output_at(cs, path, barcode_names, n_names, 0, 0);
+}
+// ... of a set that holds a contiguous range of the cells: ids start at id_base (the contig slots of the sets before it), and with
+// `append` the records follow what the file holds (the driver's cell groups write one file, group after group)
+int t4_cellset_output_at(t4_cellset *cs, const char *path, const char *const *barcode_names, int n_names, int id_base, int append) {
+  if (!cs || !path || id_base < 0) return T4_ERR_ARG;
+  FILE *fp = fopen(path, append ? "a" : "w");
   if (!fp) return T4_ERR_IO;
-  int base = 0;
+  int base = id_base;
   for (auto &kv : cs->cells) {
     const char *nm = (barcode_names && kv.first >= 0 && kv.first < n_names) ? barcode_names[kv.first] : nullptr;
     writeRecords(fp, kv.second->seqs, base, nm);

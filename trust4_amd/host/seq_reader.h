@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <condition_variable>
@@ -22,9 +23,52 @@ struct SeqReader {
   std::string id, seq, qual, comment;   // comment: rest of the header line after the separator that ends the name (kseq)
   bool hasQual = false;
   bool stripMateSuffix = true;          // false: ids as written (what the reference's threaded extractor path prints)
+  // plain (not gzip) regular files are read in 4 MiB pieces and split at the newlines here; zlib's gzgets, which also passes plain
+  // files through, costs several times the parsing itself
+  FILE *raw = nullptr;
+  std::vector<char> rbuf;
+  size_t rpos = 0, rend = 0;
+  bool getLineRaw(std::string &out) {
+    bool any = false;
+    for (;;) {
+      if (rpos == rend) {
+        if (rbuf.empty()) rbuf.resize((size_t)4 << 20);
+        rend = fread(rbuf.data(), 1, rbuf.size(), raw);
+        rpos = 0;
+        if (rend == 0) break;
+      }
+      any = true;
+      const char *b = rbuf.data() + rpos;
+      const char *nl = (const char *)memchr(b, '\n', rend - rpos);
+      if (!nl) { out.append(b, rend - rpos); rpos = rend; continue; }
+      out.append(b, (size_t)(nl - b));
+      rpos = (size_t)(nl - rbuf.data()) + 1;
+      break;
+    }
+    while (!out.empty() && out.back() == '\r') out.pop_back();
+    return any;
+  }
+  bool openNext() {
+    const char *path = files[cur].c_str();
+    struct stat st;
+    if (stat(path, &st) == 0 && S_ISREG(st.st_mode)) {
+      FILE *f = fopen(path, "rb");
+      if (!f) return false;
+      unsigned char magic[2] = {0, 0};
+      const size_t got = fread(magic, 1, 2, f);
+      if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) && fseek(f, 0, SEEK_SET) == 0) { raw = f; rpos = rend = 0; return true; }
+      fclose(f);
+    }
+    fp = gzopen(path, "rb");
+    if (fp) gzbuffer(fp, 1 << 20);
+    return fp != nullptr;
+  }
+  bool isOpen() const { return fp != nullptr || raw != nullptr; }
+  void closeCur() { if (fp) { gzclose(fp); fp = nullptr; } if (raw) { fclose(raw); raw = nullptr; } }
   bool getLine(std::string &out) {
     if (havePending) { out.swap(pending); havePending = false; return true; }
     out.clear();
+    if (raw) return getLineRaw(out);
     char buf[1 << 16];
     bool any = false;
     while (gzgets(fp, buf, sizeof buf)) {
@@ -37,19 +81,18 @@ struct SeqReader {
     }
     return any;
   }
-  void rewind() { if (fp) { gzclose(fp); fp = nullptr; } cur = 0; havePending = false; }
+  void rewind() { closeCur(); cur = 0; havePending = false; }
+  ~SeqReader() { closeCur(); }
   bool next() {
     for (;;) {
-      if (!fp) {
+      if (!isOpen()) {
         if (cur >= files.size()) return false;
-        fp = gzopen(files[cur].c_str(), "rb");
-        if (fp) gzbuffer(fp, 1 << 20);
-        if (!fp) { fprintf(stderr, "Could not open %s\n", files[cur].c_str()); exit(EXIT_FAILURE); }
+        if (!openNext()) { fprintf(stderr, "Could not open %s\n", files[cur].c_str()); exit(EXIT_FAILURE); }
       }
       std::string line;
       bool got = false;
       while (getLine(line)) if (!line.empty() && (line[0] == '>' || line[0] == '@')) { got = true; break; }
-      if (!got) { gzclose(fp); fp = nullptr; ++cur; havePending = false; continue; }
+      if (!got) { closeCur(); ++cur; havePending = false; continue; }
       size_t e = 1;
       while (e < line.size() && line[e] != ' ' && line[e] != '\t') ++e;
       id.assign(line, 1, e - 1);
@@ -61,7 +104,10 @@ struct SeqReader {
       while (getLine(line)) {
         if (!line.empty() && (line[0] == '>' || line[0] == '@')) { pending.swap(line); havePending = true; break; }
         if (!line.empty() && line[0] == '+') { plus = true; break; }
-        for (char c : line) if (c > ' ' && c < 127) seq.push_back(c);
+        bool clean = true;   // (a line of printable characters only -- every line of a well-formed file -- is appended as it is)
+        for (char c : line) clean &= (c > ' ' && c < 127);
+        if (clean) seq += line;
+        else for (char c : line) if (c > ' ' && c < 127) seq.push_back(c);
       }
       if (plus) {
         hasQual = true;

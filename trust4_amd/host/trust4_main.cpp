@@ -17,7 +17,9 @@
 // Limits of this round: no -c/--debug-ns; without barcodes `_final.out` is written as a
 // copy of `_raw.out` (the reference does the same under --skipMateExtension and always with barcodes; its mate-graph
 // extension tail is out of scope).
+#include <emmintrin.h>
 #include <fcntl.h>
+#include <sys/stat.h>
 #include <getopt.h>
 #include <math.h>
 #include <stdarg.h>
@@ -100,9 +102,21 @@ int isMateOverlap(const std::string &fr, const std::string &sr, int minOverlap, 
     if (flen - j >= 100) thr = 0.85;
     else if (flen - j >= 50) thr = 0.85 + (flen - j - 50) / 50.0 * 0.1;
     const int need = int((flen - j) * thr);
-    for (k = 0; j + k < flen && k < slen; ++k) {
-      if (fr[j + k] == sr[k]) ++matchCnt;
-      if (matchCnt + (flen - (j + k) - 1) < need) { ok = false; break; }
+    // The reference's test after every base, `matchCnt + (flen - (j + k) - 1) < need`, says "more than (flen - j) - need mismatches so
+    // far"; mismatches only grow, so an offset fails iff the mismatches of its whole range exceed that allowance -- counted 16 bases at
+    // a time (SSE2 is part of x86-64), leaving as soon as the allowance is spent. A surviving offset has k = the range, matchCnt = its matches.
+    const int range = flen - j < slen ? flen - j : slen, allowed = (flen - j) - need;
+    int mism = 0;
+    const char *a = fr.data() + j, *b = sr.data();
+    for (k = 0; k + 16 <= range; k += 16) {
+      const __m128i va = _mm_loadu_si128((const __m128i *)(a + k)), vb = _mm_loadu_si128((const __m128i *)(b + k));
+      mism += 16 - __builtin_popcount((unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(va, vb)));
+      if (mism > allowed) { ok = false; break; }
+    }
+    if (ok) {
+      for (; k < range; ++k) if (a[k] != b[k]) ++mism;
+      if (mism > allowed) ok = false;
+      matchCnt = range - mism; k = range;
     }
     if (ok) { offset = j; ++offsetCnt; overlapSize = k; bestMatchCnt = matchCnt; }
   }
@@ -228,6 +242,53 @@ struct KmerCounter {
   }
 };
 
+// Strings -> dense ints in order of first appearance: the numbering of barcodes and UMIs (main.cpp:812-820, 831-842; the reference
+// keeps a std::map<std::string, int> each). It is the serial work per record of the input loop, so strings of at most 20 letters
+// over ACGTN -- every barcode and UMI of the 10x / Drop-seq kind -- are packed into 61 bits and numbered in a flat open-addressing
+// table; anything else goes through a std::unordered_map. Both share one counter.
+struct StrNumbering {
+  std::vector<uint64_t> keys;
+  std::vector<int> vals;
+  size_t used = 0;
+  std::unordered_map<std::string, int> other;
+  int count = 0;
+  static bool pack(const std::string &s, uint64_t &k) {
+    if (s.size() > 20) return false;
+    k = 1;   // (the leading 1 tells lengths apart; 0 is the empty slot)
+    for (char c : s) {
+      uint64_t v;
+      switch (c) { case 'A': v = 1; break; case 'C': v = 2; break; case 'G': v = 3; break; case 'T': v = 4; break; case 'N': v = 5; break; default: return false; }
+      k = (k << 3) | v;
+    }
+    return true;
+  }
+  static uint64_t mix(uint64_t z) { z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31); }
+  void grow() {
+    std::vector<uint64_t> ok; std::vector<int> ov;
+    ok.swap(keys); ov.swap(vals);
+    keys.assign(ok.empty() ? (size_t)1 << 16 : ok.size() * 2, 0); vals.assign(keys.size(), 0);
+    const size_t mask = keys.size() - 1;
+    for (size_t i = 0; i < ok.size(); ++i) if (ok[i]) { size_t h = (size_t)mix(ok[i]) & mask; while (keys[h]) h = (h + 1) & mask; keys[h] = ok[i]; vals[h] = ov[i]; }
+  }
+  int number(const std::string &s, bool &isNew) {
+    uint64_t k;
+    isNew = false;
+    if (!pack(s, k)) {
+      auto it = other.find(s);
+      if (it != other.end()) return it->second;
+      isNew = true;
+      other.emplace(s, count);
+      return count++;
+    }
+    if ((used + 1) * 2 > keys.size()) grow();
+    const size_t mask = keys.size() - 1;
+    size_t h = (size_t)mix(k) & mask;
+    while (keys[h]) { if (keys[h] == k) return vals[h]; h = (h + 1) & mask; }
+    keys[h] = k; vals[h] = count; ++used; isNew = true;
+    return count++;
+  }
+};
+
 struct SortRead {
   std::string id, read, qual;
   bool hasQual = false, dead = false;
@@ -324,9 +385,9 @@ bool isLowComplexity(const std::string &s) {   // main.cpp:183-205
 // surviving reads (same multiset of AddCount calls) is done afterwards over the whole read list
 // `pre` (optional): the two IsMateOverlap tests of this pair as t4_mate_overlap computed them for the whole block --
 // {ret, offset, bestMatchCnt} of (rc(mate 2), mate 1, minOverlap, no tandem check) and of (mate 1, rc(mate 2), minOverlap2, tandem check)
-void processRead(const SortRead &in1, const SortRead &in2, bool hasMate2, std::vector<SortRead> &out, const int32_t *pre = nullptr) {
-  // private copies: every string this function frees was allocated by the calling thread (no cross-thread allocator traffic)
-  SortRead r1 = in1, r2 = in2;
+void processRead(SortRead &in1, SortRead &in2, bool hasMate2, std::vector<SortRead> &out, const int32_t *pre = nullptr) {
+  // the records are taken over, not copied: a pair that stays as it is (most do) costs no allocation at all on its way into the read list
+  SortRead r1 = std::move(in1), r2 = std::move(in2);
   int rWeight = 1;
   bool r2Alive = hasMate2;
   if (hasMate2) {
@@ -376,10 +437,10 @@ void processRead(const SortRead &in1, const SortRead &in2, bool hasMate2, std::v
     }
   }
   if (!isLowComplexity(r1.read)) {
-    out.push_back(r1);
-    if (rWeight == 2) { SortRead w = r1; w.id += ".1"; out.push_back(w); }
+    if (rWeight == 2) { SortRead w = r1; w.id += ".1"; out.push_back(std::move(r1)); out.push_back(std::move(w)); }
+    else out.push_back(std::move(r1));
   }
-  if (r2Alive && !isLowComplexity(r2.read)) out.push_back(r2);
+  if (r2Alive && !isLowComplexity(r2.read)) out.push_back(std::move(r2));
 }
 
 // SeqSet::DnaToAa / HasMotif (SeqSet.hpp:638-749, 5029-5074); note that the reference translates `read`, not its
@@ -422,7 +483,16 @@ int hasMotif(const std::string &read, int strand) {
   return ret;
 }
 
+// The end of a run whose files are written and closed: the process leaves without walking its heaps (millions of read records, the
+// host replica, the device arenas -- 1.3 s of a 14 s barcode-mode run); the driver and the OS reclaim them. T4_FULL_TEARDOWN=1 keeps
+// the orderly destruction (leak checkers, the emulator build's tests of it).
+void leave(int status) {
+  if (getenv("T4_FULL_TEARDOWN")) return;
+  exit(status);   // (exit, not _exit: stdio is flushed and atexit handlers run -- rocprofv3 writes its traces there)
+}
+thread_local t4_ctx *tlsErrCtx = nullptr;   // the ctx whose errors this thread reports (a cell group's own; else the caller's)
 void die(t4_ctx *ctx, const char *what, int rc) {
+  if (tlsErrCtx) ctx = tlsErrCtx;
   fprintf(stderr, "%s failed (%d): %s\n", what, rc, ctx ? t4_last_error(ctx) : "");
   exit(EXIT_FAILURE);
 }
@@ -530,7 +600,10 @@ int main(int argc, char *argv[]) {
   // (a block is processed on the host threads WHILE the next one is parsed: processBlock runs on its own thread, one block at a time)
   auto processBlock = [&](std::vector<InPair> &block) {   // ProcessRead of every pair of the block on the host threads, results appended in input order
     auto t0 = std::chrono::steady_clock::now();
-    std::vector<std::vector<SortRead>> outs(block.size());
+    // results per CHUNK of consecutive pairs (one vector per chunk, filled by one thread in input order: a vector per pair was a
+    // million small allocations per block, freed across threads)
+    const size_t PP_CHUNK = 1024;
+    std::vector<std::vector<SortRead>> outs((block.size() + PP_CHUNK - 1) / PP_CHUNK);
     std::vector<int32_t> pre;
     bool anyMate = false;
     for (const InPair &ip : block) if (ip.haveMate) { anyMate = true; break; }
@@ -588,11 +661,10 @@ int main(int argc, char *argv[]) {
       else if (rc) die(ctx, "t4_process_pairs", rc);
       else for (int i = 0; i < n; ++i) if (block[(size_t)i].haveMate) ++ppKinds[meta[(size_t)i * 4] & 3];
     }
-    parallelFor((long long)block.size(), threadCnt, [&](long long i) {
-      const InPair &ip = block[(size_t)i];
+    auto onePair = [&](long long i, std::vector<SortRead> &out) {
+      InPair &ip = block[(size_t)i];
       if (!meta.empty() && ip.haveMate) {
         const int len = meta[(size_t)i * 4 + 1], fl = meta[(size_t)i * 4 + 2];
-        std::vector<SortRead> &out = outs[(size_t)i];
         if (fl & 1) {
           SortRead r1 = ip.a;
           if (fl & 16) {
@@ -610,10 +682,25 @@ int main(int argc, char *argv[]) {
         }
         return;
       }
-      processRead(ip.a, ip.b, ip.haveMate, outs[(size_t)i], pre.empty() ? nullptr : &pre[(size_t)i * 6]);
+      processRead(ip.a, ip.b, ip.haveMate, out, pre.empty() ? nullptr : &pre[(size_t)i * 6]);
+    };
+    parallelFor((long long)outs.size(), threadCnt, [&](long long c) {
+      std::vector<SortRead> &out = outs[(size_t)c];
+      const size_t lo = (size_t)c * PP_CHUNK, hi = lo + PP_CHUNK < block.size() ? lo + PP_CHUNK : block.size();
+      out.reserve((hi - lo) * 2 + 2);
+      for (size_t i = lo; i < hi; ++i) onePair((long long)i, out);
     });
     auto t1 = std::chrono::steady_clock::now();
-    for (auto &v : outs) for (SortRead &r : v) sortedReads.push_back(std::move(r));
+    {   // the chunks at their places in the read list, moved on the threads (the list has room for the whole input when its size could
+        // be told from the first block and the file's size: no reallocation, every page of it touched once)
+      std::vector<size_t> first(outs.size() + 1, sortedReads.size());
+      for (size_t c = 0; c < outs.size(); ++c) first[c + 1] = first[c] + outs[c].size();
+      sortedReads.resize(first[outs.size()]);
+      parallelFor((long long)outs.size(), threadCnt, [&](long long c) {
+        std::vector<SortRead> &v = outs[(size_t)c];
+        for (size_t j = 0; j < v.size(); ++j) sortedReads[first[(size_t)c] + j] = std::move(v[j]);
+      });
+    }
     block.clear();
     secProcess += std::chrono::duration<double>(t1 - t0).count();
     secMerge += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
@@ -652,7 +739,8 @@ int main(int argc, char *argv[]) {
     });
   };
   int firstReadLen = -1, nIn = 0;
-  std::unordered_map<std::string, int> barcodeStrToInt, umiStrToInt;
+  bool reservedReadList = false;
+  StrNumbering barcodeNumbers, umiNumbers;   // strings -> dense ints in order of first appearance (main.cpp:812-820, 831-842)
   std::vector<std::string> barcodeIntToStr;
   std::vector<int> barcodePairCount;   // main.cpp:822-828 (only counted under --contigMinCov)
   {
@@ -676,9 +764,9 @@ int main(int argc, char *argv[]) {
           const std::string &bs = bB[i].seq;
           if (bs == "missing_barcode" && !keepMissingBarcode) { u.skip[i] = 1; continue; }
           int barcode;
-          auto it = barcodeStrToInt.find(bs);
-          if (it != barcodeStrToInt.end()) barcode = it->second;
-          else { barcode = (int)barcodeIntToStr.size(); barcodeStrToInt[bs] = barcode; barcodeIntToStr.push_back(bs); }
+          bool isNew = false;
+          barcode = barcodeNumbers.number(bs, isNew);
+          if (isNew) barcodeIntToStr.push_back(bs);
           if (contigMinCov > 0) { if (barcode >= (int)barcodePairCount.size()) barcodePairCount.push_back(1); else ++barcodePairCount[barcode]; }
           u.bc[i] = barcode;
         }
@@ -687,9 +775,8 @@ int main(int argc, char *argv[]) {
         if (!umiFile.nextBlock(bU) || bU.size() < n) uneven("The UMI file has fewer records than the read file.");
         for (size_t i = 0; i < n; ++i) {
           if (u.skip[i]) continue;
-          auto it = umiStrToInt.find(bU[i].seq);
-          if (it != umiStrToInt.end()) u.umi[i] = it->second;
-          else { const int umi = (int)umiStrToInt.size(); umiStrToInt[bU[i].seq] = umi; u.umi[i] = umi; }
+          bool isNew = false;
+          u.umi[i] = umiNumbers.number(bU[i].seq, isNew);
         }
       }
       size_t kept = 0;
@@ -703,6 +790,24 @@ int main(int argc, char *argv[]) {
       const int before = nIn;
       nIn += (int)(kept * (hasMate ? 2 : 1));
       for (int t = before / 100000 + 1; t <= nIn / 100000; ++t) PrintLog("Read in and count kmers for %d reads.", t * 100000);
+      if (!reservedReadList && n > 0) {   // room for the whole input, told from the first block's bytes per record and the size of the file
+        reservedReadList = true;
+        size_t bytes = 0;
+        for (size_t i = 0; i < n; ++i) bytes += u.r[i].id.size() + u.r[i].seq.size() + (u.r[i].hasQual ? u.r[i].qual.size() + 3 : 0) + 3;
+        bool plain = true;
+        double fileBytes = 0;
+        for (const std::string &f : reads.files) {
+          struct stat st;
+          if (f.size() > 3 && f.compare(f.size() - 3, 3, ".gz") == 0) plain = false;
+          else if (stat(f.c_str(), &st) == 0 && S_ISREG(st.st_mode)) fileBytes += (double)st.st_size;
+          else plain = false;
+        }
+        if (plain && bytes > 0) {
+          const double recs = fileBytes / ((double)bytes / (double)n) * 1.03 + 1024;
+          const double want = recs * (hasMate ? 2.0 : 1.0);
+          if (want < 2.0e9) sortedReads.reserve((size_t)want);
+        }
+      }
       unitPairs += kept;
       units.push_back(std::move(u));
       if (unitPairs >= BLOCK) flushBlock();
@@ -727,6 +832,8 @@ int main(int argc, char *argv[]) {
   t4_kmer_counter *gpuKc = nullptr;
   bool gpuQual = false;
   const size_t KC_CHUNK = 1u << 22;
+  std::string scratchBases; std::vector<int64_t> scratchOff;   // the reads of a chunk side by side: one buffer for every upload of the run (its pages are touched once)
+  std::vector<t4_batch *> countedBatches;   // the chunks as the count pass uploaded them, kept for the statistics pass when nothing changes in between
   auto uploadChunk = [&](size_t lo, size_t hi, std::string &bases, std::vector<int64_t> &off, bool withBarcodes = false) -> t4_batch * {
     const size_t n = hi - lo;
     off.resize(n + 1);
@@ -779,7 +886,8 @@ int main(int argc, char *argv[]) {
     const char *why = nullptr;
     rc = t4_kmer_count_create(ctx, 21, kmers + 16 < (1ll << 30) ? kmers + 16 : (1ll << 30), 0, &gpuKc);
     if (rc) why = "t4_kmer_count_create";
-    std::string bases; std::vector<int64_t> off;
+    std::string &bases = scratchBases; std::vector<int64_t> &off = scratchOff;
+    const bool keepBatches = contigMinCov <= 0 && sortedReads.size() <= ((size_t)16 << 20);   // (60 B per read on the device)
     if (!why && !kmerCountFile.empty()) {   // -c: the counts parsed from the file above, as they are (t4_kmer_count_set)
       std::vector<uint64_t> codes; std::vector<int32_t> vals;
       for (const auto &m : kmerCount.shards) for (const auto &kv : m) { codes.push_back(kv.first); vals.push_back(kv.second); }
@@ -789,9 +897,11 @@ int main(int argc, char *argv[]) {
       const size_t hi = lo + KC_CHUNK < sortedReads.size() ? lo + KC_CHUNK : sortedReads.size();
       t4_batch *b = uploadChunk(lo, hi, bases, off);
       if ((rc = t4_kmer_count_add(gpuKc, b))) why = "t4_kmer_count_add";
-      t4_batch_destroy(b);
+      if (keepBatches && !why) countedBatches.push_back(b); else t4_batch_destroy(b);
     }
     if (why) {
+      for (t4_batch *kb : countedBatches) t4_batch_destroy(kb);
+      countedBatches.clear();
       if (insistGpuKc) die(ctx, why, rc);
       fprintf(stderr, "trust4-hip: 21-mer counts on the host threads (%s: %s)\n", why, t4_last_error(ctx));
       if (gpuKc) { t4_kmer_count_destroy(gpuKc); gpuKc = nullptr; }
@@ -813,13 +923,18 @@ int main(int argc, char *argv[]) {
   }
   // ---- count statistics + quality trimming (main.cpp:980-1061)
   if (gpuKc) {
-    std::string bases, quals; std::vector<int64_t> off;
+    std::string &bases = scratchBases; std::string quals; std::vector<int64_t> &off = scratchOff;
     std::vector<int32_t> mn, md, nl; std::vector<float> av;
-    for (size_t lo = 0; lo < sortedReads.size(); lo += KC_CHUNK) {
+    const bool reuse = !countedBatches.empty();
+    for (size_t lo = 0, ci = 0; lo < sortedReads.size(); lo += KC_CHUNK, ++ci) {
       const size_t hi = lo + KC_CHUNK < sortedReads.size() ? lo + KC_CHUNK : sortedReads.size(), n = hi - lo;
-      t4_batch *b = uploadChunk(lo, hi, bases, off);
+      t4_batch *b = reuse ? countedBatches[ci] : uploadChunk(lo, hi, bases, off);
+      if (gpuQual && reuse) {   // (the offsets of the qualities: where the bases of the chunk stood)
+        off.resize(n + 1); off[0] = 0;
+        for (size_t i = 0; i < n; ++i) off[i + 1] = off[i] + (int64_t)sortedReads[lo + i].read.size();
+      }
       if (gpuQual) {   // (the qualities of a read stand where its bases stand: same offsets)
-        quals.resize(bases.size());
+        quals.resize((size_t)off[n]);
         parallelFor((long long)n, threadCnt, [&](long long i) { const SortRead &r = sortedReads[lo + (size_t)i]; const size_t m = r.qual.size() < r.read.size() ? r.qual.size() : r.read.size(); if (m) memcpy(&quals[(size_t)off[(size_t)i]], r.qual.data(), m); });
       }
       mn.resize(n); md.resize(n); nl.resize(n); av.resize(n);
@@ -834,6 +949,7 @@ int main(int argc, char *argv[]) {
         if (r.read.empty()) r.dead = true;
       });
     }
+    countedBatches.clear();   // (every kept batch was destroyed with its chunk above)
     t4_kmer_count_destroy(gpuKc);
     gpuKc = nullptr;
   } else
@@ -870,8 +986,8 @@ int main(int argc, char *argv[]) {
   // ---- rough annotation on the GPU (main.cpp:1084-1120): every distinct read once, in chunks (a 20 M-pair input must not need
   // all packed reads and all 160-byte results at the same time)
   {
-    const size_t CHUNK = (size_t)4 << 20;   // distinct reads per t4_annotate_rough call
-    std::string bases; std::vector<int64_t> off; std::vector<int> firstOf; std::vector<t4_overlap> out;
+    const size_t CHUNK = getenv("T4_ANNOT_CHUNK") && atoll(getenv("T4_ANNOT_CHUNK")) > 0 ? (size_t)atoll(getenv("T4_ANNOT_CHUNK")) : (size_t)4 << 20;   // distinct reads per t4_annotate_rough call (the variable: a testing aid, small inputs through many chunks)
+    std::string &bases = scratchBases; std::vector<int64_t> &off = scratchOff; std::vector<int> firstOf; std::vector<t4_overlap> out;
     // --readShard R/N (bulk mode: "the read-only passes shard by read range, index replicated, no exchange except gathering
     // 128-B results"): this process annotates the R-th of N ranges of read positions (cut where a new distinct read starts)
     int sliceLo = 0, sliceHi = readCnt;
@@ -881,23 +997,34 @@ int main(int argc, char *argv[]) {
     }
     int i = sliceLo;
     while (i < sliceHi) {
-      bases.clear(); off.assign(1, 0); firstOf.clear();
+      firstOf.clear();
       const int chunkBegin = i;
-      for (; i < sliceHi && firstOf.size() < CHUNK; ++i)
-        if (i == 0 || sortedReads[i].read != sortedReads[i - 1].read) { bases += sortedReads[i].read; off.push_back((int64_t)bases.size()); firstOf.push_back(i); }
-      while (i < sliceHi && sortedReads[i].read == sortedReads[i - 1].read) ++i;   // the copies of the chunk's last read belong to it
+      {   // the first positions of the chunk's distinct reads: the comparisons on the threads, the walk over their flags serial
+        const int span = (int)((long long)sliceHi - i < (long long)CHUNK * 4 ? sliceHi - i : CHUNK * 4);
+        std::vector<unsigned char> isFirst((size_t)span);
+        parallelFor((long long)span, threadCnt, [&](long long d) { const int t = chunkBegin + (int)d; isFirst[(size_t)d] = t == 0 || sortedReads[(size_t)t].read != sortedReads[(size_t)t - 1].read; });
+        int d = 0;
+        for (; d < span && firstOf.size() < CHUNK; ++d) if (isFirst[(size_t)d]) firstOf.push_back(chunkBegin + d);
+        while (d < span && !isFirst[(size_t)d]) ++d;   // the copies of the chunk's last read belong to it
+        i = chunkBegin + d;
+        if (d == span) while (i < sliceHi && sortedReads[(size_t)i].read == sortedReads[(size_t)i - 1].read) ++i;
+      }
       const int n = (int)firstOf.size();
       if (n == 0) break;
+      off.resize((size_t)n + 1); off[0] = 0;
+      for (int k = 0; k < n; ++k) off[(size_t)k + 1] = off[(size_t)k] + (int64_t)sortedReads[(size_t)firstOf[(size_t)k]].read.size();
+      bases.resize((size_t)off[(size_t)n]);
+      parallelFor((long long)n, threadCnt, [&](long long k) { const std::string &r = sortedReads[(size_t)firstOf[(size_t)k]].read; if (!r.empty()) memcpy(&bases[(size_t)off[(size_t)k]], r.data(), r.size()); });
       t4_batch *batch = nullptr;
       if ((rc = t4_reads_upload(ctx, bases.data(), off.data(), nullptr, n, &batch))) die(ctx, "t4_reads_upload", rc);
       out.resize(4 * (size_t)n);
       if ((rc = t4_annotate_rough(refSet, batch, out.data()))) die(ctx, "t4_annotate_rough", rc);
       { t4_stats st; if (t4_last_stats(ctx, &st) == T4_OK) { annotKernelMs += st.chain_kernel_ms; annotHits += st.total_hits; annotReads += st.reads; } }
       t4_batch_destroy(batch);
-      for (int k = -1, t = chunkBegin; t < i; ++t) {
-        if (k + 1 < n && firstOf[k + 1] == t) ++k;
-        for (int j = 0; j < 4; ++j) sortedReads[t].g[j] = out[4 * (size_t)k + j];
-      }
+      parallelFor((long long)n, threadCnt, [&](long long k) {   // every copy of a read takes its annotation
+        const int tEnd = k + 1 < n ? firstOf[(size_t)k + 1] : i;
+        for (int t = firstOf[(size_t)k]; t < tEnd; ++t) for (int j = 0; j < 4; ++j) sortedReads[(size_t)t].g[j] = out[4 * (size_t)k + j];
+      });
     }
     if (annotSharded) {   // (with N = 1 too: one rank still runs every call of the exchange)
       // the one exchange of this mode: every rank's annotation records (4 x 40 bytes per read position of its range) to every rank --
@@ -969,19 +1096,21 @@ int main(int argc, char *argv[]) {
       for (const SortRead &r : sortedReads) if ((int)r.read.size() >= 21) kmers += (long long)r.read.size() - 20;
       t4_kmer_counter *bkc = nullptr;
       if ((rc = t4_kmer_count_create(ctx, 21, kmers + 16 < (1ll << 30) ? kmers + 16 : (1ll << 30), 1, &bkc))) die(ctx, "t4_kmer_count_create", rc);
-      std::string bases; std::vector<int64_t> off;
+      std::string &bases = scratchBases; std::vector<int64_t> &off = scratchOff;
       std::vector<int32_t> mn, md, nl; std::vector<float> av;
+      const bool keep = sortedReads.size() <= ((size_t)16 << 20);   // the chunks of the count pass serve the statistics pass (nothing changes in between)
+      std::vector<t4_batch *> kept;
       for (int pass = 0; pass < 2; ++pass)
-        for (size_t lo = 0; lo < sortedReads.size(); lo += KC_CHUNK) {
+        for (size_t lo = 0, ci = 0; lo < sortedReads.size(); lo += KC_CHUNK, ++ci) {
           const size_t hi = lo + KC_CHUNK < sortedReads.size() ? lo + KC_CHUNK : sortedReads.size(), n = hi - lo;
-          t4_batch *b = uploadChunk(lo, hi, bases, off, true);
+          t4_batch *b = pass == 1 && keep ? kept[ci] : uploadChunk(lo, hi, bases, off, true);
           if (pass == 0) { if ((rc = t4_kmer_count_add(bkc, b))) die(ctx, "t4_kmer_count_add", rc); }
           else {
             mn.resize(n); md.resize(n); nl.resize(n); av.resize(n);
             if ((rc = t4_kmer_count_stats(bkc, b, nullptr, nullptr, mn.data(), md.data(), av.data(), nl.data()))) die(ctx, "t4_kmer_count_stats", rc);
-            for (size_t i = 0; i < n; ++i) { SortRead &r = sortedReads[lo + i]; r.barcodeMinCnt = mn[i]; r.barcodeMedianCnt = md[i]; r.barcodeAvgCnt = av[i]; }
+            parallelFor((long long)n, threadCnt, [&](long long i) { SortRead &r = sortedReads[lo + (size_t)i]; r.barcodeMinCnt = mn[(size_t)i]; r.barcodeMedianCnt = md[(size_t)i]; r.barcodeAvgCnt = av[(size_t)i]; });
           }
-          t4_batch_destroy(b);
+          if (pass == 0 && keep) kept.push_back(b); else t4_batch_destroy(b);
         }
       t4_kmer_count_destroy(bkc);
     } else
@@ -1081,6 +1210,8 @@ int main(int argc, char *argv[]) {
   // ---- the assembly loop (main.cpp:1528-1880)
   t4_assembler *seqSet = nullptr;     // bulk mode: the one contig set
   t4_cellset *cellSet = nullptr;      // barcode mode: one contig set per cell
+  std::vector<t4_cellset *> cellSets;   // ... in groups of cells (cellSet = the first)
+  std::vector<t4_ctx *> cellCtxs;
   int hitLenRequired = 31;
   if (firstReadLen / 2 < 31) { int l = firstReadLen / 2; if (l < 21) l = 21; hitLenRequired = l; }
   if (hasBarcode) hitLenRequired = 13;
@@ -1088,9 +1219,21 @@ int main(int argc, char *argv[]) {
   const bool useCells = hasBarcode && !keepMissingBarcode;   // --keepNoBarcode: the index is not keyed by barcode, one set
   if (useCells) {
     if (barcodeIntToStr.size() >= 1000003) { fprintf(stderr, "trust4-hip: more than 1000002 barcodes are not supported.\n"); return EXIT_FAILURE; }
-    if ((rc = t4_cellset_create(ctx, indexKmerLength, &cellSet))) die(ctx, "t4_cellset_create", rc);
-    t4_cellset_set_params(cellSet, hitLenRequired, 10, 0.9);
-    t4_cellset_set_threads(cellSet, threadCnt);
+    // Cells are independent, so the cells of this process are dealt to GROUPS contiguous groups, each with its own t4_ctx (stream,
+    // scratch), t4_cellset (arena of cell images) and host thread: while one group's query batch runs on the GPU the others stage
+    // images, collect and commit (round 4; one group = the round-3 loop: collect -> stage -> query -> commit, nothing overlapped).
+    int G = getenv("T4_CELL_GROUPS") ? atoi(getenv("T4_CELL_GROUPS")) : (threadCnt >= 8 ? 4 : threadCnt >= 2 ? 2 : 1);
+    if (G < 1) G = 1;
+    if (G > 16) G = 16;
+    cellCtxs.assign((size_t)G, nullptr); cellSets.assign((size_t)G, nullptr);
+    for (int g = 0; g < G; ++g) {
+      cellCtxs[(size_t)g] = ctx;
+      if (g > 0 && (rc = t4_init(getenv("T4_DEVICE") ? atoi(getenv("T4_DEVICE")) : 0, &cellCtxs[(size_t)g]))) { fprintf(stderr, "trust4-hip: t4_init for cell group %d failed (%d)\n", g, rc); return EXIT_FAILURE; }
+      if ((rc = t4_cellset_create(cellCtxs[(size_t)g], indexKmerLength, &cellSets[(size_t)g]))) die(cellCtxs[(size_t)g], "t4_cellset_create", rc);
+      t4_cellset_set_params(cellSets[(size_t)g], hitLenRequired, 10, 0.9);
+      t4_cellset_set_threads(cellSets[(size_t)g], G == 1 ? threadCnt : (threadCnt + G - 1) / G > 2 ? (threadCnt + G - 1) / G : 2);
+    }
+    cellSet = cellSets[0];
   } else {
     if ((rc = t4_assembler_create(ctx, indexKmerLength, 0, &seqSet))) die(ctx, "t4_assembler_create", rc);
     t4_assembler_set_params(seqSet, hitLenRequired, 10, 0.9);
@@ -1293,7 +1436,7 @@ int main(int argc, char *argv[]) {
       walks.push_back(w);
       i = j;
     }
-    size_t nextWalk = 0, endWalk = walks.size();
+    size_t firstWalk = 0, endWalkAll = walks.size();
     if (shardCount > 1) {   // contiguous ranges of walks with about the same number of reads
       auto bound = [&](int r) {
         const long long target = (long long)readCnt * r / shardCount;
@@ -1301,25 +1444,50 @@ int main(int argc, char *argv[]) {
         while (wI < walks.size() && walks[wI].begin < target) ++wI;
         return wI;
       };
-      nextWalk = bound(shardRank); endWalk = bound(shardRank + 1);
+      firstWalk = bound(shardRank); endWalkAll = bound(shardRank + 1);
     }
-    const size_t firstWalk = nextWalk;
+    // the walks of this process in G contiguous groups of about the same number of reads (contiguous: the output numbers the contigs
+    // cell after cell, so a group's ids are its local ones + the contig slots of the groups before it)
+    const int G = (int)cellSets.size();
+    std::vector<size_t> groupBegin((size_t)G + 1, endWalkAll);
+    {
+      const long long lo = firstWalk < walks.size() ? walks[firstWalk].begin : readCnt, hi = endWalkAll < walks.size() ? walks[endWalkAll].begin : readCnt;
+      size_t wI = firstWalk;
+      for (int g = 0; g < G; ++g) {
+        const long long target = lo + (hi - lo) * g / G;
+        while (wI < endWalkAll && walks[wI].begin < target) ++wI;
+        groupBegin[(size_t)g] = wI;
+      }
+    }
     cellOf.assign(readCnt, nullptr);
-    for (size_t wI = firstWalk; wI < endWalk; ++wI)
-      for (int i = walks[wI].begin; i < walks[wI].end; ++i) if ((rc = t4_cellset_cell(cellSet, sortedReads[i].barcode, &cellOf[i]))) die(ctx, "t4_cellset_cell", rc);
-    std::vector<int> active;
-    double secCollect = 0, secPrefetch = 0, secCommit = 0;
+    for (int g = 0; g < G; ++g)
+      for (size_t wI = groupBegin[(size_t)g]; wI < groupBegin[(size_t)g + 1]; ++wI)
+        for (int i = walks[wI].begin; i < walks[wI].end; ++i) if ((rc = t4_cellset_cell(cellSets[(size_t)g], sortedReads[i].barcode, &cellOf[i]))) die(cellCtxs[(size_t)g], "t4_cellset_cell", rc);
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
-    auto cellsOfWalkDone = [&](Walk &w) {   // its cells will not be queried again
-      for (int i = w.begin; i < w.end; ++i) if (i == w.begin || cellOf[i] != cellOf[i - 1]) t4_cellset_close_cell(cellSet, cellOf[i]);
-    };
     auto finishMain = [&](Walk &w) {
       for (int i = w.begin; i < w.end; ++i) if (i == w.begin || cellOf[i] != cellOf[i - 1]) t4_assembler_update_all_consensus(cellOf[i]);
       w.phase = w.rescue.empty() ? 2 : 1;
     };
+    struct GroupClock { double collect = 0, prefetch = 0, commit = 0, wall = 0; int64_t batches = 0; };
+    std::vector<GroupClock> clocks((size_t)G);
+    const int lanesOfGroup = LANES / G > 0 ? LANES / G : 1;
+    const int commitThreads = G == 1 ? threadCnt : ((threadCnt + G - 1) / G > 2 ? (threadCnt + G - 1) / G : 2);
+    auto runGroup = [&](int g) {
+    tlsErrCtx = cellCtxs[(size_t)g];
+    t4_cellset *cellSet = cellSets[(size_t)g];
+    t4_ctx *ctx = cellCtxs[(size_t)g];
+    int rc = 0;
+    GroupClock &clk = clocks[(size_t)g];
+    const auto tg0 = now();
+    size_t nextWalk = groupBegin[(size_t)g];
+    const size_t endWalk = groupBegin[(size_t)g + 1];
+    std::vector<int> active;
+    auto cellsOfWalkDone = [&](Walk &w) {   // its cells will not be queried again
+      for (int i = w.begin; i < w.end; ++i) if (i == w.begin || cellOf[i] != cellOf[i - 1]) t4_cellset_close_cell(cellSet, cellOf[i]);
+    };
     while (nextWalk < endWalk || !active.empty()) {
-      while (nextWalk < endWalk && (int)active.size() < LANES) active.push_back((int)nextWalk++);
+      while (nextWalk < endWalk && (int)active.size() < lanesOfGroup) active.push_back((int)nextWalk++);
       // the upcoming AddRead reads of every active walk
       auto tc0 = now();
       std::vector<t4_assembler *> qc; std::vector<const char *> qr; std::vector<int> qs;
@@ -1339,13 +1507,13 @@ int main(int argc, char *argv[]) {
           }
         }
       }
-      secCollect += since(tc0);
+      clk.collect += since(tc0);
       auto tp0 = now();
       if (!qc.empty()) {
         if ((rc = t4_cellset_prefetch(cellSet, (int)qc.size(), qc.data(), qr.data(), qs.data(), trimLevel > 1))) die(ctx, "t4_cellset_prefetch", rc);
-        ++laneBatches;
+        ++clk.batches;
       }
-      secPrefetch += since(tp0);
+      clk.prefetch += since(tp0);
       // commit, walk by walk, what was queried (reads that need no query ride along)
       auto tm0 = now();
       // walks own disjoint cells and disjoint ranges of sortedReads / goodCandidate / barcodeReadCount: they commit concurrently
@@ -1371,9 +1539,9 @@ int main(int argc, char *argv[]) {
       };
       {
         const int nA = (int)active.size();
-        const int nT = threadCnt < nA / 4 ? threadCnt : (nA / 4 > 0 ? nA / 4 : 1);
+        const int nT = commitThreads < nA / 4 ? commitThreads : (nA / 4 > 0 ? nA / 4 : 1);
         std::atomic<int> nextA(0);
-        auto worker = [&]() { for (;;) { int b = nextA.fetch_add(8); if (b >= nA) break; for (int a = b; a < b + 8 && a < nA; ++a) commitWalk((size_t)a); } };
+        auto worker = [&]() { tlsErrCtx = ctx; for (;;) { int b = nextA.fetch_add(8); if (b >= nA) break; for (int a = b; a < b + 8 && a < nA; ++a) commitWalk((size_t)a); } };
         std::vector<std::thread> pool;
         for (int t = 1; t < nT; ++t) pool.emplace_back(worker);
         worker();
@@ -1386,8 +1554,21 @@ int main(int argc, char *argv[]) {
         else still.push_back(active[a]);
       }
       active.swap(still);
-      secCommit += since(tm0);
+      clk.commit += since(tm0);
     }
+    clk.wall = since(tg0);
+    tlsErrCtx = nullptr;
+    };
+    if (G == 1) runGroup(0);
+    else {
+      std::vector<std::thread> groupThreads;
+      for (int g = 1; g < G; ++g) groupThreads.emplace_back(runGroup, g);
+      runGroup(0);
+      for (auto &th : groupThreads) th.join();
+    }
+    double secCollect = 0, secPrefetch = 0, secCommit = 0, secGroup = 0;
+    for (const GroupClock &c : clocks) { laneBatches += c.batches; secCollect += c.collect; secPrefetch += c.prefetch; secCommit += c.commit; if (c.wall > secGroup) secGroup = c.wall; }
+    if (G > 1) PrintLog("Cell groups: %d (each its own stream, image arena and host thread; slowest group %.2f s; the seconds below are sums over the groups).", G, secGroup);
     PrintLog("Assembly rounds: %lld (collect %.2f s, query batches incl. image staging %.2f s, ordered commits %.2f s).", (long long)laneBatches, secCollect, secPrefetch, secCommit);
     int mainCnt = 0;
     for (Walk &w : walks) { assembledReadIdx.insert(assembledReadIdx.end(), w.assembledMain.begin(), w.assembledMain.end()); mainCnt += (int)w.assembledMain.size(); rescueReadCnt += (int)w.rescue.size(); }
@@ -1402,12 +1583,18 @@ int main(int argc, char *argv[]) {
   std::vector<const char *> bnames;
   for (const std::string &b : barcodeIntToStr) bnames.push_back(b.c_str());
   auto writeSet = [&](const std::string &path) {
-    if (useCells) { if ((rc = t4_cellset_output(cellSet, path.c_str(), bnames.data(), (int)bnames.size()))) die(ctx, "t4_cellset_output", rc); }
+    if (useCells) {   // group after group: a group's contig ids follow the contig slots of the groups before it
+      int base = 0;
+      for (size_t g = 0; g < cellSets.size(); ++g) {
+        if ((rc = t4_cellset_output_at(cellSets[g], path.c_str(), bnames.data(), (int)bnames.size(), base, g > 0))) die(cellCtxs[g], "t4_cellset_output_at", rc);
+        base += t4_cellset_size(cellSets[g]);
+      }
+    }
     else if (hasBarcode) { if ((rc = t4_assembler_output_barcodes(seqSet, path.c_str(), bnames.data(), (int)bnames.size()))) die(ctx, "t4_assembler_output_barcodes", rc); }
     else if ((rc = t4_assembler_output(seqSet, path.c_str()))) die(ctx, "t4_assembler_output", rc);
   };
   if (contigMinCov > 0) {   // main.cpp:1952-1955
-    if (useCells) t4_cellset_release_shallow_contigs(cellSet, contigMinCov); else t4_assembler_release_shallow_contigs(seqSet, contigMinCov);
+    if (useCells) { for (t4_cellset *cs : cellSets) t4_cellset_release_shallow_contigs(cs, contigMinCov); } else t4_assembler_release_shallow_contigs(seqSet, contigMinCov);
   }
   // a prefix starting with '-' sends the two contig files to stdout (main.cpp:1960-1966, 2021-2027)
   const bool toStdout = !outputPrefix.empty() && outputPrefix[0] == '-';
@@ -1426,18 +1613,24 @@ int main(int argc, char *argv[]) {
     fflush(stdout);
     unlink(tmpl);
   };
+  auto cellSlots = [&]() { int n = 0; for (t4_cellset *cs : cellSets) n += t4_cellset_size(cs); return n; };
+  auto destroyCells = [&]() { for (size_t g = 0; g < cellSets.size(); ++g) { t4_cellset_destroy(cellSets[g]); if (g > 0) t4_destroy(cellCtxs[g]); } cellSets.clear(); };
   auto writeCellStats = [&]() {
     int64_t qb = 0, rq = 0, im = 0, by = 0; double sq = 0, ss = 0;
-    t4_cellset_counters(cellSet, &qb, &rq, &im, &by, &sq, &ss);
+    for (t4_cellset *cs : cellSets) {   // counts: sums over the cell groups; seconds: sums too (the groups overlap in time)
+      int64_t a = 0, b = 0, c = 0, d = 0; double e = 0, f = 0;
+      t4_cellset_counters(cs, &a, &b, &c, &d, &e, &f);
+      qb += a; rq += b; im += c; by += d; sq += e; ss += f;
+    }
     if (const char *sj = getenv("T4_STATS_JSON")) {
       FILE *fp = fopen(sj, "w");
       if (fp) {
         fprintf(fp, "{\"reads\": %d, \"threads\": %d, \"phases_s\": {", readCnt, threadCnt);
         for (size_t i = 0; i < phaseMarks.size(); ++i) fprintf(fp, "%s\"%s\": %.4f", i ? ", " : "", phaseMarks[i].first.c_str(), phaseMarks[i].second);
         fprintf(fp, "}, \"rough_annotation\": {\"reads\": %lld, \"hits\": %lld, \"kernel_ms\": %.3f}, ", annotReads, annotHits, annotKernelMs);
-        fprintf(fp, "\"cells\": {\"query_batches\": %lld, \"reads_queried\": %lld, \"images_staged\": %lld, \"bytes_staged\": %lld, \"query_wall_s\": %.3f, \"stage_wall_s\": %.3f}, ",
-                (long long)qb, (long long)rq, (long long)im, (long long)by, sq, ss);
-        fprintf(fp, "\"contigs\": %d, \"assembled_reads\": %d}\n", t4_cellset_size(cellSet), (int)assembledReadIdx.size());
+        fprintf(fp, "\"cells\": {\"groups\": %d, \"query_batches\": %lld, \"reads_queried\": %lld, \"images_staged\": %lld, \"bytes_staged\": %lld, \"query_wall_s\": %.3f, \"stage_wall_s\": %.3f}, ",
+                (int)cellSets.size(), (long long)qb, (long long)rq, (long long)im, (long long)by, sq, ss);
+        fprintf(fp, "\"contigs\": %d, \"assembled_reads\": %d}\n", cellSlots(), (int)assembledReadIdx.size());
         fclose(fp);
       }
     }
@@ -1508,7 +1701,7 @@ int main(int argc, char *argv[]) {
     }
     // (1) slots and byte counts of every rank
     std::vector<std::string> heads;
-    if (!exchange(std::to_string(t4_cellset_size(cellSet)) + " " + std::to_string(mainText.size()) + " " + std::to_string(rescueText.size()), true, heads)) { fprintf(stderr, "trust4-hip: the exchange of the shard headers failed\n"); return EXIT_FAILURE; }
+    if (!exchange(std::to_string(cellSlots()) + " " + std::to_string(mainText.size()) + " " + std::to_string(rescueText.size()), true, heads)) { fprintf(stderr, "trust4-hip: the exchange of the shard headers failed\n"); return EXIT_FAILURE; }
     std::vector<long long> slots((size_t)shardCount), mainBytes((size_t)shardCount), rescueBytes((size_t)shardCount);
     for (int r = 0; r < shardCount; ++r) if (sscanf(heads[(size_t)r].c_str(), "%lld %lld %lld", &slots[(size_t)r], &mainBytes[(size_t)r], &rescueBytes[(size_t)r]) != 3) { fprintf(stderr, "trust4-hip: bad shard header from rank %d\n", r); return EXIT_FAILURE; }
     long long base = 0, mainAt = 0, rescueAt = 0, mainAll = 0, slotsAll = 0;
@@ -1566,12 +1759,19 @@ int main(int argc, char *argv[]) {
     if (comm) t4_comm_destroy(comm);
     mark("outputs_written");
     writeCellStats();
-    t4_cellset_destroy(cellSet);
+    destroyCells();
     t4_index_destroy(refSet);
     t4_destroy(ctx);
     return 0;
   }
-  writeSetOrStdout(outputPrefix + "_raw.out");
+  // the three files are independent dumps of state that no longer changes: _raw.out and _final.out are written on their own
+  // threads while this one writes the reads (stdout output and shards keep the serial order)
+  const bool concurrentFiles = !toStdout && shardCount == 1 && threadCnt > 1;
+  std::thread rawWriter, finalWriter;
+  if (concurrentFiles) {
+    rawWriter = std::thread([&] { writeSet(outputPrefix + "_raw.out"); });
+    finalWriter = std::thread([&] { writeSet(outputPrefix + "_final.out"); });
+  } else writeSetOrStdout(outputPrefix + "_raw.out");
   size_t nMainAssembled = assembledReadIdx.size();
   if (shardCount > 1) nMainAssembled -= (size_t)rescuedCnt;
   {
@@ -1593,17 +1793,19 @@ int main(int argc, char *argv[]) {
   if (shardCount > 1) {   // contig ids above are local to the shard; stage1_dist.py shifts them by the slots of the earlier shards
     if (nMainAssembled == assembledReadIdx.size()) { FILE *fp = fopen((outputPrefix + "_assembled_reads_rescue.fa").c_str(), "w"); if (fp) fclose(fp); }
     FILE *fp = fopen((outputPrefix + "_shard.meta").c_str(), "w");
-    fprintf(fp, "shard %d %d\ncontig_slots %d\nreads %d\n", shardRank, shardCount, t4_cellset_size(cellSet), readCnt);
+    fprintf(fp, "shard %d %d\ncontig_slots %d\nreads %d\n", shardRank, shardCount, cellSlots(), readCnt);
     fclose(fp);
   } else {
     if (!skipMateExtension && hasMate && !hasBarcode)   // only reachable under T4_ALLOW_RAW_FINAL=1 (checked with the options)
       PrintLog("NOTE: T4_ALLOW_RAW_FINAL=1: _final.out is the raw assembly (what the reference writes under --skipMateExtension), NOT its mate-pair extension.");
-    writeSetOrStdout(outputPrefix + "_final.out");
+    if (!concurrentFiles) writeSetOrStdout(outputPrefix + "_final.out");
   }
+  if (concurrentFiles) { rawWriter.join(); finalWriter.join(); }
   if (useCells) {
     mark("outputs_written");
     writeCellStats();
-    t4_cellset_destroy(cellSet);
+    leave(0);
+    destroyCells();
     t4_index_destroy(refSet);
     t4_destroy(ctx);
     return 0;
@@ -1637,6 +1839,7 @@ int main(int argc, char *argv[]) {
            (long long)lc[0], (long long)lc[1], lc[15] / 1e6, (long long)lc[2], lc[3] / 1e6, lc[12] / 1e6, (long long)wh, (long long)lc[4], (long long)lc[5], (long long)lc[6],
            (long long)lc[7], (long long)lc[8], (long long)lc[9], (long long)lc[10], (long long)lc[11], lc[13] / 1e6, lc[14] / 1e6);
   (void)q; (void)rf; (void)sr; (void)sq;
+  leave(0);
   t4_assembler_destroy(seqSet);
   t4_index_destroy(refSet);
   t4_destroy(ctx);
