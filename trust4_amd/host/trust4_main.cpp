@@ -18,6 +18,7 @@
 // copy of `_raw.out` (the reference does the same under --skipMateExtension and always with barcodes; its mate-graph
 // extension tail is out of scope).
 #include <emmintrin.h>
+#include <malloc.h>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <getopt.h>
@@ -385,9 +386,12 @@ bool isLowComplexity(const std::string &s) {   // main.cpp:183-205
 // surviving reads (same multiset of AddCount calls) is done afterwards over the whole read list
 // `pre` (optional): the two IsMateOverlap tests of this pair as t4_mate_overlap computed them for the whole block --
 // {ret, offset, bestMatchCnt} of (rc(mate 2), mate 1, minOverlap, no tandem check) and of (mate 1, rc(mate 2), minOverlap2, tandem check)
-void processRead(SortRead &in1, SortRead &in2, bool hasMate2, std::vector<SortRead> &out, const int32_t *pre = nullptr) {
-  // the records are taken over, not copied: a pair that stays as it is (most do) costs no allocation at all on its way into the read list
-  SortRead r1 = std::move(in1), r2 = std::move(in2);
+void processRead(const SortRead &in1, const SortRead &in2, bool hasMate2, std::vector<SortRead> &out, const int32_t *pre = nullptr) {
+  // Private copies: every string the read list ends up holding was allocated by the thread that ran this function, so the passes that
+  // later shrink or free them on all threads (quality strings after the trimming, ...) meet as many allocator arenas as threads.
+  // Measured (round 4, 1 M barcoded pairs, -t 32, profiles/r04u_*): taking the reader threads' strings over instead of copying them
+  // sends every later free to the readers' two arenas -- 49 s of system time instead of 6, the run 13.6 s instead of 10.5.
+  SortRead r1 = in1, r2 = in2;
   int rWeight = 1;
   bool r2Alive = hasMate2;
   if (hasMate2) {
@@ -501,6 +505,14 @@ void die(t4_ctx *ctx, const char *what, int rc) {
 
 int main(int argc, char *argv[]) {
   if (argc <= 1) { fprintf(stderr, "%s", USAGE); return 0; }
+  // The run holds millions of small records and a few hundred buffers of megabytes that come and go with every block of input. With
+  // glibc's defaults the large ones are mapped and unmapped each time: fresh pages, and every munmap stops the page faults of all
+  // other threads (most of a run's system time, measured). Large blocks come from the heap and the heap is not handed back.
+  if (!getenv("T4_NO_MALLOPT")) {   // TEMP (measurement)
+  mallopt(M_MMAP_THRESHOLD, 32 << 20);
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
+  mallopt(M_TOP_PAD, 64 << 20);
+  }
   static struct option long_options[] = {{"trimLevel", required_argument, 0, 10001}, {"skipMateExtension", no_argument, 0, 10005},
                                          {"minHitLen", required_argument, 0, 10006}, {"cgeneEnd", required_argument, 0, 10008},
                                          {"barcode", required_argument, 0, 10002}, {"UMI", required_argument, 0, 10004},
@@ -592,6 +604,7 @@ int main(int argc, char *argv[]) {
   std::vector<InPair> block;
   const size_t BLOCK = 262144;
   double secProcess = 0, secMerge = 0;
+  std::vector<std::vector<SortRead>> chunkOuts;
   // T4_GPU_MATEOVERLAP=1 (opt-in this round): the two AlignAlgo::IsMateOverlap tests of every pair of a block come from
   // t4_mate_overlap (one pair per wavefront) instead of the host threads; the merge itself stays on the host.
   const bool gpuMate = getenv("T4_GPU_MATEOVERLAP") && atoi(getenv("T4_GPU_MATEOVERLAP")) != 0;
@@ -603,7 +616,9 @@ int main(int argc, char *argv[]) {
     // results per CHUNK of consecutive pairs (one vector per chunk, filled by one thread in input order: a vector per pair was a
     // million small allocations per block, freed across threads)
     const size_t PP_CHUNK = 1024;
-    std::vector<std::vector<SortRead>> outs((block.size() + PP_CHUNK - 1) / PP_CHUNK);
+    std::vector<std::vector<SortRead>> &outs = chunkOuts;   // (the chunk vectors keep their storage from block to block: no fresh pages after the first)
+    if (outs.size() < (block.size() + PP_CHUNK - 1) / PP_CHUNK) outs.resize((block.size() + PP_CHUNK - 1) / PP_CHUNK);
+    const size_t nChunks = (block.size() + PP_CHUNK - 1) / PP_CHUNK;
     std::vector<int32_t> pre;
     bool anyMate = false;
     for (const InPair &ip : block) if (ip.haveMate) { anyMate = true; break; }
@@ -662,7 +677,7 @@ int main(int argc, char *argv[]) {
       else for (int i = 0; i < n; ++i) if (block[(size_t)i].haveMate) ++ppKinds[meta[(size_t)i * 4] & 3];
     }
     auto onePair = [&](long long i, std::vector<SortRead> &out) {
-      InPair &ip = block[(size_t)i];
+      const InPair &ip = block[(size_t)i];
       if (!meta.empty() && ip.haveMate) {
         const int len = meta[(size_t)i * 4 + 1], fl = meta[(size_t)i * 4 + 2];
         if (fl & 1) {
@@ -684,21 +699,23 @@ int main(int argc, char *argv[]) {
       }
       processRead(ip.a, ip.b, ip.haveMate, out, pre.empty() ? nullptr : &pre[(size_t)i * 6]);
     };
-    parallelFor((long long)outs.size(), threadCnt, [&](long long c) {
+    parallelFor((long long)nChunks, threadCnt, [&](long long c) {
       std::vector<SortRead> &out = outs[(size_t)c];
       const size_t lo = (size_t)c * PP_CHUNK, hi = lo + PP_CHUNK < block.size() ? lo + PP_CHUNK : block.size();
+      out.clear();
       out.reserve((hi - lo) * 2 + 2);
       for (size_t i = lo; i < hi; ++i) onePair((long long)i, out);
     });
     auto t1 = std::chrono::steady_clock::now();
     {   // the chunks at their places in the read list, moved on the threads (the list has room for the whole input when its size could
         // be told from the first block and the file's size: no reallocation, every page of it touched once)
-      std::vector<size_t> first(outs.size() + 1, sortedReads.size());
-      for (size_t c = 0; c < outs.size(); ++c) first[c + 1] = first[c] + outs[c].size();
-      sortedReads.resize(first[outs.size()]);
-      parallelFor((long long)outs.size(), threadCnt, [&](long long c) {
+      std::vector<size_t> first(nChunks + 1, sortedReads.size());
+      for (size_t c = 0; c < nChunks; ++c) first[c + 1] = first[c] + outs[c].size();
+      sortedReads.resize(first[nChunks]);
+      parallelFor((long long)nChunks, threadCnt, [&](long long c) {
         std::vector<SortRead> &v = outs[(size_t)c];
         for (size_t j = 0; j < v.size(); ++j) sortedReads[first[(size_t)c] + j] = std::move(v[j]);
+        v.clear();
       });
     }
     block.clear();
@@ -819,6 +836,7 @@ int main(int argc, char *argv[]) {
   if (gpuProcess) PrintLog("ProcessRead on the device: %lld pairs stay as they are, %lld read-through, %lld merged, %lld with one mate for both", ppKinds[0], ppKinds[1], ppKinds[2], ppKinds[3]);
   if (gpuProcess && ppBlocksOnHost) PrintLog("ProcessRead: %lld blocks held a mate beyond the device path's length and were processed on the host threads", ppBlocksOnHost);
   if (getenv("T4_TIMING")) PrintLog("timing: input parsed and mates processed (ProcessRead %.2f s on %d threads, merge %.2f s)", secProcess, threadCnt, secMerge);
+  const auto tInputEnd = std::chrono::steady_clock::now();
   int readCnt = (int)sortedReads.size();
   int maxReadLen = 0;
   for (const SortRead &r : sortedReads) if ((int)r.read.size() > maxReadLen) maxReadLen = (int)r.read.size();
@@ -910,7 +928,7 @@ int main(int argc, char *argv[]) {
     }
   } else if (kmerCountFile.empty())
   kmerCount.addCountAll((long long)sortedReads.size(), threadCnt, [&](long long i) -> const std::string & { return sortedReads[(size_t)i].read; });
-  if (getenv("T4_TIMING")) PrintLog("timing: 21-mers counted%s", gpuKc ? " (on the device)" : "");
+  if (getenv("T4_TIMING")) PrintLog("timing: 21-mers counted%s (%.2f s since the input ended)", gpuKc ? " (on the device)" : "", std::chrono::duration<double>(std::chrono::steady_clock::now() - tInputEnd).count());
   gpuReady();
   auto writeEmpty = [&](const char *suffix) { FILE *fp = fopen((outputPrefix + suffix).c_str(), "w"); if (fp) fclose(fp); };
   if (readCnt <= 0) { writeEmpty("_raw.out"); writeEmpty("_assembled_reads.fa"); writeEmpty("_final.out"); return 0; }
@@ -969,6 +987,7 @@ int main(int argc, char *argv[]) {
     }
     readCnt = (int)sortedReads.size();
   }
+  if (getenv("T4_TIMING")) PrintLog("timing: count statistics and trimming done (%.2f s since the input ended)", std::chrono::duration<double>(std::chrono::steady_clock::now() - tInputEnd).count());
   mark("input_processed_counted");
   PrintLog("Found %i reads.", readCnt);
   kmerCount.shards.clear();
