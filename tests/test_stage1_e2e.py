@@ -197,6 +197,25 @@ def test_trim_level_2_matches_reference_binary(tmp_path):
         assert filecmp.cmp(ref_out + suffix, my_out + suffix, shallow=False), suffix
 
 
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
+def test_trim_level_2_emulated(tmp_path):
+    """the same on the emulator build (small): the V / C trimming loops of the driver run on its threads"""
+    fa = str(tmp_path / "ref.fa")
+    _gunzip(REF_FA, fa)
+    r1, r2 = Synth(12, 5).next_pairs(220)
+    f1, f2 = str(tmp_path / "s_1.fq"), str(tmp_path / "s_2.fq")
+    _write_fastq(f1, rows_to_strs(r1))
+    _write_fastq(f2, rows_to_strs(r2))
+    ref_out, my_out = str(tmp_path / "ref"), str(tmp_path / "mine")
+    args = ["--skipMateExtension", "--trimLevel", "2", "-f", fa, "-1", f1, "-2", f2]
+    subprocess.run([REF_BIN, "-t", "1"] + args + ["-o", ref_out], check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([_emulated_driver(), "-t", "4"] + args + ["-o", my_out], check=True, env=dict(os.environ, T4_PACK_MIN="16", T4_SORT_MIN="32"))
+    for suffix in ("_raw.out", "_assembled_reads.fa", "_final.out"):
+        assert filecmp.cmp(ref_out + suffix, my_out + suffix, shallow=False), suffix
+    trimmed = [len(l.strip()) for l in open(ref_out + "_assembled_reads.fa") if not l.startswith(">")]
+    assert trimmed and min(trimmed) < 150   # reads were trimmed
+
+
 def _edge_reads(seed):
     """synthetic reads plus the edge cases the reference's own input handling has branches for: reads shorter than the 21-mer
     and than k, N runs that split a read into contigs, all-N and low-complexity reads, a read-through pair, exact duplicates"""

@@ -19,6 +19,7 @@ struct SeqReader {
   size_t cur = 0;
   gzFile fp = nullptr;
   std::string pending;   // look-ahead line
+  std::string lineBuf;
   bool havePending = false;
   std::string id, seq, qual, comment;   // comment: rest of the header line after the separator that ends the name (kseq)
   bool hasQual = false;
@@ -89,7 +90,7 @@ struct SeqReader {
         if (cur >= files.size()) return false;
         if (!openNext()) { fprintf(stderr, "Could not open %s\n", files[cur].c_str()); exit(EXIT_FAILURE); }
       }
-      std::string line;
+      std::string &line = lineBuf;   // (a member: its storage serves every line of the file)
       bool got = false;
       while (getLine(line)) if (!line.empty() && (line[0] == '>' || line[0] == '@')) { got = true; break; }
       if (!got) { closeCur(); ++cur; havePending = false; continue; }
@@ -150,6 +151,7 @@ struct ThreadedSeqReader {
   // a whole block of records at once (not to be mixed with next()): the consumer's per-record work can then run on its own threads
   bool nextBlock(Block &out) {
     if (!started) start();
+    recycle(out);   // (what `out` still holds goes back to the reader)
     Block got;
     {
       std::unique_lock<std::mutex> lk(mu);
@@ -159,8 +161,16 @@ struct ThreadedSeqReader {
       ready.pop_front();
     }
     cv.notify_all();
-    out.swap(got);   // (what `out` held is freed here, outside the lock)
+    out.swap(got);
     return !out.empty();
+  }
+  // A block the consumer is done with goes back to the reader, records and all: the reader fills the records again in place, their
+  // strings keep their storage, and in the steady state nobody allocates or frees a string (the records a consumer swapped its own
+  // strings into bring those along).
+  void recycle(Block &b) {
+    if (b.empty()) return;
+    std::lock_guard<std::mutex> lk(mu);
+    if (spare.size() < (size_t)DEPTH * 8) { spare.emplace_back(); spare.back().swap(b); }
   }
   ~ThreadedSeqReader() {
     { std::lock_guard<std::mutex> lk(mu); quit = true; }
@@ -171,7 +181,7 @@ struct ThreadedSeqReader {
   std::thread th;
   std::mutex mu;
   std::condition_variable cv;
-  std::deque<Block> ready;
+  std::deque<Block> ready, spare;
   Block cur;
   size_t at = 0;
   bool started = false, done = false, quit = false;
@@ -182,8 +192,15 @@ struct ThreadedSeqReader {
       in.files = files; in.stripMateSuffix = stripMateSuffix;
       for (;;) {
         Block b;
+        { std::lock_guard<std::mutex> lk(mu); if (!spare.empty()) { b.swap(spare.back()); spare.pop_back(); } }
         b.reserve(BLOCK);
-        while (b.size() < (size_t)BLOCK && in.next()) { b.emplace_back(); Rec &r = b.back(); r.id.swap(in.id); r.seq.swap(in.seq); r.qual.swap(in.qual); r.comment.swap(in.comment); r.hasQual = in.hasQual; }
+        size_t nb = 0;
+        while (nb < (size_t)BLOCK && in.next()) {
+          if (nb == b.size()) b.emplace_back();
+          Rec &r = b[nb++];
+          r.id.swap(in.id); r.seq.swap(in.seq); r.qual.swap(in.qual); r.comment.swap(in.comment); r.hasQual = in.hasQual;
+        }
+        b.resize(nb);
         const bool last = b.size() < (size_t)BLOCK;
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return ready.size() < (size_t)DEPTH || quit; });

@@ -18,8 +18,8 @@
 // copy of `_raw.out` (the reference does the same under --skipMateExtension and always with barcodes; its mate-graph
 // extension tail is out of scope).
 #include <emmintrin.h>
-#include <malloc.h>
 #include <fcntl.h>
+#include <functional>
 #include <sys/stat.h>
 #include <getopt.h>
 #include <math.h>
@@ -505,14 +505,6 @@ void die(t4_ctx *ctx, const char *what, int rc) {
 
 int main(int argc, char *argv[]) {
   if (argc <= 1) { fprintf(stderr, "%s", USAGE); return 0; }
-  // The run holds millions of small records and a few hundred buffers of megabytes that come and go with every block of input. With
-  // glibc's defaults the large ones are mapped and unmapped each time: fresh pages, and every munmap stops the page faults of all
-  // other threads (most of a run's system time, measured). Large blocks come from the heap and the heap is not handed back.
-  if (!getenv("T4_NO_MALLOPT")) {   // TEMP (measurement)
-  mallopt(M_MMAP_THRESHOLD, 32 << 20);
-  mallopt(M_TRIM_THRESHOLD, 1 << 30);
-  mallopt(M_TOP_PAD, 64 << 20);
-  }
   static struct option long_options[] = {{"trimLevel", required_argument, 0, 10001}, {"skipMateExtension", no_argument, 0, 10005},
                                          {"minHitLen", required_argument, 0, 10006}, {"cgeneEnd", required_argument, 0, 10008},
                                          {"barcode", required_argument, 0, 10002}, {"UMI", required_argument, 0, 10004},
@@ -585,7 +577,9 @@ int main(int argc, char *argv[]) {
   });
   auto gpuReady = [&]() {
     if (!initThread.joinable()) return;
+    const auto tw = std::chrono::steady_clock::now();
     initThread.join();
+    if (getenv("T4_TIMING")) PrintLog("timing: waited %.2f s for the device and the reference set (they come up on their own thread from the start)", std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count());
     if (initRc && !ctx) { fprintf(stderr, "trust4-hip needs an MI355X (t4_init failed: %d); there is no CPU path.\n", initRc); exit(EXIT_FAILURE); }
     if (initRc) die(ctx, initWhat, initRc);
     if (t4_index_size(refSet) == 0) { fprintf(stderr, "Need to use -f to specify the receptor genome sequence.\n"); exit(EXIT_FAILURE); }
@@ -718,7 +712,6 @@ int main(int argc, char *argv[]) {
         v.clear();
       });
     }
-    block.clear();
     secProcess += std::chrono::duration<double>(t1 - t0).count();
     secMerge += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
   };
@@ -733,6 +726,7 @@ int main(int argc, char *argv[]) {
   const auto tInput0 = std::chrono::steady_clock::now();
   auto flushBlock = [&]() {
     { const auto tw = std::chrono::steady_clock::now(); if (processThread.joinable()) processThread.join(); secWaitProcess += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count(); }
+    for (Unit &u : inProcess) { reads.recycle(u.r); mateReads.recycle(u.m); }   // the consumed blocks go back to their readers, strings and all
     inProcess.clear();
     inProcess.swap(units);
     unitPairs = 0;
@@ -740,8 +734,7 @@ int main(int argc, char *argv[]) {
     processThread = std::thread([&]() {
       std::vector<std::pair<uint32_t, uint32_t>> at;
       for (size_t u = 0; u < inProcess.size(); ++u) for (size_t i = 0; i < inProcess[u].r.size(); ++i) if (!inProcess[u].skip[i]) at.push_back({(uint32_t)u, (uint32_t)i});
-      block.clear();
-      block.resize(at.size());
+      block.resize(at.size());   // (not cleared: the strings of the pairs before are swapped into the records below and travel back to the readers)
       parallelFor((long long)at.size(), threadCnt, [&](long long k) {
         Unit &un = inProcess[at[(size_t)k].first];
         const size_t i = at[(size_t)k].second;
@@ -1163,21 +1156,21 @@ int main(int argc, char *argv[]) {
   }
   auto refName = [&](int idx) { return t4_index_seq_name(refSet, idx); };
   auto eraseFront = [](std::string &s, int n) { s.erase(0, n); };
-  for (int i = 0; i < readCnt; ++i) {   // bases before the V gene
-    SortRead &sr = sortedReads[i];
+  parallelFor((long long)readCnt, threadCnt, [&](long long i) {   // bases before the V gene (every read by itself: on the threads)
+    SortRead &sr = sortedReads[(size_t)i];
     t4_overlap *g = sr.g;
-    if (sr.dead || g[0].seqIdx == -1) continue;
+    if (sr.dead || g[0].seqIdx == -1) return;
     bool mayTrim = false;
     if (g[0].seqStart < 31 && g[0].similarity > 0.9) mayTrim = true;
     if (g[0].similarity > 0.95 && g[0].seqStart <= t4_index_seq_len(refSet, g[0].seqIdx) / 3) mayTrim = true;
     if (trimLevel > 1) mayTrim = true;
-    if (!mayTrim) continue;
+    if (!mayTrim) return;
     int trimBase = g[0].readStart;
     if (trimLevel > 1 && refName(g[0].seqIdx)[0] == 'T' && g[0].similarity < 0.97) trimBase = (g[0].readStart + g[0].readEnd) / 2;
-    if (trimBase <= 0) continue;
-    if (g[2].seqIdx != -1 && g[2].readStart < trimBase && trimLevel <= 1) continue;
-    if (g[3].seqIdx != -1 && g[3].readStart < trimBase && trimLevel <= 1) continue;
-    if (sr.len - trimBase < 31) { sr.dead = true; continue; }
+    if (trimBase <= 0) return;
+    if (g[2].seqIdx != -1 && g[2].readStart < trimBase && trimLevel <= 1) return;
+    if (g[3].seqIdx != -1 && g[3].readStart < trimBase && trimLevel <= 1) return;
+    if (sr.len - trimBase < 31) { sr.dead = true; return; }
     if (g[0].strand >= 0) eraseFront(sr.read, trimBase); else sr.read.resize(sr.len - trimBase);
     for (int j = 0; j < 4; ++j) {
       if (g[j].seqIdx == -1) continue;
@@ -1186,26 +1179,26 @@ int main(int argc, char *argv[]) {
       if (g[j].readEnd < 0) { g[j].readEnd = 0; g[j].seqIdx = -1; }
     }
     sr.len -= trimBase;
-  }
-  for (int i = 0; i < readCnt; ++i) {   // bases after the C gene
-    SortRead &sr = sortedReads[i];
+  });
+  parallelFor((long long)readCnt, threadCnt, [&](long long i) {   // bases after the C gene (every read by itself: on the threads)
+    SortRead &sr = sortedReads[(size_t)i];
     t4_overlap *g = sr.g;
     const int len = sr.len;
-    if (sr.dead) continue;
+    if (sr.dead) return;
     int gidx;
     for (gidx = 2; gidx <= 3; ++gidx) if (g[gidx].seqIdx != -1) break;
-    if (gidx > 3) continue;
-    if (gidx == 2 && refName(g[gidx].seqIdx)[2] == 'H') { gidx = 3; if (g[gidx].seqIdx == -1) continue; }
+    if (gidx > 3) return;
+    if (gidx == 2 && refName(g[gidx].seqIdx)[2] == 'H') { gidx = 3; if (g[gidx].seqIdx == -1) return; }
     bool mayTrim = false;
     if (gidx == 3 && g[3].seqStart < 9 && g[3].similarity > 0.95) mayTrim = true;
     if (trimLevel > 1) mayTrim = true;
-    if (!mayTrim) continue;
+    if (!mayTrim) return;
     int trimBase = len - g[gidx].readEnd - 1;
     if (trimLevel > 1 && refName(g[gidx].seqIdx)[0] == 'T' && g[gidx].similarity < 0.97) trimBase = len - ((g[gidx].readStart + g[gidx].readEnd) / 2) - 1;
-    if (trimBase <= 0) continue;
-    if (gidx == 3 && g[2].seqIdx != -1 && g[2].readStart + trimBase >= sr.len && trimLevel <= 1) continue;
-    if (g[0].seqIdx != -1 && g[0].readStart + trimBase >= sr.len && trimLevel <= 1) continue;
-    if (sr.len - trimBase < 31) { sr.dead = true; continue; }
+    if (trimBase <= 0) return;
+    if (gidx == 3 && g[2].seqIdx != -1 && g[2].readStart + trimBase >= sr.len && trimLevel <= 1) return;
+    if (g[0].seqIdx != -1 && g[0].readStart + trimBase >= sr.len && trimLevel <= 1) return;
+    if (sr.len - trimBase < 31) { sr.dead = true; return; }
     if (g[gidx].strand < 0) eraseFront(sr.read, trimBase); else sr.read.resize(len - trimBase);
     g[3].seqIdx = -1;
     for (int j = 0; j < 4; ++j) {
@@ -1214,7 +1207,7 @@ int main(int argc, char *argv[]) {
       if (g[j].readEnd + trimBase >= len) g[j].readEnd = len - 1;
     }
     sr.len -= trimBase;
-  }
+  });
   if (firstReadLen > 200) { fprintf(stderr, "trust4-hip: long-read mode (first read > 200 bp) is not built.\n"); return EXIT_FAILURE; }
   {
     std::vector<int> remap(readCnt, -1);
@@ -1632,6 +1625,32 @@ int main(int argc, char *argv[]) {
     fflush(stdout);
     unlink(tmpl);
   };
+  // the records of _assembled_reads.fa (main.cpp:2011-2014) for positions [lo, hi) of assembledReadIdx: formatted on the threads, piece
+  // after piece of the list, the pieces then joined or written in order
+  auto formatReads = [&](size_t lo, size_t hi, const std::function<void(const std::string &)> &sink) {
+    const size_t PIECE = 16384;
+    const size_t nPieces = (hi - lo + PIECE - 1) / PIECE;
+    const size_t WAVE = (size_t)(threadCnt > 1 ? threadCnt : 1) * 4;   // pieces formatted at a time (bounds the text held in memory)
+    std::vector<std::string> text(WAVE);
+    for (size_t p0 = 0; p0 < nPieces; p0 += WAVE) {
+      const size_t np = nPieces - p0 < WAVE ? nPieces - p0 : WAVE;
+      parallelFor((long long)np, threadCnt, [&](long long q) {
+        std::string &t = text[(size_t)q];
+        t.clear();
+        const size_t a = lo + (p0 + (size_t)q) * PIECE, b = a + PIECE < hi ? a + PIECE : hi;
+        char num[64];
+        for (size_t w = a; w < b; ++w) {
+          const SortRead &sr = sortedReads[(size_t)assembledReadIdx[w]];
+          t += '>'; t += sr.id;
+          t.append(num, (size_t)snprintf(num, sizeof num, " %d %d %d", sr.strand, sr.minCnt, sr.medianCnt));
+          if (hasBarcode) { t += " barcode:"; t += barcodeIntToStr[(size_t)sr.barcode]; }
+          if (hasUmi) t.append(num, (size_t)snprintf(num, sizeof num, " umi:%d", sr.umi));
+          t += '\n'; t += sr.read; t += '\n';
+        }
+      });
+      for (size_t q = 0; q < np; ++q) sink(text[q]);
+    }
+  };
   auto cellSlots = [&]() { int n = 0; for (t4_cellset *cs : cellSets) n += t4_cellset_size(cs); return n; };
   auto destroyCells = [&]() { for (size_t g = 0; g < cellSets.size(); ++g) { t4_cellset_destroy(cellSets[g]); if (g > 0) t4_destroy(cellCtxs[g]); } cellSets.clear(); };
   auto writeCellStats = [&]() {
@@ -1708,15 +1727,8 @@ int main(int argc, char *argv[]) {
     std::string mainText, rescueText;
     {
       const size_t nMain = assembledReadIdx.size() - (size_t)rescuedCnt;
-      size_t w = 0;
-      for (int idx : assembledReadIdx) {
-        const SortRead &sr = sortedReads[idx];
-        std::string extra;
-        if (hasBarcode) extra += " barcode:" + barcodeIntToStr[sr.barcode];
-        if (hasUmi) extra += " umi:" + std::to_string(sr.umi);
-        std::string &dst = w++ < nMain ? mainText : rescueText;
-        dst += ">" + sr.id + " " + std::to_string(sr.strand) + " " + std::to_string(sr.minCnt) + " " + std::to_string(sr.medianCnt) + extra + "\n" + sr.read + "\n";
-      }
+      formatReads(0, nMain, [&](const std::string &t) { mainText += t; });
+      formatReads(nMain, assembledReadIdx.size(), [&](const std::string &t) { rescueText += t; });
     }
     // (1) slots and byte counts of every rank
     std::vector<std::string> heads;
@@ -1794,20 +1806,16 @@ int main(int argc, char *argv[]) {
   size_t nMainAssembled = assembledReadIdx.size();
   if (shardCount > 1) nMainAssembled -= (size_t)rescuedCnt;
   {
-    FILE *fp = fopen((outputPrefix + "_assembled_reads.fa").c_str(), "w");
-    size_t nWritten = 0;
-    for (int idx : assembledReadIdx) {
-      if (shardCount > 1 && nWritten++ == nMainAssembled) {   // a shard keeps the rescue-pass reads apart: the merged file lists them after every shard's main pass
-        fclose(fp);
-        fp = fopen((outputPrefix + "_assembled_reads_rescue.fa").c_str(), "w");
-      }
-      const SortRead &sr = sortedReads[idx];
-      std::string extra;
-      if (hasBarcode) extra += " barcode:" + barcodeIntToStr[sr.barcode];
-      if (hasUmi) extra += " umi:" + std::to_string(sr.umi);
-      fprintf(fp, ">%s %d %d %d%s\n%s\n", sr.id.c_str(), sr.strand, sr.minCnt, sr.medianCnt, extra.c_str(), sr.read.c_str());
-    }
-    fclose(fp);
+    auto writeReads = [&](const std::string &path, size_t lo, size_t hi) {
+      FILE *fp = fopen(path.c_str(), "w");
+      if (!fp) { fprintf(stderr, "trust4-hip: cannot write %s\n", path.c_str()); exit(EXIT_FAILURE); }
+      bool ok = true;
+      formatReads(lo, hi, [&](const std::string &t) { if (!t.empty() && fwrite(t.data(), 1, t.size(), fp) != t.size()) ok = false; });
+      if (fclose(fp) != 0 || !ok) { fprintf(stderr, "trust4-hip: writing %s failed\n", path.c_str()); exit(EXIT_FAILURE); }
+    };
+    writeReads(outputPrefix + "_assembled_reads.fa", 0, nMainAssembled);
+    // a shard keeps the rescue-pass reads apart: the merged file lists them after every shard's main pass
+    if (shardCount > 1 && nMainAssembled < assembledReadIdx.size()) writeReads(outputPrefix + "_assembled_reads_rescue.fa", nMainAssembled, assembledReadIdx.size());
   }
   if (shardCount > 1) {   // contig ids above are local to the shard; stage1_dist.py shifts them by the slots of the earlier shards
     if (nMainAssembled == assembledReadIdx.size()) { FILE *fp = fopen((outputPrefix + "_assembled_reads_rescue.fa").c_str(), "w"); if (fp) fclose(fp); }
