@@ -23,10 +23,12 @@ Rank 0 also reports
   stage0_e2e     the stage-0 candidate filter next to the reference binary.
 
 N > 1 measures the path that shards: ONE barcode-mode sample of the C5 recipe (`--cells-pairs` pairs and
-`--cells` cells per GPU of the job), cells sharded by rank through `trust4-hip --cellShard R/N --rcclId FILE` -- no exchange
-during assembly, one RCCL all-gather of the contig records inside the engine at the end, rank 0 writes the files. Strong scaling:
-the sample is fixed by N, `value` = its pairs / the slowest rank's wall time. Rank 0 then runs the same sample on one rank and
-compares the md5 sums of the three output files (`one_rank`), and reports the replicated-phase seconds of every rank.
+`--cells` cells per GPU of the job), cells sharded by rank through `trust4-hip --cellShard R/N --rcclId FILE` -- every rank parses
+the sample and counts its 21-mers, then keeps the reads of its own cells only (statistics, sort, rough annotation, barcode-wise
+counts and the cell pass on those); no exchange during assembly, the contig records gathered to rank 0 inside the engine at the
+end, every rank writes its slice of the reads. Strong scaling: the sample is fixed by N, `value` = its pairs / the slowest
+rank's wall time. Rank 0 then runs the same sample on one rank and compares the md5 sums of the three output files (`one_rank`),
+and reports every rank's seconds in the replicated phases, in the phases on its own cells and in the cell pass (`config.per_rank_s`).
 Bulk-mode stage 1 itself is one ordered chain (replicas only): it is what N = 1 measures.
 """
 import argparse
@@ -432,26 +434,31 @@ def sharded_cells(args, rank, local_rank, world, dist):
     sync()
     dist.barrier()
     dt = t4dist.max_over_ranks(dist, time.perf_counter() - t0, dev)
-    # replicated-phase seconds of this rank (everything before the Add pass runs on every rank), gathered for the report
-    rep = add = 0.0
+    # this rank's seconds, gathered for the report: the replicated phases (parse / ProcessRead / 21-mer counts of the whole sample: up to
+    # the point where a rank lets go of the other ranks' reads), the phases before the cell pass on its own cells (count statistics,
+    # sort, rough annotation, barcode-wise counts, trimming) and the cell pass itself
+    rep = own = add = 0.0
     try:
         ph = json.load(open(os.path.join(tmp, "stats_rank%d.json" % rank)))["phases_s"]
-        rep, add = ph["trimmed_ready"], ph["assembled"] - ph["trimmed_ready"]
+        rep = ph.get("counted_all_reads", ph["trimmed_ready"])
+        own, add = ph["trimmed_ready"] - rep, ph["assembled"] - ph["trimmed_ready"]
     except Exception:   # noqa: BLE001
         pass
-    t = torch.tensor([rep, add], dtype=torch.float64, device=dev)
-    parts = [torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(world)]
+    t = torch.tensor([rep, add, own], dtype=torch.float64, device=dev)
+    parts = [torch.zeros(3, dtype=torch.float64, device=dev) for _ in range(world)]
     dist.all_gather(parts, t)
     if rank == 0:
         line = {"metric": "stage-1 assembly read pairs/sec (150 bp PE), whole stage 1, barcode mode, cells sharded over the GPUs", "value": pairs * args.steps / dt,
                 "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                 "scaling": "strong", "vs_baseline": None, "dtype": "int32/u64", "data": "synthetic",
                 "config": {"workload": "C5 recipe sample: %d synthetic 150 bp PE pairs, %d cells x 2 clones, barcode + UMI files; ONE sample over %d GPUs: every rank runs trust4-hip -t %d "
-                                       "--cellShard R/%d --rcclId (parse / ProcessRead / 21-mer counts / sort / rough annotation replicated, the Add pass of a contiguous range of cells per rank, "
-                                       "one ncclAllGather of the contig records inside the engine, rank 0 writes the files); process start to exit of the slowest rank"
+                                       "--cellShard R/%d --rcclId (parse / ProcessRead / 21-mer counts of the whole sample replicated; count statistics, sort, rough annotation, barcode-wise counts "
+                                       "and the Add pass on a contiguous range of cells per rank; the contig records gathered to rank 0 inside the engine, every rank writes its slice of the reads); "
+                                       "process start to exit of the slowest rank"
                                        % (pairs, cells, world, threads, world),
                            "pairs": pairs, "cells": cells, "host_threads_per_rank": threads,
-                           "per_rank_s": {"replicated_phases": [float(x[0]) for x in parts], "add_pass_of_its_cells": [float(x[1]) for x in parts]}}}
+                           "per_rank_s": {"replicated_phases": [float(x[0]) for x in parts], "own_cells_before_the_add_pass": [float(x[2]) for x in parts],
+                                          "add_pass_of_its_cells": [float(x[1]) for x in parts]}}}
         md5s = {x: file_md5(out + x) for x in OUT_SUFFIXES}
         one = os.path.join(tmp, "one_rank")
         t1 = time.perf_counter()

@@ -96,7 +96,7 @@ def run_stage1_two_ranks(tmp_path, driver, pairs, cells, seed, world=2):
     assert open(single + "_raw.out").read().count(">") >= cells
 
 
-def run_engine_merge(tmp_path, driver, pairs, cells, seed, world, env=None):
+def run_engine_merge(tmp_path, driver, pairs, cells, seed, world, env=None, extra=(), expect_log=None):
     """The merge trust4-hip itself runs on a multi-GPU node (trust4_main.cpp: shard headers all-gathered, every rank renumbers its own
     contig records, records gathered to rank 0, every rank writes its slice of _assembled_reads.fa at its offset), with the file
     transport (--gatherDir) in place of RCCL: `world` processes of the driver, no Python in the exchange. Outputs must equal the
@@ -120,16 +120,37 @@ def run_engine_merge(tmp_path, driver, pairs, cells, seed, world, env=None):
     gdir = tmp_path / "gather"
     gdir.mkdir()
     merged = str(tmp_path / "merged")
-    procs = [subprocess.Popen([driver] + argv + ["-o", merged, "--cellShard", "%d/%d" % (r, world), "--gatherDir", str(gdir)], env=e, stderr=subprocess.PIPE, text=True)
+    procs = [subprocess.Popen([driver] + argv + ["-o", merged, "--cellShard", "%d/%d" % (r, world), "--gatherDir", str(gdir)] + list(extra), env=e, stderr=subprocess.PIPE, text=True)
              for r in range(world)]
     logs = [p.communicate(timeout=900)[1] for p in procs]
     assert [p.returncode for p in procs] == [0] * world, logs
     assert "Gathered %d shards over files" % world in logs[0]
+    if expect_log:
+        for l in logs:
+            assert expect_log in l, l[-600:]
     for suffix in ("_raw.out", "_final.out", "_assembled_reads.fa"):
         assert filecmp.cmp(single + suffix, merged + suffix, shallow=False), suffix
     n = open(single + "_raw.out").read().count(">")
     assert n >= cells
     return n
+
+
+def test_early_shard_paths(tmp_path):
+    """--cellShard with a transport (round 4): every rank lets go of the other ranks' reads once the sample's 21-mers are counted and
+    runs statistics, sort, rough annotation, barcode-wise counts and the cell pass on its own cells only. (a) the default, logged per
+    rank; (b) more ranks than cells: ranks without a read; (c) --lateShard: every rank keeps every read up to the cell pass (round 3's
+    way); (d) the fallback: identical reads either side of a rank boundary (forced here) -> every rank starts a --lateShard run of its
+    own and passes its status on. All: the single-process files byte for byte."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_stage1_e2e import _emulated_driver
+    exe = _emulated_driver()
+    env = {"HIPEMU_THREADS": "2", "T4_THREADS": "2"}
+    for tag in "abcd":
+        (tmp_path / tag).mkdir()
+    run_engine_merge(tmp_path / "a", exe, 120, 7, 9, 2, env=env, expect_log="of 7 are this rank's")
+    run_engine_merge(tmp_path / "b", exe, 60, 3, 11, 5, env={"HIPEMU_THREADS": "1"}, expect_log="are this rank's")
+    run_engine_merge(tmp_path / "c", exe, 120, 7, 9, 2, env=env, extra=["--lateShard"])
+    run_engine_merge(tmp_path / "d", exe, 120, 7, 9, 2, env=dict(env, T4_TEST_FORCE_COUPLED="1"), expect_log="starting over with --lateShard")
 
 
 def test_engine_merge_two_and_eight_ranks(tmp_path):
@@ -269,7 +290,9 @@ def test_bench_gpus2_plumbing_dry_run(tmp_path):
     assert line["n_gpus"] == 2 and line["steps"] == 1 and line["warmup"] == 1 and line["scaling"] == "strong" and line["value"] > 0
     assert line["config"]["pairs"] == 120 and line["config"]["cells"] == 8
     assert line["one_rank"]["identical"] is True
-    assert len(line["config"]["per_rank_s"]["replicated_phases"]) == 2 and min(line["config"]["per_rank_s"]["replicated_phases"]) > 0
+    per = line["config"]["per_rank_s"]
+    assert len(per["replicated_phases"]) == 2 and min(per["replicated_phases"]) > 0
+    assert len(per["own_cells_before_the_add_pass"]) == 2 and min(per["own_cells_before_the_add_pass"]) > 0   # (the early shard: a mark of its own in the stats)
 
 
 def test_two_rank_barcode_stage1(tmp_path):

@@ -19,6 +19,8 @@
 // extension tail is out of scope).
 #include <emmintrin.h>
 #include <fcntl.h>
+#include <sys/wait.h>
+#include <spawn.h>
 #include <functional>
 #include <sys/stat.h>
 #include <getopt.h>
@@ -41,6 +43,8 @@
 
 #include "../../include/trust4_hip.h"
 #include "seq_reader.h"
+
+extern char **environ;
 
 namespace {
 
@@ -69,6 +73,8 @@ const char *USAGE =
     "\t--cellShard R/N: barcode mode only; assemble the R-th of N contiguous ranges of cells, write shard outputs\n"
     "\t--rcclId FILE: with --cellShard, one process per GPU: gather the shards over RCCL (rank 0 creates FILE, the communicator id) and write the merged -o files\n"
     "\t--gatherDir DIR: the same exchange through files in DIR (a directory every rank sees) instead of RCCL\n"
+    "\t                 (with either transport a rank lets go of the other ranks' reads once the 21-mers of the sample are counted; --lateShard keeps\n"
+    "\t                 every read on every rank up to the cell pass, as a run does by itself when identical reads lie either side of a rank boundary)\n"
     "\t--readShard R/N: one sample over N processes (one per GPU): the rough annotation of the R-th range of the distinct reads here, the results\n"
     "\t                 all-gathered (--rcclId / --gatherDir); rank 0 runs the ordered assembly pass and writes the files, the others end after the exchange\n";
 
@@ -509,11 +515,12 @@ int main(int argc, char *argv[]) {
                                          {"minHitLen", required_argument, 0, 10006}, {"cgeneEnd", required_argument, 0, 10008},
                                          {"barcode", required_argument, 0, 10002}, {"UMI", required_argument, 0, 10004},
                                          {"keepNoBarcode", no_argument, 0, 10003}, {"contigMinCov", required_argument, 0, 10007},
-                                         {"cellShard", required_argument, 0, 10100}, {"rcclId", required_argument, 0, 10101}, {"gatherDir", required_argument, 0, 10102}, {"readShard", required_argument, 0, 10103}, {"debug-ns", required_argument, 0, 10000},
+                                         {"cellShard", required_argument, 0, 10100}, {"rcclId", required_argument, 0, 10101}, {"gatherDir", required_argument, 0, 10102}, {"readShard", required_argument, 0, 10103}, {"lateShard", no_argument, 0, 10104}, {"debug-ns", required_argument, 0, 10000},
                                          {(char *)0, 0, 0, 0}};
   int indexKmerLength = 9, changeKmerLengthThreshold = 4096, trimLevel = 1, minHitLen = -1, constantGeneEnd = 200;
   int shardRank = 0, shardCount = 1, threadCnt = 1, contigMinCov = 0;
   bool annotSharded = false;
+  bool lateShard = false;   // --lateShard (set by the fallback of the early shard, see below): every rank runs the phases before the cell pass over ALL reads, as round 3 did
   int annotRank = 0, annotCount = 1;   // --readShard R/N: the read-only pass of ONE sample (rough annotation) by read range over N processes, results all-gathered; rank 0 goes on alone
   std::string gatherDir;    // --gatherDir DIR: the same exchange through files of a directory every rank sees (tests without RCCL)
   std::string rcclIdPath;   // --rcclId FILE: the shards' results are gathered inside the engine (t4_comm: RCCL), rank 0 writes the merged files
@@ -542,6 +549,7 @@ int main(int argc, char *argv[]) {
     else if (c == 10004) { umiFile.files.push_back(optarg); hasUmi = true; }
     else if (c == 10101) rcclIdPath = optarg;
     else if (c == 10102) gatherDir = optarg;
+    else if (c == 10104) lateShard = true;
     else if (c == 10103) { if (sscanf(optarg, "%d/%d", &annotRank, &annotCount) != 2 || annotCount < 1 || annotRank < 0 || annotRank >= annotCount) { fprintf(stderr, "--readShard takes R/N with 0 <= R < N\n"); return EXIT_FAILURE; } annotSharded = true; }
     else if (c == 10100) { if (sscanf(optarg, "%d/%d", &shardRank, &shardCount) != 2 || shardCount < 1 || shardRank < 0 || shardRank >= shardCount) { fprintf(stderr, "--cellShard takes R/N with 0 <= R < N\n"); return EXIT_FAILURE; } }
     else if (c == 10003) keepMissingBarcode = true;
@@ -583,6 +591,48 @@ int main(int argc, char *argv[]) {
     if (initRc && !ctx) { fprintf(stderr, "trust4-hip needs an MI355X (t4_init failed: %d); there is no CPU path.\n", initRc); exit(EXIT_FAILURE); }
     if (initRc) die(ctx, initWhat, initRc);
     if (t4_index_size(refSet) == 0) { fprintf(stderr, "Need to use -f to specify the receptor genome sequence.\n"); exit(EXIT_FAILURE); }
+  };
+  // ---- the transport of the sharded modes (--cellShard): RCCL over xGMI (--rcclId: t4_comm on the ctx's stream) or files in a directory
+  // every rank sees (--gatherDir: the CPU tests). After the fallback of the early shard (--lateShard) the names carry a tag of their own,
+  // so that nothing of the first attempt is taken for the second's.
+  t4_comm *comm = nullptr;
+  int exchangeNo = 0;
+  const std::string xferTag = lateShard ? "retry." : "";
+  auto fileOf = [&](int no, int r) { return gatherDir + "/" + xferTag + "x" + std::to_string(no) + ".rank" + std::to_string(r); };
+  auto readWhole = [](const std::string &path, std::string &out) { FILE *fp = fopen(path.c_str(), "rb"); if (!fp) return false; char buf[1 << 16]; size_t n; out.clear(); while ((n = fread(buf, 1, sizeof buf, fp)) > 0) out.append(buf, n); fclose(fp); return true; };
+  // every rank contributes `mine`; everyRank: all ranks receive all contributions, else only rank 0 does
+  auto exchange = [&](const std::string &mine, bool everyRank, std::vector<std::string> &got) -> bool {
+    got.assign((size_t)shardCount, std::string());
+    const int no = exchangeNo++;
+    if (!gatherDir.empty()) {
+      const std::string tmp = fileOf(no, shardRank) + ".tmp";
+      FILE *fp = fopen(tmp.c_str(), "wb");
+      if (!fp || fwrite(mine.data(), 1, mine.size(), fp) != mine.size()) { if (fp) fclose(fp); return false; }
+      fclose(fp);
+      if (rename(tmp.c_str(), fileOf(no, shardRank).c_str())) return false;
+      if (!everyRank && shardRank != 0) return true;
+      for (int r = 0; r < shardCount; ++r) {
+        bool ok = false;
+        for (int tries = 0; tries < 36000 && !ok; ++tries) { ok = readWhole(fileOf(no, r), got[(size_t)r]); if (!ok) usleep(50000); }
+        if (!ok) return false;
+      }
+      return true;
+    }
+    if (!comm) {
+      gpuReady();
+      if ((rc = t4_comm_init(ctx, shardRank, shardCount, (rcclIdPath + (lateShard ? ".retry" : "")).c_str(), &comm))) die(ctx, "t4_comm_init", rc);
+    }
+    void *all = nullptr;
+    std::vector<int64_t> sizes((size_t)shardCount);
+    const int rr = everyRank ? t4_comm_allgather_bytes(comm, mine.data(), (int64_t)mine.size(), &all, sizes.data())
+                             : t4_comm_gather_bytes(comm, mine.data(), (int64_t)mine.size(), 0, &all, sizes.data());
+    if (rr) die(ctx, everyRank ? "t4_comm_allgather_bytes" : "t4_comm_gather_bytes", rr);
+    if (all) {
+      size_t at = 0;
+      for (int r = 0; r < shardCount; ++r) { got[(size_t)r].assign((const char *)all + at, (size_t)sizes[(size_t)r]); at += (size_t)sizes[(size_t)r]; }
+      free(all);
+    }
+    return true;
   };
   PrintLog("Start to assemble reads.");
   // wall-clock marks of the phases (written to $T4_STATS_JSON for bench.py)
@@ -931,6 +981,39 @@ int main(int argc, char *argv[]) {
     for (SortRead &r : sortedReads) if (!(r.barcode != -1 && barcodePairCount[r.barcode] < contigMinCov)) kept.push_back(std::move(r));
     sortedReads.swap(kept);
     readCnt = (int)sortedReads.size();
+  }
+  // ---- --cellShard R/N, early (round 4). The 21-mer counts above need every read of the sample; nothing after them does: statistics,
+  // trimming, sorting, rough annotation, barcode-wise counts and the cell pass of a cell look at that cell's reads only. So the cells are
+  // dealt to the ranks HERE -- contiguous ranges of the barcode numbers (= the order of the output) with about the same number of reads --
+  // and every rank lets go of the other ranks' reads. What stays replicated: parsing, ProcessRead, the global counts. One coupling
+  // between neighbouring cells exists (good-candidate propagation over identical boundary reads, see the walks below); it is looked
+  // for across the rank boundaries once the reads are in their final order, and a run that has it starts over with --lateShard.
+  if (shardCount > 1) mark("counted_all_reads");   // (what comes before is replicated on every rank of a sharded run)
+  const bool earlyShard = shardCount > 1 && !lateShard && (!rcclIdPath.empty() || !gatherDir.empty());   // (the boundary check needs the transport; shard files without one: as before)
+  if (earlyShard) {
+    const size_t nb = barcodeIntToStr.size();
+    std::vector<long long> per(nb, 0);
+    for (const SortRead &r : sortedReads) if (r.barcode >= 0) ++per[(size_t)r.barcode];
+    const long long total = (long long)sortedReads.size();
+    auto firstBarcodeOf = [&](int r) {   // barcodes [firstBarcodeOf(r), firstBarcodeOf(r + 1)) are rank r's
+      if (r >= shardCount) return nb;
+      const long long target = total * r / shardCount;
+      long long cum = 0;
+      size_t b = 0;
+      while (b < nb && cum < target) cum += per[b++];
+      return b;
+    };
+    const int bLo = (int)firstBarcodeOf(shardRank), bHi = (int)firstBarcodeOf(shardRank + 1);
+    std::vector<SortRead> kept;
+    size_t mine = 0;
+    for (const SortRead &r : sortedReads) if (r.barcode >= bLo && r.barcode < bHi) ++mine;
+    kept.reserve(mine);
+    for (SortRead &r : sortedReads) if (r.barcode >= bLo && r.barcode < bHi) kept.push_back(std::move(r));
+    sortedReads.swap(kept);
+    readCnt = (int)sortedReads.size();
+    for (t4_batch *kb : countedBatches) t4_batch_destroy(kb);   // (the chunks of the count pass held every rank's reads)
+    countedBatches.clear();
+    PrintLog("Cells %d-%d of %d are this rank's (%d of %lld reads).", bLo, bHi, (int)nb, readCnt, total);
   }
   // ---- count statistics + quality trimming (main.cpp:980-1061)
   if (gpuKc) {
@@ -1449,7 +1532,45 @@ int main(int argc, char *argv[]) {
       i = j;
     }
     size_t firstWalk = 0, endWalkAll = walks.size();
-    if (shardCount > 1) {   // contiguous ranges of walks with about the same number of reads
+    if (earlyShard) {
+      // every read here is this rank's. The coupling of neighbouring cells -- a walk that runs on into the next cell because the reads
+      // either side of the boundary are identical -- must not cross a rank boundary: the ranks tell each other their first and last read
+      std::vector<std::string> ends;
+      const std::string mineEnds = readCnt > 0 ? sortedReads[0].read + "\n" + sortedReads[(size_t)readCnt - 1].read : std::string();
+      if (!exchange(mineEnds, true, ends)) { fprintf(stderr, "trust4-hip: the exchange of the boundary reads failed\n"); return EXIT_FAILURE; }
+      bool coupled = getenv("T4_TEST_FORCE_COUPLED") != nullptr;   // (testing aid: the fallback below on inputs that do not need it)
+      std::string lastSeen;
+      for (int r = 0; r < shardCount; ++r) {
+        if (ends[(size_t)r].empty()) continue;
+        const size_t nl = ends[(size_t)r].find('\n');
+        const std::string first = ends[(size_t)r].substr(0, nl), last = ends[(size_t)r].substr(nl + 1);
+        if (!lastSeen.empty() && lastSeen == first) coupled = true;
+        lastSeen = last;
+      }
+      if (coupled) {
+        // rare (the last read of one rank's cells and the first read of the next rank's are the same sequence): the sample is run
+        // again with every rank keeping all reads up to the cell pass, where whole walks are dealt out (--lateShard). The device is
+        // given back first; the second attempt is a process of its own and this one passes its status on.
+        PrintLog("Identical reads either side of a rank boundary: starting over with --lateShard.");
+        if (comm) { t4_comm_destroy(comm); comm = nullptr; }
+        for (size_t g = 0; g < cellSets.size(); ++g) { t4_cellset_destroy(cellSets[g]); if (g > 0) t4_destroy(cellCtxs[g]); }
+        cellSets.clear();
+        t4_index_destroy(refSet);
+        t4_destroy(ctx);
+        std::vector<SortRead>().swap(sortedReads);
+        std::vector<char *> av2;
+        for (int a = 0; a < argc; ++a) av2.push_back(argv[a]);
+        char flag[] = "--lateShard";
+        av2.push_back(flag); av2.push_back(nullptr);
+        fflush(nullptr);
+        pid_t child = 0;
+        if (posix_spawn(&child, "/proc/self/exe", nullptr, nullptr, av2.data(), environ) != 0) { fprintf(stderr, "trust4-hip: cannot start the --lateShard run\n"); return EXIT_FAILURE; }
+        int st = 0;
+        if (waitpid(child, &st, 0) < 0) return EXIT_FAILURE;
+        exit(WIFEXITED(st) ? WEXITSTATUS(st) : EXIT_FAILURE);
+      }
+    } else
+    if (shardCount > 1) {   // (--lateShard) contiguous ranges of walks with about the same number of reads
       auto bound = [&](int r) {
         const long long target = (long long)readCnt * r / shardCount;
         size_t wI = 0;
@@ -1684,41 +1805,6 @@ int main(int argc, char *argv[]) {
     // Transport: RCCL over xGMI (--rcclId: t4_comm, ncclAllGather + grouped ncclSend / ncclRecv from C++ on the ctx's stream), or
     // files in a directory all ranks see (--gatherDir: the CPU tests; the merge below is the same code).
     if (!useCells) { fprintf(stderr, "trust4-hip: --rcclId / --gatherDir need --barcode (without barcodes the Add pass does not shard).\n"); return EXIT_FAILURE; }
-    t4_comm *comm = nullptr;
-    if (gatherDir.empty() && (rc = t4_comm_init(ctx, shardRank, shardCount, rcclIdPath.c_str(), &comm))) die(ctx, "t4_comm_init", rc);
-    int exchangeNo = 0;
-    auto fileOf = [&](int no, int r) { return gatherDir + "/x" + std::to_string(no) + ".rank" + std::to_string(r); };
-    auto readWhole = [](const std::string &path, std::string &out) { FILE *fp = fopen(path.c_str(), "rb"); if (!fp) return false; char buf[1 << 16]; size_t n; out.clear(); while ((n = fread(buf, 1, sizeof buf, fp)) > 0) out.append(buf, n); fclose(fp); return true; };
-    // every rank contributes `mine`; everyRank: all ranks receive all contributions, else only `root` does
-    auto exchange = [&](const std::string &mine, bool everyRank, std::vector<std::string> &got) -> bool {
-      got.assign((size_t)shardCount, std::string());
-      const int no = exchangeNo++;
-      if (!gatherDir.empty()) {
-        const std::string tmp = fileOf(no, shardRank) + ".tmp";
-        FILE *fp = fopen(tmp.c_str(), "wb");
-        if (!fp || fwrite(mine.data(), 1, mine.size(), fp) != mine.size()) { if (fp) fclose(fp); return false; }
-        fclose(fp);
-        if (rename(tmp.c_str(), fileOf(no, shardRank).c_str())) return false;
-        if (!everyRank && shardRank != 0) return true;
-        for (int r = 0; r < shardCount; ++r) {
-          bool ok = false;
-          for (int tries = 0; tries < 36000 && !ok; ++tries) { ok = readWhole(fileOf(no, r), got[(size_t)r]); if (!ok) usleep(50000); }
-          if (!ok) return false;
-        }
-        return true;
-      }
-      void *all = nullptr;
-      std::vector<int64_t> sizes((size_t)shardCount);
-      const int rr = everyRank ? t4_comm_allgather_bytes(comm, mine.data(), (int64_t)mine.size(), &all, sizes.data())
-                               : t4_comm_gather_bytes(comm, mine.data(), (int64_t)mine.size(), 0, &all, sizes.data());
-      if (rr) die(ctx, everyRank ? "t4_comm_allgather_bytes" : "t4_comm_gather_bytes", rr);
-      if (all) {
-        size_t at = 0;
-        for (int r = 0; r < shardCount; ++r) { got[(size_t)r].assign((const char *)all + at, (size_t)sizes[(size_t)r]); at += (size_t)sizes[(size_t)r]; }
-        free(all);
-      }
-      return true;
-    };
     const std::string tmpRaw = outputPrefix + ".shard" + std::to_string(shardRank) + "_raw.tmp";
     writeSet(tmpRaw);
     std::string rawText;
