@@ -83,6 +83,9 @@ struct SeqReader {
     return any;
   }
   void rewind() { closeCur(); cur = 0; havePending = false; }
+  SeqReader() = default;
+  SeqReader(const SeqReader &) = delete;              // (owns an open file)
+  SeqReader &operator=(const SeqReader &) = delete;
   ~SeqReader() { closeCur(); }
   bool next() {
     for (;;) {
