@@ -297,15 +297,8 @@ def test_bench_gpus2_plumbing_dry_run(tmp_path):
 
 def test_two_rank_barcode_stage1(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import subprocess
-    import t4check
-    lib = t4check.build_emulator_lib()
-    exe = os.path.join(ROOT, "tests", "hipemu", "trust4-hip-emu")
-    src = os.path.join(ROOT, "trust4_amd", "host", "trust4_main.cpp")
-    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(lib)):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, src, "-L" + os.path.dirname(lib), "-lt4hip_emu",
-                        "-Wl,-rpath," + os.path.dirname(lib), "-lz", "-lpthread"], check=True)
-    run_stage1_two_ranks(tmp_path, exe, 120, 7, 9)
+    from test_stage1_e2e import _emulated_driver
+    run_stage1_two_ranks(tmp_path, _emulated_driver(), 120, 7, 9)
 
 
 def test_eight_rank_barcode_stage1(tmp_path):

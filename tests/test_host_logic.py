@@ -1,0 +1,50 @@
+"""Host logic of the driver next to the oracle (CPU suite): the code trust4-hip's host threads run for ProcessRead -- IsMateOverlap with
+its 16-bases-at-a-time mismatch count, IsLowComplexity, the read-through clip / merge / choice of a mate -- compiled from
+trust4_amd/host/process_read.h into tests/host_probe.cpp together with oracle/t4_oracle.c, and the FASTA / FASTQ reader's three ways
+through a file (raw, zlib, blocks that are recycled)."""
+import gzip
+import os
+import random
+import subprocess
+
+from t4libs import ROOT
+
+
+def _probe(tmp_path):
+    exe = str(tmp_path / "host_probe")
+    subprocess.run(["gcc", "-O2", "-c", os.path.join(ROOT, "oracle", "t4_oracle.c"), "-o", str(tmp_path / "t4_oracle.o")], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "host_probe.cpp"), str(tmp_path / "t4_oracle.o"), "-lz", "-lm", "-lpthread"], check=True)
+    return exe
+
+
+def test_process_read_of_the_driver_against_the_oracle(tmp_path):
+    exe = _probe(tmp_path)
+    for seed in (1, 2):
+        p = subprocess.run([exe, "25000", str(seed)], stdout=subprocess.PIPE, text=True)
+        assert p.returncode == 0 and p.stdout.startswith("ok pairs 25000"), p.stdout[-600:]
+        counts = [int(x) for x in p.stdout.split(":")[1].split(";")[0].replace("stay", "").replace("read-through", "").replace("merged", "").replace("one-mate", "").split()]
+        assert min(counts) > 300, p.stdout   # every branch of ProcessRead was taken many times
+
+
+def test_reader_raw_zlib_and_recycled_blocks(tmp_path):
+    exe = _probe(tmp_path)
+    rnd = random.Random(3)
+    # FASTQ: 40 000 records (more than two reader blocks), CRLF here and there, a comment on some headers, no newline at the end
+    recs = []
+    for i in range(40000):
+        n = rnd.randint(1, 160)
+        s = "".join(rnd.choice("ACGTN") for _ in range(n))
+        q = "".join(chr(rnd.randint(35, 73)) for _ in range(n))
+        eol = "\r\n" if i % 97 == 0 else "\n"
+        recs.append("@r%d%s%s%s%s+%s%s%s" % (i, "/1" if i % 5 == 0 else "", " extra words" if i % 7 == 0 else "", eol, s + eol, eol, q, eol))
+    fq = "".join(recs)[:-1]
+    # FASTA: multi-line sequences, blank lines, lower case and '.' (kept: printable), a record without a sequence
+    fa = "".join(">s%d desc\n%s\n\n" % (i, "\n".join("".join(rnd.choice("ACGTacgtn.") for _ in range(rnd.randint(0, 70))) for _ in range(rnd.randint(0, 4)))) for i in range(3000))
+    for name, text in (("x.fq", fq), ("y.fa", fa)):
+        plain, gz = str(tmp_path / name), str(tmp_path / (name + ".gz"))
+        with open(plain, "w", newline="") as f:
+            f.write(text)
+        with gzip.open(gz, "wt", newline="") as f:
+            f.write(text)
+        p = subprocess.run([exe, "reader", plain, gz], stdout=subprocess.PIPE, text=True)
+        assert p.returncode == 0 and p.stdout.startswith("ok reader: %d records" % (40000 if name == "x.fq" else 3000)), p.stdout[-600:]

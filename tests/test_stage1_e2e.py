@@ -261,7 +261,8 @@ def _emulated_driver():
     lib = t4check.build_emulator_lib()
     exe = os.path.join(ROOT, "tests", "hipemu", "trust4-hip-emu")
     src = os.path.join(ROOT, "trust4_amd", "host", "trust4_main.cpp")
-    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(lib)):
+    deps = [src, lib] + [os.path.join(ROOT, "trust4_amd", "host", h) for h in ("seq_reader.h", "process_read.h")] + [os.path.join(ROOT, "include", "trust4_hip.h")]
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(d) for d in deps):
         subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, src, "-L" + os.path.dirname(lib), "-lt4hip_emu",
                         "-Wl,-rpath," + os.path.dirname(lib), "-lz", "-lpthread"], check=True)
     return exe

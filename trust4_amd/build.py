@@ -9,7 +9,7 @@ SRC_HOST = os.path.join(HERE, "csrc", "t4_assembler.cpp")
 OUT = os.path.join(HERE, "libt4hip.so")
 DEPS = [SRC, SRC_HOST, os.path.join(HERE, "host", "trust4_main.cpp"), os.path.join(HERE, "host", "fastq_extractor_main.cpp"),
         os.path.join(HERE, "host", "bam_extractor_main.cpp"), os.path.join(HERE, "host", "bam_reader.h"), os.path.join(HERE, "host", "read_format.h"),
-        os.path.join(HERE, "host", "seq_reader.h"), os.path.join(HERE, "csrc", "t4_internal.h"),
+        os.path.join(HERE, "host", "seq_reader.h"), os.path.join(HERE, "host", "process_read.h"), os.path.join(HERE, "csrc", "t4_internal.h"),
         os.path.join(HERE, "csrc", "t4_kernels.h"), os.path.join(HERE, "csrc", "t4_wide.h"), os.path.join(HERE, "csrc", "t4_device.h"),
         os.path.join(os.path.dirname(HERE), "include", "trust4_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
