@@ -352,7 +352,7 @@ int hasMotif(const std::string &read, int strand) {
 // host replica, the device arenas -- 1.3 s of a 14 s barcode-mode run); the driver and the OS reclaim them. T4_FULL_TEARDOWN=1 keeps
 // the orderly destruction (leak checkers, the emulator build's tests of it).
 void leave(int status) {
-  if (getenv("T4_FULL_TEARDOWN")) return;
+  if (getenv("T4_FULL_TEARDOWN") || getenv("T4_PHASE_DUMP")) return;   // (the phase dump of a T4_PHASE_TIMING build is written by t4_destroy)
   exit(status);   // (exit, not _exit: stdio is flushed and atexit handlers run -- rocprofv3 writes its traces there)
 }
 thread_local t4_ctx *tlsErrCtx = nullptr;   // the ctx whose errors this thread reports (a cell group's own; else the caller's)
@@ -1172,7 +1172,7 @@ int main(int argc, char *argv[]) {
     // Cells are independent, so the cells of this process are dealt to GROUPS contiguous groups, each with its own t4_ctx (stream,
     // scratch), t4_cellset (arena of cell images) and host thread: while one group's query batch runs on the GPU the others stage
     // images, collect and commit (round 4; one group = the round-3 loop: collect -> stage -> query -> commit, nothing overlapped).
-    int G = getenv("T4_CELL_GROUPS") ? atoi(getenv("T4_CELL_GROUPS")) : (threadCnt >= 8 ? 4 : threadCnt >= 2 ? 2 : 1);
+    int G = getenv("T4_CELL_GROUPS") ? atoi(getenv("T4_CELL_GROUPS")) : (threadCnt >= 8 ? 4 : 2);   // (two even at -t 1: a group's thread mostly waits for its batch, like the reader threads it is not counted against -t)
     if (G < 1) G = 1;
     if (G > 16) G = 16;
     cellCtxs.assign((size_t)G, nullptr); cellSets.assign((size_t)G, nullptr);
@@ -1181,7 +1181,7 @@ int main(int argc, char *argv[]) {
       if (g > 0 && (rc = t4_init(getenv("T4_DEVICE") ? atoi(getenv("T4_DEVICE")) : 0, &cellCtxs[(size_t)g]))) { fprintf(stderr, "trust4-hip: t4_init for cell group %d failed (%d)\n", g, rc); return EXIT_FAILURE; }
       if ((rc = t4_cellset_create(cellCtxs[(size_t)g], indexKmerLength, &cellSets[(size_t)g]))) die(cellCtxs[(size_t)g], "t4_cellset_create", rc);
       t4_cellset_set_params(cellSets[(size_t)g], hitLenRequired, 10, 0.9);
-      t4_cellset_set_threads(cellSets[(size_t)g], G == 1 ? threadCnt : (threadCnt + G - 1) / G > 2 ? (threadCnt + G - 1) / G : 2);
+      t4_cellset_set_threads(cellSets[(size_t)g], (threadCnt + G - 1) / G);
     }
     cellSet = cellSets[0];
   } else {
@@ -1460,7 +1460,7 @@ int main(int argc, char *argv[]) {
     struct GroupClock { double collect = 0, prefetch = 0, commit = 0, wall = 0; int64_t batches = 0; };
     std::vector<GroupClock> clocks((size_t)G);
     const int lanesOfGroup = LANES / G > 0 ? LANES / G : 1;
-    const int commitThreads = G == 1 ? threadCnt : ((threadCnt + G - 1) / G > 2 ? (threadCnt + G - 1) / G : 2);
+    const int commitThreads = (threadCnt + G - 1) / G;
     auto runGroup = [&](int g) {
     tlsErrCtx = cellCtxs[(size_t)g];
     t4_cellset *cellSet = cellSets[(size_t)g];
