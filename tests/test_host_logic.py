@@ -29,17 +29,32 @@ def test_process_read_of_the_driver_against_the_oracle(tmp_path):
 def test_reader_raw_zlib_and_recycled_blocks(tmp_path):
     exe = _probe(tmp_path)
     rnd = random.Random(3)
+
+    def fnv(records):   # the probe's checksum over "id|comment|seq|qual-or-dash" of every record (kseq's record model, ReadFiles.hpp:180-185)
+        h = 1469598103934665603
+        for r in records:
+            for c in r.encode():
+                h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return "%016x" % h
+
     # FASTQ: 40 000 records (more than two reader blocks), CRLF here and there, a comment on some headers, no newline at the end
-    recs = []
+    recs, want_fq = [], []
     for i in range(40000):
         n = rnd.randint(1, 160)
         s = "".join(rnd.choice("ACGTN") for _ in range(n))
         q = "".join(chr(rnd.randint(35, 73)) for _ in range(n))
         eol = "\r\n" if i % 97 == 0 else "\n"
         recs.append("@r%d%s%s%s%s+%s%s%s" % (i, "/1" if i % 5 == 0 else "", " extra words" if i % 7 == 0 else "", eol, s + eol, eol, q, eol))
+        want_fq.append("r%d|%s|%s|%s" % (i, "extra words" if i % 7 == 0 else "", s, q))
     fq = "".join(recs)[:-1]
-    # FASTA: multi-line sequences, blank lines, lower case and '.' (kept: printable), a record without a sequence
-    fa = "".join(">s%d desc\n%s\n\n" % (i, "\n".join("".join(rnd.choice("ACGTacgtn.") for _ in range(rnd.randint(0, 70))) for _ in range(rnd.randint(0, 4)))) for i in range(3000))
+    # FASTA: multi-line sequences, blank lines, lower case and '.' (kept: printable), records without a sequence
+    parts, want_fa = [], []
+    for i in range(3000):
+        lines = ["".join(rnd.choice("ACGTacgtn.") for _ in range(rnd.randint(0, 70))) for _ in range(rnd.randint(0, 4))]
+        parts.append(">s%d desc\n%s\n\n" % (i, "\n".join(lines)))
+        want_fa.append("s%d|desc|%s|-" % (i, "".join(lines)))
+    fa = "".join(parts)
+    expected = {"x.fq": fnv(want_fq), "y.fa": fnv(want_fa)}
     for name, text in (("x.fq", fq), ("y.fa", fa)):
         plain, gz = str(tmp_path / name), str(tmp_path / (name + ".gz"))
         with open(plain, "w", newline="") as f:
@@ -48,3 +63,4 @@ def test_reader_raw_zlib_and_recycled_blocks(tmp_path):
             f.write(text)
         p = subprocess.run([exe, "reader", plain, gz], stdout=subprocess.PIPE, text=True)
         assert p.returncode == 0 and p.stdout.startswith("ok reader: %d records" % (40000 if name == "x.fq" else 3000)), p.stdout[-600:]
+        assert p.stdout.strip().endswith("fnv " + expected[name]), (p.stdout, expected[name])   # ... and they are the records that were written

@@ -256,7 +256,8 @@ bool compReadWithBarcode(const SortRead &a, const SortRead &b) {   // main.cpp:1
 // comparator when no two elements tie: the read list is sorted as a permutation on the threads, and only if no two neighbours of the result tie -- the order is then THE sorted order, whatever algorithm produced it --
 // is the permutation applied. With a tie (or when the caller knows the comparator is not a strict weak order for its input) the
 // list goes through std::sort itself, as before.
-template <class Less> void sortReadsOnThreads(std::vector<SortRead> &v, int threads, Less less, bool orderIsStrict = true) {
+// `spare`: a list of the same size from an earlier call (its storage takes the sorted records; it comes back holding the old storage)
+template <class Less> void sortReadsOnThreads(std::vector<SortRead> &v, int threads, Less less, bool orderIsStrict = true, std::vector<SortRead> *spare = nullptr) {
   const size_t n = v.size();
   const size_t minN = getenv("T4_SORT_MIN") ? (size_t)atoll(getenv("T4_SORT_MIN")) : 65536;   // testing aid: small inputs through the threaded path
   const size_t minChunk = minN / 64 > 8 ? minN / 64 : 8;
@@ -303,7 +304,9 @@ template <class Less> void sortReadsOnThreads(std::vector<SortRead> &v, int thre
     std::sort(v.begin(), v.end(), less);
     return;
   }
-  std::vector<SortRead> out(n);
+  std::vector<SortRead> fresh;
+  std::vector<SortRead> &out = spare ? *spare : fresh;
+  out.resize(n);   // (2 M records of 312 bytes: built once; the second sort of a run finds them in `spare`)
   parallelFor((long long)n, threads, [&](long long i) { out[(size_t)i] = std::move(v[src[i]]); });
   v.swap(out);
 }
@@ -504,6 +507,7 @@ int main(int argc, char *argv[]) {
   const size_t BLOCK = 262144;
   double secProcess = 0, secMerge = 0;
   std::vector<std::vector<SortRead>> chunkOuts;
+  std::vector<SortRead> sortSpare;   // the second list of the threaded sorts
   // T4_GPU_MATEOVERLAP=1 (opt-in this round): the two AlignAlgo::IsMateOverlap tests of every pair of a block come from
   // t4_mate_overlap (one pair per wavefront) instead of the host threads; the merge itself stays on the host.
   const bool gpuMate = getenv("T4_GPU_MATEOVERLAP") && atoi(getenv("T4_GPU_MATEOVERLAP")) != 0;
@@ -927,7 +931,8 @@ int main(int argc, char *argv[]) {
     if (sortedReads[i].id == sortedReads[i + 1].id) { sortedReads[i].mateIdx = i + 1; sortedReads[i + 1].mateIdx = i; ++i; }
   {
     const auto ts0 = std::chrono::steady_clock::now();
-    sortReadsOnThreads(sortedReads, threadCnt, [](const SortRead &a, const SortRead &b) { return a < b; });
+    sortReadsOnThreads(sortedReads, threadCnt, [](const SortRead &a, const SortRead &b) { return a < b; }, true, &sortSpare);
+    if (!hasBarcode) std::vector<SortRead>().swap(sortSpare);   // (only barcode mode sorts again)
     if (getenv("T4_TIMING")) PrintLog("timing: read list sorted in %.2f s on %d threads", std::chrono::duration<double>(std::chrono::steady_clock::now() - ts0).count(), threadCnt);
   }
   mark("sorted");
@@ -1031,7 +1036,8 @@ int main(int argc, char *argv[]) {
     {   // compReadWithBarcode (main.cpp:128-136) is not a strict weak order once a read without barcode stands beside barcoded ones
       bool allBarcoded = true;
       for (const SortRead &r : sortedReads) if (r.barcode == -1) { allBarcoded = false; break; }
-      sortReadsOnThreads(sortedReads, threadCnt, compReadWithBarcode, allBarcoded);
+      sortReadsOnThreads(sortedReads, threadCnt, compReadWithBarcode, allBarcoded, &sortSpare);
+      std::vector<SortRead>().swap(sortSpare);
     }
     PrintLog("Get barcode-wise kmer count.");
     std::vector<std::pair<int, int>> groups;
