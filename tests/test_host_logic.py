@@ -10,10 +10,10 @@ import subprocess
 from t4libs import ROOT
 
 
-def _probe(tmp_path):
-    exe = str(tmp_path / "host_probe")
+def _probe(tmp_path, flags=(), name="host_probe"):
+    exe = str(tmp_path / name)
     subprocess.run(["gcc", "-O2", "-c", os.path.join(ROOT, "oracle", "t4_oracle.c"), "-o", str(tmp_path / "t4_oracle.o")], check=True)
-    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "host_probe.cpp"), str(tmp_path / "t4_oracle.o"), "-lz", "-lm", "-lpthread"], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17"] + list(flags) + ["-o", exe, os.path.join(ROOT, "tests", "host_probe.cpp"), str(tmp_path / "t4_oracle.o"), "-lz", "-lm", "-lpthread"], check=True)
     return exe
 
 
@@ -24,6 +24,13 @@ def test_process_read_of_the_driver_against_the_oracle(tmp_path):
         assert p.returncode == 0 and p.stdout.startswith("ok pairs 25000"), p.stdout[-600:]
         counts = [int(x) for x in p.stdout.split(":")[1].split(";")[0].replace("stay", "").replace("read-through", "").replace("merged", "").replace("one-mate", "").split()]
         assert min(counts) > 300, p.stdout   # every branch of ProcessRead was taken many times
+
+
+def test_process_read_without_sse2(tmp_path):
+    """the portable path of IsMateOverlap's mismatch count (a host whose compiler does not define __SSE2__)"""
+    exe = _probe(tmp_path, flags=["-U__SSE2__"], name="host_probe_portable")
+    p = subprocess.run([exe, "12000", "7"], stdout=subprocess.PIPE, text=True)
+    assert p.returncode == 0 and p.stdout.startswith("ok pairs 12000"), p.stdout[-600:]
 
 
 def test_reader_raw_zlib_and_recycled_blocks(tmp_path):

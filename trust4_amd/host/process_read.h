@@ -3,7 +3,9 @@
 // them, and the read record they work on. A header of its own so that tests/host_probe.cpp can put exactly this code next to the
 // oracle's restatement (tests/test_host_logic.py); trust4_main.cpp is its only product user.
 #pragma once
+#if defined(__SSE2__)
 #include <emmintrin.h>
+#endif
 #include <string.h>
 
 #include <algorithm>
@@ -40,11 +42,19 @@ inline int isMateOverlap(const std::string &fr, const std::string &sr, int minOv
     const int range = flen - j < slen ? flen - j : slen, allowed = (flen - j) - need;
     int mism = 0;
     const char *a = fr.data() + j, *b = sr.data();
-    for (k = 0; k + 16 <= range; k += 16) {
+    k = 0;
+#if defined(__SSE2__)
+    for (; k + 16 <= range; k += 16) {
       const __m128i va = _mm_loadu_si128((const __m128i *)(a + k)), vb = _mm_loadu_si128((const __m128i *)(b + k));
       mism += 16 - __builtin_popcount((unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(va, vb)));
       if (mism > allowed) { ok = false; break; }
     }
+#else   // (a host without SSE2: eight bases at a time)
+    for (; k + 8 <= range; k += 8) {
+      for (int t = 0; t < 8; ++t) mism += a[k + t] != b[k + t];
+      if (mism > allowed) { ok = false; break; }
+    }
+#endif
     if (ok) {
       for (; k < range; ++k) if (a[k] != b[k]) ++mism;
       if (mism > allowed) ok = false;

@@ -17,7 +17,6 @@
 // Limits of this round: no -c/--debug-ns; without barcodes `_final.out` is written as a
 // copy of `_raw.out` (the reference does the same under --skipMateExtension and always with barcodes; its mate-graph
 // extension tail is out of scope).
-#include <emmintrin.h>
 #include <fcntl.h>
 #include <sys/wait.h>
 #include <spawn.h>
