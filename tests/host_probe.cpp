@@ -51,8 +51,39 @@ static int readerMode(int argc, char **argv) {
   return 0;
 }
 
+// `host_probe numbering N SEED`: StrNumbering (packed 61-bit keys in a flat table, anything else through a map, one counter) against
+// a std::map numbered in order of first appearance, as the reference numbers barcodes and UMIs (main.cpp:812-820, 831-842).
+#include <map>
+static int numberingMode(long n, unsigned seed) {
+  std::mt19937 rng(seed);
+  StrNumbering sn;
+  std::map<std::string, int> ref;
+  long packed = 0, other = 0, fresh = 0;
+  for (long i = 0; i < n; ++i) {
+    std::string s;
+    const int kind = (int)(rng() % 10);
+    const int len = kind == 0 ? 21 + (int)(rng() % 12) : kind == 1 ? 0 : 1 + (int)(rng() % 20);     // longer than 20 letters; empty; packable lengths
+    const int alphabet = (int)(rng() % 3) == 0 ? 2 : 4;                                              // (small alphabets: many repeats of earlier strings)
+    for (int j = 0; j < len; ++j) s += "ACGTN"[rng() % (size_t)alphabet];
+    if (kind == 2) s[rng() % s.size()] = "acgtX-1"[rng() % 7];                                       // a letter outside ACGTN
+    if (kind == 3) s = "missing_barcode";
+    uint64_t k;
+    (StrNumbering::pack(s, k) ? packed : other)++;
+    bool isNew = false;
+    const int got = sn.number(s, isNew);
+    auto it = ref.find(s);
+    const bool wantNew = it == ref.end();
+    const int want = wantNew ? (int)ref.size() : it->second;
+    if (wantNew) { ref[s] = want; ++fresh; }
+    if (got != want || isNew != wantNew) { printf("numbering differs at %ld: '%s' -> %d (new %d), expected %d (new %d)\n", i, s.c_str(), got, (int)isNew, want, (int)wantNew); return 1; }
+  }
+  printf("ok numbering: %ld strings (%ld packed, %ld through the map), %ld distinct\n", n, packed, other, fresh);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   if (argc > 2 && !strcmp(argv[1], "reader")) return readerMode(argc, argv);
+  if (argc > 3 && !strcmp(argv[1], "numbering")) return numberingMode(atol(argv[2]), (unsigned)atol(argv[3]));
   const long pairs = argc > 1 ? atol(argv[1]) : 20000;
   std::mt19937 rng(argc > 2 ? (unsigned)atol(argv[2]) : 1u);
   const char *ac = "ACGT";

@@ -33,6 +33,15 @@ def test_process_read_without_sse2(tmp_path):
     assert p.returncode == 0 and p.stdout.startswith("ok pairs 12000"), p.stdout[-600:]
 
 
+def test_barcode_and_umi_numbering(tmp_path):
+    """order of first appearance, packed keys and the map sharing one counter; 600 k strings force the flat table to grow several times"""
+    exe = _probe(tmp_path)
+    p = subprocess.run([exe, "numbering", "600000", "11"], stdout=subprocess.PIPE, text=True)
+    assert p.returncode == 0 and p.stdout.startswith("ok numbering: 600000 strings"), p.stdout[-400:]
+    distinct = int(p.stdout.split(",")[-1].split()[0])
+    assert distinct > 150000   # (the table of 65 536 slots was outgrown)
+
+
 def test_reader_raw_zlib_and_recycled_blocks(tmp_path):
     exe = _probe(tmp_path)
     rnd = random.Random(3)

@@ -198,53 +198,6 @@ struct KmerCounter {
   }
 };
 
-// Strings -> dense ints in order of first appearance: the numbering of barcodes and UMIs (main.cpp:812-820, 831-842; the reference
-// keeps a std::map<std::string, int> each). It is the serial work per record of the input loop, so strings of at most 20 letters
-// over ACGTN -- every barcode and UMI of the 10x / Drop-seq kind -- are packed into 61 bits and numbered in a flat open-addressing
-// table; anything else goes through a std::unordered_map. Both share one counter.
-struct StrNumbering {
-  std::vector<uint64_t> keys;
-  std::vector<int> vals;
-  size_t used = 0;
-  std::unordered_map<std::string, int> other;
-  int count = 0;
-  static bool pack(const std::string &s, uint64_t &k) {
-    if (s.size() > 20) return false;
-    k = 1;   // (the leading 1 tells lengths apart; 0 is the empty slot)
-    for (char c : s) {
-      uint64_t v;
-      switch (c) { case 'A': v = 1; break; case 'C': v = 2; break; case 'G': v = 3; break; case 'T': v = 4; break; case 'N': v = 5; break; default: return false; }
-      k = (k << 3) | v;
-    }
-    return true;
-  }
-  static uint64_t mix(uint64_t z) { z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31); }
-  void grow() {
-    std::vector<uint64_t> ok; std::vector<int> ov;
-    ok.swap(keys); ov.swap(vals);
-    keys.assign(ok.empty() ? (size_t)1 << 16 : ok.size() * 2, 0); vals.assign(keys.size(), 0);
-    const size_t mask = keys.size() - 1;
-    for (size_t i = 0; i < ok.size(); ++i) if (ok[i]) { size_t h = (size_t)mix(ok[i]) & mask; while (keys[h]) h = (h + 1) & mask; keys[h] = ok[i]; vals[h] = ov[i]; }
-  }
-  int number(const std::string &s, bool &isNew) {
-    uint64_t k;
-    isNew = false;
-    if (!pack(s, k)) {
-      auto it = other.find(s);
-      if (it != other.end()) return it->second;
-      isNew = true;
-      other.emplace(s, count);
-      return count++;
-    }
-    if ((used + 1) * 2 > keys.size()) grow();
-    const size_t mask = keys.size() - 1;
-    size_t h = (size_t)mix(k) & mask;
-    while (keys[h]) { if (keys[h] == k) return vals[h]; h = (h + 1) & mask; }
-    keys[h] = k; vals[h] = count; ++used; isNew = true;
-    return count++;
-  }
-};
-
 bool compReadWithBarcode(const SortRead &a, const SortRead &b) {   // main.cpp:128-136
   if (a.barcode != -1 && a.barcode != b.barcode) return a.barcode < b.barcode;
   if (a.barcode != -1 && b.barcode != -1 && a.barcodeMinCnt != b.barcodeMinCnt) return a.barcodeMinCnt > b.barcodeMinCnt;
