@@ -439,19 +439,23 @@ def sharded_cells(args, rank, local_rank, world, dist):
     argv = ["-f", fa, "-1", pre + "_1.fq", "-2", pre + "_2.fq", "--barcode", pre + "_bc.fa", "--UMI", pre + "_umi.fa"]
     threads = max(1, min(args.cells_threads, host_cores() // world))
     out = os.path.join(tmp, "sharded")
-    id_file = out + ".rcclid"
-    gdir = os.path.join(tmp, "gather")
+    step_no = [0]
 
     def one_step(timed):
-        if rank == 0 and os.path.exists(id_file):
-            os.remove(id_file)
-        if rank == 0 and dry:
-            shutil.rmtree(gdir, ignore_errors=True)
-            os.makedirs(gdir)
+        # a fresh directory per step for the communicator id, the status files and (should RCCL not come up on every rank: the engine's
+        # automatic fall-back, trust4_main.cpp commUp) the files of the exchange: nothing of an earlier step can be taken for this one's
+        xdir = os.path.join(tmp, "xfer%d" % step_no[0])
+        step_no[0] += 1
+        if rank == 0:
+            shutil.rmtree(xdir, ignore_errors=True)
+            os.makedirs(xdir)
         sync()
         dist.barrier()
-        env = dict(os.environ, T4_DEVICE="0" if dry else str(local_rank), T4_STATS_JSON=os.path.join(tmp, "stats_rank%d.json" % rank))
-        transport = ["--gatherDir", gdir] if dry else ["--rcclId", id_file]
+        stats = os.path.join(tmp, "stats_rank%d.json" % rank)
+        env = dict(os.environ, T4_DEVICE="0" if dry else str(local_rank), T4_STATS_JSON=stats)
+        # (the CPU dry run takes the same command line: the emulated engine has no RCCL, so its t4_comm_init fails on every rank and the
+        # run goes through the fall-back -- which is what the dry run is there to cover)
+        transport = ["--rcclId", os.path.join(xdir, "rcclid")]
         t0 = time.perf_counter()
         p = subprocess.run([driver, "-t", str(threads)] + argv + ["-o", out, "--cellShard", "%d/%d" % (rank, world)] + transport, env=env, stderr=subprocess.PIPE, text=True)
         if p.returncode:
@@ -495,6 +499,10 @@ def sharded_cells(args, rank, local_rank, world, dist):
                            "pairs": pairs, "cells": cells, "host_threads_per_rank": threads,
                            "per_rank_s": {"replicated_phases": [float(x[0]) for x in parts], "own_cells_before_the_add_pass": [float(x[2]) for x in parts],
                                           "add_pass_of_its_cells": [float(x[1]) for x in parts]}}}
+        try:   # "rccl", or "files (fallback from rccl: <first rank's reason>)" when the communicator did not come up on every rank
+            line["config"]["transport"] = open(os.path.join(tmp, "stats_rank0.json.transport")).read().strip()
+        except OSError:
+            line["config"]["transport"] = None
         md5s = {x: file_md5(out + x) for x in OUT_SUFFIXES}
         one = os.path.join(tmp, "one_rank")
         t1 = time.perf_counter()

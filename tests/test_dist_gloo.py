@@ -268,7 +268,9 @@ def test_engine_merge_four_ranks_gpu(tmp_path):
 
 def test_bench_gpus2_plumbing_dry_run(tmp_path):
     """`bench.py --gpus 2` as the driver launches it (one process per rank, RANK / WORLD_SIZE / MASTER_* in the environment), without
-    GPUs: T4_BENCH_CPU_DRYRUN swaps RCCL for gloo, trust4-hip for the emulated driver and --rcclId for the file transport. Everything
+    GPUs: T4_BENCH_CPU_DRYRUN swaps RCCL for gloo and trust4-hip for the emulated driver; the command line keeps --rcclId, and since the
+    emulated engine has no RCCL its t4_comm_init fails on every rank: the run takes the engine's automatic fall-back to the file
+    transport (every rank publishes how its communicator came up, all switch together), which the line must report. Everything
     else is the code an 8-GPU node runs: the sample, the sharded steps, max over ranks, the per-rank phase report, the one-rank run and
     the md5 comparison of its files with the sharded run's."""
     import json
@@ -290,6 +292,7 @@ def test_bench_gpus2_plumbing_dry_run(tmp_path):
     assert line["n_gpus"] == 2 and line["steps"] == 1 and line["warmup"] == 1 and line["scaling"] == "strong" and line["value"] > 0
     assert line["config"]["pairs"] == 120 and line["config"]["cells"] == 8
     assert line["one_rank"]["identical"] is True
+    assert line["config"]["transport"].startswith("files (fallback from rccl: rank 0: fail"), line["config"]["transport"]
     per = line["config"]["per_rank_s"]
     assert len(per["replicated_phases"]) == 2 and min(per["replicated_phases"]) > 0
     assert len(per["own_cells_before_the_add_pass"]) == 2 and min(per["own_cells_before_the_add_pass"]) > 0   # (the early shard: a mark of its own in the stats)

@@ -1585,6 +1585,11 @@ int aqBegin(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const 
   // one big contig set, plain passes: a read beyond the LDS tier goes to the wide query (t4_wide.h) instead of one workgroup's
   // global scratch -- decided on the device, inside the one launch every read starts in (T4_WIDE_OFF: the global-scratch tier as before)
   q.wide = !views && !smallFirst && !skip_repeats && base.hasNovel == 2 && !getenv("T4_WIDE_OFF");   // (a read with a barcode stays on the old path: wideWant in processRead)
+  if (q.wide && onlySeq) {   // a round of restricted re-queries only defers nothing: the wide query's five grids stay unlaunched
+    bool anyWhole = false;
+    for (int i = 0; i < n && !anyWhole; ++i) anyWhole = onlySeq[i] < 0;
+    if (!anyWhole) q.wide = false;
+  }
   // work lists: the reads of the first LDS launch, then those that go to the global-scratch tier at once
   const bool forceGlobal = getenv("T4_AQ_FORCE_GLOBAL") != nullptr;   // testing aid: every read on the global-scratch tier
   if (forceGlobal && !smallFirst) { q.allGlobal.assign((size_t)n, 1); q.tierHint = tierHint = q.allGlobal.data(); q.wide = false; }
@@ -2401,10 +2406,10 @@ struct t4_comm {
 // The wait of a collective, bounded: a rank that died before it leaves the others in the kernel RCCL enqueued for ever.
 // Polls the stream; an asynchronous RCCL error or T4_COMM_TIMEOUT_S seconds (default 3600: ranks of a sharded sample may finish far
 // apart) abort the communicator and come back as an error instead of a hang.
-static int commWait(t4_comm *cm, const char *what) {
+static int commWait(t4_comm *cm, const char *what, double limitS = 0) {
   t4_ctx *c = cm->ctx;
   const char *ev = getenv("T4_COMM_TIMEOUT_S");
-  const double limit = ev && atof(ev) > 0 ? atof(ev) : 3600.0;
+  const double limit = limitS > 0 ? limitS : (ev && atof(ev) > 0 ? atof(ev) : 3600.0);
   const auto t0 = std::chrono::steady_clock::now();
   for (long long spin = 0;; ++spin) {
     const hipError_t q = hipStreamQuery(c->stream);
@@ -2421,6 +2426,35 @@ static int commWait(t4_comm *cm, const char *what) {
     if (spin < 2000) std::this_thread::yield(); else usleep(200);
   }
 }
+#endif
+
+#ifdef __HIPCC__
+namespace {
+// device / host buffers of one collective: released on every path out of it (the error returns leaked them)
+struct CommBufs {
+  std::vector<void *> dev; void *host = nullptr;
+  ~CommBufs() { for (void *p : dev) if (p) (void)hipFree(p); if (host) free(host); }
+  template <class T> hipError_t devAlloc(T **p, size_t bytes) { *p = nullptr; const hipError_t e = hipMalloc((void **)p, bytes ? bytes : 8); if (e == hipSuccess) dev.push_back(*p); return e; }
+  void *releaseHost() { void *h = host; host = nullptr; return h; }
+};
+// lengths of every rank's contribution: one 8-byte ncclAllGather. The bounded wait comes BEFORE any device-to-host copy is queued: a
+// copy into pageable memory runs synchronously behind the RCCL kernel, and with a dead peer the host would hang inside hipMemcpyAsync
+// and never reach commWait.
+int commLengths(t4_comm *cm, int64_t n, std::vector<unsigned long long> &lens) {
+  t4_ctx *c = cm->ctx;
+  const int R = cm->nranks;
+  CommBufs bufs;
+  unsigned long long *dLen = nullptr;
+  HIPCHK(c, bufs.devAlloc(&dLen, sizeof(unsigned long long) * (size_t)(R + 1)));
+  const unsigned long long myLen = (unsigned long long)n;
+  HIPCHK(c, hipMemcpy(dLen + R, &myLen, sizeof myLen, hipMemcpyHostToDevice));
+  if (cm->rccl->allGather(dLen + R, dLen, 1, ncclUint64, cm->comm, c->stream) != ncclSuccess) return fail(c, T4_ERR_HIP, "ncclAllGather (lengths) failed");
+  if (int wr = commWait(cm, "the lengths")) return wr;
+  lens.resize((size_t)R);
+  HIPCHK(c, hipMemcpy(lens.data(), dLen, sizeof(unsigned long long) * (size_t)R, hipMemcpyDeviceToHost));
+  return T4_OK;
+}
+}  // namespace
 #endif
 
 extern "C" {
@@ -2452,6 +2486,24 @@ int t4_comm_init(t4_ctx *c, int rank, int nranks, const char *id_path, t4_comm *
   t4_comm *cm = new t4_comm();
   cm->ctx = c; cm->rank = rank; cm->nranks = nranks; cm->rccl = rccl;
   if (rccl->commInitRank(&cm->comm, nranks, id, rank) != ncclSuccess) { delete cm; return fail(c, T4_ERR_HIP, "ncclCommInitRank(%d of %d) failed", rank, nranks); }
+  // Self-check before anything depends on the communicator (RCCL had only ever run with one rank): every rank
+  // contributes its number, everybody must receive 0..N-1 in order, within T4_COMM_INIT_TIMEOUT_S (default 120 s).
+  {
+    CommBufs bufs;
+    int *d = nullptr;
+    bool ok = bufs.devAlloc(&d, sizeof(int) * (size_t)(nranks + 1)) == hipSuccess && hipMemcpy(d + nranks, &rank, sizeof rank, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && rccl->allGather(d + nranks, d, 1, ncclInt32, cm->comm, c->stream) == ncclSuccess;
+    const char *lim = getenv("T4_COMM_INIT_TIMEOUT_S");
+    ok = ok && commWait(cm, "the self-check", lim && atof(lim) > 0 ? atof(lim) : 120.0) == T4_OK;
+    std::vector<int> got((size_t)nranks, -1);
+    ok = ok && hipMemcpy(got.data(), d, sizeof(int) * (size_t)nranks, hipMemcpyDeviceToHost) == hipSuccess;
+    for (int r = 0; ok && r < nranks; ++r) ok = got[(size_t)r] == r;
+    if (!ok) {
+      if (cm->comm) (void)rccl->commAbort(cm->comm);
+      delete cm;
+      return fail(c, T4_ERR_HIP, "t4_comm: the self-check of the new communicator failed on rank %d of %d (a 1-int all-gather did not return the rank numbers)", rank, nranks);
+    }
+  }
   *out = cm;
   return T4_OK;
 #else
@@ -2459,6 +2511,7 @@ int t4_comm_init(t4_ctx *c, int rank, int nranks, const char *id_path, t4_comm *
   return fail(c, T4_ERR_UNSUPPORTED, "t4_comm needs the hipcc build (RCCL)");
 #endif
 }
+
 
 int t4_comm_allgather_bytes(t4_comm *cm, const void *mine, int64_t n, void **all, int64_t *sizes) {
   if (!cm || n < 0 || (n > 0 && !mine) || !all || !sizes) return T4_ERR_ARG;
@@ -2468,32 +2521,26 @@ int t4_comm_allgather_bytes(t4_comm *cm, const void *mine, int64_t n, void **all
   (void)hipSetDevice(c->device);
   const int R = cm->nranks;
   // lengths first (8 bytes per rank), then the payloads padded to the longest: two ncclAllGather calls on the ctx's stream
-  unsigned long long *dLen = nullptr;
-  HIPCHK(c, hipMalloc(&dLen, sizeof(unsigned long long) * (size_t)(R + 1)));
-  const unsigned long long myLen = (unsigned long long)n;
-  HIPCHK(c, hipMemcpyAsync(dLen + R, &myLen, sizeof myLen, hipMemcpyHostToDevice, c->stream));
-  if (cm->rccl->allGather(dLen + R, dLen, 1, ncclUint64, cm->comm, c->stream) != ncclSuccess) { (void)hipFree(dLen); return fail(c, T4_ERR_HIP, "ncclAllGather (lengths) failed"); }
-  std::vector<unsigned long long> lens((size_t)R);
-  HIPCHK(c, hipMemcpyAsync(lens.data(), dLen, sizeof(unsigned long long) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
-  if (int wr = commWait(cm, "the lengths")) return wr;
-  (void)hipFree(dLen);
+  std::vector<unsigned long long> lens;
+  if (int r = commLengths(cm, n, lens)) return r;
   size_t cap = 8, total = 0;
   for (int r = 0; r < R; ++r) { sizes[r] = (int64_t)lens[(size_t)r]; total += (size_t)lens[(size_t)r]; if ((size_t)lens[(size_t)r] > cap) cap = (size_t)lens[(size_t)r]; }
   cap = (cap + 7) & ~(size_t)7;
+  CommBufs bufs;
   unsigned char *dSend = nullptr, *dRecv = nullptr;
-  HIPCHK(c, hipMalloc(&dSend, cap));
-  if (hipMalloc(&dRecv, cap * (size_t)R) != hipSuccess) { (void)hipFree(dSend); return fail(c, T4_ERR_HIP, "out of device memory for the gather"); }
-  if (n > 0) HIPCHK(c, hipMemcpyAsync(dSend, mine, (size_t)n, hipMemcpyHostToDevice, c->stream));
-  if (cm->rccl->allGather(dSend, dRecv, cap, ncclUint8, cm->comm, c->stream) != ncclSuccess) { (void)hipFree(dSend); (void)hipFree(dRecv); return fail(c, T4_ERR_HIP, "ncclAllGather (payload) failed"); }
-  unsigned char *host = (unsigned char *)malloc(total ? total : 1);
+  HIPCHK(c, bufs.devAlloc(&dSend, cap));
+  if (bufs.devAlloc(&dRecv, cap * (size_t)R) != hipSuccess) return fail(c, T4_ERR_HIP, "out of device memory for the gather");
+  if (n > 0) HIPCHK(c, hipMemcpy(dSend, mine, (size_t)n, hipMemcpyHostToDevice));
+  if (cm->rccl->allGather(dSend, dRecv, cap, ncclUint8, cm->comm, c->stream) != ncclSuccess) return fail(c, T4_ERR_HIP, "ncclAllGather (payload) failed");
+  if (int wr = commWait(cm, "the all-gather")) return wr;   // (before the copies below: see commLengths)
+  bufs.host = malloc(total ? total : 1);
+  if (!bufs.host) return fail(c, T4_ERR_HIP, "out of host memory for the gather");
   size_t at = 0;
   for (int r = 0; r < R; ++r) {
-    if (lens[(size_t)r]) HIPCHK(c, hipMemcpyAsync(host + at, dRecv + cap * (size_t)r, (size_t)lens[(size_t)r], hipMemcpyDeviceToHost, c->stream));
+    if (lens[(size_t)r]) HIPCHK(c, hipMemcpy((unsigned char *)bufs.host + at, dRecv + cap * (size_t)r, (size_t)lens[(size_t)r], hipMemcpyDeviceToHost));
     at += (size_t)lens[(size_t)r];
   }
-  if (int wr = commWait(cm, "the all-gather")) return wr;
-  (void)hipFree(dSend); (void)hipFree(dRecv);
-  *all = host;
+  *all = bufs.releaseHost();
   return T4_OK;
 #else
   return T4_ERR_UNSUPPORTED;
@@ -2510,21 +2557,15 @@ int t4_comm_gather_bytes(t4_comm *cm, const void *mine, int64_t n, int root, voi
   if (!cm->comm) return fail(c, T4_ERR_ARG, "t4_comm: the communicator was aborted");
   (void)hipSetDevice(c->device);
   const int R = cm->nranks;
-  unsigned long long *dLen = nullptr;
-  HIPCHK(c, hipMalloc(&dLen, sizeof(unsigned long long) * (size_t)(R + 1)));
-  const unsigned long long myLen = (unsigned long long)n;
-  HIPCHK(c, hipMemcpyAsync(dLen + R, &myLen, sizeof myLen, hipMemcpyHostToDevice, c->stream));
-  if (cm->rccl->allGather(dLen + R, dLen, 1, ncclUint64, cm->comm, c->stream) != ncclSuccess) { (void)hipFree(dLen); return fail(c, T4_ERR_HIP, "ncclAllGather (lengths) failed"); }
-  std::vector<unsigned long long> lens((size_t)R);
-  HIPCHK(c, hipMemcpyAsync(lens.data(), dLen, sizeof(unsigned long long) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
-  if (int wr = commWait(cm, "the lengths")) return wr;
-  (void)hipFree(dLen);
+  std::vector<unsigned long long> lens;
+  if (int r = commLengths(cm, n, lens)) return r;
   size_t total = 0;
   for (int r = 0; r < R; ++r) { sizes[r] = (int64_t)lens[(size_t)r]; total += (size_t)lens[(size_t)r]; }
+  CommBufs bufs;
   unsigned char *dSend = nullptr, *dRecv = nullptr;
-  HIPCHK(c, hipMalloc(&dSend, n > 0 ? (size_t)n : 8));
-  if (n > 0) HIPCHK(c, hipMemcpyAsync(dSend, mine, (size_t)n, hipMemcpyHostToDevice, c->stream));
-  if (cm->rank == root && hipMalloc(&dRecv, total ? total : 8) != hipSuccess) { (void)hipFree(dSend); return fail(c, T4_ERR_HIP, "out of device memory for the gather"); }
+  HIPCHK(c, bufs.devAlloc(&dSend, (size_t)n));
+  if (n > 0) HIPCHK(c, hipMemcpy(dSend, mine, (size_t)n, hipMemcpyHostToDevice));
+  if (cm->rank == root && bufs.devAlloc(&dRecv, total) != hipSuccess) return fail(c, T4_ERR_HIP, "out of device memory for the gather");
   bool ok = cm->rccl->groupStart() == ncclSuccess;
   if (ok && n > 0) ok = cm->rccl->send(dSend, (size_t)n, ncclUint8, root, cm->comm, c->stream) == ncclSuccess;
   if (ok && cm->rank == root) {
@@ -2532,16 +2573,14 @@ int t4_comm_gather_bytes(t4_comm *cm, const void *mine, int64_t n, int root, voi
     for (int r = 0; r < R && ok; ++r) { if (lens[(size_t)r]) ok = cm->rccl->recv(dRecv + at, (size_t)lens[(size_t)r], ncclUint8, r, cm->comm, c->stream) == ncclSuccess; at += (size_t)lens[(size_t)r]; }
   }
   ok = (cm->rccl->groupEnd() == ncclSuccess) && ok;
-  if (!ok) { (void)hipFree(dSend); if (dRecv) (void)hipFree(dRecv); return fail(c, T4_ERR_HIP, "ncclSend / ncclRecv (gather) failed"); }
-  unsigned char *host = nullptr;
+  if (!ok) return fail(c, T4_ERR_HIP, "ncclSend / ncclRecv (gather) failed");
+  if (int wr = commWait(cm, "the gather")) return wr;   // (before the copy below: see commLengths)
   if (cm->rank == root) {
-    host = (unsigned char *)malloc(total ? total : 1);
-    if (total) HIPCHK(c, hipMemcpyAsync(host, dRecv, total, hipMemcpyDeviceToHost, c->stream));
+    bufs.host = malloc(total ? total : 1);
+    if (!bufs.host) return fail(c, T4_ERR_HIP, "out of host memory for the gather");
+    if (total) HIPCHK(c, hipMemcpy(bufs.host, dRecv, total, hipMemcpyDeviceToHost));
   }
-  if (int wr = commWait(cm, "the gather")) return wr;
-  (void)hipFree(dSend);
-  if (dRecv) (void)hipFree(dRecv);
-  *all = host;
+  *all = bufs.releaseHost();
   return T4_OK;
 #else
   return T4_ERR_UNSUPPORTED;

@@ -611,13 +611,15 @@ struct t4_assembler : IndexListener {
   // testing / development aids, read from the environment ONCE per builder (none changes a result; DESIGN 7b lists them)
   struct Knobs {
     bool verifyWindow = false, noStableStats = false;
-    int lanes = 1, queryAhead = 0, minBatch = 4, harvestDelay = 0;
+    int lanes = 1, queryAhead = 0, minBatch = 4, harvestDelay = 0, lightAhead = -1, heavyBatch = 0; double aheadMult = 3.0;
     FILE *roundLog = nullptr;
     Knobs() {
       auto num = [](const char *n, int d) { const char *e = getenv(n); return e ? atoi(e) : d; };
       verifyWindow = getenv("T4_VERIFY_WINDOW") != nullptr;     // every served window entry is queried again and compared
       noStableStats = getenv("T4_NO_STABLE_STATS") != nullptr;  // A/B aid: the budget rule for every entry
       lanes = num("T4_LIVE_LANES", 1); queryAhead = num("T4_QUERY_AHEAD", 0); minBatch = num("T4_LIVE_MIN_BATCH", 4); harvestDelay = num("T4_LIVE_HARVEST_DELAY", 0);
+      heavyBatch = num("T4_HEAVY_BATCH", 0); if (getenv("T4_AHEAD_MULT")) aheadMult = atof(getenv("T4_AHEAD_MULT"));
+      lightAhead = num("T4_LIGHT_AHEAD", -1);   // -1: every round carries every entry without a result (within `ahead`)
       if (getenv("T4_ROUND_LOG")) roundLog = fopen(getenv("T4_ROUND_LOG"), "w");   // one line per launch: reads, kernel ms, per read us / overlaps / tier / killed in flight
     }
     ~Knobs() { if (roundLog) fclose(roundLog); }
@@ -717,7 +719,7 @@ struct t4_assembler : IndexListener {
   std::vector<Lane> lanes;
   std::deque<std::unique_ptr<DeltaRec>> deltaLog;
   int64_t deltaVersion = 0;
-  int64_t launches = 0, launchesUrgent = 0, headWaits = 0, killedInFlight = 0;
+  int64_t launches = 0, launchesUrgent = 0, headWaits = 0, killedInFlight = 0, lightRounds = 0;
   double secHeadWait = 0, secLaunch = 0, secHarvest = 0;
   int ensureLanes();
   int flushLive(Lane **out);
@@ -1969,7 +1971,7 @@ int t4_assembler::pumpLive(bool needHead, int repetitive) {
   const int fixedAhead = knobs.queryAhead, minBatch = knobs.minBatch;
   // Entries far behind the head rarely survive until they are consumed: (re-)query only as far ahead as a few times what a launch
   // for the head has recently served (every read queried adds to the latency of the launch: it ends with its slowest read)
-  const size_t ahead = fixedAhead > 0 ? (size_t)fixedAhead : (lanes.size() > 1 ? 24 : (size_t)(3.0 * runEma) + 12);
+  const size_t ahead = fixedAhead > 0 ? (size_t)fixedAhead : (lanes.size() > 1 ? 24 : (size_t)(knobs.aheadMult * runEma) + 12);
   for (;;) {
     // T4_LIVE_HARVEST_DELAY=n (testing aid): a finished launch is only noticed n calls later, so that commits pile up against queries in flight
     const int harvestDelay = knobs.harvestDelay;
@@ -2005,7 +2007,18 @@ int t4_assembler::pumpLive(bool needHead, int repetitive) {
       }
       // the head's launch carries the entries of its own weight class; the other class goes beside it when a lane is free
       std::vector<int> &mine = head.partial ? light : heavy, &other = head.partial ? heavy : light;
-      if (lanes.size() == 1) { mine.insert(mine.end(), other.begin(), other.end()); other.clear(); }   // one launch: the heavy ones run beside the others on the ctx's second stream
+      if (lanes.size() == 1) {   // one launch: the heavy ones run beside the others on the ctx's second stream
+        // A round lasts as long as its slowest read. When the head only waits for a restricted re-query (tens of microseconds), whole
+        // queries of entries further back than `lightAhead` places stay out of its round: they go with the next round whose head needs
+        // a whole query itself (or when they come within reach of the head).
+        if (head.partial && knobs.lightAhead >= 0 && (knobs.heavyBatch <= 0 || (int)other.size() < knobs.heavyBatch)) {
+          std::vector<int> near;
+          for (size_t i = 0; i < order.size() && i < ahead && (int)i <= knobs.lightAhead; ++i) { Cached &c = *pool[order[i]]; if (!c.valid && !c.inflight && !c.partial) near.push_back(order[i]); }
+          other.swap(near);
+          ++lightRounds;
+        }
+        mine.insert(mine.end(), other.begin(), other.end()); other.clear();
+      }
       {
         const double served = (double)(cacheHits - hitsAtLastRound);
         hitsAtLastRound = cacheHits;
@@ -2256,8 +2269,8 @@ int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n) {
   if (getenv("T4_TIMING")) {
     fprintf(stderr, "timing: assembler host seconds: add_read calls %.3f (incl. waits for the head), prefetch calls %.3f; launching %.3f (of which deltas %.3f, dependency sets %.3f, registering k-mers %.3f), harvesting %.3f, event examination %.3f, index edits %.3f\n",
             a->secAddTotal, a->secPrefetch, a->secLaunch, a->secDelta, a->secGroups, a->secRegister, a->secHarvest, a->secEvents, a->index.secOps);
-    fprintf(stderr, "timing: query lanes %d: %lld launches (%lld for a head without a result), %lld waits for the head's lane in %.3f s, %lld queries killed in flight\n",
-            (int)a->lanes.size(), (long long)a->launches, (long long)a->launchesUrgent, (long long)a->headWaits, a->secHeadWait, (long long)a->killedInFlight);
+    fprintf(stderr, "timing: query lanes %d: %lld launches (%lld for a head without a result, %lld of them without the whole queries of entries further back), %lld waits for the head's lane in %.3f s, %lld queries killed in flight\n",
+            (int)a->lanes.size(), (long long)a->launches, (long long)a->launchesUrgent, (long long)a->lightRounds, (long long)a->headWaits, a->secHeadWait, (long long)a->killedInFlight);
     fprintf(stderr, "timing: tolerated index edits %lld, of which %lld met an entry whose group statistics cannot move (no budget spent); tolerance kills %lld, of which %lld for lists beyond 10000 postings\n",
             (long long)a->tolerated, (long long)a->toleratedStable, (long long)a->invFragile, (long long)a->invLongLists);
     fprintf(stderr, "timing: restricted re-queries: %lld entries kept their other contigs when one contig changed, %lld merged, %lld fell back to the whole query, %lld in flight met another change of their contig\n",

@@ -410,28 +410,60 @@ int main(int argc, char *argv[]) {
   const std::string xferTag = lateShard ? "retry." : "";
   auto fileOf = [&](int no, int r) { return gatherDir + "/" + xferTag + "x" + std::to_string(no) + ".rank" + std::to_string(r); };
   auto readWhole = [](const std::string &path, std::string &out) { FILE *fp = fopen(path.c_str(), "rb"); if (!fp) return false; char buf[1 << 16]; size_t n; out.clear(); while ((n = fread(buf, 1, sizeof buf, fp)) > 0) out.append(buf, n); fclose(fp); return true; };
+  // The communicator of --rcclId, brought up so that the FIRST multi-GPU run fails soft (RCCL never ran with more than
+  // one rank on any machine the builder had): t4_comm_init checks itself (a 1-int all-gather must return the rank numbers), every
+  // rank then publishes how its communicator came up (FILE.status.rank<r>) and reads everybody's; unless every rank says "ok" ALL
+  // ranks give their communicator up and run the same exchange through files in FILE.files/ (a directory beside the id file: node-
+  // local, as the id file is). The decision is the same on every rank, it is logged, and it is reported in the statistics JSON.
+  std::string transportNote = gatherDir.empty() ? (rcclIdPath.empty() ? "none" : "rccl") : "files";
+  auto commUp = [&](int rank, int count, const std::string &idPath) -> bool {   // true: RCCL is up; false: the file transport is on (gatherDir set)
+    gpuReady();
+    const int irc = t4_comm_init(ctx, rank, count, idPath.c_str(), &comm);
+    const std::string why = irc ? (std::string("fail ") + t4_last_error(ctx)) : std::string("ok");
+    auto statusOf = [&](int r) { return idPath + ".status.rank" + std::to_string(r); };
+    {
+      FILE *fp = fopen((statusOf(rank) + ".tmp").c_str(), "wb");
+      if (!fp || fwrite(why.data(), 1, why.size(), fp) != why.size()) { if (fp) fclose(fp); die(ctx, "t4_comm_init (status file)", irc ? irc : T4_ERR_IO); }
+      fclose(fp);
+      if (rename((statusOf(rank) + ".tmp").c_str(), statusOf(rank).c_str())) die(ctx, "t4_comm_init (status file)", irc ? irc : T4_ERR_IO);
+    }
+    bool allOk = true; std::string firstBad;
+    for (int r = 0; r < count; ++r) {
+      std::string st; bool got1 = false;
+      for (int tries = 0; tries < 12000 && !got1; ++tries) { got1 = readWhole(statusOf(r), st) && !st.empty(); if (!got1) usleep(50000); }
+      if (!got1) die(ctx, "t4_comm_init (no status from every rank)", irc ? irc : T4_ERR_IO);
+      if (st != "ok") { allOk = false; if (firstBad.empty()) firstBad = "rank " + std::to_string(r) + ": " + st; }
+    }
+    if (allOk) return true;
+    if (comm) { t4_comm_destroy(comm); comm = nullptr; }
+    gatherDir = idPath + ".files";
+    (void)mkdir(gatherDir.c_str(), 0777);
+    transportNote = "files (fallback from rccl: " + firstBad + ")";
+    for (char &ch : transportNote) if (ch == '"' || ch == '\\' || ch == '\n') ch = ' ';
+    if (rank == 0) PrintLog("RCCL did not come up on every rank (%s): the exchange runs through files in %s.", firstBad.c_str(), gatherDir.c_str());
+    return false;
+  };
+  auto exchangeFiles = [&](const std::string &mine, bool everyRank, std::vector<std::string> &got, int no) -> bool {
+    const std::string tmp = fileOf(no, shardRank) + ".tmp";
+    FILE *fp = fopen(tmp.c_str(), "wb");
+    if (!fp || fwrite(mine.data(), 1, mine.size(), fp) != mine.size()) { if (fp) fclose(fp); return false; }
+    fclose(fp);
+    if (rename(tmp.c_str(), fileOf(no, shardRank).c_str())) return false;
+    if (!everyRank && shardRank != 0) return true;
+    for (int r = 0; r < shardCount; ++r) {
+      bool ok = false;
+      for (int tries = 0; tries < 36000 && !ok; ++tries) { ok = readWhole(fileOf(no, r), got[(size_t)r]); if (!ok) usleep(50000); }
+      if (!ok) return false;
+    }
+    return true;
+  };
+  const auto &exchangeRef = exchangeFiles;
   // every rank contributes `mine`; everyRank: all ranks receive all contributions, else only rank 0 does
   auto exchange = [&](const std::string &mine, bool everyRank, std::vector<std::string> &got) -> bool {
     got.assign((size_t)shardCount, std::string());
     const int no = exchangeNo++;
-    if (!gatherDir.empty()) {
-      const std::string tmp = fileOf(no, shardRank) + ".tmp";
-      FILE *fp = fopen(tmp.c_str(), "wb");
-      if (!fp || fwrite(mine.data(), 1, mine.size(), fp) != mine.size()) { if (fp) fclose(fp); return false; }
-      fclose(fp);
-      if (rename(tmp.c_str(), fileOf(no, shardRank).c_str())) return false;
-      if (!everyRank && shardRank != 0) return true;
-      for (int r = 0; r < shardCount; ++r) {
-        bool ok = false;
-        for (int tries = 0; tries < 36000 && !ok; ++tries) { ok = readWhole(fileOf(no, r), got[(size_t)r]); if (!ok) usleep(50000); }
-        if (!ok) return false;
-      }
-      return true;
-    }
-    if (!comm) {
-      gpuReady();
-      if ((rc = t4_comm_init(ctx, shardRank, shardCount, (rcclIdPath + (lateShard ? ".retry" : "")).c_str(), &comm))) die(ctx, "t4_comm_init", rc);
-    }
+    if (!gatherDir.empty()) return exchangeFiles(mine, everyRank, got, no);
+    if (!comm && !commUp(shardRank, shardCount, rcclIdPath + (lateShard ? ".retry" : ""))) return exchangeRef(mine, everyRank, got, no);   // (fell back to files)
     void *all = nullptr;
     std::vector<int64_t> sizes((size_t)shardCount);
     const int rr = everyRank ? t4_comm_allgather_bytes(comm, mine.data(), (int64_t)mine.size(), &all, sizes.data())
@@ -939,6 +971,7 @@ int main(int argc, char *argv[]) {
       std::string mine((size_t)(sliceHi - sliceLo) * 4 * sizeof(t4_overlap), '\0');
       for (int t = sliceLo; t < sliceHi; ++t) memcpy(&mine[(size_t)(t - sliceLo) * 4 * sizeof(t4_overlap)], sortedReads[(size_t)t].g, 4 * sizeof(t4_overlap));
       std::vector<std::string> got((size_t)annotCount);
+      if (gatherDir.empty()) (void)commUp(annotRank, annotCount, rcclIdPath);   // (falls back to files on every rank alike)
       if (!gatherDir.empty()) {
         const std::string mineP = gatherDir + "/annot.rank" + std::to_string(annotRank);
         FILE *fp = fopen((mineP + ".tmp").c_str(), "wb");
@@ -956,15 +989,13 @@ int main(int argc, char *argv[]) {
           if (!ok) { fprintf(stderr, "trust4-hip: no annotations from rank %d in %s\n", r, gatherDir.c_str()); return EXIT_FAILURE; }
         }
       } else {
-        t4_comm *comm = nullptr;
-        if ((rc = t4_comm_init(ctx, annotRank, annotCount, rcclIdPath.c_str(), &comm))) die(ctx, "t4_comm_init", rc);
         void *all = nullptr;
         std::vector<int64_t> sizes((size_t)annotCount);
         if ((rc = t4_comm_allgather_bytes(comm, mine.data(), (int64_t)mine.size(), &all, sizes.data()))) die(ctx, "t4_comm_allgather_bytes", rc);
         size_t at = 0;
         for (int r = 0; r < annotCount; ++r) { got[(size_t)r].assign((const char *)all + at, (size_t)sizes[(size_t)r]); at += (size_t)sizes[(size_t)r]; }
         free(all);
-        t4_comm_destroy(comm);
+        t4_comm_destroy(comm); comm = nullptr;
       }
       for (int r = 0; r < annotCount; ++r) {
         auto cut = [&](int q) { long long p = (long long)readCnt * q / annotCount; while (p > 0 && p < readCnt && sortedReads[(size_t)p].read == sortedReads[(size_t)p - 1].read) ++p; return (int)(p > readCnt ? readCnt : p); };
@@ -1297,17 +1328,28 @@ int main(int argc, char *argv[]) {
   if (!useCells) {
     Walk w;
     w.begin = 0; w.end = readCnt;
+    // The reads that will be offered to AddRead with a query of their own (distinct, not filtered), in order, with the arguments they
+    // will be offered with: none of it depends on the loop state (addArgs), so the list is made once, on the host threads -- the
+    // announcement of a round is a slice of it (making it afresh every round cost the chain 60 us per round: 7 s of config C2)
+    std::vector<int> qOf; std::vector<const char *> qReads; std::vector<int> qStrand, qBarcode;
+    if (WINDOW > 1) {
+      std::vector<unsigned char> isQ((size_t)readCnt, 0);
+      std::vector<int> stOf((size_t)readCnt, 0);
+      parallelFor((long long)readCnt, threadCnt, [&](long long j) {
+        if (!isNewRead((int)j)) return;
+        const AddArgs b = addArgs((int)j);
+        if (b.filter) return;
+        isQ[(size_t)j] = 1; stOf[(size_t)j] = b.strand;
+      });
+      for (int j = 0; j < readCnt; ++j) if (isQ[(size_t)j]) { qOf.push_back(j); qReads.push_back(sortedReads[j].read.c_str()); qStrand.push_back(stOf[(size_t)j]); qBarcode.push_back(sortedReads[j].barcode); }
+    }
+    size_t qPos = 0;
     while (w.cur < w.end) {
       const int i = w.cur;
-      if (WINDOW > 1 && needsQuery(i) && !t4_assembler_window_valid(seqSet)) {   // speculate on the next distinct, unfiltered reads
-        std::vector<const char *> rs; std::vector<int> st, bc;
-        for (int j = i; j < readCnt && (int)rs.size() < WINDOW; ++j) {
-          if (!isNewRead(j)) continue;
-          AddArgs b = addArgs(j);
-          if (b.filter) continue;
-          rs.push_back(sortedReads[j].read.c_str()); st.push_back(b.strand); bc.push_back(sortedReads[j].barcode);
-        }
-        if ((rc = t4_assembler_prefetch(seqSet, (int)rs.size(), rs.data(), st.data(), bc.data(), trimLevel > 1))) die(ctx, "t4_assembler_prefetch", rc);
+      while (qPos < qOf.size() && qOf[qPos] < i) ++qPos;
+      if (WINDOW > 1 && qPos < qOf.size() && qOf[qPos] == i && !t4_assembler_window_valid(seqSet)) {   // speculate on the next distinct, unfiltered reads
+        const int n = (int)(qOf.size() - qPos < (size_t)WINDOW ? qOf.size() - qPos : (size_t)WINDOW);
+        if ((rc = t4_assembler_prefetch(seqSet, n, qReads.data() + qPos, qStrand.data() + qPos, qBarcode.data() + qPos, trimLevel > 1))) die(ctx, "t4_assembler_prefetch", rc);
       }
       stepMain(w);
       if (assembledReadCnt > 0 && assembledReadCnt % 10000 == 0 && !hasBarcode) t4_assembler_update_all_consensus(seqSet);
@@ -1685,7 +1727,15 @@ int main(int argc, char *argv[]) {
     }
     std::vector<std::string> doneAll;
     if (!exchange("done", true, doneAll)) { fprintf(stderr, "trust4-hip: the last exchange failed\n"); return EXIT_FAILURE; }
-    if (shardRank == 0) PrintLog("Gathered %d shards over %s: %lld contig slots.", shardCount, gatherDir.empty() ? "RCCL" : "files", slotsAll);
+    if (shardRank == 0) PrintLog("Gathered %d shards over %s: %lld contig slots.", shardCount, transportNote.c_str(), slotsAll);
+    if (const char *sj = getenv("T4_STATS_JSON")) {   // which transport carried the exchange (bench.py reports it: "rccl", "files", or the fallback with its reason)
+      FILE *fp = fopen((std::string(sj) + ".transport").c_str(), "w");
+      if (fp) { fputs(transportNote.c_str(), fp); fclose(fp); }
+    }
+    // this rank's files of the exchanges every rank has passed (all but the last) and its status file leave the directory: a later
+    // run that is handed the same directory must not take them for its own (launchers hand out fresh directories anyway)
+    if (!gatherDir.empty()) for (int no = 0; no + 1 < exchangeNo; ++no) (void)unlink(fileOf(no, shardRank).c_str());
+    if (!rcclIdPath.empty()) (void)unlink((rcclIdPath + (lateShard ? ".retry" : "") + ".status.rank" + std::to_string(shardRank)).c_str());
     if (comm) t4_comm_destroy(comm);
     mark("outputs_written");
     writeCellStats();

@@ -89,16 +89,20 @@ def main(argv=None, driver=None):
         # the exchange happens inside the engine: every rank's trust4-hip joins one RCCL communicator (bootstrapped through a file
         # that rank 0 creates) and all-gathers the shard results itself; rank 0 of the engine writes PREFIX_*.  Nothing goes
         # through Python or torch (T4_DIST_PY=1 keeps the torch.distributed path below, which is also what the gloo tests run).
-        id_file = "%s.rcclid.%s" % (prefix, os.environ.get("MASTER_PORT", "0"))
-        if rank == 0 and os.path.exists(id_file):
-            os.remove(id_file)
+        # (a directory of this run's own for the id, the ranks' status files and -- should RCCL not come up on every rank -- the files of
+        # the engine's fall-back transport: a stale id or file of an earlier run can never be read)
+        import shutil
+        xdir = "%s.xfer.%s" % (prefix, os.environ.get("MASTER_PORT", "0"))
+        if rank == 0:
+            shutil.rmtree(xdir, ignore_errors=True)
+            os.makedirs(xdir)
         dist.barrier()
         env = dict(os.environ)
         env["T4_DEVICE"] = str(local_rank)
-        subprocess.run([driver] + argv + ["-o", prefix, "--cellShard", "%d/%d" % (rank, world), "--rcclId", id_file], check=True, env=env)
+        subprocess.run([driver] + argv + ["-o", prefix, "--cellShard", "%d/%d" % (rank, world), "--rcclId", os.path.join(xdir, "rcclid")], check=True, env=env)
         dist.barrier()
-        if rank == 0 and os.path.exists(id_file):
-            os.remove(id_file)
+        if rank == 0:
+            shutil.rmtree(xdir, ignore_errors=True)
         dist.destroy_process_group()
         return 0
     shard_prefix = "%s.shard%d" % (prefix, rank)
