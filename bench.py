@@ -499,7 +499,7 @@ def sharded_cells(args, rank, local_rank, world, dist):
                            "pairs": pairs, "cells": cells, "host_threads_per_rank": threads,
                            "per_rank_s": {"replicated_phases": [float(x[0]) for x in parts], "own_cells_before_the_add_pass": [float(x[2]) for x in parts],
                                           "add_pass_of_its_cells": [float(x[1]) for x in parts]}}}
-        try:   # "rccl", or "files (fallback from rccl: <first rank's reason>)" when the communicator did not come up on every rank
+        try:   # "RCCL", or "files (fallback from RCCL: <first rank's reason>)" when the communicator did not come up on every rank
             line["config"]["transport"] = open(os.path.join(tmp, "stats_rank0.json.transport")).read().strip()
         except OSError:
             line["config"]["transport"] = None
@@ -613,7 +613,7 @@ def main():
             "unit": "pairs/s",
             "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": None, "vs_baseline": None,
             "dtype": "int32/u64", "data": "synthetic",
             "config": {"workload": workload + ", -f hg38_bcrtcr.fa, k=9, bulk mode; one step = whole stage 1 through trust4-hip -t %d --skipMateExtension, FASTQ files in -> "
                                               "_raw.out / _assembled_reads.fa / _final.out out, process start to exit" % threads,

@@ -1,11 +1,9 @@
-"""N > 1 path on CPU: world_size 2 over gloo. Covers bench.py's sharding plumbing (trust4_amd/dist.py):
-rank-seeded shards are disjoint streams, the timed interval is max-reduced, totals are sum-reduced, and
-each rank's shard is processed independently (checked here with the CPU oracle standing in as the checker
-of the per-rank results; the GPU engine itself is exercised by the -m gpu suite)."""
+"""N > 1 paths on CPU: world_size 2 (and 5, 8) over gloo or through the engine's file transport. Covers bench.py's launcher plumbing
+(trust4_amd/dist.py), the sharded barcode mode and the sharded rough-annotation pass of the driver (emulated engine; the GPU engine
+itself is exercised by the -m gpu suite)."""
 import os
 import sys
 
-import numpy as np
 import pytest
 import torch.multiprocessing as mp
 
@@ -14,27 +12,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    import t4libs
     import trust4_amd.dist as t4dist
     dist = t4dist.init("gloo")
     assert dist is not None and dist.get_world_size() == world
-    arr = t4libs.Synth(200, t4dist.shard_seed(1, rank)).next_reads(50)
-    o = t4libs.Oracle(9, t4libs.REF_FA, 17)
-    exp, hp, tot = o.annotate_batch(arr, arr.shape[1], arr.shape[0])
-    checksum = float(np.frombuffer(arr.tobytes(), dtype=np.uint8).astype(np.int64).sum())
     dist.barrier()
     mx = t4dist.max_over_ranks(dist, float(rank + 1), "cpu")
-    sm = t4dist.sum_over_ranks(dist, float(tot), "cpu")
-    q.put((rank, checksum, int(tot), mx, sm, int((exp["seqIdx"] != -1).sum())))
+    q.put((rank, mx))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_sharding():
-    import t4libs
-    t4libs.build_checkers()
+def test_two_rank_plumbing():
+    """what bench.py --gpus N takes from trust4_amd/dist.py: the process group from the launcher's environment, barriers, and the
+    timed interval max-reduced over the ranks"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 400)
@@ -45,12 +36,7 @@ def test_two_rank_sharding():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, c0, t0, mx0, sm0, a0), (r1, c1, t1, mx1, sm1, a1) = res
-    assert (r0, r1) == (0, 1)
-    assert c0 != c1                      # different shards
-    assert mx0 == mx1 == 2.0             # MAX over ranks
-    assert sm0 == sm1 == float(t0 + t1)  # whole-job aggregate
-    assert a0 > 0 and a1 > 0
+    assert res == [(0, 2.0), (1, 2.0)]   # MAX over ranks, on both
 
 
 def _stage1_worker(rank, world, port, argv, prefix, driver, q):
@@ -292,7 +278,7 @@ def test_bench_gpus2_plumbing_dry_run(tmp_path):
     assert line["n_gpus"] == 2 and line["steps"] == 1 and line["warmup"] == 1 and line["scaling"] == "strong" and line["value"] > 0
     assert line["config"]["pairs"] == 120 and line["config"]["cells"] == 8
     assert line["one_rank"]["identical"] is True
-    assert line["config"]["transport"].startswith("files (fallback from rccl: rank 0: fail"), line["config"]["transport"]
+    assert line["config"]["transport"].startswith("files (fallback from RCCL: rank 0: fail"), line["config"]["transport"]
     per = line["config"]["per_rank_s"]
     assert len(per["replicated_phases"]) == 2 and min(per["replicated_phases"]) > 0
     assert len(per["own_cells_before_the_add_pass"]) == 2 and min(per["own_cells_before_the_add_pass"]) > 0   # (the early shard: a mark of its own in the stats)

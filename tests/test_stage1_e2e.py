@@ -518,6 +518,64 @@ def test_window_entries_with_stable_group_statistics_gpu(tmp_path, pairs, clones
     assert re.search(r"T4_VERIFY_WINDOW: (\d+) served window entries", logs["stable"])
 
 
+CAND_PAT = (r"candidate store: (\d+) candidate records kept with whole queries, (\d+) restricted re-queries merged through the replay of the scan "
+            r"\((\d+) with more than 50 candidates, (\d+) with more than 100 groups of four hits on a strand, (\d+) cut a candidate of another contig\), "
+            r"fell back to the whole query: (\d+) a cut candidate of another contig passes now, (\d+) the group statistics could move the threshold, "
+            r"(\d+) an overlap on the other strand, (\d+) other; (\d+) whole queries checked against the host's scan")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
+@pytest.mark.parametrize("env", [{}, {"T4_AQ_CAP_LIMIT": "2500", "T4_AQ_CAND_CAP": "64", "T4_MAX_PENDING": "2"}])
+def test_candidate_store_emulated(tmp_path, env):
+    """The candidate store: a window entry keeps EVERY scored candidate overlap of its whole query (pre-score key, scored
+    fields, cut by the pre-filters of SeqSet.hpp:1705-1794 or not) and the group statistics of 784-823; after a restricted re-query of
+    one contig the host swaps that contig's candidates, repeats the scan and checks that the statistics still certify the
+    novelMinHitRequired the other candidates were made with. Many clones on few genes, so that reads inside a shared gene segment meet
+    dozens of contigs. T4_VERIFY_WINDOW: every whole query's cut flags and survivors are compared with the host's replay of the scan,
+    and every served entry -- most of them put together from restricted re-queries -- with a fresh whole query. The second case sends
+    the heavy reads through the wide query (its merge kernel writes the candidates), starts from a candidate pool of 64 records (the
+    grow-and-repeat path) and lets an entry wait for two contigs at most."""
+    import re
+    e = {"T4_VERIFY_WINDOW": "1"}
+    e.update(env)
+    log = _bulk_case(tmp_path, _emulated_driver(), 1300, 650, 3, e, threads="4")
+    m = re.search(CAND_PAT, log)
+    assert m, log[-1500:]
+    recs, merged, big, stats, recut, fb_uncut, fb_stats, fb_strand, fb_other, checked = (int(x) for x in m.groups())
+    assert recs > 5000 and merged > 1000 and checked > 1000, m.groups()
+    assert fb_uncut + fb_stats + fb_strand + fb_other < merged // 10, m.groups()
+    v = re.search(r"T4_VERIFY_WINDOW: (\d+) served window entries queried again at serve time, all equal to their cached results \((\d+) of them put together", log)
+    assert v and int(v.group(2)) > 500, log[-800:]
+    if "T4_AQ_CAP_LIMIT" in env:
+        w = re.search(r"wide query served (\d+) window entries", log)
+        assert w and int(w.group(1)) > 0, log[-800:]
+    print(m.groups())
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not shipped")
+def test_candidate_store_gpu(tmp_path):
+    """the same on the GPU at a depth where the regimes the store exists for are met: entries with more than 50 candidates (pre-filters
+    live) and with more than 100 groups of four hits on a strand (novelMinHitRequired follows the group statistics), most heavy reads
+    served by the wide query; and the round-4 rule (T4_CANDS_OFF) on the same input for comparison of the whole queries it needs"""
+    import re
+    logs = {}
+    for name, extra in (("store", {}), ("off", {"T4_CANDS_OFF": "1"})):
+        d = tmp_path / name
+        d.mkdir()
+        env = {"T4_VERIFY_WINDOW": "1"}
+        env.update(extra)
+        logs[name] = _bulk_case(d, _driver(), 30000, 15000, 7, env, threads="8")
+    m = re.search(CAND_PAT, logs["store"])
+    assert m, logs["store"][-1500:]
+    recs, merged, big, stats, recut, fb_uncut, fb_stats, fb_strand, fb_other, checked = (int(x) for x in m.groups())
+    assert merged > 10000 and big > 100 and stats > 100 and checked > 10000, m.groups()
+    q = {k: int(re.search(r"GPU query rounds \d+ with (\d+) reads", v).group(1)) for k, v in logs.items()}
+    r = {k: int(re.search(r"restricted re-queries: \d+ entries kept their other contigs when one contig changed, (\d+) merged", v).group(1)) for k, v in logs.items()}
+    assert q["store"] - r["store"] < q["off"] - r["off"], (q, r)   # fewer whole queries
+    print(m.groups(), q, r)
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not shipped")
 def test_rccl_gather_inside_the_engine_gpu(tmp_path):

@@ -70,8 +70,8 @@ struct AqCall {
   int n = 0, skipRepeats = 0, wpk = 0, wnm = 0, attempt = 0, nFirst = 0, nDirect = 0, threads = 512;
   unsigned char *tierHint = nullptr;
   std::vector<unsigned char> allGlobal;
-  size_t oPk, oNm, oLen, oBc, oSt, oLs, oVw, oFa, oOnly, oWide, oWideA, inBytes, pCnt, pSta, pNext, pNext2, pBase, pTick, pStab, pAux, pN4, pTail, pWctl, pWplan, pWstat, pWctlA, pWplanA, pWstatA, outBytes;
-  bool hasOnly = false;
+  size_t oPk, oNm, oLen, oBc, oSt, oLs, oVw, oFa, oOnly, oForce, oWide, oWideA, inBytes, pCb, pCc, pS8, pCnt, pSta, pNext, pNext2, pBase, pTick, pStab, pAux, pN4, pTail, pWctl, pWplan, pWstat, pWctlA, pWplanA, pWstatA, outBytes;
+  bool hasOnly = false, hasForce = false, wantCands = false;
   bool extendLater = false, wide = false;
   int wideSafety = 32;   // of sixteenths: partitions are planned for half of their capacity
   T4BatchView bv; T4QueryArgs qa; T4Work wk;
@@ -110,6 +110,9 @@ struct t4_ctx {
   size_t aqInBytes = 0, aqOutBytes = 0;
   unsigned char *aqPool = nullptr, *aqPoolDev = nullptr;   // result records of t4_add_query*: pinned host memory the kernels write
   int aqPoolCap = 0;
+  unsigned char *candPool = nullptr; T4Cand *candPoolDev = nullptr;   // candidate store of t4_add_query_pool_begin2 (pinned host memory the kernels write)
+  int candCap = 0, candGrows = 0;
+  int64_t candRecords = 0;
   T4OverlapOut *aqRecDev = nullptr;   // device copy of the overlap records + the read of each, for the extension launch
   int *aqRecRead = nullptr;
   int aqRecCap = 0;
@@ -365,6 +368,7 @@ void t4_destroy(t4_ctx *c) {
   if (c->aqInHost) (void)hipHostFree(c->aqInHost);
   if (c->aqOutHost) (void)hipHostFree(c->aqOutHost);
   if (c->aqPool) (void)hipHostFree(c->aqPool);
+  if (c->candPool) (void)hipHostFree(c->candPool);
   if (c->aqRecDev) (void)hipFree(c->aqRecDev);
   if (c->aqRecRead) (void)hipFree(c->aqRecRead);
   if (c->wideInit) {
@@ -1513,7 +1517,7 @@ struct AqResult { const int32_t *counts, *base; const t4_overlap *ov, *ext; cons
 int aqLaunch(t4_ctx *c);
 int aqBegin(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const int32_t *viewOf, bool smallFirst, int n, const char *bases,
             const int64_t *offsets, const int32_t *barcodes, const int32_t *strands, int skip_repeats, const double *factors,
-            unsigned char *tierHint = nullptr, bool lean = false, const int32_t *onlySeq = nullptr) {
+            unsigned char *tierHint = nullptr, bool lean = false, const int32_t *onlySeq = nullptr, const int32_t *forceMin = nullptr, bool wantCands = false) {
   (void)hipSetDevice(c->device);
   AqCall &q = c->aq;
   if (q.active) return fail(c, T4_ERR_STATE, "an AddRead query is already in flight on this ctx");
@@ -1533,13 +1537,15 @@ int aqBegin(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const 
   q.oPk = 0; q.oNm = al8(q.oPk + sizeof(unsigned) * (size_t)n * wpk); q.oLen = al8(q.oNm + sizeof(unsigned) * (size_t)n * wnm);
   q.oBc = al8(q.oLen + sizeof(int) * (size_t)n); q.oSt = al8(q.oBc + sizeof(int) * (size_t)n); q.oLs = al8(q.oSt + sizeof(int) * (size_t)n);
   q.oVw = al8(q.oLs + sizeof(int) * (size_t)n); q.oFa = al8(q.oVw + sizeof(int) * (size_t)n); q.oOnly = al8(q.oFa + sizeof(double) * (size_t)n);
-  q.oWide = al8(q.oOnly + sizeof(int) * (size_t)n); q.hasOnly = onlySeq != nullptr;
+  q.oForce = al8(q.oOnly + sizeof(int) * (size_t)n);
+  q.oWide = al8(q.oForce + sizeof(int) * (size_t)n); q.hasOnly = onlySeq != nullptr; q.hasForce = forceMin != nullptr; q.wantCands = wantCands;
   q.oWideA = al8(q.oWide + sizeof(T4Wide)); q.inBytes = al8(q.oWideA + sizeof(T4Wide));
   q.pCnt = 0; q.pSta = al8(q.pCnt + sizeof(int) * (size_t)n); q.pNext = al8(q.pSta + sizeof(int) * (size_t)n);
   q.pNext2 = al8(q.pNext + sizeof(int) * (size_t)n); q.pBase = al8(q.pNext2 + sizeof(int) * (size_t)n);
   q.pTick = al8(q.pBase + sizeof(int) * (size_t)n); q.pStab = al8(q.pTick + sizeof(int) * (size_t)n); q.pAux = al8(q.pStab + sizeof(int) * (size_t)n);
-  q.pN4 = al8(q.pAux + sizeof(int) * (size_t)n); q.pTail = al8(q.pN4 + sizeof(int) * (size_t)n);
-  q.pWctl = q.pTail + 32; q.pWplan = q.pWctl + 32; q.pWstat = al8(q.pWplan + sizeof(T4WidePlan) * (size_t)n);
+  q.pN4 = al8(q.pAux + sizeof(int) * (size_t)n); q.pCb = al8(q.pN4 + sizeof(int) * (size_t)n); q.pCc = al8(q.pCb + sizeof(int) * (size_t)n);
+  q.pS8 = al8(q.pCc + sizeof(int) * (size_t)n); q.pTail = al8(q.pS8 + sizeof(int) * 8 * (size_t)n);   // tail: overflow1 | overflow2 | hits (8 B) | pool cursor | dir overflow | cand cursor | cand overflow
+  q.pWctl = q.pTail + 48; q.pWplan = q.pWctl + 32; q.pWstat = al8(q.pWplan + sizeof(T4WidePlan) * (size_t)n);
   q.pWctlA = al8(q.pWstat + sizeof(int) * T4_WIDE_STAT * (size_t)n); q.pWplanA = q.pWctlA + 32; q.pWstatA = al8(q.pWplanA + sizeof(T4WidePlan) * (size_t)n);
   q.outBytes = al8(q.pWstatA + sizeof(int) * T4_WIDE_STAT * (size_t)n);
   q.wideSafety = c->wideSafetyKeep;
@@ -1572,6 +1578,7 @@ int aqBegin(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const 
     int l = (int)(offsets[i + 1] - offsets[i]);
     len[i] = l; bc[i] = barcodes ? barcodes[i] : -1; st[i] = strands[i]; fa[i] = factors[i]; vw[i] = viewOf ? viewOf[i] : 0;
     ((int *)(h + q.oOnly))[i] = onlySeq ? onlySeq[i] : -1;
+    ((int *)(h + q.oForce))[i] = forceMin ? forceMin[i] : 0;
     unsigned *p = pk + (size_t)i * wpk, *qn = nm + (size_t)i * wnm;
     for (int j = 0; j < l; ++j) {
       int v = nucNum(s[j]);
@@ -1619,6 +1626,11 @@ int aqLaunch(t4_ctx *c) {
     HIPCHK(c, hipHostGetDevicePointer((void **)&c->aqPoolDev, c->aqPool, 0));
   }
   const size_t rec = (size_t)c->aqPoolCap;
+  if (q.wantCands && !c->candPool) {
+    if (!c->candCap) c->candCap = getenv("T4_AQ_CAND_CAP") ? atoi(getenv("T4_AQ_CAND_CAP")) : 1 << 18;   // (testing aid: a small pool forces the grow-and-repeat path)
+    HIPCHK(c, hipHostMalloc(&c->candPool, sizeof(T4Cand) * (size_t)c->candCap, hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer((void **)&c->candPoolDev, c->candPool, 0));
+  }
   q.tf0 = std::chrono::steady_clock::now();
   if (q.wide) {
     if ((r = ensureWide(c, n, 1, 1))) return r;
@@ -1651,6 +1663,12 @@ int aqLaunch(t4_ctx *c) {
   qa.statsStable = (int *)(c->aqOut + q.pStab);
   qa.aux = (int *)(c->aqOut + q.pAux); qa.n4 = (int *)(c->aqOut + q.pN4);
   if (q.hasOnly) qa.onlySeq = (const int *)(c->aqIn + q.oOnly);
+  if (q.hasForce) qa.forceMin = (const int *)(c->aqIn + q.oForce);
+  qa.stats8 = (int *)(c->aqOut + q.pS8);
+  if (q.wantCands) {
+    qa.candOut = c->candPoolDev; qa.candCap = c->candCap; qa.candCursor = (unsigned *)(c->aqOut + q.pTail + 32); qa.candOverflow = (int *)(c->aqOut + q.pTail + 36);
+    qa.candBase = (int *)(c->aqOut + q.pCb); qa.candCnt = (int *)(c->aqOut + q.pCc);
+  }
   qa.leanExt = q.lean ? 1 : 0;
   if (q.views) { qa.views = q.views; qa.viewOf = (const int *)(c->aqIn + q.oVw); }
   // one big set: the ExtendOverlap calls of reads with more than this many overlaps run in their own launch (0: never)
@@ -1875,6 +1893,17 @@ int aqEnd(t4_ctx *c, AqResult *res) {
                                       status[i] == 2 ? "more k-mer hits or overlaps than the global tier holds" : "gap DP or contig count beyond scratch");
     }
     if (*(const unsigned *)(o + pTail + 28)) return fail(c, T4_ERR_UNSUPPORTED, "an overhang alignment of this batch exceeds the extension kernel's direction buffer");
+    if (q.wantCands && *(const int *)(o + pTail + 36)) {   // more candidate records than their pool holds: a larger pool, and the whole call again
+      if (q.attempt >= 12) return fail(c, T4_ERR_UNSUPPORTED, "candidate pool of %d records overflows", c->candCap);
+      const unsigned want = *(const unsigned *)(o + pTail + 32);
+      (void)hipHostFree(c->candPool);
+      c->candPool = nullptr; c->candPoolDev = nullptr; ++c->candGrows;
+      while ((unsigned)c->candCap < want && c->candCap < (1 << 29)) c->candCap *= 2;
+      c->candCap *= 2;
+      ++q.attempt;
+      if ((r = aqLaunch(c))) return r;
+      continue;
+    }
     if (poolFull) {   // more result records than the pool holds: a larger pool, and the whole call again
       if (q.attempt >= 8) return fail(c, T4_ERR_UNSUPPORTED, "result pool of %d records overflows", c->aqPoolCap);
       (void)hipHostFree(c->aqPool);
@@ -1885,6 +1914,7 @@ int aqEnd(t4_ctx *c, AqResult *res) {
     }
     const size_t rec = (size_t)c->aqPoolCap;
     c->aqRecords += *(const unsigned *)(o + pTail + 24);
+    if (q.wantCands) c->candRecords += *(const unsigned *)(o + pTail + 32);
     c->aqHits += (int64_t) * (const unsigned long long *)(o + pTail + 16);
     c->aqLastTicks = (const int32_t *)(o + q.pTick); c->aqLastN = n;
     c->aqLastStable = (const int32_t *)(o + q.pStab);
@@ -2021,6 +2051,27 @@ int t4_add_query_pool_begin(t4_index *ix, int n, const char *bases, const int64_
   if (!ix->committed) return fail(c, T4_ERR_STATE, "index not committed");
   if (ix->view.firstIsRef) return fail(c, T4_ERR_UNSUPPORTED, "t4_add_query needs a contig set");
   return aqBegin(c, ix->view, nullptr, nullptr, false, n, bases, offsets, barcodes, strands, skip_repeats, factors, tier_hint, true, only_seq);   // for t4_assembler: lean records (extendOverlaps)
+}
+int t4_add_query_pool_begin2(t4_index *ix, int n, const char *bases, const int64_t *offsets, const int32_t *barcodes, const int32_t *strands,
+                             int skip_repeats, const double *factors, unsigned char *tier_hint, const int32_t *only_seq, const int32_t *force_min, int want_cands) {
+  if (!ix || n <= 0 || !bases || !offsets || !strands || !factors) return T4_ERR_ARG;
+  t4_ctx *c = ix->ctx;
+  if (!ix->committed) return fail(c, T4_ERR_STATE, "index not committed");
+  if (ix->view.firstIsRef) return fail(c, T4_ERR_UNSUPPORTED, "t4_add_query needs a contig set");
+  return aqBegin(c, ix->view, nullptr, nullptr, false, n, bases, offsets, barcodes, strands, skip_repeats, factors, tier_hint, true, only_seq, force_min, want_cands != 0);
+}
+// per read of the last finished call begun with want_cands: its candidate records (cnt[i] of them from base[i] of pool, pinned
+// memory valid until the next call) and its eight statistics words (T4QueryArgs::stats8)
+int t4_add_query_last_cands(t4_ctx *c, const t4_cand **pool, const int32_t **base, const int32_t **cnt, const int32_t **stats8, int *n) {
+  if (!c || !c->aqOutHost) return T4_ERR_ARG;
+  const AqCall &q = c->aq;
+  static_assert(sizeof(t4_cand) == sizeof(T4Cand) && sizeof(T4Cand) == 24, "candidate record layout");
+  if (pool) *pool = q.wantCands ? (const t4_cand *)c->candPool : nullptr;
+  if (base) *base = (const int32_t *)(c->aqOutHost + q.pCb);
+  if (cnt) *cnt = q.wantCands ? (const int32_t *)(c->aqOutHost + q.pCc) : nullptr;
+  if (stats8) *stats8 = (const int32_t *)(c->aqOutHost + q.pS8);
+  if (n) *n = q.n;
+  return T4_OK;
 }
 int t4_add_query_pool_done(t4_ctx *c) { return c ? aqDone(c) : 1; }
 int t4_add_query_pool_end(t4_ctx *c, const int32_t **counts, const int32_t **base, const t4_overlap **ov, const t4_overlap **ext, const int32_t **ext_ret) {

@@ -523,9 +523,25 @@ struct t4_assembler : IndexListener {
     // other contig: a commit that touches contig c of such an entry leaves the entry PARTIAL -- it keeps its records of the other
     // contigs -- and only the overlaps with c are asked for again (t4_add_query_pool_begin, only_seq).
     int nAll = 0, nOther = 0, n4 = 0, nAllBound = 0, restrictedCount = 0;
+    // ---- the candidate store: what lets an entry with MORE than 50 candidate overlaps, or with more than 100 groups of
+    // four hits, keep its other contigs when one contig changes. cands: every overlap of the read on the strand of the best one as it
+    // stood before the similarity cut, in the order of the scan of SeqSet.hpp:1673-2094, with its pre-score key, its scored fields and
+    // whether the pre-filters of 1705-1794 cut it (from the query itself: t4_add_query_last_cands). After a restricted re-query of
+    // contig c the host swaps c's candidates, repeats the scan (mergeRestricted) and needs the whole query only when a candidate of
+    // ANOTHER contig that was cut now passes (its ExtendOverlap record was never made). Group statistics (784-823): bounds of the
+    // true counts per strand -- groups of >= 4 hits, of >= 5 hits, the largest group -- and the novelMinHitRequired T the entry's
+    // candidates were made with; a restricted re-query runs with T and is accepted only if the bounds, updated with the contig's old
+    // and new group sizes, still certify T (the certificate of overlapsFromKeys: both corners give the same threshold).
+    std::vector<t4_cand> cands;
+    bool candOk = false;
+    int n4lo[2] = {0, 0}, n4hi[2] = {0, 0}, n5lo[2] = {0, 0}, n5hi[2] = {0, 0}, smlo[2] = {0, 0}, smhi[2] = {0, 0}, minT[2] = {3, 3};
+    std::vector<uint32_t> exactKeys;   // groups whose recorded hit count is exact because a restricted re-query set it (host-derived tables hold supersets)
     bool strand0Plus = false, auxOk = false;
     bool partial = false, merged = false;
     int pendingContig = -1;
+    // (with the candidate store an entry may wait for SEVERAL contigs: one restricted re-query each, in one launch; the further ones)
+    std::vector<int> morePending;
+    bool isPending(int c) const { return partial && (c == pendingContig || std::find(morePending.begin(), morePending.end(), c) != morePending.end()); }
     std::vector<std::pair<uint64_t, int>> kmerPos;   // the read's k-mers of both strands, (code, position << 1 | plus), sorted by code (built on first use)
     // a (re-)query of this entry is running on a lane: commits since its launch are examined against its dependency sets like
     // those of an entry that holds a result; `killed` = one of them invalidated it (the result is dropped when it arrives),
@@ -590,14 +606,18 @@ struct t4_assembler : IndexListener {
   bool liveReset = true;           // the next delta describes the whole image (first upload, k change)
   int64_t toleratedStable = 0, invLongLists = 0;
   int64_t wideServed = 0, wideGroupRecords = 0, wideMispredicted = 0;
-  int64_t restrictedMarks = 0, restrictedMerged = 0, restrictedFallbacks = 0, restrictedStale = 0;
-  bool restrictOn = true;
+  int64_t restrictedMarks = 0, restrictedMerged = 0, restrictedFallbacks = 0, restrictedStale = 0, restrictedMulti = 0;
+  bool restrictOn = true, candStore = true;
+  int64_t candRecords = 0, candMerges = 0, candFallbackUncut = 0, candFallbackStats = 0, candFallbackStrand = 0, candFallbackOther = 0, candRecut = 0, candSelfChecks = 0, candMergesBig = 0, candMergesStats = 0;
+  bool mergeRestricted(Cached &c, int pc, int k2, const t4_overlap *ov, const t4_overlap *ex, const int32_t *rets, const t4_cand *nc, int ncnt, const int32_t *s8);
+  static void replayScan(const std::vector<t4_cand> &cands, const std::vector<Seq> &seqs, int len, int radius, double repeatSim, std::vector<unsigned char> &cut);
   int64_t whyNot[6] = {0, 0, 0, 0, 0, 0};   // entries that fell whole although one contig changed: lists beyond 10000 postings, overlaps on the other strand, more than 44 candidate overlaps, more than ~100 groups of four hits, no report from the query, other
   bool eligibleForRestricted(const Cached &e) {
     if (!restrictOn || !e.valid || e.skip || e.barcode != -1) { ++whyNot[5]; return false; }
     if (!e.auxOk) { ++whyNot[4]; return false; }
     if (e.fragile) { ++whyNot[0]; return false; }
     if (e.nOther != 0) { ++whyNot[1]; return false; }
+    if (candStore && e.candOk) return true;   // (the replay of the scan and the certificate of the group statistics decide when the records arrive)
     if (e.nAllBound > 44) { ++whyNot[2]; return false; }
     if (e.n4 + 2 * e.restrictedCount + 2 > 100) { ++whyNot[3]; return false; }
     return true;
@@ -611,7 +631,7 @@ struct t4_assembler : IndexListener {
   // testing / development aids, read from the environment ONCE per builder (none changes a result; DESIGN 7b lists them)
   struct Knobs {
     bool verifyWindow = false, noStableStats = false;
-    int lanes = 1, queryAhead = 0, minBatch = 4, harvestDelay = 0, lightAhead = -1, heavyBatch = 0; double aheadMult = 3.0;
+    int lanes = 1, queryAhead = 0, minBatch = 4, harvestDelay = 0, lightAhead = -1, heavyBatch = 0, maxPending = 4; double aheadMult = 3.0;
     FILE *roundLog = nullptr;
     Knobs() {
       auto num = [](const char *n, int d) { const char *e = getenv(n); return e ? atoi(e) : d; };
@@ -619,6 +639,7 @@ struct t4_assembler : IndexListener {
       noStableStats = getenv("T4_NO_STABLE_STATS") != nullptr;  // A/B aid: the budget rule for every entry
       lanes = num("T4_LIVE_LANES", 1); queryAhead = num("T4_QUERY_AHEAD", 0); minBatch = num("T4_LIVE_MIN_BATCH", 4); harvestDelay = num("T4_LIVE_HARVEST_DELAY", 0);
       heavyBatch = num("T4_HEAVY_BATCH", 0); if (getenv("T4_AHEAD_MULT")) aheadMult = atof(getenv("T4_AHEAD_MULT"));
+      maxPending = num("T4_MAX_PENDING", 4);   // contigs a window entry may wait for at a time (1: round 4's rule, a second contig ends the entry)
       lightAhead = num("T4_LIGHT_AHEAD", -1);   // -1: every round carries every entry without a result (within `ahead`)
       if (getenv("T4_ROUND_LOG")) roundLog = fopen(getenv("T4_ROUND_LOG"), "w");   // one line per launch: reads, kernel ms, per read us / overlaps / tier / killed in flight
     }
@@ -713,7 +734,7 @@ struct t4_assembler : IndexListener {
     bool busy = false;
     int polls = 0;
     std::vector<int> slots; std::vector<int64_t> uids; std::vector<unsigned char> hint;
-    std::string bases; std::vector<int64_t> offs; std::vector<int32_t> bcs, sts, only; std::vector<double> fac;
+    std::string bases; std::vector<int64_t> offs; std::vector<int32_t> bcs, sts, only, force; std::vector<double> fac;
     int repetitive = 0;
   };
   std::vector<Lane> lanes;
@@ -1631,14 +1652,19 @@ void t4_assembler::processEvents() {
   // from the state its lane's replica holds)
   // the whole result of the entry falls
   auto kill = [&](Cached &e, int64_t &why) {
-    if (e.partial) { e.partial = false; e.pendingContig = -1; if (e.inflight) e.killed = true; ++invalidations; ++why; return; }
+    if (e.partial) { e.partial = false; e.pendingContig = -1; e.morePending.clear(); if (e.inflight) e.killed = true; ++invalidations; ++why; return; }
     if (e.valid) { e.valid = false; ++invalidations; ++why; }
     else if (e.inflight && !e.killed) { e.killed = true; ++invalidations; ++why; }
   };
   // what the entry's result takes from contig c falls: when the entry qualifies (Cached: restricted re-query) it keeps the rest
   auto touch = [&](Cached &e, int c, int64_t &why) {
     if (e.partial) {
-      if (c != e.pendingContig) { kill(e, why); return; }
+      if (!e.isPending(c)) {
+        // another contig of an entry that already waits for one: with the candidate store it waits for both (the re-queries are
+        // independent of each other; one that is on its way stays good), else the whole entry falls
+        if (candStore && e.candOk && (int)e.morePending.size() < knobs.maxPending - 1) { e.morePending.push_back(c); ++invalidations; ++why; ++restrictedMarks; ++restrictedMulti; return; }
+        kill(e, why); return;
+      }
       if (e.inflight && !e.killed) { e.killed = true; ++restrictedStale; }   // the restricted query on its way saw the contig before this change
       return;
     }
@@ -1651,7 +1677,7 @@ void t4_assembler::processEvents() {
       Cached &e = *pool[sl];
       if (!e.standing()) continue;
       if (e.inflight && e.expectWide && !e.hasDev) { kill(e, invContig); continue; }   // its dependency records are still on their way: nothing to examine the change against
-      if (e.partial && e.pendingContig == ev.c) {   // (its records and its group of this contig are stale already: any change of it counts)
+      if (e.isPending(ev.c)) {   // (its records and its group of this contig are stale already: any change of it counts)
         if (ev.kind == 2) kill(e, invContig); else touch(e, ev.c, ev.kind == 0 ? invRegion : invShift);
         continue;
       }
@@ -1668,11 +1694,12 @@ void t4_assembler::processEvents() {
           g->lo += ev.a; g->hi += ev.a;
         }
       }
-      if (ev.kind == 1 && e.partial && e.pendingContig == ev.c) {
+      if (ev.kind == 1 && e.isPending(ev.c)) {
         // (the contig's other-strand group, if the loop stopped at the first: its hull moves all the same -- it is rebuilt with the re-query)
       } else if (ev.kind == 1 && (e.valid || e.partial)) {
         for (t4_overlap &o : e.ov) if (o.seqIdx == ev.c) { o.seqStart += ev.a; o.seqEnd += ev.a; }
         for (t4_overlap &o : e.ext) if (o.seqIdx == ev.c) { o.seqStart += ev.a; o.seqEnd += ev.a; }
+        for (t4_cand &o : e.cands) if (o.seqIdx == ev.c) { o.ss += ev.a; o.se += ev.a; }
       } else if (ev.kind == 1 && e.standing()) e.shifts.push_back({ev.c, ev.a});   // its records are still to come
     }
   }
@@ -1738,14 +1765,14 @@ void t4_assembler::processEvents() {
         if (e.uid != o.uid || !e.standing()) continue;
         if (e.inflight && e.expectWide && !e.hasDev) { kill(e, invKey); continue; }
         if (e.fragile) { kill(e, invFragile); ++invLongLists; continue; }
-        if (e.partial && e.pendingContig == ev.idx) { touch(e, ev.idx, invKey); continue; }
+        if (e.isPending(ev.idx)) { touch(e, ev.idx, invKey); continue; }
         for (uint32_t plus = 0; plus < 2 && e.standing(); ++plus) {
           const int n = (plus ? o.f : o.r) * (ev.delta > 0 ? ev.delta : -ev.delta);
           if (!n) continue;
           if (ev.delta > 0) {
             Grp &g = e.getGroup((uint32_t)ev.idx * 2u + plus);
+            if (g.cnt + (uint32_t)n >= 3) { touch(e, ev.idx, invKey); break; }   // (the recorded size of a group of three or more stays what its last query found: mergeRestricted reads it)
             g.cnt += (uint32_t)n;
-            if (g.cnt >= 3) { touch(e, ev.idx, invKey); break; }
           } else {
             Grp *g = e.findGroup((uint32_t)ev.idx * 2u + plus);
             if (g && g->cnt >= 3) { touch(e, ev.idx, invKey); break; }
@@ -1790,6 +1817,7 @@ void t4_assembler::announceLive(int n, const char *const *reads, const int *stra
     c.uid = nextUid++; c.tier = 0; c.lastUs = 0; c.registered = false;
     c.hasDev = false; c.expectWide = false; c.devGroups.clear();
     c.partial = false; c.pendingContig = -1; c.merged = false; c.auxOk = false; c.restrictedCount = 0; c.kmerPos.clear();
+    c.cands.clear(); c.candOk = false; c.exactKeys.clear(); c.morePending.clear();
     order.push_back(sl);
   }
 }
@@ -1808,25 +1836,34 @@ int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive
     const int lim = getenv("T4_AQ_CAP_LIMIT") ? atoi(getenv("T4_AQ_CAP_LIMIT")) : 0;
     wideHitLimit = lim > 0 ? lim : (getenv("T4_WIDE_MIN_HITS") ? atoi(getenv("T4_WIDE_MIN_HITS")) : 8192);
   }
-  L.slots = todo; L.uids.resize(m); L.hint.resize(m); L.bcs.resize(m); L.sts.resize(m); L.fac.resize(m); L.only.resize(m);
+  // one item per whole query, one per contig a partial entry waits for (the items of an entry are adjacent)
+  L.slots.clear(); L.uids.clear(); L.hint.clear(); L.bcs.clear(); L.sts.clear(); L.fac.clear(); L.only.clear(); L.force.clear();
   L.bases.clear(); L.offs.assign(1, 0); L.repetitive = repetitive;
   bool anyOnly = false;
   for (int i = 0; i < m; ++i) {
     Cached &c = *pool[todo[i]];
-    L.uids[i] = c.uid; L.hint[i] = c.tier;
-    L.bases += c.read; L.offs.push_back((int64_t)L.bases.size()); L.bcs[i] = c.barcode; L.sts[i] = c.strand;
-    L.fac[i] = (c.barcode == -1 && !repetitive) ? 1.0 : 2.0;   // ExtendOverlap's mismatch factor (SeqSet.hpp:3597-3598)
+    const int nItems = c.partial ? 1 + (int)c.morePending.size() : 1;
+    for (int t = 0; t < nItems; ++t) {
+      L.slots.push_back(todo[i]); L.uids.push_back(c.uid); L.hint.push_back(c.tier);
+      L.bases += c.read; L.offs.push_back((int64_t)L.bases.size()); L.bcs.push_back(c.barcode); L.sts.push_back(c.strand);
+      L.fac.push_back((c.barcode == -1 && !repetitive) ? 1.0 : 2.0);   // ExtendOverlap's mismatch factor (SeqSet.hpp:3597-3598)
+      L.only.push_back(c.partial ? (t == 0 ? c.pendingContig : c.morePending[(size_t)t - 1]) : -1);
+      L.force.push_back((c.partial && c.candOk) ? ((c.minT[0] & 0xFFFF) | ((c.minT[1] & 0xFFFF) << 16)) : 0);   // the threshold the entry's other candidates were made with
+    }
     c.inflight = true; c.killed = false; c.shifts.clear();
-    L.only[i] = c.partial ? c.pendingContig : -1;
     if (c.partial) { anyOnly = true; continue; }   // restricted re-query: the entry keeps what it holds of the other contigs
     c.statsStable = false;
     c.hasDev = false; c.expectWide = false; c.devGroups.clear();
     c.auxOk = false; c.merged = false; c.restrictedCount = 0;
+    c.cands.clear(); c.candOk = false; c.exactKeys.clear();
   }
+  const int mi = (int)L.slots.size();
   if (L.bases.empty()) L.bases.push_back('A');
   {
     auto tq0 = std::chrono::steady_clock::now();
-    rc = t4_add_query_pool_begin(L.dev, m, L.bases.data(), L.offs.data(), L.bcs.data(), L.sts.data(), repetitive, L.fac.data(), L.hint.data(), anyOnly ? L.only.data() : nullptr);
+    candStore = !getenv("T4_CANDS_OFF");   // testing / A-B aid: the restricted path as round 4 had it (at most 44 candidates, ~100 groups of four hits)
+    rc = t4_add_query_pool_begin2(L.dev, mi, L.bases.data(), L.offs.data(), L.bcs.data(), L.sts.data(), repetitive, L.fac.data(), L.hint.data(), anyOnly ? L.only.data() : nullptr,
+                                  anyOnly ? L.force.data() : nullptr, candStore ? 1 : 0);
     secQuery += std::chrono::duration<double>(std::chrono::steady_clock::now() - tq0).count();
   }
   if (rc) { for (int sl : todo) pool[sl]->inflight = false; return rc; }
@@ -1859,6 +1896,172 @@ int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive
   if (nHelp > 0) helpers->wait();
   secGroups += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg1).count();
   return T4_OK;
+}
+
+// The scan of SeqSet.hpp:1673-2094 over a read's candidate overlaps (all on one strand, in scan order), as far as it looks across
+// contigs: which candidates the pre-filters of 1705-1794 cut. Every candidate carries its scored fields (the kernels score all of
+// them and replay the filters afterwards -- prefilterNovel, wideMergeKernel -- as does this function); bestNovelOverlap is the best
+// SCORED overlap so far by _overlap::operator< (2025-2027).
+void t4_assembler::replayScan(const std::vector<t4_cand> &cands, const std::vector<Seq> &seqs, int len, int radius, double repeatSim, std::vector<unsigned char> &cut) {
+  const int n = (int)cands.size();
+  cut.assign((size_t)n, 0);
+  if (n <= 50) return;   // (1705: the pre-filters are off)
+  auto simOf = [](const t4_cand &o) { return (o.flags & 2) ? 0.0 : (double)o.matchCnt / (double)(o.se - o.ss + 1 + o.re - o.rs + 1); };
+  int best = -1; double bs = 0;
+  for (int i = 0; i < n; ++i) {
+    const t4_cand &o = cands[i];
+    if (best != -1) {
+      const t4_cand &bn = cands[best];
+      const int m0 = o.m0;
+      bool c = false;
+      if (bn.rs == 0 && bn.re == len - 1) {
+        if (bs == 1) c = true;
+        else if (bs > repeatSim && m0 < 0.9 * bn.matchCnt) c = true;
+      }
+      if (!c && bn.rs + len - 1 - bn.re < radius) {
+        if (bs == 1 && m0 < 0.9 * bn.matchCnt) c = true;
+        else if (bs > repeatSim && m0 < 0.8 * bn.matchCnt) c = true;
+      }
+      if (!c && o.ss - o.rs >= radius && o.se + (len - 1 - o.re) + radius < (int)seqs[o.seqIdx].cons.size() &&
+          bn.matchCnt > 0.97 * (2 * len) && bs > repeatSim && m0 < 0.9 * bn.matchCnt) c = true;
+      if (!c && m0 < 0.4 * bn.matchCnt) c = true;
+      if (!c && n > 1000 && m0 < 0.9 * bn.matchCnt) c = true;
+      if (c) { cut[(size_t)i] = 1; continue; }
+    }
+    const double so = simOf(o);
+    if (!(so > 0)) continue;
+    bool better = best == -1;
+    if (!better) {   // _overlap::operator< with the scored fields (SeqSet.hpp:104-128)
+      const t4_cand &b = cands[best];
+      if (o.matchCnt != b.matchCnt) better = o.matchCnt > b.matchCnt;
+      else if (so != bs) better = so > bs;
+      else if (o.re - o.rs != b.re - b.rs) better = o.re - o.rs > b.re - b.rs;
+      else if (o.seqIdx != b.seqIdx) better = o.seqIdx < b.seqIdx;
+      else if ((o.flags & 1) != (b.flags & 1)) better = (o.flags & 1) < (b.flags & 1);
+      else if (o.rs != b.rs) better = o.rs < b.rs;
+      else if (o.re != b.re) better = o.re < b.re;
+      else if (o.ss != b.ss) better = o.ss < b.ss;
+      else better = o.se < b.se;
+    }
+    if (better) { best = i; bs = so; }
+  }
+}
+
+// A restricted re-query of contig pc came back for an entry that holds its candidate list: nc[0 .. ncnt) are ALL overlaps of the read
+// with pc (scored; ov / ex / rets are their result records, same order), s8 the true sizes of pc's two hit groups. Returns false
+// when the entry needs its whole query again.
+bool t4_assembler::mergeRestricted(Cached &c, int pc, int k2, const t4_overlap *ov, const t4_overlap *ex, const int32_t *rets, const t4_cand *nc, int ncnt, const int32_t *s8) {
+  const int len = (int)c.read.size();
+  for (int t = 0; t < ncnt; ++t) if (((nc[t].flags & 1) != 0) != c.strand0Plus) { ++candFallbackStrand; return false; }   // an overlap on the other strand: which strand is the best one's is open again
+  // ---- group statistics (SeqSet.hpp:784-823): pc's groups went from g0 to g1 hits; every other group of three or more is as it was
+  int n4lo[2], n4hi[2], n5lo[2], n5hi[2], smlo[2], smhi[2];
+  for (int t = 0; t < 2; ++t) {
+    const uint32_t key = (uint32_t)pc * 2u + (uint32_t)t;
+    const Grp *g = c.findGroup(key);
+    const int rec = g ? (int)g->cnt : 0;   // what the last query of this group found -- exactly (device records, or set by a restricted re-query) or as a superset (host-derived tables)
+    const bool exact = (c.hasDev && g && g >= c.devGroups.data() && g < c.devGroups.data() + c.devGroups.size()) || std::find(c.exactKeys.begin(), c.exactKeys.end(), key) != c.exactKeys.end();
+    const int g0hi = rec, g0lo = exact ? rec : 0, g1 = s8[4 + t];
+    n4lo[t] = c.n4lo[t] - (g0hi >= 4 ? 1 : 0) + (g1 >= 4 ? 1 : 0); n4hi[t] = c.n4hi[t] - (g0lo >= 4 ? 1 : 0) + (g1 >= 4 ? 1 : 0);
+    n5lo[t] = c.n5lo[t] - (g0hi >= 5 ? 1 : 0) + (g1 >= 5 ? 1 : 0); n5hi[t] = c.n5hi[t] - (g0lo >= 5 ? 1 : 0) + (g1 >= 5 ? 1 : 0);
+    if (n4lo[t] < 0) n4lo[t] = 0;
+    if (n5lo[t] < 0) n5lo[t] = 0;
+    smhi[t] = c.smhi[t] > g1 ? c.smhi[t] : g1;
+    if (g1 >= c.smhi[t]) smlo[t] = g1;                       // the new group is the largest
+    else if (g0hi < c.smlo[t]) smlo[t] = c.smlo[t];          // pc never was the largest: the largest of the others stands
+    else {                                                   // pc may have been the largest: the largest of the others, from the records when they are exact
+      int others = 0;
+      if (c.hasDev) { const size_t b = t ? c.devSplit : 0, e = t ? c.devGroups.size() : c.devSplit; for (size_t q = b; q < e; ++q) if (c.devGroups[q].key != key && (int)c.devGroups[q].cnt > others) others = (int)c.devGroups[q].cnt; }
+      smlo[t] = others > g1 ? others : g1;
+      if (smlo[t] > smhi[t]) smlo[t] = smhi[t];
+    }
+    // the certificate of overlapsFromKeys over the bounds: both corners give the threshold the entry's candidates were made with
+    const int lo = n5lo[t], hi = n4hi[t];
+    const int cLo = lo > 100000 ? 4 : lo > 10000 ? 3 : lo > 1000 ? 2 : lo > 100 ? 1 : 0;
+    const int cHi = hi > 100000 ? 4 : hi > 10000 ? 3 : hi > 1000 ? 2 : hi > 100 ? 1 : 0;
+    bool ok = cLo == cHi;
+    int T = 3;
+    if (ok && cLo > 0) {
+      const int a = smlo[t] - 1 > 0 ? smlo[t] - 1 : 0, big = smhi[t];
+      const int fa = cLo == 4 ? (int)(a * 0.75) : cLo == 3 ? a / 2 : cLo == 2 ? a / 3 : a / 4;
+      const int fb = cLo == 4 ? (int)(big * 0.75) : cLo == 3 ? big / 2 : cLo == 2 ? big / 3 : big / 4;
+      ok = fa == fb && fa >= 3;
+      T = fb;
+    }
+    if (!ok || T != c.minT[t]) { ++candFallbackStats; return false; }
+  }
+  // ---- the candidate list with pc's candidates swapped, in scan order: m0 desc, read span desc, contig, strand, geometry (operator< before scoring)
+  struct Item { t4_cand o; int src; unsigned char wasCut; };   // src: index into nc, -1 for a kept candidate
+  static thread_local std::vector<Item> items, fresh;
+  items.clear(); fresh.clear();
+  auto before = [](const t4_cand &a, const t4_cand &b) {
+    if (a.m0 != b.m0) return a.m0 > b.m0;
+    if (a.re - a.rs != b.re - b.rs) return a.re - a.rs > b.re - b.rs;
+    if (a.seqIdx != b.seqIdx) return a.seqIdx < b.seqIdx;
+    if ((a.flags & 1) != (b.flags & 1)) return (a.flags & 1) < (b.flags & 1);
+    if (a.rs != b.rs) return a.rs < b.rs;
+    if (a.re != b.re) return a.re < b.re;
+    if (a.ss != b.ss) return a.ss < b.ss;
+    return a.se < b.se;
+  };
+  for (int t = 0; t < ncnt; ++t) { Item it; it.o = nc[t]; it.o.flags &= (unsigned short)~4u; it.src = t; it.wasCut = 0; fresh.push_back(it); }
+  std::sort(fresh.begin(), fresh.end(), [&](const Item &a, const Item &b) { return before(a.o, b.o); });
+  {
+    size_t f = 0;
+    for (const t4_cand &o : c.cands) {
+      if (o.seqIdx == pc) continue;
+      while (f < fresh.size() && before(fresh[f].o, o)) items.push_back(fresh[f++]);
+      Item it; it.o = o; it.src = -1; it.wasCut = (o.flags & 4) ? 1 : 0; items.push_back(it);
+    }
+    while (f < fresh.size()) items.push_back(fresh[f++]);
+  }
+  static thread_local std::vector<t4_cand> list;
+  static thread_local std::vector<unsigned char> cut;
+  list.resize(items.size());
+  for (size_t t = 0; t < items.size(); ++t) list[t] = items[t].o;
+  replayScan(list, seqs, len, radius, 0.95, cut);
+  auto simOf = [](const t4_cand &o) { return (o.flags & 2) ? 0.0 : (double)o.matchCnt / (double)(o.se - o.ss + 1 + o.re - o.rs + 1); };
+  bool anyRecut = false;
+  for (size_t t = 0; t < items.size(); ++t) {
+    if (items[t].src >= 0) continue;
+    if (items[t].wasCut && !cut[t] && !(simOf(items[t].o) < novelSim)) { ++candFallbackUncut; return false; }   // it passes now, and its ExtendOverlap record was never made
+    if (!items[t].wasCut && cut[t]) anyRecut = true;
+  }
+  // ---- the entry's result records: those of pc and of candidates that are cut now leave, pc's survivors come in
+  auto sameGeom = [](const t4_overlap &r, const t4_cand &o) { return r.seqIdx == o.seqIdx && r.readStart == o.rs && r.readEnd == o.re && r.seqStart == o.ss && r.seqEnd == o.se; };
+  size_t w = 0;
+  for (size_t t = 0; t < c.ov.size(); ++t) {
+    bool keep = c.ov[t].seqIdx != pc;
+    if (keep && anyRecut) for (size_t q = 0; q < items.size() && keep; ++q) if (items[q].src < 0 && !items[q].wasCut && cut[q] && sameGeom(c.ov[t], items[q].o)) keep = false;
+    if (!keep) continue;
+    if (w != t) { c.ov[w] = c.ov[t]; c.ext[w] = c.ext[t]; c.extRet[w] = c.extRet[t]; }
+    ++w;
+  }
+  c.ov.resize(w); c.ext.resize(w); c.extRet.resize(w);
+  for (size_t t = 0; t < items.size(); ++t) {
+    const int j = items[t].src;
+    if (j < 0 || cut[t]) continue;
+    if (ov[j].similarity < novelSim) continue;   // the similarity cut (SeqSet.hpp:2105-2119)
+    c.ov.push_back(ov[j]); c.ext.push_back(ex[j]); c.extRet.push_back(rets[j]);
+  }
+  (void)k2;
+  if (anyRecut) ++candRecut;
+  if (items.size() > 50) ++candMergesBig;
+  if (n4hi[0] > 100 || n4hi[1] > 100) ++candMergesStats;
+  c.cnt = (int32_t)c.ov.size();
+  c.cands.resize(items.size());
+  for (size_t t = 0; t < items.size(); ++t) { c.cands[t] = items[t].o; if (cut[t]) c.cands[t].flags |= 4; else c.cands[t].flags &= (unsigned short)~4u; }
+  for (int t = 0; t < 2; ++t) { c.n4lo[t] = n4lo[t]; c.n4hi[t] = n4hi[t]; c.n5lo[t] = n5lo[t]; c.n5hi[t] = n5hi[t]; c.smlo[t] = smlo[t]; c.smhi[t] = smhi[t]; }
+  c.nAll = c.nAllBound = (int)c.cands.size();
+  // the dependency record of pc: hull from the contig's consensus (rebuildGroup), hits as the query counted them
+  rebuildGroup(c, pc);
+  for (int t = 0; t < 2; ++t) {
+    const uint32_t key = (uint32_t)pc * 2u + (uint32_t)t;
+    if (s8[4 + t] > 0 || c.findGroup(key)) c.getGroup(key).cnt = (uint32_t)s8[4 + t];
+    if (std::find(c.exactKeys.begin(), c.exactKeys.end(), key) == c.exactKeys.end()) c.exactKeys.push_back(key);
+  }
+  c.statsStable = true; c.n4 = c.n4hi[0] + c.n4hi[1]; c.slack = 99 - c.n4;
+  ++candMerges;
+  return true;
 }
 
 // The lane's job is over (waits for it if need be): entries that still stand take their records, with the left extensions that
@@ -1898,34 +2101,57 @@ int t4_assembler::harvest(Lane &L) {
   if (!noStable) (void)t4_add_query_last_stable(L.ctx, &stable, &nStable);
   const int32_t *aux = nullptr, *n4s = nullptr, *qstatus = nullptr; int nAux = 0;
   (void)t4_add_query_last_aux(L.ctx, &aux, &n4s, &qstatus, &nAux);
+  const t4_cand *candPool = nullptr; const int32_t *candBase = nullptr, *candCnt = nullptr, *stats8 = nullptr; int nCand = 0;
+  (void)t4_add_query_last_cands(L.ctx, &candPool, &candBase, &candCnt, &stats8, &nCand);
   for (int i = 0; i < m; ++i) {
     Cached &c = *pool[L.slots[i]];
     if (c.uid != L.uids[i] || !c.inflight) continue;   // the entry was retired (or re-announced) meanwhile
     c.inflight = false;
     if (L.only[i] >= 0) {
-      // ---- a restricted re-query comes back: every overlap of the read with contig pc, scored and extended
-      const int pc = L.only[i];
-      if (c.killed) { c.killed = false; ++killedInFlight; continue; }   // the contig changed again meanwhile (the entry stays partial), or the whole entry fell
-      if (!c.partial || c.pendingContig != pc) continue;
-      const int k2 = cnts[i] > 0 ? cnts[i] : 0;
-      bool ok = !(qstatus && i < nAux && qstatus[i] == 5);
-      for (int t = 0; ok && t < k2; ++t) if ((ov[bas[i] + t].strand == 1) != c.strand0Plus) ok = false;   // an overlap on the other strand: which strand is the best one's is open again
-      c.nAllBound += k2;
-      if (c.nAllBound > 50) ok = false;   // (the pre-filters of SeqSet.hpp:1705 may be on now)
-      if (!ok) { c.partial = false; c.pendingContig = -1; ++restrictedFallbacks; continue; }   // neither valid nor partial: the whole query, next launch
-      size_t w = 0;
-      for (size_t t = 0; t < c.ov.size(); ++t) if (c.ov[t].seqIdx != pc) { if (w != t) { c.ov[w] = c.ov[t]; c.ext[w] = c.ext[t]; c.extRet[w] = c.extRet[t]; } ++w; }
-      c.ov.resize(w); c.ext.resize(w); c.extRet.resize(w);
-      for (int t = 0; t < k2; ++t) {
-        const t4_overlap &o = ov[bas[i] + t];
-        if (o.similarity < novelSim) continue;   // the similarity cut (SeqSet.hpp:2105-2119)
-        c.ov.push_back(o); c.ext.push_back(ex[bas[i] + t]); c.extRet.push_back(rets[bas[i] + t]);
+      // ---- restricted re-queries come back: every overlap of the read with one contig, scored and extended -- one item per contig
+      // the entry waited for when the launch went out (adjacent items)
+      int j = i + 1;
+      while (j < m && L.slots[j] == L.slots[i] && L.uids[j] == L.uids[i] && L.only[j] >= 0) ++j;
+      const int i0 = i;
+      i = j - 1;
+      if (c.killed) { c.killed = false; ++killedInFlight; continue; }   // a contig it waits for changed again meanwhile (the entry stays partial), or the whole entry fell
+      if (!c.partial) continue;
+      bool fell = false;
+      for (int q = i0; q < j && !fell; ++q) {
+        const int pc = L.only[q];
+        if (!c.isPending(pc)) continue;
+        const int k2 = cnts[q] > 0 ? cnts[q] : 0;
+        if (c.candOk) {   // the candidate store: swap the contig's candidates, repeat the scan, check the group statistics
+          const bool fits = !(qstatus && q < nAux && qstatus[q] == 5) && candPool && candCnt && q < nCand && candCnt[q] == k2;
+          if (fits && mergeRestricted(c, pc, k2, ov + bas[q], ex + bas[q], rets + bas[q], candPool + (k2 ? candBase[q] : 0), k2, stats8 + 8 * (size_t)q)) {
+            ++c.restrictedCount; ++restrictedMerged;
+          } else { fell = true; c.candOk = false; if (!fits) ++candFallbackOther; }
+        } else {
+          bool ok = !(qstatus && q < nAux && qstatus[q] == 5);
+          for (int t = 0; ok && t < k2; ++t) if ((ov[bas[q] + t].strand == 1) != c.strand0Plus) ok = false;   // an overlap on the other strand: which strand is the best one's is open again
+          c.nAllBound += k2;
+          if (c.nAllBound > 50) ok = false;   // (the pre-filters of SeqSet.hpp:1705 may be on now)
+          if (!ok) { fell = true; break; }
+          size_t w = 0;
+          for (size_t t = 0; t < c.ov.size(); ++t) if (c.ov[t].seqIdx != pc) { if (w != t) { c.ov[w] = c.ov[t]; c.ext[w] = c.ext[t]; c.extRet[w] = c.extRet[t]; } ++w; }
+          c.ov.resize(w); c.ext.resize(w); c.extRet.resize(w);
+          for (int t = 0; t < k2; ++t) {
+            const t4_overlap &o = ov[bas[q] + t];
+            if (o.similarity < novelSim) continue;   // the similarity cut (SeqSet.hpp:2105-2119)
+            c.ov.push_back(o); c.ext.push_back(ex[bas[q] + t]); c.extRet.push_back(rets[bas[q] + t]);
+          }
+          c.cnt = (int32_t)c.ov.size();
+          rebuildGroup(c, pc);
+          ++c.restrictedCount; ++restrictedMerged;
+        }
+        if (!fell) {   // this contig is served
+          if (c.pendingContig == pc) { if (c.morePending.empty()) c.pendingContig = -1; else { c.pendingContig = c.morePending.back(); c.morePending.pop_back(); } }
+          else c.morePending.erase(std::find(c.morePending.begin(), c.morePending.end(), pc));
+        }
       }
-      c.cnt = (int32_t)c.ov.size();
-      rebuildGroup(c, pc);
-      c.partial = false; c.pendingContig = -1; c.merged = true; ++c.restrictedCount;
-      c.valid = true;
-      ++restrictedMerged;
+      if (fell) { c.partial = false; c.pendingContig = -1; c.morePending.clear(); ++restrictedFallbacks; continue; }   // neither valid nor partial: the whole query, next launch
+      c.merged = true;
+      if (c.pendingContig < 0) { c.partial = false; c.valid = true; }   // (else a contig joined while the launch was out: the entry goes on waiting for that one)
       continue;
     }
     c.tier = L.hint[i];
@@ -1941,9 +2167,32 @@ int t4_assembler::harvest(Lane &L) {
       for (t4_overlap &o : c.ov) if (o.seqIdx == sh.first) { o.seqStart += sh.second; o.seqEnd += sh.second; }
       for (t4_overlap &o : c.ext) if (o.seqIdx == sh.first) { o.seqStart += sh.second; o.seqEnd += sh.second; }
     }
-    c.shifts.clear();
+    std::vector<std::pair<int, int>> shiftsOfCall; shiftsOfCall.swap(c.shifts);   // (the candidate records below take them too)
     if (aux && i < nAux && aux[i] >= 0) { c.nAll = aux[i] & 32767; c.nOther = (aux[i] >> 15) & 32767; c.strand0Plus = ((aux[i] >> 30) & 1) != 0; c.n4 = n4s[i]; c.nAllBound = c.nAll; c.auxOk = true; }
     else c.auxOk = false;
+    c.cands.clear(); c.candOk = false; c.exactKeys.clear();
+    if (candStore && c.auxOk && candPool && candCnt && i < nCand && candCnt[i] == c.nAll && c.nAll < 32767 && c.nOther == 0) {
+      c.cands.assign(candPool + (c.nAll ? candBase[i] : 0), candPool + (c.nAll ? candBase[i] : 0) + c.nAll);
+      for (const auto &sh : shiftsOfCall) for (t4_cand &o : c.cands) if (o.seqIdx == sh.first) { o.ss += sh.second; o.se += sh.second; }
+      const int32_t *s8 = stats8 + 8 * (size_t)i;
+      for (int t = 0; t < 2; ++t) { c.n4lo[t] = c.n4hi[t] = s8[t]; c.n5lo[t] = c.n5hi[t] = s8[2 + t]; c.smlo[t] = c.smhi[t] = s8[4 + t]; c.minT[t] = s8[6 + t] > 0 ? s8[6 + t] : 3; }
+      c.candOk = true; candRecords += c.nAll;
+      if (knobs.verifyWindow && c.cnt >= 0) {   // the host's scan against the kernel's: the same cuts, the same survivors of the similarity cut
+        std::vector<unsigned char> cut;
+        replayScan(c.cands, seqs, (int)c.read.size(), radius, 0.95, cut);
+        int survivors = 0; bool same = true;
+        for (size_t t = 0; t < c.cands.size(); ++t) {
+          const t4_cand &o = c.cands[t];
+          if ((cut[t] != 0) != ((o.flags & 4) != 0)) same = false;
+          if (!cut[t] && !(o.flags & 2) && !((double)o.matchCnt / (double)(o.se - o.ss + 1 + o.re - o.rs + 1) < novelSim)) ++survivors;
+        }
+        ++candSelfChecks;
+        if (!same || survivors != (c.cnt > 0 ? c.cnt : 0)) {
+          fprintf(stderr, "T4_VERIFY_WINDOW: the host's replay of the pre-filter scan differs from the query's (entry %lld, %d candidates, %d survivors against %d records)\n", (long long)c.uid, c.nAll, survivors, c.cnt);
+          err = "candidate scan mismatch"; return T4_ERR_STATE;
+        }
+      }
+    }
     {
       const t4_grp *dg = nullptr; int ng = 0, huge = 0, n4 = 0;
       if (t4_add_query_groups(L.ctx, i, &dg, &ng, &huge, &n4) == 1) {
@@ -2277,6 +2526,8 @@ int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n) {
             (long long)a->restrictedMarks, (long long)a->restrictedMerged, (long long)a->restrictedFallbacks, (long long)a->restrictedStale);
     fprintf(stderr, "timing: entries that fell whole when one contig changed: %lld with lists beyond 10000 postings, %lld with overlaps on the other strand, %lld with more than 44 candidate overlaps, %lld with ~100 groups of four hits, %lld without the query's report, %lld other\n",
             (long long)a->whyNot[0], (long long)a->whyNot[1], (long long)a->whyNot[2], (long long)a->whyNot[3], (long long)a->whyNot[4], (long long)a->whyNot[5]);
+    fprintf(stderr, "timing: candidate store: %lld candidate records kept with whole queries, %lld restricted re-queries merged through the replay of the scan (%lld with more than 50 candidates, %lld with more than 100 groups of four hits on a strand, %lld cut a candidate of another contig), fell back to the whole query: %lld a cut candidate of another contig passes now, %lld the group statistics could move the threshold, %lld an overlap on the other strand, %lld other; %lld whole queries checked against the host's scan\n",
+            (long long)a->candRecords, (long long)a->candMerges, (long long)a->candMergesBig, (long long)a->candMergesStats, (long long)a->candRecut, (long long)a->candFallbackUncut, (long long)a->candFallbackStats, (long long)a->candFallbackStrand, (long long)a->candFallbackOther, (long long)a->candSelfChecks);
     fprintf(stderr, "timing: wide query served %lld window entries (%lld dependency records came back with them), %lld reads it was expected for stayed on the LDS tier\n", (long long)a->wideServed, (long long)a->wideGroupRecords, (long long)a->wideMispredicted);
   }
   return T4_OK;

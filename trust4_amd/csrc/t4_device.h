@@ -162,6 +162,19 @@ struct T4OverlapOut {        // == t4_overlap of include/trust4_hip.h
 
 struct T4HitOut { int idx, offset, readOffset, strand, repeats; };  // == t4_hit
 
+// one candidate overlap of an AddRead query, 24 bytes (see T4QueryArgs::candOut); == t4_cand of t4_internal.h
+struct T4Cand {
+  int seqIdx, ss, se;
+  short rs, re;
+  short m0;                  // matchCnt of GetOverlapsFromHits: the sort key of the scan
+  short matchCnt;            // scored (SeqSet.hpp:2009)
+  short indelCnt;
+  unsigned short flags;      // 1: plus strand, 2: scoring left similarity 0, 4: cut by the pre-filters (its scored fields are still the scored ones)
+};
+#define T4_CAND_PLUS 1
+#define T4_CAND_SIMZERO 2
+#define T4_CAND_CUT 4
+
 struct T4QueryArgs {
   int mode;                  // 0: overlaps (GetOverlapsFromRead), 1: annotate level 0, 2: AssignRead, 3: ExtendOverlap of given overlaps, 4: AddRead query
   int strand;                // strand argument of GetOverlapsFromRead
@@ -201,6 +214,21 @@ struct T4QueryArgs {
   const int *onlySeq;
   int *aux;
   int *n4;
+  // mode 4, nullable -- the candidate store of the ordered builder. cand*: EVERY overlap of the read on the strand of
+  // the best one as it stands before the similarity cut (a restricted re-query: every overlap with the one contig, both strands), in
+  // the order of the scan of SeqSet.hpp:1673-2094, with its pre-score key, its scored fields and whether the pre-filters of 1705-1794
+  // cut it: what a host-side replay of that scan needs after ONE contig's candidates were replaced. Room is taken from a pool in
+  // pinned host memory by one atomic per read (candCursor; an overflow raises candOverflow and the host repeats the call).
+  // stats8[8 r ..]: per strand (minus, plus) the groups of >= 4 and of >= 5 hits (true sizes), the largest group, and the
+  // novelMinHitRequired the pass used (SeqSet.hpp:784-823). forceMin[r] (restricted re-queries): that threshold for the one contig's
+  // groups, minus | plus << 16 (0: the pass's own statistics -- 3 for a single contig).
+  struct T4Cand *candOut;
+  unsigned *candCursor;
+  int *candOverflow;
+  int candCap;
+  int *candBase, *candCnt;
+  int *stats8;
+  const int *forceMin;
   // per-read set images (per-barcode contig sets): read r is matched against views[viewOf[r]]
   const T4IndexView *views;
   const int *viewOf;

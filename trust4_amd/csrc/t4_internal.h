@@ -52,6 +52,16 @@ int t4_add_query_pool(t4_index *ix, int n, const char *bases, const int64_t *off
 // scored and extended, none of the steps that look across contigs applied (the restricted re-query of a window entry)
 int t4_add_query_pool_begin(t4_index *ix, int n, const char *bases, const int64_t *offsets, const int32_t *barcodes, const int32_t *strands,
                             int skip_repeats, const double *factors, unsigned char *tier_hint, const int32_t *only_seq);
+// The candidate store: with want_cands the call also returns, per read, EVERY scored overlap of the pass on the strand of
+// the best one as it stands before the similarity cut (a restricted re-query: every overlap with its one contig) in the order of the
+// scan of SeqSet.hpp:1673-2094 -- pre-score key, scored fields, whether the pre-filters of 1705-1794 cut it -- and eight statistics
+// words per read: per strand (minus, plus) the groups of >= 4 hits, of >= 5 hits, the largest group (true sizes; a restricted
+// re-query: of its one contig) and the novelMinHitRequired the pass used (SeqSet.hpp:784-823). force_min (nullable, restricted
+// re-queries): that threshold for the one contig's groups, minus | plus << 16 (0: three hits).
+typedef struct { int32_t seqIdx, ss, se; int16_t rs, re, m0, matchCnt, indelCnt; uint16_t flags; } t4_cand;   // flags: 1 plus strand, 2 scoring left similarity 0, 4 cut by the pre-filters
+int t4_add_query_pool_begin2(t4_index *ix, int n, const char *bases, const int64_t *offsets, const int32_t *barcodes, const int32_t *strands,
+                             int skip_repeats, const double *factors, unsigned char *tier_hint, const int32_t *only_seq, const int32_t *force_min, int want_cands);
+int t4_add_query_last_cands(t4_ctx *ctx, const t4_cand **pool, const int32_t **base, const int32_t **cnt, const int32_t **stats8, int *n);
 int t4_add_query_last_aux(t4_ctx *ctx, const int32_t **aux, const int32_t **n4, const int32_t **status, int *n);   // see T4QueryArgs::aux / n4
 int t4_add_query_pool_done(t4_ctx *ctx);
 int t4_ctx_device(t4_ctx *ctx);   // the device ordinal the ctx was created on (t4_assembler opens further ctxs beside it: one per query lane)

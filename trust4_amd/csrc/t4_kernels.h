@@ -648,6 +648,7 @@ struct OvRec {
 #define OV_PLUS 1
 #define OV_SIMZERO 2
 #define OV_ISREF 4
+#define OV_CUT 8           // cut by the pre-filters of SeqSet.hpp:1705-1794 (mode 4: its scored fields are stashed in chainPos, see ovStashScored)
 #define OV_GENETYPE(f) (((f) >> 8) & 255)
 #define OV_NAME0(f) ((char)(((f) >> 16) & 255))
 #define OV_NAME2(f) ((char)(((unsigned)(f)) >> 24))
@@ -680,6 +681,24 @@ __device__ __forceinline__ int ovCmp(const OvRec &a, const OvRec &b, bool scored
   return 0;
 }
 __device__ __forceinline__ bool ovLess(const OvRec &a, const OvRec &b, bool scored) { return ovCmp(a, b, scored) < 0; }
+
+// A pre-filter cut leaves the overlap as the reference's `continue` does (matchCnt of GetOverlapsFromHits, similarity 0). The scored
+// fields it had are kept in chainPos (dead once the overlaps are scored): the candidate store of the ordered builder hands them to
+// the host, whose replay of the scan may find the overlap uncut after another contig's candidates changed (T4QueryArgs::candOut).
+__device__ __forceinline__ void ovCutKeepScored(OvRec &o) {
+  o.chainPos = (o.matchCnt & 0xFFF) | ((o.indelCnt & 0xFFF) << 12) | ((o.flags & OV_SIMZERO) ? (1 << 24) : 0);
+  o.matchCnt = o.chainLen; o.indelCnt = 0; o.flags |= OV_SIMZERO | OV_CUT;
+}
+__device__ __forceinline__ T4Cand ovToCand(const OvRec &o) {   // o.chainLen holds the matchCnt of GetOverlapsFromHits (scoreOverlaps leaves it there)
+  T4Cand c;
+  c.seqIdx = o.seqIdx; c.ss = o.ss; c.se = o.se; c.rs = (short)o.rs; c.re = (short)o.re; c.m0 = (short)o.chainLen;
+  const bool cut = (o.flags & OV_CUT) != 0;
+  c.matchCnt = (short)(cut ? (o.chainPos & 0xFFF) : o.matchCnt);
+  c.indelCnt = (short)(cut ? ((o.chainPos >> 12) & 0xFFF) : o.indelCnt);
+  const bool simzero = cut ? ((o.chainPos >> 24) & 1) != 0 : (o.flags & OV_SIMZERO) != 0;
+  c.flags = (unsigned short)(((o.flags & OV_PLUS) ? T4_CAND_PLUS : 0) | (simzero ? T4_CAND_SIMZERO : 0) | (cut ? T4_CAND_CUT : 0));
+  return c;
+}
 
 // ------------------------------------------------------------------------------------------------
 // per-wave working set. CAP = hit capacity, MAXOV = overlap capacity. LDS tiers use static
@@ -728,6 +747,7 @@ struct WaveState { // wave-uniform scalars kept in LDS
   int nvPossible[2], nvLongest[2];   // novel group statistics of GetOverlapsFromHits (filter 1)
   int nvN4[2], nvN5[2], nvSmax[2];   // groups of at least 4 / 5 hits and the largest group, TRUE sizes (the statistics measure a group one short or in full)
   int statsStable;                   // no pass of this read so far whose novelMinHitRequired could move (see overlapsFromKeys)
+  int forceMin[2];                   // restricted re-query: novelMinHitRequired per strand as the entry's whole query had it (0: three hits), T4QueryArgs::forceMin
   int nAll, nOther, strand0;          // GetOverlapsFromRead: overlaps on the strand of the best one (before the similarity cut), on the other strand, that strand
   int wideWant;                      // mode 4, nonzero: a pass that emits more hits than this (or outgrows the global-scratch tier) is handed to the wide query (t4_wide.h)
   unsigned hhBest[2];        // HasHitInSet: per strand, (distinct read offsets << 16) | (0xFFFF - bucket rank) of the best bucket
@@ -1531,6 +1551,7 @@ __device__ void overlapsFromKeys(const T4IndexView &ix, WaveMem &wm, WaveState *
         if (!ok) ws->statsStable = 0;
       }
   }
+  if (filter == 0 && lane == 0) { if (ws->forceMin[0] > 0) ws->novelMin[0] = ws->forceMin[0]; if (ws->forceMin[1] > 0) ws->novelMin[1] = ws->forceMin[1]; }
   __syncthreads();
   PHASE_MARK(ws, 5);
   // R1: run starts are compacted (wm.pairs is dead here); a run is the stretch up to the next start, so nobody walks a
@@ -2296,7 +2317,16 @@ __device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, 
     if (Hv < 0) return -1;
     if (Hv > 1) { if (wm.ldsArrays) bitonicSortRegLds(wm.keys, Hv); else bitonicSort(wm.keys, Hv); }
     __syncthreads();
-    overlapsFromKeys(ix, wm, ws, Hv, hitLenRequired, 0);   // (filter 0: the thresholds stay at three hits -- the caller has made sure the group statistics leave them there)
+    // the contig's two groups (true sizes): what the caller's bookkeeping of the group statistics needs (T4QueryArgs::stats8)
+    int nPlus = 0;
+    for (int i = lane; i < Hv; i += NT) nPlus += (int)(wm.keys[i] >> 63);
+    nPlus = blockSum(nPlus, ws->red);
+    overlapsFromKeys(ix, wm, ws, Hv, hitLenRequired, 0);   // (filter 0: the thresholds are the caller's -- ws->forceMin, else three hits: it has made sure the group statistics leave them there)
+    if (lane == 0) {
+      const int g[2] = {Hv - nPlus, nPlus};
+      for (int t = 0; t < 2; ++t) { ws->nvN4[t] = g[t] >= 4 ? 1 : 0; ws->nvN5[t] = g[t] >= 5 ? 1 : 0; ws->nvSmax[t] = g[t]; }
+    }
+    __syncthreads();
     return H;
   }
   if (NOVEL && !allowTotalSkip && !vjOnly && filter == 1 && H > 10000) {
@@ -2451,7 +2481,7 @@ __device__ T4_PREFILTER_NI void prefilterNovel(const T4IndexView &ix, WaveMem &w
       __syncthreads();
       const int f = ws->red[0];
       if (cut && i < f) {   // final: the best it was judged against is the one the sequential pass would have used
-        o.matchCnt = o.chainLen; o.indelCnt = 0; o.flags |= OV_SIMZERO;
+        ovCutKeepScored(o);
         wm.ov[slot] = o;
         from = 0x7FFFFFFF;
       }
@@ -3429,7 +3459,7 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
   const int lane = tid(), NT = nthr();
   const int len = bv.len[r];
   unsigned long long hitTotal = 0;
-  if (lane == 0) { ws->overflow = 0; ws->unsupported = 0; ws->finCount = 0; ws->nContig = 0; ws->ovCount = 0; ws->statsStable = 1; ws->wideWant = 0; ws->nvN4[0] = ws->nvN4[1] = 0; }
+  if (lane == 0) { ws->overflow = 0; ws->unsupported = 0; ws->finCount = 0; ws->nContig = 0; ws->ovCount = 0; ws->statsStable = 1; ws->wideWant = 0; ws->nvN4[0] = ws->nvN4[1] = 0; ws->forceMin[0] = ws->forceMin[1] = 0; }
 #ifdef T4_PHASE_TIMING
   if (lane == 0) { ws->phaseT0 = clock64(); ws->phaseBase = wm.ldsArrays ? 0 : 32; ws->curPhase = ws->phaseBase; }
 #endif
@@ -3445,6 +3475,8 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
     const int onlySeq = qa.onlySeq ? qa.onlySeq[r] : -1;
     const bool wide = onlySeq < 0 && wk.wide != nullptr && !qa.skipRepeats && barcode == -1 && ix.hasNovel == 2 && !qa.views && qa.extendLater > 0;
     if (lane == 0) ws->wideWant = wide ? (wk.wide->minHits > 0 ? wk.wide->minHits : 1) : 0;
+    if (lane == 0 && onlySeq >= 0 && qa.forceMin) { ws->forceMin[0] = qa.forceMin[r] & 0xFFFF; ws->forceMin[1] = (qa.forceMin[r] >> 16) & 0xFFFF; }
+    if (lane == 0 && qa.candCnt) qa.candCnt[r] = 0;
     loadSegment(bv, r, 0, len, wm);
     int ret = overlapsFromSegment<VARIANT != 0>(ix, wm, ws, len, qa.strandPerRead[r], barcode, qa.skipRepeats != 0, 0, sc, hitTotal, onlySeq);
     if (onlySeq >= 0 && ret == -2) {   // (one contig's hits or overlaps beyond this workgroup's arrays: the caller asks for the whole query instead)
@@ -3464,6 +3496,29 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
     if (ret == -2) return false;
     int n = ret > 0 ? ret : 0;
     if (lane == 0 && qa.statsStable) qa.statsStable[r] = ws->statsStable;
+    if (qa.stats8 && lane < 2) {
+      int *s8 = qa.stats8 + 8 * r;
+      s8[lane] = ws->nvN4[lane]; s8[2 + lane] = ws->nvN5[lane]; s8[4 + lane] = ws->nvSmax[lane]; s8[6 + lane] = ws->novelMin[lane];
+    }
+    if (qa.candOut && ret >= 0) {
+      // the candidate store: every scored overlap of the pass, in scan order (wm.ov / wm.ord stand as overlapsFromSegment left them;
+      // a restricted re-query keeps them in wm.ov[0 .. ovCount) unordered)
+      const int nc = onlySeq >= 0 ? ws->ovCount : ws->nAll;
+      if (nc > 0) {
+        if (lane == 0) {
+          const unsigned cb = atomicAdd(qa.candCursor, (unsigned)nc);
+          ws->red[13] = (cb + (unsigned)nc > (unsigned)qa.candCap) ? -1 : (int)cb;
+          if (ws->red[13] < 0) atomicOr(qa.candOverflow, 1);
+        }
+        __syncthreads();
+        const int cb = ws->red[13];
+        if (cb >= 0) {
+          for (int i = lane; i < nc; i += NT) qa.candOut[cb + i] = ovToCand(wm.ov[onlySeq >= 0 ? i : (int)wm.ord[i]]);
+          if (lane == 0) { qa.candBase[r] = cb; qa.candCnt[r] = nc; }
+        }
+        __syncthreads();
+      }
+    }
     if (lane == 0) {   // room for this read's records in the result pool
       const int base = n > 0 ? (int)atomicAdd(qa.poolCursor, (unsigned)n) : 0;
       ws->red[15] = (base + n > qa.poolCap) ? -1 : base;

@@ -278,6 +278,7 @@ __global__ __launch_bounds__(512) void wideSortKernel(T4IndexView ix, T4Wide wd)
 #define WS_M 5           // entries of uniqPref that mean something (0: not a huge read)
 #define WS_GROUPS 6
 #define WS_N4 7          // groups of four or more hits, both strands
+#define WS_STATS8 8      // [8] per strand: groups of >= 4 hits, of >= 5 hits, the largest group, novelMinHitRequired (T4QueryArgs::stats8)
 
 // SeqSet.hpp:784-823 over all groups of one read, in the reference's order: every minus-strand group by contig, then every
 // plus-strand group (a partition holds a contig range of both).
@@ -386,6 +387,7 @@ __global__ __launch_bounds__(512) void wideStatsKernel(T4IndexView ix, T4Wide wd
       st[WS_M] = 0;
       st[WS_GROUPS] = G;
       st[WS_N4] = s_acc[4] + s_acc[5];
+      for (int t = 0; t <= 1; ++t) { st[WS_STATS8 + t] = s_acc[4 + t]; st[WS_STATS8 + 2 + t] = s_acc[6 + t]; st[WS_STATS8 + 4 + t] = s_acc[8 + t]; st[WS_STATS8 + 6 + t] = st[WS_NOVELMIN + t]; }
     }
     __syncthreads();
     if (!pl.huge || !(s_acc[10] | s_acc[11])) continue;
@@ -645,6 +647,8 @@ __global__ __launch_bounds__(512) void wideMergeKernel(T4IndexView ix, T4BatchVi
     const int *st = wd.stat + (size_t)w * T4_WIDE_STAT;
     if (lane == 0 && qa.statsStable) qa.statsStable[r] = st[WS_STABLE];
     if (lane == 0 && qa.n4) qa.n4[r] = st[WS_N4];
+    if (qa.stats8 && lane < 8) qa.stats8[8 * r + lane] = st[WS_STATS8 + lane];
+    if (lane == 0 && qa.candCnt) qa.candCnt[r] = 0;
     if (N == 0) { if (lane == 0) { qa.counts[r] = 0; qa.outBase[r] = 0; if (qa.aux) qa.aux[r] = 0; } continue; }
     // std::sort(overlaps) (SeqSet.hpp:1597) on the records as GetOverlapsFromHits left them: matchCnt (kept in chainLen), read span,
     // contig, strand in one key with the record's index; ties on all four are settled by the rest of operator<
@@ -739,7 +743,7 @@ __global__ __launch_bounds__(512) void wideMergeKernel(T4IndexView ix, T4BatchVi
           __syncthreads();
           const int f = s_best;
           if (cut && i < f) {
-            o.matchCnt = o.chainLen; o.indelCnt = 0; o.flags |= OV_SIMZERO;
+            ovCutKeepScored(o);
             *op = o;
             from = 0x7FFFFFFF;
           }
@@ -749,6 +753,20 @@ __global__ __launch_bounds__(512) void wideMergeKernel(T4IndexView ix, T4BatchVi
           bn = *wideRec(wd, pl, ord[f]);
           from = from == 0x7FFFFFFF ? from : f + 1;
         }
+      }
+      __syncthreads();
+    }
+    if (qa.candOut && cnt > 0) {   // the candidate store (T4QueryArgs::candOut): every overlap on the strand of the best one, in scan order
+      if (lane == 0) {
+        const unsigned cb = atomicAdd(qa.candCursor, (unsigned)cnt);
+        s_red[13] = (cb + (unsigned)cnt > (unsigned)qa.candCap) ? -1 : (int)cb;
+        if (s_red[13] < 0) atomicOr(qa.candOverflow, 1);
+      }
+      __syncthreads();
+      const int cb = s_red[13];
+      if (cb >= 0) {
+        for (int i = lane; i < cnt; i += NT) qa.candOut[cb + i] = ovToCand(*wideRec(wd, pl, ord[i]));
+        if (lane == 0) { qa.candBase[r] = cb; qa.candCnt[r] = cnt; }
       }
       __syncthreads();
     }

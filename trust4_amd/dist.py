@@ -1,5 +1,5 @@
-"""Multi-GPU plumbing of bench.py: one process per GPU, read batches sharded by rank, no data-path
-collective on the read-only passes; only a barrier and a max-reduce of the timed interval."""
+"""Multi-GPU plumbing of bench.py / stage1_dist.py: one process per GPU; the launcher side only needs the process group, a barrier
+and the max-reduce of the timed interval (the exchange of a sharded sample happens inside the engine: t4_comm)."""
 import os
 
 
@@ -19,24 +19,10 @@ def init(backend):
     return dist
 
 
-def shard_seed(base_seed, rank):
-    """Weak scaling: every rank synthesises its own batch of the configured size from seed base+rank."""
-    return base_seed + rank
-
-
 def max_over_ranks(dist, seconds, device):
     if dist is None:
         return seconds
     import torch
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
-
-
-def sum_over_ranks(dist, value, device):
-    if dist is None:
-        return value
-    import torch
-    t = torch.tensor([value], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())

@@ -415,7 +415,7 @@ int main(int argc, char *argv[]) {
   // rank then publishes how its communicator came up (FILE.status.rank<r>) and reads everybody's; unless every rank says "ok" ALL
   // ranks give their communicator up and run the same exchange through files in FILE.files/ (a directory beside the id file: node-
   // local, as the id file is). The decision is the same on every rank, it is logged, and it is reported in the statistics JSON.
-  std::string transportNote = gatherDir.empty() ? (rcclIdPath.empty() ? "none" : "rccl") : "files";
+  std::string transportNote = gatherDir.empty() ? (rcclIdPath.empty() ? "none" : "RCCL") : "files";
   auto commUp = [&](int rank, int count, const std::string &idPath) -> bool {   // true: RCCL is up; false: the file transport is on (gatherDir set)
     gpuReady();
     const int irc = t4_comm_init(ctx, rank, count, idPath.c_str(), &comm);
@@ -438,7 +438,7 @@ int main(int argc, char *argv[]) {
     if (comm) { t4_comm_destroy(comm); comm = nullptr; }
     gatherDir = idPath + ".files";
     (void)mkdir(gatherDir.c_str(), 0777);
-    transportNote = "files (fallback from rccl: " + firstBad + ")";
+    transportNote = "files (fallback from RCCL: " + firstBad + ")";
     for (char &ch : transportNote) if (ch == '"' || ch == '\\' || ch == '\n') ch = ' ';
     if (rank == 0) PrintLog("RCCL did not come up on every rank (%s): the exchange runs through files in %s.", firstBad.c_str(), gatherDir.c_str());
     return false;
