@@ -70,7 +70,7 @@ struct AqCall {
   int n = 0, skipRepeats = 0, wpk = 0, wnm = 0, attempt = 0, nFirst = 0, nDirect = 0, threads = 512;
   unsigned char *tierHint = nullptr;
   std::vector<unsigned char> allGlobal;
-  size_t oPk, oNm, oLen, oBc, oSt, oLs, oVw, oFa, oOnly, oForce, oWide, oWideA, inBytes, pCb, pCc, pS8, pCnt, pSta, pNext, pNext2, pBase, pTick, pStab, pAux, pN4, pTail, pWctl, pWplan, pWstat, pWctlA, pWplanA, pWstatA, outBytes;
+  size_t oPk, oNm, oLen, oBc, oSt, oLs, oVw, oFa, oOnly, oForce, oCs, oWide, oWideA, inBytes, pCb, pCc, pS8, pCnt, pSta, pNext, pNext2, pBase, pTick, pStab, pAux, pN4, pTail, pWctl, pWplan, pWstat, pWctlA, pWplanA, pWstatA, outBytes;
   bool hasOnly = false, hasForce = false, wantCands = false;
   bool extendLater = false, wide = false;
   int wideSafety = 32;   // of sixteenths: partitions are planned for half of their capacity
@@ -1538,7 +1538,8 @@ int aqBegin(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const 
   q.oBc = al8(q.oLen + sizeof(int) * (size_t)n); q.oSt = al8(q.oBc + sizeof(int) * (size_t)n); q.oLs = al8(q.oSt + sizeof(int) * (size_t)n);
   q.oVw = al8(q.oLs + sizeof(int) * (size_t)n); q.oFa = al8(q.oVw + sizeof(int) * (size_t)n); q.oOnly = al8(q.oFa + sizeof(double) * (size_t)n);
   q.oForce = al8(q.oOnly + sizeof(int) * (size_t)n);
-  q.oWide = al8(q.oForce + sizeof(int) * (size_t)n); q.hasOnly = onlySeq != nullptr; q.hasForce = forceMin != nullptr; q.wantCands = wantCands;
+  q.oCs = al8(q.oForce + sizeof(int) * (size_t)n);
+  q.oWide = al8(q.oCs + sizeof(T4CandArgs)); q.hasOnly = onlySeq != nullptr; q.hasForce = forceMin != nullptr; q.wantCands = wantCands;
   q.oWideA = al8(q.oWide + sizeof(T4Wide)); q.inBytes = al8(q.oWideA + sizeof(T4Wide));
   q.pCnt = 0; q.pSta = al8(q.pCnt + sizeof(int) * (size_t)n); q.pNext = al8(q.pSta + sizeof(int) * (size_t)n);
   q.pNext2 = al8(q.pNext + sizeof(int) * (size_t)n); q.pBase = al8(q.pNext2 + sizeof(int) * (size_t)n);
@@ -1647,6 +1648,17 @@ int aqLaunch(t4_ctx *c) {
     wa.ctl = (int *)(c->aqOut + q.pWctlA); wa.plan = (T4WidePlan *)(c->aqOut + q.pWplanA); wa.stat = (int *)(c->aqOut + q.pWstatA);
     memcpy(c->aqInHost + q.oWideA, &wa, sizeof wa);
   }
+  {
+    T4CandArgs cs;
+    memset(&cs, 0, sizeof cs);
+    cs.stats8 = (int *)(c->aqOut + q.pS8);
+    if (q.hasForce) cs.forceMin = (const int *)(c->aqIn + q.oForce);
+    if (q.wantCands) {
+      cs.candOut = c->candPoolDev; cs.candCap = c->candCap; cs.candCursor = (unsigned *)(c->aqOut + q.pTail + 32); cs.candOverflow = (int *)(c->aqOut + q.pTail + 36);
+      cs.candBase = (int *)(c->aqOut + q.pCb); cs.candCnt = (int *)(c->aqOut + q.pCc);
+    }
+    memcpy(c->aqInHost + q.oCs, &cs, sizeof cs);
+  }
   HIPCHK(c, hipMemcpyAsync(c->aqIn, c->aqInHost, q.inBytes, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemsetAsync(c->aqOut, 0, q.outBytes, c->stream));   // counts, status, overflow lists, bases, tail
   T4BatchView &bv = q.bv;
@@ -1663,11 +1675,8 @@ int aqLaunch(t4_ctx *c) {
   qa.statsStable = (int *)(c->aqOut + q.pStab);
   qa.aux = (int *)(c->aqOut + q.pAux); qa.n4 = (int *)(c->aqOut + q.pN4);
   if (q.hasOnly) qa.onlySeq = (const int *)(c->aqIn + q.oOnly);
-  if (q.hasForce) qa.forceMin = (const int *)(c->aqIn + q.oForce);
-  qa.stats8 = (int *)(c->aqOut + q.pS8);
-  if (q.wantCands) {
-    qa.candOut = c->candPoolDev; qa.candCap = c->candCap; qa.candCursor = (unsigned *)(c->aqOut + q.pTail + 32); qa.candOverflow = (int *)(c->aqOut + q.pTail + 36);
-    qa.candBase = (int *)(c->aqOut + q.pCb); qa.candCnt = (int *)(c->aqOut + q.pCc);
+  {   // statistics words always; candidate records when asked for (the struct travels in the input blob: filled before the H2D copy above)
+    qa.cs = (const T4CandArgs *)(c->aqIn + q.oCs);
   }
   qa.leanExt = q.lean ? 1 : 0;
   if (q.views) { qa.views = q.views; qa.viewOf = (const int *)(c->aqIn + q.oVw); }

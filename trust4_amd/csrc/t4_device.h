@@ -171,6 +171,15 @@ struct T4Cand {
   short indelCnt;
   unsigned short flags;      // 1: plus strand, 2: scoring left similarity 0, 4: cut by the pre-filters (its scored fields are still the scored ones)
 };
+struct T4CandArgs {
+  T4Cand *candOut;
+  unsigned *candCursor;
+  int *candOverflow;
+  int candCap;
+  int *candBase, *candCnt;   // null with candOut
+  int *stats8;
+  const int *forceMin;       // nullable
+};
 #define T4_CAND_PLUS 1
 #define T4_CAND_SIMZERO 2
 #define T4_CAND_CUT 4
@@ -222,13 +231,7 @@ struct T4QueryArgs {
   // stats8[8 r ..]: per strand (minus, plus) the groups of >= 4 and of >= 5 hits (true sizes), the largest group, and the
   // novelMinHitRequired the pass used (SeqSet.hpp:784-823). forceMin[r] (restricted re-queries): that threshold for the one contig's
   // groups, minus | plus << 16 (0: the pass's own statistics -- 3 for a single contig).
-  struct T4Cand *candOut;
-  unsigned *candCursor;
-  int *candOverflow;
-  int candCap;
-  int *candBase, *candCnt;
-  int *stats8;
-  const int *forceMin;
+  const struct T4CandArgs *cs;   // (behind a pointer: every word of this struct costs the AddRead kernel private stack, see queryKernel)
   // per-read set images (per-barcode contig sets): read r is matched against views[viewOf[r]]
   const T4IndexView *views;
   const int *viewOf;

@@ -3453,6 +3453,26 @@ __device__ void extendOverlaps(const T4IndexView &ix, WaveMem &wm, WaveState *ws
 // (2, 3, 4). Separate instantiations: the extension code must not cost the rough-annotation kernels registers.
 #include "t4_wide.h"
 
+// The candidate store (T4QueryArgs::candOut): every scored overlap of the pass, in scan order (wm.ov / wm.ord stand as
+// overlapsFromSegment left them; a restricted re-query keeps them in wm.ov[0 .. ovCount) unordered). Out of line: its registers are its own.
+__device__ T4_NI void emitCands(const T4CandArgs *cs, WaveMem &wm, WaveState *ws, long long r, int nc, bool identity) {
+  const int lane = tid(), NT = nthr();
+  if (nc <= 0) return;
+  if (lane == 0) {
+    const unsigned cb = atomicAdd(cs->candCursor, (unsigned)nc);
+    ws->red[13] = (cb + (unsigned)nc > (unsigned)cs->candCap) ? -1 : (int)cb;
+    if (ws->red[13] < 0) atomicOr(cs->candOverflow, 1);
+  }
+  __syncthreads();
+  const int cb = ws->red[13];
+  if (cb >= 0) {
+    T4Cand *out = cs->candOut;
+    for (int i = lane; i < nc; i += NT) out[cb + i] = ovToCand(wm.ov[identity ? i : (int)wm.ord[i]]);
+    if (lane == 0) { cs->candBase[r] = cb; cs->candCnt[r] = nc; }
+  }
+  __syncthreads();
+}
+
 template <int VARIANT>
 __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const T4Work &wk, const T4QueryArgs &qa,
                             WaveMem &wm, WaveState *ws, long long r, DPScratch sc) {
@@ -3475,8 +3495,11 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
     const int onlySeq = qa.onlySeq ? qa.onlySeq[r] : -1;
     const bool wide = onlySeq < 0 && wk.wide != nullptr && !qa.skipRepeats && barcode == -1 && ix.hasNovel == 2 && !qa.views && qa.extendLater > 0;
     if (lane == 0) ws->wideWant = wide ? (wk.wide->minHits > 0 ? wk.wide->minHits : 1) : 0;
-    if (lane == 0 && onlySeq >= 0 && qa.forceMin) { ws->forceMin[0] = qa.forceMin[r] & 0xFFFF; ws->forceMin[1] = (qa.forceMin[r] >> 16) & 0xFFFF; }
-    if (lane == 0 && qa.candCnt) qa.candCnt[r] = 0;
+    if (lane == 0 && qa.cs) {
+      const T4CandArgs *cs = qa.cs;
+      if (onlySeq >= 0 && cs->forceMin) { const int f = cs->forceMin[r]; ws->forceMin[0] = f & 0xFFFF; ws->forceMin[1] = (f >> 16) & 0xFFFF; }
+      if (cs->candCnt) cs->candCnt[r] = 0;
+    }
     loadSegment(bv, r, 0, len, wm);
     int ret = overlapsFromSegment<VARIANT != 0>(ix, wm, ws, len, qa.strandPerRead[r], barcode, qa.skipRepeats != 0, 0, sc, hitTotal, onlySeq);
     if (onlySeq >= 0 && ret == -2) {   // (one contig's hits or overlaps beyond this workgroup's arrays: the caller asks for the whole query instead)
@@ -3496,29 +3519,11 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
     if (ret == -2) return false;
     int n = ret > 0 ? ret : 0;
     if (lane == 0 && qa.statsStable) qa.statsStable[r] = ws->statsStable;
-    if (qa.stats8 && lane < 2) {
-      int *s8 = qa.stats8 + 8 * r;
+    if (qa.cs && lane < 2) {
+      int *s8 = qa.cs->stats8 + 8 * r;
       s8[lane] = ws->nvN4[lane]; s8[2 + lane] = ws->nvN5[lane]; s8[4 + lane] = ws->nvSmax[lane]; s8[6 + lane] = ws->novelMin[lane];
     }
-    if (qa.candOut && ret >= 0) {
-      // the candidate store: every scored overlap of the pass, in scan order (wm.ov / wm.ord stand as overlapsFromSegment left them;
-      // a restricted re-query keeps them in wm.ov[0 .. ovCount) unordered)
-      const int nc = onlySeq >= 0 ? ws->ovCount : ws->nAll;
-      if (nc > 0) {
-        if (lane == 0) {
-          const unsigned cb = atomicAdd(qa.candCursor, (unsigned)nc);
-          ws->red[13] = (cb + (unsigned)nc > (unsigned)qa.candCap) ? -1 : (int)cb;
-          if (ws->red[13] < 0) atomicOr(qa.candOverflow, 1);
-        }
-        __syncthreads();
-        const int cb = ws->red[13];
-        if (cb >= 0) {
-          for (int i = lane; i < nc; i += NT) qa.candOut[cb + i] = ovToCand(wm.ov[onlySeq >= 0 ? i : (int)wm.ord[i]]);
-          if (lane == 0) { qa.candBase[r] = cb; qa.candCnt[r] = nc; }
-        }
-        __syncthreads();
-      }
-    }
+    if (qa.cs && qa.cs->candOut && ret >= 0) emitCands(qa.cs, wm, ws, r, onlySeq >= 0 ? ws->ovCount : ws->nAll, onlySeq >= 0);
     if (lane == 0) {   // room for this read's records in the result pool
       const int base = n > 0 ? (int)atomicAdd(qa.poolCursor, (unsigned)n) : 0;
       ws->red[15] = (base + n > qa.poolCap) ? -1 : base;

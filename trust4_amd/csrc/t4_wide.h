@@ -647,8 +647,9 @@ __global__ __launch_bounds__(512) void wideMergeKernel(T4IndexView ix, T4BatchVi
     const int *st = wd.stat + (size_t)w * T4_WIDE_STAT;
     if (lane == 0 && qa.statsStable) qa.statsStable[r] = st[WS_STABLE];
     if (lane == 0 && qa.n4) qa.n4[r] = st[WS_N4];
-    if (qa.stats8 && lane < 8) qa.stats8[8 * r + lane] = st[WS_STATS8 + lane];
-    if (lane == 0 && qa.candCnt) qa.candCnt[r] = 0;
+    const T4CandArgs *cs = qa.cs;
+    if (cs && lane < 8) cs->stats8[8 * r + lane] = st[WS_STATS8 + lane];
+    if (lane == 0 && cs && cs->candCnt) cs->candCnt[r] = 0;
     if (N == 0) { if (lane == 0) { qa.counts[r] = 0; qa.outBase[r] = 0; if (qa.aux) qa.aux[r] = 0; } continue; }
     // std::sort(overlaps) (SeqSet.hpp:1597) on the records as GetOverlapsFromHits left them: matchCnt (kept in chainLen), read span,
     // contig, strand in one key with the record's index; ties on all four are settled by the rest of operator<
@@ -756,17 +757,18 @@ __global__ __launch_bounds__(512) void wideMergeKernel(T4IndexView ix, T4BatchVi
       }
       __syncthreads();
     }
-    if (qa.candOut && cnt > 0) {   // the candidate store (T4QueryArgs::candOut): every overlap on the strand of the best one, in scan order
+    if (cs && cs->candOut && cnt > 0) {   // the candidate store (T4QueryArgs::cs): every overlap on the strand of the best one, in scan order
       if (lane == 0) {
-        const unsigned cb = atomicAdd(qa.candCursor, (unsigned)cnt);
-        s_red[13] = (cb + (unsigned)cnt > (unsigned)qa.candCap) ? -1 : (int)cb;
-        if (s_red[13] < 0) atomicOr(qa.candOverflow, 1);
+        const unsigned cb = atomicAdd(cs->candCursor, (unsigned)cnt);
+        s_red[13] = (cb + (unsigned)cnt > (unsigned)cs->candCap) ? -1 : (int)cb;
+        if (s_red[13] < 0) atomicOr(cs->candOverflow, 1);
       }
       __syncthreads();
       const int cb = s_red[13];
       if (cb >= 0) {
-        for (int i = lane; i < cnt; i += NT) qa.candOut[cb + i] = ovToCand(*wideRec(wd, pl, ord[i]));
-        if (lane == 0) { qa.candBase[r] = cb; qa.candCnt[r] = cnt; }
+        T4Cand *out = cs->candOut;
+        for (int i = lane; i < cnt; i += NT) out[cb + i] = ovToCand(*wideRec(wd, pl, ord[i]));
+        if (lane == 0) { cs->candBase[r] = cb; cs->candCnt[r] = cnt; }
       }
       __syncthreads();
     }
