@@ -187,6 +187,21 @@ def add_roofline(aq, note=""):
                     "bytes to one query per served read as the reference does" + note}
 
 
+def chain_block(st):
+    """The chain of dependent query rounds of one stage 1 (stats JSON `chain`, t4_assembler_chain_stats) with its floor: what the
+    Add pass would cost if EVERY round were as short as the shortest ones are (5th percentile of launch call -> results on the host)
+    -- rounds only end when a commit has changed what the next read must be matched against, so this is the part of the pass that no
+    amount of chip can shorten at bit-identity; the distance between the pass and it is what the engine still owes."""
+    ch = st.get("chain")
+    if not ch:
+        return None
+    ch = dict(ch)
+    ch["floor_s"] = ch["rounds"] * ch["round_wall_ms_p05"] * 1e-3
+    ch["addread_pass_s"] = st["phases_s"]["assembled"] - st["phases_s"]["trimmed_ready"]
+    ch["whole_queries_per_served_read"] = ch["whole_queries"] / max(1, st["add_query"]["reads_served"])
+    return ch
+
+
 def config_leg(name, threads, device, mode="skipMateExtension", keep=None, cpu_prefix_pairs=0):
     """One whole stage 1 through trust4-hip on a BASELINE config itself (C2 = 1 M pairs, 20 k clones, seed 1; `c3p*` = a stated
     prefix of C3's read stream), under this run's clock, outputs compared with the md5 sums of the REFERENCE's outputs on the same
@@ -229,7 +244,7 @@ def config_leg(name, threads, device, mode="skipMateExtension", keep=None, cpu_p
                         "kernel_ms": aq["kernel_ms"], "launch_ms_avg": aq["kernel_ms"] / max(1, aq["rounds"]), "hits": aq["hits"],
                         "host_wait_for_queries_s": aq.get("host_wait_for_queries_s"), "wide": aq.get("wide"),
                         "addread_pass_s": st["phases_s"]["assembled"] - st["phases_s"]["trimmed_ready"], "phases_s": st["phases_s"],
-                        "roofline": add_roofline(aq)})
+                        "roofline": add_roofline(aq), "chain": chain_block(st)})
             out["files"] = (fa, f1, f2, mine, stats_path)
         if golden is None or mode not in golden.get("modes", {}):
             out["identical"] = None
@@ -622,7 +637,7 @@ def main():
                        "phases_s": {"parse_processread_21mers": ph["input_processed_counted"], "sort": ph["sorted"] - ph["input_processed_counted"],
                                     "rough_annotation": ph["rough_annotation"] - ph["sorted"], "trim": ph["trimmed_ready"] - ph["rough_annotation"],
                                     "addread_pass": ph["assembled"] - ph["trimmed_ready"], "outputs": ph["outputs_written"] - ph["assembled"]}},
-            "roofline": roof,
+            "roofline": roof, "chain": chain_block(st),
             "passes": {"add_query": aq,
                        "rough_annotation_in_step": {"reads": ra["reads"], "hits": ra["hits"], "kernel_ms": ra["kernel_ms"],
                                                     "achieved_GBs": alg_ann / (max(ra["kernel_ms"], 1e-6) * 1e-3) / 1e9}},

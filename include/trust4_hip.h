@@ -271,6 +271,12 @@ int t4_assembler_set_threads(t4_assembler *a, int host_threads);
  * the ctx's AddRead query path: calls, reads, launches of the global-scratch tier, reads it served, result records,
  * microseconds of its kernels (HIP events), _hit records its seed stages emitted. */
 int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n);
+/* The chain of dependent query rounds of a live set ("the floor"): up to 10 values -- rounds; rounds that carried restricted
+ * re-queries only; 5th percentile and median of a round's kernel milliseconds (HIP events); 5th percentile and median of a round's
+ * wall milliseconds from the launch call to its results on the host; whole queries; restricted re-queries (one contig); candidate
+ * records kept with whole queries; restricted re-queries merged through the replay of the pre-filter scan. rounds x the 5th
+ * percentile of the wall time is what the chain would cost if every round were as short as the shortest ones. */
+int t4_assembler_chain_stats(const t4_assembler *a, double *out, int n);
 int t4_assembler_counters(const t4_assembler *a, int64_t *queries, int64_t *refreshes, int64_t *window_hits);
 /* host seconds spent refreshing the device image / in GPU query batches (upload + kernels + download) */
 int t4_assembler_timers(const t4_assembler *a, double *sec_refresh, double *sec_query);

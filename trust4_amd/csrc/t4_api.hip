@@ -72,7 +72,7 @@ struct AqCall {
   std::vector<unsigned char> allGlobal;
   size_t oPk, oNm, oLen, oBc, oSt, oLs, oVw, oFa, oOnly, oForce, oCs, oWide, oWideA, inBytes, pCb, pCc, pS8, pCnt, pSta, pNext, pNext2, pBase, pTick, pStab, pAux, pN4, pTail, pWctl, pWplan, pWstat, pWctlA, pWplanA, pWstatA, outBytes;
   bool hasOnly = false, hasForce = false, wantCands = false;
-  bool extendLater = false, wide = false;
+  bool extendLater = false, wide = false, onlyRestricted = false;
   int wideSafety = 32;   // of sixteenths: partitions are planned for half of their capacity
   T4BatchView bv; T4QueryArgs qa; T4Work wk;
   std::chrono::steady_clock::time_point tf0;
@@ -123,6 +123,18 @@ struct t4_ctx {
   const int32_t *aqLastTicks = nullptr; int aqLastN = 0;   // per-read wall-clock ticks (10 ns) of the last AddRead query call (in the pinned header blob)
   double aqLastMs = 0;
   AqCall aq;
+  // testing aids of the AddRead query path, read from the environment once per ctx (a query round is a few hundred microseconds; a
+  // dozen getenv calls in it are not nothing)
+  struct AqEnv {
+    bool forceGlobal, wideNoHint;
+    int capLimit, extendDefer, poolCap, candCap, wideMinHits;
+    AqEnv() {
+      auto num = [](const char *n, int d) { const char *e = getenv(n); return e ? atoi(e) : d; };
+      forceGlobal = getenv("T4_AQ_FORCE_GLOBAL") != nullptr; wideNoHint = getenv("T4_WIDE_NO_HINT") != nullptr;
+      capLimit = num("T4_AQ_CAP_LIMIT", 0); extendDefer = num("T4_AQ_EXTEND_DEFER", 64); poolCap = num("T4_AQ_POOL_CAP", 0); candCap = num("T4_AQ_CAND_CAP", 1 << 18);
+      wideMinHits = num("T4_WIDE_MIN_HITS", 8192);
+    }
+  } aqEnv;
   // the wide query (t4_wide.h): pools of the deferred reads of one call, grown on demand
   T4Wide wide;               // device pointers + capacities (a copy travels in every call's input blob)
   bool wideInit = false;
@@ -1545,7 +1557,7 @@ int aqBegin(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const 
   q.pNext2 = al8(q.pNext + sizeof(int) * (size_t)n); q.pBase = al8(q.pNext2 + sizeof(int) * (size_t)n);
   q.pTick = al8(q.pBase + sizeof(int) * (size_t)n); q.pStab = al8(q.pTick + sizeof(int) * (size_t)n); q.pAux = al8(q.pStab + sizeof(int) * (size_t)n);
   q.pN4 = al8(q.pAux + sizeof(int) * (size_t)n); q.pCb = al8(q.pN4 + sizeof(int) * (size_t)n); q.pCc = al8(q.pCb + sizeof(int) * (size_t)n);
-  q.pS8 = al8(q.pCc + sizeof(int) * (size_t)n); q.pTail = al8(q.pS8 + sizeof(int) * 8 * (size_t)n);   // tail: overflow1 | overflow2 | hits (8 B) | pool cursor | dir overflow | cand cursor | cand overflow
+  q.pS8 = al8(q.pCc + sizeof(int) * (size_t)n); q.pTail = al8(q.pS8 + sizeof(int) * T4_QSTATS * (size_t)n);   // tail: overflow1 | overflow2 | hits (8 B) | pool cursor | dir overflow | cand cursor | cand overflow
   q.pWctl = q.pTail + 48; q.pWplan = q.pWctl + 32; q.pWstat = al8(q.pWplan + sizeof(T4WidePlan) * (size_t)n);
   q.pWctlA = al8(q.pWstat + sizeof(int) * T4_WIDE_STAT * (size_t)n); q.pWplanA = q.pWctlA + 32; q.pWstatA = al8(q.pWplanA + sizeof(T4WidePlan) * (size_t)n);
   q.outBytes = al8(q.pWstatA + sizeof(int) * T4_WIDE_STAT * (size_t)n);
@@ -1592,17 +1604,18 @@ int aqBegin(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const 
   }
   // one big contig set, plain passes: a read beyond the LDS tier goes to the wide query (t4_wide.h) instead of one workgroup's
   // global scratch -- decided on the device, inside the one launch every read starts in (T4_WIDE_OFF: the global-scratch tier as before)
-  q.wide = !views && !smallFirst && !skip_repeats && base.hasNovel == 2 && !getenv("T4_WIDE_OFF");   // (a read with a barcode stays on the old path: wideWant in processRead)
-  if (q.wide && onlySeq) {   // a round of restricted re-queries only defers nothing: the wide query's five grids stay unlaunched
-    bool anyWhole = false;
+  q.wide = !views && !smallFirst && !skip_repeats && base.hasNovel == 2 && !getenv("T4_WIDE_OFF");   // (read per call: tests/test_wide_query.py switches it between two calls on one ctx)   // (a read with a barcode stays on the old path: wideWant in processRead)
+  q.onlyRestricted = false;
+  if (onlySeq) {   // a round of restricted re-queries only defers nothing: the wide query's five grids stay unlaunched, and its reads
+    bool anyWhole = false;   // (a few overlaps with one contig each) extend inside the query kernel -- no extendKernel behind it
     for (int i = 0; i < n && !anyWhole; ++i) anyWhole = onlySeq[i] < 0;
-    if (!anyWhole) q.wide = false;
+    if (!anyWhole) { q.wide = false; q.onlyRestricted = !views && !smallFirst; }
   }
   // work lists: the reads of the first LDS launch, then those that go to the global-scratch tier at once
-  const bool forceGlobal = getenv("T4_AQ_FORCE_GLOBAL") != nullptr;   // testing aid: every read on the global-scratch tier
+  const bool forceGlobal = c->aqEnv.forceGlobal;   // testing aid: every read on the global-scratch tier
   if (forceGlobal && !smallFirst) { q.allGlobal.assign((size_t)n, 1); q.tierHint = tierHint = q.allGlobal.data(); q.wide = false; }
   // (with the wide query on, a hinted read -- served wide the last time -- starts on the second stream: wideSeedKernel)
-  auto direct = [&](int i) { return tierHint && tierHint[i] && !smallFirst && !(onlySeq && onlySeq[i] >= 0) && !(q.wide && getenv("T4_WIDE_NO_HINT")); };
+  auto direct = [&](int i) { return tierHint && tierHint[i] && !smallFirst && !(onlySeq && onlySeq[i] >= 0) && !(q.wide && c->aqEnv.wideNoHint); };
   int nFirst = 0, nDirect = 0;
   for (int i = 0; i < n; ++i) if (!direct(i)) ls[nFirst++] = i;
   for (int i = 0; i < n; ++i) if (direct(i)) ls[nFirst + nDirect++] = i;
@@ -1620,7 +1633,7 @@ int aqLaunch(t4_ctx *c) {
   const bool smallFirst = q.smallFirst;
   int r;
   if (!c->aqPool) {
-    const int poolCap0 = getenv("T4_AQ_POOL_CAP") ? atoi(getenv("T4_AQ_POOL_CAP")) : 0;   // testing aid: a small pool forces the grow-and-repeat path
+    const int poolCap0 = c->aqEnv.poolCap;   // testing aid: a small pool forces the grow-and-repeat path
     if (!c->aqPoolCap) c->aqPoolCap = poolCap0 > 0 ? poolCap0 : 1 << 16;
     const size_t rec = (size_t)c->aqPoolCap;
     HIPCHK(c, hipHostMalloc(&c->aqPool, rec * (2 * sizeof(t4_overlap) + sizeof(int32_t)), hipHostMallocMapped));
@@ -1628,7 +1641,7 @@ int aqLaunch(t4_ctx *c) {
   }
   const size_t rec = (size_t)c->aqPoolCap;
   if (q.wantCands && !c->candPool) {
-    if (!c->candCap) c->candCap = getenv("T4_AQ_CAND_CAP") ? atoi(getenv("T4_AQ_CAND_CAP")) : 1 << 18;   // (testing aid: a small pool forces the grow-and-repeat path)
+    if (!c->candCap) c->candCap = c->aqEnv.candCap > 0 ? c->aqEnv.candCap : 1 << 18;   // (testing aid: a small pool forces the grow-and-repeat path)
     HIPCHK(c, hipHostMalloc(&c->candPool, sizeof(T4Cand) * (size_t)c->candCap, hipHostMallocMapped));
     HIPCHK(c, hipHostGetDevicePointer((void **)&c->candPoolDev, c->candPool, 0));
   }
@@ -1641,7 +1654,7 @@ int aqLaunch(t4_ctx *c) {
     // launch, beside the other reads of the round): the wide query's kernels run behind the launch and cost a round about 0.25 ms
     // whatever the read is (profiles/r04b-h); from the LDS tier.s capacity on it beats one workgroup.s global scratch (C2 122 -> 93 s, profiles/r04h_*). The testing aid T4_AQ_CAP_LIMIT lowers
     // the threshold with the LDS tier's capacity.
-    { const int lim = getenv("T4_AQ_CAP_LIMIT") ? atoi(getenv("T4_AQ_CAP_LIMIT")) : 0; w.minHits = lim > 0 ? lim : wideEnv("T4_WIDE_MIN_HITS", 8192); }
+    { const int lim = c->aqEnv.capLimit; w.minHits = lim > 0 ? lim : c->aqEnv.wideMinHits; }
     w.ctl = (int *)(c->aqOut + q.pWctl); w.plan = (T4WidePlan *)(c->aqOut + q.pWplan); w.stat = (int *)(c->aqOut + q.pWstat);
     memcpy(c->aqInHost + q.oWide, &w, sizeof w);
     wa.enabled = 1; wa.safetyNum = w.safetyNum; wa.minHits = w.minHits;
@@ -1681,9 +1694,9 @@ int aqLaunch(t4_ctx *c) {
   qa.leanExt = q.lean ? 1 : 0;
   if (q.views) { qa.views = q.views; qa.viewOf = (const int *)(c->aqIn + q.oVw); }
   // one big set: the ExtendOverlap calls of reads with more than this many overlaps run in their own launch (0: never)
-  int deferMin = getenv("T4_AQ_EXTEND_DEFER") ? atoi(getenv("T4_AQ_EXTEND_DEFER")) : 64;   // testing aid
+  int deferMin = c->aqEnv.extendDefer;   // testing aid
   if (q.wide && deferMin <= 0) deferMin = 64;   // the wide query leaves every ExtendOverlap to extendKernel
-  const bool extendLater = deferMin > 0 && !q.views && !smallFirst;
+  const bool extendLater = deferMin > 0 && !q.views && !smallFirst && !q.onlyRestricted;
   q.extendLater = extendLater;
   if (extendLater) {
     if (c->aqRecCap < c->aqPoolCap) {
@@ -1708,7 +1721,7 @@ int aqLaunch(t4_ctx *c) {
   wk.nextList = (int *)(c->aqOut + q.pNext); wk.nextCount = (int *)(c->aqOut + q.pTail);
   wk.status = (int *)(c->aqOut + q.pSta); wk.hitCounter = (unsigned long long *)(c->aqOut + q.pTail + 16);
   wk.dpRows = c->dpRows; wk.dpDir = c->dpDir;
-  wk.capLimit = getenv("T4_AQ_CAP_LIMIT") ? atoi(getenv("T4_AQ_CAP_LIMIT")) : 0;   // testing aid
+  wk.capLimit = c->aqEnv.capLimit;   // testing aid
   wk.wide = q.wide ? (const T4Wide *)(c->aqIn + q.oWide) : nullptr;
   if (!smallFirst && (r = ensureGlobalTier(c, grid0 + (q.wide ? 0 : nDirect)))) return r;   // before anything of this call runs: growing it frees the old arrays
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
@@ -2074,7 +2087,7 @@ int t4_add_query_pool_begin2(t4_index *ix, int n, const char *bases, const int64
 int t4_add_query_last_cands(t4_ctx *c, const t4_cand **pool, const int32_t **base, const int32_t **cnt, const int32_t **stats8, int *n) {
   if (!c || !c->aqOutHost) return T4_ERR_ARG;
   const AqCall &q = c->aq;
-  static_assert(sizeof(t4_cand) == sizeof(T4Cand) && sizeof(T4Cand) == 24, "candidate record layout");
+  static_assert(sizeof(t4_cand) == sizeof(T4Cand) && sizeof(T4Cand) == 24 && T4_QUERY_STATS == T4_QSTATS, "candidate record layout");
   if (pool) *pool = q.wantCands ? (const t4_cand *)c->candPool : nullptr;
   if (base) *base = (const int32_t *)(c->aqOutHost + q.pCb);
   if (cnt) *cnt = q.wantCands ? (const int32_t *)(c->aqOutHost + q.pCc) : nullptr;

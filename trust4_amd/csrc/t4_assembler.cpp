@@ -494,6 +494,7 @@ struct t4_assembler : IndexListener {
     int64_t uid = 0;
     bool registered = false;     // its k-mers are in winKmers (done beside its first query: nothing looks an entry up before it holds a result)
     unsigned char tier = 0;      // the last query of this read ended on the global-scratch tier
+    bool hintPredicted = false;  // tier was set (or left) by a count of the read's emitted hits before its first query (launchOn: the reads of the NEXT whole-query round)
     bool fragile = false;        // any change of one of its keys' lists invalidates it
     int slack = 0;               // tolerated hit-set changes left before possibleOverlapCnt could pass 100 (SeqSet.hpp:813-823)
     int lastUs = 0;              // what this read's last query took in its workgroup (microseconds; 0: never queried): a launch lasts as long as its slowest read
@@ -535,6 +536,7 @@ struct t4_assembler : IndexListener {
     std::vector<t4_cand> cands;
     bool candOk = false;
     int n4lo[2] = {0, 0}, n4hi[2] = {0, 0}, n5lo[2] = {0, 0}, n5hi[2] = {0, 0}, smlo[2] = {0, 0}, smhi[2] = {0, 0}, minT[2] = {3, 3};
+    int toleratedSince = 0;            // index edits of small groups this entry has tolerated since its whole query (their recorded sizes are bounds from then on)
     std::vector<uint32_t> exactKeys;   // groups whose recorded hit count is exact because a restricted re-query set it (host-derived tables hold supersets)
     bool strand0Plus = false, auxOk = false;
     bool partial = false, merged = false;
@@ -604,11 +606,12 @@ struct t4_assembler : IndexListener {
   int64_t baseUsed = 0;            // device arena of consensus chars / posWeight predicate bytes (one offset space)
   std::vector<int> dirtySeqs;
   bool liveReset = true;           // the next delta describes the whole image (first upload, k change)
+  int maxSeqLenSeen = 0;
   int64_t toleratedStable = 0, invLongLists = 0;
   int64_t wideServed = 0, wideGroupRecords = 0, wideMispredicted = 0;
   int64_t restrictedMarks = 0, restrictedMerged = 0, restrictedFallbacks = 0, restrictedStale = 0, restrictedMulti = 0;
   bool restrictOn = true, candStore = true;
-  int64_t candRecords = 0, candMerges = 0, candFallbackUncut = 0, candFallbackStats = 0, candFallbackStrand = 0, candFallbackOther = 0, candRecut = 0, candSelfChecks = 0, candMergesBig = 0, candMergesStats = 0;
+  int64_t candRecords = 0, candMerges = 0, candFallbackUncut = 0, candFallbackStats = 0, candFallbackStrand = 0, candFallbackOther = 0, candRecut = 0, candSelfChecks = 0, candMergesBig = 0, candMergesStats = 0, candExactStats = 0;
   bool mergeRestricted(Cached &c, int pc, int k2, const t4_overlap *ov, const t4_overlap *ex, const int32_t *rets, const t4_cand *nc, int ncnt, const int32_t *s8);
   static void replayScan(const std::vector<t4_cand> &cands, const std::vector<Seq> &seqs, int len, int radius, double repeatSim, std::vector<unsigned char> &cut);
   int64_t whyNot[6] = {0, 0, 0, 0, 0, 0};   // entries that fell whole although one contig changed: lists beyond 10000 postings, overlaps on the other strand, more than 44 candidate overlaps, more than ~100 groups of four hits, no report from the query, other
@@ -630,7 +633,8 @@ struct t4_assembler : IndexListener {
 
   // testing / development aids, read from the environment ONCE per builder (none changes a result; DESIGN 7b lists them)
   struct Knobs {
-    bool verifyWindow = false, noStableStats = false;
+    bool verifyWindow = false, noStableStats = false, wideQueries = true, candStore = true, restrictOn = true, predictHints = true;
+    int wideHitLimit = 8192;
     int lanes = 1, queryAhead = 0, minBatch = 4, harvestDelay = 0, lightAhead = -1, heavyBatch = 0, maxPending = 4; double aheadMult = 3.0;
     FILE *roundLog = nullptr;
     Knobs() {
@@ -639,6 +643,11 @@ struct t4_assembler : IndexListener {
       noStableStats = getenv("T4_NO_STABLE_STATS") != nullptr;  // A/B aid: the budget rule for every entry
       lanes = num("T4_LIVE_LANES", 1); queryAhead = num("T4_QUERY_AHEAD", 0); minBatch = num("T4_LIVE_MIN_BATCH", 4); harvestDelay = num("T4_LIVE_HARVEST_DELAY", 0);
       heavyBatch = num("T4_HEAVY_BATCH", 0); if (getenv("T4_AHEAD_MULT")) aheadMult = atof(getenv("T4_AHEAD_MULT"));
+      wideQueries = !getenv("T4_WIDE_OFF") && !getenv("T4_AQ_FORCE_GLOBAL");
+      { const int lim = num("T4_AQ_CAP_LIMIT", 0); wideHitLimit = lim > 0 ? lim : num("T4_WIDE_MIN_HITS", 8192); }
+      predictHints = !getenv("T4_NO_PREDICT");   // A-B aid: no look at the reads of the next whole-query round
+      candStore = !getenv("T4_CANDS_OFF");      // testing / A-B aid: the restricted path as round 4 had it (at most 44 candidates, ~100 groups of four hits)
+      restrictOn = !getenv("T4_RESTRICT_OFF");  // testing / A-B aid: every invalidated entry is queried again in full
       maxPending = num("T4_MAX_PENDING", 4);   // contigs a window entry may wait for at a time (1: round 4's rule, a second contig ends the entry)
       lightAhead = num("T4_LIGHT_AHEAD", -1);   // -1: every round carries every entry without a result (within `ahead`)
       if (getenv("T4_ROUND_LOG")) roundLog = fopen(getenv("T4_ROUND_LOG"), "w");   // one line per launch: reads, kernel ms, per read us / overlaps / tier / killed in flight
@@ -740,7 +749,9 @@ struct t4_assembler : IndexListener {
   std::vector<Lane> lanes;
   std::deque<std::unique_ptr<DeltaRec>> deltaLog;
   int64_t deltaVersion = 0;
-  int64_t launches = 0, launchesUrgent = 0, headWaits = 0, killedInFlight = 0, lightRounds = 0;
+  int64_t launches = 0, launchesUrgent = 0, headWaits = 0, killedInFlight = 0, lightRounds = 0, restrictedOnlyRounds = 0, wholeQueries = 0, restrictedQueries = 0;
+  std::vector<float> roundKernelMs, roundWallMs;   // per launch (t4_assembler_chain_stats)
+  std::chrono::steady_clock::time_point laneT0;
   double secHeadWait = 0, secLaunch = 0, secHarvest = 0;
   int ensureLanes();
   int flushLive(Lane **out);
@@ -876,7 +887,7 @@ struct t4_assembler : IndexListener {
     if (live()) {   // a fresh image: every contig gets a new place in the arena
       for (Lane &L : lanes) { if (L.dev) { t4_index_destroy(L.dev); L.dev = nullptr; } L.version = deltaVersion; }   // (no job is in flight: dropWindow above)
       deltaLog.clear();
-      liveReset = true; baseUsed = 0; dirtySeqs.clear();
+      liveReset = true; baseUsed = 0; dirtySeqs.clear(); maxSeqLenSeen = 0;
       for (int i = 0; i < (int)seqs.size(); ++i) { seqs[i].baseOff = -1; seqs[i].baseCap = 0; seqs[i].devDirty = false; markSeqDirty(i); }
     }
     dirty = true;
@@ -1322,6 +1333,7 @@ int t4_assembler::makeDelta() {
     Seq &q = seqs[c];
     q.devDirty = false;
     const int len = q.released ? 0 : (int)q.cons.size();
+    if (len > maxLen) maxLen = len;
     int lo = q.dLo, hi = q.dHi;
     if (len + 1 > q.baseCap) {   // a new place with room to grow
       q.baseCap = len + 1 + (len < 512 ? 256 : len / 2);
@@ -1344,7 +1356,10 @@ int t4_assembler::makeDelta() {
     }
   }
   dirtySeqs.clear();
-  for (const Seq &q : seqs) if (!q.released && (int)q.cons.size() > maxLen) maxLen = (int)q.cons.size();
+  // (the longest contig so far: every contig whose length changes is in this delta, so the maximum over the deltas is an upper bound
+  // of the current maximum -- all the image needs it for, t4Key32Bits; walking every contig per delta cost tens of microseconds a round)
+  if (maxLen > maxSeqLenSeen) maxSeqLenSeen = maxLen;
+  maxLen = maxSeqLenSeen;
   d.table_slots = index.tabSlots; d.table_rebuilt = index.tabRebuilt ? 1 : 0;
   d.post_cap = (int64_t)index.arena.size(); d.base_cap = baseUsed + 1024; d.seq_cap = (int32_t)seqs.size() + 64;
   d.nseq = (int32_t)seqs.size(); d.max_seq_len = maxLen;
@@ -1778,7 +1793,7 @@ void t4_assembler::processEvents() {
             if (g && g->cnt >= 3) { touch(e, ev.idx, invKey); break; }
             if (g && !e.hasDev) g->cnt = g->cnt > (uint32_t)n ? g->cnt - (uint32_t)n : 0;   // (device records count emitted hits: see Cached::devGroups)
           }
-          ++tolerated;
+          ++tolerated; ++e.toleratedSince;
           if (e.statsStable) { ++toleratedStable; continue; }   // exact: the statistics of this read's query cannot move (overlapsFromKeys)
           if (--e.slack < 0) { kill(e, invFragile); break; }
         }
@@ -1814,7 +1829,7 @@ void t4_assembler::announceLive(int n, const char *const *reads, const int *stra
     c.read = reads[i]; c.strand = strands[i]; c.barcode = barcodes ? barcodes[i] : -1; c.skip = repetitive; c.cnt = 0; c.valid = false;
     c.inflight = false; c.killed = false; c.shifts.clear();
     c.ov.clear(); c.ext.clear(); c.extRet.clear();
-    c.uid = nextUid++; c.tier = 0; c.lastUs = 0; c.registered = false;
+    c.uid = nextUid++; c.tier = 0; c.hintPredicted = false; c.lastUs = 0; c.registered = false;
     c.hasDev = false; c.expectWide = false; c.devGroups.clear();
     c.partial = false; c.pendingContig = -1; c.merged = false; c.auxOk = false; c.restrictedCount = 0; c.kmerPos.clear();
     c.cands.clear(); c.candOk = false; c.exactKeys.clear(); c.morePending.clear();
@@ -1831,11 +1846,7 @@ int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive
   if ((rc = makeDelta())) return rc;
   { auto t0 = std::chrono::steady_clock::now(); rc = bringUpToDate(L); secDelta += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); if (rc) return rc; }
   const int m = (int)todo.size();
-  {   // what t4_add_query_pool_begin does with a heavy read under the testing aids of csrc/t4_api.hip
-    wideQueries = !getenv("T4_WIDE_OFF") && !getenv("T4_AQ_FORCE_GLOBAL");
-    const int lim = getenv("T4_AQ_CAP_LIMIT") ? atoi(getenv("T4_AQ_CAP_LIMIT")) : 0;
-    wideHitLimit = lim > 0 ? lim : (getenv("T4_WIDE_MIN_HITS") ? atoi(getenv("T4_WIDE_MIN_HITS")) : 8192);
-  }
+  wideQueries = knobs.wideQueries; wideHitLimit = knobs.wideHitLimit;   // what t4_add_query_pool_begin does with a heavy read under the testing aids of csrc/t4_api.hip
   // one item per whole query, one per contig a partial entry waits for (the items of an entry are adjacent)
   L.slots.clear(); L.uids.clear(); L.hint.clear(); L.bcs.clear(); L.sts.clear(); L.fac.clear(); L.only.clear(); L.force.clear();
   L.bases.clear(); L.offs.assign(1, 0); L.repetitive = repetitive;
@@ -1858,10 +1869,14 @@ int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive
     c.cands.clear(); c.candOk = false; c.exactKeys.clear();
   }
   const int mi = (int)L.slots.size();
+  bool anyOnlyAll = true;
+  for (int v : L.only) if (v < 0) { anyOnlyAll = false; break; }
+  { int nOnly = 0; for (int v : L.only) nOnly += v >= 0 ? 1 : 0; restrictedQueries += nOnly; wholeQueries += mi - nOnly; if (nOnly == mi) ++restrictedOnlyRounds; }
+  laneT0 = tl0_;
   if (L.bases.empty()) L.bases.push_back('A');
   {
     auto tq0 = std::chrono::steady_clock::now();
-    candStore = !getenv("T4_CANDS_OFF");   // testing / A-B aid: the restricted path as round 4 had it (at most 44 candidates, ~100 groups of four hits)
+    candStore = knobs.candStore;
     rc = t4_add_query_pool_begin2(L.dev, mi, L.bases.data(), L.offs.data(), L.bcs.data(), L.sts.data(), repetitive, L.fac.data(), L.hint.data(), anyOnly ? L.only.data() : nullptr,
                                   anyOnly ? L.force.data() : nullptr, candStore ? 1 : 0);
     secQuery += std::chrono::duration<double>(std::chrono::steady_clock::now() - tq0).count();
@@ -1875,7 +1890,7 @@ int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive
   auto tg1 = std::chrono::steady_clock::now();
   std::atomic<int> nextG(0);
   std::atomic<bool> regTaken(false);
-  restrictOn = !getenv("T4_RESTRICT_OFF");   // testing / A-B aid: every invalidated entry is queried again in full
+  restrictOn = knobs.restrictOn;
   const auto registerNew = [&]() { for (int sl : todo) if (!pool[sl]->registered) registerKmers(*pool[sl], sl); };
   const std::function<void()> groupWorker = [&]() {
     if (!regTaken.exchange(true)) registerNew();
@@ -1890,9 +1905,35 @@ int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive
       else buildGroups(e);
     }
   };
-  const int nHelp = m >= 2 ? (threads - 1 < m - 1 ? threads - 1 : m - 1) : 0;
-  if (nHelp > 0) { if (!helpers) helpers.reset(new HelperPool()); helpers->start(nHelp, groupWorker); }
-  groupWorker();
+  // While this round's whole queries run, the reads of the NEXT such round are looked at: a read that has never been queried and
+  // whose seed stage will emit more hits than the LDS tier takes starts on the wide pipeline at once, on the second stream beside the
+  // round's query kernel (Cached::tier is that hint), instead of being deferred by the query kernel first -- a fresh heavy read then
+  // costs its round the wide kernels, not the query kernel AND the wide kernels one after the other. A count against the replica as
+  // it is now; it is a hint: either path serves any read.
+  std::vector<int> predict;
+  std::atomic<int> nextP(0);
+  if (wideQueries && !repetitive && mi > 0 && !anyOnlyAll && knobs.predictHints) {
+    size_t seen = 0;
+    for (size_t i = 0; i < order.size() && seen < 48; ++i) {
+      Cached &e = *pool[order[i]];
+      if (e.valid || e.inflight || e.partial || e.hintPredicted || e.tier || e.lastUs || e.barcode != -1) continue;
+      predict.push_back(order[i]); ++seen;
+    }
+  }
+  const std::function<void()> worker2 = [&]() {
+    groupWorker();
+    for (;;) {
+      const int t = nextP.fetch_add(1);
+      if (t >= (int)predict.size()) break;
+      Cached &e = *pool[predict[(size_t)t]];
+      if (emittedHits(e) > wideHitLimit) e.tier = 1;
+      e.hintPredicted = true;
+    }
+  };
+  const int work = m + (int)predict.size();
+  const int nHelp = work >= 2 ? (threads - 1 < work - 1 ? threads - 1 : work - 1) : 0;
+  if (nHelp > 0) { if (!helpers) helpers.reset(new HelperPool()); helpers->start(nHelp, worker2); }
+  worker2();
   if (nHelp > 0) helpers->wait();
   secGroups += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg1).count();
   return T4_OK;
@@ -1955,6 +1996,7 @@ bool t4_assembler::mergeRestricted(Cached &c, int pc, int k2, const t4_overlap *
   for (int t = 0; t < ncnt; ++t) if (((nc[t].flags & 1) != 0) != c.strand0Plus) { ++candFallbackStrand; return false; }   // an overlap on the other strand: which strand is the best one's is open again
   // ---- group statistics (SeqSet.hpp:784-823): pc's groups went from g0 to g1 hits; every other group of three or more is as it was
   int n4lo[2], n4hi[2], n5lo[2], n5hi[2], smlo[2], smhi[2];
+  bool needExact = false, exactStable = true;
   for (int t = 0; t < 2; ++t) {
     const uint32_t key = (uint32_t)pc * 2u + (uint32_t)t;
     const Grp *g = c.findGroup(key);
@@ -1987,7 +2029,71 @@ bool t4_assembler::mergeRestricted(Cached &c, int pc, int k2, const t4_overlap *
       ok = fa == fb && fa >= 3;
       T = fb;
     }
-    if (!ok || T != c.minT[t]) { ++candFallbackStats; return false; }
+    if (!ok || T != c.minT[t]) needExact = true;
+  }
+  if (needExact) {
+    // The bounds do not pin the threshold (e.g. longestHits / 4 changes between the largest group and the largest group - 1). When the
+    // entry's dependency records are the query's own (every group with its emitted hits, in the reference's order: minus strand by
+    // contig, then plus strand) and no index edit of a small group has been tolerated since, the statistics loop of
+    // SeqSet.hpp:784-811 is repeated exactly over them, with pc's groups at their new sizes -- including its `i = j; ++i` stepping
+    // (a group that follows a measured one is measured from its second hit; a one-hit group there vanishes).
+    if (!c.hasDev || c.toleratedSince != 0) { ++candFallbackStats; return false; }
+    struct Extra { uint32_t key; int cnt; };
+    std::vector<Extra> extra;   // groups that are not among the device records: earlier restricted re-queries put them into the table
+    for (uint32_t key : c.exactKeys) {
+      const Grp *g = c.findGroup(key);
+      if (g && !(g >= c.devGroups.data() && g < c.devGroups.data() + c.devGroups.size()) && (key >> 1) != (uint32_t)pc) extra.push_back(Extra{key, (int)g->cnt});
+    }
+    for (int t = 0; t < 2; ++t) {
+      const uint32_t key = (uint32_t)pc * 2u + (uint32_t)t;
+      const Grp *g = c.findGroup(key);
+      if (!(g && g >= c.devGroups.data() && g < c.devGroups.data() + c.devGroups.size())) extra.push_back(Extra{key, s8[4 + t]});
+    }
+    std::sort(extra.begin(), extra.end(), [](const Extra &a, const Extra &b) { return (a.key & 1u) != (b.key & 1u) ? (a.key & 1u) < (b.key & 1u) : a.key < b.key; });
+    int possible[2] = {0, 0}, longest[2] = {0, 0}, e4[2] = {0, 0}, e5[2] = {0, 0}, big[2] = {0, 0};
+    bool skip = false;
+    size_t xe = 0;
+    auto visit = [&](uint32_t key, int n) {
+      if (n <= 0) return;
+      const int plus = (int)(key & 1u);
+      const int m = n - (skip ? 1 : 0);
+      if (m > 0) { if (m > 3) ++possible[plus]; if (m > longest[plus]) longest[plus] = m; }
+      skip = !(skip && n == 1);
+      if (n >= 4) ++e4[plus];
+      if (n >= 5) ++e5[plus];
+      if (n > big[plus]) big[plus] = n;
+    };
+    auto before = [](uint32_t a, uint32_t b) { return (a & 1u) != (b & 1u) ? (a & 1u) < (b & 1u) : a < b; };
+    for (size_t q = 0; q < c.devGroups.size(); ++q) {
+      const Grp &g = c.devGroups[q];
+      while (xe < extra.size() && before(extra[xe].key, g.key)) { visit(extra[xe].key, extra[xe].cnt); ++xe; }
+      visit(g.key, (g.key >> 1) == (uint32_t)pc ? s8[4 + (int)(g.key & 1u)] : (int)g.cnt);
+    }
+    while (xe < extra.size()) { visit(extra[xe].key, extra[xe].cnt); ++xe; }
+    for (int t = 0; t < 2; ++t) {
+      int T = 3;
+      if (possible[t] > 100000) T = (int)(longest[t] * 0.75);
+      else if (possible[t] > 10000) T = longest[t] / 2;
+      else if (possible[t] > 1000) T = longest[t] / 3;
+      else if (possible[t] > 100) T = longest[t] / 4;
+      if (T != c.minT[t]) { ++candFallbackStats; return false; }
+      n4lo[t] = n4hi[t] = e4[t]; n5lo[t] = n5hi[t] = e5[t]; smlo[t] = smhi[t] = big[t];
+    }
+    ++candExactStats;
+    // (is the threshold safe from edits of small groups from here on? the certificate again, over the exact numbers)
+    for (int t = 0; t < 2 && exactStable; ++t) {
+      const int lo = n5lo[t], hi = n4hi[t];
+      const int cLo = lo > 100000 ? 4 : lo > 10000 ? 3 : lo > 1000 ? 2 : lo > 100 ? 1 : 0;
+      const int cHi = hi > 100000 ? 4 : hi > 10000 ? 3 : hi > 1000 ? 2 : hi > 100 ? 1 : 0;
+      bool ok = cLo == cHi;
+      if (ok && cLo > 0) {
+        const int a = smlo[t] - 1 > 0 ? smlo[t] - 1 : 0, bg = smhi[t];
+        const int fa = cLo == 4 ? (int)(a * 0.75) : cLo == 3 ? a / 2 : cLo == 2 ? a / 3 : a / 4;
+        const int fb = cLo == 4 ? (int)(bg * 0.75) : cLo == 3 ? bg / 2 : cLo == 2 ? bg / 3 : bg / 4;
+        ok = fa == fb && fa >= 3;
+      }
+      exactStable = ok;
+    }
   }
   // ---- the candidate list with pc's candidates swapped, in scan order: m0 desc, read span desc, contig, strand, geometry (operator< before scoring)
   struct Item { t4_cand o; int src; unsigned char wasCut; };   // src: index into nc, -1 for a kept candidate
@@ -2052,14 +2158,13 @@ bool t4_assembler::mergeRestricted(Cached &c, int pc, int k2, const t4_overlap *
   for (size_t t = 0; t < items.size(); ++t) { c.cands[t] = items[t].o; if (cut[t]) c.cands[t].flags |= 4; else c.cands[t].flags &= (unsigned short)~4u; }
   for (int t = 0; t < 2; ++t) { c.n4lo[t] = n4lo[t]; c.n4hi[t] = n4hi[t]; c.n5lo[t] = n5lo[t]; c.n5hi[t] = n5hi[t]; c.smlo[t] = smlo[t]; c.smhi[t] = smhi[t]; }
   c.nAll = c.nAllBound = (int)c.cands.size();
-  // the dependency record of pc: hull from the contig's consensus (rebuildGroup), hits as the query counted them
-  rebuildGroup(c, pc);
+  // the dependency record of pc as the query found it: emitted hits per strand, hull of the diagonals with three or more of them
   for (int t = 0; t < 2; ++t) {
     const uint32_t key = (uint32_t)pc * 2u + (uint32_t)t;
-    if (s8[4 + t] > 0 || c.findGroup(key)) c.getGroup(key).cnt = (uint32_t)s8[4 + t];
+    if (s8[4 + t] > 0 || c.findGroup(key)) { Grp &g = c.getGroup(key); g.cnt = (uint32_t)s8[4 + t]; g.lo = s8[8 + t]; g.hi = s8[10 + t]; }
     if (std::find(c.exactKeys.begin(), c.exactKeys.end(), key) == c.exactKeys.end()) c.exactKeys.push_back(key);
   }
-  c.statsStable = true; c.n4 = c.n4hi[0] + c.n4hi[1]; c.slack = 99 - c.n4;
+  c.statsStable = exactStable && !knobs.noStableStats; c.n4 = c.n4hi[0] + c.n4hi[1]; c.slack = 99 - c.n4;
   ++candMerges;
   return true;
 }
@@ -2080,6 +2185,11 @@ int t4_assembler::harvest(Lane &L) {
   }
   L.busy = false;
   const int m = (int)L.slots.size();
+  if (!rc && lanes.size() == 1) {
+    double ms_ = 0; (void)t4_add_query_last_call(L.ctx, &ms_, nullptr, nullptr);
+    roundKernelMs.push_back((float)ms_);
+    roundWallMs.push_back((float)(std::chrono::duration<double>(std::chrono::steady_clock::now() - laneT0).count() * 1e3));
+  }
   if (rc) {
     if (L.ctx != ctx) err = t4_last_error(L.ctx);
     for (int i = 0; i < m; ++i) { Cached &c = *pool[L.slots[i]]; if (c.uid == L.uids[i]) { c.inflight = false; c.killed = false; } }
@@ -2103,6 +2213,38 @@ int t4_assembler::harvest(Lane &L) {
   (void)t4_add_query_last_aux(L.ctx, &aux, &n4s, &qstatus, &nAux);
   const t4_cand *candPool = nullptr; const int32_t *candBase = nullptr, *candCnt = nullptr, *stats8 = nullptr; int nCand = 0;
   (void)t4_add_query_last_cands(L.ctx, &candPool, &candBase, &candCnt, &stats8, &nCand);
+  // The dependency records of the reads the wide query served are the bulk of what a round hands back (thousands of 16-byte records
+  // per read; 17 G of them over the first 2 M pairs of C3, where copying them was a third of the pass): when a round brings many,
+  // the host threads copy them side by side before the entries are gone through one after the other.
+  std::vector<unsigned char> groupsCopied((size_t)m, 0);
+  if (threads > 1 && m >= 2) {
+    std::vector<int> big; size_t total = 0;
+    for (int i = 0; i < m; ++i) {
+      if (L.only[i] >= 0) continue;
+      const Cached &c = *pool[L.slots[i]];
+      if (c.uid != L.uids[i] || !c.inflight || c.killed) continue;
+      const t4_grp *dg = nullptr; int ng = 0;
+      if (t4_add_query_groups(L.ctx, i, &dg, &ng, nullptr, nullptr) == 1 && ng >= 1024) { big.push_back(i); total += (size_t)ng; }
+    }
+    if (big.size() >= 2 && total >= 16384) {
+      std::atomic<int> next(0);
+      const std::function<void()> copier = [&]() {
+        for (;;) {
+          const int t = next.fetch_add(1);
+          if (t >= (int)big.size()) break;
+          const int i = big[(size_t)t];
+          Cached &c = *pool[L.slots[i]];
+          const t4_grp *dg = nullptr; int ng = 0;
+          if (t4_add_query_groups(L.ctx, i, &dg, &ng, nullptr, nullptr) == 1) { c.devGroups.assign((const Grp *)dg, (const Grp *)dg + ng); groupsCopied[(size_t)i] = 1; }
+        }
+      };
+      const int nHelp = (int)big.size() - 1 < threads - 1 ? (int)big.size() - 1 : threads - 1;
+      if (!helpers) helpers.reset(new HelperPool());
+      helpers->start(nHelp, copier);
+      copier();
+      helpers->wait();
+    }
+  }
   for (int i = 0; i < m; ++i) {
     Cached &c = *pool[L.slots[i]];
     if (c.uid != L.uids[i] || !c.inflight) continue;   // the entry was retired (or re-announced) meanwhile
@@ -2123,7 +2265,7 @@ int t4_assembler::harvest(Lane &L) {
         const int k2 = cnts[q] > 0 ? cnts[q] : 0;
         if (c.candOk) {   // the candidate store: swap the contig's candidates, repeat the scan, check the group statistics
           const bool fits = !(qstatus && q < nAux && qstatus[q] == 5) && candPool && candCnt && q < nCand && candCnt[q] == k2;
-          if (fits && mergeRestricted(c, pc, k2, ov + bas[q], ex + bas[q], rets + bas[q], candPool + (k2 ? candBase[q] : 0), k2, stats8 + 8 * (size_t)q)) {
+          if (fits && mergeRestricted(c, pc, k2, ov + bas[q], ex + bas[q], rets + bas[q], candPool + (k2 ? candBase[q] : 0), k2, stats8 + T4_QUERY_STATS * (size_t)q)) {
             ++c.restrictedCount; ++restrictedMerged;
           } else { fell = true; c.candOk = false; if (!fits) ++candFallbackOther; }
         } else {
@@ -2174,9 +2316,9 @@ int t4_assembler::harvest(Lane &L) {
     if (candStore && c.auxOk && candPool && candCnt && i < nCand && candCnt[i] == c.nAll && c.nAll < 32767 && c.nOther == 0) {
       c.cands.assign(candPool + (c.nAll ? candBase[i] : 0), candPool + (c.nAll ? candBase[i] : 0) + c.nAll);
       for (const auto &sh : shiftsOfCall) for (t4_cand &o : c.cands) if (o.seqIdx == sh.first) { o.ss += sh.second; o.se += sh.second; }
-      const int32_t *s8 = stats8 + 8 * (size_t)i;
+      const int32_t *s8 = stats8 + T4_QUERY_STATS * (size_t)i;
       for (int t = 0; t < 2; ++t) { c.n4lo[t] = c.n4hi[t] = s8[t]; c.n5lo[t] = c.n5hi[t] = s8[2 + t]; c.smlo[t] = c.smhi[t] = s8[4 + t]; c.minT[t] = s8[6 + t] > 0 ? s8[6 + t] : 3; }
-      c.candOk = true; candRecords += c.nAll;
+      c.candOk = true; c.toleratedSince = 0; candRecords += c.nAll;
       if (knobs.verifyWindow && c.cnt >= 0) {   // the host's scan against the kernel's: the same cuts, the same survivors of the similarity cut
         std::vector<unsigned char> cut;
         replayScan(c.cands, seqs, (int)c.read.size(), radius, 0.95, cut);
@@ -2197,7 +2339,7 @@ int t4_assembler::harvest(Lane &L) {
       const t4_grp *dg = nullptr; int ng = 0, huge = 0, n4 = 0;
       if (t4_add_query_groups(L.ctx, i, &dg, &ng, &huge, &n4) == 1) {
         static_assert(sizeof(t4_grp) == sizeof(Grp), "dependency record layout");
-        c.devGroups.assign((const Grp *)dg, (const Grp *)dg + ng);
+        if (!groupsCopied[(size_t)i]) c.devGroups.assign((const Grp *)dg, (const Grp *)dg + ng);
         c.devSplit = 0;
         { size_t lo = 0, hi = c.devGroups.size(); while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (c.devGroups[mid].key & 1u) hi = mid; else lo = mid + 1; } c.devSplit = lo; }
         c.hasDev = true; c.groups.reset(16);
@@ -2226,6 +2368,7 @@ int t4_assembler::pumpLive(bool needHead, int repetitive) {
     const int harvestDelay = knobs.harvestDelay;
     for (Lane &L : lanes) if (L.busy && ++L.polls > harvestDelay && t4_add_query_pool_done(L.ctx)) { if ((rc = harvest(L))) return rc; }
     if (order.empty()) return T4_OK;
+    if (needHead && lanes.size() == 1 && pool[order.front()]->valid) return T4_OK;   // (one lane: nothing is launched beside a head that holds its result)
     if (index.total == 0) {   // an empty set has no hit for anybody
       for (size_t i = 0; i < order.size() && i < ahead; ++i) {
         Cached &c = *pool[order[i]];
@@ -2526,10 +2669,18 @@ int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n) {
             (long long)a->restrictedMarks, (long long)a->restrictedMerged, (long long)a->restrictedFallbacks, (long long)a->restrictedStale);
     fprintf(stderr, "timing: entries that fell whole when one contig changed: %lld with lists beyond 10000 postings, %lld with overlaps on the other strand, %lld with more than 44 candidate overlaps, %lld with ~100 groups of four hits, %lld without the query's report, %lld other\n",
             (long long)a->whyNot[0], (long long)a->whyNot[1], (long long)a->whyNot[2], (long long)a->whyNot[3], (long long)a->whyNot[4], (long long)a->whyNot[5]);
-    fprintf(stderr, "timing: candidate store: %lld candidate records kept with whole queries, %lld restricted re-queries merged through the replay of the scan (%lld with more than 50 candidates, %lld with more than 100 groups of four hits on a strand, %lld cut a candidate of another contig), fell back to the whole query: %lld a cut candidate of another contig passes now, %lld the group statistics could move the threshold, %lld an overlap on the other strand, %lld other; %lld whole queries checked against the host's scan\n",
-            (long long)a->candRecords, (long long)a->candMerges, (long long)a->candMergesBig, (long long)a->candMergesStats, (long long)a->candRecut, (long long)a->candFallbackUncut, (long long)a->candFallbackStats, (long long)a->candFallbackStrand, (long long)a->candFallbackOther, (long long)a->candSelfChecks);
+    fprintf(stderr, "timing: candidate store: %lld candidate records kept with whole queries, %lld restricted re-queries merged through the replay of the scan (%lld with more than 50 candidates, %lld with more than 100 groups of four hits on a strand, %lld cut a candidate of another contig), fell back to the whole query: %lld a cut candidate of another contig passes now, %lld the group statistics could move the threshold, %lld an overlap on the other strand, %lld other; %lld whole queries checked against the host's scan; %lld thresholds settled by repeating the statistics loop over the entry's groups\n",
+            (long long)a->candRecords, (long long)a->candMerges, (long long)a->candMergesBig, (long long)a->candMergesStats, (long long)a->candRecut, (long long)a->candFallbackUncut, (long long)a->candFallbackStats, (long long)a->candFallbackStrand, (long long)a->candFallbackOther, (long long)a->candSelfChecks, (long long)a->candExactStats);
     fprintf(stderr, "timing: wide query served %lld window entries (%lld dependency records came back with them), %lld reads it was expected for stayed on the LDS tier\n", (long long)a->wideServed, (long long)a->wideGroupRecords, (long long)a->wideMispredicted);
   }
+  return T4_OK;
+}
+int t4_assembler_chain_stats(const t4_assembler *a, double *out, int n) {
+  if (!a || !out || n < 1) return T4_ERR_ARG;
+  auto pct = [](std::vector<float> v, double p) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return (double)v[(size_t)(p * (double)(v.size() - 1))]; };
+  const double v[10] = {(double)a->rounds, (double)a->restrictedOnlyRounds, pct(a->roundKernelMs, 0.05), pct(a->roundKernelMs, 0.5), pct(a->roundWallMs, 0.05), pct(a->roundWallMs, 0.5),
+                        (double)a->wholeQueries, (double)a->restrictedQueries, (double)a->candRecords, (double)a->candMerges};
+  for (int i = 0; i < n && i < 10; ++i) out[i] = v[i];
   return T4_OK;
 }
 int t4_assembler_output(t4_assembler *a, const char *path) { return a ? a->output(path) : T4_ERR_ARG; }

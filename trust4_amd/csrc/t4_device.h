@@ -171,6 +171,7 @@ struct T4Cand {
   short indelCnt;
   unsigned short flags;      // 1: plus strand, 2: scoring left similarity 0, 4: cut by the pre-filters (its scored fields are still the scored ones)
 };
+#define T4_QSTATS 12         // statistics words per read: [0..7] see T4QueryArgs (stats8), [8..11] restricted re-queries: hull lo (minus, plus), hull hi (minus, plus) of the one contig's group
 struct T4CandArgs {
   T4Cand *candOut;
   unsigned *candCursor;

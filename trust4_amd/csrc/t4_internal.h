@@ -56,8 +56,11 @@ int t4_add_query_pool_begin(t4_index *ix, int n, const char *bases, const int64_
 // the best one as it stands before the similarity cut (a restricted re-query: every overlap with its one contig) in the order of the
 // scan of SeqSet.hpp:1673-2094 -- pre-score key, scored fields, whether the pre-filters of 1705-1794 cut it -- and eight statistics
 // words per read: per strand (minus, plus) the groups of >= 4 hits, of >= 5 hits, the largest group (true sizes; a restricted
-// re-query: of its one contig) and the novelMinHitRequired the pass used (SeqSet.hpp:784-823). force_min (nullable, restricted
+// re-query: of its one contig) and the novelMinHitRequired the pass used (SeqSet.hpp:784-823); a restricted re-query adds the hull of
+// the read's projections along the contig's diagonals with three or more hits (lo minus / plus, hi minus / plus; lo > hi: none):
+// T4_QUERY_STATS words per read. force_min (nullable, restricted
 // re-queries): that threshold for the one contig's groups, minus | plus << 16 (0: three hits).
+#define T4_QUERY_STATS 12
 typedef struct { int32_t seqIdx, ss, se; int16_t rs, re, m0, matchCnt, indelCnt; uint16_t flags; } t4_cand;   // flags: 1 plus strand, 2 scoring left similarity 0, 4 cut by the pre-filters
 int t4_add_query_pool_begin2(t4_index *ix, int n, const char *bases, const int64_t *offsets, const int32_t *barcodes, const int32_t *strands,
                              int skip_repeats, const double *factors, unsigned char *tier_hint, const int32_t *only_seq, const int32_t *force_min, int want_cands);

@@ -747,6 +747,7 @@ struct WaveState { // wave-uniform scalars kept in LDS
   int nvPossible[2], nvLongest[2];   // novel group statistics of GetOverlapsFromHits (filter 1)
   int nvN4[2], nvN5[2], nvSmax[2];   // groups of at least 4 / 5 hits and the largest group, TRUE sizes (the statistics measure a group one short or in full)
   int statsStable;                   // no pass of this read so far whose novelMinHitRequired could move (see overlapsFromKeys)
+  int hullLo[2], hullHi[2];          // restricted re-query: per strand, hull of the read's projections along the diagonals that hold three or more hits with the contig (lo > hi: none)
   int forceMin[2];                   // restricted re-query: novelMinHitRequired per strand as the entry's whole query had it (0: three hits), T4QueryArgs::forceMin
   int nAll, nOther, strand0;          // GetOverlapsFromRead: overlaps on the strand of the best one (before the similarity cut), on the other strand, that strand
   int wideWant;                      // mode 4, nonzero: a pass that emits more hits than this (or outgrows the global-scratch tier) is handed to the wide query (t4_wide.h)
@@ -2321,6 +2322,21 @@ __device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, 
     int nPlus = 0;
     for (int i = lane; i < Hv; i += NT) nPlus += (int)(wm.keys[i] >> 63);
     nPlus = blockSum(nPlus, ws->red);
+    // ... and the stretch of the contig the read lies on along every diagonal with three or more hits (the entry's dependency record
+    // of this contig: what t4_assembler::rebuildGroup derived from the consensus, a superset, on the host)
+    if (lane == 0) { ws->hullLo[0] = ws->hullLo[1] = 0x7FFFFFFF; ws->hullHi[0] = ws->hullHi[1] = -0x7FFFFFFF; }
+    __syncthreads();
+    for (int i = lane; i < Hv; i += NT) {
+      const unsigned long long ki = wm.keys[i];
+      const unsigned long long dg = ki >> T4_B_BITS;   // (strand, contig, diagonal)
+      if (i > 0 && (wm.keys[i - 1] >> T4_B_BITS) == dg) continue;   // not the first hit of its diagonal
+      if (i + 2 < Hv && (wm.keys[i + 2] >> T4_B_BITS) == dg) {
+        const int at = -(KEY_C(ki) - T4_C_BIAS), st = KEY_PLUS(ki);
+        atomicMin(&ws->hullLo[st], at);
+        atomicMax(&ws->hullHi[st], at + segLen - 1);
+      }
+    }
+    __syncthreads();
     overlapsFromKeys(ix, wm, ws, Hv, hitLenRequired, 0);   // (filter 0: the thresholds are the caller's -- ws->forceMin, else three hits: it has made sure the group statistics leave them there)
     if (lane == 0) {
       const int g[2] = {Hv - nPlus, nPlus};
@@ -3520,8 +3536,9 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
     int n = ret > 0 ? ret : 0;
     if (lane == 0 && qa.statsStable) qa.statsStable[r] = ws->statsStable;
     if (qa.cs && lane < 2) {
-      int *s8 = qa.cs->stats8 + 8 * r;
+      int *s8 = qa.cs->stats8 + T4_QSTATS * r;
       s8[lane] = ws->nvN4[lane]; s8[2 + lane] = ws->nvN5[lane]; s8[4 + lane] = ws->nvSmax[lane]; s8[6 + lane] = ws->novelMin[lane];
+      if (onlySeq >= 0) { s8[8 + lane] = ws->hullLo[lane]; s8[10 + lane] = ws->hullHi[lane]; }
     }
     if (qa.cs && qa.cs->candOut && ret >= 0) emitCands(qa.cs, wm, ws, r, onlySeq >= 0 ? ws->ovCount : ws->nAll, onlySeq >= 0);
     if (lane == 0) {   // room for this read's records in the result pool

@@ -648,7 +648,7 @@ __global__ __launch_bounds__(512) void wideMergeKernel(T4IndexView ix, T4BatchVi
     if (lane == 0 && qa.statsStable) qa.statsStable[r] = st[WS_STABLE];
     if (lane == 0 && qa.n4) qa.n4[r] = st[WS_N4];
     const T4CandArgs *cs = qa.cs;
-    if (cs && lane < 8) cs->stats8[8 * r + lane] = st[WS_STATS8 + lane];
+    if (cs && lane < 8) cs->stats8[T4_QSTATS * r + lane] = st[WS_STATS8 + lane];
     if (lane == 0 && cs && cs->candCnt) cs->candCnt[r] = 0;
     if (N == 0) { if (lane == 0) { qa.counts[r] = 0; qa.outBase[r] = 0; if (qa.aux) qa.aux[r] = 0; } continue; }
     // std::sort(overlaps) (SeqSet.hpp:1597) on the records as GetOverlapsFromHits left them: matchCnt (kept in chainLen), read span,

@@ -1804,6 +1804,11 @@ int main(int argc, char *argv[]) {
                   "\"wide\": {\"reads\": %lld, \"partitions\": %lld, \"calls_repeated\": %lld, \"dependency_records\": %lld}}, ",
               (long long)lc[0], (long long)lc[1], (long long)wh, lc[21] / 1e3, (long long)lc[22], (long long)lc[20], (long long)lc[18], (long long)lc[19], (long long)lc[2],
               (long long)lc[3], (long long)lc[4], lc[15] / 1e6, (long long)lc[23], (long long)lc[24], (long long)lc[25], (long long)lc[26]);
+      double cs[10] = {0};
+      t4_assembler_chain_stats(seqSet, cs, 10);
+      fprintf(fp, "\"chain\": {\"rounds\": %.0f, \"restricted_only_rounds\": %.0f, \"round_kernel_ms_p05\": %.4f, \"round_kernel_ms_p50\": %.4f, \"round_wall_ms_p05\": %.4f, \"round_wall_ms_p50\": %.4f, "
+                  "\"whole_queries\": %.0f, \"restricted_queries\": %.0f, \"candidate_records\": %.0f, \"restricted_merged_by_replay\": %.0f}, ",
+              cs[0], cs[1], cs[2], cs[3], cs[4], cs[5], cs[6], cs[7], cs[8], cs[9]);
       fprintf(fp, "\"contigs\": %d, \"assembled_reads\": %d}\n", t4_assembler_size(seqSet), (int)assembledReadIdx.size());
       fclose(fp);
     }
