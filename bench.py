@@ -208,6 +208,10 @@ def config_leg(name, threads, device, mode="skipMateExtension", keep=None, cpu_p
     files (tests/golden/c2_digests.json, produced by tools/c2_digests.py from oracle/_ref/trust4; the input files are
     regenerated here and their md5 sums are checked too)."""
     name, _, variant = name.partition(":")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import c2_digests as _cd
+    if name in _cd.CELL_CONFIGS:
+        return cell_config_leg(name, device)
     if variant == "dropin":   # the reference's main.cpp bound to the C ABI (integration/), run-trust4's DEFAULT options: mate-pair extension tail included
         mode = "default"
     tmp = keep or tempfile.mkdtemp(prefix="t4%s_" % name)
@@ -273,6 +277,39 @@ def config_leg(name, threads, device, mode="skipMateExtension", keep=None, cpu_p
     finally:
         if not keep:
             shutil.rmtree(tmp, ignore_errors=True)
+
+
+def cell_config_leg(name, device, threads=32):
+    """A barcode-mode config (tools/c2_digests.py CELL_CONFIGS: the C5 recipe at a stated size) through trust4-hip on one GPU, outputs
+    against the md5 sums of the reference's run on the same files."""
+    import c2_digests
+    tmp = tempfile.mkdtemp(prefix="t4%s_" % name)
+    try:
+        golden = json.load(open(c2_digests.OUT)).get(name)
+        fa, f1, f2, bc, umi, n = c2_digests.make_cell_inputs(tmp, name)
+        cells = c2_digests.CELL_CONFIGS[name][1]
+        out = {"workload": "C5 recipe at %d synthetic 150 bp PE pairs, %d cells x 2 clones, barcode + UMI files; whole stage 1 through trust4-hip -t %d, process start to exit" % (n, cells, threads), "pairs": n}
+        inputs_ok = golden is not None and [file_md5(x) for x in (f1, f2, bc, umi)] == golden["inputs_md5"]
+        mine, stats_path = os.path.join(tmp, "mine"), os.path.join(tmp, "stats.json")
+        t0 = time.perf_counter()
+        p = subprocess.run([DRIVER, "-t", str(threads), "-f", fa, "-1", f1, "-2", f2, "--barcode", bc, "--UMI", umi, "-o", mine],
+                           env=dict(os.environ, T4_DEVICE=str(device), T4_STATS_JSON=stats_path), stderr=subprocess.PIPE, text=True)
+        dt = time.perf_counter() - t0
+        if p.returncode:
+            out["error"] = "trust4-hip exit %d: %s" % (p.returncode, " | ".join(p.stderr.strip().split("\n")[-3:]))[:400]
+            return out
+        md5s = {x: file_md5(mine + x) for x in OUT_SUFFIXES}
+        out.update({"seconds": dt, "pairs_per_s": n / dt, "md5": md5s, "phases_s": json.load(open(stats_path)).get("phases_s")})
+        if golden:
+            g = golden["modes"]["barcode"]
+            out["identical"] = bool(inputs_ok and all(md5s[x] == g["md5"][x] for x in OUT_SUFFIXES))
+            out["reference_digest_run"] = {"seconds": g["reference_seconds"], "threads": g["reference_threads"], "pairs_per_s": n / g["reference_seconds"],
+                                           "where": "the builder's container (tools/c2_digests.py --config %s), not this box: a digest, not a baseline" % name}
+        return out
+    except Exception as e:   # noqa: BLE001
+        return {"error": repr(e)[:300]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def pmc_traffic(fa, f1, f2, threads, device, tmp, kernels=("queryKernel", "extendKernel")):
@@ -551,7 +588,7 @@ def main():
     ap.add_argument("--side-legs", type=int, default=1, help="0 = skip passes.rough_annotation_c2 / stage1_cells / stage0_e2e")
     ap.add_argument("--traffic", type=int, default=1, help="0 = skip the two rocprofv3 PMC passes that measure roofline.traffic")
     ap.add_argument("--c2", type=int, default=1, help="0 = skip the run of config C2 itself (then the steps are timed on the 100 k-pair batch)")
-    ap.add_argument("--config-leg", default="", help="additional config legs, comma separated (c3p05, c3p2, c3p5: prefixes of C3; c2:dropin = C2 with default options through the reference's main.cpp bound to the C ABI)")
+    ap.add_argument("--config-leg", default="", help="additional config legs, comma separated (c3p05, c3p2, c3p5: prefixes of C3; c5m5: the C5 recipe at 5 M pairs / 50 k cells, barcode mode; c2:dropin = C2 with default options through the reference's main.cpp bound to the C ABI)")
     ap.add_argument("--cells-pairs", type=int, default=250000, help="N > 1: pairs of the barcode-mode sample per GPU of the job")
     ap.add_argument("--cells", type=int, default=2500, help="N > 1: cells of the sample per GPU of the job")
     ap.add_argument("--cells-threads", type=int, default=16, help="N > 1: host threads per rank")

@@ -26,6 +26,8 @@ REF_BIN = os.path.join(ROOT, "oracle", "_ref", "trust4")
 OUT = os.path.join(ROOT, "tests", "golden", "c2_digests.json")
 SUFFIXES = ("_raw.out", "_assembled_reads.fa", "_final.out")
 # name -> (pairs, clones, seed, prefix pairs or 0): SURVEY.md 8(d)
+# (c5m5: the C5 recipe -- barcode + UMI files, 50 k cells x 2 clones, seed 4 -- at 5 M pairs; barcode mode, no --skipMateExtension)
+CELL_CONFIGS = {"c5m5": (5000000, 50000, 4)}
 CONFIGS = {"c2": (1000000, 20000, 1, 0), "c3p5": (20000000, 200000, 2, 5000000), "c3p2": (20000000, 200000, 2, 2000000), "c3p05": (20000000, 200000, 2, 500000)}
 
 
@@ -51,13 +53,47 @@ def make_inputs(tmp, name):
     return fa, pre + "_1.fq", pre + "_2.fq", n
 
 
+def make_cell_inputs(tmp, name):
+    """the C5-recipe files of a CELL_CONFIGS entry: reads, mates, barcodes, UMIs + the plain gene FASTA"""
+    pairs, cells, seed = CELL_CONFIGS[name]
+    fa = os.path.join(tmp, "ref.fa")
+    with gzip.open(os.path.join(ROOT, "data", "hg38_bcrtcr.fa.gz"), "rb") as f, open(fa, "wb") as g:
+        shutil.copyfileobj(f, g)
+    pre = os.path.join(tmp, name)
+    subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, str(pairs), "0", str(seed), pre, "--cells", str(cells)], check=True, stdout=subprocess.DEVNULL)
+    return fa, pre + "_1.fq", pre + "_2.fq", pre + "_bc.fa", pre + "_umi.fa", pairs
+
+
+def digest_cells(name, threads, keep):
+    """barcode-mode digest: oracle/_ref/trust4 --barcode --UMI on the C5-recipe sample (38 minutes at -t 8 for c5m5)"""
+    tmp = keep or tempfile.mkdtemp(prefix="t4c5_")
+    os.makedirs(tmp, exist_ok=True)
+    try:
+        fa, f1, f2, bc, umi, n = make_cell_inputs(tmp, name)
+        out = os.path.join(tmp, "ref")
+        t0 = time.time()
+        subprocess.run([REF_BIN, "-t", str(threads), "-f", fa, "-1", f1, "-2", f2, "--barcode", bc, "--UMI", umi, "-o", out], check=True, stderr=subprocess.DEVNULL)
+        rec = {"pairs": n, "cells": CELL_CONFIGS[name][1], "seed": CELL_CONFIGS[name][2], "inputs_md5": [md5(x) for x in (f1, f2, bc, umi)],
+               "modes": {"barcode": {"md5": {s: md5(out + s) for s in SUFFIXES}, "reference_seconds": round(time.time() - t0, 1), "reference_threads": threads}}}
+        allrec = json.load(open(OUT)) if os.path.exists(OUT) else {}
+        allrec[name] = rec
+        with open(OUT, "w") as f:
+            json.dump(allrec, f, indent=1, sort_keys=True)
+            f.write("\n")
+    finally:
+        if not keep:
+            shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS) + sorted(CELL_CONFIGS))
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
     ap.add_argument("--keep", default="", help="directory to keep the files in (default: a temporary one)")
     ap.add_argument("--modes", default="skipMateExtension,default", help="which option sets to digest")
     args = ap.parse_args()
+    if args.config in CELL_CONFIGS:
+        return digest_cells(args.config, args.threads, args.keep)
     tmp = args.keep or tempfile.mkdtemp(prefix="t4c2_")
     os.makedirs(tmp, exist_ok=True)
     try:

@@ -615,6 +615,10 @@ struct t4_assembler : IndexListener {
   bool mergeRestricted(Cached &c, int pc, int k2, const t4_overlap *ov, const t4_overlap *ex, const int32_t *rets, const t4_cand *nc, int ncnt, const int32_t *s8);
   static void replayScan(const std::vector<t4_cand> &cands, const std::vector<Seq> &seqs, int len, int radius, double repeatSim, std::vector<unsigned char> &cut);
   int64_t whyNot[6] = {0, 0, 0, 0, 0, 0};   // entries that fell whole although one contig changed: lists beyond 10000 postings, overlaps on the other strand, more than 44 candidate overlaps, more than ~100 groups of four hits, no report from the query, other
+  // (precondition of every restricted path: what the entry's result takes from one contig is independent of the other contigs. The
+  // one step of GetOverlapsFromRead that pairs hits ACROSS sequences, the VJ-junction rescue of SeqSet.hpp:1570-1575, considers
+  // reference genes only and a contig set holds none; the query reports a result that came from it as nOther = 32767, which keeps
+  // the entry out of here.)
   bool eligibleForRestricted(const Cached &e) {
     if (!restrictOn || !e.valid || e.skip || e.barcode != -1) { ++whyNot[5]; return false; }
     if (!e.auxOk) { ++whyNot[4]; return false; }

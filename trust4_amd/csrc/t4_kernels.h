@@ -749,6 +749,7 @@ struct WaveState { // wave-uniform scalars kept in LDS
   int statsStable;                   // no pass of this read so far whose novelMinHitRequired could move (see overlapsFromKeys)
   int hullLo[2], hullHi[2];          // restricted re-query: per strand, hull of the read's projections along the diagonals that hold three or more hits with the contig (lo > hi: none)
   int forceMin[2];                   // restricted re-query: novelMinHitRequired per strand as the entry's whole query had it (0: three hits), T4QueryArgs::forceMin
+  int vjRescue;                      // the pass ended in the VJ-junction rescue (GetVJOverlapsFromHits looks ACROSS sequences: such a result is not the sum of per-contig parts)
   int nAll, nOther, strand0;          // GetOverlapsFromRead: overlaps on the strand of the best one (before the similarity cut), on the other strand, that strand
   int wideWant;                      // mode 4, nonzero: a pass that emits more hits than this (or outgrows the global-scratch tier) is handed to the wide query (t4_wide.h)
   unsigned hhBest[2];        // HasHitInSet: per strand, (distinct read offsets << 16) | (0xFFFF - bucket rank) of the best bucket
@@ -2687,7 +2688,7 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
   const int lane = tid(), NT = nthr();
   if (segLen < ix.k) return -1;
   int overlapCnt = 0;
-  if (lane == 0) { ws->nAll = 0; ws->nOther = 0; ws->strand0 = 0; }
+  if (lane == 0) { ws->nAll = 0; ws->nOther = 0; ws->strand0 = 0; ws->vjRescue = 0; }
   if (ROWS && onlySeq >= 0) {
     // Restricted re-query (T4QueryArgs::onlySeq): every overlap of the read with ONE contig, scored; nothing that looks across
     // contigs is applied (strand of the best overlap, pre-filters, similarity cut: the caller merges with what it holds)
@@ -2734,6 +2735,7 @@ __device__ int overlapsFromSegment(const T4IndexView &ix, WaveMem &wm, WaveState
       __syncthreads();
       overlapCnt = ws->ovCount;
       if (overlapCnt == 0) return 0;
+      if (lane == 0) ws->vjRescue = 1;   // (only reference genes can pair up there: never in a set of contigs alone, where restricted re-queries live -- enforced, not assumed: ADVICE r4)
     }
   }
 #ifdef T4_DEBUG
@@ -3523,7 +3525,7 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
       return true;
     }
     if (lane == 0 && onlySeq < 0) {
-      if (qa.aux) qa.aux[r] = (ret == -2 || ret == -3) ? -1 : ((ws->nAll > 32767 ? 32767 : ws->nAll) | ((ws->nOther > 32767 ? 32767 : ws->nOther) << 15) | (ws->strand0 << 30));
+      if (qa.aux) qa.aux[r] = (ret == -2 || ret == -3) ? -1 : ((ws->nAll > 32767 ? 32767 : ws->nAll) | (((ws->nOther > 32767 || ws->vjRescue) ? 32767 : ws->nOther) << 15) | (ws->strand0 << 30));   // (a VJ-rescue result reads as "overlaps on the other strand": never eligible for a restricted re-query)
       if (qa.n4) qa.n4[r] = ws->nvN4[0] + ws->nvN4[1];
     }
     if (wide && (ret == -3 || (ret == -2 && !wm.ldsArrays))) {   // (overlaps beyond the LDS tier's arrays: the global-scratch pass of this workgroup first)

@@ -1164,11 +1164,24 @@ int main(int argc, char *argv[]) {
     int G = getenv("T4_CELL_GROUPS") ? atoi(getenv("T4_CELL_GROUPS")) : (threadCnt >= 8 ? 4 : 2);   // (two even at -t 1: a group's thread mostly waits for its batch, like the reader threads it is not counted against -t)
     if (G < 1) G = 1;
     if (G > 16) G = 16;
-    cellCtxs.assign((size_t)G, nullptr); cellSets.assign((size_t)G, nullptr);
+    // (every group beyond the first costs the device a ctx of its own -- stream, scratch, result pools, an arena of cell images: a few
+    // hundred MB --; on a shared or smaller GPU one that cannot be had is left out and the run goes on with the groups it has: one group
+    // is the round-3 path. ADVICE r4.)
+    cellCtxs.clear(); cellSets.clear();
     for (int g = 0; g < G; ++g) {
-      cellCtxs[(size_t)g] = ctx;
-      if (g > 0 && (rc = t4_init(getenv("T4_DEVICE") ? atoi(getenv("T4_DEVICE")) : 0, &cellCtxs[(size_t)g]))) { fprintf(stderr, "trust4-hip: t4_init for cell group %d failed (%d)\n", g, rc); return EXIT_FAILURE; }
-      if ((rc = t4_cellset_create(cellCtxs[(size_t)g], indexKmerLength, &cellSets[(size_t)g]))) die(cellCtxs[(size_t)g], "t4_cellset_create", rc);
+      t4_ctx *gc = ctx;
+      t4_cellset *gs = nullptr;
+      if (g > 0 && (rc = t4_init(getenv("T4_DEVICE") ? atoi(getenv("T4_DEVICE")) : 0, &gc))) { fprintf(stderr, "trust4-hip: no ctx for cell group %d (%d): going on with %d group(s)\n", g, rc, g); break; }
+      if ((rc = t4_cellset_create(gc, indexKmerLength, &gs))) {
+        if (g == 0) die(gc, "t4_cellset_create", rc);
+        fprintf(stderr, "trust4-hip: no cell set for cell group %d (%s): going on with %d group(s)\n", g, t4_last_error(gc), g);
+        t4_destroy(gc);
+        break;
+      }
+      cellCtxs.push_back(gc); cellSets.push_back(gs);
+    }
+    G = (int)cellSets.size();
+    for (int g = 0; g < G; ++g) {
       t4_cellset_set_params(cellSets[(size_t)g], hitLenRequired, 10, 0.9);
       t4_cellset_set_threads(cellSets[(size_t)g], (threadCnt + G - 1) / G);
     }
@@ -1570,16 +1583,25 @@ int main(int argc, char *argv[]) {
   // ---- outputs (main.cpp:1959-2036)
   std::vector<const char *> bnames;
   for (const std::string &b : barcodeIntToStr) bnames.push_back(b.c_str());
-  auto writeSet = [&](const std::string &path) {
+  // (returns the status instead of ending the process: two of these run on threads of their own below, and a die() there would call
+  // exit() while the main thread is still writing the reads -- ADVICE r4; every caller reports after its join)
+  auto writeSetRc = [&](const std::string &path, t4_ctx **errCtx, const char **what) -> int {
+    int wrc = 0;
     if (useCells) {   // group after group: a group's contig ids follow the contig slots of the groups before it
       int base = 0;
       for (size_t g = 0; g < cellSets.size(); ++g) {
-        if ((rc = t4_cellset_output_at(cellSets[g], path.c_str(), bnames.data(), (int)bnames.size(), base, g > 0))) die(cellCtxs[g], "t4_cellset_output_at", rc);
+        if ((wrc = t4_cellset_output_at(cellSets[g], path.c_str(), bnames.data(), (int)bnames.size(), base, g > 0))) { *errCtx = cellCtxs[g]; *what = "t4_cellset_output_at"; return wrc; }
         base += t4_cellset_size(cellSets[g]);
       }
     }
-    else if (hasBarcode) { if ((rc = t4_assembler_output_barcodes(seqSet, path.c_str(), bnames.data(), (int)bnames.size()))) die(ctx, "t4_assembler_output_barcodes", rc); }
-    else if ((rc = t4_assembler_output(seqSet, path.c_str()))) die(ctx, "t4_assembler_output", rc);
+    else if (hasBarcode) { if ((wrc = t4_assembler_output_barcodes(seqSet, path.c_str(), bnames.data(), (int)bnames.size()))) { *errCtx = ctx; *what = "t4_assembler_output_barcodes"; } }
+    else if ((wrc = t4_assembler_output(seqSet, path.c_str()))) { *errCtx = ctx; *what = "t4_assembler_output"; }
+    return wrc;
+  };
+  auto writeSet = [&](const std::string &path) {
+    t4_ctx *ec = ctx; const char *what = "";
+    const int wrc = writeSetRc(path, &ec, &what);
+    if (wrc) die(ec, what, wrc);
   };
   if (contigMinCov > 0) {   // main.cpp:1952-1955
     if (useCells) { for (t4_cellset *cs : cellSets) t4_cellset_release_shallow_contigs(cs, contigMinCov); } else t4_assembler_release_shallow_contigs(seqSet, contigMinCov);
@@ -1748,9 +1770,10 @@ int main(int argc, char *argv[]) {
   // threads while this one writes the reads (stdout output and shards keep the serial order)
   const bool concurrentFiles = !toStdout && shardCount == 1 && threadCnt > 1;
   std::thread rawWriter, finalWriter;
+  int rawRc = 0, finalRc = 0; t4_ctx *rawCtx = ctx, *finalCtx = ctx; const char *rawWhat = "", *finalWhat = "";
   if (concurrentFiles) {
-    rawWriter = std::thread([&] { writeSet(outputPrefix + "_raw.out"); });
-    finalWriter = std::thread([&] { writeSet(outputPrefix + "_final.out"); });
+    rawWriter = std::thread([&] { rawRc = writeSetRc(outputPrefix + "_raw.out", &rawCtx, &rawWhat); });
+    finalWriter = std::thread([&] { finalRc = writeSetRc(outputPrefix + "_final.out", &finalCtx, &finalWhat); });
   } else writeSetOrStdout(outputPrefix + "_raw.out");
   size_t nMainAssembled = assembledReadIdx.size();
   if (shardCount > 1) nMainAssembled -= (size_t)rescuedCnt;
@@ -1776,7 +1799,11 @@ int main(int argc, char *argv[]) {
       PrintLog("NOTE: T4_ALLOW_RAW_FINAL=1: _final.out is the raw assembly (what the reference writes under --skipMateExtension), NOT its mate-pair extension.");
     if (!concurrentFiles) writeSetOrStdout(outputPrefix + "_final.out");
   }
-  if (concurrentFiles) { rawWriter.join(); finalWriter.join(); }
+  if (concurrentFiles) {
+    rawWriter.join(); finalWriter.join();
+    if (rawRc) die(rawCtx, rawWhat, rawRc);
+    if (finalRc) die(finalCtx, finalWhat, finalRc);
+  }
   if (useCells) {
     mark("outputs_written");
     writeCellStats();
