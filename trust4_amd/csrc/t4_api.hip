@@ -71,7 +71,7 @@ struct AqCall {
   unsigned char *tierHint = nullptr;
   std::vector<unsigned char> allGlobal;
   size_t oPk, oNm, oLen, oBc, oSt, oLs, oVw, oFa, oOnly, oForce, oCs, oWide, oWideA, inBytes, pCb, pCc, pS8, pCnt, pSta, pNext, pNext2, pBase, pTick, pStab, pAux, pN4, pTail, pWctl, pWplan, pWstat, pWctlA, pWplanA, pWstatA, outBytes;
-  bool hasOnly = false, hasForce = false, wantCands = false;
+  bool hasOnly = false, hasForce = false, wantCands = false, useMarks = false;
   bool extendLater = false, wide = false, onlyRestricted = false;
   int wideSafety = 32;   // of sixteenths: partitions are planned for half of their capacity
   T4BatchView bv; T4QueryArgs qa; T4Work wk;
@@ -1529,7 +1529,7 @@ struct AqResult { const int32_t *counts, *base; const t4_overlap *ov, *ext; cons
 int aqLaunch(t4_ctx *c);
 int aqBegin(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const int32_t *viewOf, bool smallFirst, int n, const char *bases,
             const int64_t *offsets, const int32_t *barcodes, const int32_t *strands, int skip_repeats, const double *factors,
-            unsigned char *tierHint = nullptr, bool lean = false, const int32_t *onlySeq = nullptr, const int32_t *forceMin = nullptr, bool wantCands = false) {
+            unsigned char *tierHint = nullptr, bool lean = false, const int32_t *onlySeq = nullptr, const int32_t *forceMin = nullptr, int wantCands = 0) {
   (void)hipSetDevice(c->device);
   AqCall &q = c->aq;
   if (q.active) return fail(c, T4_ERR_STATE, "an AddRead query is already in flight on this ctx");
@@ -1551,7 +1551,7 @@ int aqBegin(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const 
   q.oVw = al8(q.oLs + sizeof(int) * (size_t)n); q.oFa = al8(q.oVw + sizeof(int) * (size_t)n); q.oOnly = al8(q.oFa + sizeof(double) * (size_t)n);
   q.oForce = al8(q.oOnly + sizeof(int) * (size_t)n);
   q.oCs = al8(q.oForce + sizeof(int) * (size_t)n);
-  q.oWide = al8(q.oCs + sizeof(T4CandArgs)); q.hasOnly = onlySeq != nullptr; q.hasForce = forceMin != nullptr; q.wantCands = wantCands;
+  q.oWide = al8(q.oCs + sizeof(T4CandArgs)); q.hasOnly = onlySeq != nullptr; q.hasForce = forceMin != nullptr; q.wantCands = (wantCands & 1) != 0; q.useMarks = (wantCands & 2) != 0;
   q.oWideA = al8(q.oWide + sizeof(T4Wide)); q.inBytes = al8(q.oWideA + sizeof(T4Wide));
   q.pCnt = 0; q.pSta = al8(q.pCnt + sizeof(int) * (size_t)n); q.pNext = al8(q.pSta + sizeof(int) * (size_t)n);
   q.pNext2 = al8(q.pNext + sizeof(int) * (size_t)n); q.pBase = al8(q.pNext2 + sizeof(int) * (size_t)n);
@@ -1666,6 +1666,7 @@ int aqLaunch(t4_ctx *c) {
     memset(&cs, 0, sizeof cs);
     cs.stats8 = (int *)(c->aqOut + q.pS8);
     if (q.hasForce) cs.forceMin = (const int *)(c->aqIn + q.oForce);
+    cs.useMarks = q.useMarks ? 1 : 0;
     if (q.wantCands) {
       cs.candOut = c->candPoolDev; cs.candCap = c->candCap; cs.candCursor = (unsigned *)(c->aqOut + q.pTail + 32); cs.candOverflow = (int *)(c->aqOut + q.pTail + 36);
       cs.candBase = (int *)(c->aqOut + q.pCb); cs.candCnt = (int *)(c->aqOut + q.pCc);
@@ -2080,7 +2081,7 @@ int t4_add_query_pool_begin2(t4_index *ix, int n, const char *bases, const int64
   t4_ctx *c = ix->ctx;
   if (!ix->committed) return fail(c, T4_ERR_STATE, "index not committed");
   if (ix->view.firstIsRef) return fail(c, T4_ERR_UNSUPPORTED, "t4_add_query needs a contig set");
-  return aqBegin(c, ix->view, nullptr, nullptr, false, n, bases, offsets, barcodes, strands, skip_repeats, factors, tier_hint, true, only_seq, force_min, want_cands != 0);
+  return aqBegin(c, ix->view, nullptr, nullptr, false, n, bases, offsets, barcodes, strands, skip_repeats, factors, tier_hint, true, only_seq, force_min, want_cands);
 }
 // per read of the last finished call begun with want_cands: its candidate records (cnt[i] of them from base[i] of pool, pinned
 // memory valid until the next call) and its eight statistics words (T4QueryArgs::stats8)

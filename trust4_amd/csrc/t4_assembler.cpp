@@ -301,6 +301,11 @@ struct Seq {
   std::string name, cons;
   std::vector<PosWeight> pw;
   bool released = false;
+  // live set: postings (this contig, offset) the index holds, per offset -- shipped as "posting marks" in bits 5-6 of the predicate
+  // bytes (t4_device.h T4_PW_MARK_*), so that a restricted re-query reads a contig's postings off the contig itself
+  std::vector<uint8_t> postCnt;
+  bool marksBad = false;   // an offset held more than three postings once: the marks of this contig are not used
+  bool pwTouched = true;   // posWeight or consensus changed since UpdateAllConsensus last looked at this contig (it is idempotent on a contig that did not)
   bool frozen = false;   // ReleaseFinishedBarcodeSeq: out of the index, posWeight final (SeqSet.hpp:10847-10935)
   int minLeftExtAnchor = 0, minRightExtAnchor = 0, barcode = -1, numRead = 0;
   // live set: place in the device arena of consensus chars / predicate bytes, and what of it changed since the last delta
@@ -637,9 +642,9 @@ struct t4_assembler : IndexListener {
 
   // testing / development aids, read from the environment ONCE per builder (none changes a result; DESIGN 7b lists them)
   struct Knobs {
-    bool verifyWindow = false, noStableStats = false, wideQueries = true, candStore = true, restrictOn = true, predictHints = true;
+    bool verifyWindow = false, noStableStats = false, wideQueries = true, candStore = true, restrictOn = true, predictHints = true, useMarks = true;
     int wideHitLimit = 8192;
-    int lanes = 1, queryAhead = 0, minBatch = 4, harvestDelay = 0, lightAhead = -1, heavyBatch = 0, maxPending = 4; double aheadMult = 3.0;
+    int lanes = 1, queryAhead = 0, minBatch = 4, harvestDelay = 0, lightAhead = 0, heavyBatch = 0, maxPending = 4; double aheadMult = 3.0;
     FILE *roundLog = nullptr;
     Knobs() {
       auto num = [](const char *n, int d) { const char *e = getenv(n); return e ? atoi(e) : d; };
@@ -649,11 +654,12 @@ struct t4_assembler : IndexListener {
       heavyBatch = num("T4_HEAVY_BATCH", 0); if (getenv("T4_AHEAD_MULT")) aheadMult = atof(getenv("T4_AHEAD_MULT"));
       wideQueries = !getenv("T4_WIDE_OFF") && !getenv("T4_AQ_FORCE_GLOBAL");
       { const int lim = num("T4_AQ_CAP_LIMIT", 0); wideHitLimit = lim > 0 ? lim : num("T4_WIDE_MIN_HITS", 8192); }
+      useMarks = !getenv("T4_NO_MARKS");        // A-B aid: restricted re-queries walk the read's posting lists as in round 4
       predictHints = !getenv("T4_NO_PREDICT");   // A-B aid: no look at the reads of the next whole-query round
       candStore = !getenv("T4_CANDS_OFF");      // testing / A-B aid: the restricted path as round 4 had it (at most 44 candidates, ~100 groups of four hits)
       restrictOn = !getenv("T4_RESTRICT_OFF");  // testing / A-B aid: every invalidated entry is queried again in full
       maxPending = num("T4_MAX_PENDING", 4);   // contigs a window entry may wait for at a time (1: round 4's rule, a second contig ends the entry)
-      lightAhead = num("T4_LIGHT_AHEAD", -1);   // -1: every round carries every entry without a result (within `ahead`)
+      lightAhead = num("T4_LIGHT_AHEAD", 0);    // whole queries ride with a head that waits for a restricted re-query only when they are this near the head (0: the head's own); -1: every round carries every entry without a result (round 4)
       if (getenv("T4_ROUND_LOG")) roundLog = fopen(getenv("T4_ROUND_LOG"), "w");   // one line per launch: reads, kernel ms, per read us / overlaps / tier / killed in flight
     }
     ~Knobs() { if (roundLog) fclose(roundLog); }
@@ -674,16 +680,28 @@ struct t4_assembler : IndexListener {
   void invalidateSlot(int slot) { if (slot >= (int)cacheHead && slot < (int)cache.size() && cache[slot].valid) { cache[slot].valid = false; ++invalidations; } }
   void invalidateCell() { for (size_t q = cacheHead; q < cache.size(); ++q) invalidateSlot((int)q); }
   // IndexListener: cells end their window on any index change; live sets examine the change at the end of the commit
+  void postMark(int idx, int off, int delta) {   // the posting marks of contig idx (see Seq::postCnt)
+    if (idx < 0 || idx >= (int)seqs.size() || off < 0) return;
+    Seq &q = seqs[idx];
+    if ((int)q.postCnt.size() <= off) q.postCnt.resize((size_t)off + 64, 0);
+    uint8_t &v = q.postCnt[(size_t)off];
+    if (delta > 0) { if (v >= 3 && !q.marksBad) { q.marksBad = true; markBaseDirty(idx, 0); } if (v < 255) ++v; }
+    else if (v > 0) --v;
+    markBaseDirty(idx, off);
+  }
   void onInsert(uint64_t code, int h, int idx, int off, uint32_t sizeAfter) override {
     if (!live()) { invalidateCell(); return; }
+    postMark(idx, off, +1);
     if (!order.empty()) idxEvents.push_back(IdxEv{code, h, idx, off, +1, sizeAfter});
   }
   void onRemove(uint64_t code, int h, int idx, int off, uint32_t sizeAfter) override {
     if (!live()) { invalidateCell(); return; }
+    postMark(idx, off, -1);
     if (!order.empty()) idxEvents.push_back(IdxEv{code, h, idx, off, -1, sizeAfter});
   }
   void onMove(uint64_t code, int h, int oldIdx, int oldOff, int idx, int off) override {
     if (!live()) { invalidateCell(); return; }
+    postMark(oldIdx, oldOff, -1); postMark(idx, off, +1);
     if (order.empty() || oldIdx == idx) return;   // a shift of one contig's postings is one structural event (evShift)
     idxEvents.push_back(IdxEv{code, h, oldIdx, oldOff, -1, 0xFFFFFFFFu});   // sizes unchanged
     idxEvents.push_back(IdxEv{code, h, idx, off, +1, 0xFFFFFFFFu});
@@ -710,6 +728,7 @@ struct t4_assembler : IndexListener {
   }
   // ++count[base] of one posWeight column; reports whether AlignAlgo::IsBaseEqual (AlignAlgo.hpp:49-55) can now answer differently
   void bumpWeight(int seqIdx, PosWeight &w, int base) {
+    seqs[seqIdx].pwTouched = true;
     int sum = w.c[0] + w.c[1] + w.c[2] + w.c[3];
     unsigned before = sum == 0 ? 16u : 0u, after = 0;
     for (int x = 0; x < 4; ++x) before |= (sum < 3 * w.c[x]) ? (1u << x) : 0u;
@@ -841,7 +860,12 @@ struct t4_assembler : IndexListener {
     if (updateIndex) index.build(s.cons.c_str(), (int)s.cons.size(), seqIdx, s.barcode, 0);
     structuralChange(seqIdx, true);
   }
-  void updateAllConsensus() { for (int i = 0; i < (int)seqs.size(); ++i) if (!seqs[i].released) updateConsensus(i, true); }
+  // UpdateAllConsensus (SeqSet.hpp:4525-4535). The driver calls it every 10 000 assembled reads (main.cpp:1862-1868); a contig whose
+  // counts and consensus are what they were at the last call comes out of UpdateConsensus unchanged (the call before settled every
+  // column), so only the contigs a read has touched since are walked -- all 23 k of them 170 times was 3-4 s of config C2's chain.
+  void updateAllConsensus() {
+    for (int i = 0; i < (int)seqs.size(); ++i) if (!seqs[i].released && seqs[i].pwTouched) { updateConsensus(i, true); seqs[i].pwTouched = false; }
+  }
 
   // SubstituteConsensusPos (SeqSet.hpp:11058-11080), updateIndex == true
   void substituteConsensusPos(int seqIdx, int pos, char c) {
@@ -885,6 +909,7 @@ struct t4_assembler : IndexListener {
     std::vector<Seq> kept;
     for (Seq &s : seqs) if (!s.released) kept.push_back(std::move(s));
     seqs.swap(kept);
+    for (Seq &s : seqs) { s.postCnt.clear(); s.marksBad = false; }   // (the builds below mark every posting of the new index)
     for (int i = 0; i < (int)seqs.size(); ++i) index.build(seqs[i].cons.c_str(), (int)seqs[i].cons.size(), i, seqs[i].barcode, 0);
     setPrev(-1, -1, -1, -1, -1, 0);
     if (dev) { t4_index_destroy(dev); dev = nullptr; }   // nomatchGapLimit and the lookup layout depend on k
@@ -1235,6 +1260,7 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
       i = j;
     }
     ret = seqIdx;
+    seq.pwTouched = true;   // (extension / merge / placement: counts or consensus of this contig changed)
   }
   // a set of novel contigs has no reference sequence to anchor a new contig on (SeqSet.hpp:4373-4384)
   if (ret == -1) { setPrev(-2, -1, -1, -1, -1, 0); ret = -2; }
@@ -1354,8 +1380,11 @@ int t4_assembler::makeDelta() {
     if (hi > lo) {
       R.baseAt.push_back(q.baseOff + lo); R.baseLen.push_back(hi - lo);
       for (int t = lo; t < hi; ++t) {
-        if (t < len) { R.baseCons.push_back(q.cons[t]); R.basePw.push_back(t4PwByte(q.pw[t].c[0], q.pw[t].c[1], q.pw[t].c[2], q.pw[t].c[3])); }
-        else { R.baseCons.push_back('\0'); R.basePw.push_back(t4PwByte(0, 0, 0, 0)); }
+        unsigned char mark = 0;   // posting marks (t4_device.h): postings at this offset, and on the first byte whether the contig's marks count
+        if (t < (int)q.postCnt.size()) mark = (unsigned char)((q.postCnt[(size_t)t] > 3 ? 3 : q.postCnt[(size_t)t]) << 5);
+        if (t == 0 && q.marksBad) mark |= 128;
+        if (t < len) { R.baseCons.push_back(q.cons[t]); R.basePw.push_back((uint8_t)(t4PwByte(q.pw[t].c[0], q.pw[t].c[1], q.pw[t].c[2], q.pw[t].c[3]) | mark)); }
+        else { R.baseCons.push_back('\0'); R.basePw.push_back((uint8_t)(t4PwByte(0, 0, 0, 0) | mark)); }
       }
     }
   }
@@ -1882,7 +1911,7 @@ int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive
     auto tq0 = std::chrono::steady_clock::now();
     candStore = knobs.candStore;
     rc = t4_add_query_pool_begin2(L.dev, mi, L.bases.data(), L.offs.data(), L.bcs.data(), L.sts.data(), repetitive, L.fac.data(), L.hint.data(), anyOnly ? L.only.data() : nullptr,
-                                  anyOnly ? L.force.data() : nullptr, candStore ? 1 : 0);
+                                  anyOnly ? L.force.data() : nullptr, (candStore ? 1 : 0) | (knobs.useMarks ? 2 : 0));
     secQuery += std::chrono::duration<double>(std::chrono::steady_clock::now() - tq0).count();
   }
   if (rc) { for (int sl : todo) pool[sl]->inflight = false; return rc; }

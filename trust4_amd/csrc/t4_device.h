@@ -180,7 +180,13 @@ struct T4CandArgs {
   int *candBase, *candCnt;   // null with candOut
   int *stats8;
   const int *forceMin;       // nullable
+  int useMarks;              // the image's predicate bytes carry posting marks (T4_PW_MARK_*): restricted re-queries read a contig's postings off the contig
 };
+// Bits 5-6 of a contig's predicate byte at offset o: the number of postings (contig, o) the index holds (0-3); bit 7 of the byte at
+// offset 0: the marks of this contig are not to be trusted (an offset with more than three postings). Written by the ordered
+// builder's deltas (t4_assembler::makeDelta); AlignAlgo::IsBaseEqual's bits 0-4 are all baseEqualW looks at.
+#define T4_PW_MARK_SHIFT 5
+#define T4_PW_MARK_BAD 128
 #define T4_CAND_PLUS 1
 #define T4_CAND_SIMZERO 2
 #define T4_CAND_CUT 4

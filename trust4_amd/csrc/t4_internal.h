@@ -58,7 +58,9 @@ int t4_add_query_pool_begin(t4_index *ix, int n, const char *bases, const int64_
 // words per read: per strand (minus, plus) the groups of >= 4 hits, of >= 5 hits, the largest group (true sizes; a restricted
 // re-query: of its one contig) and the novelMinHitRequired the pass used (SeqSet.hpp:784-823); a restricted re-query adds the hull of
 // the read's projections along the contig's diagonals with three or more hits (lo minus / plus, hi minus / plus; lo > hi: none):
-// T4_QUERY_STATS words per read. force_min (nullable, restricted
+// T4_QUERY_STATS words per read. want_cands: 1 = return the candidate records; | 2 = the image's predicate bytes carry posting marks
+// (bits 5-6 of the byte at offset o: postings (contig, o) in the index, bit 7 of a contig's first byte: marks not to be trusted --
+// t4_assembler::makeDelta writes them), so a restricted re-query reads the contig's postings off the contig. force_min (nullable, restricted
 // re-queries): that threshold for the one contig's groups, minus | plus << 16 (0: three hits).
 #define T4_QUERY_STATS 12
 typedef struct { int32_t seqIdx, ss, se; int16_t rs, re, m0, matchCnt, indelCnt; uint16_t flags; } t4_cand;   // flags: 1 plus strand, 2 scoring left similarity 0, 4 cut by the pre-filters

@@ -748,6 +748,7 @@ struct WaveState { // wave-uniform scalars kept in LDS
   int nvN4[2], nvN5[2], nvSmax[2];   // groups of at least 4 / 5 hits and the largest group, TRUE sizes (the statistics measure a group one short or in full)
   int statsStable;                   // no pass of this read so far whose novelMinHitRequired could move (see overlapsFromKeys)
   int hullLo[2], hullHi[2];          // restricted re-query: per strand, hull of the read's projections along the diagonals that hold three or more hits with the contig (lo > hi: none)
+  int useMarks;                      // restricted re-query: read the contig's postings off its posting marks (T4CandArgs::useMarks)
   int forceMin[2];                   // restricted re-query: novelMinHitRequired per strand as the entry's whole query had it (0: three hits), T4QueryArgs::forceMin
   int vjRescue;                      // the pass ended in the VJ-junction rescue (GetVJOverlapsFromHits looks ACROSS sequences: such a result is not the sum of per-contig parts)
   int nAll, nOther, strand0;          // GetOverlapsFromRead: overlaps on the strand of the best one (before the similarity cut), on the other strand, that strand
@@ -1110,6 +1111,79 @@ __device__ int expandHitsOnly(const T4IndexView &ix, WaveMem &wm, WaveState *ws,
   const int n = ws->candCount;
   __syncthreads();
   return n <= wm.hitLimit ? n : -1;
+}
+
+// The same hits read off the CONTIG instead of the read's posting lists (restricted re-query with posting marks, T4CandArgs::useMarks):
+// a posting (seq, o) exists for every offset o whose predicate byte carries a mark, its code is the contig's k-mer at o (the index
+// is kept in step with the consensus: KmerIndex entries are removed and rebuilt whenever a consensus base changes, SeqSet.hpp:4537-
+// 4588, 11058-11080), and it is a hit of read position q exactly when q was emitted by the seed stage and holds that code. A heavy
+// read's restricted re-query then costs the contig's length, not the read's tens of thousands of postings. codeBuf: the codes of the
+// read's 2 nk positions (left in the key array by the seed stage); the hits are built behind them and moved to the front.
+// Returns their number, -1 when they outgrow the key array, -2 when the contig's marks are not to be trusted.
+__device__ T4_NI int expandHitsContig(const T4IndexView &ix, WaveMem &wm, WaveState *ws, int nk, int seq, const unsigned *posPref) {
+  const int lane = tid(), NT = nthr(), K = ix.k;
+  const T4SeqInfo si = ix.seqs[seq];
+  if (si.len >= 1 && (ix.pw[si.pwOff] & T4_PW_MARK_BAD)) return -2;
+  const unsigned long long *codeBuf = wm.keys;
+  unsigned *head = wm.cand, *next = wm.cand + 1024;   // 1024 chain heads (q + 1; 0: empty), 2 nk links
+  const int HOFF = 1024;                              // the hits start behind the codes (2 nk <= 768 of them)
+  if (2 * nk > 768 || wm.candCap < 1024 + 768 || wm.hitLimit <= HOFF + 64) return -2;
+  for (int i = lane; i < 1024; i += NT) head[i] = 0u;
+  if (lane == 0) ws->candCount = 0;
+  __syncthreads();
+  for (int q = lane; q < 2 * nk; q += NT) {
+    if (posPref[q + 1] == posPref[q]) continue;   // not emitted (or an empty list)
+    const unsigned long long code = codeBuf[q];
+    unsigned h = (unsigned)((code * 0x9E3779B97F4A7C15ull) >> 54);   // 10 bits
+    for (;;) {
+      const unsigned cur = head[h];
+      if (cur == 0u) { if (atomicCAS(&head[h], 0u, (unsigned)q + 1u) == 0u) { next[q] = 0u; break; } continue; }
+      if (codeBuf[cur - 1u] == code) { next[q] = atomicExch(&head[h], (unsigned)q + 1u); break; }   // (the slot stays with this code: every later head holds it too)
+      h = (h + 1u) & 1023u;
+    }
+  }
+  __syncthreads();
+  const unsigned long long mask = K < 32 ? ((1ull << (2 * K)) - 1ull) : ~0ull;
+  for (int o = lane; o + K <= si.len; o += NT) {
+    const int m = (ix.pw[si.pwOff + o] >> T4_PW_MARK_SHIFT) & 3;
+    if (!m) continue;
+    unsigned long long code = 0;
+    bool ok = true;
+    for (int t = 0; t < K; ++t) { const char ch = ix.cons[si.consOff + o + t]; if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') ok = false; code = (code << 2) | (unsigned long long)nuc2(ch); }
+    if (!ok) continue;
+    code &= mask;
+    unsigned h = (unsigned)((code * 0x9E3779B97F4A7C15ull) >> 54);
+    for (;;) {
+      const unsigned cur = head[h];
+      if (cur == 0u) break;
+      if (codeBuf[cur - 1u] == code) {
+        for (unsigned q1 = cur; q1 != 0u; q1 = next[q1 - 1u]) {
+          const int q = (int)q1 - 1, st = q >= nk, a = st ? q - nk : q;
+          for (int t = 0; t < m; ++t) {
+            const int at = atomicAdd(&ws->candCount, 1);
+            if (HOFF + at < wm.hitLimit)
+              wm.keys[HOFF + at] = ((st ? 0ull : 1ull) << 63) | ((unsigned long long)seq << (T4_C_BITS + T4_B_BITS)) |
+                                   ((unsigned long long)(a - o + T4_C_BIAS) << T4_B_BITS) | (unsigned long long)o;
+          }
+        }
+        break;
+      }
+      h = (h + 1u) & 1023u;
+    }
+  }
+  __syncthreads();
+  const int n = ws->candCount;
+  __syncthreads();
+  if (HOFF + n > wm.hitLimit) return -1;
+  for (int i0 = 0; i0 < n; i0 += NT) {   // to the front, a chunk at a time (the ranges overlap once n passes HOFF)
+    const int i = i0 + lane;
+    unsigned long long v = 0;
+    if (i < n) v = wm.keys[HOFF + i];
+    __syncthreads();
+    if (i < n) wm.keys[i] = v;
+    __syncthreads();
+  }
+  return n;
 }
 
 // Workgroup bitonic sort of keys[0, n) (any n): the all-ascending network on the next power of two with VIRTUAL +inf
@@ -2315,8 +2389,12 @@ __device__ int seedChainPass(const T4IndexView &ix, WaveMem &wm, WaveState *ws, 
   int H = NOVEL ? seedPositionsNovel(ix, wm, segLen, strandArg, barcode, allowTotalSkip, posStart, posPref, ws->red, wm.keys, ws)
                 : seedPositions(ix, wm, segLen, strandArg, barcode, allowTotalSkip, posStart, posPref, ws->red);   // the key array is free until the hits are expanded
   if (NOVEL && onlySeq >= 0) {   // restricted re-query: the hits with one contig (a few hundred at most), whatever the read's total
-    const int Hv = expandHitsOnly(ix, wm, ws, nk, H, onlySeq, posStart, posPref);
+    int Hv = -2;
+    if (ws->useMarks) { __syncthreads(); Hv = expandHitsContig(ix, wm, ws, nk, onlySeq, posPref); }
+    const bool offContig = Hv != -2;
+    if (!offContig) Hv = expandHitsOnly(ix, wm, ws, nk, H, onlySeq, posStart, posPref);
     if (Hv < 0) return -1;
+    if (offContig) H = Hv;   // (the postings this pass looked at)
     if (Hv > 1) { if (wm.ldsArrays) bitonicSortRegLds(wm.keys, Hv); else bitonicSort(wm.keys, Hv); }
     __syncthreads();
     // the contig's two groups (true sizes): what the caller's bookkeeping of the group statistics needs (T4QueryArgs::stats8)
@@ -3497,7 +3575,7 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
   const int lane = tid(), NT = nthr();
   const int len = bv.len[r];
   unsigned long long hitTotal = 0;
-  if (lane == 0) { ws->overflow = 0; ws->unsupported = 0; ws->finCount = 0; ws->nContig = 0; ws->ovCount = 0; ws->statsStable = 1; ws->wideWant = 0; ws->nvN4[0] = ws->nvN4[1] = 0; ws->forceMin[0] = ws->forceMin[1] = 0; }
+  if (lane == 0) { ws->overflow = 0; ws->unsupported = 0; ws->finCount = 0; ws->nContig = 0; ws->ovCount = 0; ws->statsStable = 1; ws->wideWant = 0; ws->nvN4[0] = ws->nvN4[1] = 0; ws->forceMin[0] = ws->forceMin[1] = 0; ws->useMarks = 0; }
 #ifdef T4_PHASE_TIMING
   if (lane == 0) { ws->phaseT0 = clock64(); ws->phaseBase = wm.ldsArrays ? 0 : 32; ws->curPhase = ws->phaseBase; }
 #endif
@@ -3516,6 +3594,7 @@ __device__ bool processRead(const T4IndexView &ix, const T4BatchView &bv, const 
     if (lane == 0 && qa.cs) {
       const T4CandArgs *cs = qa.cs;
       if (onlySeq >= 0 && cs->forceMin) { const int f = cs->forceMin[r]; ws->forceMin[0] = f & 0xFFFF; ws->forceMin[1] = (f >> 16) & 0xFFFF; }
+      if (onlySeq >= 0) ws->useMarks = cs->useMarks;
       if (cs->candCnt) cs->candCnt[r] = 0;
     }
     loadSegment(bv, r, 0, len, wm);
