@@ -8,7 +8,8 @@ text, device bring-up and every host phase are INSIDE the timed region (the boun
 so there is no "inputs resident in HBM" variant of this metric; the kernel-only numbers are in `roofline` / `passes`).
 
 N = 1. The workload is BASELINE.json's config C2 ITSELF (1 M synthetic 150 bp PE pairs, 20 k clones, seed 1, -f hg38_bcrtcr.fa,
-bulk mode) whenever `steps + warmup` runs of it fit the time budget (T4_BENCH_BUDGET_S, default 1500 s): the first run is C2 in
+bulk mode) whenever `steps + warmup` runs of it fit the time budget (T4_BENCH_BUDGET_S, default 1800 s: the driver's 20 + 5 steps of C2
+at its 61 s per step): the first run is C2 in
 any case -- it is compared with the committed md5 sums of the reference's outputs, it is the first warm-up step when C2 is the
 workload, and it is reported as `c2` (with its own roofline block and a same-box reference timing on a stated prefix of the same
 files). When the runs do not fit, the steps are timed on the C2 recipe at 100 k pairs (`config.workload` says which ran).
@@ -581,7 +582,7 @@ def main():
                                                          "a number forces the C2 recipe at that size")
     ap.add_argument("--clones", type=int, default=0, help="clones of the batch (default: pairs / 50, the C2 ratio)")
     ap.add_argument("--threads", type=int, default=8, help="host threads of trust4-hip (-t)")
-    ap.add_argument("--budget", type=float, default=float(os.environ.get("T4_BENCH_BUDGET_S", "1500")), help="seconds the warm-up + timed steps may take (decides whether C2 itself is the workload)")
+    ap.add_argument("--budget", type=float, default=float(os.environ.get("T4_BENCH_BUDGET_S", "1800")), help="seconds the warm-up + timed steps may take (decides whether C2 itself is the workload)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 = skip the reference legs")
     ap.add_argument("--cpu-single-pairs", type=int, default=20000, help="prefix timed with the reference's -t 1 (0 = skip)")
     ap.add_argument("--cpu-c2-pairs", type=int, default=200000, help="prefix of C2's files the reference is timed on, on this box (0 = skip)")

@@ -131,8 +131,11 @@ struct t4_ctx {
     AqEnv() {
       auto num = [](const char *n, int d) { const char *e = getenv(n); return e ? atoi(e) : d; };
       forceGlobal = getenv("T4_AQ_FORCE_GLOBAL") != nullptr; wideNoHint = getenv("T4_WIDE_NO_HINT") != nullptr;
-      capLimit = num("T4_AQ_CAP_LIMIT", 0); extendDefer = num("T4_AQ_EXTEND_DEFER", 64); poolCap = num("T4_AQ_POOL_CAP", 0); candCap = num("T4_AQ_CAND_CAP", 1 << 18);
-      wideMinHits = num("T4_WIDE_MIN_HITS", 8192);
+      capLimit = num("T4_AQ_CAP_LIMIT", 0); poolCap = num("T4_AQ_POOL_CAP", 0); candCap = num("T4_AQ_CAND_CAP", 1 << 18);
+      // (64 until round 5: with light rounds extendKernel runs behind the whole-query rounds anyway, and a read's 17th overlap is better
+      // off there -- profiles/r05e, r05f)
+      extendDefer = num("T4_AQ_EXTEND_DEFER", 16);
+      wideMinHits = num("T4_WIDE_MIN_HITS", 4096);   // (8192, the LDS tier's capacity, until round 5: fresh heavy reads now start on the wide pipeline beside the query kernel, so the wide query pays from half of it on -- C2 67.5 -> 61.0 s, profiles/r05e_c2_w4k, r05f)
     }
   } aqEnv;
   // the wide query (t4_wide.h): pools of the deferred reads of one call, grown on demand
@@ -1696,7 +1699,7 @@ int aqLaunch(t4_ctx *c) {
   if (q.views) { qa.views = q.views; qa.viewOf = (const int *)(c->aqIn + q.oVw); }
   // one big set: the ExtendOverlap calls of reads with more than this many overlaps run in their own launch (0: never)
   int deferMin = c->aqEnv.extendDefer;   // testing aid
-  if (q.wide && deferMin <= 0) deferMin = 64;   // the wide query leaves every ExtendOverlap to extendKernel
+  if (q.wide && deferMin <= 0) deferMin = 16;   // the wide query leaves every ExtendOverlap to extendKernel
   const bool extendLater = deferMin > 0 && !q.views && !smallFirst && !q.onlyRestricted;
   q.extendLater = extendLater;
   if (extendLater) {

@@ -635,7 +635,7 @@ struct t4_assembler : IndexListener {
     return true;
   }
   void rebuildGroup(Cached &e, int c);
-  bool wideQueries = true; int wideHitLimit = 8192;   // what t4_add_query_pool_begin will do with a read of that many emitted hits (set in ensureLanes)
+  bool wideQueries = true; int wideHitLimit = 4096;   // what t4_add_query_pool_begin will do with a read of that many emitted hits (set in ensureLanes)
   int emittedHits(const Cached &e);
   int64_t deltas = 0, deltaBytes = 0, rounds = 0, readsQueried = 0, invKey = 0, invCross = 0, invRegion = 0, invShift = 0, invContig = 0, invFragile = 0, tolerated = 0;
   double secDelta = 0, secGroups = 0, secEvents = 0, secRegister = 0, secPrefetch = 0, secAddTotal = 0;
@@ -643,8 +643,8 @@ struct t4_assembler : IndexListener {
   // testing / development aids, read from the environment ONCE per builder (none changes a result; DESIGN 7b lists them)
   struct Knobs {
     bool verifyWindow = false, noStableStats = false, wideQueries = true, candStore = true, restrictOn = true, predictHints = true, useMarks = true;
-    int wideHitLimit = 8192;
-    int lanes = 1, queryAhead = 0, minBatch = 4, harvestDelay = 0, lightAhead = 0, heavyBatch = 0, maxPending = 4; double aheadMult = 3.0;
+    int wideHitLimit = 4096;
+    int lanes = 1, queryAhead = 0, minBatch = 4, harvestDelay = 0, lightAhead = 0, heavyBatch = 0, maxPending = 8; double aheadMult = 3.0;
     FILE *roundLog = nullptr;
     Knobs() {
       auto num = [](const char *n, int d) { const char *e = getenv(n); return e ? atoi(e) : d; };
@@ -653,12 +653,12 @@ struct t4_assembler : IndexListener {
       lanes = num("T4_LIVE_LANES", 1); queryAhead = num("T4_QUERY_AHEAD", 0); minBatch = num("T4_LIVE_MIN_BATCH", 4); harvestDelay = num("T4_LIVE_HARVEST_DELAY", 0);
       heavyBatch = num("T4_HEAVY_BATCH", 0); if (getenv("T4_AHEAD_MULT")) aheadMult = atof(getenv("T4_AHEAD_MULT"));
       wideQueries = !getenv("T4_WIDE_OFF") && !getenv("T4_AQ_FORCE_GLOBAL");
-      { const int lim = num("T4_AQ_CAP_LIMIT", 0); wideHitLimit = lim > 0 ? lim : num("T4_WIDE_MIN_HITS", 8192); }
+      { const int lim = num("T4_AQ_CAP_LIMIT", 0); wideHitLimit = lim > 0 ? lim : num("T4_WIDE_MIN_HITS", 4096); }
       useMarks = !getenv("T4_NO_MARKS");        // A-B aid: restricted re-queries walk the read's posting lists as in round 4
       predictHints = !getenv("T4_NO_PREDICT");   // A-B aid: no look at the reads of the next whole-query round
       candStore = !getenv("T4_CANDS_OFF");      // testing / A-B aid: the restricted path as round 4 had it (at most 44 candidates, ~100 groups of four hits)
       restrictOn = !getenv("T4_RESTRICT_OFF");  // testing / A-B aid: every invalidated entry is queried again in full
-      maxPending = num("T4_MAX_PENDING", 4);   // contigs a window entry may wait for at a time (1: round 4's rule, a second contig ends the entry)
+      maxPending = num("T4_MAX_PENDING", 8);   // contigs a window entry may wait for at a time (1: round 4's rule, a second contig ends the entry)
       lightAhead = num("T4_LIGHT_AHEAD", 0);    // whole queries ride with a head that waits for a restricted re-query only when they are this near the head (0: the head's own); -1: every round carries every entry without a result (round 4)
       if (getenv("T4_ROUND_LOG")) roundLog = fopen(getenv("T4_ROUND_LOG"), "w");   // one line per launch: reads, kernel ms, per read us / overlaps / tier / killed in flight
     }
