@@ -123,6 +123,7 @@ struct t4_ctx {
   const int32_t *aqLastTicks = nullptr; int aqLastN = 0;   // per-read wall-clock ticks (10 ns) of the last AddRead query call (in the pinned header blob)
   double aqLastMs = 0;
   AqCall aq;
+  uint64_t syncEpoch = 1;   // bumped whenever the ctx's stream has been waited for: work queued before that is done (t4_index_apply_delta's staging buffer)
   // testing aids of the AddRead query path, read from the environment once per ctx (a query round is a few hundred microseconds; a
   // dozen getenv calls in it are not nothing)
   struct AqEnv {
@@ -176,6 +177,7 @@ struct t4_index {
   size_t stCap = 0;
   hipEvent_t stEvent = 0;
   bool stPending = false;
+  uint64_t stEpoch = 0;      // the ctx's syncEpoch when the staging buffer was last handed to a copy
 };
 
 struct t4_batch {
@@ -753,7 +755,10 @@ int t4_index_apply_delta(t4_index *ix, const t4_index_delta *d) {
   {
     size_t bytes = al8(sizeof(T4CopyDesc) * nDesc) + sizeof(T4HashEntC) * (size_t)d->n_slots + 8 * (size_t)postTotal + al8(sizeof(T4SeqInfo)) * (size_t)d->n_seqs;
     for (int64_t i = 0; i < d->n_base_runs; ++i) bytes += 2 * al8((size_t)d->base_len[i]);
-    if (ix->stPending) { HIPCHK(c, hipEventSynchronize(ix->stEvent)); ix->stPending = false; }
+    // the staging buffer is free once the copy that read it is done: a wait for the stream since then (every query round ends with
+    // one) says so without an event of its own; two deltas with no wait in between (query lanes) take the wait here
+    if (ix->stPending && ix->stEpoch == c->syncEpoch) { HIPCHK(c, hipStreamSynchronize(c->stream)); ++c->syncEpoch; }
+    ix->stPending = false;
     if (bytes > ix->stCap) {
       if (ix->stHost) (void)hipHostFree(ix->stHost);
       if (ix->stDev) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(ix->stDev); }
@@ -808,8 +813,7 @@ int t4_index_apply_delta(t4_index *ix, const t4_index_delta *d) {
       bAt += d->base_len[i];
     }
     HIPCHK(c, hipMemcpyAsync(ix->stDev, ix->stHost, at, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipEventRecord(ix->stEvent, c->stream));
-    ix->stPending = true;
+    ix->stPending = true; ix->stEpoch = c->syncEpoch;
     int grid = (int)((nd + 3) / 4);
     if (grid > c->cus * 8) grid = c->cus * 8;
     hipLaunchKernelGGL(t4k::deltaKernel, dim3(grid), dim3(256), 0, c->stream, (const unsigned char *)ix->stDev, (const T4CopyDesc *)ix->stDev, (int)nd);
@@ -1826,6 +1830,7 @@ int aqEnd(t4_ctx *c, AqResult *res) {
     // sleeps wakes up tens of microseconds after the kernels are done; a round is a few hundred)
     for (int spin = 0; spin < 200000 && hipEventQuery(c->ev[3]) == hipErrorNotReady; ++spin) { }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    ++c->syncEpoch;
     { float ms = 0; if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) { c->aqKernelMs += ms; c->aqLastMs = ms; } }
     int overflow = *(int *)(c->aqOutHost + pTail);
     { const int inKernel = *(int *)(c->aqOutHost + pTail + 8); if (!smallFirst && inKernel > 0) { c->aqGlobalReads += inKernel; ++c->aqGlobalLaunches; } }

@@ -728,8 +728,16 @@ struct t4_assembler : IndexListener {
   }
   // ++count[base] of one posWeight column; reports whether AlignAlgo::IsBaseEqual (AlignAlgo.hpp:49-55) can now answer differently
   void bumpWeight(int seqIdx, PosWeight &w, int base) {
-    seqs[seqIdx].pwTouched = true;
     int sum = w.c[0] + w.c[1] + w.c[2] + w.c[3];
+    {
+      // 150 calls per committed read: the common case -- no predicate bit can flip -- decided without building the two masks. With
+      // s = sum: bit x != base flips (1 -> 0) iff 3 c[x] == s + 1; the base's own bit flips (0 -> 1) iff 3 c <= s <= 3 c + 1; the
+      // empty-column bit iff s == 0.
+      const int s1 = sum + 1;
+      bool flip = sum == 0 || (unsigned)(sum - 3 * w.c[base]) < 2u;
+      for (int x = 0; x < 4; ++x) flip = flip || (x != base && 3 * w.c[x] == s1);
+      if (!flip) { ++w.c[base]; return; }
+    }
     unsigned before = sum == 0 ? 16u : 0u, after = 0;
     for (int x = 0; x < 4; ++x) before |= (sum < 3 * w.c[x]) ? (1u << x) : 0u;
     ++w.c[base]; ++sum;
@@ -888,6 +896,7 @@ struct t4_assembler : IndexListener {
     std::string r = read;
     if (prevAdd.strand == -1) reverseComplement(r, std::string(read));
     Seq &s = seqs[prevAdd.seqIdx];
+    s.pwTouched = true;
     for (int i = prevAdd.readStart; i <= prevAdd.readEnd; ++i) {
       if (r[i] == 'N') continue;
       bumpWeight(prevAdd.seqIdx, s.pw[i + prevAdd.seqStart], nucNum(r[i]));
@@ -981,29 +990,37 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
   int overlapCnt = cnt;
   if (overlapCnt <= 0) return -1;
 
+  // (this runs once per served read, between two query rounds: the candidate records are filtered in place and ordered through an
+  // index array, and the working arrays keep their storage from call to call)
   struct Cand { Ov ov; Ov ext; int extRet; };
-  std::vector<Cand> cands;
-  for (int i = 0; i < overlapCnt; ++i) cands.push_back(Cand{fromT4(ovBuf[i]), fromT4(extBuf[i]), extRet[i]});
-  if (geneName[0] != '\0') {
-    std::vector<Cand> kept;
-    for (auto &c : cands) {
-      const std::string &nm = seqs[c.ov.seqIdx].name;
+  static thread_local std::vector<Cand> candStore_, cands;
+  static thread_local std::vector<int> ordIdx;
+  candStore_.clear();
+  candStore_.reserve((size_t)overlapCnt);
+  for (int i = 0; i < overlapCnt; ++i) {
+    if (geneName[0] != '\0') {   // SeqSet.hpp:3462-3473: contigs of another gene family are left out
+      const std::string &nm = seqs[ovBuf[i].seqIdx].name;
       int j = 3;
       if (!nm.empty() && nm[0] >= 'A' && nm[0] <= 'Z') {
         for (j = 0; j < 3; ++j) if ((j < (int)nm.size() ? nm[j] : '\0') != geneName[j]) break;
       }
-      if (j == 3 || nm == "Novel") kept.push_back(c);
+      if (!(j == 3 || nm == "Novel")) continue;
     }
-    cands.swap(kept);
-    overlapCnt = (int)cands.size();
-    if (overlapCnt <= 0) return -1;
+    candStore_.push_back(Cand{fromT4(ovBuf[i]), fromT4(extBuf[i]), extRet[i]});
   }
-  std::stable_sort(cands.begin(), cands.end(), [](const Cand &a, const Cand &b) { return ovLess(a.ov, b.ov); });
-  std::vector<Ov> overlaps(overlapCnt);
+  overlapCnt = (int)candStore_.size();
+  if (overlapCnt <= 0) return -1;
+  ordIdx.resize((size_t)overlapCnt);
+  for (int i = 0; i < overlapCnt; ++i) ordIdx[(size_t)i] = i;
+  std::stable_sort(ordIdx.begin(), ordIdx.end(), [&](int a, int b) { return ovLess(candStore_[(size_t)a].ov, candStore_[(size_t)b].ov); });
+  cands.resize((size_t)overlapCnt);
+  for (int i = 0; i < overlapCnt; ++i) cands[(size_t)i] = candStore_[(size_t)ordIdx[(size_t)i]];
+  static thread_local std::vector<Ov> overlaps, ext, failed;
+  static thread_local std::vector<std::pair<int, int>> oldMinExtAnchor;
+  overlaps.resize((size_t)overlapCnt);
   for (int i = 0; i < overlapCnt; ++i) overlaps[i] = cands[i].ov;
-
-  std::vector<Ov> ext(overlapCnt), failed(overlapCnt);
-  std::vector<std::pair<int, int>> oldMinExtAnchor(overlapCnt);
+  ext.assign((size_t)overlapCnt, Ov()); failed.assign((size_t)overlapCnt, Ov());
+  oldMinExtAnchor.assign((size_t)overlapCnt, std::pair<int, int>(0, 0));
   int ne = 0, ret = -1, failedCnt = 0, tag = 0, jMerge = 0;
   bool sortExtended = true;
   Ov good;
