@@ -126,6 +126,16 @@ def test_kmer_count_set_emulated(emu_engine):
     assert list(mn) == [7, 7, 1, 1]
 
 
+def test_kmer_count_table_grows_emulated(emu_engine, monkeypatch):
+    """The table starts at a fraction of what `max_kmers` stands for and is rehashed on the device into one four times as large as it
+    fills (round 5: a table for every k-mer POSITION of a million pairs was 12 GB). T4_KC_SLOTS starts it at 1024 slots: the counts of
+    a few hundred reads then go through several rehashes, and must equal the oracle's all the same (global and per-barcode tables)."""
+    monkeypatch.setenv("T4_KC_SLOTS", "1024")
+    kc, reads = check_engine_kmer_counts(emu_engine, 21, 240)
+    assert kc.distinct() > 4096
+    check_per_barcode_counts(emu_engine, 22, 160)
+
+
 def test_kmer_count_table_full_is_loud(emu_engine):
     reads = rows_to_strs(Synth(40, 3).next_reads(40))
     kc = emu_engine.kmer_counter(21, max_kmers=16)   # 1024 slots: far too few

@@ -1229,27 +1229,72 @@ int t4_process_pairs(t4_ctx *c, int n, const int64_t *off1, const char *r1, cons
 struct t4_kmer_counter {
   t4_ctx *ctx = nullptr;
   T4KmerTable tb{};
-  unsigned long long slots = 0;
+  unsigned long long slots = 0, maxSlots = 0;
 };
+
+namespace {
+// a table of `slots` slots (a power of two), zeroed; the counter's small words (overflow flag, used-slot count) stay as they are
+int kmerTableAlloc(t4_ctx *c, unsigned long long slots, T4KmerTable &tb) {
+  tb.keys = nullptr; tb.cnt = nullptr;
+  if (hipMalloc(&tb.keys, sizeof(unsigned long long) * slots) != hipSuccess || hipMalloc(&tb.cnt, sizeof(unsigned) * slots) != hipSuccess) {
+    if (tb.keys) (void)hipFree(tb.keys);
+    tb.keys = nullptr;
+    return fail(c, T4_ERR_HIP, "k-mer count table: no device memory for %llu slots", slots);
+  }
+  HIPCHK(c, hipMemsetAsync(tb.keys, 0, sizeof(unsigned long long) * slots, c->stream));
+  HIPCHK(c, hipMemsetAsync(tb.cnt, 0, sizeof(unsigned) * slots, c->stream));
+  tb.mask = slots - 1;
+  return T4_OK;
+}
+// Room for `incoming` more k-mers at a load of at most 0.6: the table is rehashed on the device into one four times as large as
+// often as that takes (never beyond the size the caller's max_kmers stands for: then the old behaviour -- a full table fails).
+int kmerEnsureRoom(t4_kmer_counter *kc, unsigned long long incoming) {
+  t4_ctx *c = kc->ctx;
+  unsigned long long used = 0;
+  HIPCHK(c, hipMemcpyAsync(&used, kc->tb.used, sizeof used, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  while (kc->slots < kc->maxSlots && (used + incoming) * 10ull > kc->slots * 6ull) {
+    unsigned long long ns = kc->slots * 4ull;
+    if (ns > kc->maxSlots) ns = kc->maxSlots;
+    T4KmerTable to = kc->tb;
+    int r;
+    if ((r = kmerTableAlloc(c, ns, to))) return r;
+    const unsigned long long blocks = (kc->slots + 255ull) / 256ull;
+    const int grid = (int)(blocks < (unsigned long long)c->cus * 16ull ? blocks : (unsigned long long)c->cus * 16ull);
+    hipLaunchKernelGGL(t4k::kmerRehashKernel, dim3(grid), dim3(256), 0, c->stream, kc->tb, to);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(kc->tb.keys); (void)hipFree(kc->tb.cnt);
+    kc->tb = to; kc->slots = ns;
+  }
+  return T4_OK;
+}
+}  // namespace
 
 int t4_kmer_count_create(t4_ctx *c, int k, int64_t max_kmers, int per_barcode, t4_kmer_counter **out) {
   if (!c || !out) return T4_ERR_ARG;
   if (k < 1 || k > 31 || max_kmers < 1) return fail(c, T4_ERR_ARG, "t4_kmer_count_create: k in 1..31 and max_kmers >= 1 (got %d, %lld)", k, (long long)max_kmers);
   if (per_barcode && k > 21) return fail(c, T4_ERR_UNSUPPORTED, "t4_kmer_count_create: per-barcode counts take k <= 21 (the barcode shares the 64-bit key)");
   (void)hipSetDevice(c->device);
-  unsigned long long slots = 1024;
-  while (slots < 2ull * (unsigned long long)max_kmers) slots <<= 1;
+  unsigned long long maxSlots = 1024;
+  while (maxSlots < 2ull * (unsigned long long)max_kmers) maxSlots <<= 1;
+  // max_kmers is an upper bound -- every k-mer position of the input -- and a read set repeats itself: a table for all of them was
+  // 12 GB for a million pairs. It starts at an eighth of that (at least 4 M slots) and grows as it fills.
+  unsigned long long slots = maxSlots / 8ull;
+  if (slots < (1ull << 22)) slots = (1ull << 22) < maxSlots ? (1ull << 22) : maxSlots;
+  if (getenv("T4_KC_SLOTS")) { slots = 1024; const unsigned long long want = strtoull(getenv("T4_KC_SLOTS"), nullptr, 10); while (slots < want && slots < maxSlots) slots <<= 1; }   // testing aid: a small first table (the growth path)
   t4_kmer_counter *kc = new t4_kmer_counter;
-  kc->ctx = c; kc->slots = slots;
-  kc->tb.k = k; kc->tb.mask = slots - 1; kc->tb.perBarcode = per_barcode ? 1 : 0;
-  if (hipMalloc(&kc->tb.keys, sizeof(unsigned long long) * slots) != hipSuccess || hipMalloc(&kc->tb.cnt, sizeof(unsigned) * slots) != hipSuccess ||
-      hipMalloc(&kc->tb.overflow, sizeof(int)) != hipSuccess) {
+  kc->ctx = c; kc->slots = slots; kc->maxSlots = maxSlots;
+  kc->tb.k = k; kc->tb.perBarcode = per_barcode ? 1 : 0;
+  kc->tb.overflow = nullptr; kc->tb.used = nullptr;
+  int r = kmerTableAlloc(c, slots, kc->tb);
+  if (r || hipMalloc(&kc->tb.overflow, sizeof(int)) != hipSuccess || hipMalloc(&kc->tb.used, sizeof(unsigned long long)) != hipSuccess) {
     t4_kmer_count_destroy(kc);
-    return fail(c, T4_ERR_HIP, "t4_kmer_count_create: no device memory for %llu slots", slots);
+    return r ? r : fail(c, T4_ERR_HIP, "t4_kmer_count_create: no device memory");
   }
-  HIPCHK(c, hipMemset(kc->tb.keys, 0, sizeof(unsigned long long) * slots));
-  HIPCHK(c, hipMemset(kc->tb.cnt, 0, sizeof(unsigned) * slots));
-  HIPCHK(c, hipMemset(kc->tb.overflow, 0, sizeof(int)));
+  HIPCHK(c, hipMemsetAsync(kc->tb.overflow, 0, sizeof(int), c->stream));
+  HIPCHK(c, hipMemsetAsync(kc->tb.used, 0, sizeof(unsigned long long), c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   *out = kc;
   return T4_OK;
 }
@@ -1259,6 +1304,7 @@ void t4_kmer_count_destroy(t4_kmer_counter *kc) {
   if (kc->tb.keys) (void)hipFree(kc->tb.keys);
   if (kc->tb.cnt) (void)hipFree(kc->tb.cnt);
   if (kc->tb.overflow) (void)hipFree(kc->tb.overflow);
+  if (kc->tb.used) (void)hipFree(kc->tb.used);
   delete kc;
 }
 
@@ -1270,9 +1316,22 @@ int t4_kmer_count_add(t4_kmer_counter *kc, t4_batch *b) {
   (void)hipSetDevice(c->device);
   const long long n = b->n;
   if (kc->tb.perBarcode && !b->dBarcode) return fail(c, T4_ERR_ARG, "t4_kmer_count_add: per-barcode counts need a batch uploaded with barcodes");
-  const int grid = (int)(n < (long long)c->cus * 32 ? n : (long long)c->cus * 32);
-  hipLaunchKernelGGL(t4k::kmerAddKernel, dim3(grid), dim3(64), 0, c->stream, b->view, kc->tb);
-  HIPCHK(c, hipGetLastError());
+  // in slices of reads whose k-mers (every one new, at worst) leave the table under a load of 0.6; between slices the table grows
+  const long long perRead = b->maxLen >= kc->tb.k ? (long long)(b->maxLen - kc->tb.k + 1) : 1;
+  for (long long lo = 0; lo < n;) {
+    long long cnt = n - lo;
+    if (kc->slots < kc->maxSlots) {
+      long long fit = (long long)(kc->slots * 3ull / 10ull) / perRead;
+      if (fit < 4096) fit = 4096;
+      if (cnt > fit) cnt = fit;
+      int r = kmerEnsureRoom(kc, (unsigned long long)(cnt * perRead));
+      if (r) return r;
+    }
+    const int grid = (int)(cnt < (long long)c->cus * 32 ? cnt : (long long)c->cus * 32);
+    hipLaunchKernelGGL(t4k::kmerAddKernel, dim3(grid), dim3(64), 0, c->stream, b->view, kc->tb, lo, lo + cnt);
+    HIPCHK(c, hipGetLastError());
+    lo += cnt;
+  }
   int overflow = 0;
   HIPCHK(c, hipMemcpyAsync(&overflow, kc->tb.overflow, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1294,6 +1353,7 @@ int t4_kmer_count_set(t4_kmer_counter *kc, const uint64_t *codes, const int32_t 
   for (const auto &kv : last) { hc.push_back((unsigned long long)kv.first); hv.push_back((int)kv.second); }
   const long long m = (long long)hc.size();
   int r;
+  if ((r = kmerEnsureRoom(kc, (unsigned long long)m))) return r;
   unsigned long long *dC = nullptr; int *dV = nullptr;
   if ((r = devAlloc(c, &dC, (size_t)m)) || (r = devAlloc(c, &dV, (size_t)m))) return r;
   HIPCHK(c, hipMemcpy(dC, hc.data(), sizeof(unsigned long long) * (size_t)m, hipMemcpyHostToDevice));

@@ -153,6 +153,7 @@ struct T4KmerTable {
   int k;
   int perBarcode;            // 1: the read's barcode is part of the key (bits 42..62; k <= 21) -- one KmerCount per barcode
   int *overflow;             // set when an insert found the table full
+  unsigned long long *used;  // occupied slots (one atomic per wavefront pass): the host grows the table before it fills (t4_kmer_count_add)
 };
 
 struct T4OverlapOut {        // == t4_overlap of include/trust4_hip.h

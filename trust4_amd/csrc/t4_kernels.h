@@ -4033,7 +4033,7 @@ void queryKernel(T4IndexView ixArg, T4BatchView bvArg, T4Work wkArg, T4QueryArgs
 // inside a workgroup. The records of one read no longer wait for each other in one workgroup's eight wavefronts: a read that
 // overlaps two thousand contigs becomes a few hundred independent blocks.
 #ifndef T4_EXT_NREC
-#define T4_EXT_NREC 8
+#define T4_EXT_NREC 4   // (8 until round 5: a wavefront steps eight overhang alignments at a time, so eight records were two passes per block; the chip is empty behind a whole-query round and four records -- one pass -- per block shorten its tail: C2 kernels 26.5 -> 25.5 s, profiles/r05h_c2_ext4_*)
 #endif
 __global__ __launch_bounds__(64) void extendKernel(T4IndexView ix, T4BatchView bv, T4QueryArgs qa, int recBegin) {
   __shared__ OvRec s_fin[T4_EXT_NREC];
@@ -4252,12 +4252,12 @@ __device__ __forceinline__ unsigned long long canonicalAt(const WaveMem &wm, int
 }
 
 // KmerCount::AddCount (KmerCount.hpp:64-97) for every read of the batch; one wavefront per read, a lane per position.
-__global__ __launch_bounds__(64) void kmerAddKernel(T4BatchView bv, T4KmerTable tb) {
+__global__ __launch_bounds__(64) void kmerAddKernel(T4BatchView bv, T4KmerTable tb, long long rBegin, long long rEnd) {
   __shared__ char s_seg[T4_MAXL + 8];
   __shared__ char s_rc[T4_MAXL + 8];
   WaveMem wm;
   wm.seg = s_seg; wm.rc = s_rc;
-  for (long long r = blockIdx.x; r < bv.n; r += gridDim.x) {
+  for (long long r = rBegin + blockIdx.x; r < rEnd; r += gridDim.x) {
     const int len = bv.len[r];
     if (len >= tb.k) {   // block-uniform
       loadSegment(bv, r, 0, len, wm);
@@ -4267,12 +4267,14 @@ __global__ __launch_bounds__(64) void kmerAddKernel(T4BatchView bv, T4KmerTable 
         const unsigned long long kc = canonicalAt(wm, len, p, tb.k, valid) | salt;
         if (!valid) continue;
         unsigned long long h = kcMix(kc) & tb.mask, probes = 0;
+        bool fresh = false;
         for (; probes <= tb.mask; ++probes) {
           const unsigned long long old = atomicCAS(&tb.keys[h], 0ull, kc + 1ull);
-          if (old == 0ull || old == kc + 1ull) { atomicAdd(&tb.cnt[h], 1u); break; }
+          if (old == 0ull || old == kc + 1ull) { atomicAdd(&tb.cnt[h], 1u); fresh = old == 0ull; break; }
           h = (h + 1ull) & tb.mask;
         }
         if (probes > tb.mask) *tb.overflow = 1;
+        if (fresh) atomicAdd(tb.used, 1ull);   // occupied slots (every k-mer is new at first, nearly none later; a wave-wide vote here would sit in divergent code)
       }
     }
     __syncthreads();
@@ -4287,7 +4289,7 @@ __global__ __launch_bounds__(256) void kmerSetKernel(T4KmerTable tb, const unsig
     unsigned long long h = kcMix(kc) & tb.mask, probes = 0;
     for (; probes <= tb.mask; ++probes) {
       const unsigned long long old = atomicCAS(&tb.keys[h], 0ull, kc + 1ull);
-      if (old == 0ull || old == kc + 1ull) { tb.cnt[h] = (unsigned)counts[i]; break; }
+      if (old == 0ull || old == kc + 1ull) { tb.cnt[h] = (unsigned)counts[i]; if (old == 0ull) atomicAdd(tb.used, 1ull); break; }
       h = (h + 1ull) & tb.mask;
     }
     if (probes > tb.mask) *tb.overflow = 1;
@@ -4298,6 +4300,20 @@ __global__ __launch_bounds__(256) void kmerSetKernel(T4KmerTable tb, const unsig
 // valid k-mers (absent or non-positive counts read as 1), the quality trimming when quals != null (the read's qualities at
 // quals + qoff[r], as long as the read), and the N rule on the minimum. lenOut = the length the read is cut to (0: emptied).
 // One wavefront per read: lookups a lane per position, the order-dependent scans on lane 0, the median by ranks.
+// every (k-mer, count) of a full-ish table into one four times as large (t4_kmer_count_add grows the table as it fills)
+__global__ __launch_bounds__(256) void kmerRehashKernel(T4KmerTable from, T4KmerTable to) {
+  for (unsigned long long s = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; s <= from.mask; s += (unsigned long long)gridDim.x * blockDim.x) {
+    const unsigned long long key = from.keys[s];
+    if (!key) continue;
+    unsigned long long h = kcMix(key - 1ull) & to.mask;
+    for (;;) {
+      const unsigned long long old = atomicCAS(&to.keys[h], 0ull, key);
+      if (old == 0ull || old == key) { atomicAdd(&to.cnt[h], from.cnt[s]); break; }
+      h = (h + 1ull) & to.mask;
+    }
+  }
+}
+
 __global__ __launch_bounds__(64) void kmerStatsKernel(T4BatchView bv, T4KmerTable tb, const char *quals, const long long *qoff,
                                                      int *minOut, int *medOut, float *avgOut, int *lenOut) {
   __shared__ char s_seg[T4_MAXL + 8];
