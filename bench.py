@@ -15,7 +15,7 @@ workload, and it is reported as `c2` (with its own roofline block and a same-box
 files). When the runs do not fit, the steps are timed on the C2 recipe at 100 k pairs (`config.workload` says which ran).
 Rank 0 also reports
   cpu_baseline   the reference binary (oracle/_ref/trust4) on the SAME box: on the whole batch of the timed steps when that is the
-                 100 k-pair batch (outputs compared byte for byte, `parity_on_bench_batch`), on the first 200 k pairs of C2's files
+                 100 k-pair batch (outputs compared byte for byte, `parity_on_bench_batch`), on the first 100 k pairs of C2's files
                  when C2 is the workload (-t <host cores>; `sample` names the files);
   roofline       the dominant kernels of a step (the AddRead query launches), HIP-event time on the engine's stream, bytes as
                  SURVEY 8d defines them, `traffic` from two rocprofv3 PMC passes of the 100 k-pair command;
@@ -585,7 +585,7 @@ def main():
     ap.add_argument("--budget", type=float, default=float(os.environ.get("T4_BENCH_BUDGET_S", "1800")), help="seconds the warm-up + timed steps may take (decides whether C2 itself is the workload)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 = skip the reference legs")
     ap.add_argument("--cpu-single-pairs", type=int, default=20000, help="prefix timed with the reference's -t 1 (0 = skip)")
-    ap.add_argument("--cpu-c2-pairs", type=int, default=200000, help="prefix of C2's files the reference is timed on, on this box (0 = skip)")
+    ap.add_argument("--cpu-c2-pairs", type=int, default=100000, help="prefix of C2's files the reference is timed on, on this box (0 = skip)")
     ap.add_argument("--side-legs", type=int, default=1, help="0 = skip passes.rough_annotation_c2 / stage1_cells / stage0_e2e")
     ap.add_argument("--traffic", type=int, default=1, help="0 = skip the two rocprofv3 PMC passes that measure roofline.traffic")
     ap.add_argument("--c2", type=int, default=1, help="0 = skip the run of config C2 itself (then the steps are timed on the 100 k-pair batch)")

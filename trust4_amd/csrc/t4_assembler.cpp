@@ -644,14 +644,13 @@ struct t4_assembler : IndexListener {
   struct Knobs {
     bool verifyWindow = false, noStableStats = false, wideQueries = true, candStore = true, restrictOn = true, predictHints = true, useMarks = true;
     int wideHitLimit = 4096;
-    int lanes = 1, queryAhead = 0, minBatch = 4, harvestDelay = 0, lightAhead = 0, heavyBatch = 0, maxPending = 8; double aheadMult = 3.0;
+    int lanes = 1, queryAhead = 0, minBatch = 4, harvestDelay = 0, lightAhead = 0, maxPending = 8;
     FILE *roundLog = nullptr;
     Knobs() {
       auto num = [](const char *n, int d) { const char *e = getenv(n); return e ? atoi(e) : d; };
       verifyWindow = getenv("T4_VERIFY_WINDOW") != nullptr;     // every served window entry is queried again and compared
       noStableStats = getenv("T4_NO_STABLE_STATS") != nullptr;  // A/B aid: the budget rule for every entry
       lanes = num("T4_LIVE_LANES", 1); queryAhead = num("T4_QUERY_AHEAD", 0); minBatch = num("T4_LIVE_MIN_BATCH", 4); harvestDelay = num("T4_LIVE_HARVEST_DELAY", 0);
-      heavyBatch = num("T4_HEAVY_BATCH", 0); if (getenv("T4_AHEAD_MULT")) aheadMult = atof(getenv("T4_AHEAD_MULT"));
       wideQueries = !getenv("T4_WIDE_OFF") && !getenv("T4_AQ_FORCE_GLOBAL");
       { const int lim = num("T4_AQ_CAP_LIMIT", 0); wideHitLimit = lim > 0 ? lim : num("T4_WIDE_MIN_HITS", 4096); }
       useMarks = !getenv("T4_NO_MARKS");        // A-B aid: restricted re-queries walk the read's posting lists as in round 4
@@ -2412,7 +2411,7 @@ int t4_assembler::pumpLive(bool needHead, int repetitive) {
   const int fixedAhead = knobs.queryAhead, minBatch = knobs.minBatch;
   // Entries far behind the head rarely survive until they are consumed: (re-)query only as far ahead as a few times what a launch
   // for the head has recently served (every read queried adds to the latency of the launch: it ends with its slowest read)
-  const size_t ahead = fixedAhead > 0 ? (size_t)fixedAhead : (lanes.size() > 1 ? 24 : (size_t)(knobs.aheadMult * runEma) + 12);
+  const size_t ahead = fixedAhead > 0 ? (size_t)fixedAhead : (lanes.size() > 1 ? 24 : (size_t)(3.0 * runEma) + 12);   // (factors 2 and 4 measured in round 5 with light rounds: 66.4 / 64.1 s against 61.3 s on C2, profiles/r05f)
   for (;;) {
     // T4_LIVE_HARVEST_DELAY=n (testing aid): a finished launch is only noticed n calls later, so that commits pile up against queries in flight
     const int harvestDelay = knobs.harvestDelay;
@@ -2453,7 +2452,7 @@ int t4_assembler::pumpLive(bool needHead, int repetitive) {
         // A round lasts as long as its slowest read. When the head only waits for a restricted re-query (tens of microseconds), whole
         // queries of entries further back than `lightAhead` places stay out of its round: they go with the next round whose head needs
         // a whole query itself (or when they come within reach of the head).
-        if (head.partial && knobs.lightAhead >= 0 && (knobs.heavyBatch <= 0 || (int)other.size() < knobs.heavyBatch)) {
+        if (head.partial && knobs.lightAhead >= 0) {
           std::vector<int> near;
           for (size_t i = 0; i < order.size() && i < ahead && (int)i <= knobs.lightAhead; ++i) { Cached &c = *pool[order[i]]; if (!c.valid && !c.inflight && !c.partial) near.push_back(order[i]); }
           other.swap(near);
