@@ -525,7 +525,7 @@ CAND_PAT = (r"candidate store: (\d+) candidate records kept with whole queries, 
 
 
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
-@pytest.mark.parametrize("env", [{}, {"T4_AQ_CAP_LIMIT": "2500", "T4_AQ_CAND_CAP": "64", "T4_MAX_PENDING": "2"}])
+@pytest.mark.parametrize("env", [{}, {"T4_AQ_CAP_LIMIT": "1500", "T4_AQ_CAND_CAP": "64", "T4_MAX_PENDING": "2"}])
 def test_candidate_store_emulated(tmp_path, env):
     """The candidate store: a window entry keeps EVERY scored candidate overlap of its whole query (pre-score key, scored
     fields, cut by the pre-filters of SeqSet.hpp:1705-1794 or not) and the group statistics of 784-823; after a restricted re-query of
@@ -538,7 +538,7 @@ def test_candidate_store_emulated(tmp_path, env):
     import re
     e = {"T4_VERIFY_WINDOW": "1"}
     e.update(env)
-    log = _bulk_case(tmp_path, _emulated_driver(), 1300, 650, 3, e, threads="4")
+    log = _bulk_case(tmp_path, _emulated_driver(), 800, 400, 3, e, threads="4")
     m = re.search(CAND_PAT, log)
     assert m, log[-1500:]
     recs, merged, big, stats, recut, fb_uncut, fb_stats, fb_strand, fb_other, checked = (int(x) for x in m.groups())
