@@ -616,7 +616,7 @@ struct t4_assembler : IndexListener {
   int64_t wideServed = 0, wideGroupRecords = 0, wideMispredicted = 0;
   int64_t restrictedMarks = 0, restrictedMerged = 0, restrictedFallbacks = 0, restrictedStale = 0, restrictedMulti = 0;
   bool restrictOn = true, candStore = true;
-  int64_t candRecords = 0, candMerges = 0, candFallbackUncut = 0, candFallbackStats = 0, candFallbackStrand = 0, candFallbackOther = 0, candRecut = 0, candSelfChecks = 0, candMergesBig = 0, candMergesStats = 0, candExactStats = 0;
+  int64_t candRecords = 0, candMerges = 0, candFallbackUncut = 0, candFallbackStats = 0, candFallbackStrand = 0, candFallbackOther = 0, candRecut = 0, candSelfChecks = 0, candMergesBig = 0, candMergesStats = 0, candExactStats = 0, candRaised = 0;
   bool mergeRestricted(Cached &c, int pc, int k2, const t4_overlap *ov, const t4_overlap *ex, const int32_t *rets, const t4_cand *nc, int ncnt, const int32_t *s8);
   static void replayScan(const std::vector<t4_cand> &cands, const std::vector<Seq> &seqs, int len, int radius, double repeatSim, std::vector<unsigned char> &cut);
   int64_t whyNot[6] = {0, 0, 0, 0, 0, 0};   // entries that fell whole although one contig changed: lists beyond 10000 postings, overlaps on the other strand, more than 44 candidate overlaps, more than ~100 groups of four hits, no report from the query, other
@@ -2046,6 +2046,7 @@ bool t4_assembler::mergeRestricted(Cached &c, int pc, int k2, const t4_overlap *
   // ---- group statistics (SeqSet.hpp:784-823): pc's groups went from g0 to g1 hits; every other group of three or more is as it was
   int n4lo[2], n4hi[2], n5lo[2], n5hi[2], smlo[2], smhi[2];
   bool needExact = false, exactStable = true;
+  int newT[2] = {c.minT[0], c.minT[1]};
   for (int t = 0; t < 2; ++t) {
     const uint32_t key = (uint32_t)pc * 2u + (uint32_t)t;
     const Grp *g = c.findGroup(key);
@@ -2078,7 +2079,8 @@ bool t4_assembler::mergeRestricted(Cached &c, int pc, int k2, const t4_overlap *
       ok = fa == fb && fa >= 3;
       T = fb;
     }
-    if (!ok || T != c.minT[t]) needExact = true;
+    if (!ok || T < c.minT[t]) needExact = true;
+    newT[t] = T;   // (certified; a RAISED threshold is served below: candidates chained from shorter runs leave the list)
   }
   if (needExact) {
     // The bounds do not pin the threshold (e.g. longestHits / 4 changes between the largest group and the largest group - 1). When the
@@ -2125,7 +2127,8 @@ bool t4_assembler::mergeRestricted(Cached &c, int pc, int k2, const t4_overlap *
       else if (possible[t] > 10000) T = longest[t] / 2;
       else if (possible[t] > 1000) T = longest[t] / 3;
       else if (possible[t] > 100) T = longest[t] / 4;
-      if (T != c.minT[t]) { ++candFallbackStats; return false; }
+      if (T < c.minT[t]) { ++candFallbackStats; return false; }   // a LOWER threshold lets runs in that no record of this entry describes
+      newT[t] = T;
       n4lo[t] = n4hi[t] = e4[t]; n5lo[t] = n5hi[t] = e5[t]; smlo[t] = smhi[t] = big[t];
     }
     ++candExactStats;
@@ -2158,12 +2161,28 @@ bool t4_assembler::mergeRestricted(Cached &c, int pc, int k2, const t4_overlap *
     if (a.ss != b.ss) return a.ss < b.ss;
     return a.se < b.se;
   };
-  for (int t = 0; t < ncnt; ++t) { Item it; it.o = nc[t]; it.o.flags &= (unsigned short)~4u; it.src = t; it.wasCut = 0; fresh.push_back(it); }
+  // A raised novelMinHitRequired (the contig's group grew: a read that hangs over a contig end the commit before it extended) drops
+  // exactly the candidates whose run holds fewer hits than the new threshold (SeqSet.hpp:923-925; every other test of a run is its
+  // own): those of pc that the re-query -- run with the OLD threshold -- still returned, and those of the other contigs, whose
+  // records leave the entry's result. Run sizes travel with the candidate records (bits 3-12 of the flags).
+  const int s0 = c.strand0Plus ? 1 : 0;
+  const int raisedT = newT[s0] > c.minT[s0] ? newT[s0] : 0;
+  auto runOf = [](const t4_cand &o) { return (int)((o.flags >> 3) & 1023u); };
+  static thread_local std::vector<t4_cand> droppedKept;
+  droppedKept.clear();
+  if (newT[s0] > 1023) { ++candFallbackStats; return false; }   // (the field saturates there)
+  if (raisedT) for (const t4_cand &o : c.cands) if (runOf(o) == 0) { ++candFallbackStats; return false; }   // (a record without a run size: never from this engine's kernels)
+  for (int t = 0; t < ncnt; ++t) if (runOf(nc[t]) == 0) { ++candFallbackStats; return false; }
+  for (int t = 0; t < ncnt; ++t) {
+    if (runOf(nc[t]) < newT[s0]) continue;   // (the re-query ran with the threshold of its launch, which an earlier merge of this entry may have raised since)
+    Item it; it.o = nc[t]; it.o.flags &= (unsigned short)~4u; it.src = t; it.wasCut = 0; fresh.push_back(it);
+  }
   std::sort(fresh.begin(), fresh.end(), [&](const Item &a, const Item &b) { return before(a.o, b.o); });
   {
     size_t f = 0;
     for (const t4_cand &o : c.cands) {
       if (o.seqIdx == pc) continue;
+      if (raisedT && runOf(o) < raisedT) { if (!(o.flags & 4)) droppedKept.push_back(o); continue; }
       while (f < fresh.size() && before(fresh[f].o, o)) items.push_back(fresh[f++]);
       Item it; it.o = o; it.src = -1; it.wasCut = (o.flags & 4) ? 1 : 0; items.push_back(it);
     }
@@ -2187,6 +2206,7 @@ bool t4_assembler::mergeRestricted(Cached &c, int pc, int k2, const t4_overlap *
   for (size_t t = 0; t < c.ov.size(); ++t) {
     bool keep = c.ov[t].seqIdx != pc;
     if (keep && anyRecut) for (size_t q = 0; q < items.size() && keep; ++q) if (items[q].src < 0 && !items[q].wasCut && cut[q] && sameGeom(c.ov[t], items[q].o)) keep = false;
+    if (keep) for (size_t q = 0; q < droppedKept.size() && keep; ++q) if (sameGeom(c.ov[t], droppedKept[q])) keep = false;
     if (!keep) continue;
     if (w != t) { c.ov[w] = c.ov[t]; c.ext[w] = c.ext[t]; c.extRet[w] = c.extRet[t]; }
     ++w;
@@ -2205,7 +2225,8 @@ bool t4_assembler::mergeRestricted(Cached &c, int pc, int k2, const t4_overlap *
   c.cnt = (int32_t)c.ov.size();
   c.cands.resize(items.size());
   for (size_t t = 0; t < items.size(); ++t) { c.cands[t] = items[t].o; if (cut[t]) c.cands[t].flags |= 4; else c.cands[t].flags &= (unsigned short)~4u; }
-  for (int t = 0; t < 2; ++t) { c.n4lo[t] = n4lo[t]; c.n4hi[t] = n4hi[t]; c.n5lo[t] = n5lo[t]; c.n5hi[t] = n5hi[t]; c.smlo[t] = smlo[t]; c.smhi[t] = smhi[t]; }
+  for (int t = 0; t < 2; ++t) { c.n4lo[t] = n4lo[t]; c.n4hi[t] = n4hi[t]; c.n5lo[t] = n5lo[t]; c.n5hi[t] = n5hi[t]; c.smlo[t] = smlo[t]; c.smhi[t] = smhi[t]; c.minT[t] = newT[t]; }
+  if (raisedT) ++candRaised;
   c.nAll = c.nAllBound = (int)c.cands.size();
   // the dependency record of pc as the query found it: emitted hits per strand, hull of the diagonals with three or more of them
   for (int t = 0; t < 2; ++t) {
@@ -2718,8 +2739,8 @@ int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n) {
             (long long)a->restrictedMarks, (long long)a->restrictedMerged, (long long)a->restrictedFallbacks, (long long)a->restrictedStale);
     fprintf(stderr, "timing: entries that fell whole when one contig changed: %lld with lists beyond 10000 postings, %lld with overlaps on the other strand, %lld with more than 44 candidate overlaps, %lld with ~100 groups of four hits, %lld without the query's report, %lld other\n",
             (long long)a->whyNot[0], (long long)a->whyNot[1], (long long)a->whyNot[2], (long long)a->whyNot[3], (long long)a->whyNot[4], (long long)a->whyNot[5]);
-    fprintf(stderr, "timing: candidate store: %lld candidate records kept with whole queries, %lld restricted re-queries merged through the replay of the scan (%lld with more than 50 candidates, %lld with more than 100 groups of four hits on a strand, %lld cut a candidate of another contig), fell back to the whole query: %lld a cut candidate of another contig passes now, %lld the group statistics could move the threshold, %lld an overlap on the other strand, %lld other; %lld whole queries checked against the host's scan; %lld thresholds settled by repeating the statistics loop over the entry's groups\n",
-            (long long)a->candRecords, (long long)a->candMerges, (long long)a->candMergesBig, (long long)a->candMergesStats, (long long)a->candRecut, (long long)a->candFallbackUncut, (long long)a->candFallbackStats, (long long)a->candFallbackStrand, (long long)a->candFallbackOther, (long long)a->candSelfChecks, (long long)a->candExactStats);
+    fprintf(stderr, "timing: candidate store: %lld candidate records kept with whole queries, %lld restricted re-queries merged through the replay of the scan (%lld with more than 50 candidates, %lld with more than 100 groups of four hits on a strand, %lld cut a candidate of another contig), fell back to the whole query: %lld a cut candidate of another contig passes now, %lld the group statistics could move the threshold, %lld an overlap on the other strand, %lld other; %lld whole queries checked against the host's scan; %lld thresholds settled by repeating the statistics loop over the entry's groups, %lld raised thresholds served by dropping the candidates of shorter runs\n",
+            (long long)a->candRecords, (long long)a->candMerges, (long long)a->candMergesBig, (long long)a->candMergesStats, (long long)a->candRecut, (long long)a->candFallbackUncut, (long long)a->candFallbackStats, (long long)a->candFallbackStrand, (long long)a->candFallbackOther, (long long)a->candSelfChecks, (long long)a->candExactStats, (long long)a->candRaised);
     fprintf(stderr, "timing: wide query served %lld window entries (%lld dependency records came back with them), %lld reads it was expected for stayed on the LDS tier\n", (long long)a->wideServed, (long long)a->wideGroupRecords, (long long)a->wideMispredicted);
   }
   return T4_OK;

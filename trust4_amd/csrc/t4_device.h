@@ -170,7 +170,7 @@ struct T4Cand {
   short m0;                  // matchCnt of GetOverlapsFromHits: the sort key of the scan
   short matchCnt;            // scored (SeqSet.hpp:2009)
   short indelCnt;
-  unsigned short flags;      // 1: plus strand, 2: scoring left similarity 0, 4: cut by the pre-filters (its scored fields are still the scored ones)
+  unsigned short flags;      // 1: plus strand, 2: scoring left similarity 0, 4: cut by the pre-filters (its scored fields are still the scored ones), bits 3-12: run size
 };
 #define T4_QSTATS 12         // statistics words per read: [0..7] see T4QueryArgs (stats8), [8..11] restricted re-queries: hull lo (minus, plus), hull hi (minus, plus) of the one contig's group
 struct T4CandArgs {
@@ -191,6 +191,7 @@ struct T4CandArgs {
 #define T4_CAND_PLUS 1
 #define T4_CAND_SIMZERO 2
 #define T4_CAND_CUT 4
+#define T4_CAND_RUN_SHIFT 3   // bits 3-12: hits of the run the overlap was chained from (what novelMinHitRequired is compared with)
 
 struct T4QueryArgs {
   int mode;                  // 0: overlaps (GetOverlapsFromRead), 1: annotate level 0, 2: AssignRead, 3: ExtendOverlap of given overlaps, 4: AddRead query

@@ -685,18 +685,24 @@ __device__ __forceinline__ bool ovLess(const OvRec &a, const OvRec &b, bool scor
 // A pre-filter cut leaves the overlap as the reference's `continue` does (matchCnt of GetOverlapsFromHits, similarity 0). The scored
 // fields it had are kept in chainPos (dead once the overlaps are scored): the candidate store of the ordered builder hands them to
 // the host, whose replay of the scan may find the overlap uncut after another contig's candidates changed (T4QueryArgs::candOut).
+// (chainPos of a scored overlap of a contig: bits 21-30 the size of the run it was chained from -- the number novelMinHitRequired is
+// compared with, SeqSet.hpp:923-925 --, and once the pre-filters cut it, bits 0-9 / 10-19 / 20 its scored matchCnt / indelCnt / zero flag)
+#define OV_RUN_SHIFT 21
+__device__ __forceinline__ void ovKeepRunSize(OvRec &o, int runSize) { o.chainPos = (runSize > 1023 ? 1023 : runSize) << OV_RUN_SHIFT; }
 __device__ __forceinline__ void ovCutKeepScored(OvRec &o) {
-  o.chainPos = (o.matchCnt & 0xFFF) | ((o.indelCnt & 0xFFF) << 12) | ((o.flags & OV_SIMZERO) ? (1 << 24) : 0);
+  const int ind = o.indelCnt > 1023 ? 1023 : o.indelCnt;
+  o.chainPos = (o.chainPos & (0x3FF << OV_RUN_SHIFT)) | (o.matchCnt & 0x3FF) | (ind << 10) | ((o.flags & OV_SIMZERO) ? (1 << 20) : 0);
   o.matchCnt = o.chainLen; o.indelCnt = 0; o.flags |= OV_SIMZERO | OV_CUT;
 }
 __device__ __forceinline__ T4Cand ovToCand(const OvRec &o) {   // o.chainLen holds the matchCnt of GetOverlapsFromHits (scoreOverlaps leaves it there)
   T4Cand c;
   c.seqIdx = o.seqIdx; c.ss = o.ss; c.se = o.se; c.rs = (short)o.rs; c.re = (short)o.re; c.m0 = (short)o.chainLen;
   const bool cut = (o.flags & OV_CUT) != 0;
-  c.matchCnt = (short)(cut ? (o.chainPos & 0xFFF) : o.matchCnt);
-  c.indelCnt = (short)(cut ? ((o.chainPos >> 12) & 0xFFF) : o.indelCnt);
-  const bool simzero = cut ? ((o.chainPos >> 24) & 1) != 0 : (o.flags & OV_SIMZERO) != 0;
-  c.flags = (unsigned short)(((o.flags & OV_PLUS) ? T4_CAND_PLUS : 0) | (simzero ? T4_CAND_SIMZERO : 0) | (cut ? T4_CAND_CUT : 0));
+  c.matchCnt = (short)(cut ? (o.chainPos & 0x3FF) : o.matchCnt);
+  c.indelCnt = (short)(cut ? ((o.chainPos >> 10) & 0x3FF) : (o.indelCnt > 32767 ? 32767 : o.indelCnt));
+  const bool simzero = cut ? ((o.chainPos >> 20) & 1) != 0 : (o.flags & OV_SIMZERO) != 0;
+  const int runSize = (o.chainPos >> OV_RUN_SHIFT) & 0x3FF;
+  c.flags = (unsigned short)(((o.flags & OV_PLUS) ? T4_CAND_PLUS : 0) | (simzero ? T4_CAND_SIMZERO : 0) | (cut ? T4_CAND_CUT : 0) | (runSize << T4_CAND_RUN_SHIFT));
   return c;
 }
 
@@ -1434,7 +1440,7 @@ __device__ void chainFinish(const T4IndexView &ix, WaveMem &wm, WaveState *ws, i
   o.seqIdx = seqIdx;
   o.rs = PA(lisOut[0]); o.re = PA(lisOut[lisSize - 1]) + K - 1;
   o.ss = PB(lisOut[0]); o.se = PB(lisOut[lisSize - 1]) + K - 1;
-  o.matchCnt = 2 * hitLen; o.indelCnt = 0;
+  o.matchCnt = 2 * hitLen; o.indelCnt = isRef ? 0 : n;   // (a novel overlap's run size rides here until scoring overwrites the field: ovKeepRunSize)
   o.chainPos = s; o.chainLen = lisSize;
   {
     const T4SeqInfo si = ix.seqs[seqIdx];   // gene class + chain letters ride along for the V/J/C selection
@@ -2262,6 +2268,7 @@ __device__ T4_NI void finishOverlapsRows(const T4IndexView &ix, WaveMem &wm, Wav
     const bool has = i < overlapCnt;
     OvRec o = wm.ov[wm.ord[has ? i : 0]];
     const bool fast = (o.flags & OV_ISREF) != 0 && ix.radius > 0;
+    const int runSize = (o.flags & OV_ISREF) ? 0 : o.indelCnt;   // (chainFinish left it there)
     const unsigned *hc = (const unsigned *)(wm.keys + o.chainPos);
     const unsigned *res = hc + o.chainLen;
     int jBreak = 0x7FFFFFFF, add = 0, ind = 0, failed = 0;
@@ -2325,6 +2332,7 @@ __device__ T4_NI void finishOverlapsRows(const T4IndexView &ix, WaveMem &wm, Wav
       }
 #endif
       o.chainLen = m0;
+      if (!(o.flags & OV_ISREF)) ovKeepRunSize(o, runSize);   // (the chain is done with: its index makes room)
       wm.ov[wm.ord[i]] = o;
     }
   }
@@ -2744,11 +2752,13 @@ __device__ __forceinline__ bool scoreOverlaps(const T4IndexView &ix, WaveMem &wm
   for (int i = lane; i < overlapCnt; i += NT) {
     OvRec o = wm.ov[wm.ord[i]];
     int m0 = o.matchCnt;
+    const int runSize = (o.flags & OV_ISREF) ? 0 : o.indelCnt;   // (chainFinish left it there)
     if ((o.flags & OV_ISREF) && ix.radius > 0) {   // sums are complete (see walkOverlap): no second walk
       o.matchCnt = (int)((const unsigned *)(wm.keys + o.chainPos))[o.chainLen];
       if (lowComplex(wm, (o.flags & OV_PLUS) != 0, o.rs, o.re)) o.flags |= OV_SIMZERO;
     } else walkOverlap(ix, wm, ws, o, i, false);
     o.chainLen = m0;                       // chain no longer needed: keep the pre-score matchCnt here
+    if (!(o.flags & OV_ISREF)) ovKeepRunSize(o, runSize);
     wm.ov[wm.ord[i]] = o;
   }
   __syncthreads();
