@@ -8,8 +8,9 @@ text, device bring-up and every host phase are INSIDE the timed region (the boun
 so there is no "inputs resident in HBM" variant of this metric; the kernel-only numbers are in `roofline` / `passes`).
 
 N = 1. The workload is BASELINE.json's config C2 ITSELF (1 M synthetic 150 bp PE pairs, 20 k clones, seed 1, -f hg38_bcrtcr.fa,
-bulk mode) whenever `steps + warmup` runs of it fit the time budget (T4_BENCH_BUDGET_S, default 1800 s: the driver's 20 + 5 steps of C2
-at its 61 s per step): the first run is C2 in
+bulk mode) whenever `steps + warmup` runs of it fit into the time the WHOLE run of bench.py may take (T4_BENCH_BUDGET_S, default 1740 s from
+process start to the printed line: the driver stops bench.py after 1800 s, and its 20 + 5 steps of C2 at 58-61 s per step need
+1450-1525 s of that; decided from the first run's own seconds and what has been spent by then): the first run is C2 in
 any case -- it is compared with the committed md5 sums of the reference's outputs, it is the first warm-up step when C2 is the
 workload, and it is reported as `c2` (with its own roofline block and a same-box reference timing on a stated prefix of the same
 files). When the runs do not fit, the steps are timed on the C2 recipe at 100 k pairs (`config.workload` says which ran).
@@ -43,6 +44,13 @@ import subprocess
 import sys
 import tempfile
 import time
+
+T_PROC0 = time.time()   # (the driver's clock runs from the start of the process: the interpreter's own start-up is a fraction of a second before this line)
+try:
+    import psutil
+    T_PROC0 = psutil.Process().create_time()
+except Exception:   # noqa: BLE001
+    pass
 
 import numpy as np
 
@@ -580,9 +588,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=0, help="read pairs per step: 0 = config C2 itself (1 M pairs) when steps + warmup runs of it fit the budget, else the C2 recipe at 100 k pairs; "
                                                          "a number forces the C2 recipe at that size")
+    ap.add_argument("--fallback-pairs", type=int, default=100000, help="pairs of the C2-recipe batch the steps are timed on when C2 itself does not fit")
     ap.add_argument("--clones", type=int, default=0, help="clones of the batch (default: pairs / 50, the C2 ratio)")
     ap.add_argument("--threads", type=int, default=8, help="host threads of trust4-hip (-t)")
-    ap.add_argument("--budget", type=float, default=float(os.environ.get("T4_BENCH_BUDGET_S", "1800")), help="seconds the warm-up + timed steps may take (decides whether C2 itself is the workload)")
+    ap.add_argument("--budget", type=float, default=float(os.environ.get("T4_BENCH_BUDGET_S", "1740")),
+                    help="seconds the WHOLE run may take, process start to the printed line (the driver stops bench.py after 1800 s): decides whether C2 itself is the workload and which side legs run")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 = skip the reference legs")
     ap.add_argument("--cpu-single-pairs", type=int, default=20000, help="prefix timed with the reference's -t 1 (0 = skip)")
     ap.add_argument("--cpu-c2-pairs", type=int, default=100000, help="prefix of C2's files the reference is timed on, on this box (0 = skip)")
@@ -602,12 +612,22 @@ def main():
     rank, local_rank, world = t4dist.env_rank()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    dry = bool(os.environ.get("T4_BENCH_CPU_DRYRUN")) and world > 1   # the N > 1 plumbing without GPUs (CPU test suite): gloo, emulated driver, file transport
+    # T4_BENCH_CPU_DRYRUN: the plumbing without GPUs (CPU test suite, never a measurement) -- N > 1: gloo, the emulated driver, the file
+    # transport; N = 1: the emulated driver ($T4_DRIVER) on a stand-in for C2, so that the choice of the workload and the order of the legs are tested
+    dry = bool(os.environ.get("T4_BENCH_CPU_DRYRUN"))
     if not dry and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the measured path")
     if not dry:
         torch.cuda.set_device(local_rank)
+    elif world == 1:
+        global DRIVER
+        DRIVER = os.environ["T4_DRIVER"]
+        args.traffic = args.side_legs = 0
     dist = t4dist.init("gloo" if dry else "nccl")   # RCCL: barrier + max-reduce of the timed interval (the data-path collective of the sharded run is inside the engine)
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
 
     if rank == 0 and not dry:
         trust4_amd.build.build()
@@ -624,16 +644,31 @@ def main():
     tmp = tempfile.mkdtemp(prefix="t4bench_")
     try:
         threads = max(1, min(args.threads, host_cores()))
-        t_bench0 = time.perf_counter()
+
+        def spent():
+            return time.time() - T_PROC0
         c2 = None
         use_c2 = False
+        c2_cpu = None
+        c2name = "c2"
         if args.pairs == 0 and args.c2:
             # config C2 itself, once: digest check, the first warm-up step if C2 is the workload, the `c2` record either way
             c2dir = os.path.join(tmp, "c2")
             os.makedirs(c2dir)
-            c2 = config_leg("c2", threads, local_rank, keep=c2dir)
-            use_c2 = "seconds" in c2 and c2["seconds"] * (args.steps + args.warmup) <= args.budget and args.warmup >= 1
-        pairs = 1000000 if use_c2 else (args.pairs if args.pairs > 0 else 100000)
+            c2name = os.environ.get("T4_BENCH_C2_STANDIN", "c2")   # testing aid: "c2mini" walks the same code in seconds (the line then says it is not config C2)
+            c2 = config_leg(c2name, threads, local_rank, keep=c2dir)
+            # the reference on this box on a prefix of C2's own files, BEFORE the steps: the line carries its cpu_baseline whatever the
+            # steps leave of the budget (about 30 s; nothing else runs beside it or beside a timed step)
+            if "files" in c2 and args.cpu_baseline and os.path.exists(REF_BIN) and args.cpu_c2_pairs > 0:
+                try:
+                    c2_cpu = config_leg_cpu_only(c2["files"], c2name, min(args.cpu_c2_pairs, c2["pairs"]), limit_s=max(30.0, min(300.0, args.budget - spent() - 200)))
+                except Exception as e:   # noqa: BLE001
+                    c2_cpu = {"value": None, "unit": "pairs/s", "cores": host_cores(), "kind": "reference", "sample": "not measured: %s" % repr(e)[:200]}
+            # C2 is the workload when the remaining steps + warm-up runs of it (2 % slack), and 50 s for what must follow them, end inside the budget
+            need = c2.get("seconds", 1e9) * (args.steps + args.warmup - 1) * 1.02 + 50
+            use_c2 = "seconds" in c2 and args.warmup >= 1 and spent() + need <= args.budget
+            c2["workload_decision"] = {"spent_s_before_the_steps": spent(), "needed_s": need, "budget_s": args.budget}
+        pairs = c2["pairs"] if use_c2 else (args.pairs if args.pairs > 0 else args.fallback_pairs)
         clones = args.clones if args.clones > 0 else max(1, pairs // 50)
         if use_c2:
             fa, f1, f2, _, _ = c2["files"]
@@ -644,19 +679,26 @@ def main():
 
         for _ in range(args.warmup - (1 if use_c2 else 0)):
             run_stage1(fa, f1, f2, mine, threads, local_rank)
-        torch.cuda.synchronize()
+        sync()
         t0 = time.perf_counter()
+        steps_done = 0
         for _ in range(args.steps):
+            # last resort, never expected (the decision above leaves slack): a box that turned so much slower during the steps that the
+            # next one would run into the driver's limit -- a line over the steps that were timed, saying so, instead of no line at all
+            if use_c2 and steps_done >= 1 and spent() + (time.perf_counter() - t0) / steps_done * 1.05 > args.budget + 45:
+                break
             run_stage1(fa, f1, f2, mine, threads, local_rank, stats=stats_path)
-        torch.cuda.synchronize()
+            steps_done += 1
+        sync()
         dt = time.perf_counter() - t0
+        steps_asked, args.steps = args.steps, steps_done
 
         st = json.load(open(stats_path))
         ph = st["phases_s"]
         aq, ra = st["add_query"], st["rough_annotation"]
         alg_ann = annotate_bytes(ra["reads"], 150, ra["hits"])
         roof = add_roofline(aq)
-        workload = ("config C2 itself: 1000000 synthetic 150 bp PE pairs (20000 clones, seed 1)" if use_c2 else
+        workload = (("config C2 itself: 1000000 synthetic 150 bp PE pairs (20000 clones, seed 1)" if c2name == "c2" else "NOT config C2 -- the stand-in %s of T4_BENCH_C2_STANDIN: %d pairs (%d clones, seed 1)" % (c2name, pairs, clones)) if use_c2 else
                     "C2 recipe, %d synthetic 150 bp PE pairs (%d clones, seed 1)%s" % (pairs, clones,
                     ": config C2 itself takes %.1f s per step here, %d steps + %d warm-up do not fit the budget of %.0f s -- C2 is the `c2` record of this line"
                     % (c2["seconds"], args.steps, args.warmup, args.budget) if c2 and "seconds" in c2 else ""))
@@ -670,7 +712,7 @@ def main():
             "dtype": "int32/u64", "data": "synthetic",
             "config": {"workload": workload + ", -f hg38_bcrtcr.fa, k=9, bulk mode; one step = whole stage 1 through trust4-hip -t %d --skipMateExtension, FASTQ files in -> "
                                               "_raw.out / _assembled_reads.fa / _final.out out, process start to exit" % threads,
-                       "pairs_per_step": pairs, "is_baseline_config_c2": bool(use_c2), "host_threads": threads, "contigs": st["contigs"], "assembled_reads": st["assembled_reads"],
+                       "pairs_per_step": pairs, "is_baseline_config_c2": bool(use_c2 and c2name == "c2"), "host_threads": threads, "contigs": st["contigs"], "assembled_reads": st["assembled_reads"],
                        "sharding": "N = 1: bulk-mode stage 1 is one ordered chain; N > 1 measures the barcode-mode sample sharded by cells (see the docstring)",
                        "phases_s": {"parse_processread_21mers": ph["input_processed_counted"], "sort": ph["sorted"] - ph["input_processed_counted"],
                                     "rough_annotation": ph["rough_annotation"] - ph["sorted"], "trim": ph["trimmed_ready"] - ph["rough_annotation"],
@@ -680,18 +722,22 @@ def main():
                        "rough_annotation_in_step": {"reads": ra["reads"], "hits": ra["hits"], "kernel_ms": ra["kernel_ms"],
                                                     "achieved_GBs": alg_ann / (max(ra["kernel_ms"], 1e-6) * 1e-3) / 1e9}},
         }
+        if steps_done != steps_asked:
+            out["steps_cut_short"] = "%d of the %d steps asked for were timed: the next one would have ended beyond the %d s the whole run may take" % (steps_done, steps_asked, int(args.budget))
         if use_c2:
             out["parity_on_bench_batch"] = bool(c2.get("identical")) and all(file_md5(mine + x) == c2["md5"][x] for x in OUT_SUFFIXES)
         # the reference on this box
         if args.cpu_baseline and os.path.exists(REF_BIN):
             if use_c2:
-                leg = config_leg_cpu_only(c2["files"], "c2", args.cpu_c2_pairs)
-                out["cpu_baseline"] = leg
+                out["cpu_baseline"] = c2_cpu
             else:
                 out["cpu_baseline"], out["parity_on_bench_batch"] = cpu_baseline(tmp, fa, f1, f2, pairs, mine, args.cpu_single_pairs)
-                if c2 and "files" in c2 and args.cpu_c2_pairs > 0:
-                    c2["cpu_baseline"] = config_leg_cpu_only(c2["files"], "c2", args.cpu_c2_pairs)
-        if args.traffic:
+                if c2 and c2_cpu:
+                    c2["cpu_baseline"] = c2_cpu
+        left = args.budget + 30 - spent()   # what follows is left out when it could run into the driver's limit
+        if args.traffic and left < 150:
+            out["roofline"]["traffic_detail"] = {"skipped": "%.0f s left of the run's budget: the two PMC passes are in the line of `python bench.py` with its default steps (profiles/)" % left}
+        elif args.traffic:
             try:
                 pf = (fa, f1, f2) if not use_c2 else make_batch(tmp, 100000, 2000, 1)
                 tr, detail = pmc_traffic(pf[0], pf[1], pf[2], threads, local_rank, tmp)
@@ -713,25 +759,27 @@ def main():
             c2.pop("files", None)
             out["c2"] = c2
         if args.side_legs:
-            left = 2400 - (time.perf_counter() - t_bench0)   # side legs only while the whole run stays well inside the driver's patience
             for extra in [x for x in args.config_leg.split(",") if x]:
                 out[extra.replace(":", "_")] = config_leg(extra, threads, local_rank)
                 out[extra.replace(":", "_")].pop("files", None)
-            if left > 120:
+            left = args.budget + 30 - spent()   # side legs only while the whole run stays inside the driver's limit
+            if left > 300:
                 try:
                     out["passes"]["rough_annotation_c2"] = annotate_pass_c2(local_rank, 1000000, 20000, 3)
                 except Exception as e:   # noqa: BLE001
                     out["passes"]["rough_annotation_c2"] = {"error": repr(e)[:300]}
                 out["stage1_cells"] = stage1_cells(100000, 1000)
                 out["stage0_e2e"] = stage0_e2e(400000)
-                if 2400 - (time.perf_counter() - t_bench0) > 90:
+                if args.budget + 30 - spent() > 150:
                     out["stage1_cells_1m"] = stage1_cells_1m()
+            else:
+                out["side_legs_skipped"] = "%.0f s left of the run's budget" % left
         print(json.dumps(out))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def config_leg_cpu_only(files, name, prefix_pairs):
+def config_leg_cpu_only(files, name, prefix_pairs, limit_s=None):
     """the reference on THIS box on the first prefix_pairs pairs of a config's own files"""
     fa, f1, f2 = files[0], files[1], files[2]
     tmp = os.path.dirname(f1)
@@ -740,7 +788,7 @@ def config_leg_cpu_only(files, name, prefix_pairs):
     head_fastq(f2, h2, prefix_pairs)
     cores = host_cores()
     t0 = time.perf_counter()
-    subprocess.run([REF_BIN, "-t", str(cores), "--skipMateExtension", "-f", fa, "-1", h1, "-2", h2, "-o", os.path.join(tmp, "cpuref")], check=True, stderr=subprocess.DEVNULL)
+    subprocess.run([REF_BIN, "-t", str(cores), "--skipMateExtension", "-f", fa, "-1", h1, "-2", h2, "-o", os.path.join(tmp, "cpuref")], check=True, stderr=subprocess.DEVNULL, timeout=limit_s)
     dc = time.perf_counter() - t0
     return {"value": prefix_pairs / dc, "unit": "pairs/s", "cores": cores, "kind": "reference", "seconds": dc,
             "sample": "oracle/_ref/trust4 -t %d --skipMateExtension on the first %d pairs of config %s's own files (%s, %s), on this box, %.1f s wall"

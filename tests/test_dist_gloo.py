@@ -310,3 +310,38 @@ def test_two_rank_barcode_stage1_gpu(tmp_path):
     import trust4_amd.build as b
     b.build()
     run_stage1_two_ranks(tmp_path, os.path.join(ROOT, "trust4_amd", "bin", "trust4-hip"), 2000, 50, 11)
+
+
+def _bench_single_dry_run(tmp_path, extra):
+    import json
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_stage1_e2e import _emulated_driver
+    env = dict(os.environ, T4_BENCH_CPU_DRYRUN="1", T4_DRIVER=_emulated_driver(), T4_BENCH_C2_STANDIN="c2micro", HIPEMU_THREADS="4", TMPDIR=str(tmp_path))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-c2-pairs", "200", "--cpu-single-pairs", "50"] + extra,
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-800:]
+    return json.loads([x for x in p.stdout.strip().split("\n") if x.startswith("{")][-1])
+
+
+def test_bench_single_gpu_workload_choice_dry_run(tmp_path):
+    """`python bench.py --steps K --warmup W` at N = 1 without a GPU (T4_BENCH_CPU_DRYRUN: the emulated driver, a 400-pair stand-in for
+    config C2): the run of "C2" comes first, the reference's timing on a prefix of its files before the steps, then the choice of the
+    workload from what the WHOLE run may take -- inside the budget the steps are timed on the "C2" files (and the line says whether
+    that was config C2: here it was not), outside it on the fallback batch with the "C2" run as the `c2` record."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "trust4")):
+        pytest.skip("oracle/_ref/trust4 not built")
+    line = _bench_single_dry_run(tmp_path, [])
+    assert line["steps"] == 2 and line["warmup"] == 1 and line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] is None
+    assert line["config"]["pairs_per_step"] == 400 and line["config"]["is_baseline_config_c2"] is False and "stand-in c2micro" in line["config"]["workload"]
+    assert line["cpu_baseline"]["kind"] == "reference" and line["cpu_baseline"]["value"] > 0 and "first 200 pairs" in line["cpu_baseline"]["sample"]
+    assert line["c2"]["workload_decision"]["budget_s"] == 1740 and line["c2"]["workload_decision"]["spent_s_before_the_steps"] > 0
+    assert "steps_cut_short" not in line and line["roofline"]["traffic"] is None
+    # the whole run may take 1 s: "C2" cannot be the workload
+    line = _bench_single_dry_run(tmp_path, ["--budget", "1", "--fallback-pairs", "300"])
+    assert line["steps"] == 2 and line["config"]["pairs_per_step"] == 300 and line["config"]["is_baseline_config_c2"] is False
+    assert "do not fit the budget" in line["config"]["workload"]
+    assert line["parity_on_bench_batch"] is True and line["cpu_baseline"]["value"] > 0 and "whole batch" in line["cpu_baseline"]["sample"]
+    assert line["c2"]["pairs"] == 400 and line["c2"]["cpu_baseline"]["value"] > 0
