@@ -8,7 +8,7 @@ text, device bring-up and every host phase are INSIDE the timed region (the boun
 so there is no "inputs resident in HBM" variant of this metric; the kernel-only numbers are in `roofline` / `passes`).
 
 N = 1. The workload is BASELINE.json's config C2 ITSELF (1 M synthetic 150 bp PE pairs, 20 k clones, seed 1, -f hg38_bcrtcr.fa,
-bulk mode) whenever `steps + warmup` runs of it fit into the time the WHOLE run of bench.py may take (T4_BENCH_BUDGET_S, default 1740 s from
+bulk mode) whenever `steps + warmup` runs of it fit into the time the WHOLE run of bench.py may take (T4_BENCH_BUDGET_S, default 1770 s from
 process start to the printed line: the driver stops bench.py after 1800 s, and its 20 + 5 steps of C2 at 58-61 s per step need
 1450-1525 s of that; decided from the first run's own seconds and what has been spent by then): the first run is C2 in
 any case -- it is compared with the committed md5 sums of the reference's outputs, it is the first warm-up step when C2 is the
@@ -591,7 +591,7 @@ def main():
     ap.add_argument("--fallback-pairs", type=int, default=100000, help="pairs of the C2-recipe batch the steps are timed on when C2 itself does not fit")
     ap.add_argument("--clones", type=int, default=0, help="clones of the batch (default: pairs / 50, the C2 ratio)")
     ap.add_argument("--threads", type=int, default=8, help="host threads of trust4-hip (-t)")
-    ap.add_argument("--budget", type=float, default=float(os.environ.get("T4_BENCH_BUDGET_S", "1740")),
+    ap.add_argument("--budget", type=float, default=float(os.environ.get("T4_BENCH_BUDGET_S", "1770")),
                     help="seconds the WHOLE run may take, process start to the printed line (the driver stops bench.py after 1800 s): decides whether C2 itself is the workload and which side legs run")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 = skip the reference legs")
     ap.add_argument("--cpu-single-pairs", type=int, default=20000, help="prefix timed with the reference's -t 1 (0 = skip)")
@@ -664,8 +664,9 @@ def main():
                     c2_cpu = config_leg_cpu_only(c2["files"], c2name, min(args.cpu_c2_pairs, c2["pairs"]), limit_s=max(30.0, min(300.0, args.budget - spent() - 200)))
                 except Exception as e:   # noqa: BLE001
                     c2_cpu = {"value": None, "unit": "pairs/s", "cores": host_cores(), "kind": "reference", "sample": "not measured: %s" % repr(e)[:200]}
-            # C2 is the workload when the remaining steps + warm-up runs of it (2 % slack), and 50 s for what must follow them, end inside the budget
-            need = c2.get("seconds", 1e9) * (args.steps + args.warmup - 1) * 1.02 + 50
+            # C2 is the workload when the remaining steps + warm-up runs of it (1.5 % slack; runs of one box differ by less), and 20 s for what
+            # must follow them (md5 sums of the outputs, the line), end inside the budget
+            need = c2.get("seconds", 1e9) * (args.steps + args.warmup - 1) * 1.015 + 20
             use_c2 = "seconds" in c2 and args.warmup >= 1 and spent() + need <= args.budget
             c2["workload_decision"] = {"spent_s_before_the_steps": spent(), "needed_s": need, "budget_s": args.budget}
         pairs = c2["pairs"] if use_c2 else (args.pairs if args.pairs > 0 else args.fallback_pairs)
@@ -685,7 +686,7 @@ def main():
         for _ in range(args.steps):
             # last resort, never expected (the decision above leaves slack): a box that turned so much slower during the steps that the
             # next one would run into the driver's limit -- a line over the steps that were timed, saying so, instead of no line at all
-            if use_c2 and steps_done >= 1 and spent() + (time.perf_counter() - t0) / steps_done * 1.05 > args.budget + 45:
+            if use_c2 and steps_done >= 1 and spent() + (time.perf_counter() - t0) / steps_done * 1.03 > args.budget + 15:
                 break
             run_stage1(fa, f1, f2, mine, threads, local_rank, stats=stats_path)
             steps_done += 1
@@ -734,7 +735,7 @@ def main():
                 out["cpu_baseline"], out["parity_on_bench_batch"] = cpu_baseline(tmp, fa, f1, f2, pairs, mine, args.cpu_single_pairs)
                 if c2 and c2_cpu:
                     c2["cpu_baseline"] = c2_cpu
-        left = args.budget + 30 - spent()   # what follows is left out when it could run into the driver's limit
+        left = args.budget + 10 - spent()   # what follows is left out when it could run into the driver's limit
         if args.traffic and left < 150:
             out["roofline"]["traffic_detail"] = {"skipped": "%.0f s left of the run's budget: the two PMC passes are in the line of `python bench.py` with its default steps (profiles/)" % left}
         elif args.traffic:
@@ -762,7 +763,7 @@ def main():
             for extra in [x for x in args.config_leg.split(",") if x]:
                 out[extra.replace(":", "_")] = config_leg(extra, threads, local_rank)
                 out[extra.replace(":", "_")].pop("files", None)
-            left = args.budget + 30 - spent()   # side legs only while the whole run stays inside the driver's limit
+            left = args.budget + 10 - spent()   # side legs only while the whole run stays inside the driver's limit
             if left > 300:
                 try:
                     out["passes"]["rough_annotation_c2"] = annotate_pass_c2(local_rank, 1000000, 20000, 3)
@@ -770,7 +771,7 @@ def main():
                     out["passes"]["rough_annotation_c2"] = {"error": repr(e)[:300]}
                 out["stage1_cells"] = stage1_cells(100000, 1000)
                 out["stage0_e2e"] = stage0_e2e(400000)
-                if args.budget + 30 - spent() > 150:
+                if args.budget + 10 - spent() > 150:
                     out["stage1_cells_1m"] = stage1_cells_1m()
             else:
                 out["side_legs_skipped"] = "%.0f s left of the run's budget" % left

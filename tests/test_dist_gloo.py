@@ -337,7 +337,7 @@ def test_bench_single_gpu_workload_choice_dry_run(tmp_path):
     assert line["steps"] == 2 and line["warmup"] == 1 and line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] is None
     assert line["config"]["pairs_per_step"] == 400 and line["config"]["is_baseline_config_c2"] is False and "stand-in c2micro" in line["config"]["workload"]
     assert line["cpu_baseline"]["kind"] == "reference" and line["cpu_baseline"]["value"] > 0 and "first 200 pairs" in line["cpu_baseline"]["sample"]
-    assert line["c2"]["workload_decision"]["budget_s"] == 1740 and line["c2"]["workload_decision"]["spent_s_before_the_steps"] > 0
+    assert line["c2"]["workload_decision"]["budget_s"] == 1770 and line["c2"]["workload_decision"]["spent_s_before_the_steps"] > 0
     assert "steps_cut_short" not in line and line["roofline"]["traffic"] is None
     # the whole run may take 1 s: "C2" cannot be the workload
     line = _bench_single_dry_run(tmp_path, ["--budget", "1", "--fallback-pairs", "300"])
