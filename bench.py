@@ -321,7 +321,7 @@ def cell_config_leg(name, device, threads=32):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def pmc_traffic(fa, f1, f2, threads, device, tmp, kernels=("queryKernel", "extendKernel")):
+def pmc_traffic(fa, f1, f2, threads, device, tmp, kernels=("queryKernel", "extendKernel"), limit_s=None):
     """HBM-side bytes of the dominant kernels of ONE step, from rocprofv3's TCC counters: the step's own command run twice more
     under `rocprofv3 --pmc <C> --kernel-trace` (FETCH_SIZE and WRITE_SIZE in separate passes, as the counter slots demand),
     the counter summed over every launch of the query kernels. Correction of MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts
@@ -338,7 +338,11 @@ def pmc_traffic(fa, f1, f2, threads, device, tmp, kernels=("queryKernel", "exten
         d = os.path.join(tmp, "pmc_" + counter)
         cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
                DRIVER, "-t", str(threads), "--skipMateExtension", "-f", fa, "-1", f1, "-2", f2, "-o", os.path.join(tmp, "pmcrun")]
-        p = subprocess.run(cmd, env=dict(os.environ, T4_DEVICE=str(device), TMPDIR="/tmp"), cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+        try:
+            p = subprocess.run(cmd, env=dict(os.environ, T4_DEVICE=str(device), TMPDIR="/tmp"), cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
+                               timeout=limit_s / 2 if limit_s else None)
+        except subprocess.TimeoutExpired:
+            return None, {"error": "rocprofv3 --pmc %s did not end within the %.0f s the run's budget left for it" % (counter, limit_s / 2)}
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         if p.returncode or not files:
             return None, {"error": "rocprofv3 --pmc %s failed (%d): %s" % (counter, p.returncode, p.stderr.strip().split("\n")[-1][:200])}
@@ -741,7 +745,7 @@ def main():
         elif args.traffic:
             try:
                 pf = (fa, f1, f2) if not use_c2 else make_batch(tmp, 100000, 2000, 1)
-                tr, detail = pmc_traffic(pf[0], pf[1], pf[2], threads, local_rank, tmp)
+                tr, detail = pmc_traffic(pf[0], pf[1], pf[2], threads, local_rank, tmp, limit_s=max(60.0, left - 40))
             except Exception as e:   # noqa: BLE001
                 tr, detail = None, {"error": repr(e)[:300]}
             out["roofline"]["traffic_detail"] = detail
