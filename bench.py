@@ -26,9 +26,10 @@ Rank 0 also reports
   stage0_e2e     the stage-0 candidate filter next to the reference binary.
 
 N > 1 measures the path that shards: ONE barcode-mode sample of the C5 recipe (`--cells-pairs` pairs and
-`--cells` cells per GPU of the job), cells sharded by rank through `trust4-hip --cellShard R/N --rcclId FILE` -- every rank parses
-the sample and counts its 21-mers, then keeps the reads of its own cells only (statistics, sort, rough annotation, barcode-wise
-counts and the cell pass on those); no exchange during assembly, the contig records gathered to rank 0 inside the engine at the
+`--cells` cells per GPU of the job), cells sharded by rank through `trust4-hip --cellShard R/N --rcclId FILE` -- every rank splits
+the text of the sample into records but builds, ProcessReads and counts the pairs of its own cells only (the cells follow from the
+barcode file; the ranks' 21-mer tables are put together in one all-gather), then statistics, sort, rough annotation, barcode-wise
+counts and the cell pass on those; no exchange during assembly, the contig records gathered to rank 0 inside the engine at the
 end, every rank writes its slice of the reads. Strong scaling: the sample is fixed by N, `value` = its pairs / the slowest
 rank's wall time. Rank 0 then runs the same sample on one rank and compares the md5 sums of the three output files (`one_rank`),
 and reports every rank's seconds in the replicated phases, in the phases on its own cells and in the cell pass (`config.per_rank_s`).
@@ -539,8 +540,9 @@ def sharded_cells(args, rank, local_rank, world, dist):
     sync()
     dist.barrier()
     dt = t4dist.max_over_ranks(dist, time.perf_counter() - t0, dev)
-    # this rank's seconds, gathered for the report: the replicated phases (parse / ProcessRead / 21-mer counts of the whole sample: up to
-    # the point where a rank lets go of the other ranks' reads), the phases before the cell pass on its own cells (count statistics,
+    # this rank's seconds, gathered for the report: up to the point where the sample's 21-mer counts are complete on the rank (the text of
+    # the whole sample split into records on every rank, ProcessRead and the counts of its own cells, the exchange of the ranks' tables:
+    # `replicated_phases` -- only the parse still is), the phases before the cell pass on its own cells (count statistics,
     # sort, rough annotation, barcode-wise counts, trimming) and the cell pass itself
     rep = own = add = 0.0
     try:
@@ -557,8 +559,9 @@ def sharded_cells(args, rank, local_rank, world, dist):
                 "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                 "scaling": "strong", "vs_baseline": None, "dtype": "int32/u64", "data": "synthetic",
                 "config": {"workload": "C5 recipe sample: %d synthetic 150 bp PE pairs, %d cells x 2 clones, barcode + UMI files; ONE sample over %d GPUs: every rank runs trust4-hip -t %d "
-                                       "--cellShard R/%d --rcclId (parse / ProcessRead / 21-mer counts of the whole sample replicated; count statistics, sort, rough annotation, barcode-wise counts "
-                                       "and the Add pass on a contiguous range of cells per rank; the contig records gathered to rank 0 inside the engine, every rank writes its slice of the reads); "
+                                       "--cellShard R/%d --rcclId (every rank splits the text of the whole sample into records; ProcessRead, the 21-mer counts -- the ranks' tables put together in one all-gather --, "
+                                       "count statistics, sort, rough annotation, barcode-wise counts and the Add pass on a contiguous range of cells per rank; the contig records gathered to rank 0 "
+                                       "inside the engine, every rank writes its slice of the reads); "
                                        "process start to exit of the slowest rank"
                                        % (pairs, cells, world, threads, world),
                            "pairs": pairs, "cells": cells, "host_threads_per_rank": threads,

@@ -371,6 +371,15 @@ int t4_kmer_count_stats(t4_kmer_counter *kc, t4_batch *reads, const char *quals,
                         int32_t *min_cnt, int32_t *median_cnt, float *avg_cnt, int32_t *new_len);
 /* number of distinct k-mers counted so far */
 int64_t t4_kmer_count_distinct(t4_kmer_counter *kc);
+/* The counts of two read sets put together. KmerCount::AddCount (KmerCount.hpp:64-97) only increments, so the table of a union of
+ * read sets is the sum of the sets' tables: a run whose INPUT is dealt out by cells (trust4-hip --cellShard: every rank parses the
+ * files but runs ProcessRead and the 21-mer count over the reads of its own cells only, where main.cpp:787-915 does both for the
+ * whole sample) counts its reads, hands the other ranks its pairs and adds theirs. export: the table's (k-mer, count) pairs in any
+ * order -- *n = how many there are; with cap == 0 nothing else happens, else the first min(*n, cap) pairs are written. merge:
+ * count[codes[i]] += counts[i]; only_present != 0 passes over the pairs whose k-mer the table does not hold (the statistics of a
+ * rank's reads look up those reads' k-mers only). Keys of a per-barcode counter travel as the table holds them (barcode included). */
+int t4_kmer_count_export(t4_kmer_counter *kc, uint64_t *codes, int32_t *counts, int64_t cap, int64_t *n);
+int t4_kmer_count_merge(t4_kmer_counter *kc, const uint64_t *codes, const int32_t *counts, int64_t n, int only_present);
 
 /* ---- ranks of one node: the one exchange of barcode mode, inside the engine ---------------------------------
  * Barcode mode shards by cell ranges with no exchange during assembly (main.cpp:1126-1192, 1549-1559 make cells independent); what

@@ -82,7 +82,7 @@ def run_stage1_two_ranks(tmp_path, driver, pairs, cells, seed, world=2):
     assert open(single + "_raw.out").read().count(">") >= cells
 
 
-def run_engine_merge(tmp_path, driver, pairs, cells, seed, world, env=None, extra=(), expect_log=None):
+def run_engine_merge(tmp_path, driver, pairs, cells, seed, world, env=None, extra=(), expect_log=None, common=()):
     """The merge trust4-hip itself runs on a multi-GPU node (trust4_main.cpp: shard headers all-gathered, every rank renumbers its own
     contig records, records gathered to rank 0, every rank writes its slice of _assembled_reads.fa at its offset), with the file
     transport (--gatherDir) in place of RCCL: `world` processes of the driver, no Python in the exchange. Outputs must equal the
@@ -98,7 +98,7 @@ def run_engine_merge(tmp_path, driver, pairs, cells, seed, world, env=None, extr
         shutil.copyfileobj(f, g)
     pre = str(tmp_path / "c5")
     subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, str(pairs), "0", str(seed), pre, "--cells", str(cells)], check=True)
-    argv = ["-f", fa, "-1", pre + "_1.fq", "-2", pre + "_2.fq", "--barcode", pre + "_bc.fa", "--UMI", pre + "_umi.fa"]
+    argv = ["-f", fa, "-1", pre + "_1.fq", "-2", pre + "_2.fq", "--barcode", pre + "_bc.fa", "--UMI", pre + "_umi.fa"] + list(common)   # (common: options of the single-process run too)
     e = dict(os.environ)
     e.update(env or {})
     single = str(tmp_path / "single")
@@ -117,8 +117,34 @@ def run_engine_merge(tmp_path, driver, pairs, cells, seed, world, env=None, extr
     for suffix in ("_raw.out", "_final.out", "_assembled_reads.fa"):
         assert filecmp.cmp(single + suffix, merged + suffix, shallow=False), suffix
     n = open(single + "_raw.out").read().count(">")
-    assert n >= cells
+    assert n >= (1 if common else cells)   # (options like --contigMinCov drop cells)
     return n
+
+
+def test_input_dealt_out_by_cells(tmp_path):
+    """--cellShard with a transport, round 5: a rank builds, ProcessReads and counts the pairs of ITS cells only (the cells follow from
+    the barcode file alone), and the 21-mer counts of the whole sample are put together through one exchange of the ranks' tables
+    (t4_kmer_count_export / _merge on the device, the host threads' maps under T4_GPU_KMERCOUNT=0). (a) device counts, 3 ranks;
+    (b) host counts; (c) more ranks than cells (ranks without a pair); (d) T4_SHARD_INPUT=0: round 4's way (input phases over the
+    whole sample on every rank); (e) --contigMinCov (pair counts per barcode come from the whole barcode file). All: the
+    single-process files byte for byte -- the read statistics of `_assembled_reads.fa` (min / median count per read) are where a
+    count that missed another rank's reads would show."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_stage1_e2e import _emulated_driver
+    exe = _emulated_driver()
+    env = {"HIPEMU_THREADS": "2", "T4_THREADS": "2"}
+    for tag in "abcde":
+        (tmp_path / tag).mkdir()
+    dealt = "their pairs alone are processed and counted here"
+    run_engine_merge(tmp_path / "a", exe, 150, 9, 21, 3, env=env, expect_log=dealt)
+    run_engine_merge(tmp_path / "b", exe, 150, 9, 22, 3, env=dict(env, T4_GPU_KMERCOUNT="0"), expect_log="pairs of this rank's table went to the other ranks")
+    run_engine_merge(tmp_path / "c", exe, 60, 3, 23, 5, env={"HIPEMU_THREADS": "1"}, expect_log=dealt)
+    run_engine_merge(tmp_path / "d", exe, 150, 9, 21, 3, env=dict(env, T4_SHARD_INPUT="0"), expect_log="are this rank's (")
+    run_engine_merge(tmp_path / "e", exe, 150, 9, 24, 2, env=env, common=["--contigMinCov", "8"], expect_log=dealt)
+    # negative control: without the other ranks' counts the files differ (the comparison above does see the counts)
+    (tmp_path / "f").mkdir()
+    with pytest.raises(AssertionError, match="_assembled_reads.fa|_raw.out"):
+        run_engine_merge(tmp_path / "f", exe, 150, 9, 21, 3, env=dict(env, T4_TEST_NO_COUNT_MERGE="1"))
 
 
 def test_early_shard_paths(tmp_path):

@@ -136,6 +136,48 @@ def test_kmer_count_table_grows_emulated(emu_engine, monkeypatch):
     check_per_barcode_counts(emu_engine, 22, 160)
 
 
+def check_kmer_count_merge(eng, seed, n_reads, parts=3, k=21):
+    """The table of a read set = the sum of the tables of its parts (what the ranks of a run with its input dealt out by cells do:
+    t4_kmer_count_export / _merge): a counter per part; part 0's counter takes the others' pairs (a) whole -- it then IS the table
+    of the whole set: same pairs as a counter fed every read -- and (b) only where it holds the k-mer already: the statistics of
+    part 0's reads equal the oracle's over the whole set, and the table has not grown."""
+    import numpy as np
+    reads, quals = kmer_count_case(seed, n_reads)
+    cut = [len(reads) * p // parts for p in range(parts + 1)]
+    cap = sum(max(0, len(r) - k + 1) for r in reads) + 8
+    whole = eng.kmer_counter(k, max_kmers=cap).add(eng.upload(reads))
+    part = [eng.kmer_counter(k, max_kmers=cap).add(eng.upload(reads[cut[p]:cut[p + 1]])) for p in range(parts)]
+    only = eng.kmer_counter(k, max_kmers=cap).add(eng.upload(reads[cut[0]:cut[1]]))
+    d0 = only.distinct()
+    for p in range(1, parts):
+        codes, vals = part[p].export()
+        assert len(codes) == part[p].distinct() and len(set(codes.tolist())) == len(codes)
+        part[0].merge(codes, vals)
+        only.merge(codes, vals, only_present=True)
+    as_dict = lambda kc: dict(zip(*[x.tolist() for x in kc.export()]))
+    assert as_dict(part[0]) == as_dict(whole)
+    assert only.distinct() == d0
+    w = as_dict(whole)
+    assert as_dict(only) == {c: w[c] for c in as_dict(only)}
+    oracle = KmerCountChecker(k)
+    for r in reads:
+        oracle.add(r)
+    mine = reads[cut[0]:cut[1]]
+    mn, md, av, ln = only.stats(eng.upload(mine), quals[cut[0]:cut[1]])
+    for i, r in enumerate(mine):
+        ret, omn, omd, oav, r_after, _ = oracle.stats(r, quals[cut[0] + i])
+        assert (int(mn[i]), int(md[i]), int(ln[i])) == (omn, omd, len(r_after)) and same(float(av[i]), float(oav)), (i, r)
+    empty = eng.kmer_counter(k, max_kmers=64)
+    assert len(empty.export()[0]) == 0
+    empty.merge(np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.int32))
+
+
+def test_kmer_count_export_merge_emulated(emu_engine, monkeypatch):
+    check_kmer_count_merge(emu_engine, 31, 180)
+    monkeypatch.setenv("T4_KC_SLOTS", "1024")   # the merged table outgrows its first size
+    check_kmer_count_merge(emu_engine, 32, 120, parts=2)
+
+
 def test_kmer_count_table_full_is_loud(emu_engine):
     reads = rows_to_strs(Synth(40, 3).next_reads(40))
     kc = emu_engine.kmer_counter(21, max_kmers=16)   # 1024 slots: far too few

@@ -5,7 +5,7 @@ import os
 
 import pytest
 
-from test_kmer_count_emu import check_engine_kmer_counts, check_per_barcode_counts
+from test_kmer_count_emu import check_engine_kmer_counts, check_kmer_count_merge, check_per_barcode_counts
 
 pytestmark = pytest.mark.gpu
 
@@ -29,6 +29,10 @@ def test_kmer_count_k31_gpu(eng):
 
 def test_per_barcode_counts_gpu(eng):
     check_per_barcode_counts(eng, 23, 2000, n_barcodes=40)
+
+
+def test_kmer_count_export_merge_gpu(eng):
+    check_kmer_count_merge(eng, 24, 3000, parts=4)
 
 
 def test_driver_with_device_host_phases_gpu(tmp_path):

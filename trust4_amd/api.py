@@ -246,6 +246,21 @@ class KmerCounter:
         self.eng.check(self.eng.lib.t4_kmer_count_stats(self.h, batch.h, qb, qo, mn.ctypes.data_as(V), md.ctypes.data_as(V), av.ctypes.data_as(V), ln.ctypes.data_as(V)))
         return mn, md, av, ln
 
+    def export(self):
+        """-> (codes uint64[n], counts int32[n]): the table's pairs, in any order (t4_kmer_count_export)"""
+        n = C.c_int64(0)
+        self.eng.check(self.eng.lib.t4_kmer_count_export(self.h, None, None, C.c_int64(0), C.byref(n)))
+        codes, vals = np.zeros(max(1, n.value), dtype=np.uint64), np.zeros(max(1, n.value), dtype=np.int32)
+        if n.value:
+            self.eng.check(self.eng.lib.t4_kmer_count_export(self.h, codes.ctypes.data_as(C.c_void_p), vals.ctypes.data_as(C.c_void_p), C.c_int64(n.value), C.byref(n)))
+        return codes[:n.value], vals[:n.value]
+
+    def merge(self, codes, counts, only_present=False):
+        """count[codes[i]] += counts[i] (t4_kmer_count_merge); only_present: k-mers the table does not hold are passed over"""
+        codes, counts = np.ascontiguousarray(codes, dtype=np.uint64), np.ascontiguousarray(counts, dtype=np.int32)
+        self.eng.check(self.eng.lib.t4_kmer_count_merge(self.h, codes.ctypes.data_as(C.c_void_p), counts.ctypes.data_as(C.c_void_p), C.c_int64(len(codes)), 1 if only_present else 0))
+        return self
+
     def distinct(self):
         self.eng.lib.t4_kmer_count_distinct.restype = C.c_int64
         return int(self.eng.lib.t4_kmer_count_distinct(self.h))

@@ -1369,6 +1369,63 @@ int t4_kmer_count_set(t4_kmer_counter *kc, const uint64_t *codes, const int32_t 
   return T4_OK;
 }
 
+int t4_kmer_count_export(t4_kmer_counter *kc, uint64_t *codes, int32_t *counts, int64_t cap, int64_t *n_out) {
+  if (!kc || !n_out || cap < 0 || (cap > 0 && (!codes || !counts))) return T4_ERR_ARG;
+  t4_ctx *c = kc->ctx;
+  (void)hipSetDevice(c->device);
+  unsigned long long used = 0;
+  HIPCHK(c, hipMemcpyAsync(&used, kc->tb.used, sizeof used, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *n_out = (int64_t)used;
+  if (cap == 0 || used == 0) return T4_OK;
+  int r;
+  unsigned long long *dC = nullptr, *dCur = nullptr; int *dV = nullptr;
+  if ((r = devAlloc(c, &dC, (size_t)cap)) || (r = devAlloc(c, &dV, (size_t)cap)) || (r = devAlloc(c, &dCur, (size_t)1))) { if (dC) (void)hipFree(dC); if (dV) (void)hipFree(dV); return r; }
+  HIPCHK(c, hipMemsetAsync(dCur, 0, sizeof(unsigned long long), c->stream));
+  const unsigned long long blocks = (kc->slots + 255ull) / 256ull;
+  const int grid = (int)(blocks < (unsigned long long)c->cus * 16ull ? blocks : (unsigned long long)c->cus * 16ull);
+  hipLaunchKernelGGL(t4k::kmerExportKernel, dim3(grid), dim3(256), 0, c->stream, kc->tb, dC, dV, dCur, (unsigned long long)cap);
+  HIPCHK(c, hipGetLastError());
+  unsigned long long got = 0;
+  HIPCHK(c, hipMemcpyAsync(&got, dCur, sizeof got, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t m = (size_t)(got < (unsigned long long)cap ? got : (unsigned long long)cap);
+  if (m) {
+    HIPCHK(c, hipMemcpy(codes, dC, sizeof(unsigned long long) * m, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(counts, dV, sizeof(int) * m, hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(dC); (void)hipFree(dV); (void)hipFree(dCur);
+  if (got != used) return fail(c, T4_ERR_STATE, "t4_kmer_count_export: %llu pairs in a table that counted %llu distinct k-mers", got, used);
+  return T4_OK;
+}
+
+int t4_kmer_count_merge(t4_kmer_counter *kc, const uint64_t *codes, const int32_t *counts, int64_t n, int only_present) {
+  if (!kc || n < 0 || (n > 0 && (!codes || !counts))) return T4_ERR_ARG;
+  t4_ctx *c = kc->ctx;
+  if (n == 0) return T4_OK;
+  (void)hipSetDevice(c->device);
+  int r;
+  const int64_t SLICE = (int64_t)1 << 26;   // pairs per upload (768 MB of device memory at most)
+  unsigned long long *dC = nullptr; int *dV = nullptr;
+  const size_t cap = (size_t)(n < SLICE ? n : SLICE);
+  if ((r = devAlloc(c, &dC, cap)) || (r = devAlloc(c, &dV, cap))) { if (dC) (void)hipFree(dC); return r; }
+  int overflow = 0;
+  for (int64_t lo = 0; lo < n && !overflow; lo += SLICE) {
+    const int64_t m = n - lo < SLICE ? n - lo : SLICE;
+    if (!only_present && (r = kmerEnsureRoom(kc, (unsigned long long)m))) { (void)hipFree(dC); (void)hipFree(dV); return r; }
+    HIPCHK(c, hipMemcpy(dC, codes + lo, sizeof(unsigned long long) * (size_t)m, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(dV, counts + lo, sizeof(int) * (size_t)m, hipMemcpyHostToDevice));
+    const int grid = (int)((m + 255) / 256 < (long long)c->cus * 8 ? (m + 255) / 256 : (long long)c->cus * 8);
+    hipLaunchKernelGGL(t4k::kmerMergeKernel, dim3(grid), dim3(256), 0, c->stream, kc->tb, (const unsigned long long *)dC, (const int *)dV, (long long)m, only_present ? 1 : 0);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(&overflow, kc->tb.overflow, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  (void)hipFree(dC); (void)hipFree(dV);
+  if (overflow) return fail(c, T4_ERR_UNSUPPORTED, "t4_kmer_count_merge: more distinct k-mers than the table was created for (%llu slots)", kc->slots);
+  return T4_OK;
+}
+
 int t4_kmer_count_stats(t4_kmer_counter *kc, t4_batch *b, const char *quals, const int64_t *qual_off,
                         int32_t *min_cnt, int32_t *median_cnt, float *avg_cnt, int32_t *new_len) {
   if (!kc || !b || !min_cnt || !median_cnt || !avg_cnt || !new_len || (quals && !qual_off)) return T4_ERR_ARG;

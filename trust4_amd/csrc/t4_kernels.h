@@ -4324,6 +4324,39 @@ __global__ __launch_bounds__(256) void kmerRehashKernel(T4KmerTable from, T4Kmer
   }
 }
 
+// every (k-mer key, count) pair of the table side by side, in any order (t4_kmer_count_export: what a rank of a run whose input is
+// dealt out by cells hands the other ranks). cursor counts the pairs; only the first cap of them are written.
+__global__ __launch_bounds__(256) void kmerExportKernel(T4KmerTable tb, unsigned long long *codes, int *counts, unsigned long long *cursor, unsigned long long cap) {
+  for (unsigned long long s = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; s <= tb.mask; s += (unsigned long long)gridDim.x * blockDim.x) {
+    const unsigned long long key = tb.keys[s];
+    if (!key) continue;
+    const unsigned long long at = atomicAdd(cursor, 1ull);
+    if (at < cap) { codes[at] = key - 1ull; counts[at] = (int)tb.cnt[s]; }
+  }
+}
+
+// The counts of another read set added to this table's: KmerCount::AddCount (KmerCount.hpp:64-97) only ever increments, so the counts
+// of a union of read sets are the sums of the sets' counts. onlyPresent: a pair whose k-mer this table does not hold is passed over
+// (a rank of a sharded run looks up the k-mers of its own reads only, and those are all here).
+__global__ __launch_bounds__(256) void kmerMergeKernel(T4KmerTable tb, const unsigned long long *codes, const int *counts, long long n, int onlyPresent) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const unsigned long long key = codes[i] + 1ull;
+    unsigned long long h = kcMix(codes[i]) & tb.mask, probes = 0;
+    for (; probes <= tb.mask; ++probes) {
+      if (onlyPresent) {
+        const unsigned long long cur = tb.keys[h];
+        if (cur == 0ull) break;
+        if (cur == key) { atomicAdd(&tb.cnt[h], (unsigned)counts[i]); break; }
+      } else {
+        const unsigned long long old = atomicCAS(&tb.keys[h], 0ull, key);
+        if (old == 0ull || old == key) { atomicAdd(&tb.cnt[h], (unsigned)counts[i]); if (old == 0ull) atomicAdd(tb.used, 1ull); break; }
+      }
+      h = (h + 1ull) & tb.mask;
+    }
+    if (!onlyPresent && probes > tb.mask) *tb.overflow = 1;
+  }
+}
+
 __global__ __launch_bounds__(64) void kmerStatsKernel(T4BatchView bv, T4KmerTable tb, const char *quals, const long long *qoff,
                                                      int *minOut, int *medOut, float *avgOut, int *lenOut) {
   __shared__ char s_seg[T4_MAXL + 8];

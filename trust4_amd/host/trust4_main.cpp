@@ -73,8 +73,9 @@ const char *USAGE =
     "\t--cellShard R/N: barcode mode only; assemble the R-th of N contiguous ranges of cells, write shard outputs\n"
     "\t--rcclId FILE: with --cellShard, one process per GPU: gather the shards over RCCL (rank 0 creates FILE, the communicator id) and write the merged -o files\n"
     "\t--gatherDir DIR: the same exchange through files in DIR (a directory every rank sees) instead of RCCL\n"
-    "\t                 (with either transport a rank lets go of the other ranks' reads once the 21-mers of the sample are counted; --lateShard keeps\n"
-    "\t                 every read on every rank up to the cell pass, as a run does by itself when identical reads lie either side of a rank boundary)\n"
+    "\t                 (with either transport a rank builds, processes and counts the read pairs of its own cells only -- the cells follow from the\n"
+    "\t                 barcode file -- and the ranks' 21-mer counts are put together in one exchange; --lateShard keeps every read on every rank\n"
+    "\t                 up to the cell pass, as a run does by itself when identical reads lie either side of a rank boundary)\n"
     "\t--readShard R/N: one sample over N processes (one per GPU): the rough annotation of the R-th range of the distinct reads here, the results\n"
     "\t                 all-gathered (--rcclId / --gatherDir); rank 0 runs the ordered assembly pass and writes the files, the others end after the exchange\n";
 
@@ -644,6 +645,46 @@ int main(int argc, char *argv[]) {
   int firstReadLen = -1, nIn = 0;
   bool reservedReadList = false;
   StrNumbering barcodeNumbers, umiNumbers;   // strings -> dense ints in order of first appearance (main.cpp:812-820, 831-842)
+  // ---- --cellShard R/N with a transport: the INPUT is dealt out by cells (round 5; VERDICT r3 / r4 "parse / ProcessRead / counts
+  // replicated"). Which cells are a rank's follows from the barcode file alone -- barcodes are numbered in order of first appearance
+  // (main.cpp:812-820) and the ranks get contiguous ranges of those numbers with about the same number of read pairs --, so every
+  // rank reads the barcode file once ahead of the input loop, and the loop then builds, ProcessReads and counts the 21-mers of the
+  // pairs of ITS cells only. Every rank still splits the FASTQ text of the whole sample into records (no record can be found without
+  // the ones before it) and numbers every UMI (numbers are in order of first appearance over the whole sample, main.cpp:831-842).
+  // The 21-mer counts of the whole sample, which the statistics of every read look at, are put together afterwards: counts only
+  // ever add up (KmerCount.hpp:64-97), so every rank hands the others the pairs of its table and adds theirs where it holds the k-mer
+  // (t4_kmer_count_export / _merge; one all-gather). T4_SHARD_INPUT=0: every rank runs the input phases over the whole sample
+  // and lets go of the other ranks' reads after the counts, as round 4 did (A/B and the tests' second path).
+  const bool shardInput = shardCount > 1 && !lateShard && (!rcclIdPath.empty() || !gatherDir.empty()) && !(getenv("T4_SHARD_INPUT") && atoi(getenv("T4_SHARD_INPUT")) == 0);
+  int ownLo = 0, ownHi = 0;   // this rank's barcode numbers [ownLo, ownHi)
+  long long ownPairs = 0, allPairs = 0;
+  if (shardInput) {
+    ThreadedSeqReader pre;
+    pre.files = barcodeFile.files;
+    ThreadedSeqReader::Block b;
+    StrNumbering numbers;
+    std::vector<long long> per;
+    while (pre.nextBlock(b))
+      for (const ThreadedSeqReader::Rec &r : b) {
+        if (r.seq == "missing_barcode" && !keepMissingBarcode) continue;
+        bool isNew = false;
+        const int x = numbers.number(r.seq, isNew);
+        if (x >= (int)per.size()) per.push_back(1); else ++per[(size_t)x];
+        ++allPairs;
+      }
+    const size_t nb = per.size();
+    auto firstBarcodeOf = [&](int r) {
+      if (r >= shardCount) return nb;
+      const long long target = allPairs * r / shardCount;
+      long long cum = 0;
+      size_t x = 0;
+      while (x < nb && cum < target) cum += per[x++];
+      return x;
+    };
+    ownLo = (int)firstBarcodeOf(shardRank); ownHi = (int)firstBarcodeOf(shardRank + 1);
+    for (int x = ownLo; x < ownHi; ++x) ownPairs += per[(size_t)x];
+    PrintLog("Cells %d-%d of %d are this rank's (%lld of %lld read pairs by the barcode file): their pairs alone are processed and counted here.", ownLo, ownHi, (int)nb, ownPairs, allPairs);
+  }
   std::vector<std::string> barcodeIntToStr;
   std::vector<int> barcodePairCount;   // main.cpp:822-828 (only counted under --contigMinCov)
   {
@@ -672,18 +713,20 @@ int main(int argc, char *argv[]) {
           if (isNew) barcodeIntToStr.push_back(bs);
           if (contigMinCov > 0) { if (barcode >= (int)barcodePairCount.size()) barcodePairCount.push_back(1); else ++barcodePairCount[barcode]; }
           u.bc[i] = barcode;
+          if (shardInput && (barcode < ownLo || barcode >= ownHi)) u.skip[i] = 2;   // another rank's cell: the record is numbered (barcode, UMI) and let go
         }
       }
       if (hasUmi) {       // main.cpp:831-842
         if (!umiFile.nextBlock(bU) || bU.size() < n) uneven("The UMI file has fewer records than the read file.");
         for (size_t i = 0; i < n; ++i) {
-          if (u.skip[i]) continue;
+          if (u.skip[i] == 1) continue;
           bool isNew = false;
           u.umi[i] = umiNumbers.number(bU[i].seq, isNew);
         }
       }
-      size_t kept = 0;
-      for (size_t i = 0; i < n; ++i) if (!u.skip[i]) {
+      size_t kept = 0, keptHere = 0;
+      for (size_t i = 0; i < n; ++i) if (u.skip[i] != 1) {
+        if (!u.skip[i]) ++keptHere;
         if (firstReadLen == -1) {
           firstReadLen = (int)u.r[i].seq.size();
           if (firstReadLen > 200) { fprintf(stderr, "trust4-hip: long-read mode (first read > 200 bp, main.cpp:1467-1481) is not built.\n"); if (processThread.joinable()) processThread.join(); if (initThread.joinable()) initThread.join(); return EXIT_FAILURE; }
@@ -707,13 +750,13 @@ int main(int argc, char *argv[]) {
         }
         if (plain && bytes > 0) {
           const double recs = fileBytes / ((double)bytes / (double)n) * 1.03 + 1024;
-          const double want = recs * (hasMate ? 2.0 : 1.0);
+          const double want = recs * (hasMate ? 2.0 : 1.0) * (shardInput && allPairs > 0 ? (double)ownPairs / (double)allPairs * 1.05 : 1.0);
           if (want < 2.0e9) sortedReads.reserve((size_t)want);
         }
       }
-      unitPairs += kept;
+      unitPairs += keptHere;
       units.push_back(std::move(u));
-      if (unitPairs >= BLOCK) flushBlock();
+      if (unitPairs >= BLOCK || (shardInput && units.size() >= 24)) flushBlock();   // (blocks of other ranks' cells go back to their readers before long)
     }
   }
   flushBlock();
@@ -816,8 +859,55 @@ int main(int argc, char *argv[]) {
   kmerCount.addCountAll((long long)sortedReads.size(), threadCnt, [&](long long i) -> const std::string & { return sortedReads[(size_t)i].read; });
   if (getenv("T4_TIMING")) PrintLog("timing: 21-mers counted%s (%.2f s since the input ended)", gpuKc ? " (on the device)" : "", std::chrono::duration<double>(std::chrono::steady_clock::now() - tInputEnd).count());
   gpuReady();
+  if (shardInput && kmerCountFile.empty()) {
+    // The counts of the whole sample: every rank's pairs to every rank (payload: n, n codes, n counts), the others' added where this
+    // rank's table holds the k-mer -- its reads' k-mers are all there, and nothing else is ever looked up.
+    const auto tm0 = std::chrono::steady_clock::now();
+    std::string mine;
+    int64_t n = 0;
+    if (gpuKc) {
+      if ((rc = t4_kmer_count_export(gpuKc, nullptr, nullptr, 0, &n))) die(ctx, "t4_kmer_count_export", rc);
+      mine.resize(8 + (size_t)n * 12);
+      if (n > 0 && (rc = t4_kmer_count_export(gpuKc, (uint64_t *)(&mine[8]), (int32_t *)(&mine[8 + (size_t)n * 8]), n, &n))) die(ctx, "t4_kmer_count_export", rc);
+    } else {
+      for (const auto &m : kmerCount.shards) n += (int64_t)m.size();
+      mine.resize(8 + (size_t)n * 12);
+      uint64_t *codes = (uint64_t *)(&mine[8]); int32_t *vals = (int32_t *)(&mine[8 + (size_t)n * 8]);
+      size_t at = 0;
+      for (const auto &m : kmerCount.shards) for (const auto &kv : m) { codes[at] = kv.first; vals[at] = kv.second; ++at; }
+    }
+    memcpy(&mine[0], &n, 8);
+    std::vector<std::string> got;
+    if (!exchange(mine, true, got)) { fprintf(stderr, "trust4-hip: the exchange of the 21-mer counts failed\n"); return EXIT_FAILURE; }
+    std::string().swap(mine);
+    long long taken = 0;
+    for (int r = 0; r < shardCount; ++r) {
+      if (r == shardRank || getenv("T4_TEST_NO_COUNT_MERGE")) continue;   // (testing aid: the negative control of tests/test_dist_gloo.py -- without the other ranks' counts the read statistics are wrong)
+      std::string &g = got[(size_t)r];
+      int64_t m = 0;
+      if (g.size() >= 8) memcpy(&m, g.data(), 8);
+      if (g.size() < 8 || m < 0 || g.size() != 8 + (size_t)m * 12) { fprintf(stderr, "trust4-hip: rank %d sent %zu bytes of 21-mer counts that do not hold %lld pairs\n", r, g.size(), (long long)m); return EXIT_FAILURE; }
+      const uint64_t *codes = (const uint64_t *)(g.data() + 8); const int32_t *vals = (const int32_t *)(g.data() + 8 + (size_t)m * 8);
+      if (gpuKc) { if ((rc = t4_kmer_count_merge(gpuKc, codes, vals, m, 1))) die(ctx, "t4_kmer_count_merge", rc); }
+      else
+        parallelFor((long long)kmerCount.shards.size(), threadCnt, [&](long long sh) {
+          auto &tab = kmerCount.shards[(size_t)sh];
+          const bool one = kmerCount.shards.size() == 1;
+          for (int64_t i = 0; i < m; ++i) {
+            if (!one && (long long)kmerCount.shardOf(codes[i]) != sh) continue;
+            auto it = tab.find(codes[i]);
+            if (it != tab.end()) it->second += vals[i];
+          }
+        });
+      taken += (long long)m;
+      std::string().swap(g);
+    }
+    PrintLog("21-mer counts of the whole sample: %lld pairs of this rank's table went to the other ranks, %lld of theirs were looked at.", (long long)n, taken);
+    if (getenv("T4_TIMING")) PrintLog("timing: counts of the ranks put together in %.2f s", std::chrono::duration<double>(std::chrono::steady_clock::now() - tm0).count());
+  }
   auto writeEmpty = [&](const char *suffix) { FILE *fp = fopen((outputPrefix + suffix).c_str(), "w"); if (fp) fclose(fp); };
-  if (readCnt <= 0) { writeEmpty("_raw.out"); writeEmpty("_assembled_reads.fa"); writeEmpty("_final.out"); return 0; }
+  // (a rank of a run whose input is dealt out by cells may hold no read at all: it goes on, as a rank without cells always has, and takes part in the exchanges)
+  if (readCnt <= 0 && !(shardInput && allPairs > 0)) { writeEmpty("_raw.out"); writeEmpty("_assembled_reads.fa"); writeEmpty("_final.out"); return 0; }
 
   if (contigMinCov > 0) {   // reads of barcodes with too few read pairs are dropped, after their k-mers were counted (main.cpp:951-977)
     std::vector<SortRead> kept;
@@ -833,7 +923,8 @@ int main(int argc, char *argv[]) {
   // for across the rank boundaries once the reads are in their final order, and a run that has it starts over with --lateShard.
   if (shardCount > 1) mark("counted_all_reads");   // (what comes before is replicated on every rank of a sharded run)
   const bool earlyShard = shardCount > 1 && !lateShard && (!rcclIdPath.empty() || !gatherDir.empty());   // (the boundary check needs the transport; shard files without one: as before)
-  if (earlyShard) {
+  if (earlyShard && shardInput) PrintLog("Cells %d-%d of %d are this rank's (%d reads).", ownLo, ownHi, (int)barcodeIntToStr.size(), readCnt);   // (the input loop kept nothing else)
+  else if (earlyShard) {
     const size_t nb = barcodeIntToStr.size();
     std::vector<long long> per(nb, 0);
     for (const SortRead &r : sortedReads) if (r.barcode >= 0) ++per[(size_t)r.barcode];
