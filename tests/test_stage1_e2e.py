@@ -593,3 +593,11 @@ def test_rccl_gather_inside_the_engine_gpu(tmp_path):
     assert p.returncode == 0 and "over RCCL" in p.stderr, p.stderr[-800:]
     for suffix in ("_raw.out", "_assembled_reads.fa", "_final.out"):
         assert filecmp.cmp(ref_out + suffix, my_out + suffix, shallow=False), suffix
+    # the exchange of the 21-mer tables of a run whose input is dealt out by cells (round 5), through the same communicator: one rank
+    # owns every cell, exports its table from the device and all-gathers it (T4_SHARD_INPUT=2 lets a single rank take that path)
+    my2 = str(tmp_path / "mine2")
+    p = subprocess.run([_driver(), "-t", "4"] + args + ["-o", my2, "--cellShard", "0/1", "--rcclId", str(tmp_path / "id2")], stderr=subprocess.PIPE, text=True,
+                       env=dict(os.environ, T4_SHARD_INPUT="2"))
+    assert p.returncode == 0 and "over RCCL" in p.stderr and "pairs of this rank's table went to the other ranks" in p.stderr, p.stderr[-800:]
+    for suffix in ("_raw.out", "_assembled_reads.fa", "_final.out"):
+        assert filecmp.cmp(ref_out + suffix, my2 + suffix, shallow=False), suffix

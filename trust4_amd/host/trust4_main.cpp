@@ -655,7 +655,9 @@ int main(int argc, char *argv[]) {
   // ever add up (KmerCount.hpp:64-97), so every rank hands the others the pairs of its table and adds theirs where it holds the k-mer
   // (t4_kmer_count_export / _merge; one all-gather). T4_SHARD_INPUT=0: every rank runs the input phases over the whole sample
   // and lets go of the other ranks' reads after the counts, as round 4 did (A/B and the tests' second path).
-  const bool shardInput = shardCount > 1 && !lateShard && (!rcclIdPath.empty() || !gatherDir.empty()) && !(getenv("T4_SHARD_INPUT") && atoi(getenv("T4_SHARD_INPUT")) == 0);
+  // (=2, a testing aid: also with ONE rank, which then owns every cell -- the export and the exchange run as they do with more, over RCCL on a one-GPU box)
+  const bool shardInput = (shardCount > 1 || (getenv("T4_SHARD_INPUT") && atoi(getenv("T4_SHARD_INPUT")) == 2 && hasBarcode && !keepMissingBarcode)) && !lateShard &&
+                          (!rcclIdPath.empty() || !gatherDir.empty()) && !(getenv("T4_SHARD_INPUT") && atoi(getenv("T4_SHARD_INPUT")) == 0);
   int ownLo = 0, ownHi = 0;   // this rank's barcode numbers [ownLo, ownHi)
   long long ownPairs = 0, allPairs = 0;
   if (shardInput) {
