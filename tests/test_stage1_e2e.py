@@ -573,6 +573,15 @@ def test_candidate_store_gpu(tmp_path):
     q = {k: int(re.search(r"GPU query rounds \d+ with (\d+) reads", v).group(1)) for k, v in logs.items()}
     r = {k: int(re.search(r"restricted re-queries: \d+ entries kept their other contigs when one contig changed, (\d+) merged", v).group(1)) for k, v in logs.items()}
     assert q["store"] - r["store"] < q["off"] - r["off"], (q, r)   # fewer whole queries
+    # few clones at the same depth: hundreds of contigs share a constant-gene segment, a commit that lengthens one of them RAISES the
+    # novelMinHitRequired of the reads inside it (longestHits / 4 of a larger group) -- served from the store by dropping the candidates
+    # chained from runs shorter than the new threshold (run sizes ride with the candidate records), every entry verified as above
+    d = tmp_path / "raise"
+    d.mkdir()
+    log = _bulk_case(d, _driver(), 30000, 600, 1, {"T4_VERIFY_WINDOW": "1"}, threads="8")
+    raised = re.search(r"(\d+) raised thresholds served by dropping the candidates of shorter runs", log)
+    assert raised and int(raised.group(1)) >= 5, log[-1500:]
+    assert "all equal to their cached results" in log
     print(m.groups(), q, r)
 
 
