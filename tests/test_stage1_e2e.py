@@ -552,6 +552,54 @@ def test_candidate_store_emulated(tmp_path, env):
     print(m.groups())
 
 
+def _shared_constant_gene_fasta(path):
+    """a gene set whose five chains hold the SAME genes (the IGK records under the names of all five chains): every clone t4synth draws
+    then shares one constant gene, and a read inside it meets hundreds of contigs at a depth the emulator can run"""
+    recs, cur = [], None
+    with gzip.open(REF_FA, "rt") as f:
+        for line in f:
+            if line.startswith(">"):
+                cur = [line, ""] if line[1:4] == "IGK" else None
+                if cur:
+                    recs.append(cur)
+            elif cur:
+                cur[1] += line
+    with open(path, "w") as g:
+        for chain in ("IGK", "IGH", "IGL", "TRA", "TRB"):
+            for h, q in recs:
+                g.write(">" + chain + h[4:] + q)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
+def test_candidate_store_group_statistics_emulated(tmp_path):
+    """The candidate store where novelMinHitRequired follows the group statistics (SeqSet.hpp:784-823: more than 100 groups of four
+    hits on a strand): 1 100 pairs over 400 clones that all share one constant gene. Restricted re-queries of such entries are merged
+    when the bounds of the statistics certify the threshold, when the exact replay of the statistics loop over the entry's dependency
+    records gives the same one, and -- round 5 -- when it gives a HIGHER one: the candidates chained from runs shorter than the new
+    threshold leave the list (run sizes ride with the candidate records). T4_VERIFY_WINDOW compares every served entry with a fresh
+    whole query; the three files are the reference binary's."""
+    import re
+    fa = str(tmp_path / "shared.fa")
+    _shared_constant_gene_fasta(fa)
+    pre = str(tmp_path / "b")
+    subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, "1100", "400", "6", pre], check=True, stdout=subprocess.DEVNULL)
+    args = ["--skipMateExtension", "-f", fa, "-1", pre + "_1.fq", "-2", pre + "_2.fq"]
+    ref_out, my_out = str(tmp_path / "ref"), str(tmp_path / "mine")
+    subprocess.run([REF_BIN, "-t", "1"] + args + ["-o", ref_out], check=True, stderr=subprocess.DEVNULL)
+    p = subprocess.run([_emulated_driver(), "-t", "8"] + args + ["-o", my_out], check=True, env=dict(os.environ, T4_TIMING="1", T4_VERIFY_WINDOW="1"), stderr=subprocess.PIPE, text=True)
+    for suffix in ("_raw.out", "_assembled_reads.fa", "_final.out"):
+        assert filecmp.cmp(ref_out + suffix, my_out + suffix, shallow=False), suffix
+    log = p.stderr
+    m = re.search(CAND_PAT, log)
+    assert m, log[-1500:]
+    recs, merged, big, stats, recut, fb_uncut, fb_stats, fb_strand, fb_other, checked = (int(x) for x in m.groups())
+    assert merged > 2000 and big > 300 and stats > 300 and checked > 1000, m.groups()
+    x = re.search(r"(\d+) thresholds settled by repeating the statistics loop over the entry's groups, (\d+) raised thresholds served", log)
+    assert x and int(x.group(1)) >= 10 and int(x.group(2)) >= 3, log[-1500:]
+    v = re.search(r"T4_VERIFY_WINDOW: (\d+) served window entries queried again at serve time, all equal to their cached results \((\d+) of them put together", log)
+    assert v and int(v.group(2)) > 500, log[-800:]
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not shipped")
 def test_candidate_store_gpu(tmp_path):
