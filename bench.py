@@ -629,7 +629,9 @@ def main():
     elif world == 1:
         global DRIVER
         DRIVER = os.environ["T4_DRIVER"]
-        args.traffic = args.side_legs = 0
+        args.side_legs = 0
+        if not os.environ.get("T4_BENCH_DRY_TRAFFIC"):   # (set: the PMC legs are walked too -- rocprofv3 fails without a GPU, which is a path of its own)
+            args.traffic = 0
     dist = t4dist.init("gloo" if dry else "nccl")   # RCCL: barrier + max-reduce of the timed interval (the data-path collective of the sharded run is inside the engine)
 
     def sync():
@@ -676,6 +678,23 @@ def main():
             need = c2.get("seconds", 1e9) * (args.steps + args.warmup - 1) * 1.015 + 20
             use_c2 = "seconds" in c2 and args.warmup >= 1 and spent() + need <= args.budget
             c2["workload_decision"] = {"spent_s_before_the_steps": spent(), "needed_s": need, "budget_s": args.budget}
+
+        def pmc_on_small_batch(limit_s):
+            """roofline.traffic when C2 is the workload: the two PMC passes run on the C2 recipe at 100 k pairs (a C2 run under the
+            counters would take a quarter of an hour), plus one plain run of that batch for its rounds and algorithmic bytes"""
+            pf = make_batch(tmp, 100000, 2000, 1)
+            tr, detail = pmc_traffic(pf[0], pf[1], pf[2], threads, local_rank, tmp, limit_s=limit_s)
+            if not tr:
+                return None, detail, None
+            run_stage1(pf[0], pf[1], pf[2], os.path.join(tmp, "pmcb"), threads, local_rank, stats=os.path.join(tmp, "pmcb.json"))
+            return tr, detail, json.load(open(os.path.join(tmp, "pmcb.json")))["add_query"]
+        pmc_early = None
+        if use_c2 and args.traffic and spent() + need + 110 <= args.budget:   # with time to spare the passes come first too: the line has its traffic whatever the steps leave
+            try:
+                pmc_early = pmc_on_small_batch(100.0)
+                c2["workload_decision"]["pmc_passes_before_the_steps_s"] = spent() - c2["workload_decision"]["spent_s_before_the_steps"]
+            except Exception as e:   # noqa: BLE001
+                pmc_early = (None, {"error": repr(e)[:300]}, None)
         pairs = c2["pairs"] if use_c2 else (args.pairs if args.pairs > 0 else args.fallback_pairs)
         clones = args.clones if args.clones > 0 else max(1, pairs // 50)
         if use_c2:
@@ -743,21 +762,24 @@ def main():
                 if c2 and c2_cpu:
                     c2["cpu_baseline"] = c2_cpu
         left = args.budget + 10 - spent()   # what follows is left out when it could run into the driver's limit
-        if args.traffic and left < 150:
+        if args.traffic and pmc_early is None and left < 150:
             out["roofline"]["traffic_detail"] = {"skipped": "%.0f s left of the run's budget: the two PMC passes are in the line of `python bench.py` with its default steps (profiles/)" % left}
         elif args.traffic:
+            aqb = None
             try:
-                pf = (fa, f1, f2) if not use_c2 else make_batch(tmp, 100000, 2000, 1)
-                tr, detail = pmc_traffic(pf[0], pf[1], pf[2], threads, local_rank, tmp, limit_s=max(60.0, left - 40))
+                if pmc_early is not None:
+                    tr, detail, aqb = pmc_early
+                elif use_c2:
+                    tr, detail, aqb = pmc_on_small_batch(max(60.0, left - 50))
+                else:
+                    tr, detail = pmc_traffic(fa, f1, f2, threads, local_rank, tmp, limit_s=max(60.0, left - 40))
             except Exception as e:   # noqa: BLE001
                 tr, detail = None, {"error": repr(e)[:300]}
             out["roofline"]["traffic_detail"] = detail
             if tr and not use_c2:
                 out["roofline"]["traffic"] = tr
                 out["roofline"]["traffic_over_algorithmic"] = tr / roof["algorithmic_bytes_per_step"]
-            elif tr:   # measured on the 100 k-pair batch of the same recipe: per step of THAT batch, next to its own algorithmic bytes
-                run_stage1(pf[0], pf[1], pf[2], os.path.join(tmp, "pmcb"), threads, local_rank, stats=os.path.join(tmp, "pmcb.json"))
-                aqb = json.load(open(os.path.join(tmp, "pmcb.json")))["add_query"]
+            elif tr and aqb:   # measured on the 100 k-pair batch of the same recipe: per step of THAT batch, next to its own algorithmic bytes
                 algb = add_bytes(aqb["reads_queried"], 150, aqb["hits"])
                 out["roofline"]["traffic"] = tr / max(1, aqb["rounds"]) * aq["rounds"]
                 out["roofline"]["traffic_over_algorithmic"] = tr / algb
