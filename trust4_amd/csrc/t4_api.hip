@@ -1380,7 +1380,8 @@ int t4_kmer_count_export(t4_kmer_counter *kc, uint64_t *codes, int32_t *counts, 
   if (cap == 0 || used == 0) return T4_OK;
   int r;
   unsigned long long *dC = nullptr, *dCur = nullptr; int *dV = nullptr;
-  if ((r = devAlloc(c, &dC, (size_t)cap)) || (r = devAlloc(c, &dV, (size_t)cap)) || (r = devAlloc(c, &dCur, (size_t)1))) { if (dC) (void)hipFree(dC); if (dV) (void)hipFree(dV); return r; }
+  struct Free { unsigned long long *&a, *&b; int *&v; ~Free() { if (a) (void)hipFree(a); if (b) (void)hipFree(b); if (v) (void)hipFree(v); } } freeOnReturn{dC, dCur, dV};   // (every path out of here)
+  if ((r = devAlloc(c, &dC, (size_t)cap)) || (r = devAlloc(c, &dV, (size_t)cap)) || (r = devAlloc(c, &dCur, (size_t)1))) return r;
   HIPCHK(c, hipMemsetAsync(dCur, 0, sizeof(unsigned long long), c->stream));
   const unsigned long long blocks = (kc->slots + 255ull) / 256ull;
   const int grid = (int)(blocks < (unsigned long long)c->cus * 16ull ? blocks : (unsigned long long)c->cus * 16ull);
@@ -1394,7 +1395,6 @@ int t4_kmer_count_export(t4_kmer_counter *kc, uint64_t *codes, int32_t *counts, 
     HIPCHK(c, hipMemcpy(codes, dC, sizeof(unsigned long long) * m, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(counts, dV, sizeof(int) * m, hipMemcpyDeviceToHost));
   }
-  (void)hipFree(dC); (void)hipFree(dV); (void)hipFree(dCur);
   if (got != used) return fail(c, T4_ERR_STATE, "t4_kmer_count_export: %llu pairs in a table that counted %llu distinct k-mers", got, used);
   return T4_OK;
 }
@@ -1408,11 +1408,12 @@ int t4_kmer_count_merge(t4_kmer_counter *kc, const uint64_t *codes, const int32_
   const int64_t SLICE = (int64_t)1 << 26;   // pairs per upload (768 MB of device memory at most)
   unsigned long long *dC = nullptr; int *dV = nullptr;
   const size_t cap = (size_t)(n < SLICE ? n : SLICE);
-  if ((r = devAlloc(c, &dC, cap)) || (r = devAlloc(c, &dV, cap))) { if (dC) (void)hipFree(dC); return r; }
+  struct Free { unsigned long long *&a; int *&v; ~Free() { if (a) (void)hipFree(a); if (v) (void)hipFree(v); } } freeOnReturn{dC, dV};   // (every path out of here)
+  if ((r = devAlloc(c, &dC, cap)) || (r = devAlloc(c, &dV, cap))) return r;
   int overflow = 0;
   for (int64_t lo = 0; lo < n && !overflow; lo += SLICE) {
     const int64_t m = n - lo < SLICE ? n - lo : SLICE;
-    if (!only_present && (r = kmerEnsureRoom(kc, (unsigned long long)m))) { (void)hipFree(dC); (void)hipFree(dV); return r; }
+    if (!only_present && (r = kmerEnsureRoom(kc, (unsigned long long)m))) return r;
     HIPCHK(c, hipMemcpy(dC, codes + lo, sizeof(unsigned long long) * (size_t)m, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(dV, counts + lo, sizeof(int) * (size_t)m, hipMemcpyHostToDevice));
     const int grid = (int)((m + 255) / 256 < (long long)c->cus * 8 ? (m + 255) / 256 : (long long)c->cus * 8);
@@ -1421,7 +1422,6 @@ int t4_kmer_count_merge(t4_kmer_counter *kc, const uint64_t *codes, const int32_
     HIPCHK(c, hipMemcpyAsync(&overflow, kc->tb.overflow, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
-  (void)hipFree(dC); (void)hipFree(dV);
   if (overflow) return fail(c, T4_ERR_UNSUPPORTED, "t4_kmer_count_merge: more distinct k-mers than the table was created for (%llu slots)", kc->slots);
   return T4_OK;
 }
