@@ -136,15 +136,15 @@ def test_input_dealt_out_by_cells(tmp_path):
     for tag in "abcde":
         (tmp_path / tag).mkdir()
     dealt = "their pairs alone are processed and counted here"
-    run_engine_merge(tmp_path / "a", exe, 150, 9, 21, 3, env=env, expect_log=dealt)
-    run_engine_merge(tmp_path / "b", exe, 150, 9, 22, 3, env=dict(env, T4_GPU_KMERCOUNT="0"), expect_log="pairs of this rank's table went to the other ranks")
-    run_engine_merge(tmp_path / "c", exe, 60, 3, 23, 5, env={"HIPEMU_THREADS": "1"}, expect_log=dealt)
-    run_engine_merge(tmp_path / "d", exe, 150, 9, 21, 3, env=dict(env, T4_SHARD_INPUT="0"), expect_log="are this rank's (")
-    run_engine_merge(tmp_path / "e", exe, 150, 9, 24, 2, env=env, common=["--contigMinCov", "8"], expect_log=dealt)
+    run_engine_merge(tmp_path / "a", exe, 120, 7, 21, 3, env=env, expect_log=dealt)
+    run_engine_merge(tmp_path / "b", exe, 100, 6, 22, 3, env=dict(env, T4_GPU_KMERCOUNT="0"), expect_log="pairs of this rank's table went to the other ranks")
+    run_engine_merge(tmp_path / "c", exe, 50, 3, 23, 5, env={"HIPEMU_THREADS": "1"}, expect_log=dealt)
+    run_engine_merge(tmp_path / "d", exe, 100, 6, 21, 2, env=dict(env, T4_SHARD_INPUT="0"), expect_log="are this rank's (")
+    run_engine_merge(tmp_path / "e", exe, 120, 7, 24, 2, env=env, common=["--contigMinCov", "8"], expect_log=dealt)
     # negative control: without the other ranks' counts the files differ (the comparison above does see the counts)
     (tmp_path / "f").mkdir()
     with pytest.raises(AssertionError, match="_assembled_reads.fa|_raw.out"):
-        run_engine_merge(tmp_path / "f", exe, 150, 9, 21, 3, env=dict(env, T4_TEST_NO_COUNT_MERGE="1"))
+        run_engine_merge(tmp_path / "f", exe, 120, 7, 21, 3, env=dict(env, T4_TEST_NO_COUNT_MERGE="1"))
 
 
 def test_early_shard_paths(tmp_path):
@@ -346,7 +346,7 @@ def _bench_single_dry_run(tmp_path, extra):
     env = dict(os.environ, T4_BENCH_CPU_DRYRUN="1", T4_DRIVER=_emulated_driver(), T4_BENCH_C2_STANDIN="c2micro", HIPEMU_THREADS="4", TMPDIR=str(tmp_path))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-c2-pairs", "200", "--cpu-single-pairs", "50"] + extra,
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--cpu-c2-pairs", "200", "--cpu-single-pairs", "50"] + extra,
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
     assert p.returncode == 0, p.stderr[-800:]
     return json.loads([x for x in p.stdout.strip().split("\n") if x.startswith("{")][-1])
@@ -360,14 +360,14 @@ def test_bench_single_gpu_workload_choice_dry_run(tmp_path):
     if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "trust4")):
         pytest.skip("oracle/_ref/trust4 not built")
     line = _bench_single_dry_run(tmp_path, [])
-    assert line["steps"] == 2 and line["warmup"] == 1 and line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] is None
+    assert line["steps"] == 1 and line["warmup"] == 1 and line["n_gpus"] == 1 and line["value"] > 0 and line["scaling"] is None
     assert line["config"]["pairs_per_step"] == 400 and line["config"]["is_baseline_config_c2"] is False and "stand-in c2micro" in line["config"]["workload"]
     assert line["cpu_baseline"]["kind"] == "reference" and line["cpu_baseline"]["value"] > 0 and "first 200 pairs" in line["cpu_baseline"]["sample"]
     assert line["c2"]["workload_decision"]["budget_s"] == 1770 and line["c2"]["workload_decision"]["spent_s_before_the_steps"] > 0
     assert "steps_cut_short" not in line and line["roofline"]["traffic"] is None
     # the whole run may take 1 s: "C2" cannot be the workload
     line = _bench_single_dry_run(tmp_path, ["--budget", "1", "--fallback-pairs", "300"])
-    assert line["steps"] == 2 and line["config"]["pairs_per_step"] == 300 and line["config"]["is_baseline_config_c2"] is False
+    assert line["steps"] == 1 and line["config"]["pairs_per_step"] == 300 and line["config"]["is_baseline_config_c2"] is False
     assert "do not fit the budget" in line["config"]["workload"]
     assert line["parity_on_bench_batch"] is True and line["cpu_baseline"]["value"] > 0 and "whole batch" in line["cpu_baseline"]["sample"]
     assert line["c2"]["pairs"] == 400 and line["c2"]["cpu_baseline"]["value"] > 0

@@ -573,7 +573,7 @@ def _shared_constant_gene_fasta(path):
 @pytest.mark.skipif(not os.path.exists(REF_BIN), reason="oracle/_ref/trust4 not built")
 def test_candidate_store_group_statistics_emulated(tmp_path):
     """The candidate store where novelMinHitRequired follows the group statistics (SeqSet.hpp:784-823: more than 100 groups of four
-    hits on a strand): 1 100 pairs over 400 clones that all share one constant gene. Restricted re-queries of such entries are merged
+    hits on a strand): 700 pairs over 350 clones that all share one constant gene. Restricted re-queries of such entries are merged
     when the bounds of the statistics certify the threshold, when the exact replay of the statistics loop over the entry's dependency
     records gives the same one, and -- round 5 -- when it gives a HIGHER one: the candidates chained from runs shorter than the new
     threshold leave the list (run sizes ride with the candidate records). T4_VERIFY_WINDOW compares every served entry with a fresh
@@ -582,7 +582,7 @@ def test_candidate_store_group_statistics_emulated(tmp_path):
     fa = str(tmp_path / "shared.fa")
     _shared_constant_gene_fasta(fa)
     pre = str(tmp_path / "b")
-    subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, "1100", "400", "6", pre], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, "700", "350", "7", pre], check=True, stdout=subprocess.DEVNULL)
     args = ["--skipMateExtension", "-f", fa, "-1", pre + "_1.fq", "-2", pre + "_2.fq"]
     ref_out, my_out = str(tmp_path / "ref"), str(tmp_path / "mine")
     subprocess.run([REF_BIN, "-t", "1"] + args + ["-o", ref_out], check=True, stderr=subprocess.DEVNULL)
@@ -593,11 +593,11 @@ def test_candidate_store_group_statistics_emulated(tmp_path):
     m = re.search(CAND_PAT, log)
     assert m, log[-1500:]
     recs, merged, big, stats, recut, fb_uncut, fb_stats, fb_strand, fb_other, checked = (int(x) for x in m.groups())
-    assert merged > 2000 and big > 300 and stats > 300 and checked > 1000, m.groups()
+    assert merged > 1500 and big > 300 and stats > 80 and checked > 600, m.groups()
     x = re.search(r"(\d+) thresholds settled by repeating the statistics loop over the entry's groups, (\d+) raised thresholds served", log)
-    assert x and int(x.group(1)) >= 10 and int(x.group(2)) >= 3, log[-1500:]
+    assert x and int(x.group(1)) >= 5 and int(x.group(2)) >= 2, log[-1500:]
     v = re.search(r"T4_VERIFY_WINDOW: (\d+) served window entries queried again at serve time, all equal to their cached results \((\d+) of them put together", log)
-    assert v and int(v.group(2)) > 500, log[-800:]
+    assert v and int(v.group(2)) > 400, log[-800:]
 
 
 @pytest.mark.gpu
