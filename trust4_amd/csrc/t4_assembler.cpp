@@ -2039,7 +2039,10 @@ void t4_assembler::replayScan(const std::vector<t4_cand> &cands, const std::vect
 
 // A restricted re-query of contig pc came back for an entry that holds its candidate list: nc[0 .. ncnt) are ALL overlaps of the read
 // with pc (scored; ov / ex / rets are their result records, same order), s8 the true sizes of pc's two hit groups. Returns false
-// when the entry needs its whole query again.
+// when the entry needs its whole query again. Three things are settled here, in this order: the threshold novelMinHitRequired under
+// the new group sizes (certified by bounds, or the statistics loop repeated exactly; equal to the entry's or HIGHER -- a lower one
+// falls back), the candidate list (pc's candidates swapped, candidates of runs shorter than a raised threshold dropped), and the
+// scan of the pre-filters over the new list (replayScan).
 bool t4_assembler::mergeRestricted(Cached &c, int pc, int k2, const t4_overlap *ov, const t4_overlap *ex, const int32_t *rets, const t4_cand *nc, int ncnt, const int32_t *s8) {
   const int len = (int)c.read.size();
   for (int t = 0; t < ncnt; ++t) if (((nc[t].flags & 1) != 0) != c.strand0Plus) { ++candFallbackStrand; return false; }   // an overlap on the other strand: which strand is the best one's is open again
