@@ -10,7 +10,7 @@ threshold follows the group statistics, exact replays, raised thresholds). Every
     python tests/stress/candidate_store_stress.py SEED RUNS        # random sizes / seeds / policy switches
     python tests/stress/candidate_store_stress.py one PAIRS CLONES SEED [NAME=VALUE ...]
 
-Round 5: 16 + 40 runs, all identical."""
+Round 5: 16 + 40 + 30 runs, all identical."""
 import filecmp
 import os
 import random

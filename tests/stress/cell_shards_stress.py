@@ -6,7 +6,7 @@ against one process, byte for byte (tests/test_dist_gloo.py::run_engine_merge).
 
     python tests/stress/cell_shards_stress.py SEED RUNS
 
-Round 5: 40 runs, all identical."""
+Round 5: 40 + 60 runs, all identical."""
 import os
 import pathlib
 import random
