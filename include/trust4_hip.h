@@ -377,7 +377,9 @@ int64_t t4_kmer_count_distinct(t4_kmer_counter *kc);
  * whole sample) counts its reads, hands the other ranks its pairs and adds theirs. export: the table's (k-mer, count) pairs in any
  * order -- *n = how many there are; with cap == 0 nothing else happens, else the first min(*n, cap) pairs are written. merge:
  * count[codes[i]] += counts[i]; only_present != 0 passes over the pairs whose k-mer the table does not hold (the statistics of a
- * rank's reads look up those reads' k-mers only). Keys of a per-barcode counter travel as the table holds them (barcode included). */
+ * rank's reads look up those reads' k-mers only). Keys of a per-barcode counter travel as the table holds them (barcode included).
+ * With only_present == 0 the table grows beyond what max_kmers of t4_kmer_count_create stood for when the other set's k-mers need the
+ * room (device memory permitting); on an error the pairs of the slices before the failing one have been added. */
 int t4_kmer_count_export(t4_kmer_counter *kc, uint64_t *codes, int32_t *counts, int64_t cap, int64_t *n);
 int t4_kmer_count_merge(t4_kmer_counter *kc, const uint64_t *codes, const int32_t *counts, int64_t n, int only_present);
 

@@ -133,6 +133,7 @@ template <class T> static inline T atomicCAS(T *p, T cmp, T v) { __atomic_compar
 template <class T> static inline T atomicExch(T *p, T v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline void __threadfence_block() {}
+static inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 
 // ---- host API
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
@@ -153,6 +154,7 @@ static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = 0; return hipSuc
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = 0; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipPeekAtLastError() { return hipSuccess; }

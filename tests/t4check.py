@@ -17,7 +17,7 @@ def build_emulator_lib():
     deps += [os.path.join(ROOT, "tests", "hipemu", "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "trust4_hip.h")]
     if os.path.exists(EMU_LIB) and all(os.path.getmtime(EMU_LIB) >= os.path.getmtime(d) for d in deps):
         return EMU_LIB
-    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-I",
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-DT4_TEST_KNOBS", "-ffp-contract=off", "-fPIC", "-shared", "-I",
                     os.path.join(ROOT, "tests", "hipemu"), "-o", EMU_LIB, "-x", "c++"] + units + ["-lz", "-lpthread"], check=True)
     return EMU_LIB
 

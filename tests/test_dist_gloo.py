@@ -310,6 +310,38 @@ def test_bench_gpus2_plumbing_dry_run(tmp_path):
     assert len(per["own_cells_before_the_add_pass"]) == 2 and min(per["own_cells_before_the_add_pass"]) > 0   # (the early shard: a mark of its own in the stats)
 
 
+def test_bench_gpus8_plumbing_dry_run(tmp_path):
+    """`bench.py --gpus 8` as the driver will launch it on the first 8-GPU node, without GPUs: eight ranks over gloo, the
+    emulated driver, FIVE cells of uneven sizes for eight ranks -- so some ranks own no cell at all and the others own one or two --, the
+    engine's agreed fall-back from RCCL to the file transport on every rank, and the line a first SCALE record will be read from:
+    `config.per_rank_s` with eight entries per phase, `one_rank.identical` and `one_rank.speedup_of_the_sharded_run`."""
+    import json
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_stage1_e2e import _emulated_driver
+    exe = _emulated_driver()
+    port = 29950 + (os.getpid() % 40)
+    procs = []
+    for r in range(8):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   T4_BENCH_CPU_DRYRUN="1", T4_DRIVER=exe, HIPEMU_THREADS="1", OMP_NUM_THREADS="1", TMPDIR=str(tmp_path))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--cells-pairs", "15", "--cells-total", "5",
+                                       "--cells-threads", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=1500) for p in procs]
+    assert [p.returncode for p in procs] == [0] * 8, [o[1][-400:] for o in outs]
+    line = json.loads([x for x in outs[0][0].strip().split("\n") if x.startswith("{")][-1])
+    for r in range(1, 8):
+        assert not [x for x in outs[r][0].split("\n") if x.startswith("{")]          # rank 0 alone prints the line
+    assert line["n_gpus"] == 8 and line["steps"] == 1 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["pairs"] == 120 and line["config"]["cells"] == 5
+    assert line["one_rank"]["identical"] is True and line["one_rank"]["speedup_of_the_sharded_run"] > 0
+    assert line["config"]["transport"].startswith("files (fallback from RCCL: rank 0: fail"), line["config"]["transport"]
+    per = line["config"]["per_rank_s"]
+    for key in ("replicated_phases", "own_cells_before_the_add_pass", "add_pass_of_its_cells"):
+        assert len(per[key]) == 8, key
+    assert min(per["replicated_phases"]) > 0
+
+
 def test_two_rank_barcode_stage1(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_stage1_e2e import _emulated_driver

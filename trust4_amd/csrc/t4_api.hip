@@ -106,7 +106,11 @@ struct t4_ctx {
   // lean path of t4_add_query (small batches, one launch, one round trip)
   int aqCap = 0, aqWpk = 0, aqWnm = 0, aqMax = 0;
   unsigned char *aqIn = nullptr, *aqOut = nullptr;      // device blobs
-  unsigned char *aqInHost = nullptr, *aqOutHost = nullptr;   // pinned staging
+  unsigned char *aqInHost = nullptr, *aqOutHost = nullptr;   // pinned staging, mapped: aqPrologueKernel reads the one, aqEpilogueKernel writes the other
+  unsigned char *aqInHostDev = nullptr, *aqOutHostDev = nullptr;   // their device addresses
+  unsigned *aqFlagHost = nullptr, *aqFlagDev = nullptr;   // pinned word the epilogue of a call leaves the call's sequence number in: what the host waits for
+  unsigned *aqDoneCtr = nullptr;   // device: blocks of a running epilogue that have written their share
+  unsigned aqSeq = 0;
   size_t aqInBytes = 0, aqOutBytes = 0;
   unsigned char *aqPool = nullptr, *aqPoolDev = nullptr;   // result records of t4_add_query*: pinned host memory the kernels write
   int aqPoolCap = 0;
@@ -173,7 +177,7 @@ struct t4_index {
   T4HashEntC *dCtab = nullptr;
   int64_t capTable = 0, capPost = 0, capBase = 0;
   int capSeq = 0, liveNseq = 0;
-  unsigned char *stHost = nullptr, *stDev = nullptr;
+  unsigned char *stHost = nullptr, *stDev = nullptr, *stHostDev = nullptr;   // (stHostDev: the pinned staging buffer as the device addresses it)
   size_t stCap = 0;
   hipEvent_t stEvent = 0;
   bool stPending = false;
@@ -347,6 +351,9 @@ int t4_init(int device_ordinal, t4_ctx **out) {
   for (int i = 0; i < 4; ++i) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return T4_ERR_HIP; }
   memset(&c->stats, 0, sizeof c->stats);
   if (hipMalloc(&c->listCounts, sizeof(int) * 16) != hipSuccess || hipMalloc(&c->hitCounter, sizeof(unsigned long long)) != hipSuccess) { delete c; return T4_ERR_HIP; }
+  if (hipHostMalloc(&c->aqFlagHost, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void **)&c->aqFlagDev, c->aqFlagHost, 0) != hipSuccess ||
+      hipMalloc(&c->aqDoneCtr, sizeof(unsigned)) != hipSuccess || hipMemset(c->aqDoneCtr, 0, sizeof(unsigned)) != hipSuccess) { delete c; return T4_ERR_HIP; }
+  *c->aqFlagHost = 0;
   *out = c;
   return T4_OK;
 }
@@ -384,6 +391,8 @@ void t4_destroy(t4_ctx *c) {
                   c->listCounts, c->status, c->counts, c->hitCounter, c->result, c->aqIn, c->aqOut};
   if (c->aqInHost) (void)hipHostFree(c->aqInHost);
   if (c->aqOutHost) (void)hipHostFree(c->aqOutHost);
+  if (c->aqFlagHost) (void)hipHostFree(c->aqFlagHost);
+  if (c->aqDoneCtr) (void)hipFree(c->aqDoneCtr);
   if (c->aqPool) (void)hipHostFree(c->aqPool);
   if (c->candPool) (void)hipHostFree(c->candPool);
   if (c->aqRecDev) (void)hipFree(c->aqRecDev);
@@ -764,7 +773,8 @@ int t4_index_apply_delta(t4_index *ix, const t4_index_delta *d) {
       if (ix->stDev) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(ix->stDev); }
       ix->stHost = nullptr; ix->stDev = nullptr;
       ix->stCap = bytes * 2 > ((size_t)1 << 20) ? bytes * 2 : ((size_t)1 << 20);
-      HIPCHK(c, hipHostMalloc(&ix->stHost, ix->stCap, hipHostMallocDefault));
+      HIPCHK(c, hipHostMalloc(&ix->stHost, ix->stCap, hipHostMallocMapped));
+      HIPCHK(c, hipHostGetDevicePointer((void **)&ix->stHostDev, ix->stHost, 0));
       HIPCHK(c, hipMalloc(&ix->stDev, ix->stCap));
     }
     T4CopyDesc *desc = (T4CopyDesc *)ix->stHost;
@@ -812,11 +822,16 @@ int t4_index_apply_delta(t4_index *ix, const t4_index_delta *d) {
       at += al8(b);
       bAt += d->base_len[i];
     }
-    HIPCHK(c, hipMemcpyAsync(ix->stDev, ix->stHost, at, hipMemcpyHostToDevice, c->stream));
+    // A round's delta is a few kilobytes: the kernel reads descriptors and payload straight out of the pinned staging buffer (one
+    // stream operation; an H2D copy in front of it was a hop to a copy engine and back on the ordered chain's critical path). The
+    // whole image of a fresh set, or a rebuilt table, goes through the copy engine as before.
+    const bool direct = at <= ((size_t)1 << 18);
+    if (!direct) HIPCHK(c, hipMemcpyAsync(ix->stDev, ix->stHost, at, hipMemcpyHostToDevice, c->stream));
     ix->stPending = true; ix->stEpoch = c->syncEpoch;
     int grid = (int)((nd + 3) / 4);
     if (grid > c->cus * 8) grid = c->cus * 8;
-    hipLaunchKernelGGL(t4k::deltaKernel, dim3(grid), dim3(256), 0, c->stream, (const unsigned char *)ix->stDev, (const T4CopyDesc *)ix->stDev, (int)nd);
+    const unsigned char *stg = direct ? ix->stHostDev : ix->stDev;
+    hipLaunchKernelGGL(t4k::deltaKernel, dim3(grid), dim3(256), 0, c->stream, stg, (const T4CopyDesc *)stg, (int)nd);
     HIPCHK(c, hipGetLastError());
   }
 view:
@@ -1248,11 +1263,14 @@ int kmerTableAlloc(t4_ctx *c, unsigned long long slots, T4KmerTable &tb) {
 }
 // Room for `incoming` more k-mers at a load of at most 0.6: the table is rehashed on the device into one four times as large as
 // often as that takes (never beyond the size the caller's max_kmers stands for: then the old behaviour -- a full table fails).
-int kmerEnsureRoom(t4_kmer_counter *kc, unsigned long long incoming) {
+// raiseMax: the incoming k-mers are another read set's (t4_kmer_count_merge without only_present), which the caller's max_kmers at
+// create time knew nothing of -- the ceiling moves so that what is there plus what comes fits.
+int kmerEnsureRoom(t4_kmer_counter *kc, unsigned long long incoming, bool raiseMax = false) {
   t4_ctx *c = kc->ctx;
   unsigned long long used = 0;
   HIPCHK(c, hipMemcpyAsync(&used, kc->tb.used, sizeof used, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (raiseMax) while ((used + incoming) * 10ull > kc->maxSlots * 6ull && kc->maxSlots < (1ull << 40)) kc->maxSlots <<= 1;
   while (kc->slots < kc->maxSlots && (used + incoming) * 10ull > kc->slots * 6ull) {
     unsigned long long ns = kc->slots * 4ull;
     if (ns > kc->maxSlots) ns = kc->maxSlots;
@@ -1282,7 +1300,9 @@ int t4_kmer_count_create(t4_ctx *c, int k, int64_t max_kmers, int per_barcode, t
   // 12 GB for a million pairs. It starts at an eighth of that (at least 4 M slots) and grows as it fills.
   unsigned long long slots = maxSlots / 8ull;
   if (slots < (1ull << 22)) slots = (1ull << 22) < maxSlots ? (1ull << 22) : maxSlots;
+#ifdef T4_TEST_KNOBS   // (emulator / test builds only)
   if (getenv("T4_KC_SLOTS")) { slots = 1024; const unsigned long long want = strtoull(getenv("T4_KC_SLOTS"), nullptr, 10); while (slots < want && slots < maxSlots) slots <<= 1; }   // testing aid: a small first table (the growth path)
+#endif
   t4_kmer_counter *kc = new t4_kmer_counter;
   kc->ctx = c; kc->slots = slots; kc->maxSlots = maxSlots;
   kc->tb.k = k; kc->tb.perBarcode = per_barcode ? 1 : 0;
@@ -1413,7 +1433,7 @@ int t4_kmer_count_merge(t4_kmer_counter *kc, const uint64_t *codes, const int32_
   int overflow = 0;
   for (int64_t lo = 0; lo < n && !overflow; lo += SLICE) {
     const int64_t m = n - lo < SLICE ? n - lo : SLICE;
-    if (!only_present && (r = kmerEnsureRoom(kc, (unsigned long long)m))) return r;
+    if (!only_present && (r = kmerEnsureRoom(kc, (unsigned long long)m, true))) return r;
     HIPCHK(c, hipMemcpy(dC, codes + lo, sizeof(unsigned long long) * (size_t)m, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(dV, counts + lo, sizeof(int) * (size_t)m, hipMemcpyHostToDevice));
     const int grid = (int)((m + 255) / 256 < (long long)c->cus * 8 ? (m + 255) / 256 : (long long)c->cus * 8);
@@ -1691,7 +1711,8 @@ int aqBegin(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const 
     if (c->aqInHost) (void)hipHostFree(c->aqInHost);
     c->aqIn = nullptr; c->aqInHost = nullptr;
     HIPCHK(c, hipMalloc(&c->aqIn, q.inBytes * 2));
-    HIPCHK(c, hipHostMalloc(&c->aqInHost, q.inBytes * 2, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc(&c->aqInHost, q.inBytes * 2, hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer((void **)&c->aqInHostDev, c->aqInHost, 0));
     c->aqInBytes = q.inBytes * 2;
   }
   if (q.outBytes > c->aqOutBytes) {
@@ -1699,7 +1720,8 @@ int aqBegin(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const 
     if (c->aqOutHost) (void)hipHostFree(c->aqOutHost);
     c->aqOut = nullptr; c->aqOutHost = nullptr;
     HIPCHK(c, hipMalloc(&c->aqOut, q.outBytes * 2));
-    HIPCHK(c, hipHostMalloc(&c->aqOutHost, q.outBytes * 2, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc(&c->aqOutHost, q.outBytes * 2, hipHostMallocMapped));
+    HIPCHK(c, hipHostGetDevicePointer((void **)&c->aqOutHostDev, c->aqOutHost, 0));
     c->aqOutBytes = q.outBytes * 2;
   }
   auto tNow = [] { return std::chrono::steady_clock::now(); };
@@ -1797,8 +1819,16 @@ int aqLaunch(t4_ctx *c) {
     }
     memcpy(c->aqInHost + q.oCs, &cs, sizeof cs);
   }
-  HIPCHK(c, hipMemcpyAsync(c->aqIn, c->aqInHost, q.inBytes, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(c->aqOut, 0, q.outBytes, c->stream));   // counts, status, overflow lists, bases, tail
+  {   // input blob into device memory, header block zeroed (counts, status, overflow lists, bases, tail): one kernel, no copy engine (t4_kernels.h: aqPrologueKernel)
+    const unsigned long long inW = q.inBytes >> 3, outW = q.outBytes >> 3;
+    const unsigned long long most = inW > outW ? inW : outW;
+    int grid = (int)((most + 2047) / 2048);
+    if (grid < 1) grid = 1;
+    if (grid > c->cus * 4) grid = c->cus * 4;
+    hipLaunchKernelGGL(t4k::aqPrologueKernel, dim3(grid), dim3(256), 0, c->stream, (const unsigned long long *)c->aqInHostDev, (unsigned long long *)c->aqIn, inW,
+                       (unsigned long long *)c->aqOut, outW);
+    HIPCHK(c, hipGetLastError());
+  }
   T4BatchView &bv = q.bv;
   bv.pk = (const unsigned *)(c->aqIn + q.oPk); bv.nm = (const unsigned *)(c->aqIn + q.oNm); bv.len = (const int *)(c->aqIn + q.oLen);
   bv.barcode = (const int *)(c->aqIn + q.oBc); bv.wpk = q.wpk; bv.wnm = q.wnm; bv.n = n;
@@ -1916,16 +1946,42 @@ int aqLaunch(t4_ctx *c) {
     HIPCHK(c, hipGetLastError());
   }
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->aqOutHost, c->aqOut, q.outBytes, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipEventRecord(c->ev[3], c->stream));   // the call's results are on the host once this event has passed
+  {   // the header block into pinned host memory, then the call's sequence number into the word the host polls (aqEpilogueKernel)
+    const unsigned long long outW = q.outBytes >> 3;
+    int grid = (int)((outW + 4095) / 4096);
+    if (grid < 1) grid = 1;
+    if (grid > 64) grid = 64;
+    ++c->aqSeq;
+    if (c->aqSeq == 0) c->aqSeq = 1;
+    hipLaunchKernelGGL(t4k::aqEpilogueKernel, dim3(grid), dim3(256), 0, c->stream, (const unsigned long long *)c->aqOut, (unsigned long long *)c->aqOutHostDev, outW,
+                       c->aqDoneCtr, c->aqFlagDev, c->aqSeq);
+    HIPCHK(c, hipGetLastError());
+  }
   return T4_OK;
+}
+
+// The call's results are on the host once the epilogue's word holds the call's number. The caller sits on the ordered chain's critical
+// path: it polls (a blocking wait wakes up tens of microseconds after the kernels are done; a round is a few hundred). Every 2^16 polls
+// -- a fraction of a millisecond -- the stream itself is asked, so that a kernel that died is an error and not a wait without end.
+int aqWait(t4_ctx *c) {
+  const unsigned want = c->aqSeq;
+  for (unsigned long long spin = 1;; ++spin) {
+    if (__atomic_load_n(c->aqFlagHost, __ATOMIC_ACQUIRE) == want) return T4_OK;
+    if ((spin & 0xFFFFull) == 0) {
+      const hipError_t e = hipStreamQuery(c->stream);
+      if (e == hipSuccess) {
+        if (__atomic_load_n(c->aqFlagHost, __ATOMIC_ACQUIRE) == want) return T4_OK;
+        return fail(c, T4_ERR_HIP, "the stream of an AddRead query call is idle but its epilogue never reported (word %u, expected %u)", *c->aqFlagHost, want);
+      }
+      if (e != hipErrorNotReady) return fail(c, T4_ERR_HIP, "AddRead query call: %s", hipGetErrorString(e));
+    }
+  }
 }
 
 // has the call in flight finished on the device? (1 yes or nothing in flight, 0 not yet)
 int aqDone(t4_ctx *c) {
   if (!c->aq.active) return 1;
-  (void)hipSetDevice(c->device);
-  return hipEventQuery(c->ev[3]) == hipSuccess ? 1 : 0;
+  return __atomic_load_n(c->aqFlagHost, __ATOMIC_ACQUIRE) == c->aqSeq ? 1 : 0;
 }
 
 int aqEnd(t4_ctx *c, AqResult *res) {
@@ -1945,10 +2001,17 @@ int aqEnd(t4_ctx *c, AqResult *res) {
   for (;;) {
     // The caller sits on the ordered chain's critical path: poll for the round's last event before the blocking wait (a wait that
     // sleeps wakes up tens of microseconds after the kernels are done; a round is a few hundred)
-    for (int spin = 0; spin < 200000 && hipEventQuery(c->ev[3]) == hipErrorNotReady; ++spin) { }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((r = aqWait(c))) return r;
+    // (everything queued on the stream before the epilogue is done: what a wait for the stream said before. The runtime is told now and
+    // then too, so that it retires what it keeps per command.)
+    if ((c->aqSeq & 255u) == 0) HIPCHK(c, hipStreamSynchronize(c->stream));
     ++c->syncEpoch;
-    { float ms = 0; if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) { c->aqKernelMs += ms; c->aqLastMs = ms; } }
+    {
+      float ms = 0;
+      hipError_t ee = hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
+      if (ee == hipErrorNotReady) { (void)hipEventSynchronize(c->ev[1]); ee = hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); }
+      if (ee == hipSuccess) { c->aqKernelMs += ms; c->aqLastMs = ms; }
+    }
     int overflow = *(int *)(c->aqOutHost + pTail);
     { const int inKernel = *(int *)(c->aqOutHost + pTail + 8); if (!smallFirst && inKernel > 0) { c->aqGlobalReads += inKernel; ++c->aqGlobalLaunches; } }
     c->aqSecFirst += tSince(q.tf0);

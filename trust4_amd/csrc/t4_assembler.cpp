@@ -472,8 +472,30 @@ struct HelperPool {
   void wait() { std::unique_lock<std::mutex> lk(mu); cvDone.wait(lk, [&] { return running == 0; }); }
 };
 
+// Where the one host thread of the ordered chain spends its time (T4_TIMING): time-stamp counter sections, a few nanoseconds each
+#if defined(__x86_64__)
+#include <x86intrin.h>
+static inline uint64_t t4Tick() { return __rdtsc(); }
+#else
+static inline uint64_t t4Tick() { return (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count(); }
+#endif
+enum { TS_ADD_SERVE, TS_ADD_CANDS, TS_ADD_DECIDE, TS_ADD_MERGE, TS_ADD_EXTEND, TS_ADD_BUMP, TS_REPEAT, TS_NOVEL, TS_EVENTS_STRUCT, TS_EVENTS_INDEX, TS_HARVEST_WAIT, TS_HARVEST_COPY,
+       TS_HARVEST_MERGE, TS_ANNOUNCE, TS_PUMP_OTHER, TS_LAUNCH_PACK, TS_LAUNCH_CALL, TS_UPDATE_CONS, TS_DELTA, TS_LAUNCH_GROUPS, TS_N };
+static const char *const TS_NAMES[TS_N] = {"addRead: serving the entry", "addRead: candidate list", "addRead: decision loops", "addRead: contig merge", "addRead: extension", "addRead: weights + N fill",
+                                           "RepeatAddRead", "InputNovelRead", "events: structural", "events: index", "harvest: waiting for the device", "harvest: whole-query records",
+                                           "harvest: restricted merges", "announcement", "pump: choosing what to launch", "launch: packing the items", "launch: the query call", "UpdateAllConsensus", "launch: delta", "launch: dependency sets beside the kernels"};
+struct TscSections {
+  uint64_t acc[TS_N] = {}, t0 = 0, tStart = 0;
+  std::chrono::steady_clock::time_point wall0 = std::chrono::steady_clock::now();
+  TscSections() { tStart = t4Tick(); }
+  void begin() { t0 = t4Tick(); }
+  void lap(int sec) { const uint64_t t = t4Tick(); acc[sec] += t - t0; t0 = t; }
+  double secondsPerTick() const { const double w = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count(); const uint64_t d = t4Tick() - tStart; return d ? w / (double)d : 0; }
+};
+
 struct t4_cellset;
 struct t4_assembler : IndexListener {
+  TscSections ts;
   t4_ctx *ctx;
   t4_index *dev = nullptr;   // device image of the current set
   t4_cellset *owner = nullptr;   // cell of a per-barcode set: the image lives in the owner's arena slot
@@ -948,6 +970,7 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
   std::vector<int32_t> extRet;
   int32_t cnt = 0;
   if (live()) {
+    ts.lap(TS_ADD_SERVE);
     processEvents();   // a release_* call or UpdateAllConsensus may have changed the set since the last commit was examined
     auto lines = [&](const Cached &c) { return c.read == read && c.strand == *strandIO && c.barcode == barcode && c.skip == (repetitiveData ? 1 : 0); };
     if (!order.empty() && lines(*pool[order.front()])) {
@@ -966,6 +989,7 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
     order.pop_front();
     c.valid = false; c.partial = false; c.uid = 0; freeSlots.push_back(sl);   // its winKmers references are stale from here on
     if (c.registered) { --winKmerLive; c.registered = false; }
+    ts.lap(TS_ADD_SERVE);
   } else {
     bool served = false;
     if (cacheHead < cache.size()) {
@@ -1029,6 +1053,7 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
   int readInConsensusOffset = 0, seqIdx = -1;
   bool addNew = true;
   int i, j;
+  ts.lap(TS_ADD_CANDS);
 
   auto clen = [&](int s) { return (int)seqs[s].cons.size(); };
   for (i = 0; i < overlapCnt; ++i) {
@@ -1125,6 +1150,7 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
     if (dup) ne = 0;
   }
 
+  ts.lap(TS_ADD_DECIDE);
   if (ne > 1) {
     // ---- merge contigs through the read (SeqSet.hpp:3878-4130)
     const int eCnt = ne;
@@ -1190,6 +1216,7 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
     readInConsensusOffset = ext[0].seqStart > 0 ? ext[0].seqStart : 0;
     seqIdx = newSeqIdx;
     for (i = 0; i < eCnt; ++i) structuralChange(ext[i].seqIdx);
+    ts.lap(TS_ADD_MERGE);
   } else if (ne == 1) {
     // ---- extend one contig, or place the read inside it (SeqSet.hpp:4131-4316)
     addNew = false;
@@ -1251,6 +1278,7 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
       structuralChange(seqIdx, true);
       for (auto &p : replacement) substituteConsensusPos(seqIdx, p.first, (char)p.second);
     } else readInConsensusOffset = ext[0].seqStart;
+    ts.lap(TS_ADD_EXTEND);
   }
 
   if (!addNew) {
@@ -1277,6 +1305,7 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
     }
     ret = seqIdx;
     seq.pwTouched = true;   // (extension / merge / placement: counts or consensus of this contig changed)
+    ts.lap(TS_ADD_BUMP);
   }
   // a set of novel contigs has no reference sequence to anchor a new contig on (SeqSet.hpp:4373-4384)
   if (ret == -1) { setPrev(-2, -1, -1, -1, -1, 0); ret = -2; }
@@ -1768,6 +1797,7 @@ void t4_assembler::processEvents() {
     }
   }
   structEvents.clear();
+  ts.lap(TS_EVENTS_STRUCT);
   // index events: net effect per (key, posting)
   if (!idxEvents.empty()) {
     bool ins = false, rem = false;
@@ -1849,6 +1879,7 @@ void t4_assembler::processEvents() {
       }
     }
     idxEvents.clear();
+    ts.lap(TS_EVENTS_INDEX);
   }
 }
 
@@ -1892,9 +1923,11 @@ int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive
   auto tl0_ = std::chrono::steady_clock::now();
   struct Tl { double &acc; std::chrono::steady_clock::time_point t0; ~Tl() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tl_{secLaunch, tl0_};
   int rc;
+  ts.lap(TS_PUMP_OTHER);
   if ((rc = makeDelta())) return rc;
   { auto t0 = std::chrono::steady_clock::now(); rc = bringUpToDate(L); secDelta += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); if (rc) return rc; }
   const int m = (int)todo.size();
+  ts.lap(TS_DELTA);
   wideQueries = knobs.wideQueries; wideHitLimit = knobs.wideHitLimit;   // what t4_add_query_pool_begin does with a heavy read under the testing aids of csrc/t4_api.hip
   // one item per whole query, one per contig a partial entry waits for (the items of an entry are adjacent)
   L.slots.clear(); L.uids.clear(); L.hint.clear(); L.bcs.clear(); L.sts.clear(); L.fac.clear(); L.only.clear(); L.force.clear();
@@ -1923,6 +1956,7 @@ int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive
   { int nOnly = 0; for (int v : L.only) nOnly += v >= 0 ? 1 : 0; restrictedQueries += nOnly; wholeQueries += mi - nOnly; if (nOnly == mi) ++restrictedOnlyRounds; }
   laneT0 = tl0_;
   if (L.bases.empty()) L.bases.push_back('A');
+  ts.lap(TS_LAUNCH_PACK);
   {
     auto tq0 = std::chrono::steady_clock::now();
     candStore = knobs.candStore;
@@ -1930,6 +1964,7 @@ int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive
                                   anyOnly ? L.force.data() : nullptr, (candStore ? 1 : 0) | (knobs.useMarks ? 2 : 0));
     secQuery += std::chrono::duration<double>(std::chrono::steady_clock::now() - tq0).count();
   }
+  ts.lap(TS_LAUNCH_CALL);
   if (rc) { for (int sl : todo) pool[sl]->inflight = false; return rc; }
   L.busy = true; L.polls = 0;
   ++queries; ++rounds; ++launches; readsQueried += m;
@@ -1985,6 +2020,7 @@ int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive
   worker2();
   if (nHelp > 0) helpers->wait();
   secGroups += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg1).count();
+  ts.lap(TS_LAUNCH_GROUPS);
   return T4_OK;
 }
 
@@ -2251,11 +2287,13 @@ int t4_assembler::harvest(Lane &L) {
   const int32_t *cnts = nullptr, *bas = nullptr, *rets = nullptr;
   const t4_overlap *ov = nullptr, *ex = nullptr;
   int rc;
+  ts.lap(TS_PUMP_OTHER);
   {
     auto tq0 = std::chrono::steady_clock::now();
     rc = t4_add_query_pool_end(L.ctx, &cnts, &bas, &ov, &ex, &rets);
     secQuery += std::chrono::duration<double>(std::chrono::steady_clock::now() - tq0).count();
   }
+  ts.lap(TS_HARVEST_WAIT);
   L.busy = false;
   const int m = (int)L.slots.size();
   if (!rc && lanes.size() == 1) {
@@ -2364,6 +2402,7 @@ int t4_assembler::harvest(Lane &L) {
           else c.morePending.erase(std::find(c.morePending.begin(), c.morePending.end(), pc));
         }
       }
+      ts.lap(TS_HARVEST_MERGE);
       if (fell) { c.partial = false; c.pendingContig = -1; c.morePending.clear(); ++restrictedFallbacks; continue; }   // neither valid nor partial: the whole query, next launch
       c.merged = true;
       if (c.pendingContig < 0) { c.partial = false; c.valid = true; }   // (else a contig joined while the launch was out: the entry goes on waiting for that one)
@@ -2423,6 +2462,7 @@ int t4_assembler::harvest(Lane &L) {
     }
     c.valid = true;
   }
+  ts.lap(TS_HARVEST_COPY);
   return T4_OK;
 }
 
@@ -2516,9 +2556,13 @@ int t4_assembler::pumpLive(bool needHead, int repetitive) {
 int t4_assembler::prefetchLive(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive) {
   auto tp0_ = std::chrono::steady_clock::now();
   struct Tp { double &acc; std::chrono::steady_clock::time_point t0; ~Tp() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tp_{secPrefetch, tp0_};
+  ts.begin();
   processEvents();
   announceLive(n, reads, strands, barcodes, repetitive);
-  return pumpLive(true, repetitive);
+  ts.lap(TS_ANNOUNCE);
+  const int rcPump = pumpLive(true, repetitive);
+  ts.lap(TS_PUMP_OTHER);
+  return rcPump;
 }
 
 void t4_assembler::beginWindow(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive) {
@@ -2680,7 +2724,9 @@ int t4_assembler_set_params(t4_assembler *a, int hit_len_required, int radius, d
 }
 int t4_assembler_input_novel_read(t4_assembler *a, const char *id, const char *read, int strand, int barcode) {
   if (!a || !id || !read) return T4_ERR_ARG - 100;
+  a->ts.begin();
   const int r = a->inputNovelRead(id, read, strand, barcode);
+  a->ts.lap(TS_NOVEL);
   a->processEvents();
   return r;
 }
@@ -2688,7 +2734,9 @@ int t4_assembler_add_read(t4_assembler *a, const char *read, const char *gene_na
                           int repetitive_data, double similarity_threshold) {
   if (!a || !read || !gene_name || !strand) return T4_ERR_ARG - 100;
   auto t0 = std::chrono::steady_clock::now();
+  a->ts.begin();
   const int r = a->addRead(read, gene_name, strand, barcode, min_kmer_count, repetitive_data != 0, similarity_threshold);
+  a->ts.lap(TS_ADD_DECIDE);   // (the early returns: no overlap, no candidate of the gene family)
   a->processEvents();
   a->secAddTotal += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return r;
@@ -2717,11 +2765,13 @@ int t4_assembler_timers(const t4_assembler *a, double *sec_refresh, double *sec_
 }
 int t4_assembler_repeat_add_read(t4_assembler *a, const char *read) {
   if (!a) return T4_ERR_ARG - 100;
+  a->ts.begin();
   const int r = a->repeatAddRead(read);
+  a->ts.lap(TS_REPEAT);
   a->processEvents();
   return r;
 }
-int t4_assembler_update_all_consensus(t4_assembler *a) { if (!a) return T4_ERR_ARG; a->updateAllConsensus(); a->processEvents(); return T4_OK; }
+int t4_assembler_update_all_consensus(t4_assembler *a) { if (!a) return T4_ERR_ARG; a->ts.begin(); a->updateAllConsensus(); a->ts.lap(TS_UPDATE_CONS); a->processEvents(); return T4_OK; }
 int t4_assembler_set_threads(t4_assembler *a, int host_threads) { if (!a || host_threads < 1) return T4_ERR_ARG; a->threads = host_threads > 64 ? 64 : host_threads; return T4_OK; }
 int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n) {
   if (!a || !out || n < 1) return T4_ERR_ARG;
@@ -2734,6 +2784,11 @@ int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n) {
   if (getenv("T4_TIMING")) {
     fprintf(stderr, "timing: assembler host seconds: add_read calls %.3f (incl. waits for the head), prefetch calls %.3f; launching %.3f (of which deltas %.3f, dependency sets %.3f, registering k-mers %.3f), harvesting %.3f, event examination %.3f, index edits %.3f\n",
             a->secAddTotal, a->secPrefetch, a->secLaunch, a->secDelta, a->secGroups, a->secRegister, a->secHarvest, a->secEvents, a->index.secOps);
+    {
+      const double spt = a->ts.secondsPerTick();
+      fprintf(stderr, "timing: the chain's host thread by section (seconds):");
+      for (int i = 0; i < TS_N; ++i) fprintf(stderr, " %s %.3f%s", TS_NAMES[i], (double)a->ts.acc[i] * spt, i + 1 < TS_N ? ";" : "\n");
+    }
     fprintf(stderr, "timing: query lanes %d: %lld launches (%lld for a head without a result, %lld of them without the whole queries of entries further back), %lld waits for the head's lane in %.3f s, %lld queries killed in flight\n",
             (int)a->lanes.size(), (long long)a->launches, (long long)a->launchesUrgent, (long long)a->lightRounds, (long long)a->headWaits, a->secHeadWait, (long long)a->killedInFlight);
     fprintf(stderr, "timing: tolerated index edits %lld, of which %lld met an entry whose group statistics cannot move (no budget spent); tolerance kills %lld, of which %lld for lists beyond 10000 postings\n",

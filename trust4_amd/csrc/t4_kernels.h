@@ -688,6 +688,9 @@ __device__ __forceinline__ bool ovLess(const OvRec &a, const OvRec &b, bool scor
 // (chainPos of a scored overlap of a contig: bits 21-30 the size of the run it was chained from -- the number novelMinHitRequired is
 // compared with, SeqSet.hpp:923-925 --, and once the pre-filters cut it, bits 0-9 / 10-19 / 20 its scored matchCnt / indelCnt / zero flag)
 #define OV_RUN_SHIFT 21
+// (a scored matchCnt is at most the two spans of the overlap, 2 * T4_MAXL: ten bits hold it only while reads stay this short -- and
+// T4Cand carries rs / re / m0 as 16-bit fields)
+static_assert(2 * T4_MAXL < 1024, "ovCutKeepScored packs the scored matchCnt into ten bits: widen the packing before T4_MAXL grows");
 __device__ __forceinline__ void ovKeepRunSize(OvRec &o, int runSize) { o.chainPos = (runSize > 1023 ? 1023 : runSize) << OV_RUN_SHIFT; }
 __device__ __forceinline__ void ovCutKeepScored(OvRec &o) {
   const int ind = o.indelCnt > 1023 ? 1023 : o.indelCnt;
@@ -4192,6 +4195,36 @@ __global__ __launch_bounds__(256) void deltaKernel(const unsigned char *staging,
       for (unsigned long long i = lane; i < n8; i += 64) ((unsigned long long *)dst)[i] = ((const unsigned long long *)src)[i];
     } else
       for (unsigned long long i = lane; i < cd.bytes; i += 64) dst[i] = src[i];
+  }
+}
+
+// ---- one AddRead query call without a copy engine (round 6). A round of the ordered builder is a chain of dependent stream
+// operations a few tens of microseconds long each; an H2D copy, a memset and a D2H copy between the kernels were half of them, and
+// every hop between the compute queue and a copy engine costs more than a kernel boundary. The call's input blob sits in pinned
+// host memory the device can read, its header goes back into pinned host memory the device can write:
+//   aqPrologueKernel: input blob host -> device (the query kernels read it many times: device memory), header block zeroed
+//   aqEpilogueKernel: header block device -> host, then ONE word -- the call's sequence number -- that the host polls for
+// (the results themselves are written into pinned pools by the kernels that make them, as before).
+__global__ __launch_bounds__(256) void aqPrologueKernel(const unsigned long long *hostIn, unsigned long long *devIn, unsigned long long inWords,
+                                                        unsigned long long *devOut, unsigned long long outWords) {
+  const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, nt = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = t; i < inWords; i += nt) devIn[i] = hostIn[i];
+  for (unsigned long long i = t; i < outWords; i += nt) devOut[i] = 0ull;
+}
+// `done` counts the blocks of this launch that have written their share (device memory, left at zero by the last block)
+__global__ __launch_bounds__(256) void aqEpilogueKernel(const unsigned long long *devOut, unsigned long long *hostOut, unsigned long long outWords,
+                                                        unsigned *done, unsigned *hostFlag, unsigned seq) {
+  const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, nt = (unsigned long long)gridDim.x * blockDim.x;
+  for (unsigned long long i = t; i < outWords; i += nt) hostOut[i] = devOut[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned before = atomicAdd(done, 1u);
+    if (before + 1u == gridDim.x) {
+      *done = 0u;
+      __threadfence_system();
+      __atomic_store_n(hostFlag, seq, __ATOMIC_RELEASE);
+    }
   }
 }
 

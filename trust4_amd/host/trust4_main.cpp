@@ -77,7 +77,8 @@ const char *USAGE =
     "\t                 barcode file -- and the ranks' 21-mer counts are put together in one exchange; --lateShard keeps every read on every rank\n"
     "\t                 up to the cell pass, as a run does by itself when identical reads lie either side of a rank boundary)\n"
     "\t--readShard R/N: one sample over N processes (one per GPU): the rough annotation of the R-th range of the distinct reads here, the results\n"
-    "\t                 all-gathered (--rcclId / --gatherDir); rank 0 runs the ordered assembly pass and writes the files, the others end after the exchange\n";
+    "\t                 all-gathered (--rcclId / --gatherDir); rank 0 runs the ordered assembly pass and writes the files, the others end after the exchange\n"
+    "\t--allowRawFinal: bulk paired-end input without --skipMateExtension: write the raw assembly as _final.out (the mate-pair extension is not part of this build; logged)\n";
 
 void PrintLog(const char *fmt, ...) {
   char buf[2048], stime[256];
@@ -326,11 +327,12 @@ int main(int argc, char *argv[]) {
                                          {"minHitLen", required_argument, 0, 10006}, {"cgeneEnd", required_argument, 0, 10008},
                                          {"barcode", required_argument, 0, 10002}, {"UMI", required_argument, 0, 10004},
                                          {"keepNoBarcode", no_argument, 0, 10003}, {"contigMinCov", required_argument, 0, 10007},
-                                         {"cellShard", required_argument, 0, 10100}, {"rcclId", required_argument, 0, 10101}, {"gatherDir", required_argument, 0, 10102}, {"readShard", required_argument, 0, 10103}, {"lateShard", no_argument, 0, 10104}, {"debug-ns", required_argument, 0, 10000},
+                                         {"cellShard", required_argument, 0, 10100}, {"rcclId", required_argument, 0, 10101}, {"gatherDir", required_argument, 0, 10102}, {"readShard", required_argument, 0, 10103}, {"lateShard", no_argument, 0, 10104}, {"allowRawFinal", no_argument, 0, 10105}, {"debug-ns", required_argument, 0, 10000},
                                          {(char *)0, 0, 0, 0}};
   int indexKmerLength = 9, changeKmerLengthThreshold = 4096, trimLevel = 1, minHitLen = -1, constantGeneEnd = 200;
   int shardRank = 0, shardCount = 1, threadCnt = 1, contigMinCov = 0;
   bool annotSharded = false;
+  bool allowRawFinal = false;   // --allowRawFinal: bulk paired-end input without --skipMateExtension writes the raw assembly as _final.out (logged)
   bool lateShard = false;   // --lateShard (set by the fallback of the early shard, see below): every rank runs the phases before the cell pass over ALL reads, as round 3 did
   int annotRank = 0, annotCount = 1;   // --readShard R/N: the read-only pass of ONE sample (rough annotation) by read range over N processes, results all-gathered; rank 0 goes on alone
   std::string gatherDir;    // --gatherDir DIR: the same exchange through files of a directory every rank sees (tests without RCCL)
@@ -363,19 +365,28 @@ int main(int argc, char *argv[]) {
     else if (c == 10104) lateShard = true;
     else if (c == 10103) { if (sscanf(optarg, "%d/%d", &annotRank, &annotCount) != 2 || annotCount < 1 || annotRank < 0 || annotRank >= annotCount) { fprintf(stderr, "--readShard takes R/N with 0 <= R < N\n"); return EXIT_FAILURE; } annotSharded = true; }
     else if (c == 10100) { if (sscanf(optarg, "%d/%d", &shardRank, &shardCount) != 2 || shardCount < 1 || shardRank < 0 || shardRank >= shardCount) { fprintf(stderr, "--cellShard takes R/N with 0 <= R < N\n"); return EXIT_FAILURE; } }
+    else if (c == 10105) allowRawFinal = true;
     else if (c == 10003) keepMissingBarcode = true;
     else if (c == 10007) contigMinCov = atoi(optarg);
     else { fprintf(stderr, "%s", USAGE); return EXIT_FAILURE; }
   }
   if (refFa.empty()) { fprintf(stderr, "Need to use -f to specify the receptor genome sequence.\n"); return EXIT_FAILURE; }
-  if (hasMate && !hasBarcode && !skipMateExtension && !getenv("T4_ALLOW_RAW_FINAL")) {
+  if (hasMate && !hasBarcode && !skipMateExtension && !allowRawFinal) {
     // main.cpp:2018-2312: the reference would go on to its mate-pair extension (ExtendSeqFromReads, RemoveRedundantSeq) and the
     // annotator reads _final.out. A silent copy of the raw assembly there would change contigs and CDR3 calls downstream.
     fprintf(stderr, "trust4-hip: the mate-pair extension of the assemblies (what the reference runs for paired-end input without barcodes) is not part of this build.\n"
-                    "Pass --skipMateExtension (run-trust4 forwards it; _final.out is then the raw assembly, as in the reference), or set T4_ALLOW_RAW_FINAL=1 to get that file without the flag.\n");
+                    "Pass --skipMateExtension (run-trust4 forwards it; _final.out is then the raw assembly, as in the reference), or --allowRawFinal to get that file knowingly without the flag.\n");
     return EXIT_FAILURE;
   }
   if (getenv("T4_THREADS")) threadCnt = atoi(getenv("T4_THREADS")) > 0 ? atoi(getenv("T4_THREADS")) : 1;
+  // Switches that exist for the CPU suite's negative controls and forced fall-backs only. They are compiled into the emulator build of
+  // the driver (-DT4_TEST_KNOBS, tests/test_stage1_e2e.py:_emulated_driver) and into nothing that ships: one of them changes the result.
+#ifdef T4_TEST_KNOBS
+  const bool testNoCountMerge = getenv("T4_TEST_NO_COUNT_MERGE") != nullptr;   // the other ranks' 21-mer counts are NOT added (the files must then differ)
+  const bool testForceCoupled = getenv("T4_TEST_FORCE_COUPLED") != nullptr;    // the early shard's fall-back on inputs that do not need it
+#else
+  const bool testNoCountMerge = false, testForceCoupled = false;
+#endif
   if (shardCount > 1 && (!hasBarcode || keepMissingBarcode)) { fprintf(stderr, "--cellShard needs --barcode: without barcodes the Add pass does not shard (DESIGN.md 6).\n"); return EXIT_FAILURE; }
   if (annotSharded && shardCount > 1) { fprintf(stderr, "--readShard and --cellShard are two ways to spread one sample: take one.\n"); return EXIT_FAILURE; }
   if (annotSharded && rcclIdPath.empty() && gatherDir.empty()) { fprintf(stderr, "--readShard needs --rcclId FILE or --gatherDir DIR for the exchange of the annotations.\n"); return EXIT_FAILURE; }
@@ -419,9 +430,24 @@ int main(int argc, char *argv[]) {
   std::string transportNote = gatherDir.empty() ? (rcclIdPath.empty() ? "none" : "RCCL") : "files";
   auto commUp = [&](int rank, int count, const std::string &idPath) -> bool {   // true: RCCL is up; false: the file transport is on (gatherDir set)
     gpuReady();
-    const int irc = t4_comm_init(ctx, rank, count, idPath.c_str(), &comm);
-    const std::string why = irc ? (std::string("fail ") + t4_last_error(ctx)) : std::string("ok");
     auto statusOf = [&](int r) { return idPath + ".status.rank" + std::to_string(r); };
+    //  A status file an earlier run left on the same path must not be taken for this run's: a rank removes its own before
+    // its communicator comes up -- no rank gets through the self-check of t4_comm_init before every rank is inside it, so by the time
+    // a rank that came up reads the others' files, theirs are this run's or absent --, and every status carries the run's nonce (the
+    // first bytes of the id file rank 0 made for THIS run); a file with another nonce counts as not written yet. A rank that could not
+    // even read the id writes "-": it has failed, which sends every rank to the file transport whatever the others say.
+    (void)unlink(statusOf(rank).c_str());
+    const int irc = t4_comm_init(ctx, rank, count, idPath.c_str(), &comm);
+    std::string nonce = "-";
+    {
+      std::string idBytes;
+      if (readWhole(idPath, idBytes) && !idBytes.empty()) {
+        static const char *hx = "0123456789abcdef";
+        nonce.clear();
+        for (size_t t = 0; t < idBytes.size() && t < 16; ++t) { nonce.push_back(hx[((unsigned char)idBytes[t]) >> 4]); nonce.push_back(hx[((unsigned char)idBytes[t]) & 15]); }
+      }
+    }
+    const std::string why = nonce + ":" + (irc ? (std::string("fail ") + t4_last_error(ctx)) : std::string("ok"));
     {
       FILE *fp = fopen((statusOf(rank) + ".tmp").c_str(), "wb");
       if (!fp || fwrite(why.data(), 1, why.size(), fp) != why.size()) { if (fp) fclose(fp); die(ctx, "t4_comm_init (status file)", irc ? irc : T4_ERR_IO); }
@@ -431,8 +457,13 @@ int main(int argc, char *argv[]) {
     bool allOk = true; std::string firstBad;
     for (int r = 0; r < count; ++r) {
       std::string st; bool got1 = false;
-      for (int tries = 0; tries < 12000 && !got1; ++tries) { got1 = readWhole(statusOf(r), st) && !st.empty(); if (!got1) usleep(50000); }
+      // (the bound of exchangeFiles: with the input dealt out by cells the ranks reach their first exchange minutes apart)
+      for (int tries = 0; tries < 36000 && !got1; ++tries) {
+        got1 = readWhole(statusOf(r), st) && !st.empty() && (st.compare(0, nonce.size() + 1, nonce + ":") == 0 || st.compare(0, 7, "-:fail ") == 0 || nonce == "-");
+        if (!got1) usleep(50000);
+      }
       if (!got1) die(ctx, "t4_comm_init (no status from every rank)", irc ? irc : T4_ERR_IO);
+      st = st.substr(st.find(':') + 1);
       if (st != "ok") { allOk = false; if (firstBad.empty()) firstBad = "rank " + std::to_string(r) + ": " + st; }
     }
     if (allOk) return true;
@@ -656,8 +687,20 @@ int main(int argc, char *argv[]) {
   // (t4_kmer_count_export / _merge; one all-gather). T4_SHARD_INPUT=0: every rank runs the input phases over the whole sample
   // and lets go of the other ranks' reads after the counts, as round 4 did (A/B and the tests' second path).
   // (=2, a testing aid: also with ONE rank, which then owns every cell -- the export and the exchange run as they do with more, over RCCL on a one-GPU box)
-  const bool shardInput = (shardCount > 1 || (getenv("T4_SHARD_INPUT") && atoi(getenv("T4_SHARD_INPUT")) == 2 && hasBarcode && !keepMissingBarcode)) && !lateShard &&
-                          (!rcclIdPath.empty() || !gatherDir.empty()) && !(getenv("T4_SHARD_INPUT") && atoi(getenv("T4_SHARD_INPUT")) == 0);
+  bool shardInput = (shardCount > 1 || (getenv("T4_SHARD_INPUT") && atoi(getenv("T4_SHARD_INPUT")) == 2 && hasBarcode && !keepMissingBarcode)) && !lateShard &&
+                    (!rcclIdPath.empty() || !gatherDir.empty()) && !(getenv("T4_SHARD_INPUT") && atoi(getenv("T4_SHARD_INPUT")) == 0);
+  // (the pass ahead of the loop reads the barcode file a first time: a FIFO, a process substitution or /dev/stdin would be drained by
+  // it. Whether every barcode file is a regular file follows from argv alone, so every rank decides alike: round 4's way then --
+  // the input phases over the whole sample on every rank, one read of every file. ADVICE r5.)
+  if (shardInput)
+    for (const std::string &f : barcodeFile.files) {
+      struct stat sb;
+      if (stat(f.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) {
+        shardInput = false;
+        PrintLog("The barcode file %s cannot be read twice (not a regular file): the input is not dealt out by cells, every rank reads the whole sample.", f.c_str());
+        break;
+      }
+    }
   int ownLo = 0, ownHi = 0;   // this rank's barcode numbers [ownLo, ownHi)
   long long ownPairs = 0, allPairs = 0;
   if (shardInput) {
@@ -884,7 +927,7 @@ int main(int argc, char *argv[]) {
     std::string().swap(mine);
     long long taken = 0;
     for (int r = 0; r < shardCount; ++r) {
-      if (r == shardRank || getenv("T4_TEST_NO_COUNT_MERGE")) continue;   // (testing aid: the negative control of tests/test_dist_gloo.py -- without the other ranks' counts the read statistics are wrong)
+      if (r == shardRank || testNoCountMerge) continue;   // (testing aid: the negative control of tests/test_dist_gloo.py -- without the other ranks' counts the read statistics are wrong)
       std::string &g = got[(size_t)r];
       int64_t m = 0;
       if (g.size() >= 8) memcpy(&m, g.data(), 8);
@@ -1097,6 +1140,8 @@ int main(int argc, char *argv[]) {
         if (r != annotRank) for (int t = lo; t < hi; ++t) memcpy(sortedReads[(size_t)t].g, &got[(size_t)r][(size_t)(t - lo) * 4 * sizeof(t4_overlap)], 4 * sizeof(t4_overlap));
       }
       PrintLog("Rough annotations of %d read ranges exchanged over %s (this rank: reads %d-%d of %d).", annotCount, gatherDir.empty() ? "RCCL" : "files", sliceLo, sliceHi, readCnt);
+      // (every rank has read every status by now -- nobody contributes to the exchange before -- so this rank's can go: ADVICE r5)
+      if (!rcclIdPath.empty()) (void)unlink((rcclIdPath + ".status.rank" + std::to_string(annotRank)).c_str());
       if (annotRank != 0) {   // the ordered assembly pass is one chain: rank 0 runs it and writes the files
         t4_index_destroy(refSet);
         t4_destroy(ctx);
@@ -1499,7 +1544,7 @@ int main(int argc, char *argv[]) {
       std::vector<std::string> ends;
       const std::string mineEnds = readCnt > 0 ? sortedReads[0].read + "\n" + sortedReads[(size_t)readCnt - 1].read : std::string();
       if (!exchange(mineEnds, true, ends)) { fprintf(stderr, "trust4-hip: the exchange of the boundary reads failed\n"); return EXIT_FAILURE; }
-      bool coupled = getenv("T4_TEST_FORCE_COUPLED") != nullptr;   // (testing aid: the fallback below on inputs that do not need it)
+      bool coupled = testForceCoupled;   // (testing aid: the fallback below on inputs that do not need it)
       std::string lastSeen;
       for (int r = 0; r < shardCount; ++r) {
         if (ends[(size_t)r].empty()) continue;
@@ -1888,8 +1933,8 @@ int main(int argc, char *argv[]) {
     fprintf(fp, "shard %d %d\ncontig_slots %d\nreads %d\n", shardRank, shardCount, cellSlots(), readCnt);
     fclose(fp);
   } else {
-    if (!skipMateExtension && hasMate && !hasBarcode)   // only reachable under T4_ALLOW_RAW_FINAL=1 (checked with the options)
-      PrintLog("NOTE: T4_ALLOW_RAW_FINAL=1: _final.out is the raw assembly (what the reference writes under --skipMateExtension), NOT its mate-pair extension.");
+    if (!skipMateExtension && hasMate && !hasBarcode)   // only reachable under --allowRawFinal (checked with the options)
+      PrintLog("NOTE: --allowRawFinal: _final.out is the raw assembly (what the reference writes under --skipMateExtension), NOT its mate-pair extension.");
     if (!concurrentFiles) writeSetOrStdout(outputPrefix + "_final.out");
   }
   if (concurrentFiles) {
