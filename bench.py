@@ -322,7 +322,10 @@ def cell_config_leg(name, device, threads=32):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def pmc_traffic(fa, f1, f2, threads, device, tmp, kernels=("queryKernel", "extendKernel"), limit_s=None):
+ADD_KERNELS = ("queryKernel<8192, 512, 512, 1>", "wideSeedKernel", "wideScatterKernel", "wideSortKernel", "wideStatsKernel", "wideChainKernel", "wideMergeKernel", "extendKernel")   # == tools/pmc_c2_summary.py
+
+
+def pmc_traffic(fa, f1, f2, threads, device, tmp, kernels=ADD_KERNELS, limit_s=None):
     """HBM-side bytes of the dominant kernels of ONE step, from rocprofv3's TCC counters: the step's own command run twice more
     under `rocprofv3 --pmc <C> --kernel-trace` (FETCH_SIZE and WRITE_SIZE in separate passes, as the counter slots demand),
     the counter summed over every launch of the query kernels. Correction of MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts
@@ -371,7 +374,7 @@ def pmc_traffic(fa, f1, f2, threads, device, tmp, kernels=("queryKernel", "exten
         shutil.rmtree(d, ignore_errors=True)
     traffic = (2.0 * raw["FETCH_SIZE"]["counter_units_KB"] + raw["WRITE_SIZE"]["counter_units_KB"]) * 1024.0
     return traffic, {"raw": raw, "fetch_bytes_corrected": 2.0 * raw["FETCH_SIZE"]["counter_units_KB"] * 1024.0, "write_bytes": raw["WRITE_SIZE"]["counter_units_KB"] * 1024.0,
-                     "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace (separate passes) on the step's command; FETCH_SIZE x 2 (gfx950), units KB; queryKernel + extendKernel launches of one step"}
+                     "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE --kernel-trace (separate passes) on the step's command; FETCH_SIZE x 2 (gfx950), units KB; the AddRead query launches of one step (the query kernel, the wide query's six kernels, extendKernel)"}
 
 
 def stage1_cells(pairs, cells):
@@ -786,12 +789,26 @@ def main():
             if tr and not use_c2:
                 out["roofline"]["traffic"] = tr
                 out["roofline"]["traffic_over_algorithmic"] = tr / roof["algorithmic_bytes_per_step"]
-            elif tr and aqb:   # measured on the 100 k-pair batch of the same recipe: per step of THAT batch, next to its own algorithmic bytes
+            elif tr and aqb:
+                # measured on the 100 k-pair batch of the same recipe, live in this run: a block of its OWN -- traffic, algorithmic bytes and their
+                # ratio all of THAT batch (a number scaled to C2's rounds beside the small batch's ratio contradicted
+                # itself; C2's rounds are three times heavier). `roofline.traffic` stays null: it is not this workload's traffic.
                 algb = add_bytes(aqb["reads_queried"], 150, aqb["hits"])
-                out["roofline"]["traffic"] = tr / max(1, aqb["rounds"]) * aq["rounds"]
-                out["roofline"]["traffic_over_algorithmic"] = tr / algb
-                out["roofline"]["traffic_detail"]["basis"] = ("PMC passes ran on the C2 recipe at 100 k pairs (%d query rounds, %.3e algorithmic bytes); `traffic` scales its per-round average to this "
-                                                             "step's %d rounds, `traffic_over_algorithmic` is the 100 k-pair batch's own ratio" % (aqb["rounds"], algb, aq["rounds"]))
+                out["roofline"]["traffic_small_batch"] = {"workload": "C2 recipe at 100 k pairs (2 000 clones, seed 1), one whole run under each counter, this box, this run",
+                                                          "traffic": tr, "algorithmic_bytes": algb, "traffic_over_algorithmic": tr / algb, "rounds": aqb["rounds"],
+                                                          "traffic_per_round": tr / max(1, aqb["rounds"]), "algorithmic_bytes_per_round": algb / max(1, aqb["rounds"])}
+        # config C2's own traffic: two PMC passes over a whole C2 run take seven minutes, more than a bench run can spare beside 25 timed
+        # C2 steps -- measured in the builder's GPU session with this engine and committed (tools/pmc_c2_summary.py); cited, with its
+        # source, not measured by this run
+        if use_c2 and c2name == "c2":
+            try:
+                cand = sorted(x for x in os.listdir(os.path.join(ROOT, "profiles")) if x.startswith("r06") and x.endswith("_c2_pmc_summary.json"))
+                prof = json.load(open(os.path.join(ROOT, "profiles", cand[-1])))
+                out["roofline"]["traffic_c2_profile"] = {"source": "profiles/" + cand[-1] + " (committed measurement of a builder session, NOT of this run)", "traffic": prof["traffic_bytes"],
+                                                         "algorithmic_bytes": prof["algorithmic_bytes"], "traffic_over_algorithmic": prof["traffic_over_algorithmic"],
+                                                         "fetch_bytes_corrected": prof["fetch_bytes_corrected"], "write_bytes": prof["write_bytes"], "note": prof.get("note", "")}
+            except Exception:   # noqa: BLE001
+                pass
         if c2 is not None:
             c2.pop("files", None)
             out["c2"] = c2

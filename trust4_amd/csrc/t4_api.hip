@@ -73,6 +73,7 @@ struct AqCall {
   size_t oPk, oNm, oLen, oBc, oSt, oLs, oVw, oFa, oOnly, oForce, oCs, oWide, oWideA, inBytes, pCb, pCc, pS8, pCnt, pSta, pNext, pNext2, pBase, pTick, pStab, pAux, pN4, pTail, pWctl, pWplan, pWstat, pWctlA, pWplanA, pWstatA, outBytes;
   bool hasOnly = false, hasForce = false, wantCands = false, useMarks = false;
   bool extendLater = false, wide = false, onlyRestricted = false;
+  bool lazyDone = false, lazyStage = false;   // the wide pipeline behind the query kernel is launched only once the kernel is known to have deferred a read (aqEnd)
   int wideSafety = 32;   // of sixteenths: partitions are planned for half of their capacity
   T4BatchView bv; T4QueryArgs qa; T4Work wk;
   std::chrono::steady_clock::time_point tf0;
@@ -122,6 +123,7 @@ struct t4_ctx {
   int aqRecCap = 0;
   int64_t aqCalls = 0, aqReads = 0, aqGlobalLaunches = 0, aqGlobalReads = 0, aqRecords = 0;
   double aqSecPack = 0, aqSecFirst = 0, aqSecGlobal = 0;
+  double aqSecLaunch[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // host seconds inside aqLaunch: preparation, prologue, second stream, query kernel, wide + extension, events, epilogue
   int aqPoolGrows = 0;
   const int32_t *aqLastStable = nullptr;   // per-read flags of the last AddRead query call: group statistics that index edits of small groups cannot move
   const int32_t *aqLastTicks = nullptr; int aqLastN = 0;   // per-read wall-clock ticks (10 ns) of the last AddRead query call (in the pinned header blob)
@@ -131,11 +133,12 @@ struct t4_ctx {
   // testing aids of the AddRead query path, read from the environment once per ctx (a query round is a few hundred microseconds; a
   // dozen getenv calls in it are not nothing)
   struct AqEnv {
-    bool forceGlobal, wideNoHint;
+    bool forceGlobal, wideNoHint, wideEager;
     int capLimit, extendDefer, poolCap, candCap, wideMinHits;
     AqEnv() {
       auto num = [](const char *n, int d) { const char *e = getenv(n); return e ? atoi(e) : d; };
       forceGlobal = getenv("T4_AQ_FORCE_GLOBAL") != nullptr; wideNoHint = getenv("T4_WIDE_NO_HINT") != nullptr;
+      wideEager = getenv("T4_WIDE_EAGER") != nullptr;   // A/B aid: the five wide kernels behind every whole-query round's query kernel, as until round 6
       capLimit = num("T4_AQ_CAP_LIMIT", 0); poolCap = num("T4_AQ_POOL_CAP", 0); candCap = num("T4_AQ_CAND_CAP", 1 << 18);
       // (64 until round 5: with light rounds extendKernel runs behind the whole-query rounds anyway, and a read's 17th overlap is better
       // off there -- profiles/r05e, r05f)
@@ -148,6 +151,7 @@ struct t4_ctx {
   bool wideInit = false;
   unsigned char *grpPoolHost = nullptr;   // pinned; T4Wide::grpPool is its device address
   int64_t wideReads = 0, wideParts = 0, wideRetries = 0, wideGroups = 0;
+  int64_t wideCalls = 0, wideCallsDeferred = 0, wideCallsDirect = 0;   // calls with the wide query on; those whose query kernel deferred a read; those with reads on the second stream
   int wideSafetyKeep = 32, wideCallsSinceRepeat = 0;   // partition load factor that recent calls needed (of sixteenths: 32 = partitions planned half full); decays back when nothing overflows
   int64_t wideFlagCounts[6] = {0, 0, 0, 0, 0, 0};     // calls repeated because: reads, partitions, keys of a partition, overlaps of a partition, dependency records, other
   int wideRecentParts = 0, wideRecentReads = 0;   // the largest counts of the last calls, decayed: sizes the (persistent) grids of the next call's wide kernels
@@ -1772,6 +1776,39 @@ int aqBegin(t4_ctx *c, const T4IndexView &base, const T4IndexView *views, const 
   return r;
 }
 
+// the wide query of the reads the round's query kernel deferred, on the ctx's stream. known: the header of the call is on the host
+// (the counts of deferred reads and their partitions size the grids); else the grids are sized from what recent calls needed
+void aqLaunchDeferredWide(t4_ctx *c, bool known) {
+  AqCall &q = c->aq;
+  T4Wide w;
+  memcpy(&w, c->aqInHost + q.oWide, sizeof w);
+  const int cus = c->cus > 0 ? c->cus : 1;
+  // The grids are persistent (any size serves any number of reads / partitions); an empty grid of several hundred 100 KB-LDS workgroups
+  // still takes microseconds to come and go.
+  auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; };
+  int parts = 2 * c->wideRecentParts + 4, reads = 2 * c->wideRecentReads + 2;
+  if (known) { const int *ctl = (const int *)(c->aqOutHost + q.pWctl); parts = ctl[1] + 1; reads = ctl[0]; }
+  const int gParts = clampi(parts, 4, cus * 2), gReads = clampi(reads, known ? 1 : 2, cus < 64 ? cus : 64);
+  hipLaunchKernelGGL(t4k::wideScatterKernel, dim3(clampi(8 * gParts, 16, cus * 8)), dim3(256), 0, c->stream, q.base, w);   // (a partition is planned for four of the kernel's chunks)
+  hipLaunchKernelGGL((t4k::wideSortKernel<8192>), dim3(gParts), dim3(512), 0, c->stream, q.base, w);
+  hipLaunchKernelGGL(t4k::wideStatsKernel, dim3(gReads), dim3(512), 0, c->stream, q.base, w);
+  hipLaunchKernelGGL((t4k::wideChainKernel<8192, 1 << T4_WIDE_OVBITS>), dim3(gParts < cus ? gParts : cus), dim3(512), 0, c->stream, q.base, q.bv, q.wk, q.qa, w);
+  hipLaunchKernelGGL(t4k::wideMergeKernel, dim3(gReads), dim3(512), 0, c->stream, q.base, q.bv, q.wk, q.qa, w);
+}
+int aqLaunchEpilogue(t4_ctx *c) {   // the header block into pinned host memory, then the call's sequence number into the word the host polls (aqEpilogueKernel)
+  AqCall &q = c->aq;
+  const unsigned long long outW = q.outBytes >> 3;
+  int grid = (int)((outW + 4095) / 4096);
+  if (grid < 1) grid = 1;
+  if (grid > 64) grid = 64;
+  ++c->aqSeq;
+  if (c->aqSeq == 0) c->aqSeq = 1;
+  hipLaunchKernelGGL(t4k::aqEpilogueKernel, dim3(grid), dim3(256), 0, c->stream, (const unsigned long long *)c->aqOut, (unsigned long long *)c->aqOutHostDev, outW,
+                     c->aqDoneCtr, c->aqFlagDev, c->aqSeq);
+  HIPCHK(c, hipGetLastError());
+  return T4_OK;
+}
+
 // copies, kernels and the header copy of one attempt, enqueued on the ctx's stream (nothing waits here)
 int aqLaunch(t4_ctx *c) {
   AqCall &q = c->aq;
@@ -1792,6 +1829,8 @@ int aqLaunch(t4_ctx *c) {
     HIPCHK(c, hipHostGetDevicePointer((void **)&c->candPoolDev, c->candPool, 0));
   }
   q.tf0 = std::chrono::steady_clock::now();
+  auto tl_ = q.tf0;
+  auto lapL = [&](int i) { const auto t = std::chrono::steady_clock::now(); c->aqSecLaunch[i] += std::chrono::duration<double>(t - tl_).count(); tl_ = t; };
   if (q.wide) {
     if ((r = ensureWide(c, n, 1, 1))) return r;
     T4Wide w = wideHalf(c, 0), wa = wideHalf(c, 1);
@@ -1819,6 +1858,7 @@ int aqLaunch(t4_ctx *c) {
     }
     memcpy(c->aqInHost + q.oCs, &cs, sizeof cs);
   }
+  lapL(0);
   {   // input blob into device memory, header block zeroed (counts, status, overflow lists, bases, tail): one kernel, no copy engine (t4_kernels.h: aqPrologueKernel)
     const unsigned long long inW = q.inBytes >> 3, outW = q.outBytes >> 3;
     const unsigned long long most = inW > outW ? inW : outW;
@@ -1829,6 +1869,7 @@ int aqLaunch(t4_ctx *c) {
                        (unsigned long long *)c->aqOut, outW);
     HIPCHK(c, hipGetLastError());
   }
+  lapL(1);
   T4BatchView &bv = q.bv;
   bv.pk = (const unsigned *)(c->aqIn + q.oPk); bv.nm = (const unsigned *)(c->aqIn + q.oNm); bv.len = (const int *)(c->aqIn + q.oLen);
   bv.barcode = (const int *)(c->aqIn + q.oBc); bv.wpk = q.wpk; bv.wnm = q.wnm; bv.n = n;
@@ -1879,7 +1920,9 @@ int aqLaunch(t4_ctx *c) {
   wk.capLimit = c->aqEnv.capLimit;   // testing aid
   wk.wide = q.wide ? (const T4Wide *)(c->aqIn + q.oWide) : nullptr;
   if (!smallFirst && (r = ensureGlobalTier(c, grid0 + (q.wide ? 0 : nDirect)))) return r;   // before anything of this call runs: growing it frees the old arrays
+  lapL(0);
   HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+  lapL(5);
   if (nDirect > 0) {   // beside the LDS tier, on the second stream (its own blocks of the DP scratch)
     if (!c->stream2) { HIPCHK(c, hipStreamCreate(&c->stream2)); HIPCHK(c, hipEventCreate(&c->evIn)); HIPCHK(c, hipEventCreate(&c->evG)); }
     HIPCHK(c, hipEventRecord(c->evIn, c->stream));
@@ -1911,6 +1954,7 @@ int aqLaunch(t4_ctx *c) {
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(c->evG, c->stream2));
   }
+  lapL(2);
   if (nFirst > 0) {
     if (smallFirst) launchTier<1024, 128, 256>(grid0, c->stream, q.base, bv, wk, qa);
     else {   // a read that outgrows the LDS arrays goes on in global scratch inside the same launch
@@ -1923,21 +1967,14 @@ int aqLaunch(t4_ctx *c) {
     }
     HIPCHK(c, hipGetLastError());
   }
+  lapL(3);
   if (nDirect > 0 && !q.wide) HIPCHK(c, hipStreamWaitEvent(c->stream, c->evG, 0));
-  if (q.wide) {   // the reads the launch above deferred (none: five empty grids)
-    T4Wide w;
-    memcpy(&w, c->aqInHost + q.oWide, sizeof w);
-    const int cus = c->cus > 0 ? c->cus : 1;
-    // The grids are persistent (any size serves any number of reads / partitions); most rounds defer nothing, and an empty grid of
-    // several hundred 100 KB-LDS workgroups still takes microseconds to come and go -- so they are sized for what recent calls needed.
-    auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; };
-    const int gParts = clampi(2 * c->wideRecentParts + 4, 4, cus * 2), gReads = clampi(2 * c->wideRecentReads + 2, 2, cus < 64 ? cus : 64);
-    hipLaunchKernelGGL(t4k::wideScatterKernel, dim3(clampi(8 * gParts, 16, cus * 8)), dim3(256), 0, c->stream, q.base, w);   // (a partition is planned for four of the kernel's chunks)
-    hipLaunchKernelGGL((t4k::wideSortKernel<8192>), dim3(gParts), dim3(512), 0, c->stream, q.base, w);
-    hipLaunchKernelGGL(t4k::wideStatsKernel, dim3(gReads), dim3(512), 0, c->stream, q.base, w);
-    hipLaunchKernelGGL((t4k::wideChainKernel<8192, 1 << T4_WIDE_OVBITS>), dim3(gParts < cus ? gParts : cus), dim3(512), 0, c->stream, q.base, bv, wk, qa, w);
-    hipLaunchKernelGGL(t4k::wideMergeKernel, dim3(gReads), dim3(512), 0, c->stream, q.base, bv, wk, qa, w);
-    HIPCHK(c, hipGetLastError());
+  q.lazyDone = false; q.lazyStage = false;
+  if (q.wide) {
+    // The reads the launch above deferred. Since round 5 a fresh heavy read is recognised on the host a round ahead and starts on the
+    // second stream, so the query kernel defers a read in one whole-query round of twenty (config C2: 2 434 of 42 654): the five kernels
+    // behind it were five empty grids in the others. They are launched when the header says that a read was deferred (aqEnd).
+    if (c->aqEnv.wideEager) { aqLaunchDeferredWide(c, false); HIPCHK(c, hipGetLastError()); q.lazyDone = true; }
     if (nDirect > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->evG, 0));   // the other pipeline's records are in the pool before the extensions run
   }
   if (extendLater) {   // all records of the batch, spread over the chip
@@ -1945,19 +1982,12 @@ int aqLaunch(t4_ctx *c) {
     hipLaunchKernelGGL(t4k::extendKernel, dim3(grid), dim3(64), 0, c->stream, q.base, bv, qa, 0);
     HIPCHK(c, hipGetLastError());
   }
+  lapL(4);
   HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-  {   // the header block into pinned host memory, then the call's sequence number into the word the host polls (aqEpilogueKernel)
-    const unsigned long long outW = q.outBytes >> 3;
-    int grid = (int)((outW + 4095) / 4096);
-    if (grid < 1) grid = 1;
-    if (grid > 64) grid = 64;
-    ++c->aqSeq;
-    if (c->aqSeq == 0) c->aqSeq = 1;
-    hipLaunchKernelGGL(t4k::aqEpilogueKernel, dim3(grid), dim3(256), 0, c->stream, (const unsigned long long *)c->aqOut, (unsigned long long *)c->aqOutHostDev, outW,
-                       c->aqDoneCtr, c->aqFlagDev, c->aqSeq);
-    HIPCHK(c, hipGetLastError());
-  }
-  return T4_OK;
+  lapL(5);
+  r = aqLaunchEpilogue(c);
+  lapL(6);
+  return r;
 }
 
 // The call's results are on the host once the epilogue's word holds the call's number. The caller sits on the ordered chain's critical
@@ -2010,7 +2040,25 @@ int aqEnd(t4_ctx *c, AqResult *res) {
       float ms = 0;
       hipError_t ee = hipEventElapsedTime(&ms, c->ev[0], c->ev[1]);
       if (ee == hipErrorNotReady) { (void)hipEventSynchronize(c->ev[1]); ee = hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); }
-      if (ee == hipSuccess) { c->aqKernelMs += ms; c->aqLastMs = ms; }
+      if (ee == hipSuccess) { c->aqKernelMs += ms; c->aqLastMs = q.lazyStage ? c->aqLastMs + ms : ms; }
+    }
+    if (q.wide && !q.lazyDone) {   // did the query kernel defer a read? then its wide query runs now, and the extensions of its records behind it
+      q.lazyDone = true;
+      const int *ctl0 = (const int *)(c->aqOutHost + q.pWctl);
+      if (ctl0[0] > 0 && !ctl0[2] && !*(const int *)(c->aqOutHost + q.pWctlA + 8)) {
+        const int recsBefore = (int)*(const unsigned *)(c->aqOutHost + pTail + 24);
+        q.lazyStage = true;
+        HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+        aqLaunchDeferredWide(c, true);
+        HIPCHK(c, hipGetLastError());
+        if (q.extendLater) {
+          hipLaunchKernelGGL(t4k::extendKernel, dim3(c->cus * 16), dim3(64), 0, c->stream, q.base, bv, qa, recsBefore < c->aqPoolCap ? recsBefore : c->aqPoolCap);
+          HIPCHK(c, hipGetLastError());
+        }
+        HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+        if ((r = aqLaunchEpilogue(c))) return r;
+        continue;
+      }
     }
     int overflow = *(int *)(c->aqOutHost + pTail);
     { const int inKernel = *(int *)(c->aqOutHost + pTail + 8); if (!smallFirst && inKernel > 0) { c->aqGlobalReads += inKernel; ++c->aqGlobalLaunches; } }
@@ -2086,6 +2134,7 @@ int aqEnd(t4_ctx *c, AqResult *res) {
         continue;
       }
       c->wideReads += ctl[0] + ctlA[0]; c->wideParts += ctl[1] + ctlA[1]; c->wideGroups += ctl[3] + ctlA[3];
+      ++c->wideCalls; if (ctl[0] > 0) ++c->wideCallsDeferred; if (ctlA[0] > 0) ++c->wideCallsDirect;
       if (ctl[0] + ctlA[0] > 0 && ++c->wideCallsSinceRepeat >= 2048 && c->wideSafetyKeep > 32) { c->wideSafetyKeep /= 2; c->wideCallsSinceRepeat = 0; }
       c->wideRecentParts = ctl[1] > c->wideRecentParts ? ctl[1] : (c->wideRecentParts * 7 + ctl[1]) / 8;
       c->wideRecentReads = ctl[0] > c->wideRecentReads ? ctl[0] : (c->wideRecentReads * 7 + ctl[0]) / 8;
@@ -2171,6 +2220,9 @@ int t4_add_query_stats(t4_ctx *c, int64_t *out5) {   // 7 values
   out5[0] = c->aqCalls; out5[1] = c->aqReads; out5[2] = c->aqGlobalLaunches; out5[3] = c->aqGlobalReads; out5[4] = c->aqRecords;
   out5[5] = (int64_t)(c->aqKernelMs * 1e3); out5[6] = c->aqHits;
   if (getenv("T4_TIMING")) fprintf(stderr, "timing: AddRead query path host seconds: pack %.3f, first launch to sync %.3f, overflow tiers %.3f; result pool grown %d times\n", c->aqSecPack, c->aqSecFirst, c->aqSecGlobal, c->aqPoolGrows);
+  if (getenv("T4_TIMING")) fprintf(stderr, "timing: AddRead query path, host seconds inside the launch: preparation %.3f, prologue %.3f, second stream %.3f, query kernel %.3f, wide + extension %.3f, two event records %.3f, epilogue %.3f\n",
+                                   c->aqSecLaunch[0], c->aqSecLaunch[1], c->aqSecLaunch[2], c->aqSecLaunch[3], c->aqSecLaunch[4], c->aqSecLaunch[5], c->aqSecLaunch[6]);
+  if (getenv("T4_TIMING")) fprintf(stderr, "timing: wide query: %lld calls with the wide pipeline behind the query kernel, %lld of them had a read deferred to it; %lld with reads on the second stream\n", (long long)c->wideCalls, (long long)c->wideCallsDeferred, (long long)c->wideCallsDirect);
   if (getenv("T4_TIMING")) fprintf(stderr, "timing: wide query: %lld calls repeated -- partition pool %lld, keys of a partition %lld, overlaps of a partition %lld, dependency records %lld; partitions planned %d/16 full at the end\n",
                                    (long long)c->wideRetries, (long long)c->wideFlagCounts[1], (long long)c->wideFlagCounts[2], (long long)c->wideFlagCounts[3], (long long)c->wideFlagCounts[4], 16 * 16 / (c->wideSafetyKeep > 0 ? c->wideSafetyKeep : 32));
   return T4_OK;

@@ -185,6 +185,46 @@ struct HostIndex {
   std::vector<uint32_t> dirtyPost;
   std::vector<unsigned char> dirtyPostFlag;
   explicit HostIndex(int kl) : k(kl) {}
+  // ---- where a contig's postings are (round 6). KmerIndex::Remove and UpdateIndexFromRead (KmerIndex.hpp:143-201) walk a posting list
+  // until they meet (idx, offset); with k = 9 the lists of a gene segment that thousands of contigs share hold thousands of postings, and
+  // a left extension rewrites every posting of its contig: 26 us per extension on config C2, the largest item of the chain's host thread.
+  // hint[idx][offset] is the arena position of a posting (idx, offset) and the k-mer code of the list it stands in. It is kept current
+  // through every move of a posting (a list that moves to a larger place, the last posting of a list that fills a hole) and cleared when
+  // its posting leaves or is rewritten, so a hint that is set names a LIVE posting of the list of `code`. A lookup takes it only if it
+  // names the list of the k-mer in hand and holds (idx, offset) -- any such posting is as good as the one the walk would have met first
+  // (the reference only ever picks among equal postings of one list) -- and walks the list as before otherwise.
+  static constexpr uint32_t NOPOS = 0xFFFFFFFFu;
+  struct Hint { uint32_t pos, codeLo, codeHi; };
+  std::vector<std::vector<Hint>> hint;
+  int64_t hintHits = 0, hintWalks = 0, walkSteps = 0;
+  uint32_t hintGet(int idx, int off) const {
+    if (idx < 0 || off < 0 || (size_t)idx >= hint.size() || (size_t)off >= hint[(size_t)idx].size()) return NOPOS;
+    return hint[(size_t)idx][(size_t)off].pos;
+  }
+  void hintSet(int idx, int off, uint32_t pos, uint64_t code) {
+    if (idx < 0 || off < 0) return;
+    if ((size_t)idx >= hint.size()) hint.resize((size_t)idx + 1 + ((size_t)idx >> 3));
+    std::vector<Hint> &v = hint[(size_t)idx];
+    if ((size_t)off >= v.size()) v.resize((size_t)off + 64, Hint{NOPOS, 0u, 0u});
+    v[(size_t)off] = Hint{pos, (uint32_t)code, (uint32_t)(code >> 32)};
+  }
+  void hintMoved(const Post &p, uint32_t from, uint32_t to) { if (hintGet(p.idx, p.offset) == from) hint[(size_t)p.idx][(size_t)p.offset].pos = to; }
+  // the hint of (idx, off) when it names a posting (idx, off) of the list of `code`: no look at the key map at all
+  uint32_t hintOf(int idx, int off, uint64_t code) const {
+    if (idx < 0 || off < 0 || (size_t)idx >= hint.size() || (size_t)off >= hint[(size_t)idx].size()) return NOPOS;
+    const Hint &hp = hint[(size_t)idx][(size_t)off];
+    if (hp.pos == NOPOS || hp.codeLo != (uint32_t)code || hp.codeHi != (uint32_t)(code >> 32)) return NOPOS;
+    return arena[hp.pos].idx == idx && arena[hp.pos].offset == off ? hp.pos : NOPOS;
+  }
+  // position in list l of a posting (idx, off), NOPOS when the list holds none
+  uint32_t findPost(const ListRef &l, int idx, int off) {
+    const uint32_t h = hintGet(idx, off);
+    if (h != NOPOS && h - l.start < l.cnt && arena[h].idx == idx && arena[h].offset == off) { ++hintHits; return h; }
+    ++hintWalks;
+    for (uint32_t i = 0; i < l.cnt; ++i) if (arena[l.start + i].idx == idx && arena[l.start + i].offset == off) { walkSteps += i + 1; return l.start + i; }
+    walkSteps += l.cnt;
+    return NOPOS;
+  }
   int bucket(uint64_t code, int barcode) const { return (int)((code + (uint64_t)(int64_t)(considerBarcode ? barcode + 1 : 0)) % 1000003ull); }
   void markPost(uint32_t at) {
     if (!mirror) return;
@@ -222,12 +262,13 @@ struct HostIndex {
     if (l.cnt == l.cap) {   // move the list to the end of the arena with twice the room
       const uint32_t ncap = l.cap ? l.cap * 2 : 2;
       if (arenaUsed + ncap > arena.size()) arena.resize((arenaUsed + ncap) * 2 > 1024 ? (arenaUsed + ncap) * 2 : 1024);
-      for (uint32_t i = 0; i < l.cnt; ++i) { arena[arenaUsed + i] = arena[l.start + i]; markPost((uint32_t)arenaUsed + i); }
+      for (uint32_t i = 0; i < l.cnt; ++i) { arena[arenaUsed + i] = arena[l.start + i]; markPost((uint32_t)arenaUsed + i); hintMoved(arena[l.start + i], l.start + i, (uint32_t)arenaUsed + i); }
       garbage += l.cap;
       l.start = (uint32_t)arenaUsed; l.cap = ncap; arenaUsed += ncap;
     }
     arena[l.start + l.cnt] = Post{idx, off};
     markPost(l.start + l.cnt);
+    hintSet(idx, off, l.start + l.cnt, kc.code);
     ++l.cnt; ++total;
     markKey(kv);
     if (hook) hook->onInsert(kc.code, h, idx, off, l.cnt);
@@ -238,14 +279,15 @@ struct HostIndex {
     auto it = map.find(Key{kc.code, h});
     if (it == map.end()) return;
     ListRef &l = it->second;
-    for (uint32_t i = 0; i < l.cnt; ++i)
-      if (arena[l.start + i].idx == idx && arena[l.start + i].offset == off) {
-        if (i + 1 != l.cnt) { arena[l.start + i] = arena[l.start + l.cnt - 1]; markPost(l.start + i); }
-        --l.cnt; --total;
-        markKey(&*it);
-        if (hook) hook->onRemove(kc.code, h, idx, off, l.cnt);
-        break;
-      }
+    const uint32_t at = findPost(l, idx, off);
+    if (at != NOPOS) {
+      const uint32_t last = l.start + l.cnt - 1;
+      if (hintGet(idx, off) == at) hint[(size_t)idx][(size_t)off].pos = NOPOS;   // (an equal posting elsewhere in the list is found by the walk when it is asked for)
+      if (at != last) { arena[at] = arena[last]; markPost(at); hintMoved(arena[at], last, at); }
+      --l.cnt; --total;
+      markKey(&*it);
+      if (hook) hook->onRemove(kc.code, h, idx, off, l.cnt);
+    }
     if (l.cnt == 0 && !mirror) { garbage += l.cap; map.erase(it); }   // a live set keeps the key (its table slot) with an empty list
   }
   double secOps = 0;   // seconds in build / update / removeSeq (live sets report it)
@@ -268,22 +310,41 @@ struct HostIndex {
     KCode kc(k);
     int i;
     for (i = 0; i < k - 1; ++i) kc.append(s[i]);
+    // (the hints of oldId are in the old coordinates; what BuildIndexFromRead has just inserted for the prepended bases is in the new
+    // ones, below `shift`. The rewritten postings' hints are collected apart and take their place afterwards.)
+    static thread_local std::vector<uint32_t> moved;
+    static thread_local std::vector<uint64_t> movedCode;
+    moved.assign((size_t)(len > 0 ? len : 0), NOPOS);
+    movedCode.resize(moved.size());
     for (; i < len; ++i) {
       kc.append(s[i]);
       if (!kc.valid()) continue;
       const int h = bucket(kc.code, barcode);
-      auto it = map.find(Key{kc.code, h});
-      if (it == map.end()) continue;
-      ListRef &l = it->second;
-      for (uint32_t t = 0; t < l.cnt; ++t) {
-        Post &p = arena[l.start + t];
-        if (p.idx == oldId && p.offset == i - k + 1) {
-          p.idx = id; p.offset += shift; markPost(l.start + t);
-          if (hook) hook->onMove(kc.code, h, oldId, i - k + 1, id, p.offset);
-          break;
-        }
+      const int off = i - k + 1;
+      // (a contig of 600 bases is 600 look-ups of the key map, two cache misses each: most of what a left extension cost the chain)
+      uint32_t at = hintOf(oldId, off, kc.code);
+      if (at != NOPOS) ++hintHits;
+      else {
+        auto it = map.find(Key{kc.code, h});
+        if (it == map.end()) continue;
+        at = findPost(it->second, oldId, off);
+        if (at == NOPOS) continue;
+      }
+      Post &p = arena[at];
+      p.idx = id; p.offset += shift; markPost(at);
+      moved[(size_t)off] = at; movedCode[(size_t)off] = kc.code;
+      if (hook) hook->onMove(kc.code, h, oldId, off, id, p.offset);
+    }
+    // hints: those of the old coordinates go (a cell that named a rewritten posting is stale either way), the rewritten ones come in
+    if (oldId >= 0 && (size_t)oldId < hint.size()) {
+      std::vector<Hint> &v = hint[(size_t)oldId];
+      for (size_t o = 0; o < v.size(); ++o) {
+        const uint32_t hp = v[o].pos;
+        if (hp == NOPOS) continue;
+        if (!(arena[hp].idx == oldId && arena[hp].offset == (int)o)) v[o].pos = NOPOS;
       }
     }
+    for (int o = 0; o < len; ++o) if (moved[(size_t)o] != NOPOS) hintSet(id, o + shift, moved[(size_t)o], movedCode[(size_t)o]);
   }
   void removeSeq(const char *s, int len, int id, int barcode, int offset) {  // RemoveIndexFromRead
     if (len < k) return;
@@ -480,10 +541,10 @@ static inline uint64_t t4Tick() { return __rdtsc(); }
 static inline uint64_t t4Tick() { return (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count(); }
 #endif
 enum { TS_ADD_SERVE, TS_ADD_CANDS, TS_ADD_DECIDE, TS_ADD_MERGE, TS_ADD_EXTEND, TS_ADD_BUMP, TS_REPEAT, TS_NOVEL, TS_EVENTS_STRUCT, TS_EVENTS_INDEX, TS_HARVEST_WAIT, TS_HARVEST_COPY,
-       TS_HARVEST_MERGE, TS_ANNOUNCE, TS_PUMP_OTHER, TS_LAUNCH_PACK, TS_LAUNCH_CALL, TS_UPDATE_CONS, TS_DELTA, TS_LAUNCH_GROUPS, TS_N };
+       TS_HARVEST_MERGE, TS_ANNOUNCE, TS_PUMP_OTHER, TS_LAUNCH_PACK, TS_LAUNCH_CALL, TS_UPDATE_CONS, TS_DELTA, TS_LAUNCH_GROUPS, TS_EXT_STRINGS, TS_EXT_BUILD, TS_EXT_UPDATE, TS_EXT_PW, TS_EXT_SUBST, TS_N };
 static const char *const TS_NAMES[TS_N] = {"addRead: serving the entry", "addRead: candidate list", "addRead: decision loops", "addRead: contig merge", "addRead: extension", "addRead: weights + N fill",
                                            "RepeatAddRead", "InputNovelRead", "events: structural", "events: index", "harvest: waiting for the device", "harvest: whole-query records",
-                                           "harvest: restricted merges", "announcement", "pump: choosing what to launch", "launch: packing the items", "launch: the query call", "UpdateAllConsensus", "launch: delta", "launch: dependency sets beside the kernels"};
+                                           "harvest: restricted merges", "announcement", "pump: choosing what to launch", "launch: packing the items", "launch: the query call", "UpdateAllConsensus", "launch: delta", "launch: dependency sets beside the kernels", "extension: strings", "extension: BuildIndexFromRead of the new ends", "extension: UpdateIndexFromRead", "extension: weights moved", "extension: SubstituteConsensusPos"};
 struct TscSections {
   uint64_t acc[TS_N] = {}, t0 = 0, tStart = 0;
   std::chrono::steady_clock::time_point wall0 = std::chrono::steady_clock::now();
@@ -787,7 +848,12 @@ struct t4_assembler : IndexListener {
     std::vector<int64_t> baseAt; std::vector<int32_t> baseLen; std::string baseCons; std::vector<uint8_t> basePw;
     t4_index_delta d;
     int64_t version = 0;
+    void reset() {
+      slot.clear(); slotCode.clear(); slotStart.clear(); slotCnt.clear(); postAt.clear(); postLen.clear(); postData.clear(); seqId.clear(); seqRec.clear();
+      baseAt.clear(); baseLen.clear(); baseCons.clear(); basePw.clear(); version = 0;
+    }
   };
+  std::vector<std::unique_ptr<DeltaRec>> deltaSpare;
   struct Lane {
     t4_ctx *ctx = nullptr; bool ownCtx = false;
     t4_index *dev = nullptr;
@@ -1232,13 +1298,17 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
       if (ext[0].readEnd < len - 1) newCons.append(r.data() + ext[0].readEnd + 1, len - 1 - ext[0].readEnd);
       const int newLen = (int)newCons.size();
       const int shift = ext[0].readStart;
+      ts.lap(TS_EXT_STRINGS);
       if (shift > 0) {
         index.build(newCons.c_str(), ext[0].readStart + K - 1, seqIdx, barcode);
+        ts.lap(TS_EXT_BUILD);
         index.update(seq.cons.c_str(), oldLen, barcode, shift, seqIdx, seqIdx);
+        ts.lap(TS_EXT_UPDATE);
       }
       if (ext[0].readEnd < len - 1) {
         int start = ext[0].readStart + ext[0].seqEnd - K + 2;
         index.build(newCons.c_str() + start, newLen - start, seqIdx, barcode, start);
+        ts.lap(TS_EXT_BUILD);
       }
       const int expandSize = ext[0].readStart + (len - 1 - ext[0].readEnd);
       seq.pw.resize(oldLen + expandSize, PosWeight{{0, 0, 0, 0}});
@@ -1276,7 +1346,9 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
       if (shift > 0) evShift(seqIdx, shift);
       if (ext[0].readEnd < len - 1) evRegion(seqIdx, shift + oldLen - 2, 0x7FFFFFFF);
       structuralChange(seqIdx, true);
+      ts.lap(TS_EXT_PW);
       for (auto &p : replacement) substituteConsensusPos(seqIdx, p.first, (char)p.second);
+      ts.lap(TS_EXT_SUBST);
     } else readInConsensusOffset = ext[0].seqStart;
     ts.lap(TS_ADD_EXTEND);
   }
@@ -1381,7 +1453,9 @@ int t4_assembler::makeDelta() {
     for (uint32_t at = 0; at < (uint32_t)index.arenaUsed; ++at) index.dirtyPost.push_back(at);
     for (int i = 0; i < (int)seqs.size(); ++i) markSeqDirty(i);
   }
-  std::unique_ptr<DeltaRec> recp(new DeltaRec());
+  std::unique_ptr<DeltaRec> recp;
+  if (!deltaSpare.empty()) { recp = std::move(deltaSpare.back()); deltaSpare.pop_back(); recp->reset(); }   // (a dozen vectors allocated afresh per round otherwise)
+  else recp.reset(new DeltaRec());
   DeltaRec &R = *recp;
   t4_index_delta &d = R.d;
   memset(&d, 0, sizeof d);
@@ -1482,7 +1556,7 @@ int t4_assembler::bringUpToDate(Lane &L) {
   }
   int64_t minV = deltaVersion;
   for (const Lane &x : lanes) if (x.version < minV) minV = x.version;
-  while (!deltaLog.empty() && deltaLog.front()->version <= minV) deltaLog.pop_front();
+  while (!deltaLog.empty() && deltaLog.front()->version <= minV) { if (deltaSpare.size() < 8) deltaSpare.push_back(std::move(deltaLog.front())); deltaLog.pop_front(); }
   return T4_OK;
 }
 
@@ -2558,7 +2632,16 @@ int t4_assembler::prefetchLive(int n, const char *const *reads, const int *stran
   struct Tp { double &acc; std::chrono::steady_clock::time_point t0; ~Tp() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tp_{secPrefetch, tp0_};
   ts.begin();
   processEvents();
-  announceLive(n, reads, strands, barcodes, repetitive);
+  // The driver announces before every round (whenever the head holds no result); going through up to 192 window entries to see that
+  // they still line up was 12 us of every round. While the head lines up and the window is nearly full, the entries behind it are what
+  // the calls before announced -- should the caller ever offer another read than it announced, the entry is caught when it is served
+  // (addRead compares the head with the read in hand) -- so the window is topped up only when 32 or more places are free.
+  bool skipAnnounce = false;
+  if (n > 0 && !order.empty() && (int)order.size() + 32 >= n && (int)order.size() <= n) {
+    const Cached &h = *pool[order.front()];
+    skipAnnounce = h.strand == strands[0] && h.barcode == (barcodes ? barcodes[0] : -1) && h.skip == repetitive && h.read == reads[0];
+  }
+  if (!skipAnnounce) announceLive(n, reads, strands, barcodes, repetitive);
   ts.lap(TS_ANNOUNCE);
   const int rcPump = pumpLive(true, repetitive);
   ts.lap(TS_PUMP_OTHER);
@@ -2788,6 +2871,7 @@ int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n) {
       const double spt = a->ts.secondsPerTick();
       fprintf(stderr, "timing: the chain's host thread by section (seconds):");
       for (int i = 0; i < TS_N; ++i) fprintf(stderr, " %s %.3f%s", TS_NAMES[i], (double)a->ts.acc[i] * spt, i + 1 < TS_N ? ";" : "\n");
+      fprintf(stderr, "timing: host index: %lld postings found through their hint, %lld by walking a list (%lld postings walked over)\n", (long long)a->index.hintHits, (long long)a->index.hintWalks, (long long)a->index.walkSteps);
     }
     fprintf(stderr, "timing: query lanes %d: %lld launches (%lld for a head without a result, %lld of them without the whole queries of entries further back), %lld waits for the head's lane in %.3f s, %lld queries killed in flight\n",
             (int)a->lanes.size(), (long long)a->launches, (long long)a->launchesUrgent, (long long)a->lightRounds, (long long)a->headWaits, a->secHeadWait, (long long)a->killedInFlight);
