@@ -134,10 +134,11 @@ struct t4_ctx {
   // dozen getenv calls in it are not nothing)
   struct AqEnv {
     bool forceGlobal, wideNoHint, wideEager;
-    int capLimit, extendDefer, poolCap, candCap, wideMinHits;
+    int capLimit, extendDefer, poolCap, candCap, wideMinHits, wideSample;
     AqEnv() {
       auto num = [](const char *n, int d) { const char *e = getenv(n); return e ? atoi(e) : d; };
       forceGlobal = getenv("T4_AQ_FORCE_GLOBAL") != nullptr; wideNoHint = getenv("T4_WIDE_NO_HINT") != nullptr;
+      wideSample = num("T4_WIDE_SAMPLE", 0);   // hits sampled per planned partition for the partition boundaries of a wide read (0: 4 096 per read)
       wideEager = getenv("T4_WIDE_EAGER") != nullptr;   // A/B aid: the five wide kernels behind every whole-query round's query kernel, as until round 6
       capLimit = num("T4_AQ_CAP_LIMIT", 0); poolCap = num("T4_AQ_POOL_CAP", 0); candCap = num("T4_AQ_CAND_CAP", 1 << 18);
       // (64 until round 5: with light rounds extendKernel runs behind the whole-query rounds anyway, and a read's 17th overlap is better
@@ -1834,7 +1835,7 @@ int aqLaunch(t4_ctx *c) {
   if (q.wide) {
     if ((r = ensureWide(c, n, 1, 1))) return r;
     T4Wide w = wideHalf(c, 0), wa = wideHalf(c, 1);
-    w.enabled = 1; w.safetyNum = q.wideSafety;
+    w.enabled = 1; w.safetyNum = q.wideSafety; w.samplePerPart = wa.samplePerPart = c->aqEnv.wideSample;
     // Reads of up to T4_WIDE_MIN_HITS emitted hits stay with one workgroup (LDS tier, then its slice of global scratch inside the same
     // launch, beside the other reads of the round): the wide query's kernels run behind the launch and cost a round about 0.25 ms
     // whatever the read is (profiles/r04b-h); from the LDS tier.s capacity on it beats one workgroup.s global scratch (C2 122 -> 93 s, profiles/r04h_*). The testing aid T4_AQ_CAP_LIMIT lowers

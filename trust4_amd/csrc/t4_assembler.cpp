@@ -315,36 +315,51 @@ struct HostIndex {
     static thread_local std::vector<uint32_t> moved;
     static thread_local std::vector<uint64_t> movedCode;
     moved.assign((size_t)(len > 0 ? len : 0), NOPOS);
-    movedCode.resize(moved.size());
+    movedCode.assign(moved.size(), ~0ull);
+    // Pass 1: the k-mer of every offset and where its hint says the posting stands -- the postings of one contig lie all over the arena
+    // (each in the list of its k-mer), so every one of them is a cache miss, and so is its dirty flag: both are asked for ahead of pass 2
+    // (600 independent misses overlap instead of queueing up: a left extension was 25 us of them).
+    const std::vector<Hint> *hv = (oldId >= 0 && (size_t)oldId < hint.size()) ? &hint[(size_t)oldId] : nullptr;
     for (; i < len; ++i) {
       kc.append(s[i]);
       if (!kc.valid()) continue;
-      const int h = bucket(kc.code, barcode);
       const int off = i - k + 1;
-      // (a contig of 600 bases is 600 look-ups of the key map, two cache misses each: most of what a left extension cost the chain)
-      uint32_t at = hintOf(oldId, off, kc.code);
-      if (at != NOPOS) ++hintHits;
+      movedCode[(size_t)off] = kc.code;
+      if (hv && (size_t)off < hv->size()) {
+        const Hint &hp = (*hv)[(size_t)off];
+        if (hp.pos != NOPOS && hp.codeLo == (uint32_t)kc.code && hp.codeHi == (uint32_t)(kc.code >> 32)) {
+          moved[(size_t)off] = hp.pos;
+          __builtin_prefetch(&arena[hp.pos], 1);
+          if (mirror && hp.pos < dirtyPostFlag.size()) __builtin_prefetch(&dirtyPostFlag[hp.pos], 1);
+        }
+      }
+    }
+    // Pass 2: the rewrite, offset by offset as UpdateIndexFromRead goes
+    for (int off = 0; off + k <= len; ++off) {
+      const uint64_t code = movedCode[(size_t)off];
+      if (code == ~0ull) continue;   // (no valid k-mer here)
+      const int h = bucket(code, barcode);
+      uint32_t at = moved[(size_t)off];
+      moved[(size_t)off] = NOPOS;
+      if (at != NOPOS && arena[at].idx == oldId && arena[at].offset == off) ++hintHits;
       else {
-        auto it = map.find(Key{kc.code, h});
+        auto it = map.find(Key{code, h});
         if (it == map.end()) continue;
         at = findPost(it->second, oldId, off);
         if (at == NOPOS) continue;
       }
       Post &p = arena[at];
       p.idx = id; p.offset += shift; markPost(at);
-      moved[(size_t)off] = at; movedCode[(size_t)off] = kc.code;
-      if (hook) hook->onMove(kc.code, h, oldId, off, id, p.offset);
+      moved[(size_t)off] = at;
+      if (hook) hook->onMove(code, h, oldId, off, id, p.offset);
     }
     // hints: those of the old coordinates go (a cell that named a rewritten posting is stale either way), the rewritten ones come in
-    if (oldId >= 0 && (size_t)oldId < hint.size()) {
-      std::vector<Hint> &v = hint[(size_t)oldId];
-      for (size_t o = 0; o < v.size(); ++o) {
-        const uint32_t hp = v[o].pos;
-        if (hp == NOPOS) continue;
-        if (!(arena[hp].idx == oldId && arena[hp].offset == (int)o)) v[o].pos = NOPOS;
-      }
+    // (a cell names a posting (oldId, its offset) only: the cells of the rewritten postings are exactly those at the offsets they had)
+    for (int o = 0; o < len; ++o) {
+      if (moved[(size_t)o] == NOPOS) continue;
+      if (hintGet(oldId, o) == moved[(size_t)o]) hint[(size_t)oldId][(size_t)o].pos = NOPOS;
+      hintSet(id, o + shift, moved[(size_t)o], movedCode[(size_t)o]);
     }
-    for (int o = 0; o < len; ++o) if (moved[(size_t)o] != NOPOS) hintSet(id, o + shift, moved[(size_t)o], movedCode[(size_t)o]);
   }
   void removeSeq(const char *s, int len, int id, int barcode, int offset) {  // RemoveIndexFromRead
     if (len < k) return;
@@ -679,8 +694,21 @@ struct t4_assembler : IndexListener {
       while (tab[s].head != -2) { if (tab[s].code == code && tab[s].h == h) return tab[s].head; s = (s + 1) & (tab.size() - 1); }
       return -1;
     }
-  } winKmers;
+  };
+  // (four shards by the key's hash: the reads a round queries for the first time are registered by up to four host threads side by
+  // side, each writing its own shard -- the map was filled by one thread, 6 s of config C2 that the round's other dependency work waited for)
+  static constexpr int WK_SHARDS = 4;
+  WinKmers winShard[WK_SHARDS];
+  static int shardOf(uint64_t code, int h) { return (int)((WinKmers::hashOf(code, h) >> 60) & (WK_SHARDS - 1)); }
   size_t winKmerRefs = 0, winKmerLive = 0;
+  // the window reads that hold k-mer `code` (of a contig of barcode class h's set): fn(occurrence, onForward)
+  template <class F> void forEachOcc(uint64_t code, int h, F fn) {
+    { const WinKmers &wkm = winShard[shardOf(code, h)]; for (int nd = wkm.find(code, h); nd >= 0; nd = wkm.nodes[nd].next) fn(wkm.nodes[nd], true); }
+    uint64_t rc = 0, x = code;
+    for (int i = 0; i < k; ++i) { rc = (rc << 2) | (3ull - (x & 3ull)); x >>= 2; }
+    // (the bucket of a window read's key is that of its own barcode class: a live set is not keyed by barcode, so it follows from the code)
+    { const int hr = index.bucket(rc, -1); const WinKmers &wkm = winShard[shardOf(rc, hr)]; for (int nd = wkm.find(rc, hr); nd >= 0; nd = wkm.nodes[nd].next) fn(wkm.nodes[nd], false); }
+  }
   std::vector<Cached *> pool;      // window entries by slot (stable while the entry lives)
   std::vector<int> freeSlots;
   std::deque<int> order;           // slots of the upcoming reads, head first
@@ -756,7 +784,7 @@ struct t4_assembler : IndexListener {
     cache.clear(); cacheHead = 0;
     abandonJobs();
     for (int s : order) { pool[s]->valid = false; pool[s]->partial = false; pool[s]->inflight = false; pool[s]->uid = 0; freeSlots.push_back(s); }
-    order.clear(); winKmers.clear(); winKmerRefs = winKmerLive = 0;
+    order.clear(); for (WinKmers &w : winShard) w.clear(); winKmerRefs = winKmerLive = 0;
     idxEvents.clear(); structEvents.clear();
   }
   void invalidateSlot(int slot) { if (slot >= (int)cacheHead && slot < (int)cache.size() && cache[slot].valid) { cache[slot].valid = false; ++invalidations; } }
@@ -837,7 +865,7 @@ struct t4_assembler : IndexListener {
   int prefetch(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive);
   int prefetchLive(int n, const char *const *reads, const int *strands, const int *barcodes, int repetitive);
   void buildGroups(Cached &e);
-  void registerKmers(Cached &e, int slot);
+  void registerKmers(Cached &e, int slot, int shard = -1);   // shard >= 0: that shard's keys only, no bookkeeping (several threads, one per shard; the caller does the bookkeeping once)
   // ---- asynchronous query lanes of a live set. Every lane owns a ctx (its stream and scratch) and a REPLICA of the device image;
   // a delta is built once (makeDelta) and applied to a lane right before that lane's next launch, so a query always runs against
   // an image nothing else touches while the host goes on committing reads -- and later deltas go to the other replicas.
@@ -1632,31 +1660,29 @@ int t4_assembler::verifyServed(const Cached &c) {
 }
 
 // the read's keys (every valid k-mer of both strands) join the window's inverted map
-void t4_assembler::registerKmers(Cached &e, int slotId) {
+void t4_assembler::registerKmers(Cached &e, int slotId, int shard) {
   auto t0_ = std::chrono::steady_clock::now();
-  struct Tm { double &acc; std::chrono::steady_clock::time_point t0; ~Tm() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tm_{secRegister, t0_};
+  double secLocal = 0;
+  struct Tm { double &acc; std::chrono::steady_clock::time_point t0; ~Tm() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } tm_{shard <= 0 ? secRegister : secLocal, t0_};
   // one reference per occurrence (a k-mer that occurs twice in the read is examined twice, each time for one occurrence: the
-  // same verdicts, a tolerance budget spent a little faster); the reverse strand's codes are the reverse complements of the
-  // forward ones, position by position
+  // same verdicts, a tolerance budget spent a little faster). Only the codes of the read AS GIVEN are stored: the reverse strand's codes
+  // are their reverse complements position by position, so whoever asks for the readers of a code X asks for X (occurrences on the
+  // forward strand) and for the reverse complement of X (occurrences on the reverse strand): forEachOcc. Half the insertions -- 284 per
+  // read were 6 s of one host thread per config C2 run -- and a map half the size.
   const int len = (int)e.read.size();
   if (len >= k) {
     KCode kc(k);
-    const uint64_t top = 2ull * (uint64_t)(k - 1);
-    uint64_t rcCode = 0;
-    int sinceN = 0;   // bases since the last N (k-mer valid once k of them)
     for (int i = 0; i < len; ++i) {
-      const char c = e.read[i];
-      kc.append(c);
-      const int v = nucNum(c);
-      rcCode = (rcCode >> 2) | ((uint64_t)(3 - (v < 0 ? 0 : v)) << top);
-      sinceN = c == 'N' ? 0 : sinceN + 1;
+      kc.append(e.read[i]);
       if (i < k - 1 || !kc.valid()) continue;
-      (void)sinceN;
-      winKmers.add(kc.code, index.bucket(kc.code, e.barcode), KOcc{e.uid, slotId, 1, 0, -1});
-      winKmers.add(rcCode, index.bucket(rcCode, e.barcode), KOcc{e.uid, slotId, 0, 1, -1});
-      winKmerRefs += 2;
+      const int h = index.bucket(kc.code, e.barcode);
+      const int sh = shardOf(kc.code, h);
+      if (shard >= 0 && sh != shard) continue;
+      winShard[sh].add(kc.code, h, KOcc{e.uid, slotId, 1, 0, -1});
+      if (shard < 0) winKmerRefs += 1;
     }
   }
+  if (shard >= 0) return;
   ++winKmerLive;
   e.registered = true;
 }
@@ -1920,22 +1946,20 @@ void t4_assembler::processEvents() {
       const uint32_t before = first.delta > 0 ? first.sizeAfter - 1 : first.sizeAfter + 1, after = idxEvents[ordv[e2 - 1]].sizeAfter;
       g = e2;
       if ((before >= 100) == (after >= 100) && (before > 10000) == (after > 10000)) continue;   // 10000: removeOnlyRepeats / the repeat test of a run (SeqSet.hpp:802, 876, 936)
-      for (int nd = winKmers.find(first.code, first.h); nd >= 0; nd = winKmers.nodes[nd].next) {
-        const KOcc &o = winKmers.nodes[nd];
+      forEachOcc(first.code, first.h, [&](const KOcc &o, bool) {
         Cached &e = *pool[o.slot];
         if (e.uid == o.uid) kill(e, invCross);
-      }
+      });
     }
     for (const IdxEv &ev : net) {
-      for (int nd = winKmers.find(ev.code, ev.h); nd >= 0; nd = winKmers.nodes[nd].next) {
-        const KOcc &o = winKmers.nodes[nd];
+      forEachOcc(ev.code, ev.h, [&](const KOcc &o, bool onForward) {
         Cached &e = *pool[o.slot];
-        if (e.uid != o.uid || !e.standing()) continue;
-        if (e.inflight && e.expectWide && !e.hasDev) { kill(e, invKey); continue; }
-        if (e.fragile) { kill(e, invFragile); ++invLongLists; continue; }
-        if (e.isPending(ev.idx)) { touch(e, ev.idx, invKey); continue; }
+        if (e.uid != o.uid || !e.standing()) return;
+        if (e.inflight && e.expectWide && !e.hasDev) { kill(e, invKey); return; }
+        if (e.fragile) { kill(e, invFragile); ++invLongLists; return; }
+        if (e.isPending(ev.idx)) { touch(e, ev.idx, invKey); return; }
         for (uint32_t plus = 0; plus < 2 && e.standing(); ++plus) {
-          const int n = (plus ? o.f : o.r) * (ev.delta > 0 ? ev.delta : -ev.delta);
+          const int n = ((plus != 0) == onForward ? 1 : 0) * (ev.delta > 0 ? ev.delta : -ev.delta);
           if (!n) continue;
           if (ev.delta > 0) {
             Grp &g = e.getGroup((uint32_t)ev.idx * 2u + plus);
@@ -1950,7 +1974,7 @@ void t4_assembler::processEvents() {
           if (e.statsStable) { ++toleratedStable; continue; }   // exact: the statistics of this read's query cannot move (overlapsFromKeys)
           if (--e.slack < 0) { kill(e, invFragile); break; }
         }
-      }
+      });
     }
     idxEvents.clear();
     ts.lap(TS_EVENTS_INDEX);
@@ -1971,8 +1995,8 @@ void t4_assembler::announceLive(int n, const char *const *reads, const int *stra
     pool[sl]->valid = false; pool[sl]->partial = false; pool[sl]->inflight = false; pool[sl]->uid = 0; freeSlots.push_back(sl);   // a running query of it is ignored when it returns (uid)
     if (pool[sl]->registered) { --winKmerLive; pool[sl]->registered = false; }
   }
-  if (winKmerRefs > 64 * 284 && winKmerRefs > 4 * (winKmerLive + 1) * 284) {   // mostly references of retired entries: rebuild
-    winKmers.clear(); winKmerRefs = 0; winKmerLive = 0;
+  if (winKmerRefs > 64 * 142 && winKmerRefs > 4 * (winKmerLive + 1) * 142) {   // mostly references of retired entries: rebuild
+    for (WinKmers &w : winShard) w.clear(); winKmerRefs = 0; winKmerLive = 0;
     for (int sl : order) if (pool[sl]->registered) registerKmers(*pool[sl], sl);
   }
   for (size_t i = keep; i < (size_t)n; ++i) {
@@ -2047,11 +2071,19 @@ int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive
   // writer and, until this returns, no reader)
   auto tg1 = std::chrono::steady_clock::now();
   std::atomic<int> nextG(0);
-  std::atomic<bool> regTaken(false);
+  std::atomic<int> regShard(0);
   restrictOn = knobs.restrictOn;
-  const auto registerNew = [&]() { for (int sl : todo) if (!pool[sl]->registered) registerKmers(*pool[sl], sl); };
+  std::vector<int> regList;
+  for (int sl : todo) if (!pool[sl]->registered) regList.push_back(sl);
+  const auto registerNew = [&]() {   // a shard of the map per taker (the first WK_SHARDS threads that come by)
+    for (;;) {
+      const int sh = regShard.fetch_add(1);
+      if (sh >= WK_SHARDS) break;
+      for (int sl : regList) registerKmers(*pool[sl], sl, sh);
+    }
+  };
   const std::function<void()> groupWorker = [&]() {
-    if (!regTaken.exchange(true)) registerNew();
+    if (!regList.empty() && regShard.load() < WK_SHARDS) registerNew();
     for (;;) {
       int i = nextG.fetch_add(1);
       if (i >= m) break;
@@ -2093,6 +2125,12 @@ int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive
   if (nHelp > 0) { if (!helpers) helpers.reset(new HelperPool()); helpers->start(nHelp, worker2); }
   worker2();
   if (nHelp > 0) helpers->wait();
+  for (int sl : regList) {   // (the shards are filled: the bookkeeping of the registrations, once)
+    Cached &e = *pool[sl];
+    const int len = (int)e.read.size();
+    if (len >= k) winKmerRefs += (size_t)(len - k + 1);   // (what the rebuild of a map full of retired references is decided on: an N less does not matter)
+    ++winKmerLive; e.registered = true;
+  }
   secGroups += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg1).count();
   ts.lap(TS_LAUNCH_GROUPS);
   return T4_OK;

@@ -99,6 +99,7 @@ struct T4WidePlan { int pBase, P, Wd /* unused since the partitions follow the h
 struct T4Wide {
   int enabled;
   int maxReads, maxPart, pcap, maxOvPart, safetyNum /* partitions are planned for pcap * 16 / safetyNum hits */, maxPartPerRead;
+  int samplePerPart;         // hits sampled per planned partition for the partition boundaries (0: 4096 per read whatever it plans)
   int minHits;               // a read goes wide when its seed stage emits more hits than this (or meets a list beyond 10000 postings, or outgrows the global-scratch tier)
   int *ctl;                  // [0] reads, [1] partitions, [2] overflow flags (1 reads, 2 partitions, 4 keys of a partition, 8 overlaps of a partition, 16 group pool), [3] group pool cursor
   T4WidePlan *plan;          // [maxReads]

@@ -69,6 +69,11 @@ __device__ T4_NI void wideDeferRead(const T4IndexView &ix, WaveMem &wm, WaveStat
     int *bd = wd.bounds + (size_t)slot * (T4_WIDE_MAXP + 1);
     unsigned *smp = (unsigned *)wm.keys;   // (the key array is free: the seed stage's code buffer died with it)
     int nS = 2 * wm.cap < 4096 ? 2 * wm.cap : 4096;
+    if (wd.samplePerPart > 0) {   // (a read that plans four partitions does not need 4 096 samples to cut them: gathers and sort of the sample are on the round's critical path)
+      int want = wd.samplePerPart * P;
+      if (want < 512) want = 512;
+      if (want < nS) nS = want;
+    }
     if (nS > H) nS = H;
     if (P > 1 && nS > 0) {
       for (int j = lane; j < nS; j += NT) {
