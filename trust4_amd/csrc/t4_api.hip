@@ -138,13 +138,13 @@ struct t4_ctx {
     AqEnv() {
       auto num = [](const char *n, int d) { const char *e = getenv(n); return e ? atoi(e) : d; };
       forceGlobal = getenv("T4_AQ_FORCE_GLOBAL") != nullptr; wideNoHint = getenv("T4_WIDE_NO_HINT") != nullptr;
-      wideSample = num("T4_WIDE_SAMPLE", 0);   // hits sampled per planned partition for the partition boundaries of a wide read (0: 4 096 per read)
+      wideSample = num("T4_WIDE_SAMPLE", 256);   // hits sampled per planned partition for the partition boundaries of a wide read (0: 4 096 per read, the rule until round 6 -- a read that plans four partitions does not need them: kernels of C2 23.9 -> 23.3 s, no partition overflowed, profiles/r06g)
       wideEager = getenv("T4_WIDE_EAGER") != nullptr;   // A/B aid: the five wide kernels behind every whole-query round's query kernel, as until round 6
       capLimit = num("T4_AQ_CAP_LIMIT", 0); poolCap = num("T4_AQ_POOL_CAP", 0); candCap = num("T4_AQ_CAND_CAP", 1 << 18);
       // (64 until round 5: with light rounds extendKernel runs behind the whole-query rounds anyway, and a read's 17th overlap is better
       // off there -- profiles/r05e, r05f)
       extendDefer = num("T4_AQ_EXTEND_DEFER", 16);
-      wideMinHits = num("T4_WIDE_MIN_HITS", 4096);   // (8192, the LDS tier's capacity, until round 5: fresh heavy reads now start on the wide pipeline beside the query kernel, so the wide query pays from half of it on -- C2 67.5 -> 61.0 s, profiles/r05e_c2_w4k, r05f)
+      wideMinHits = num("T4_WIDE_MIN_HITS", 3072);   // (round 6: 3 072 -- kernels of C2 23.9 -> 23.6 s, 2 % fewer rounds, profiles/r06g; 4 096 in round 5:)   // (8192, the LDS tier's capacity, until round 5: fresh heavy reads now start on the wide pipeline beside the query kernel, so the wide query pays from half of it on -- C2 67.5 -> 61.0 s, profiles/r05e_c2_w4k, r05f)
     }
   } aqEnv;
   // the wide query (t4_wide.h): pools of the deferred reads of one call, grown on demand

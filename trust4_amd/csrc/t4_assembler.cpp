@@ -598,6 +598,7 @@ struct t4_assembler : IndexListener {
     bool registered = false;     // its k-mers are in winKmers (done beside its first query: nothing looks an entry up before it holds a result)
     unsigned char tier = 0;      // the last query of this read ended on the global-scratch tier
     bool hintPredicted = false;  // tier was set (or left) by a count of the read's emitted hits before its first query (launchOn: the reads of the NEXT whole-query round)
+    unsigned char lastKill = 0;  // why its last result fell whole (0: it never held one; 1 key, 2 list >= 100, 3 region, 4 shift, 5 contig, 6 tolerance, 7 a restricted re-query fell back): reporting only
     bool fragile = false;        // any change of one of its keys' lists invalidates it
     int slack = 0;               // tolerated hit-set changes left before possibleOverlapCnt could pass 100 (SeqSet.hpp:813-823)
     int lastUs = 0;              // what this read's last query took in its workgroup (microseconds; 0: never queried): a launch lasts as long as its slowest read
@@ -639,7 +640,15 @@ struct t4_assembler : IndexListener {
     std::vector<t4_cand> cands;
     bool candOk = false;
     int n4lo[2] = {0, 0}, n4hi[2] = {0, 0}, n5lo[2] = {0, 0}, n5hi[2] = {0, 0}, smlo[2] = {0, 0}, smhi[2] = {0, 0}, minT[2] = {3, 3};
-    int toleratedSince = 0;            // index edits of small groups this entry has tolerated since its whole query (their recorded sizes are bounds from then on)
+    int toleratedSince = 0;            // index edits of small groups this entry has tolerated since its whole query
+    // Are the recorded sizes of the entry's groups still EXACT (the hits the query would emit now)? A tolerated index edit is booked
+    // exactly when the edited k-mer is certain to be emitted by GetHitsFromRead: its list holds fewer than 100 postings before and after
+    // (the repeat-skip rule of SeqSet.hpp:1381-1391 only passes over lists of 100 and more) and the read has no two equal k-mers within
+    // k / 2 + 1 positions (the rule's other test: a k-mer equal to the last one looked up is not looked up again). Any other tolerated
+    // edit leaves the sizes as bounds -- `inexact` -- until the entry's next whole query. While they are exact, the statistics loop of
+    // SeqSet.hpp:784-811 can be repeated on the host at any time (exactStats): an entry whose threshold the query could not certify
+    // against edits of small groups (statsStable false) is then CHECKED after such an edit instead of spending a budget and falling.
+    bool inexact = false, repeatNear = false, checkPending = false;
     std::vector<uint32_t> exactKeys;   // groups whose recorded hit count is exact because a restricted re-query set it (host-derived tables hold supersets)
     bool strand0Plus = false, auxOk = false;
     bool partial = false, merged = false;
@@ -746,15 +755,18 @@ struct t4_assembler : IndexListener {
     return true;
   }
   void rebuildGroup(Cached &e, int c);
-  bool wideQueries = true; int wideHitLimit = 4096;   // what t4_add_query_pool_begin will do with a read of that many emitted hits (set in ensureLanes)
+  bool wideQueries = true; int wideHitLimit = 3072;   // what t4_add_query_pool_begin will do with a read of that many emitted hits (set in ensureLanes)
   int emittedHits(const Cached &e);
+  int64_t headWholeWhy[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t toleranceChecks = 0, toleranceCheckKills = 0;
+  bool exactStats(const Cached &c, int pc, const int32_t *pcSize, int T[2], int e4[2], int e5[2], int big[2]);
   int64_t deltas = 0, deltaBytes = 0, rounds = 0, readsQueried = 0, invKey = 0, invCross = 0, invRegion = 0, invShift = 0, invContig = 0, invFragile = 0, tolerated = 0;
   double secDelta = 0, secGroups = 0, secEvents = 0, secRegister = 0, secPrefetch = 0, secAddTotal = 0;
 
   // testing / development aids, read from the environment ONCE per builder (none changes a result; DESIGN 7b lists them)
   struct Knobs {
-    bool verifyWindow = false, noStableStats = false, wideQueries = true, candStore = true, restrictOn = true, predictHints = true, useMarks = true;
-    int wideHitLimit = 4096;
+    bool verifyWindow = false, noStableStats = false, wideQueries = true, candStore = true, restrictOn = true, predictHints = true, useMarks = true, contigKills = false, exactTolerance = true;
+    int wideHitLimit = 3072;
     int lanes = 1, queryAhead = 0, minBatch = 4, harvestDelay = 0, lightAhead = 0, maxPending = 8;
     FILE *roundLog = nullptr;
     Knobs() {
@@ -763,7 +775,9 @@ struct t4_assembler : IndexListener {
       noStableStats = getenv("T4_NO_STABLE_STATS") != nullptr;  // A/B aid: the budget rule for every entry
       lanes = num("T4_LIVE_LANES", 1); queryAhead = num("T4_QUERY_AHEAD", 0); minBatch = num("T4_LIVE_MIN_BATCH", 4); harvestDelay = num("T4_LIVE_HARVEST_DELAY", 0);
       wideQueries = !getenv("T4_WIDE_OFF") && !getenv("T4_AQ_FORCE_GLOBAL");
-      { const int lim = num("T4_AQ_CAP_LIMIT", 0); wideHitLimit = lim > 0 ? lim : num("T4_WIDE_MIN_HITS", 4096); }
+      { const int lim = num("T4_AQ_CAP_LIMIT", 0); wideHitLimit = lim > 0 ? lim : num("T4_WIDE_MIN_HITS", 3072); }
+      exactTolerance = !getenv("T4_NO_EXACT_TOLERANCE");   // A-B aid: the budget rule for every entry whose query did not certify its threshold (until round 6)
+      contigKills = getenv("T4_CONTIG_KILLS") != nullptr;   // A-B aid: a merge ends every window entry with a hit on the merged contigs (until round 6)
       useMarks = !getenv("T4_NO_MARKS");        // A-B aid: restricted re-queries walk the read's posting lists as in round 4
       predictHints = !getenv("T4_NO_PREDICT");   // A-B aid: no look at the reads of the next whole-query round
       candStore = !getenv("T4_CANDS_OFF");      // testing / A-B aid: the restricted path as round 4 had it (at most 44 candidates, ~100 groups of four hits)
@@ -1672,15 +1686,23 @@ void t4_assembler::registerKmers(Cached &e, int slotId, int shard) {
   const int len = (int)e.read.size();
   if (len >= k) {
     KCode kc(k);
+    uint64_t recent[20]; int nRecent = 0;   // codes of the last k / 2 + 1 valid positions (k <= 31)
+    const int back = k / 2 + 1;
+    bool near = false;
     for (int i = 0; i < len; ++i) {
       kc.append(e.read[i]);
-      if (i < k - 1 || !kc.valid()) continue;
+      if (i < k - 1 || !kc.valid()) { if (i >= k - 1) near = true; continue; }   // (a read with an N: the rule's `last code` runs on over the window of the N -- never booked exactly)
+      if (shard <= 0) {   // (one of the registering threads looks for repeats at short distance: Cached::repeatNear)
+        for (int t = 0; t < nRecent; ++t) if (recent[t] == kc.code) near = true;
+        if (nRecent < back) recent[nRecent++] = kc.code; else { for (int t = 1; t < back; ++t) recent[t - 1] = recent[t]; recent[back - 1] = kc.code; }
+      }
       const int h = index.bucket(kc.code, e.barcode);
       const int sh = shardOf(kc.code, h);
       if (shard >= 0 && sh != shard) continue;
       winShard[sh].add(kc.code, h, KOcc{e.uid, slotId, 1, 0, -1});
       if (shard < 0) winKmerRefs += 1;
     }
+    if (shard <= 0) e.repeatNear = near;
   }
   if (shard >= 0) return;
   ++winKmerLive;
@@ -1845,6 +1867,7 @@ void t4_assembler::processEvents() {
   // from the state its lane's replica holds)
   // the whole result of the entry falls
   auto kill = [&](Cached &e, int64_t &why) {
+    e.lastKill = (unsigned char)(&why == &invKey ? 1 : &why == &invCross ? 2 : &why == &invRegion ? 3 : &why == &invShift ? 4 : &why == &invContig ? 5 : 6);
     if (e.partial) { e.partial = false; e.pendingContig = -1; e.morePending.clear(); if (e.inflight) e.killed = true; ++invalidations; ++why; return; }
     if (e.valid) { e.valid = false; ++invalidations; ++why; }
     else if (e.inflight && !e.killed) { e.killed = true; ++invalidations; ++why; }
@@ -1871,14 +1894,24 @@ void t4_assembler::processEvents() {
       if (!e.standing()) continue;
       if (e.inflight && e.expectWide && !e.hasDev) { kill(e, invContig); continue; }   // its dependency records are still on their way: nothing to examine the change against
       if (e.isPending(ev.c)) {   // (its records and its group of this contig are stale already: any change of it counts)
-        if (ev.kind == 2) kill(e, invContig); else touch(e, ev.c, ev.kind == 0 ? invRegion : invShift);
+        if (ev.kind == 2 && knobs.contigKills) kill(e, invContig); else touch(e, ev.c, ev.kind == 0 ? invRegion : ev.kind == 1 ? invShift : invContig);
         continue;
       }
       const int margin = radius + 2;
       for (uint32_t plus = 0; plus < 2; ++plus) {
         Grp *g = e.findGroup((uint32_t)ev.c * 2u + plus);
         if (!g || g->cnt == 0) continue;
-        if (ev.kind == 2) { kill(e, invContig); break; }
+        if (ev.kind == 2) {
+          // A contig that took part in a merge (SeqSet.hpp:3878-4130: the survivor carries the joined consensus, the others are
+          // released). Until round 6 every entry with a hit on it fell whole -- 35 k entries of config C2, each a whole-query round when it
+          // comes to the head. What such an entry's result takes from the contig is what a restricted re-query asks for again: nothing
+          // of a released contig (it has no posting left), the overlaps with the new consensus of the survivor -- and the removals and
+          // insertions of the merge reach the entry's small groups as index events like any other edit. A group below three hits holds
+          // no candidate (SeqSet.hpp:923-925) and is left to those events.
+          if (knobs.contigKills) { kill(e, invContig); break; }
+          if (g->cnt >= 3 || g->lo <= g->hi) { touch(e, ev.c, invContig); break; }
+          continue;
+        }
         if (g->lo > g->hi) continue;   // no diagonal with three hits: nothing of the contig is read
         if (ev.kind == 0) {
           if (ev.a <= g->hi + margin && ev.b > g->lo - margin) { touch(e, ev.c, invRegion); break; }
@@ -1939,22 +1972,38 @@ void t4_assembler::processEvents() {
       if (p.h != q.h) return p.h < q.h;
       return x < y;
     });
+    static thread_local std::vector<std::pair<uint64_t, int>> longBefore;   // keys whose list held 100 postings or more before this commit (sorted: ordv is)
+    longBefore.clear();
     for (size_t g = 0; g < ordv.size();) {
       size_t e2 = g;
       const IdxEv &first = idxEvents[ordv[g]];
       while (e2 < ordv.size() && idxEvents[ordv[e2]].code == first.code && idxEvents[ordv[e2]].h == first.h) ++e2;
       const uint32_t before = first.delta > 0 ? first.sizeAfter - 1 : first.sizeAfter + 1, after = idxEvents[ordv[e2 - 1]].sizeAfter;
       g = e2;
+      if (before >= 100) longBefore.push_back({first.code, first.h});
       if ((before >= 100) == (after >= 100) && (before > 10000) == (after > 10000)) continue;   // 10000: removeOnlyRepeats / the repeat test of a run (SeqSet.hpp:802, 876, 936)
       forEachOcc(first.code, first.h, [&](const KOcc &o, bool) {
         Cached &e = *pool[o.slot];
         if (e.uid == o.uid) kill(e, invCross);
       });
     }
+    static thread_local std::vector<int> checkSlots;   // entries whose threshold is checked by repeating the statistics loop once this commit's edits are booked
+    checkSlots.clear();
     for (const IdxEv &ev : net) {
+      // is the edited k-mer certain to be emitted by GetHitsFromRead (Cached::inexact)? its list below 100 postings before the commit
+      // and now (an edit that crosses 100 has ended the entries above; a move leaves the size as it is) -- looked up when first asked for
+      int shortList = -1;
+      const auto listIsShort = [&]() {
+        if (shortList < 0) {
+          const ListRef *l = index.find(ev.code, ev.h);
+          shortList = (!l || l->cnt < 100u) && !std::binary_search(longBefore.begin(), longBefore.end(), std::make_pair(ev.code, ev.h)) ? 1 : 0;
+        }
+        return shortList == 1;
+      };
       forEachOcc(ev.code, ev.h, [&](const KOcc &o, bool onForward) {
         Cached &e = *pool[o.slot];
         if (e.uid != o.uid || !e.standing()) return;
+        if ((e.strand == 1 && !onForward) || (e.strand == -1 && onForward)) return;   // (a strand the query of this read does not search: SeqSet.hpp:1352-1356)
         if (e.inflight && e.expectWide && !e.hasDev) { kill(e, invKey); return; }
         if (e.fragile) { kill(e, invFragile); ++invLongLists; return; }
         if (e.isPending(ev.idx)) { touch(e, ev.idx, invKey); return; }
@@ -1968,13 +2017,31 @@ void t4_assembler::processEvents() {
           } else {
             Grp *g = e.findGroup((uint32_t)ev.idx * 2u + plus);
             if (g && g->cnt >= 3) { touch(e, ev.idx, invKey); break; }
-            if (g && !e.hasDev) g->cnt = g->cnt > (uint32_t)n ? g->cnt - (uint32_t)n : 0;   // (device records count emitted hits: see Cached::devGroups)
+            // (device records count emitted hits, see Cached::devGroups: a removal is subtracted from them only when the k-mer is certain to have been emitted)
+            if (g && (!e.hasDev || (!e.inexact && !e.repeatNear && listIsShort()))) g->cnt = g->cnt > (uint32_t)n ? g->cnt - (uint32_t)n : 0;
           }
           ++tolerated; ++e.toleratedSince;
+          if (e.hasDev && !e.inexact && (e.repeatNear || !listIsShort())) e.inexact = true;
           if (e.statsStable) { ++toleratedStable; continue; }   // exact: the statistics of this read's query cannot move (overlapsFromKeys)
+          if (knobs.exactTolerance && e.hasDev && !e.inexact && e.candOk) {   // the statistics loop decides, below
+            if (!e.checkPending) { e.checkPending = true; checkSlots.push_back(o.slot); }
+            continue;
+          }
           if (--e.slack < 0) { kill(e, invFragile); break; }
         }
       });
+    }
+    // The entries that took an edit of a small group which their query could not certify harmless, and whose group sizes are exact: the
+    // statistics loop of SeqSet.hpp:784-811 over the sizes as they are now. The same novelMinHitRequired on both strands: every
+    // candidate run is judged as before (866, 923) and the result stands. (An entry that waits for a restricted re-query is settled
+    // when its records arrive: mergeRestricted.)
+    for (int sl : checkSlots) {
+      Cached &e = *pool[sl];
+      e.checkPending = false;
+      if (!e.valid) continue;
+      int T[2], e4[2], e5[2], big[2];
+      ++toleranceChecks;
+      if (e.inexact || !exactStats(e, -1, nullptr, T, e4, e5, big) || T[0] != e.minT[0] || T[1] != e.minT[1]) { kill(e, invFragile); ++toleranceCheckKills; }
     }
     idxEvents.clear();
     ts.lap(TS_EVENTS_INDEX);
@@ -2007,10 +2074,10 @@ void t4_assembler::announceLive(int n, const char *const *reads, const int *stra
     c.read = reads[i]; c.strand = strands[i]; c.barcode = barcodes ? barcodes[i] : -1; c.skip = repetitive; c.cnt = 0; c.valid = false;
     c.inflight = false; c.killed = false; c.shifts.clear();
     c.ov.clear(); c.ext.clear(); c.extRet.clear();
-    c.uid = nextUid++; c.tier = 0; c.hintPredicted = false; c.lastUs = 0; c.registered = false;
+    c.uid = nextUid++; c.tier = 0; c.hintPredicted = false; c.lastUs = 0; c.registered = false; c.lastKill = 0;
     c.hasDev = false; c.expectWide = false; c.devGroups.clear();
     c.partial = false; c.pendingContig = -1; c.merged = false; c.auxOk = false; c.restrictedCount = 0; c.kmerPos.clear();
-    c.cands.clear(); c.candOk = false; c.exactKeys.clear(); c.morePending.clear();
+    c.cands.clear(); c.candOk = false; c.exactKeys.clear(); c.morePending.clear(); c.inexact = false; c.repeatNear = false; c.checkPending = false;
     order.push_back(sl);
   }
 }
@@ -2185,6 +2252,56 @@ void t4_assembler::replayScan(const std::vector<t4_cand> &cands, const std::vect
   }
 }
 
+// The statistics loop of SeqSet.hpp:784-811 repeated over an entry's groups as they stand: the query's own dependency records (every
+// group with its emitted hits, in the reference's order -- minus strand by contig, then plus strand), the groups restricted re-queries
+// and exactly booked index edits have added or resized since (the host's table), and -- pc >= 0 -- contig pc's two groups at the sizes
+// pcSize[0 / 1] a re-query has just reported. Including the loop's `i = j; ++i` stepping: a group that follows a measured one is measured
+// from its second hit, a one-hit group there vanishes. False when the entry's sizes are not exact (Cached::inexact, no device records).
+// Out: novelMinHitRequired per strand (813-823), groups of >= 4 / >= 5 hits and the largest group (true sizes).
+bool t4_assembler::exactStats(const Cached &c, int pc, const int32_t *pcSize, int T[2], int e4[2], int e5[2], int big[2]) {
+  if (!c.hasDev || c.inexact) return false;
+  struct Extra { uint32_t key; int cnt; };
+  static thread_local std::vector<Extra> extra;   // groups that are not among the device records
+  extra.clear();
+  const Grp *d0 = c.devGroups.data(), *d1 = d0 + c.devGroups.size();
+  for (const Grp &g : c.groups.t) if (g.key != 0xFFFFFFFFu && (pc < 0 || (g.key >> 1) != (uint32_t)pc)) extra.push_back(Extra{g.key, (int)g.cnt});
+  if (pc >= 0)
+    for (int t = 0; t < 2; ++t) {
+      const uint32_t key = (uint32_t)pc * 2u + (uint32_t)t;
+      const Grp *g = const_cast<Cached &>(c).findGroup(key);
+      if (!(g && g >= d0 && g < d1)) extra.push_back(Extra{key, pcSize[t]});
+    }
+  std::sort(extra.begin(), extra.end(), [](const Extra &a, const Extra &b) { return (a.key & 1u) != (b.key & 1u) ? (a.key & 1u) < (b.key & 1u) : a.key < b.key; });
+  int possible[2] = {0, 0}, longest[2] = {0, 0};
+  e4[0] = e4[1] = e5[0] = e5[1] = big[0] = big[1] = 0;
+  bool skip = false;
+  size_t xe = 0;
+  auto visit = [&](uint32_t key, int n) {
+    if (n <= 0) return;
+    const int plus = (int)(key & 1u);
+    const int m = n - (skip ? 1 : 0);
+    if (m > 0) { if (m > 3) ++possible[plus]; if (m > longest[plus]) longest[plus] = m; }
+    skip = !(skip && n == 1);
+    if (n >= 4) ++e4[plus];
+    if (n >= 5) ++e5[plus];
+    if (n > big[plus]) big[plus] = n;
+  };
+  auto before = [](uint32_t a, uint32_t b) { return (a & 1u) != (b & 1u) ? (a & 1u) < (b & 1u) : a < b; };
+  for (const Grp *g = d0; g < d1; ++g) {
+    while (xe < extra.size() && before(extra[xe].key, g->key)) { visit(extra[xe].key, extra[xe].cnt); ++xe; }
+    visit(g->key, pc >= 0 && (g->key >> 1) == (uint32_t)pc ? pcSize[(int)(g->key & 1u)] : (int)g->cnt);
+  }
+  while (xe < extra.size()) { visit(extra[xe].key, extra[xe].cnt); ++xe; }
+  for (int t = 0; t < 2; ++t) {
+    T[t] = 3;
+    if (possible[t] > 100000) T[t] = (int)(longest[t] * 0.75);
+    else if (possible[t] > 10000) T[t] = longest[t] / 2;
+    else if (possible[t] > 1000) T[t] = longest[t] / 3;
+    else if (possible[t] > 100) T[t] = longest[t] / 4;
+  }
+  return true;
+}
+
 // A restricted re-query of contig pc came back for an entry that holds its candidate list: nc[0 .. ncnt) are ALL overlaps of the read
 // with pc (scored; ov / ex / rets are their result records, same order), s8 the true sizes of pc's two hit groups. Returns false
 // when the entry needs its whole query again. Three things are settled here, in this order: the threshold novelMinHitRequired under
@@ -2239,47 +2356,11 @@ bool t4_assembler::mergeRestricted(Cached &c, int pc, int k2, const t4_overlap *
     // contig, then plus strand) and no index edit of a small group has been tolerated since, the statistics loop of
     // SeqSet.hpp:784-811 is repeated exactly over them, with pc's groups at their new sizes -- including its `i = j; ++i` stepping
     // (a group that follows a measured one is measured from its second hit; a one-hit group there vanishes).
-    if (!c.hasDev || c.toleratedSince != 0) { ++candFallbackStats; return false; }
-    struct Extra { uint32_t key; int cnt; };
-    std::vector<Extra> extra;   // groups that are not among the device records: earlier restricted re-queries put them into the table
-    for (uint32_t key : c.exactKeys) {
-      const Grp *g = c.findGroup(key);
-      if (g && !(g >= c.devGroups.data() && g < c.devGroups.data() + c.devGroups.size()) && (key >> 1) != (uint32_t)pc) extra.push_back(Extra{key, (int)g->cnt});
-    }
+    int Tx[2], e4[2], e5[2], big[2];
+    if (!exactStats(c, pc, s8 + 4, Tx, e4, e5, big)) { ++candFallbackStats; return false; }
     for (int t = 0; t < 2; ++t) {
-      const uint32_t key = (uint32_t)pc * 2u + (uint32_t)t;
-      const Grp *g = c.findGroup(key);
-      if (!(g && g >= c.devGroups.data() && g < c.devGroups.data() + c.devGroups.size())) extra.push_back(Extra{key, s8[4 + t]});
-    }
-    std::sort(extra.begin(), extra.end(), [](const Extra &a, const Extra &b) { return (a.key & 1u) != (b.key & 1u) ? (a.key & 1u) < (b.key & 1u) : a.key < b.key; });
-    int possible[2] = {0, 0}, longest[2] = {0, 0}, e4[2] = {0, 0}, e5[2] = {0, 0}, big[2] = {0, 0};
-    bool skip = false;
-    size_t xe = 0;
-    auto visit = [&](uint32_t key, int n) {
-      if (n <= 0) return;
-      const int plus = (int)(key & 1u);
-      const int m = n - (skip ? 1 : 0);
-      if (m > 0) { if (m > 3) ++possible[plus]; if (m > longest[plus]) longest[plus] = m; }
-      skip = !(skip && n == 1);
-      if (n >= 4) ++e4[plus];
-      if (n >= 5) ++e5[plus];
-      if (n > big[plus]) big[plus] = n;
-    };
-    auto before = [](uint32_t a, uint32_t b) { return (a & 1u) != (b & 1u) ? (a & 1u) < (b & 1u) : a < b; };
-    for (size_t q = 0; q < c.devGroups.size(); ++q) {
-      const Grp &g = c.devGroups[q];
-      while (xe < extra.size() && before(extra[xe].key, g.key)) { visit(extra[xe].key, extra[xe].cnt); ++xe; }
-      visit(g.key, (g.key >> 1) == (uint32_t)pc ? s8[4 + (int)(g.key & 1u)] : (int)g.cnt);
-    }
-    while (xe < extra.size()) { visit(extra[xe].key, extra[xe].cnt); ++xe; }
-    for (int t = 0; t < 2; ++t) {
-      int T = 3;
-      if (possible[t] > 100000) T = (int)(longest[t] * 0.75);
-      else if (possible[t] > 10000) T = longest[t] / 2;
-      else if (possible[t] > 1000) T = longest[t] / 3;
-      else if (possible[t] > 100) T = longest[t] / 4;
-      if (T < c.minT[t]) { ++candFallbackStats; return false; }   // a LOWER threshold lets runs in that no record of this entry describes
-      newT[t] = T;
+      if (Tx[t] < c.minT[t]) { ++candFallbackStats; return false; }   // a LOWER threshold lets runs in that no record of this entry describes
+      newT[t] = Tx[t];
       n4lo[t] = n4hi[t] = e4[t]; n5lo[t] = n5hi[t] = e5[t]; smlo[t] = smhi[t] = big[t];
     }
     ++candExactStats;
@@ -2515,7 +2596,7 @@ int t4_assembler::harvest(Lane &L) {
         }
       }
       ts.lap(TS_HARVEST_MERGE);
-      if (fell) { c.partial = false; c.pendingContig = -1; c.morePending.clear(); ++restrictedFallbacks; continue; }   // neither valid nor partial: the whole query, next launch
+      if (fell) { c.partial = false; c.pendingContig = -1; c.morePending.clear(); c.lastKill = 7; ++restrictedFallbacks; continue; }   // neither valid nor partial: the whole query, next launch
       c.merged = true;
       if (c.pendingContig < 0) { c.partial = false; c.valid = true; }   // (else a contig joined while the launch was out: the entry goes on waiting for that one)
       continue;
@@ -2542,7 +2623,7 @@ int t4_assembler::harvest(Lane &L) {
       for (const auto &sh : shiftsOfCall) for (t4_cand &o : c.cands) if (o.seqIdx == sh.first) { o.ss += sh.second; o.se += sh.second; }
       const int32_t *s8 = stats8 + T4_QUERY_STATS * (size_t)i;
       for (int t = 0; t < 2; ++t) { c.n4lo[t] = c.n4hi[t] = s8[t]; c.n5lo[t] = c.n5hi[t] = s8[2 + t]; c.smlo[t] = c.smhi[t] = s8[4 + t]; c.minT[t] = s8[6 + t] > 0 ? s8[6 + t] : 3; }
-      c.candOk = true; c.toleratedSince = 0; candRecords += c.nAll;
+      c.candOk = true; c.toleratedSince = 0; c.inexact = false; candRecords += c.nAll;
       if (knobs.verifyWindow && c.cnt >= 0) {   // the host's scan against the kernel's: the same cuts, the same survivors of the similarity cut
         std::vector<unsigned char> cut;
         replayScan(c.cands, seqs, (int)c.read.size(), radius, 0.95, cut);
@@ -2641,6 +2722,7 @@ int t4_assembler::pumpLive(bool needHead, int repetitive) {
         hitsAtLastRound = cacheHits;
         if (launchesUrgent > 0) runEma = 0.8 * runEma + 0.2 * served;
       }
+      if (!head.partial) ++headWholeWhy[head.lastKill & 7];   // (what stalls the chain for a whole-query round)
       if ((rc = launchOn(*free1, mine, repetitive))) return rc;
       ++launchesUrgent; launched = true;
       if (!other.empty() && idle >= 2) for (Lane &L : lanes) if (!L.busy) { if ((rc = launchOn(L, other, repetitive))) return rc; break; }
@@ -2913,6 +2995,9 @@ int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n) {
     }
     fprintf(stderr, "timing: query lanes %d: %lld launches (%lld for a head without a result, %lld of them without the whole queries of entries further back), %lld waits for the head's lane in %.3f s, %lld queries killed in flight\n",
             (int)a->lanes.size(), (long long)a->launches, (long long)a->launchesUrgent, (long long)a->lightRounds, (long long)a->headWaits, a->secHeadWait, (long long)a->killedInFlight);
+    fprintf(stderr, "timing: rounds whose head waited for a WHOLE query: %lld never queried before, fallen to a change of: a key %lld, a list crossing 100 / 10000 postings %lld, a region %lld, a shift %lld, a whole contig %lld, the tolerance budget %lld, a restricted re-query that fell back %lld\n",
+            (long long)a->headWholeWhy[0], (long long)a->headWholeWhy[1], (long long)a->headWholeWhy[2], (long long)a->headWholeWhy[3], (long long)a->headWholeWhy[4], (long long)a->headWholeWhy[5], (long long)a->headWholeWhy[6], (long long)a->headWholeWhy[7]);
+    fprintf(stderr, "timing: thresholds checked after an edit of a small group by repeating the statistics loop: %lld entries, %lld of them fell\n", (long long)a->toleranceChecks, (long long)a->toleranceCheckKills);
     fprintf(stderr, "timing: tolerated index edits %lld, of which %lld met an entry whose group statistics cannot move (no budget spent); tolerance kills %lld, of which %lld for lists beyond 10000 postings\n",
             (long long)a->tolerated, (long long)a->toleratedStable, (long long)a->invFragile, (long long)a->invLongLists);
     fprintf(stderr, "timing: restricted re-queries: %lld entries kept their other contigs when one contig changed, %lld merged, %lld fell back to the whole query, %lld in flight met another change of their contig\n",
