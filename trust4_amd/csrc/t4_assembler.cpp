@@ -569,6 +569,7 @@ struct TscSections {
   double secondsPerTick() const { const double w = std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count(); const uint64_t d = t4Tick() - tStart; return d ? w / (double)d : 0; }
 };
 
+#define T4_MAX_READ_KMERS 512   // k-mer positions of a read (reads are at most 384 bases: t4_device.h T4_MAXL)
 struct t4_cellset;
 struct t4_assembler : IndexListener {
   TscSections ts;
@@ -611,6 +612,8 @@ struct t4_assembler : IndexListener {
     std::vector<Grp> devGroups;
     size_t devSplit = 0;          // first plus-strand record
     bool hasDev = false;
+    std::vector<Grp> dbgGroups;   // T4_VERIFY_WINDOW: what buildGroups derives for a read the wide query serves
+    bool hostRecords = false;     // ... derived on the host (buildGroups: the emitted hits of a read of the LDS tier), not returned by the wide query
     bool expectWide = false;      // the launch expects the wide query to serve this read: no table derived beside the launch
     Grp *findGroup(uint32_t key) {
       if (hasDev) {
@@ -649,6 +652,12 @@ struct t4_assembler : IndexListener {
     // SeqSet.hpp:784-811 can be repeated on the host at any time (exactStats): an entry whose threshold the query could not certify
     // against edits of small groups (statsStable false) is then CHECKED after such an edit instead of spending a budget and falling.
     bool inexact = false, repeatNear = false, checkPending = false;
+    // Which k-mer positions GetHitsFromRead LOOKS UP and does not pass over (SeqSet.hpp:1367-1391), per strand (0: the read as given,
+    // 1: its reverse complement), replayed on the host against the index the entry's query ran on (buildGroups / emittedHits). The
+    // decisions only move when a list crosses 100 postings, which ends the entry (processEvents); until then an index edit of a key
+    // changes this read's hits exactly at the occurrences whose position is in the mask -- and not at all at the others.
+    uint64_t emitMask[2][(T4_MAX_READ_KMERS + 63) / 64];
+    bool maskOk = false;
     std::vector<uint32_t> exactKeys;   // groups whose recorded hit count is exact because a restricted re-query set it (host-derived tables hold supersets)
     bool strand0Plus = false, auxOk = false;
     bool partial = false, merged = false;
@@ -673,7 +682,7 @@ struct t4_assembler : IndexListener {
   int threads = 1;
   std::unique_ptr<HelperPool> helpers;
   int64_t nextUid = 1;
-  struct KOcc { int64_t uid; int slot; unsigned char f, r; int next; };   // occurrences of a key in a window read, forward / reverse-complement
+  struct KOcc { int64_t uid; int slot; unsigned char f, r; short pos; int next; };   // an occurrence of a key in a window read: the k-mer of the read as given that starts at pos (its reverse complement is the k-mer of the reverse strand at len - k - pos)
   // inverted map key -> window reads that hold it: open addressing on (code, bucket), chains of KOcc nodes; references of
   // retired reads stay (their uid no longer matches) until the map is rebuilt
   struct WinKmers {
@@ -756,9 +765,9 @@ struct t4_assembler : IndexListener {
   }
   void rebuildGroup(Cached &e, int c);
   bool wideQueries = true; int wideHitLimit = 3072;   // what t4_add_query_pool_begin will do with a read of that many emitted hits (set in ensureLanes)
-  int emittedHits(const Cached &e);
+  int emittedHits(Cached &e);
   int64_t headWholeWhy[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int64_t toleranceChecks = 0, toleranceCheckKills = 0;
+  int64_t toleranceChecks = 0, toleranceCheckKills = 0, groupSelfChecks = 0;
   bool exactStats(const Cached &c, int pc, const int32_t *pcSize, int T[2], int e4[2], int e5[2], int big[2]);
   int64_t deltas = 0, deltaBytes = 0, rounds = 0, readsQueried = 0, invKey = 0, invCross = 0, invRegion = 0, invShift = 0, invContig = 0, invFragile = 0, tolerated = 0;
   double secDelta = 0, secGroups = 0, secEvents = 0, secRegister = 0, secPrefetch = 0, secAddTotal = 0;
@@ -1699,7 +1708,7 @@ void t4_assembler::registerKmers(Cached &e, int slotId, int shard) {
       const int h = index.bucket(kc.code, e.barcode);
       const int sh = shardOf(kc.code, h);
       if (shard >= 0 && sh != shard) continue;
-      winShard[sh].add(kc.code, h, KOcc{e.uid, slotId, 1, 0, -1});
+      winShard[sh].add(kc.code, h, KOcc{e.uid, slotId, 1, 0, (short)(i - k + 1), -1});
       if (shard < 0) winKmerRefs += 1;
     }
     if (shard <= 0) e.repeatNear = near;
@@ -1761,12 +1770,15 @@ void t4_assembler::rebuildGroup(Cached &e, int c) {
 // the list sizes of its k-mers under the repeat-skip rule (a list of 100+ postings is passed over while fewer than k / 2 were since
 // the last emitted one; a k-mer equal to the last one not passed over is not looked up again). What the query kernel's seed stage
 // will find, so that the launch knows which reads the wide query will serve.
-int t4_assembler::emittedHits(const Cached &e) {
+int t4_assembler::emittedHits(Cached &e) {
   std::string rcs;
   reverseComplement(rcs, e.read);
   const int len = (int)e.read.size(), skipLimit = k / 2;
+  memset(e.emitMask, 0, sizeof e.emitMask);
+  e.maskOk = len - k + 1 <= T4_MAX_READ_KMERS;
   if (len < k) return 0;
   int64_t H = 0;
+  bool huge = false;
   uint64_t prev = 0;
   for (int st = 0; st < 2; ++st) {
     if (st == 0 ? e.strand == -1 : e.strand == 1) continue;
@@ -1780,14 +1792,16 @@ int t4_assembler::emittedHits(const Cached &e) {
         const ListRef *l = kc.valid() ? index.find(kc.code, index.bucket(kc.code, e.barcode)) : nullptr;
         const uint32_t size = l ? l->cnt : 0;
         if (size >= 100 && i != k - 1 && i != len - 1 && skipCnt < skipLimit) { ++skipCnt; continue; }
+        if (size >= 100 && e.skip) continue;   // allowTotalSkip (repetitive data, --trimLevel 2: SeqSet.hpp:1392-1393)
         skipCnt = 0;
+        if (e.maskOk) e.emitMask[st][(i - k + 1) >> 6] |= 1ull << ((i - k + 1) & 63);   // looked up, not passed over (Cached::emitMask)
         H += size;
-        if (size > 10000) return 0x7FFFFFFF;   // a list beyond 10000 postings: the wide query whatever the total (removeOnlyRepeats)
+        if (size > 10000) huge = true;   // a list beyond 10000 postings: the wide query whatever the total (removeOnlyRepeats)
       }
       prev = kc.code;
     }
   }
-  return H > 0x7FFFFFFF ? 0x7FFFFFFF : (int)H;
+  return huge || H > 0x7FFFFFFF ? 0x7FFFFFFF : (int)H;
 }
 
 // Hits of the read per (strand, contig) against the current index (host replica; read-only here): the number of hits, and the
@@ -1796,47 +1810,64 @@ int t4_assembler::emittedHits(const Cached &e) {
 // everything the query then reads of the contig (gap DPs, ExtendOverlap, the distance tests to the contig ends) lies within
 // the read's projection along that diagonal +- radius.
 void t4_assembler::buildGroups(Cached &e) {
+  // Round 6: the hits GetHitsFromRead EMITS (SeqSet.hpp:1341-1501 with its repeat-skip rule replayed: a list of 100+ postings is passed
+  // over while fewer than k / 2 were since the last emitted one, a k-mer equal to the last one looked up is not looked up again; the
+  // strands the query searches; the barcode filter of a set that holds several barcodes) -- the records the wide query returns for the
+  // reads it serves, derived here for a read of the LDS tier: same content, same order (devGroups), so that every rule that holds for
+  // device records holds for these (exact sizes: Cached::inexact, exactStats). Until round 6 this table counted every posting of every
+  // k-mer of both strands -- a superset that cost thousands of postings per k-mer of a shared gene segment and pinned nothing down.
   std::string rcs;
   reverseComplement(rcs, e.read);
-  const int len = (int)e.read.size();
-  // (contig, strand, start of the read on the contig) -> hits, in a scratch table of this thread (a list of 100+ postings
-  // brings thousands of hits that the kernel's repeat skipping drops: counting must not cost a sort)
+  const int len = (int)e.read.size(), skipLimit = k / 2;
   struct Slot { uint64_t key; uint32_t cnt; };
   static thread_local std::vector<Slot> tab;
   static thread_local std::vector<uint32_t> usedSlots;
+  struct Emit { const ListRef *l; int a; uint32_t plus; };
+  static thread_local std::vector<Emit> emits;
+  emits.clear();
   size_t nPost = 0;
   uint32_t maxList = 0;
-  for (int pass = 0; pass < 2; ++pass) {   // pass 0 sizes the table, pass 1 fills it
-    if (pass == 1) {
-      size_t sz = 1024;
-      while (sz < 2 * nPost + 2) sz <<= 1;
-      if (tab.size() < sz) tab.assign(sz, Slot{~0ull, 0});
-      usedSlots.clear();
-    }
-    const size_t mask = tab.size() - 1;
-    for (int st = 0; st < 2; ++st) {
-      const std::string &r = st ? rcs : e.read;
-      if ((int)r.size() < k) continue;
-      const uint64_t plus = st ? 0u : 1u;
-      KCode kc(k);
-      for (int i = 0; i < (int)r.size(); ++i) {
-        kc.append(r[i]);
-        if (i < k - 1 || !kc.valid()) continue;
-        const ListRef *l = index.find(kc.code, index.bucket(kc.code, e.barcode));
-        if (!l) continue;
-        if (pass == 0) { nPost += l->cnt; if (l->cnt > maxList) maxList = l->cnt; continue; }
-        const int a = i - k + 1;
-        for (uint32_t t = 0; t < l->cnt; ++t) {
-          const Post &p = index.arena[l->start + t];
-          const uint64_t key = (((uint64_t)(uint32_t)p.idx * 2u + plus) << 32) | (uint32_t)(p.offset - a + (1 << 30));
-          size_t s2 = (size_t)mix64h(key) & mask;
-          while (tab[s2].key != key && tab[s2].key != ~0ull) s2 = (s2 + 1) & mask;
-          if (tab[s2].key == ~0ull) { tab[s2].key = key; tab[s2].cnt = 0; usedSlots.push_back((uint32_t)s2); }
-          ++tab[s2].cnt;
-        }
+  uint64_t prev = 0;
+  memset(e.emitMask, 0, sizeof e.emitMask);
+  e.maskOk = len - k + 1 <= T4_MAX_READ_KMERS;
+  for (int st = 0; st < 2 && len >= k; ++st) {
+    if (st == 0 ? e.strand == -1 : e.strand == 1) continue;
+    const std::string &r = st ? rcs : e.read;
+    KCode kc(k);
+    int skipCnt = 0;
+    for (int i = 0; i < len; ++i) {
+      kc.append(r[i]);
+      if (i < k - 1) continue;
+      if (i == k - 1 || prev != kc.code) {
+        const ListRef *l = kc.valid() ? index.find(kc.code, index.bucket(kc.code, e.barcode)) : nullptr;
+        const uint32_t size = l ? l->cnt : 0;
+        if (size > maxList) maxList = size;
+        if (size >= 100 && i != k - 1 && i != len - 1 && skipCnt < skipLimit) { ++skipCnt; continue; }
+        if (size >= 100 && e.skip) continue;   // allowTotalSkip (repetitive data, --trimLevel 2: SeqSet.hpp:1392-1393)
+        skipCnt = 0;
+        if (e.maskOk) e.emitMask[st][(i - k + 1) >> 6] |= 1ull << ((i - k + 1) & 63);   // looked up, not passed over (Cached::emitMask)
+        if (size) { emits.push_back(Emit{l, i - k + 1, st ? 0u : 1u}); nPost += size; }
       }
+      prev = kc.code;
     }
   }
+  {
+    size_t sz = 1024;
+    while (sz < 2 * nPost + 2) sz <<= 1;
+    if (tab.size() < sz) tab.assign(sz, Slot{~0ull, 0});
+    usedSlots.clear();
+  }
+  const size_t mask = tab.size() - 1;
+  for (const Emit &em : emits)
+    for (uint32_t t = 0; t < em.l->cnt; ++t) {
+      const Post &p = index.arena[em.l->start + t];
+      if (e.barcode != -1 && seqs[(size_t)p.idx].barcode != e.barcode) continue;   // (SeqSet.hpp:1418)
+      const uint64_t key = (((uint64_t)(uint32_t)p.idx * 2u + em.plus) << 32) | (uint32_t)(p.offset - em.a + (1 << 30));
+      size_t s2 = (size_t)mix64h(key) & mask;
+      while (tab[s2].key != key && tab[s2].key != ~0ull) s2 = (s2 + 1) & mask;
+      if (tab[s2].key == ~0ull) { tab[s2].key = key; tab[s2].cnt = 0; usedSlots.push_back((uint32_t)s2); }
+      ++tab[s2].cnt;
+    }
   e.groups.reset((uint32_t)(usedSlots.size() < 64 ? 64 : usedSlots.size()));
   for (uint32_t s2 : usedSlots) {
     const Slot &x = tab[s2];
@@ -1849,8 +1880,15 @@ void t4_assembler::buildGroups(Cached &e) {
     }
   }
   for (uint32_t s2 : usedSlots) tab[s2].key = ~0ull;   // leave the scratch table empty
+  // the records in the order of the device's: minus strand (even keys) by contig, then plus strand
+  e.devGroups.clear();
   int u4 = 0;
-  for (const Grp &g : e.groups.t) if (g.key != 0xFFFFFFFFu && g.cnt >= 4) ++u4;
+  for (const Grp &g : e.groups.t) if (g.key != 0xFFFFFFFFu) { e.devGroups.push_back(g); if (g.cnt >= 4) ++u4; }
+  std::sort(e.devGroups.begin(), e.devGroups.end(), [](const Grp &a, const Grp &b) { return (a.key & 1u) != (b.key & 1u) ? (a.key & 1u) < (b.key & 1u) : a.key < b.key; });
+  e.devSplit = 0;
+  while (e.devSplit < e.devGroups.size() && !(e.devGroups[e.devSplit].key & 1u)) ++e.devSplit;
+  e.hasDev = true; e.hostRecords = true;
+  e.groups.reset(16);
   // possibleOverlapCnt counts groups measured at more than 3 hits (SeqSet.hpp:784-810); while it cannot pass 100 the
   // group statistics of GetOverlapsFromHits leave novelMinHitRequired at 3 whatever small groups come and go
   e.slack = 99 - u4;               // negative: no tolerated edit at all (the statistics are live for this read)
@@ -2004,6 +2042,10 @@ void t4_assembler::processEvents() {
         Cached &e = *pool[o.slot];
         if (e.uid != o.uid || !e.standing()) return;
         if ((e.strand == 1 && !onForward) || (e.strand == -1 && onForward)) return;   // (a strand the query of this read does not search: SeqSet.hpp:1352-1356)
+        if (e.maskOk) {   // (a position GetHitsFromRead passes over, or does not look up again: no hit of this read changes with the list)
+          const int lenk = (int)e.read.size() - k, sp = onForward ? (int)o.pos : lenk - (int)o.pos;
+          if (sp < 0 || sp > lenk || !((e.emitMask[onForward ? 0 : 1][sp >> 6] >> (sp & 63)) & 1ull)) return;
+        }
         if (e.inflight && e.expectWide && !e.hasDev) { kill(e, invKey); return; }
         if (e.fragile) { kill(e, invFragile); ++invLongLists; return; }
         if (e.isPending(ev.idx)) { touch(e, ev.idx, invKey); return; }
@@ -2018,10 +2060,10 @@ void t4_assembler::processEvents() {
             Grp *g = e.findGroup((uint32_t)ev.idx * 2u + plus);
             if (g && g->cnt >= 3) { touch(e, ev.idx, invKey); break; }
             // (device records count emitted hits, see Cached::devGroups: a removal is subtracted from them only when the k-mer is certain to have been emitted)
-            if (g && (!e.hasDev || (!e.inexact && !e.repeatNear && listIsShort()))) g->cnt = g->cnt > (uint32_t)n ? g->cnt - (uint32_t)n : 0;
+            if (g && (!e.hasDev || (!e.inexact && (e.maskOk || (!e.repeatNear && listIsShort()))))) g->cnt = g->cnt > (uint32_t)n ? g->cnt - (uint32_t)n : 0;
           }
           ++tolerated; ++e.toleratedSince;
-          if (e.hasDev && !e.inexact && (e.repeatNear || !listIsShort())) e.inexact = true;
+          if (e.hasDev && !e.inexact && !e.maskOk && (e.repeatNear || !listIsShort())) e.inexact = true;
           if (e.statsStable) { ++toleratedStable; continue; }   // exact: the statistics of this read's query cannot move (overlapsFromKeys)
           if (knobs.exactTolerance && e.hasDev && !e.inexact && e.candOk) {   // the statistics loop decides, below
             if (!e.checkPending) { e.checkPending = true; checkSlots.push_back(o.slot); }
@@ -2075,9 +2117,9 @@ void t4_assembler::announceLive(int n, const char *const *reads, const int *stra
     c.inflight = false; c.killed = false; c.shifts.clear();
     c.ov.clear(); c.ext.clear(); c.extRet.clear();
     c.uid = nextUid++; c.tier = 0; c.hintPredicted = false; c.lastUs = 0; c.registered = false; c.lastKill = 0;
-    c.hasDev = false; c.expectWide = false; c.devGroups.clear();
+    c.hasDev = false; c.hostRecords = false; c.expectWide = false; c.devGroups.clear(); c.dbgGroups.clear();
     c.partial = false; c.pendingContig = -1; c.merged = false; c.auxOk = false; c.restrictedCount = 0; c.kmerPos.clear();
-    c.cands.clear(); c.candOk = false; c.exactKeys.clear(); c.morePending.clear(); c.inexact = false; c.repeatNear = false; c.checkPending = false;
+    c.cands.clear(); c.candOk = false; c.exactKeys.clear(); c.morePending.clear(); c.inexact = false; c.repeatNear = false; c.checkPending = false; c.maskOk = false;
     order.push_back(sl);
   }
 }
@@ -2111,7 +2153,7 @@ int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive
     c.inflight = true; c.killed = false; c.shifts.clear();
     if (c.partial) { anyOnly = true; continue; }   // restricted re-query: the entry keeps what it holds of the other contigs
     c.statsStable = false;
-    c.hasDev = false; c.expectWide = false; c.devGroups.clear();
+    c.hasDev = false; c.hostRecords = false; c.expectWide = false; c.devGroups.clear(); c.dbgGroups.clear();
     c.auxOk = false; c.merged = false; c.restrictedCount = 0;
     c.cands.clear(); c.candOk = false; c.exactKeys.clear();
   }
@@ -2158,7 +2200,11 @@ int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive
       if (e.partial) continue;   // (its group of the one contig is rebuilt when the records arrive)
       // a read whose emitted hits outgrow the LDS tier is served by the wide query, which returns its dependency records itself
       // (deriving them here would cost several times the query: every posting of every k-mer, the ones the repeat-skip rule passes over included)
-      if (wideQueries && !repetitive && e.barcode == -1 && emittedHits(e) > wideHitLimit) { e.expectWide = true; e.groups.reset(16); e.slack = -1; e.fragile = true; }
+      if (wideQueries && !repetitive && e.barcode == -1 && emittedHits(e) > wideHitLimit) {
+        // (T4_VERIFY_WINDOW: the host's replay of the emitted hits is derived all the same and held against the wide query's records when they arrive)
+        if (knobs.verifyWindow) { buildGroups(e); e.dbgGroups.swap(e.devGroups); e.devGroups.clear(); e.hasDev = false; e.hostRecords = false; }
+        e.expectWide = true; e.groups.reset(16); e.slack = -1; e.fragile = true;
+      }
       else buildGroups(e);
     }
   };
@@ -2647,7 +2693,24 @@ int t4_assembler::harvest(Lane &L) {
         if (!groupsCopied[(size_t)i]) c.devGroups.assign((const Grp *)dg, (const Grp *)dg + ng);
         c.devSplit = 0;
         { size_t lo = 0, hi = c.devGroups.size(); while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (c.devGroups[mid].key & 1u) hi = mid; else lo = mid + 1; } c.devSplit = lo; }
-        c.hasDev = true; c.groups.reset(16);
+        if (knobs.verifyWindow && !c.dbgGroups.empty()) {   // the host's replay of GetHitsFromRead against the kernels' (both describe the same image)
+          bool same = c.dbgGroups.size() == c.devGroups.size();
+          for (size_t q = 0; same && q < c.devGroups.size(); ++q) {
+            const Grp &a = c.dbgGroups[q], &b = c.devGroups[q];
+            same = a.key == b.key && a.cnt == b.cnt && (a.lo > a.hi ? b.lo > b.hi : (a.lo == b.lo && a.hi == b.hi));
+          }
+          ++groupSelfChecks;
+          if (!same) {
+            fprintf(stderr, "T4_VERIFY_WINDOW: the host's dependency records of a read differ from the wide query's (entry %lld, %zu against %zu records)\n", (long long)c.uid, c.dbgGroups.size(), c.devGroups.size());
+            for (size_t q = 0, shown = 0; q < c.devGroups.size() && q < c.dbgGroups.size() && shown < 6; ++q) {
+              const Grp &a = c.dbgGroups[q], &b = c.devGroups[q];
+              if (a.key != b.key || a.cnt != b.cnt || a.lo != b.lo || a.hi != b.hi) { fprintf(stderr, "  #%zu host key %u cnt %u hull %d..%d   device key %u cnt %u hull %d..%d\n", q, a.key, a.cnt, a.lo, a.hi, b.key, b.cnt, b.lo, b.hi); ++shown; }
+            }
+            err = "dependency records mismatch"; return T4_ERR_STATE;
+          }
+          c.dbgGroups.clear();
+        }
+        c.hasDev = true; c.hostRecords = false; c.groups.reset(16);
         c.slack = 99 - n4; c.fragile = huge != 0;
         ++wideServed; wideGroupRecords += ng;
       } else if (c.expectWide) { buildGroups(c); ++wideMispredicted; }   // (the LDS tier served it after all)
@@ -2983,6 +3046,7 @@ int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n) {
   for (int i = 0; i < n && i < 16; ++i) out[i] = v[i];
   if (n >= 23) t4_add_query_stats(a->ctx, out + 16);
   if (n >= 27) t4_add_query_wide_stats(a->ctx, out + 23);   // the wide query: reads it served, partitions, calls repeated with larger pools, dependency records
+  if (getenv("T4_VERIFY_WINDOW")) fprintf(stderr, "T4_VERIFY_WINDOW: the host's replay of the emitted hits equals the wide query's dependency records for all %lld reads it was held against\n", (long long)a->groupSelfChecks);
   if (getenv("T4_VERIFY_WINDOW")) fprintf(stderr, "T4_VERIFY_WINDOW: %lld served window entries queried again at serve time, all equal to their cached results (%lld of them put together from restricted re-queries)\n", (long long)a->verified, (long long)a->verifiedMerged);
   if (getenv("T4_TIMING")) {
     fprintf(stderr, "timing: assembler host seconds: add_read calls %.3f (incl. waits for the head), prefetch calls %.3f; launching %.3f (of which deltas %.3f, dependency sets %.3f, registering k-mers %.3f), harvesting %.3f, event examination %.3f, index edits %.3f\n",
