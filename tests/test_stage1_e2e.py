@@ -500,11 +500,14 @@ def test_window_entries_with_stable_group_statistics_gpu(tmp_path, pairs, clones
     """Many clones on few genes: reads inside a shared gene meet hundreds of contigs, more than 100 groups of four hits, so
     novelMinHitRequired follows the group statistics (SeqSet.hpp:813-823). The query reports when those statistics cannot move
     under index edits of small groups (T4QueryArgs::statsStable) and the window then keeps the entry across such edits without a
-    budget. T4_VERIFY_WINDOW checks every served entry against a fresh query; the same input under the budget rule alone
-    (T4_NO_STABLE_STATS) must lose more entries to the tolerance rule."""
+    budget. Round 6: an entry without that certificate is CHECKED after such an edit -- its group sizes are booked exactly (the emit mask
+    says at which k-mer positions an edit reaches the read at all), the statistics loop is repeated over them on the host, and the
+    entry stands while novelMinHitRequired comes out the same. T4_VERIFY_WINDOW checks every served entry against a fresh query; the
+    same input with neither (T4_NO_STABLE_STATS + T4_NO_EXACT_TOLERANCE: the budget rule alone) must lose more entries to the tolerance
+    rule, and with the checks alone (T4_NO_STABLE_STATS) the checks must have run."""
     import re
     logs = {}
-    for name, extra in (("stable", {}), ("budget", {"T4_NO_STABLE_STATS": "1"})):
+    for name, extra in (("stable", {}), ("checks", {"T4_NO_STABLE_STATS": "1"}), ("budget", {"T4_NO_STABLE_STATS": "1", "T4_NO_EXACT_TOLERANCE": "1"})):
         d = tmp_path / name
         d.mkdir()
         env = {"T4_VERIFY_WINDOW": "1", "T4_TIMING": "1"}
@@ -515,6 +518,9 @@ def test_window_entries_with_stable_group_statistics_gpu(tmp_path, pairs, clones
     assert st and bu, logs["stable"][-600:]
     assert int(st.group(2)) > 0 and int(bu.group(2)) == 0
     assert int(st.group(3)) < int(bu.group(3)), (st.groups(), bu.groups())
+    ck = re.search(pat, logs["checks"])
+    ran = re.search(r"thresholds checked after an edit of a small group by repeating the statistics loop: (\d+) entries, (\d+) of them fell", logs["checks"])
+    assert ck and ran and int(ran.group(1)) > 0 and int(ck.group(3)) < int(bu.group(3)), (ck.groups(), ran.groups() if ran else None, bu.groups())
     assert re.search(r"T4_VERIFY_WINDOW: (\d+) served window entries", logs["stable"])
 
 

@@ -776,7 +776,7 @@ struct t4_assembler : IndexListener {
   struct Knobs {
     bool verifyWindow = false, noStableStats = false, wideQueries = true, candStore = true, restrictOn = true, predictHints = true, useMarks = true, contigKills = false, exactTolerance = true;
     int wideHitLimit = 3072;
-    int lanes = 1, queryAhead = 0, minBatch = 4, harvestDelay = 0, lightAhead = 0, maxPending = 8;
+    int lanes = 1, queryAhead = 0, minBatch = 4, harvestDelay = 0, lightAhead = 0, maxPending = 8, restrictAhead = 0;
     FILE *roundLog = nullptr;
     Knobs() {
       auto num = [](const char *n, int d) { const char *e = getenv(n); return e ? atoi(e) : d; };
@@ -791,6 +791,7 @@ struct t4_assembler : IndexListener {
       predictHints = !getenv("T4_NO_PREDICT");   // A-B aid: no look at the reads of the next whole-query round
       candStore = !getenv("T4_CANDS_OFF");      // testing / A-B aid: the restricted path as round 4 had it (at most 44 candidates, ~100 groups of four hits)
       restrictOn = !getenv("T4_RESTRICT_OFF");  // testing / A-B aid: every invalidated entry is queried again in full
+      restrictAhead = num("T4_RESTRICT_AHEAD", 0);   // restricted re-queries only for entries within this many places of the head (0: as far as whole queries reach; -n: n/2 x the reads a round has recently served + 4)
       maxPending = num("T4_MAX_PENDING", 8);   // contigs a window entry may wait for at a time (1: round 4's rule, a second contig ends the entry)
       lightAhead = num("T4_LIGHT_AHEAD", 0);    // whole queries ride with a head that waits for a restricted re-query only when they are this near the head (0: the head's own); -1: every round carries every entry without a result (round 4)
       if (getenv("T4_ROUND_LOG")) roundLog = fopen(getenv("T4_ROUND_LOG"), "w");   // one line per launch: reads, kernel ms, per read us / overlaps / tier / killed in flight
@@ -2732,6 +2733,7 @@ int t4_assembler::pumpLive(bool needHead, int repetitive) {
   // Entries far behind the head rarely survive until they are consumed: (re-)query only as far ahead as a few times what a launch
   // for the head has recently served (every read queried adds to the latency of the launch: it ends with its slowest read)
   const size_t ahead = fixedAhead > 0 ? (size_t)fixedAhead : (lanes.size() > 1 ? 24 : (size_t)(3.0 * runEma) + 12);   // (factors 2 and 4 measured in round 5 with light rounds: 66.4 / 64.1 s against 61.3 s on C2, profiles/r05f)
+  const size_t restrictAhead = knobs.restrictAhead > 0 ? (size_t)knobs.restrictAhead : knobs.restrictAhead < 0 ? (size_t)(-knobs.restrictAhead * 0.5 * runEma) + 4 : 0;
   for (;;) {
     // T4_LIVE_HARVEST_DELAY=n (testing aid): a finished launch is only noticed n calls later, so that commits pile up against queries in flight
     const int harvestDelay = knobs.harvestDelay;
@@ -2755,6 +2757,9 @@ int t4_assembler::pumpLive(bool needHead, int repetitive) {
       // two classes of work: restricted re-queries (one contig of an entry that keeps the rest: tens of microseconds) and whole
       // queries (hundreds; a read the wide query serves, more). With two lanes the head's restricted re-query does not wait for
       // the whole queries of the entries behind it.
+      // (an entry that waits for a contig far behind the head is likely to meet another change of that contig before it is served -- the
+      // reads of a clone extend the same contig end one after the other --: its re-query waits until it comes within restrictAhead places)
+      if (c.partial && restrictAhead > 0 && i >= restrictAhead) continue;
       (c.partial ? light : heavy).push_back(order[i]);
     }
     const bool headWaits_ = !head.valid && !head.inflight;

@@ -109,8 +109,10 @@ __global__ __launch_bounds__(512) void wideSeedKernel(T4IndexView ixArg, T4Batch
   __shared__ T4IndexView s_ix;
   __shared__ T4BatchView s_bv;
   __shared__ WaveMem s_wm;
+  __shared__ T4Wide s_wd;   // (by reference into wideDeferRead: as a by-value kernel parameter it was copied into EVERY lane's private stack -- 224 B
+                            // per lane, 60 GB written and 31 GB fetched per config C2 run by the PMC counters, profiles/r06m_c2_pmc_*)
   if (threadIdx.x == 0) {
-    s_ix = ixArg; s_bv = bvArg;
+    s_ix = ixArg; s_bv = bvArg; s_wd = wd;
     WaveMem &m = s_wm;
     m.keys = s_code; m.pairs = s_pref; m.cand = s_pref; m.ov = (OvRec *)s_start; m.fin = (OvRec *)s_start; m.ord = (unsigned short *)s_start;
     m.cap = 2048; m.maxOv = 0; m.maxFin = 0; m.candCap = 0; m.ldsArrays = 1; m.hitLimit = 0;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(512) void wideSeedKernel(T4IndexView ixArg, T4Batch
     if (len < s_ix.k) { if (threadIdx.x == 0) qa.counts[r] = -1; continue; }   // (GetOverlapsFromRead's own answer: no k-mer)
     loadSegment(s_bv, r, 0, len, s_wm);
     unsigned long long hitTotal = 0;
-    wideDeferRead(s_ix, s_wm, &s_ws, wd, len, qa.strandPerRead[r], r, hitTotal);
+    wideDeferRead(s_ix, s_wm, &s_ws, s_wd, len, qa.strandPerRead[r], r, hitTotal);
     if (threadIdx.x == 0) atomicAdd(wk.hitCounter, hitTotal);
   }
 }
