@@ -10,7 +10,7 @@ threshold follows the group statistics, exact replays, raised thresholds). Every
     python tests/stress/candidate_store_stress.py SEED RUNS        # random sizes / seeds / policy switches
     python tests/stress/candidate_store_stress.py one PAIRS CLONES SEED [NAME=VALUE ...]
 
-Round 5: 16 + 40 + 30 runs, all identical."""
+Round 5: 16 + 40 + 30 runs, all identical; round 6: see DESIGN 3g."""
 import filecmp
 import os
 import random
@@ -26,7 +26,9 @@ from test_stage1_e2e import REF_BIN, ROOT, _emulated_driver, _shared_constant_ge
 KNOBS = [("T4_MAX_PENDING", ["1", "2", "4", "8"]), ("T4_LIGHT_AHEAD", ["0", "1", "3"]), ("T4_LIVE_LANES", ["1", "2", "4"]), ("T4_LIVE_HARVEST_DELAY", ["0", "3"]),
          ("T4_WINDOW", ["9", "33", "192"]), ("T4_QUERY_AHEAD", ["4", "30"]), ("T4_AQ_CAP_LIMIT", ["400", "1500"]), ("T4_AQ_CAND_CAP", ["64"]), ("T4_AQ_POOL_CAP", ["8", "64"]),
          ("T4_AQ_EXTEND_DEFER", ["0", "1", "16"]), ("T4_WIDE_MIN_HITS", ["300", "2000"]), ("T4_NO_MARKS", ["1"]), ("T4_NO_PREDICT", ["1"]), ("T4_NO_STABLE_STATS", ["1"]),
-         ("T4_WIDE_PCAP", ["512"]), ("T4_WIDE_OFF", ["1"]), ("T4_LIVE_MIN_BATCH", ["1", "6"]), ("T4_CANDS_OFF", ["1"])]
+         ("T4_WIDE_PCAP", ["512"]), ("T4_WIDE_OFF", ["1"]), ("T4_LIVE_MIN_BATCH", ["1", "6"]), ("T4_CANDS_OFF", ["1"]),
+         # round 6: the wide kernels behind every round, the sample of the partition plan, merges that end entries, the budget rule, restricted re-queries near the head only
+         ("T4_WIDE_EAGER", ["1"]), ("T4_WIDE_SAMPLE", ["0", "64"]), ("T4_CONTIG_KILLS", ["1"]), ("T4_NO_EXACT_TOLERANCE", ["1"]), ("T4_RESTRICT_AHEAD", ["2", "6", "-2"])]
 
 
 def one(pairs, clones, seed, env):

@@ -118,7 +118,8 @@ def groups_of(eng, i):
     got = eng.lib.t4_add_query_groups(eng.h, i, C.byref(g), C.byref(n), C.byref(huge), C.byref(n4))
     if got != 1:
         return None
-    return [(g[t].key, g[t].cnt, g[t].lo, g[t].hi) for t in range(n.value)], huge.value, n4.value
+    # (bits 24-27 of a record's count, reads with lists beyond 10000 postings: hits of shorter lists capped at 4, first hit of a shorter list)
+    return [(g[t].key, g[t].cnt & 0xFFFFFF, g[t].lo, g[t].hi) for t in range(n.value)], huge.value, n4.value, [g[t].cnt >> 24 for t in range(n.value)]
 
 
 def expected_groups(o, read, strand):
@@ -133,6 +134,21 @@ def expected_groups(o, read, strand):
         ats = [at for at, c in d.items() if c >= 3]
         lo, hi = (min(ats), max(ats) + len(read) - 1) if ats else (0x7FFFFFFF, -0x7FFFFFFF)
         out.append((key, sum(d.values()), lo, hi))
+    return out
+
+
+def expected_group_info(o, read, strand):
+    """per group, in the records' order: hits of lists of at most 10000 postings (capped at 4) | 8 when its hit lowest on the read is one"""
+    h = o.hits(read, strand=strand, cap=1 << 22)
+    tab = {}
+    for idx, off, roff, st, rep in h.tolist():
+        tab.setdefault(idx * 2 + (1 if st == 1 else 0), []).append((roff, rep))
+    out = []
+    for key in sorted(tab, key=lambda x: (x & 1, x >> 1)):
+        hits = tab[key]
+        small = sum(1 for _, rep in hits if rep <= 10000)
+        first = min(hits)[1] <= 10000
+        out.append(min(small, 4) | (8 if first else 0))
     return out
 
 
@@ -153,6 +169,10 @@ def check_wide(eng, o, ix, reads, strands, factors, room, expect_wide=True, stat
         if g is not None:
             n_wide += 1
             assert g[0] == expected_groups(o, rd, int(strands[i])), (i, "dependency records")
+            if g[1]:   # a read with lists beyond 10000 postings: what the statistics loop reads of every group for removeOnlyRepeats
+                assert g[3] == expected_group_info(o, rd, int(strands[i])), (i, "hits of shorter lists per group")
+            else:
+                assert not any(g[3]), (i, "info bits on a read without long lists")
     if expect_wide:
         assert n_wide > 0
     return cnt, n_wide

@@ -612,6 +612,14 @@ struct t4_assembler : IndexListener {
     std::vector<Grp> devGroups;
     size_t devSplit = 0;          // first plus-strand record
     bool hasDev = false;
+    // A read with lists beyond 10000 postings (fragile): per device record the group's hits of shorter lists (capped at 4, bits 0-2) and
+    // whether its first hit is one (bit 3) -- what the statistics loop reads of a group for removeOnlyRepeats (SeqSet.hpp:796-806) --,
+    // removeOnlyRepeats per strand as the query found it, and the groups this commit's edits touched (processEvents: such an entry stands
+    // while the loop, repeated over its groups, gives the same threshold and the same removeOnlyRepeats and no edit lies within the first
+    // `largest group` hits of the hit array, which the run test of 934-940 reads)
+    std::vector<uint8_t> devInfo;
+    bool ror0[2] = {false, false}, rorOk = false;
+    std::vector<uint32_t> editedKeys;
     std::vector<Grp> dbgGroups;   // T4_VERIFY_WINDOW: what buildGroups derives for a read the wide query serves
     bool hostRecords = false;     // ... derived on the host (buildGroups: the emitted hits of a read of the LDS tier), not returned by the wide query
     bool expectWide = false;      // the launch expects the wide query to serve this read: no table derived beside the launch
@@ -767,14 +775,14 @@ struct t4_assembler : IndexListener {
   bool wideQueries = true; int wideHitLimit = 3072;   // what t4_add_query_pool_begin will do with a read of that many emitted hits (set in ensureLanes)
   int emittedHits(Cached &e);
   int64_t headWholeWhy[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int64_t toleranceChecks = 0, toleranceCheckKills = 0, groupSelfChecks = 0;
-  bool exactStats(const Cached &c, int pc, const int32_t *pcSize, int T[2], int e4[2], int e5[2], int big[2]);
+  int64_t toleranceChecks = 0, toleranceCheckKills = 0, groupSelfChecks = 0, fragileChecks = 0;
+  bool exactStats(const Cached &c, int pc, const int32_t *pcSize, int T[2], int e4[2], int e5[2], int big[2], bool *ror = nullptr, int headLen = 0, bool *headTouched = nullptr);
   int64_t deltas = 0, deltaBytes = 0, rounds = 0, readsQueried = 0, invKey = 0, invCross = 0, invRegion = 0, invShift = 0, invContig = 0, invFragile = 0, tolerated = 0;
   double secDelta = 0, secGroups = 0, secEvents = 0, secRegister = 0, secPrefetch = 0, secAddTotal = 0;
 
   // testing / development aids, read from the environment ONCE per builder (none changes a result; DESIGN 7b lists them)
   struct Knobs {
-    bool verifyWindow = false, noStableStats = false, wideQueries = true, candStore = true, restrictOn = true, predictHints = true, useMarks = true, contigKills = false, exactTolerance = true;
+    bool verifyWindow = false, noStableStats = false, wideQueries = true, candStore = true, restrictOn = true, predictHints = true, useMarks = true, contigKills = false, exactTolerance = true, fragileChecks = false;
     int wideHitLimit = 3072;
     int lanes = 1, queryAhead = 0, minBatch = 4, harvestDelay = 0, lightAhead = 0, maxPending = 8, restrictAhead = 0;
     FILE *roundLog = nullptr;
@@ -785,6 +793,7 @@ struct t4_assembler : IndexListener {
       lanes = num("T4_LIVE_LANES", 1); queryAhead = num("T4_QUERY_AHEAD", 0); minBatch = num("T4_LIVE_MIN_BATCH", 4); harvestDelay = num("T4_LIVE_HARVEST_DELAY", 0);
       wideQueries = !getenv("T4_WIDE_OFF") && !getenv("T4_AQ_FORCE_GLOBAL");
       { const int lim = num("T4_AQ_CAP_LIMIT", 0); wideHitLimit = lim > 0 ? lim : num("T4_WIDE_MIN_HITS", 3072); }
+      fragileChecks = getenv("T4_FRAGILE_CHECKS") != nullptr;   // entries of reads with lists beyond 10000 postings take booked edits and are checked (threshold, removeOnlyRepeats, head of the hit array) instead of falling to every edit
       exactTolerance = !getenv("T4_NO_EXACT_TOLERANCE");   // A-B aid: the budget rule for every entry whose query did not certify its threshold (until round 6)
       contigKills = getenv("T4_CONTIG_KILLS") != nullptr;   // A-B aid: a merge ends every window entry with a hit on the merged contigs (until round 6)
       useMarks = !getenv("T4_NO_MARKS");        // A-B aid: restricted re-queries walk the read's posting lists as in round 4
@@ -2048,7 +2057,14 @@ void t4_assembler::processEvents() {
           if (sp < 0 || sp > lenk || !((e.emitMask[onForward ? 0 : 1][sp >> 6] >> (sp & 63)) & 1ull)) return;
         }
         if (e.inflight && e.expectWide && !e.hasDev) { kill(e, invKey); return; }
-        if (e.fragile) { kill(e, invFragile); ++invLongLists; return; }
+        // (a read with lists beyond 10000 postings: removeOnlyRepeats and the run test of SeqSet.hpp:934-940 look across its groups. With
+        // the query's own records -- exact sizes, the hits of shorter lists per group -- the edit is booked and the entry checked below;
+        // without them every edit of one of its keys ends it, as until round 6)
+        // Measured on the first 2 M pairs of C3 (profiles/r06p_*): 14 745 such checks, 17 entries fell, the 320 k kills of this kind gone,
+        // outputs identical -- and the run no faster: the entries fall a little later to a change of one of their groups of three or more
+        // hits, because no restricted re-query exists for them. Off unless T4_FRAGILE_CHECKS is set, until that path exists
+        // and T4_VERIFY_WINDOW has been run at a depth where such reads occur.
+        if (e.fragile && !(knobs.fragileChecks && knobs.exactTolerance && e.rorOk && e.maskOk && !e.inexact && e.hasDev && e.candOk)) { kill(e, invFragile); ++invLongLists; return; }
         if (e.isPending(ev.idx)) { touch(e, ev.idx, invKey); return; }
         for (uint32_t plus = 0; plus < 2 && e.standing(); ++plus) {
           const int n = ((plus != 0) == onForward ? 1 : 0) * (ev.delta > 0 ? ev.delta : -ev.delta);
@@ -2064,8 +2080,10 @@ void t4_assembler::processEvents() {
             if (g && (!e.hasDev || (!e.inexact && (e.maskOk || (!e.repeatNear && listIsShort()))))) g->cnt = g->cnt > (uint32_t)n ? g->cnt - (uint32_t)n : 0;
           }
           ++tolerated; ++e.toleratedSince;
+          if (e.fragile) e.editedKeys.push_back((uint32_t)ev.idx * 2u + plus);
           if (e.hasDev && !e.inexact && !e.maskOk && (e.repeatNear || !listIsShort())) e.inexact = true;
           if (e.statsStable) { ++toleratedStable; continue; }   // exact: the statistics of this read's query cannot move (overlapsFromKeys)
+          if (e.fragile && e.inexact) { kill(e, invFragile); ++invLongLists; break; }
           if (knobs.exactTolerance && e.hasDev && !e.inexact && e.candOk) {   // the statistics loop decides, below
             if (!e.checkPending) { e.checkPending = true; checkSlots.push_back(o.slot); }
             continue;
@@ -2081,10 +2099,15 @@ void t4_assembler::processEvents() {
     for (int sl : checkSlots) {
       Cached &e = *pool[sl];
       e.checkPending = false;
-      if (!e.valid) continue;
+      if (!e.valid) { e.editedKeys.clear(); continue; }
       int T[2], e4[2], e5[2], big[2];
+      bool ror[2] = {false, false}, headTouched = false;
       ++toleranceChecks;
-      if (e.inexact || !exactStats(e, -1, nullptr, T, e4, e5, big) || T[0] != e.minT[0] || T[1] != e.minT[1]) { kill(e, invFragile); ++toleranceCheckKills; }
+      const int headLen = e.smhi[0] > e.smhi[1] ? e.smhi[0] : e.smhi[1];
+      bool ok = !e.inexact && exactStats(e, -1, nullptr, T, e4, e5, big, e.fragile ? ror : nullptr, headLen, e.fragile ? &headTouched : nullptr) && T[0] == e.minT[0] && T[1] == e.minT[1];
+      if (ok && e.fragile) { ++fragileChecks; ok = e.rorOk && ror[0] == e.ror0[0] && ror[1] == e.ror0[1] && !headTouched; if (!ok) ++invLongLists; }
+      e.editedKeys.clear();
+      if (!ok) { kill(e, invFragile); ++toleranceCheckKills; }
     }
     idxEvents.clear();
     ts.lap(TS_EVENTS_INDEX);
@@ -2118,7 +2141,7 @@ void t4_assembler::announceLive(int n, const char *const *reads, const int *stra
     c.inflight = false; c.killed = false; c.shifts.clear();
     c.ov.clear(); c.ext.clear(); c.extRet.clear();
     c.uid = nextUid++; c.tier = 0; c.hintPredicted = false; c.lastUs = 0; c.registered = false; c.lastKill = 0;
-    c.hasDev = false; c.hostRecords = false; c.expectWide = false; c.devGroups.clear(); c.dbgGroups.clear();
+    c.hasDev = false; c.hostRecords = false; c.expectWide = false; c.devGroups.clear(); c.dbgGroups.clear(); c.devInfo.clear(); c.rorOk = false; c.editedKeys.clear();
     c.partial = false; c.pendingContig = -1; c.merged = false; c.auxOk = false; c.restrictedCount = 0; c.kmerPos.clear();
     c.cands.clear(); c.candOk = false; c.exactKeys.clear(); c.morePending.clear(); c.inexact = false; c.repeatNear = false; c.checkPending = false; c.maskOk = false;
     order.push_back(sl);
@@ -2154,7 +2177,7 @@ int t4_assembler::launchOn(Lane &L, const std::vector<int> &todo, int repetitive
     c.inflight = true; c.killed = false; c.shifts.clear();
     if (c.partial) { anyOnly = true; continue; }   // restricted re-query: the entry keeps what it holds of the other contigs
     c.statsStable = false;
-    c.hasDev = false; c.hostRecords = false; c.expectWide = false; c.devGroups.clear(); c.dbgGroups.clear();
+    c.hasDev = false; c.hostRecords = false; c.expectWide = false; c.devGroups.clear(); c.dbgGroups.clear(); c.devInfo.clear(); c.rorOk = false; c.editedKeys.clear();
     c.auxOk = false; c.merged = false; c.restrictedCount = 0;
     c.cands.clear(); c.candOk = false; c.exactKeys.clear();
   }
@@ -2305,8 +2328,12 @@ void t4_assembler::replayScan(const std::vector<t4_cand> &cands, const std::vect
 // pcSize[0 / 1] a re-query has just reported. Including the loop's `i = j; ++i` stepping: a group that follows a measured one is measured
 // from its second hit, a one-hit group there vanishes. False when the entry's sizes are not exact (Cached::inexact, no device records).
 // Out: novelMinHitRequired per strand (813-823), groups of >= 4 / >= 5 hits and the largest group (true sizes).
-bool t4_assembler::exactStats(const Cached &c, int pc, const int32_t *pcSize, int T[2], int e4[2], int e5[2], int big[2]) {
+// ror (optional, entries with lists beyond 10000 postings): removeOnlyRepeats per strand -- some group holds three hits of shorter lists in
+// its measured part (796-806). headTouched: one of c.editedKeys lies within the first headLen hits of the array in the reference's order.
+bool t4_assembler::exactStats(const Cached &c, int pc, const int32_t *pcSize, int T[2], int e4[2], int e5[2], int big[2], bool *ror, int headLen, bool *headTouched) {
   if (!c.hasDev || c.inexact) return false;
+  if (ror) { if (c.devInfo.size() != c.devGroups.size()) return false; ror[0] = ror[1] = false; }
+  if (headTouched) *headTouched = false;
   struct Extra { uint32_t key; int cnt; };
   static thread_local std::vector<Extra> extra;   // groups that are not among the device records
   extra.clear();
@@ -2323,22 +2350,30 @@ bool t4_assembler::exactStats(const Cached &c, int pc, const int32_t *pcSize, in
   e4[0] = e4[1] = e5[0] = e5[1] = big[0] = big[1] = 0;
   bool skip = false;
   size_t xe = 0;
-  auto visit = [&](uint32_t key, int n) {
+  long long hitsBefore = 0;   // hits of the groups visited so far: the position of the next group's first hit in the array
+  auto visit = [&](uint32_t key, int n, int info) {
+    if (headTouched && hitsBefore < headLen && std::find(c.editedKeys.begin(), c.editedKeys.end(), key) != c.editedKeys.end()) *headTouched = true;
     if (n <= 0) return;
     const int plus = (int)(key & 1u);
     const int m = n - (skip ? 1 : 0);
-    if (m > 0) { if (m > 3) ++possible[plus]; if (m > longest[plus]) longest[plus] = m; }
+    if (m > 0) {
+      if (m > 3) ++possible[plus];
+      if (m > longest[plus]) longest[plus] = m;
+      if (ror && (info & 7) - ((skip && (info & 8)) ? 1 : 0) >= 3) ror[plus] = true;
+    }
     skip = !(skip && n == 1);
     if (n >= 4) ++e4[plus];
     if (n >= 5) ++e5[plus];
     if (n > big[plus]) big[plus] = n;
+    hitsBefore += n;
   };
   auto before = [](uint32_t a, uint32_t b) { return (a & 1u) != (b & 1u) ? (a & 1u) < (b & 1u) : a < b; };
   for (const Grp *g = d0; g < d1; ++g) {
-    while (xe < extra.size() && before(extra[xe].key, g->key)) { visit(extra[xe].key, extra[xe].cnt); ++xe; }
-    visit(g->key, pc >= 0 && (g->key >> 1) == (uint32_t)pc ? pcSize[(int)(g->key & 1u)] : (int)g->cnt);
+    // (a group the host has added since holds fewer than three hits: no three of shorter lists, whatever they are)
+    while (xe < extra.size() && before(extra[xe].key, g->key)) { visit(extra[xe].key, extra[xe].cnt, 0); ++xe; }
+    visit(g->key, pc >= 0 && (g->key >> 1) == (uint32_t)pc ? pcSize[(int)(g->key & 1u)] : (int)g->cnt, ror ? (int)c.devInfo[(size_t)(g - d0)] : 0);
   }
-  while (xe < extra.size()) { visit(extra[xe].key, extra[xe].cnt); ++xe; }
+  while (xe < extra.size()) { visit(extra[xe].key, extra[xe].cnt, 0); ++xe; }
   for (int t = 0; t < 2; ++t) {
     T[t] = 3;
     if (possible[t] > 100000) T[t] = (int)(longest[t] * 0.75);
@@ -2693,6 +2728,11 @@ int t4_assembler::harvest(Lane &L) {
         static_assert(sizeof(t4_grp) == sizeof(Grp), "dependency record layout");
         if (!groupsCopied[(size_t)i]) c.devGroups.assign((const Grp *)dg, (const Grp *)dg + ng);
         c.devSplit = 0;
+        c.devInfo.clear(); c.rorOk = false;
+        if (huge) {   // (bits 24-27 of a record's count: T4_GRP_INFO_SHIFT in t4_wide.h)
+          c.devInfo.resize(c.devGroups.size());
+          for (size_t q = 0; q < c.devGroups.size(); ++q) { c.devInfo[q] = (uint8_t)((c.devGroups[q].cnt >> 24) & 15u); c.devGroups[q].cnt &= 0xFFFFFFu; }
+        }
         { size_t lo = 0, hi = c.devGroups.size(); while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (c.devGroups[mid].key & 1u) hi = mid; else lo = mid + 1; } c.devSplit = lo; }
         if (knobs.verifyWindow && !c.dbgGroups.empty()) {   // the host's replay of GetHitsFromRead against the kernels' (both describe the same image)
           bool same = c.dbgGroups.size() == c.devGroups.size();
@@ -2713,6 +2753,11 @@ int t4_assembler::harvest(Lane &L) {
         }
         c.hasDev = true; c.hostRecords = false; c.groups.reset(16);
         c.slack = 99 - n4; c.fragile = huge != 0;
+        c.inexact = false; c.editedKeys.clear();
+        if (huge && c.candOk) {   // removeOnlyRepeats as this query found it, from its own records (exactStats repeats the loop the kernel ran)
+          int T[2], e4[2], e5[2], big[2];
+          c.rorOk = exactStats(c, -1, nullptr, T, e4, e5, big, c.ror0) && T[0] == c.minT[0] && T[1] == c.minT[1];
+        }
         ++wideServed; wideGroupRecords += ng;
       } else if (c.expectWide) { buildGroups(c); ++wideMispredicted; }   // (the LDS tier served it after all)
       c.expectWide = false;
@@ -3066,7 +3111,7 @@ int t4_assembler_live_counters(const t4_assembler *a, int64_t *out, int n) {
             (int)a->lanes.size(), (long long)a->launches, (long long)a->launchesUrgent, (long long)a->lightRounds, (long long)a->headWaits, a->secHeadWait, (long long)a->killedInFlight);
     fprintf(stderr, "timing: rounds whose head waited for a WHOLE query: %lld never queried before, fallen to a change of: a key %lld, a list crossing 100 / 10000 postings %lld, a region %lld, a shift %lld, a whole contig %lld, the tolerance budget %lld, a restricted re-query that fell back %lld\n",
             (long long)a->headWholeWhy[0], (long long)a->headWholeWhy[1], (long long)a->headWholeWhy[2], (long long)a->headWholeWhy[3], (long long)a->headWholeWhy[4], (long long)a->headWholeWhy[5], (long long)a->headWholeWhy[6], (long long)a->headWholeWhy[7]);
-    fprintf(stderr, "timing: thresholds checked after an edit of a small group by repeating the statistics loop: %lld entries, %lld of them fell\n", (long long)a->toleranceChecks, (long long)a->toleranceCheckKills);
+    fprintf(stderr, "timing: thresholds checked after an edit of a small group by repeating the statistics loop: %lld entries, %lld of them fell (%lld of the checks for reads with lists beyond 10000 postings: removeOnlyRepeats and the head of the hit array as well)\n", (long long)a->toleranceChecks, (long long)a->toleranceCheckKills, (long long)a->fragileChecks);
     fprintf(stderr, "timing: tolerated index edits %lld, of which %lld met an entry whose group statistics cannot move (no budget spent); tolerance kills %lld, of which %lld for lists beyond 10000 postings\n",
             (long long)a->tolerated, (long long)a->toleratedStable, (long long)a->invFragile, (long long)a->invLongLists);
     fprintf(stderr, "timing: restricted re-queries: %lld entries kept their other contigs when one contig changed, %lld merged, %lld fell back to the whole query, %lld in flight met another change of their contig\n",

@@ -77,7 +77,9 @@ int t4_add_query_pool_end(t4_ctx *ctx, const int32_t **counts, const int32_t **b
 int t4_add_query_stats(t4_ctx *ctx, int64_t *out7);
 int t4_add_query_last_stable(t4_ctx *ctx, const int32_t **flags, int *n);   // see T4QueryArgs::statsStable
 // the wide query (csrc/t4_wide.h): dependency records of a read it served -- see t4_api.hip
-typedef struct { uint32_t key, cnt; int32_t lo, hi; } t4_grp;   // key = contig * 2 + (strand == 1); hits; hull of the diagonals with three or more hits (lo > hi: none)
+typedef struct { uint32_t key, cnt; int32_t lo, hi; } t4_grp;   // key = contig * 2 + (strand == 1); hits (bits 0-23); hull of the diagonals with three or more hits (lo > hi: none)
+// (records of a read with lists beyond 10000 postings -- `huge` -- carry in bits 24-27 of cnt what SeqSet.hpp:796-806 reads of the group:
+// bits 24-26 its hits of lists of at most 10000 postings, capped at 4; bit 27 whether its hit lowest on the read is one)
 int t4_add_query_groups(t4_ctx *ctx, int i, const t4_grp **groups, int *n, int *huge, int *n4);
 int t4_add_query_wide_stats(t4_ctx *ctx, int64_t *out4);
 int t4_add_query_last_call(t4_ctx *ctx, double *kernel_ms, const int32_t **ticks10ns, int *n);   // development aid (T4_ROUND_LOG)

@@ -547,6 +547,9 @@ __global__ __launch_bounds__(512) void wideChainKernel(T4IndexView ixArg, T4Batc
         const unsigned long long k0 = s_keys[s0];
         T4Grp rec;
         rec.key = (unsigned)KEY_IDX(k0) * 2u + (unsigned)KEY_PLUS(k0); rec.cnt = (unsigned)(e0 - s0); rec.lo = lo; rec.hi = hi;
+        // (a read with lists beyond 10000 postings: the group's hits of shorter lists, capped at 4, and whether its first hit is one --
+        // what the statistics loop reads of it for removeOnlyRepeats, SeqSet.hpp:796-806 -- ride in bits 24-27 of the count: T4_GRP_INFO_SHIFT)
+        if (pl.huge) rec.cnt |= (unsigned)wd.gInfo[(size_t)pg * wd.pcap + g] << 24;
         out[g < nMinus ? off0 + g : off1 + (g - nMinus)] = rec;
       }
     }
