@@ -1162,7 +1162,13 @@ int t4_assembler::addRead(const char *readC, const char *geneName, int *strandIO
   if (overlapCnt <= 0) return -1;
   ordIdx.resize((size_t)overlapCnt);
   for (int i = 0; i < overlapCnt; ++i) ordIdx[(size_t)i] = i;
-  std::stable_sort(ordIdx.begin(), ordIdx.end(), [&](int a, int b) { return ovLess(candStore_[(size_t)a].ov, candStore_[(size_t)b].ov); });
+  // (the order of std::stable_sort by _overlap::operator<, without its temporary buffer per call: ties go by position)
+  if (overlapCnt > 1)
+    std::sort(ordIdx.begin(), ordIdx.end(), [&](int a, int b) {
+      if (ovLess(candStore_[(size_t)a].ov, candStore_[(size_t)b].ov)) return true;
+      if (ovLess(candStore_[(size_t)b].ov, candStore_[(size_t)a].ov)) return false;
+      return a < b;
+    });
   cands.resize((size_t)overlapCnt);
   for (int i = 0; i < overlapCnt; ++i) cands[(size_t)i] = candStore_[(size_t)ordIdx[(size_t)i]];
   static thread_local std::vector<Ov> overlaps, ext, failed;
@@ -1559,12 +1565,17 @@ int t4_assembler::makeDelta() {
     R.seqId.push_back(c); R.seqRec.push_back(rec);
     if (hi > lo) {
       R.baseAt.push_back(q.baseOff + lo); R.baseLen.push_back(hi - lo);
+      const size_t at0 = R.baseCons.size();
+      R.baseCons.resize(at0 + (size_t)(hi - lo)); R.basePw.resize(at0 + (size_t)(hi - lo));
+      char *bc = &R.baseCons[at0];
+      uint8_t *bp = &R.basePw[at0];
+      const int nMarks = (int)q.postCnt.size();
       for (int t = lo; t < hi; ++t) {
         unsigned char mark = 0;   // posting marks (t4_device.h): postings at this offset, and on the first byte whether the contig's marks count
-        if (t < (int)q.postCnt.size()) mark = (unsigned char)((q.postCnt[(size_t)t] > 3 ? 3 : q.postCnt[(size_t)t]) << 5);
+        if (t < nMarks) mark = (unsigned char)((q.postCnt[(size_t)t] > 3 ? 3 : q.postCnt[(size_t)t]) << 5);
         if (t == 0 && q.marksBad) mark |= 128;
-        if (t < len) { R.baseCons.push_back(q.cons[t]); R.basePw.push_back((uint8_t)(t4PwByte(q.pw[t].c[0], q.pw[t].c[1], q.pw[t].c[2], q.pw[t].c[3]) | mark)); }
-        else { R.baseCons.push_back('\0'); R.basePw.push_back((uint8_t)(t4PwByte(0, 0, 0, 0) | mark)); }
+        if (t < len) { bc[t - lo] = q.cons[t]; bp[t - lo] = (uint8_t)(t4PwByte(q.pw[t].c[0], q.pw[t].c[1], q.pw[t].c[2], q.pw[t].c[3]) | mark); }
+        else { bc[t - lo] = '\0'; bp[t - lo] = (uint8_t)(t4PwByte(0, 0, 0, 0) | mark); }
       }
     }
   }
