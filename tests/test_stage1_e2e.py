@@ -604,6 +604,13 @@ def test_candidate_store_group_statistics_emulated(tmp_path):
     assert x and int(x.group(1)) >= 5 and int(x.group(2)) >= 2, log[-1500:]
     v = re.search(r"T4_VERIFY_WINDOW: (\d+) served window entries queried again at serve time, all equal to their cached results \((\d+) of them put together", log)
     assert v and int(v.group(2)) > 400, log[-800:]
+    # round 6: the dependency records of LDS-tier reads are the host's replay of GetHitsFromRead -- held against the wide query's own
+    # records for every read the wide query served --, and an entry whose threshold the query could not certify is checked by repeating
+    # the statistics loop over its (exactly booked) group sizes instead of spending a budget
+    g = re.search(r"the host's replay of the emitted hits equals the wide query's dependency records for all (\d+) reads", log)
+    assert g and int(g.group(1)) > 100, log[-1500:]
+    c = re.search(r"thresholds checked after an edit of a small group by repeating the statistics loop: (\d+) entries, (\d+) of them fell", log)
+    assert c and int(c.group(1)) >= 1, log[-1500:]
 
 
 @pytest.mark.gpu
