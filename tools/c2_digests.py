@@ -27,7 +27,7 @@ OUT = os.path.join(ROOT, "tests", "golden", "c2_digests.json")
 SUFFIXES = ("_raw.out", "_assembled_reads.fa", "_final.out")
 # name -> (pairs, clones, seed, prefix pairs or 0): SURVEY.md 8(d)
 # (c5m5: the C5 recipe -- barcode + UMI files, 50 k cells x 2 clones, seed 4 -- at 5 M pairs; barcode mode, no --skipMateExtension)
-CELL_CONFIGS = {"c5m5": (5000000, 50000, 4)}
+CELL_CONFIGS = {"c5m5": (5000000, 50000, 4), "c5m20": (20000000, 50000, 4)}   # (c5m20: 40 % of config C5's pairs over all of its cells, VERDICT r5 #6c)
 CONFIGS = {"c2": (1000000, 20000, 1, 0), "c2mini": (20000, 400, 1, 0), "c2micro": (400, 8, 1, 0),   # (c2mini / c2micro: no digests -- stand-ins that let bench.py's C2-as-the-workload path be exercised in seconds, T4_BENCH_C2_STANDIN)
            "c3p5": (20000000, 200000, 2, 5000000), "c3p2": (20000000, 200000, 2, 2000000), "c3p05": (20000000, 200000, 2, 500000)}
 

@@ -1327,7 +1327,10 @@ int main(int argc, char *argv[]) {
   } else {
     if ((rc = t4_assembler_create(ctx, indexKmerLength, 0, &seqSet))) die(ctx, "t4_assembler_create", rc);
     t4_assembler_set_params(seqSet, hitLenRequired, 10, 0.9);
-    t4_assembler_set_threads(seqSet, threadCnt);
+    // (the helpers beside the chain's host thread: dependency records and window k-mers of a round's fresh reads, a few hundred
+    // microseconds of work per round -- more than eight of them cost more in wake-ups than they take off it: C2 67 s at -t 16 / 32 against
+    // 61 s at -t 8 in round 5; the input phases take all of -t)
+    t4_assembler_set_threads(seqSet, getenv("T4_CHAIN_THREADS") ? atoi(getenv("T4_CHAIN_THREADS")) > 0 ? atoi(getenv("T4_CHAIN_THREADS")) : 1 : (threadCnt < 8 ? threadCnt : 8));
   }
   for (const NovelFa &nf : novelFa) {   // SeqSet::InputNovelFa (SeqSet.hpp:2986-2993): every record becomes a contig, strand 1, no barcode
     if (useCells) { fprintf(stderr, "trust4-hip: --debug-ns is not supported together with --barcode (use --keepNoBarcode).\n"); return EXIT_FAILURE; }
