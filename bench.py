@@ -609,7 +609,7 @@ def main():
     ap.add_argument("--side-legs", type=int, default=1, help="0 = skip passes.rough_annotation_c2 / stage1_cells / stage0_e2e")
     ap.add_argument("--traffic", type=int, default=1, help="0 = skip the two rocprofv3 PMC passes that measure roofline.traffic")
     ap.add_argument("--c2", type=int, default=1, help="0 = skip the run of config C2 itself (then the steps are timed on the 100 k-pair batch)")
-    ap.add_argument("--config-leg", default="", help="additional config legs, comma separated (c3p05, c3p2, c3p5: prefixes of C3; c5m5: the C5 recipe at 5 M pairs / 50 k cells, barcode mode; c2:dropin = C2 with default options through the reference's main.cpp bound to the C ABI)")
+    ap.add_argument("--config-leg", default="", help="additional config legs, comma separated (c3p05, c3p2, c3p5: prefixes of C3; c5m5 / c5m20: the C5 recipe at 5 M / 20 M pairs over 50 k cells, barcode mode; c2:dropin = C2 with default options through the reference's main.cpp bound to the C ABI)")
     ap.add_argument("--cells-pairs", type=int, default=250000, help="N > 1: pairs of the barcode-mode sample per GPU of the job")
     ap.add_argument("--cells", type=int, default=2500, help="N > 1: cells of the sample per GPU of the job")
     ap.add_argument("--cells-total", type=int, default=0, help="N > 1: cells of the whole sample instead of --cells per GPU (fewer cells than ranks: ranks without a cell)")
