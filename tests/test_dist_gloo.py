@@ -147,6 +147,53 @@ def test_input_dealt_out_by_cells(tmp_path):
         run_engine_merge(tmp_path / "f", exe, 120, 7, 21, 3, env=dict(env, T4_TEST_NO_COUNT_MERGE="1"))
 
 
+def test_barcode_file_that_cannot_be_read_twice(tmp_path):
+    """with the input dealt out by cells every rank reads the barcode file once AHEAD of the input loop -- a FIFO (process
+    substitution, /dev/stdin) would be drained by that. Whether every barcode file is a regular file follows from argv, so every rank
+    decides alike: the input is not dealt out, every rank reads the whole sample once (round 4's way), and says so. Two ranks, each
+    with its own FIFO in place of the barcode file: the single-process files byte for byte."""
+    import filecmp
+    import gzip
+    import shutil
+    import subprocess
+    import threading
+    import t4libs
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_stage1_e2e import _emulated_driver
+    exe = _emulated_driver()
+    t4libs.build_checkers()
+    fa = str(tmp_path / "ref.fa")
+    with gzip.open(t4libs.REF_FA, "rb") as f, open(fa, "wb") as g:
+        shutil.copyfileobj(f, g)
+    pre = str(tmp_path / "c5")
+    subprocess.run([os.path.join(ROOT, "tools", "t4synth"), fa, "100", "0", "31", pre, "--cells", "6"], check=True)
+    env = dict(os.environ, HIPEMU_THREADS="2", T4_THREADS="2")
+    base = ["-f", fa, "-1", pre + "_1.fq", "-2", pre + "_2.fq", "--UMI", pre + "_umi.fa"]
+    single = str(tmp_path / "single")
+    subprocess.run([exe] + base + ["--barcode", pre + "_bc.fa", "-o", single], check=True, env=env, stderr=subprocess.DEVNULL)
+    gdir = tmp_path / "gather"
+    gdir.mkdir()
+    merged = str(tmp_path / "merged")
+    procs, feeders = [], []
+    for r in range(2):
+        fifo = str(tmp_path / ("bc%d.fifo" % r))
+        os.mkfifo(fifo)
+
+        def feed(path=fifo):
+            with open(pre + "_bc.fa", "rb") as src, open(path, "wb") as dst:   # (blocks until the driver opens its end)
+                shutil.copyfileobj(src, dst)
+        t = threading.Thread(target=feed, daemon=True)
+        t.start()
+        feeders.append(t)
+        procs.append(subprocess.Popen([exe] + base + ["--barcode", fifo, "-o", merged, "--cellShard", "%d/2" % r, "--gatherDir", str(gdir)], env=env, stderr=subprocess.PIPE, text=True))
+    logs = [p.communicate(timeout=600)[1] for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], logs
+    for l in logs:
+        assert "cannot be read twice" in l and "their pairs alone are processed and counted here" not in l, l[-600:]
+    for suffix in ("_raw.out", "_final.out", "_assembled_reads.fa"):
+        assert filecmp.cmp(single + suffix, merged + suffix, shallow=False), suffix
+
+
 def test_early_shard_paths(tmp_path):
     """--cellShard with a transport (round 4): every rank lets go of the other ranks' reads once the sample's 21-mers are counted and
     runs statistics, sort, rough annotation, barcode-wise counts and the cell pass on its own cells only. (a) the default, logged per
